@@ -1,0 +1,203 @@
+"""oracle -- TEST INFRASTRUCTURE ONLY.
+
+numpy/ctypes front-end of ``oracle/dss_oracle.c``: the CPU restatement of the reference's EWA
+splatting hot path, used as the parity checker for the HIP library.  Only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this package; the
+product (``dss_amd``) never does.
+
+``oracle.ref()`` returns the compiled *unmodified* reference CPU extension (``oracle/_ref``) when
+it has been built (``make -C oracle ref``, needs /root/reference at build time only), else None.
+"""
+import ctypes
+import importlib.util
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(with_ref: bool = False) -> None:
+    """Compile liboracle.so (and oracle/_ref when the reference checkout is present)."""
+    targets = ["all"]
+    if with_ref and os.path.isdir("/root/reference/DSS/csrc"):
+        targets.append("ref")
+    subprocess.run(["make", "-s", "-C", _HERE] + targets, check=True)
+
+
+def _lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "liboracle.so")
+        src = os.path.join(_HERE, "dss_oracle.c")
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+            build()
+        _LIB = ctypes.CDLL(so)
+    return _LIB
+
+
+def ref():
+    """The compiled reference CPU extension (module ``dss_ref_cpu``) or None if not built."""
+    d = os.path.join(_HERE, "_ref")
+    if not os.path.isdir(d):
+        return None
+    for f in os.listdir(d):
+        if f.startswith("dss_ref_cpu") and f.endswith(".so"):
+            import torch  # noqa: F401  (the extension links against libtorch)
+            spec = importlib.util.spec_from_file_location("dss_ref_cpu", os.path.join(d, f))
+            mod = importlib.util.module_from_spec(spec)
+            sys.modules.setdefault("dss_ref_cpu", mod)
+            spec.loader.exec_module(mod)
+            return mod
+    return None
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _i64(a):
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def splat_forward(points, ellipse, cutoff, radii, first_idx, num_pts, S, K, thr,
+                  brute: bool = False, cpu_bbox_and: bool = False):
+    """-> idx int32 (N,S,S,K), zbuf, qvalue f32 (N,S,S,K), occ f32 (N,S,S)."""
+    points, ellipse, cutoff, radii = _f32(points), _f32(ellipse), _f32(cutoff), _f32(radii)
+    first_idx, num_pts = _i64(first_idx), _i64(num_pts)
+    N = first_idx.shape[0]
+    idx = np.empty((N, S, S, K), np.int32)
+    zbuf = np.empty((N, S, S, K), np.float32)
+    qv = np.empty((N, S, S, K), np.float32)
+    occ = np.empty((N, S, S), np.float32)
+    L = _lib()
+    if brute or cpu_bbox_and:
+        rc = L.oracle_splat_forward_brute(_p(points), _p(ellipse), _p(cutoff), _p(radii), _p(first_idx),
+                                          _p(num_pts), N, S, K, ctypes.c_float(thr),
+                                          1 if cpu_bbox_and else 0, _p(idx), _p(zbuf), _p(qv), _p(occ))
+    else:
+        rc = L.oracle_splat_forward(_p(points), _p(ellipse), _p(cutoff), _p(radii), _p(first_idx),
+                                    _p(num_pts), N, S, K, ctypes.c_float(thr),
+                                    _p(idx), _p(zbuf), _p(qv), _p(occ))
+    if rc != 0:
+        raise RuntimeError("oracle_splat_forward failed: %d" % rc)
+    return idx, zbuf, qv, occ
+
+
+def visibility(idx, P):
+    idx = np.ascontiguousarray(idx, np.int32)
+    N, S, _, K = idx.shape
+    vis = np.zeros((P,), np.uint8)
+    _lib().oracle_visibility(_p(idx), N, S, K, ctypes.c_int64(P), _p(vis))
+    return vis.astype(bool)
+
+
+def backward_radius(radii, vis, first_idx, num_pts, radii_s):
+    radii = _f32(radii)
+    vis = np.ascontiguousarray(vis, np.uint8)
+    first_idx, num_pts = _i64(first_idx), _i64(num_pts)
+    N = first_idx.shape[0]
+    rs = np.zeros((N,), np.float32)
+    _lib().oracle_backward_radius(_p(radii), _p(vis), _p(first_idx), _p(num_pts), N,
+                                  ctypes.c_float(radii_s), _p(rs))
+    return rs
+
+
+def occ_backward_fast(points, radii, vis, rs, grad_occ, first_idx, num_pts):
+    points, radii, rs, grad_occ = _f32(points), _f32(radii), _f32(rs), _f32(grad_occ)
+    vis = np.ascontiguousarray(vis, np.uint8)
+    first_idx, num_pts = _i64(first_idx), _i64(num_pts)
+    N, S = grad_occ.shape[0], grad_occ.shape[1]
+    P = points.shape[0]
+    g = np.zeros((P, 2), np.float32)
+    _lib().oracle_occ_backward_fast(_p(points), _p(radii), _p(vis), _p(rs), _p(grad_occ), _p(first_idx),
+                                    _p(num_pts), N, ctypes.c_int64(P), S, _p(g))
+    return g
+
+
+def occ_backward_slow_cpu(points, radii, grad_occ, first_idx, num_pts, radii_s):
+    points, radii, grad_occ = _f32(points), _f32(radii), _f32(grad_occ)
+    first_idx, num_pts = _i64(first_idx), _i64(num_pts)
+    N, S = grad_occ.shape[0], grad_occ.shape[1]
+    P = points.shape[0]
+    g = np.zeros((P, 2), np.float32)
+    _lib().oracle_occ_backward_slow_cpu(_p(points), _p(radii), _p(grad_occ), _p(first_idx), _p(num_pts),
+                                        N, ctypes.c_int64(P), S, ctypes.c_float(radii_s), _p(g))
+    return g
+
+
+def zbuf_backward(idx, grad_zbuf, P, z_grad=None):
+    idx = np.ascontiguousarray(idx, np.int32)
+    grad_zbuf = _f32(grad_zbuf)
+    N, S, _, K = idx.shape
+    if z_grad is None:
+        z_grad = np.zeros((P,), np.float32)
+    _lib().oracle_zbuf_backward(_p(idx), _p(grad_zbuf), N, S, K, _p(z_grad))
+    return z_grad
+
+
+def clip_grad(grad, clip):
+    g = _f32(grad).copy()
+    _lib().oracle_clip_grad(_p(g), ctypes.c_int64(g.shape[0]), ctypes.c_float(clip))
+    return g
+
+
+def splat_backward(points, radii, idx, grad_occ, grad_zbuf, first_idx, num_pts, radii_s, clip=-1.0):
+    """Full EllipticalRasterizer.backward (rasterizer.py:787-977 + clip hook :667-673):
+    -> grad_pts (P,3), vis (P,) bool, rs (N,)."""
+    P = np.asarray(points).shape[0]
+    vis = visibility(idx, P)
+    rs = backward_radius(radii, vis, first_idx, num_pts, radii_s)
+    gxy = occ_backward_fast(points, radii, vis, rs, grad_occ, first_idx, num_pts)
+    gz = np.zeros((P,), np.float32)
+    if grad_zbuf is not None:
+        zbuf_backward(idx, grad_zbuf, P, gz)
+    g = np.concatenate([gxy, gz[:, None]], axis=1).astype(np.float32)
+    if clip is not None and clip > 0:
+        g = clip_grad(g, clip)
+    return g, vis, rs
+
+
+def blend_forward(idx, qv, occ, scaler, feat):
+    idx = np.ascontiguousarray(idx, np.int32)
+    qv, occ, scaler, feat = _f32(qv), _f32(occ), _f32(scaler), _f32(feat)
+    N, S, _, K = idx.shape
+    C = feat.shape[1]
+    out = np.empty((N, S, S, C + 1), np.float32)
+    _lib().oracle_blend_forward(_p(idx), _p(qv), _p(occ), _p(scaler), _p(feat), N, S, K, C, _p(out))
+    return out
+
+
+def blend_backward(grad_out, idx, qv, scaler, P):
+    grad_out = _f32(grad_out)
+    idx = np.ascontiguousarray(idx, np.int32)
+    qv, scaler = _f32(qv), _f32(scaler)
+    N, S, _, K = idx.shape
+    C = grad_out.shape[-1] - 1
+    gf = np.empty((P, C), np.float32)
+    go = np.empty((N, S, S), np.float32)
+    _lib().oracle_blend_backward(_p(grad_out), _p(idx), _p(qv), _p(scaler), N, S, K, C,
+                                 ctypes.c_int64(P), _p(gf), _p(go))
+    return gf, go
+
+
+def point_setup(pts_world, normals, h, cloud_of, M, V, S, cutoff, sigma):
+    pts_world, normals, h, M, V = _f32(pts_world), _f32(normals), _f32(h), _f32(M), _f32(V)
+    cloud_of = np.ascontiguousarray(cloud_of, np.int32)
+    P = pts_world.shape[0]
+    ps = np.empty((P, 3), np.float32)
+    el = np.empty((P, 3), np.float32)
+    ra = np.empty((P, 2), np.float32)
+    sc = np.empty((P,), np.float32)
+    cu = np.empty((P,), np.float32)
+    _lib().oracle_point_setup(_p(pts_world), _p(normals), _p(h), _p(cloud_of), _p(M), _p(V),
+                              ctypes.c_int64(P), S, ctypes.c_float(cutoff), ctypes.c_float(sigma),
+                              _p(ps), _p(el), _p(ra), _p(sc), _p(cu))
+    return ps, el, ra, sc, cu

@@ -1,0 +1,564 @@
+/*
+ * oracle/dss_oracle.c -- TEST INFRASTRUCTURE ONLY.
+ *
+ * Plain-C, single-threaded CPU restatement of the DSS EWA surface-splatting hot path
+ * (SURVEY.md section 8a).  It is the checker for the HIP library in dss_amd/csrc; it is
+ * never linked, imported or called by the product path (only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may use it).
+ *
+ * Every function cites the reference lines it restates (paths relative to /root/reference).
+ * Compile with -ffp-contract=off so fp32 expressions round exactly like the reference's CPU
+ * build (x86-64 baseline: no FMA contraction).
+ *
+ * Parity pinning status (see oracle/README.md, tests/test_oracle_pinning.py):
+ *   forward rasterizer      PINNED   bit-exact vs the compiled reference CPU naive path
+ *                                    (oracle/_ref, DSS/csrc/rasterize_points_cpu.cpp:27-144)
+ *   slow occupancy backward PINNED   bit-exact vs reference CPU (rasterize_points_cpu.cpp:380-477)
+ *   zbuf backward           PINNED   bit-exact vs reference CPU (rasterize_points_cpu.cpp:479-513)
+ *   fast occupancy backward UNPINNED restated from DSS/csrc/rasterize_points_backward.cu:30-212 and
+ *                                    DSS/core/rasterizer.py:853-888 (CUDA only; cannot run here)
+ *   blend fwd/bwd           UNPINNED pytorch3d norm_weighted_sum is not under /root/reference
+ *   per-point EWA setup     UNPINNED needs pytorch3d cameras; restated from rasterizer.py:404-565
+ */
+#define _GNU_SOURCE
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define DSS_ORACLE_API __attribute__((visibility("default")))
+
+/* rasterization_utils.cuh:8-11 / rasterize_points_cpu.cpp:10-14 */
+static inline float pix_to_ndc(int i, int S) { return -1 + (2 * i + 1.0f) / S; }
+
+/* rasterize_points_cpu.cpp:22-25, rasterize_points.cu:98 (same expression, same order) */
+static inline float qvalue_of(float dx, float dy, float a, float b, float c)
+{
+    return a * dx * dx + b * dx * dy + c * dy * dy;
+}
+
+typedef struct { float z; int32_t idx; float q; } frag_t;
+
+/* strict total order used for the K-nearest set: (z, idx) ascending.
+ * rasterize_points_cpu.cpp:85 keeps the K smallest std::tuple<z, idx, q>; the CUDA kernels
+ * (rasterize_points.cu:99-123) visit points in index order and only evict on strict z<max,
+ * which yields the same set whenever z values are distinct. */
+static inline int frag_less(const frag_t *a, const frag_t *b)
+{
+    if (a->z < b->z) return 1;
+    if (a->z > b->z) return 0;
+    return a->idx < b->idx;
+}
+
+/* insert into an ascending list of at most K entries */
+static inline void frag_insert(frag_t *q, int *count, int K, frag_t e)
+{
+    int n = *count;
+    if (n == K) {
+        if (!frag_less(&e, &q[K - 1])) return;
+        n = K - 1;
+    }
+    int k = n;
+    while (k > 0 && frag_less(&e, &q[k - 1])) { q[k] = q[k - 1]; --k; }
+    q[k] = e;
+    *count = n + 1;
+}
+
+/* hit test of one (pixel, point) pair.
+ * CUDA form rasterize_points.cu:79-96: skip if pz<0; skip if |dx|>rx OR |dy|>ry; skip if Q>cutoff.
+ * CPU form rasterize_points_cpu.cpp:92-104 uses AND in the bbox pre-test (flag bit 0 selects it;
+ * only used to pin this file against the compiled CPU reference on arbitrary radii). */
+static inline int pair_hit(float xf, float yf, float px, float py, float pz,
+                           float a, float b, float c, float rx, float ry, float cutoff,
+                           int cpu_bbox_and, float *q_out)
+{
+    if (pz < 0) return 0;
+    const float dx = xf - px;
+    const float dy = yf - py;
+    if (cpu_bbox_and) {
+        if (fabsf(dx) > rx && fabsf(dy) > ry) return 0;
+    } else {
+        if (fabsf(dx) > rx || fabsf(dy) > ry) return 0;
+    }
+    const float q = qvalue_of(dx, dy, a, b, c);
+    if (q > cutoff) return 0;
+    *q_out = q;
+    return 1;
+}
+
+static void write_pixel(const frag_t *q, int count, int K, float thr,
+                        int32_t *idx, float *zbuf, float *qv, float *occ)
+{
+    /* outputs pre-filled with -1 / 0: rasterize_points.cu:254-257, 634-637 */
+    for (int k = 0; k < K; ++k) { idx[k] = -1; zbuf[k] = -1.0f; qv[k] = -1.0f; }
+    *occ = 0.0f;
+    if (count == 0) return;
+    *occ = 1.0f; /* rasterize_points.cu:196-200 / :581-585 (pz>=0 for every hit) */
+    for (int k = 0; k < count; ++k) {
+        /* depth merge, rasterize_points.cu:201-210 / :586-595 */
+        if (q[k].z - q[0].z > thr) break;
+        idx[k] = q[k].idx; zbuf[k] = q[k].z; qv[k] = q[k].q;
+    }
+}
+
+/* ---------------------------------------------------------------------------------------
+ * Forward rasterizer, literal per-pixel brute force.
+ * Restates RasterizePointsNaiveCudaKernel (rasterize_points.cu:131-212) ==
+ * RasterizePointsNaiveCpu (rasterize_points_cpu.cpp:27-144).
+ * Image pixel (r, c) has NDC centre (pix_to_ndc(S-1-c), pix_to_ndc(S-1-r)).
+ * flags bit0: CPU-variant bbox pre-test (see pair_hit).
+ * ------------------------------------------------------------------------------------- */
+DSS_ORACLE_API int oracle_splat_forward_brute(
+    const float *points, const float *ellipse, const float *cutoff, const float *radii,
+    const int64_t *first_idx, const int64_t *num_pts, int N, int S, int K, float thr, int flags,
+    int32_t *idx, float *zbuf, float *qv, float *occ)
+{
+    if (K <= 0 || S <= 0) return -1;
+    frag_t *q = (frag_t *)malloc(sizeof(frag_t) * (size_t)K);
+    if (!q) return -2;
+    for (int n = 0; n < N; ++n) {
+        const int64_t p0 = first_idx[n], p1 = p0 + num_pts[n];
+        for (int r = 0; r < S; ++r) {
+            const float yf = pix_to_ndc(S - 1 - r, S);
+            for (int c = 0; c < S; ++c) {
+                const float xf = pix_to_ndc(S - 1 - c, S);
+                int count = 0;
+                for (int64_t p = p0; p < p1; ++p) {
+                    float qq;
+                    if (!pair_hit(xf, yf, points[3 * p], points[3 * p + 1], points[3 * p + 2],
+                                  ellipse[3 * p], ellipse[3 * p + 1], ellipse[3 * p + 2],
+                                  radii[2 * p], radii[2 * p + 1], cutoff[p], flags & 1, &qq))
+                        continue;
+                    frag_t e = { points[3 * p + 2], (int32_t)p, qq };
+                    frag_insert(q, &count, K, e);
+                }
+                const size_t pix = ((size_t)n * S + r) * S + c;
+                write_pixel(q, count, K, thr, idx + pix * K, zbuf + pix * K, qv + pix * K, occ + pix);
+            }
+        }
+    }
+    free(q);
+    return 0;
+}
+
+/* ---------------------------------------------------------------------------------------
+ * Forward rasterizer, same per-pair rule but driven per splat over a conservative pixel
+ * window (bbox +-2 px) so that BASELINE-sized inputs finish in seconds.  Because the pair
+ * test is evaluated with the identical expression and the K-set is defined by the total
+ * order (z, idx), the result is identical to the brute-force loop (checked in tests).
+ * CUDA-form bbox test only.
+ * ------------------------------------------------------------------------------------- */
+DSS_ORACLE_API int oracle_splat_forward(
+    const float *points, const float *ellipse, const float *cutoff, const float *radii,
+    const int64_t *first_idx, const int64_t *num_pts, int N, int S, int K, float thr,
+    int32_t *idx, float *zbuf, float *qv, float *occ)
+{
+    if (K <= 0 || S <= 0) return -1;
+    const size_t npix = (size_t)S * S;
+    frag_t *lists = (frag_t *)malloc(sizeof(frag_t) * npix * (size_t)K);
+    int *counts = (int *)malloc(sizeof(int) * npix);
+    if (!lists || !counts) { free(lists); free(counts); return -2; }
+    for (int n = 0; n < N; ++n) {
+        memset(counts, 0, sizeof(int) * npix);
+        const int64_t p0 = first_idx[n], p1 = p0 + num_pts[n];
+        for (int64_t p = p0; p < p1; ++p) {
+            const float px = points[3 * p], py = points[3 * p + 1], pz = points[3 * p + 2];
+            const float rx = radii[2 * p], ry = radii[2 * p + 1];
+            if (pz < 0) continue;
+            /* NaN / inf radii or positions: fall back to the whole image for this splat */
+            int c_lo = 0, c_hi = S - 1, r_lo = 0, r_hi = S - 1;
+            if (isfinite(px) && isfinite(rx)) {
+                /* ndc index i = S-1-c ; centre = -1 + (2i+1)/S  ->  i = ((x+1)*S-1)/2 */
+                double i_lo = (((double)px - (double)rx + 1.0) * S - 1.0) / 2.0;
+                double i_hi = (((double)px + (double)rx + 1.0) * S - 1.0) / 2.0;
+                if (i_hi < -3.0 || i_lo > S + 2.0) continue;
+                int ilo = (int)floor(fmax(i_lo, -4.0)) - 2, ihi = (int)ceil(fmin(i_hi, S + 4.0)) + 2;
+                if (ilo < 0) ilo = 0;
+                if (ihi > S - 1) ihi = S - 1;
+                c_lo = S - 1 - ihi; c_hi = S - 1 - ilo;
+            }
+            if (isfinite(py) && isfinite(ry)) {
+                double i_lo = (((double)py - (double)ry + 1.0) * S - 1.0) / 2.0;
+                double i_hi = (((double)py + (double)ry + 1.0) * S - 1.0) / 2.0;
+                if (i_hi < -3.0 || i_lo > S + 2.0) continue;
+                int ilo = (int)floor(fmax(i_lo, -4.0)) - 2, ihi = (int)ceil(fmin(i_hi, S + 4.0)) + 2;
+                if (ilo < 0) ilo = 0;
+                if (ihi > S - 1) ihi = S - 1;
+                r_lo = S - 1 - ihi; r_hi = S - 1 - ilo;
+            }
+            for (int r = r_lo; r <= r_hi; ++r) {
+                const float yf = pix_to_ndc(S - 1 - r, S);
+                for (int c = c_lo; c <= c_hi; ++c) {
+                    const float xf = pix_to_ndc(S - 1 - c, S);
+                    float qq;
+                    if (!pair_hit(xf, yf, px, py, pz, ellipse[3 * p], ellipse[3 * p + 1],
+                                  ellipse[3 * p + 2], rx, ry, cutoff[p], 0, &qq))
+                        continue;
+                    const size_t pix = (size_t)r * S + c;
+                    frag_t e = { pz, (int32_t)p, qq };
+                    frag_insert(lists + pix * K, &counts[pix], K, e);
+                }
+            }
+        }
+        for (size_t pix = 0; pix < npix; ++pix) {
+            const size_t o = (size_t)n * npix + pix;
+            write_pixel(lists + pix * K, counts[pix], K, thr, idx + o * K, zbuf + o * K, qv + o * K, occ + o);
+        }
+    }
+    free(lists); free(counts);
+    return 0;
+}
+
+/* ---------------------------------------------------------------------------------------
+ * Per-point visibility: point p is visible iff it appears in the fragment list of any pixel
+ * whose first slot is filled.  DSS/utils/__init__.py:320-340 (forward, rasterizer.py:639-641)
+ * and rasterizer.py:854-860 (backward).
+ * ------------------------------------------------------------------------------------- */
+DSS_ORACLE_API void oracle_visibility(const int32_t *idx, int N, int S, int K, int64_t P, uint8_t *vis)
+{
+    memset(vis, 0, (size_t)P);
+    const size_t npix = (size_t)N * S * S;
+    for (size_t i = 0; i < npix; ++i) {
+        if (idx[i * K] < 0) continue;
+        for (int k = 0; k < K; ++k) {
+            const int32_t p = idx[i * K + k];
+            if (p >= 0 && p < P) vis[p] = 1;
+        }
+    }
+}
+
+static int cmp_float(const void *a, const void *b)
+{
+    const float x = *(const float *)a, y = *(const float *)b;
+    return (x > y) - (x < y);
+}
+
+/* rs[n] = median(flattened (n_vis, 2) radii of the visible points of cloud n) * radii_s
+ * rasterizer.py:885-888 (torch.median = lower median).  Clouds without visible points get 0. */
+DSS_ORACLE_API void oracle_backward_radius(const float *radii, const uint8_t *vis,
+                                           const int64_t *first_idx, const int64_t *num_pts, int N,
+                                           float radii_s, float *rs)
+{
+    for (int n = 0; n < N; ++n) {
+        const int64_t p0 = first_idx[n], p1 = p0 + num_pts[n];
+        int64_t cnt = 0;
+        for (int64_t p = p0; p < p1; ++p) cnt += vis[p] ? 2 : 0;
+        rs[n] = 0.0f;
+        if (cnt == 0) continue;
+        float *tmp = (float *)malloc(sizeof(float) * (size_t)cnt);
+        int64_t j = 0;
+        for (int64_t p = p0; p < p1; ++p)
+            if (vis[p]) { tmp[j++] = radii[2 * p]; tmp[j++] = radii[2 * p + 1]; }
+        qsort(tmp, (size_t)cnt, sizeof(float), cmp_float);
+        rs[n] = tmp[(cnt - 1) / 2] * radii_s;
+        free(tmp);
+    }
+}
+
+/* ---------------------------------------------------------------------------------------
+ * FAST occupancy backward (the one train_mvr.py uses, rasterizer.py:816 backward_occ_fast=True).
+ * Restates RasterizePointsBackwardCudaFastKernel, rasterize_points_backward.cu:85-96 (pixel ->
+ * NDC), :141-178 (per-pair rule).  The FRNN grid (rasterizer.py:889-933) only enumerates the
+ * visible points within rs of the pixel, so the result equals this brute force over the
+ * visible points of cloud n.
+ *   for pixel (r,c), g = grad_occ != 0, xf = ndc(S-1-c), yf = ndc(S-1-r):
+ *     for p visible in cloud n with pz>=0, |px|<=1, |py|<=1:
+ *        d2 = dx*dx+dy*dy ; skip if d2 > rs^2
+ *        skip if g>0 and (|dx|>rx or |dy|>ry)
+ *        den = eps_denom(d2, 1e-10)  (rasterization_utils.cuh:38-43)
+ *        grad[p] += (dx,dy)/den*g
+ * Documented divergence: eps_denom(0) = 0 gives 0/0 = NaN in the reference when a point sits
+ * exactly on a pixel centre; here (and in the HIP path) such a pair contributes 0.
+ * Accumulation is in double (the order-independent limit of the reference's fp32 atomics);
+ * each per-pair term is rounded in fp32 exactly as the reference computes it.
+ * ------------------------------------------------------------------------------------- */
+DSS_ORACLE_API void oracle_occ_backward_fast(
+    const float *points, const float *radii, const uint8_t *vis, const float *rs,
+    const float *grad_occ, const int64_t *first_idx, const int64_t *num_pts,
+    int N, int64_t P, int S, float *grad_xy /* (P,2) */)
+{
+    double *acc = (double *)calloc((size_t)P * 2, sizeof(double));
+    for (int n = 0; n < N; ++n) {
+        const int64_t p0 = first_idx[n], p1 = p0 + num_pts[n];
+        const float cur_r = rs[n];
+        const float cur_r2 = cur_r * cur_r;
+        for (int64_t p = p0; p < p1; ++p) {
+            if (!vis[p]) continue;
+            const float px = points[3 * p], py = points[3 * p + 1], pz = points[3 * p + 2];
+            if (pz < 0 || fabsf(py) > 1.0f || fabsf(px) > 1.0f) continue;
+            const float rx = radii[2 * p], ry = radii[2 * p + 1];
+            /* conservative pixel window around the point (+-2 px slack); exact test inside */
+            double ix_lo = (((double)px - (double)cur_r + 1.0) * S - 1.0) / 2.0;
+            double ix_hi = (((double)px + (double)cur_r + 1.0) * S - 1.0) / 2.0;
+            double iy_lo = (((double)py - (double)cur_r + 1.0) * S - 1.0) / 2.0;
+            double iy_hi = (((double)py + (double)cur_r + 1.0) * S - 1.0) / 2.0;
+            int xlo = 0, xhi = S - 1, ylo = 0, yhi = S - 1;
+            if (isfinite(ix_lo) && isfinite(ix_hi)) {
+                xlo = (int)floor(fmax(ix_lo, -4.0)) - 2; xhi = (int)ceil(fmin(ix_hi, S + 4.0)) + 2;
+                if (xlo < 0) xlo = 0;
+                if (xhi > S - 1) xhi = S - 1;
+            }
+            if (isfinite(iy_lo) && isfinite(iy_hi)) {
+                ylo = (int)floor(fmax(iy_lo, -4.0)) - 2; yhi = (int)ceil(fmin(iy_hi, S + 4.0)) + 2;
+                if (ylo < 0) ylo = 0;
+                if (yhi > S - 1) yhi = S - 1;
+            }
+            double gx = 0.0, gy = 0.0;
+            for (int yi = ylo; yi <= yhi; ++yi) {
+                const float yf = pix_to_ndc(yi, S);
+                const int r = S - 1 - yi;
+                for (int xi = xlo; xi <= xhi; ++xi) {
+                    const int c = S - 1 - xi;
+                    const float g = grad_occ[((size_t)n * S + r) * S + c];
+                    if (g == 0.0f) continue;
+                    const float xf = pix_to_ndc(xi, S);
+                    const float dx = xf - px, dy = yf - py;
+                    const float d2 = dx * dx + dy * dy;
+                    if (d2 > cur_r2) continue;
+                    const int outside = (fabsf(dx) > rx) || (fabsf(dy) > ry);
+                    if (g > 0.0f && outside) continue;
+                    if (d2 == 0.0f) continue; /* documented divergence (reference: NaN) */
+                    const float den = fmaxf(d2, 1e-10f);
+                    gx += (double)(dx / den * g);
+                    gy += (double)(dy / den * g);
+                }
+            }
+            acc[2 * p] = gx; acc[2 * p + 1] = gy;
+        }
+    }
+    for (int64_t i = 0; i < 2 * P; ++i) grad_xy[i] = (float)acc[i];
+    free(acc);
+}
+
+/* ---------------------------------------------------------------------------------------
+ * SLOW occupancy backward, CPU semantics: RasterizePointsOccBackwardCpu,
+ * rasterize_points_cpu.cpp:380-477 (box support radii*radii_s with AND, eps 1e-8, every point
+ * of the cloud).  Same loop nest and fp32 accumulation order -> bit-exact vs oracle/_ref.
+ * Not on the default training path (rasterizer.py:816); restated only to pin the shared
+ * pixel->NDC / skip-rule arithmetic against runnable reference code.
+ * ------------------------------------------------------------------------------------- */
+DSS_ORACLE_API void oracle_occ_backward_slow_cpu(
+    const float *points, const float *radii, const float *grad_occ,
+    const int64_t *first_idx, const int64_t *num_pts, int N, int64_t P, int S, float radii_s,
+    float *grad_xy /* (P,2), zeroed here */)
+{
+    memset(grad_xy, 0, sizeof(float) * (size_t)P * 2);
+    for (int n = 0; n < N; ++n) {
+        const int p0 = (int)first_idx[n], p1 = p0 + (int)num_pts[n];
+        for (int yi = 0; yi < S; ++yi) {
+            const float yf = pix_to_ndc(S - 1 - yi, S);
+            for (int xi = 0; xi < S; ++xi) {
+                const float xf = pix_to_ndc(S - 1 - xi, S);
+                const float g = grad_occ[((size_t)n * S + yi) * S + xi];
+                if (g == 0.0f) continue;
+                for (int p = p0; p < p1; ++p) {
+                    const float px = points[3 * p], py = points[3 * p + 1], pz = points[3 * p + 2];
+                    if (pz < 0 || fabsf(py) > 1.0 || fabsf(px) > 1.0) continue;
+                    const float dx = xf - px, dy = yf - py;
+                    const float rxs = radii[2 * p] * radii_s, rys = radii[2 * p + 1] * radii_s;
+                    const int outside = (fabsf(dx) > rxs / radii_s) || (fabsf(dy) > rys / radii_s);
+                    if (g > 0.0f && outside) continue;
+                    if (fabsf(dx) > rxs && fabsf(dy) > rys) continue;
+                    const float d2 = dx * dx + dy * dy;
+                    const float den = d2 > 1e-8f ? d2 : 1e-8f;
+                    grad_xy[2 * p] += dx / den * g;
+                    grad_xy[2 * p + 1] += dy / den * g;
+                }
+            }
+        }
+    }
+}
+
+/* ---------------------------------------------------------------------------------------
+ * zbuf backward: z_grad[idx[n,y,x,k]] += grad_zbuf[n,y,x,k]; zero grads skipped, stop at the
+ * first idx<0.  rasterize_points.cu:823-846 == rasterize_points_cpu.cpp:479-513.
+ * fp32 accumulation in raster order (bit-exact vs the CPU reference).  Accumulates IN PLACE.
+ * ------------------------------------------------------------------------------------- */
+DSS_ORACLE_API void oracle_zbuf_backward(const int32_t *idx, const float *grad_zbuf,
+                                         int N, int S, int K, float *z_grad /* (P,) in/out */)
+{
+    const size_t npix = (size_t)N * S * S;
+    for (size_t i = 0; i < npix; ++i)
+        for (int k = 0; k < K; ++k) {
+            const float g = grad_zbuf[i * K + k];
+            if (g == 0.0f) continue;
+            const int32_t p = idx[i * K + k];
+            if (p < 0) break;
+            z_grad[p] += g;
+        }
+}
+
+/* ---------------------------------------------------------------------------------------
+ * Per-point gradient clipping hook: grad <- normalize(grad) * min(||grad||, clip)
+ * rasterizer.py:667-673 (F.normalize eps = 1e-12), installed at :735-737.
+ * ------------------------------------------------------------------------------------- */
+DSS_ORACLE_API void oracle_clip_grad(float *grad /* (P,3) */, int64_t P, float clip)
+{
+    for (int64_t p = 0; p < P; ++p) {
+        float *g = grad + 3 * p;
+        const float nrm = sqrtf(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]);
+        const float scaler = nrm < clip ? nrm : clip;       /* clamp(0, value) */
+        const float den = nrm > 1e-12f ? nrm : 1e-12f;       /* F.normalize */
+        for (int j = 0; j < 3; ++j) g[j] = g[j] / den * scaler;
+    }
+}
+
+/* ---------------------------------------------------------------------------------------
+ * Blend.  weights: renderer.py:53 with the scaler gather of rasterizer.py:631-633
+ * (utils/__init__.py:172-185):  w_k = exp(-0.5*Q_k) * scaler[idx_k]  (0 where idx_k < 0).
+ * Compositor: pytorch3d NormWeightedCompositor / norm_weighted_sum at renderer.py:67-72
+ * [third party, pytorch3d 0.2.5-0.4.0, not under /root/reference; published algorithm]:
+ *     cum = sum_k w_k (idx_k>=0) ; cum = max(cum, 1e-4)
+ *     img[ch] = sum_k f[idx_k][ch] * w_k / cum
+ * RGBA assembly renderer.py:75-78: out[..., C] = occupancy.
+ * features are (P, C) row-major (= Pointclouds.features_packed()).
+ * ------------------------------------------------------------------------------------- */
+DSS_ORACLE_API void oracle_blend_forward(
+    const int32_t *idx, const float *qv, const float *occ, const float *scaler,
+    const float *feat, int N, int S, int K, int C, float *out /* (N,S,S,C+1) */)
+{
+    const size_t npix = (size_t)N * S * S;
+    for (size_t i = 0; i < npix; ++i) {
+        float cum = 0.0f;
+        for (int k = 0; k < K; ++k) {
+            const int32_t p = idx[i * K + k];
+            if (p < 0) continue;
+            cum += expf(-0.5f * qv[i * K + k]) * scaler[p];
+        }
+        if (cum < 1e-4f) cum = 1e-4f;
+        for (int ch = 0; ch < C; ++ch) {
+            float acc = 0.0f;
+            for (int k = 0; k < K; ++k) {
+                const int32_t p = idx[i * K + k];
+                if (p < 0) continue;
+                const float w = expf(-0.5f * qv[i * K + k]) * scaler[p];
+                acc += feat[(size_t)p * C + ch] * w / cum;
+            }
+            out[i * (C + 1) + ch] = acc;
+        }
+        out[i * (C + 1) + C] = occ[i];
+    }
+}
+
+/* Blend backward to the per-point features (colours):
+ *     grad_f[idx_k][ch] += grad_out[ch] * w_k / cum
+ * (pytorch3d norm_weighted_sum backward; the gradient w.r.t. the weights is dead in DSS because
+ * EllipticalRasterizer.backward ignores qvalue_grad, rasterizer.py:788-789, and the EWA terms
+ * are detached, :562-565).  The alpha channel's gradient is returned as grad_occ (N,S,S).
+ * Double accumulation (order-independent limit of the reference's atomics). */
+DSS_ORACLE_API void oracle_blend_backward(
+    const float *grad_out /* (N,S,S,C+1) */, const int32_t *idx, const float *qv,
+    const float *scaler, int N, int S, int K, int C, int64_t P,
+    float *grad_feat /* (P,C) */, float *grad_occ /* (N,S,S) */)
+{
+    double *acc = (double *)calloc((size_t)P * C, sizeof(double));
+    const size_t npix = (size_t)N * S * S;
+    for (size_t i = 0; i < npix; ++i) {
+        grad_occ[i] = grad_out[i * (C + 1) + C];
+        float cum = 0.0f;
+        for (int k = 0; k < K; ++k) {
+            const int32_t p = idx[i * K + k];
+            if (p < 0) continue;
+            cum += expf(-0.5f * qv[i * K + k]) * scaler[p];
+        }
+        if (cum < 1e-4f) cum = 1e-4f;
+        for (int k = 0; k < K; ++k) {
+            const int32_t p = idx[i * K + k];
+            if (p < 0) continue;
+            const float w = expf(-0.5f * qv[i * K + k]) * scaler[p];
+            for (int ch = 0; ch < C; ++ch)
+                acc[(size_t)p * C + ch] += (double)(grad_out[i * (C + 1) + ch] * w / cum);
+        }
+    }
+    for (size_t i = 0; i < (size_t)P * C; ++i) grad_feat[i] = (float)acc[i];
+    free(acc);
+}
+
+/* ---------------------------------------------------------------------------------------
+ * Per-point EWA setup, fp32.
+ *
+ * Inputs per camera n: M (4x4, row-vector convention p_h @ M, = pytorch3d
+ * cameras.get_full_projection_transform().get_matrix()[n]) and V (4x4 world->view, same
+ * convention); per point: world position, unit normal, source-space variance scale h.
+ *
+ *   projection (pytorch3d PointsRasterizer.transform at rasterizer.py:614 [third party]):
+ *       clip = p_h @ M ; ndc_xy = clip.xy / clip.w ; z = (p_h @ V).z   (view-space depth)
+ *   Jacobian (rasterizer.py:443-496, _compute_WJk):
+ *       w = p_h . M[:,3] ; xy = p_h @ M[:, :2]
+ *       Jk[0][0] = Jk[1][1] = 1/eps_denom(w) ; Jk[3][j] = -xy[j]/eps_denom(w*w)
+ *       WJk = M[:3,:] @ Jk                                   (3x2)
+ *   source variance (rasterizer.py:293-342): Vrk = h * Sk^T Sk = h * (I - n n^T)
+ *       (Sk is a random orthonormal tangent basis; the product is basis independent for unit n)
+ *   Vk = WJk^T Vrk WJk ; GV = Vk + sigma*I*(2/S)^2            (rasterizer.py:404-441)
+ *   |detMk| = |det(Sk @ WJk)| = sqrt(det(Vk))/h  -> we evaluate sqrt(max(det(Vk),0))/h
+ *   GVinv = inverse(GV); (a,b,c) = (GVinv00, GVinv01+GVinv10, GVinv11)   (rasterizer.py:541-550)
+ *   radii (rasterizer.py:498-523): den = eps_denom(4ac-b^2); rx = sqrt(eps_sqrt(4*c*C/den)),
+ *       ry = sqrt(eps_sqrt(4*a*C/den))
+ *   scaler = |detMk| / eps_denom(sqrt(eps_sqrt(det(GV)*4*pi^2)))        (rasterizer.py:556-558)
+ * eps_denom / eps_sqrt: DSS/utils/mathHelper.py:10-21 (eps 1e-17).
+ * ------------------------------------------------------------------------------------- */
+static inline float eps_denom_py(float d)
+{
+    const float s = (d > 0) - (d < 0) + (d == 0.0f ? 1.0f : 0.0f);
+    const float a = fabsf(d);
+    return s * (a > 1e-17f ? a : 1e-17f);
+}
+static inline float eps_sqrt_py(float d) { const float a = fabsf(d); return a > 1e-17f ? a : 1e-17f; }
+
+DSS_ORACLE_API void oracle_point_setup(
+    const float *pts_world /* (P,3) */, const float *normals /* (P,3) */, const float *h /* (P,) */,
+    const int32_t *cloud_of /* (P,) */, const float *M /* (N,4,4) */, const float *V /* (N,4,4) */,
+    int64_t P, int S, float cutoffC, float sigma,
+    float *pts_screen /* (P,3) */, float *ellipse /* (P,3) */, float *radii /* (P,2) */,
+    float *scaler /* (P,) */, float *cutoff /* (P,) */)
+{
+    const float pixel = 2.0f / (float)S;
+    for (int64_t p = 0; p < P; ++p) {
+        const float *m = M + 16 * cloud_of[p];
+        const float *v = V + 16 * cloud_of[p];
+        const float ph[4] = { pts_world[3 * p], pts_world[3 * p + 1], pts_world[3 * p + 2], 1.0f };
+        float clip[4];
+        for (int j = 0; j < 4; ++j)
+            clip[j] = ph[0] * m[0 * 4 + j] + ph[1] * m[1 * 4 + j] + ph[2] * m[2 * 4 + j] + ph[3] * m[3 * 4 + j];
+        const float zview = ph[0] * v[0 * 4 + 2] + ph[1] * v[1 * 4 + 2] + ph[2] * v[2 * 4 + 2] + ph[3] * v[3 * 4 + 2];
+        const float w = clip[3];
+        pts_screen[3 * p] = clip[0] / w;
+        pts_screen[3 * p + 1] = clip[1] / w;
+        pts_screen[3 * p + 2] = zview;
+
+        const float dw = eps_denom_py(w), dw2 = eps_denom_py(w * w);
+        /* WJk[i][j] = M[i][j]/dw + M[i][3] * (-clip[j]/dw2) , i<3, j<2 */
+        float WJ[3][2];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 2; ++j)
+                WJ[i][j] = m[i * 4 + j] * (1.0f / dw) + m[i * 4 + 3] * (-1.0f / dw2 * clip[j]);
+        const float *nn = normals + 3 * p;
+        const float hh = h[p];
+        /* Vrk = h (I - n n^T) */
+        float Vr[3][3];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j)
+                Vr[i][j] = hh * ((i == j ? 1.0f : 0.0f) - nn[i] * nn[j]);
+        float T[3][2];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 2; ++j)
+                T[i][j] = Vr[i][0] * WJ[0][j] + Vr[i][1] * WJ[1][j] + Vr[i][2] * WJ[2][j];
+        float Vk[2][2];
+        for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < 2; ++j)
+                Vk[i][j] = WJ[0][i] * T[0][j] + WJ[1][i] * T[1][j] + WJ[2][i] * T[2][j];
+        const float detVk = Vk[0][0] * Vk[1][1] - Vk[0][1] * Vk[1][0];
+        const float absdetMk = sqrtf(detVk > 0.0f ? detVk : 0.0f) / hh;
+        const float G00 = Vk[0][0] + sigma * (pixel * pixel), G11 = Vk[1][1] + sigma * (pixel * pixel);
+        const float G01 = Vk[0][1], G10 = Vk[1][0];
+        const float detG = G00 * G11 - G01 * G10;
+        const float a = G11 / detG, c = G00 / detG, b = (-G01 / detG) + (-G10 / detG);
+        ellipse[3 * p] = a; ellipse[3 * p + 1] = b; ellipse[3 * p + 2] = c;
+        const float den = eps_denom_py(4.0f * a * c - b * b);
+        radii[2 * p] = sqrtf(eps_sqrt_py(4.0f * c * cutoffC / den));
+        radii[2 * p + 1] = sqrtf(eps_sqrt_py(4.0f * a * cutoffC / den));
+        const float sc = sqrtf(eps_sqrt_py(detG * 4.0f * (float)M_PI * (float)M_PI));
+        scaler[p] = absdetMk / eps_denom_py(sc);
+        cutoff[p] = cutoffC;
+    }
+}
