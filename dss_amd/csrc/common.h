@@ -1,0 +1,62 @@
+// Shared host/device helpers for libdss_hip.so (gfx950 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/dss_hip.h"
+
+#define DSS_WAVE 64
+#define DSS_TILE 16          // screen tile side in pixels (one 256-thread workgroup per tile)
+#define DSS_TILE_PIX (DSS_TILE * DSS_TILE)
+
+namespace dss {
+
+void set_error(const char *fmt, ...);
+
+// Pixel index -> NDC centre.  Same expression, same fp32 rounding as PixToNdc
+// (reference rasterization_utils.cuh:8-11): -1 + (2*i + 1.0f) / S.
+__device__ __forceinline__ float pix_to_ndc(int i, int S) { return -1 + (2 * i + 1.0f) / S; }
+
+// Cloud that owns packed point p (N is small; clouds are disjoint index ranges).
+__device__ __forceinline__ int find_cloud(int64_t p, const int64_t *__restrict__ first_idx,
+                                          const int64_t *__restrict__ num_pts, int N)
+{
+    for (int n = 0; n < N; ++n) {
+        const int64_t f = first_idx[n];
+        if (p >= f && p < f + num_pts[n]) return n;
+    }
+    return -1;
+}
+
+// Range [lo, hi] of NDC pixel indices i in [0,S) whose centre may satisfy |ndc(i) - x| <= r.
+// Conservative (one pixel of slack each side); the exact fp32 test runs later per pixel.
+// Non-finite inputs select the whole axis.  Returns false if the range is empty.
+__device__ __forceinline__ bool ndc_index_range(float x, float r, int S, int &lo, int &hi)
+{
+    const float flo = ((x - r + 1.0f) * S - 1.0f) * 0.5f;
+    const float fhi = ((x + r + 1.0f) * S - 1.0f) * 0.5f;
+    lo = 0;
+    hi = S - 1;
+    if (flo == flo && fhi == fhi) {  // not NaN
+        if (fhi < -2.0f || flo > (float)S + 1.0f) return false;
+        const float a = fmaxf(flo, -2.0f), b = fminf(fhi, (float)S + 1.0f);
+        lo = max(0, (int)floorf(a) - 1);
+        hi = min(S - 1, (int)ceilf(b) + 1);
+    }
+    return lo <= hi;
+}
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+static inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+int check_launch(const char *what);
+
+}  // namespace dss

@@ -1,0 +1,492 @@
+// Forward EWA splat rasterizer for gfx950 (MI355X).
+//
+// Replaces the reference's naive / coarse / fine CUDA kernels
+// (DSS/csrc/rasterize_points.cu:131-212, 293-432, 506-597) with a different decomposition:
+//
+//   bin_count   one thread per splat: exact pixel rect -> 16x16 screen-tile rect, per-tile counts
+//   bin_scan    exclusive scan of the per-tile counts (compacted lists, no dense (N,B,B,M) table)
+//   bin_fill    one thread per splat: append its id to every tile list it overlaps
+//   fine        one 256-thread workgroup per tile = four wavefronts, one 8x8 pixel quadrant each.
+//               Candidates are staged through LDS in chunks of 256 (SoA); every wavefront culls
+//               the chunk against its quadrant with one ballot per 64 candidates and walks only
+//               the surviving bits; every lane keeps the K nearest hits of its pixel sorted in
+//               registers; results leave through an LDS transpose so that each image row of the
+//               tile is written as one contiguous run.
+//
+// The per-pair arithmetic (dx, dy, Q, comparisons) is written exactly like the reference
+// (rasterize_points.cu:64-124) and compiled with -ffp-contract=off, so fragments are bit-identical
+// to the reference CPU/CUDA naive path; the K-set is defined by the total order (z, idx).
+#include "common.h"
+
+namespace dss {
+
+struct TileGrid {
+    int S;        // image side
+    int row0;     // first image row of the band
+    int rows;     // rows in the band
+    int tiles_x;  // tiles per band row
+    int tiles_y;  // tile rows in the band
+};
+
+// ---------------------------------------------------------------------------------------------
+// Splat -> tile rectangle (band-local tile coordinates).  Image column c <-> NDC index S-1-c.
+// The rectangle is exact: it is the set of tiles containing at least one pixel whose centre
+// passes both axis tests |dx|<=rx and |dy|<=ry (the Q test can only remove pixels).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool splat_tile_rect(float px, float py, float pz, float rx, float ry,
+                                                const TileGrid g, int &tx0, int &tx1, int &ty0, int &ty1)
+{
+    if (pz < 0) return false;  // rasterize_points.cu:79-80
+    int xlo, xhi, ylo, yhi;
+    if (!ndc_index_range(px, rx, g.S, xlo, xhi)) return false;
+    if (!ndc_index_range(py, ry, g.S, ylo, yhi)) return false;
+    // tighten with the exact per-pixel predicate (monotone in the pixel index)
+    while (xlo <= xhi && fabsf(pix_to_ndc(xlo, g.S) - px) > rx) ++xlo;
+    while (xhi >= xlo && fabsf(pix_to_ndc(xhi, g.S) - px) > rx) --xhi;
+    while (ylo <= yhi && fabsf(pix_to_ndc(ylo, g.S) - py) > ry) ++ylo;
+    while (yhi >= ylo && fabsf(pix_to_ndc(yhi, g.S) - py) > ry) --yhi;
+    if (xlo > xhi || ylo > yhi) return false;
+    const int c0 = g.S - 1 - xhi, c1 = g.S - 1 - xlo;
+    int r0 = g.S - 1 - yhi, r1 = g.S - 1 - ylo;
+    r0 = max(r0, g.row0);
+    r1 = min(r1, g.row0 + g.rows - 1);
+    if (r0 > r1) return false;
+    tx0 = c0 / DSS_TILE;
+    tx1 = c1 / DSS_TILE;
+    ty0 = (r0 - g.row0) / DSS_TILE;
+    ty1 = (r1 - g.row0) / DSS_TILE;
+    return true;
+}
+
+__global__ __launch_bounds__(256) void bin_count_kernel(
+    const float *__restrict__ points, const float *__restrict__ radii,
+    const int64_t *__restrict__ first_idx, const int64_t *__restrict__ num_pts, int N, int64_t P,
+    TileGrid g, uint32_t *__restrict__ tile_count /* (N*tiles) */, uint2 *__restrict__ rects /* (P) */)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    uint2 rc = make_uint2(0xffffffffu, 0u);  // empty
+    const int n = find_cloud(p, first_idx, num_pts, N);
+    if (n >= 0) {
+        int tx0, tx1, ty0, ty1;
+        if (splat_tile_rect(points[3 * p], points[3 * p + 1], points[3 * p + 2], radii[2 * p],
+                            radii[2 * p + 1], g, tx0, tx1, ty0, ty1)) {
+            rc.x = (uint32_t)tx0 | ((uint32_t)tx1 << 16);
+            rc.y = (uint32_t)ty0 | ((uint32_t)ty1 << 16) ;
+            uint32_t *cnt = tile_count + (size_t)n * g.tiles_x * g.tiles_y;
+            for (int ty = ty0; ty <= ty1; ++ty)
+                for (int tx = tx0; tx <= tx1; ++tx) atomicAdd(&cnt[ty * g.tiles_x + tx], 1u);
+        }
+    }
+    rects[p] = rc;
+    // cloud id is recomputed in bin_fill (N is tiny); keeps the rect record at 8 bytes
+}
+
+// Exclusive scan of `count[0..n)` by ONE workgroup of 1024 threads (n <= a few 100k tiles).
+// Writes offsets[0..n] (offsets[n] = total) and cursor[i] = offsets[i]; sets *overflow = 1 when
+// the total exceeds `capacity` (the fine kernel then scans whole clouds instead of lists).
+__global__ __launch_bounds__(1024) void bin_scan_kernel(const uint32_t *__restrict__ count, int n,
+                                                        uint32_t *__restrict__ offsets,
+                                                        uint32_t *__restrict__ cursor,
+                                                        uint32_t capacity, uint32_t *__restrict__ overflow)
+{
+    __shared__ uint32_t wave_tot[16];
+    __shared__ uint32_t carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + tid;
+        const uint32_t v = (i < n) ? count[i] : 0u;
+        // inclusive scan inside the wave
+        uint32_t x = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t y = __shfl_up(x, o, 64);
+            if (lane >= o) x += y;
+        }
+        if (lane == 63) wave_tot[wid] = x;
+        __syncthreads();
+        uint32_t wave_off = 0;
+        for (int w = 0; w < wid; ++w) wave_off += wave_tot[w];
+        const uint32_t carry = carry_s;
+        const uint32_t excl = carry + wave_off + x - v;
+        if (i < n) {
+            offsets[i] = excl;
+            cursor[i] = excl;
+        }
+        __syncthreads();
+        if (tid == 1023) carry_s = excl + v;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const uint32_t total = carry_s;
+        offsets[n] = total;
+        *overflow = (total > capacity) ? 1u : 0u;
+    }
+}
+
+__global__ __launch_bounds__(256) void bin_fill_kernel(
+    const uint2 *__restrict__ rects, const int64_t *__restrict__ first_idx,
+    const int64_t *__restrict__ num_pts, int N, int64_t P, TileGrid g,
+    uint32_t *__restrict__ cursor, const uint32_t *__restrict__ overflow,
+    int32_t *__restrict__ list)
+{
+    if (*overflow) return;
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const uint2 rc = rects[p];
+    if (rc.x == 0xffffffffu) return;
+    const int n = find_cloud(p, first_idx, num_pts, N);
+    const int tx0 = rc.x & 0xffff, tx1 = rc.x >> 16, ty0 = rc.y & 0xffff, ty1 = rc.y >> 16;
+    uint32_t *cur = cursor + (size_t)n * g.tiles_x * g.tiles_y;
+    for (int ty = ty0; ty <= ty1; ++ty)
+        for (int tx = tx0; tx <= tx1; ++tx) {
+            const uint32_t pos = atomicAdd(&cur[ty * g.tiles_x + tx], 1u);
+            list[pos] = (int32_t)p;
+        }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fine pass.
+// ---------------------------------------------------------------------------------------------
+#define CHUNK 256
+
+struct FineArgs {
+    const float *points, *ellipse, *cutoff, *radii;
+    const int64_t *first_idx, *num_pts;
+    const uint32_t *offsets;   // (N*tiles + 1) or nullptr (naive mode)
+    const uint32_t *cursor;    // list end per tile (= offsets[t] + count[t]) after bin_fill
+    const uint32_t *overflow;  // nullptr in naive mode
+    const int32_t *list;
+    int32_t *idx;
+    float *zbuf, *qv, *occ;
+    uint8_t *visible;
+    TileGrid g;
+    int N, K;
+    float thr;
+};
+
+// (z, idx) strict order.  rasterize_points_cpu.cpp:85 (tuple order); see oracle/dss_oracle.c.
+__device__ __forceinline__ bool frag_less(float za, int ia, float zb, int ib)
+{
+    return (za < zb) || (za == zb && ia < ib);
+}
+
+template <int KMAX>
+__global__ __launch_bounds__(256) void fine_kernel(const FineArgs A)
+{
+    __shared__ float s_px[CHUNK], s_py[CHUNK], s_pz[CHUNK], s_rx[CHUNK], s_ry[CHUNK];
+    __shared__ float s_a[CHUNK], s_b[CHUNK], s_c[CHUNK], s_cut[CHUNK];
+    __shared__ int s_id[CHUNK];
+    __shared__ int s_out[DSS_TILE_PIX * KMAX];
+
+    const TileGrid g = A.g;
+    const int tiles = g.tiles_x * g.tiles_y;
+    const int n = blockIdx.x / tiles;
+    const int t = blockIdx.x - n * tiles;
+    const int ty = t / g.tiles_x, tx = t - ty * g.tiles_x;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    // wave -> 8x8 quadrant of the tile; lane -> pixel inside the quadrant
+    const int qx = wid & 1, qy = wid >> 1;
+    const int lx = lane & 7, ly = lane >> 3;
+    const int tr = qy * 8 + ly, tc = qx * 8 + lx;                   // pixel inside the tile
+    const int r = g.row0 + ty * DSS_TILE + tr;                      // image row
+    const int c = tx * DSS_TILE + tc;                               // image col
+    const int S = g.S;
+    const float xf = pix_to_ndc(S - 1 - c, S);
+    const float yf = pix_to_ndc(S - 1 - r, S);
+    // NDC extent of this wave's quadrant (pixel centres).  NDC decreases with the image index.
+    const int qc0 = tx * DSS_TILE + qx * 8, qr0 = g.row0 + ty * DSS_TILE + qy * 8;
+    const float q_xmax = pix_to_ndc(S - 1 - qc0, S), q_xmin = pix_to_ndc(S - 1 - (qc0 + 7), S);
+    const float q_ymax = pix_to_ndc(S - 1 - qr0, S), q_ymin = pix_to_ndc(S - 1 - (qr0 + 7), S);
+
+    // candidate source: tile list (binned) or the whole cloud (naive / list overflow)
+    int64_t src0;
+    int64_t count;
+    const bool use_list = (A.offsets != nullptr) && (*A.overflow == 0u);
+    if (use_list) {
+        src0 = A.offsets[blockIdx.x];
+        count = (int64_t)A.cursor[blockIdx.x] - src0;
+    } else {
+        src0 = A.first_idx[n];
+        count = A.num_pts[n];
+    }
+
+    // K nearest, ascending (z, idx); sentinels at the tail
+    float kz[KMAX], kq[KMAX];
+    int ki[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        kz[k] = __builtin_huge_valf();
+        ki[k] = 0x7fffffff;
+        kq[k] = -1.0f;
+    }
+
+    for (int64_t base = 0; base < count; base += CHUNK) {
+        const int m = (int)min((int64_t)CHUNK, count - base);
+        __syncthreads();  // previous chunk fully consumed
+        if (tid < m) {
+            const int64_t p = use_list ? (int64_t)A.list[src0 + base + tid] : (src0 + base + tid);
+            s_id[tid] = (int)p;
+            s_px[tid] = A.points[3 * p];
+            s_py[tid] = A.points[3 * p + 1];
+            s_pz[tid] = A.points[3 * p + 2];
+            s_rx[tid] = A.radii[2 * p];
+            s_ry[tid] = A.radii[2 * p + 1];
+            s_a[tid] = A.ellipse[3 * p];
+            s_b[tid] = A.ellipse[3 * p + 1];
+            s_c[tid] = A.ellipse[3 * p + 2];
+            s_cut[tid] = A.cutoff[p];
+        }
+        __syncthreads();
+        for (int sub = 0; sub < m; sub += 64) {
+            // one candidate per lane: conservative (rounding-monotone) cull against the quadrant
+            const int j = sub + lane;
+            bool keep = false;
+            if (j < m) {
+                const float px = s_px[j], py = s_py[j], rx = s_rx[j], ry = s_ry[j];
+                const bool out = (s_pz[j] < 0) || ((q_xmax - px) < -rx) || ((q_xmin - px) > rx) ||
+                                 ((q_ymax - py) < -ry) || ((q_ymin - py) > ry);
+                keep = !out;
+            }
+            unsigned long long mask = __ballot(keep);
+            while (mask) {
+                const int b = __builtin_ctzll(mask);
+                mask &= mask - 1;
+                const int jj = sub + b;  // wave-uniform -> LDS broadcast reads
+                const float px = s_px[jj], py = s_py[jj], pz = s_pz[jj];
+                const float dx = xf - px;
+                const float dy = yf - py;
+                // rasterize_points.cu:92-101, same expression order
+                bool hit = !(fabsf(dx) > s_rx[jj] || fabsf(dy) > s_ry[jj]);
+                const float qval = s_a[jj] * dx * dx + s_b[jj] * dx * dy + s_c[jj] * dy * dy;
+                hit = hit && !(qval > s_cut[jj]);
+                if (__ballot(hit) == 0ull) continue;
+                const int id = s_id[jj];
+                // sorted insertion; non-hitting lanes insert nothing
+                const float ez = hit ? pz : __builtin_huge_valf();
+                const int ei = hit ? id : 0x7fffffff;
+                bool lt[KMAX];  // e < slot[k], evaluated on the old list
+#pragma unroll
+                for (int k = 0; k < KMAX; ++k) lt[k] = frag_less(ez, ei, kz[k], ki[k]);
+#pragma unroll
+                for (int k = KMAX - 1; k >= 0; --k) {
+                    if (k > 0 && lt[k > 0 ? k - 1 : 0]) {  // shift right
+                        kz[k] = kz[k > 0 ? k - 1 : 0];
+                        ki[k] = ki[k > 0 ? k - 1 : 0];
+                        kq[k] = kq[k > 0 ? k - 1 : 0];
+                    } else if (lt[k]) {  // e lands here
+                        kz[k] = ez;
+                        ki[k] = ei;
+                        kq[k] = qval;
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: depth merge, occupancy, visibility, LDS-transposed stores ----
+    const int K = A.K;
+    const bool in_img = (c < S) && (r < g.row0 + g.rows);
+    const float z0 = kz[0];
+    const bool any = ki[0] != 0x7fffffff;
+    bool alive = any;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        // rasterize_points.cu:586-595: stop at the first k with z[k]-z[0] > thr
+        alive = alive && (ki[k] != 0x7fffffff) && !(kz[k] - z0 > A.thr);
+        if (!alive) {
+            ki[k] = -1;
+            kz[k] = -1.0f;
+            kq[k] = -1.0f;
+        }
+    }
+    if (in_img) {
+        const size_t pix = ((size_t)n * g.rows + (r - g.row0)) * S + c;
+        A.occ[pix] = any ? 1.0f : 0.0f;
+        if (A.visible) {
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k)
+                if (k < K && ki[k] >= 0) A.visible[ki[k]] = 1;
+        }
+    }
+
+    // rows of the tile are contiguous runs of 16*K dwords in the (N,rows,S,K) tensors
+    const int run = DSS_TILE * K;
+    const int c0 = tx * DSS_TILE;
+    const int valid_cols = min(DSS_TILE, S - c0) * K;
+    const int valid_rows = min(DSS_TILE, g.rows - ty * DSS_TILE);
+    const size_t tile_base = (((size_t)n * g.rows + (size_t)ty * DSS_TILE) * S + c0) * K;
+    const int lds_pix = (tr * DSS_TILE + tc) * K;
+
+#define DSS_STORE_PLANE(REGS, DST, CAST)                                                          \
+    __syncthreads();                                                                              \
+    _Pragma("unroll") for (int k = 0; k < KMAX; ++k) if (k < K) s_out[lds_pix + k] = CAST(REGS[k]); \
+    __syncthreads();                                                                              \
+    for (int rr = wid * 4; rr < wid * 4 + 4; ++rr) {                                              \
+        if (rr >= valid_rows) break;                                                              \
+        for (int cc = lane; cc < valid_cols; cc += 64)                                            \
+            reinterpret_cast<int *>(DST)[tile_base + (size_t)rr * S * K + cc] = s_out[rr * run + cc]; \
+    }
+
+    DSS_STORE_PLANE(ki, A.idx, (int))
+    DSS_STORE_PLANE(kz, A.zbuf, __float_as_int)
+    DSS_STORE_PLANE(kq, A.qv, __float_as_int)
+#undef DSS_STORE_PLANE
+}
+
+template <int KMAX>
+static void launch_fine(const FineArgs &A, int blocks, hipStream_t st)
+{
+    hipLaunchKernelGGL(fine_kernel<KMAX>, dim3(blocks), dim3(256), 0, st, A);
+}
+
+static bool dispatch_fine(const FineArgs &A, int blocks, hipStream_t st)
+{
+    const int K = A.K;
+    switch (K) {
+        case 1: launch_fine<1>(A, blocks, st); return true;
+        case 2: launch_fine<2>(A, blocks, st); return true;
+        case 3: launch_fine<3>(A, blocks, st); return true;
+        case 4: launch_fine<4>(A, blocks, st); return true;
+        case 5: launch_fine<5>(A, blocks, st); return true;
+        case 6: launch_fine<6>(A, blocks, st); return true;
+        case 7: launch_fine<7>(A, blocks, st); return true;
+        case 8: launch_fine<8>(A, blocks, st); return true;
+        default: break;
+    }
+    if (K <= 12) { launch_fine<12>(A, blocks, st); return true; }
+    if (K <= 16) { launch_fine<16>(A, blocks, st); return true; }
+    if (K <= 24) { launch_fine<24>(A, blocks, st); return true; }
+    if (K <= 32) { launch_fine<32>(A, blocks, st); return true; }
+    return false;
+}
+
+// workspace layout (binned mode)
+struct FwdWorkspace {
+    uint32_t *tile_count;  // N*tiles
+    uint32_t *offsets;     // N*tiles + 1
+    uint32_t *cursor;      // N*tiles
+    uint32_t *overflow;    // 1
+    uint2 *rects;          // P
+    int32_t *list;         // capacity
+    uint32_t capacity;
+    size_t bytes;
+};
+
+static FwdWorkspace carve_fwd(void *ws, int N, int64_t P, int S, size_t avail)
+{
+    FwdWorkspace w;
+    const size_t tiles_max = (size_t)N * ((S + DSS_TILE - 1) / DSS_TILE) * ((S + DSS_TILE - 1) / DSS_TILE);
+    char *p = reinterpret_cast<char *>(ws);
+    size_t off = 0;
+    w.tile_count = reinterpret_cast<uint32_t *>(p + off); off += align_up(tiles_max * 4, 256);
+    w.offsets = reinterpret_cast<uint32_t *>(p + off);    off += align_up((tiles_max + 1) * 4, 256);
+    w.cursor = reinterpret_cast<uint32_t *>(p + off);     off += align_up(tiles_max * 4, 256);
+    w.overflow = reinterpret_cast<uint32_t *>(p + off);   off += 256;
+    w.rects = reinterpret_cast<uint2 *>(p + off);         off += align_up((size_t)P * 8, 256);
+    w.list = reinterpret_cast<int32_t *>(p + off);
+    // everything that is left is list capacity (recommended: 8 pairs per splat, see below)
+    const size_t rest = (avail > off) ? (avail - off) / 4 : 0;
+    w.capacity = (uint32_t)(rest > 0xfffffff0ull ? 0xfffffff0ull : rest);
+    w.bytes = off;
+    return w;
+}
+
+}  // namespace dss
+
+using namespace dss;
+
+extern "C" size_t dss_splat_forward_workspace(int N, int64_t P, int S, int K, int bin_size)
+{
+    (void)K;
+    if (bin_size == 0 || N <= 0 || P <= 0 || S <= 0) return 256;
+    FwdWorkspace w = carve_fwd(nullptr, N, P, S, 0);
+    // list capacity: 8 (splat, tile) pairs per splat + one per tile.  A view that needs more
+    // (splats much larger than a tile) transparently falls back to whole-cloud scanning.
+    const size_t tiles = (size_t)N * ((S + DSS_TILE - 1) / DSS_TILE) * ((S + DSS_TILE - 1) / DSS_TILE);
+    return w.bytes + align_up(((size_t)P * 8 + tiles) * 4, 256);
+}
+
+extern "C" int dss_splat_forward(const float *points, const float *ellipse, const float *cutoff,
+                                 const float *radii, const int64_t *first_idx, const int64_t *num_pts,
+                                 int N, int64_t P, float merge_thr, int S, int K, int bin_size,
+                                 int row0, int row1, int32_t *idx, float *zbuf, float *qvalue, float *occ,
+                                 uint8_t *visible, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (N <= 0 || P < 0 || S <= 0 || K <= 0) {
+        set_error("dss_splat_forward: N=%d P=%lld S=%d K=%d must be positive", N, (long long)P, S, K);
+        return DSS_ERR_INVALID_ARGUMENT;
+    }
+    if (row0 < 0 || row1 > S || row0 >= row1) {
+        set_error("dss_splat_forward: row band [%d,%d) outside image of side %d", row0, row1, S);
+        return DSS_ERR_INVALID_ARGUMENT;
+    }
+    if (K > DSS_MAX_K) {
+        set_error("dss_splat_forward: points_per_pixel %d exceeds kMaxPointsPerPixel=%d", K, DSS_MAX_K);
+        return DSS_ERR_INVALID_ARGUMENT;
+    }
+    if (K > DSS_MAX_K_FAST) {
+        set_error("dss_splat_forward: points_per_pixel %d > %d not implemented yet", K, DSS_MAX_K_FAST);
+        return DSS_ERR_UNSUPPORTED;
+    }
+    if (S > 65535 * DSS_TILE || P > 0x7ffffff0ll) {
+        set_error("dss_splat_forward: S=%d or P=%lld too large", S, (long long)P);
+        return DSS_ERR_UNSUPPORTED;
+    }
+    if (!idx || !zbuf || !qvalue || !occ || !first_idx || !num_pts ||
+        (P > 0 && (!points || !ellipse || !cutoff || !radii))) {
+        set_error("dss_splat_forward: NULL tensor pointer");
+        return DSS_ERR_INVALID_ARGUMENT;
+    }
+    hipStream_t st = as_stream(stream);
+    TileGrid g;
+    g.S = S;
+    g.row0 = row0;
+    g.rows = row1 - row0;
+    g.tiles_x = (S + DSS_TILE - 1) / DSS_TILE;
+    g.tiles_y = (g.rows + DSS_TILE - 1) / DSS_TILE;
+    const int tiles = g.tiles_x * g.tiles_y;
+    const long long blocks_ll = (long long)N * tiles;
+    if (blocks_ll > 0x7fffffffll) {
+        set_error("dss_splat_forward: too many tiles");
+        return DSS_ERR_UNSUPPORTED;
+    }
+
+    if (visible && P > 0) {
+        if (hipMemsetAsync(visible, 0, (size_t)P, st) != hipSuccess) return check_launch("memset visible");
+    }
+
+    FineArgs A;
+    A.points = points; A.ellipse = ellipse; A.cutoff = cutoff; A.radii = radii;
+    A.first_idx = first_idx; A.num_pts = num_pts;
+    A.offsets = nullptr; A.cursor = nullptr; A.overflow = nullptr; A.list = nullptr;
+    A.idx = idx; A.zbuf = zbuf; A.qv = qvalue; A.occ = occ; A.visible = visible;
+    A.g = g; A.N = N; A.K = K; A.thr = merge_thr;
+
+    if (bin_size != 0 && P > 0) {
+        const size_t need = dss_splat_forward_workspace(N, P, S, K, bin_size);
+        if (!workspace || workspace_bytes < need) {
+            set_error("dss_splat_forward: workspace %zu bytes < required %zu", workspace_bytes, need);
+            return DSS_ERR_WORKSPACE;
+        }
+        FwdWorkspace w = carve_fwd(workspace, N, P, S, workspace_bytes);
+        if (hipMemsetAsync(w.tile_count, 0, (size_t)N * tiles * 4, st) != hipSuccess)
+            return check_launch("memset tile_count");
+        const int pb = (int)((P + 255) / 256);
+        hipLaunchKernelGGL(bin_count_kernel, dim3(pb), dim3(256), 0, st, points, radii, first_idx, num_pts,
+                           N, P, g, w.tile_count, w.rects);
+        hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), 0, st, w.tile_count, N * tiles, w.offsets,
+                           w.cursor, w.capacity, w.overflow);
+        hipLaunchKernelGGL(bin_fill_kernel, dim3(pb), dim3(256), 0, st, w.rects, first_idx, num_pts, N, P, g,
+                           w.cursor, w.overflow, w.list);
+        A.offsets = w.offsets; A.cursor = w.cursor; A.overflow = w.overflow; A.list = w.list;
+    }
+    if (!dispatch_fine(A, (int)blocks_ll, st)) {
+        set_error("dss_splat_forward: no kernel for K=%d", K);
+        return DSS_ERR_UNSUPPORTED;
+    }
+    return check_launch("dss_splat_forward");
+}

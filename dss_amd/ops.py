@@ -1,0 +1,231 @@
+"""Tensor-level operators over the C ABI: the functions the reference binds in ``DSS._C``
+(DSS/csrc/ext.cpp:5-18), same names and argument meaning, plus the fused blend.
+
+All inputs must be GPU tensors; outputs are freshly allocated on the input's device
+(rasterize_points.cu:632-637) except ``_backward_zbuf`` which accumulates in place
+(rasterize_points.h:388-392).
+"""
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+
+_f32, _i32, _i64, _u8 = torch.float32, torch.int32, torch.int64, torch.uint8
+
+
+def _check_raster_inputs(points, ellipse_params, cutoff_thres, radii, first_idx, num_pts):
+    # shape checks of RasterizePoints, rasterize_points.h:474-488
+    if points.dim() != 2 or points.shape[1] != 3:
+        raise RuntimeError("points must have shape (P, 3), got %s" % (tuple(points.shape),))
+    P = points.shape[0]
+    if tuple(radii.shape) != (P, 2):
+        raise RuntimeError("radii must have shape (%d, 2), got %s" % (P, tuple(radii.shape)))
+    if tuple(ellipse_params.shape) != (P, 3):
+        raise RuntimeError("ellipse_params must have shape (%d, 3), got %s" % (P, tuple(ellipse_params.shape)))
+    if tuple(cutoff_thres.shape) != (P,):
+        raise RuntimeError("cutoff_thres must have shape (%d,), got %s" % (P, tuple(cutoff_thres.shape)))
+    if first_idx.shape != num_pts.shape or first_idx.dim() != 1:
+        raise RuntimeError("cloud_to_packed_first_idx and num_points_per_cloud must both be (N,)")
+    return P
+
+
+def splat_points(points, ellipse_params, cutoff_thres, radii, cloud_to_packed_first_idx,
+                 num_points_per_cloud, depth_merging_thres: float, image_size: int,
+                 points_per_pixel: int, bin_size: Optional[int] = None,
+                 max_points_per_bin: Optional[int] = None, *, rows: Optional[Tuple[int, int]] = None,
+                 return_visible: bool = False):
+    """``DSS._C.splat_points`` (ext.cpp:8, rasterize_points.h:461-525).
+
+    Returns ``(idx int32 (N,S,S,K), zbuf, qvalue f32 (N,S,S,K), occupancy f32 (N,S,S))``.
+    ``bin_size == 0`` scans every cloud per tile (the reference's naive mode); any other value
+    (or None) builds compacted screen-tile lists.  ``max_points_per_bin`` is accepted for
+    signature compatibility and ignored: tile lists are compacted, never truncated.
+    ``rows=(row0,row1)`` renders only that row band (outputs are band shaped);
+    ``return_visible`` appends the per-point visibility mask (bool (P,)).
+    """
+    lib = _lib.load()
+    P = _check_raster_inputs(points, ellipse_params, cutoff_thres, radii, cloud_to_packed_first_idx,
+                             num_points_per_cloud)
+    points = _lib.require_gpu(points, "points", _f32)
+    dev = points.device
+    ellipse_params = _lib.require_gpu(ellipse_params, "ellipse_params", _f32)
+    cutoff_thres = _lib.require_gpu(cutoff_thres, "cutoff_thres", _f32)
+    radii = _lib.require_gpu(radii, "radii", _f32)
+    first = _lib.require_gpu(cloud_to_packed_first_idx, "cloud_to_packed_first_idx", _i64)
+    num = _lib.require_gpu(num_points_per_cloud, "num_points_per_cloud", _i64)
+    N, S, K = first.shape[0], int(image_size), int(points_per_pixel)
+    row0, row1 = (0, S) if rows is None else (int(rows[0]), int(rows[1]))
+    nrows = max(row1 - row0, 0)
+    bs = 1 if bin_size is None else int(bin_size)
+    with torch.cuda.device(dev):
+        idx = torch.empty((N, nrows, S, K), dtype=_i32, device=dev)
+        zbuf = torch.empty((N, nrows, S, K), dtype=_f32, device=dev)
+        qv = torch.empty((N, nrows, S, K), dtype=_f32, device=dev)
+        occ = torch.empty((N, nrows, S), dtype=_f32, device=dev)
+        vis = torch.empty((P,), dtype=_u8, device=dev) if return_visible else None
+        nbytes = lib.dss_splat_forward_workspace(N, P, S, K, bs)
+        ws = _lib.workspace(dev, nbytes)
+        rc = lib.dss_splat_forward(_lib.ptr(points), _lib.ptr(ellipse_params), _lib.ptr(cutoff_thres),
+                                   _lib.ptr(radii), _lib.ptr(first), _lib.ptr(num), N, P,
+                                   float(depth_merging_thres), S, K, bs, row0, row1,
+                                   _lib.ptr(idx), _lib.ptr(zbuf), _lib.ptr(qv), _lib.ptr(occ), _lib.ptr(vis),
+                                   _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
+    _lib.check(rc, "dss_splat_forward")
+    if return_visible:
+        return idx, zbuf, qv, occ, vis.bool()
+    return idx, zbuf, qv, occ
+
+
+def _splat_points_naive(points, ellipse_params, cutoff_thres, radii, cloud_to_packed_first_idx,
+                        num_points_per_cloud, depth_merging_thres, image_size, points_per_pixel):
+    """``DSS._C._splat_points_naive`` (ext.cpp:9)."""
+    return splat_points(points, ellipse_params, cutoff_thres, radii, cloud_to_packed_first_idx,
+                        num_points_per_cloud, depth_merging_thres, image_size, points_per_pixel, 0, 0)
+
+
+def backward_radius(radii, visible, cloud_to_packed_first_idx, num_points_per_cloud, radii_s: float):
+    """Search radius of the backward pass, rasterizer.py:885-888 -> f32 (N,)."""
+    lib = _lib.load()
+    radii = _lib.require_gpu(radii, "radii", _f32)
+    dev = radii.device
+    vis = _lib.require_gpu(visible.to(_u8) if visible.dtype == torch.bool else visible, "visible", _u8)
+    first = _lib.require_gpu(cloud_to_packed_first_idx, "cloud_to_packed_first_idx", _i64)
+    num = _lib.require_gpu(num_points_per_cloud, "num_points_per_cloud", _i64)
+    N, P = first.shape[0], radii.shape[0]
+    with torch.cuda.device(dev):
+        rs = torch.empty((N,), dtype=_f32, device=dev)
+        rc = lib.dss_backward_radius(_lib.ptr(radii), _lib.ptr(vis), _lib.ptr(first), _lib.ptr(num), N, P,
+                                     float(radii_s), _lib.ptr(rs), None, 0, _lib.stream_ptr(dev))
+    _lib.check(rc, "dss_backward_radius")
+    return rs
+
+
+def occ_backward(points, radii, visible, rs, grad_occ, cloud_to_packed_first_idx, num_points_per_cloud,
+                 image_size: Optional[int] = None, rows: Optional[Tuple[int, int]] = None):
+    """Occupancy surrogate gradient -> (P,3) with z column 0.  Replaces the FRNN grid build
+    (rasterizer.py:889-950) + ``DSS._C._splat_points_occ_fast_cuda_backward`` (ext.cpp:14)."""
+    lib = _lib.load()
+    points = _lib.require_gpu(points, "points", _f32)
+    dev = points.device
+    radii = _lib.require_gpu(radii, "radii", _f32)
+    vis = _lib.require_gpu(visible.to(_u8) if visible.dtype == torch.bool else visible, "visible", _u8)
+    rs = _lib.require_gpu(rs, "rs", _f32)
+    grad_occ = _lib.require_gpu(grad_occ, "grad_occ", _f32)
+    first = _lib.require_gpu(cloud_to_packed_first_idx, "cloud_to_packed_first_idx", _i64)
+    num = _lib.require_gpu(num_points_per_cloud, "num_points_per_cloud", _i64)
+    N, P = first.shape[0], points.shape[0]
+    S = int(image_size) if image_size is not None else grad_occ.shape[2]
+    row0, row1 = (0, S) if rows is None else (int(rows[0]), int(rows[1]))
+    if tuple(grad_occ.shape) != (N, row1 - row0, S):
+        raise RuntimeError("grad_occ must have shape (%d, %d, %d), got %s" % (N, row1 - row0, S, tuple(grad_occ.shape)))
+    with torch.cuda.device(dev):
+        grad = torch.empty((P, 3), dtype=_f32, device=dev)
+        rc = lib.dss_occ_backward(_lib.ptr(points), _lib.ptr(radii), _lib.ptr(vis), _lib.ptr(rs), _lib.ptr(grad_occ),
+                                  _lib.ptr(first), _lib.ptr(num), N, P, S, row0, row1, _lib.ptr(grad),
+                                  _lib.stream_ptr(dev))
+    _lib.check(rc, "dss_occ_backward")
+    return grad
+
+
+def _backward_zbuf(idx, grad_zbuf, point_grad):
+    """``DSS._C._backward_zbuf`` (ext.cpp:17): in-place scatter-add.  ``point_grad`` is either the
+    reference's (P,1) z-gradient tensor or a (P,3) point-gradient tensor (z column updated)."""
+    lib = _lib.load()
+    idx = _lib.require_gpu(idx, "idx", _i32)
+    dev = idx.device
+    grad_zbuf = _lib.require_gpu(grad_zbuf, "grad_zbuf", _f32)
+    if idx.dim() != 4 or idx.shape != grad_zbuf.shape:
+        raise RuntimeError("idx and grad_zbuf must both be (N,H,W,K)")
+    if not (point_grad.is_cuda and point_grad.dtype == _f32 and point_grad.is_contiguous() and point_grad.dim() == 2):
+        raise RuntimeError("point_grad must be a contiguous float32 GPU tensor of shape (P,1) or (P,3)")
+    N, H, W, K = idx.shape
+    with torch.cuda.device(dev):
+        if point_grad.shape[1] == 3:
+            rc = lib.dss_zbuf_backward(_lib.ptr(idx), _lib.ptr(grad_zbuf), N, H, W, K, _lib.ptr(point_grad),
+                                       _lib.stream_ptr(dev))
+        elif point_grad.shape[1] == 1:
+            tmp = torch.zeros((point_grad.shape[0], 3), dtype=_f32, device=dev)
+            rc = lib.dss_zbuf_backward(_lib.ptr(idx), _lib.ptr(grad_zbuf), N, H, W, K, _lib.ptr(tmp),
+                                       _lib.stream_ptr(dev))
+            point_grad += tmp[:, 2:3]
+        else:
+            raise RuntimeError("point_grad must have 1 or 3 columns")
+    _lib.check(rc, "dss_zbuf_backward")
+
+
+def clip_grad_(grad_pts, clip: float):
+    """In-place per-point norm clip (rasterizer.py:667-673)."""
+    lib = _lib.load()
+    if not (grad_pts.is_cuda and grad_pts.dtype == _f32 and grad_pts.is_contiguous()):
+        raise RuntimeError("grad_pts must be a contiguous float32 GPU tensor")
+    with torch.cuda.device(grad_pts.device):
+        rc = lib.dss_clip_grad(_lib.ptr(grad_pts), grad_pts.shape[0], float(clip), _lib.stream_ptr(grad_pts.device))
+    _lib.check(rc, "dss_clip_grad")
+    return grad_pts
+
+
+def splat_backward(points, radii, visible, idx, grad_occ, grad_zbuf, cloud_to_packed_first_idx,
+                   num_points_per_cloud, radii_s: float, clip: float = -1.0, return_rs: bool = False):
+    """Whole ``EllipticalRasterizer.backward`` (rasterizer.py:787-977) in one call -> grad (P,3)."""
+    lib = _lib.load()
+    points = _lib.require_gpu(points, "points", _f32)
+    dev = points.device
+    radii = _lib.require_gpu(radii, "radii", _f32)
+    vis = _lib.require_gpu(visible.to(_u8) if visible.dtype == torch.bool else visible, "visible", _u8)
+    idx = _lib.require_gpu(idx, "idx", _i32)
+    grad_occ = _lib.require_gpu(grad_occ, "grad_occ", _f32)
+    if grad_zbuf is not None:
+        grad_zbuf = _lib.require_gpu(grad_zbuf, "grad_zbuf", _f32)
+    first = _lib.require_gpu(cloud_to_packed_first_idx, "cloud_to_packed_first_idx", _i64)
+    num = _lib.require_gpu(num_points_per_cloud, "num_points_per_cloud", _i64)
+    N, S, _, K = idx.shape
+    P = points.shape[0]
+    with torch.cuda.device(dev):
+        grad = torch.empty((P, 3), dtype=_f32, device=dev)
+        rs = torch.empty((N,), dtype=_f32, device=dev)
+        rc = lib.dss_splat_backward(_lib.ptr(points), _lib.ptr(radii), _lib.ptr(vis), _lib.ptr(idx),
+                                    _lib.ptr(grad_occ), _lib.ptr(grad_zbuf), _lib.ptr(first), _lib.ptr(num),
+                                    N, P, S, K, float(radii_s), float(clip), _lib.ptr(grad), _lib.ptr(rs),
+                                    None, 0, _lib.stream_ptr(dev))
+    _lib.check(rc, "dss_splat_backward")
+    return (grad, rs) if return_rs else grad
+
+
+def blend_forward(idx, qvalue, occupancy, scaler, features):
+    """Fused weights + NormWeightedCompositor + RGBA assembly (renderer.py:53-78).
+    ``features`` is (P,C); returns (N,H,W,C+1)."""
+    lib = _lib.load()
+    idx = _lib.require_gpu(idx, "idx", _i32)
+    dev = idx.device
+    qvalue = _lib.require_gpu(qvalue, "qvalue", _f32)
+    occupancy = _lib.require_gpu(occupancy, "occupancy", _f32)
+    scaler = _lib.require_gpu(scaler, "scaler", _f32)
+    features = _lib.require_gpu(features, "features", _f32)
+    N, H, W, K = idx.shape
+    C = features.shape[1]
+    with torch.cuda.device(dev):
+        out = torch.empty((N, H, W, C + 1), dtype=_f32, device=dev)
+        rc = lib.dss_blend_forward(_lib.ptr(idx), _lib.ptr(qvalue), _lib.ptr(occupancy), _lib.ptr(scaler),
+                                   _lib.ptr(features), N, H, W, K, C, _lib.ptr(out), _lib.stream_ptr(dev))
+    _lib.check(rc, "dss_blend_forward")
+    return out
+
+
+def blend_backward(grad_out, idx, qvalue, scaler, num_points: int):
+    """-> (grad_features (P,C), grad_occupancy (N,H,W))."""
+    lib = _lib.load()
+    grad_out = _lib.require_gpu(grad_out, "grad_out", _f32)
+    dev = grad_out.device
+    idx = _lib.require_gpu(idx, "idx", _i32)
+    qvalue = _lib.require_gpu(qvalue, "qvalue", _f32)
+    scaler = _lib.require_gpu(scaler, "scaler", _f32)
+    N, H, W, K = idx.shape
+    C = grad_out.shape[-1] - 1
+    with torch.cuda.device(dev):
+        gf = torch.empty((num_points, C), dtype=_f32, device=dev)
+        go = torch.empty((N, H, W), dtype=_f32, device=dev)
+        rc = lib.dss_blend_backward(_lib.ptr(grad_out), _lib.ptr(idx), _lib.ptr(qvalue), _lib.ptr(scaler),
+                                    N, H, W, K, C, num_points, _lib.ptr(gf), _lib.ptr(go), _lib.stream_ptr(dev))
+    _lib.check(rc, "dss_blend_backward")
+    return gf, go

@@ -1,0 +1,153 @@
+/*
+ * dss_hip.h -- C ABI of libdss_hip.so, the MI355X (gfx950) implementation of the DSS
+ * differentiable EWA surface-splatting hot path.
+ *
+ * This is the drop-in boundary for the reference's native module `DSS._C`
+ * (/root/reference/DSS/csrc/ext.cpp:5-18).  Every entry point names the reference interface it
+ * replaces.  Conventions (all entry points):
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless it says "host";
+ *   - all tensors are dense row-major float32 / int32 / int64 / uint8 exactly as the reference's
+ *     torch tensors are laid out after .contiguous() (rasterize_points.cu:648-663);
+ *   - the caller owns every buffer (outputs and workspace); nothing is allocated inside;
+ *   - work is enqueued asynchronously on `stream` (a hipStream_t; NULL = default stream); no host
+ *     synchronisation happens inside the library; no global mutable state; re-entrant;
+ *   - return value: 0 on success, negative DSS_ERR_* otherwise (no exceptions cross the ABI);
+ *     dss_last_error() returns a thread-local message for the last failing call on this thread;
+ *   - `row0,row1` select the image row band [row0,row1) a rank renders (multi-GPU row
+ *     partitioning); band-shaped tensors have `rows = row1-row0` rows.  Single GPU: 0, S.
+ *
+ * Image convention (rasterization_utils.cuh:8-11, rasterize_points.cu:160-164, 577-580):
+ * image pixel [row r, col c] has NDC centre ( -1+(2*(S-1-c)+1)/S , -1+(2*(S-1-r)+1)/S ).
+ */
+#ifndef DSS_HIP_H
+#define DSS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DSS_HIP_VERSION 100
+
+#if defined(__GNUC__)
+#define DSS_API __attribute__((visibility("default")))
+#else
+#define DSS_API
+#endif
+
+#define DSS_OK 0
+#define DSS_ERR_INVALID_ARGUMENT (-1) /* shape / range check failed (reference: TORCH_CHECK / checkSize) */
+#define DSS_ERR_WORKSPACE (-2)        /* workspace pointer NULL or too small */
+#define DSS_ERR_UNSUPPORTED (-3)      /* legal in the reference but not implemented here */
+#define DSS_ERR_LAUNCH (-4)           /* hipGetLastError() after a launch (reference: AT_CUDA_CHECK) */
+
+/* Largest points_per_pixel with a register-resident K-list.  The reference's compile-time bound
+ * is kMaxPointsPerPixel = 150 (rasterization_utils.cuh:18); K in (DSS_MAX_K_FAST, 150] is served
+ * by a slower scratch-memory kernel. */
+#define DSS_MAX_K_FAST 32
+#define DSS_MAX_K 150
+
+DSS_API int dss_version(void);
+DSS_API const char *dss_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Forward rasterizer.
+ * Replaces  DSS._C.splat_points  (ext.cpp:8) = RasterizePoints (rasterize_points.h:461-525):
+ * naive kernel rasterize_points.cu:131-212 for bin_size==0, coarse+fine kernels :293-432 and
+ * :506-597 otherwise.  Both modes return identical results here; bin_size only selects whether
+ * screen-tile lists are built (bin_size != 0) or every tile scans its whole cloud (bin_size == 0).
+ *
+ *   points   (P,3)  NDC x, NDC y, view-space z      ellipse (P,3)  a,b,c of Q = a dx^2 + b dx dy + c dy^2
+ *   cutoff   (P,)   per-point Q threshold           radii   (P,2)  axis-aligned NDC half extents
+ *   first_idx, num_pts (N,) int64                   cloud_to_packed_first_idx / num_points_per_cloud
+ *   merge_thr       depth_merging_threshold         S image side, K points_per_pixel
+ * outputs (band shaped, fully written, no pre-fill needed):
+ *   idx int32 (N,rows,S,K)  zbuf f32 (N,rows,S,K)  qvalue f32 (N,rows,S,K)  occ f32 (N,rows,S)
+ *   visible uint8 (P,) or NULL: set to 1 for every point that appears in a fragment of this band,
+ *           0 otherwise (replaces get_per_point_visibility_mask, DSS/utils/__init__.py:320-340,
+ *           called at rasterizer.py:639-641 and again in the backward at :854-860).
+ * Per-pixel rule: hit iff pz>=0, |dx|<=rx, |dy|<=ry, Q<=cutoff; keep the K smallest (z, idx);
+ * ascending; drop k with z[k]-z[0] > merge_thr; unfilled slots idx=-1, zbuf=-1, qvalue=-1.
+ * ------------------------------------------------------------------------------------------- */
+DSS_API size_t dss_splat_forward_workspace(int N, int64_t P, int S, int K, int bin_size);
+
+DSS_API int dss_splat_forward(const float *points, const float *ellipse, const float *cutoff,
+                      const float *radii, const int64_t *first_idx, const int64_t *num_pts,
+                      int N, int64_t P, float merge_thr, int S, int K, int bin_size,
+                      int row0, int row1,
+                      int32_t *idx, float *zbuf, float *qvalue, float *occ, uint8_t *visible,
+                      void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Backward of the rasterizer = EllipticalRasterizer.backward (rasterizer.py:787-977) with
+ * backward_occ_fast=True (:816), in four pieces so that a multi-GPU caller can reduce between
+ * them; dss_splat_backward() chains all four for the single-GPU case.
+ * ------------------------------------------------------------------------------------------- */
+
+/* rs[n] = lower_median( flattened (x,y) radii of the visible points of cloud n ) * radii_s
+ * (rasterizer.py:885-888, torch.median).  Clouds without visible points get rs = 0. */
+DSS_API size_t dss_backward_radius_workspace(int N, int64_t P);
+DSS_API int dss_backward_radius(const float *radii, const uint8_t *visible, const int64_t *first_idx,
+                        const int64_t *num_pts, int N, int64_t P, float radii_s,
+                        float *rs /* (N,) */, void *workspace, size_t workspace_bytes, void *stream);
+
+/* Occupancy surrogate gradient.  Replaces the Python grid build (rasterizer.py:889-950: FRNN
+ * insert_points_cuda / prefix_sum_cuda / counting_sort_cuda) plus
+ * DSS._C._splat_points_occ_fast_cuda_backward (ext.cpp:14, rasterize_points_backward.cu:30-212):
+ *   for every pixel (r,c) of the band with g = grad_occ != 0 and every VISIBLE point p of the same
+ *   cloud with pz>=0, |px|<=1, |py|<=1, d2 = dx^2+dy^2 <= rs[n]^2:
+ *       skip if g>0 and (|dx|>rx or |dy|>ry);   grad_xy[p] += (dx,dy)/max(d2,1e-10)*g
+ *   (a pair with d2 == 0 contributes 0; the reference produces NaN there).
+ * Writes grad_pts[:,0:2] for ALL points (0 for invisible ones) and sets grad_pts[:,2] = 0.
+ * Gather formulation: one wavefront per point, no atomics, deterministic. */
+DSS_API int dss_occ_backward(const float *points, const float *radii, const uint8_t *visible,
+                     const float *rs, const float *grad_occ /* (N,rows,S) */,
+                     const int64_t *first_idx, const int64_t *num_pts, int N, int64_t P, int S,
+                     int row0, int row1, float *grad_pts /* (P,3) */, void *stream);
+
+/* Replaces DSS._C._backward_zbuf (ext.cpp:17, rasterize_points.cu:823-846): accumulates IN PLACE
+ * z_grad[idx[n,r,c,k]] += grad_zbuf[n,r,c,k] (zero grads skipped, stop at first idx<0), into the
+ * z column of grad_pts (P,3). */
+DSS_API int dss_zbuf_backward(const int32_t *idx, const float *grad_zbuf, int N, int rows, int S, int K,
+                      float *grad_pts /* (P,3), in/out */, void *stream);
+
+/* Per-point gradient clip hook (rasterizer.py:667-673, installed at :735-737), in place:
+ * g <- g / max(||g||,1e-12) * min(||g||, clip).  No-op when clip <= 0. */
+DSS_API int dss_clip_grad(float *grad_pts /* (P,3) */, int64_t P, float clip, void *stream);
+
+DSS_API size_t dss_splat_backward_workspace(int N, int64_t P);
+DSS_API int dss_splat_backward(const float *points, const float *radii, const uint8_t *visible,
+                       const int32_t *idx, const float *grad_occ,
+                       const float *grad_zbuf /* NULL = all zero */,
+                       const int64_t *first_idx, const int64_t *num_pts,
+                       int N, int64_t P, int S, int K, float radii_s, float clip,
+                       float *grad_pts /* (P,3), fully written */, float *rs_out /* (N,) or NULL */,
+                       void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Blend = SurfaceSplattingRenderer.forward after rasterization (renderer.py:53-78):
+ *   w_k = exp(-0.5*Q_k) * scaler[idx_k]          (renderer.py:53, rasterizer.py:631-633)
+ *   img[ch] = sum_k feat[idx_k][ch] * w_k / max(sum_k w_k, 1e-4)   (pytorch3d NormWeightedCompositor,
+ *                                                 renderer.py:67-72; third-party norm_weighted_sum)
+ *   out[..., C] = occ                            (renderer.py:75-78)
+ * feat is (P,C) row-major (Pointclouds.features_packed()); out is (N,rows,S,C+1). 1 <= C <= 8.
+ * ------------------------------------------------------------------------------------------- */
+DSS_API int dss_blend_forward(const int32_t *idx, const float *qvalue, const float *occ,
+                      const float *scaler, const float *feat, int N, int rows, int S, int K, int C,
+                      float *out, void *stream);
+
+/* Backward of the blend to the per-point features and to occupancy:
+ *   grad_feat[idx_k][ch] += grad_out[ch] * w_k / max(sum w, 1e-4)      (zeroed here first)
+ *   grad_occ = grad_out[..., C]
+ * The gradient w.r.t. the weights is not produced: the reference discards it
+ * (rasterizer.py:788-789 ignores qvalue_grad; EWA terms are detached, :562-565). */
+DSS_API int dss_blend_backward(const float *grad_out, const int32_t *idx, const float *qvalue,
+                       const float *scaler, int N, int rows, int S, int K, int C, int64_t P,
+                       float *grad_feat /* (P,C) */, float *grad_occ /* (N,rows,S) */, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DSS_HIP_H */

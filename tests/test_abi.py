@@ -1,0 +1,63 @@
+"""CPU: the C-ABI library loads and exports every symbol include/dss_hip.h declares; argument
+validation is reachable without a GPU; the product never falls back to CPU."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from dss_amd import _lib, ops
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "dss_hip.h")).read()
+    return sorted(set(re.findall(r"DSS_API\s+[\w \*]+?\b(dss_\w+)\s*\(", text)))
+
+
+def test_header_symbols_exported_and_bound():
+    declared = _declared_symbols()
+    assert len(declared) >= 13
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), "libdss_hip.so does not export %s" % name
+    assert sorted(_lib.SIGNATURES) == declared
+
+
+def test_version_and_error_channel():
+    lib = _lib.load()
+    assert lib.dss_version() == 100
+    rc = lib.dss_splat_forward(None, None, None, None, None, None, 0, 0, 0.05, 16, 5, 0, 0, 16,
+                               None, None, None, None, None, None, 0, None)
+    assert rc == -1
+    assert b"must be positive" in lib.dss_last_error()
+    rc = lib.dss_blend_forward(None, None, None, None, None, 1, 4, 4, 5, 99, None, None)
+    assert rc == -1 and b"C=99" in lib.dss_last_error()
+    with pytest.raises(RuntimeError, match="dss_splat_forward"):
+        _lib.check(-1, "dss_splat_forward")
+
+
+def test_workspace_query():
+    lib = _lib.load()
+    assert lib.dss_splat_forward_workspace(1, 32684, 512, 5, 0) == 256
+    assert lib.dss_splat_forward_workspace(1, 32684, 512, 5, 32) > 32684 * 8 * 4
+    assert lib.dss_splat_backward_workspace(8, 1000) >= 32
+
+
+def test_no_cpu_fallback():
+    pts = torch.zeros(4, 3)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.splat_points(pts, torch.zeros(4, 3), torch.zeros(4), torch.zeros(4, 2), torch.zeros(1, dtype=torch.int64),
+                         torch.full((1,), 4, dtype=torch.int64), 0.05, 16, 5)
+
+
+def test_shape_checks_match_reference():
+    # rasterize_points.h:474-488
+    with pytest.raises(RuntimeError, match="radii must have shape"):
+        ops.splat_points(torch.zeros(4, 3), torch.zeros(4, 3), torch.zeros(4), torch.zeros(4, 3),
+                         torch.zeros(1, dtype=torch.int64), torch.zeros(1, dtype=torch.int64), 0.05, 16, 5)
+    with pytest.raises(RuntimeError, match="points must have shape"):
+        ops.splat_points(torch.zeros(4, 2), torch.zeros(4, 3), torch.zeros(4), torch.zeros(4, 2),
+                         torch.zeros(1, dtype=torch.int64), torch.zeros(1, dtype=torch.int64), 0.05, 16, 5)
