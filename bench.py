@@ -1,0 +1,287 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the EWA splatting hot path on MI355X (contract: see README / task).
+
+One "step" = one forward + backward pass of the whole hot path over one batch of synthetic input
+already resident in HBM:
+    point_setup -> splat_forward (bin + fine) -> blend_forward -> [row all-gather]
+    -> blend_backward -> backward_radius -> occ_backward -> [grad all-reduce] -> clip -> project_backward
+Workload at N=1 = BASELINE.json configs[1]: "bunny ~30k" (bunny-8000 x4 tangent-plane jitter =
+32,684 points), 1 camera, 512x512, K=5, fwd+bwd with grad_out = randn(seed 1) on RGBA.
+For N GPUs the batch holds N cameras (ring, azim = 45 deg * k) and every image is row-partitioned
+across the N ranks (weak scaling: rows x cameras per rank is constant); bands are reassembled with
+an RCCL all-gather and gradient partials are all-reduced.
+
+Metric: Msplats/s = (cameras * points per cloud) / step time, whole job.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from dss_amd import _lib, ops  # noqa: E402
+from dss_amd.cameras import FoVPerspectiveCameras, look_at_view_transform  # noqa: E402
+from dss_amd.distributed import RowPartition, gather_rows, reduce_grads_, reduce_visibility_  # noqa: E402
+
+S, K, THR, RADII_S, CLIP, CUTOFF, SIGMA = 512, 5, 0.05, 5.0, 0.05, 1.0, 1.0
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def bunny_cloud():
+    """bunny-8000 (tests/golden/clouds.npz, converted from the reference fixture) x4 jitter upsample."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import scenes
+    pts, nrm = scenes.load_cloud("bunny")
+    pts = scenes.normalize_unit_sphere(pts)
+    pts, nrm = scenes.upsample_jitter(pts, nrm, 4, seed=0)
+    h = scenes.global_h(pts)
+    col = np.random.default_rng(0).uniform(0, 1, pts.shape).astype(np.float32)
+    return pts, nrm, col, h
+
+
+class Workload:
+    def __init__(self, device, n_cams, part: RowPartition):
+        pts, nrm, col, h = bunny_cloud()
+        self.dev, self.N, self.part = device, n_cams, part
+        self.Pc = pts.shape[0]
+        self.P = self.N * self.Pc
+        t = lambda a: torch.from_numpy(a).to(device)
+        self.world, self.normals = t(pts), t(nrm)
+        self.colors = t(col).repeat(self.N, 1).contiguous()  # packed (N*Pc,3) features of the extended cloud
+        self.h = torch.full((self.N,), h, device=device)
+        R, T = look_at_view_transform(2.0, 30.0, [45.0 + 45.0 * k for k in range(self.N)])
+        cam = FoVPerspectiveCameras(znear=0.1, zfar=100.0, fov=60.0, R=R, T=T)
+        self.M = cam.get_full_projection_transform().get_matrix().to(device).contiguous()
+        self.V = cam.get_world_to_view_transform().get_matrix().to(device).contiguous()
+        self.znear = torch.full((self.N,), 0.1, device=device)
+        self.zfar = torch.full((self.N,), 100.0, device=device)
+        self.first = torch.arange(self.N, device=device, dtype=torch.int64) * self.Pc
+        self.num = torch.full((self.N,), self.Pc, device=device, dtype=torch.int64)
+        g = torch.Generator(device="cpu").manual_seed(1)
+        self.grad_out = torch.randn((self.N, S, S, 4), generator=g).to(device)  # d loss / d RGBA
+
+    def step(self):
+        p = self.part
+        info = ops.point_setup(self.world, self.normals, self.h, self.M, self.V, self.znear, self.zfar, self.first,
+                               self.num, S, CUTOFF, SIGMA, False, True)
+        idx, zbuf, qv, occ, vis = ops.splat_points(info["pts_screen"], info["ellipse_params"],
+                                                   info["cutoff_threshold"], info["radii"], self.first, self.num,
+                                                   THR, S, K, None, None, rows=p.rows, return_visible=True)
+        band = ops.blend_forward(idx, qv, occ, info["scaler"], self.colors)
+        image = gather_rows(band, p)
+        g_band = p.slice(self.grad_out).contiguous() if p.world_size > 1 else self.grad_out
+        g_feat, g_occ = ops.blend_backward(g_band, idx, qv, info["scaler"], self.P)
+        if p.world_size == 1:
+            g_pts = ops.splat_backward(info["pts_screen"], info["radii"], vis, idx, g_occ, None, self.first,
+                                       self.num, RADII_S, CLIP)
+        else:
+            vis8 = vis.to(torch.uint8)
+            reduce_visibility_(vis8, p)
+            rs = ops.backward_radius(info["radii"], vis8, self.first, self.num, RADII_S)
+            g_pts = ops.occ_backward(info["pts_screen"], info["radii"], vis8, rs, g_occ, self.first, self.num,
+                                     image_size=S, rows=p.rows)
+            reduce_grads_(g_pts, g_feat, part=p)
+            ops.clip_grad_(g_pts, CLIP)
+        g_world = ops.project_backward(self.world, self.M, self.V, self.first, self.num, g_pts, info["valid"], True)
+        g_col = g_feat.view(self.N, self.Pc, 3).sum(0) if self.N > 1 else g_feat
+        return image, g_world, g_col
+
+    # ---- dominant-kernel timing (fine kernel, exactly one launch per call) ------------------
+    def fine_kernel_ms(self, iters=50):
+        lib = _lib.load()
+        info = ops.point_setup(self.world, self.normals, self.h, self.M, self.V, self.znear, self.zfar, self.first,
+                               self.num, S, CUTOFF, SIGMA, False, True)
+        r0, r1 = self.part.rows
+        rows = r1 - r0
+        dev = self.dev
+        idx = torch.empty((self.N, rows, S, K), dtype=torch.int32, device=dev)
+        zbuf = torch.empty((self.N, rows, S, K), device=dev)
+        qv = torch.empty_like(zbuf)
+        occ = torch.empty((self.N, rows, S), device=dev)
+        vis = torch.zeros((self.P,), dtype=torch.uint8, device=dev)
+        nbytes = lib.dss_splat_forward_workspace(self.N, self.P, S, K, 1)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        st = _lib.stream_ptr(dev)
+        a = (_lib.ptr(info["pts_screen"]), _lib.ptr(info["ellipse_params"]), _lib.ptr(info["cutoff_threshold"]),
+             _lib.ptr(info["radii"]), _lib.ptr(self.first), _lib.ptr(self.num), self.N, self.P)
+        _lib.check(lib.dss_splat_bin(a[0], a[3], a[4], a[5], self.N, self.P, S, r0, r1, _lib.ptr(ws), nbytes, st),
+                   "dss_splat_bin")
+        run = lambda: lib.dss_splat_fine(*a, THR, S, K, r0, r1, _lib.ptr(idx), _lib.ptr(zbuf), _lib.ptr(qv),
+                                         _lib.ptr(occ), _lib.ptr(vis), _lib.ptr(ws), nbytes, st)
+        for _ in range(5):
+            _lib.check(run(), "dss_splat_fine")
+        # HIP events on the stream the kernel is launched on (torch's current stream)
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+        for s, e in ev:
+            s.record()
+            run()
+            e.record()
+        torch.cuda.synchronize()
+        ms = sorted(s.elapsed_time(e) for s, e in ev)
+        return float(np.mean(ms)), float(ms[len(ms) // 2])
+
+
+def cpu_baseline():
+    """Reference CPU fallback (oracle/_ref = unmodified DSS/csrc/rasterize_points_cpu.cpp) timed on ONE
+    host core (the code has no OpenMP / at::parallel_for) on a bounded sample of the same workload:
+    the same 32,684-point scene at 256x256 (1/4 of the pixels; the naive CPU path is O(S^2 * P))."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle
+    import scenes
+    pts, nrm, col, h = bunny_cloud()
+    Sb = 256
+    M, V, _ = scenes.camera_matrices(2.0, 30.0, 45.0)
+    sc = scenes.setup_scene(pts, nrm, M, V, Sb, h=h)
+    P = sc["points"].shape[0]
+    rng = np.random.default_rng(1)
+    gocc = rng.standard_normal((1, Sb, Sb)).astype(np.float32)
+    R = oracle.ref()
+    torch.set_num_threads(1)
+    if R is not None:
+        t = lambda k: torch.from_numpy(np.ascontiguousarray(sc[k]))
+        t0 = time.perf_counter()
+        R.splat_points(t("points"), t("ellipse"), t("cutoff"), t("radii"), t("first_idx"), t("num_pts"), THR, Sb, K, 0, 0)
+        t_f = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        R._splat_points_occ_backward(t("points"), t("radii"), torch.from_numpy(gocc), t("first_idx"), t("num_pts"),
+                                     RADII_S, THR)
+        t_b = time.perf_counter() - t0
+        kind = "reference"
+        what = "reference CPU splat_points(bin_size=0) + _splat_points_occ_backward"
+    else:
+        t0 = time.perf_counter()
+        o = oracle.splat_forward(sc["points"], sc["ellipse"], sc["cutoff"], sc["radii"], sc["first_idx"],
+                                 sc["num_pts"], Sb, K, THR, brute=True)
+        t_f = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        oracle.splat_backward(sc["points"], sc["radii"], o[0], gocc, None, sc["first_idx"], sc["num_pts"], RADII_S)
+        t_b = time.perf_counter() - t0
+        kind = "port"
+        what = "oracle C port (brute-force forward + fast backward)"
+    return {"value": round(P / (t_f + t_b) / 1e6, 6), "unit": "Msplats/s", "cores": 1, "kind": kind,
+            "sample": "%s, raster fwd+bwd only (no blend), same %d-point bunny scene at %dx%d (1/4 of the pixels "
+                      "of the 512x512 workload), fwd %.2fs + bwd %.2fs on 1 of %d host cores"
+                      % (what, P, Sb, Sb, t_f, t_b, os.cpu_count())}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--mode", choices=["graph", "eager"], default=None,
+                    help="graph: replay the captured step as a hipGraph (default on 1 GPU); eager: plain launches")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d"
+                             % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    mode = args.mode or ("graph" if world == 1 else "eager")
+
+    part = RowPartition(S, world, rank)
+    wl = Workload(dev, world, part)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    graph = None
+    if mode == "graph":
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                wl.step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            outs = wl.step()
+        run = graph.replay
+    else:
+        run = wl.step
+
+    for _ in range(args.warmup):
+        run()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    ms_step = dt / args.steps * 1e3
+    splats = wl.P  # cameras * points per cloud submitted per step (whole job)
+    value = splats / (ms_step * 1e-3) / 1e6
+
+    # secondary: the other launch mode, for the record
+    other = None
+    if world == 1:
+        alt = wl.step if mode == "graph" else None
+        if alt is not None:
+            for _ in range(5):
+                alt()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(50):
+                alt()
+            torch.cuda.synchronize()
+            other = (time.perf_counter() - t0) / 50 * 1e3
+
+    fine_mean, fine_med = wl.fine_kernel_ms()
+    r0, r1 = part.rows
+    # algorithmic bytes of ONE fine-kernel launch (DESIGN.md "fine kernel"): every pixel of the band
+    # writes idx+zbuf+qvalue (12K B) + occ (4 B); every splat's 36-B screen record (pos 12, ellipse 12,
+    # radii 8, cutoff 4) is read once.
+    alg_bytes = wl.N * (r1 - r0) * S * (12 * K + 4) + wl.P * 36
+    achieved = alg_bytes / (fine_mean * 1e-3) / 1e9
+    if rank == 0:
+        rec = {
+            "metric": "Msplats/s fwd+bwd @512^2", "value": round(value, 3), "unit": "Msplats/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 5),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: bunny-8000 x4 jitter = %d pts/cloud, %d camera(s), "
+                                   "512x512, K=5, fwd+bwd (setup+raster+blend and their backward), "
+                                   "grad_out=randn(seed 1)" % (wl.Pc, wl.N),
+                       "points_per_cloud": wl.Pc, "cameras": wl.N, "image_size": S, "points_per_pixel": K,
+                       "parallelism": "rows%d" % world, "launch": mode},
+            "roofline": {"bound": "hbm", "kernel": "fine_kernel<5>", "achieved": round(achieved, 2),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                         "traffic": None, "algorithmic_bytes": alg_bytes, "kernel_ms_mean": round(fine_mean, 5),
+                         "kernel_ms_median": round(fine_med, 5)},
+        }
+        if other is not None:
+            rec["config"]["ms_per_step_eager"] = round(other, 5)
+        if not args.no_cpu_baseline:
+            rec["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(rec))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

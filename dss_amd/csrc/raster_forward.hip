@@ -410,83 +410,126 @@ extern "C" size_t dss_splat_forward_workspace(int N, int64_t P, int S, int K, in
     return w.bytes + align_up(((size_t)P * 8 + tiles) * 4, 256);
 }
 
-extern "C" int dss_splat_forward(const float *points, const float *ellipse, const float *cutoff,
-                                 const float *radii, const int64_t *first_idx, const int64_t *num_pts,
-                                 int N, int64_t P, float merge_thr, int S, int K, int bin_size,
-                                 int row0, int row1, int32_t *idx, float *zbuf, float *qvalue, float *occ,
-                                 uint8_t *visible, void *workspace, size_t workspace_bytes, void *stream)
+static int validate_fwd(const char *fn, int N, int64_t P, int S, int K, int row0, int row1)
 {
     if (N <= 0 || P < 0 || S <= 0 || K <= 0) {
-        set_error("dss_splat_forward: N=%d P=%lld S=%d K=%d must be positive", N, (long long)P, S, K);
+        set_error("%s: N=%d P=%lld S=%d K=%d must be positive", fn, N, (long long)P, S, K);
         return DSS_ERR_INVALID_ARGUMENT;
     }
     if (row0 < 0 || row1 > S || row0 >= row1) {
-        set_error("dss_splat_forward: row band [%d,%d) outside image of side %d", row0, row1, S);
+        set_error("%s: row band [%d,%d) outside image of side %d", fn, row0, row1, S);
         return DSS_ERR_INVALID_ARGUMENT;
     }
     if (K > DSS_MAX_K) {
-        set_error("dss_splat_forward: points_per_pixel %d exceeds kMaxPointsPerPixel=%d", K, DSS_MAX_K);
+        set_error("%s: points_per_pixel %d exceeds kMaxPointsPerPixel=%d", fn, K, DSS_MAX_K);
         return DSS_ERR_INVALID_ARGUMENT;
     }
     if (K > DSS_MAX_K_FAST) {
-        set_error("dss_splat_forward: points_per_pixel %d > %d not implemented yet", K, DSS_MAX_K_FAST);
+        set_error("%s: points_per_pixel %d > %d not implemented yet", fn, K, DSS_MAX_K_FAST);
         return DSS_ERR_UNSUPPORTED;
     }
     if (S > 65535 * DSS_TILE || P > 0x7ffffff0ll) {
-        set_error("dss_splat_forward: S=%d or P=%lld too large", S, (long long)P);
+        set_error("%s: S=%d or P=%lld too large", fn, S, (long long)P);
         return DSS_ERR_UNSUPPORTED;
     }
-    if (!idx || !zbuf || !qvalue || !occ || !first_idx || !num_pts ||
-        (P > 0 && (!points || !ellipse || !cutoff || !radii))) {
-        set_error("dss_splat_forward: NULL tensor pointer");
-        return DSS_ERR_INVALID_ARGUMENT;
-    }
-    hipStream_t st = as_stream(stream);
+    return DSS_OK;
+}
+
+static TileGrid make_grid(int S, int row0, int row1)
+{
     TileGrid g;
     g.S = S;
     g.row0 = row0;
     g.rows = row1 - row0;
     g.tiles_x = (S + DSS_TILE - 1) / DSS_TILE;
     g.tiles_y = (g.rows + DSS_TILE - 1) / DSS_TILE;
+    return g;
+}
+
+extern "C" int dss_splat_bin(const float *points, const float *radii, const int64_t *first_idx,
+                             const int64_t *num_pts, int N, int64_t P, int S, int row0, int row1,
+                             void *workspace, size_t workspace_bytes, void *stream)
+{
+    int rc = validate_fwd("dss_splat_bin", N, P, S, 1, row0, row1);
+    if (rc) return rc;
+    if (P == 0) return DSS_OK;
+    if (!points || !radii || !first_idx || !num_pts) {
+        set_error("dss_splat_bin: NULL tensor pointer");
+        return DSS_ERR_INVALID_ARGUMENT;
+    }
+    const size_t need = dss_splat_forward_workspace(N, P, S, 1, 1);
+    if (!workspace || workspace_bytes < need) {
+        set_error("dss_splat_bin: workspace %zu bytes < required %zu", workspace_bytes, need);
+        return DSS_ERR_WORKSPACE;
+    }
+    hipStream_t st = as_stream(stream);
+    const TileGrid g = make_grid(S, row0, row1);
     const int tiles = g.tiles_x * g.tiles_y;
-    const long long blocks_ll = (long long)N * tiles;
-    if (blocks_ll > 0x7fffffffll) {
-        set_error("dss_splat_forward: too many tiles");
-        return DSS_ERR_UNSUPPORTED;
-    }
+    if ((long long)N * tiles > 0x7fffffffll) { set_error("dss_splat_bin: too many tiles"); return DSS_ERR_UNSUPPORTED; }
+    FwdWorkspace w = carve_fwd(workspace, N, P, S, workspace_bytes);
+    if (hipMemsetAsync(w.tile_count, 0, (size_t)N * tiles * 4, st) != hipSuccess) return check_launch("memset tile_count");
+    const int pb = (int)((P + 255) / 256);
+    hipLaunchKernelGGL(bin_count_kernel, dim3(pb), dim3(256), 0, st, points, radii, first_idx, num_pts, N, P, g,
+                       w.tile_count, w.rects);
+    hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), 0, st, w.tile_count, N * tiles, w.offsets, w.cursor,
+                       w.capacity, w.overflow);
+    hipLaunchKernelGGL(bin_fill_kernel, dim3(pb), dim3(256), 0, st, w.rects, first_idx, num_pts, N, P, g, w.cursor,
+                       w.overflow, w.list);
+    return check_launch("dss_splat_bin");
+}
 
-    if (visible && P > 0) {
-        if (hipMemsetAsync(visible, 0, (size_t)P, st) != hipSuccess) return check_launch("memset visible");
+extern "C" int dss_splat_fine(const float *points, const float *ellipse, const float *cutoff, const float *radii,
+                              const int64_t *first_idx, const int64_t *num_pts, int N, int64_t P, float merge_thr,
+                              int S, int K, int row0, int row1, int32_t *idx, float *zbuf, float *qvalue, float *occ,
+                              uint8_t *visible, const void *workspace, size_t workspace_bytes, void *stream)
+{
+    int rc = validate_fwd("dss_splat_fine", N, P, S, K, row0, row1);
+    if (rc) return rc;
+    if (!idx || !zbuf || !qvalue || !occ || !first_idx || !num_pts ||
+        (P > 0 && (!points || !ellipse || !cutoff || !radii))) {
+        set_error("dss_splat_fine: NULL tensor pointer");
+        return DSS_ERR_INVALID_ARGUMENT;
     }
-
+    const TileGrid g = make_grid(S, row0, row1);
+    const long long blocks_ll = (long long)N * g.tiles_x * g.tiles_y;
+    if (blocks_ll > 0x7fffffffll) { set_error("dss_splat_fine: too many tiles"); return DSS_ERR_UNSUPPORTED; }
     FineArgs A;
     A.points = points; A.ellipse = ellipse; A.cutoff = cutoff; A.radii = radii;
     A.first_idx = first_idx; A.num_pts = num_pts;
     A.offsets = nullptr; A.cursor = nullptr; A.overflow = nullptr; A.list = nullptr;
     A.idx = idx; A.zbuf = zbuf; A.qv = qvalue; A.occ = occ; A.visible = visible;
     A.g = g; A.N = N; A.K = K; A.thr = merge_thr;
-
-    if (bin_size != 0 && P > 0) {
-        const size_t need = dss_splat_forward_workspace(N, P, S, K, bin_size);
-        if (!workspace || workspace_bytes < need) {
-            set_error("dss_splat_forward: workspace %zu bytes < required %zu", workspace_bytes, need);
+    if (workspace && P > 0) {
+        if (workspace_bytes < dss_splat_forward_workspace(N, P, S, K, 1)) {
+            set_error("dss_splat_fine: workspace too small");
             return DSS_ERR_WORKSPACE;
         }
-        FwdWorkspace w = carve_fwd(workspace, N, P, S, workspace_bytes);
-        if (hipMemsetAsync(w.tile_count, 0, (size_t)N * tiles * 4, st) != hipSuccess)
-            return check_launch("memset tile_count");
-        const int pb = (int)((P + 255) / 256);
-        hipLaunchKernelGGL(bin_count_kernel, dim3(pb), dim3(256), 0, st, points, radii, first_idx, num_pts,
-                           N, P, g, w.tile_count, w.rects);
-        hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), 0, st, w.tile_count, N * tiles, w.offsets,
-                           w.cursor, w.capacity, w.overflow);
-        hipLaunchKernelGGL(bin_fill_kernel, dim3(pb), dim3(256), 0, st, w.rects, first_idx, num_pts, N, P, g,
-                           w.cursor, w.overflow, w.list);
+        FwdWorkspace w = carve_fwd(const_cast<void *>(workspace), N, P, S, workspace_bytes);
         A.offsets = w.offsets; A.cursor = w.cursor; A.overflow = w.overflow; A.list = w.list;
     }
-    if (!dispatch_fine(A, (int)blocks_ll, st)) {
-        set_error("dss_splat_forward: no kernel for K=%d", K);
+    if (!dispatch_fine(A, (int)blocks_ll, as_stream(stream))) {
+        set_error("dss_splat_fine: no kernel for K=%d", K);
         return DSS_ERR_UNSUPPORTED;
     }
-    return check_launch("dss_splat_forward");
+    return check_launch("dss_splat_fine");
+}
+
+extern "C" int dss_splat_forward(const float *points, const float *ellipse, const float *cutoff,
+                                 const float *radii, const int64_t *first_idx, const int64_t *num_pts,
+                                 int N, int64_t P, float merge_thr, int S, int K, int bin_size,
+                                 int row0, int row1, int32_t *idx, float *zbuf, float *qvalue, float *occ,
+                                 uint8_t *visible, void *workspace, size_t workspace_bytes, void *stream)
+{
+    int rc = validate_fwd("dss_splat_forward", N, P, S, K, row0, row1);
+    if (rc) return rc;
+    if (visible && P > 0) {
+        if (hipMemsetAsync(visible, 0, (size_t)P, as_stream(stream)) != hipSuccess) return check_launch("memset visible");
+    }
+    const bool binned = (bin_size != 0 && P > 0);
+    if (binned) {
+        rc = dss_splat_bin(points, radii, first_idx, num_pts, N, P, S, row0, row1, workspace, workspace_bytes, stream);
+        if (rc) return rc;
+    }
+    return dss_splat_fine(points, ellipse, cutoff, radii, first_idx, num_pts, N, P, merge_thr, S, K, row0, row1, idx,
+                          zbuf, qvalue, occ, visible, binned ? workspace : nullptr, workspace_bytes, stream);
 }

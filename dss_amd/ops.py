@@ -229,3 +229,73 @@ def blend_backward(grad_out, idx, qvalue, scaler, num_points: int):
                                     N, H, W, K, C, num_points, _lib.ptr(gf), _lib.ptr(go), _lib.stream_ptr(dev))
     _lib.check(rc, "dss_blend_backward")
     return gf, go
+
+
+def point_setup(world, normals, h, M, V, znear, zfar, cloud_to_packed_first_idx, num_points_per_cloud,
+                image_size: int, cutoff_threshold: float, antialiasing_sigma: float = 1.0,
+                backface_culling: bool = False, shared_cloud: bool = False):
+    """Fused culling + projection + EWA per-point setup (rasterizer.py:183-254, 443-565, 614).
+
+    ``h`` is either per point ``(Pw,)`` or per cloud ``(N,)``.  Returns a dict with
+    ``pts_screen (P,3), ellipse_params (P,3), radii (P,2), scaler (P,), cutoff_threshold (P,),
+    valid bool (P,)``.
+    """
+    lib = _lib.load()
+    world = _lib.require_gpu(world, "world", _f32)
+    dev = world.device
+    normals = _lib.require_gpu(normals, "normals", _f32)
+    h = _lib.require_gpu(h, "h", _f32)
+    M = _lib.require_gpu(M, "M", _f32)
+    V = _lib.require_gpu(V, "V", _f32)
+    znear = _lib.require_gpu(znear, "znear", _f32)
+    zfar = _lib.require_gpu(zfar, "zfar", _f32)
+    first = _lib.require_gpu(cloud_to_packed_first_idx, "cloud_to_packed_first_idx", _i64)
+    num = _lib.require_gpu(num_points_per_cloud, "num_points_per_cloud", _i64)
+    N, Pw = first.shape[0], world.shape[0]
+    if tuple(M.shape) != (N, 4, 4) or tuple(V.shape) != (N, 4, 4) or znear.numel() != N or zfar.numel() != N:
+        raise RuntimeError("camera tensors must be M,V (N,4,4) and znear,zfar (N,) with N=%d" % N)
+    if normals.shape != world.shape:
+        raise RuntimeError("normals must match world points")
+    P = N * Pw if shared_cloud else Pw
+    per_point = h.numel() == Pw and not (h.numel() == N and Pw == N)
+    if not per_point and h.numel() != N:
+        raise RuntimeError("h must have %d (per point) or %d (per cloud) entries" % (Pw, N))
+    with torch.cuda.device(dev):
+        out = dict(pts_screen=torch.empty((P, 3), dtype=_f32, device=dev),
+                   ellipse_params=torch.empty((P, 3), dtype=_f32, device=dev),
+                   radii=torch.empty((P, 2), dtype=_f32, device=dev),
+                   scaler=torch.empty((P,), dtype=_f32, device=dev),
+                   cutoff_threshold=torch.empty((P,), dtype=_f32, device=dev))
+        valid = torch.empty((P,), dtype=_u8, device=dev)
+        rc = lib.dss_point_setup(_lib.ptr(world), _lib.ptr(normals), _lib.ptr(h) if per_point else None,
+                                 None if per_point else _lib.ptr(h), _lib.ptr(M), _lib.ptr(V), _lib.ptr(znear),
+                                 _lib.ptr(zfar), _lib.ptr(first), _lib.ptr(num), N, P, int(shared_cloud),
+                                 int(backface_culling), int(image_size), float(cutoff_threshold),
+                                 float(antialiasing_sigma), _lib.ptr(out["pts_screen"]),
+                                 _lib.ptr(out["ellipse_params"]), _lib.ptr(out["radii"]), _lib.ptr(out["scaler"]),
+                                 _lib.ptr(out["cutoff_threshold"]), _lib.ptr(valid), _lib.stream_ptr(dev))
+    _lib.check(rc, "dss_point_setup")
+    out["valid"] = valid.bool()
+    return out
+
+
+def project_backward(world, M, V, cloud_to_packed_first_idx, num_points_per_cloud, grad_screen, valid,
+                     shared_cloud: bool = False):
+    """grad of (NDC x, NDC y, view z) w.r.t. the world points -> (Pw,3)."""
+    lib = _lib.load()
+    world = _lib.require_gpu(world, "world", _f32)
+    dev = world.device
+    M = _lib.require_gpu(M, "M", _f32)
+    V = _lib.require_gpu(V, "V", _f32)
+    first = _lib.require_gpu(cloud_to_packed_first_idx, "cloud_to_packed_first_idx", _i64)
+    num = _lib.require_gpu(num_points_per_cloud, "num_points_per_cloud", _i64)
+    grad_screen = _lib.require_gpu(grad_screen, "grad_screen", _f32)
+    vis = _lib.require_gpu(valid.to(_u8) if valid.dtype == torch.bool else valid, "valid", _u8)
+    N, Pw = first.shape[0], world.shape[0]
+    with torch.cuda.device(dev):
+        gw = torch.empty((Pw, 3), dtype=_f32, device=dev)
+        rc = lib.dss_project_backward(_lib.ptr(world), _lib.ptr(M), _lib.ptr(V), _lib.ptr(first), _lib.ptr(num), N,
+                                      Pw, int(shared_cloud), _lib.ptr(grad_screen), _lib.ptr(vis), _lib.ptr(gw),
+                                      _lib.stream_ptr(dev))
+    _lib.check(rc, "dss_project_backward")
+    return gw

@@ -80,6 +80,22 @@ DSS_API int dss_splat_forward(const float *points, const float *ellipse, const f
                       int32_t *idx, float *zbuf, float *qvalue, float *occ, uint8_t *visible,
                       void *workspace, size_t workspace_bytes, void *stream);
 
+/* The two phases of dss_splat_forward, callable separately (the binned lists in `workspace` stay
+ * valid until the next dss_splat_bin on it):
+ *   dss_splat_bin   tile binning: count -> exclusive scan -> fill (replaces the coarse kernel
+ *                   rasterize_points.cu:293-432 and its dense (N,B,B,M) bin table)
+ *   dss_splat_fine  exactly ONE kernel launch: per-tile K-nearest + stores (replaces the fine kernel
+ *                   rasterize_points.cu:506-597); workspace==NULL scans whole clouds (naive mode,
+ *                   :131-212).  `visible`, if given, must have been zeroed by the caller. */
+DSS_API int dss_splat_bin(const float *points, const float *radii, const int64_t *first_idx,
+                          const int64_t *num_pts, int N, int64_t P, int S, int row0, int row1,
+                          void *workspace, size_t workspace_bytes, void *stream);
+DSS_API int dss_splat_fine(const float *points, const float *ellipse, const float *cutoff,
+                           const float *radii, const int64_t *first_idx, const int64_t *num_pts,
+                           int N, int64_t P, float merge_thr, int S, int K, int row0, int row1,
+                           int32_t *idx, float *zbuf, float *qvalue, float *occ, uint8_t *visible,
+                           const void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Backward of the rasterizer = EllipticalRasterizer.backward (rasterizer.py:787-977) with
  * backward_occ_fast=True (:816), in four pieces so that a multi-GPU caller can reduce between
@@ -146,6 +162,38 @@ DSS_API int dss_blend_forward(const int32_t *idx, const float *qvalue, const flo
 DSS_API int dss_blend_backward(const float *grad_out, const int32_t *idx, const float *qvalue,
                        const float *scaler, int N, int rows, int S, int K, int C, int64_t P,
                        float *grad_feat /* (P,C) */, float *grad_occ /* (N,rows,S) */, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused per-point setup = everything SurfaceSplatting.forward does before _C.splat_points:
+ *   filter_renderable (rasterizer.py:219-254: view-z in [znear,zfar], optional back-face cull),
+ *   pytorch3d PointsRasterizer.transform (rasterizer.py:614: NDC x,y + view-space z),
+ *   _compute_WJk (:443-496), Vrk = h (I - n n^T) (:293-402), _compute_variance_and_detMk (:404-441),
+ *   _get_per_point_info / _get_ellipse_axis_aligned_radius (:525-565, :498-523).
+ *   world, normals (Pw,3); h_point (Pw,) or h_cloud (N,) (exactly one may be NULL);
+ *   M, V (N,4,4): cameras.get_full_projection_transform().get_matrix() and
+ *   get_world_to_view_transform().get_matrix() (row-vector convention, p_h @ M);
+ *   shared_cloud=1: one cloud of Pw points is rendered by all N cameras (Pointclouds.extend(N),
+ *   rasterizer.py:236-240) and packed point p reads world[p - first_idx[n]]; else Pw == P.
+ * Outputs (P = packed points): pts_screen (P,3), ellipse (P,3), radii (P,2), scaler (P,),
+ * cutoff (P,), valid uint8 (P,).  Culled points are NOT compacted away: they get valid=0 and
+ * z=-1 (ignored by every kernel), so no host round trip is needed for the new sizes.
+ * ------------------------------------------------------------------------------------------- */
+DSS_API int dss_point_setup(const float *world, const float *normals, const float *h_point,
+                            const float *h_cloud, const float *M, const float *V, const float *znear,
+                            const float *zfar, const int64_t *first_idx, const int64_t *num_pts,
+                            int N, int64_t P, int shared_cloud, int backface_culling, int S,
+                            float cutoff_threshold, float antialiasing_sigma,
+                            float *pts_screen, float *ellipse, float *radii, float *scaler,
+                            float *cutoff, uint8_t *valid, void *stream);
+
+/* Backward of the projection (autograd of pytorch3d's transform, rasterizer.py:614):
+ * grad_world[i] = sum over the cameras that see world point i of J^T grad_screen, J = d(ndc_x,
+ * ndc_y, view_z)/d(world).  grad_world (Pw,3) is fully written; deterministic. */
+DSS_API int dss_project_backward(const float *world, const float *M, const float *V,
+                                 const int64_t *first_idx, const int64_t *num_pts, int N, int64_t Pw,
+                                 int shared_cloud, const float *grad_screen /* (P,3) */,
+                                 const uint8_t *valid /* (P,) */, float *grad_world /* (Pw,3) */,
+                                 void *stream);
 
 #ifdef __cplusplus
 }

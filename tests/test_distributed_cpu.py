@@ -1,0 +1,83 @@
+"""CPU, world_size 2 over gloo: the row-partition exchange steps of dss_amd.distributed.
+The per-band compute is supplied by the oracle (the HIP kernels need a GPU); what is tested here is
+that bands reassemble to the single-process image and that the backward exchanges (visibility
+union, gradient partial sums) reproduce the single-process gradients."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, S, tmp):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle
+    import scenes
+    from dss_amd.distributed import GatherRows, RowPartition, reduce_grads_, reduce_visibility_
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sc = scenes.random_splats(700, S, 2, seed=3)
+        K, P = 4, sc["points"].shape[0]
+        idx, zbuf, qv, occ = oracle.splat_forward(sc["points"], sc["ellipse"], sc["cutoff"], sc["radii"],
+                                                  sc["first_idx"], sc["num_pts"], S, K, 0.5)
+        full = oracle.blend_forward(idx, qv, occ, sc["scaler"], sc["colors"])
+        part = RowPartition(S, world, rank)
+        r0, r1 = part.rows
+        # forward: each rank owns a band; all-gather must rebuild the single-process image exactly
+        band = torch.from_numpy(full[:, r0:r1].copy()).requires_grad_(True)
+        img = GatherRows.apply(band, part, None)
+        assert torch.equal(img.detach(), torch.from_numpy(full)), "gathered image differs"
+        g_full = torch.from_numpy(np.random.default_rng(5).standard_normal(full.shape).astype(np.float32))
+        (img * g_full).sum().backward()
+        assert torch.equal(band.grad, g_full[:, r0:r1])
+        # backward: visibility union + gradient partial sums
+        vis_band = torch.from_numpy(oracle.visibility(
+            np.concatenate([np.full_like(idx[:, :r0], -1), idx[:, r0:r1], np.full_like(idx[:, r1:], -1)], 1), P)
+            .astype(np.uint8))
+        vis = reduce_visibility_(vis_band.clone(), part)
+        assert np.array_equal(vis.numpy().astype(bool), oracle.visibility(idx, P))
+        rs = oracle.backward_radius(sc["radii"], vis.numpy(), sc["first_idx"], sc["num_pts"], 3.0)
+        gocc = g_full[..., 3].numpy()
+        masked = np.zeros_like(gocc)
+        masked[:, r0:r1] = gocc[:, r0:r1]
+        g_part = torch.from_numpy(oracle.occ_backward_fast(sc["points"], sc["radii"], vis.numpy(), rs, masked,
+                                                           sc["first_idx"], sc["num_pts"]))
+        g_masked = np.zeros_like(g_full.numpy())
+        g_masked[:, r0:r1] = g_full[:, r0:r1].numpy()
+        gf_part, _ = oracle.blend_backward(g_masked, idx, qv, sc["scaler"], P)
+        gf_part = torch.from_numpy(gf_part)
+        reduce_grads_(g_part, gf_part, part=part)
+        g_all = oracle.occ_backward_fast(sc["points"], sc["radii"], vis.numpy(), rs, gocc, sc["first_idx"], sc["num_pts"])
+        gf_all, _ = oracle.blend_backward(g_full.numpy(), idx, qv, sc["scaler"], P)
+        assert np.allclose(g_part.numpy(), g_all, rtol=1e-4, atol=1e-4)
+        assert np.allclose(gf_part.numpy(), gf_all, rtol=1e-4, atol=1e-5)
+        open(os.path.join(tmp, "ok%d" % rank), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("S", [32, 37])
+def test_row_partition_gloo_world2(tmp_path, S):
+    port = 29600 + (os.getpid() % 200) + S
+    mp.spawn(_worker, args=(2, port, S, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
+
+
+def test_row_partition_bounds():
+    sys.path.insert(0, ROOT)
+    from dss_amd.distributed import RowPartition
+    for S, W in ((512, 8), (37, 2), (5, 8), (1024, 3)):
+        rows = [RowPartition(S, W, r).rows for r in range(W)]
+        assert rows[0][0] == 0 and rows[-1][1] == S or rows[-1][0] == rows[-1][1] == S
+        cover = sum(b - a for a, b in rows)
+        assert cover == S
+        for (a, b), (c, d) in zip(rows[:-1], rows[1:]):
+            assert b == c
