@@ -80,12 +80,16 @@ __global__ __launch_bounds__(256) void point_setup_kernel(const SetupArgs A)
                 for (int j = 0; j < 2; ++j)
                     WJ[i][j] = m[i * 4 + j] * (1.0f / dw) + m[i * 4 + 3] * (-1.0f / dw2 * clip[j]);
             const float hh = A.h_point ? A.h_point[wi] : A.h_cloud[n];
-            const float nn[3] = {n0, n1, n2};
+            // Sk^T Sk = I - n^ n^^T with the NORMALISED normal (rasterizer.py:337-341); zero normal -> 0
+            const float nlen = sqrtf(n0 * n0 + n1 * n1 + n2 * n2);
+            const float nden = nlen > 1e-12f ? nlen : 1e-12f;
+            const float nn[3] = {n0 / nden, n1 / nden, n2 / nden};
+            const float hv = nlen > 1e-12f ? hh : 0.0f;
             float Vr[3][3];
 #pragma unroll
             for (int i = 0; i < 3; ++i)
 #pragma unroll
-                for (int j = 0; j < 3; ++j) Vr[i][j] = hh * ((i == j ? 1.0f : 0.0f) - nn[i] * nn[j]);
+                for (int j = 0; j < 3; ++j) Vr[i][j] = hv * ((i == j ? 1.0f : 0.0f) - nn[i] * nn[j]);
             float T[3][2];
 #pragma unroll
             for (int i = 0; i < 3; ++i)

@@ -487,8 +487,8 @@ DSS_ORACLE_API void oracle_blend_backward(
  *       w = p_h . M[:,3] ; xy = p_h @ M[:, :2]
  *       Jk[0][0] = Jk[1][1] = 1/eps_denom(w) ; Jk[3][j] = -xy[j]/eps_denom(w*w)
  *       WJk = M[:3,:] @ Jk                                   (3x2)
- *   source variance (rasterizer.py:293-342): Vrk = h * Sk^T Sk = h * (I - n n^T)
- *       (Sk is a random orthonormal tangent basis; the product is basis independent for unit n)
+ *   source variance (rasterizer.py:293-342): Vrk = h * Sk^T Sk = h * (I - n^ n^^T), n^ = n/|n|
+ *       (Sk is a random orthonormal tangent basis; the product is basis independent)
  *   Vk = WJk^T Vrk WJk ; GV = Vk + sigma*I*(2/S)^2            (rasterizer.py:404-441)
  *   |detMk| = |det(Sk @ WJk)| = sqrt(det(Vk))/h  -> we evaluate sqrt(max(det(Vk),0))/h
  *   GVinv = inverse(GV); (a,b,c) = (GVinv00, GVinv01+GVinv10, GVinv11)   (rasterizer.py:541-550)
@@ -532,13 +532,20 @@ DSS_ORACLE_API void oracle_point_setup(
         for (int i = 0; i < 3; ++i)
             for (int j = 0; j < 2; ++j)
                 WJ[i][j] = m[i * 4 + j] * (1.0f / dw) + m[i * 4 + 3] * (-1.0f / dw2 * clip[j]);
-        const float *nn = normals + 3 * p;
+        /* Sk is built from NORMALISED cross products (rasterizer.py:337-341, F.normalize eps 1e-12), so
+         * Sk^T Sk = I - n^ n^^T for the unit normal n^ whatever the length of the stored normal
+         * (bunny-8000.ply stores |n| = 56.25); a zero normal gives Sk = 0. */
+        const float *nraw = normals + 3 * p;
+        const float nlen = sqrtf(nraw[0] * nraw[0] + nraw[1] * nraw[1] + nraw[2] * nraw[2]);
+        const float nden = nlen > 1e-12f ? nlen : 1e-12f;
+        const float nn[3] = { nraw[0] / nden, nraw[1] / nden, nraw[2] / nden };
         const float hh = h[p];
-        /* Vrk = h (I - n n^T) */
+        const float hv = nlen > 1e-12f ? hh : 0.0f;
+        /* Vrk = h (I - n^ n^^T) */
         float Vr[3][3];
         for (int i = 0; i < 3; ++i)
             for (int j = 0; j < 3; ++j)
-                Vr[i][j] = hh * ((i == j ? 1.0f : 0.0f) - nn[i] * nn[j]);
+                Vr[i][j] = hv * ((i == j ? 1.0f : 0.0f) - nn[i] * nn[j]);
         float T[3][2];
         for (int i = 0; i < 3; ++i)
             for (int j = 0; j < 2; ++j)
