@@ -74,10 +74,12 @@ class Workload:
         idx, zbuf, qv, occ, vis = ops.splat_points(info["pts_screen"], info["ellipse_params"],
                                                    info["cutoff_threshold"], info["radii"], self.first, self.num,
                                                    THR, S, K, None, None, rows=p.rows, return_visible=True)
-        band = ops.blend_forward(idx, qv, occ, info["scaler"], self.colors)
+        band, wsum = ops.blend_forward(idx, qv, occ, info["scaler"], self.colors, return_wsum=True)
         image = gather_rows(band, p)
         g_band = p.slice(self.grad_out).contiguous() if p.world_size > 1 else self.grad_out
-        g_feat, g_occ = ops.blend_backward(g_band, idx, qv, info["scaler"], self.P)
+        geom = (info["pts_screen"], info["radii"], vis, self.first, self.num)
+        g_feat, g_occ = ops.blend_backward(g_band, idx, qv, info["scaler"], self.P, geometry=geom, wsum=wsum,
+                                           image_size=S, rows=p.rows)
         if p.world_size == 1:
             g_pts = ops.splat_backward(info["pts_screen"], info["radii"], vis, idx, g_occ, None, self.first,
                                        self.num, RADII_S, CLIP)

@@ -15,7 +15,7 @@ template <int C>
 __global__ __launch_bounds__(256) void blend_forward_kernel(
     const int32_t *__restrict__ idx, const float *__restrict__ qv, const float *__restrict__ occ,
     const float *__restrict__ scaler, const float *__restrict__ feat, size_t npix, int K, int Crt,
-    float *__restrict__ out)
+    float *__restrict__ out, float *__restrict__ wsum)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= npix) return;
@@ -27,6 +27,7 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(
         cum += expf(-0.5f * qv[i * K + k]) * scaler[p];
     }
     if (cum < 1e-4f) cum = 1e-4f;
+    if (wsum) wsum[i] = cum;
     float acc[(C > 0) ? C : BLEND_MAX_C];
 #pragma unroll
     for (int ch = 0; ch < ((C > 0) ? C : BLEND_MAX_C); ++ch) acc[ch] = 0.0f;
@@ -49,45 +50,116 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(
     }
 }
 
+// Backward to the per-point features, point-centric: one wavefront per visible point gathers over
+// the pixels of the point's own bounding box (a fragment (pixel,k) with idx == p can only exist where
+// the hit test passed, i.e. inside |dx|<=rx, |dy|<=ry), finds its slot in the pixel's K-list and
+// accumulates grad_out * w / cum.  No atomics (pytorch3d's norm_weighted_sum backward scatters with
+// atomicAdd per fragment and channel), deterministic, and invisible points cost one byte load.
 template <int C>
 __global__ __launch_bounds__(256) void blend_backward_kernel(
     const float *__restrict__ grad_out, const int32_t *__restrict__ idx, const float *__restrict__ qv,
-    const float *__restrict__ scaler, size_t npix, int K, int Crt, float *__restrict__ grad_feat,
-    float *__restrict__ grad_occ)
+    const float *__restrict__ wsum, const float *__restrict__ scaler, const float *__restrict__ points,
+    const float *__restrict__ radii, const uint8_t *__restrict__ visible,
+    const int64_t *__restrict__ first_idx, const int64_t *__restrict__ num_pts, int N, int64_t P, int S, int K,
+    int Crt, int row0, int rows, float *__restrict__ grad_feat)
 {
+    constexpr int CM = (C > 0) ? C : BLEND_MAX_C;
+    const int Cn = (C > 0) ? C : Crt;
+    const int lane = threadIdx.x & 63;
+    const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= P) return;
+    float acc[CM];
+#pragma unroll
+    for (int ch = 0; ch < CM; ++ch) acc[ch] = 0.0f;
+    bool act = visible[p] != 0;
+    int n = -1;
+    if (act) {
+        n = find_cloud(p, first_idx, num_pts, N);
+        act = n >= 0;
+    }
+    if (act) {
+        const float px = points[3 * p], py = points[3 * p + 1];
+        const float rx = radii[2 * p], ry = radii[2 * p + 1];
+        const float sc = scaler[p];
+        int xlo, xhi, ylo, yhi;
+        act = ndc_index_range(px, rx, S, xlo, xhi) && ndc_index_range(py, ry, S, ylo, yhi);
+        if (act) {
+            ylo = max(ylo, S - row0 - rows);
+            yhi = min(yhi, S - 1 - row0);
+            const int w = xhi - xlo + 1;
+            const int lw_log = (w <= 8) ? 3 : (w <= 16) ? 4 : (w <= 32) ? 5 : 6;
+            const int LW = 1 << lw_log, LH = 64 >> lw_log;
+            const int lxx = lane & (LW - 1), lyy = lane >> lw_log;
+            for (int yi = ylo + lyy; yi <= yhi; yi += LH) {
+                const size_t rowbase = ((size_t)n * rows + (S - 1 - yi - row0)) * S;
+                for (int xi = xlo + lxx; xi <= xhi; xi += LW) {
+                    const size_t pix = rowbase + (S - 1 - xi);
+                    const int32_t *pi = idx + pix * K;
+                    int kk = -1;
+                    for (int k = 0; k < K; ++k) {
+                        const int32_t v = pi[k];
+                        if (v == (int32_t)p) kk = k;
+                    }
+                    if (kk < 0) continue;
+                    float cum;
+                    if (wsum) {
+                        cum = wsum[pix];
+                    } else {
+                        cum = 0.0f;
+                        for (int k = 0; k < K; ++k) {
+                            const int32_t v = pi[k];
+                            if (v >= 0) cum += expf(-0.5f * qv[pix * K + k]) * scaler[v];
+                        }
+                        if (cum < 1e-4f) cum = 1e-4f;
+                    }
+                    const float wgt = expf(-0.5f * qv[pix * K + kk]) * sc;
+                    const float *go = grad_out + pix * (Cn + 1);
+#pragma unroll
+                    for (int ch = 0; ch < CM; ++ch)
+                        if (ch < Cn) acc[ch] += go[ch] * wgt / cum;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int ch = 0; ch < CM; ++ch) {
+        if (ch < Cn) {
+            const float v = wave_sum(acc[ch]);
+            if (lane == 0) grad_feat[(size_t)p * Cn + ch] = v;
+        }
+    }
+}
+
+// Pixel-centric scatter variant (the shape of pytorch3d's norm_weighted_sum backward): used only when
+// the caller has fragments but not the splat geometry.  One atomicAdd per fragment and channel.
+template <int C>
+__global__ __launch_bounds__(256) void blend_backward_scatter_kernel(
+    const float *__restrict__ grad_out, const int32_t *__restrict__ idx, const float *__restrict__ qv,
+    const float *__restrict__ scaler, size_t npix, int K, int Crt, float *__restrict__ grad_feat)
+{
+    constexpr int CM = (C > 0) ? C : BLEND_MAX_C;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= npix) return;
     const int Cn = (C > 0) ? C : Crt;
-    float g[(C > 0) ? C : BLEND_MAX_C];
-    const float *go = grad_out + i * (Cn + 1);
-    if (C == 3) {
-        const float4 v = *reinterpret_cast<const float4 *>(go);
-        g[0] = v.x; g[1] = v.y; g[2] = v.z;
-        grad_occ[i] = v.w;
-    } else {
-#pragma unroll
-        for (int ch = 0; ch < ((C > 0) ? C : BLEND_MAX_C); ++ch) g[ch] = (ch < Cn) ? go[ch] : 0.0f;
-        grad_occ[i] = go[Cn];
-    }
-    if (idx[i * K] < 0) {
-        // fragments are packed front to back: an empty first slot means an empty pixel
-        bool any = false;
-        for (int k = 1; k < K; ++k) any = any || (idx[i * K + k] >= 0);
-        if (!any) return;
-    }
     float cum = 0.0f;
+    bool any = false;
     for (int k = 0; k < K; ++k) {
         const int32_t p = idx[i * K + k];
         if (p < 0) continue;
+        any = true;
         cum += expf(-0.5f * qv[i * K + k]) * scaler[p];
     }
+    if (!any) return;
     if (cum < 1e-4f) cum = 1e-4f;
+    float g[CM];
+#pragma unroll
+    for (int ch = 0; ch < CM; ++ch) g[ch] = (ch < Cn) ? grad_out[i * (Cn + 1) + ch] : 0.0f;
     for (int k = 0; k < K; ++k) {
         const int32_t p = idx[i * K + k];
         if (p < 0) continue;
         const float w = expf(-0.5f * qv[i * K + k]) * scaler[p];
 #pragma unroll
-        for (int ch = 0; ch < ((C > 0) ? C : BLEND_MAX_C); ++ch)
+        for (int ch = 0; ch < CM; ++ch)
             if (ch < Cn) atomicAdd(&grad_feat[(size_t)p * Cn + ch], g[ch] * w / cum);
     }
 }
@@ -97,7 +169,8 @@ __global__ __launch_bounds__(256) void blend_backward_kernel(
 using namespace dss;
 
 extern "C" int dss_blend_forward(const int32_t *idx, const float *qvalue, const float *occ, const float *scaler,
-                                 const float *feat, int N, int rows, int S, int K, int C, float *out, void *stream)
+                                 const float *feat, int N, int rows, int S, int K, int C, float *out, float *wsum,
+                                 void *stream)
 {
     if (N <= 0 || rows <= 0 || S <= 0 || K <= 0 || C < 1 || C > BLEND_MAX_C) {
         set_error("dss_blend_forward: bad sizes N=%d rows=%d S=%d K=%d C=%d", N, rows, S, K, C);
@@ -111,22 +184,49 @@ extern "C" int dss_blend_forward(const int32_t *idx, const float *qvalue, const 
     const dim3 grid((unsigned)((npix + 255) / 256)), block(256);
     hipStream_t st = as_stream(stream);
     if (C == 3)
-        hipLaunchKernelGGL(blend_forward_kernel<3>, grid, block, 0, st, idx, qvalue, occ, scaler, feat, npix, K, C, out);
+        hipLaunchKernelGGL(blend_forward_kernel<3>, grid, block, 0, st, idx, qvalue, occ, scaler, feat, npix, K, C, out, wsum);
     else
-        hipLaunchKernelGGL(blend_forward_kernel<0>, grid, block, 0, st, idx, qvalue, occ, scaler, feat, npix, K, C, out);
+        hipLaunchKernelGGL(blend_forward_kernel<0>, grid, block, 0, st, idx, qvalue, occ, scaler, feat, npix, K, C, out, wsum);
     return check_launch("dss_blend_forward");
 }
 
-extern "C" int dss_blend_backward(const float *grad_out, const int32_t *idx, const float *qvalue,
-                                  const float *scaler, int N, int rows, int S, int K, int C, int64_t P,
-                                  float *grad_feat, float *grad_occ, void *stream)
+extern "C" int dss_blend_backward(const float *grad_out, const int32_t *idx, const float *qvalue, const float *wsum,
+                                  const float *scaler, const float *points, const float *radii,
+                                  const uint8_t *visible, const int64_t *first_idx, const int64_t *num_pts, int N,
+                                  int64_t P, int S, int K, int C, int row0, int row1, float *grad_feat, void *stream)
 {
-    if (N <= 0 || rows <= 0 || S <= 0 || K <= 0 || C < 1 || C > BLEND_MAX_C || P < 0) {
-        set_error("dss_blend_backward: bad sizes N=%d rows=%d S=%d K=%d C=%d", N, rows, S, K, C);
+    if (N <= 0 || S <= 0 || K <= 0 || C < 1 || C > BLEND_MAX_C || P < 0 || row0 < 0 || row1 > S || row0 >= row1) {
+        set_error("dss_blend_backward: bad sizes N=%d S=%d K=%d C=%d rows=[%d,%d)", N, S, K, C, row0, row1);
         return DSS_ERR_INVALID_ARGUMENT;
     }
-    if (!grad_out || !idx || !qvalue || !scaler || !grad_occ || (P > 0 && !grad_feat)) {
+    if (P == 0) return DSS_OK;
+    if (!grad_out || !idx || !qvalue || !scaler || !points || !radii || !visible || !first_idx || !num_pts || !grad_feat) {
         set_error("dss_blend_backward: NULL tensor pointer");
+        return DSS_ERR_INVALID_ARGUMENT;
+    }
+    const long long blocks = (P + 3) / 4;
+    if (blocks > 0x7fffffffll) { set_error("dss_blend_backward: P too large"); return DSS_ERR_UNSUPPORTED; }
+    hipStream_t st = as_stream(stream);
+    const dim3 grid((unsigned)blocks), block(256);
+    if (C == 3)
+        hipLaunchKernelGGL(blend_backward_kernel<3>, grid, block, 0, st, grad_out, idx, qvalue, wsum, scaler, points,
+                           radii, visible, first_idx, num_pts, N, P, S, K, C, row0, row1 - row0, grad_feat);
+    else
+        hipLaunchKernelGGL(blend_backward_kernel<0>, grid, block, 0, st, grad_out, idx, qvalue, wsum, scaler, points,
+                           radii, visible, first_idx, num_pts, N, P, S, K, C, row0, row1 - row0, grad_feat);
+    return check_launch("dss_blend_backward");
+}
+
+extern "C" int dss_blend_backward_scatter(const float *grad_out, const int32_t *idx, const float *qvalue,
+                                          const float *scaler, int N, int rows, int S, int K, int C, int64_t P,
+                                          float *grad_feat, void *stream)
+{
+    if (N <= 0 || rows <= 0 || S <= 0 || K <= 0 || C < 1 || C > BLEND_MAX_C || P < 0) {
+        set_error("dss_blend_backward_scatter: bad sizes N=%d rows=%d S=%d K=%d C=%d", N, rows, S, K, C);
+        return DSS_ERR_INVALID_ARGUMENT;
+    }
+    if (!grad_out || !idx || !qvalue || !scaler || (P > 0 && !grad_feat)) {
+        set_error("dss_blend_backward_scatter: NULL tensor pointer");
         return DSS_ERR_INVALID_ARGUMENT;
     }
     hipStream_t st = as_stream(stream);
@@ -135,10 +235,10 @@ extern "C" int dss_blend_backward(const float *grad_out, const int32_t *idx, con
     const size_t npix = (size_t)N * rows * S;
     const dim3 grid((unsigned)((npix + 255) / 256)), block(256);
     if (C == 3)
-        hipLaunchKernelGGL(blend_backward_kernel<3>, grid, block, 0, st, grad_out, idx, qvalue, scaler, npix, K, C,
-                           grad_feat, grad_occ);
+        hipLaunchKernelGGL(blend_backward_scatter_kernel<3>, grid, block, 0, st, grad_out, idx, qvalue, scaler, npix, K,
+                           C, grad_feat);
     else
-        hipLaunchKernelGGL(blend_backward_kernel<0>, grid, block, 0, st, grad_out, idx, qvalue, scaler, npix, K, C,
-                           grad_feat, grad_occ);
-    return check_launch("dss_blend_backward");
+        hipLaunchKernelGGL(blend_backward_scatter_kernel<0>, grid, block, 0, st, grad_out, idx, qvalue, scaler, npix, K,
+                           C, grad_feat);
+    return check_launch("dss_blend_backward_scatter");
 }

@@ -46,91 +46,128 @@ __device__ __forceinline__ void hist_add(uint32_t *hist, uint32_t bin, bool acti
     if (active) atomicAdd(&hist[bin], 1u);
 }
 
-#define MED_THREADS 1024
+#define MED_THREADS 256
 #define MED_BINS 2048
+#define MED_PTS_PER_WG 2048
 
-// Find the bin that holds rank k in hist[0..MED_BINS); returns bin and the rank inside it.
-__device__ void select_bin(uint32_t *hist, uint32_t k, uint32_t *s_scan, uint32_t *s_res)
+// Rank-k selection in a 2048-bin histogram (global or LDS) by one 256-thread workgroup:
+// returns the bin that holds rank k and the rank inside that bin (uniform across the workgroup).
+// If total_out != nullptr the sum of all bins is stored there.
+__device__ __forceinline__ void select_bin(const uint32_t *hist, uint32_t k, bool k_is_lower_median,
+                                           uint32_t *s_scan /*[4+3]*/, uint32_t &bin_out, uint32_t &k_out,
+                                           uint32_t &total_out)
 {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const uint32_t h0 = hist[2 * tid], h1 = hist[2 * tid + 1];
-    uint32_t x = h0 + h1;
-    const uint32_t v = x;
+    uint32_t h[8];
+    uint32_t v = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        h[i] = hist[8 * tid + i];
+        v += h[i];
+    }
+    uint32_t x = v;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
         const uint32_t y = __shfl_up(x, o, 64);
         if (lane >= o) x += y;
     }
+    __syncthreads();  // s_scan reuse
     if (lane == 63) s_scan[wid] = x;
     __syncthreads();
-    uint32_t woff = 0;
-    for (int w = 0; w < wid; ++w) woff += s_scan[w];
-    const uint32_t excl = woff + x - v;
-    if (k >= excl && k < excl + v) {
-        if (k < excl + h0) { s_res[0] = 2 * tid; s_res[1] = k - excl; }
-        else { s_res[0] = 2 * tid + 1; s_res[1] = k - excl - h0; }
+    uint32_t woff = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < MED_THREADS / 64; ++w) {
+        if (w < wid) woff += s_scan[w];
+        total += s_scan[w];
+    }
+    if (k_is_lower_median) k = (total > 0) ? (total - 1) / 2 : 0;  // torch.median = lower median
+    uint32_t excl = woff + x - v;
+    if (total > 0 && k >= excl && k < excl + v) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (k >= excl && k < excl + h[i]) {
+                s_scan[4] = 8 * tid + i;
+                s_scan[5] = k - excl;
+            }
+            excl += h[i];
+        }
     }
     __syncthreads();
+    bin_out = s_scan[4];
+    k_out = s_scan[5];
+    total_out = total;
 }
 
-__global__ __launch_bounds__(MED_THREADS) void median_radius_kernel(
-    const float *__restrict__ radii, const uint8_t *__restrict__ visible,
-    const int64_t *__restrict__ first_idx, const int64_t *__restrict__ num_pts, float radii_s,
-    float *__restrict__ rs)
-{
-    __shared__ uint32_t hist[MED_BINS];
-    __shared__ uint32_t s_scan[MED_THREADS / 64];
-    __shared__ uint32_t s_res[2];
-    __shared__ uint32_t s_total;
-    const int n = blockIdx.x, tid = threadIdx.x;
-    const int64_t p0 = first_idx[n], cnt_pts = num_pts[n];
+// digits of the order-preserving key: bits [31:21], [20:10], [9:0]
+__device__ __forceinline__ int med_shift(int pass) { return pass == 0 ? 21 : (pass == 1 ? 10 : 0); }
+__device__ __forceinline__ uint32_t med_mask(int pass) { return pass == 2 ? 0x3ffu : 0x7ffu; }
 
-    uint32_t prefix = 0, prefix_mask = 0, k = 0;
-    // digits: bits [31:21], [20:10], [9:0]
-    const int shifts[3] = {21, 10, 0};
-    const uint32_t widths[3] = {11, 11, 10};
-    for (int pass = 0; pass < 3; ++pass) {
-        for (int i = tid; i < MED_BINS; i += MED_THREADS) hist[i] = 0;
-        if (tid == 0) s_total = 0;
+// One radix-select pass over all packed points, many workgroups.  hist: (3, N, MED_BINS) zeroed by
+// the host wrapper.  Pass p first re-derives the prefix chosen by passes < p from their finished
+// histograms (cheap: 2048 bins per pass), then histograms digit p of the matching visible radii.
+template <int PASS>
+__global__ __launch_bounds__(MED_THREADS) void median_hist_kernel(
+    const float *__restrict__ radii, const uint8_t *__restrict__ visible,
+    const int64_t *__restrict__ first_idx, const int64_t *__restrict__ num_pts, int N, int64_t P,
+    uint32_t *__restrict__ hist)
+{
+    __shared__ uint32_t lh[MED_BINS];
+    __shared__ uint32_t s_scan[8];
+    const int tid = threadIdx.x;
+    const int64_t c0 = (int64_t)blockIdx.x * MED_PTS_PER_WG;
+    const int64_t c1 = min(c0 + MED_PTS_PER_WG, P);
+    for (int n = 0; n < N; ++n) {
+        const int64_t lo = max(c0, first_idx[n]), hi = min(c1, first_idx[n] + num_pts[n]);
+        if (lo >= hi) continue;  // uniform
+        uint32_t prefix = 0, pmask = 0;
+        if (PASS > 0) {
+            uint32_t k = 0, bin, tot;
+#pragma unroll
+            for (int q = 0; q < PASS; ++q) {
+                select_bin(hist + ((size_t)q * N + n) * MED_BINS, k, q == 0, s_scan, bin, k, tot);
+                prefix |= bin << med_shift(q);
+                pmask |= med_mask(q) << med_shift(q);
+            }
+        }
         __syncthreads();
-        const int sh = shifts[pass];
-        const uint32_t dmask = (1u << widths[pass]) - 1u;
-        for (int64_t base = 0; base < cnt_pts; base += MED_THREADS) {
-            const int64_t i = base + tid;
-            bool act = (i < cnt_pts) && (visible[p0 + i] != 0);
+        for (int i = tid; i < MED_BINS; i += MED_THREADS) lh[i] = 0;
+        __syncthreads();
+        const int sh = med_shift(PASS);
+        const uint32_t dm = med_mask(PASS);
+        for (int64_t i = lo + tid; i < lo + ((hi - lo + MED_THREADS - 1) / MED_THREADS) * MED_THREADS; i += MED_THREADS) {
+            const bool act = (i < hi) && (visible[i] != 0);
             uint32_t kx = 0, ky = 0;
             if (act) {
-                const float2 r = reinterpret_cast<const float2 *>(radii)[p0 + i];
+                const float2 r = reinterpret_cast<const float2 *>(radii)[i];
                 kx = float_key(r.x);
                 ky = float_key(r.y);
             }
-            hist_add(hist, (kx >> sh) & dmask, act && ((kx & prefix_mask) == prefix));
-            hist_add(hist, (ky >> sh) & dmask, act && ((ky & prefix_mask) == prefix));
+            hist_add(lh, (kx >> sh) & dm, act && ((kx & pmask) == prefix));
+            hist_add(lh, (ky >> sh) & dm, act && ((ky & pmask) == prefix));
         }
         __syncthreads();
-        if (pass == 0) {
-            // total number of values = sum of the histogram
-            uint32_t s = hist[2 * tid] + hist[2 * tid + 1];
-            uint32_t x = s;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
-            if ((tid & 63) == 0) atomicAdd(&s_total, x);
-            __syncthreads();
-            const uint32_t total = s_total;
-            if (total == 0) {
-                if (tid == 0) rs[n] = 0.0f;
-                return;
-            }
-            k = (total - 1) / 2;  // lower median (torch.median)
+        uint32_t *gh = hist + ((size_t)PASS * N + n) * MED_BINS;
+        for (int i = tid; i < MED_BINS; i += MED_THREADS) {
+            const uint32_t c = lh[i];
+            if (c) atomicAdd(&gh[i], c);
         }
-        select_bin(hist, k, s_scan, s_res);
-        const uint32_t bin = s_res[0];
-        k = s_res[1];
-        prefix |= bin << sh;
-        prefix_mask |= dmask << sh;
         __syncthreads();
     }
-    if (tid == 0) rs[n] = key_float(prefix) * radii_s;
+}
+
+__global__ __launch_bounds__(MED_THREADS) void median_final_kernel(const uint32_t *__restrict__ hist, int N,
+                                                                   float radii_s, float *__restrict__ rs)
+{
+    __shared__ uint32_t s_scan[8];
+    const int n = blockIdx.x;
+    uint32_t key = 0, k = 0, bin, tot, total0 = 0;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        select_bin(hist + ((size_t)q * N + n) * MED_BINS, k, q == 0, s_scan, bin, k, tot);
+        if (q == 0) total0 = tot;
+        key |= bin << med_shift(q);
+    }
+    if (threadIdx.x == 0) rs[n] = total0 ? key_float(key) * radii_s : 0.0f;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -140,7 +177,7 @@ __global__ __launch_bounds__(256) void occ_backward_kernel(
     const float *__restrict__ points, const float *__restrict__ radii,
     const uint8_t *__restrict__ visible, const float *__restrict__ rs,
     const float *__restrict__ grad_occ, const int64_t *__restrict__ first_idx,
-    const int64_t *__restrict__ num_pts, int N, int64_t P, int S, int row0, int rows,
+    const int64_t *__restrict__ num_pts, int N, int64_t P, int S, int row0, int rows, int gstride,
     float *__restrict__ grad_pts)
 {
     const int lane = threadIdx.x & 63;
@@ -171,23 +208,35 @@ __global__ __launch_bounds__(256) void occ_backward_kernel(
             const int lw_log = (w <= 8) ? 3 : (w <= 16) ? 4 : (w <= 32) ? 5 : 6;
             const int LW = 1 << lw_log, LH = 64 >> lw_log;
             const int lxx = lane & (LW - 1), lyy = lane >> lw_log;
-            for (int yi = ylo + lyy; yi <= yhi; yi += LH) {
-                const float yf = pix_to_ndc(yi, S);
-                const float dy = yf - py;
-                const float *grow = grad_occ + ((size_t)n * rows + (S - 1 - yi - row0)) * S;
-                for (int xi = xlo + lxx; xi <= xhi; xi += LW) {
-                    const float g = grow[S - 1 - xi];
-                    if (g == 0.0f) continue;
-                    const float xf = pix_to_ndc(xi, S);
-                    const float dx = xf - px;
-                    const float d2 = dx * dx + dy * dy;
-                    if (d2 > cur_r2) continue;
-                    const bool outside = (fabsf(dx) > rx) || (fabsf(dy) > ry);
-                    if (g > 0.0f && outside) continue;
-                    if (d2 == 0.0f) continue;  // reference yields 0/0 here; see include/dss_hip.h
-                    const float den = fmaxf(d2, 1e-10f);
-                    gx += dx / den * g;
-                    gy += dy / den * g;
+            const float *gbase = grad_occ + (size_t)n * rows * S * gstride;
+            for (int xi = xlo + lxx; xi <= xhi; xi += LW) {
+                // column-invariant terms hoisted out of the row loop
+                const float dx = pix_to_ndc(xi, S) - px;
+                const float dx2 = dx * dx;
+                const bool out_x = fabsf(dx) > rx;
+                const float *gcol = gbase + (size_t)(S - 1 - xi) * gstride;
+                // four rows per trip: the four loads are independent and issue back to back
+                for (int y0 = ylo + lyy; y0 <= yhi; y0 += 4 * LH) {
+                    float g[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int yi = y0 + u * LH;
+                        g[u] = (yi <= yhi) ? gcol[(size_t)(S - 1 - yi - row0) * S * gstride] : 0.0f;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int yi = y0 + u * LH;
+                        const float dy = pix_to_ndc(yi, S) - py;
+                        const float d2 = dx2 + dy * dy;
+                        // rasterize_points_backward.cu:151-168; d2 == 0 contributes 0 (see dss_hip.h)
+                        const bool outside = out_x || (fabsf(dy) > ry);
+                        const bool use = (g[u] != 0.0f) && !(d2 > cur_r2) && !(g[u] > 0.0f && outside) && (d2 != 0.0f);
+                        // dx / max(d2,1e-10) * g with a 1-ulp reciprocal (tolerance-checked, not bit-pinned:
+                        // the reference accumulates with unordered fp32 atomics anyway)
+                        const float s = use ? __builtin_amdgcn_rcpf(fmaxf(d2, 1e-10f)) * g[u] : 0.0f;
+                        gx += dx * s;
+                        gy += dy * s;
+                    }
                 }
             }
         }
@@ -235,30 +284,45 @@ using namespace dss;
 
 extern "C" size_t dss_backward_radius_workspace(int N, int64_t P)
 {
-    (void)N; (void)P;
-    return 256;
+    (void)P;
+    return align_up((size_t)3 * (N > 0 ? N : 1) * MED_BINS * sizeof(uint32_t), 256);
 }
 
 extern "C" int dss_backward_radius(const float *radii, const uint8_t *visible, const int64_t *first_idx,
                                    const int64_t *num_pts, int N, int64_t P, float radii_s, float *rs,
                                    void *workspace, size_t workspace_bytes, void *stream)
 {
-    (void)workspace; (void)workspace_bytes;
     if (N <= 0 || P < 0 || !rs || !first_idx || !num_pts || (P > 0 && (!radii || !visible))) {
         set_error("dss_backward_radius: bad arguments (N=%d P=%lld)", N, (long long)P);
         return DSS_ERR_INVALID_ARGUMENT;
     }
-    hipLaunchKernelGGL(median_radius_kernel, dim3(N), dim3(MED_THREADS), 0, as_stream(stream), radii, visible,
-                       first_idx, num_pts, radii_s, rs);
+    const size_t need = dss_backward_radius_workspace(N, P);
+    if (!workspace || workspace_bytes < need) {
+        set_error("dss_backward_radius: workspace %zu bytes < required %zu", workspace_bytes, need);
+        return DSS_ERR_WORKSPACE;
+    }
+    hipStream_t st = as_stream(stream);
+    uint32_t *hist = reinterpret_cast<uint32_t *>(workspace);
+    if (hipMemsetAsync(hist, 0, need, st) != hipSuccess) return check_launch("memset median hist");
+    const unsigned blocks = (unsigned)((P + MED_PTS_PER_WG - 1) / MED_PTS_PER_WG);
+    if (blocks > 0) {
+        hipLaunchKernelGGL(median_hist_kernel<0>, dim3(blocks), dim3(MED_THREADS), 0, st, radii, visible, first_idx,
+                           num_pts, N, P, hist);
+        hipLaunchKernelGGL(median_hist_kernel<1>, dim3(blocks), dim3(MED_THREADS), 0, st, radii, visible, first_idx,
+                           num_pts, N, P, hist);
+        hipLaunchKernelGGL(median_hist_kernel<2>, dim3(blocks), dim3(MED_THREADS), 0, st, radii, visible, first_idx,
+                           num_pts, N, P, hist);
+    }
+    hipLaunchKernelGGL(median_final_kernel, dim3(N), dim3(MED_THREADS), 0, st, hist, N, radii_s, rs);
     return check_launch("dss_backward_radius");
 }
 
 extern "C" int dss_occ_backward(const float *points, const float *radii, const uint8_t *visible,
                                 const float *rs, const float *grad_occ, const int64_t *first_idx,
                                 const int64_t *num_pts, int N, int64_t P, int S, int row0, int row1,
-                                float *grad_pts, void *stream)
+                                int grad_pixel_stride, float *grad_pts, void *stream)
 {
-    if (N <= 0 || P < 0 || S <= 0 || row0 < 0 || row1 > S || row0 >= row1) {
+    if (N <= 0 || P < 0 || S <= 0 || row0 < 0 || row1 > S || row0 >= row1 || grad_pixel_stride < 1) {
         set_error("dss_occ_backward: bad sizes N=%d P=%lld S=%d rows=[%d,%d)", N, (long long)P, S, row0, row1);
         return DSS_ERR_INVALID_ARGUMENT;
     }
@@ -270,7 +334,7 @@ extern "C" int dss_occ_backward(const float *points, const float *radii, const u
     const long long blocks = (P + 3) / 4;
     if (blocks > 0x7fffffffll) { set_error("dss_occ_backward: P too large"); return DSS_ERR_UNSUPPORTED; }
     hipLaunchKernelGGL(occ_backward_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), points, radii,
-                       visible, rs, grad_occ, first_idx, num_pts, N, P, S, row0, row1 - row0, grad_pts);
+                       visible, rs, grad_occ, first_idx, num_pts, N, P, S, row0, row1 - row0, grad_pixel_stride, grad_pts);
     return check_launch("dss_occ_backward");
 }
 
@@ -298,28 +362,28 @@ extern "C" int dss_clip_grad(float *grad_pts, int64_t P, float clip, void *strea
 
 extern "C" size_t dss_splat_backward_workspace(int N, int64_t P)
 {
-    (void)P;
     return align_up((size_t)(N > 0 ? N : 1) * 4, 256) + dss_backward_radius_workspace(N, P);
 }
 
 extern "C" int dss_splat_backward(const float *points, const float *radii, const uint8_t *visible,
                                   const int32_t *idx, const float *grad_occ, const float *grad_zbuf,
                                   const int64_t *first_idx, const int64_t *num_pts, int N, int64_t P, int S, int K,
-                                  float radii_s, float clip, float *grad_pts, float *rs_out, void *workspace,
+                                  int grad_pixel_stride, float radii_s, float clip, float *grad_pts, float *rs_out,
+                                  void *workspace,
                                   size_t workspace_bytes, void *stream)
 {
     if (N <= 0) { set_error("dss_splat_backward: N=%d", N); return DSS_ERR_INVALID_ARGUMENT; }
-    float *rs = rs_out;
-    if (!rs) {
-        if (!workspace || workspace_bytes < dss_splat_backward_workspace(N, P)) {
-            set_error("dss_splat_backward: workspace too small");
-            return DSS_ERR_WORKSPACE;
-        }
-        rs = reinterpret_cast<float *>(workspace);
+    if (!workspace || workspace_bytes < dss_splat_backward_workspace(N, P)) {
+        set_error("dss_splat_backward: workspace too small");
+        return DSS_ERR_WORKSPACE;
     }
-    int rc = dss_backward_radius(radii, visible, first_idx, num_pts, N, P, radii_s, rs, nullptr, 0, stream);
+    const size_t rs_bytes = align_up((size_t)N * 4, 256);
+    float *rs = rs_out ? rs_out : reinterpret_cast<float *>(workspace);
+    int rc = dss_backward_radius(radii, visible, first_idx, num_pts, N, P, radii_s, rs,
+                                 reinterpret_cast<char *>(workspace) + rs_bytes, workspace_bytes - rs_bytes, stream);
     if (rc) return rc;
-    rc = dss_occ_backward(points, radii, visible, rs, grad_occ, first_idx, num_pts, N, P, S, 0, S, grad_pts, stream);
+    rc = dss_occ_backward(points, radii, visible, rs, grad_occ, first_idx, num_pts, N, P, S, 0, S, grad_pixel_stride,
+                          grad_pts, stream);
     if (rc) return rc;
     if (grad_zbuf) {
         if (!idx) { set_error("dss_splat_backward: grad_zbuf given without idx"); return DSS_ERR_INVALID_ARGUMENT; }

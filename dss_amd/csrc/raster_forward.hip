@@ -167,18 +167,20 @@ struct FineArgs {
     float thr;
 };
 
-// (z, idx) strict order.  rasterize_points_cpu.cpp:85 (tuple order); see oracle/dss_oracle.c.
-__device__ __forceinline__ bool frag_less(float za, int ia, float zb, int ib)
-{
-    return (za < zb) || (za == zb && ia < ib);
-}
+// K-nearest bookkeeping: one 64-bit key per slot, (z bits << 32) | idx.  Hits have z >= 0
+// (pz < 0 is culled, rasterize_points.cu:79-80), for which the IEEE bit pattern is monotone, so
+// one unsigned 64-bit compare implements the strict total order (z, idx) of
+// rasterize_points_cpu.cpp:85 / oracle frag_less.  Empty slots hold ~0.
+#define KEY_EMPTY 0xffffffffffffffffull
 
 template <int KMAX>
 __global__ __launch_bounds__(256) void fine_kernel(const FineArgs A)
 {
-    __shared__ float s_px[CHUNK], s_py[CHUNK], s_pz[CHUNK], s_rx[CHUNK], s_ry[CHUNK];
-    __shared__ float s_a[CHUNK], s_b[CHUNK], s_c[CHUNK], s_cut[CHUNK];
-    __shared__ int s_id[CHUNK];
+    // candidate chunk, staged as three records per splat so the inner loop needs 2x ds_read_b128
+    // + 1x ds_read_b64 (broadcast) instead of ten ds_read_b32
+    __shared__ float4 s_geo[CHUNK];   // px, py, rx, ry
+    __shared__ float4 s_ell[CHUNK];   // a, b, c, cutoff
+    __shared__ float2 s_zid[CHUNK];   // pz, idx (bits)
     __shared__ int s_out[DSS_TILE_PIX * KMAX];
 
     const TileGrid g = A.g;
@@ -214,13 +216,12 @@ __global__ __launch_bounds__(256) void fine_kernel(const FineArgs A)
         count = A.num_pts[n];
     }
 
-    // K nearest, ascending (z, idx); sentinels at the tail
-    float kz[KMAX], kq[KMAX];
-    int ki[KMAX];
+    // K nearest, ascending key; empty slots at the tail
+    unsigned long long key[KMAX];
+    float kq[KMAX];
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) {
-        kz[k] = __builtin_huge_valf();
-        ki[k] = 0x7fffffff;
+        key[k] = KEY_EMPTY;
         kq[k] = -1.0f;
     }
 
@@ -229,16 +230,11 @@ __global__ __launch_bounds__(256) void fine_kernel(const FineArgs A)
         __syncthreads();  // previous chunk fully consumed
         if (tid < m) {
             const int64_t p = use_list ? (int64_t)A.list[src0 + base + tid] : (src0 + base + tid);
-            s_id[tid] = (int)p;
-            s_px[tid] = A.points[3 * p];
-            s_py[tid] = A.points[3 * p + 1];
-            s_pz[tid] = A.points[3 * p + 2];
-            s_rx[tid] = A.radii[2 * p];
-            s_ry[tid] = A.radii[2 * p + 1];
-            s_a[tid] = A.ellipse[3 * p];
-            s_b[tid] = A.ellipse[3 * p + 1];
-            s_c[tid] = A.ellipse[3 * p + 2];
-            s_cut[tid] = A.cutoff[p];
+            const float px = A.points[3 * p], py = A.points[3 * p + 1], pz = A.points[3 * p + 2];
+            const float2 rr = reinterpret_cast<const float2 *>(A.radii)[p];
+            s_geo[tid] = make_float4(px, py, rr.x, rr.y);
+            s_ell[tid] = make_float4(A.ellipse[3 * p], A.ellipse[3 * p + 1], A.ellipse[3 * p + 2], A.cutoff[p]);
+            s_zid[tid] = make_float2(pz, __int_as_float((int)p));
         }
         __syncthreads();
         for (int sub = 0; sub < m; sub += 64) {
@@ -246,43 +242,53 @@ __global__ __launch_bounds__(256) void fine_kernel(const FineArgs A)
             const int j = sub + lane;
             bool keep = false;
             if (j < m) {
-                const float px = s_px[j], py = s_py[j], rx = s_rx[j], ry = s_ry[j];
-                const bool out = (s_pz[j] < 0) || ((q_xmax - px) < -rx) || ((q_xmin - px) > rx) ||
-                                 ((q_ymax - py) < -ry) || ((q_ymin - py) > ry);
+                const float4 ge = s_geo[j];
+                const bool out = (s_zid[j].x < 0) || ((q_xmax - ge.x) < -ge.z) || ((q_xmin - ge.x) > ge.z) ||
+                                 ((q_ymax - ge.y) < -ge.w) || ((q_ymin - ge.y) > ge.w);
                 keep = !out;
             }
             unsigned long long mask = __ballot(keep);
-            while (mask) {
-                const int b = __builtin_ctzll(mask);
+            if (mask == 0ull) continue;
+            // walk the surviving bits; the next record is fetched while the current one is processed
+            int jj = sub + __builtin_ctzll(mask);
+            float4 ge = s_geo[jj], el = s_ell[jj];
+            float2 zi = s_zid[jj];
+            while (true) {
                 mask &= mask - 1;
-                const int jj = sub + b;  // wave-uniform -> LDS broadcast reads
-                const float px = s_px[jj], py = s_py[jj], pz = s_pz[jj];
-                const float dx = xf - px;
-                const float dy = yf - py;
-                // rasterize_points.cu:92-101, same expression order
-                bool hit = !(fabsf(dx) > s_rx[jj] || fabsf(dy) > s_ry[jj]);
-                const float qval = s_a[jj] * dx * dx + s_b[jj] * dx * dy + s_c[jj] * dy * dy;
-                hit = hit && !(qval > s_cut[jj]);
-                if (__ballot(hit) == 0ull) continue;
-                const int id = s_id[jj];
-                // sorted insertion; non-hitting lanes insert nothing
-                const float ez = hit ? pz : __builtin_huge_valf();
-                const int ei = hit ? id : 0x7fffffff;
-                bool lt[KMAX];  // e < slot[k], evaluated on the old list
-#pragma unroll
-                for (int k = 0; k < KMAX; ++k) lt[k] = frag_less(ez, ei, kz[k], ki[k]);
-#pragma unroll
-                for (int k = KMAX - 1; k >= 0; --k) {
-                    if (k > 0 && lt[k > 0 ? k - 1 : 0]) {  // shift right
-                        kz[k] = kz[k > 0 ? k - 1 : 0];
-                        ki[k] = ki[k > 0 ? k - 1 : 0];
-                        kq[k] = kq[k > 0 ? k - 1 : 0];
-                    } else if (lt[k]) {  // e lands here
-                        kz[k] = ez;
-                        ki[k] = ei;
-                        kq[k] = qval;
-                    }
+                const bool more = mask != 0ull;
+                float4 ge_n = ge, el_n = el;
+                float2 zi_n = zi;
+                if (more) {
+                    jj = sub + __builtin_ctzll(mask);
+                    ge_n = s_geo[jj];
+                    el_n = s_ell[jj];
+                    zi_n = s_zid[jj];
                 }
+                const float dx = xf - ge.x;
+                const float dy = yf - ge.y;
+                // rasterize_points.cu:92-101, same expression order (no FMA contraction)
+                const float qval = el.x * dx * dx + el.y * dx * dy + el.z * dy * dy;
+                const bool hit = !(fabsf(dx) > ge.z || fabsf(dy) > ge.w) && !(qval > el.w);
+                if (__ballot(hit) != 0ull) {
+                    const unsigned long long ekey =
+                        hit ? (((unsigned long long)__float_as_uint(zi.x + 0.0f) << 32) |
+                               (unsigned long long)(unsigned)__float_as_int(zi.y))
+                            : KEY_EMPTY;
+                    bool lt[KMAX];  // e < slot[k], evaluated on the old list (monotone in k)
+#pragma unroll
+                    for (int k = 0; k < KMAX; ++k) lt[k] = ekey < key[k];
+#pragma unroll
+                    for (int k = KMAX - 1; k >= 1; --k) {
+                        key[k] = lt[k - 1] ? key[k - 1] : (lt[k] ? ekey : key[k]);
+                        kq[k] = lt[k - 1] ? kq[k - 1] : (lt[k] ? qval : kq[k]);
+                    }
+                    key[0] = lt[0] ? ekey : key[0];
+                    kq[0] = lt[0] ? qval : kq[0];
+                }
+                if (!more) break;
+                ge = ge_n;
+                el = el_n;
+                zi = zi_n;
             }
         }
     }
@@ -290,18 +296,19 @@ __global__ __launch_bounds__(256) void fine_kernel(const FineArgs A)
     // ---- epilogue: depth merge, occupancy, visibility, LDS-transposed stores ----
     const int K = A.K;
     const bool in_img = (c < S) && (r < g.row0 + g.rows);
-    const float z0 = kz[0];
-    const bool any = ki[0] != 0x7fffffff;
+    float kz[KMAX];
+    int ki[KMAX];
+    const float z0 = __uint_as_float((unsigned)(key[0] >> 32));
+    const bool any = key[0] != KEY_EMPTY;
     bool alive = any;
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) {
+        const float z = __uint_as_float((unsigned)(key[k] >> 32));
         // rasterize_points.cu:586-595: stop at the first k with z[k]-z[0] > thr
-        alive = alive && (ki[k] != 0x7fffffff) && !(kz[k] - z0 > A.thr);
-        if (!alive) {
-            ki[k] = -1;
-            kz[k] = -1.0f;
-            kq[k] = -1.0f;
-        }
+        alive = alive && (key[k] != KEY_EMPTY) && !(z - z0 > A.thr);
+        ki[k] = alive ? (int)(unsigned)(key[k] & 0xffffffffull) : -1;
+        kz[k] = alive ? z : -1.0f;
+        kq[k] = alive ? kq[k] : -1.0f;
     }
     if (in_img) {
         const size_t pix = ((size_t)n * g.rows + (r - g.row0)) * S + c;

@@ -95,23 +95,34 @@ def backward_radius(radii, visible, cloud_to_packed_first_idx, num_points_per_cl
     N, P = first.shape[0], radii.shape[0]
     with torch.cuda.device(dev):
         rs = torch.empty((N,), dtype=_f32, device=dev)
+        ws = _lib.workspace(dev, lib.dss_backward_radius_workspace(N, P))
         rc = lib.dss_backward_radius(_lib.ptr(radii), _lib.ptr(vis), _lib.ptr(first), _lib.ptr(num), N, P,
-                                     float(radii_s), _lib.ptr(rs), None, 0, _lib.stream_ptr(dev))
+                                     float(radii_s), _lib.ptr(rs), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
     _lib.check(rc, "dss_backward_radius")
     return rs
+
+
+def _pixel_strided(t, N, rows, S):
+    """(tensor, pixel stride) for an (N,rows,S) float32 GPU view that is dense up to a constant element
+    stride per pixel (e.g. ``grad_image[..., 3]``); anything else is made contiguous."""
+    if t.is_cuda and t.dtype == _f32 and tuple(t.shape) == (N, rows, S) and t.numel() > 0:
+        c = t.stride(2)
+        if c >= 1 and t.stride(1) == S * c and t.stride(0) == rows * S * c:
+            return t, c
+    return _lib.require_gpu(t, "grad_occ", _f32), 1
 
 
 def occ_backward(points, radii, visible, rs, grad_occ, cloud_to_packed_first_idx, num_points_per_cloud,
                  image_size: Optional[int] = None, rows: Optional[Tuple[int, int]] = None):
     """Occupancy surrogate gradient -> (P,3) with z column 0.  Replaces the FRNN grid build
-    (rasterizer.py:889-950) + ``DSS._C._splat_points_occ_fast_cuda_backward`` (ext.cpp:14)."""
+    (rasterizer.py:889-950) + ``DSS._C._splat_points_occ_fast_cuda_backward`` (ext.cpp:14).
+    ``grad_occ`` may be a strided channel view of an image gradient (read in place)."""
     lib = _lib.load()
     points = _lib.require_gpu(points, "points", _f32)
     dev = points.device
     radii = _lib.require_gpu(radii, "radii", _f32)
     vis = _lib.require_gpu(visible.to(_u8) if visible.dtype == torch.bool else visible, "visible", _u8)
     rs = _lib.require_gpu(rs, "rs", _f32)
-    grad_occ = _lib.require_gpu(grad_occ, "grad_occ", _f32)
     first = _lib.require_gpu(cloud_to_packed_first_idx, "cloud_to_packed_first_idx", _i64)
     num = _lib.require_gpu(num_points_per_cloud, "num_points_per_cloud", _i64)
     N, P = first.shape[0], points.shape[0]
@@ -119,10 +130,11 @@ def occ_backward(points, radii, visible, rs, grad_occ, cloud_to_packed_first_idx
     row0, row1 = (0, S) if rows is None else (int(rows[0]), int(rows[1]))
     if tuple(grad_occ.shape) != (N, row1 - row0, S):
         raise RuntimeError("grad_occ must have shape (%d, %d, %d), got %s" % (N, row1 - row0, S, tuple(grad_occ.shape)))
+    grad_occ, gstride = _pixel_strided(grad_occ, N, row1 - row0, S)
     with torch.cuda.device(dev):
         grad = torch.empty((P, 3), dtype=_f32, device=dev)
         rc = lib.dss_occ_backward(_lib.ptr(points), _lib.ptr(radii), _lib.ptr(vis), _lib.ptr(rs), _lib.ptr(grad_occ),
-                                  _lib.ptr(first), _lib.ptr(num), N, P, S, row0, row1, _lib.ptr(grad),
+                                  _lib.ptr(first), _lib.ptr(num), N, P, S, row0, row1, gstride, _lib.ptr(grad),
                                   _lib.stream_ptr(dev))
     _lib.check(rc, "dss_occ_backward")
     return grad
@@ -174,27 +186,30 @@ def splat_backward(points, radii, visible, idx, grad_occ, grad_zbuf, cloud_to_pa
     radii = _lib.require_gpu(radii, "radii", _f32)
     vis = _lib.require_gpu(visible.to(_u8) if visible.dtype == torch.bool else visible, "visible", _u8)
     idx = _lib.require_gpu(idx, "idx", _i32)
-    grad_occ = _lib.require_gpu(grad_occ, "grad_occ", _f32)
+    if not grad_occ.is_cuda:
+        raise RuntimeError("dss_amd: grad_occ must be a GPU tensor (no CPU fallback)")
     if grad_zbuf is not None:
         grad_zbuf = _lib.require_gpu(grad_zbuf, "grad_zbuf", _f32)
     first = _lib.require_gpu(cloud_to_packed_first_idx, "cloud_to_packed_first_idx", _i64)
     num = _lib.require_gpu(num_points_per_cloud, "num_points_per_cloud", _i64)
     N, S, _, K = idx.shape
     P = points.shape[0]
+    grad_occ, gstride = _pixel_strided(grad_occ, N, S, S)
     with torch.cuda.device(dev):
         grad = torch.empty((P, 3), dtype=_f32, device=dev)
         rs = torch.empty((N,), dtype=_f32, device=dev)
+        ws = _lib.workspace(dev, lib.dss_splat_backward_workspace(N, P))
         rc = lib.dss_splat_backward(_lib.ptr(points), _lib.ptr(radii), _lib.ptr(vis), _lib.ptr(idx),
                                     _lib.ptr(grad_occ), _lib.ptr(grad_zbuf), _lib.ptr(first), _lib.ptr(num),
-                                    N, P, S, K, float(radii_s), float(clip), _lib.ptr(grad), _lib.ptr(rs),
-                                    None, 0, _lib.stream_ptr(dev))
+                                    N, P, S, K, gstride, float(radii_s), float(clip), _lib.ptr(grad), _lib.ptr(rs),
+                                    _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
     _lib.check(rc, "dss_splat_backward")
     return (grad, rs) if return_rs else grad
 
 
-def blend_forward(idx, qvalue, occupancy, scaler, features):
+def blend_forward(idx, qvalue, occupancy, scaler, features, return_wsum: bool = False):
     """Fused weights + NormWeightedCompositor + RGBA assembly (renderer.py:53-78).
-    ``features`` is (P,C); returns (N,H,W,C+1)."""
+    ``features`` is (P,C); returns (N,H,W,C+1) [and the per-pixel weight sum max(sum w, 1e-4)]."""
     lib = _lib.load()
     idx = _lib.require_gpu(idx, "idx", _i32)
     dev = idx.device
@@ -206,14 +221,21 @@ def blend_forward(idx, qvalue, occupancy, scaler, features):
     C = features.shape[1]
     with torch.cuda.device(dev):
         out = torch.empty((N, H, W, C + 1), dtype=_f32, device=dev)
+        wsum = torch.empty((N, H, W), dtype=_f32, device=dev) if return_wsum else None
         rc = lib.dss_blend_forward(_lib.ptr(idx), _lib.ptr(qvalue), _lib.ptr(occupancy), _lib.ptr(scaler),
-                                   _lib.ptr(features), N, H, W, K, C, _lib.ptr(out), _lib.stream_ptr(dev))
+                                   _lib.ptr(features), N, H, W, K, C, _lib.ptr(out), _lib.ptr(wsum),
+                                   _lib.stream_ptr(dev))
     _lib.check(rc, "dss_blend_forward")
-    return out
+    return (out, wsum) if return_wsum else out
 
 
-def blend_backward(grad_out, idx, qvalue, scaler, num_points: int):
-    """-> (grad_features (P,C), grad_occupancy (N,H,W))."""
+def blend_backward(grad_out, idx, qvalue, scaler, num_points: int, geometry=None, wsum=None,
+                   image_size: Optional[int] = None, rows: Optional[Tuple[int, int]] = None):
+    """-> (grad_features (P,C), grad_occupancy (N,H,W) = strided view ``grad_out[..., C]``).
+
+    ``geometry = (pts_screen, radii, visible, first_idx, num_points_per_cloud)`` selects the
+    point-centric gather kernel (no atomics, deterministic); without it the pixel-centric scatter
+    kernel is used."""
     lib = _lib.load()
     grad_out = _lib.require_gpu(grad_out, "grad_out", _f32)
     dev = grad_out.device
@@ -224,11 +246,29 @@ def blend_backward(grad_out, idx, qvalue, scaler, num_points: int):
     C = grad_out.shape[-1] - 1
     with torch.cuda.device(dev):
         gf = torch.empty((num_points, C), dtype=_f32, device=dev)
-        go = torch.empty((N, H, W), dtype=_f32, device=dev)
-        rc = lib.dss_blend_backward(_lib.ptr(grad_out), _lib.ptr(idx), _lib.ptr(qvalue), _lib.ptr(scaler),
-                                    N, H, W, K, C, num_points, _lib.ptr(gf), _lib.ptr(go), _lib.stream_ptr(dev))
-    _lib.check(rc, "dss_blend_backward")
-    return gf, go
+        if geometry is None:
+            rc = lib.dss_blend_backward_scatter(_lib.ptr(grad_out), _lib.ptr(idx), _lib.ptr(qvalue), _lib.ptr(scaler),
+                                                N, H, W, K, C, num_points, _lib.ptr(gf), _lib.stream_ptr(dev))
+            _lib.check(rc, "dss_blend_backward_scatter")
+        else:
+            pts, radii, vis, first, num = geometry
+            pts = _lib.require_gpu(pts, "pts_screen", _f32)
+            radii = _lib.require_gpu(radii, "radii", _f32)
+            vis = _lib.require_gpu(vis.to(_u8) if vis.dtype == torch.bool else vis, "visible", _u8)
+            first = _lib.require_gpu(first, "cloud_to_packed_first_idx", _i64)
+            num = _lib.require_gpu(num, "num_points_per_cloud", _i64)
+            if wsum is not None:
+                wsum = _lib.require_gpu(wsum, "wsum", _f32)
+            S = int(image_size) if image_size is not None else W
+            row0, row1 = (0, S) if rows is None else (int(rows[0]), int(rows[1]))
+            if H != row1 - row0 or W != S:
+                raise RuntimeError("fragment tensors must be (N, %d, %d, K)" % (row1 - row0, S))
+            rc = lib.dss_blend_backward(_lib.ptr(grad_out), _lib.ptr(idx), _lib.ptr(qvalue), _lib.ptr(wsum),
+                                        _lib.ptr(scaler), _lib.ptr(pts), _lib.ptr(radii), _lib.ptr(vis),
+                                        _lib.ptr(first), _lib.ptr(num), first.shape[0], num_points, S, K, C, row0,
+                                        row1, _lib.ptr(gf), _lib.stream_ptr(dev))
+            _lib.check(rc, "dss_blend_backward")
+    return gf, grad_out[..., C]
 
 
 def point_setup(world, normals, h, M, V, znear, zfar, cloud_to_packed_first_idx, num_points_per_cloud,

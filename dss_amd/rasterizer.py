@@ -25,12 +25,15 @@ __all__ = ["PointFragments", "PointsRasterizationSettings", "SurfaceSplatting", 
            "EllipticalRasterizer", "knn_variance_scale"]
 
 
-class PointFragments(NamedTuple):  # rasterizer.py:31-36
+class PointFragments(NamedTuple):  # rasterizer.py:31-36 (+ one optional trailing field)
     idx: torch.Tensor
     zbuf: torch.Tensor
     qvalue: torch.Tensor
     scaler: torch.Tensor
     occupancy: torch.Tensor
+    # (pts_screen, radii, visible, first_idx, num_points): lets the blend backward run as a
+    # deterministic point-centric gather instead of an atomic scatter.  None is always legal.
+    geometry: Optional[tuple] = None
 
 
 class PointsRasterizationSettings:
@@ -72,6 +75,7 @@ class EllipticalRasterizer(autograd.Function):
         idx, zbuf, qvalue_map, occ_map, visible = ops.splat_points(
             pts_screen, ellipse_param, cutoff_threshold, radii, cloud_to_packed_first_idx, num_points_per_cloud,
             depth_merging_threshold, image_size, points_per_pixel, bin_size, max_points_per_bin, return_visible=True)
+        EllipticalRasterizer.last_visible = visible  # side channel for SurfaceSplatting (not an autograd output)
         ctx.radii_backward_scaler = radii_backward_scaler
         ctx.clip_pts_grad = -1.0 if clip_pts_grad is None else float(clip_pts_grad)
         ctx.save_for_backward(pts_screen, radii, idx, visible, cloud_to_packed_first_idx, num_points_per_cloud)
@@ -229,11 +233,12 @@ class SurfaceSplatting(torch.nn.Module):
 
         # the per-fragment scaler gather of rasterizer.py:631-633 is fused into the blend kernel; the
         # fragments carry the per-POINT scaler (P,) instead (renderer consumes either form)
-        fragments = PointFragments(idx=idx, zbuf=zbuf, qvalue=qvalue_map, scaler=scaler, occupancy=occ_map)
+        visible = EllipticalRasterizer.last_visible
+        fragments = PointFragments(idx=idx, zbuf=zbuf, qvalue=qvalue_map, scaler=scaler, occupancy=occ_map,
+                                   geometry=(pts_screen.detach(), radii, visible, first_idx, num_points))
         self._last_valid = valid
         if point_clouds_filter is not None and hasattr(point_clouds_filter, "set_filter"):
-            vis = ops_visibility_from_fragments(idx, world.shape[0] if not shared else N * world.shape[0])
-            point_clouds_filter.set_filter(visibility=vis.view(N, -1) if shared else vis)
+            point_clouds_filter.set_filter(visibility=visible.view(N, -1) if shared else visible)
         if kwargs.get("verbose", False):
             info = {"radii": radii, "ellipse_params": ellipse, "cutoff_threshold": cutoff, "scaler": scaler}
             return fragments, out_clouds, info

@@ -15,17 +15,19 @@ __all__ = ["SurfaceSplattingRenderer", "NormWeightedCompositor"]
 
 class _Blend(autograd.Function):
     @staticmethod
-    def forward(ctx, features, occupancy, idx, qvalue, scaler):
-        out = ops.blend_forward(idx, qvalue, occupancy, scaler, features)
-        ctx.save_for_backward(idx, qvalue, scaler)
+    def forward(ctx, features, occupancy, idx, qvalue, scaler, geometry):
+        out, wsum = ops.blend_forward(idx, qvalue, occupancy, scaler, features, return_wsum=True)
+        ctx.save_for_backward(idx, qvalue, scaler, wsum)
+        ctx.geometry = geometry
         ctx.num_points = features.shape[0]
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
-        idx, qvalue, scaler = ctx.saved_tensors
-        grad_feat, grad_occ = ops.blend_backward(grad_out.contiguous(), idx, qvalue, scaler, ctx.num_points)
-        return grad_feat, grad_occ, None, None, None
+        idx, qvalue, scaler, wsum = ctx.saved_tensors
+        grad_feat, grad_occ = ops.blend_backward(grad_out.contiguous(), idx, qvalue, scaler, ctx.num_points,
+                                                 geometry=ctx.geometry, wsum=wsum)
+        return grad_feat, grad_occ, None, None, None, None
 
 
 class NormWeightedCompositor(torch.nn.Module):
@@ -41,7 +43,7 @@ class NormWeightedCompositor(torch.nn.Module):
         feat = features.permute(1, 0).contiguous()
         occ = (idx[..., 0] >= 0).float()
         ones = torch.ones(feat.shape[0], device=feat.device)
-        out = _Blend.apply(feat, occ, idx, q, ones)
+        out = _Blend.apply(feat, occ, idx, q, ones, None)
         return out[..., :-1].permute(0, 3, 1, 2)
 
 
@@ -76,7 +78,8 @@ class SurfaceSplattingRenderer(torch.nn.Module):
         else:
             qv = fragments.qvalue
         if self.compositor is None or isinstance(self.compositor, NormWeightedCompositor):
-            images = _Blend.apply(pts_rgb, fragments.occupancy, fragments.idx, qv, scaler)
+            images = _Blend.apply(pts_rgb, fragments.occupancy, fragments.idx, qv, scaler,
+                                  getattr(fragments, "geometry", None))
         else:
             # foreign compositor object: call it exactly like renderer.py:53-78
             safe = fragments.idx.clamp_min(0).long()

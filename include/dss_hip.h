@@ -117,11 +117,14 @@ DSS_API int dss_backward_radius(const float *radii, const uint8_t *visible, cons
  *       skip if g>0 and (|dx|>rx or |dy|>ry);   grad_xy[p] += (dx,dy)/max(d2,1e-10)*g
  *   (a pair with d2 == 0 contributes 0; the reference produces NaN there).
  * Writes grad_pts[:,0:2] for ALL points (0 for invisible ones) and sets grad_pts[:,2] = 0.
+ * grad_pixel_stride: elements between consecutive pixels of grad_occ (1 = dense (N,rows,S); C+1 =
+ * read the alpha channel of an (N,rows,S,C+1) image gradient in place, no copy).
  * Gather formulation: one wavefront per point, no atomics, deterministic. */
 DSS_API int dss_occ_backward(const float *points, const float *radii, const uint8_t *visible,
                      const float *rs, const float *grad_occ /* (N,rows,S) */,
                      const int64_t *first_idx, const int64_t *num_pts, int N, int64_t P, int S,
-                     int row0, int row1, float *grad_pts /* (P,3) */, void *stream);
+                     int row0, int row1, int grad_pixel_stride, float *grad_pts /* (P,3) */,
+                     void *stream);
 
 /* Replaces DSS._C._backward_zbuf (ext.cpp:17, rasterize_points.cu:823-846): accumulates IN PLACE
  * z_grad[idx[n,r,c,k]] += grad_zbuf[n,r,c,k] (zero grads skipped, stop at first idx<0), into the
@@ -138,7 +141,7 @@ DSS_API int dss_splat_backward(const float *points, const float *radii, const ui
                        const int32_t *idx, const float *grad_occ,
                        const float *grad_zbuf /* NULL = all zero */,
                        const int64_t *first_idx, const int64_t *num_pts,
-                       int N, int64_t P, int S, int K, float radii_s, float clip,
+                       int N, int64_t P, int S, int K, int grad_pixel_stride, float radii_s, float clip,
                        float *grad_pts /* (P,3), fully written */, float *rs_out /* (N,) or NULL */,
                        void *workspace, size_t workspace_bytes, void *stream);
 
@@ -151,17 +154,32 @@ DSS_API int dss_splat_backward(const float *points, const float *radii, const ui
  * feat is (P,C) row-major (Pointclouds.features_packed()); out is (N,rows,S,C+1). 1 <= C <= 8.
  * ------------------------------------------------------------------------------------------- */
 DSS_API int dss_blend_forward(const int32_t *idx, const float *qvalue, const float *occ,
-                      const float *scaler, const float *feat, int N, int rows, int S, int K, int C,
-                      float *out, void *stream);
+                              const float *scaler, const float *feat, int N, int rows, int S, int K, int C,
+                              float *out, float *wsum /* (N,rows,S) or NULL: max(sum_k w_k, 1e-4) */,
+                              void *stream);
 
-/* Backward of the blend to the per-point features and to occupancy:
- *   grad_feat[idx_k][ch] += grad_out[ch] * w_k / max(sum w, 1e-4)      (zeroed here first)
- *   grad_occ = grad_out[..., C]
- * The gradient w.r.t. the weights is not produced: the reference discards it
- * (rasterizer.py:788-789 ignores qvalue_grad; EWA terms are detached, :562-565). */
-DSS_API int dss_blend_backward(const float *grad_out, const int32_t *idx, const float *qvalue,
-                       const float *scaler, int N, int rows, int S, int K, int C, int64_t P,
-                       float *grad_feat /* (P,C) */, float *grad_occ /* (N,rows,S) */, void *stream);
+/* Backward of the blend to the per-point features:
+ *   grad_feat[p][ch] = sum over fragments (pixel,k) with idx == p of grad_out[pixel][ch] * w_k / wsum[pixel]
+ * evaluated point-centric (one wavefront per visible point gathers over the pixels of its own
+ * bounding box |dx|<=rx, |dy|<=ry): no atomics, deterministic, grad_feat (P,C) fully written.
+ * wsum = the optional output of dss_blend_forward (NULL: recomputed per pixel).
+ * The gradient w.r.t. occupancy is simply grad_out[..., C] (read it in place with
+ * dss_occ_backward's grad_pixel_stride = C+1).  The gradient w.r.t. the weights is not produced:
+ * the reference discards it (rasterizer.py:788-789 ignores qvalue_grad; EWA terms are detached,
+ * :562-565). */
+DSS_API int dss_blend_backward(const float *grad_out /* (N,rows,S,C+1) */, const int32_t *idx,
+                               const float *qvalue, const float *wsum, const float *scaler,
+                               const float *points, const float *radii, const uint8_t *visible,
+                               const int64_t *first_idx, const int64_t *num_pts, int N, int64_t P,
+                               int S, int K, int C, int row0, int row1, float *grad_feat /* (P,C) */,
+                               void *stream);
+
+/* Same gradient, pixel-centric scatter with one atomicAdd per fragment and channel (the shape of
+ * pytorch3d's norm_weighted_sum backward); for callers that hold fragments but not the splat
+ * geometry.  grad_feat (P,C) is zeroed here first. */
+DSS_API int dss_blend_backward_scatter(const float *grad_out, const int32_t *idx, const float *qvalue,
+                                       const float *scaler, int N, int rows, int S, int K, int C,
+                                       int64_t P, float *grad_feat, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused per-point setup = everything SurfaceSplatting.forward does before _C.splat_points:

@@ -149,10 +149,16 @@ def test_cfg2_bunny_512_forward_backward_vs_oracle():
     # backward with grad_out = randn(seed 1) on RGBA
     rng = np.random.default_rng(1)
     grad_out = rng.standard_normal((1, S, S, 4)).astype(np.float32)
-    gf, gocc = ops.blend_backward(torch.from_numpy(grad_out).to(DEV), idx, qv, scaler, P)
     o_gf, o_gocc = oracle.blend_backward(grad_out, o_idx, o_qv, sc["scaler"], P)
-    assert np.array_equal(gocc.cpu().numpy(), o_gocc)
-    assert _rel_l2(gf.cpu().numpy(), o_gf) <= 1e-3
+    img2, wsum = ops.blend_forward(idx, qv, occ, scaler, feat, return_wsum=True)
+    assert torch.equal(img2, img)
+    geom = (d["points"], d["radii"], vis, d["first"], d["num"])
+    for kw in (dict(), dict(geometry=geom), dict(geometry=geom, wsum=wsum)):  # scatter / gather / gather+wsum
+        gf, gocc = ops.blend_backward(torch.from_numpy(grad_out).to(DEV), idx, qv, scaler, P, **kw)
+        assert np.array_equal(gocc.cpu().numpy(), o_gocc)
+        assert _rel_l2(gf.cpu().numpy(), o_gf) <= 1e-3, kw.keys()
+    gf2, _ = ops.blend_backward(torch.from_numpy(grad_out).to(DEV), idx, qv, scaler, P, geometry=geom, wsum=wsum)
+    assert torch.equal(gf, gf2)  # gather formulation is deterministic
 
     grad_zbuf = rng.standard_normal((1, S, S, K)).astype(np.float32)
     for gz, cl in ((None, clip), (grad_zbuf, -1.0), (grad_zbuf, clip)):
@@ -230,9 +236,12 @@ def test_blend_generic_channels(C):
     img = ops.blend_forward(t(idx), t(qv), t(occ), t(sc["scaler"]), t(feat))
     assert np.abs(img.cpu().numpy() - oracle.blend_forward(idx, qv, occ, sc["scaler"], feat)).max() <= 1e-5
     go = rng.standard_normal((2, 40, 40, C + 1)).astype(np.float32)
-    gf, gocc = ops.blend_backward(t(go), t(idx), t(qv), t(sc["scaler"]), feat.shape[0])
     o_gf, o_gocc = oracle.blend_backward(go, idx, qv, sc["scaler"], feat.shape[0])
-    assert _rel_l2(gf.cpu().numpy(), o_gf) <= 1e-5 and np.array_equal(gocc.cpu().numpy(), o_gocc)
+    vis = t(oracle.visibility(idx, feat.shape[0]))
+    geom = (t(sc["points"]), t(sc["radii"]), vis, t(sc["first_idx"]), t(sc["num_pts"]))
+    for kw in (dict(), dict(geometry=geom)):
+        gf, gocc = ops.blend_backward(t(go), t(idx), t(qv), t(sc["scaler"]), feat.shape[0], **kw)
+        assert _rel_l2(gf.cpu().numpy(), o_gf) <= 1e-5 and np.array_equal(gocc.cpu().numpy(), o_gocc)
 
 
 def test_large_synthetic_properties():
