@@ -84,7 +84,7 @@ class Workload:
             g_pts = ops.splat_backward(info["pts_screen"], info["radii"], vis, idx, g_occ, None, self.first,
                                        self.num, RADII_S, CLIP)
         else:
-            vis8 = vis.to(torch.uint8)
+            vis8 = vis.view(torch.uint8)
             reduce_visibility_(vis8, p)
             rs = ops.backward_radius(info["radii"], vis8, self.first, self.num, RADII_S)
             g_pts = ops.occ_backward(info["pts_screen"], info["radii"], vis8, rs, g_occ, self.first, self.num,

@@ -28,24 +28,6 @@ __device__ __forceinline__ float key_float(uint32_t k)
     return __uint_as_float(b);
 }
 
-// LDS histogram increment with wave-level aggregation of equal bins (radii cluster in a few
-// exponent bins, which would serialise plain LDS atomics 64-way).
-__device__ __forceinline__ void hist_add(uint32_t *hist, uint32_t bin, bool active)
-{
-#pragma unroll 1
-    for (int round = 0; round < 4; ++round) {
-        const unsigned long long act = __ballot(active);
-        if (act == 0ull) return;
-        const int leader = __builtin_ctzll(act);
-        const uint32_t lbin = __shfl(bin, leader, 64);
-        const bool same = active && (bin == lbin);
-        const unsigned long long m = __ballot(same);
-        if ((int)(threadIdx.x & 63) == leader) atomicAdd(&hist[lbin], (uint32_t)__popcll(m));
-        active = active && !same;
-    }
-    if (active) atomicAdd(&hist[bin], 1u);
-}
-
 #define MED_THREADS 256
 #define MED_BINS 2048
 #define MED_PTS_PER_WG 2048
@@ -134,16 +116,25 @@ __global__ __launch_bounds__(MED_THREADS) void median_hist_kernel(
         __syncthreads();
         const int sh = med_shift(PASS);
         const uint32_t dm = med_mask(PASS);
-        for (int64_t i = lo + tid; i < lo + ((hi - lo + MED_THREADS - 1) / MED_THREADS) * MED_THREADS; i += MED_THREADS) {
-            const bool act = (i < hi) && (visible[i] != 0);
-            uint32_t kx = 0, ky = 0;
-            if (act) {
-                const float2 r = reinterpret_cast<const float2 *>(radii)[i];
-                kx = float_key(r.x);
-                ky = float_key(r.y);
+        // 8 points per thread; all loads are issued before the first use (latency overlapped).
+        // Plain LDS atomics: a 64-way same-bin conflict costs ~64 LDS cycles, far less than the loads.
+        constexpr int PER = MED_PTS_PER_WG / MED_THREADS;
+        uint8_t vis[PER];
+        float2 rr[PER];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int64_t i = lo + tid + (int64_t)u * MED_THREADS;
+            const bool in = i < hi;
+            vis[u] = in ? visible[i] : (uint8_t)0;
+            rr[u] = in ? reinterpret_cast<const float2 *>(radii)[i] : make_float2(0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            if (vis[u]) {
+                const uint32_t kx = float_key(rr[u].x), ky = float_key(rr[u].y);
+                if ((kx & pmask) == prefix) atomicAdd(&lh[(kx >> sh) & dm], 1u);
+                if ((ky & pmask) == prefix) atomicAdd(&lh[(ky >> sh) & dm], 1u);
             }
-            hist_add(lh, (kx >> sh) & dm, act && ((kx & pmask) == prefix));
-            hist_add(lh, (ky >> sh) & dm, act && ((ky & pmask) == prefix));
         }
         __syncthreads();
         uint32_t *gh = hist + ((size_t)PASS * N + n) * MED_BINS;

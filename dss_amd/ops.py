@@ -14,6 +14,11 @@ from . import _lib
 _f32, _i32, _i64, _u8 = torch.float32, torch.int32, torch.int64, torch.uint8
 
 
+def _as_u8(mask):
+    """bool -> uint8 without a copy kernel (same storage, values 0/1)."""
+    return mask.view(_u8) if mask.dtype == torch.bool else mask
+
+
 def _check_raster_inputs(points, ellipse_params, cutoff_thres, radii, first_idx, num_pts):
     # shape checks of RasterizePoints, rasterize_points.h:474-488
     if points.dim() != 2 or points.shape[1] != 3:
@@ -73,7 +78,7 @@ def splat_points(points, ellipse_params, cutoff_thres, radii, cloud_to_packed_fi
                                    _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
     _lib.check(rc, "dss_splat_forward")
     if return_visible:
-        return idx, zbuf, qv, occ, vis.bool()
+        return idx, zbuf, qv, occ, vis.view(torch.bool)  # zero-copy reinterpretation (values are 0/1)
     return idx, zbuf, qv, occ
 
 
@@ -89,7 +94,7 @@ def backward_radius(radii, visible, cloud_to_packed_first_idx, num_points_per_cl
     lib = _lib.load()
     radii = _lib.require_gpu(radii, "radii", _f32)
     dev = radii.device
-    vis = _lib.require_gpu(visible.to(_u8) if visible.dtype == torch.bool else visible, "visible", _u8)
+    vis = _lib.require_gpu(_as_u8(visible), "visible", _u8)
     first = _lib.require_gpu(cloud_to_packed_first_idx, "cloud_to_packed_first_idx", _i64)
     num = _lib.require_gpu(num_points_per_cloud, "num_points_per_cloud", _i64)
     N, P = first.shape[0], radii.shape[0]
@@ -121,7 +126,7 @@ def occ_backward(points, radii, visible, rs, grad_occ, cloud_to_packed_first_idx
     points = _lib.require_gpu(points, "points", _f32)
     dev = points.device
     radii = _lib.require_gpu(radii, "radii", _f32)
-    vis = _lib.require_gpu(visible.to(_u8) if visible.dtype == torch.bool else visible, "visible", _u8)
+    vis = _lib.require_gpu(_as_u8(visible), "visible", _u8)
     rs = _lib.require_gpu(rs, "rs", _f32)
     first = _lib.require_gpu(cloud_to_packed_first_idx, "cloud_to_packed_first_idx", _i64)
     num = _lib.require_gpu(num_points_per_cloud, "num_points_per_cloud", _i64)
@@ -184,7 +189,7 @@ def splat_backward(points, radii, visible, idx, grad_occ, grad_zbuf, cloud_to_pa
     points = _lib.require_gpu(points, "points", _f32)
     dev = points.device
     radii = _lib.require_gpu(radii, "radii", _f32)
-    vis = _lib.require_gpu(visible.to(_u8) if visible.dtype == torch.bool else visible, "visible", _u8)
+    vis = _lib.require_gpu(_as_u8(visible), "visible", _u8)
     idx = _lib.require_gpu(idx, "idx", _i32)
     if not grad_occ.is_cuda:
         raise RuntimeError("dss_amd: grad_occ must be a GPU tensor (no CPU fallback)")
@@ -254,7 +259,7 @@ def blend_backward(grad_out, idx, qvalue, scaler, num_points: int, geometry=None
             pts, radii, vis, first, num = geometry
             pts = _lib.require_gpu(pts, "pts_screen", _f32)
             radii = _lib.require_gpu(radii, "radii", _f32)
-            vis = _lib.require_gpu(vis.to(_u8) if vis.dtype == torch.bool else vis, "visible", _u8)
+            vis = _lib.require_gpu(_as_u8(vis), "visible", _u8)
             first = _lib.require_gpu(first, "cloud_to_packed_first_idx", _i64)
             num = _lib.require_gpu(num, "num_points_per_cloud", _i64)
             if wsum is not None:
@@ -315,7 +320,7 @@ def point_setup(world, normals, h, M, V, znear, zfar, cloud_to_packed_first_idx,
                                  _lib.ptr(out["ellipse_params"]), _lib.ptr(out["radii"]), _lib.ptr(out["scaler"]),
                                  _lib.ptr(out["cutoff_threshold"]), _lib.ptr(valid), _lib.stream_ptr(dev))
     _lib.check(rc, "dss_point_setup")
-    out["valid"] = valid.bool()
+    out["valid"] = valid.view(torch.bool)
     return out
 
 
@@ -330,7 +335,7 @@ def project_backward(world, M, V, cloud_to_packed_first_idx, num_points_per_clou
     first = _lib.require_gpu(cloud_to_packed_first_idx, "cloud_to_packed_first_idx", _i64)
     num = _lib.require_gpu(num_points_per_cloud, "num_points_per_cloud", _i64)
     grad_screen = _lib.require_gpu(grad_screen, "grad_screen", _f32)
-    vis = _lib.require_gpu(valid.to(_u8) if valid.dtype == torch.bool else valid, "valid", _u8)
+    vis = _lib.require_gpu(_as_u8(valid), "valid", _u8)
     N, Pw = first.shape[0], world.shape[0]
     with torch.cuda.device(dev):
         gw = torch.empty((Pw, 3), dtype=_f32, device=dev)
