@@ -6,12 +6,13 @@
 //   bin_count   one thread per splat: exact pixel rect -> 16x16 screen-tile rect, per-tile counts
 //   bin_scan    exclusive scan of the per-tile counts (compacted lists, no dense (N,B,B,M) table)
 //   bin_fill    one thread per splat: append its id to every tile list it overlaps
-//   fine        one 256-thread workgroup per tile = four wavefronts, one 8x8 pixel quadrant each.
-//               Candidates are staged through LDS in chunks of 256 (SoA); every wavefront culls
-//               the chunk against its quadrant with one ballot per 64 candidates and walks only
-//               the surviving bits; every lane keeps the K nearest hits of its pixel sorted in
-//               registers; results leave through an LDS transpose so that each image row of the
-//               tile is written as one contiguous run.
+//   fine        one 1024-thread workgroup per tile = sixteen wavefronts, one 4x4 pixel footprint
+//               each, four candidate slices per pixel.  Candidates are staged through LDS in
+//               chunks of 512; every wavefront culls the chunk against its footprint with one
+//               ballot per 64 candidates and compacts the survivors (mbcnt prefix); every lane keeps
+//               the K nearest hits of its (pixel, slice) sorted in registers; the four slices are
+//               merged with xor-shuffles; results leave through an LDS transpose so that each image
+//               row of the tile is written as one contiguous run.
 //
 // The per-pair arithmetic (dx, dy, Q, comparisons) is written exactly like the reference
 // (rasterize_points.cu:64-124) and compiled with -ffp-contract=off, so fragments are bit-identical
@@ -181,7 +182,6 @@ __global__ __launch_bounds__(256) void bin_fill_kernel(
 // ---------------------------------------------------------------------------------------------
 // Fine pass.
 // ---------------------------------------------------------------------------------------------
-#define CHUNK 256
 
 struct FineArgs {
     const float *points, *ellipse, *cutoff, *radii;
@@ -204,14 +204,42 @@ struct FineArgs {
 // rasterize_points_cpu.cpp:85 / oracle frag_less.  Empty slots hold ~0.
 #define KEY_EMPTY 0xffffffffffffffffull
 
+// sorted insertion of (ekey, eq) into an ascending K-list held in registers; branch-free.
 template <int KMAX>
-__global__ __launch_bounds__(256) void fine_kernel(const FineArgs A)
+__device__ __forceinline__ void klist_insert(unsigned long long (&key)[KMAX], float (&kq)[KMAX],
+                                             unsigned long long ekey, float eq)
 {
-    // candidate chunk, staged as three records per splat so the inner loop needs 2x ds_read_b128
-    // + 1x ds_read_b64 (broadcast) instead of ten ds_read_b32
+    bool lt[KMAX];  // e < slot[k] on the old list (monotone in k)
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) lt[k] = ekey < key[k];
+#pragma unroll
+    for (int k = KMAX - 1; k >= 1; --k) {
+        key[k] = lt[k - 1] ? key[k - 1] : (lt[k] ? ekey : key[k]);
+        kq[k] = lt[k - 1] ? kq[k - 1] : (lt[k] ? eq : kq[k]);
+    }
+    key[0] = lt[0] ? ekey : key[0];
+    kq[0] = lt[0] ? eq : kq[0];
+}
+
+// Work decomposition of one 16x16 tile (one 1024-thread workgroup = 16 wavefronts):
+//   wavefront w  -> 4x4 pixel footprint (w%4, w/4) of the tile
+//   lane l       -> pixel (l%16) of the footprint, candidate slice l/16 (4 slices)
+// A pixel's candidates are split 4 ways across lanes 16 apart; each lane keeps its own K-list and
+// the four lists are merged at the end with two xor-shuffle rounds.  The per-pixel serial chain is
+// what bounds this kernel at DSS sizes (the longest tile list, not bandwidth), and this layout cuts
+// it ~8x versus one lane per pixel walking a whole 8x8 quadrant's survivors.
+#define FINE_THREADS 1024
+#define FINE_WAVES 16
+#define CHUNK 512
+
+template <int KMAX>
+__global__ __launch_bounds__(FINE_THREADS) void fine_kernel(const FineArgs A)
+{
+    // candidate chunk: three records per splat -> 2x ds_read_b128 + 1x ds_read_b64 per test
     __shared__ float4 s_geo[CHUNK];   // px, py, rx, ry
     __shared__ float4 s_ell[CHUNK];   // a, b, c, cutoff
     __shared__ float2 s_zid[CHUNK];   // pz, idx (bits)
+    __shared__ unsigned short s_surv[FINE_WAVES][CHUNK];  // per-wavefront compacted survivor slots
     __shared__ int s_out[DSS_TILE_PIX * KMAX];
 
     const TileGrid g = A.g;
@@ -221,19 +249,18 @@ __global__ __launch_bounds__(256) void fine_kernel(const FineArgs A)
     const int ty = t / g.tiles_x, tx = t - ty * g.tiles_x;
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    // wave -> 8x8 quadrant of the tile; lane -> pixel inside the quadrant
-    const int qx = wid & 1, qy = wid >> 1;
-    const int lx = lane & 7, ly = lane >> 3;
-    const int tr = qy * 8 + ly, tc = qx * 8 + lx;                   // pixel inside the tile
-    const int r = g.row0 + ty * DSS_TILE + tr;                      // image row
-    const int c = tx * DSS_TILE + tc;                               // image col
+    const int fx = wid & 3, fy = wid >> 2;            // footprint inside the tile
+    const int pl = lane & 15, slice = lane >> 4;      // pixel inside the footprint, candidate slice
+    const int tr = fy * 4 + (pl >> 2), tc = fx * 4 + (pl & 3);
+    const int r = g.row0 + ty * DSS_TILE + tr;        // image row
+    const int c = tx * DSS_TILE + tc;                 // image col
     const int S = g.S;
     const float xf = pix_to_ndc(S - 1 - c, S);
     const float yf = pix_to_ndc(S - 1 - r, S);
-    // NDC extent of this wave's quadrant (pixel centres).  NDC decreases with the image index.
-    const int qc0 = tx * DSS_TILE + qx * 8, qr0 = g.row0 + ty * DSS_TILE + qy * 8;
-    const float q_xmax = pix_to_ndc(S - 1 - qc0, S), q_xmin = pix_to_ndc(S - 1 - (qc0 + 7), S);
-    const float q_ymax = pix_to_ndc(S - 1 - qr0, S), q_ymin = pix_to_ndc(S - 1 - (qr0 + 7), S);
+    // NDC extent of this wavefront's footprint (pixel centres).  NDC decreases with the image index.
+    const int fc0 = tx * DSS_TILE + fx * 4, fr0 = g.row0 + ty * DSS_TILE + fy * 4;
+    const float f_xmax = pix_to_ndc(S - 1 - fc0, S), f_xmin = pix_to_ndc(S - 1 - (fc0 + 3), S);
+    const float f_ymax = pix_to_ndc(S - 1 - fr0, S), f_ymin = pix_to_ndc(S - 1 - (fr0 + 3), S);
 
     // candidate source: tile list (binned) or the whole cloud (naive / list overflow)
     int64_t src0;
@@ -248,7 +275,6 @@ __global__ __launch_bounds__(256) void fine_kernel(const FineArgs A)
         count = A.num_pts[n];
     }
 
-    // K nearest, ascending key; empty slots at the tail
     unsigned long long key[KMAX];
     float kq[KMAX];
 #pragma unroll
@@ -256,6 +282,7 @@ __global__ __launch_bounds__(256) void fine_kernel(const FineArgs A)
         key[k] = KEY_EMPTY;
         kq[k] = -1.0f;
     }
+    unsigned short *surv = s_surv[wid];
 
     for (int64_t base = 0; base < count; base += CHUNK) {
         const int m = (int)min((int64_t)CHUNK, count - base);
@@ -269,65 +296,72 @@ __global__ __launch_bounds__(256) void fine_kernel(const FineArgs A)
             s_zid[tid] = make_float2(pz, __int_as_float((int)p));
         }
         __syncthreads();
+        // ---- cull + compact: one candidate per lane, ballot, prefix popcount -> survivor list ----
+        int nsurv = 0;
         for (int sub = 0; sub < m; sub += 64) {
-            // one candidate per lane: conservative (rounding-monotone) cull against the quadrant
             const int j = sub + lane;
             bool keep = false;
             if (j < m) {
                 const float4 ge = s_geo[j];
-                const bool out = (s_zid[j].x < 0) || ((q_xmax - ge.x) < -ge.z) || ((q_xmin - ge.x) > ge.z) ||
-                                 ((q_ymax - ge.y) < -ge.w) || ((q_ymin - ge.y) > ge.w);
+                // conservative, rounding-monotone rejection against the footprint (see splat_tile_rect)
+                const bool out = (s_zid[j].x < 0) || ((f_xmax - ge.x) < -ge.z) || ((f_xmin - ge.x) > ge.z) ||
+                                 ((f_ymax - ge.y) < -ge.w) || ((f_ymin - ge.y) > ge.w);
                 keep = !out;
             }
-            unsigned long long mask = __ballot(keep);
-            if (mask == 0ull) continue;
-            // walk the surviving bits; the next record is fetched while the current one is processed
-            int jj = sub + __builtin_ctzll(mask);
-            float4 ge = s_geo[jj], el = s_ell[jj];
-            float2 zi = s_zid[jj];
-            while (true) {
-                mask &= mask - 1;
-                const bool more = mask != 0ull;
-                float4 ge_n = ge, el_n = el;
-                float2 zi_n = zi;
-                if (more) {
-                    jj = sub + __builtin_ctzll(mask);
-                    ge_n = s_geo[jj];
-                    el_n = s_ell[jj];
-                    zi_n = s_zid[jj];
-                }
-                const float dx = xf - ge.x;
-                const float dy = yf - ge.y;
-                // rasterize_points.cu:92-101, same expression order (no FMA contraction)
-                const float qval = el.x * dx * dx + el.y * dx * dy + el.z * dy * dy;
-                const bool hit = !(fabsf(dx) > ge.z || fabsf(dy) > ge.w) && !(qval > el.w);
-                if (__ballot(hit) != 0ull) {
-                    const unsigned long long ekey =
-                        hit ? (((unsigned long long)__float_as_uint(zi.x + 0.0f) << 32) |
-                               (unsigned long long)(unsigned)__float_as_int(zi.y))
-                            : KEY_EMPTY;
-                    bool lt[KMAX];  // e < slot[k], evaluated on the old list (monotone in k)
-#pragma unroll
-                    for (int k = 0; k < KMAX; ++k) lt[k] = ekey < key[k];
-#pragma unroll
-                    for (int k = KMAX - 1; k >= 1; --k) {
-                        key[k] = lt[k - 1] ? key[k - 1] : (lt[k] ? ekey : key[k]);
-                        kq[k] = lt[k - 1] ? kq[k - 1] : (lt[k] ? qval : kq[k]);
-                    }
-                    key[0] = lt[0] ? ekey : key[0];
-                    kq[0] = lt[0] ? qval : kq[0];
-                }
-                if (!more) break;
-                ge = ge_n;
-                el = el_n;
-                zi = zi_n;
+            const unsigned long long mask = __ballot(keep);
+            if (keep) {
+                const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                                           __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                surv[nsurv + rank] = (unsigned short)j;
+            }
+            nsurv += __popcll(mask);
+        }
+        // same wavefront wrote and now reads `surv`: LDS ops of one wave complete in order; the wave
+        // barrier only stops the compiler from moving the reads above the writes
+        __builtin_amdgcn_wave_barrier();
+        // ---- test + insert: lane (pixel, slice) takes survivors slice, slice+4, ... ----
+        const int trips = (nsurv + 3) >> 2;
+        for (int it = 0; it < trips; ++it) {
+            const int si = it * 4 + slice;
+            const bool live = si < nsurv;
+            const int jj = live ? (int)surv[si] : 0;
+            const float4 ge = s_geo[jj], el = s_ell[jj];
+            const float2 zi = s_zid[jj];
+            const float dx = xf - ge.x;
+            const float dy = yf - ge.y;
+            // rasterize_points.cu:92-101, same expression order (no FMA contraction)
+            const float qval = el.x * dx * dx + el.y * dx * dy + el.z * dy * dy;
+            const bool hit = live && !(fabsf(dx) > ge.z || fabsf(dy) > ge.w) && !(qval > el.w);
+            if (__ballot(hit) != 0ull) {
+                const unsigned long long ekey =
+                    hit ? (((unsigned long long)__float_as_uint(zi.x + 0.0f) << 32) |
+                           (unsigned long long)(unsigned)__float_as_int(zi.y))
+                        : KEY_EMPTY;
+                klist_insert<KMAX>(key, kq, ekey, qval);
             }
         }
     }
 
-    // ---- epilogue: depth merge, occupancy, visibility, LDS-transposed stores ----
+    // ---- merge the four candidate slices of every pixel (lanes 16 and 32 apart) ----
+#pragma unroll
+    for (int xo = 16; xo <= 32; xo <<= 1) {
+        unsigned long long okey[KMAX];
+        float oq[KMAX];
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const unsigned lo = __shfl_xor((unsigned)key[k], xo, 64);
+            const unsigned hi = __shfl_xor((unsigned)(key[k] >> 32), xo, 64);
+            okey[k] = ((unsigned long long)hi << 32) | lo;
+            oq[k] = __shfl_xor(kq[k], xo, 64);
+        }
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) klist_insert<KMAX>(key, kq, okey[k], oq[k]);
+    }
+
+    // ---- epilogue (slice 0 lanes own the pixel): depth merge, occupancy, visibility, stores ----
     const int K = A.K;
-    const bool in_img = (c < S) && (r < g.row0 + g.rows);
+    const bool owner = slice == 0;
+    const bool in_img = owner && (c < S) && (r < g.row0 + g.rows);
     float kz[KMAX];
     int ki[KMAX];
     const float z0 = __uint_as_float((unsigned)(key[0] >> 32));
@@ -352,7 +386,8 @@ __global__ __launch_bounds__(256) void fine_kernel(const FineArgs A)
         }
     }
 
-    // rows of the tile are contiguous runs of 16*K dwords in the (N,rows,S,K) tensors
+    // rows of the tile are contiguous runs of 16*K dwords in the (N,rows,S,K) tensors: stage the
+    // tile through LDS and let each wavefront stream one full row
     const int run = DSS_TILE * K;
     const int c0 = tx * DSS_TILE;
     const int valid_cols = min(DSS_TILE, S - c0) * K;
@@ -362,12 +397,13 @@ __global__ __launch_bounds__(256) void fine_kernel(const FineArgs A)
 
 #define DSS_STORE_PLANE(REGS, DST, CAST)                                                          \
     __syncthreads();                                                                              \
-    _Pragma("unroll") for (int k = 0; k < KMAX; ++k) if (k < K) s_out[lds_pix + k] = CAST(REGS[k]); \
+    if (owner) {                                                                                  \
+        _Pragma("unroll") for (int k = 0; k < KMAX; ++k) if (k < K) s_out[lds_pix + k] = CAST(REGS[k]); \
+    }                                                                                             \
     __syncthreads();                                                                              \
-    for (int rr = wid * 4; rr < wid * 4 + 4; ++rr) {                                              \
-        if (rr >= valid_rows) break;                                                              \
+    if (wid < valid_rows) {                                                                       \
         for (int cc = lane; cc < valid_cols; cc += 64)                                            \
-            reinterpret_cast<int *>(DST)[tile_base + (size_t)rr * S * K + cc] = s_out[rr * run + cc]; \
+            reinterpret_cast<int *>(DST)[tile_base + (size_t)wid * S * K + cc] = s_out[wid * run + cc]; \
     }
 
     DSS_STORE_PLANE(ki, A.idx, (int))
@@ -379,7 +415,7 @@ __global__ __launch_bounds__(256) void fine_kernel(const FineArgs A)
 template <int KMAX>
 static void launch_fine(const FineArgs &A, int blocks, hipStream_t st)
 {
-    hipLaunchKernelGGL(fine_kernel<KMAX>, dim3(blocks), dim3(256), 0, st, A);
+    hipLaunchKernelGGL(fine_kernel<KMAX>, dim3(blocks), dim3(FINE_THREADS), 0, st, A);
 }
 
 static bool dispatch_fine(const FineArgs &A, int blocks, hipStream_t st)
