@@ -17,6 +17,21 @@ void set_error(const char *fmt, ...);
 // (reference rasterization_utils.cuh:8-11): -1 + (2*i + 1.0f) / S.
 __device__ __forceinline__ float pix_to_ndc(int i, int S) { return -1 + (2 * i + 1.0f) / S; }
 
+// Same value as pix_to_ndc for every S: when S is a power of two, multiplying by the exactly
+// representable 1/S rounds identically to the division (one v_mul instead of a ~10-instruction
+// IEEE divide in inner loops); otherwise fall back to the division.  `pow2` is wave-uniform.
+struct NdcMap {
+    int S;
+    float invS;
+    bool pow2;
+    __device__ __forceinline__ explicit NdcMap(int S_) : S(S_), invS(1.0f / (float)S_), pow2((S_ & (S_ - 1)) == 0) {}
+    __device__ __forceinline__ float operator()(int i) const
+    {
+        const float t = 2 * i + 1.0f;
+        return pow2 ? -1 + t * invS : -1 + t / S;
+    }
+};
+
 // Cloud that owns packed point p (N is small; clouds are disjoint index ranges).
 __device__ __forceinline__ int find_cloud(int64_t p, const int64_t *__restrict__ first_idx,
                                           const int64_t *__restrict__ num_pts, int N)

@@ -200,9 +200,10 @@ __global__ __launch_bounds__(256) void occ_backward_kernel(
             const int LW = 1 << lw_log, LH = 64 >> lw_log;
             const int lxx = lane & (LW - 1), lyy = lane >> lw_log;
             const float *gbase = grad_occ + (size_t)n * rows * S * gstride;
+            const NdcMap ndc(S);
             for (int xi = xlo + lxx; xi <= xhi; xi += LW) {
                 // column-invariant terms hoisted out of the row loop
-                const float dx = pix_to_ndc(xi, S) - px;
+                const float dx = ndc(xi) - px;
                 const float dx2 = dx * dx;
                 const bool out_x = fabsf(dx) > rx;
                 const float *gcol = gbase + (size_t)(S - 1 - xi) * gstride;
@@ -217,7 +218,7 @@ __global__ __launch_bounds__(256) void occ_backward_kernel(
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const int yi = y0 + u * LH;
-                        const float dy = pix_to_ndc(yi, S) - py;
+                        const float dy = ndc(yi) - py;
                         const float d2 = dx2 + dy * dy;
                         // rasterize_points_backward.cu:151-168; d2 == 0 contributes 0 (see dss_hip.h)
                         const bool outside = out_x || (fabsf(dy) > ry);

@@ -232,15 +232,18 @@ __device__ __forceinline__ void klist_insert(unsigned long long (&key)[KMAX], fl
 #define FINE_WAVES 16
 #define CHUNK 512
 
+// launch bounds: two resident workgroups per CU (8 waves/SIMD, <= 64 VGPRs) for the register-light
+// K <= 8 instantiations -- with one workgroup per CU the latency of a tile is fully exposed.
 template <int KMAX>
-__global__ __launch_bounds__(FINE_THREADS) void fine_kernel(const FineArgs A)
+__global__ __launch_bounds__(FINE_THREADS, (KMAX <= 8 ? 2 : 1)) void fine_kernel(const FineArgs A)
 {
     // candidate chunk: three records per splat -> 2x ds_read_b128 + 1x ds_read_b64 per test
     __shared__ float4 s_geo[CHUNK];   // px, py, rx, ry
     __shared__ float4 s_ell[CHUNK];   // a, b, c, cutoff
     __shared__ float2 s_zid[CHUNK];   // pz, idx (bits)
     __shared__ unsigned short s_surv[FINE_WAVES][CHUNK];  // per-wavefront compacted survivor slots
-    __shared__ int s_out[DSS_TILE_PIX * KMAX];
+    constexpr int PLANES = (KMAX <= 8) ? 3 : 1;   // idx / zbuf / qvalue staged together when they fit
+    __shared__ int s_out[PLANES][DSS_TILE_PIX * KMAX];
 
     const TileGrid g = A.g;
     const int tiles = g.tiles_x * g.tiles_y;
@@ -265,14 +268,43 @@ __global__ __launch_bounds__(FINE_THREADS) void fine_kernel(const FineArgs A)
     // candidate source: tile list (binned) or the whole cloud (naive / list overflow)
     int64_t src0;
     int64_t count;
-    const bool use_list = (A.offsets != nullptr) && (*A.overflow == 0u);
-    if (use_list) {
-        // the DSS_SUB sub-lists of a tile are adjacent: [offsets[tile*SUB], offsets[(tile+1)*SUB])
-        src0 = A.offsets[(size_t)blockIdx.x * DSS_SUB];
-        count = (int64_t)A.offsets[((size_t)blockIdx.x + 1) * DSS_SUB] - src0;
-    } else {
+    bool use_list = false;
+    if (A.offsets != nullptr) {
+        // the three loads are independent; the DSS_SUB sub-lists of a tile are adjacent:
+        // [offsets[tile*SUB], offsets[(tile+1)*SUB])
+        const uint32_t ovf = *A.overflow;
+        const uint32_t o0 = A.offsets[(size_t)blockIdx.x * DSS_SUB];
+        const uint32_t o1 = A.offsets[((size_t)blockIdx.x + 1) * DSS_SUB];
+        use_list = ovf == 0u;
+        src0 = o0;
+        count = (int64_t)o1 - (int64_t)o0;
+    }
+    if (!use_list) {
         src0 = A.first_idx[n];
         count = A.num_pts[n];
+    }
+
+    // rows of the tile are contiguous runs of 16*K dwords in the (N,rows,S,K) tensors
+    const int K = A.K;
+    const int run = DSS_TILE * K;
+    const int c0 = tx * DSS_TILE;
+    const int valid_cols = min(DSS_TILE, S - c0) * K;
+    const int valid_rows = min(DSS_TILE, g.rows - ty * DSS_TILE);
+    const size_t tile_base = (((size_t)n * g.rows + (size_t)ty * DSS_TILE) * S + c0) * K;
+
+    if (count <= 0) {
+        // empty tile (most of the screen): stream the fill values, no LDS, no barriers
+        if (wid < valid_rows) {
+            const size_t rb = tile_base + (size_t)wid * S * K;
+            for (int cc = lane; cc < valid_cols; cc += 64) {
+                A.idx[rb + cc] = -1;
+                A.zbuf[rb + cc] = -1.0f;
+                A.qv[rb + cc] = -1.0f;
+            }
+            if (lane < min(DSS_TILE, S - c0))
+                A.occ[((size_t)n * g.rows + (size_t)ty * DSS_TILE + wid) * S + c0 + lane] = 0.0f;
+        }
+        return;
     }
 
     unsigned long long key[KMAX];
@@ -359,7 +391,6 @@ __global__ __launch_bounds__(FINE_THREADS) void fine_kernel(const FineArgs A)
     }
 
     // ---- epilogue (slice 0 lanes own the pixel): depth merge, occupancy, visibility, stores ----
-    const int K = A.K;
     const bool owner = slice == 0;
     const bool in_img = owner && (c < S) && (r < g.row0 + g.rows);
     float kz[KMAX];
@@ -386,30 +417,44 @@ __global__ __launch_bounds__(FINE_THREADS) void fine_kernel(const FineArgs A)
         }
     }
 
-    // rows of the tile are contiguous runs of 16*K dwords in the (N,rows,S,K) tensors: stage the
-    // tile through LDS and let each wavefront stream one full row
-    const int run = DSS_TILE * K;
-    const int c0 = tx * DSS_TILE;
-    const int valid_cols = min(DSS_TILE, S - c0) * K;
-    const int valid_rows = min(DSS_TILE, g.rows - ty * DSS_TILE);
-    const size_t tile_base = (((size_t)n * g.rows + (size_t)ty * DSS_TILE) * S + c0) * K;
+    // stage the tile through LDS and let each wavefront stream one full image row per plane
     const int lds_pix = (tr * DSS_TILE + tc) * K;
-
+    const size_t rb = tile_base + (size_t)wid * S * K;
+    if (PLANES == 3) {
+        __syncthreads();
+        if (owner) {
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k)
+                if (k < K) {
+                    s_out[0][lds_pix + k] = ki[k];
+                    s_out[PLANES - 1 > 0 ? 1 : 0][lds_pix + k] = __float_as_int(kz[k]);
+                    s_out[PLANES - 1][lds_pix + k] = __float_as_int(kq[k]);
+                }
+        }
+        __syncthreads();
+        if (wid < valid_rows) {
+            for (int cc = lane; cc < valid_cols; cc += 64) {
+                A.idx[rb + cc] = s_out[0][wid * run + cc];
+                reinterpret_cast<int *>(A.zbuf)[rb + cc] = s_out[PLANES - 1 > 0 ? 1 : 0][wid * run + cc];
+                reinterpret_cast<int *>(A.qv)[rb + cc] = s_out[PLANES - 1][wid * run + cc];
+            }
+        }
+    } else {
 #define DSS_STORE_PLANE(REGS, DST, CAST)                                                          \
     __syncthreads();                                                                              \
     if (owner) {                                                                                  \
-        _Pragma("unroll") for (int k = 0; k < KMAX; ++k) if (k < K) s_out[lds_pix + k] = CAST(REGS[k]); \
+        _Pragma("unroll") for (int k = 0; k < KMAX; ++k) if (k < K) s_out[0][lds_pix + k] = CAST(REGS[k]); \
     }                                                                                             \
     __syncthreads();                                                                              \
     if (wid < valid_rows) {                                                                       \
         for (int cc = lane; cc < valid_cols; cc += 64)                                            \
-            reinterpret_cast<int *>(DST)[tile_base + (size_t)wid * S * K + cc] = s_out[wid * run + cc]; \
+            reinterpret_cast<int *>(DST)[rb + cc] = s_out[0][wid * run + cc];                     \
     }
-
-    DSS_STORE_PLANE(ki, A.idx, (int))
-    DSS_STORE_PLANE(kz, A.zbuf, __float_as_int)
-    DSS_STORE_PLANE(kq, A.qv, __float_as_int)
+        DSS_STORE_PLANE(ki, A.idx, (int))
+        DSS_STORE_PLANE(kz, A.zbuf, __float_as_int)
+        DSS_STORE_PLANE(kq, A.qv, __float_as_int)
 #undef DSS_STORE_PLANE
+    }
 }
 
 template <int KMAX>
