@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void occ_backward_kernel(
     const float *__restrict__ points, const float *__restrict__ radii,
     const uint8_t *__restrict__ visible, const float *__restrict__ rs,
     const float *__restrict__ grad_occ, const int64_t *__restrict__ first_idx,
-    const int64_t *__restrict__ num_pts, int N, int64_t P, int S, int row0, int rows, int gstride,
+    const int64_t *__restrict__ num_pts, int N, int64_t P, int S, int row0, int rows, int gstride, float clip,
     float *__restrict__ grad_pts)
 {
     const int lane = threadIdx.x & 63;
@@ -236,6 +236,12 @@ __global__ __launch_bounds__(256) void occ_backward_kernel(
     gx = wave_sum(gx);
     gy = wave_sum(gy);
     if (lane == 0) {
+        if (clip > 0.0f) {
+            // fused per-point clip hook (rasterizer.py:667-673) when no zbuf gradient follows (z grad = 0)
+            const float nrm = sqrtf(gx * gx + gy * gy);
+            gx = gx / fmaxf(nrm, 1e-12f) * fminf(nrm, clip);
+            gy = gy / fmaxf(nrm, 1e-12f) * fminf(nrm, clip);
+        }
         grad_pts[3 * p] = gx;
         grad_pts[3 * p + 1] = gy;
         grad_pts[3 * p + 2] = 0.0f;
@@ -309,10 +315,10 @@ extern "C" int dss_backward_radius(const float *radii, const uint8_t *visible, c
     return check_launch("dss_backward_radius");
 }
 
-extern "C" int dss_occ_backward(const float *points, const float *radii, const uint8_t *visible,
-                                const float *rs, const float *grad_occ, const int64_t *first_idx,
-                                const int64_t *num_pts, int N, int64_t P, int S, int row0, int row1,
-                                int grad_pixel_stride, float *grad_pts, void *stream)
+static int occ_backward_impl(const float *points, const float *radii, const uint8_t *visible,
+                             const float *rs, const float *grad_occ, const int64_t *first_idx,
+                             const int64_t *num_pts, int N, int64_t P, int S, int row0, int row1,
+                             int grad_pixel_stride, float fused_clip, float *grad_pts, void *stream)
 {
     if (N <= 0 || P < 0 || S <= 0 || row0 < 0 || row1 > S || row0 >= row1 || grad_pixel_stride < 1) {
         set_error("dss_occ_backward: bad sizes N=%d P=%lld S=%d rows=[%d,%d)", N, (long long)P, S, row0, row1);
@@ -326,8 +332,18 @@ extern "C" int dss_occ_backward(const float *points, const float *radii, const u
     const long long blocks = (P + 3) / 4;
     if (blocks > 0x7fffffffll) { set_error("dss_occ_backward: P too large"); return DSS_ERR_UNSUPPORTED; }
     hipLaunchKernelGGL(occ_backward_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), points, radii,
-                       visible, rs, grad_occ, first_idx, num_pts, N, P, S, row0, row1 - row0, grad_pixel_stride, grad_pts);
+                       visible, rs, grad_occ, first_idx, num_pts, N, P, S, row0, row1 - row0, grad_pixel_stride, fused_clip,
+                       grad_pts);
     return check_launch("dss_occ_backward");
+}
+
+extern "C" int dss_occ_backward(const float *points, const float *radii, const uint8_t *visible,
+                                const float *rs, const float *grad_occ, const int64_t *first_idx,
+                                const int64_t *num_pts, int N, int64_t P, int S, int row0, int row1,
+                                int grad_pixel_stride, float *grad_pts, void *stream)
+{
+    return occ_backward_impl(points, radii, visible, rs, grad_occ, first_idx, num_pts, N, P, S, row0, row1,
+                             grad_pixel_stride, -1.0f, grad_pts, stream);
 }
 
 extern "C" int dss_zbuf_backward(const int32_t *idx, const float *grad_zbuf, int N, int rows, int S, int K,
@@ -374,10 +390,12 @@ extern "C" int dss_splat_backward(const float *points, const float *radii, const
     int rc = dss_backward_radius(radii, visible, first_idx, num_pts, N, P, radii_s, rs,
                                  reinterpret_cast<char *>(workspace) + rs_bytes, workspace_bytes - rs_bytes, stream);
     if (rc) return rc;
-    rc = dss_occ_backward(points, radii, visible, rs, grad_occ, first_idx, num_pts, N, P, S, 0, S, grad_pixel_stride,
-                          grad_pts, stream);
+    // without a zbuf gradient the z column is 0 and the clip hook is fused into the gather kernel
+    rc = occ_backward_impl(points, radii, visible, rs, grad_occ, first_idx, num_pts, N, P, S, 0, S, grad_pixel_stride,
+                           grad_zbuf ? -1.0f : clip, grad_pts, stream);
     if (rc) return rc;
-    if (grad_zbuf) {
+    if (!grad_zbuf) return DSS_OK;
+    {
         if (!idx) { set_error("dss_splat_backward: grad_zbuf given without idx"); return DSS_ERR_INVALID_ARGUMENT; }
         rc = dss_zbuf_backward(idx, grad_zbuf, N, S, S, K, grad_pts, stream);
         if (rc) return rc;

@@ -204,6 +204,24 @@ struct FineArgs {
 // rasterize_points_cpu.cpp:85 / oracle frag_less.  Empty slots hold ~0.
 #define KEY_EMPTY 0xffffffffffffffffull
 
+// Optional per-workgroup phase timestamps (tools/fine_timing.py builds a -DDSS_FINE_TIMING copy of the
+// library; never compiled into the shipped libdss_hip.so).
+#ifdef DSS_FINE_TIMING
+__device__ long long *g_fine_timing = nullptr;  // (blocks, 12) int64
+#define FT_MARK(slot)                                                                   \
+    do {                                                                                \
+        if (g_fine_timing && threadIdx.x == 0)                                          \
+            g_fine_timing[(size_t)blockIdx.x * 12 + (slot)] = (long long)__builtin_amdgcn_s_memtime(); \
+    } while (0)
+#define FT_VAL(slot, v)                                                                 \
+    do {                                                                                \
+        if (g_fine_timing && threadIdx.x == 0) g_fine_timing[(size_t)blockIdx.x * 12 + (slot)] = (long long)(v); \
+    } while (0)
+#else
+#define FT_MARK(slot)
+#define FT_VAL(slot, v)
+#endif
+
 // sorted insertion of (ekey, eq) into an ascending K-list held in registers; branch-free.
 template <int KMAX>
 __device__ __forceinline__ void klist_insert(unsigned long long (&key)[KMAX], float (&kq)[KMAX],
@@ -245,6 +263,8 @@ __global__ __launch_bounds__(FINE_THREADS, (KMAX <= 8 ? 2 : 1)) void fine_kernel
     constexpr int PLANES = (KMAX <= 8) ? 3 : 1;   // idx / zbuf / qvalue staged together when they fit
     __shared__ int s_out[PLANES][DSS_TILE_PIX * KMAX];
 
+    FT_MARK(0);
+    FT_VAL(8, __builtin_amdgcn_s_memrealtime());
     const TileGrid g = A.g;
     const int tiles = g.tiles_x * g.tiles_y;
     const int n = blockIdx.x / tiles;
@@ -292,6 +312,8 @@ __global__ __launch_bounds__(FINE_THREADS, (KMAX <= 8 ? 2 : 1)) void fine_kernel
     const int valid_rows = min(DSS_TILE, g.rows - ty * DSS_TILE);
     const size_t tile_base = (((size_t)n * g.rows + (size_t)ty * DSS_TILE) * S + c0) * K;
 
+    FT_MARK(1);
+    FT_VAL(10, count);
     if (count <= 0) {
         // empty tile (most of the screen): stream the fill values, no LDS, no barriers
         if (wid < valid_rows) {
@@ -304,6 +326,8 @@ __global__ __launch_bounds__(FINE_THREADS, (KMAX <= 8 ? 2 : 1)) void fine_kernel
             if (lane < min(DSS_TILE, S - c0))
                 A.occ[((size_t)n * g.rows + (size_t)ty * DSS_TILE + wid) * S + c0 + lane] = 0.0f;
         }
+        FT_MARK(7);
+        FT_VAL(9, __builtin_amdgcn_s_memrealtime());
         return;
     }
 
@@ -328,6 +352,7 @@ __global__ __launch_bounds__(FINE_THREADS, (KMAX <= 8 ? 2 : 1)) void fine_kernel
             s_zid[tid] = make_float2(pz, __int_as_float((int)p));
         }
         __syncthreads();
+        if (base == 0) FT_MARK(2);
         // ---- cull + compact: one candidate per lane, ballot, prefix popcount -> survivor list ----
         int nsurv = 0;
         for (int sub = 0; sub < m; sub += 64) {
@@ -351,6 +376,7 @@ __global__ __launch_bounds__(FINE_THREADS, (KMAX <= 8 ? 2 : 1)) void fine_kernel
         // same wavefront wrote and now reads `surv`: LDS ops of one wave complete in order; the wave
         // barrier only stops the compiler from moving the reads above the writes
         __builtin_amdgcn_wave_barrier();
+        if (base == 0) FT_MARK(3);
         // ---- test + insert: lane (pixel, slice) takes survivors slice, slice+4, ... ----
         const int trips = (nsurv + 3) >> 2;
         for (int it = 0; it < trips; ++it) {
@@ -364,16 +390,20 @@ __global__ __launch_bounds__(FINE_THREADS, (KMAX <= 8 ? 2 : 1)) void fine_kernel
             // rasterize_points.cu:92-101, same expression order (no FMA contraction)
             const float qval = el.x * dx * dx + el.y * dx * dy + el.z * dy * dy;
             const bool hit = live && !(fabsf(dx) > ge.z || fabsf(dy) > ge.w) && !(qval > el.w);
-            if (__ballot(hit) != 0ull) {
-                const unsigned long long ekey =
-                    hit ? (((unsigned long long)__float_as_uint(zi.x + 0.0f) << 32) |
-                           (unsigned long long)(unsigned)__float_as_int(zi.y))
-                        : KEY_EMPTY;
-                klist_insert<KMAX>(key, kq, ekey, qval);
-            }
+            const unsigned long long ekey =
+                hit ? (((unsigned long long)__float_as_uint(zi.x + 0.0f) << 32) |
+                       (unsigned long long)(unsigned)__float_as_int(zi.y))
+                    : KEY_EMPTY;
+            // A hit can only reach the output if it beats this lane's current K-th entry AND lies within
+            // the depth-merge threshold of the nearest entry seen so far (the final nearest is never
+            // farther, so dropping it now is exact: rasterize_points.cu:586-595 would drop it later).
+            const float znear_now = __uint_as_float((unsigned)(key[0] >> 32));
+            const bool useful = (ekey < key[KMAX - 1]) && !(key[0] != KEY_EMPTY && (zi.x - znear_now > A.thr));
+            if (__ballot(useful) != 0ull) klist_insert<KMAX>(key, kq, useful ? ekey : KEY_EMPTY, qval);
         }
     }
 
+    FT_MARK(4);
     // ---- merge the four candidate slices of every pixel (lanes 16 and 32 apart) ----
 #pragma unroll
     for (int xo = 16; xo <= 32; xo <<= 1) {
@@ -390,6 +420,7 @@ __global__ __launch_bounds__(FINE_THREADS, (KMAX <= 8 ? 2 : 1)) void fine_kernel
         for (int k = 0; k < KMAX; ++k) klist_insert<KMAX>(key, kq, okey[k], oq[k]);
     }
 
+    FT_MARK(5);
     // ---- epilogue (slice 0 lanes own the pixel): depth merge, occupancy, visibility, stores ----
     const bool owner = slice == 0;
     const bool in_img = owner && (c < S) && (r < g.row0 + g.rows);
@@ -455,6 +486,8 @@ __global__ __launch_bounds__(FINE_THREADS, (KMAX <= 8 ? 2 : 1)) void fine_kernel
         DSS_STORE_PLANE(kq, A.qv, __float_as_int)
 #undef DSS_STORE_PLANE
     }
+    FT_MARK(7);
+    FT_VAL(9, __builtin_amdgcn_s_memrealtime());
 }
 
 template <int KMAX>
@@ -663,3 +696,10 @@ extern "C" int dss_splat_forward(const float *points, const float *ellipse, cons
     return dss_splat_fine(points, ellipse, cutoff, radii, first_idx, num_pts, N, P, merge_thr, S, K, row0, row1, idx,
                           zbuf, qvalue, occ, visible, binned ? workspace : nullptr, workspace_bytes, stream);
 }
+
+#ifdef DSS_FINE_TIMING
+extern "C" __attribute__((visibility("default"))) int dss_debug_set_fine_timing(long long *buf)
+{
+    return hipMemcpyToSymbol(HIP_SYMBOL(dss::g_fine_timing), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
+}
+#endif
