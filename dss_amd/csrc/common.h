@@ -6,7 +6,7 @@
 #include "../../include/dss_hip.h"
 
 #define DSS_WAVE 64
-#define DSS_TILE 16          // screen tile side in pixels (one 256-thread workgroup per tile)
+#define DSS_TILE 8           // screen tile side in pixels (one 256-thread workgroup per tile)
 #define DSS_TILE_PIX (DSS_TILE * DSS_TILE)
 
 namespace dss {

@@ -3,12 +3,12 @@
 // Replaces the reference's naive / coarse / fine CUDA kernels
 // (DSS/csrc/rasterize_points.cu:131-212, 293-432, 506-597) with a different decomposition:
 //
-//   bin_count   one thread per splat: exact pixel rect -> 16x16 screen-tile rect, per-tile counts
+//   bin_count   one thread per splat: exact pixel rect -> 8x8 screen-tile rect, per-tile counts
 //   bin_scan    exclusive scan of the per-tile counts (compacted lists, no dense (N,B,B,M) table)
 //   bin_fill    one thread per splat: append its id to every tile list it overlaps
-//   fine        one 1024-thread workgroup per tile = sixteen wavefronts, one 4x4 pixel footprint
+//   fine        one 256-thread workgroup per tile = four wavefronts, one 4x4 pixel footprint
 //               each, four candidate slices per pixel.  Candidates are staged through LDS in
-//               chunks of 512; every wavefront culls the chunk against its footprint with one
+//               chunks of 256; every wavefront culls the chunk against its footprint with one
 //               ballot per 64 candidates and compacts the survivors (mbcnt prefix); every lane keeps
 //               the K nearest hits of its (pixel, slice) sorted in registers; the four slices are
 //               merged with xor-shuffles; results leave through an LDS transpose so that each image
@@ -25,7 +25,7 @@ namespace dss {
 // Same-address global atomics serialise (~50 ns each on MI355X: 523 splats on the hottest tile of
 // the bunny scene cost ~30 us); splitting cuts the depth of every hot address by DSS_SUB, and because
 // the sub-lists of one tile are adjacent in the scanned offset array the tile list stays contiguous.
-#define DSS_SUB 16
+#define DSS_SUB 8
 
 struct TileGrid {
     int S;        // image side
@@ -239,21 +239,22 @@ __device__ __forceinline__ void klist_insert(unsigned long long (&key)[KMAX], fl
     kq[0] = lt[0] ? eq : kq[0];
 }
 
-// Work decomposition of one 16x16 tile (one 1024-thread workgroup = 16 wavefronts):
-//   wavefront w  -> 4x4 pixel footprint (w%4, w/4) of the tile
+// Work decomposition of one 8x8 tile (one 256-thread workgroup = 4 wavefronts):
+//   wavefront w  -> 4x4 pixel footprint (w%2, w/2) of the tile
 //   lane l       -> pixel (l%16) of the footprint, candidate slice l/16 (4 slices)
 // A pixel's candidates are split 4 ways across lanes 16 apart; each lane keeps its own K-list and
-// the four lists are merged at the end with two xor-shuffle rounds.  The per-pixel serial chain is
-// what bounds this kernel at DSS sizes (the longest tile list, not bandwidth), and this layout cuts
-// it ~8x versus one lane per pixel walking a whole 8x8 quadrant's survivors.
-#define FINE_THREADS 1024
-#define FINE_WAVES 16
-#define CHUNK 512
+// the four lists are merged at the end with two xor-shuffle rounds.  At DSS sizes this kernel is
+// bound by instruction issue on the CUs that host the densest screen regions (tools/fine_timing.py),
+// not by bandwidth: small tiles spread a dense region over several CUs, and the candidate slices cut
+// the serial per-pixel chain 4x.
+#define FOOT 4
+#define FOOT_PER_ROW (DSS_TILE / FOOT)
+#define FINE_WAVES (FOOT_PER_ROW * FOOT_PER_ROW)
+#define FINE_THREADS (FINE_WAVES * 64)
+#define CHUNK FINE_THREADS
 
-// launch bounds: two resident workgroups per CU (8 waves/SIMD, <= 64 VGPRs) for the register-light
-// K <= 8 instantiations -- with one workgroup per CU the latency of a tile is fully exposed.
 template <int KMAX>
-__global__ __launch_bounds__(FINE_THREADS, (KMAX <= 8 ? 2 : 1)) void fine_kernel(const FineArgs A)
+__global__ __launch_bounds__(FINE_THREADS) void fine_kernel(const FineArgs A)
 {
     // candidate chunk: three records per splat -> 2x ds_read_b128 + 1x ds_read_b64 per test
     __shared__ float4 s_geo[CHUNK];   // px, py, rx, ry
@@ -272,16 +273,16 @@ __global__ __launch_bounds__(FINE_THREADS, (KMAX <= 8 ? 2 : 1)) void fine_kernel
     const int ty = t / g.tiles_x, tx = t - ty * g.tiles_x;
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int fx = wid & 3, fy = wid >> 2;            // footprint inside the tile
+    const int fx = wid % FOOT_PER_ROW, fy = wid / FOOT_PER_ROW;  // footprint inside the tile
     const int pl = lane & 15, slice = lane >> 4;      // pixel inside the footprint, candidate slice
-    const int tr = fy * 4 + (pl >> 2), tc = fx * 4 + (pl & 3);
+    const int tr = fy * FOOT + (pl >> 2), tc = fx * FOOT + (pl & 3);
     const int r = g.row0 + ty * DSS_TILE + tr;        // image row
     const int c = tx * DSS_TILE + tc;                 // image col
     const int S = g.S;
     const float xf = pix_to_ndc(S - 1 - c, S);
     const float yf = pix_to_ndc(S - 1 - r, S);
     // NDC extent of this wavefront's footprint (pixel centres).  NDC decreases with the image index.
-    const int fc0 = tx * DSS_TILE + fx * 4, fr0 = g.row0 + ty * DSS_TILE + fy * 4;
+    const int fc0 = tx * DSS_TILE + fx * FOOT, fr0 = g.row0 + ty * DSS_TILE + fy * FOOT;
     const float f_xmax = pix_to_ndc(S - 1 - fc0, S), f_xmin = pix_to_ndc(S - 1 - (fc0 + 3), S);
     const float f_ymax = pix_to_ndc(S - 1 - fr0, S), f_ymin = pix_to_ndc(S - 1 - (fr0 + 3), S);
 
@@ -316,15 +317,15 @@ __global__ __launch_bounds__(FINE_THREADS, (KMAX <= 8 ? 2 : 1)) void fine_kernel
     FT_VAL(10, count);
     if (count <= 0) {
         // empty tile (most of the screen): stream the fill values, no LDS, no barriers
-        if (wid < valid_rows) {
-            const size_t rb = tile_base + (size_t)wid * S * K;
+        for (int rr = wid; rr < valid_rows; rr += FINE_WAVES) {
+            const size_t rb = tile_base + (size_t)rr * S * K;
             for (int cc = lane; cc < valid_cols; cc += 64) {
                 A.idx[rb + cc] = -1;
                 A.zbuf[rb + cc] = -1.0f;
                 A.qv[rb + cc] = -1.0f;
             }
             if (lane < min(DSS_TILE, S - c0))
-                A.occ[((size_t)n * g.rows + (size_t)ty * DSS_TILE + wid) * S + c0 + lane] = 0.0f;
+                A.occ[((size_t)n * g.rows + (size_t)ty * DSS_TILE + rr) * S + c0 + lane] = 0.0f;
         }
         FT_MARK(7);
         FT_VAL(9, __builtin_amdgcn_s_memrealtime());
@@ -450,7 +451,6 @@ __global__ __launch_bounds__(FINE_THREADS, (KMAX <= 8 ? 2 : 1)) void fine_kernel
 
     // stage the tile through LDS and let each wavefront stream one full image row per plane
     const int lds_pix = (tr * DSS_TILE + tc) * K;
-    const size_t rb = tile_base + (size_t)wid * S * K;
     if (PLANES == 3) {
         __syncthreads();
         if (owner) {
@@ -463,11 +463,12 @@ __global__ __launch_bounds__(FINE_THREADS, (KMAX <= 8 ? 2 : 1)) void fine_kernel
                 }
         }
         __syncthreads();
-        if (wid < valid_rows) {
+        for (int rr = wid; rr < valid_rows; rr += FINE_WAVES) {
+            const size_t rb = tile_base + (size_t)rr * S * K;
             for (int cc = lane; cc < valid_cols; cc += 64) {
-                A.idx[rb + cc] = s_out[0][wid * run + cc];
-                reinterpret_cast<int *>(A.zbuf)[rb + cc] = s_out[PLANES - 1 > 0 ? 1 : 0][wid * run + cc];
-                reinterpret_cast<int *>(A.qv)[rb + cc] = s_out[PLANES - 1][wid * run + cc];
+                A.idx[rb + cc] = s_out[0][rr * run + cc];
+                reinterpret_cast<int *>(A.zbuf)[rb + cc] = s_out[PLANES - 1 > 0 ? 1 : 0][rr * run + cc];
+                reinterpret_cast<int *>(A.qv)[rb + cc] = s_out[PLANES - 1][rr * run + cc];
             }
         }
     } else {
@@ -477,9 +478,9 @@ __global__ __launch_bounds__(FINE_THREADS, (KMAX <= 8 ? 2 : 1)) void fine_kernel
         _Pragma("unroll") for (int k = 0; k < KMAX; ++k) if (k < K) s_out[0][lds_pix + k] = CAST(REGS[k]); \
     }                                                                                             \
     __syncthreads();                                                                              \
-    if (wid < valid_rows) {                                                                       \
+    for (int rr = wid; rr < valid_rows; rr += FINE_WAVES) {                                       \
         for (int cc = lane; cc < valid_cols; cc += 64)                                            \
-            reinterpret_cast<int *>(DST)[rb + cc] = s_out[0][wid * run + cc];                     \
+            reinterpret_cast<int *>(DST)[tile_base + (size_t)rr * S * K + cc] = s_out[0][rr * run + cc]; \
     }
         DSS_STORE_PLANE(ki, A.idx, (int))
         DSS_STORE_PLANE(kz, A.zbuf, __float_as_int)

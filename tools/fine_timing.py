@@ -28,7 +28,7 @@ dev = torch.device("cuda:0")
 lib = _lib.load()
 lib.dss_debug_set_fine_timing.argtypes = [ctypes.c_void_p]
 wl = bench.Workload(dev, 1, bench.RowPartition(bench.S, 1, 0))
-blocks = (bench.S // 16) ** 2
+blocks = (bench.S // 8) ** 2  # DSS_TILE = 8
 buf = torch.zeros((blocks, 12), dtype=torch.int64, device=dev)
 for _ in range(3):
     wl.fine_kernel_ms(iters=5)
