@@ -192,11 +192,16 @@ def main():
                              % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    local = local % torch.cuda.device_count()  # (BENCH_DIST_BACKEND=gloo lets two ranks share one GPU in tests)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     mode = args.mode or ("graph" if world == 1 else "eager")
 
     part = RowPartition(S, world, rank)
@@ -254,6 +259,11 @@ def main():
             other = (time.perf_counter() - t0) / 50 * 1e3
 
     fine_mean, fine_med = wl.fine_kernel_ms()
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", "traffic_fine_kernel.json")
+    if world == 1 and os.path.exists(tfile):
+        # HBM bytes per launch from rocprofv3 PMC passes of this same command (tools/collect_traffic.py)
+        traffic = json.load(open(tfile)).get("traffic_bytes_per_launch")
     r0, r1 = part.rows
     # algorithmic bytes of ONE fine-kernel launch (DESIGN.md "fine kernel"): every pixel of the band
     # writes idx+zbuf+qvalue (12K B) + occ (4 B); every splat's 36-B screen record (pos 12, ellipse 12,
@@ -272,7 +282,7 @@ def main():
                        "parallelism": "rows%d" % world, "launch": mode},
             "roofline": {"bound": "hbm", "kernel": "fine_kernel<5>", "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                         "traffic": None, "algorithmic_bytes": alg_bytes, "kernel_ms_mean": round(fine_mean, 5),
+                         "traffic": traffic, "algorithmic_bytes": alg_bytes, "kernel_ms_mean": round(fine_mean, 5),
                          "kernel_ms_median": round(fine_med, 5)},
         }
         if other is not None:

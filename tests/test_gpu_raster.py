@@ -274,3 +274,37 @@ def test_large_synthetic_properties():
     band = _fwd(d, S, K, thr, rows=(256, 640))
     assert torch.equal(band[0], idx[:, 256:640]) and torch.equal(band[3], occ[:, 256:640])
     assert occ.mean().item() > 0.2
+
+
+def test_bench_two_rank_row_partition_matches_single_rank(tmp_path):
+    """The N>1 path of bench.py (row bands + all-gather + visibility/grad reductions) on ONE GPU:
+    two ranks share cuda:0 over gloo; the gathered image and the reduced gradients must equal the
+    single-rank step (image bit-exact, gradients to fp32 reduction order)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = os.path.join(str(tmp_path), "two_rank.py")
+    open(script, "w").write('''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+import bench
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dev = torch.device("cuda:0"); torch.cuda.set_device(dev)
+dist.init_process_group("gloo")
+wl = bench.Workload(dev, world, bench.RowPartition(bench.S, world, rank))
+img, gw, gc = wl.step()
+ref = bench.Workload(dev, world, bench.RowPartition(bench.S, 1, 0))
+img1, gw1, gc1 = ref.step()
+torch.cuda.synchronize()
+assert torch.equal(img, img1), "gathered image differs from the single-rank render"
+rel = lambda a, b: float((a - b).norm() / b.norm())
+assert rel(gw, gw1) < 1e-5 and rel(gc, gc1) < 1e-5, (rel(gw, gw1), rel(gc, gc1))
+print("rank", rank, "ok", rel(gw, gw1), rel(gc, gc1))
+dist.destroy_process_group()
+''' % root)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29711", script],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    assert out.stdout.count(" ok ") == 2

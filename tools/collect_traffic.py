@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Developer tool (GPU box): HBM traffic of the dominant kernel from rocprofv3 PMC counters.
+
+Runs bench.py under rocprofv3 twice -- FETCH_SIZE and WRITE_SIZE in SEPARATE passes, with
+--kernel-trace only (MI355X_MICROARCH.md "rocprofv3 PMC slots": FETCH_SIZE costs 3 TCC slots,
+WRITE_SIZE 2; they do not fit one pass) -- and averages the counters over the fine_kernel
+dispatches.  Corrections per MI355X_MICROARCH.md "HBM": both counters are in KiB; on gfx950
+FETCH_SIZE reports half of the bytes of wide coalesced reads -> doubled; WRITE_SIZE is taken as is
+(uncalibrated).  Writes profiles/traffic_fine_kernel.json, which bench.py reports as
+roofline.traffic (bytes per launch)."""
+import csv
+import glob
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "gpurun_out", "traffic")
+KERNEL = "fine_kernel"
+
+
+def one_pass(counter):
+    d = os.path.join(OUT, counter)
+    os.makedirs(d, exist_ok=True)
+    env = dict(os.environ, TMPDIR="/tmp")
+    cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "--",
+           sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "eager", "--no-cpu-baseline", "--steps", "20",
+           "--warmup", "5"]
+    subprocess.run(cmd, cwd="/tmp", env=env, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    vals = []
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if KERNEL in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                vals.append(float(r["Counter_Value"]))
+    if not vals:
+        raise SystemExit("no %s samples for %s" % (counter, KERNEL))
+    return sum(vals) / len(vals), len(vals)
+
+
+def main():
+    fetch, nf = one_pass("FETCH_SIZE")
+    write, nw = one_pass("WRITE_SIZE")
+    rec = {"kernel": "fine_kernel<5>", "command": "bench.py --mode eager --steps 20 (BASELINE configs[1])",
+           "FETCH_SIZE_KiB_raw": fetch, "WRITE_SIZE_KiB_raw": write, "samples": [nf, nw],
+           "correction": "FETCH_SIZE x2 (gfx950 counts 128-B requests at 64 B), WRITE_SIZE as reported",
+           "traffic_bytes_per_launch": int((2.0 * fetch + write) * 1024)}
+    os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "traffic_fine_kernel.json"), "w") as f:
+        json.dump(rec, f, indent=1)
+    print(json.dumps(rec))
+
+
+if __name__ == "__main__":
+    main()
