@@ -199,38 +199,47 @@ __global__ __launch_bounds__(256) void occ_backward_kernel(
             const int lw_log = (w <= 8) ? 3 : (w <= 16) ? 4 : (w <= 32) ? 5 : 6;
             const int LW = 1 << lw_log, LH = 64 >> lw_log;
             const int lxx = lane & (LW - 1), lyy = lane >> lw_log;
-            const float *gbase = grad_occ + (size_t)n * rows * S * gstride;
+            // wave-uniform image base (SGPR) + 32-bit element offsets -> saddr-form loads, no 64-bit
+            // VALU address arithmetic in the loop (one band of one cloud is < 2^31 elements)
+            const int n_u = __builtin_amdgcn_readfirstlane(n);
+            const float *__restrict__ gimg = grad_occ + (size_t)n_u * rows * S * gstride;
+            const int rowstride = S * gstride;
+            const int rstep = LH * rowstride;
             const NdcMap ndc(S);
-            for (int xi = xlo + lxx; xi <= xhi; xi += LW) {
-                // column-invariant terms hoisted out of the row loop
-                const float dx = ndc(xi) - px;
-                const float dx2 = dx * dx;
-                const bool out_x = fabsf(dx) > rx;
-                const float *gcol = gbase + (size_t)(S - 1 - xi) * gstride;
-                // four rows per trip: the four loads are independent and issue back to back
-                for (int y0 = ylo + lyy; y0 <= yhi; y0 += 4 * LH) {
-                    float g[4];
+            if (ylo <= yhi) {
+                for (int xi = xlo + lxx; xi <= xhi; xi += LW) {
+                    // column-invariant terms hoisted out of the row loop
+                    const float dx = ndc(xi) - px;
+                    const float dx2 = dx * dx;
+                    const bool out_x = fabsf(dx) > rx;
+                    const int coff = (S - 1 - xi) * gstride - row0 * rowstride;
+                    // four rows per trip: the four loads are independent and issue back to back
+                    for (int y0 = ylo + lyy; y0 <= yhi; y0 += 4 * LH) {
+                        float g[4];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int yi = y0 + u * LH;
-                        g[u] = (yi <= yhi) ? gcol[(size_t)(S - 1 - yi - row0) * S * gstride] : 0.0f;
-                    }
+                        for (int u = 0; u < 4; ++u) {
+                            const int yc = min(y0 + u * LH, yhi);  // clamped: always a legal address
+                            g[u] = gimg[(S - 1 - yc) * rowstride + coff];
+                        }
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int yi = y0 + u * LH;
-                        const float dy = ndc(yi) - py;
-                        const float d2 = dx2 + dy * dy;
-                        // rasterize_points_backward.cu:151-168; d2 == 0 contributes 0 (see dss_hip.h)
-                        const bool outside = out_x || (fabsf(dy) > ry);
-                        const bool use = (g[u] != 0.0f) && !(d2 > cur_r2) && !(g[u] > 0.0f && outside) && (d2 != 0.0f);
-                        // dx / max(d2,1e-10) * g with a 1-ulp reciprocal (tolerance-checked, not bit-pinned:
-                        // the reference accumulates with unordered fp32 atomics anyway)
-                        const float s = use ? __builtin_amdgcn_rcpf(fmaxf(d2, 1e-10f)) * g[u] : 0.0f;
-                        gx += dx * s;
-                        gy += dy * s;
+                        for (int u = 0; u < 4; ++u) {
+                            const int yi = y0 + u * LH;
+                            const float dy = ndc(yi) - py;
+                            const float d2 = dx2 + dy * dy;
+                            // rasterize_points_backward.cu:151-168; d2 == 0 contributes 0 (see dss_hip.h)
+                            const bool outside = out_x || (fabsf(dy) > ry);
+                            const bool use = (yi <= yhi) && (g[u] != 0.0f) && !(d2 > cur_r2) &&
+                                             !(g[u] > 0.0f && outside) && (d2 != 0.0f);
+                            // dx / max(d2,1e-10) * g with a 1-ulp reciprocal (tolerance-checked, not
+                            // bit-pinned: the reference accumulates with unordered fp32 atomics anyway)
+                            const float sgl = use ? __builtin_amdgcn_rcpf(fmaxf(d2, 1e-10f)) * g[u] : 0.0f;
+                            gx += dx * sgl;
+                            gy += dy * sgl;
+                        }
                     }
                 }
             }
+            (void)rstep;
         }
     }
     gx = wave_sum(gx);

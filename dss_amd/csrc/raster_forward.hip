@@ -48,10 +48,11 @@ __device__ __forceinline__ bool splat_tile_rect(float px, float py, float pz, fl
     if (!ndc_index_range(px, rx, g.S, xlo, xhi)) return false;
     if (!ndc_index_range(py, ry, g.S, ylo, yhi)) return false;
     // tighten with the exact per-pixel predicate (monotone in the pixel index)
-    while (xlo <= xhi && fabsf(pix_to_ndc(xlo, g.S) - px) > rx) ++xlo;
-    while (xhi >= xlo && fabsf(pix_to_ndc(xhi, g.S) - px) > rx) --xhi;
-    while (ylo <= yhi && fabsf(pix_to_ndc(ylo, g.S) - py) > ry) ++ylo;
-    while (yhi >= ylo && fabsf(pix_to_ndc(yhi, g.S) - py) > ry) --yhi;
+    const NdcMap ndc(g.S);
+    while (xlo <= xhi && fabsf(ndc(xlo) - px) > rx) ++xlo;
+    while (xhi >= xlo && fabsf(ndc(xhi) - px) > rx) --xhi;
+    while (ylo <= yhi && fabsf(ndc(ylo) - py) > ry) ++ylo;
+    while (yhi >= ylo && fabsf(ndc(yhi) - py) > ry) --yhi;
     if (xlo > xhi || ylo > yhi) return false;
     const int c0 = g.S - 1 - xhi, c1 = g.S - 1 - xlo;
     int r0 = g.S - 1 - yhi, r1 = g.S - 1 - ylo;
@@ -92,32 +93,33 @@ __global__ __launch_bounds__(256) void bin_count_kernel(
 }
 
 // Exclusive scan of the (n_tiles x DSS_SUB) counters by ONE workgroup of 1024 threads; every thread
-// owns the DSS_SUB counters of one tile (64 contiguous bytes) per trip.  Writes offsets[0..n*SUB]
-// (last = total) and cursor[i] = offsets[i]; sets *overflow = 1 when the total exceeds `capacity`
-// (the fine kernel then scans whole clouds instead of lists).
+// owns SCAN_TPT consecutive tiles (SCAN_TPT * DSS_SUB counters = 128 contiguous bytes) per trip, so a
+// 512^2 image (4096 tiles) is one trip.  Writes offsets[0..n*SUB] (last = total) and
+// cursor[i] = offsets[i]; sets *overflow = 1 when the total exceeds `capacity` (the fine kernel
+// then scans whole clouds instead of lists).
+#define SCAN_TPT 4
 __global__ __launch_bounds__(1024) void bin_scan_kernel(const uint32_t *__restrict__ count, int n_tiles,
                                                         uint32_t *__restrict__ offsets,
                                                         uint32_t *__restrict__ cursor,
                                                         uint32_t capacity, uint32_t *__restrict__ overflow)
 {
+    constexpr int CPT = SCAN_TPT * DSS_SUB;  // counters per thread per trip
     __shared__ uint32_t wave_tot[16];
     __shared__ uint32_t carry_s;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const long long n_cnt = (long long)n_tiles * DSS_SUB;
     if (tid == 0) carry_s = 0;
     __syncthreads();
-    for (int base = 0; base < n_tiles; base += 1024) {
-        const int t = base + tid;
-        uint32_t c[DSS_SUB];
+    for (long long base = 0; base < n_cnt; base += 1024ll * CPT) {
+        const long long i0 = base + (long long)tid * CPT;
+        uint32_t c[CPT];
         uint32_t v = 0;
-        if (t < n_tiles) {
-            const uint4 *src = reinterpret_cast<const uint4 *>(count + (size_t)t * DSS_SUB);
 #pragma unroll
-            for (int q = 0; q < DSS_SUB / 4; ++q) {
-                const uint4 u = src[q];
-                c[4 * q] = u.x; c[4 * q + 1] = u.y; c[4 * q + 2] = u.z; c[4 * q + 3] = u.w;
-            }
-#pragma unroll
-            for (int q = 0; q < DSS_SUB; ++q) v += c[q];
+        for (int q = 0; q < CPT / 4; ++q) {
+            uint4 u = make_uint4(0, 0, 0, 0);
+            if (i0 + 4 * q < n_cnt) u = reinterpret_cast<const uint4 *>(count + i0)[q];  // n_cnt % 4 == 0
+            c[4 * q] = u.x; c[4 * q + 1] = u.y; c[4 * q + 2] = u.z; c[4 * q + 3] = u.w;
+            v += u.x + u.y + u.z + u.w;
         }
         uint32_t x = v;  // inclusive scan inside the wave
 #pragma unroll
@@ -130,21 +132,17 @@ __global__ __launch_bounds__(1024) void bin_scan_kernel(const uint32_t *__restri
         uint32_t wave_off = 0;
         for (int w = 0; w < wid; ++w) wave_off += wave_tot[w];
         const uint32_t excl = carry_s + wave_off + x - v;
-        if (t < n_tiles) {
-            uint32_t run = excl;
-            uint32_t o[DSS_SUB];
+        uint32_t run = excl;
 #pragma unroll
-            for (int q = 0; q < DSS_SUB; ++q) {
-                o[q] = run;
-                run += c[q];
-            }
-            uint4 *d0 = reinterpret_cast<uint4 *>(offsets + (size_t)t * DSS_SUB);
-            uint4 *d1 = reinterpret_cast<uint4 *>(cursor + (size_t)t * DSS_SUB);
-#pragma unroll
-            for (int q = 0; q < DSS_SUB / 4; ++q) {
-                const uint4 u = make_uint4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
-                d0[q] = u;
-                d1[q] = u;
+        for (int q = 0; q < CPT / 4; ++q) {
+            uint4 u;
+            u.x = run; run += c[4 * q];
+            u.y = run; run += c[4 * q + 1];
+            u.z = run; run += c[4 * q + 2];
+            u.w = run; run += c[4 * q + 3];
+            if (i0 + 4 * q < n_cnt) {
+                reinterpret_cast<uint4 *>(offsets + i0)[q] = u;
+                reinterpret_cast<uint4 *>(cursor + i0)[q] = u;
             }
         }
         __syncthreads();
@@ -153,7 +151,7 @@ __global__ __launch_bounds__(1024) void bin_scan_kernel(const uint32_t *__restri
     }
     if (tid == 0) {
         const uint32_t total = carry_s;
-        offsets[(size_t)n_tiles * DSS_SUB] = total;
+        offsets[n_cnt] = total;
         *overflow = (total > capacity) ? 1u : 0u;
     }
 }
@@ -172,9 +170,25 @@ __global__ __launch_bounds__(256) void bin_fill_kernel(
     const int n = find_cloud(p, first_idx, num_pts, N);
     const int tx0 = rc.x & 0xffff, tx1 = rc.x >> 16, ty0 = rc.y & 0xffff, ty1 = rc.y >> 16;
     uint32_t *cur = cursor + ((size_t)n * g.tiles_x * g.tiles_y) * DSS_SUB + ((unsigned)p & (DSS_SUB - 1));
+    if (tx1 - tx0 <= 1 && ty1 - ty0 <= 1) {
+        // common case (splat overlaps at most 2x2 tiles): the returning atomics are independent, issue
+        // them back to back so their latencies overlap instead of chaining
+        const int t00 = ty0 * g.tiles_x + tx0;
+        const bool hx = tx1 > tx0, hy = ty1 > ty0;
+        uint32_t p0, p1 = 0, p2 = 0, p3 = 0;
+        p0 = atomicAdd(&cur[(size_t)t00 * DSS_SUB], 1u);
+        if (hx) p1 = atomicAdd(&cur[(size_t)(t00 + 1) * DSS_SUB], 1u);
+        if (hy) p2 = atomicAdd(&cur[(size_t)(t00 + g.tiles_x) * DSS_SUB], 1u);
+        if (hx && hy) p3 = atomicAdd(&cur[(size_t)(t00 + g.tiles_x + 1) * DSS_SUB], 1u);
+        list[p0] = (int32_t)p;
+        if (hx) list[p1] = (int32_t)p;
+        if (hy) list[p2] = (int32_t)p;
+        if (hx && hy) list[p3] = (int32_t)p;
+        return;
+    }
     for (int ty = ty0; ty <= ty1; ++ty)
         for (int tx = tx0; tx <= tx1; ++tx) {
-            const uint32_t pos = atomicAdd(&cur[(ty * g.tiles_x + tx) * DSS_SUB], 1u);
+            const uint32_t pos = atomicAdd(&cur[(size_t)(ty * g.tiles_x + tx) * DSS_SUB], 1u);
             list[pos] = (int32_t)p;
         }
 }
