@@ -349,10 +349,10 @@ static int occ_backward_impl(const float *points, const float *radii, const uint
 extern "C" int dss_occ_backward(const float *points, const float *radii, const uint8_t *visible,
                                 const float *rs, const float *grad_occ, const int64_t *first_idx,
                                 const int64_t *num_pts, int N, int64_t P, int S, int row0, int row1,
-                                int grad_pixel_stride, float *grad_pts, void *stream)
+                                int grad_pixel_stride, float clip, float *grad_pts, void *stream)
 {
     return occ_backward_impl(points, radii, visible, rs, grad_occ, first_idx, num_pts, N, P, S, row0, row1,
-                             grad_pixel_stride, -1.0f, grad_pts, stream);
+                             grad_pixel_stride, clip, grad_pts, stream);
 }
 
 extern "C" int dss_zbuf_backward(const int32_t *idx, const float *grad_zbuf, int N, int rows, int S, int K,

@@ -93,11 +93,10 @@ __global__ __launch_bounds__(256) void bin_count_kernel(
 }
 
 // Exclusive scan of the (n_tiles x DSS_SUB) counters by ONE workgroup of 1024 threads; every thread
-// owns SCAN_TPT consecutive tiles (SCAN_TPT * DSS_SUB counters = 128 contiguous bytes) per trip, so a
-// 512^2 image (4096 tiles) is one trip.  Writes offsets[0..n*SUB] (last = total) and
+// owns SCAN_TPT consecutive tiles (SCAN_TPT * DSS_SUB counters) per trip.  Writes offsets[0..n*SUB] (last = total) and
 // cursor[i] = offsets[i]; sets *overflow = 1 when the total exceeds `capacity` (the fine kernel
 // then scans whole clouds instead of lists).
-#define SCAN_TPT 4
+#define SCAN_TPT 1   // measured: 4 tiles (128 B) per thread is slower (14 us vs 8 us at 4096 tiles): lane stride kills coalescing
 __global__ __launch_bounds__(1024) void bin_scan_kernel(const uint32_t *__restrict__ count, int n_tiles,
                                                         uint32_t *__restrict__ offsets,
                                                         uint32_t *__restrict__ cursor,

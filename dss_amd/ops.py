@@ -118,10 +118,11 @@ def _pixel_strided(t, N, rows, S):
 
 
 def occ_backward(points, radii, visible, rs, grad_occ, cloud_to_packed_first_idx, num_points_per_cloud,
-                 image_size: Optional[int] = None, rows: Optional[Tuple[int, int]] = None):
+                 image_size: Optional[int] = None, rows: Optional[Tuple[int, int]] = None, clip: float = -1.0):
     """Occupancy surrogate gradient -> (P,3) with z column 0.  Replaces the FRNN grid build
     (rasterizer.py:889-950) + ``DSS._C._splat_points_occ_fast_cuda_backward`` (ext.cpp:14).
-    ``grad_occ`` may be a strided channel view of an image gradient (read in place)."""
+    ``grad_occ`` may be a strided channel view of an image gradient (read in place).  ``clip > 0`` fuses
+    the per-point clip hook (valid only when no zbuf gradient / cross-rank reduction follows)."""
     lib = _lib.load()
     points = _lib.require_gpu(points, "points", _f32)
     dev = points.device
@@ -139,8 +140,8 @@ def occ_backward(points, radii, visible, rs, grad_occ, cloud_to_packed_first_idx
     with torch.cuda.device(dev):
         grad = torch.empty((P, 3), dtype=_f32, device=dev)
         rc = lib.dss_occ_backward(_lib.ptr(points), _lib.ptr(radii), _lib.ptr(vis), _lib.ptr(rs), _lib.ptr(grad_occ),
-                                  _lib.ptr(first), _lib.ptr(num), N, P, S, row0, row1, gstride, _lib.ptr(grad),
-                                  _lib.stream_ptr(dev))
+                                  _lib.ptr(first), _lib.ptr(num), N, P, S, row0, row1, gstride, float(clip),
+                                  _lib.ptr(grad), _lib.stream_ptr(dev))
     _lib.check(rc, "dss_occ_backward")
     return grad
 

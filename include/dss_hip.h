@@ -119,12 +119,14 @@ DSS_API int dss_backward_radius(const float *radii, const uint8_t *visible, cons
  * Writes grad_pts[:,0:2] for ALL points (0 for invisible ones) and sets grad_pts[:,2] = 0.
  * grad_pixel_stride: elements between consecutive pixels of grad_occ (1 = dense (N,rows,S); C+1 =
  * read the alpha channel of an (N,rows,S,C+1) image gradient in place, no copy).
+ * clip > 0 fuses the per-point clip hook (dss_clip_grad) into the final store; only valid when no
+ * zbuf gradient and no cross-rank reduction follows (single GPU, grad_zbuf == NULL).  Pass <= 0 otherwise.
  * Gather formulation: one wavefront per point, no atomics, deterministic. */
 DSS_API int dss_occ_backward(const float *points, const float *radii, const uint8_t *visible,
                      const float *rs, const float *grad_occ /* (N,rows,S) */,
                      const int64_t *first_idx, const int64_t *num_pts, int N, int64_t P, int S,
-                     int row0, int row1, int grad_pixel_stride, float *grad_pts /* (P,3) */,
-                     void *stream);
+                     int row0, int row1, int grad_pixel_stride, float clip,
+                     float *grad_pts /* (P,3) */, void *stream);
 
 /* Replaces DSS._C._backward_zbuf (ext.cpp:17, rasterize_points.cu:823-846): accumulates IN PLACE
  * z_grad[idx[n,r,c,k]] += grad_zbuf[n,r,c,k] (zero grads skipped, stop at first idx<0), into the
