@@ -66,7 +66,6 @@ class Workload:
         self.num = torch.full((self.N,), self.Pc, device=device, dtype=torch.int64)
         g = torch.Generator(device="cpu").manual_seed(1)
         self.grad_out = torch.randn((self.N, S, S, 4), generator=g).to(device)  # d loss / d RGBA
-        self.side = torch.cuda.Stream(device=device)
 
     def step(self):
         p = self.part
@@ -80,17 +79,12 @@ class Workload:
         g_band = p.slice(self.grad_out).contiguous() if p.world_size > 1 else self.grad_out
         geom = (info["pts_screen"], info["radii"], vis, self.first, self.num)
         if p.world_size == 1:
-            # the radix-select median (4 tiny launches) only needs `visible`: run it on a side stream so it
-            # overlaps the blend kernels (separate branch of the captured hipGraph)
-            main = torch.cuda.current_stream()
-            self.side.wait_stream(main)
-            with torch.cuda.stream(self.side):
-                rs = ops.backward_radius(info["radii"], vis, self.first, self.num, RADII_S)
+            # (running the median on a side stream / graph branch was measured: no gain, ROCm replays the
+            # graph's kernel nodes back to back)
             g_feat, g_occ = ops.blend_backward(g_band, idx, qv, info["scaler"], self.P, geometry=geom, wsum=wsum,
                                                image_size=S, rows=p.rows)
-            main.wait_stream(self.side)
-            g_pts = ops.occ_backward(info["pts_screen"], info["radii"], vis, rs, g_occ, self.first, self.num,
-                                     image_size=S, rows=p.rows, clip=CLIP)
+            g_pts = ops.splat_backward(info["pts_screen"], info["radii"], vis, idx, g_occ, None, self.first,
+                                       self.num, RADII_S, CLIP)
         else:
             g_feat, g_occ = ops.blend_backward(g_band, idx, qv, info["scaler"], self.P, geometry=geom, wsum=wsum,
                                                image_size=S, rows=p.rows)
