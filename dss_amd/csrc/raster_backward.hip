@@ -164,6 +164,20 @@ __global__ __launch_bounds__(MED_THREADS) void median_final_kernel(const uint32_
 // ---------------------------------------------------------------------------------------------
 // Occupancy surrogate gradient: one wavefront per point.
 // ---------------------------------------------------------------------------------------------
+#ifdef DSS_FINE_TIMING
+__device__ long long *g_occ_timing = nullptr;  // (P, 6) int64, developer tool only (tools/occ_timing.py)
+#define OT_MARK(slot)                                                                              \
+    do {                                                                                           \
+        if (g_occ_timing && (threadIdx.x & 63) == 0) g_occ_timing[p * 6 + (slot)] = (long long)__builtin_amdgcn_s_memtime(); \
+    } while (0)
+#define OT_VAL(slot, v)                                                                            \
+    do {                                                                                           \
+        if (g_occ_timing && (threadIdx.x & 63) == 0) g_occ_timing[p * 6 + (slot)] = (long long)(v); \
+    } while (0)
+#else
+#define OT_MARK(slot)
+#define OT_VAL(slot, v)
+#endif
 __global__ __launch_bounds__(256) void occ_backward_kernel(
     const float *__restrict__ points, const float *__restrict__ radii,
     const uint8_t *__restrict__ visible, const float *__restrict__ rs,
@@ -174,6 +188,8 @@ __global__ __launch_bounds__(256) void occ_backward_kernel(
     const int lane = threadIdx.x & 63;
     const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (p >= P) return;
+    OT_MARK(0);
+    OT_VAL(4, __builtin_amdgcn_s_memrealtime());
     float gx = 0.0f, gy = 0.0f;
     bool act = visible[p] != 0;
     int n = -1;
@@ -191,6 +207,7 @@ __global__ __launch_bounds__(256) void occ_backward_kernel(
         int xlo, xhi, ylo, yhi;
         act = act && ndc_index_range(px, cur_r, S, xlo, xhi) && ndc_index_range(py, cur_r, S, ylo, yhi);
         if (act) {
+            OT_MARK(1);
             // band rows: image row = S-1-yi in [row0, row0+rows)
             ylo = max(ylo, S - row0 - rows);
             yhi = min(yhi, S - 1 - row0);
@@ -242,8 +259,11 @@ __global__ __launch_bounds__(256) void occ_backward_kernel(
             (void)rstep;
         }
     }
+    OT_MARK(2);
     gx = wave_sum(gx);
     gy = wave_sum(gy);
+    OT_MARK(3);
+    OT_VAL(5, __builtin_amdgcn_s_memrealtime());
     if (lane == 0) {
         if (clip > 0.0f) {
             // fused per-point clip hook (rasterizer.py:667-673) when no zbuf gradient follows (z grad = 0)
@@ -411,3 +431,10 @@ extern "C" int dss_splat_backward(const float *points, const float *radii, const
     }
     return dss_clip_grad(grad_pts, P, clip, stream);
 }
+
+#ifdef DSS_FINE_TIMING
+extern "C" __attribute__((visibility("default"))) int dss_debug_set_occ_timing(long long *buf)
+{
+    return hipMemcpyToSymbol(HIP_SYMBOL(dss::g_occ_timing), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
+}
+#endif
