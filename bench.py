@@ -79,12 +79,9 @@ class Workload:
         g_band = p.slice(self.grad_out).contiguous() if p.world_size > 1 else self.grad_out
         geom = (info["pts_screen"], info["radii"], vis, self.first, self.num)
         if p.world_size == 1:
-            # (running the median on a side stream / graph branch was measured: no gain, ROCm replays the
-            # graph's kernel nodes back to back)
-            g_feat, g_occ = ops.blend_backward(g_band, idx, qv, info["scaler"], self.P, geometry=geom, wsum=wsum,
-                                               image_size=S, rows=p.rows)
-            g_pts = ops.splat_backward(info["pts_screen"], info["radii"], vis, idx, g_occ, None, self.first,
-                                       self.num, RADII_S, CLIP)
+            # fused backward: persistent wavefronts over the compacted visible list (dss_render_backward)
+            g_feat, g_pts = ops.render_backward(g_band, idx, qv, wsum, info["scaler"], info["pts_screen"],
+                                                info["radii"], vis, self.first, self.num, RADII_S, CLIP)
         else:
             g_feat, g_occ = ops.blend_backward(g_band, idx, qv, info["scaler"], self.P, geometry=geom, wsum=wsum,
                                                image_size=S, rows=p.rows)

@@ -5,11 +5,9 @@
 //   w_k   = exp(-0.5*Q_k) * scaler[idx_k]
 //   img   = sum_k feat[idx_k] * w_k / max(sum_k w_k, 1e-4)      (norm_weighted_sum, kEpsilon = 1e-4)
 //   out   = (img, occ)
-#include "common.h"
+#include "point_bodies.h"
 
 namespace dss {
-
-#define BLEND_MAX_C 8
 
 template <int C>
 __global__ __launch_bounds__(256) void blend_forward_kernel(
@@ -71,55 +69,10 @@ __global__ __launch_bounds__(256) void blend_backward_kernel(
     float acc[CM];
 #pragma unroll
     for (int ch = 0; ch < CM; ++ch) acc[ch] = 0.0f;
-    bool act = visible[p] != 0;
-    int n = -1;
-    if (act) {
-        n = find_cloud(p, first_idx, num_pts, N);
-        act = n >= 0;
-    }
-    if (act) {
-        const float px = points[3 * p], py = points[3 * p + 1];
-        const float rx = radii[2 * p], ry = radii[2 * p + 1];
-        const float sc = scaler[p];
-        int xlo, xhi, ylo, yhi;
-        act = ndc_index_range(px, rx, S, xlo, xhi) && ndc_index_range(py, ry, S, ylo, yhi);
-        if (act) {
-            ylo = max(ylo, S - row0 - rows);
-            yhi = min(yhi, S - 1 - row0);
-            const int w = xhi - xlo + 1;
-            const int lw_log = (w <= 8) ? 3 : (w <= 16) ? 4 : (w <= 32) ? 5 : 6;
-            const int LW = 1 << lw_log, LH = 64 >> lw_log;
-            const int lxx = lane & (LW - 1), lyy = lane >> lw_log;
-            for (int yi = ylo + lyy; yi <= yhi; yi += LH) {
-                const size_t rowbase = ((size_t)n * rows + (S - 1 - yi - row0)) * S;
-                for (int xi = xlo + lxx; xi <= xhi; xi += LW) {
-                    const size_t pix = rowbase + (S - 1 - xi);
-                    const int32_t *pi = idx + pix * K;
-                    int kk = -1;
-                    for (int k = 0; k < K; ++k) {
-                        const int32_t v = pi[k];
-                        if (v == (int32_t)p) kk = k;
-                    }
-                    if (kk < 0) continue;
-                    float cum;
-                    if (wsum) {
-                        cum = wsum[pix];
-                    } else {
-                        cum = 0.0f;
-                        for (int k = 0; k < K; ++k) {
-                            const int32_t v = pi[k];
-                            if (v >= 0) cum += expf(-0.5f * qv[pix * K + k]) * scaler[v];
-                        }
-                        if (cum < 1e-4f) cum = 1e-4f;
-                    }
-                    const float wgt = expf(-0.5f * qv[pix * K + kk]) * sc;
-                    const float *go = grad_out + pix * (Cn + 1);
-#pragma unroll
-                    for (int ch = 0; ch < CM; ++ch)
-                        if (ch < Cn) acc[ch] += go[ch] * wgt / cum;
-                }
-            }
-        }
+    if (visible[p] != 0) {
+        const int n = find_cloud(p, first_idx, num_pts, N);
+        if (n >= 0)
+            blend_point_gather<C>(lane, p, n, grad_out, idx, qv, wsum, scaler, points, radii, S, K, Cn, row0, rows, acc);
     }
 #pragma unroll
     for (int ch = 0; ch < CM; ++ch) {

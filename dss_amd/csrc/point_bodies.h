@@ -1,0 +1,135 @@
+// Per-point gather bodies shared by the stand-alone backward kernels (one wavefront per packed point)
+// and by the fused persistent backward kernel (wavefronts loop over the compacted visible list).
+// Both are executed by a full wavefront for ONE point; results are per-lane partial sums that the
+// caller reduces with wave_sum().
+#pragma once
+#include "common.h"
+
+namespace dss {
+
+#define BLEND_MAX_C 8
+
+// lane tiling of a W-column pixel window: LW columns x (64/LW) rows per sweep
+struct LaneTiling {
+    int LW, LH, lxx, lyy;
+    __device__ __forceinline__ LaneTiling(int w, int lane)
+    {
+        const int lw_log = (w <= 8) ? 3 : (w <= 16) ? 4 : (w <= 32) ? 5 : 6;
+        LW = 1 << lw_log;
+        LH = 64 >> lw_log;
+        lxx = lane & (LW - 1);
+        lyy = lane >> lw_log;
+    }
+};
+
+// Occupancy surrogate gradient of point p (cloud n) over the band rows [row0, row0+rows):
+//   for every pixel with g = grad_occ != 0 and d2 = dx^2+dy^2 <= rs^2:
+//       skip if g>0 and (|dx|>rx or |dy|>ry);  (gx,gy) += (dx,dy)/max(d2,1e-10)*g
+// (rasterize_points_backward.cu:141-178; a pair with d2 == 0 contributes 0, see dss_hip.h).
+// grad_occ is read with an element stride `gstride` per pixel (alpha channel of an image gradient).
+__device__ __forceinline__ void occ_point_gather(int lane, int64_t p, int n, const float *__restrict__ points,
+                                                 const float *__restrict__ radii, const float *__restrict__ rs,
+                                                 const float *__restrict__ grad_occ, int S, int row0, int rows,
+                                                 int gstride, float &gx, float &gy)
+{
+    const float px = points[3 * p], py = points[3 * p + 1], pz = points[3 * p + 2];
+    const float rx = radii[2 * p], ry = radii[2 * p + 1];
+    const float cur_r = rs[n];
+    const float cur_r2 = cur_r * cur_r;
+    // rasterize_points_backward.cu:141-143
+    if (pz < 0 || fabsf(py) > 1.0f || fabsf(px) > 1.0f) return;
+    int xlo, xhi, ylo, yhi;
+    if (!ndc_index_range(px, cur_r, S, xlo, xhi) || !ndc_index_range(py, cur_r, S, ylo, yhi)) return;
+    // band rows: image row = S-1-yi in [row0, row0+rows)
+    ylo = max(ylo, S - row0 - rows);
+    yhi = min(yhi, S - 1 - row0);
+    if (ylo > yhi) return;
+    const LaneTiling T(xhi - xlo + 1, lane);
+    // wave-uniform image base (SGPR) + 32-bit element offsets (one band of one cloud is < 2^31 elements)
+    const int n_u = __builtin_amdgcn_readfirstlane(n);
+    const float *__restrict__ gimg = grad_occ + (size_t)n_u * rows * S * gstride;
+    const int rowstride = S * gstride;
+    const NdcMap ndc(S);
+    for (int xi = xlo + T.lxx; xi <= xhi; xi += T.LW) {
+        // column-invariant terms hoisted out of the row loop
+        const float dx = ndc(xi) - px;
+        const float dx2 = dx * dx;
+        const bool out_x = fabsf(dx) > rx;
+        const int coff = (S - 1 - xi) * gstride - row0 * rowstride;
+        // four rows per trip: the four loads are independent and issue back to back
+        for (int y0 = ylo + T.lyy; y0 <= yhi; y0 += 4 * T.LH) {
+            float g[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int yc = min(y0 + u * T.LH, yhi);  // clamped: always a legal address
+                g[u] = gimg[(S - 1 - yc) * rowstride + coff];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int yi = y0 + u * T.LH;
+                const float dy = ndc(yi) - py;
+                const float d2 = dx2 + dy * dy;
+                const bool outside = out_x || (fabsf(dy) > ry);
+                const bool use = (yi <= yhi) && (g[u] != 0.0f) && !(d2 > cur_r2) && !(g[u] > 0.0f && outside) &&
+                                 (d2 != 0.0f);
+                // dx / max(d2,1e-10) * g with a 1-ulp reciprocal (tolerance-checked, not bit-pinned: the
+                // reference accumulates with unordered fp32 atomics anyway)
+                const float sgl = use ? __builtin_amdgcn_rcpf(fmaxf(d2, 1e-10f)) * g[u] : 0.0f;
+                gx += dx * sgl;
+                gy += dy * sgl;
+            }
+        }
+    }
+}
+
+// Blend backward of point p: sum over the pixels of the point's own bounding box (a fragment with
+// idx == p can only exist where the hit test passed) of grad_out * w / wsum.
+template <int C>
+__device__ __forceinline__ void blend_point_gather(int lane, int64_t p, int n, const float *__restrict__ grad_out,
+                                                   const int32_t *__restrict__ idx, const float *__restrict__ qv,
+                                                   const float *__restrict__ wsum, const float *__restrict__ scaler,
+                                                   const float *__restrict__ points, const float *__restrict__ radii,
+                                                   int S, int K, int Cn, int row0, int rows,
+                                                   float (&acc)[(C > 0) ? C : BLEND_MAX_C])
+{
+    constexpr int CM = (C > 0) ? C : BLEND_MAX_C;
+    const float px = points[3 * p], py = points[3 * p + 1];
+    const float rx = radii[2 * p], ry = radii[2 * p + 1];
+    const float sc = scaler[p];
+    int xlo, xhi, ylo, yhi;
+    if (!ndc_index_range(px, rx, S, xlo, xhi) || !ndc_index_range(py, ry, S, ylo, yhi)) return;
+    ylo = max(ylo, S - row0 - rows);
+    yhi = min(yhi, S - 1 - row0);
+    const LaneTiling T(xhi - xlo + 1, lane);
+    for (int yi = ylo + T.lyy; yi <= yhi; yi += T.LH) {
+        const size_t rowbase = ((size_t)n * rows + (S - 1 - yi - row0)) * S;
+        for (int xi = xlo + T.lxx; xi <= xhi; xi += T.LW) {
+            const size_t pix = rowbase + (S - 1 - xi);
+            const int32_t *pi = idx + pix * K;
+            int kk = -1;
+            for (int k = 0; k < K; ++k) {
+                const int32_t v = pi[k];
+                if (v == (int32_t)p) kk = k;
+            }
+            if (kk < 0) continue;
+            float cum;
+            if (wsum) {
+                cum = wsum[pix];
+            } else {
+                cum = 0.0f;
+                for (int k = 0; k < K; ++k) {
+                    const int32_t v = pi[k];
+                    if (v >= 0) cum += expf(-0.5f * qv[pix * K + k]) * scaler[v];
+                }
+                if (cum < 1e-4f) cum = 1e-4f;
+            }
+            const float wgt = expf(-0.5f * qv[pix * K + kk]) * sc;
+            const float *go = grad_out + pix * (Cn + 1);
+#pragma unroll
+            for (int ch = 0; ch < CM; ++ch)
+                if (ch < Cn) acc[ch] += go[ch] * wgt / cum;
+        }
+    }
+}
+
+}  // namespace dss

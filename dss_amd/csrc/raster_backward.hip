@@ -12,7 +12,7 @@
 //   occ_backward_kernel    occupancy surrogate gradient                   rasterize_points_backward.cu:141-178
 //   zbuf_backward_kernel   z_grad scatter                                 rasterize_points.cu:823-846
 //   clip_grad_kernel       per-point norm clip hook                       rasterizer.py:667-673
-#include "common.h"
+#include "point_bodies.h"
 
 namespace dss {
 
@@ -191,73 +191,10 @@ __global__ __launch_bounds__(256) void occ_backward_kernel(
     OT_MARK(0);
     OT_VAL(4, __builtin_amdgcn_s_memrealtime());
     float gx = 0.0f, gy = 0.0f;
-    bool act = visible[p] != 0;
-    int n = -1;
-    if (act) {
-        n = find_cloud(p, first_idx, num_pts, N);
-        act = n >= 0;
-    }
-    if (act) {
-        const float px = points[3 * p], py = points[3 * p + 1], pz = points[3 * p + 2];
-        const float rx = radii[2 * p], ry = radii[2 * p + 1];
-        const float cur_r = rs[n];
-        const float cur_r2 = cur_r * cur_r;
-        // rasterize_points_backward.cu:141-143
-        act = !(pz < 0 || fabsf(py) > 1.0f || fabsf(px) > 1.0f);
-        int xlo, xhi, ylo, yhi;
-        act = act && ndc_index_range(px, cur_r, S, xlo, xhi) && ndc_index_range(py, cur_r, S, ylo, yhi);
-        if (act) {
-            OT_MARK(1);
-            // band rows: image row = S-1-yi in [row0, row0+rows)
-            ylo = max(ylo, S - row0 - rows);
-            yhi = min(yhi, S - 1 - row0);
-            const int w = xhi - xlo + 1;
-            // lane tiling of the window: LW columns x (64/LW) rows per sweep
-            const int lw_log = (w <= 8) ? 3 : (w <= 16) ? 4 : (w <= 32) ? 5 : 6;
-            const int LW = 1 << lw_log, LH = 64 >> lw_log;
-            const int lxx = lane & (LW - 1), lyy = lane >> lw_log;
-            // wave-uniform image base (SGPR) + 32-bit element offsets -> saddr-form loads, no 64-bit
-            // VALU address arithmetic in the loop (one band of one cloud is < 2^31 elements)
-            const int n_u = __builtin_amdgcn_readfirstlane(n);
-            const float *__restrict__ gimg = grad_occ + (size_t)n_u * rows * S * gstride;
-            const int rowstride = S * gstride;
-            const int rstep = LH * rowstride;
-            const NdcMap ndc(S);
-            if (ylo <= yhi) {
-                for (int xi = xlo + lxx; xi <= xhi; xi += LW) {
-                    // column-invariant terms hoisted out of the row loop
-                    const float dx = ndc(xi) - px;
-                    const float dx2 = dx * dx;
-                    const bool out_x = fabsf(dx) > rx;
-                    const int coff = (S - 1 - xi) * gstride - row0 * rowstride;
-                    // four rows per trip: the four loads are independent and issue back to back
-                    for (int y0 = ylo + lyy; y0 <= yhi; y0 += 4 * LH) {
-                        float g[4];
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const int yc = min(y0 + u * LH, yhi);  // clamped: always a legal address
-                            g[u] = gimg[(S - 1 - yc) * rowstride + coff];
-                        }
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const int yi = y0 + u * LH;
-                            const float dy = ndc(yi) - py;
-                            const float d2 = dx2 + dy * dy;
-                            // rasterize_points_backward.cu:151-168; d2 == 0 contributes 0 (see dss_hip.h)
-                            const bool outside = out_x || (fabsf(dy) > ry);
-                            const bool use = (yi <= yhi) && (g[u] != 0.0f) && !(d2 > cur_r2) &&
-                                             !(g[u] > 0.0f && outside) && (d2 != 0.0f);
-                            // dx / max(d2,1e-10) * g with a 1-ulp reciprocal (tolerance-checked, not
-                            // bit-pinned: the reference accumulates with unordered fp32 atomics anyway)
-                            const float sgl = use ? __builtin_amdgcn_rcpf(fmaxf(d2, 1e-10f)) * g[u] : 0.0f;
-                            gx += dx * sgl;
-                            gy += dy * sgl;
-                        }
-                    }
-                }
-            }
-            (void)rstep;
-        }
+    if (visible[p] != 0) {
+        const int n = find_cloud(p, first_idx, num_pts, N);
+        OT_MARK(1);
+        if (n >= 0) occ_point_gather(lane, p, n, points, radii, rs, grad_occ, S, row0, rows, gstride, gx, gy);
     }
     OT_MARK(2);
     gx = wave_sum(gx);
@@ -274,6 +211,149 @@ __global__ __launch_bounds__(256) void occ_backward_kernel(
         grad_pts[3 * p] = gx;
         grad_pts[3 * p + 1] = gy;
         grad_pts[3 * p + 2] = 0.0f;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused single-GPU backward (dss_render_backward): the stand-alone kernels launch one wavefront per
+// packed point, and tools/occ_timing.py shows that at DSS sizes they are bound by the workgroup
+// DISPATCH rate (8171 workgroups take ~26 us to start, 60 % of them only to find their point
+// invisible), not by the gather itself.  Here
+//   visible_scan_kernel     = radix-select pass 0 + compaction of the visible point ids + zero fill of
+//                             the gradients of invisible points (one pass over the flags)
+//   render_backward_kernel  = persistent wavefronts (one full-occupancy grid) that walk the compacted
+//                             list and evaluate BOTH gathers (blend backward + occupancy backward + clip)
+//                             per visible point.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(MED_THREADS) void visible_scan_kernel(
+    const float *__restrict__ radii, const uint8_t *__restrict__ visible,
+    const int64_t *__restrict__ first_idx, const int64_t *__restrict__ num_pts, int N, int64_t P,
+    uint32_t *__restrict__ hist, uint32_t *__restrict__ vis_count, int32_t *__restrict__ vis_list,
+    float *__restrict__ grad_pts, float *__restrict__ grad_feat, int C)
+{
+    __shared__ uint32_t lh[MED_BINS];
+    __shared__ uint32_t s_wave[MED_THREADS / 64];
+    __shared__ uint32_t s_base;
+    constexpr int PER = MED_PTS_PER_WG / MED_THREADS;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int64_t c0 = (int64_t)blockIdx.x * MED_PTS_PER_WG;
+    const int64_t c1 = min(c0 + MED_PTS_PER_WG, P);
+    // all loads first (latency overlapped)
+    uint8_t vis[PER];
+    float2 rr[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int64_t i = c0 + tid + (int64_t)u * MED_THREADS;
+        const bool in = i < c1;
+        vis[u] = in ? visible[i] : (uint8_t)0;
+        rr[u] = in ? reinterpret_cast<const float2 *>(radii)[i] : make_float2(0.f, 0.f);
+    }
+    // ---- compaction: wave ballots -> ranks; one global atomic per workgroup ----
+    uint32_t rank[PER];
+    uint32_t wave_cnt = 0;
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const unsigned long long m = __ballot(vis[u] != 0);
+        rank[u] = wave_cnt + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        wave_cnt += (uint32_t)__popcll(m);
+    }
+    if (lane == 0) s_wave[wid] = wave_cnt;
+    for (int i = tid; i < MED_BINS; i += MED_THREADS) lh[i] = 0;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t tot = 0;
+        for (int w = 0; w < MED_THREADS / 64; ++w) tot += s_wave[w];
+        s_base = tot ? atomicAdd(vis_count, tot) : 0u;
+    }
+    __syncthreads();
+    uint32_t base = s_base;
+    for (int w = 0; w < wid; ++w) base += s_wave[w];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int64_t i = c0 + tid + (int64_t)u * MED_THREADS;
+        if (vis[u]) {
+            vis_list[base + rank[u]] = (int32_t)i;
+        } else if (i < c1) {
+            grad_pts[3 * i] = 0.0f; grad_pts[3 * i + 1] = 0.0f; grad_pts[3 * i + 2] = 0.0f;
+            if (grad_feat)
+                for (int ch = 0; ch < C; ++ch) grad_feat[(size_t)i * C + ch] = 0.0f;
+        }
+    }
+    // ---- radix-select pass 0 (digit [31:21]) per cloud overlapping this chunk ----
+    for (int n = 0; n < N; ++n) {
+        const int64_t lo = max(c0, first_idx[n]), hi = min(c1, first_idx[n] + num_pts[n]);
+        if (lo >= hi) continue;  // uniform
+        bool any = false;
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int64_t i = c0 + tid + (int64_t)u * MED_THREADS;
+            if (vis[u] && i >= lo && i < hi) {
+                atomicAdd(&lh[(float_key(rr[u].x) >> 21) & 0x7ffu], 1u);
+                atomicAdd(&lh[(float_key(rr[u].y) >> 21) & 0x7ffu], 1u);
+                any = true;
+            }
+        }
+        (void)any;
+        __syncthreads();
+        uint32_t *gh = hist + (size_t)n * MED_BINS;  // pass 0 block of the (3,N,BINS) array
+        for (int i = tid; i < MED_BINS; i += MED_THREADS) {
+            const uint32_t c = lh[i];
+            if (c) {
+                atomicAdd(&gh[i], c);
+                lh[i] = 0;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void render_backward_kernel(
+    const float *__restrict__ grad_out, const int32_t *__restrict__ idx, const float *__restrict__ qv,
+    const float *__restrict__ wsum, const float *__restrict__ scaler, const float *__restrict__ points,
+    const float *__restrict__ radii, const float *__restrict__ rs, const int64_t *__restrict__ first_idx,
+    const int64_t *__restrict__ num_pts, const uint32_t *__restrict__ vis_count,
+    const int32_t *__restrict__ vis_list, int N, int S, int K, int Crt, float clip,
+    float *__restrict__ grad_feat, float *__restrict__ grad_pts)
+{
+    constexpr int CM = (C > 0) ? C : BLEND_MAX_C;
+    const int Cn = (C > 0) ? C : Crt;
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint32_t n_waves = gridDim.x * 4;
+    const uint32_t count = *vis_count;
+    for (uint32_t t = wave; t < count; t += n_waves) {
+        const int64_t p = vis_list[t];
+        const int n = find_cloud(p, first_idx, num_pts, N);
+        if (n < 0) continue;
+        float gx = 0.0f, gy = 0.0f;
+        // occupancy gradient = alpha channel of the image gradient, read in place
+        occ_point_gather(lane, p, n, points, radii, rs, grad_out + Cn, S, 0, S, Cn + 1, gx, gy);
+        float acc[CM];
+#pragma unroll
+        for (int ch = 0; ch < CM; ++ch) acc[ch] = 0.0f;
+        if (grad_feat)
+            blend_point_gather<C>(lane, p, n, grad_out, idx, qv, wsum, scaler, points, radii, S, K, Cn, 0, S, acc);
+        gx = wave_sum(gx);
+        gy = wave_sum(gy);
+#pragma unroll
+        for (int ch = 0; ch < CM; ++ch)
+            if (ch < Cn) acc[ch] = wave_sum(acc[ch]);
+        if (lane == 0) {
+            if (clip > 0.0f) {  // rasterizer.py:667-673 (z gradient is 0 on this path)
+                const float nrm = sqrtf(gx * gx + gy * gy);
+                gx = gx / fmaxf(nrm, 1e-12f) * fminf(nrm, clip);
+                gy = gy / fmaxf(nrm, 1e-12f) * fminf(nrm, clip);
+            }
+            grad_pts[3 * p] = gx;
+            grad_pts[3 * p + 1] = gy;
+            grad_pts[3 * p + 2] = 0.0f;
+            if (grad_feat) {
+#pragma unroll
+                for (int ch = 0; ch < CM; ++ch)
+                    if (ch < Cn) grad_feat[(size_t)p * Cn + ch] = acc[ch];
+            }
+        }
     }
 }
 
@@ -430,6 +510,67 @@ extern "C" int dss_splat_backward(const float *points, const float *radii, const
         if (rc) return rc;
     }
     return dss_clip_grad(grad_pts, P, clip, stream);
+}
+
+extern "C" size_t dss_render_backward_workspace(int N, int64_t P)
+{
+    const int n = N > 0 ? N : 1;
+    return align_up((size_t)3 * n * MED_BINS * 4 + 256, 256)  // histograms + visible counter
+           + align_up((size_t)(P > 0 ? P : 1) * 4, 256)       // compacted visible list
+           + align_up((size_t)n * 4, 256);                    // rs
+}
+
+extern "C" int dss_render_backward(const float *grad_out, const int32_t *idx, const float *qvalue, const float *wsum,
+                                   const float *scaler, const float *points, const float *radii,
+                                   const uint8_t *visible, const int64_t *first_idx, const int64_t *num_pts, int N,
+                                   int64_t P, int S, int K, int C, float radii_s, float clip, float *grad_feat,
+                                   float *grad_pts, float *rs_out, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (N <= 0 || P < 0 || S <= 0 || K <= 0 || C < 1 || C > BLEND_MAX_C) {
+        set_error("dss_render_backward: bad sizes N=%d P=%lld S=%d K=%d C=%d", N, (long long)P, S, K, C);
+        return DSS_ERR_INVALID_ARGUMENT;
+    }
+    if (P == 0) return DSS_OK;
+    if (P > 0x7ffffff0ll) { set_error("dss_render_backward: P too large"); return DSS_ERR_UNSUPPORTED; }
+    if (!grad_out || !points || !radii || !visible || !first_idx || !num_pts || !grad_pts ||
+        (grad_feat && (!idx || !qvalue || !scaler))) {
+        set_error("dss_render_backward: NULL tensor pointer");
+        return DSS_ERR_INVALID_ARGUMENT;
+    }
+    const size_t need = dss_render_backward_workspace(N, P);
+    if (!workspace || workspace_bytes < need) {
+        set_error("dss_render_backward: workspace %zu bytes < required %zu", workspace_bytes, need);
+        return DSS_ERR_WORKSPACE;
+    }
+    hipStream_t st = as_stream(stream);
+    char *w = reinterpret_cast<char *>(workspace);
+    const size_t hist_bytes = (size_t)3 * N * MED_BINS * 4;
+    uint32_t *hist = reinterpret_cast<uint32_t *>(w);
+    uint32_t *vis_count = reinterpret_cast<uint32_t *>(w + hist_bytes);
+    size_t off = align_up(hist_bytes + 256, 256);
+    int32_t *vis_list = reinterpret_cast<int32_t *>(w + off);
+    off += align_up((size_t)P * 4, 256);
+    float *rs = rs_out ? rs_out : reinterpret_cast<float *>(w + off);
+    if (hipMemsetAsync(hist, 0, hist_bytes + 256, st) != hipSuccess) return check_launch("memset render_backward");
+    const unsigned blocks = (unsigned)((P + MED_PTS_PER_WG - 1) / MED_PTS_PER_WG);
+    hipLaunchKernelGGL(visible_scan_kernel, dim3(blocks), dim3(MED_THREADS), 0, st, radii, visible, first_idx, num_pts,
+                       N, P, hist, vis_count, vis_list, grad_pts, grad_feat, C);
+    hipLaunchKernelGGL(median_hist_kernel<1>, dim3(blocks), dim3(MED_THREADS), 0, st, radii, visible, first_idx,
+                       num_pts, N, P, hist);
+    hipLaunchKernelGGL(median_hist_kernel<2>, dim3(blocks), dim3(MED_THREADS), 0, st, radii, visible, first_idx,
+                       num_pts, N, P, hist);
+    hipLaunchKernelGGL(median_final_kernel, dim3(N), dim3(MED_THREADS), 0, st, hist, N, radii_s, rs);
+    // persistent grid: every wavefront slot of the chip once (256 CUs x 8 workgroups of 4 wavefronts)
+    const unsigned pgrid = (unsigned)((P + 3) / 4 < 2048 ? (P + 3) / 4 : 2048);
+    if (C == 3)
+        hipLaunchKernelGGL(render_backward_kernel<3>, dim3(pgrid), dim3(256), 0, st, grad_out, idx, qvalue, wsum, scaler,
+                           points, radii, rs, first_idx, num_pts, vis_count, vis_list, N, S, K, C, clip, grad_feat,
+                           grad_pts);
+    else
+        hipLaunchKernelGGL(render_backward_kernel<0>, dim3(pgrid), dim3(256), 0, st, grad_out, idx, qvalue, wsum, scaler,
+                           points, radii, rs, first_idx, num_pts, vis_count, vis_list, N, S, K, C, clip, grad_feat,
+                           grad_pts);
+    return check_launch("dss_render_backward");
 }
 
 #ifdef DSS_FINE_TIMING

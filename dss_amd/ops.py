@@ -277,6 +277,43 @@ def blend_backward(grad_out, idx, qvalue, scaler, num_points: int, geometry=None
     return gf, grad_out[..., C]
 
 
+def render_backward(grad_out, idx, qvalue, wsum, scaler, points, radii, visible, cloud_to_packed_first_idx,
+                    num_points_per_cloud, radii_s: float, clip: float = -1.0, with_features: bool = True,
+                    return_rs: bool = False):
+    """Fused single-GPU backward of renderer + rasterizer (blend backward + median radius + occupancy
+    backward + clip) -> (grad_features (P,C) or None, grad_pts_screen (P,3))."""
+    lib = _lib.load()
+    grad_out = _lib.require_gpu(grad_out, "grad_out", _f32)
+    dev = grad_out.device
+    idx = _lib.require_gpu(idx, "idx", _i32)
+    qvalue = _lib.require_gpu(qvalue, "qvalue", _f32)
+    scaler = _lib.require_gpu(scaler, "scaler", _f32)
+    points = _lib.require_gpu(points, "points", _f32)
+    radii = _lib.require_gpu(radii, "radii", _f32)
+    vis = _lib.require_gpu(_as_u8(visible), "visible", _u8)
+    first = _lib.require_gpu(cloud_to_packed_first_idx, "cloud_to_packed_first_idx", _i64)
+    num = _lib.require_gpu(num_points_per_cloud, "num_points_per_cloud", _i64)
+    if wsum is not None:
+        wsum = _lib.require_gpu(wsum, "wsum", _f32)
+    N, S, S2, K = idx.shape
+    C = grad_out.shape[-1] - 1
+    P = points.shape[0]
+    if S != S2 or tuple(grad_out.shape[:3]) != (N, S, S):
+        raise RuntimeError("render_backward needs full square images: idx (N,S,S,K), grad_out (N,S,S,C+1)")
+    with torch.cuda.device(dev):
+        gf = torch.empty((P, C), dtype=_f32, device=dev) if with_features else None
+        gp = torch.empty((P, 3), dtype=_f32, device=dev)
+        rs = torch.empty((N,), dtype=_f32, device=dev)
+        ws = _lib.workspace(dev, lib.dss_render_backward_workspace(N, P))
+        rc = lib.dss_render_backward(_lib.ptr(grad_out), _lib.ptr(idx), _lib.ptr(qvalue), _lib.ptr(wsum),
+                                     _lib.ptr(scaler), _lib.ptr(points), _lib.ptr(radii), _lib.ptr(vis),
+                                     _lib.ptr(first), _lib.ptr(num), N, P, S, K, C, float(radii_s), float(clip),
+                                     _lib.ptr(gf), _lib.ptr(gp), _lib.ptr(rs), _lib.ptr(ws), ws.numel(),
+                                     _lib.stream_ptr(dev))
+    _lib.check(rc, "dss_render_backward")
+    return (gf, gp, rs) if return_rs else (gf, gp)
+
+
 def point_setup(world, normals, h, M, V, znear, zfar, cloud_to_packed_first_idx, num_points_per_cloud,
                 image_size: int, cutoff_threshold: float, antialiasing_sigma: float = 1.0,
                 backface_culling: bool = False, shared_cloud: bool = False):

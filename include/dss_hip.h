@@ -184,6 +184,24 @@ DSS_API int dss_blend_backward_scatter(const float *grad_out, const int32_t *idx
                                        int64_t P, float *grad_feat, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Fused single-GPU backward of renderer + rasterizer: dss_blend_backward + dss_backward_radius +
+ * dss_occ_backward + dss_clip_grad in five launches, with the per-point work done by persistent
+ * wavefronts over the compacted list of visible points (the stand-alone kernels are bound by the
+ * workgroup dispatch rate at DSS sizes).  Full image only (row0=0,row1=S), no zbuf gradient; the
+ * occupancy gradient is the alpha channel of grad_out (N,S,S,C+1), read in place.
+ * grad_feat may be NULL (rasterizer backward only).  grad_pts (P,3) and grad_feat (P,C) are fully
+ * written.  Same results as the unfused entry points (same per-point arithmetic and reduction order).
+ * ------------------------------------------------------------------------------------------- */
+DSS_API size_t dss_render_backward_workspace(int N, int64_t P);
+DSS_API int dss_render_backward(const float *grad_out, const int32_t *idx, const float *qvalue,
+                                const float *wsum, const float *scaler, const float *points,
+                                const float *radii, const uint8_t *visible, const int64_t *first_idx,
+                                const int64_t *num_pts, int N, int64_t P, int S, int K, int C,
+                                float radii_s, float clip, float *grad_feat /* (P,C) or NULL */,
+                                float *grad_pts /* (P,3) */, float *rs_out /* (N,) or NULL */,
+                                void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Fused per-point setup = everything SurfaceSplatting.forward does before _C.splat_points:
  *   filter_renderable (rasterizer.py:219-254: view-z in [znear,zfar], optional back-face cull),
  *   pytorch3d PointsRasterizer.transform (rasterizer.py:614: NDC x,y + view-space z),

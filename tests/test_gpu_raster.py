@@ -171,6 +171,22 @@ def test_cfg2_bunny_512_forward_backward_vs_oracle():
         assert _rel_l2(g.cpu().numpy(), o_g) <= 1e-3, (cl, gz is None)
         assert np.isfinite(g.cpu().numpy()).all()
 
+    # fused single-GPU backward (persistent wavefronts over the compacted visible list): identical bits
+    g_ref, rs_ref = ops.splat_backward(d["points"], d["radii"], vis, idx, gocc, None, d["first"], d["num"], radii_s,
+                                       clip, return_rs=True)
+    gf_ref, _ = ops.blend_backward(torch.from_numpy(grad_out).to(DEV), idx, qv, scaler, P, geometry=geom, wsum=wsum)
+    for ws_ in (wsum, None):
+        gf_f, g_f, rs_f = ops.render_backward(torch.from_numpy(grad_out).to(DEV), idx, qv, ws_, scaler, d["points"],
+                                              d["radii"], vis, d["first"], d["num"], radii_s, clip, return_rs=True)
+        assert torch.equal(rs_f, rs_ref) and torch.equal(g_f, g_ref)
+        assert _rel_l2(gf_f.cpu().numpy(), o_gf) <= 1e-3
+    assert torch.equal(gf_f if ws_ is not None else ops.render_backward(
+        torch.from_numpy(grad_out).to(DEV), idx, qv, wsum, scaler, d["points"], d["radii"], vis, d["first"], d["num"],
+        radii_s, clip)[0], gf_ref)
+    _, g_only = ops.render_backward(torch.from_numpy(grad_out).to(DEV), idx, qv, wsum, scaler, d["points"], d["radii"],
+                                    vis, d["first"], d["num"], radii_s, clip, with_features=False)
+    assert torch.equal(g_only, g_ref)
+
 
 @pytest.mark.parametrize("name", CASES)
 def test_backward_pieces_vs_oracle(golden_dir, name):
@@ -308,3 +324,24 @@ dist.destroy_process_group()
                          env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     assert out.stdout.count(" ok ") == 2
+
+
+def test_render_backward_multi_cloud_matches_unfused():
+    sc = scenes.random_splats(3000, 96, 3, seed=11)
+    sc["first_idx"] = np.array([0, 3000, 6500], np.int64)     # ragged clouds + a gap of unowned points
+    sc["num_pts"] = np.array([2900, 3500, 2500], np.int64)
+    d = _dev(sc)
+    idx, zbuf, qv, occ, vis = _fwd(d, 96, 5, 0.3, return_visible=True)
+    scaler = torch.from_numpy(sc["scaler"]).to(DEV)
+    feat = torch.from_numpy(sc["colors"]).to(DEV)
+    img, wsum = ops.blend_forward(idx, qv, occ, scaler, feat, return_wsum=True)
+    go = torch.randn_like(img)
+    P = sc["points"].shape[0]
+    geom = (d["points"], d["radii"], vis, d["first"], d["num"])
+    gf_ref, gocc = ops.blend_backward(go, idx, qv, scaler, P, geometry=geom, wsum=wsum)
+    g_ref = ops.splat_backward(d["points"], d["radii"], vis, idx, gocc, None, d["first"], d["num"], 4.0, 0.05)
+    gf, g = ops.render_backward(go, idx, qv, wsum, scaler, d["points"], d["radii"], vis, d["first"], d["num"], 4.0, 0.05)
+    assert torch.equal(gf, gf_ref) and torch.equal(g, g_ref)
+    o_g, _, _ = oracle.splat_backward(sc["points"], sc["radii"], idx.cpu().numpy(), go[..., 3].cpu().numpy(), None,
+                                      sc["first_idx"], sc["num_pts"], 4.0, 0.05)
+    assert _rel_l2(g.cpu().numpy(), o_g) <= 1e-4
