@@ -56,16 +56,18 @@ __device__ __forceinline__ void occ_point_gather(int lane, int64_t p, int n, con
         const float dx2 = dx * dx;
         const bool out_x = fabsf(dx) > rx;
         const int coff = (S - 1 - xi) * gstride - row0 * rowstride;
-        // four rows per trip: the four loads are independent and issue back to back
-        for (int y0 = ylo + T.lyy; y0 <= yhi; y0 += 4 * T.LH) {
-            float g[4];
+        // ROWS_PER_TRIP rows per trip: the loads are independent and issue back to back, so a 29-row window
+        // (rs = 14 px) costs two memory round trips instead of fifteen
+        constexpr int RPT = 8;
+        for (int y0 = ylo + T.lyy; y0 <= yhi; y0 += RPT * T.LH) {
+            float g[RPT];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < RPT; ++u) {
                 const int yc = min(y0 + u * T.LH, yhi);  // clamped: always a legal address
                 g[u] = gimg[(S - 1 - yc) * rowstride + coff];
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < RPT; ++u) {
                 const int yi = y0 + u * T.LH;
                 const float dy = ndc(yi) - py;
                 const float d2 = dx2 + dy * dy;
@@ -106,17 +108,19 @@ __device__ __forceinline__ void blend_point_gather(int lane, int64_t p, int n, c
         for (int xi = xlo + T.lxx; xi <= xhi; xi += T.LW) {
             const size_t pix = rowbase + (S - 1 - xi);
             const int32_t *pi = idx + pix * K;
+            // loads that do not depend on the slot search are issued first (one round trip for all)
+            const float *go = grad_out + pix * (Cn + 1);
+            float gch[CM];
+#pragma unroll
+            for (int ch = 0; ch < CM; ++ch) gch[ch] = (ch < Cn) ? go[ch] : 0.0f;
+            float cum = wsum ? wsum[pix] : 0.0f;
             int kk = -1;
             for (int k = 0; k < K; ++k) {
                 const int32_t v = pi[k];
                 if (v == (int32_t)p) kk = k;
             }
             if (kk < 0) continue;
-            float cum;
-            if (wsum) {
-                cum = wsum[pix];
-            } else {
-                cum = 0.0f;
+            if (!wsum) {
                 for (int k = 0; k < K; ++k) {
                     const int32_t v = pi[k];
                     if (v >= 0) cum += expf(-0.5f * qv[pix * K + k]) * scaler[v];
@@ -124,10 +128,9 @@ __device__ __forceinline__ void blend_point_gather(int lane, int64_t p, int n, c
                 if (cum < 1e-4f) cum = 1e-4f;
             }
             const float wgt = expf(-0.5f * qv[pix * K + kk]) * sc;
-            const float *go = grad_out + pix * (Cn + 1);
 #pragma unroll
             for (int ch = 0; ch < CM; ++ch)
-                if (ch < Cn) acc[ch] += go[ch] * wgt / cum;
+                if (ch < Cn) acc[ch] += gch[ch] * wgt / cum;
         }
     }
 }
