@@ -560,8 +560,24 @@ extern "C" int dss_render_backward(const float *grad_out, const int32_t *idx, co
     hipLaunchKernelGGL(median_hist_kernel<2>, dim3(blocks), dim3(MED_THREADS), 0, st, radii, visible, first_idx,
                        num_pts, N, P, hist);
     hipLaunchKernelGGL(median_final_kernel, dim3(N), dim3(MED_THREADS), 0, st, hist, N, radii_s, rs);
-    // persistent grid: every wavefront slot of the chip once (256 CUs x 8 workgroups of 4 wavefronts)
-    const unsigned pgrid = (unsigned)((P + 3) / 4 < 2048 ? (P + 3) / 4 : 2048);
+    // persistent grid = exactly the resident capacity of the chip for this kernel (a larger grid would
+    // leave late workgroups waiting for slots while their share of the list sits idle)
+    static int cap3 = 0, cap0 = 0;  // benign race: every thread computes the same value
+    int &cap = (C == 3) ? cap3 : cap0;
+    if (cap == 0) {
+        int dev = 0, cus = 256, per_cu = 4;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            cus = prop.multiProcessorCount;
+        if (C == 3)
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_backward_kernel<3>, 256, 0);
+        else
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_backward_kernel<0>, 256, 0);
+        if (per_cu < 1) per_cu = 1;
+        cap = cus * per_cu;
+        (void)hipGetLastError();
+    }
+    const unsigned pgrid = (unsigned)((P + 3) / 4 < cap ? (P + 3) / 4 : cap);
     if (C == 3)
         hipLaunchKernelGGL(render_backward_kernel<3>, dim3(pgrid), dim3(256), 0, st, grad_out, idx, qvalue, wsum, scaler,
                            points, radii, rs, first_idx, num_pts, vis_count, vis_list, N, S, K, C, clip, grad_feat,
