@@ -322,13 +322,27 @@ __global__ __launch_bounds__(256) void render_backward_kernel(
     const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6);
     const uint32_t n_waves = gridDim.x * 4;
     const uint32_t count = *vis_count;
+#ifdef DSS_FINE_TIMING
+    long long tm_rt0 = __builtin_amdgcn_s_memrealtime(), tm_occ = 0, tm_blend = 0, tm_pro = 0, tm_tasks = 0;
+#endif
     for (uint32_t t = wave; t < count; t += n_waves) {
+#ifdef DSS_FINE_TIMING
+        const long long tm0 = __builtin_amdgcn_s_memtime();
+#endif
         const int64_t p = vis_list[t];
         const int n = find_cloud(p, first_idx, num_pts, N);
         if (n < 0) continue;
         float gx = 0.0f, gy = 0.0f;
+#ifdef DSS_FINE_TIMING
+        const long long tm1 = __builtin_amdgcn_s_memtime();
+#endif
         // occupancy gradient = alpha channel of the image gradient, read in place
         occ_point_gather(lane, p, n, points, radii, rs, grad_out + Cn, S, 0, S, Cn + 1, gx, gy);
+#ifdef DSS_FINE_TIMING
+        gx = wave_sum(gx) * (1.0f / 64.0f) * 64.0f / 64.0f;  // force completion of the gather before the stamp
+        const long long tm2 = __builtin_amdgcn_s_memtime();
+        tm_pro += tm1 - tm0; tm_occ += tm2 - tm1; tm_tasks += 1;
+#endif
         float acc[CM];
 #pragma unroll
         for (int ch = 0; ch < CM; ++ch) acc[ch] = 0.0f;
@@ -339,6 +353,9 @@ __global__ __launch_bounds__(256) void render_backward_kernel(
 #pragma unroll
         for (int ch = 0; ch < CM; ++ch)
             if (ch < Cn) acc[ch] = wave_sum(acc[ch]);
+#ifdef DSS_FINE_TIMING
+        tm_blend += (long long)__builtin_amdgcn_s_memtime() - tm2;
+#endif
         if (lane == 0) {
             if (clip > 0.0f) {  // rasterizer.py:667-673 (z gradient is 0 on this path)
                 const float nrm = sqrtf(gx * gx + gy * gy);
@@ -355,6 +372,12 @@ __global__ __launch_bounds__(256) void render_backward_kernel(
             }
         }
     }
+#ifdef DSS_FINE_TIMING
+    if (g_occ_timing && lane == 0) {
+        long long *o = g_occ_timing + (size_t)wave * 6;
+        o[0] = tm_rt0; o[1] = __builtin_amdgcn_s_memrealtime(); o[2] = tm_tasks; o[3] = tm_occ; o[4] = tm_blend; o[5] = tm_pro;
+    }
+#endif
 }
 
 __global__ __launch_bounds__(256) void zbuf_backward_kernel(const int32_t *__restrict__ idx,
