@@ -61,11 +61,26 @@ __device__ __forceinline__ bool ndc_index_range(float x, float r, int S, int &lo
     return lo <= hi;
 }
 
+// Wave-wide sum without LDS traffic: `__shfl_xor` lowers to ds_bpermute_b32 (an LDS round trip per
+// stage, six dependent stages); DPP row operations are plain VALU.  Four DPP stages leave the sum of
+// each 16-lane row in every lane of the row, then four v_readlane + scalar-operand adds combine the
+// rows.  Result is wave-uniform; the summation order is fixed (deterministic).
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
 __device__ __forceinline__ float wave_sum(float v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_f32<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_f32<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += dpp_f32<0x141>(v);  // row_half_mirror
+    v += dpp_f32<0x140>(v);  // row_mirror
+    const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return (a + b) + (c + d);
 }
 
 static inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
