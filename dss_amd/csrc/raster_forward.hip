@@ -504,6 +504,86 @@ __global__ __launch_bounds__(FINE_THREADS) void fine_kernel(const FineArgs A)
     FT_VAL(9, __builtin_amdgcn_s_memrealtime());
 }
 
+// ---------------------------------------------------------------------------------------------
+// Generic-K path for DSS_MAX_K_FAST < K <= kMaxPointsPerPixel (=150, rasterization_utils.cuh:18):
+// one wavefront per 8x8 tile, one lane per pixel, the K-list lives in scratch memory (like the
+// reference's thread-local `Pix q[150]`, rasterize_points.cu:177) and is kept sorted by binary
+// insertion.  Rare configuration: correctness over speed.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void fine_generic_kernel(const FineArgs A)
+{
+    const TileGrid g = A.g;
+    const int tiles = g.tiles_x * g.tiles_y;
+    const int n = blockIdx.x / tiles;
+    const int t = blockIdx.x - n * tiles;
+    const int ty = t / g.tiles_x, tx = t - ty * g.tiles_x;
+    const int lane = threadIdx.x;
+    const int r = g.row0 + ty * DSS_TILE + (lane >> 3);
+    const int c = tx * DSS_TILE + (lane & 7);
+    const int S = g.S, K = A.K;
+    const float xf = pix_to_ndc(S - 1 - c, S);
+    const float yf = pix_to_ndc(S - 1 - r, S);
+    int64_t src0, count;
+    bool use_list = false;
+    if (A.offsets != nullptr) {
+        const uint32_t o0 = A.offsets[(size_t)blockIdx.x * DSS_SUB], o1 = A.offsets[((size_t)blockIdx.x + 1) * DSS_SUB];
+        use_list = *A.overflow == 0u;
+        src0 = o0;
+        count = (int64_t)o1 - (int64_t)o0;
+    }
+    if (!use_list) {
+        src0 = A.first_idx[n];
+        count = A.num_pts[n];
+    }
+    unsigned long long key[DSS_MAX_K];
+    float kq[DSS_MAX_K];
+    int cnt = 0;
+    for (int64_t j = 0; j < count; ++j) {
+        const int64_t p = use_list ? (int64_t)A.list[src0 + j] : (src0 + j);  // wave-uniform
+        const float pz = A.points[3 * p + 2];
+        if (pz < 0) continue;
+        const float dx = xf - A.points[3 * p];
+        const float dy = yf - A.points[3 * p + 1];
+        if (fabsf(dx) > A.radii[2 * p] || fabsf(dy) > A.radii[2 * p + 1]) continue;
+        const float qval = A.ellipse[3 * p] * dx * dx + A.ellipse[3 * p + 1] * dx * dy + A.ellipse[3 * p + 2] * dy * dy;
+        if (qval > A.cutoff[p]) continue;
+        const unsigned long long ekey = ((unsigned long long)__float_as_uint(pz + 0.0f) << 32) | (unsigned long long)(unsigned)p;
+        if (cnt == K && !(ekey < key[K - 1])) continue;
+        int pos = (cnt < K) ? cnt : K - 1;
+        while (pos > 0 && ekey < key[pos - 1]) {
+            key[pos] = key[pos - 1];
+            kq[pos] = kq[pos - 1];
+            --pos;
+        }
+        key[pos] = ekey;
+        kq[pos] = qval;
+        if (cnt < K) ++cnt;
+    }
+    if (c >= S || r >= g.row0 + g.rows) return;
+    const size_t pix = ((size_t)n * g.rows + (r - g.row0)) * S + c;
+    A.occ[pix] = cnt > 0 ? 1.0f : 0.0f;
+    const float z0 = cnt > 0 ? __uint_as_float((unsigned)(key[0] >> 32)) : 0.0f;
+    bool alive = cnt > 0;
+    for (int k = 0; k < K; ++k) {
+        float z = -1.0f, qv = -1.0f;
+        int id = -1;
+        if (alive && k < cnt) {
+            z = __uint_as_float((unsigned)(key[k] >> 32));
+            if (z - z0 > A.thr) {
+                alive = false;
+                z = -1.0f;
+            } else {
+                id = (int)(unsigned)(key[k] & 0xffffffffull);
+                qv = kq[k];
+                if (A.visible) A.visible[id] = 1;
+            }
+        }
+        A.idx[pix * K + k] = id;
+        A.zbuf[pix * K + k] = z;
+        A.qv[pix * K + k] = qv;
+    }
+}
+
 template <int KMAX>
 static void launch_fine(const FineArgs &A, int blocks, hipStream_t st)
 {
@@ -528,6 +608,10 @@ static bool dispatch_fine(const FineArgs &A, int blocks, hipStream_t st)
     if (K <= 16) { launch_fine<16>(A, blocks, st); return true; }
     if (K <= 24) { launch_fine<24>(A, blocks, st); return true; }
     if (K <= 32) { launch_fine<32>(A, blocks, st); return true; }
+    if (K <= DSS_MAX_K) {
+        hipLaunchKernelGGL(fine_generic_kernel, dim3(blocks), dim3(64), 0, st, A);
+        return true;
+    }
     return false;
 }
 
@@ -590,10 +674,6 @@ static int validate_fwd(const char *fn, int N, int64_t P, int S, int K, int row0
     if (K > DSS_MAX_K) {
         set_error("%s: points_per_pixel %d exceeds kMaxPointsPerPixel=%d", fn, K, DSS_MAX_K);
         return DSS_ERR_INVALID_ARGUMENT;
-    }
-    if (K > DSS_MAX_K_FAST) {
-        set_error("%s: points_per_pixel %d > %d not implemented yet", fn, K, DSS_MAX_K_FAST);
-        return DSS_ERR_UNSUPPORTED;
     }
     if (S > 65535 * DSS_TILE || P > 0x7ffffff0ll) {
         set_error("%s: S=%d or P=%lld too large", fn, S, (long long)P);

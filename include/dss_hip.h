@@ -45,7 +45,7 @@ extern "C" {
 
 /* Largest points_per_pixel with a register-resident K-list.  The reference's compile-time bound
  * is kMaxPointsPerPixel = 150 (rasterization_utils.cuh:18); K in (DSS_MAX_K_FAST, 150] is served
- * by a slower scratch-memory kernel. */
+ * by a slower scratch-memory kernel (fine_generic_kernel). */
 #define DSS_MAX_K_FAST 32
 #define DSS_MAX_K 150
 

@@ -47,7 +47,7 @@ def test_forward_bit_exact_vs_reference_golden(golden_dir, name, bin_size):
     assert np.array_equal(occ.cpu().numpy(), z["ref_occ"])
 
 
-@pytest.mark.parametrize("K", [1, 2, 5, 8, 11, 16, 20, 32])
+@pytest.mark.parametrize("K", [1, 2, 5, 8, 11, 16, 20, 32, 33, 64, 150])
 def test_forward_all_k_vs_oracle(K):
     sc = scenes.random_splats(900, 56, 2, seed=K, rmin=2.0, rmax=9.0)
     S, thr = 56, 0.4
