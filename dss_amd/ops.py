@@ -382,3 +382,39 @@ def project_backward(world, M, V, cloud_to_packed_first_idx, num_points_per_clou
                                       _lib.stream_ptr(dev))
     _lib.check(rc, "dss_project_backward")
     return gw
+
+
+def knn_kth_sqdist(points, cloud_to_packed_first_idx, num_points_per_cloud, K: int = 7):
+    """K-th smallest squared distance of every point to its own cloud (self included) -> (P,).
+    Exact grid search in HIP; replaces frnn.frnn_grid_points / pytorch3d.ops.knn_points for the
+    variance-scale statistic (rasterizer.py:310-321, 366-383)."""
+    lib = _lib.load()
+    points = _lib.require_gpu(points, "points", _f32)
+    dev = points.device
+    first = _lib.require_gpu(cloud_to_packed_first_idx, "cloud_to_packed_first_idx", _i64)
+    num = _lib.require_gpu(num_points_per_cloud, "num_points_per_cloud", _i64)
+    N, P = first.shape[0], points.shape[0]
+    with torch.cuda.device(dev):
+        out = torch.empty((P,), dtype=_f32, device=dev)
+        ws = _lib.workspace(dev, lib.dss_knn_workspace(N, P))
+        rc = lib.dss_knn_kth_sqdist(_lib.ptr(points), _lib.ptr(first), _lib.ptr(num), N, P, int(K), _lib.ptr(out),
+                                    _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
+    _lib.check(rc, "dss_knn_kth_sqdist")
+    return out
+
+
+def cloud_mean_clamp(values, cloud_to_packed_first_idx, num_points_per_cloud, scale: float, lo: float, hi: float,
+                     fallback: float, min_points: int):
+    """Per-cloud clamp(mean(values*scale), lo, hi) -> (N,), deterministic."""
+    lib = _lib.load()
+    values = _lib.require_gpu(values, "values", _f32)
+    dev = values.device
+    first = _lib.require_gpu(cloud_to_packed_first_idx, "cloud_to_packed_first_idx", _i64)
+    num = _lib.require_gpu(num_points_per_cloud, "num_points_per_cloud", _i64)
+    N = first.shape[0]
+    with torch.cuda.device(dev):
+        out = torch.empty((N,), dtype=_f32, device=dev)
+        rc = lib.dss_cloud_mean_clamp(_lib.ptr(values), _lib.ptr(first), _lib.ptr(num), N, float(scale), float(lo),
+                                      float(hi), float(fallback), int(min_points), _lib.ptr(out), _lib.stream_ptr(dev))
+    _lib.check(rc, "dss_cloud_mean_clamp")
+    return out

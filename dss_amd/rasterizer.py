@@ -131,21 +131,14 @@ class _ProjectAndSetup(autograd.Function):
         return (gw,) + (None,) * 13
 
 
-def knn_variance_scale(points: torch.Tensor, K: int = 7, chunk: int = 2048) -> torch.Tensor:
-    """Per-point 0.5*max(squared distance to the K-1 nearest neighbours) (rasterizer.py:310-321, 366-383).
-
-    NOT part of the HIP hot path yet: the reference delegates this to third-party CUDA
-    (FRNN ``frnn_grid_points`` / pytorch3d ``knn_points``); SURVEY 8f ranks a HIP grid kNN as the next
-    row.  This chunked torch.cdist/topk stand-in is O(P^2) and only meant for moderate P."""
-    P = points.shape[0]
-    if P < K:
-        return points.new_full((P,), 0.5e-3)
-    out = []
+def knn_variance_scale(point_clouds, K: int = 7) -> torch.Tensor:
+    """Per-point 0.5 * (K-th smallest squared distance to the own cloud, self included), packed (P,)
+    = ``0.5 * knn(...)[:, :, 1:].max(-1)`` of rasterizer.py:310-321 / 366-383, computed by the HIP grid
+    search ``dss_knn_kth_sqdist`` (the reference uses FRNN / pytorch3d CUDA here)."""
     with torch.no_grad():
-        for s in range(0, P, chunk):
-            d2 = torch.cdist(points[s:s + chunk], points).pow(2)
-            out.append(0.5 * d2.topk(K, dim=1, largest=False).values[:, -1])
-    return torch.cat(out)
+        d = ops.knn_kth_sqdist(point_clouds.points_packed().detach(), point_clouds.cloud_to_packed_first_idx(),
+                               point_clouds.num_points_per_cloud(), K)
+    return 0.5 * d
 
 
 class SurfaceSplatting(torch.nn.Module):
@@ -165,12 +158,15 @@ class SurfaceSplatting(torch.nn.Module):
     def _variance_scale(self, point_clouds, raster_settings, refresh=True):
         if not refresh and self._Vrk_h is not None:
             return self._Vrk_h
-        pts = point_clouds.points_list()
+        first, num = point_clouds.cloud_to_packed_first_idx(), point_clouds.num_points_per_cloud()
+        with torch.no_grad():
+            d = ops.knn_kth_sqdist(point_clouds.points_packed().detach(), first, num, 7)
         if raster_settings.Vrk_invariant:
-            # one scalar per cloud: mean_i(0.5 max kNN-7 d^2) clamped to [5e-5, 1e-3]  (:321-326)
-            h = torch.stack([knn_variance_scale(p.detach()).mean().clamp(5e-5, 1e-3) for p in pts])
+            # one scalar per cloud: mean_i(0.5 max kNN-7 d^2) clamped to [5e-5, 1e-3]; clouds with fewer than
+            # 7 points use sq_dist = 1e-3 (rasterizer.py:320-326)
+            h = ops.cloud_mean_clamp(d, first, num, 0.5, 5e-5, 1e-3, 0.5e-3, 7)
         elif raster_settings.Vrk_isotropic:
-            h = torch.cat([knn_variance_scale(p.detach()).clamp(5e-5, 0.01) for p in pts])  # (:385-388)
+            h = (0.5 * d).clamp_(5e-5, 0.01)  # per point (rasterizer.py:383-388)
         else:
             raise NotImplementedError("anisotropic Vrk (rasterizer.py:256-291) needs torch-batch-svd local "
                                       "frames; use Vrk_invariant or Vrk_isotropic")

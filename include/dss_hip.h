@@ -233,6 +233,25 @@ DSS_API int dss_project_backward(const float *world, const float *M, const float
                                  const uint8_t *valid /* (P,) */, float *grad_world /* (Pw,3) */,
                                  void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * kNN statistic behind the source-space variance scale h (rasterizer.py:310-326, 366-388):
+ * kth_sqdist[p] = K-th smallest squared distance from point p to the points of its own cloud,
+ * the point itself included (= max over knn_points(..., K)[:, :, 1:] for K=7).  Exact uniform-grid
+ * search; replaces the third-party CUDA calls frnn.frnn_grid_points / pytorch3d.ops.knn_points.
+ * 1 <= K <= 16.  Clouds with fewer than K points report their farthest point.
+ * dss_cloud_mean_clamp: out[n] = clamp(mean_i(values[i]*scale), lo, hi) per cloud, `fallback` for
+ * clouds with fewer than min_points points (rasterizer.py:322-326: scale 0.5, [5e-5,1e-3], 1e-3*0.5
+ * when the cloud has < 7 points); deterministic summation order.
+ * ------------------------------------------------------------------------------------------- */
+DSS_API size_t dss_knn_workspace(int N, int64_t P);
+DSS_API int dss_knn_kth_sqdist(const float *points /* (P,3) */, const int64_t *first_idx,
+                               const int64_t *num_pts, int N, int64_t P, int K,
+                               float *kth_sqdist /* (P,) */, void *workspace, size_t workspace_bytes,
+                               void *stream);
+DSS_API int dss_cloud_mean_clamp(const float *values /* (P,) */, const int64_t *first_idx,
+                                 const int64_t *num_pts, int N, float scale, float lo, float hi,
+                                 float fallback, int min_points, float *out /* (N,) */, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

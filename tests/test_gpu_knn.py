@@ -1,0 +1,78 @@
+"""GPU: exact grid kNN statistic behind the EWA variance scale h (rasterizer.py:310-326, 366-388)."""
+import numpy as np
+import pytest
+import torch
+from scipy.spatial import cKDTree
+
+import scenes
+from dss_amd import ops
+from dss_amd.cameras import FoVPerspectiveCameras, look_at_view_transform
+from dss_amd.cloud import PointClouds3D
+from dss_amd.rasterizer import PointsRasterizationSettings, SurfaceSplatting
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _ref_kth(points, K):
+    if points.shape[0] == 0:
+        return np.zeros(0, np.float32)
+    k = min(K, points.shape[0])
+    d, _ = cKDTree(points.astype(np.float64)).query(points.astype(np.float64), k=k)
+    d = d.reshape(points.shape[0], -1)
+    return (d[:, -1] ** 2).astype(np.float32)
+
+
+@pytest.mark.parametrize("K", [1, 7, 12, 16])
+def test_knn_kth_matches_kdtree_multi_cloud(K):
+    rng = np.random.default_rng(K)
+    bunny, _ = scenes.load_cloud("bunny")
+    clouds = [scenes.normalize_unit_sphere(bunny),                      # surface
+              rng.uniform(-1, 1, (5000, 3)).astype(np.float32),       # volume
+              rng.normal(0, 0.01, (300, 3)).astype(np.float32) + 5,   # tiny far-away cluster
+              rng.uniform(0, 1, (3, 3)).astype(np.float32),           # fewer points than K
+              np.zeros((0, 3), np.float32),                           # empty
+              np.repeat(rng.uniform(0, 1, (40, 3)), 5, 0).astype(np.float32)]  # duplicates
+    pts = np.concatenate(clouds, 0)
+    num = np.array([c.shape[0] for c in clouds], np.int64)
+    first = np.cumsum(num) - num
+    got = ops.knn_kth_sqdist(torch.from_numpy(pts).to(DEV), torch.from_numpy(first).to(DEV),
+                             torch.from_numpy(num).to(DEV), K).cpu().numpy()
+    want = np.concatenate([_ref_kth(c, K) for c in clouds])
+    # exact neighbour sets; distances differ only by fp32 vs fp64 evaluation of the same pair
+    assert np.allclose(got, want, rtol=2e-5, atol=1e-9), np.abs(got - want).max()
+
+
+def test_knn_large_cloud_and_global_h():
+    pts, nrm, col = scenes.synthetic_cloud(200_000, seed=3)
+    t = torch.from_numpy(pts).to(DEV)
+    first = torch.zeros(1, dtype=torch.int64, device=DEV)
+    num = torch.full((1,), pts.shape[0], dtype=torch.int64, device=DEV)
+    got = ops.knn_kth_sqdist(t, first, num, 7).cpu().numpy()
+    want = _ref_kth(pts, 7)
+    assert np.allclose(got, want, rtol=2e-5, atol=1e-10)
+    h = ops.cloud_mean_clamp(torch.from_numpy(got).to(DEV), first, num, 0.5, 5e-5, 1e-3, 0.5e-3, 7).item()
+    assert abs(h - float(np.clip((0.5 * want.astype(np.float64)).mean(), 5e-5, 1e-3))) <= 1e-6 * h + 1e-12
+    h2 = ops.cloud_mean_clamp(torch.from_numpy(got).to(DEV), first, num, 0.5, 5e-5, 1e-3, 0.5e-3, 7).item()
+    assert h == h2  # deterministic
+
+
+def test_rasterizer_computes_h_itself():
+    """SurfaceSplatting without a precomputed Vrk_h: global (Vrk_invariant) and per-point (isotropic) scales."""
+    pts, nrm = scenes.load_cloud("teapot")
+    pts = scenes.normalize_unit_sphere(pts)
+    R, T = look_at_view_transform(2.0, 30.0, 45.0)
+    cams = FoVPerspectiveCameras(znear=0.1, R=R, T=T, device=DEV)
+    cloud = PointClouds3D([torch.from_numpy(pts).to(DEV)], [torch.from_numpy(nrm).to(DEV)],
+                          [torch.ones(pts.shape[0], 3, device=DEV)])
+    for inv, iso in ((True, False), (False, True)):
+        st = PointsRasterizationSettings(backface_culling=False, Vrk_invariant=inv, Vrk_isotropic=iso, image_size=128,
+                                         points_per_pixel=5, bin_size=None, radii_backward_scaler=5)
+        rast = SurfaceSplatting(cameras=cams, raster_settings=st)
+        frags, _ = rast(cloud)
+        assert frags.occupancy.mean().item() > 0.05
+        if inv:
+            assert abs(rast._Vrk_h.item() - scenes.global_h(pts)) <= 1e-5 * scenes.global_h(pts)
+        else:
+            want = np.clip(0.5 * _ref_kth(pts, 7), 5e-5, 0.01)
+            assert np.allclose(rast._Vrk_h.cpu().numpy(), want, rtol=2e-5)
