@@ -47,7 +47,7 @@ def test_inverse_rendering_loss_decreases():
         loss.backward()
         assert torch.isfinite(P.grad).all() and torch.isfinite(C.grad).all()
         opt.step()
-        losses.append(float(loss))
+        losses.append(loss.item())
         p_err.append(float((P.detach() - torch.from_numpy(pts).to(DEV)).norm(dim=1).mean()))
     assert losses[-1] < 0.6 * losses[0], losses[::8]
     assert p_err[-1] < 0.9 * p_err[0], p_err[::8]   # geometry moved towards the target, not just colours
