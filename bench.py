@@ -69,12 +69,11 @@ class Workload:
 
     def step(self):
         p = self.part
-        info = ops.point_setup(self.world, self.normals, self.h, self.M, self.V, self.znear, self.zfar, self.first,
-                               self.num, S, CUTOFF, SIGMA, False, True)
-        idx, zbuf, qv, occ, vis = ops.splat_points(info["pts_screen"], info["ellipse_params"],
-                                                   info["cutoff_threshold"], info["radii"], self.first, self.num,
-                                                   THR, S, K, None, None, rows=p.rows, return_visible=True)
-        band, wsum = ops.blend_forward(idx, qv, occ, info["scaler"], self.colors, return_wsum=True)
+        # fused forward: [setup + tile count] -> scan -> fill -> [fine + blend]
+        f = ops.render_forward(self.world, self.normals, self.h, self.M, self.V, self.znear, self.zfar, self.first,
+                               self.num, self.colors, S, K, CUTOFF, THR, SIGMA, False, True, rows=p.rows)
+        info = {"pts_screen": f["pts_screen"], "radii": f["radii"], "scaler": f["scaler"], "valid": f["valid"]}
+        idx, qv, vis, band, wsum = f["idx"], f["qvalue"], f["visible"], f["image"], f["wsum"]
         image = gather_rows(band, p)
         g_band = p.slice(self.grad_out).contiguous() if p.world_size > 1 else self.grad_out
         geom = (info["pts_screen"], info["radii"], vis, self.first, self.num)

@@ -17,7 +17,7 @@
 // The per-pair arithmetic (dx, dy, Q, comparisons) is written exactly like the reference
 // (rasterize_points.cu:64-124) and compiled with -ffp-contract=off, so fragments are bit-identical
 // to the reference CPU/CUDA naive path; the K-set is defined by the total order (z, idx).
-#include "common.h"
+#include "setup_body.h"
 
 namespace dss {
 
@@ -66,6 +66,25 @@ __device__ __forceinline__ bool splat_tile_rect(float px, float py, float pz, fl
     return true;
 }
 
+// count the tiles of one splat (screen record given) and store its tile rectangle
+__device__ __forceinline__ void bin_count_point(int64_t p, int n, float px, float py, float pz, float rx, float ry,
+                                                const TileGrid g, uint32_t *__restrict__ tile_count,
+                                                uint2 *__restrict__ rects)
+{
+    uint2 rc = make_uint2(0xffffffffu, 0u);  // empty
+    if (n >= 0) {
+        int tx0, tx1, ty0, ty1;
+        if (splat_tile_rect(px, py, pz, rx, ry, g, tx0, tx1, ty0, ty1)) {
+            rc.x = (uint32_t)tx0 | ((uint32_t)tx1 << 16);
+            rc.y = (uint32_t)ty0 | ((uint32_t)ty1 << 16);
+            uint32_t *cnt = tile_count + ((size_t)n * g.tiles_x * g.tiles_y) * DSS_SUB + ((unsigned)p & (DSS_SUB - 1));
+            for (int ty = ty0; ty <= ty1; ++ty)
+                for (int tx = tx0; tx <= tx1; ++tx) atomicAdd(&cnt[(ty * g.tiles_x + tx) * DSS_SUB], 1u);
+        }
+    }
+    rects[p] = rc;  // the cloud id is recomputed in bin_fill (N is tiny): keeps the record at 8 bytes
+}
+
 __global__ __launch_bounds__(256) void bin_count_kernel(
     const float *__restrict__ points, const float *__restrict__ radii,
     const int64_t *__restrict__ first_idx, const int64_t *__restrict__ num_pts, int N, int64_t P,
@@ -75,21 +94,25 @@ __global__ __launch_bounds__(256) void bin_count_kernel(
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= P) return;
     if (visible_to_clear) visible_to_clear[p] = 0;  // saves a separate memset launch
-    uint2 rc = make_uint2(0xffffffffu, 0u);  // empty
     const int n = find_cloud(p, first_idx, num_pts, N);
-    if (n >= 0) {
-        int tx0, tx1, ty0, ty1;
-        if (splat_tile_rect(points[3 * p], points[3 * p + 1], points[3 * p + 2], radii[2 * p],
-                            radii[2 * p + 1], g, tx0, tx1, ty0, ty1)) {
-            rc.x = (uint32_t)tx0 | ((uint32_t)tx1 << 16);
-            rc.y = (uint32_t)ty0 | ((uint32_t)ty1 << 16) ;
-            uint32_t *cnt = tile_count + ((size_t)n * g.tiles_x * g.tiles_y) * DSS_SUB + ((unsigned)p & (DSS_SUB - 1));
-            for (int ty = ty0; ty <= ty1; ++ty)
-                for (int tx = tx0; tx <= tx1; ++tx) atomicAdd(&cnt[(ty * g.tiles_x + tx) * DSS_SUB], 1u);
-        }
-    }
-    rects[p] = rc;
-    // cloud id is recomputed in bin_fill (N is tiny); keeps the rect record at 8 bytes
+    bin_count_point(p, n, points[3 * p], points[3 * p + 1], points[3 * p + 2], radii[2 * p], radii[2 * p + 1], g,
+                    tile_count, rects);
+}
+
+// dss_render_forward: per-point setup (culling + projection + EWA terms) fused with the tile count --
+// the screen record goes from registers straight into the binning, one launch and one re-read fewer.
+__global__ __launch_bounds__(256) void setup_bin_count_kernel(const SetupArgs A, TileGrid g,
+                                                              uint32_t *__restrict__ tile_count,
+                                                              uint2 *__restrict__ rects,
+                                                              uint8_t *__restrict__ visible_to_clear)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= A.P) return;
+    if (visible_to_clear) visible_to_clear[p] = 0;
+    const int n = find_cloud(p, A.first_idx, A.num_pts, A.N);
+    float px, py, pz, rx, ry;
+    setup_point(A, p, n, px, py, pz, rx, ry);
+    bin_count_point(p, n, px, py, pz, rx, ry, g, tile_count, rects);
 }
 
 // Exclusive scan of the (n_tiles x DSS_SUB) counters by ONE workgroup of 1024 threads; every thread
@@ -209,6 +232,10 @@ struct FineArgs {
     TileGrid g;
     int N, K;
     float thr;
+    // optional fused blend (dss_render_forward): image (N,rows,S,C+1) and wsum (N,rows,S)
+    const float *scaler, *feat;
+    float *image, *wsum;
+    int C;
 };
 
 // K-nearest bookkeeping: one 64-bit key per slot, (z bits << 32) | idx.  Hits have z >= 0
@@ -337,8 +364,14 @@ __global__ __launch_bounds__(FINE_THREADS) void fine_kernel(const FineArgs A)
                 A.zbuf[rb + cc] = -1.0f;
                 A.qv[rb + cc] = -1.0f;
             }
-            if (lane < min(DSS_TILE, S - c0))
-                A.occ[((size_t)n * g.rows + (size_t)ty * DSS_TILE + rr) * S + c0 + lane] = 0.0f;
+            if (lane < min(DSS_TILE, S - c0)) {
+                const size_t pix = ((size_t)n * g.rows + (size_t)ty * DSS_TILE + rr) * S + c0 + lane;
+                A.occ[pix] = 0.0f;
+                if (A.image) {  // fused blend of an empty pixel: zeros, weight sum clamped to kEpsilon
+                    for (int ch = 0; ch <= A.C; ++ch) A.image[pix * (A.C + 1) + ch] = 0.0f;
+                    A.wsum[pix] = 1e-4f;
+                }
+            }
         }
         FT_MARK(7);
         FT_VAL(9, __builtin_amdgcn_s_memrealtime());
@@ -459,6 +492,31 @@ __global__ __launch_bounds__(FINE_THREADS) void fine_kernel(const FineArgs A)
 #pragma unroll
             for (int k = 0; k < KMAX; ++k)
                 if (k < K && ki[k] >= 0) A.visible[ki[k]] = 1;
+        }
+        if (A.image) {
+            // fused blend (same arithmetic and order as blend_forward_kernel): w = exp(-q/2)*scaler,
+            // img = sum f*w/cum, alpha = occupancy
+            float wk[KMAX];
+            float cum = 0.0f;
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) {
+                wk[k] = 0.0f;
+                if (k < K && ki[k] >= 0) {
+                    wk[k] = expf(-0.5f * kq[k]) * A.scaler[ki[k]];
+                    cum += wk[k];
+                }
+            }
+            if (cum < 1e-4f) cum = 1e-4f;
+            A.wsum[pix] = cum;
+            float *o = A.image + pix * (A.C + 1);
+            for (int ch = 0; ch < A.C; ++ch) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int k = 0; k < KMAX; ++k)
+                    if (k < K && ki[k] >= 0) acc += A.feat[(size_t)ki[k] * A.C + ch] * wk[k] / cum;
+                o[ch] = acc;
+            }
+            o[A.C] = any ? 1.0f : 0.0f;
         }
     }
 
@@ -755,6 +813,7 @@ extern "C" int dss_splat_fine(const float *points, const float *ellipse, const f
     A.offsets = nullptr; A.cursor = nullptr; A.overflow = nullptr; A.list = nullptr;
     A.idx = idx; A.zbuf = zbuf; A.qv = qvalue; A.occ = occ; A.visible = visible;
     A.g = g; A.N = N; A.K = K; A.thr = merge_thr;
+    A.scaler = nullptr; A.feat = nullptr; A.image = nullptr; A.wsum = nullptr; A.C = 0;
     if (workspace && P > 0) {
         if (workspace_bytes < dss_splat_forward_workspace(N, P, S, K, 1)) {
             set_error("dss_splat_fine: workspace too small");
@@ -797,3 +856,75 @@ extern "C" __attribute__((visibility("default"))) int dss_debug_set_fine_timing(
     return hipMemcpyToSymbol(HIP_SYMBOL(dss::g_fine_timing), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
 }
 #endif
+
+// ---------------------------------------------------------------------------------------------
+// Fused single-call forward: setup+count -> scan -> fill -> fine(+blend).  Five launches (with the
+// counter memset) instead of eight for the separate entry points, and neither the screen records nor
+// the fragment lists are re-read by a separate setup/blend pass.
+// ---------------------------------------------------------------------------------------------
+extern "C" size_t dss_render_forward_workspace(int N, int64_t P, int S, int K)
+{
+    return dss_splat_forward_workspace(N, P, S, K, 1);
+}
+
+extern "C" int dss_render_forward(const float *world, const float *normals, const float *h_point, const float *h_cloud,
+                                  const float *M, const float *V, const float *znear, const float *zfar,
+                                  const int64_t *first_idx, const int64_t *num_pts, int N, int64_t P, int shared_cloud,
+                                  int backface_culling, int S, int K, float cutoff_threshold, float antialiasing_sigma,
+                                  float merge_thr, int row0, int row1, const float *feat, int C,
+                                  float *pts_screen, float *ellipse, float *radii, float *scaler, float *cutoff,
+                                  uint8_t *valid, int32_t *idx, float *zbuf, float *qvalue, float *occ,
+                                  uint8_t *visible, float *image, float *wsum, void *workspace, size_t workspace_bytes,
+                                  void *stream)
+{
+    int rc = validate_fwd("dss_render_forward", N, P, S, K, row0, row1);
+    if (rc) return rc;
+    if (K > DSS_MAX_K_FAST) {
+        set_error("dss_render_forward: fused path needs points_per_pixel <= %d (use the separate entry points)",
+                  DSS_MAX_K_FAST);
+        return DSS_ERR_UNSUPPORTED;
+    }
+    if (P == 0 || C < 1 || C > 8) {
+        set_error("dss_render_forward: needs P > 0 and 1 <= C <= 8 (P=%lld C=%d)", (long long)P, C);
+        return DSS_ERR_INVALID_ARGUMENT;
+    }
+    if (!world || !normals || (!h_point && !h_cloud) || !M || !V || !znear || !zfar || !first_idx || !num_pts || !feat ||
+        !pts_screen || !ellipse || !radii || !scaler || !cutoff || !valid || !idx || !zbuf || !qvalue || !occ ||
+        !visible || !image || !wsum) {
+        set_error("dss_render_forward: NULL tensor pointer");
+        return DSS_ERR_INVALID_ARGUMENT;
+    }
+    const size_t need = dss_splat_forward_workspace(N, P, S, K, 1);
+    if (!workspace || workspace_bytes < need) {
+        set_error("dss_render_forward: workspace %zu bytes < required %zu", workspace_bytes, need);
+        return DSS_ERR_WORKSPACE;
+    }
+    hipStream_t st = as_stream(stream);
+    const TileGrid g = make_grid(S, row0, row1);
+    const int tiles = g.tiles_x * g.tiles_y;
+    if ((long long)N * tiles > 0x7fffffffll) { set_error("dss_render_forward: too many tiles"); return DSS_ERR_UNSUPPORTED; }
+    FwdWorkspace w = carve_fwd(workspace, N, P, S, workspace_bytes);
+    if (hipMemsetAsync(w.tile_count, 0, (size_t)N * tiles * DSS_SUB * 4, st) != hipSuccess)
+        return check_launch("memset tile_count");
+    SetupArgs SA;
+    SA.world = world; SA.normals = normals; SA.h_point = h_point; SA.h_cloud = h_cloud; SA.M = M; SA.V = V;
+    SA.znear = znear; SA.zfar = zfar; SA.first_idx = first_idx; SA.num_pts = num_pts; SA.N = N; SA.P = P;
+    SA.shared = shared_cloud; SA.backface = backface_culling; SA.S = S; SA.cutoffC = cutoff_threshold;
+    SA.sigma = antialiasing_sigma; SA.screen = pts_screen; SA.ellipse = ellipse; SA.radii = radii; SA.scaler = scaler;
+    SA.cutoff = cutoff; SA.valid = valid;
+    const int pb = (int)((P + 255) / 256);
+    hipLaunchKernelGGL(setup_bin_count_kernel, dim3(pb), dim3(256), 0, st, SA, g, w.tile_count, w.rects, visible);
+    hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), 0, st, w.tile_count, N * tiles, w.offsets, w.cursor,
+                       w.capacity, w.overflow);
+    hipLaunchKernelGGL(bin_fill_kernel, dim3(pb), dim3(256), 0, st, w.rects, first_idx, num_pts, N, P, g, w.cursor,
+                       w.overflow, w.list);
+    FineArgs A;
+    A.points = pts_screen; A.ellipse = ellipse; A.cutoff = cutoff; A.radii = radii;
+    A.first_idx = first_idx; A.num_pts = num_pts;
+    A.offsets = w.offsets; A.cursor = w.cursor; A.overflow = w.overflow; A.list = w.list;
+    A.idx = idx; A.zbuf = zbuf; A.qv = qvalue; A.occ = occ; A.visible = visible;
+    A.g = g; A.N = N; A.K = K; A.thr = merge_thr;
+    A.scaler = scaler; A.feat = feat; A.image = image; A.wsum = wsum; A.C = C;
+    if (!dispatch_fine(A, N * tiles, st)) { set_error("dss_render_forward: no kernel for K=%d", K); return DSS_ERR_UNSUPPORTED; }
+    return check_launch("dss_render_forward");
+}

@@ -277,6 +277,56 @@ def blend_backward(grad_out, idx, qvalue, scaler, num_points: int, geometry=None
     return gf, grad_out[..., C]
 
 
+def render_forward(world, normals, h, M, V, znear, zfar, cloud_to_packed_first_idx, num_points_per_cloud, features,
+                   image_size: int, points_per_pixel: int, cutoff_threshold: float, depth_merging_thres: float,
+                   antialiasing_sigma: float = 1.0, backface_culling: bool = False, shared_cloud: bool = False,
+                   rows: Optional[Tuple[int, int]] = None):
+    """Fused forward (setup + binning + fine + blend, ``dss_render_forward``).  ``features`` are the
+    packed (P,C) features.  Returns a dict with everything the separate calls produce:
+    ``pts_screen, ellipse_params, radii, scaler, cutoff_threshold, valid, idx, zbuf, qvalue, occupancy,
+    visible, image, wsum``."""
+    lib = _lib.load()
+    world = _lib.require_gpu(world, "world", _f32)
+    dev = world.device
+    normals = _lib.require_gpu(normals, "normals", _f32)
+    h = _lib.require_gpu(h, "h", _f32)
+    M = _lib.require_gpu(M, "M", _f32)
+    V = _lib.require_gpu(V, "V", _f32)
+    znear = _lib.require_gpu(znear, "znear", _f32)
+    zfar = _lib.require_gpu(zfar, "zfar", _f32)
+    first = _lib.require_gpu(cloud_to_packed_first_idx, "cloud_to_packed_first_idx", _i64)
+    num = _lib.require_gpu(num_points_per_cloud, "num_points_per_cloud", _i64)
+    features = _lib.require_gpu(features, "features", _f32)
+    N, Pw = first.shape[0], world.shape[0]
+    P = N * Pw if shared_cloud else Pw
+    if features.shape[0] != P:
+        raise RuntimeError("features must be packed (P,C) with P=%d, got %s" % (P, tuple(features.shape)))
+    per_point = h.numel() == Pw and not (h.numel() == N and Pw == N)
+    if not per_point and h.numel() != N:
+        raise RuntimeError("h must have %d (per point) or %d (per cloud) entries" % (Pw, N))
+    S, K, C = int(image_size), int(points_per_pixel), features.shape[1]
+    row0, row1 = (0, S) if rows is None else (int(rows[0]), int(rows[1]))
+    nr = row1 - row0
+    e = lambda *shape, dtype=_f32: torch.empty(shape, dtype=dtype, device=dev)
+    with torch.cuda.device(dev):
+        o = dict(pts_screen=e(P, 3), ellipse_params=e(P, 3), radii=e(P, 2), scaler=e(P), cutoff_threshold=e(P),
+                 idx=e(N, nr, S, K, dtype=_i32), zbuf=e(N, nr, S, K), qvalue=e(N, nr, S, K), occupancy=e(N, nr, S),
+                 image=e(N, nr, S, C + 1), wsum=e(N, nr, S))
+        valid, vis = e(P, dtype=_u8), e(P, dtype=_u8)
+        ws = _lib.workspace(dev, lib.dss_render_forward_workspace(N, P, S, K))
+        rc = lib.dss_render_forward(
+            _lib.ptr(world), _lib.ptr(normals), _lib.ptr(h) if per_point else None, None if per_point else _lib.ptr(h),
+            _lib.ptr(M), _lib.ptr(V), _lib.ptr(znear), _lib.ptr(zfar), _lib.ptr(first), _lib.ptr(num), N, P,
+            int(shared_cloud), int(backface_culling), S, K, float(cutoff_threshold), float(antialiasing_sigma),
+            float(depth_merging_thres), row0, row1, _lib.ptr(features), C, _lib.ptr(o["pts_screen"]),
+            _lib.ptr(o["ellipse_params"]), _lib.ptr(o["radii"]), _lib.ptr(o["scaler"]), _lib.ptr(o["cutoff_threshold"]),
+            _lib.ptr(valid), _lib.ptr(o["idx"]), _lib.ptr(o["zbuf"]), _lib.ptr(o["qvalue"]), _lib.ptr(o["occupancy"]),
+            _lib.ptr(vis), _lib.ptr(o["image"]), _lib.ptr(o["wsum"]), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
+    _lib.check(rc, "dss_render_forward")
+    o["valid"], o["visible"] = valid.view(torch.bool), vis.view(torch.bool)
+    return o
+
+
 def render_backward(grad_out, idx, qvalue, wsum, scaler, points, radii, visible, cloud_to_packed_first_idx,
                     num_points_per_cloud, radii_s: float, clip: float = -1.0, with_features: bool = True,
                     return_rs: bool = False):

@@ -184,6 +184,26 @@ DSS_API int dss_blend_backward_scatter(const float *grad_out, const int32_t *idx
                                        int64_t P, float *grad_feat, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Fused forward of SurfaceSplattingRenderer.forward (renderer.py:36-82 incl. the whole
+ * SurfaceSplatting.forward, rasterizer.py:584-664) in one call and five launches:
+ * [setup + tile count] -> scan -> fill -> [fine + blend].  Same inputs as dss_point_setup +
+ * dss_splat_forward + dss_blend_forward, same outputs (all of them are written: the per-point
+ * screen-space arrays, the fragments, visibility, the (N,rows,S,C+1) image and wsum), same bits.
+ * K <= DSS_MAX_K_FAST, 1 <= C <= 8.
+ * ------------------------------------------------------------------------------------------- */
+DSS_API size_t dss_render_forward_workspace(int N, int64_t P, int S, int K);
+DSS_API int dss_render_forward(const float *world, const float *normals, const float *h_point,
+                               const float *h_cloud, const float *M, const float *V, const float *znear,
+                               const float *zfar, const int64_t *first_idx, const int64_t *num_pts,
+                               int N, int64_t P, int shared_cloud, int backface_culling, int S, int K,
+                               float cutoff_threshold, float antialiasing_sigma, float merge_thr,
+                               int row0, int row1, const float *feat /* (P,C) */, int C,
+                               float *pts_screen, float *ellipse, float *radii, float *scaler,
+                               float *cutoff, uint8_t *valid, int32_t *idx, float *zbuf, float *qvalue,
+                               float *occ, uint8_t *visible, float *image, float *wsum,
+                               void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Fused single-GPU backward of renderer + rasterizer: dss_blend_backward + dss_backward_radius +
  * dss_occ_backward + dss_clip_grad in five launches, with the per-point work done by persistent
  * wavefronts over the compacted list of visible points (the stand-alone kernels are bound by the

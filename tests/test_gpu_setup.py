@@ -124,3 +124,33 @@ def test_foreign_compositor_call_convention():
     out = NormWeightedCompositor()(t(idx).long().permute(0, 3, 1, 2), t(w).permute(0, 3, 1, 2), t(sc["colors"]).permute(1, 0))
     want = oracle.blend_forward(idx, qv, occ, sc["scaler"], sc["colors"])[..., :3]
     assert np.abs(out.permute(0, 2, 3, 1).cpu().numpy() - want).max() <= 1e-4
+
+
+@pytest.mark.parametrize("shared", [True, False])
+def test_render_forward_fused_equals_separate_calls(shared):
+    pts, nrm, col, M, V, az = _scene()
+    N, Pc, S, K = M.shape[0], pts.shape[0], 128, 5
+    h = scenes.global_h(pts)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    if shared:
+        world, normals = t(pts), t(nrm)
+    else:
+        world, normals = t(np.tile(pts, (N, 1))), t(np.tile(nrm, (N, 1)))
+    feat = t(np.tile(col, (N, 1)))
+    first = torch.arange(N, device=DEV) * Pc
+    num = torch.full((N,), Pc, device=DEV, dtype=torch.int64)
+    hh = torch.full((N,), h, device=DEV)
+    zn, zf = torch.full((N,), 0.6, device=DEV), torch.full((N,), 100.0, device=DEV)
+    for rows in (None, (32, 96)):
+        f = ops.render_forward(world, normals, hh, t(M), t(V), zn, zf, first, num, feat, S, K, 1.0, 0.05, 1.0, True,
+                               shared, rows=rows)
+        info = ops.point_setup(world, normals, hh, t(M), t(V), zn, zf, first, num, S, 1.0, 1.0, True, shared)
+        idx, zbuf, qv, occ, vis = ops.splat_points(info["pts_screen"], info["ellipse_params"], info["cutoff_threshold"],
+                                                   info["radii"], first, num, 0.05, S, K, None, None, rows=rows,
+                                                   return_visible=True)
+        img, wsum = ops.blend_forward(idx, qv, occ, info["scaler"], feat, return_wsum=True)
+        for k in ("pts_screen", "ellipse_params", "radii", "scaler", "cutoff_threshold", "valid"):
+            assert torch.equal(f[k], info[k]), k
+        assert torch.equal(f["idx"], idx) and torch.equal(f["zbuf"], zbuf) and torch.equal(f["qvalue"], qv)
+        assert torch.equal(f["occupancy"], occ) and torch.equal(f["visible"], vis)
+        assert torch.equal(f["image"], img) and torch.equal(f["wsum"], wsum)
