@@ -3,9 +3,10 @@
 // Replaces the reference's naive / coarse / fine CUDA kernels
 // (DSS/csrc/rasterize_points.cu:131-212, 293-432, 506-597) with a different decomposition:
 //
-//   bin_count   one thread per splat: exact pixel rect -> 8x8 screen-tile rect, per-tile counts
-//   bin_scan    exclusive scan of the per-tile counts (compacted lists, no dense (N,B,B,M) table)
-//   bin_fill    one thread per splat: append its id to every tile list it overlaps
+//   bin         one thread per splat: exact pixel rect -> 8x8 screen-tile rect; the splat id is
+//               appended straight into fixed-capacity per-tile sub-lists (one returning atomic per
+//               (splat, tile) pair; no count/scan/fill passes, no single-workgroup scan).  A tile whose
+//               sub-list overflows is rasterized from the whole cloud instead (exact, just slower).
 //   fine        one 256-thread workgroup per tile = four wavefronts, one 4x4 pixel footprint
 //               each, four candidate slices per pixel.  Candidates are staged through LDS in
 //               chunks of 256; every wavefront culls the chunk against its footprint with one
@@ -21,10 +22,12 @@
 
 namespace dss {
 
-// Each tile owns DSS_SUB consecutive counters / sub-lists, selected by the low bits of the splat id.
-// Same-address global atomics serialise (~50 ns each on MI355X: 523 splats on the hottest tile of
-// the bunny scene cost ~30 us); splitting cuts the depth of every hot address by DSS_SUB, and because
-// the sub-lists of one tile are adjacent in the scanned offset array the tile list stays contiguous.
+// Each tile owns DSS_SUB counters / sub-lists, selected by the low bits of the splat id.
+// Same-address global atomics serialise (~50 ns each on MI355X: 523 splats on the hottest 16x16 tile of
+// the bunny scene cost ~30 us); splitting cuts the depth of every hot address by DSS_SUB.
+// Sub-lists have a fixed capacity `cap` (workspace layout: counts (N*tiles*SUB) uint32, then lists
+// (N*tiles*SUB*cap) int32), sized ~32x the mean load (see bin_capacity); a count above `cap` marks the
+// tile as overflowed.
 #define DSS_SUB 8
 
 struct TileGrid {
@@ -66,45 +69,59 @@ __device__ __forceinline__ bool splat_tile_rect(float px, float py, float pz, fl
     return true;
 }
 
-// count the tiles of one splat (screen record given) and store its tile rectangle
-__device__ __forceinline__ void bin_count_point(int64_t p, int n, float px, float py, float pz, float rx, float ry,
-                                                const TileGrid g, uint32_t *__restrict__ tile_count,
-                                                uint2 *__restrict__ rects)
+// append splat p to the sub-list (p mod SUB) of every tile of its rectangle
+__device__ __forceinline__ void bin_point(int64_t p, int n, float px, float py, float pz, float rx, float ry,
+                                          const TileGrid g, uint32_t *__restrict__ counts,
+                                          int32_t *__restrict__ lists, uint32_t cap)
 {
-    uint2 rc = make_uint2(0xffffffffu, 0u);  // empty
-    if (n >= 0) {
-        int tx0, tx1, ty0, ty1;
-        if (splat_tile_rect(px, py, pz, rx, ry, g, tx0, tx1, ty0, ty1)) {
-            rc.x = (uint32_t)tx0 | ((uint32_t)tx1 << 16);
-            rc.y = (uint32_t)ty0 | ((uint32_t)ty1 << 16);
-            uint32_t *cnt = tile_count + ((size_t)n * g.tiles_x * g.tiles_y) * DSS_SUB + ((unsigned)p & (DSS_SUB - 1));
-            for (int ty = ty0; ty <= ty1; ++ty)
-                for (int tx = tx0; tx <= tx1; ++tx) atomicAdd(&cnt[(ty * g.tiles_x + tx) * DSS_SUB], 1u);
-        }
+    if (n < 0) return;
+    int tx0, tx1, ty0, ty1;
+    if (!splat_tile_rect(px, py, pz, rx, ry, g, tx0, tx1, ty0, ty1)) return;
+    const size_t sub0 = ((size_t)n * g.tiles_x * g.tiles_y) * DSS_SUB + ((unsigned)p & (DSS_SUB - 1));
+    if (tx1 - tx0 <= 1 && ty1 - ty0 <= 1) {
+        // common case (splat overlaps at most 2x2 tiles): the returning atomics are independent, issue
+        // them back to back so their latencies overlap instead of chaining
+        const size_t t00 = sub0 + (size_t)(ty0 * g.tiles_x + tx0) * DSS_SUB;
+        const size_t t01 = t00 + DSS_SUB, t10 = t00 + (size_t)g.tiles_x * DSS_SUB, t11 = t10 + DSS_SUB;
+        const bool hx = tx1 > tx0, hy = ty1 > ty0;
+        uint32_t p0, p1 = 0, p2 = 0, p3 = 0;
+        p0 = atomicAdd(&counts[t00], 1u);
+        if (hx) p1 = atomicAdd(&counts[t01], 1u);
+        if (hy) p2 = atomicAdd(&counts[t10], 1u);
+        if (hx && hy) p3 = atomicAdd(&counts[t11], 1u);
+        if (p0 < cap) lists[t00 * cap + p0] = (int32_t)p;
+        if (hx && p1 < cap) lists[t01 * cap + p1] = (int32_t)p;
+        if (hy && p2 < cap) lists[t10 * cap + p2] = (int32_t)p;
+        if (hx && hy && p3 < cap) lists[t11 * cap + p3] = (int32_t)p;
+        return;
     }
-    rects[p] = rc;  // the cloud id is recomputed in bin_fill (N is tiny): keeps the record at 8 bytes
+    for (int ty = ty0; ty <= ty1; ++ty)
+        for (int tx = tx0; tx <= tx1; ++tx) {
+            const size_t t = sub0 + (size_t)(ty * g.tiles_x + tx) * DSS_SUB;
+            const uint32_t pos = atomicAdd(&counts[t], 1u);
+            if (pos < cap) lists[t * cap + pos] = (int32_t)p;
+        }
 }
 
-__global__ __launch_bounds__(256) void bin_count_kernel(
+__global__ __launch_bounds__(256) void bin_kernel(
     const float *__restrict__ points, const float *__restrict__ radii,
     const int64_t *__restrict__ first_idx, const int64_t *__restrict__ num_pts, int N, int64_t P,
-    TileGrid g, uint32_t *__restrict__ tile_count /* (N*tiles*SUB) */, uint2 *__restrict__ rects /* (P) */,
+    TileGrid g, uint32_t *__restrict__ counts, int32_t *__restrict__ lists, uint32_t cap,
     uint8_t *__restrict__ visible_to_clear /* (P) or nullptr */)
 {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= P) return;
     if (visible_to_clear) visible_to_clear[p] = 0;  // saves a separate memset launch
     const int n = find_cloud(p, first_idx, num_pts, N);
-    bin_count_point(p, n, points[3 * p], points[3 * p + 1], points[3 * p + 2], radii[2 * p], radii[2 * p + 1], g,
-                    tile_count, rects);
+    bin_point(p, n, points[3 * p], points[3 * p + 1], points[3 * p + 2], radii[2 * p], radii[2 * p + 1], g, counts,
+              lists, cap);
 }
 
-// dss_render_forward: per-point setup (culling + projection + EWA terms) fused with the tile count --
-// the screen record goes from registers straight into the binning, one launch and one re-read fewer.
-__global__ __launch_bounds__(256) void setup_bin_count_kernel(const SetupArgs A, TileGrid g,
-                                                              uint32_t *__restrict__ tile_count,
-                                                              uint2 *__restrict__ rects,
-                                                              uint8_t *__restrict__ visible_to_clear)
+// dss_render_forward: per-point setup (culling + projection + EWA terms) fused with the binning --
+// the screen record goes from registers straight into the tile lists.
+__global__ __launch_bounds__(256) void setup_bin_kernel(const SetupArgs A, TileGrid g, uint32_t *__restrict__ counts,
+                                                        int32_t *__restrict__ lists, uint32_t cap,
+                                                        uint8_t *__restrict__ visible_to_clear)
 {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= A.P) return;
@@ -112,107 +129,7 @@ __global__ __launch_bounds__(256) void setup_bin_count_kernel(const SetupArgs A,
     const int n = find_cloud(p, A.first_idx, A.num_pts, A.N);
     float px, py, pz, rx, ry;
     setup_point(A, p, n, px, py, pz, rx, ry);
-    bin_count_point(p, n, px, py, pz, rx, ry, g, tile_count, rects);
-}
-
-// Exclusive scan of the (n_tiles x DSS_SUB) counters by ONE workgroup of 1024 threads; every thread
-// owns SCAN_TPT consecutive tiles (SCAN_TPT * DSS_SUB counters) per trip.  Writes offsets[0..n*SUB] (last = total) and
-// cursor[i] = offsets[i]; sets *overflow = 1 when the total exceeds `capacity` (the fine kernel
-// then scans whole clouds instead of lists).
-#define SCAN_TPT 1   // measured: 4 tiles (128 B) per thread is slower (14 us vs 8 us at 4096 tiles): lane stride kills coalescing
-__global__ __launch_bounds__(1024) void bin_scan_kernel(const uint32_t *__restrict__ count, int n_tiles,
-                                                        uint32_t *__restrict__ offsets,
-                                                        uint32_t *__restrict__ cursor,
-                                                        uint32_t capacity, uint32_t *__restrict__ overflow)
-{
-    constexpr int CPT = SCAN_TPT * DSS_SUB;  // counters per thread per trip
-    __shared__ uint32_t wave_tot[16];
-    __shared__ uint32_t carry_s;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const long long n_cnt = (long long)n_tiles * DSS_SUB;
-    if (tid == 0) carry_s = 0;
-    __syncthreads();
-    for (long long base = 0; base < n_cnt; base += 1024ll * CPT) {
-        const long long i0 = base + (long long)tid * CPT;
-        uint32_t c[CPT];
-        uint32_t v = 0;
-#pragma unroll
-        for (int q = 0; q < CPT / 4; ++q) {
-            uint4 u = make_uint4(0, 0, 0, 0);
-            if (i0 + 4 * q < n_cnt) u = reinterpret_cast<const uint4 *>(count + i0)[q];  // n_cnt % 4 == 0
-            c[4 * q] = u.x; c[4 * q + 1] = u.y; c[4 * q + 2] = u.z; c[4 * q + 3] = u.w;
-            v += u.x + u.y + u.z + u.w;
-        }
-        uint32_t x = v;  // inclusive scan inside the wave
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t y = __shfl_up(x, o, 64);
-            if (lane >= o) x += y;
-        }
-        if (lane == 63) wave_tot[wid] = x;
-        __syncthreads();
-        uint32_t wave_off = 0;
-        for (int w = 0; w < wid; ++w) wave_off += wave_tot[w];
-        const uint32_t excl = carry_s + wave_off + x - v;
-        uint32_t run = excl;
-#pragma unroll
-        for (int q = 0; q < CPT / 4; ++q) {
-            uint4 u;
-            u.x = run; run += c[4 * q];
-            u.y = run; run += c[4 * q + 1];
-            u.z = run; run += c[4 * q + 2];
-            u.w = run; run += c[4 * q + 3];
-            if (i0 + 4 * q < n_cnt) {
-                reinterpret_cast<uint4 *>(offsets + i0)[q] = u;
-                reinterpret_cast<uint4 *>(cursor + i0)[q] = u;
-            }
-        }
-        __syncthreads();
-        if (tid == 1023) carry_s = excl + v;
-        __syncthreads();
-    }
-    if (tid == 0) {
-        const uint32_t total = carry_s;
-        offsets[n_cnt] = total;
-        *overflow = (total > capacity) ? 1u : 0u;
-    }
-}
-
-__global__ __launch_bounds__(256) void bin_fill_kernel(
-    const uint2 *__restrict__ rects, const int64_t *__restrict__ first_idx,
-    const int64_t *__restrict__ num_pts, int N, int64_t P, TileGrid g,
-    uint32_t *__restrict__ cursor, const uint32_t *__restrict__ overflow,
-    int32_t *__restrict__ list)
-{
-    if (*overflow) return;
-    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= P) return;
-    const uint2 rc = rects[p];
-    if (rc.x == 0xffffffffu) return;
-    const int n = find_cloud(p, first_idx, num_pts, N);
-    const int tx0 = rc.x & 0xffff, tx1 = rc.x >> 16, ty0 = rc.y & 0xffff, ty1 = rc.y >> 16;
-    uint32_t *cur = cursor + ((size_t)n * g.tiles_x * g.tiles_y) * DSS_SUB + ((unsigned)p & (DSS_SUB - 1));
-    if (tx1 - tx0 <= 1 && ty1 - ty0 <= 1) {
-        // common case (splat overlaps at most 2x2 tiles): the returning atomics are independent, issue
-        // them back to back so their latencies overlap instead of chaining
-        const int t00 = ty0 * g.tiles_x + tx0;
-        const bool hx = tx1 > tx0, hy = ty1 > ty0;
-        uint32_t p0, p1 = 0, p2 = 0, p3 = 0;
-        p0 = atomicAdd(&cur[(size_t)t00 * DSS_SUB], 1u);
-        if (hx) p1 = atomicAdd(&cur[(size_t)(t00 + 1) * DSS_SUB], 1u);
-        if (hy) p2 = atomicAdd(&cur[(size_t)(t00 + g.tiles_x) * DSS_SUB], 1u);
-        if (hx && hy) p3 = atomicAdd(&cur[(size_t)(t00 + g.tiles_x + 1) * DSS_SUB], 1u);
-        list[p0] = (int32_t)p;
-        if (hx) list[p1] = (int32_t)p;
-        if (hy) list[p2] = (int32_t)p;
-        if (hx && hy) list[p3] = (int32_t)p;
-        return;
-    }
-    for (int ty = ty0; ty <= ty1; ++ty)
-        for (int tx = tx0; tx <= tx1; ++tx) {
-            const uint32_t pos = atomicAdd(&cur[(size_t)(ty * g.tiles_x + tx) * DSS_SUB], 1u);
-            list[pos] = (int32_t)p;
-        }
+    bin_point(p, n, px, py, pz, rx, ry, g, counts, lists, cap);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -222,10 +139,9 @@ __global__ __launch_bounds__(256) void bin_fill_kernel(
 struct FineArgs {
     const float *points, *ellipse, *cutoff, *radii;
     const int64_t *first_idx, *num_pts;
-    const uint32_t *offsets;   // (N*tiles*DSS_SUB + 1) or nullptr (naive mode)
-    const uint32_t *cursor;    // fill cursors (unused by the fine kernel)
-    const uint32_t *overflow;  // nullptr in naive mode
-    const int32_t *list;
+    const uint32_t *counts;    // (N*tiles*DSS_SUB) sub-list fill counts, or nullptr (naive mode)
+    const int32_t *lists;      // (N*tiles*DSS_SUB*cap)
+    uint32_t cap;              // sub-list capacity
     int32_t *idx;
     float *zbuf, *qv, *occ;
     uint8_t *visible;
@@ -236,6 +152,53 @@ struct FineArgs {
     const float *scaler, *feat;
     float *image, *wsum;
     int C;
+};
+
+// Candidate source of one tile: its DSS_SUB fixed-capacity sub-lists (binned mode) or the whole cloud
+// (naive mode, or a tile whose sub-list overflowed).  `at(i)` maps the i-th candidate to a splat id.
+struct TileSource {
+    bool use_list;
+    int64_t first;          // cloud scan: first packed index
+    int64_t count;
+    const int32_t *base;    // binned: &lists[tile*SUB*cap]
+    uint32_t cap;
+    uint32_t ps[DSS_SUB + 1];  // prefix sums of the sub-list lengths
+    __device__ __forceinline__ void init(const FineArgs &A, int n)
+    {
+        use_list = false;
+        if (A.counts != nullptr) {
+            const uint4 *c4 = reinterpret_cast<const uint4 *>(A.counts + (size_t)blockIdx.x * DSS_SUB);
+            uint32_t c[DSS_SUB];
+#pragma unroll
+            for (int q = 0; q < DSS_SUB / 4; ++q) {
+                const uint4 u = c4[q];
+                c[4 * q] = u.x; c[4 * q + 1] = u.y; c[4 * q + 2] = u.z; c[4 * q + 3] = u.w;
+            }
+            bool ok = true;
+            ps[0] = 0;
+#pragma unroll
+            for (int q = 0; q < DSS_SUB; ++q) {
+                ok = ok && (c[q] <= A.cap);
+                ps[q + 1] = ps[q] + c[q];
+            }
+            use_list = ok;
+            count = ps[DSS_SUB];
+            cap = A.cap;
+            base = A.lists + (size_t)blockIdx.x * DSS_SUB * A.cap;
+        }
+        if (!use_list) {
+            first = A.first_idx[n];
+            count = A.num_pts[n];
+        }
+    }
+    __device__ __forceinline__ int64_t at(int64_t i) const
+    {
+        if (!use_list) return first + i;
+        int sub = 0;
+#pragma unroll
+        for (int q = 1; q < DSS_SUB; ++q) sub += ((uint32_t)i >= ps[q]) ? 1 : 0;
+        return (int64_t)base[(size_t)sub * cap + ((uint32_t)i - ps[sub])];
+    }
 };
 
 // K-nearest bookkeeping: one 64-bit key per slot, (z bits << 32) | idx.  Hits have z >= 0
@@ -326,24 +289,10 @@ __global__ __launch_bounds__(FINE_THREADS) void fine_kernel(const FineArgs A)
     const float f_xmax = pix_to_ndc(S - 1 - fc0, S), f_xmin = pix_to_ndc(S - 1 - (fc0 + 3), S);
     const float f_ymax = pix_to_ndc(S - 1 - fr0, S), f_ymin = pix_to_ndc(S - 1 - (fr0 + 3), S);
 
-    // candidate source: tile list (binned) or the whole cloud (naive / list overflow)
-    int64_t src0;
-    int64_t count;
-    bool use_list = false;
-    if (A.offsets != nullptr) {
-        // the three loads are independent; the DSS_SUB sub-lists of a tile are adjacent:
-        // [offsets[tile*SUB], offsets[(tile+1)*SUB])
-        const uint32_t ovf = *A.overflow;
-        const uint32_t o0 = A.offsets[(size_t)blockIdx.x * DSS_SUB];
-        const uint32_t o1 = A.offsets[((size_t)blockIdx.x + 1) * DSS_SUB];
-        use_list = ovf == 0u;
-        src0 = o0;
-        count = (int64_t)o1 - (int64_t)o0;
-    }
-    if (!use_list) {
-        src0 = A.first_idx[n];
-        count = A.num_pts[n];
-    }
+    // candidate source: tile sub-lists (binned) or the whole cloud (naive / overflowed tile)
+    TileSource src;
+    src.init(A, n);
+    const int64_t count = src.count;
 
     // rows of the tile are contiguous runs of 16*K dwords in the (N,rows,S,K) tensors
     const int K = A.K;
@@ -391,7 +340,7 @@ __global__ __launch_bounds__(FINE_THREADS) void fine_kernel(const FineArgs A)
         const int m = (int)min((int64_t)CHUNK, count - base);
         __syncthreads();  // previous chunk fully consumed
         if (tid < m) {
-            const int64_t p = use_list ? (int64_t)A.list[src0 + base + tid] : (src0 + base + tid);
+            const int64_t p = src.at(base + tid);
             const float px = A.points[3 * p], py = A.points[3 * p + 1], pz = A.points[3 * p + 2];
             const float2 rr = reinterpret_cast<const float2 *>(A.radii)[p];
             s_geo[tid] = make_float4(px, py, rr.x, rr.y);
@@ -581,23 +530,14 @@ __global__ __launch_bounds__(64) void fine_generic_kernel(const FineArgs A)
     const int S = g.S, K = A.K;
     const float xf = pix_to_ndc(S - 1 - c, S);
     const float yf = pix_to_ndc(S - 1 - r, S);
-    int64_t src0, count;
-    bool use_list = false;
-    if (A.offsets != nullptr) {
-        const uint32_t o0 = A.offsets[(size_t)blockIdx.x * DSS_SUB], o1 = A.offsets[((size_t)blockIdx.x + 1) * DSS_SUB];
-        use_list = *A.overflow == 0u;
-        src0 = o0;
-        count = (int64_t)o1 - (int64_t)o0;
-    }
-    if (!use_list) {
-        src0 = A.first_idx[n];
-        count = A.num_pts[n];
-    }
+    TileSource src;
+    src.init(A, n);
+    const int64_t count = src.count;
     unsigned long long key[DSS_MAX_K];
     float kq[DSS_MAX_K];
     int cnt = 0;
     for (int64_t j = 0; j < count; ++j) {
-        const int64_t p = use_list ? (int64_t)A.list[src0 + j] : (src0 + j);  // wave-uniform
+        const int64_t p = src.at(j);  // wave-uniform
         const float pz = A.points[3 * p + 2];
         if (pz < 0) continue;
         const float dx = xf - A.points[3 * p];
@@ -673,34 +613,36 @@ static bool dispatch_fine(const FineArgs &A, int blocks, hipStream_t st)
     return false;
 }
 
-// workspace layout (binned mode)
+// workspace layout (binned mode): counts | lists
 struct FwdWorkspace {
-    uint32_t *tile_count;  // N*tiles
-    uint32_t *offsets;     // N*tiles + 1
-    uint32_t *cursor;      // N*tiles
-    uint32_t *overflow;    // 1
-    uint2 *rects;          // P
-    int32_t *list;         // capacity
-    uint32_t capacity;
+    uint32_t *counts;  // N*tiles*SUB
+    int32_t *lists;    // N*tiles*SUB*cap
+    uint32_t cap;
+    size_t count_bytes;
     size_t bytes;
 };
 
-static FwdWorkspace carve_fwd(void *ws, int N, int64_t P, int S, size_t avail)
+// Sub-list capacity: ~32x the mean number of (splat, tile) pairs per sub-list (2 tiles per splat assumed),
+// a power of two in [32, 16384].  Depends only on (N, P, S) so the size query and the launch agree.
+static uint32_t bin_capacity(int N, int64_t P, int S)
+{
+    const double tiles = (double)((S + DSS_TILE - 1) / DSS_TILE) * ((S + DSS_TILE - 1) / DSS_TILE);
+    const double mean_sub = 2.0 * ((double)P / (N > 0 ? N : 1)) / (tiles * DSS_SUB);
+    uint32_t cap = 32;
+    while (cap < 16384 && (double)cap < 32.0 * mean_sub) cap <<= 1;
+    return cap;
+}
+
+static FwdWorkspace carve_fwd(void *ws, int N, int64_t P, int S)
 {
     FwdWorkspace w;
     const size_t tiles_max = (size_t)N * ((S + DSS_TILE - 1) / DSS_TILE) * ((S + DSS_TILE - 1) / DSS_TILE);
     char *p = reinterpret_cast<char *>(ws);
-    size_t off = 0;
-    w.tile_count = reinterpret_cast<uint32_t *>(p + off); off += align_up(tiles_max * DSS_SUB * 4, 256);
-    w.offsets = reinterpret_cast<uint32_t *>(p + off);    off += align_up((tiles_max * DSS_SUB + 1) * 4, 256);
-    w.cursor = reinterpret_cast<uint32_t *>(p + off);     off += align_up(tiles_max * DSS_SUB * 4, 256);
-    w.overflow = reinterpret_cast<uint32_t *>(p + off);   off += 256;
-    w.rects = reinterpret_cast<uint2 *>(p + off);         off += align_up((size_t)P * 8, 256);
-    w.list = reinterpret_cast<int32_t *>(p + off);
-    // everything that is left is list capacity (recommended: 8 pairs per splat, see below)
-    const size_t rest = (avail > off) ? (avail - off) / 4 : 0;
-    w.capacity = (uint32_t)(rest > 0xfffffff0ull ? 0xfffffff0ull : rest);
-    w.bytes = off;
+    w.cap = bin_capacity(N, P, S);
+    w.count_bytes = align_up(tiles_max * DSS_SUB * 4, 256);
+    w.counts = reinterpret_cast<uint32_t *>(p);
+    w.lists = reinterpret_cast<int32_t *>(p + w.count_bytes);
+    w.bytes = w.count_bytes + align_up(tiles_max * DSS_SUB * (size_t)w.cap * 4, 256);
     return w;
 }
 
@@ -712,11 +654,7 @@ extern "C" size_t dss_splat_forward_workspace(int N, int64_t P, int S, int K, in
 {
     (void)K;
     if (bin_size == 0 || N <= 0 || P <= 0 || S <= 0) return 256;
-    FwdWorkspace w = carve_fwd(nullptr, N, P, S, 0);
-    // list capacity: 8 (splat, tile) pairs per splat + one per tile.  A view that needs more
-    // (splats much larger than a tile) transparently falls back to whole-cloud scanning.
-    const size_t tiles = (size_t)N * ((S + DSS_TILE - 1) / DSS_TILE) * ((S + DSS_TILE - 1) / DSS_TILE);
-    return w.bytes + align_up(((size_t)P * 8 + tiles) * 4, 256);
+    return carve_fwd(nullptr, N, P, S).bytes;
 }
 
 static int validate_fwd(const char *fn, int N, int64_t P, int S, int K, int row0, int row1)
@@ -771,16 +709,12 @@ static int splat_bin_impl(const float *points, const float *radii, const int64_t
     const TileGrid g = make_grid(S, row0, row1);
     const int tiles = g.tiles_x * g.tiles_y;
     if ((long long)N * tiles > 0x7fffffffll) { set_error("dss_splat_bin: too many tiles"); return DSS_ERR_UNSUPPORTED; }
-    FwdWorkspace w = carve_fwd(workspace, N, P, S, workspace_bytes);
-    if (hipMemsetAsync(w.tile_count, 0, (size_t)N * tiles * DSS_SUB * 4, st) != hipSuccess)
-        return check_launch("memset tile_count");
+    FwdWorkspace w = carve_fwd(workspace, N, P, S);
+    if (hipMemsetAsync(w.counts, 0, (size_t)N * tiles * DSS_SUB * 4, st) != hipSuccess)
+        return check_launch("memset tile counts");
     const int pb = (int)((P + 255) / 256);
-    hipLaunchKernelGGL(bin_count_kernel, dim3(pb), dim3(256), 0, st, points, radii, first_idx, num_pts, N, P, g,
-                       w.tile_count, w.rects, visible_to_clear);
-    hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), 0, st, w.tile_count, N * tiles, w.offsets, w.cursor,
-                       w.capacity, w.overflow);
-    hipLaunchKernelGGL(bin_fill_kernel, dim3(pb), dim3(256), 0, st, w.rects, first_idx, num_pts, N, P, g, w.cursor,
-                       w.overflow, w.list);
+    hipLaunchKernelGGL(bin_kernel, dim3(pb), dim3(256), 0, st, points, radii, first_idx, num_pts, N, P, g, w.counts,
+                       w.lists, w.cap, visible_to_clear);
     return check_launch("dss_splat_bin");
 }
 
@@ -810,7 +744,7 @@ extern "C" int dss_splat_fine(const float *points, const float *ellipse, const f
     FineArgs A;
     A.points = points; A.ellipse = ellipse; A.cutoff = cutoff; A.radii = radii;
     A.first_idx = first_idx; A.num_pts = num_pts;
-    A.offsets = nullptr; A.cursor = nullptr; A.overflow = nullptr; A.list = nullptr;
+    A.counts = nullptr; A.lists = nullptr; A.cap = 0;
     A.idx = idx; A.zbuf = zbuf; A.qv = qvalue; A.occ = occ; A.visible = visible;
     A.g = g; A.N = N; A.K = K; A.thr = merge_thr;
     A.scaler = nullptr; A.feat = nullptr; A.image = nullptr; A.wsum = nullptr; A.C = 0;
@@ -819,8 +753,8 @@ extern "C" int dss_splat_fine(const float *points, const float *ellipse, const f
             set_error("dss_splat_fine: workspace too small");
             return DSS_ERR_WORKSPACE;
         }
-        FwdWorkspace w = carve_fwd(const_cast<void *>(workspace), N, P, S, workspace_bytes);
-        A.offsets = w.offsets; A.cursor = w.cursor; A.overflow = w.overflow; A.list = w.list;
+        FwdWorkspace w = carve_fwd(const_cast<void *>(workspace), N, P, S);
+        A.counts = w.counts; A.lists = w.lists; A.cap = w.cap;
     }
     if (!dispatch_fine(A, (int)blocks_ll, as_stream(stream))) {
         set_error("dss_splat_fine: no kernel for K=%d", K);
@@ -858,9 +792,8 @@ extern "C" __attribute__((visibility("default"))) int dss_debug_set_fine_timing(
 #endif
 
 // ---------------------------------------------------------------------------------------------
-// Fused single-call forward: setup+count -> scan -> fill -> fine(+blend).  Five launches (with the
-// counter memset) instead of eight for the separate entry points, and neither the screen records nor
-// the fragment lists are re-read by a separate setup/blend pass.
+// Fused single-call forward: [setup + binning] -> [fine + blend]: two kernel launches plus the counter
+// memset, and neither the screen records nor the fragment lists are re-read by a separate pass.
 // ---------------------------------------------------------------------------------------------
 extern "C" size_t dss_render_forward_workspace(int N, int64_t P, int S, int K)
 {
@@ -903,9 +836,9 @@ extern "C" int dss_render_forward(const float *world, const float *normals, cons
     const TileGrid g = make_grid(S, row0, row1);
     const int tiles = g.tiles_x * g.tiles_y;
     if ((long long)N * tiles > 0x7fffffffll) { set_error("dss_render_forward: too many tiles"); return DSS_ERR_UNSUPPORTED; }
-    FwdWorkspace w = carve_fwd(workspace, N, P, S, workspace_bytes);
-    if (hipMemsetAsync(w.tile_count, 0, (size_t)N * tiles * DSS_SUB * 4, st) != hipSuccess)
-        return check_launch("memset tile_count");
+    FwdWorkspace w = carve_fwd(workspace, N, P, S);
+    if (hipMemsetAsync(w.counts, 0, (size_t)N * tiles * DSS_SUB * 4, st) != hipSuccess)
+        return check_launch("memset tile counts");
     SetupArgs SA;
     SA.world = world; SA.normals = normals; SA.h_point = h_point; SA.h_cloud = h_cloud; SA.M = M; SA.V = V;
     SA.znear = znear; SA.zfar = zfar; SA.first_idx = first_idx; SA.num_pts = num_pts; SA.N = N; SA.P = P;
@@ -913,15 +846,11 @@ extern "C" int dss_render_forward(const float *world, const float *normals, cons
     SA.sigma = antialiasing_sigma; SA.screen = pts_screen; SA.ellipse = ellipse; SA.radii = radii; SA.scaler = scaler;
     SA.cutoff = cutoff; SA.valid = valid;
     const int pb = (int)((P + 255) / 256);
-    hipLaunchKernelGGL(setup_bin_count_kernel, dim3(pb), dim3(256), 0, st, SA, g, w.tile_count, w.rects, visible);
-    hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), 0, st, w.tile_count, N * tiles, w.offsets, w.cursor,
-                       w.capacity, w.overflow);
-    hipLaunchKernelGGL(bin_fill_kernel, dim3(pb), dim3(256), 0, st, w.rects, first_idx, num_pts, N, P, g, w.cursor,
-                       w.overflow, w.list);
+    hipLaunchKernelGGL(setup_bin_kernel, dim3(pb), dim3(256), 0, st, SA, g, w.counts, w.lists, w.cap, visible);
     FineArgs A;
     A.points = pts_screen; A.ellipse = ellipse; A.cutoff = cutoff; A.radii = radii;
     A.first_idx = first_idx; A.num_pts = num_pts;
-    A.offsets = w.offsets; A.cursor = w.cursor; A.overflow = w.overflow; A.list = w.list;
+    A.counts = w.counts; A.lists = w.lists; A.cap = w.cap;
     A.idx = idx; A.zbuf = zbuf; A.qv = qvalue; A.occ = occ; A.visible = visible;
     A.g = g; A.N = N; A.K = K; A.thr = merge_thr;
     A.scaler = scaler; A.feat = feat; A.image = image; A.wsum = wsum; A.C = C;
