@@ -47,9 +47,10 @@ def bunny_cloud():
 
 
 class Workload:
-    def __init__(self, device, n_cams, part: RowPartition):
-        pts, nrm, col, h = bunny_cloud()
+    def __init__(self, device, n_cams, part: RowPartition, cloud=None):
+        pts, nrm, col, h = bunny_cloud() if cloud is None else cloud
         self.dev, self.N, self.part = device, n_cams, part
+        S = part.S  # image side (module constant S for the benchmark; tools/bench_large.py passes others)
         self.Pc = pts.shape[0]
         self.P = self.N * self.Pc
         t = lambda a: torch.from_numpy(a).to(device)
@@ -66,9 +67,11 @@ class Workload:
         self.num = torch.full((self.N,), self.Pc, device=device, dtype=torch.int64)
         g = torch.Generator(device="cpu").manual_seed(1)
         self.grad_out = torch.randn((self.N, S, S, 4), generator=g).to(device)  # d loss / d RGBA
+        self.S = S
 
     def step(self):
         p = self.part
+        S = self.S
         # fused forward: [setup + tile count] -> scan -> fill -> [fine + blend]
         f = ops.render_forward(self.world, self.normals, self.h, self.M, self.V, self.znear, self.zfar, self.first,
                                self.num, self.colors, S, K, CUTOFF, THR, SIGMA, False, True, rows=p.rows)
@@ -98,6 +101,7 @@ class Workload:
     # ---- dominant-kernel timing (fine kernel, exactly one launch per call) ------------------
     def fine_kernel_ms(self, iters=50):
         lib = _lib.load()
+        S = self.S
         info = ops.point_setup(self.world, self.normals, self.h, self.M, self.V, self.znear, self.zfar, self.first,
                                self.num, S, CUTOFF, SIGMA, False, True)
         r0, r1 = self.part.rows

@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Developer tool (GPU box): the bench step on the larger BASELINE configs, single GPU.
+  cfg4-like: synthetic 1M-point cloud, 8 ring cameras, 1024x1024
+  cfg5-like: synthetic 4M-point cloud, 1 camera, 2048x2048
+Prints ms/step (eager + graph) and the fine-kernel roofline numbers; meant to be run under rocprofv3."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import bench  # noqa: E402
+import scenes  # noqa: E402
+
+which = sys.argv[1] if len(sys.argv) > 1 else "cfg4"
+P, S, N = {"cfg4": (1_000_000, 1024, 8), "cfg5": (4_000_000, 2048, 1), "cfg3": (99_790, 512, 8)}[which]
+pts, nrm, col = scenes.synthetic_cloud(P, seed=0)
+h = scenes.global_h(pts[:: max(1, P // 200_000)]) * (200_000 / P if P > 200_000 else 1.0)  # density-scaled estimate
+h = float(np.clip(h, 5e-6, 1e-3))
+dev = torch.device("cuda:0")
+wl = bench.Workload(dev, N, bench.RowPartition(S, 1, 0), cloud=(pts, nrm, col, h))
+for _ in range(3):
+    wl.step()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+steps = 10
+for _ in range(steps):
+    wl.step()
+torch.cuda.synchronize()
+ms = (time.perf_counter() - t0) / steps * 1e3
+fine_mean, fine_med = wl.fine_kernel_ms(iters=10)
+K = bench.K
+alg = wl.N * S * S * (12 * K + 4) + wl.P * 36
+out = wl.step()
+img = out[0]
+rec = {"config": which, "points_per_cloud": P, "cameras": N, "image_size": S, "ms_per_step_eager": round(ms, 4),
+       "Msplats_per_s": round(wl.P / ms / 1e3, 2), "fine_kernel_ms": round(fine_mean, 4),
+       "fine_algorithmic_bytes": alg, "fine_GBps": round(alg / fine_mean / 1e6, 1),
+       "fine_frac_of_8TBps": round(alg / fine_mean / 1e6 / 8000, 4), "occupancy_mean": round(float(img[..., 3].mean()), 4), "h": h}
+print(json.dumps(rec))
