@@ -60,25 +60,34 @@ __device__ __forceinline__ void occ_point_gather(int lane, int64_t p, int n, con
         // (rs = 14 px) costs two memory round trips; offsets are unsigned 32-bit (saddr-form loads)
         constexpr int RPT = 8;
         for (int y0 = ylo + T.lyy; y0 <= yhi; y0 += RPT * T.LH) {
+            // rows of this trip that exist for at least one lane (wave-uniform): small windows (rs of a few
+            // pixels at high point density) must not pay for eight row slots
+            const int yb = y0 - T.lyy;                       // uniform
+            const int nrow = min(RPT, (yhi - yb) / T.LH + 1);  // uniform, >= 1
             float g[RPT];
 #pragma unroll
             for (int u = 0; u < RPT; ++u) {
-                const int yc = min(y0 + u * T.LH, yhi);  // clamped: always a legal address
-                g[u] = gimg[(unsigned)((S - 1 - yc) * rowstride + coff)];
+                g[u] = 0.0f;
+                if (u < nrow) {
+                    const int yc = min(y0 + u * T.LH, yhi);  // clamped: always a legal address
+                    g[u] = gimg[(unsigned)((S - 1 - yc) * rowstride + coff)];
+                }
             }
 #pragma unroll
             for (int u = 0; u < RPT; ++u) {
-                const int yi = y0 + u * T.LH;
-                const float dy = ndc(yi) - py;
-                const float d2 = dx2 + dy * dy;
-                const bool outside = out_x || (fabsf(dy) > ry);
-                const bool use = (yi <= yhi) && (g[u] != 0.0f) && !(d2 > cur_r2) && !(g[u] > 0.0f && outside) &&
-                                 (d2 != 0.0f);
-                // dx / max(d2,1e-10) * g with a 1-ulp reciprocal and fused accumulation (tolerance-checked,
-                // not bit-pinned: the reference accumulates with unordered fp32 atomics anyway)
-                const float sgl = use ? __builtin_amdgcn_rcpf(fmaxf(d2, 1e-10f)) * g[u] : 0.0f;
-                gx = fmaf(dx, sgl, gx);
-                gy = fmaf(dy, sgl, gy);
+                if (u < nrow) {
+                    const int yi = y0 + u * T.LH;
+                    const float dy = ndc(yi) - py;
+                    const float d2 = dx2 + dy * dy;
+                    const bool outside = out_x || (fabsf(dy) > ry);
+                    const bool use = (yi <= yhi) && (g[u] != 0.0f) && !(d2 > cur_r2) && !(g[u] > 0.0f && outside) &&
+                                     (d2 != 0.0f);
+                    // dx / max(d2,1e-10) * g with a 1-ulp reciprocal and fused accumulation (tolerance-checked,
+                    // not bit-pinned: the reference accumulates with unordered fp32 atomics anyway)
+                    const float sgl = use ? __builtin_amdgcn_rcpf(fmaxf(d2, 1e-10f)) * g[u] : 0.0f;
+                    gx = fmaf(dx, sgl, gx);
+                    gy = fmaf(dy, sgl, gy);
+                }
             }
         }
     }
