@@ -147,118 +147,3 @@ __device__ __forceinline__ void blend_point_gather(int lane, int64_t p, int n, c
 }
 
 }  // namespace dss
-
-// =============================================================================================
-// Grouped variants: L lanes per point (L = 8, 16, 32 or 64), 64/L points per wavefront.  The per-point
-// overhead (record loads, window set-up, reduction, stores) is what dominates when the gather window is
-// small (high point density -> small radii), and it is paid once per wavefront: with L=16 four points
-// share it.  A 16-lane group is exactly one DPP row, so its reduction is four VALU instructions.
-// Lane l of a group owns window column(s) xlo + l (+ L, ...) and walks the rows sequentially.
-// =============================================================================================
-namespace dss {
-
-template <int L>
-__device__ __forceinline__ float group_sum(float v)
-{
-    v += dpp_f32<0xB1>(v);                 // quad_perm [1,0,3,2]
-    v += dpp_f32<0x4E>(v);                 // quad_perm [2,3,0,1]
-    v += dpp_f32<0x141>(v);                // row_half_mirror  -> sum of 8
-    if (L >= 16) v += dpp_f32<0x140>(v);   // row_mirror       -> sum of 16
-    if (L >= 32) v += __shfl_xor(v, 16, 64);
-    if (L >= 64) v += __shfl_xor(v, 32, 64);
-    return v;
-}
-
-template <int L>
-__device__ __forceinline__ void occ_group_gather(int l, bool active, int64_t p, int n, const float *__restrict__ points,
-                                                 const float *__restrict__ radii, const float *__restrict__ rs,
-                                                 const float *__restrict__ grad_occ, int S, int gstride, float &gx,
-                                                 float &gy)
-{
-    if (!active) return;
-    const float px = points[3 * p], py = points[3 * p + 1], pz = points[3 * p + 2];
-    const float rx = radii[2 * p], ry = radii[2 * p + 1];
-    const float cur_r = rs[n];
-    const float cur_r2 = cur_r * cur_r;
-    if (pz < 0 || fabsf(py) > 1.0f || fabsf(px) > 1.0f) return;  // rasterize_points_backward.cu:141-143
-    int xlo, xhi, ylo, yhi;
-    if (!ndc_index_range(px, cur_r, S, xlo, xhi) || !ndc_index_range(py, cur_r, S, ylo, yhi)) return;
-    const float *__restrict__ gimg = grad_occ + (size_t)n * S * S * gstride;
-    const int rowstride = S * gstride;
-    const NdcMap ndc(S);
-    constexpr int RPT = 8;
-    for (int xi = xlo + l; xi <= xhi; xi += L) {
-        const float dx = ndc(xi) - px;
-        const float dx2 = dx * dx;
-        const bool out_x = fabsf(dx) > rx;
-        const int coff = (S - 1 - xi) * gstride;
-        for (int y0 = ylo; y0 <= yhi; y0 += RPT) {
-            float g[RPT];
-#pragma unroll
-            for (int u = 0; u < RPT; ++u) {
-                const int yc = min(y0 + u, yhi);  // clamped: always a legal address
-                g[u] = gimg[(unsigned)((S - 1 - yc) * rowstride + coff)];
-            }
-#pragma unroll
-            for (int u = 0; u < RPT; ++u) {
-                const int yi = y0 + u;
-                const float dy = ndc(yi) - py;
-                const float d2 = dx2 + dy * dy;
-                const bool outside = out_x || (fabsf(dy) > ry);
-                const bool use = (yi <= yhi) && (g[u] != 0.0f) && !(d2 > cur_r2) && !(g[u] > 0.0f && outside) &&
-                                 (d2 != 0.0f);
-                const float sgl = use ? __builtin_amdgcn_rcpf(fmaxf(d2, 1e-10f)) * g[u] : 0.0f;
-                gx = fmaf(dx, sgl, gx);
-                gy = fmaf(dy, sgl, gy);
-            }
-        }
-    }
-}
-
-template <int C, int L>
-__device__ __forceinline__ void blend_group_gather(int l, bool active, int64_t p, int n,
-                                                   const float *__restrict__ grad_out, const int32_t *__restrict__ idx,
-                                                   const float *__restrict__ qv, const float *__restrict__ wsum,
-                                                   const float *__restrict__ scaler, const float *__restrict__ points,
-                                                   const float *__restrict__ radii, int S, int K, int Cn,
-                                                   float (&acc)[(C > 0) ? C : BLEND_MAX_C])
-{
-    constexpr int CM = (C > 0) ? C : BLEND_MAX_C;
-    if (!active) return;
-    const float px = points[3 * p], py = points[3 * p + 1];
-    const float rx = radii[2 * p], ry = radii[2 * p + 1];
-    const float sc = scaler[p];
-    int xlo, xhi, ylo, yhi;
-    if (!ndc_index_range(px, rx, S, xlo, xhi) || !ndc_index_range(py, ry, S, ylo, yhi)) return;
-    for (int xi = xlo + l; xi <= xhi; xi += L) {
-        for (int yi = ylo; yi <= yhi; ++yi) {
-            const size_t pix = ((size_t)n * S + (S - 1 - yi)) * S + (S - 1 - xi);
-            const int32_t *pi = idx + pix * K;
-            const float *go = grad_out + pix * (Cn + 1);
-            float gch[CM];
-#pragma unroll
-            for (int ch = 0; ch < CM; ++ch) gch[ch] = (ch < Cn) ? go[ch] : 0.0f;
-            float cum = wsum ? wsum[pix] : 0.0f;
-            int kk = -1;
-            for (int k = 0; k < K; ++k) {
-                const int32_t v = pi[k];
-                if (v == (int32_t)p) kk = k;
-            }
-            if (kk < 0) continue;
-            if (!wsum) {
-                for (int k = 0; k < K; ++k) {
-                    const int32_t v = pi[k];
-                    if (v >= 0) cum += expf(-0.5f * qv[pix * K + k]) * scaler[v];
-                }
-                if (cum < 1e-4f) cum = 1e-4f;
-            }
-            const float wgt = __builtin_amdgcn_exp2f(-0.72134752f * qv[pix * K + kk]) * sc;
-            const float wn = wgt * __builtin_amdgcn_rcpf(cum);
-#pragma unroll
-            for (int ch = 0; ch < CM; ++ch)
-                if (ch < Cn) acc[ch] = fmaf(gch[ch], wn, acc[ch]);
-        }
-    }
-}
-
-}  // namespace dss

@@ -380,85 +380,6 @@ __global__ __launch_bounds__(256) void render_backward_kernel(
 #endif
 }
 
-// Grouped persistent variant: L lanes per visible point, 64/L points per wavefront (see point_bodies.h).
-// L is one value for the whole launch, derived on the device from the largest search radius.
-template <int C, int L>
-__device__ __forceinline__ void render_backward_grouped_body(
-    const float *__restrict__ grad_out, const int32_t *__restrict__ idx, const float *__restrict__ qv,
-    const float *__restrict__ wsum, const float *__restrict__ scaler, const float *__restrict__ points,
-    const float *__restrict__ radii, const float *__restrict__ rs, const int64_t *__restrict__ first_idx,
-    const int64_t *__restrict__ num_pts, uint32_t count, const int32_t *__restrict__ vis_list, int N, int S, int K,
-    int Crt, float clip, float *__restrict__ grad_feat, float *__restrict__ grad_pts)
-{
-    constexpr int CM = (C > 0) ? C : BLEND_MAX_C;
-    constexpr int G = 64 / L;
-    const int Cn = (C > 0) ? C : Crt;
-    const int lane = threadIdx.x & 63;
-    const int grp = lane / L, l = lane % L;
-    const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const uint32_t n_waves = gridDim.x * 4;
-    for (uint32_t t0 = wave * G; t0 < count; t0 += n_waves * G) {
-        const uint32_t t = t0 + grp;
-        bool active = t < count;
-        const int64_t p = active ? (int64_t)vis_list[t] : 0;
-        int n = 0;
-        if (active) {
-            n = find_cloud(p, first_idx, num_pts, N);
-            active = n >= 0;
-        }
-        float gx = 0.0f, gy = 0.0f;
-        // occupancy gradient = alpha channel of the image gradient, read in place
-        occ_group_gather<L>(l, active, p, n, points, radii, rs, grad_out + Cn, S, Cn + 1, gx, gy);
-        float acc[CM];
-#pragma unroll
-        for (int ch = 0; ch < CM; ++ch) acc[ch] = 0.0f;
-        if (grad_feat)
-            blend_group_gather<C, L>(l, active, p, n, grad_out, idx, qv, wsum, scaler, points, radii, S, K, Cn, acc);
-        gx = group_sum<L>(gx);
-        gy = group_sum<L>(gy);
-#pragma unroll
-        for (int ch = 0; ch < CM; ++ch)
-            if (ch < Cn) acc[ch] = group_sum<L>(acc[ch]);
-        if (active && l == 0) {
-            if (clip > 0.0f) {  // rasterizer.py:667-673 (z gradient is 0 on this path)
-                const float nrm = sqrtf(gx * gx + gy * gy);
-                gx = gx / fmaxf(nrm, 1e-12f) * fminf(nrm, clip);
-                gy = gy / fmaxf(nrm, 1e-12f) * fminf(nrm, clip);
-            }
-            grad_pts[3 * p] = gx;
-            grad_pts[3 * p + 1] = gy;
-            grad_pts[3 * p + 2] = 0.0f;
-            if (grad_feat) {
-#pragma unroll
-                for (int ch = 0; ch < CM; ++ch)
-                    if (ch < Cn) grad_feat[(size_t)p * Cn + ch] = acc[ch];
-            }
-        }
-    }
-}
-
-template <int C>
-__global__ __launch_bounds__(256) void render_backward_grouped_kernel(
-    const float *__restrict__ grad_out, const int32_t *__restrict__ idx, const float *__restrict__ qv,
-    const float *__restrict__ wsum, const float *__restrict__ scaler, const float *__restrict__ points,
-    const float *__restrict__ radii, const float *__restrict__ rs, const int64_t *__restrict__ first_idx,
-    const int64_t *__restrict__ num_pts, const uint32_t *__restrict__ vis_count,
-    const int32_t *__restrict__ vis_list, int N, int S, int K, int Crt, float clip,
-    float *__restrict__ grad_feat, float *__restrict__ grad_pts)
-{
-    // lanes per point from the widest occupancy window of the launch: 2*rs (in pixels) + 3
-    float rmax = 0.0f;
-    for (int n = 0; n < N; ++n) rmax = fmaxf(rmax, rs[n]);
-    const float wpx = rmax * (float)S + 3.0f;  // 2 * (rs * S/2) + 3
-    const uint32_t count = *vis_count;
-#define RB_ARGS grad_out, idx, qv, wsum, scaler, points, radii, rs, first_idx, num_pts, count, vis_list, N, S, K, Crt, clip, grad_feat, grad_pts
-    if (wpx <= 8.0f) render_backward_grouped_body<C, 8>(RB_ARGS);
-    else if (wpx <= 16.0f) render_backward_grouped_body<C, 16>(RB_ARGS);
-    else if (wpx <= 32.0f) render_backward_grouped_body<C, 32>(RB_ARGS);
-    else render_backward_grouped_body<C, 64>(RB_ARGS);
-#undef RB_ARGS
-}
-
 __global__ __launch_bounds__(256) void zbuf_backward_kernel(const int32_t *__restrict__ idx,
                                                             const float *__restrict__ grad_zbuf,
                                                             size_t npix, int K, float *__restrict__ grad_pts)
@@ -672,20 +593,20 @@ extern "C" int dss_render_backward(const float *grad_out, const int32_t *idx, co
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
             cus = prop.multiProcessorCount;
         if (C == 3)
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_backward_grouped_kernel<3>, 256, 0);
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_backward_kernel<3>, 256, 0);
         else
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_backward_grouped_kernel<0>, 256, 0);
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_backward_kernel<0>, 256, 0);
         if (per_cu < 1) per_cu = 1;
         cap = cus * per_cu;
         (void)hipGetLastError();
     }
     const unsigned pgrid = (unsigned)((P + 3) / 4 < cap ? (P + 3) / 4 : cap);
     if (C == 3)
-        hipLaunchKernelGGL(render_backward_grouped_kernel<3>, dim3(pgrid), dim3(256), 0, st, grad_out, idx, qvalue, wsum, scaler,
+        hipLaunchKernelGGL(render_backward_kernel<3>, dim3(pgrid), dim3(256), 0, st, grad_out, idx, qvalue, wsum, scaler,
                            points, radii, rs, first_idx, num_pts, vis_count, vis_list, N, S, K, C, clip, grad_feat,
                            grad_pts);
     else
-        hipLaunchKernelGGL(render_backward_grouped_kernel<0>, dim3(pgrid), dim3(256), 0, st, grad_out, idx, qvalue, wsum, scaler,
+        hipLaunchKernelGGL(render_backward_kernel<0>, dim3(pgrid), dim3(256), 0, st, grad_out, idx, qvalue, wsum, scaler,
                            points, radii, rs, first_idx, num_pts, vis_count, vis_list, N, S, K, C, clip, grad_feat,
                            grad_pts);
     return check_launch("dss_render_backward");

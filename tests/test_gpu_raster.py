@@ -171,26 +171,21 @@ def test_cfg2_bunny_512_forward_backward_vs_oracle():
         assert _rel_l2(g.cpu().numpy(), o_g) <= 1e-3, (cl, gz is None)
         assert np.isfinite(g.cpu().numpy()).all()
 
-    # fused single-GPU backward (persistent wavefronts, L lanes per visible point): same per-pair terms,
-    # different (still fixed) summation order than the one-wavefront-per-point kernels
+    # fused single-GPU backward (persistent wavefronts over the compacted visible list): identical bits
     g_ref, rs_ref = ops.splat_backward(d["points"], d["radii"], vis, idx, gocc, None, d["first"], d["num"], radii_s,
                                        clip, return_rs=True)
     gf_ref, _ = ops.blend_backward(torch.from_numpy(grad_out).to(DEV), idx, qv, scaler, P, geometry=geom, wsum=wsum)
-    o_g, _, _ = oracle.splat_backward(sc["points"], sc["radii"], o_idx, o_gocc, None, sc["first_idx"], sc["num_pts"],
-                                      radii_s, clip)
     for ws_ in (wsum, None):
         gf_f, g_f, rs_f = ops.render_backward(torch.from_numpy(grad_out).to(DEV), idx, qv, ws_, scaler, d["points"],
                                               d["radii"], vis, d["first"], d["num"], radii_s, clip, return_rs=True)
-        assert torch.equal(rs_f, rs_ref)
-        assert _rel_l2(g_f.cpu().numpy(), g_ref.cpu().numpy()) <= 1e-5 and _rel_l2(g_f.cpu().numpy(), o_g) <= 1e-3
-        assert _rel_l2(gf_f.cpu().numpy(), gf_ref.cpu().numpy()) <= 1e-5 and _rel_l2(gf_f.cpu().numpy(), o_gf) <= 1e-3
-        assert (g_f[~vis] == 0).all() and (gf_f[~vis] == 0).all()
-        gf_2, g_2 = ops.render_backward(torch.from_numpy(grad_out).to(DEV), idx, qv, ws_, scaler, d["points"],
-                                        d["radii"], vis, d["first"], d["num"], radii_s, clip)
-        assert torch.equal(g_2, g_f) and torch.equal(gf_2, gf_f)  # deterministic
+        assert torch.equal(rs_f, rs_ref) and torch.equal(g_f, g_ref)
+        assert _rel_l2(gf_f.cpu().numpy(), o_gf) <= 1e-3
+    assert torch.equal(gf_f if ws_ is not None else ops.render_backward(
+        torch.from_numpy(grad_out).to(DEV), idx, qv, wsum, scaler, d["points"], d["radii"], vis, d["first"], d["num"],
+        radii_s, clip)[0], gf_ref)
     _, g_only = ops.render_backward(torch.from_numpy(grad_out).to(DEV), idx, qv, wsum, scaler, d["points"], d["radii"],
                                     vis, d["first"], d["num"], radii_s, clip, with_features=False)
-    assert torch.equal(g_only, g_f)
+    assert torch.equal(g_only, g_ref)
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -346,27 +341,7 @@ def test_render_backward_multi_cloud_matches_unfused():
     gf_ref, gocc = ops.blend_backward(go, idx, qv, scaler, P, geometry=geom, wsum=wsum)
     g_ref = ops.splat_backward(d["points"], d["radii"], vis, idx, gocc, None, d["first"], d["num"], 4.0, 0.05)
     gf, g = ops.render_backward(go, idx, qv, wsum, scaler, d["points"], d["radii"], vis, d["first"], d["num"], 4.0, 0.05)
-    assert _rel_l2(gf.cpu().numpy(), gf_ref.cpu().numpy()) <= 1e-5 and _rel_l2(g.cpu().numpy(), g_ref.cpu().numpy()) <= 1e-5
+    assert torch.equal(gf, gf_ref) and torch.equal(g, g_ref)
     o_g, _, _ = oracle.splat_backward(sc["points"], sc["radii"], idx.cpu().numpy(), go[..., 3].cpu().numpy(), None,
                                       sc["first_idx"], sc["num_pts"], 4.0, 0.05)
     assert _rel_l2(g.cpu().numpy(), o_g) <= 1e-4
-
-
-@pytest.mark.parametrize("radii_s", [0.4, 1.5, 4.0, 12.0])
-def test_render_backward_all_group_widths(radii_s):
-    """The fused backward picks 8/16/32/64 lanes per point from the search radius; exercise each."""
-    sc = scenes.random_splats(4000, 128, 2, seed=21, rmin=1.0, rmax=2.5)
-    d = _dev(sc)
-    idx, zbuf, qv, occ, vis = _fwd(d, 128, 5, 0.3, return_visible=True)
-    scaler = torch.from_numpy(sc["scaler"]).to(DEV)
-    feat = torch.from_numpy(sc["colors"]).to(DEV)
-    img, wsum = ops.blend_forward(idx, qv, occ, scaler, feat, return_wsum=True)
-    go = torch.randn_like(img)
-    P = sc["points"].shape[0]
-    gf, g, rs = ops.render_backward(go, idx, qv, wsum, scaler, d["points"], d["radii"], vis, d["first"], d["num"],
-                                    radii_s, -1.0, return_rs=True)
-    o_g, o_vis, o_rs = oracle.splat_backward(sc["points"], sc["radii"], idx.cpu().numpy(), go[..., 3].cpu().numpy(),
-                                             None, sc["first_idx"], sc["num_pts"], radii_s, -1.0)
-    o_gf, _ = oracle.blend_backward(go.cpu().numpy(), idx.cpu().numpy(), qv.cpu().numpy(), sc["scaler"], P)
-    assert np.array_equal(rs.cpu().numpy(), o_rs)
-    assert _rel_l2(g.cpu().numpy(), o_g) <= 1e-4 and _rel_l2(gf.cpu().numpy(), o_gf) <= 1e-4
