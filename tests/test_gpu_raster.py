@@ -345,3 +345,23 @@ def test_render_backward_multi_cloud_matches_unfused():
     o_g, _, _ = oracle.splat_backward(sc["points"], sc["radii"], idx.cpu().numpy(), go[..., 3].cpu().numpy(), None,
                                       sc["first_idx"], sc["num_pts"], 4.0, 0.05)
     assert _rel_l2(g.cpu().numpy(), o_g) <= 1e-4
+
+
+@pytest.mark.parametrize("radii_s", [0.4, 1.5, 4.0, 12.0])
+def test_render_backward_search_radius_sweep(radii_s):
+    """radii_backward_scaler decays during training (scheduler.py:36-48): tiny to very large windows."""
+    sc = scenes.random_splats(4000, 128, 2, seed=21, rmin=1.0, rmax=2.5)
+    d = _dev(sc)
+    idx, zbuf, qv, occ, vis = _fwd(d, 128, 5, 0.3, return_visible=True)
+    scaler = torch.from_numpy(sc["scaler"]).to(DEV)
+    feat = torch.from_numpy(sc["colors"]).to(DEV)
+    img, wsum = ops.blend_forward(idx, qv, occ, scaler, feat, return_wsum=True)
+    go = torch.randn_like(img)
+    P = sc["points"].shape[0]
+    gf, g, rs = ops.render_backward(go, idx, qv, wsum, scaler, d["points"], d["radii"], vis, d["first"], d["num"],
+                                    radii_s, -1.0, return_rs=True)
+    o_g, o_vis, o_rs = oracle.splat_backward(sc["points"], sc["radii"], idx.cpu().numpy(), go[..., 3].cpu().numpy(),
+                                             None, sc["first_idx"], sc["num_pts"], radii_s, -1.0)
+    o_gf, _ = oracle.blend_backward(go.cpu().numpy(), idx.cpu().numpy(), qv.cpu().numpy(), sc["scaler"], P)
+    assert np.array_equal(rs.cpu().numpy(), o_rs)
+    assert _rel_l2(g.cpu().numpy(), o_g) <= 1e-4 and _rel_l2(gf.cpu().numpy(), o_gf) <= 1e-4
