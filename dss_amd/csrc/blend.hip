@@ -70,8 +70,9 @@ __global__ __launch_bounds__(256) void blend_backward_kernel(
 #pragma unroll
     for (int ch = 0; ch < CM; ++ch) acc[ch] = 0.0f;
     if (visible[p] != 0) {
-        const PointRec R = load_point_rec(p, points, radii, scaler, nullptr, first_idx, num_pts, N);
-        if (R.n >= 0) blend_point_gather<C>(lane, p, R, grad_out, idx, qv, wsum, scaler, S, K, Cn, row0, rows, acc);
+        const int n = find_cloud(p, first_idx, num_pts, N);
+        if (n >= 0)
+            blend_point_gather<C>(lane, p, n, grad_out, idx, qv, wsum, scaler, points, radii, S, K, Cn, row0, rows, acc);
     }
 #pragma unroll
     for (int ch = 0; ch < CM; ++ch) {

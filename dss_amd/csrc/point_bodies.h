@@ -22,37 +22,19 @@ struct LaneTiling {
     }
 };
 
-// Everything the two gathers need about one point, loaded up front (so the persistent kernel can fetch
-// the next point's record while it works on the current one).
-struct PointRec {
-    float px, py, pz, rx, ry, sc, rs;
-    int n;
-};
-__device__ __forceinline__ PointRec load_point_rec(int64_t p, const float *__restrict__ points,
-                                                   const float *__restrict__ radii, const float *__restrict__ scaler,
-                                                   const float *__restrict__ rs, const int64_t *__restrict__ first_idx,
-                                                   const int64_t *__restrict__ num_pts, int N)
-{
-    PointRec r;
-    r.px = points[3 * p]; r.py = points[3 * p + 1]; r.pz = points[3 * p + 2];
-    r.rx = radii[2 * p]; r.ry = radii[2 * p + 1];
-    r.sc = scaler ? scaler[p] : 0.0f;
-    r.n = find_cloud(p, first_idx, num_pts, N);
-    r.rs = (rs && r.n >= 0) ? rs[r.n] : 0.0f;
-    return r;
-}
-
 // Occupancy surrogate gradient of point p (cloud n) over the band rows [row0, row0+rows):
 //   for every pixel with g = grad_occ != 0 and d2 = dx^2+dy^2 <= rs^2:
 //       skip if g>0 and (|dx|>rx or |dy|>ry);  (gx,gy) += (dx,dy)/max(d2,1e-10)*g
 // (rasterize_points_backward.cu:141-178; a pair with d2 == 0 contributes 0, see dss_hip.h).
 // grad_occ is read with an element stride `gstride` per pixel (alpha channel of an image gradient).
-__device__ __forceinline__ void occ_point_gather(int lane, const PointRec &R, const float *__restrict__ grad_occ, int S,
-                                                 int row0, int rows, int gstride, float &gx, float &gy)
+__device__ __forceinline__ void occ_point_gather(int lane, int64_t p, int n, const float *__restrict__ points,
+                                                 const float *__restrict__ radii, const float *__restrict__ rs,
+                                                 const float *__restrict__ grad_occ, int S, int row0, int rows,
+                                                 int gstride, float &gx, float &gy)
 {
-    const float px = R.px, py = R.py, pz = R.pz, rx = R.rx, ry = R.ry;
-    const int n = R.n;
-    const float cur_r = R.rs;
+    const float px = points[3 * p], py = points[3 * p + 1], pz = points[3 * p + 2];
+    const float rx = radii[2 * p], ry = radii[2 * p + 1];
+    const float cur_r = rs[n];
     const float cur_r2 = cur_r * cur_r;
     // rasterize_points_backward.cu:141-143
     if (pz < 0 || fabsf(py) > 1.0f || fabsf(px) > 1.0f) return;
@@ -74,9 +56,9 @@ __device__ __forceinline__ void occ_point_gather(int lane, const PointRec &R, co
         const float dx2 = dx * dx;
         const bool out_x = fabsf(dx) > rx;
         const int coff = (S - 1 - xi) * gstride - row0 * rowstride;
-        // up to RPT rows per trip: the loads are independent and issue back to back, so a 29-row window
-        // (rs = 14 px) costs ONE memory round trip -- the gather is latency-, not issue-bound
-        constexpr int RPT = 16;
+        // RPT rows per trip: the loads are independent and issue back to back, so a 29-row window
+        // (rs = 14 px) costs two memory round trips; offsets are unsigned 32-bit (saddr-form loads)
+        constexpr int RPT = 8;
         for (int y0 = ylo + T.lyy; y0 <= yhi; y0 += RPT * T.LH) {
             // rows of this trip that exist for at least one lane (wave-uniform): small windows (rs of a few
             // pixels at high point density) must not pay for eight row slots
@@ -114,15 +96,17 @@ __device__ __forceinline__ void occ_point_gather(int lane, const PointRec &R, co
 // Blend backward of point p: sum over the pixels of the point's own bounding box (a fragment with
 // idx == p can only exist where the hit test passed) of grad_out * w / wsum.
 template <int C>
-__device__ __forceinline__ void blend_point_gather(int lane, int64_t p, const PointRec &R,
-                                                   const float *__restrict__ grad_out, const int32_t *__restrict__ idx,
-                                                   const float *__restrict__ qv, const float *__restrict__ wsum,
-                                                   const float *__restrict__ scaler, int S, int K, int Cn, int row0,
-                                                   int rows, float (&acc)[(C > 0) ? C : BLEND_MAX_C])
+__device__ __forceinline__ void blend_point_gather(int lane, int64_t p, int n, const float *__restrict__ grad_out,
+                                                   const int32_t *__restrict__ idx, const float *__restrict__ qv,
+                                                   const float *__restrict__ wsum, const float *__restrict__ scaler,
+                                                   const float *__restrict__ points, const float *__restrict__ radii,
+                                                   int S, int K, int Cn, int row0, int rows,
+                                                   float (&acc)[(C > 0) ? C : BLEND_MAX_C])
 {
     constexpr int CM = (C > 0) ? C : BLEND_MAX_C;
-    const float px = R.px, py = R.py, rx = R.rx, ry = R.ry, sc = R.sc;
-    const int n = R.n;
+    const float px = points[3 * p], py = points[3 * p + 1];
+    const float rx = radii[2 * p], ry = radii[2 * p + 1];
+    const float sc = scaler[p];
     int xlo, xhi, ylo, yhi;
     if (!ndc_index_range(px, rx, S, xlo, xhi) || !ndc_index_range(py, ry, S, ylo, yhi)) return;
     ylo = max(ylo, S - row0 - rows);

@@ -192,9 +192,9 @@ __global__ __launch_bounds__(256) void occ_backward_kernel(
     OT_VAL(4, __builtin_amdgcn_s_memrealtime());
     float gx = 0.0f, gy = 0.0f;
     if (visible[p] != 0) {
-        const PointRec R = load_point_rec(p, points, radii, nullptr, rs, first_idx, num_pts, N);
+        const int n = find_cloud(p, first_idx, num_pts, N);
         OT_MARK(1);
-        if (R.n >= 0) occ_point_gather(lane, R, grad_occ, S, row0, rows, gstride, gx, gy);
+        if (n >= 0) occ_point_gather(lane, p, n, points, radii, rs, grad_occ, S, row0, rows, gstride, gx, gy);
     }
     OT_MARK(2);
     gx = wave_sum(gx);
@@ -325,28 +325,19 @@ __global__ __launch_bounds__(256) void render_backward_kernel(
 #ifdef DSS_FINE_TIMING
     long long tm_rt0 = __builtin_amdgcn_s_memrealtime(), tm_occ = 0, tm_blend = 0, tm_pro = 0, tm_tasks = 0;
 #endif
-    // two-deep software pipeline over the task list: while point i is processed, the record of point i+1
-    // and the list entry of point i+2 are already in flight
-    uint32_t t = wave;
-    int64_t p_cur = (t < count) ? (int64_t)vis_list[t] : 0;
-    int64_t p_nxt = (t + n_waves < count) ? (int64_t)vis_list[t + n_waves] : 0;
-    PointRec R_nxt = load_point_rec(p_cur, points, radii, scaler, rs, first_idx, num_pts, N);
-    for (; t < count; t += n_waves) {
+    for (uint32_t t = wave; t < count; t += n_waves) {
 #ifdef DSS_FINE_TIMING
         const long long tm0 = __builtin_amdgcn_s_memtime();
 #endif
-        const int64_t p = p_cur;
-        const PointRec R = R_nxt;
-        p_cur = p_nxt;
-        R_nxt = load_point_rec(p_cur, points, radii, scaler, rs, first_idx, num_pts, N);  // (dummy reload of a valid id at the tail)
-        p_nxt = (t + 2 * n_waves < count) ? (int64_t)vis_list[t + 2 * n_waves] : p_cur;
-        if (R.n < 0) continue;
+        const int64_t p = vis_list[t];
+        const int n = find_cloud(p, first_idx, num_pts, N);
+        if (n < 0) continue;
         float gx = 0.0f, gy = 0.0f;
 #ifdef DSS_FINE_TIMING
         const long long tm1 = __builtin_amdgcn_s_memtime();
 #endif
         // occupancy gradient = alpha channel of the image gradient, read in place
-        occ_point_gather(lane, R, grad_out + Cn, S, 0, S, Cn + 1, gx, gy);
+        occ_point_gather(lane, p, n, points, radii, rs, grad_out + Cn, S, 0, S, Cn + 1, gx, gy);
 #ifdef DSS_FINE_TIMING
         gx = wave_sum(gx) * (1.0f / 64.0f) * 64.0f / 64.0f;  // force completion of the gather before the stamp
         const long long tm2 = __builtin_amdgcn_s_memtime();
@@ -356,7 +347,7 @@ __global__ __launch_bounds__(256) void render_backward_kernel(
 #pragma unroll
         for (int ch = 0; ch < CM; ++ch) acc[ch] = 0.0f;
         if (grad_feat)
-            blend_point_gather<C>(lane, p, R, grad_out, idx, qv, wsum, scaler, S, K, Cn, 0, S, acc);
+            blend_point_gather<C>(lane, p, n, grad_out, idx, qv, wsum, scaler, points, radii, S, K, Cn, 0, S, acc);
         gx = wave_sum(gx);
         gy = wave_sum(gy);
 #pragma unroll
