@@ -119,8 +119,13 @@ class Workload:
              _lib.ptr(info["radii"]), _lib.ptr(self.first), _lib.ptr(self.num), self.N, self.P)
         _lib.check(lib.dss_splat_bin(a[0], a[3], a[4], a[5], self.N, self.P, S, r0, r1, _lib.ptr(ws), nbytes, st),
                    "dss_splat_bin")
-        run = lambda: lib.dss_splat_fine(*a, THR, S, K, r0, r1, _lib.ptr(idx), _lib.ptr(zbuf), _lib.ptr(qv),
-                                         _lib.ptr(occ), _lib.ptr(vis), _lib.ptr(ws), nbytes, st)
+        # exactly the kernel the step launches: fine pass with the blend fused into its epilogue
+        image = torch.empty((self.N, rows, S, 4), device=dev)
+        wsum = torch.empty((self.N, rows, S), device=dev)
+        run = lambda: lib.dss_splat_fine_blend(*a, THR, S, K, r0, r1, _lib.ptr(idx), _lib.ptr(zbuf), _lib.ptr(qv),
+                                               _lib.ptr(occ), _lib.ptr(vis), _lib.ptr(info["scaler"]),
+                                               _lib.ptr(self.colors), 3, _lib.ptr(image), _lib.ptr(wsum), _lib.ptr(ws),
+                                               nbytes, st)
         for _ in range(5):
             _lib.check(run(), "dss_splat_fine")
         # HIP events on the stream the kernel is launched on (torch's current stream)
@@ -269,10 +274,10 @@ def main():
         # HBM bytes per launch from rocprofv3 PMC passes of this same command (tools/collect_traffic.py)
         traffic = json.load(open(tfile)).get("traffic_bytes_per_launch")
     r0, r1 = part.rows
-    # algorithmic bytes of ONE fine-kernel launch (DESIGN.md "fine kernel"): every pixel of the band
-    # writes idx+zbuf+qvalue (12K B) + occ (4 B); every splat's 36-B screen record (pos 12, ellipse 12,
-    # radii 8, cutoff 4) is read once.
-    alg_bytes = wl.N * (r1 - r0) * S * (12 * K + 4) + wl.P * 36
+    # algorithmic bytes of ONE fine-kernel launch: every pixel of the band writes
+    # idx+zbuf+qvalue (12K B) + occ (4 B) + RGBA (16 B) + wsum (4 B); every splat's screen record (pos 12,
+    # ellipse 12, radii 8, cutoff 4) + scaler (4) + colour (12) = 52 B is read once.
+    alg_bytes = wl.N * (r1 - r0) * S * (12 * K + 4 + 16 + 4) + wl.P * 52
     achieved = alg_bytes / (fine_mean * 1e-3) / 1e9
     if rank == 0:
         rec = {
@@ -284,7 +289,7 @@ def main():
                                    "grad_out=randn(seed 1)" % (wl.Pc, wl.N),
                        "points_per_cloud": wl.Pc, "cameras": wl.N, "image_size": S, "points_per_pixel": K,
                        "parallelism": "rows%d" % world, "launch": mode},
-            "roofline": {"bound": "hbm", "kernel": "fine_kernel<5>", "achieved": round(achieved, 2),
+            "roofline": {"bound": "hbm", "kernel": "fine_kernel<5> (fine pass + fused blend)", "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                          "traffic": traffic, "algorithmic_bytes": alg_bytes, "kernel_ms_mean": round(fine_mean, 5),
                          "kernel_ms_median": round(fine_med, 5)},

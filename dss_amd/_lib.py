@@ -31,6 +31,8 @@ SIGNATURES = {
     "dss_splat_bin": (_c_int, [_c_vp] * 4 + [_c_int, _c_i64, _c_int, _c_int, _c_int, _c_vp, _c_sz, _c_vp]),
     "dss_splat_fine": (_c_int, [_c_vp] * 6 + [_c_int, _c_i64, _c_f32, _c_int, _c_int, _c_int, _c_int]
                        + [_c_vp] * 5 + [_c_vp, _c_sz, _c_vp]),
+    "dss_splat_fine_blend": (_c_int, [_c_vp] * 6 + [_c_int, _c_i64, _c_f32, _c_int, _c_int, _c_int, _c_int]
+                             + [_c_vp] * 5 + [_c_vp, _c_vp, _c_int, _c_vp, _c_vp] + [_c_vp, _c_sz, _c_vp]),
     "dss_backward_radius_workspace": (_c_sz, [_c_int, _c_i64]),
     "dss_backward_radius": (_c_int, [_c_vp] * 4 + [_c_int, _c_i64, _c_f32, _c_vp, _c_vp, _c_sz, _c_vp]),
     "dss_occ_backward": (_c_int, [_c_vp] * 7 + [_c_int, _c_i64, _c_int, _c_int, _c_int, _c_int, _c_f32, _c_vp, _c_vp]),

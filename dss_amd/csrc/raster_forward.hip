@@ -726,10 +726,11 @@ extern "C" int dss_splat_bin(const float *points, const float *radii, const int6
                           stream);
 }
 
-extern "C" int dss_splat_fine(const float *points, const float *ellipse, const float *cutoff, const float *radii,
-                              const int64_t *first_idx, const int64_t *num_pts, int N, int64_t P, float merge_thr,
-                              int S, int K, int row0, int row1, int32_t *idx, float *zbuf, float *qvalue, float *occ,
-                              uint8_t *visible, const void *workspace, size_t workspace_bytes, void *stream)
+static int splat_fine_impl(const float *points, const float *ellipse, const float *cutoff, const float *radii,
+                           const int64_t *first_idx, const int64_t *num_pts, int N, int64_t P, float merge_thr,
+                           int S, int K, int row0, int row1, int32_t *idx, float *zbuf, float *qvalue, float *occ,
+                           uint8_t *visible, const float *scaler, const float *feat, int C, float *image, float *wsum,
+                           const void *workspace, size_t workspace_bytes, void *stream)
 {
     int rc = validate_fwd("dss_splat_fine", N, P, S, K, row0, row1);
     if (rc) return rc;
@@ -747,7 +748,7 @@ extern "C" int dss_splat_fine(const float *points, const float *ellipse, const f
     A.counts = nullptr; A.lists = nullptr; A.cap = 0;
     A.idx = idx; A.zbuf = zbuf; A.qv = qvalue; A.occ = occ; A.visible = visible;
     A.g = g; A.N = N; A.K = K; A.thr = merge_thr;
-    A.scaler = nullptr; A.feat = nullptr; A.image = nullptr; A.wsum = nullptr; A.C = 0;
+    A.scaler = scaler; A.feat = feat; A.image = image; A.wsum = wsum; A.C = C;
     if (workspace && P > 0) {
         if (workspace_bytes < dss_splat_forward_workspace(N, P, S, K, 1)) {
             set_error("dss_splat_fine: workspace too small");
@@ -761,6 +762,31 @@ extern "C" int dss_splat_fine(const float *points, const float *ellipse, const f
         return DSS_ERR_UNSUPPORTED;
     }
     return check_launch("dss_splat_fine");
+}
+
+extern "C" int dss_splat_fine(const float *points, const float *ellipse, const float *cutoff, const float *radii,
+                              const int64_t *first_idx, const int64_t *num_pts, int N, int64_t P, float merge_thr,
+                              int S, int K, int row0, int row1, int32_t *idx, float *zbuf, float *qvalue, float *occ,
+                              uint8_t *visible, const void *workspace, size_t workspace_bytes, void *stream)
+{
+    return splat_fine_impl(points, ellipse, cutoff, radii, first_idx, num_pts, N, P, merge_thr, S, K, row0, row1, idx,
+                           zbuf, qvalue, occ, visible, nullptr, nullptr, 0, nullptr, nullptr, workspace, workspace_bytes,
+                           stream);
+}
+
+extern "C" int dss_splat_fine_blend(const float *points, const float *ellipse, const float *cutoff, const float *radii,
+                                    const int64_t *first_idx, const int64_t *num_pts, int N, int64_t P,
+                                    float merge_thr, int S, int K, int row0, int row1, int32_t *idx, float *zbuf,
+                                    float *qvalue, float *occ, uint8_t *visible, const float *scaler, const float *feat,
+                                    int C, float *image, float *wsum, const void *workspace, size_t workspace_bytes,
+                                    void *stream)
+{
+    if (K > DSS_MAX_K_FAST || C < 1 || C > 8 || !scaler || !feat || !image || !wsum) {
+        set_error("dss_splat_fine_blend: needs K <= %d, 1 <= C <= 8 and non-NULL blend tensors", DSS_MAX_K_FAST);
+        return DSS_ERR_INVALID_ARGUMENT;
+    }
+    return splat_fine_impl(points, ellipse, cutoff, radii, first_idx, num_pts, N, P, merge_thr, S, K, row0, row1, idx,
+                           zbuf, qvalue, occ, visible, scaler, feat, C, image, wsum, workspace, workspace_bytes, stream);
 }
 
 extern "C" int dss_splat_forward(const float *points, const float *ellipse, const float *cutoff,

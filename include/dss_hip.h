@@ -96,6 +96,16 @@ DSS_API int dss_splat_fine(const float *points, const float *ellipse, const floa
                            int32_t *idx, float *zbuf, float *qvalue, float *occ, uint8_t *visible,
                            const void *workspace, size_t workspace_bytes, void *stream);
 
+/* dss_splat_fine with the blend fused into its epilogue (still exactly ONE kernel launch): besides the
+ * fragments it writes image (N,rows,S,C+1) and wsum (N,rows,S) exactly like dss_blend_forward would.
+ * This is the kernel dss_render_forward launches; K <= DSS_MAX_K_FAST, 1 <= C <= 8. */
+DSS_API int dss_splat_fine_blend(const float *points, const float *ellipse, const float *cutoff,
+                                 const float *radii, const int64_t *first_idx, const int64_t *num_pts,
+                                 int N, int64_t P, float merge_thr, int S, int K, int row0, int row1,
+                                 int32_t *idx, float *zbuf, float *qvalue, float *occ, uint8_t *visible,
+                                 const float *scaler, const float *feat, int C, float *image, float *wsum,
+                                 const void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Backward of the rasterizer = EllipticalRasterizer.backward (rasterizer.py:787-977) with
  * backward_occ_fast=True (:816), in four pieces so that a multi-GPU caller can reduce between

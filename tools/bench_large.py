@@ -35,7 +35,7 @@ torch.cuda.synchronize()
 ms = (time.perf_counter() - t0) / steps * 1e3
 fine_mean, fine_med = wl.fine_kernel_ms(iters=10)
 K = bench.K
-alg = wl.N * S * S * (12 * K + 4) + wl.P * 36
+alg = wl.N * S * S * (12 * K + 4 + 16 + 4) + wl.P * 52
 out = wl.step()
 img = out[0]
 rec = {"config": which, "points_per_cloud": P, "cameras": N, "image_size": S, "ms_per_step_eager": round(ms, 4),
