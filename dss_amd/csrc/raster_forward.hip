@@ -154,6 +154,17 @@ struct FineArgs {
     int C;
 };
 
+// block id -> tile id such that XCD x (= block id mod 8, the observed dispatch order; used for speed only,
+// any placement is correct) owns the contiguous tiles [x*per, (x+1)*per).  The grid is rounded up to a
+// multiple of 8; surplus blocks return -1.
+#define DSS_XCDS 8
+__device__ __forceinline__ int xcd_tile(unsigned b, int total)
+{
+    const int per = (total + DSS_XCDS - 1) / DSS_XCDS;
+    const int t = (int)(b % DSS_XCDS) * per + (int)(b / DSS_XCDS);
+    return ((int)(b / DSS_XCDS) < per && t < total) ? t : -1;
+}
+
 // Candidate source of one tile: its DSS_SUB fixed-capacity sub-lists (binned mode) or the whole cloud
 // (naive mode, or a tile whose sub-list overflowed).  `at(i)` maps the i-th candidate to a splat id.
 struct TileSource {
@@ -163,11 +174,11 @@ struct TileSource {
     const int32_t *base;    // binned: &lists[tile*SUB*cap]
     uint32_t cap;
     uint32_t ps[DSS_SUB + 1];  // prefix sums of the sub-list lengths
-    __device__ __forceinline__ void init(const FineArgs &A, int n)
+    __device__ __forceinline__ void init(const FineArgs &A, int n, int tile_id)
     {
         use_list = false;
         if (A.counts != nullptr) {
-            const uint4 *c4 = reinterpret_cast<const uint4 *>(A.counts + (size_t)blockIdx.x * DSS_SUB);
+            const uint4 *c4 = reinterpret_cast<const uint4 *>(A.counts + (size_t)tile_id * DSS_SUB);
             uint32_t c[DSS_SUB];
 #pragma unroll
             for (int q = 0; q < DSS_SUB / 4; ++q) {
@@ -184,7 +195,7 @@ struct TileSource {
             use_list = ok;
             count = ps[DSS_SUB];
             cap = A.cap;
-            base = A.lists + (size_t)blockIdx.x * DSS_SUB * A.cap;
+            base = A.lists + (size_t)tile_id * DSS_SUB * A.cap;
         }
         if (!use_list) {
             first = A.first_idx[n];
@@ -271,8 +282,15 @@ __global__ __launch_bounds__(FINE_THREADS) void fine_kernel(const FineArgs A)
     FT_VAL(8, __builtin_amdgcn_s_memrealtime());
     const TileGrid g = A.g;
     const int tiles = g.tiles_x * g.tiles_y;
-    const int n = blockIdx.x / tiles;
-    const int t = blockIdx.x - n * tiles;
+    // XCD-aware block -> tile mapping.  Consecutive workgroup ids are dealt round-robin to the 8 XCDs, each
+    // with its own L2; horizontally adjacent 8x8 tiles share 128-byte lines of the (N,rows,S,K) tensors
+    // (a tile row is only 8*K*4 = 160 B), so with the identity mapping every XCD wrote partial lines and
+    // the PMC write traffic was 3.7x the algorithmic bytes.  Give every XCD one contiguous run of tiles:
+    // neighbouring tiles then meet in the same L2 and leave as full lines.
+    const int tile_id = xcd_tile(blockIdx.x, A.N * tiles);
+    if (tile_id < 0) return;
+    const int n = tile_id / tiles;
+    const int t = tile_id - n * tiles;
     const int ty = t / g.tiles_x, tx = t - ty * g.tiles_x;
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -291,7 +309,7 @@ __global__ __launch_bounds__(FINE_THREADS) void fine_kernel(const FineArgs A)
 
     // candidate source: tile sub-lists (binned) or the whole cloud (naive / overflowed tile)
     TileSource src;
-    src.init(A, n);
+    src.init(A, n, tile_id);
     const int64_t count = src.count;
 
     // rows of the tile are contiguous runs of 16*K dwords in the (N,rows,S,K) tensors
@@ -521,8 +539,10 @@ __global__ __launch_bounds__(64) void fine_generic_kernel(const FineArgs A)
 {
     const TileGrid g = A.g;
     const int tiles = g.tiles_x * g.tiles_y;
-    const int n = blockIdx.x / tiles;
-    const int t = blockIdx.x - n * tiles;
+    const int tile_id = xcd_tile(blockIdx.x, A.N * tiles);
+    if (tile_id < 0) return;
+    const int n = tile_id / tiles;
+    const int t = tile_id - n * tiles;
     const int ty = t / g.tiles_x, tx = t - ty * g.tiles_x;
     const int lane = threadIdx.x;
     const int r = g.row0 + ty * DSS_TILE + (lane >> 3);
@@ -531,7 +551,7 @@ __global__ __launch_bounds__(64) void fine_generic_kernel(const FineArgs A)
     const float xf = pix_to_ndc(S - 1 - c, S);
     const float yf = pix_to_ndc(S - 1 - r, S);
     TileSource src;
-    src.init(A, n);
+    src.init(A, n, tile_id);
     const int64_t count = src.count;
     unsigned long long key[DSS_MAX_K];
     float kq[DSS_MAX_K];
@@ -585,7 +605,7 @@ __global__ __launch_bounds__(64) void fine_generic_kernel(const FineArgs A)
 template <int KMAX>
 static void launch_fine(const FineArgs &A, int blocks, hipStream_t st)
 {
-    hipLaunchKernelGGL(fine_kernel<KMAX>, dim3(blocks), dim3(FINE_THREADS), 0, st, A);
+    hipLaunchKernelGGL(fine_kernel<KMAX>, dim3((blocks + DSS_XCDS - 1) / DSS_XCDS * DSS_XCDS), dim3(FINE_THREADS), 0, st, A);
 }
 
 static bool dispatch_fine(const FineArgs &A, int blocks, hipStream_t st)
@@ -607,7 +627,7 @@ static bool dispatch_fine(const FineArgs &A, int blocks, hipStream_t st)
     if (K <= 24) { launch_fine<24>(A, blocks, st); return true; }
     if (K <= 32) { launch_fine<32>(A, blocks, st); return true; }
     if (K <= DSS_MAX_K) {
-        hipLaunchKernelGGL(fine_generic_kernel, dim3(blocks), dim3(64), 0, st, A);
+        hipLaunchKernelGGL(fine_generic_kernel, dim3((blocks + DSS_XCDS - 1) / DSS_XCDS * DSS_XCDS), dim3(64), 0, st, A);
         return true;
     }
     return false;
