@@ -335,7 +335,11 @@ __global__ __launch_bounds__(FINE_THREADS) void fine_kernel(const FineArgs A)
                 const size_t pix = ((size_t)n * g.rows + (size_t)ty * DSS_TILE + rr) * S + c0 + lane;
                 A.occ[pix] = 0.0f;
                 if (A.image) {  // fused blend of an empty pixel: zeros, weight sum clamped to kEpsilon
-                    for (int ch = 0; ch <= A.C; ++ch) A.image[pix * (A.C + 1) + ch] = 0.0f;
+                    if (A.C == 3) {
+                        *reinterpret_cast<float4 *>(A.image + pix * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+                    } else {
+                        for (int ch = 0; ch <= A.C; ++ch) A.image[pix * (A.C + 1) + ch] = 0.0f;
+                    }
                     A.wsum[pix] = 1e-4f;
                 }
             }
@@ -476,14 +480,29 @@ __global__ __launch_bounds__(FINE_THREADS) void fine_kernel(const FineArgs A)
             if (cum < 1e-4f) cum = 1e-4f;
             A.wsum[pix] = cum;
             float *o = A.image + pix * (A.C + 1);
-            for (int ch = 0; ch < A.C; ++ch) {
-                float acc = 0.0f;
+            if (A.C == 3) {
+                // RGBA as ONE 16-byte store per pixel (four dword stores at a 16-byte stride quadruple the
+                // write requests the memory side sees)
+                float acc3[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
                 for (int k = 0; k < KMAX; ++k)
-                    if (k < K && ki[k] >= 0) acc += A.feat[(size_t)ki[k] * A.C + ch] * wk[k] / cum;
-                o[ch] = acc;
+                    if (k < K && ki[k] >= 0) {
+                        const float *f = A.feat + (size_t)ki[k] * 3;
+                        acc3[0] += f[0] * wk[k] / cum;
+                        acc3[1] += f[1] * wk[k] / cum;
+                        acc3[2] += f[2] * wk[k] / cum;
+                    }
+                *reinterpret_cast<float4 *>(o) = make_float4(acc3[0], acc3[1], acc3[2], any ? 1.0f : 0.0f);
+            } else {
+                for (int ch = 0; ch < A.C; ++ch) {
+                    float acc = 0.0f;
+#pragma unroll
+                    for (int k = 0; k < KMAX; ++k)
+                        if (k < K && ki[k] >= 0) acc += A.feat[(size_t)ki[k] * A.C + ch] * wk[k] / cum;
+                    o[ch] = acc;
+                }
+                o[A.C] = any ? 1.0f : 0.0f;
             }
-            o[A.C] = any ? 1.0f : 0.0f;
         }
     }
 
