@@ -205,10 +205,16 @@ struct TileSource {
     __device__ __forceinline__ int64_t at(int64_t i) const
     {
         if (!use_list) return first + i;
-        int sub = 0;
+        // ps[] is only ever indexed with compile-time constants: a dynamic ps[sub] sends the whole array to
+        // scratch memory (measured: +60 MB of HBM writes per launch at 512^2)
+        uint32_t sub = 0, start = 0;
 #pragma unroll
-        for (int q = 1; q < DSS_SUB; ++q) sub += ((uint32_t)i >= ps[q]) ? 1 : 0;
-        return (int64_t)base[(size_t)sub * cap + ((uint32_t)i - ps[sub])];
+        for (int q = 1; q < DSS_SUB; ++q) {
+            const bool ge = (uint32_t)i >= ps[q];
+            sub = ge ? (uint32_t)q : sub;
+            start = ge ? ps[q] : start;
+        }
+        return (int64_t)base[(size_t)sub * cap + ((uint32_t)i - start)];
     }
 };
 
