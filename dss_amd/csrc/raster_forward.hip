@@ -160,6 +160,9 @@ struct FineArgs {
 #define DSS_XCDS 8
 __device__ __forceinline__ int xcd_tile(unsigned b, int total)
 {
+#ifdef DSS_NO_XCD_MAP  // A/B switch for tools/ab_xcd.py
+    return (int)b < total ? (int)b : -1;
+#endif
     const int per = (total + DSS_XCDS - 1) / DSS_XCDS;
     const int t = (int)(b % DSS_XCDS) * per + (int)(b / DSS_XCDS);
     return ((int)(b / DSS_XCDS) < per && t < total) ? t : -1;
