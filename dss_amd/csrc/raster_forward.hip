@@ -154,19 +154,13 @@ struct FineArgs {
     int C;
 };
 
-// block id -> tile id such that XCD x (= block id mod 8, the observed dispatch order; used for speed only,
-// any placement is correct) owns the contiguous tiles [x*per, (x+1)*per).  The grid is rounded up to a
-// multiple of 8; surplus blocks return -1.
-#define DSS_XCDS 8
-__device__ __forceinline__ int xcd_tile(unsigned b, int total)
-{
-#ifdef DSS_NO_XCD_MAP  // A/B switch for tools/ab_xcd.py
-    return (int)b < total ? (int)b : -1;
-#endif
-    const int per = (total + DSS_XCDS - 1) / DSS_XCDS;
-    const int t = (int)(b % DSS_XCDS) * per + (int)(b / DSS_XCDS);
-    return ((int)(b / DSS_XCDS) < per && t < total) ? t : -1;
-}
+// block id -> tile id.  Identity on purpose.  Consecutive workgroup ids are dealt round-robin to the 8
+// XCDs (each with its own L2); an XCD-contiguous mapping (XCD x owns tiles [x*T/8, (x+1)*T/8)) was
+// measured with tools/ab_xcd.py and is SLOWER (512^2 bunny: 37.3 vs 33.4 us; 8 x 1024^2, 1M points: 1.36
+// vs 1.31 ms): the dense screen region then sits on one XCD, and the write traffic is already at the
+// algorithmic minimum (PMC WRITE_SIZE 22.7 MB vs 22.5 MB) so there is nothing for the shared L2 to merge.
+// Round-robin placement doubles as load balancing here.
+__device__ __forceinline__ int xcd_tile(unsigned b, int total) { return (int)b < total ? (int)b : -1; }
 
 // Candidate source of one tile: its DSS_SUB fixed-capacity sub-lists (binned mode) or the whole cloud
 // (naive mode, or a tile whose sub-list overflowed).  `at(i)` maps the i-th candidate to a splat id.
@@ -291,11 +285,6 @@ __global__ __launch_bounds__(FINE_THREADS) void fine_kernel(const FineArgs A)
     FT_VAL(8, __builtin_amdgcn_s_memrealtime());
     const TileGrid g = A.g;
     const int tiles = g.tiles_x * g.tiles_y;
-    // XCD-aware block -> tile mapping.  Consecutive workgroup ids are dealt round-robin to the 8 XCDs, each
-    // with its own L2; horizontally adjacent 8x8 tiles share 128-byte lines of the (N,rows,S,K) tensors
-    // (a tile row is only 8*K*4 = 160 B), so with the identity mapping every XCD wrote partial lines and
-    // the PMC write traffic was 3.7x the algorithmic bytes.  Give every XCD one contiguous run of tiles:
-    // neighbouring tiles then meet in the same L2 and leave as full lines.
     const int tile_id = xcd_tile(blockIdx.x, A.N * tiles);
     if (tile_id < 0) return;
     const int n = tile_id / tiles;
@@ -633,7 +622,7 @@ __global__ __launch_bounds__(64) void fine_generic_kernel(const FineArgs A)
 template <int KMAX>
 static void launch_fine(const FineArgs &A, int blocks, hipStream_t st)
 {
-    hipLaunchKernelGGL(fine_kernel<KMAX>, dim3((blocks + DSS_XCDS - 1) / DSS_XCDS * DSS_XCDS), dim3(FINE_THREADS), 0, st, A);
+    hipLaunchKernelGGL(fine_kernel<KMAX>, dim3(blocks), dim3(FINE_THREADS), 0, st, A);
 }
 
 static bool dispatch_fine(const FineArgs &A, int blocks, hipStream_t st)
@@ -655,7 +644,7 @@ static bool dispatch_fine(const FineArgs &A, int blocks, hipStream_t st)
     if (K <= 24) { launch_fine<24>(A, blocks, st); return true; }
     if (K <= 32) { launch_fine<32>(A, blocks, st); return true; }
     if (K <= DSS_MAX_K) {
-        hipLaunchKernelGGL(fine_generic_kernel, dim3((blocks + DSS_XCDS - 1) / DSS_XCDS * DSS_XCDS), dim3(64), 0, st, A);
+        hipLaunchKernelGGL(fine_generic_kernel, dim3(blocks), dim3(64), 0, st, A);
         return true;
     }
     return false;
