@@ -28,7 +28,7 @@ sys.path.insert(0, ROOT)
 
 from dss_amd import _lib, ops  # noqa: E402
 from dss_amd.cameras import FoVPerspectiveCameras, look_at_view_transform  # noqa: E402
-from dss_amd.distributed import RowPartition, gather_rows, reduce_grads_, reduce_visibility_  # noqa: E402
+from dss_amd.distributed import RowPartition, gather_rows, gather_rows_and_visibility, reduce_grads_  # noqa: E402
 
 S, K, THR, RADII_S, CLIP, CUTOFF, SIGMA = 512, 5, 0.05, 5.0, 0.05, 1.0, 1.0
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
@@ -77,21 +77,20 @@ class Workload:
                                self.num, self.colors, S, K, CUTOFF, THR, SIGMA, False, True, rows=p.rows)
         info = {"pts_screen": f["pts_screen"], "radii": f["radii"], "scaler": f["scaler"], "valid": f["valid"]}
         idx, qv, vis, band, wsum = f["idx"], f["qvalue"], f["visible"], f["image"], f["wsum"]
-        image = gather_rows(band, p)
+        if p.world_size == 1:
+            image = gather_rows(band, p)
+        else:  # one collective for the RGBA bands AND the visibility union
+            image, vis8 = gather_rows_and_visibility(band, vis, p)
         g_band = p.slice(self.grad_out).contiguous() if p.world_size > 1 else self.grad_out
-        geom = (info["pts_screen"], info["radii"], vis, self.first, self.num)
         if p.world_size == 1:
             # fused backward: persistent wavefronts over the compacted visible list (dss_render_backward)
             g_feat, g_pts = ops.render_backward(g_band, idx, qv, wsum, info["scaler"], info["pts_screen"],
                                                 info["radii"], vis, self.first, self.num, RADII_S, CLIP)
         else:
-            g_feat, g_occ = ops.blend_backward(g_band, idx, qv, info["scaler"], self.P, geometry=geom, wsum=wsum,
-                                               image_size=S, rows=p.rows)
-            vis8 = vis.view(torch.uint8)
-            reduce_visibility_(vis8, p)
-            rs = ops.backward_radius(info["radii"], vis8, self.first, self.num, RADII_S)
-            g_pts = ops.occ_backward(info["pts_screen"], info["radii"], vis8, rs, g_occ, self.first, self.num,
-                                     image_size=S, rows=p.rows)
+            # same fused kernel on the band; visibility = union over ranks, clip after the reduction
+            g_feat, g_pts = ops.render_backward(g_band, idx, qv, wsum, info["scaler"], info["pts_screen"],
+                                                info["radii"], vis8, self.first, self.num, RADII_S, -1.0,
+                                                image_size=S, rows=p.rows)
             reduce_grads_(g_pts, g_feat, part=p)
             ops.clip_grad_(g_pts, CLIP)
         g_world = ops.project_backward(self.world, self.M, self.V, self.first, self.num, g_pts, info["valid"], True)

@@ -313,7 +313,7 @@ __global__ __launch_bounds__(256) void render_backward_kernel(
     const float *__restrict__ wsum, const float *__restrict__ scaler, const float *__restrict__ points,
     const float *__restrict__ radii, const float *__restrict__ rs, const int64_t *__restrict__ first_idx,
     const int64_t *__restrict__ num_pts, const uint32_t *__restrict__ vis_count,
-    const int32_t *__restrict__ vis_list, int N, int S, int K, int Crt, float clip,
+    const int32_t *__restrict__ vis_list, int N, int S, int K, int Crt, float clip, int row0, int rows,
     float *__restrict__ grad_feat, float *__restrict__ grad_pts)
 {
     constexpr int CM = (C > 0) ? C : BLEND_MAX_C;
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(256) void render_backward_kernel(
         const long long tm1 = __builtin_amdgcn_s_memtime();
 #endif
         // occupancy gradient = alpha channel of the image gradient, read in place
-        occ_point_gather(lane, p, n, points, radii, rs, grad_out + Cn, S, 0, S, Cn + 1, gx, gy);
+        occ_point_gather(lane, p, n, points, radii, rs, grad_out + Cn, S, row0, rows, Cn + 1, gx, gy);
 #ifdef DSS_FINE_TIMING
         gx = wave_sum(gx) * (1.0f / 64.0f) * 64.0f / 64.0f;  // force completion of the gather before the stamp
         const long long tm2 = __builtin_amdgcn_s_memtime();
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(256) void render_backward_kernel(
 #pragma unroll
         for (int ch = 0; ch < CM; ++ch) acc[ch] = 0.0f;
         if (grad_feat)
-            blend_point_gather<C>(lane, p, n, grad_out, idx, qv, wsum, scaler, points, radii, S, K, Cn, 0, S, acc);
+            blend_point_gather<C>(lane, p, n, grad_out, idx, qv, wsum, scaler, points, radii, S, K, Cn, row0, rows, acc);
         gx = wave_sum(gx);
         gy = wave_sum(gy);
 #pragma unroll
@@ -546,10 +546,11 @@ extern "C" size_t dss_render_backward_workspace(int N, int64_t P)
 extern "C" int dss_render_backward(const float *grad_out, const int32_t *idx, const float *qvalue, const float *wsum,
                                    const float *scaler, const float *points, const float *radii,
                                    const uint8_t *visible, const int64_t *first_idx, const int64_t *num_pts, int N,
-                                   int64_t P, int S, int K, int C, float radii_s, float clip, float *grad_feat,
-                                   float *grad_pts, float *rs_out, void *workspace, size_t workspace_bytes, void *stream)
+                                   int64_t P, int S, int K, int C, int row0, int row1, float radii_s, float clip,
+                                   float *grad_feat, float *grad_pts, float *rs_out, void *workspace,
+                                   size_t workspace_bytes, void *stream)
 {
-    if (N <= 0 || P < 0 || S <= 0 || K <= 0 || C < 1 || C > BLEND_MAX_C) {
+    if (N <= 0 || P < 0 || S <= 0 || K <= 0 || C < 1 || C > BLEND_MAX_C || row0 < 0 || row1 > S || row0 >= row1) {
         set_error("dss_render_backward: bad sizes N=%d P=%lld S=%d K=%d C=%d", N, (long long)P, S, K, C);
         return DSS_ERR_INVALID_ARGUMENT;
     }
@@ -603,12 +604,12 @@ extern "C" int dss_render_backward(const float *grad_out, const int32_t *idx, co
     const unsigned pgrid = (unsigned)((P + 3) / 4 < cap ? (P + 3) / 4 : cap);
     if (C == 3)
         hipLaunchKernelGGL(render_backward_kernel<3>, dim3(pgrid), dim3(256), 0, st, grad_out, idx, qvalue, wsum, scaler,
-                           points, radii, rs, first_idx, num_pts, vis_count, vis_list, N, S, K, C, clip, grad_feat,
-                           grad_pts);
+                           points, radii, rs, first_idx, num_pts, vis_count, vis_list, N, S, K, C, clip, row0, row1 - row0,
+                           grad_feat, grad_pts);
     else
         hipLaunchKernelGGL(render_backward_kernel<0>, dim3(pgrid), dim3(256), 0, st, grad_out, idx, qvalue, wsum, scaler,
-                           points, radii, rs, first_idx, num_pts, vis_count, vis_list, N, S, K, C, clip, grad_feat,
-                           grad_pts);
+                           points, radii, rs, first_idx, num_pts, vis_count, vis_list, N, S, K, C, clip, row0, row1 - row0,
+                           grad_feat, grad_pts);
     return check_launch("dss_render_backward");
 }
 

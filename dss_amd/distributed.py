@@ -62,6 +62,30 @@ def gather_rows(band: torch.Tensor, part: RowPartition, group=None) -> torch.Ten
     return full[:, :part.S]
 
 
+def gather_rows_and_visibility(band: torch.Tensor, visible: torch.Tensor, part: RowPartition, group=None):
+    """ONE all-gather for both end-of-forward exchanges: the RGBA row bands and the per-band visibility
+    flags travel in the same byte buffer (collectives here are latency-, not bandwidth-bound: fewer calls
+    matter more than fewer bytes).  Returns (full image (N,S,S,ch), union of the visibility flags uint8 (P,))."""
+    if part.world_size == 1:
+        return band, visible
+    n, rows = band.shape[0], band.shape[1]
+    if rows < part.band:
+        pad = band.new_zeros((n, part.band - rows) + tuple(band.shape[2:]))
+        band = torch.cat([band, pad], dim=1)
+    vis8 = visible.view(torch.uint8) if visible.dtype == torch.bool else visible
+    nb = band.numel() * band.element_size()
+    send = torch.cat([band.contiguous().view(-1).view(torch.uint8), vis8.reshape(-1)])
+    out = send.new_empty((part.world_size, send.numel()))
+    if dist.get_backend(group) == "gloo":
+        dist.all_gather(list(out.unbind(0)), send, group=group)
+    else:
+        dist.all_gather_into_tensor(out, send, group=group)
+    bands = out[:, :nb].contiguous().view(band.dtype).view((part.world_size,) + tuple(band.shape))
+    full = bands.permute(1, 0, 2, *range(3, bands.dim())).reshape((n, part.world_size * part.band) + tuple(band.shape[2:]))
+    vis_all = out[:, nb:].max(dim=0).values
+    return full[:, :part.S], vis_all
+
+
 class GatherRows(torch.autograd.Function):
     """Differentiable ``gather_rows``.  Every rank evaluates the same loss on the same full image, so
     the gradient of the local band is simply its slice of the full-image gradient (no collective)."""

@@ -329,9 +329,11 @@ def render_forward(world, normals, h, M, V, znear, zfar, cloud_to_packed_first_i
 
 def render_backward(grad_out, idx, qvalue, wsum, scaler, points, radii, visible, cloud_to_packed_first_idx,
                     num_points_per_cloud, radii_s: float, clip: float = -1.0, with_features: bool = True,
-                    return_rs: bool = False):
-    """Fused single-GPU backward of renderer + rasterizer (blend backward + median radius + occupancy
-    backward + clip) -> (grad_features (P,C) or None, grad_pts_screen (P,3))."""
+                    return_rs: bool = False, image_size: Optional[int] = None,
+                    rows: Optional[Tuple[int, int]] = None):
+    """Fused backward of renderer + rasterizer (blend backward + median radius + occupancy backward +
+    clip) -> (grad_features (P,C) or None, grad_pts_screen (P,3)).  With ``rows`` (multi-GPU band) pass the
+    union of the visibility flags and ``clip <= 0``; the results are the band's partial sums."""
     lib = _lib.load()
     grad_out = _lib.require_gpu(grad_out, "grad_out", _f32)
     dev = grad_out.device
@@ -345,11 +347,13 @@ def render_backward(grad_out, idx, qvalue, wsum, scaler, points, radii, visible,
     num = _lib.require_gpu(num_points_per_cloud, "num_points_per_cloud", _i64)
     if wsum is not None:
         wsum = _lib.require_gpu(wsum, "wsum", _f32)
-    N, S, S2, K = idx.shape
+    N, H, W, K = idx.shape
     C = grad_out.shape[-1] - 1
     P = points.shape[0]
-    if S != S2 or tuple(grad_out.shape[:3]) != (N, S, S):
-        raise RuntimeError("render_backward needs full square images: idx (N,S,S,K), grad_out (N,S,S,C+1)")
+    S = int(image_size) if image_size is not None else W
+    row0, row1 = (0, S) if rows is None else (int(rows[0]), int(rows[1]))
+    if W != S or H != row1 - row0 or tuple(grad_out.shape[:3]) != (N, H, W):
+        raise RuntimeError("render_backward needs idx (N,rows,S,K) and grad_out (N,rows,S,C+1)")
     with torch.cuda.device(dev):
         gf = torch.empty((P, C), dtype=_f32, device=dev) if with_features else None
         gp = torch.empty((P, 3), dtype=_f32, device=dev)
@@ -357,8 +361,8 @@ def render_backward(grad_out, idx, qvalue, wsum, scaler, points, radii, visible,
         ws = _lib.workspace(dev, lib.dss_render_backward_workspace(N, P))
         rc = lib.dss_render_backward(_lib.ptr(grad_out), _lib.ptr(idx), _lib.ptr(qvalue), _lib.ptr(wsum),
                                      _lib.ptr(scaler), _lib.ptr(points), _lib.ptr(radii), _lib.ptr(vis),
-                                     _lib.ptr(first), _lib.ptr(num), N, P, S, K, C, float(radii_s), float(clip),
-                                     _lib.ptr(gf), _lib.ptr(gp), _lib.ptr(rs), _lib.ptr(ws), ws.numel(),
+                                     _lib.ptr(first), _lib.ptr(num), N, P, S, K, C, row0, row1, float(radii_s),
+                                     float(clip), _lib.ptr(gf), _lib.ptr(gp), _lib.ptr(rs), _lib.ptr(ws), ws.numel(),
                                      _lib.stream_ptr(dev))
     _lib.check(rc, "dss_render_backward")
     return (gf, gp, rs) if return_rs else (gf, gp)

@@ -217,8 +217,10 @@ DSS_API int dss_render_forward(const float *world, const float *normals, const f
  * Fused single-GPU backward of renderer + rasterizer: dss_blend_backward + dss_backward_radius +
  * dss_occ_backward + dss_clip_grad in five launches, with the per-point work done by persistent
  * wavefronts over the compacted list of visible points (the stand-alone kernels are bound by the
- * workgroup dispatch rate at DSS sizes).  Full image only (row0=0,row1=S), no zbuf gradient; the
- * occupancy gradient is the alpha channel of grad_out (N,S,S,C+1), read in place.
+ * workgroup dispatch rate at DSS sizes).  No zbuf gradient; the occupancy gradient is the alpha channel
+ * of grad_out (N,rows,S,C+1), read in place.  With a row band (multi-GPU) `visible` must be the union
+ * over all ranks, the outputs are this band's partial sums, and clip must be <= 0 (clip after the
+ * all-reduce with dss_clip_grad).
  * grad_feat may be NULL (rasterizer backward only).  grad_pts (P,3) and grad_feat (P,C) are fully
  * written.  Same results as the unfused entry points (same per-point arithmetic and reduction order).
  * ------------------------------------------------------------------------------------------- */
@@ -227,7 +229,8 @@ DSS_API int dss_render_backward(const float *grad_out, const int32_t *idx, const
                                 const float *wsum, const float *scaler, const float *points,
                                 const float *radii, const uint8_t *visible, const int64_t *first_idx,
                                 const int64_t *num_pts, int N, int64_t P, int S, int K, int C,
-                                float radii_s, float clip, float *grad_feat /* (P,C) or NULL */,
+                                int row0, int row1, float radii_s, float clip,
+                                float *grad_feat /* (P,C) or NULL */,
                                 float *grad_pts /* (P,3) */, float *rs_out /* (N,) or NULL */,
                                 void *workspace, size_t workspace_bytes, void *stream);
 

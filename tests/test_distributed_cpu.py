@@ -19,7 +19,8 @@ def _worker(rank, world, port, S, tmp):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle
     import scenes
-    from dss_amd.distributed import GatherRows, RowPartition, reduce_grads_, reduce_visibility_
+    from dss_amd.distributed import (GatherRows, RowPartition, gather_rows_and_visibility, reduce_grads_,
+                                     reduce_visibility_)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -44,6 +45,8 @@ def _worker(rank, world, port, S, tmp):
             .astype(np.uint8))
         vis = reduce_visibility_(vis_band.clone(), part)
         assert np.array_equal(vis.numpy().astype(bool), oracle.visibility(idx, P))
+        img2, vis2 = gather_rows_and_visibility(torch.from_numpy(full[:, r0:r1].copy()), vis_band.clone(), part)
+        assert torch.equal(img2, torch.from_numpy(full)) and torch.equal(vis2, vis)
         rs = oracle.backward_radius(sc["radii"], vis.numpy(), sc["first_idx"], sc["num_pts"], 3.0)
         gocc = g_full[..., 3].numpy()
         masked = np.zeros_like(gocc)

@@ -365,3 +365,22 @@ def test_render_backward_search_radius_sweep(radii_s):
     o_gf, _ = oracle.blend_backward(go.cpu().numpy(), idx.cpu().numpy(), qv.cpu().numpy(), sc["scaler"], P)
     assert np.array_equal(rs.cpu().numpy(), o_rs)
     assert _rel_l2(g.cpu().numpy(), o_g) <= 1e-4 and _rel_l2(gf.cpu().numpy(), o_gf) <= 1e-4
+
+
+def test_render_backward_row_bands_sum_to_full():
+    """Multi-GPU contract of the fused backward: band partial sums (global visibility, no clip) add up to
+    the full-image result."""
+    sc = scenes.random_splats(3000, 96, 2, seed=31)
+    d = _dev(sc)
+    idx, zbuf, qv, occ, vis = _fwd(d, 96, 5, 0.3, return_visible=True)
+    scaler = torch.from_numpy(sc["scaler"]).to(DEV)
+    img, wsum = ops.blend_forward(idx, qv, occ, scaler, torch.from_numpy(sc["colors"]).to(DEV), return_wsum=True)
+    go = torch.randn_like(img)
+    gf, g = ops.render_backward(go, idx, qv, wsum, scaler, d["points"], d["radii"], vis, d["first"], d["num"], 4.0, -1.0)
+    parts = []
+    for a, b in ((0, 40), (40, 96)):
+        parts.append(ops.render_backward(go[:, a:b].contiguous(), idx[:, a:b].contiguous(), qv[:, a:b].contiguous(),
+                                         wsum[:, a:b].contiguous(), scaler, d["points"], d["radii"], vis, d["first"],
+                                         d["num"], 4.0, -1.0, image_size=96, rows=(a, b)))
+    assert _rel_l2((parts[0][1] + parts[1][1]).cpu().numpy(), g.cpu().numpy()) <= 1e-5
+    assert _rel_l2((parts[0][0] + parts[1][0]).cpu().numpy(), gf.cpu().numpy()) <= 1e-5
