@@ -181,7 +181,10 @@ class SurfaceSplatting(torch.nn.Module):
                               scaler=torch.zeros((batch_size, S, S, K), device=device),
                               occupancy=torch.zeros((batch_size, S, S), device=device))
 
-    def forward(self, point_clouds, point_clouds_filter=None, **kwargs):
+    def _prepare(self, point_clouds, **kwargs):
+        """Everything the kernels need from the (camera, cloud) objects: packed world points / normals,
+        variance scale, camera matrices, cloud ranges.  One cloud is shared by all N cameras
+        (Pointclouds.extend, rasterizer.py:236-240) or there are N clouds."""
         raster_settings = kwargs.get("raster_settings", self.raster_settings)
         cameras = kwargs.get("cameras", self.cameras)
         if cameras is None:
@@ -189,17 +192,14 @@ class SurfaceSplatting(torch.nn.Module):
         self.cameras = cameras
         N = cameras.R.shape[0]
         dev = point_clouds.device
-        if point_clouds.isempty():
-            return self._empty_fragments(N, dev, raster_settings), point_clouds
-
         shared = len(point_clouds) == 1 and N >= 1
         if not shared and len(point_clouds) != N:
             raise ValueError("need 1 or %d point clouds for %d cameras, got %d" % (N, N, len(point_clouds)))
         h = kwargs.get("Vrk_h", None)
         if h is None:
             h = self._variance_scale(point_clouds, raster_settings, kwargs.get("refresh", True))
+        world, normals = point_clouds.points_packed(), point_clouds.normals_packed()
         if shared:
-            world, normals = point_clouds.points_packed(), point_clouds.normals_packed()
             Pc = world.shape[0]
             first_idx = torch.arange(N, device=dev, dtype=torch.int64) * Pc
             num_points = torch.full((N,), Pc, device=dev, dtype=torch.int64)
@@ -207,17 +207,26 @@ class SurfaceSplatting(torch.nn.Module):
                 h = h.reshape(1).expand(N).contiguous()
             out_clouds = point_clouds.extend(N) if N > 1 else point_clouds
         else:
-            world, normals = point_clouds.points_packed(), point_clouds.normals_packed()
             first_idx, num_points = point_clouds.cloud_to_packed_first_idx(), point_clouds.num_points_per_cloud()
             out_clouds = point_clouds
         M = cameras.get_full_projection_transform().get_matrix().to(dev, torch.float32).contiguous()
         V = cameras.get_world_to_view_transform().get_matrix().to(dev, torch.float32).contiguous()
         as_n = lambda v, d: torch.as_tensor(getattr(cameras, v, kwargs.get(v, d)), dtype=torch.float32,
                                             device=dev).reshape(-1).expand(N).contiguous()
-        znear, zfar = as_n("znear", 1.0), as_n("zfar", 100.0)
+        return dict(N=N, shared=shared, world=world, normals=normals, h=h.to(dev, torch.float32), M=M, V=V,
+                    znear=as_n("znear", 1.0), zfar=as_n("zfar", 100.0), first_idx=first_idx, num_points=num_points,
+                    out_clouds=out_clouds, raster_settings=raster_settings)
+
+    def forward(self, point_clouds, point_clouds_filter=None, **kwargs):
+        raster_settings = kwargs.get("raster_settings", self.raster_settings)
+        if point_clouds.isempty():
+            cameras = kwargs.get("cameras", self.cameras)
+            return self._empty_fragments(cameras.R.shape[0], point_clouds.device, raster_settings), point_clouds
+        a = self._prepare(point_clouds, **kwargs)
+        N, shared, first_idx, num_points = a["N"], a["shared"], a["first_idx"], a["num_points"]
 
         pts_screen, ellipse, radii, scaler, cutoff, valid = _ProjectAndSetup.apply(
-            world, normals, h.to(dev, torch.float32), M, V, znear, zfar, first_idx, num_points,
+            a["world"], a["normals"], a["h"], a["M"], a["V"], a["znear"], a["zfar"], first_idx, num_points,
             raster_settings.image_size, raster_settings.cutoff_threshold, raster_settings.antialiasing_sigma,
             bool(raster_settings.backface_culling), shared)
 
@@ -237,8 +246,55 @@ class SurfaceSplatting(torch.nn.Module):
             point_clouds_filter.set_filter(visibility=visible.view(N, -1) if shared else visible)
         if kwargs.get("verbose", False):
             info = {"radii": radii, "ellipse_params": ellipse, "cutoff_threshold": cutoff, "scaler": scaler}
-            return fragments, out_clouds, info
-        return fragments, out_clouds
+            return fragments, a["out_clouds"], info
+        return fragments, a["out_clouds"]
+
+    def render_fused(self, point_clouds, point_clouds_filter=None, **kwargs):
+        """Rasterize AND blend in the fused kernels (``dss_render_forward`` / ``dss_render_backward``):
+        -> ``(images (N,S,S,C+1), PointFragments, point_clouds)``.  Same values as ``forward`` + the
+        renderer's blend; the autograd graph is one node, so gradients flow to the world points and the
+        features only (a loss on ``fragments.zbuf`` needs the unfused path)."""
+        a = self._prepare(point_clouds, **kwargs)
+        st = a["raster_settings"]
+        feats = a["out_clouds"].features_packed()
+        outs = _RenderFused.apply(a["world"], feats[:, :min(feats.shape[1], 8)].contiguous(), a["normals"], a["h"],
+                                  a["M"], a["V"], a["znear"], a["zfar"], a["first_idx"], a["num_points"],
+                                  st.image_size, st.points_per_pixel, st.cutoff_threshold, st.depth_merging_threshold,
+                                  st.antialiasing_sigma, bool(st.backface_culling), a["shared"],
+                                  st.radii_backward_scaler, st.clip_pts_grad)
+        image, idx, zbuf, qv, occ, scaler, pts_screen, radii, visible = outs
+        fragments = PointFragments(idx=idx, zbuf=zbuf, qvalue=qv, scaler=scaler, occupancy=occ,
+                                   geometry=(pts_screen, radii, visible, a["first_idx"], a["num_points"]))
+        if point_clouds_filter is not None and hasattr(point_clouds_filter, "set_filter"):
+            point_clouds_filter.set_filter(visibility=visible.view(a["N"], -1) if a["shared"] else visible)
+        return image, fragments, a["out_clouds"]
+
+
+class _RenderFused(autograd.Function):
+    """One autograd node for the whole hot path: forward = dss_render_forward ([setup+bin] -> [fine+blend]),
+    backward = dss_render_backward (+clip) -> dss_project_backward."""
+
+    @staticmethod
+    def forward(ctx, world, features, normals, h, M, V, znear, zfar, first_idx, num_points, image_size,
+                points_per_pixel, cutoff, merge_thr, sigma, backface, shared, radii_s, clip):
+        f = ops.render_forward(world, normals, h, M, V, znear, zfar, first_idx, num_points, features, image_size,
+                               points_per_pixel, cutoff, merge_thr, sigma, backface, shared)
+        ctx.save_for_backward(world, M, V, first_idx, num_points, f["idx"], f["qvalue"], f["wsum"], f["scaler"],
+                              f["pts_screen"], f["radii"], f["visible"], f["valid"])
+        ctx.shared, ctx.radii_s = shared, float(radii_s)
+        ctx.clip = -1.0 if clip is None else float(clip)
+        outs = (f["image"], f["idx"], f["zbuf"], f["qvalue"], f["occupancy"], f["scaler"], f["pts_screen"],
+                f["radii"], f["visible"])
+        ctx.mark_non_differentiable(*outs[1:])
+        return outs
+
+    @staticmethod
+    def backward(ctx, g_image, *unused):
+        world, M, V, first_idx, num_points, idx, qv, wsum, scaler, pts_screen, radii, visible, valid = ctx.saved_tensors
+        g_feat, g_pts = ops.render_backward(g_image.contiguous(), idx, qv, wsum, scaler, pts_screen, radii, visible,
+                                            first_idx, num_points, ctx.radii_s, ctx.clip)
+        g_world = ops.project_backward(world, M, V, first_idx, num_points, g_pts, valid, ctx.shared)
+        return (g_world, g_feat) + (None,) * 17
 
 
 def ops_visibility_from_fragments(idx: torch.Tensor, P: int) -> torch.Tensor:

@@ -49,8 +49,12 @@ class NormWeightedCompositor(torch.nn.Module):
 
 class SurfaceSplattingRenderer(torch.nn.Module):
     def __init__(self, rasterizer, compositor=None, antialiasing_sigma: float = 1.0, density: float = 1e-4,
-                 frnn_radius=-1):
+                 frnn_radius=-1, fused: bool = False):
+        """``fused=True`` (not in the reference signature) runs rasterizer + blend as ONE autograd node on
+        the fused kernels (dss_render_forward / dss_render_backward): same images, ~2x fewer launches; the
+        only loss of generality is that gradients w.r.t. ``fragments.zbuf`` are not propagated."""
         super().__init__()
+        self.fused = fused
         self.rasterizer = rasterizer
         self.compositor = compositor
         self.cameras = self.rasterizer.cameras
@@ -63,6 +67,14 @@ class SurfaceSplattingRenderer(torch.nn.Module):
         if point_clouds.isempty():
             return None
         fragments = kwargs.get("fragments", None)
+        if (fragments is None and self.fused and hasattr(self.rasterizer, "render_fused")
+                and (self.compositor is None or isinstance(self.compositor, NormWeightedCompositor))
+                and self.rasterizer.raster_settings.points_per_pixel <= 32):
+            kw = {k: v for k, v in kwargs.items() if k != "fragments"}
+            images, fragments, point_clouds = self.rasterizer.render_fused(point_clouds, **kw)
+            if images.shape[-1] != 4:  # RGBA contract of renderer.py:75-78: first three feature channels + occupancy
+                images = torch.cat([images[..., :3], images[..., -1:]], dim=-1)
+            return (images, fragments) if kwargs.get("verbose", False) else images
         if fragments is None:
             if kwargs.get("verbose", False):
                 fragments, point_clouds, _ = self.rasterizer(point_clouds, **kwargs)

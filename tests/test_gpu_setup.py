@@ -154,3 +154,32 @@ def test_render_forward_fused_equals_separate_calls(shared):
         assert torch.equal(f["idx"], idx) and torch.equal(f["zbuf"], zbuf) and torch.equal(f["qvalue"], qv)
         assert torch.equal(f["occupancy"], occ) and torch.equal(f["visible"], vis)
         assert torch.equal(f["image"], img) and torch.equal(f["wsum"], wsum)
+
+
+@pytest.mark.parametrize("n_cams", [1, 3])
+def test_fused_renderer_matches_unfused(n_cams):
+    """SurfaceSplattingRenderer(fused=True): one autograd node on the fused kernels."""
+    S, K = 128, 5
+    pts, nrm = scenes.load_cloud("teapot")
+    pts = scenes.normalize_unit_sphere(pts)
+    h = scenes.global_h(pts)
+    col = np.random.default_rng(0).uniform(0, 1, pts.shape).astype(np.float32)
+    R, T = look_at_view_transform(2.0, 30.0, [45.0 + 100.0 * k for k in range(n_cams)])
+    cams = FoVPerspectiveCameras(znear=0.1, R=R, T=T, device=DEV)
+    st = PointsRasterizationSettings(backface_culling=False, cutoff_threshold=1.0, Vrk_invariant=True,
+                                     radii_backward_scaler=5, image_size=S, points_per_pixel=K, bin_size=None,
+                                     clip_pts_grad=0.05)
+    g = torch.from_numpy(np.random.default_rng(1).standard_normal((n_cams, S, S, 4)).astype(np.float32)).to(DEV)
+    res = []
+    for fused in (False, True):
+        renderer = SurfaceSplattingRenderer(SurfaceSplatting(cameras=cams, raster_settings=st), NormWeightedCompositor(),
+                                            fused=fused)
+        P = torch.nn.Parameter(torch.from_numpy(pts).to(DEV))
+        C = torch.nn.Parameter(torch.from_numpy(col).to(DEV))
+        img, frags = renderer(PointClouds3D([P], [torch.from_numpy(nrm).to(DEV)], [C]),
+                              Vrk_h=torch.tensor([h], device=DEV), verbose=True)
+        (img * g).sum().backward()
+        res.append((img.detach(), frags.idx, P.grad.clone(), C.grad.clone()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    rel = lambda a, b: float((a - b).norm() / b.norm())
+    assert rel(res[1][2], res[0][2]) < 1e-5 and rel(res[1][3], res[0][3]) < 1e-5

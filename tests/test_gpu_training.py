@@ -15,7 +15,8 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def test_inverse_rendering_loss_decreases():
+@pytest.mark.parametrize("fused", [False, True])
+def test_inverse_rendering_loss_decreases(fused):
     torch.manual_seed(0)
     S, n_cams = 128, 4
     pts, nrm = scenes.load_cloud("teapot")
@@ -26,7 +27,8 @@ def test_inverse_rendering_loss_decreases():
     st = PointsRasterizationSettings(backface_culling=False, cutoff_threshold=1.0, Vrk_invariant=True,
                                      radii_backward_scaler=5, image_size=S, points_per_pixel=5, bin_size=None,
                                      clip_pts_grad=0.05)
-    renderer = SurfaceSplattingRenderer(SurfaceSplatting(cameras=cams, raster_settings=st), NormWeightedCompositor())
+    renderer = SurfaceSplattingRenderer(SurfaceSplatting(cameras=cams, raster_settings=st), NormWeightedCompositor(),
+                                        fused=fused)
     normals = torch.from_numpy(nrm).to(DEV)
     with torch.no_grad():
         target = renderer(PointClouds3D([torch.from_numpy(pts).to(DEV)], [normals], [torch.from_numpy(col).to(DEV)]))
