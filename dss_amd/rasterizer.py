@@ -295,11 +295,3 @@ class _RenderFused(autograd.Function):
                                             first_idx, num_points, ctx.radii_s, ctx.clip)
         g_world = ops.project_backward(world, M, V, first_idx, num_points, g_pts, valid, ctx.shared)
         return (g_world, g_feat) + (None,) * 17
-
-
-def ops_visibility_from_fragments(idx: torch.Tensor, P: int) -> torch.Tensor:
-    """get_per_point_visibility_mask (DSS/utils/__init__.py:320-340) from a fragment tensor."""
-    vis = torch.zeros(P, dtype=torch.bool, device=idx.device)
-    sel = idx[idx >= 0].long()
-    vis[sel] = True
-    return vis
