@@ -28,7 +28,7 @@ sys.path.insert(0, ROOT)
 
 from dss_amd import _lib, ops  # noqa: E402
 from dss_amd.cameras import FoVPerspectiveCameras, look_at_view_transform  # noqa: E402
-from dss_amd.distributed import RowPartition, gather_rows, gather_rows_and_visibility, reduce_grads_  # noqa: E402
+from dss_amd.distributed import ForwardExchange, RowPartition, gather_rows  # noqa: E402
 
 S, K, THR, RADII_S, CLIP, CUTOFF, SIGMA = 512, 5, 0.05, 5.0, 0.05, 1.0, 1.0
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
@@ -68,30 +68,38 @@ class Workload:
         g = torch.Generator(device="cpu").manual_seed(1)
         self.grad_out = torch.randn((self.N, S, S, 4), generator=g).to(device)  # d loss / d RGBA
         self.S = S
+        if part.world_size > 1:
+            # multi-GPU: the forward kernel writes its RGBA band and visibility flags straight into the
+            # all-gather send buffer; the backward writes both gradients into one all-reduce bucket
+            self.fx = ForwardExchange(part, self.N, 4, self.P, device)
+            self.bucket = torch.empty(self.P * 6, device=device)
 
     def step(self):
         p = self.part
         S = self.S
-        # fused forward: [setup + tile count] -> scan -> fill -> [fine + blend]
+        multi = p.world_size > 1
+        # fused forward: [setup + binning] -> [fine + blend]
         f = ops.render_forward(self.world, self.normals, self.h, self.M, self.V, self.znear, self.zfar, self.first,
-                               self.num, self.colors, S, K, CUTOFF, THR, SIGMA, False, True, rows=p.rows)
+                               self.num, self.colors, S, K, CUTOFF, THR, SIGMA, False, True, rows=p.rows,
+                               out_image=self.fx.image if multi else None,
+                               out_visible=self.fx.visible if multi else None)
         info = {"pts_screen": f["pts_screen"], "radii": f["radii"], "scaler": f["scaler"], "valid": f["valid"]}
         idx, qv, vis, band, wsum = f["idx"], f["qvalue"], f["visible"], f["image"], f["wsum"]
-        if p.world_size == 1:
+        if not multi:
             image = gather_rows(band, p)
-        else:  # one collective for the RGBA bands AND the visibility union
-            image, vis8 = gather_rows_and_visibility(band, vis, p)
-        g_band = p.slice(self.grad_out).contiguous() if p.world_size > 1 else self.grad_out
-        if p.world_size == 1:
             # fused backward: persistent wavefronts over the compacted visible list (dss_render_backward)
-            g_feat, g_pts = ops.render_backward(g_band, idx, qv, wsum, info["scaler"], info["pts_screen"],
+            g_feat, g_pts = ops.render_backward(self.grad_out, idx, qv, wsum, info["scaler"], info["pts_screen"],
                                                 info["radii"], vis, self.first, self.num, RADII_S, CLIP)
         else:
+            # collective 1/2: RGBA bands + visibility flags in ONE all-gather
+            image, vis_all = self.fx.exchange(band)
+            g_band = p.slice(self.grad_out).contiguous()
+            g_feat = self.bucket[:self.P * 3].view(self.P, 3)
+            g_pts = self.bucket[self.P * 3:].view(self.P, 3)
             # same fused kernel on the band; visibility = union over ranks, clip after the reduction
-            g_feat, g_pts = ops.render_backward(g_band, idx, qv, wsum, info["scaler"], info["pts_screen"],
-                                                info["radii"], vis8, self.first, self.num, RADII_S, -1.0,
-                                                image_size=S, rows=p.rows)
-            reduce_grads_(g_pts, g_feat, part=p)
+            ops.render_backward(g_band, idx, qv, wsum, info["scaler"], info["pts_screen"], info["radii"], vis_all,
+                                self.first, self.num, RADII_S, -1.0, image_size=S, rows=p.rows, out=(g_feat, g_pts))
+            dist.all_reduce(self.bucket, op=dist.ReduceOp.SUM)  # collective 2/2: both gradient partials, one bucket
             ops.clip_grad_(g_pts, CLIP)
         g_world = ops.project_backward(self.world, self.M, self.V, self.first, self.num, g_pts, info["valid"], True)
         g_col = g_feat.view(self.N, self.Pc, 3).sum(0) if self.N > 1 else g_feat

@@ -86,6 +86,38 @@ def gather_rows_and_visibility(band: torch.Tensor, visible: torch.Tensor, part: 
     return full[:, :part.S], vis_all
 
 
+class ForwardExchange:
+    """Zero-copy variant of ``gather_rows_and_visibility``: the send buffer is laid out once
+    ([band image | visibility flags], bytes); the forward kernel writes both outputs straight into it
+    (``ops.render_forward(out_image=..., out_visible=...)``), so the step issues no packing kernels."""
+
+    def __init__(self, part: RowPartition, n_images: int, channels: int, num_points: int, device):
+        self.part = part
+        self.shape = (n_images, part.band, part.S, channels)
+        self.nb = n_images * part.band * part.S * channels * 4
+        self.P = num_points
+        self.send = torch.zeros(self.nb + num_points, dtype=torch.uint8, device=device)
+        self.recv = torch.empty((part.world_size, self.nb + num_points), dtype=torch.uint8, device=device)
+        rows = part.row1 - part.row0
+        full_band = self.send[:self.nb].view(torch.float32).view(self.shape)
+        self.image = full_band[:, :rows] if rows == part.band else None  # short last band: pack by copy
+        self.visible = self.send[self.nb:]
+
+    def exchange(self, band: Optional[torch.Tensor] = None, group=None):
+        """-> (full image (N,S,S,ch), union of the visibility flags uint8 (P,))."""
+        part = self.part
+        if band is not None and (self.image is None or band.data_ptr() != self.image.data_ptr()):
+            self.send[:self.nb].view(torch.float32).view(self.shape)[:, :band.shape[1]].copy_(band)
+        if dist.get_backend(group) == "gloo":
+            dist.all_gather(list(self.recv.unbind(0)), self.send, group=group)
+        else:
+            dist.all_gather_into_tensor(self.recv, self.send, group=group)
+        n = self.shape[0]
+        bands = self.recv[:, :self.nb].contiguous().view(torch.float32).view((part.world_size,) + self.shape)
+        full = bands.permute(1, 0, 2, 3, 4).reshape((n, part.world_size * part.band) + self.shape[2:])
+        return full[:, :part.S], self.recv[:, self.nb:].max(dim=0).values
+
+
 class GatherRows(torch.autograd.Function):
     """Differentiable ``gather_rows``.  Every rank evaluates the same loss on the same full image, so
     the gradient of the local band is simply its slice of the full-image gradient (no collective)."""

@@ -280,8 +280,11 @@ def blend_backward(grad_out, idx, qvalue, scaler, num_points: int, geometry=None
 def render_forward(world, normals, h, M, V, znear, zfar, cloud_to_packed_first_idx, num_points_per_cloud, features,
                    image_size: int, points_per_pixel: int, cutoff_threshold: float, depth_merging_thres: float,
                    antialiasing_sigma: float = 1.0, backface_culling: bool = False, shared_cloud: bool = False,
-                   rows: Optional[Tuple[int, int]] = None):
-    """Fused forward (setup + binning + fine + blend, ``dss_render_forward``).  ``features`` are the
+                   rows: Optional[Tuple[int, int]] = None, out_image: Optional[torch.Tensor] = None,
+                   out_visible: Optional[torch.Tensor] = None):
+    """Fused forward (setup + binning + fine + blend, ``dss_render_forward``).  ``out_image`` (float32
+    (N,rows,S,C+1), 16-byte aligned) / ``out_visible`` (uint8 (P,)) let the caller place these two outputs
+    in its own buffer (the multi-GPU step points them into one all-gather send buffer).  ``features`` are the
     packed (P,C) features.  Returns a dict with everything the separate calls produce:
     ``pts_screen, ellipse_params, radii, scaler, cutoff_threshold, valid, idx, zbuf, qvalue, occupancy,
     visible, image, wsum``."""
@@ -311,8 +314,12 @@ def render_forward(world, normals, h, M, V, znear, zfar, cloud_to_packed_first_i
     with torch.cuda.device(dev):
         o = dict(pts_screen=e(P, 3), ellipse_params=e(P, 3), radii=e(P, 2), scaler=e(P), cutoff_threshold=e(P),
                  idx=e(N, nr, S, K, dtype=_i32), zbuf=e(N, nr, S, K), qvalue=e(N, nr, S, K), occupancy=e(N, nr, S),
-                 image=e(N, nr, S, C + 1), wsum=e(N, nr, S))
-        valid, vis = e(P, dtype=_u8), e(P, dtype=_u8)
+                 image=e(N, nr, S, C + 1) if out_image is None else out_image, wsum=e(N, nr, S))
+        valid = e(P, dtype=_u8)
+        vis = e(P, dtype=_u8) if out_visible is None else out_visible
+        if tuple(o["image"].shape) != (N, nr, S, C + 1) or o["image"].dtype != _f32 or not o["image"].is_contiguous() \
+                or o["image"].data_ptr() % 16 or tuple(vis.shape) != (P,) or vis.dtype != _u8:
+            raise RuntimeError("out_image must be contiguous float32 (N,rows,S,C+1), 16-byte aligned; out_visible uint8 (P,)")
         ws = _lib.workspace(dev, lib.dss_render_forward_workspace(N, P, S, K))
         rc = lib.dss_render_forward(
             _lib.ptr(world), _lib.ptr(normals), _lib.ptr(h) if per_point else None, None if per_point else _lib.ptr(h),
@@ -330,7 +337,7 @@ def render_forward(world, normals, h, M, V, znear, zfar, cloud_to_packed_first_i
 def render_backward(grad_out, idx, qvalue, wsum, scaler, points, radii, visible, cloud_to_packed_first_idx,
                     num_points_per_cloud, radii_s: float, clip: float = -1.0, with_features: bool = True,
                     return_rs: bool = False, image_size: Optional[int] = None,
-                    rows: Optional[Tuple[int, int]] = None):
+                    rows: Optional[Tuple[int, int]] = None, out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
     """Fused backward of renderer + rasterizer (blend backward + median radius + occupancy backward +
     clip) -> (grad_features (P,C) or None, grad_pts_screen (P,3)).  With ``rows`` (multi-GPU band) pass the
     union of the visibility flags and ``clip <= 0``; the results are the band's partial sums."""
@@ -355,8 +362,14 @@ def render_backward(grad_out, idx, qvalue, wsum, scaler, points, radii, visible,
     if W != S or H != row1 - row0 or tuple(grad_out.shape[:3]) != (N, H, W):
         raise RuntimeError("render_backward needs idx (N,rows,S,K) and grad_out (N,rows,S,C+1)")
     with torch.cuda.device(dev):
-        gf = torch.empty((P, C), dtype=_f32, device=dev) if with_features else None
-        gp = torch.empty((P, 3), dtype=_f32, device=dev)
+        if out is not None:  # caller-provided (P,C) / (P,3) float32 views, e.g. slices of one all-reduce bucket
+            gf, gp = out
+            if tuple(gf.shape) != (P, C) or tuple(gp.shape) != (P, 3) or gf.dtype != _f32 or gp.dtype != _f32 \
+                    or not gf.is_contiguous() or not gp.is_contiguous():
+                raise RuntimeError("out must be contiguous float32 tensors of shape (P,C) and (P,3)")
+        else:
+            gf = torch.empty((P, C), dtype=_f32, device=dev) if with_features else None
+            gp = torch.empty((P, 3), dtype=_f32, device=dev)
         rs = torch.empty((N,), dtype=_f32, device=dev)
         ws = _lib.workspace(dev, lib.dss_render_backward_workspace(N, P))
         rc = lib.dss_render_backward(_lib.ptr(grad_out), _lib.ptr(idx), _lib.ptr(qvalue), _lib.ptr(wsum),

@@ -19,8 +19,8 @@ def _worker(rank, world, port, S, tmp):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle
     import scenes
-    from dss_amd.distributed import (GatherRows, RowPartition, gather_rows_and_visibility, reduce_grads_,
-                                     reduce_visibility_)
+    from dss_amd.distributed import (ForwardExchange, GatherRows, RowPartition, gather_rows_and_visibility,
+                                     reduce_grads_, reduce_visibility_)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -47,6 +47,15 @@ def _worker(rank, world, port, S, tmp):
         assert np.array_equal(vis.numpy().astype(bool), oracle.visibility(idx, P))
         img2, vis2 = gather_rows_and_visibility(torch.from_numpy(full[:, r0:r1].copy()), vis_band.clone(), part)
         assert torch.equal(img2, torch.from_numpy(full)) and torch.equal(vis2, vis)
+        fx = ForwardExchange(part, 2, full.shape[-1], P, "cpu")
+        if fx.image is not None:  # zero-copy path: the producer writes into the send buffer
+            fx.image.copy_(torch.from_numpy(full[:, r0:r1].copy()))
+            fx.visible.copy_(vis_band)
+            img3, vis3 = fx.exchange(fx.image)
+        else:
+            fx.visible.copy_(vis_band)
+            img3, vis3 = fx.exchange(torch.from_numpy(full[:, r0:r1].copy()))
+        assert torch.equal(img3, torch.from_numpy(full)) and torch.equal(vis3, vis)
         rs = oracle.backward_radius(sc["radii"], vis.numpy(), sc["first_idx"], sc["num_pts"], 3.0)
         gocc = g_full[..., 3].numpy()
         masked = np.zeros_like(gocc)
