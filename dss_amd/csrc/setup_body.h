@@ -88,7 +88,13 @@ __device__ __forceinline__ void setup_point(const SetupArgs &A, int64_t p, int n
 #pragma unroll
                 for (int j = 0; j < 2; ++j) Vk[i][j] = WJ[0][i] * T[0][j] + WJ[1][i] * T[1][j] + WJ[2][i] * T[2][j];
             const float detVk = Vk[0][0] * Vk[1][1] - Vk[0][1] * Vk[1][0];
-            const float absdetMk = sqrtf(detVk > 0.0f ? detVk : 0.0f) / hh;
+            // |det(Sk WJk)| = |n^ . (w0 x w1)| (Binet-Cauchy), see oracle_point_setup: well conditioned
+            // for edge-on splats where sqrt(det Vk)/h cancels catastrophically
+            const float cx0 = WJ[1][0] * WJ[2][1] - WJ[2][0] * WJ[1][1];
+            const float cx1 = WJ[2][0] * WJ[0][1] - WJ[0][0] * WJ[2][1];
+            const float cx2 = WJ[0][0] * WJ[1][1] - WJ[1][0] * WJ[0][1];
+            const float absdetMk = nlen > 1e-12f ? fabsf(nn[0] * cx0 + nn[1] * cx1 + nn[2] * cx2) : 0.0f;
+            (void)detVk;
             const float pixel = 2.0f / (float)A.S;
             const float G00 = Vk[0][0] + A.sigma * (pixel * pixel), G11 = Vk[1][1] + A.sigma * (pixel * pixel);
             const float G01 = Vk[0][1], G10 = Vk[1][0];

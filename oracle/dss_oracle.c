@@ -18,7 +18,10 @@
  *   fast occupancy backward UNPINNED restated from DSS/csrc/rasterize_points_backward.cu:30-212 and
  *                                    DSS/core/rasterizer.py:853-888 (CUDA only; cannot run here)
  *   blend fwd/bwd           UNPINNED pytorch3d norm_weighted_sum is not under /root/reference
- *   per-point EWA setup     UNPINNED needs pytorch3d cameras; restated from rasterizer.py:404-565
+ *   per-point EWA setup     PINNED   vs the reference's own Python (rasterizer.py:293-565) run with stubbed
+ *                                    third-party imports (tests/golden/make_golden_setup.py); the projection
+ *                                    itself (pytorch3d cameras) stays unpinned
+ *   visible set / median rs PINNED   vs the Python half of EllipticalRasterizer.backward (rasterizer.py:853-913)
  */
 #define _GNU_SOURCE
 #include <math.h>
@@ -490,7 +493,7 @@ DSS_ORACLE_API void oracle_blend_backward(
  *   source variance (rasterizer.py:293-342): Vrk = h * Sk^T Sk = h * (I - n^ n^^T), n^ = n/|n|
  *       (Sk is a random orthonormal tangent basis; the product is basis independent)
  *   Vk = WJk^T Vrk WJk ; GV = Vk + sigma*I*(2/S)^2            (rasterizer.py:404-441)
- *   |detMk| = |det(Sk @ WJk)| = sqrt(det(Vk))/h  -> we evaluate sqrt(max(det(Vk),0))/h
+ *   |detMk| = |det(Sk @ WJk)| = |n^ . (WJk[:,0] x WJk[:,1])|   (Binet-Cauchy, basis independent)
  *   GVinv = inverse(GV); (a,b,c) = (GVinv00, GVinv01+GVinv10, GVinv11)   (rasterizer.py:541-550)
  *   radii (rasterizer.py:498-523): den = eps_denom(4ac-b^2); rx = sqrt(eps_sqrt(4*c*C/den)),
  *       ry = sqrt(eps_sqrt(4*a*C/den))
@@ -555,7 +558,14 @@ DSS_ORACLE_API void oracle_point_setup(
             for (int j = 0; j < 2; ++j)
                 Vk[i][j] = WJ[0][i] * T[0][j] + WJ[1][i] * T[1][j] + WJ[2][i] * T[2][j];
         const float detVk = Vk[0][0] * Vk[1][1] - Vk[0][1] * Vk[1][0];
-        const float absdetMk = sqrtf(detVk > 0.0f ? detVk : 0.0f) / hh;
+        /* |det(Sk WJk)| (rasterizer.py:430-439 torch.det(Mk)) = |n^ . (w0 x w1)| with w_j = WJk[:, j]
+         * (Binet-Cauchy: det([u0;u1][w0 w1]) = (u0 x u1).(w0 x w1), u0 x u1 = +-n^): basis independent and,
+         * unlike sqrt(det Vk)/h, well conditioned for splats seen edge-on. */
+        const float cx0 = WJ[1][0] * WJ[2][1] - WJ[2][0] * WJ[1][1];
+        const float cx1 = WJ[2][0] * WJ[0][1] - WJ[0][0] * WJ[2][1];
+        const float cx2 = WJ[0][0] * WJ[1][1] - WJ[1][0] * WJ[0][1];
+        const float absdetMk = nlen > 1e-12f ? fabsf(nn[0] * cx0 + nn[1] * cx1 + nn[2] * cx2) : 0.0f;
+        (void)detVk;
         const float G00 = Vk[0][0] + sigma * (pixel * pixel), G11 = Vk[1][1] + sigma * (pixel * pixel);
         const float G01 = Vk[0][1], G10 = Vk[1][0];
         const float detG = G00 * G11 - G01 * G10;

@@ -183,3 +183,22 @@ def test_fused_renderer_matches_unfused(n_cams):
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
     rel = lambda a, b: float((a - b).norm() / b.norm())
     assert rel(res[1][2], res[0][2]) < 1e-5 and rel(res[1][3], res[0][3]) < 1e-5
+
+
+@pytest.mark.parametrize("mode", ["global", "iso"])
+@pytest.mark.parametrize("tag", ["1cam", "3cam"])
+def test_point_setup_matches_reference_python_golden(golden_dir, tag, mode):
+    """HIP per-point setup vs vectors produced by the reference's own Python (make_golden_setup.py)."""
+    import os
+    from test_oracle_pinning import _check_setup_against_reference, _setup_inputs
+    z = np.load(os.path.join(golden_dir, "ref_setup_teapot.npz"))
+    pw, nw, h, cloud_of, M, V = _setup_inputs(z, tag, mode)
+    N, Pc = M.shape[0], len(z["points"])
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    first = torch.arange(N, device=DEV) * Pc
+    num = torch.full((N,), Pc, device=DEV, dtype=torch.int64)
+    out = ops.point_setup(t(pw), t(nw), t(h), t(M), t(V), torch.full((N,), 0.1, device=DEV),
+                          torch.full((N,), 100.0, device=DEV), first, num, int(z["S"]), 1.0, 1.0, False, False)
+    assert out["valid"].all()
+    _check_setup_against_reference(z, tag, mode, out["radii"].cpu().numpy(), out["ellipse_params"].cpu().numpy(),
+                                   out["scaler"].cpu().numpy(), out["cutoff_threshold"].cpu().numpy())
