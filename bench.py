@@ -41,9 +41,8 @@ def bunny_cloud():
     pts, nrm = scenes.load_cloud("bunny")
     pts = scenes.normalize_unit_sphere(pts)
     pts, nrm = scenes.upsample_jitter(pts, nrm, 4, seed=0)
-    h = scenes.global_h(pts)
     col = np.random.default_rng(0).uniform(0, 1, pts.shape).astype(np.float32)
-    return pts, nrm, col, h
+    return pts, nrm, col, None  # h (variance scale) is computed on the GPU by the HIP kNN in Workload
 
 
 class Workload:
@@ -56,6 +55,13 @@ class Workload:
         t = lambda a: torch.from_numpy(a).to(device)
         self.world, self.normals = t(pts), t(nrm)
         self.colors = t(col).repeat(self.N, 1).contiguous()  # packed (N*Pc,3) features of the extended cloud
+        if h is None:
+            # Vrk_invariant scale (rasterizer.py:310-326) from the HIP grid kNN; an input of the step, computed
+            # once outside the timed region (the reference caches it the same way with refresh=False)
+            one = torch.zeros(1, dtype=torch.int64, device=device)
+            cnt = torch.full((1,), self.Pc, dtype=torch.int64, device=device)
+            h = float(ops.cloud_mean_clamp(ops.knn_kth_sqdist(self.world, one, cnt, 7), one, cnt, 0.5, 5e-5, 1e-3,
+                                           0.5e-3, 7).item())
         self.h = torch.full((self.N,), h, device=device)
         R, T = look_at_view_transform(2.0, 30.0, [45.0 + 45.0 * k for k in range(self.N)])
         cam = FoVPerspectiveCameras(znear=0.1, zfar=100.0, fov=60.0, R=R, T=T)
@@ -153,7 +159,8 @@ def cpu_baseline():
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle
     import scenes
-    pts, nrm, col, h = bunny_cloud()
+    pts, nrm, col, _ = bunny_cloud()
+    h = scenes.global_h(pts)
     Sb = 256
     M, V, _ = scenes.camera_matrices(2.0, 30.0, 45.0)
     sc = scenes.setup_scene(pts, nrm, M, V, Sb, h=h)
