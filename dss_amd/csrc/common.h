@@ -70,6 +70,23 @@ __device__ __forceinline__ float dpp_f32(float v)
 {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
 }
+// Same range with only 0.01 px of slack (the fp32 evaluation error of the bounds and of the pixel centres
+// is ~1e-4 px at S = 4096).  Used by the backward gathers: a window that creeps from 30 to 33 columns
+// because of whole-pixel slack falls off the 32-lane tiling and doubles the work.
+__device__ __forceinline__ bool ndc_index_range_tight(float x, float r, int S, int &lo, int &hi)
+{
+    const float flo = ((x - r + 1.0f) * S - 1.0f) * 0.5f;
+    const float fhi = ((x + r + 1.0f) * S - 1.0f) * 0.5f;
+    lo = 0;
+    hi = S - 1;
+    if (flo == flo && fhi == fhi) {  // not NaN
+        if (fhi < -1.0f || flo > (float)S) return false;
+        lo = max(0, (int)ceilf(fmaxf(flo, -1.0f) - 0.01f));
+        hi = min(S - 1, (int)floorf(fminf(fhi, (float)S) + 0.01f));
+    }
+    return lo <= hi;
+}
+
 __device__ __forceinline__ float wave_sum(float v)
 {
     v += dpp_f32<0xB1>(v);   // quad_perm [1,0,3,2]

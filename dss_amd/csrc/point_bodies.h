@@ -39,7 +39,7 @@ __device__ __forceinline__ void occ_point_gather(int lane, int64_t p, int n, con
     // rasterize_points_backward.cu:141-143
     if (pz < 0 || fabsf(py) > 1.0f || fabsf(px) > 1.0f) return;
     int xlo, xhi, ylo, yhi;
-    if (!ndc_index_range(px, cur_r, S, xlo, xhi) || !ndc_index_range(py, cur_r, S, ylo, yhi)) return;
+    if (!ndc_index_range_tight(px, cur_r, S, xlo, xhi) || !ndc_index_range_tight(py, cur_r, S, ylo, yhi)) return;
     // band rows: image row = S-1-yi in [row0, row0+rows)
     ylo = max(ylo, S - row0 - rows);
     yhi = min(yhi, S - 1 - row0);
@@ -108,7 +108,7 @@ __device__ __forceinline__ void blend_point_gather(int lane, int64_t p, int n, c
     const float rx = radii[2 * p], ry = radii[2 * p + 1];
     const float sc = scaler[p];
     int xlo, xhi, ylo, yhi;
-    if (!ndc_index_range(px, rx, S, xlo, xhi) || !ndc_index_range(py, ry, S, ylo, yhi)) return;
+    if (!ndc_index_range_tight(px, rx, S, xlo, xhi) || !ndc_index_range_tight(py, ry, S, ylo, yhi)) return;
     ylo = max(ylo, S - row0 - rows);
     yhi = min(yhi, S - 1 - row0);
     const LaneTiling T(xhi - xlo + 1, lane);
