@@ -432,13 +432,8 @@ __global__ __launch_bounds__(FINE_THREADS) void fine_kernel(const FineArgs A)
             okey[k] = ((unsigned long long)hi << 32) | lo;
             oq[k] = __shfl_xor(kq[k], xo, 64);
         }
-        // partner lists are ascending with the empty slots at the tail: stop at the first slot that is empty
-        // in every lane (typical lists hold 2-3 entries of K)
 #pragma unroll
-        for (int k = 0; k < KMAX; ++k) {
-            if (__ballot(okey[k] != KEY_EMPTY) == 0ull) break;
-            klist_insert<KMAX>(key, kq, okey[k], oq[k]);
-        }
+        for (int k = 0; k < KMAX; ++k) klist_insert<KMAX>(key, kq, okey[k], oq[k]);
     }
 
     FT_MARK(5);
