@@ -307,13 +307,322 @@ __global__ __launch_bounds__(MED_THREADS) void visible_scan_kernel(
     }
 }
 
-template <int C>
+// ---------------------------------------------------------------------------------------------
+// Small-cloud preparation (P <= PREP_MAX_POINTS): TWO launches, no memset, no global atomics, replace
+// memset + visible_scan + median_hist<1> + median_hist<2> + median_final (five launches of pure latency,
+// ~26 us for ~300 KB of traffic at DSS sizes).
+//   backward_compact_kernel  one 1024-thread workgroup per 2048-point chunk of the packed array: compacts the
+//                            chunk's visible ids AND radius keys into the chunk's own segment
+//                            (vis_list / vis_keys [chunk * 2048 + rank], seg_count[chunk]), zero-fills the
+//                            gradients of invisible points and writes the chunk's pass-0 histogram (8-bit
+//                            digit [31:24], per overlapping cloud) with plain stores.
+//   median_visible_kernel    one 1024-thread workgroup per cloud: sums the chunk histograms -> digit 0, then
+//                            selects digits [23:12] and [11:0] over the COMPACTED keys held in registers
+//                            (up to 32 visible points per thread; larger clouds are re-streamed per pass).
+// One CU scanning every packed radius three times (a single-launch variant, measured) took 23-29 us: the
+// wave-instruction issue rate of ONE CU, not memory, is the limit, hence the split: all-points work on many
+// CUs, single-CU work only on the visible ~40 %.
+// Pass-0 histograms are replicated 32x by lane (address = bin * 32 + lane % 32): screen-space radii share one
+// or two exponent bytes and same-address LDS atomics serialise.
+// ---------------------------------------------------------------------------------------------
+#define PREP_THREADS 1024
+#define PREP_CHUNK 2048          // points per compaction segment
+#define PREP_MAX_SEG 64          // segments a wavefront can scan in registers
+#define PREP_MAX_POINTS (PREP_CHUNK * PREP_MAX_SEG)
+#define PREP_RES 32              // visible points per thread resident in registers in the median workgroup
+
+#ifdef DSS_FINE_TIMING
+#define PREP_MARK(slot)                                                                                       \
+    do {                                                                                                      \
+        if (g_occ_timing && threadIdx.x == 0)                                                                 \
+            g_occ_timing[(size_t)blockIdx.x * 12 + (slot)] = (long long)__builtin_amdgcn_s_memrealtime();     \
+    } while (0)
+#else
+#define PREP_MARK(slot)
+#endif
+
+// Wave-wide inclusive scan on the VALU (DPP row shifts + row broadcasts; `__shfl_up` would be six dependent
+// ds_bpermute round trips).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_u32_zero(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
+{
+    v += dpp_u32_zero<0x111, 0xf>(v);  // row_shr:1
+    v += dpp_u32_zero<0x112, 0xf>(v);  // row_shr:2
+    v += dpp_u32_zero<0x114, 0xf>(v);  // row_shr:4
+    v += dpp_u32_zero<0x118, 0xf>(v);  // row_shr:8  -> inclusive scan inside each row of 16
+    v += dpp_u32_zero<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+    v += dpp_u32_zero<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
+// Sum of the 32 lane-replicas of bin (tid >> 2), valid in the lanes with (tid & 3) == 0 (others return 0).
+__device__ __forceinline__ uint32_t replica_sum_256(const uint32_t *lh)
+{
+    int b = threadIdx.x >> 2;
+    const int q = threadIdx.x & 3;
+    asm volatile("" : "+v"(b));  // keep the eight LDS addresses out of the long-lived register set
+    uint32_t v = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v += lh[b * 32 + ((q * 8 + i + b) & 31)];  // rotated by the bin: <= 2-way conflicts
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true);  // quad_perm [1,0,3,2]
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true);  // quad_perm [2,3,0,1]
+    return q == 0 ? v : 0u;
+}
+
+// Rank-k selection by a 1024-thread workgroup: thread owns bins first_bin .. first_bin + 3 with counts h[].
+__device__ __forceinline__ void block_select(const uint32_t (&h)[4], uint32_t first_bin, uint32_t k,
+                                             bool k_is_lower_median, uint32_t *s_w /*[16]*/, uint32_t *s_sel /*[2]*/,
+                                             uint32_t &bin_out, uint32_t &k_out, uint32_t &total_out)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const uint32_t v = (h[0] + h[1]) + (h[2] + h[3]);
+    const uint32_t x = wave_incl_scan(v);
+    __syncthreads();  // s_w / s_sel reuse
+    if (lane == 63) s_w[wid] = x;
+    __syncthreads();
+    uint32_t woff = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < PREP_THREADS / 64; ++w) {
+        const uint32_t c = s_w[w];
+        if (w < wid) woff += c;
+        total += c;
+    }
+    if (k_is_lower_median) k = (total > 0) ? (total - 1) / 2 : 0;  // torch.median = lower median
+    uint32_t excl = woff + x - v;
+    if (total > 0 && k >= excl && k < excl + v) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (k >= excl && k < excl + h[i]) {
+                s_sel[0] = first_bin + i;
+                s_sel[1] = k - excl;
+            }
+            excl += h[i];
+        }
+    }
+    __syncthreads();
+    bin_out = s_sel[0];
+    k_out = s_sel[1];
+    total_out = total;
+}
+
+__global__ __launch_bounds__(PREP_THREADS) void backward_compact_kernel(
+    const float *__restrict__ radii, const uint8_t *__restrict__ visible, const int64_t *__restrict__ first_idx,
+    const int64_t *__restrict__ num_pts, int N, int64_t P, int chunks, uint32_t *__restrict__ seg_count,
+    int32_t *__restrict__ vis_list, uint2 *__restrict__ vis_keys, uint32_t *__restrict__ chunk_hist /*(N,chunks,256)*/,
+    uint2 *__restrict__ seg_range /*(N,chunks)*/, float *__restrict__ grad_pts, float *__restrict__ grad_feat, int C)
+{
+    constexpr int PER = PREP_CHUNK / PREP_THREADS;
+    __shared__ uint32_t lh[256 * 32];
+    __shared__ uint32_t s_w[PER * PREP_THREADS / 64];
+    __shared__ uint32_t s_rng[2];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const unsigned chunk = blockIdx.x;
+    const int64_t c0 = (int64_t)chunk * PREP_CHUNK;
+    const int64_t c1 = min(c0 + PREP_CHUNK, P);
+    PREP_MARK(0);
+    uint8_t vis[PER];
+    uint2 kk[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int64_t i = c0 + tid + (int64_t)u * PREP_THREADS;
+        const bool in = i < c1;
+        vis[u] = in ? visible[i] : (uint8_t)0;
+        const float2 r = in ? reinterpret_cast<const float2 *>(radii)[i] : make_float2(0.f, 0.f);
+        kk[u] = make_uint2(float_key(r.x), float_key(r.y));
+    }
+    for (int i = tid; i < 256 * 32; i += PREP_THREADS) lh[i] = 0;
+    // order-preserving ranks (entries of a segment are sorted by point id, so the entries of one cloud are a
+    // contiguous range of it): rank = visible points before (u, wave, lane) in that order
+    uint32_t rank[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const unsigned long long m = __ballot(vis[u] != 0);
+        rank[u] = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        if (lane == 0) s_w[u * (PREP_THREADS / 64) + wid] = (uint32_t)__popcll(m);
+    }
+    __syncthreads();
+    uint32_t tot = 0;
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        uint32_t before = tot;
+#pragma unroll
+        for (int w = 0; w < PREP_THREADS / 64; ++w) {
+            const uint32_t c = s_w[u * (PREP_THREADS / 64) + w];
+            if (w < wid) before += c;
+            tot += c;
+        }
+        rank[u] += before;
+    }
+    if (tid == 0) seg_count[chunk] = tot;
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int64_t i = c0 + tid + (int64_t)u * PREP_THREADS;
+        if (vis[u]) {
+            vis_list[c0 + rank[u]] = (int32_t)i;
+            vis_keys[c0 + rank[u]] = kk[u];
+        } else if (i < c1 && grad_pts) {
+            grad_pts[3 * i] = 0.0f; grad_pts[3 * i + 1] = 0.0f; grad_pts[3 * i + 2] = 0.0f;
+            if (grad_feat)
+                for (int ch = 0; ch < C; ++ch) grad_feat[(size_t)i * C + ch] = 0.0f;
+        }
+    }
+    // pass-0 histogram of this chunk, one per cloud that overlaps it (normally one)
+    for (int n = 0; n < N; ++n) {
+        const int64_t lo = max(c0, first_idx[n]), hi = min(c1, first_idx[n] + num_pts[n]);
+        if (lo >= hi) continue;  // uniform
+        if (tid < 2) s_rng[tid] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int64_t i = c0 + tid + (int64_t)u * PREP_THREADS;
+            const bool mine = vis[u] && i >= lo && i < hi;
+            const unsigned long long mb = __ballot(vis[u] && i < lo), mi = __ballot(mine);
+            if (lane == 0) {
+                if (mb) atomicAdd(&s_rng[0], (uint32_t)__popcll(mb));
+                if (mi) atomicAdd(&s_rng[1], (uint32_t)__popcll(mi));
+            }
+            if (mine) {
+                atomicAdd(&lh[(kk[u].x >> 24) * 32 + (lane & 31)], 1u);
+                atomicAdd(&lh[(kk[u].y >> 24) * 32 + (lane & 31)], 1u);
+            }
+        }
+        __syncthreads();
+        // where cloud n's entries sit inside this chunk's segment: (first entry, count)
+        if (tid == 0) seg_range[(size_t)n * chunks + chunk] = make_uint2(s_rng[0], s_rng[1]);
+        const uint32_t v = replica_sum_256(lh);
+        if ((tid & 3) == 0) chunk_hist[((size_t)n * chunks + chunk) * 256 + (tid >> 2)] = v;
+        __syncthreads();
+        for (int i = tid; i < 256 * 32; i += PREP_THREADS) lh[i] = 0;
+        __syncthreads();
+    }
+    PREP_MARK(1);
+}
+
+__global__ __launch_bounds__(PREP_THREADS) void median_visible_kernel(
+    const int64_t *__restrict__ first_idx, const int64_t *__restrict__ num_pts, int64_t P, int chunks,
+    const uint2 *__restrict__ seg_range, const uint2 *__restrict__ vis_keys, const uint32_t *__restrict__ chunk_hist,
+    float radii_s, float *__restrict__ rs)
+{
+    __shared__ uint32_t lh[4096];
+    __shared__ uint32_t s_w[PREP_THREADS / 64];
+    __shared__ uint32_t s_sel[2];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int n = blockIdx.x;
+    const int64_t f = first_idx[n];
+    const int64_t cnt = max((int64_t)0, min(num_pts[n], P - f));
+    PREP_MARK(6);
+    if (cnt <= 0) {
+        if (tid == 0) rs[n] = 0.0f;
+        return;
+    }
+    const int c_lo = (int)(f / PREP_CHUNK), c_hi = (int)((f + cnt - 1) / PREP_CHUNK);
+    const int n_c = c_hi - c_lo + 1;  // <= PREP_MAX_SEG
+    // ---- all global loads are issued up front: chunk histograms, segment ranges, then the keys ----
+    const int hb = tid >> 2, hq = tid & 3;
+    uint32_t hv = 0;
+    for (int c = c_lo + hq; c <= c_hi; c += 4) hv += chunk_hist[((size_t)n * chunks + c) * 256 + hb];
+    // entries of cloud n, flattened in units of WAVE SLOTS (64 consecutive entries of one segment): slot g ->
+    // segment with one ballot over the per-lane slot prefix (every wave keeps the table in its lanes)
+    const uint2 rg = lane < n_c ? seg_range[(size_t)n * chunks + c_lo + lane] : make_uint2(0u, 0u);
+    const uint32_t seg_start = rg.x, seg_cnt = rg.y;
+    const uint32_t seg_slots = (seg_cnt + 63u) >> 6;
+    const uint32_t slot_incl = wave_incl_scan(seg_slots);
+    const uint32_t slot_excl = slot_incl - seg_slots;
+    const uint32_t n_slots = (uint32_t)__builtin_amdgcn_readlane((int)slot_incl, 63);
+    constexpr uint32_t WAVES = PREP_THREADS / 64;
+    constexpr uint32_t RES_SLOTS = (uint32_t)PREP_RES * WAVES;  // wave slots resident in registers per round
+    const uint32_t wid = (uint32_t)tid >> 6;
+    uint2 kk[PREP_RES];
+    uint32_t vm = 0;
+    uint32_t resident = 0;
+    auto load_round = [&](uint32_t base) {  // up to 512 wave slots (~32768 visible points)
+        const uint32_t rem = min(n_slots - base, RES_SLOTS);
+        vm = 0;
+#pragma unroll
+        for (int u = 0; u < PREP_RES; ++u) {
+            kk[u] = make_uint2(0u, 0u);
+            if ((uint32_t)u * WAVES < rem) {  // uniform
+                const uint32_t g = base + (uint32_t)u * WAVES + wid;  // wave-uniform
+                if (g < n_slots) {
+                    const int seg = (int)__popcll(__ballot(slot_incl <= g));  // first segment with incl > g
+                    const uint32_t off = (g - (uint32_t)__builtin_amdgcn_readlane((int)slot_excl, seg)) * 64u + lane;
+                    if (off < (uint32_t)__builtin_amdgcn_readlane((int)seg_cnt, seg)) {
+                        kk[u] = vis_keys[(size_t)(c_lo + seg) * PREP_CHUNK +
+                                         (uint32_t)__builtin_amdgcn_readlane((int)seg_start, seg) + off];
+                        vm |= 1u << u;
+                    }
+                }
+            }
+        }
+    };
+    if (n_slots > 0) load_round(0);
+    // ---- digit 0: sum of the chunk histograms (4 partial sums per bin, quad reduce) ----
+    uint32_t prefix, pmask, k, total0;
+    {
+        hv += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hv, 0xB1, 0xf, 0xf, true);
+        hv += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hv, 0x4E, 0xf, 0xf, true);
+        const uint32_t h[4] = {hq == 0 ? hv : 0u, 0u, 0u, 0u};
+        uint32_t bin;
+        block_select(h, (uint32_t)hb, 0u, true, s_w, s_sel, bin, k, total0);
+        prefix = bin << 24;
+        pmask = 0xff000000u;
+    }
+    PREP_MARK(7);
+    if (total0 == 0) {  // nothing visible in this cloud
+        if (tid == 0) rs[n] = 0.0f;
+        return;
+    }
+#pragma unroll
+    for (int pass = 1; pass < 3; ++pass) {
+        for (int i = tid; i < 4096; i += PREP_THREADS) lh[i] = 0;
+        __syncthreads();
+        const int sh = pass == 1 ? 12 : 0;
+        for (uint32_t base = 0; base < n_slots; base += RES_SLOTS) {
+            const uint32_t rem = min(n_slots - base, RES_SLOTS);
+            if (resident != base) {  // uniform; only clouds with more than ~32768 visible points re-stream
+                load_round(base);
+                resident = base;
+            }
+#pragma unroll
+            for (int u = 0; u < PREP_RES; ++u) {
+                if ((uint32_t)u * WAVES < rem) {  // uniform
+                    const uint32_t kx = kk[u].x, ky = kk[u].y;
+                    const bool v = (vm >> u) & 1u;
+                    const bool mx = v && (kx & pmask) == prefix, my = v && (ky & pmask) == prefix;
+                    if (mx || my) {
+                        if (mx) atomicAdd(&lh[(kx >> sh) & 0xfffu], 1u);
+                        if (my) atomicAdd(&lh[(ky >> sh) & 0xfffu], 1u);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        PREP_MARK(6 + 2 * pass);
+        int t4 = tid;
+        asm volatile("" : "+v"(t4));
+        const uint4 q = reinterpret_cast<const uint4 *>(lh)[t4];
+        const uint32_t h[4] = {q.x, q.y, q.z, q.w};
+        uint32_t bin, tot;
+        block_select(h, 4u * tid, k, false, s_w, s_sel, bin, k, tot);
+        prefix |= bin << sh;
+        pmask |= 0xfffu << sh;
+        __syncthreads();  // lh is re-zeroed by the next pass
+        PREP_MARK(7 + 2 * pass);
+    }
+    if (tid == 0) rs[n] = key_float(prefix) * radii_s;
+}
+
+template <int C, bool SEG>
 __global__ __launch_bounds__(256) void render_backward_kernel(
     const float *__restrict__ grad_out, const int32_t *__restrict__ idx, const float *__restrict__ qv,
     const float *__restrict__ wsum, const float *__restrict__ scaler, const float *__restrict__ points,
     const float *__restrict__ radii, const float *__restrict__ rs, const int64_t *__restrict__ first_idx,
     const int64_t *__restrict__ num_pts, const uint32_t *__restrict__ vis_count,
-    const int32_t *__restrict__ vis_list, int N, int S, int K, int Crt, float clip, int row0, int rows,
+    const int32_t *__restrict__ vis_list, int n_seg, int N, int S, int K, int Crt, float clip, int row0, int rows,
     float *__restrict__ grad_feat, float *__restrict__ grad_pts)
 {
     constexpr int CM = (C > 0) ? C : BLEND_MAX_C;
@@ -321,7 +630,22 @@ __global__ __launch_bounds__(256) void render_backward_kernel(
     const int lane = threadIdx.x & 63;
     const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6);
     const uint32_t n_waves = gridDim.x * 4;
-    const uint32_t count = *vis_count;
+    // SEG: vis_count[0..n_seg) are per-segment counts written by backward_compact_kernel (n_seg <= 64): every
+    // wavefront scans them in registers once; a task index t maps to (segment, offset) with one ballot.
+    uint32_t count, seg_excl = 0;  // first task index of segment `lane`
+    if (SEG) {
+        const uint32_t seg_cnt = lane < n_seg ? vis_count[lane] : 0u;
+        uint32_t seg_incl = seg_cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t y = __shfl_up(seg_incl, o, 64);
+            if (lane >= o) seg_incl += y;
+        }
+        count = (uint32_t)__builtin_amdgcn_readlane((int)seg_incl, 63);
+        seg_excl = seg_incl - seg_cnt;
+    } else {
+        count = *vis_count;
+    }
 #ifdef DSS_FINE_TIMING
     long long tm_rt0 = __builtin_amdgcn_s_memrealtime(), tm_occ = 0, tm_blend = 0, tm_pro = 0, tm_tasks = 0;
 #endif
@@ -329,7 +653,16 @@ __global__ __launch_bounds__(256) void render_backward_kernel(
 #ifdef DSS_FINE_TIMING
         const long long tm0 = __builtin_amdgcn_s_memtime();
 #endif
-        const int64_t p = vis_list[t];
+        int64_t p;
+        if (SEG) {
+            // last segment that starts at or before t (starts are non-decreasing over lanes; empty segments
+            // share their successor's start and lose the tie)
+            const int seg = (int)__popcll(__ballot(seg_excl <= t)) - 1;
+            const uint32_t excl = (uint32_t)__builtin_amdgcn_readlane((int)seg_excl, seg);
+            p = vis_list[(size_t)seg * PREP_CHUNK + (t - excl)];
+        } else {
+            p = vis_list[t];
+        }
         const int n = find_cloud(p, first_idx, num_pts, N);
         if (n < 0) continue;
         float gx = 0.0f, gy = 0.0f;
@@ -412,9 +745,46 @@ __global__ __launch_bounds__(256) void clip_grad_kernel(float *__restrict__ grad
 
 using namespace dss;
 
+// Workspace of the two-launch preparation (P <= PREP_MAX_POINTS), relative to its own base.
+struct PrepLayout {
+    size_t seg_count, vis_list, vis_keys, chunk_hist, seg_range, rs, bytes;
+    int chunks;
+};
+static PrepLayout prep_layout(int N, int64_t P)
+{
+    PrepLayout L;
+    const size_t n = N > 0 ? N : 1, p = P > 0 ? (size_t)P : 1;
+    L.chunks = (int)((p + PREP_CHUNK - 1) / PREP_CHUNK);
+    size_t off = 0;
+    L.seg_count = off;  off += 256;                                              // PREP_MAX_SEG counters
+    L.vis_list = off;   off += align_up(p * 4, 256);
+    L.vis_keys = off;   off += align_up(p * 8, 256);
+    L.chunk_hist = off; off += align_up(n * (size_t)L.chunks * 256 * 4, 256);
+    L.seg_range = off;  off += align_up(n * (size_t)L.chunks * 8, 256);
+    L.rs = off;         off += align_up(n * 4, 256);
+    L.bytes = off;
+    return L;
+}
+
+static void launch_prep(const float *radii, const uint8_t *visible, const int64_t *first_idx, const int64_t *num_pts,
+                        int N, int64_t P, float radii_s, float *rs, char *w, const PrepLayout &L, float *grad_pts,
+                        float *grad_feat, int C, hipStream_t st)
+{
+    uint32_t *seg_count = reinterpret_cast<uint32_t *>(w + L.seg_count);
+    int32_t *vis_list = reinterpret_cast<int32_t *>(w + L.vis_list);
+    uint2 *vis_keys = reinterpret_cast<uint2 *>(w + L.vis_keys);
+    uint32_t *chunk_hist = reinterpret_cast<uint32_t *>(w + L.chunk_hist);
+    uint2 *seg_range = reinterpret_cast<uint2 *>(w + L.seg_range);
+    hipLaunchKernelGGL(backward_compact_kernel, dim3(L.chunks), dim3(PREP_THREADS), 0, st, radii, visible, first_idx,
+                       num_pts, N, P, L.chunks, seg_count, vis_list, vis_keys, chunk_hist, seg_range, grad_pts, grad_feat,
+                       C);
+    hipLaunchKernelGGL(median_visible_kernel, dim3(N), dim3(PREP_THREADS), 0, st, first_idx, num_pts, P, L.chunks,
+                       seg_range, vis_keys, chunk_hist, radii_s, rs);
+}
+
 extern "C" size_t dss_backward_radius_workspace(int N, int64_t P)
 {
-    (void)P;
+    if (P <= PREP_MAX_POINTS) return prep_layout(N, P).bytes;
     return align_up((size_t)3 * (N > 0 ? N : 1) * MED_BINS * sizeof(uint32_t), 256);
 }
 
@@ -433,6 +803,14 @@ extern "C" int dss_backward_radius(const float *radii, const uint8_t *visible, c
     }
     hipStream_t st = as_stream(stream);
     uint32_t *hist = reinterpret_cast<uint32_t *>(workspace);
+    if (P <= PREP_MAX_POINTS) {
+        if (P > 0)
+            launch_prep(radii, visible, first_idx, num_pts, N, P, radii_s, rs, reinterpret_cast<char *>(workspace),
+                        prep_layout(N, P), nullptr, nullptr, 0, st);
+        else
+            (void)hipMemsetAsync(rs, 0, (size_t)N * 4, st);
+        return check_launch("dss_backward_radius");
+    }
     if (hipMemsetAsync(hist, 0, need, st) != hipSuccess) return check_launch("memset median hist");
     const unsigned blocks = (unsigned)((P + MED_PTS_PER_WG - 1) / MED_PTS_PER_WG);
     if (blocks > 0) {
@@ -538,6 +916,7 @@ extern "C" int dss_splat_backward(const float *points, const float *radii, const
 extern "C" size_t dss_render_backward_workspace(int N, int64_t P)
 {
     const int n = N > 0 ? N : 1;
+    if (P <= PREP_MAX_POINTS) return prep_layout(N, P).bytes;
     return align_up((size_t)3 * n * MED_BINS * 4 + 256, 256)  // histograms + visible counter
            + align_up((size_t)(P > 0 ? P : 1) * 4, 256)       // compacted visible list
            + align_up((size_t)n * 4, 256);                    // rs
@@ -568,22 +947,36 @@ extern "C" int dss_render_backward(const float *grad_out, const int32_t *idx, co
     }
     hipStream_t st = as_stream(stream);
     char *w = reinterpret_cast<char *>(workspace);
-    const size_t hist_bytes = (size_t)3 * N * MED_BINS * 4;
-    uint32_t *hist = reinterpret_cast<uint32_t *>(w);
-    uint32_t *vis_count = reinterpret_cast<uint32_t *>(w + hist_bytes);
-    size_t off = align_up(hist_bytes + 256, 256);
-    int32_t *vis_list = reinterpret_cast<int32_t *>(w + off);
-    off += align_up((size_t)P * 4, 256);
-    float *rs = rs_out ? rs_out : reinterpret_cast<float *>(w + off);
-    if (hipMemsetAsync(hist, 0, hist_bytes + 256, st) != hipSuccess) return check_launch("memset render_backward");
-    const unsigned blocks = (unsigned)((P + MED_PTS_PER_WG - 1) / MED_PTS_PER_WG);
-    hipLaunchKernelGGL(visible_scan_kernel, dim3(blocks), dim3(MED_THREADS), 0, st, radii, visible, first_idx, num_pts,
-                       N, P, hist, vis_count, vis_list, grad_pts, grad_feat, C);
-    hipLaunchKernelGGL(median_hist_kernel<1>, dim3(blocks), dim3(MED_THREADS), 0, st, radii, visible, first_idx,
-                       num_pts, N, P, hist);
-    hipLaunchKernelGGL(median_hist_kernel<2>, dim3(blocks), dim3(MED_THREADS), 0, st, radii, visible, first_idx,
-                       num_pts, N, P, hist);
-    hipLaunchKernelGGL(median_final_kernel, dim3(N), dim3(MED_THREADS), 0, st, hist, N, radii_s, rs);
+    const bool small = P <= PREP_MAX_POINTS;
+    int n_seg = 0;
+    uint32_t *vis_count;  // small: PREP_MAX_SEG per-segment counters; otherwise one global counter
+    int32_t *vis_list;
+    float *rs;
+    if (small) {
+        const PrepLayout L = prep_layout(N, P);
+        n_seg = L.chunks;
+        vis_count = reinterpret_cast<uint32_t *>(w + L.seg_count);
+        vis_list = reinterpret_cast<int32_t *>(w + L.vis_list);
+        rs = rs_out ? rs_out : reinterpret_cast<float *>(w + L.rs);
+        launch_prep(radii, visible, first_idx, num_pts, N, P, radii_s, rs, w, L, grad_pts, grad_feat, C, st);
+    } else {
+        const size_t hist_bytes = (size_t)3 * N * MED_BINS * 4;
+        uint32_t *hist = reinterpret_cast<uint32_t *>(w);
+        vis_count = reinterpret_cast<uint32_t *>(w + hist_bytes);
+        size_t off = align_up(hist_bytes + 256, 256);
+        vis_list = reinterpret_cast<int32_t *>(w + off);
+        off += align_up((size_t)P * 4, 256);
+        rs = rs_out ? rs_out : reinterpret_cast<float *>(w + off);
+        if (hipMemsetAsync(hist, 0, hist_bytes + 256, st) != hipSuccess) return check_launch("memset render_backward");
+        const unsigned blocks = (unsigned)((P + MED_PTS_PER_WG - 1) / MED_PTS_PER_WG);
+        hipLaunchKernelGGL(visible_scan_kernel, dim3(blocks), dim3(MED_THREADS), 0, st, radii, visible, first_idx,
+                           num_pts, N, P, hist, vis_count, vis_list, grad_pts, grad_feat, C);
+        hipLaunchKernelGGL(median_hist_kernel<1>, dim3(blocks), dim3(MED_THREADS), 0, st, radii, visible, first_idx,
+                           num_pts, N, P, hist);
+        hipLaunchKernelGGL(median_hist_kernel<2>, dim3(blocks), dim3(MED_THREADS), 0, st, radii, visible, first_idx,
+                           num_pts, N, P, hist);
+        hipLaunchKernelGGL(median_final_kernel, dim3(N), dim3(MED_THREADS), 0, st, hist, N, radii_s, rs);
+    }
     // persistent grid = exactly the resident capacity of the chip for this kernel (a larger grid would
     // leave late workgroups waiting for slots while their share of the list sits idle)
     static int cap3 = 0, cap0 = 0;  // benign race: every thread computes the same value
@@ -594,22 +987,24 @@ extern "C" int dss_render_backward(const float *grad_out, const int32_t *idx, co
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
             cus = prop.multiProcessorCount;
         if (C == 3)
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_backward_kernel<3>, 256, 0);
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_backward_kernel<3, true>, 256, 0);
         else
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_backward_kernel<0>, 256, 0);
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_backward_kernel<0, true>, 256, 0);
         if (per_cu < 1) per_cu = 1;
         cap = cus * per_cu;
         (void)hipGetLastError();
     }
     const unsigned pgrid = (unsigned)((P + 3) / 4 < cap ? (P + 3) / 4 : cap);
-    if (C == 3)
-        hipLaunchKernelGGL(render_backward_kernel<3>, dim3(pgrid), dim3(256), 0, st, grad_out, idx, qvalue, wsum, scaler,
-                           points, radii, rs, first_idx, num_pts, vis_count, vis_list, N, S, K, C, clip, row0, row1 - row0,
-                           grad_feat, grad_pts);
-    else
-        hipLaunchKernelGGL(render_backward_kernel<0>, dim3(pgrid), dim3(256), 0, st, grad_out, idx, qvalue, wsum, scaler,
-                           points, radii, rs, first_idx, num_pts, vis_count, vis_list, N, S, K, C, clip, row0, row1 - row0,
-                           grad_feat, grad_pts);
+#define DSS_LAUNCH_RB(CC, SS)                                                                                          \
+    hipLaunchKernelGGL((render_backward_kernel<CC, SS>), dim3(pgrid), dim3(256), 0, st, grad_out, idx, qvalue, wsum,   \
+                       scaler, points, radii, rs, first_idx, num_pts, vis_count, vis_list, n_seg, N, S, K, C, clip,    \
+                       row0, row1 - row0, grad_feat, grad_pts)
+    if (C == 3) {
+        if (small) DSS_LAUNCH_RB(3, true); else DSS_LAUNCH_RB(3, false);
+    } else {
+        if (small) DSS_LAUNCH_RB(0, true); else DSS_LAUNCH_RB(0, false);
+    }
+#undef DSS_LAUNCH_RB
     return check_launch("dss_render_backward");
 }
 

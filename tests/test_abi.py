@@ -43,7 +43,8 @@ def test_workspace_query():
     lib = _lib.load()
     assert lib.dss_splat_forward_workspace(1, 32684, 512, 5, 0) == 256
     assert lib.dss_splat_forward_workspace(1, 32684, 512, 5, 32) > 32684 * 8 * 4
-    assert lib.dss_splat_backward_workspace(8, 1000) >= 3 * 8 * 2048 * 4
+    assert lib.dss_splat_backward_workspace(8, 1000) >= 1000 * 12          # compacted ids + keys (small clouds)
+    assert lib.dss_splat_backward_workspace(8, 1 << 20) >= 3 * 8 * 2048 * 4  # radix-select histograms
 
 
 def test_no_cpu_fallback():
@@ -73,7 +74,7 @@ def test_hot_kernels_do_not_spill_to_scratch():
         pytest.skip("hipcc not available")
     hot = ["fine_kernelILi%dE" % k for k in (1, 2, 3, 4, 5, 8)] + [
         "render_backward_kernelILi3E", "occ_backward_kernel", "blend_backward_kernelILi3E", "setup_bin_kernel",
-        "bin_kernel", "visible_scan_kernel", "median_hist_kernel", "point_setup_kernel", "project_backward_kernel",
+        "bin_kernel", "visible_scan_kernel", "median_hist_kernel", "backward_compact_kernel", "median_visible_kernel", "point_setup_kernel", "project_backward_kernel",
         "blend_forward_kernelILi3E"]
     seen = {}
     for src in ("raster_forward.hip", "raster_backward.hip", "blend.hip", "setup.hip"):

@@ -384,3 +384,58 @@ def test_render_backward_row_bands_sum_to_full():
                                          d["num"], 4.0, -1.0, image_size=96, rows=(a, b)))
     assert _rel_l2((parts[0][1] + parts[1][1]).cpu().numpy(), g.cpu().numpy()) <= 1e-5
     assert _rel_l2((parts[0][0] + parts[1][0]).cpu().numpy(), gf.cpu().numpy()) <= 1e-5
+
+
+@pytest.mark.parametrize("sizes,frac,dist", [
+    ((0,), 0.5, "lognormal"),               # empty cloud
+    ((1,), 1.0, "lognormal"),               # single point, two radii
+    ((777, 0, 3001), 0.3, "lognormal"),     # ragged, one empty cloud
+    ((32768,), 0.4, "lognormal"),           # exactly the register-resident capacity of the median workgroup
+    ((32769, 5), 0.4, "equal"),             # one past it (second streaming chunk), all radii equal
+    ((100000, 31072), 0.25, "lognormal"),   # 131072 points = upper edge of the single-launch path (64 segments)
+    ((120000, 11000), 0.9, "lognormal"),    # > 32768 visible points in one cloud: keys re-streamed per pass
+    ((131073,), 0.25, "wide"),              # one past it: multi-kernel radix select
+    ((4096, 4096), 0.0, "lognormal"),       # nothing visible: rs = 0
+])
+def test_backward_radius_and_compaction_sizes(sizes, frac, dist):
+    """Median radius (rasterizer.py:885-888) through BOTH device paths (single-launch register/LDS radix select
+    for P <= 131072, multi-kernel select above) against the oracle, bit for bit, at their size boundaries; and
+    the fused backward's compaction (every visible point gets a gradient row, every invisible one zeros)."""
+    rng = np.random.default_rng(sum(sizes) + len(sizes))
+    P = int(sum(sizes))
+    if dist == "lognormal":
+        radii = np.exp(rng.normal(-4.0, 0.7, size=(P, 2))).astype(np.float32)
+    elif dist == "equal":
+        radii = np.full((P, 2), 0.0123, np.float32)
+    else:
+        radii = (10.0 ** rng.uniform(-30, 30, size=(P, 2))).astype(np.float32)
+    vis = (rng.random(P) < frac).astype(np.uint8)
+    num = np.asarray(sizes, np.int64)
+    first = np.concatenate([[0], np.cumsum(num)[:-1]]).astype(np.int64)
+    o_rs = oracle.backward_radius(radii, vis, first, num, 2.5)
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    if P > 0:
+        rs = ops.backward_radius(t(radii), t(vis), t(first), t(num), 2.5)
+        assert np.array_equal(rs.cpu().numpy(), o_rs), (rs.cpu().numpy(), o_rs)
+    # fused backward on an empty image gradient: checks rs again plus the compaction bookkeeping
+    S, K, N = 16, 2, len(sizes)
+    if P == 0:
+        return
+    pts = np.zeros((P, 3), np.float32)
+    pts[:, :2] = rng.uniform(-0.9, 0.9, size=(P, 2))
+    pts[:, 2] = 1.0
+    grad_out = np.zeros((N, S, S, 4), np.float32)
+    grad_out[..., 3] = 1.0
+    idx = torch.full((N, S, S, K), -1, dtype=torch.int32, device=DEV)
+    qv = torch.zeros((N, S, S, K), device=DEV)
+    wsum = torch.ones((N, S, S), device=DEV)
+    scaler = torch.ones(P, device=DEV)
+    small_r = np.minimum(radii, 0.05).astype(np.float32)
+    o_rs2 = oracle.backward_radius(small_r, vis, first, num, 2.5)
+    gf, g, rs2 = ops.render_backward(t(grad_out), idx, qv, wsum, scaler, t(pts), t(small_r), t(vis), t(first), t(num),
+                                     2.5, 0.0, return_rs=True)
+    assert np.array_equal(rs2.cpu().numpy(), o_rs2)
+    o_g = oracle.occ_backward_fast(pts, small_r, vis, o_rs2, grad_out[..., 3].copy(), first, num)
+    gn = g.cpu().numpy()
+    assert (gn[vis == 0] == 0).all() and (gf.cpu().numpy()[vis == 0] == 0).all()
+    assert _rel_l2(gn[:, :2], o_g) <= 1e-5
