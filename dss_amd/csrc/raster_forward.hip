@@ -30,6 +30,20 @@ namespace dss {
 // tile as overflowed.
 #define DSS_SUB 8
 
+// Heavy-first dispatch.  The fine kernel's duration is set by its slowest workgroups (the densest tiles run
+// 2-3x longer than the mean, tools/fine_timing.py) and a launch needs two occupancy rounds at 512^2, so a
+// dense tile that is dispatched late ends the kernel late.  While binning, the thread that brings sub-list 0
+// of a tile to DSS_HEAVY_SUB0 entries (~8x that in the whole tile) appends the tile to a short queue and
+// flags it; the fine kernel's first DSS_HEAVY_MAX workgroups serve the queue, the others skip flagged
+// tiles.  Queue counter and flags live in the memset region of the tile counters.
+#define DSS_HEAVY_MAX 2048
+#define DSS_HEAVY_SUB0 4
+struct HeavyQ {
+    uint32_t *count;  // 1 word, zeroed with the tile counters
+    int32_t *list;    // DSS_HEAVY_MAX tile ids
+    uint8_t *flag;    // one byte per tile, zeroed with the tile counters
+};
+
 struct TileGrid {
     int S;        // image side
     int row0;     // first image row of the band
@@ -69,10 +83,21 @@ __device__ __forceinline__ bool splat_tile_rect(float px, float py, float pz, fl
     return true;
 }
 
+// exactly one thread per tile gets here (the one whose atomic brought sub-list 0 to the threshold)
+__device__ __forceinline__ void mark_heavy(const HeavyQ hq, int tile)
+{
+    if (!hq.count) return;
+    const uint32_t slot = atomicAdd(hq.count, 1u);
+    if (slot < DSS_HEAVY_MAX) {
+        hq.list[slot] = tile;
+        hq.flag[tile] = 1;  // only queued tiles are flagged: a full queue leaves the rest to the normal workgroups
+    }
+}
+
 // append splat p to the sub-list (p mod SUB) of every tile of its rectangle
 __device__ __forceinline__ void bin_point(int64_t p, int n, float px, float py, float pz, float rx, float ry,
                                           const TileGrid g, uint32_t *__restrict__ counts,
-                                          int32_t *__restrict__ lists, uint32_t cap)
+                                          int32_t *__restrict__ lists, uint32_t cap, const HeavyQ hq)
 {
     if (n < 0) return;
     int tx0, tx1, ty0, ty1;
@@ -93,6 +118,12 @@ __device__ __forceinline__ void bin_point(int64_t p, int n, float px, float py, 
         if (hx && p1 < cap) lists[t01 * cap + p1] = (int32_t)p;
         if (hy && p2 < cap) lists[t10 * cap + p2] = (int32_t)p;
         if (hx && hy && p3 < cap) lists[t11 * cap + p3] = (int32_t)p;
+        if (((unsigned)p & (DSS_SUB - 1)) == 0) {  // sub-list 0 decides
+            if (p0 == DSS_HEAVY_SUB0 - 1) mark_heavy(hq, (int)(t00 / DSS_SUB));
+            if (hx && p1 == DSS_HEAVY_SUB0 - 1) mark_heavy(hq, (int)(t01 / DSS_SUB));
+            if (hy && p2 == DSS_HEAVY_SUB0 - 1) mark_heavy(hq, (int)(t10 / DSS_SUB));
+            if (hx && hy && p3 == DSS_HEAVY_SUB0 - 1) mark_heavy(hq, (int)(t11 / DSS_SUB));
+        }
         return;
     }
     for (int ty = ty0; ty <= ty1; ++ty)
@@ -100,13 +131,14 @@ __device__ __forceinline__ void bin_point(int64_t p, int n, float px, float py, 
             const size_t t = sub0 + (size_t)(ty * g.tiles_x + tx) * DSS_SUB;
             const uint32_t pos = atomicAdd(&counts[t], 1u);
             if (pos < cap) lists[t * cap + pos] = (int32_t)p;
+            if (((unsigned)p & (DSS_SUB - 1)) == 0 && pos == DSS_HEAVY_SUB0 - 1) mark_heavy(hq, (int)(t / DSS_SUB));
         }
 }
 
 __global__ __launch_bounds__(256) void bin_kernel(
     const float *__restrict__ points, const float *__restrict__ radii,
     const int64_t *__restrict__ first_idx, const int64_t *__restrict__ num_pts, int N, int64_t P,
-    TileGrid g, uint32_t *__restrict__ counts, int32_t *__restrict__ lists, uint32_t cap,
+    TileGrid g, uint32_t *__restrict__ counts, int32_t *__restrict__ lists, uint32_t cap, HeavyQ hq,
     uint8_t *__restrict__ visible_to_clear /* (P) or nullptr */)
 {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -114,13 +146,13 @@ __global__ __launch_bounds__(256) void bin_kernel(
     if (visible_to_clear) visible_to_clear[p] = 0;  // saves a separate memset launch
     const int n = find_cloud(p, first_idx, num_pts, N);
     bin_point(p, n, points[3 * p], points[3 * p + 1], points[3 * p + 2], radii[2 * p], radii[2 * p + 1], g, counts,
-              lists, cap);
+              lists, cap, hq);
 }
 
 // dss_render_forward: per-point setup (culling + projection + EWA terms) fused with the binning --
 // the screen record goes from registers straight into the tile lists.
 __global__ __launch_bounds__(256) void setup_bin_kernel(const SetupArgs A, TileGrid g, uint32_t *__restrict__ counts,
-                                                        int32_t *__restrict__ lists, uint32_t cap,
+                                                        int32_t *__restrict__ lists, uint32_t cap, HeavyQ hq,
                                                         uint8_t *__restrict__ visible_to_clear)
 {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -129,7 +161,7 @@ __global__ __launch_bounds__(256) void setup_bin_kernel(const SetupArgs A, TileG
     const int n = find_cloud(p, A.first_idx, A.num_pts, A.N);
     float px, py, pz, rx, ry;
     setup_point(A, p, n, px, py, pz, rx, ry);
-    bin_point(p, n, px, py, pz, rx, ry, g, counts, lists, cap);
+    bin_point(p, n, px, py, pz, rx, ry, g, counts, lists, cap, hq);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -142,6 +174,7 @@ struct FineArgs {
     const uint32_t *counts;    // (N*tiles*DSS_SUB) sub-list fill counts, or nullptr (naive mode)
     const int32_t *lists;      // (N*tiles*DSS_SUB*cap)
     uint32_t cap;              // sub-list capacity
+    HeavyQ heavy;              // heavy-first queue (count == nullptr: identity order)
     int32_t *idx;
     float *zbuf, *qv, *occ;
     uint8_t *visible;
@@ -271,7 +304,7 @@ __device__ __forceinline__ void klist_insert(unsigned long long (&key)[KMAX], fl
 #define CHUNK FINE_THREADS
 
 template <int KMAX>
-__global__ __launch_bounds__(FINE_THREADS) void fine_kernel(const FineArgs A)
+__device__ __forceinline__ void fine_tile(const FineArgs &A, const int tile_id)
 {
     // candidate chunk: three records per splat -> 2x ds_read_b128 + 1x ds_read_b64 per test
     __shared__ float4 s_geo[CHUNK];   // px, py, rx, ry
@@ -285,8 +318,6 @@ __global__ __launch_bounds__(FINE_THREADS) void fine_kernel(const FineArgs A)
     FT_VAL(8, __builtin_amdgcn_s_memrealtime());
     const TileGrid g = A.g;
     const int tiles = g.tiles_x * g.tiles_y;
-    const int tile_id = xcd_tile(blockIdx.x, A.N * tiles);
-    if (tile_id < 0) return;
     const int n = tile_id / tiles;
     const int t = tile_id - n * tiles;
     const int ty = t / g.tiles_x, tx = t - ty * g.tiles_x;
@@ -546,6 +577,31 @@ __global__ __launch_bounds__(FINE_THREADS) void fine_kernel(const FineArgs A)
     FT_VAL(9, __builtin_amdgcn_s_memrealtime());
 }
 
+// Binned mode: grid = DSS_HEAVY_MAX + tiles.  The first workgroups (dispatched first) take the queued dense
+// tiles, the others their own tile unless it is flagged as queued.  One workgroup per tile on purpose: the
+// hardware dispatcher is the dynamic scheduler.  Both persistent variants were measured and are slower at
+// 512^2 (36 us -> 54 us with a static snake schedule: a workgroup that draws two dense tiles ends the kernel;
+// +38 us with an atomic work counter: ~4600 same-address atomics).
+template <int KMAX>
+__global__ __launch_bounds__(FINE_THREADS) void fine_kernel(const FineArgs A)
+{
+    const int total = A.N * A.g.tiles_x * A.g.tiles_y;
+    int tile_id;
+    if (A.heavy.count != nullptr) {
+        if (blockIdx.x < DSS_HEAVY_MAX) {
+            if (blockIdx.x >= min(*A.heavy.count, (uint32_t)DSS_HEAVY_MAX)) return;
+            tile_id = A.heavy.list[blockIdx.x];
+        } else {
+            tile_id = xcd_tile(blockIdx.x - DSS_HEAVY_MAX, total);
+            if (tile_id < 0 || A.heavy.flag[tile_id]) return;
+        }
+    } else {
+        tile_id = xcd_tile(blockIdx.x, total);
+        if (tile_id < 0) return;
+    }
+    fine_tile<KMAX>(A, tile_id);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Generic-K path for DSS_MAX_K_FAST < K <= kMaxPointsPerPixel (=150, rasterization_utils.cuh:18):
 // one wavefront per 8x8 tile, one lane per pixel, the K-list lives in scratch memory (like the
@@ -622,7 +678,8 @@ __global__ __launch_bounds__(64) void fine_generic_kernel(const FineArgs A)
 template <int KMAX>
 static void launch_fine(const FineArgs &A, int blocks, hipStream_t st)
 {
-    hipLaunchKernelGGL(fine_kernel<KMAX>, dim3(blocks), dim3(FINE_THREADS), 0, st, A);
+    const int grid = blocks + (A.heavy.count ? DSS_HEAVY_MAX : 0);
+    hipLaunchKernelGGL(fine_kernel<KMAX>, dim3(grid), dim3(FINE_THREADS), 0, st, A);
 }
 
 static bool dispatch_fine(const FineArgs &A, int blocks, hipStream_t st)
@@ -655,7 +712,8 @@ struct FwdWorkspace {
     uint32_t *counts;  // N*tiles*SUB
     int32_t *lists;    // N*tiles*SUB*cap
     uint32_t cap;
-    size_t count_bytes;
+    HeavyQ heavy;
+    size_t count_bytes;  // bytes to zero before binning: tile counters + heavy flags + queue counter
     size_t bytes;
 };
 
@@ -676,10 +734,15 @@ static FwdWorkspace carve_fwd(void *ws, int N, int64_t P, int S)
     const size_t tiles_max = (size_t)N * ((S + DSS_TILE - 1) / DSS_TILE) * ((S + DSS_TILE - 1) / DSS_TILE);
     char *p = reinterpret_cast<char *>(ws);
     w.cap = bin_capacity(N, P, S);
-    w.count_bytes = align_up(tiles_max * DSS_SUB * 4, 256);
+    const size_t cbytes = align_up(tiles_max * DSS_SUB * 4, 256), fbytes = align_up(tiles_max, 256);
+    w.count_bytes = cbytes + fbytes + 256;
     w.counts = reinterpret_cast<uint32_t *>(p);
-    w.lists = reinterpret_cast<int32_t *>(p + w.count_bytes);
-    w.bytes = w.count_bytes + align_up(tiles_max * DSS_SUB * (size_t)w.cap * 4, 256);
+    w.heavy.flag = reinterpret_cast<uint8_t *>(p + cbytes);
+    w.heavy.count = reinterpret_cast<uint32_t *>(p + cbytes + fbytes);
+    w.heavy.list = reinterpret_cast<int32_t *>(p + w.count_bytes);
+    const size_t lists_off = w.count_bytes + align_up((size_t)DSS_HEAVY_MAX * 4, 256);
+    w.lists = reinterpret_cast<int32_t *>(p + lists_off);
+    w.bytes = lists_off + align_up(tiles_max * DSS_SUB * (size_t)w.cap * 4, 256);
     return w;
 }
 
@@ -747,11 +810,10 @@ static int splat_bin_impl(const float *points, const float *radii, const int64_t
     const int tiles = g.tiles_x * g.tiles_y;
     if ((long long)N * tiles > 0x7fffffffll) { set_error("dss_splat_bin: too many tiles"); return DSS_ERR_UNSUPPORTED; }
     FwdWorkspace w = carve_fwd(workspace, N, P, S);
-    if (hipMemsetAsync(w.counts, 0, (size_t)N * tiles * DSS_SUB * 4, st) != hipSuccess)
-        return check_launch("memset tile counts");
+    if (hipMemsetAsync(w.counts, 0, w.count_bytes, st) != hipSuccess) return check_launch("memset tile counts");
     const int pb = (int)((P + 255) / 256);
     hipLaunchKernelGGL(bin_kernel, dim3(pb), dim3(256), 0, st, points, radii, first_idx, num_pts, N, P, g, w.counts,
-                       w.lists, w.cap, visible_to_clear);
+                       w.lists, w.cap, w.heavy, visible_to_clear);
     return check_launch("dss_splat_bin");
 }
 
@@ -783,6 +845,7 @@ static int splat_fine_impl(const float *points, const float *ellipse, const floa
     A.points = points; A.ellipse = ellipse; A.cutoff = cutoff; A.radii = radii;
     A.first_idx = first_idx; A.num_pts = num_pts;
     A.counts = nullptr; A.lists = nullptr; A.cap = 0;
+    A.heavy.count = nullptr; A.heavy.list = nullptr; A.heavy.flag = nullptr;
     A.idx = idx; A.zbuf = zbuf; A.qv = qvalue; A.occ = occ; A.visible = visible;
     A.g = g; A.N = N; A.K = K; A.thr = merge_thr;
     A.scaler = scaler; A.feat = feat; A.image = image; A.wsum = wsum; A.C = C;
@@ -792,7 +855,7 @@ static int splat_fine_impl(const float *points, const float *ellipse, const floa
             return DSS_ERR_WORKSPACE;
         }
         FwdWorkspace w = carve_fwd(const_cast<void *>(workspace), N, P, S);
-        A.counts = w.counts; A.lists = w.lists; A.cap = w.cap;
+        A.counts = w.counts; A.lists = w.lists; A.cap = w.cap; A.heavy = w.heavy;
     }
     if (!dispatch_fine(A, (int)blocks_ll, as_stream(stream))) {
         set_error("dss_splat_fine: no kernel for K=%d", K);
@@ -900,20 +963,21 @@ extern "C" int dss_render_forward(const float *world, const float *normals, cons
     const int tiles = g.tiles_x * g.tiles_y;
     if ((long long)N * tiles > 0x7fffffffll) { set_error("dss_render_forward: too many tiles"); return DSS_ERR_UNSUPPORTED; }
     FwdWorkspace w = carve_fwd(workspace, N, P, S);
-    if (hipMemsetAsync(w.counts, 0, (size_t)N * tiles * DSS_SUB * 4, st) != hipSuccess)
-        return check_launch("memset tile counts");
+    if (hipMemsetAsync(w.counts, 0, w.count_bytes, st) != hipSuccess) return check_launch("memset tile counts");
     SetupArgs SA;
     SA.world = world; SA.normals = normals; SA.h_point = h_point; SA.h_cloud = h_cloud; SA.M = M; SA.V = V;
     SA.znear = znear; SA.zfar = zfar; SA.first_idx = first_idx; SA.num_pts = num_pts; SA.N = N; SA.P = P;
     SA.shared = shared_cloud; SA.backface = backface_culling; SA.S = S; SA.cutoffC = cutoff_threshold;
     SA.sigma = antialiasing_sigma; SA.screen = pts_screen; SA.ellipse = ellipse; SA.radii = radii; SA.scaler = scaler;
     SA.cutoff = cutoff; SA.valid = valid;
-    const int pb = (int)((P + 255) / 256);
-    hipLaunchKernelGGL(setup_bin_kernel, dim3(pb), dim3(256), 0, st, SA, g, w.counts, w.lists, w.cap, visible);
+    // one wave per workgroup: at DSS sizes (tens of thousands of points) 256-thread groups would occupy only
+    // half of the CUs with one wave per SIMD, and this kernel is a chain of dependent latencies
+    const int pb = (int)((P + 63) / 64);
+    hipLaunchKernelGGL(setup_bin_kernel, dim3(pb), dim3(64), 0, st, SA, g, w.counts, w.lists, w.cap, w.heavy, visible);
     FineArgs A;
     A.points = pts_screen; A.ellipse = ellipse; A.cutoff = cutoff; A.radii = radii;
     A.first_idx = first_idx; A.num_pts = num_pts;
-    A.counts = w.counts; A.lists = w.lists; A.cap = w.cap;
+    A.counts = w.counts; A.lists = w.lists; A.cap = w.cap; A.heavy = w.heavy;
     A.idx = idx; A.zbuf = zbuf; A.qv = qvalue; A.occ = occ; A.visible = visible;
     A.g = g; A.N = N; A.K = K; A.thr = merge_thr;
     A.scaler = scaler; A.feat = feat; A.image = image; A.wsum = wsum; A.C = C;
