@@ -43,7 +43,7 @@ SIGNATURES = {
                                                   _c_vp, _c_vp, _c_vp, _c_sz, _c_vp]),
     "dss_render_forward_workspace": (_c_sz, [_c_int, _c_i64, _c_int, _c_int]),
     "dss_render_forward": (_c_int, [_c_vp] * 10 + [_c_int, _c_i64, _c_int, _c_int, _c_int, _c_int, _c_f32, _c_f32, _c_f32,
-                                                  _c_int, _c_int, _c_vp, _c_int] + [_c_vp] * 13 + [_c_vp, _c_sz, _c_vp]),
+                                                  _c_int, _c_int, _c_vp, _c_int] + [_c_vp] * 13 + [_c_vp, _c_sz, _c_int, _c_vp]),
     "dss_render_backward_workspace": (_c_sz, [_c_int, _c_i64]),
     "dss_render_backward": (_c_int, [_c_vp] * 10 + [_c_int, _c_i64, _c_int, _c_int, _c_int, _c_int, _c_int, _c_f32, _c_f32]
                             + [_c_vp] * 3 + [_c_vp, _c_sz, _c_vp]),
@@ -107,6 +107,27 @@ def require_gpu(t: torch.Tensor, name: str, dtype=None) -> torch.Tensor:
 
 
 _ws_cache = {}
+
+
+_clean_cache = {}
+
+
+def clean_workspace(device, tag, nbytes: int) -> torch.Tensor:
+    """Zero-initialised buffer owned by ONE entry point and ONE problem size (`tag`) on the current stream:
+    the DSS_WS_CLEAN contract of include/dss_hip.h (the library leaves it zero-filled after every successful
+    call, so the per-call memset launch is skipped).  Call `drop_clean_workspace` if the call fails."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream, tag)
+    buf = _clean_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        if len(_clean_cache) >= 16:  # problem sizes come and go (tests): keep the cache small
+            _clean_cache.pop(next(iter(_clean_cache)))
+        buf = torch.zeros(int(nbytes), dtype=torch.uint8, device=device)
+        _clean_cache[key] = buf
+    return buf
+
+
+def drop_clean_workspace(device, tag) -> None:
+    _clean_cache.pop((device.index, torch.cuda.current_stream(device).cuda_stream, tag), None)
 
 
 def workspace(device, nbytes: int) -> torch.Tensor:

@@ -39,8 +39,8 @@ namespace dss {
 #define DSS_HEAVY_MAX 2048
 #define DSS_HEAVY_SUB0 4
 struct HeavyQ {
-    uint32_t *count;  // 1 word, zeroed with the tile counters
-    int32_t *list;    // DSS_HEAVY_MAX tile ids
+    uint32_t *count;  // 1 word, zeroed with the tile counters (only the binning pass uses it)
+    int32_t *list;    // DSS_HEAVY_MAX slots holding tile id + 1, 0 = empty; zeroed with the tile counters
     uint8_t *flag;    // one byte per tile, zeroed with the tile counters
 };
 
@@ -89,7 +89,7 @@ __device__ __forceinline__ void mark_heavy(const HeavyQ hq, int tile)
     if (!hq.count) return;
     const uint32_t slot = atomicAdd(hq.count, 1u);
     if (slot < DSS_HEAVY_MAX) {
-        hq.list[slot] = tile;
+        hq.list[slot] = tile + 1;  // 0 = empty slot
         hq.flag[tile] = 1;  // only queued tiles are flagged: a full queue leaves the rest to the normal workgroups
     }
 }
@@ -175,6 +175,7 @@ struct FineArgs {
     const int32_t *lists;      // (N*tiles*DSS_SUB*cap)
     uint32_t cap;              // sub-list capacity
     HeavyQ heavy;              // heavy-first queue (count == nullptr: identity order)
+    uint32_t *clean_counts;    // DSS_WS_CLEAN: == counts, every owner resets what it has read; else nullptr
     int32_t *idx;
     float *zbuf, *qv, *occ;
     uint8_t *visible;
@@ -390,6 +391,8 @@ __device__ __forceinline__ void fine_tile(const FineArgs &A, const int tile_id)
     for (int64_t base = 0; base < count; base += CHUNK) {
         const int m = (int)min((int64_t)CHUNK, count - base);
         __syncthreads();  // previous chunk fully consumed
+        // DSS_WS_CLEAN: every thread has read the tile's counters (src.init) before this barrier
+        if (base == 0 && A.clean_counts && tid < DSS_SUB) A.clean_counts[(size_t)tile_id * DSS_SUB + tid] = 0;
         if (tid < m) {
             const int64_t p = src.at(base + tid);
             const float px = A.points[3 * p], py = A.points[3 * p + 1], pz = A.points[3 * p + 2];
@@ -586,14 +589,28 @@ template <int KMAX>
 __global__ __launch_bounds__(FINE_THREADS) void fine_kernel(const FineArgs A)
 {
     const int total = A.N * A.g.tiles_x * A.g.tiles_y;
+    const bool clean = A.clean_counts != nullptr;
     int tile_id;
     if (A.heavy.count != nullptr) {
+        if (clean && blockIdx.x == 0 && threadIdx.x == 0) *A.heavy.count = 0;  // only the binning pass reads it
+        // the resets happen after a barrier: every thread of the workgroup must have read the value first
         if (blockIdx.x < DSS_HEAVY_MAX) {
-            if (blockIdx.x >= min(*A.heavy.count, (uint32_t)DSS_HEAVY_MAX)) return;
-            tile_id = A.heavy.list[blockIdx.x];
+            const int e = A.heavy.list[blockIdx.x];
+            if (clean) {
+                __syncthreads();
+                if (threadIdx.x == 0) A.heavy.list[blockIdx.x] = 0;  // this workgroup is the slot's only reader
+            }
+            if (e == 0) return;
+            tile_id = e - 1;
         } else {
             tile_id = xcd_tile(blockIdx.x - DSS_HEAVY_MAX, total);
-            if (tile_id < 0 || A.heavy.flag[tile_id]) return;
+            if (tile_id < 0) return;
+            const uint8_t queued = A.heavy.flag[tile_id];
+            if (clean) {
+                __syncthreads();
+                if (queued && threadIdx.x == 0) A.heavy.flag[tile_id] = 0;  // ... and the flag's only reader
+            }
+            if (queued) return;
         }
     } else {
         tile_id = xcd_tile(blockIdx.x, total);
@@ -735,12 +752,13 @@ static FwdWorkspace carve_fwd(void *ws, int N, int64_t P, int S)
     char *p = reinterpret_cast<char *>(ws);
     w.cap = bin_capacity(N, P, S);
     const size_t cbytes = align_up(tiles_max * DSS_SUB * 4, 256), fbytes = align_up(tiles_max, 256);
-    w.count_bytes = cbytes + fbytes + 256;
+    const size_t qbytes = align_up((size_t)DSS_HEAVY_MAX * 4, 256);
+    w.count_bytes = cbytes + fbytes + 256 + qbytes;
     w.counts = reinterpret_cast<uint32_t *>(p);
     w.heavy.flag = reinterpret_cast<uint8_t *>(p + cbytes);
     w.heavy.count = reinterpret_cast<uint32_t *>(p + cbytes + fbytes);
-    w.heavy.list = reinterpret_cast<int32_t *>(p + w.count_bytes);
-    const size_t lists_off = w.count_bytes + align_up((size_t)DSS_HEAVY_MAX * 4, 256);
+    w.heavy.list = reinterpret_cast<int32_t *>(p + cbytes + fbytes + 256);
+    const size_t lists_off = w.count_bytes;
     w.lists = reinterpret_cast<int32_t *>(p + lists_off);
     w.bytes = lists_off + align_up(tiles_max * DSS_SUB * (size_t)w.cap * 4, 256);
     return w;
@@ -845,7 +863,7 @@ static int splat_fine_impl(const float *points, const float *ellipse, const floa
     A.points = points; A.ellipse = ellipse; A.cutoff = cutoff; A.radii = radii;
     A.first_idx = first_idx; A.num_pts = num_pts;
     A.counts = nullptr; A.lists = nullptr; A.cap = 0;
-    A.heavy.count = nullptr; A.heavy.list = nullptr; A.heavy.flag = nullptr;
+    A.heavy.count = nullptr; A.heavy.list = nullptr; A.heavy.flag = nullptr; A.clean_counts = nullptr;
     A.idx = idx; A.zbuf = zbuf; A.qv = qvalue; A.occ = occ; A.visible = visible;
     A.g = g; A.N = N; A.K = K; A.thr = merge_thr;
     A.scaler = scaler; A.feat = feat; A.image = image; A.wsum = wsum; A.C = C;
@@ -934,7 +952,7 @@ extern "C" int dss_render_forward(const float *world, const float *normals, cons
                                   float *pts_screen, float *ellipse, float *radii, float *scaler, float *cutoff,
                                   uint8_t *valid, int32_t *idx, float *zbuf, float *qvalue, float *occ,
                                   uint8_t *visible, float *image, float *wsum, void *workspace, size_t workspace_bytes,
-                                  void *stream)
+                                  int workspace_state, void *stream)
 {
     int rc = validate_fwd("dss_render_forward", N, P, S, K, row0, row1);
     if (rc) return rc;
@@ -963,7 +981,8 @@ extern "C" int dss_render_forward(const float *world, const float *normals, cons
     const int tiles = g.tiles_x * g.tiles_y;
     if ((long long)N * tiles > 0x7fffffffll) { set_error("dss_render_forward: too many tiles"); return DSS_ERR_UNSUPPORTED; }
     FwdWorkspace w = carve_fwd(workspace, N, P, S);
-    if (hipMemsetAsync(w.counts, 0, w.count_bytes, st) != hipSuccess) return check_launch("memset tile counts");
+    const bool clean = workspace_state == DSS_WS_CLEAN;
+    if (!clean && hipMemsetAsync(w.counts, 0, w.count_bytes, st) != hipSuccess) return check_launch("memset tile counts");
     SetupArgs SA;
     SA.world = world; SA.normals = normals; SA.h_point = h_point; SA.h_cloud = h_cloud; SA.M = M; SA.V = V;
     SA.znear = znear; SA.zfar = zfar; SA.first_idx = first_idx; SA.num_pts = num_pts; SA.N = N; SA.P = P;
@@ -978,6 +997,7 @@ extern "C" int dss_render_forward(const float *world, const float *normals, cons
     A.points = pts_screen; A.ellipse = ellipse; A.cutoff = cutoff; A.radii = radii;
     A.first_idx = first_idx; A.num_pts = num_pts;
     A.counts = w.counts; A.lists = w.lists; A.cap = w.cap; A.heavy = w.heavy;
+    A.clean_counts = clean ? w.counts : nullptr;
     A.idx = idx; A.zbuf = zbuf; A.qv = qvalue; A.occ = occ; A.visible = visible;
     A.g = g; A.N = N; A.K = K; A.thr = merge_thr;
     A.scaler = scaler; A.feat = feat; A.image = image; A.wsum = wsum; A.C = C;

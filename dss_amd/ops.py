@@ -320,7 +320,9 @@ def render_forward(world, normals, h, M, V, znear, zfar, cloud_to_packed_first_i
         if tuple(o["image"].shape) != (N, nr, S, C + 1) or o["image"].dtype != _f32 or not o["image"].is_contiguous() \
                 or o["image"].data_ptr() % 16 or tuple(vis.shape) != (P,) or vis.dtype != _u8:
             raise RuntimeError("out_image must be contiguous float32 (N,rows,S,C+1), 16-byte aligned; out_visible uint8 (P,)")
-        ws = _lib.workspace(dev, lib.dss_render_forward_workspace(N, P, S, K))
+        # dedicated zero-initialised buffer per problem size: the library keeps it clean (no memset launch)
+        tag = ("render_forward", N, P, S)
+        ws = _lib.clean_workspace(dev, tag, lib.dss_render_forward_workspace(N, P, S, K))
         rc = lib.dss_render_forward(
             _lib.ptr(world), _lib.ptr(normals), _lib.ptr(h) if per_point else None, None if per_point else _lib.ptr(h),
             _lib.ptr(M), _lib.ptr(V), _lib.ptr(znear), _lib.ptr(zfar), _lib.ptr(first), _lib.ptr(num), N, P,
@@ -328,7 +330,9 @@ def render_forward(world, normals, h, M, V, znear, zfar, cloud_to_packed_first_i
             float(depth_merging_thres), row0, row1, _lib.ptr(features), C, _lib.ptr(o["pts_screen"]),
             _lib.ptr(o["ellipse_params"]), _lib.ptr(o["radii"]), _lib.ptr(o["scaler"]), _lib.ptr(o["cutoff_threshold"]),
             _lib.ptr(valid), _lib.ptr(o["idx"]), _lib.ptr(o["zbuf"]), _lib.ptr(o["qvalue"]), _lib.ptr(o["occupancy"]),
-            _lib.ptr(vis), _lib.ptr(o["image"]), _lib.ptr(o["wsum"]), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
+            _lib.ptr(vis), _lib.ptr(o["image"]), _lib.ptr(o["wsum"]), _lib.ptr(ws), ws.numel(), 1, _lib.stream_ptr(dev))
+        if rc:
+            _lib.drop_clean_workspace(dev, tag)
     _lib.check(rc, "dss_render_forward")
     o["valid"], o["visible"] = valid.view(torch.bool), vis.view(torch.bool)
     return o

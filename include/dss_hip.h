@@ -200,7 +200,16 @@ DSS_API int dss_blend_backward_scatter(const float *grad_out, const int32_t *idx
  * dss_splat_forward + dss_blend_forward, same outputs (all of them are written: the per-point
  * screen-space arrays, the fragments, visibility, the (N,rows,S,C+1) image and wsum), same bits.
  * K <= DSS_MAX_K_FAST, 1 <= C <= 8.
+ *
+ * workspace_state: DSS_WS_UNKNOWN (0) -- contents arbitrary: the call zeroes the tile counters itself (one
+ * memset launch).  DSS_WS_CLEAN (1) -- the caller guarantees that the first dss_render_forward_workspace()
+ * bytes are either zero-filled (once, after allocation) or were left by a previous SUCCESSFUL
+ * DSS_WS_CLEAN call with the same (N, P, S) on this buffer, and that nothing else wrote to them since:
+ * the memset launch is skipped and the fine pass restores the all-zero state on its way out (every counter,
+ * flag and queue slot has exactly one owning workgroup that resets it after its last read).
  * ------------------------------------------------------------------------------------------- */
+#define DSS_WS_UNKNOWN 0
+#define DSS_WS_CLEAN 1
 DSS_API size_t dss_render_forward_workspace(int N, int64_t P, int S, int K);
 DSS_API int dss_render_forward(const float *world, const float *normals, const float *h_point,
                                const float *h_cloud, const float *M, const float *V, const float *znear,
@@ -211,7 +220,7 @@ DSS_API int dss_render_forward(const float *world, const float *normals, const f
                                float *pts_screen, float *ellipse, float *radii, float *scaler,
                                float *cutoff, uint8_t *valid, int32_t *idx, float *zbuf, float *qvalue,
                                float *occ, uint8_t *visible, float *image, float *wsum,
-                               void *workspace, size_t workspace_bytes, void *stream);
+                               void *workspace, size_t workspace_bytes, int workspace_state, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused single-GPU backward of renderer + rasterizer: dss_blend_backward + dss_backward_radius +

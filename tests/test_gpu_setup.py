@@ -202,3 +202,37 @@ def test_point_setup_matches_reference_python_golden(golden_dir, tag, mode):
     assert out["valid"].all()
     _check_setup_against_reference(z, tag, mode, out["radii"].cpu().numpy(), out["ellipse_params"].cpu().numpy(),
                                    out["scaler"].cpu().numpy(), out["cutoff_threshold"].cpu().numpy())
+
+
+@pytest.mark.parametrize("h_scale", [1.0, 40.0])
+def test_render_forward_leaves_its_workspace_clean(h_scale):
+    """DSS_WS_CLEAN contract (include/dss_hip.h): ops.render_forward skips the counter memset and relies on the
+    fine pass to zero every tile counter, queue slot and flag it has read.  Repeated calls must give identical
+    bits, and the zero region of the cached buffer must be all zero after each call.  h_scale = 40 makes giant
+    splats: dense tiles (heavy-first queue in use) and overflowing sub-lists (cloud-scan fallback)."""
+    from dss_amd import _lib
+    pts, nrm, col, M, V, az = _scene()
+    N, Pc, S, K = M.shape[0], pts.shape[0], 128, 5
+    h = scenes.global_h(pts) * h_scale
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    world, normals, feat = t(pts), t(nrm), t(np.tile(col, (N, 1)))
+    first = torch.arange(N, device=DEV) * Pc
+    num = torch.full((N,), Pc, device=DEV, dtype=torch.int64)
+    hh = torch.full((N,), h, device=DEV)
+    zn, zf = torch.full((N,), 0.6, device=DEV), torch.full((N,), 100.0, device=DEV)
+    tiles = N * (S // 8) ** 2
+    up = lambda x: (x + 255) // 256 * 256
+    zero_bytes = up(tiles * 8 * 4) + up(tiles) + 256 + up(2048 * 4)  # mirrors carve_fwd (raster_forward.hip)
+    outs = []
+    for rep in range(3):
+        f = ops.render_forward(world, normals, hh, t(M), t(V), zn, zf, first, num, feat, S, K, 1.0, 0.05, 1.0, True, True)
+        torch.cuda.synchronize()
+        bufs = [b for k, b in _lib._clean_cache.items() if k[2] == ("render_forward", N, N * Pc, S)]
+        assert len(bufs) == 1 and int(bufs[0][:zero_bytes].count_nonzero()) == 0, rep
+        outs.append(f)
+    for k in ("idx", "zbuf", "qvalue", "occupancy", "image", "wsum", "visible"):
+        assert torch.equal(outs[0][k], outs[1][k]) and torch.equal(outs[0][k], outs[2][k]), k
+    info = ops.point_setup(world, normals, hh, t(M), t(V), zn, zf, first, num, S, 1.0, 1.0, True, True)
+    idx, zbuf, qv, occ, vis = ops.splat_points(info["pts_screen"], info["ellipse_params"], info["cutoff_threshold"],
+                                               info["radii"], first, num, 0.05, S, K, None, None, return_visible=True)
+    assert torch.equal(outs[2]["idx"], idx) and torch.equal(outs[2]["zbuf"], zbuf) and torch.equal(outs[2]["visible"], vis)
