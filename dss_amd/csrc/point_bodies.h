@@ -27,14 +27,16 @@ struct LaneTiling {
 //       skip if g>0 and (|dx|>rx or |dy|>ry);  (gx,gy) += (dx,dy)/max(d2,1e-10)*g
 // (rasterize_points_backward.cu:141-178; a pair with d2 == 0 contributes 0, see dss_hip.h).
 // grad_occ is read with an element stride `gstride` per pixel (alpha channel of an image gradient).
-__device__ __forceinline__ void occ_point_gather(int lane, int64_t p, int n, const float *__restrict__ points,
-                                                 const float *__restrict__ radii, const float *__restrict__ rs,
+// screen-space record of one splat as the gathers need it
+struct SplatRec {
+    float px, py, pz, rx, ry, sc;
+};
+
+__device__ __forceinline__ void occ_point_gather(int lane, int n, const SplatRec &R, float cur_r,
                                                  const float *__restrict__ grad_occ, int S, int row0, int rows,
                                                  int gstride, float &gx, float &gy)
 {
-    const float px = points[3 * p], py = points[3 * p + 1], pz = points[3 * p + 2];
-    const float rx = radii[2 * p], ry = radii[2 * p + 1];
-    const float cur_r = rs[n];
+    const float px = R.px, py = R.py, pz = R.pz, rx = R.rx, ry = R.ry;
     const float cur_r2 = cur_r * cur_r;
     // rasterize_points_backward.cu:141-143
     if (pz < 0 || fabsf(py) > 1.0f || fabsf(px) > 1.0f) return;
@@ -93,20 +95,29 @@ __device__ __forceinline__ void occ_point_gather(int lane, int64_t p, int n, con
     }
 }
 
+__device__ __forceinline__ void occ_point_gather(int lane, int64_t p, int n, const float *__restrict__ points,
+                                                 const float *__restrict__ radii, const float *__restrict__ rs,
+                                                 const float *__restrict__ grad_occ, int S, int row0, int rows,
+                                                 int gstride, float &gx, float &gy)
+{
+    SplatRec R;
+    R.px = points[3 * p]; R.py = points[3 * p + 1]; R.pz = points[3 * p + 2];
+    R.rx = radii[2 * p]; R.ry = radii[2 * p + 1]; R.sc = 0.0f;
+    occ_point_gather(lane, n, R, rs[n], grad_occ, S, row0, rows, gstride, gx, gy);
+}
+
 // Blend backward of point p: sum over the pixels of the point's own bounding box (a fragment with
 // idx == p can only exist where the hit test passed) of grad_out * w / wsum.
 template <int C>
-__device__ __forceinline__ void blend_point_gather(int lane, int64_t p, int n, const float *__restrict__ grad_out,
+__device__ __forceinline__ void blend_point_gather(int lane, int64_t p, int n, const SplatRec &R,
+                                                   const float *__restrict__ grad_out,
                                                    const int32_t *__restrict__ idx, const float *__restrict__ qv,
                                                    const float *__restrict__ wsum, const float *__restrict__ scaler,
-                                                   const float *__restrict__ points, const float *__restrict__ radii,
                                                    int S, int K, int Cn, int row0, int rows,
                                                    float (&acc)[(C > 0) ? C : BLEND_MAX_C])
 {
     constexpr int CM = (C > 0) ? C : BLEND_MAX_C;
-    const float px = points[3 * p], py = points[3 * p + 1];
-    const float rx = radii[2 * p], ry = radii[2 * p + 1];
-    const float sc = scaler[p];
+    const float px = R.px, py = R.py, rx = R.rx, ry = R.ry, sc = R.sc;
     int xlo, xhi, ylo, yhi;
     if (!ndc_index_range_tight(px, rx, S, xlo, xhi) || !ndc_index_range_tight(py, ry, S, ylo, yhi)) return;
     ylo = max(ylo, S - row0 - rows);
@@ -144,6 +155,20 @@ __device__ __forceinline__ void blend_point_gather(int lane, int64_t p, int n, c
                 if (ch < Cn) acc[ch] = fmaf(gch[ch], wn, acc[ch]);
         }
     }
+}
+
+template <int C>
+__device__ __forceinline__ void blend_point_gather(int lane, int64_t p, int n, const float *__restrict__ grad_out,
+                                                   const int32_t *__restrict__ idx, const float *__restrict__ qv,
+                                                   const float *__restrict__ wsum, const float *__restrict__ scaler,
+                                                   const float *__restrict__ points, const float *__restrict__ radii,
+                                                   int S, int K, int Cn, int row0, int rows,
+                                                   float (&acc)[(C > 0) ? C : BLEND_MAX_C])
+{
+    SplatRec R;
+    R.px = points[3 * p]; R.py = points[3 * p + 1]; R.pz = 0.0f;
+    R.rx = radii[2 * p]; R.ry = radii[2 * p + 1]; R.sc = scaler[p];
+    blend_point_gather<C>(lane, p, n, R, grad_out, idx, qv, wsum, scaler, S, K, Cn, row0, rows, acc);
 }
 
 }  // namespace dss

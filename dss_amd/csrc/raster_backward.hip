@@ -623,13 +623,13 @@ __global__ __launch_bounds__(256) void render_backward_kernel(
     const float *__restrict__ radii, const float *__restrict__ rs, const int64_t *__restrict__ first_idx,
     const int64_t *__restrict__ num_pts, const uint32_t *__restrict__ vis_count,
     const int32_t *__restrict__ vis_list, int n_seg, int N, int S, int K, int Crt, float clip, int row0, int rows,
-    float *__restrict__ grad_feat, float *__restrict__ grad_pts)
+    uint32_t large_waves, float *__restrict__ grad_feat, float *__restrict__ grad_pts)
 {
     constexpr int CM = (C > 0) ? C : BLEND_MAX_C;
     const int Cn = (C > 0) ? C : Crt;
     const int lane = threadIdx.x & 63;
     const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const uint32_t n_waves = gridDim.x * 4;
+    uint32_t n_waves = gridDim.x * 4;
     // SEG: vis_count[0..n_seg) are per-segment counts written by backward_compact_kernel (n_seg <= 64): every
     // wavefront scans them in registers once; a task index t maps to (segment, offset) with one ballot.
     uint32_t count, seg_excl = 0;  // first task index of segment `lane`
@@ -646,31 +646,73 @@ __global__ __launch_bounds__(256) void render_backward_kernel(
     } else {
         count = *vis_count;
     }
+    // Long lists use 6 workgroups per CU: more resident gathers only evict each other's image rows from L2
+    // (8 x 1M points at 1024^2: 1169 Msplats/s with 6 per CU, 1058 with 7).  Short lists (a few tasks per
+    // wavefront) use every resident wavefront; equalising the task counts (ceil(count / rounds) wavefronts)
+    // was measured and is slower (329 vs 348 Msplats/s on the 512^2 bunny).
+    if (count > 8u * n_waves) n_waves = min(n_waves, large_waves);
+    if (wave >= n_waves) return;
 #ifdef DSS_FINE_TIMING
     long long tm_rt0 = __builtin_amdgcn_s_memrealtime(), tm_occ = 0, tm_blend = 0, tm_pro = 0, tm_tasks = 0;
 #endif
-    for (uint32_t t = wave; t < count; t += n_waves) {
-#ifdef DSS_FINE_TIMING
-        const long long tm0 = __builtin_amdgcn_s_memtime();
-#endif
-        int64_t p;
+    // One task = one visible point, handled by the whole wavefront.  Everything that identifies the task is
+    // wave-uniform, so it is kept in SGPRs (readfirstlane) and fetched with scalar loads; the NEXT task's
+    // point id and record are requested before the current task's gathers and arrive during them (the
+    // prologue was ~10 % of a task: two dependent round trips before the first gather load could issue).
+    auto task_point = [&](uint32_t t) -> int {
         if (SEG) {
             // last segment that starts at or before t (starts are non-decreasing over lanes; empty segments
             // share their successor's start and lose the tie)
             const int seg = (int)__popcll(__ballot(seg_excl <= t)) - 1;
             const uint32_t excl = (uint32_t)__builtin_amdgcn_readlane((int)seg_excl, seg);
-            p = vis_list[(size_t)seg * PREP_CHUNK + (t - excl)];
-        } else {
-            p = vis_list[t];
+            return vis_list[(size_t)seg * PREP_CHUNK + (t - excl)];
         }
+        return vis_list[t];
+    };
+    // the six floats of a record come from three arrays: ONE vector load with a different address per lane
+    // (six scalar loads per task throttle on the scalar cache once tasks are short, measured on 8 x 1M points)
+    auto issue_rec = [&](int p) -> float {
+        const float *a = lane < 3 ? points + 3 * (size_t)p + lane
+                       : lane < 5 ? radii + 2 * (size_t)p + (lane - 3)
+                                  : (scaler ? scaler + p : points + 3 * (size_t)p);
+        return lane < 6 ? *a : 0.0f;
+    };
+    auto unpack_rec = [&](float v, SplatRec &R) {
+        R.px = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+        R.py = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 1));
+        R.pz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 2));
+        R.rx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 3));
+        R.ry = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 4));
+        R.sc = scaler ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 5)) : 0.0f;
+    };
+    const uint32_t wave_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave);
+    uint32_t t = wave_u;
+    // software pipeline, two tasks deep: point id of task i+2 and record of task i+1 are in flight during task i
+    int p_cur = 0, p_nx = 0;
+    SplatRec cur;
+    if (t < count) {
+        p_cur = __builtin_amdgcn_readfirstlane(task_point(t));
+        if (t + n_waves < count) p_nx = __builtin_amdgcn_readfirstlane(task_point(t + n_waves));
+        unpack_rec(issue_rec(p_cur), cur);
+    }
+    while (t < count) {
+#ifdef DSS_FINE_TIMING
+        const long long tm0 = __builtin_amdgcn_s_memtime();
+#endif
+        const uint32_t t_next = t + n_waves;
+        int p_nx2 = 0;
+        float v_nx = 0.0f;
+        if (t_next + n_waves < count) p_nx2 = task_point(t_next + n_waves);
+        if (t_next < count) v_nx = issue_rec(p_nx);
+        const int64_t p = p_cur;
         const int n = find_cloud(p, first_idx, num_pts, N);
-        if (n < 0) continue;
+        if (n >= 0) {
         float gx = 0.0f, gy = 0.0f;
 #ifdef DSS_FINE_TIMING
         const long long tm1 = __builtin_amdgcn_s_memtime();
 #endif
         // occupancy gradient = alpha channel of the image gradient, read in place
-        occ_point_gather(lane, p, n, points, radii, rs, grad_out + Cn, S, row0, rows, Cn + 1, gx, gy);
+        occ_point_gather(lane, n, cur, rs[n], grad_out + Cn, S, row0, rows, Cn + 1, gx, gy);
 #ifdef DSS_FINE_TIMING
         gx = wave_sum(gx) * (1.0f / 64.0f) * 64.0f / 64.0f;  // force completion of the gather before the stamp
         const long long tm2 = __builtin_amdgcn_s_memtime();
@@ -680,7 +722,7 @@ __global__ __launch_bounds__(256) void render_backward_kernel(
 #pragma unroll
         for (int ch = 0; ch < CM; ++ch) acc[ch] = 0.0f;
         if (grad_feat)
-            blend_point_gather<C>(lane, p, n, grad_out, idx, qv, wsum, scaler, points, radii, S, K, Cn, row0, rows, acc);
+            blend_point_gather<C>(lane, p, n, cur, grad_out, idx, qv, wsum, scaler, S, K, Cn, row0, rows, acc);
         gx = wave_sum(gx);
         gy = wave_sum(gy);
 #pragma unroll
@@ -704,6 +746,11 @@ __global__ __launch_bounds__(256) void render_backward_kernel(
                     if (ch < Cn) grad_feat[(size_t)p * Cn + ch] = acc[ch];
             }
         }
+        }
+        t = t_next;
+        p_cur = p_nx;
+        p_nx = __builtin_amdgcn_readfirstlane(p_nx2);
+        if (t < count) unpack_rec(v_nx, cur);
     }
 #ifdef DSS_FINE_TIMING
     if (g_occ_timing && lane == 0) {
@@ -979,7 +1026,7 @@ extern "C" int dss_render_backward(const float *grad_out, const int32_t *idx, co
     }
     // persistent grid = exactly the resident capacity of the chip for this kernel (a larger grid would
     // leave late workgroups waiting for slots while their share of the list sits idle)
-    static int cap3 = 0, cap0 = 0;  // benign race: every thread computes the same value
+    static int cap3 = 0, cap0 = 0, n_cus = 256;  // benign race: every thread computes the same value
     int &cap = (C == 3) ? cap3 : cap0;
     if (cap == 0) {
         int dev = 0, cus = 256, per_cu = 4;
@@ -991,14 +1038,16 @@ extern "C" int dss_render_backward(const float *grad_out, const int32_t *idx, co
         else
             (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_backward_kernel<0, true>, 256, 0);
         if (per_cu < 1) per_cu = 1;
+        n_cus = cus;
         cap = cus * per_cu;
         (void)hipGetLastError();
     }
     const unsigned pgrid = (unsigned)((P + 3) / 4 < cap ? (P + 3) / 4 : cap);
+    const uint32_t large_waves = 6u * (uint32_t)n_cus * 4u;
 #define DSS_LAUNCH_RB(CC, SS)                                                                                          \
     hipLaunchKernelGGL((render_backward_kernel<CC, SS>), dim3(pgrid), dim3(256), 0, st, grad_out, idx, qvalue, wsum,   \
                        scaler, points, radii, rs, first_idx, num_pts, vis_count, vis_list, n_seg, N, S, K, C, clip,    \
-                       row0, row1 - row0, grad_feat, grad_pts)
+                       row0, row1 - row0, large_waves, grad_feat, grad_pts)
     if (C == 3) {
         if (small) DSS_LAUNCH_RB(3, true); else DSS_LAUNCH_RB(3, false);
     } else {
