@@ -409,12 +409,38 @@ __device__ __forceinline__ void block_select(const uint32_t (&h)[4], uint32_t fi
     total_out = total;
 }
 
+// Dense copy of the alpha channel of the image gradient: plane[i] = grad_out[i * (C + 1) + C].
+#define ALPHA_PIX_PER_WG 8192
+__device__ __forceinline__ void alpha_plane_body(unsigned block, unsigned threads, const float *__restrict__ grad_out,
+                                                 float *__restrict__ plane, size_t npix, int C)
+{
+    const size_t i0 = (size_t)block * ALPHA_PIX_PER_WG;
+    const size_t i1 = min(i0 + ALPHA_PIX_PER_WG, npix);
+    if (C == 3) {
+        const float4 *g4 = reinterpret_cast<const float4 *>(grad_out);  // (N,rows,S,4): 16-byte aligned pixels
+        for (size_t i = i0 + threadIdx.x; i < i1; i += threads) plane[i] = g4[i].w;
+    } else {
+        for (size_t i = i0 + threadIdx.x; i < i1; i += threads) plane[i] = grad_out[i * (C + 1) + C];
+    }
+}
+
+__global__ __launch_bounds__(1024) void alpha_plane_kernel(const float *__restrict__ grad_out, float *__restrict__ plane,
+                                                           size_t npix, int C)
+{
+    alpha_plane_body(blockIdx.x, blockDim.x, grad_out, plane, npix, C);
+}
+
 __global__ __launch_bounds__(PREP_THREADS) void backward_compact_kernel(
     const float *__restrict__ radii, const uint8_t *__restrict__ visible, const int64_t *__restrict__ first_idx,
     const int64_t *__restrict__ num_pts, int N, int64_t P, int chunks, uint32_t *__restrict__ seg_count,
     int32_t *__restrict__ vis_list, uint2 *__restrict__ vis_keys, uint32_t *__restrict__ chunk_hist /*(N,chunks,256)*/,
-    uint2 *__restrict__ seg_range /*(N,chunks)*/, float *__restrict__ grad_pts, float *__restrict__ grad_feat, int C)
+    uint2 *__restrict__ seg_range /*(N,chunks)*/, float *__restrict__ grad_pts, float *__restrict__ grad_feat, int C,
+    const float *__restrict__ grad_out, float *__restrict__ alpha_plane, size_t npix)
 {
+    if ((int)blockIdx.x >= chunks) {  // extra workgroups of the launch: dense alpha plane for the gather kernel
+        alpha_plane_body(blockIdx.x - chunks, PREP_THREADS, grad_out, alpha_plane, npix, C);
+        return;
+    }
     constexpr int PER = PREP_CHUNK / PREP_THREADS;
     __shared__ uint32_t lh[256 * 32];
     __shared__ uint32_t s_w[PER * PREP_THREADS / 64];
@@ -618,7 +644,8 @@ __global__ __launch_bounds__(PREP_THREADS) void median_visible_kernel(
 
 template <int C, bool SEG>
 __global__ __launch_bounds__(256) void render_backward_kernel(
-    const float *__restrict__ grad_out, const int32_t *__restrict__ idx, const float *__restrict__ qv,
+    const float *__restrict__ grad_out, const float *__restrict__ grad_alpha /* dense (N,rows,S) */,
+    const int32_t *__restrict__ idx, const float *__restrict__ qv,
     const float *__restrict__ wsum, const float *__restrict__ scaler, const float *__restrict__ points,
     const float *__restrict__ radii, const float *__restrict__ rs, const int64_t *__restrict__ first_idx,
     const int64_t *__restrict__ num_pts, const uint32_t *__restrict__ vis_count,
@@ -685,44 +712,50 @@ __global__ __launch_bounds__(256) void render_backward_kernel(
         R.ry = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 4));
         R.sc = scaler ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 5)) : 0.0f;
     };
+    // Static schedule: task t = wave, wave + n_waves, ...  (A dynamic one -- 64 atomic queue heads, one returning
+    // atomic per task, next position prefetched -- was measured at HALF the speed on every configuration: a
+    // returning global atomic is slower than a whole gather trip and sits in the same in-order return queue as
+    // the gather loads.)  Software pipeline, two tasks deep: point id of task i+2 (scalar load) and record of
+    // task i+1 (requested mid-gather) are in flight during task i.
     const uint32_t wave_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave);
     uint32_t t = wave_u;
-    // software pipeline, two tasks deep: point id of task i+2 and record of task i+1 are in flight during task i
-    int p_cur = 0, p_nx = 0;
+    if (t >= count) return;
+    int p_cur = __builtin_amdgcn_readfirstlane(task_point(t));
+    int p_nx = (t + n_waves < count) ? __builtin_amdgcn_readfirstlane(task_point(t + n_waves)) : 0;
     SplatRec cur;
-    if (t < count) {
-        p_cur = __builtin_amdgcn_readfirstlane(task_point(t));
-        if (t + n_waves < count) p_nx = __builtin_amdgcn_readfirstlane(task_point(t + n_waves));
-        unpack_rec(issue_rec(p_cur), cur);
-    }
-    while (t < count) {
+    unpack_rec(issue_rec(p_cur), cur);
+    for (;;) {
 #ifdef DSS_FINE_TIMING
         const long long tm0 = __builtin_amdgcn_s_memtime();
 #endif
         const uint32_t t_next = t + n_waves;
+        const bool have_next = t_next < count;
         int p_nx2 = 0;
         float v_nx = 0.0f;
         if (t_next + n_waves < count) p_nx2 = task_point(t_next + n_waves);
-        if (t_next < count) v_nx = issue_rec(p_nx);
         const int64_t p = p_cur;
         const int n = find_cloud(p, first_idx, num_pts, N);
-        if (n >= 0) {
         float gx = 0.0f, gy = 0.0f;
-#ifdef DSS_FINE_TIMING
-        const long long tm1 = __builtin_amdgcn_s_memtime();
-#endif
-        // occupancy gradient = alpha channel of the image gradient, read in place
-        occ_point_gather(lane, n, cur, rs[n], grad_out + Cn, S, row0, rows, Cn + 1, gx, gy);
-#ifdef DSS_FINE_TIMING
-        gx = wave_sum(gx) * (1.0f / 64.0f) * 64.0f / 64.0f;  // force completion of the gather before the stamp
-        const long long tm2 = __builtin_amdgcn_s_memtime();
-        tm_pro += tm1 - tm0; tm_occ += tm2 - tm1; tm_tasks += 1;
-#endif
         float acc[CM];
 #pragma unroll
         for (int ch = 0; ch < CM; ++ch) acc[ch] = 0.0f;
-        if (grad_feat)
-            blend_point_gather<C>(lane, p, n, cur, grad_out, idx, qv, wsum, scaler, S, K, Cn, row0, rows, acc);
+#ifdef DSS_FINE_TIMING
+        const long long tm1 = __builtin_amdgcn_s_memtime();
+#endif
+        auto mid = [&]() {
+            if (have_next) v_nx = issue_rec(p_nx);
+        };
+        if (n >= 0) {
+            // occupancy gradient = dense copy of the alpha channel of the image gradient; blend loads overlapped
+            occ_blend_point_gather<C>(lane, p, n, cur, rs[n], grad_alpha, 1, grad_out, idx, qv, wsum, scaler, S, K, Cn,
+                                      row0, rows, grad_feat != nullptr, gx, gy, acc, mid);
+        } else {
+            mid();
+        }
+#ifdef DSS_FINE_TIMING
+        const long long tm2 = __builtin_amdgcn_s_memtime();
+        tm_pro += tm1 - tm0; tm_occ += tm2 - tm1; tm_tasks += 1;
+#endif
         gx = wave_sum(gx);
         gy = wave_sum(gy);
 #pragma unroll
@@ -731,7 +764,7 @@ __global__ __launch_bounds__(256) void render_backward_kernel(
 #ifdef DSS_FINE_TIMING
         tm_blend += (long long)__builtin_amdgcn_s_memtime() - tm2;
 #endif
-        if (lane == 0) {
+        if (lane == 0 && n >= 0) {
             if (clip > 0.0f) {  // rasterizer.py:667-673 (z gradient is 0 on this path)
                 const float nrm = sqrtf(gx * gx + gy * gy);
                 gx = gx / fmaxf(nrm, 1e-12f) * fminf(nrm, clip);
@@ -746,11 +779,11 @@ __global__ __launch_bounds__(256) void render_backward_kernel(
                     if (ch < Cn) grad_feat[(size_t)p * Cn + ch] = acc[ch];
             }
         }
-        }
+        if (!have_next) break;
         t = t_next;
         p_cur = p_nx;
         p_nx = __builtin_amdgcn_readfirstlane(p_nx2);
-        if (t < count) unpack_rec(v_nx, cur);
+        unpack_rec(v_nx, cur);
     }
 #ifdef DSS_FINE_TIMING
     if (g_occ_timing && lane == 0) {
@@ -794,10 +827,10 @@ using namespace dss;
 
 // Workspace of the two-launch preparation (P <= PREP_MAX_POINTS), relative to its own base.
 struct PrepLayout {
-    size_t seg_count, vis_list, vis_keys, chunk_hist, seg_range, rs, bytes;
+    size_t seg_count, vis_list, vis_keys, chunk_hist, seg_range, rs, alpha, bytes;
     int chunks;
 };
-static PrepLayout prep_layout(int N, int64_t P)
+static PrepLayout prep_layout(int N, int64_t P, int S)
 {
     PrepLayout L;
     const size_t n = N > 0 ? N : 1, p = P > 0 ? (size_t)P : 1;
@@ -809,29 +842,32 @@ static PrepLayout prep_layout(int N, int64_t P)
     L.chunk_hist = off; off += align_up(n * (size_t)L.chunks * 256 * 4, 256);
     L.seg_range = off;  off += align_up(n * (size_t)L.chunks * 8, 256);
     L.rs = off;         off += align_up(n * 4, 256);
+    L.alpha = off;      off += align_up(n * (size_t)(S > 0 ? S : 0) * (size_t)(S > 0 ? S : 0) * 4, 256);  // S = 0: none
     L.bytes = off;
     return L;
 }
 
 static void launch_prep(const float *radii, const uint8_t *visible, const int64_t *first_idx, const int64_t *num_pts,
                         int N, int64_t P, float radii_s, float *rs, char *w, const PrepLayout &L, float *grad_pts,
-                        float *grad_feat, int C, hipStream_t st)
+                        float *grad_feat, int C, const float *grad_out, size_t npix, hipStream_t st)
 {
+    float *alpha = reinterpret_cast<float *>(w + L.alpha);
+    const unsigned alpha_wgs = grad_out ? (unsigned)((npix + ALPHA_PIX_PER_WG - 1) / ALPHA_PIX_PER_WG) : 0u;
     uint32_t *seg_count = reinterpret_cast<uint32_t *>(w + L.seg_count);
     int32_t *vis_list = reinterpret_cast<int32_t *>(w + L.vis_list);
     uint2 *vis_keys = reinterpret_cast<uint2 *>(w + L.vis_keys);
     uint32_t *chunk_hist = reinterpret_cast<uint32_t *>(w + L.chunk_hist);
     uint2 *seg_range = reinterpret_cast<uint2 *>(w + L.seg_range);
-    hipLaunchKernelGGL(backward_compact_kernel, dim3(L.chunks), dim3(PREP_THREADS), 0, st, radii, visible, first_idx,
-                       num_pts, N, P, L.chunks, seg_count, vis_list, vis_keys, chunk_hist, seg_range, grad_pts, grad_feat,
-                       C);
+    hipLaunchKernelGGL(backward_compact_kernel, dim3(L.chunks + alpha_wgs), dim3(PREP_THREADS), 0, st, radii, visible,
+                       first_idx, num_pts, N, P, L.chunks, seg_count, vis_list, vis_keys, chunk_hist, seg_range, grad_pts,
+                       grad_feat, C, grad_out, alpha, npix);
     hipLaunchKernelGGL(median_visible_kernel, dim3(N), dim3(PREP_THREADS), 0, st, first_idx, num_pts, P, L.chunks,
                        seg_range, vis_keys, chunk_hist, radii_s, rs);
 }
 
 extern "C" size_t dss_backward_radius_workspace(int N, int64_t P)
 {
-    if (P <= PREP_MAX_POINTS) return prep_layout(N, P).bytes;
+    if (P <= PREP_MAX_POINTS) return prep_layout(N, P, 0).bytes;
     return align_up((size_t)3 * (N > 0 ? N : 1) * MED_BINS * sizeof(uint32_t), 256);
 }
 
@@ -853,7 +889,7 @@ extern "C" int dss_backward_radius(const float *radii, const uint8_t *visible, c
     if (P <= PREP_MAX_POINTS) {
         if (P > 0)
             launch_prep(radii, visible, first_idx, num_pts, N, P, radii_s, rs, reinterpret_cast<char *>(workspace),
-                        prep_layout(N, P), nullptr, nullptr, 0, st);
+                        prep_layout(N, P, 0), nullptr, nullptr, 0, nullptr, 0, st);
         else
             (void)hipMemsetAsync(rs, 0, (size_t)N * 4, st);
         return check_launch("dss_backward_radius");
@@ -960,13 +996,14 @@ extern "C" int dss_splat_backward(const float *points, const float *radii, const
     return dss_clip_grad(grad_pts, P, clip, stream);
 }
 
-extern "C" size_t dss_render_backward_workspace(int N, int64_t P)
+extern "C" size_t dss_render_backward_workspace(int N, int64_t P, int S)
 {
-    const int n = N > 0 ? N : 1;
-    if (P <= PREP_MAX_POINTS) return prep_layout(N, P).bytes;
+    const size_t n = N > 0 ? N : 1, s = S > 0 ? S : 1;
+    if (P <= PREP_MAX_POINTS) return prep_layout(N, P, S).bytes;
     return align_up((size_t)3 * n * MED_BINS * 4 + 256, 256)  // histograms + visible counter
            + align_up((size_t)(P > 0 ? P : 1) * 4, 256)       // compacted visible list
-           + align_up((size_t)n * 4, 256);                    // rs
+           + align_up(n * 4, 256)                             // rs
+           + align_up(n * s * s * 4, 256);                    // dense alpha-gradient plane
 }
 
 extern "C" int dss_render_backward(const float *grad_out, const int32_t *idx, const float *qvalue, const float *wsum,
@@ -987,7 +1024,7 @@ extern "C" int dss_render_backward(const float *grad_out, const int32_t *idx, co
         set_error("dss_render_backward: NULL tensor pointer");
         return DSS_ERR_INVALID_ARGUMENT;
     }
-    const size_t need = dss_render_backward_workspace(N, P);
+    const size_t need = dss_render_backward_workspace(N, P, S);
     if (!workspace || workspace_bytes < need) {
         set_error("dss_render_backward: workspace %zu bytes < required %zu", workspace_bytes, need);
         return DSS_ERR_WORKSPACE;
@@ -999,13 +1036,17 @@ extern "C" int dss_render_backward(const float *grad_out, const int32_t *idx, co
     uint32_t *vis_count;  // small: PREP_MAX_SEG per-segment counters; otherwise one global counter
     int32_t *vis_list;
     float *rs;
+    const size_t npix = (size_t)N * (row1 - row0) * S;
+    const float *alpha;
+    if (((uintptr_t)grad_out & 15u) && C == 3) { set_error("dss_render_backward: grad_out must be 16-byte aligned"); return DSS_ERR_INVALID_ARGUMENT; }
     if (small) {
-        const PrepLayout L = prep_layout(N, P);
+        const PrepLayout L = prep_layout(N, P, S);
         n_seg = L.chunks;
+        alpha = reinterpret_cast<const float *>(w + L.alpha);
         vis_count = reinterpret_cast<uint32_t *>(w + L.seg_count);
         vis_list = reinterpret_cast<int32_t *>(w + L.vis_list);
         rs = rs_out ? rs_out : reinterpret_cast<float *>(w + L.rs);
-        launch_prep(radii, visible, first_idx, num_pts, N, P, radii_s, rs, w, L, grad_pts, grad_feat, C, st);
+        launch_prep(radii, visible, first_idx, num_pts, N, P, radii_s, rs, w, L, grad_pts, grad_feat, C, grad_out, npix, st);
     } else {
         const size_t hist_bytes = (size_t)3 * N * MED_BINS * 4;
         uint32_t *hist = reinterpret_cast<uint32_t *>(w);
@@ -1014,6 +1055,11 @@ extern "C" int dss_render_backward(const float *grad_out, const int32_t *idx, co
         vis_list = reinterpret_cast<int32_t *>(w + off);
         off += align_up((size_t)P * 4, 256);
         rs = rs_out ? rs_out : reinterpret_cast<float *>(w + off);
+        off += align_up((size_t)N * 4, 256);
+        float *plane = reinterpret_cast<float *>(w + off);
+        alpha = plane;
+        hipLaunchKernelGGL(alpha_plane_kernel, dim3((unsigned)((npix + ALPHA_PIX_PER_WG - 1) / ALPHA_PIX_PER_WG)), dim3(1024),
+                           0, st, grad_out, plane, npix, C);
         if (hipMemsetAsync(hist, 0, hist_bytes + 256, st) != hipSuccess) return check_launch("memset render_backward");
         const unsigned blocks = (unsigned)((P + MED_PTS_PER_WG - 1) / MED_PTS_PER_WG);
         hipLaunchKernelGGL(visible_scan_kernel, dim3(blocks), dim3(MED_THREADS), 0, st, radii, visible, first_idx,
@@ -1045,7 +1091,7 @@ extern "C" int dss_render_backward(const float *grad_out, const int32_t *idx, co
     const unsigned pgrid = (unsigned)((P + 3) / 4 < cap ? (P + 3) / 4 : cap);
     const uint32_t large_waves = 6u * (uint32_t)n_cus * 4u;
 #define DSS_LAUNCH_RB(CC, SS)                                                                                          \
-    hipLaunchKernelGGL((render_backward_kernel<CC, SS>), dim3(pgrid), dim3(256), 0, st, grad_out, idx, qvalue, wsum,   \
+    hipLaunchKernelGGL((render_backward_kernel<CC, SS>), dim3(pgrid), dim3(256), 0, st, grad_out, alpha, idx, qvalue, wsum, \
                        scaler, points, radii, rs, first_idx, num_pts, vis_count, vis_list, n_seg, N, S, K, C, clip,    \
                        row0, row1 - row0, large_waves, grad_feat, grad_pts)
     if (C == 3) {

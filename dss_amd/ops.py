@@ -375,7 +375,7 @@ def render_backward(grad_out, idx, qvalue, wsum, scaler, points, radii, visible,
             gf = torch.empty((P, C), dtype=_f32, device=dev) if with_features else None
             gp = torch.empty((P, 3), dtype=_f32, device=dev)
         rs = torch.empty((N,), dtype=_f32, device=dev)
-        ws = _lib.workspace(dev, lib.dss_render_backward_workspace(N, P))
+        ws = _lib.workspace(dev, lib.dss_render_backward_workspace(N, P, S))
         rc = lib.dss_render_backward(_lib.ptr(grad_out), _lib.ptr(idx), _lib.ptr(qvalue), _lib.ptr(wsum),
                                      _lib.ptr(scaler), _lib.ptr(points), _lib.ptr(radii), _lib.ptr(vis),
                                      _lib.ptr(first), _lib.ptr(num), N, P, S, K, C, row0, row1, float(radii_s),

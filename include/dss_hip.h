@@ -227,13 +227,15 @@ DSS_API int dss_render_forward(const float *world, const float *normals, const f
  * dss_occ_backward + dss_clip_grad in five launches, with the per-point work done by persistent
  * wavefronts over the compacted list of visible points (the stand-alone kernels are bound by the
  * workgroup dispatch rate at DSS sizes).  No zbuf gradient; the occupancy gradient is the alpha channel
- * of grad_out (N,rows,S,C+1), read in place.  With a row band (multi-GPU) `visible` must be the union
+ * of grad_out (N,rows,S,C+1); it is first copied into a dense (N,rows,S) plane in the workspace (the
+ * occupancy gather reads ~30 x 30 pixel windows per visible point: at a 16-byte stride it is bound by
+ * L2 bandwidth, three quarters of every cache line fetched being colour gradient it does not need).  With a row band (multi-GPU) `visible` must be the union
  * over all ranks, the outputs are this band's partial sums, and clip must be <= 0 (clip after the
  * all-reduce with dss_clip_grad).
  * grad_feat may be NULL (rasterizer backward only).  grad_pts (P,3) and grad_feat (P,C) are fully
  * written.  Same results as the unfused entry points (same per-point arithmetic and reduction order).
  * ------------------------------------------------------------------------------------------- */
-DSS_API size_t dss_render_backward_workspace(int N, int64_t P);
+DSS_API size_t dss_render_backward_workspace(int N, int64_t P, int S);
 DSS_API int dss_render_backward(const float *grad_out, const int32_t *idx, const float *qvalue,
                                 const float *wsum, const float *scaler, const float *points,
                                 const float *radii, const uint8_t *visible, const int64_t *first_idx,
