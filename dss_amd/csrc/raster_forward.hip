@@ -38,8 +38,9 @@ namespace dss {
 // tiles.  Queue counter and flags live in the memset region of the tile counters.
 #define DSS_HEAVY_MAX 2048
 #define DSS_HEAVY_SUB0 4
+#define DSS_HEAVY_QUEUES 32  // independent queue heads: ~1100 appends per launch on ONE counter serialise (+6 us)
 struct HeavyQ {
-    uint32_t *count;  // 1 word, zeroed with the tile counters (only the binning pass uses it)
+    uint32_t *count;  // DSS_HEAVY_QUEUES words, zeroed with the tile counters (only the binning pass uses them)
     int32_t *list;    // DSS_HEAVY_MAX slots holding tile id + 1, 0 = empty; zeroed with the tile counters
     uint8_t *flag;    // one byte per tile, zeroed with the tile counters
 };
@@ -87,7 +88,11 @@ __device__ __forceinline__ bool splat_tile_rect(float px, float py, float pz, fl
 __device__ __forceinline__ void mark_heavy(const HeavyQ hq, int tile)
 {
     if (!hq.count) return;
-    const uint32_t slot = atomicAdd(hq.count, 1u);
+    // queue q holds list slots q, q + QUEUES, q + 2 QUEUES, ...: workgroup b of the fine kernel reads slot b,
+    // so the queues drain interleaved
+    const uint32_t q = (uint32_t)tile & (DSS_HEAVY_QUEUES - 1);
+    const uint32_t pos = atomicAdd(&hq.count[q], 1u);
+    const uint32_t slot = pos * DSS_HEAVY_QUEUES + q;
     if (slot < DSS_HEAVY_MAX) {
         hq.list[slot] = tile + 1;  // 0 = empty slot
         hq.flag[tile] = 1;  // only queued tiles are flagged: a full queue leaves the rest to the normal workgroups
@@ -592,7 +597,7 @@ __global__ __launch_bounds__(FINE_THREADS) void fine_kernel(const FineArgs A)
     const bool clean = A.clean_counts != nullptr;
     int tile_id;
     if (A.heavy.count != nullptr) {
-        if (clean && blockIdx.x == 0 && threadIdx.x == 0) *A.heavy.count = 0;  // only the binning pass reads it
+        if (clean && blockIdx.x == 0 && threadIdx.x < DSS_HEAVY_QUEUES) A.heavy.count[threadIdx.x] = 0;  // binning-only state
         // the resets happen after a barrier: every thread of the workgroup must have read the value first
         if (blockIdx.x < DSS_HEAVY_MAX) {
             const int e = A.heavy.list[blockIdx.x];
