@@ -28,7 +28,7 @@ sys.path.insert(0, ROOT)
 
 from dss_amd import _lib, ops  # noqa: E402
 from dss_amd.cameras import FoVPerspectiveCameras, look_at_view_transform  # noqa: E402
-from dss_amd.distributed import ForwardExchange, RowPartition, gather_rows  # noqa: E402
+from dss_amd.distributed import OverlappedExchange, RowPartition, gather_rows  # noqa: E402
 
 S, K, THR, RADII_S, CLIP, CUTOFF, SIGMA = 512, 5, 0.05, 5.0, 0.05, 1.0, 1.0
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
@@ -76,8 +76,8 @@ class Workload:
         self.S = S
         if part.world_size > 1:
             # multi-GPU: the forward kernel writes its RGBA band and visibility flags straight into the
-            # all-gather send buffer; the backward writes both gradients into one all-reduce bucket
-            self.fx = ForwardExchange(part, self.N, 4, self.P, device)
+            # all-gather send buffers; the backward writes both gradients into one all-reduce bucket
+            self.fx = OverlappedExchange(part, self.N, 4, self.P, device)
             self.bucket = torch.empty(self.P * 6, device=device)
 
     def step(self):
@@ -97,16 +97,18 @@ class Workload:
             g_feat, g_pts = ops.render_backward(self.grad_out, idx, qv, wsum, info["scaler"], info["pts_screen"],
                                                 info["radii"], vis, self.first, self.num, RADII_S, CLIP)
         else:
-            # collective 1/2: RGBA bands + visibility flags in ONE all-gather
-            image, vis_all = self.fx.exchange(band)
+            # collectives 1-2/3: the RGBA bands leave on their own communicator and arrive during the backward;
+            # only the small visibility all-gather is waited for here
+            vis_all = self.fx.start()
             g_band = p.slice(self.grad_out).contiguous()
             g_feat = self.bucket[:self.P * 3].view(self.P, 3)
             g_pts = self.bucket[self.P * 3:].view(self.P, 3)
             # same fused kernel on the band; visibility = union over ranks, clip after the reduction
             ops.render_backward(g_band, idx, qv, wsum, info["scaler"], info["pts_screen"], info["radii"], vis_all,
                                 self.first, self.num, RADII_S, -1.0, image_size=S, rows=p.rows, out=(g_feat, g_pts))
-            dist.all_reduce(self.bucket, op=dist.ReduceOp.SUM)  # collective 2/2: both gradient partials, one bucket
+            dist.all_reduce(self.bucket, op=dist.ReduceOp.SUM)  # collective 3/3: both gradient partials, one bucket
             ops.clip_grad_(g_pts, CLIP)
+            image = self.fx.finish()  # full render, (N,S,S,4) view of the receive buffer
         g_world = ops.project_backward(self.world, self.M, self.V, self.first, self.num, g_pts, info["valid"], True)
         g_col = g_feat.view(self.N, self.Pc, 3).sum(0) if self.N > 1 else g_feat
         return image, g_world, g_col

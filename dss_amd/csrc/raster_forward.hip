@@ -191,6 +191,10 @@ struct FineArgs {
     const float *scaler, *feat;
     float *image, *wsum;
     int C;
+    // element strides of `image` over (camera, band row); a pixel's C+1 channels are contiguous and pixels of a
+    // row are contiguous.  Dense (N,rows,S,C+1): rows*S*(C+1) and S*(C+1).  The multi-GPU send buffer is laid out
+    // (row, camera, col, ch) so that the all-gathered bands ARE the full image, no reassembly copy.
+    long long img_sn, img_sr;
 };
 
 // block id -> tile id.  Identity on purpose.  Consecutive workgroup ids are dealt round-robin to the 8
@@ -370,10 +374,12 @@ __device__ __forceinline__ void fine_tile(const FineArgs &A, const int tile_id)
                 const size_t pix = ((size_t)n * g.rows + (size_t)ty * DSS_TILE + rr) * S + c0 + lane;
                 A.occ[pix] = 0.0f;
                 if (A.image) {  // fused blend of an empty pixel: zeros, weight sum clamped to kEpsilon
+                    float *o = A.image + (size_t)n * A.img_sn + (size_t)(ty * DSS_TILE + rr) * A.img_sr +
+                               (size_t)(c0 + lane) * (A.C + 1);
                     if (A.C == 3) {
-                        *reinterpret_cast<float4 *>(A.image + pix * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+                        *reinterpret_cast<float4 *>(o) = make_float4(0.f, 0.f, 0.f, 0.f);
                     } else {
-                        for (int ch = 0; ch <= A.C; ++ch) A.image[pix * (A.C + 1) + ch] = 0.0f;
+                        for (int ch = 0; ch <= A.C; ++ch) o[ch] = 0.0f;
                     }
                     A.wsum[pix] = 1e-4f;
                 }
@@ -516,7 +522,7 @@ __device__ __forceinline__ void fine_tile(const FineArgs &A, const int tile_id)
             }
             if (cum < 1e-4f) cum = 1e-4f;
             A.wsum[pix] = cum;
-            float *o = A.image + pix * (A.C + 1);
+            float *o = A.image + (size_t)n * A.img_sn + (size_t)(r - g.row0) * A.img_sr + (size_t)c * (A.C + 1);
             if (A.C == 3) {
                 // RGBA as ONE 16-byte store per pixel (four dword stores at a 16-byte stride quadruple the
                 // write requests the memory side sees)
@@ -872,6 +878,7 @@ static int splat_fine_impl(const float *points, const float *ellipse, const floa
     A.idx = idx; A.zbuf = zbuf; A.qv = qvalue; A.occ = occ; A.visible = visible;
     A.g = g; A.N = N; A.K = K; A.thr = merge_thr;
     A.scaler = scaler; A.feat = feat; A.image = image; A.wsum = wsum; A.C = C;
+    A.img_sn = (long long)g.rows * S * (C + 1); A.img_sr = (long long)S * (C + 1);
     if (workspace && P > 0) {
         if (workspace_bytes < dss_splat_forward_workspace(N, P, S, K, 1)) {
             set_error("dss_splat_fine: workspace too small");
@@ -956,8 +963,9 @@ extern "C" int dss_render_forward(const float *world, const float *normals, cons
                                   float merge_thr, int row0, int row1, const float *feat, int C,
                                   float *pts_screen, float *ellipse, float *radii, float *scaler, float *cutoff,
                                   uint8_t *valid, int32_t *idx, float *zbuf, float *qvalue, float *occ,
-                                  uint8_t *visible, float *image, float *wsum, void *workspace, size_t workspace_bytes,
-                                  int workspace_state, void *stream)
+                                  uint8_t *visible, float *image, int64_t image_cam_stride, int64_t image_row_stride,
+                                  float *wsum, void *workspace, size_t workspace_bytes, int workspace_state,
+                                  void *stream)
 {
     int rc = validate_fwd("dss_render_forward", N, P, S, K, row0, row1);
     if (rc) return rc;
@@ -1006,6 +1014,8 @@ extern "C" int dss_render_forward(const float *world, const float *normals, cons
     A.idx = idx; A.zbuf = zbuf; A.qv = qvalue; A.occ = occ; A.visible = visible;
     A.g = g; A.N = N; A.K = K; A.thr = merge_thr;
     A.scaler = scaler; A.feat = feat; A.image = image; A.wsum = wsum; A.C = C;
+    A.img_sn = image_cam_stride > 0 ? image_cam_stride : (long long)g.rows * S * (C + 1);
+    A.img_sr = image_row_stride > 0 ? image_row_stride : (long long)S * (C + 1);
     if (!dispatch_fine(A, N * tiles, st)) { set_error("dss_render_forward: no kernel for K=%d", K); return DSS_ERR_UNSUPPORTED; }
     return check_launch("dss_render_forward");
 }

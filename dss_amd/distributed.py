@@ -118,6 +118,59 @@ class ForwardExchange:
         return full[:, :part.S], self.recv[:, self.nb:].max(dim=0).values
 
 
+class OverlappedExchange:
+    """End-of-forward exchanges arranged for overlap with the backward (bench.py, multi-GPU):
+
+    * visibility flags (P bytes per rank) -- a small all-gather on ``group``; the backward needs the union
+      before its first kernel (``rs`` is the median radius of the GLOBALLY visible points), so this one is
+      on the critical path and latency-bound;
+    * RGBA bands (N * band * S * ch * 4 bytes per rank, 4 MB at 8 cameras x 512^2) -- an ASYNCHRONOUS
+      all-gather on ``image_group``, a second process group (= its own RCCL communicator, so it neither
+      orders with nor blocks the gradient all-reduce); it completes while the backward runs and is
+      awaited at the end of the step (``finish``).
+
+    The send buffer is laid out (band row, camera, col, channel): the rows a rank owns are contiguous for
+    ALL cameras, so the gathered buffer is the full image in (row, camera, col, channel) order and is handed
+    out as an (N, S, S, ch) strided view -- no reassembly copy (the (G, N, band, ...) layout needed a
+    32 MB permute at 8 cameras).  ``image`` is the (N, rows, S, ch) view the forward kernel writes through
+    (``ops.render_forward(out_image=...)`` takes camera / row strides)."""
+
+    def __init__(self, part: RowPartition, n_images: int, channels: int, num_points: int, device, group=None,
+                 image_group=None):
+        self.part, self.group = part, group
+        self.image_group = image_group
+        if image_group is None and part.world_size > 1 and dist.is_initialized():
+            self.image_group = dist.new_group()  # collective: every rank constructs its exchange
+        G, band, S = part.world_size, part.band, part.S
+        self.send_img = torch.zeros((band, n_images, S, channels), dtype=torch.float32, device=device)
+        self.recv_img = torch.empty((G * band, n_images, S, channels), dtype=torch.float32, device=device)
+        rows = part.row1 - part.row0
+        self.image = self.send_img[:rows].permute(1, 0, 2, 3)  # (N, rows, S, ch), strided
+        self.visible = torch.zeros(num_points, dtype=torch.uint8, device=device)
+        self.recv_vis = torch.empty((G, num_points), dtype=torch.uint8, device=device)
+        self._work = None
+
+    @staticmethod
+    def _all_gather(out2d: torch.Tensor, send: torch.Tensor, group, async_op: bool):
+        if dist.get_backend(group) == "gloo":  # CPU tests; gloo has no all_gather_into_tensor
+            return dist.all_gather(list(out2d.unbind(0)), send, group=group, async_op=async_op)
+        return dist.all_gather_into_tensor(out2d, send, group=group, async_op=async_op)
+
+    def start(self) -> torch.Tensor:
+        """Issue both exchanges; returns the union of the visibility flags, uint8 (P,)."""
+        G = self.part.world_size
+        self._work = self._all_gather(self.recv_img.view(G, -1), self.send_img.view(-1), self.image_group, True)
+        self._all_gather(self.recv_vis, self.visible, self.group, False)
+        return self.recv_vis.max(dim=0).values
+
+    def finish(self) -> torch.Tensor:
+        """Wait for the image bands; returns the full render (N, S, S, ch) (strided view of the receive buffer)."""
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
+        return self.recv_img[:self.part.S].permute(1, 0, 2, 3)
+
+
 class GatherRows(torch.autograd.Function):
     """Differentiable ``gather_rows``.  Every rank evaluates the same loss on the same full image, so
     the gradient of the local band is simply its slice of the full-image gradient (no collective)."""

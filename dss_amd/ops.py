@@ -317,9 +317,12 @@ def render_forward(world, normals, h, M, V, znear, zfar, cloud_to_packed_first_i
                  image=e(N, nr, S, C + 1) if out_image is None else out_image, wsum=e(N, nr, S))
         valid = e(P, dtype=_u8)
         vis = e(P, dtype=_u8) if out_visible is None else out_visible
-        if tuple(o["image"].shape) != (N, nr, S, C + 1) or o["image"].dtype != _f32 or not o["image"].is_contiguous() \
-                or o["image"].data_ptr() % 16 or tuple(vis.shape) != (P,) or vis.dtype != _u8:
-            raise RuntimeError("out_image must be contiguous float32 (N,rows,S,C+1), 16-byte aligned; out_visible uint8 (P,)")
+        img = o["image"]
+        if tuple(img.shape) != (N, nr, S, C + 1) or img.dtype != _f32 or img.data_ptr() % 16 \
+                or img.stride(3) != 1 or img.stride(2) != C + 1 or img.stride(0) % 4 or img.stride(1) % 4 \
+                or tuple(vis.shape) != (P,) or vis.dtype != _u8:
+            raise RuntimeError("out_image must be float32 (N,rows,S,C+1), 16-byte aligned, with contiguous rows "
+                               "(any camera / row strides that are multiples of 4 floats); out_visible uint8 (P,)")
         # dedicated zero-initialised buffer per problem size: the library keeps it clean (no memset launch)
         tag = ("render_forward", N, P, S)
         ws = _lib.clean_workspace(dev, tag, lib.dss_render_forward_workspace(N, P, S, K))
@@ -330,7 +333,8 @@ def render_forward(world, normals, h, M, V, znear, zfar, cloud_to_packed_first_i
             float(depth_merging_thres), row0, row1, _lib.ptr(features), C, _lib.ptr(o["pts_screen"]),
             _lib.ptr(o["ellipse_params"]), _lib.ptr(o["radii"]), _lib.ptr(o["scaler"]), _lib.ptr(o["cutoff_threshold"]),
             _lib.ptr(valid), _lib.ptr(o["idx"]), _lib.ptr(o["zbuf"]), _lib.ptr(o["qvalue"]), _lib.ptr(o["occupancy"]),
-            _lib.ptr(vis), _lib.ptr(o["image"]), _lib.ptr(o["wsum"]), _lib.ptr(ws), ws.numel(), 1, _lib.stream_ptr(dev))
+            _lib.ptr(vis), _lib.ptr(img), int(img.stride(0)), int(img.stride(1)), _lib.ptr(o["wsum"]), _lib.ptr(ws),
+            ws.numel(), 1, _lib.stream_ptr(dev))
         if rc:
             _lib.drop_clean_workspace(dev, tag)
     _lib.check(rc, "dss_render_forward")

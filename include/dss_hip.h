@@ -201,6 +201,10 @@ DSS_API int dss_blend_backward_scatter(const float *grad_out, const int32_t *idx
  * screen-space arrays, the fragments, visibility, the (N,rows,S,C+1) image and wsum), same bits.
  * K <= DSS_MAX_K_FAST, 1 <= C <= 8.
  *
+ * image_cam_stride / image_row_stride: element strides of `image` over (camera, band row); 0, 0 = dense
+ * (N,rows,S,C+1).  A pixel's C+1 channels and the pixels of a row are always contiguous.  The multi-GPU layer
+ * passes a (row, camera, col, channel) send buffer so that the all-gathered bands are the full image.
+ *
  * workspace_state: DSS_WS_UNKNOWN (0) -- contents arbitrary: the call zeroes the tile counters itself (one
  * memset launch).  DSS_WS_CLEAN (1) -- the caller guarantees that the first dss_render_forward_workspace()
  * bytes are either zero-filled (once, after allocation) or were left by a previous SUCCESSFUL
@@ -219,7 +223,8 @@ DSS_API int dss_render_forward(const float *world, const float *normals, const f
                                int row0, int row1, const float *feat /* (P,C) */, int C,
                                float *pts_screen, float *ellipse, float *radii, float *scaler,
                                float *cutoff, uint8_t *valid, int32_t *idx, float *zbuf, float *qvalue,
-                               float *occ, uint8_t *visible, float *image, float *wsum,
+                               float *occ, uint8_t *visible, float *image,
+                               int64_t image_cam_stride, int64_t image_row_stride, float *wsum,
                                void *workspace, size_t workspace_bytes, int workspace_state, void *stream);
 
 /* ---------------------------------------------------------------------------------------------

@@ -19,7 +19,7 @@ def _worker(rank, world, port, S, tmp):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle
     import scenes
-    from dss_amd.distributed import (ForwardExchange, GatherRows, RowPartition, gather_rows_and_visibility,
+    from dss_amd.distributed import (ForwardExchange, GatherRows, OverlappedExchange, RowPartition, gather_rows_and_visibility,
                                      reduce_grads_, reduce_visibility_)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -56,6 +56,17 @@ def _worker(rank, world, port, S, tmp):
             fx.visible.copy_(vis_band)
             img3, vis3 = fx.exchange(torch.from_numpy(full[:, r0:r1].copy()))
         assert torch.equal(img3, torch.from_numpy(full)) and torch.equal(vis3, vis)
+        # overlapped variant (bench.py): image bands on a second group, asynchronous; (row, camera, col, ch)
+        # send layout written through a strided (N, rows, S, ch) view; twice, to cover buffer reuse
+        ox = OverlappedExchange(part, 2, full.shape[-1], P, "cpu")
+        assert ox.image.shape == (2, r1 - r0, S, full.shape[-1]) and not ox.image.is_contiguous()
+        for rep in range(2):
+            ox.image.copy_(torch.from_numpy(full[:, r0:r1].copy()) * (rep + 1))
+            ox.visible.copy_(vis_band)
+            vis4 = ox.start()
+            assert torch.equal(vis4, vis)
+            img4 = ox.finish()
+            assert img4.shape == full.shape and torch.equal(img4, torch.from_numpy(full) * (rep + 1))
         rs = oracle.backward_radius(sc["radii"], vis.numpy(), sc["first_idx"], sc["num_pts"], 3.0)
         gocc = g_full[..., 3].numpy()
         masked = np.zeros_like(gocc)
