@@ -326,9 +326,16 @@ __global__ __launch_bounds__(MED_THREADS) void visible_scan_kernel(
 // or two exponent bytes and same-address LDS atomics serialise.
 // ---------------------------------------------------------------------------------------------
 #define PREP_THREADS 1024
-#define PREP_CHUNK 2048          // points per compaction segment
 #define PREP_MAX_SEG 64          // segments a wavefront can scan in registers
-#define PREP_MAX_POINTS (PREP_CHUNK * PREP_MAX_SEG)
+#define PREP_MAX_PER 8           // points per thread of the compaction kernel: 2, 4 or 8 -> segments of 2048..8192 points
+#define PREP_MAX_POINTS (PREP_MAX_PER * PREP_THREADS * PREP_MAX_SEG)   // 524,288
+// segment size for P points: the smallest of 2048 / 4096 / 8192 that needs at most PREP_MAX_SEG segments
+static inline int prep_points_per_thread(int64_t P)
+{
+    int per = 2;
+    while (per < PREP_MAX_PER && (int64_t)per * PREP_THREADS * PREP_MAX_SEG < P) per *= 2;
+    return per;
+}
 #define PREP_RES 32              // visible points per thread resident in registers in the median workgroup
 
 #ifdef DSS_FINE_TIMING
@@ -430,6 +437,7 @@ __global__ __launch_bounds__(1024) void alpha_plane_kernel(const float *__restri
     alpha_plane_body(blockIdx.x, blockDim.x, grad_out, plane, npix, C);
 }
 
+template <int PER>
 __global__ __launch_bounds__(PREP_THREADS) void backward_compact_kernel(
     const float *__restrict__ radii, const uint8_t *__restrict__ visible, const int64_t *__restrict__ first_idx,
     const int64_t *__restrict__ num_pts, int N, int64_t P, int chunks, uint32_t *__restrict__ seg_count,
@@ -441,7 +449,7 @@ __global__ __launch_bounds__(PREP_THREADS) void backward_compact_kernel(
         alpha_plane_body(blockIdx.x - chunks, PREP_THREADS, grad_out, alpha_plane, npix, C);
         return;
     }
-    constexpr int PER = PREP_CHUNK / PREP_THREADS;
+    constexpr int PREP_CHUNK = PER * PREP_THREADS;
     __shared__ uint32_t lh[256 * 32];
     __shared__ uint32_t s_w[PER * PREP_THREADS / 64];
     __shared__ uint32_t s_rng[2];
@@ -529,7 +537,7 @@ __global__ __launch_bounds__(PREP_THREADS) void backward_compact_kernel(
 }
 
 __global__ __launch_bounds__(PREP_THREADS) void median_visible_kernel(
-    const int64_t *__restrict__ first_idx, const int64_t *__restrict__ num_pts, int64_t P, int chunks,
+    const int64_t *__restrict__ first_idx, const int64_t *__restrict__ num_pts, int64_t P, int chunks, int seg_pts,
     const uint2 *__restrict__ seg_range, const uint2 *__restrict__ vis_keys, const uint32_t *__restrict__ chunk_hist,
     float radii_s, float *__restrict__ rs)
 {
@@ -545,7 +553,7 @@ __global__ __launch_bounds__(PREP_THREADS) void median_visible_kernel(
         if (tid == 0) rs[n] = 0.0f;
         return;
     }
-    const int c_lo = (int)(f / PREP_CHUNK), c_hi = (int)((f + cnt - 1) / PREP_CHUNK);
+    const int c_lo = (int)(f / seg_pts), c_hi = (int)((f + cnt - 1) / seg_pts);
     const int n_c = c_hi - c_lo + 1;  // <= PREP_MAX_SEG
     // ---- all global loads are issued up front: chunk histograms, segment ranges, then the keys ----
     const int hb = tid >> 2, hq = tid & 3;
@@ -577,7 +585,7 @@ __global__ __launch_bounds__(PREP_THREADS) void median_visible_kernel(
                     const int seg = (int)__popcll(__ballot(slot_incl <= g));  // first segment with incl > g
                     const uint32_t off = (g - (uint32_t)__builtin_amdgcn_readlane((int)slot_excl, seg)) * 64u + lane;
                     if (off < (uint32_t)__builtin_amdgcn_readlane((int)seg_cnt, seg)) {
-                        kk[u] = vis_keys[(size_t)(c_lo + seg) * PREP_CHUNK +
+                        kk[u] = vis_keys[(size_t)(c_lo + seg) * seg_pts +
                                          (uint32_t)__builtin_amdgcn_readlane((int)seg_start, seg) + off];
                         vm |= 1u << u;
                     }
@@ -649,8 +657,8 @@ __global__ __launch_bounds__(256) void render_backward_kernel(
     const float *__restrict__ wsum, const float *__restrict__ scaler, const float *__restrict__ points,
     const float *__restrict__ radii, const float *__restrict__ rs, const int64_t *__restrict__ first_idx,
     const int64_t *__restrict__ num_pts, const uint32_t *__restrict__ vis_count,
-    const int32_t *__restrict__ vis_list, int n_seg, int N, int S, int K, int Crt, float clip, int row0, int rows,
-    uint32_t large_waves, float *__restrict__ grad_feat, float *__restrict__ grad_pts)
+    const int32_t *__restrict__ vis_list, int n_seg, int seg_pts, int N, int S, int K, int Crt, float clip, int row0,
+    int rows, uint32_t large_waves, float *__restrict__ grad_feat, float *__restrict__ grad_pts)
 {
     constexpr int CM = (C > 0) ? C : BLEND_MAX_C;
     const int Cn = (C > 0) ? C : Crt;
@@ -692,7 +700,7 @@ __global__ __launch_bounds__(256) void render_backward_kernel(
             // share their successor's start and lose the tie)
             const int seg = (int)__popcll(__ballot(seg_excl <= t)) - 1;
             const uint32_t excl = (uint32_t)__builtin_amdgcn_readlane((int)seg_excl, seg);
-            return vis_list[(size_t)seg * PREP_CHUNK + (t - excl)];
+            return vis_list[(size_t)seg * seg_pts + (t - excl)];
         }
         return vis_list[t];
     };
@@ -828,13 +836,15 @@ using namespace dss;
 // Workspace of the two-launch preparation (P <= PREP_MAX_POINTS), relative to its own base.
 struct PrepLayout {
     size_t seg_count, vis_list, vis_keys, chunk_hist, seg_range, rs, alpha, bytes;
-    int chunks;
+    int chunks, per;  // segments, points per thread of the compaction kernel (segment = per * 1024 points)
 };
 static PrepLayout prep_layout(int N, int64_t P, int S)
 {
     PrepLayout L;
     const size_t n = N > 0 ? N : 1, p = P > 0 ? (size_t)P : 1;
-    L.chunks = (int)((p + PREP_CHUNK - 1) / PREP_CHUNK);
+    L.per = prep_points_per_thread(P);
+    const size_t seg = (size_t)L.per * PREP_THREADS;
+    L.chunks = (int)((p + seg - 1) / seg);
     size_t off = 0;
     L.seg_count = off;  off += 256;                                              // PREP_MAX_SEG counters
     L.vis_list = off;   off += align_up(p * 4, 256);
@@ -858,11 +868,16 @@ static void launch_prep(const float *radii, const uint8_t *visible, const int64_
     uint2 *vis_keys = reinterpret_cast<uint2 *>(w + L.vis_keys);
     uint32_t *chunk_hist = reinterpret_cast<uint32_t *>(w + L.chunk_hist);
     uint2 *seg_range = reinterpret_cast<uint2 *>(w + L.seg_range);
-    hipLaunchKernelGGL(backward_compact_kernel, dim3(L.chunks + alpha_wgs), dim3(PREP_THREADS), 0, st, radii, visible,
-                       first_idx, num_pts, N, P, L.chunks, seg_count, vis_list, vis_keys, chunk_hist, seg_range, grad_pts,
-                       grad_feat, C, grad_out, alpha, npix);
+#define DSS_LAUNCH_COMPACT(PER_)                                                                                       \
+    hipLaunchKernelGGL(backward_compact_kernel<PER_>, dim3(L.chunks + alpha_wgs), dim3(PREP_THREADS), 0, st, radii,       \
+                       visible, first_idx, num_pts, N, P, L.chunks, seg_count, vis_list, vis_keys, chunk_hist, seg_range, \
+                       grad_pts, grad_feat, C, grad_out, alpha, npix)
+    if (L.per == 2) DSS_LAUNCH_COMPACT(2);
+    else if (L.per == 4) DSS_LAUNCH_COMPACT(4);
+    else DSS_LAUNCH_COMPACT(8);
+#undef DSS_LAUNCH_COMPACT
     hipLaunchKernelGGL(median_visible_kernel, dim3(N), dim3(PREP_THREADS), 0, st, first_idx, num_pts, P, L.chunks,
-                       seg_range, vis_keys, chunk_hist, radii_s, rs);
+                       L.per * PREP_THREADS, seg_range, vis_keys, chunk_hist, radii_s, rs);
 }
 
 extern "C" size_t dss_backward_radius_workspace(int N, int64_t P)
@@ -1032,7 +1047,7 @@ extern "C" int dss_render_backward(const float *grad_out, const int32_t *idx, co
     hipStream_t st = as_stream(stream);
     char *w = reinterpret_cast<char *>(workspace);
     const bool small = P <= PREP_MAX_POINTS;
-    int n_seg = 0;
+    int n_seg = 0, seg_pts = 0;
     uint32_t *vis_count;  // small: PREP_MAX_SEG per-segment counters; otherwise one global counter
     int32_t *vis_list;
     float *rs;
@@ -1042,6 +1057,7 @@ extern "C" int dss_render_backward(const float *grad_out, const int32_t *idx, co
     if (small) {
         const PrepLayout L = prep_layout(N, P, S);
         n_seg = L.chunks;
+        seg_pts = L.per * PREP_THREADS;
         alpha = reinterpret_cast<const float *>(w + L.alpha);
         vis_count = reinterpret_cast<uint32_t *>(w + L.seg_count);
         vis_list = reinterpret_cast<int32_t *>(w + L.vis_list);
@@ -1092,7 +1108,7 @@ extern "C" int dss_render_backward(const float *grad_out, const int32_t *idx, co
     const uint32_t large_waves = 6u * (uint32_t)n_cus * 4u;
 #define DSS_LAUNCH_RB(CC, SS)                                                                                          \
     hipLaunchKernelGGL((render_backward_kernel<CC, SS>), dim3(pgrid), dim3(256), 0, st, grad_out, alpha, idx, qvalue, wsum, \
-                       scaler, points, radii, rs, first_idx, num_pts, vis_count, vis_list, n_seg, N, S, K, C, clip,    \
+                       scaler, points, radii, rs, first_idx, num_pts, vis_count, vis_list, n_seg, seg_pts, N, S, K, C, clip, \
                        row0, row1 - row0, large_waves, grad_feat, grad_pts)
     if (C == 3) {
         if (small) DSS_LAUNCH_RB(3, true); else DSS_LAUNCH_RB(3, false);
