@@ -327,9 +327,10 @@ __global__ __launch_bounds__(MED_THREADS) void visible_scan_kernel(
 // ---------------------------------------------------------------------------------------------
 #define PREP_THREADS 1024
 #define PREP_MAX_SEG 64          // segments a wavefront can scan in registers
-#define PREP_MAX_PER 8           // points per thread of the compaction kernel: 2, 4 or 8 -> segments of 2048..8192 points
-#define PREP_MAX_POINTS (PREP_MAX_PER * PREP_THREADS * PREP_MAX_SEG)   // 524,288
-// segment size for P points: the smallest of 2048 / 4096 / 8192 that needs at most PREP_MAX_SEG segments
+#define PREP_MAX_PER 4           // points per thread of the compaction kernel: 2 or 4 -> segments of 2048 / 4096 points
+                                 // (8 per thread needs > 128 VGPRs at 1024 threads: spills)
+#define PREP_MAX_POINTS (PREP_MAX_PER * PREP_THREADS * PREP_MAX_SEG)   // 262,144
+// segment size for P points: the smallest of 2048 / 4096 that needs at most PREP_MAX_SEG segments
 static inline int prep_points_per_thread(int64_t P)
 {
     int per = 2;
@@ -458,15 +459,25 @@ __global__ __launch_bounds__(PREP_THREADS) void backward_compact_kernel(
     const int64_t c0 = (int64_t)chunk * PREP_CHUNK;
     const int64_t c1 = min(c0 + PREP_CHUNK, P);
     PREP_MARK(0);
-    uint8_t vis[PER];
+    uint32_t vmask = 0;  // bit u: point c0 + tid + u * 1024 is visible
     uint2 kk[PER];
+    {
+        // unconditional loads from clamped addresses (a bounds branch around each load made the compiler wait
+        // for every load in turn and spill), all in flight together
+        uint8_t vb[PER];
+        float2 rr[PER];
 #pragma unroll
-    for (int u = 0; u < PER; ++u) {
-        const int64_t i = c0 + tid + (int64_t)u * PREP_THREADS;
-        const bool in = i < c1;
-        vis[u] = in ? visible[i] : (uint8_t)0;
-        const float2 r = in ? reinterpret_cast<const float2 *>(radii)[i] : make_float2(0.f, 0.f);
-        kk[u] = make_uint2(float_key(r.x), float_key(r.y));
+        for (int u = 0; u < PER; ++u) {
+            const int64_t ic = min(c0 + tid + (int64_t)u * PREP_THREADS, P - 1);
+            vb[u] = visible[ic];
+            rr[u] = reinterpret_cast<const float2 *>(radii)[ic];
+        }
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const bool in = c0 + tid + (int64_t)u * PREP_THREADS < c1;
+            vmask |= ((in && vb[u] != 0) ? 1u : 0u) << u;
+            kk[u] = make_uint2(float_key(rr[u].x), float_key(rr[u].y));
+        }
     }
     for (int i = tid; i < 256 * 32; i += PREP_THREADS) lh[i] = 0;
     // order-preserving ranks (entries of a segment are sorted by point id, so the entries of one cloud are a
@@ -474,7 +485,7 @@ __global__ __launch_bounds__(PREP_THREADS) void backward_compact_kernel(
     uint32_t rank[PER];
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
-        const unsigned long long m = __ballot(vis[u] != 0);
+        const unsigned long long m = __ballot((vmask >> u) & 1u);
         rank[u] = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
         if (lane == 0) s_w[u * (PREP_THREADS / 64) + wid] = (uint32_t)__popcll(m);
     }
@@ -495,7 +506,7 @@ __global__ __launch_bounds__(PREP_THREADS) void backward_compact_kernel(
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
         const int64_t i = c0 + tid + (int64_t)u * PREP_THREADS;
-        if (vis[u]) {
+        if ((vmask >> u) & 1u) {
             vis_list[c0 + rank[u]] = (int32_t)i;
             vis_keys[c0 + rank[u]] = kk[u];
         } else if (i < c1 && grad_pts) {
@@ -513,8 +524,9 @@ __global__ __launch_bounds__(PREP_THREADS) void backward_compact_kernel(
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
             const int64_t i = c0 + tid + (int64_t)u * PREP_THREADS;
-            const bool mine = vis[u] && i >= lo && i < hi;
-            const unsigned long long mb = __ballot(vis[u] && i < lo), mi = __ballot(mine);
+            const bool vis_u = (vmask >> u) & 1u;
+            const bool mine = vis_u && i >= lo && i < hi;
+            const unsigned long long mb = __ballot(vis_u && i < lo), mi = __ballot(mine);
             if (lane == 0) {
                 if (mb) atomicAdd(&s_rng[0], (uint32_t)__popcll(mb));
                 if (mi) atomicAdd(&s_rng[1], (uint32_t)__popcll(mi));
@@ -873,8 +885,7 @@ static void launch_prep(const float *radii, const uint8_t *visible, const int64_
                        visible, first_idx, num_pts, N, P, L.chunks, seg_count, vis_list, vis_keys, chunk_hist, seg_range, \
                        grad_pts, grad_feat, C, grad_out, alpha, npix)
     if (L.per == 2) DSS_LAUNCH_COMPACT(2);
-    else if (L.per == 4) DSS_LAUNCH_COMPACT(4);
-    else DSS_LAUNCH_COMPACT(8);
+    else DSS_LAUNCH_COMPACT(4);
 #undef DSS_LAUNCH_COMPACT
     hipLaunchKernelGGL(median_visible_kernel, dim3(N), dim3(PREP_THREADS), 0, st, first_idx, num_pts, P, L.chunks,
                        L.per * PREP_THREADS, seg_range, vis_keys, chunk_hist, radii_s, rs);

@@ -395,13 +395,13 @@ def test_render_backward_row_bands_sum_to_full():
     ((100000, 31072), 0.25, "lognormal"),   # 131072 points = 64 segments of 2048
     ((120000, 11000), 0.9, "lognormal"),    # > 32768 visible points in one cloud: keys re-streamed per pass
     ((131073,), 0.25, "wide"),              # one past it: segments of 4096 points
-    ((300000, 224288), 0.3, "lognormal"),   # 524288 points = 64 segments of 8192: upper edge of the two-launch path
-    ((524289,), 0.2, "wide"),               # one past it: multi-kernel radix select
+    ((200000, 62144), 0.3, "lognormal"),    # 262144 points = 64 segments of 4096: upper edge of the two-launch path
+    ((262145,), 0.2, "wide"),               # one past it: multi-kernel radix select
     ((4096, 4096), 0.0, "lognormal"),       # nothing visible: rs = 0
 ])
 def test_backward_radius_and_compaction_sizes(sizes, frac, dist):
     """Median radius (rasterizer.py:885-888) through BOTH device paths (two-launch compaction + register/LDS radix
-    select for P <= 524288, multi-kernel select above) against the oracle, bit for bit, at their size boundaries; and
+    select for P <= 262144, multi-kernel select above) against the oracle, bit for bit, at their size boundaries; and
     the fused backward's compaction (every visible point gets a gradient row, every invisible one zeros)."""
     rng = np.random.default_rng(sum(sizes) + len(sizes))
     P = int(sum(sizes))
