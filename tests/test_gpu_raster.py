@@ -441,3 +441,32 @@ def test_backward_radius_and_compaction_sizes(sizes, frac, dist):
     gn = g.cpu().numpy()
     assert (gn[vis == 0] == 0).all() and (gf.cpu().numpy()[vis == 0] == 0).all()
     assert _rel_l2(gn[:, :2], o_g) <= 1e-5
+
+
+@pytest.mark.parametrize("K,C,rmax", [(1, 3, 2.5), (8, 1, 2.5), (12, 3, 2.5), (5, 5, 14.0), (3, 3, 40.0)])
+def test_render_backward_fragment_depths_channels_and_splat_sizes(K, C, rmax):
+    """Fused backward vs the oracle outside the benchmark shape: K = 1 / 8 (register path of the prefetched blend
+    pixel) / 12 (generic blend path), C != 3 (runtime channel count), splats larger than one sweep of the
+    wavefront (bounding boxes of up to 80 pixels: multi-step blend gather, multi-column occupancy window)."""
+    sc = scenes.random_splats(1500, 128, 2, seed=31 + K, rmin=1.0, rmax=rmax)
+    d = _dev(sc)
+    idx, zbuf, qv, occ, vis = _fwd(d, 128, K, 0.3, return_visible=True)
+    P = sc["points"].shape[0]
+    rng = np.random.default_rng(K * 10 + C)
+    feat_np = rng.random((P, C)).astype(np.float32)
+    scaler = torch.from_numpy(sc["scaler"]).to(DEV)
+    img, wsum = ops.blend_forward(idx, qv, occ, scaler, torch.from_numpy(feat_np).to(DEV), return_wsum=True)
+    assert img.shape[-1] == C + 1
+    go = torch.randn_like(img)
+    gf, g, rs = ops.render_backward(go, idx, qv, wsum, scaler, d["points"], d["radii"], vis, d["first"], d["num"],
+                                    3.0, 0.05, return_rs=True)
+    o_g, o_vis, o_rs = oracle.splat_backward(sc["points"], sc["radii"], idx.cpu().numpy(), go[..., C].cpu().numpy(),
+                                             None, sc["first_idx"], sc["num_pts"], 3.0, 0.05)
+    o_gf, _ = oracle.blend_backward(go.cpu().numpy(), idx.cpu().numpy(), qv.cpu().numpy(), sc["scaler"], P)
+    assert np.array_equal(rs.cpu().numpy(), o_rs)
+    assert _rel_l2(g.cpu().numpy(), o_g) <= 1e-4 and _rel_l2(gf.cpu().numpy(), o_gf) <= 1e-4
+    # and the unfused entry points give the same bits
+    geom = (d["points"], d["radii"], vis, d["first"], d["num"])
+    gf_ref, gocc = ops.blend_backward(go, idx, qv, scaler, P, geometry=geom, wsum=wsum)
+    g_ref = ops.splat_backward(d["points"], d["radii"], vis, idx, gocc, None, d["first"], d["num"], 3.0, 0.05)
+    assert torch.equal(gf, gf_ref) and torch.equal(g, g_ref)
