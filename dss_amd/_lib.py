@@ -49,6 +49,7 @@ SIGNATURES = {
                             + [_c_vp] * 3 + [_c_vp, _c_sz, _c_vp]),
     "dss_knn_workspace": (_c_sz, [_c_int, _c_i64]),
     "dss_knn_kth_sqdist": (_c_int, [_c_vp] * 3 + [_c_int, _c_i64, _c_int, _c_vp, _c_vp, _c_sz, _c_vp]),
+    "dss_knn_points": (_c_int, [_c_vp] * 3 + [_c_int, _c_i64, _c_int, _c_vp, _c_vp, _c_vp, _c_sz, _c_vp]),
     "dss_cloud_mean_clamp": (_c_int, [_c_vp] * 3 + [_c_int, _c_f32, _c_f32, _c_f32, _c_f32, _c_int, _c_vp, _c_vp]),
     "dss_blend_forward": (_c_int, [_c_vp] * 5 + [_c_int] * 5 + [_c_vp, _c_vp, _c_vp]),
     "dss_point_setup": (_c_int, [_c_vp] * 10 + [_c_int, _c_i64, _c_int, _c_int, _c_int, _c_f32, _c_f32]

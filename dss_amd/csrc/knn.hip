@@ -174,17 +174,28 @@ __global__ __launch_bounds__(256) void knn_fill_kernel(const float *__restrict__
     sorted[first_idx[n] + pos] = make_float4(pts[3 * p], pts[3 * p + 1], pts[3 * p + 2], __int_as_float((int)p));
 }
 
-template <int K>
+// FULL = false: K-th squared distance only (kth_sqdist (P,)).  FULL = true: the whole neighbour list, ascending in
+// (distance, id): dists (P,Krt) squared distances and idx (P,Krt) cloud-local ids, zero-padded when the cloud has
+// fewer than Krt points (the layout pytorch3d.ops.knn_points returns for a self query, losses.py:157-180).
+template <int K, bool FULL>
 __global__ __launch_bounds__(256) void knn_query_kernel(const float *__restrict__ pts, const int64_t *__restrict__ first_idx,
                                                         const int64_t *__restrict__ num_pts, int N, int64_t P,
                                                         const KnnGrid *__restrict__ grids, const uint32_t *__restrict__ offsets,
                                                         const float4 *__restrict__ sorted, int Krt,
-                                                        float *__restrict__ kth_sqdist)
+                                                        float *__restrict__ kth_sqdist, float *__restrict__ dists,
+                                                        int64_t *__restrict__ idx)
 {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= P) return;
     const int n = find_cloud(p, first_idx, num_pts, N);
-    if (n < 0) { kth_sqdist[p] = 0.0f; return; }
+    if (n < 0) {
+        if (FULL) {
+            for (int k = 0; k < Krt; ++k) { dists[p * Krt + k] = 0.0f; idx[p * Krt + k] = 0; }
+        } else {
+            kth_sqdist[p] = 0.0f;
+        }
+        return;
+    }
     const KnnGrid g = grids[n];
     const int64_t f0 = first_idx[n];
     const int64_t cnt_n = num_pts[n];
@@ -194,10 +205,16 @@ __global__ __launch_bounds__(256) void knn_query_kernel(const float *__restrict_
     const int cy = cell_coord(qy, g.miny, g.inv_cell, g.res);
     const int cz = cell_coord(qz, g.minz, g.inv_cell, g.res);
     float best[K];
+    int bid[FULL ? K : 1];
 #pragma unroll
     for (int k = 0; k < K; ++k) best[k] = __builtin_huge_valf();
+#pragma unroll
+    for (int k = 0; k < (FULL ? K : 1); ++k) bid[k] = 0x7fffffff;
     const int kk = (int)min((int64_t)Krt, cnt_n);  // fewer points than K: k-th = farthest available
-    if (kk <= 0) { kth_sqdist[p] = 0.0f; return; }
+    if (kk <= 0) {
+        if (!FULL) kth_sqdist[p] = 0.0f;
+        return;
+    }
     for (int ring = 0; ring < g.res; ++ring) {
         const int x0 = max(cx - ring, 0), x1 = min(cx + ring, g.res - 1);
         const int y0 = max(cy - ring, 0), y1 = min(cy + ring, g.res - 1);
@@ -214,7 +231,22 @@ __global__ __launch_bounds__(256) void knn_query_kernel(const float *__restrict_
                         const float4 q = sorted[f0 + j];
                         const float dx = q.x - qx, dy = q.y - qy, dz = q.z - qz;
                         const float d2 = dx * dx + dy * dy + dz * dz;
-                        if (d2 < best[K - 1]) {
+                        if (FULL) {
+                            // total order (distance, id): deterministic lists whatever the cell order
+                            const int id = __float_as_int(q.w);
+                            if (d2 < best[K - 1] || (d2 == best[K - 1] && id < bid[K - 1])) {
+                                bool lt[K];
+#pragma unroll
+                                for (int k = 0; k < K; ++k) lt[k] = d2 < best[k] || (d2 == best[k] && id < bid[k]);
+#pragma unroll
+                                for (int k = K - 1; k >= 1; --k) {
+                                    best[k] = lt[k - 1] ? best[k - 1] : (lt[k] ? d2 : best[k]);
+                                    bid[k] = lt[k - 1] ? bid[k - 1] : (lt[k] ? id : bid[k]);
+                                }
+                                best[0] = lt[0] ? d2 : best[0];
+                                bid[0] = lt[0] ? id : bid[0];
+                            }
+                        } else if (d2 < best[K - 1]) {
 #pragma unroll
                             for (int k = K - 1; k >= 1; --k) {
                                 const bool sh = d2 < best[k - 1];
@@ -240,6 +272,15 @@ __global__ __launch_bounds__(256) void knn_query_kernel(const float *__restrict_
 #pragma unroll
         for (int k = 1; k < K; ++k) kth = (k < kk) ? best[k] : kth;
         if (bound == __builtin_huge_valf() || (bound > 0.0f && kth <= bound * bound)) break;
+    }
+    if (FULL) {
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+            if (k < Krt) {
+                dists[p * Krt + k] = k < kk ? best[k] : 0.0f;
+                idx[p * Krt + k] = k < kk ? (int64_t)bid[k] - f0 : 0;
+            }
+        return;
     }
     float kth = best[0];
 #pragma unroll
@@ -283,21 +324,25 @@ extern "C" size_t dss_knn_workspace(int N, int64_t P)
            align_up(p * 4, 256) + align_up(p * 16, 256);
 }
 
-extern "C" int dss_knn_kth_sqdist(const float *points, const int64_t *first_idx, const int64_t *num_pts, int N,
-                                  int64_t P, int K, float *kth_sqdist, void *workspace, size_t workspace_bytes,
-                                  void *stream)
+#define KNN_FULL_MAX_K 40
+
+// grid build + query; exactly one of (kth_sqdist) / (dists, idx) is written
+static int knn_run(const char *who, const float *points, const int64_t *first_idx, const int64_t *num_pts, int N, int64_t P,
+                   int K, float *kth_sqdist, float *dists, int64_t *idx, void *workspace, size_t workspace_bytes,
+                   void *stream)
 {
-    if (N <= 0 || P < 0 || K < 1 || K > KNN_MAX_K) {
-        set_error("dss_knn_kth_sqdist: bad sizes N=%d P=%lld K=%d (K <= %d)", N, (long long)P, K, KNN_MAX_K);
+    const bool full = dists != nullptr;
+    if (N <= 0 || P < 0 || K < 1 || K > (full ? KNN_FULL_MAX_K : KNN_MAX_K)) {
+        set_error("%s: bad sizes N=%d P=%lld K=%d (K <= %d)", who, N, (long long)P, K, full ? KNN_FULL_MAX_K : KNN_MAX_K);
         return DSS_ERR_INVALID_ARGUMENT;
     }
     if (P == 0) return DSS_OK;
-    if (!points || !first_idx || !num_pts || !kth_sqdist) {
-        set_error("dss_knn_kth_sqdist: NULL tensor pointer");
+    if (!points || !first_idx || !num_pts || (!full && !kth_sqdist) || (full && !idx)) {
+        set_error("%s: NULL tensor pointer", who);
         return DSS_ERR_INVALID_ARGUMENT;
     }
     if (!workspace || workspace_bytes < dss_knn_workspace(N, P)) {
-        set_error("dss_knn_kth_sqdist: workspace too small");
+        set_error("%s: workspace too small", who);
         return DSS_ERR_WORKSPACE;
     }
     hipStream_t st = as_stream(stream);
@@ -322,13 +367,38 @@ extern "C" int dss_knn_kth_sqdist(const float *points, const int64_t *first_idx,
     hipLaunchKernelGGL(knn_scan_kernel, dim3(N), dim3(1024), 0, st, counts, grids, offsets, cursor);
     hipLaunchKernelGGL(knn_fill_kernel, dim3(pb), dim3(256), 0, st, points, first_idx, num_pts, N, P, cell_of, cursor,
                        sorted);
-    if (K <= 8)
-        hipLaunchKernelGGL(knn_query_kernel<8>, dim3(pb), dim3(256), 0, st, points, first_idx, num_pts, N, P, grids,
-                           offsets, sorted, K, kth_sqdist);
-    else
-        hipLaunchKernelGGL(knn_query_kernel<KNN_MAX_K>, dim3(pb), dim3(256), 0, st, points, first_idx, num_pts, N, P,
-                           grids, offsets, sorted, K, kth_sqdist);
-    return check_launch("dss_knn_kth_sqdist");
+#define KNN_LAUNCH(KK, FF)                                                                                          \
+    hipLaunchKernelGGL((knn_query_kernel<KK, FF>), dim3(pb), dim3(256), 0, st, points, first_idx, num_pts, N, P, grids,  \
+                       offsets, sorted, K, kth_sqdist, dists, idx)
+    if (full) {
+        if (K <= 8) KNN_LAUNCH(8, true);
+        else if (K <= 16) KNN_LAUNCH(16, true);
+        else KNN_LAUNCH(KNN_FULL_MAX_K, true);
+    } else {
+        if (K <= 8) KNN_LAUNCH(8, false);
+        else KNN_LAUNCH(KNN_MAX_K, false);
+    }
+#undef KNN_LAUNCH
+    return check_launch(who);
+}
+
+extern "C" int dss_knn_kth_sqdist(const float *points, const int64_t *first_idx, const int64_t *num_pts, int N,
+                                  int64_t P, int K, float *kth_sqdist, void *workspace, size_t workspace_bytes,
+                                  void *stream)
+{
+    return knn_run("dss_knn_kth_sqdist", points, first_idx, num_pts, N, P, K, kth_sqdist, nullptr, nullptr, workspace,
+                   workspace_bytes, stream);
+}
+
+extern "C" int dss_knn_points(const float *points, const int64_t *first_idx, const int64_t *num_pts, int N, int64_t P,
+                              int K, float *dists, int64_t *idx, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (!dists) {
+        set_error("dss_knn_points: NULL tensor pointer");
+        return DSS_ERR_INVALID_ARGUMENT;
+    }
+    return knn_run("dss_knn_points", points, first_idx, num_pts, N, P, K, nullptr, dists, idx, workspace, workspace_bytes,
+                   stream);
 }
 
 extern "C" int dss_cloud_mean_clamp(const float *values, const int64_t *first_idx, const int64_t *num_pts, int N,

@@ -478,6 +478,26 @@ def knn_kth_sqdist(points, cloud_to_packed_first_idx, num_points_per_cloud, K: i
     return out
 
 
+def knn_points(points, cloud_to_packed_first_idx, num_points_per_cloud, K: int):
+    """Self kNN of packed clouds -> (dists (P,K) squared, idx (P,K) int64 cloud-local), ascending, the point itself
+    first, zero-padded for clouds with fewer than K points: the packed form of
+    ``pytorch3d.ops.knn_points(p, p, lengths, lengths, K)`` used by the regularisers (losses.py:157-180)."""
+    lib = _lib.load()
+    points = _lib.require_gpu(points, "points", _f32)
+    dev = points.device
+    first = _lib.require_gpu(cloud_to_packed_first_idx, "cloud_to_packed_first_idx", _i64)
+    num = _lib.require_gpu(num_points_per_cloud, "num_points_per_cloud", _i64)
+    N, P = first.shape[0], points.shape[0]
+    with torch.cuda.device(dev):
+        dists = torch.empty((P, int(K)), dtype=_f32, device=dev)
+        idx = torch.empty((P, int(K)), dtype=_i64, device=dev)
+        ws = _lib.workspace(dev, lib.dss_knn_workspace(N, P))
+        rc = lib.dss_knn_points(_lib.ptr(points), _lib.ptr(first), _lib.ptr(num), N, P, int(K), _lib.ptr(dists),
+                                _lib.ptr(idx), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
+    _lib.check(rc, "dss_knn_points")
+    return dists, idx
+
+
 def cloud_mean_clamp(values, cloud_to_packed_first_idx, num_points_per_cloud, scale: float, lo: float, hi: float,
                      fallback: float, min_points: int):
     """Per-cloud clamp(mean(values*scale), lo, hi) -> (N,), deterministic."""

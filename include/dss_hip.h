@@ -297,6 +297,13 @@ DSS_API int dss_knn_kth_sqdist(const float *points /* (P,3) */, const int64_t *f
                                const int64_t *num_pts, int N, int64_t P, int K,
                                float *kth_sqdist /* (P,) */, void *workspace, size_t workspace_bytes,
                                void *stream);
+/* Full neighbour lists of the same search (the self query pytorch3d.ops.knn_points(p, p, lengths,
+ * lengths, K) of the regularisers, losses.py:157-180): dists (P,K) squared distances ascending in (distance, id),
+ * idx (P,K) int64 cloud-local ids; the point itself is entry 0; clouds with fewer than K points are zero-padded
+ * like pytorch3d's padded result.  1 <= K <= 40.  Same workspace as dss_knn_kth_sqdist. */
+DSS_API int dss_knn_points(const float *points /* (P,3) */, const int64_t *first_idx, const int64_t *num_pts,
+                           int N, int64_t P, int K, float *dists /* (P,K) */, int64_t *idx /* (P,K) */,
+                           void *workspace, size_t workspace_bytes, void *stream);
 DSS_API int dss_cloud_mean_clamp(const float *values /* (P,) */, const int64_t *first_idx,
                                  const int64_t *num_pts, int N, float scale, float lo, float hi,
                                  float fallback, int min_points, float *out /* (N,) */, void *stream);

@@ -76,3 +76,46 @@ def test_rasterizer_computes_h_itself():
         else:
             want = np.clip(0.5 * _ref_kth(pts, 7), 5e-5, 0.01)
             assert np.allclose(rast._Vrk_h.cpu().numpy(), want, rtol=2e-5)
+
+
+@pytest.mark.parametrize("K", [1, 8, 12, 34])
+def test_knn_points_lists_match_kdtree(K):
+    """Full neighbour lists (the self query of the regularisers, losses.py:157-180): distances
+    to 2e-5 of scipy's fp64 KD-tree, indices identical wherever neighbouring distances are separated (duplicates and
+    near-ties may swap), self first, zero padding for clouds smaller than K; deterministic."""
+    rng = np.random.default_rng(100 + K)
+    bunny, _ = scenes.load_cloud("bunny")
+    clouds = [scenes.normalize_unit_sphere(bunny), rng.uniform(-1, 1, (4000, 3)).astype(np.float32),
+              rng.uniform(0, 1, (5, 3)).astype(np.float32), np.zeros((0, 3), np.float32),
+              rng.normal(0, 0.02, (700, 3)).astype(np.float32) - 3]
+    pts = np.concatenate(clouds, 0)
+    num = np.array([c.shape[0] for c in clouds], np.int64)
+    first = np.cumsum(num) - num
+    args = (torch.from_numpy(pts).to(DEV), torch.from_numpy(first).to(DEV), torch.from_numpy(num).to(DEV), K)
+    d_t, i_t = ops.knn_points(*args)
+    d2_t, i2_t = ops.knn_points(*args)
+    assert torch.equal(d_t, d2_t) and torch.equal(i_t, i2_t)
+    d, i = d_t.cpu().numpy(), i_t.cpu().numpy()
+    assert d.shape == (pts.shape[0], K) and i.dtype == np.int64
+    for c, f in zip(clouds, first):
+        n = c.shape[0]
+        if n == 0:
+            continue
+        k = min(K, n)
+        wd, wi = cKDTree(c.astype(np.float64)).query(c.astype(np.float64), k=k)
+        wd, wi = wd.reshape(n, k), wi.reshape(n, k)
+        gd, gi = d[f:f + n], i[f:f + n]
+        assert np.allclose(gd[:, :k], (wd ** 2).astype(np.float32), rtol=2e-5, atol=1e-9)
+        assert (np.diff(gd[:, :k], axis=1) >= 0).all() and (gd[:, 0] == 0).all()
+        assert (gi[:, :k] >= 0).all() and (gi[:, :k] < n).all()
+        assert (gd[:, k:] == 0).all() and (gi[:, k:] == 0).all()          # padding
+        # a listed neighbour really is at the listed distance
+        diff = c[gi[:, :k]] - c[:, None, :]
+        assert np.allclose((diff.astype(np.float64) ** 2).sum(-1), gd[:, :k], rtol=2e-5, atol=1e-9)
+        # indices agree with the KD-tree wherever the ordering is unambiguous
+        sep = np.ones((n, k), bool)
+        if k > 1:
+            gap = np.diff(wd, axis=1) > 1e-6 * np.maximum(wd[:, 1:], 1e-12)
+            sep[:, 1:] &= gap
+            sep[:, :-1] &= gap
+        assert (gi[:, :k][sep] == wi[sep]).all()
