@@ -32,10 +32,11 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(
     for (int k = 0; k < K; ++k) {
         const int32_t p = idx[i * K + k];
         if (p < 0) continue;
-        const float w = expf(-0.5f * qv[i * K + k]) * scaler[p];
+        // normalised weight once per fragment (same arithmetic as the fused epilogue of the fine pass)
+        const float w = expf(-0.5f * qv[i * K + k]) * scaler[p] / cum;
 #pragma unroll
         for (int ch = 0; ch < ((C > 0) ? C : BLEND_MAX_C); ++ch)
-            if (ch < Cn) acc[ch] += feat[(size_t)p * Cn + ch] * w / cum;
+            if (ch < Cn) acc[ch] += feat[(size_t)p * Cn + ch] * w;
     }
     float *o = out + i * (Cn + 1);
     if (C == 3) {

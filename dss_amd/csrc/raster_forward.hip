@@ -354,12 +354,13 @@ __device__ __forceinline__ void fine_tile(const FineArgs &A, const int tile_id)
     const int r = g.row0 + ty * DSS_TILE + tr;        // image row
     const int c = tx * DSS_TILE + tc;                 // image col
     const int S = g.S;
-    const float xf = pix_to_ndc(S - 1 - c, S);
-    const float yf = pix_to_ndc(S - 1 - r, S);
+    const NdcMap ndc(S);  // same values as pix_to_ndc; one multiply instead of an IEEE divide when S = 2^k
+    const float xf = ndc(S - 1 - c);
+    const float yf = ndc(S - 1 - r);
     // NDC extent of this wavefront's footprint (pixel centres).  NDC decreases with the image index.
     const int fc0 = tx * DSS_TILE + fx * FOOT, fr0 = g.row0 + ty * DSS_TILE + fy * FOOT;
-    const float f_xmax = pix_to_ndc(S - 1 - fc0, S), f_xmin = pix_to_ndc(S - 1 - (fc0 + 3), S);
-    const float f_ymax = pix_to_ndc(S - 1 - fr0, S), f_ymin = pix_to_ndc(S - 1 - (fr0 + 3), S);
+    const float f_xmax = ndc(S - 1 - fc0), f_xmin = ndc(S - 1 - (fc0 + 3));
+    const float f_ymax = ndc(S - 1 - fr0), f_ymin = ndc(S - 1 - (fr0 + 3));
 
     // candidate source: tile sub-lists (binned) or the whole cloud (naive / overflowed tile)
     TileSource src;
@@ -559,6 +560,9 @@ __device__ __forceinline__ void fine_tile(const FineArgs &A, const int tile_id)
             }
             if (cum < 1e-4f) cum = 1e-4f;
             A.wsum[pix] = cum;
+            // normalised weights once per fragment (K IEEE divides per pixel, not K*C): img = sum f * (w / cum)
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) wk[k] = wk[k] / cum;
             float *o = A.image + (size_t)n * A.img_sn + (size_t)(r - g.row0) * A.img_sr + (size_t)c * (A.C + 1);
             if (A.C == 3) {
                 // RGBA as ONE 16-byte store per pixel (four dword stores at a 16-byte stride quadruple the
@@ -568,9 +572,9 @@ __device__ __forceinline__ void fine_tile(const FineArgs &A, const int tile_id)
                 for (int k = 0; k < KMAX; ++k)
                     if (k < K && ki[k] >= 0) {
                         const float *f = A.feat + (size_t)ki[k] * 3;
-                        acc3[0] += f[0] * wk[k] / cum;
-                        acc3[1] += f[1] * wk[k] / cum;
-                        acc3[2] += f[2] * wk[k] / cum;
+                        acc3[0] += f[0] * wk[k];
+                        acc3[1] += f[1] * wk[k];
+                        acc3[2] += f[2] * wk[k];
                     }
                 *reinterpret_cast<float4 *>(o) = make_float4(acc3[0], acc3[1], acc3[2], any ? 1.0f : 0.0f);
             } else {
@@ -578,7 +582,7 @@ __device__ __forceinline__ void fine_tile(const FineArgs &A, const int tile_id)
                     float acc = 0.0f;
 #pragma unroll
                     for (int k = 0; k < KMAX; ++k)
-                        if (k < K && ki[k] >= 0) acc += A.feat[(size_t)ki[k] * A.C + ch] * wk[k] / cum;
+                        if (k < K && ki[k] >= 0) acc += A.feat[(size_t)ki[k] * A.C + ch] * wk[k];
                     o[ch] = acc;
                 }
                 o[A.C] = any ? 1.0f : 0.0f;
