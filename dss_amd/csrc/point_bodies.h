@@ -12,12 +12,13 @@ namespace dss {
 
 // lane tiling of a W-column pixel window: LW columns x (64/LW) rows per sweep
 struct LaneTiling {
-    int LW, LH, lxx, lyy;
+    int LW, LH, lh_log, lxx, lyy;
     __device__ __forceinline__ LaneTiling(int w, int lane)
     {
         const int lw_log = (w <= 8) ? 3 : (w <= 16) ? 4 : (w <= 32) ? 5 : 6;
         LW = 1 << lw_log;
         LH = 64 >> lw_log;
+        lh_log = 6 - lw_log;  // divisions by LH are shifts (a runtime integer divide is ~25 instructions)
         lxx = lane & (LW - 1);
         lyy = lane >> lw_log;
     }
@@ -201,7 +202,7 @@ __device__ __forceinline__ void occ_blend_point_gather(int lane, int64_t p, int 
         // row slot u of this trip is image row S-1-(yb + lyy + u LH): a wave-uniform row pointer (scalar
         // arithmetic) plus ONE per-lane offset for all slots; lanes outside the window are masked, not clamped
         const int lane_off = (S - 1 - min(xi, xhi)) * gstride - T.lyy * rowstride;
-        const int nrow = min(RPT, (yhi - yb) / T.LH + 1);  // uniform, >= 1
+        const int nrow = min(RPT, ((yhi - yb) >> T.lh_log) + 1);  // uniform, >= 1
 #pragma unroll
         for (int u = 0; u < RPT; ++u) {
             g[u] = 0.0f;
@@ -219,7 +220,7 @@ __device__ __forceinline__ void occ_blend_point_gather(int lane, int64_t p, int 
         // "g > 0 and outside the splat's box" (|dx| > rx or |dy| > ry): with ry_eff = -1 for out-of-box columns
         // the row test alone decides (|dy| > -1 is always true)
         const float ry_eff = (fabsf(dx) > rx) ? -1.0f : ry;
-        const int nrow = min(RPT, (yhi - yb) / T.LH + 1);
+        const int nrow = min(RPT, ((yhi - yb) >> T.lh_log) + 1);
         const int yi0 = yb + T.lyy;
         const float nd0 = ndc(yi0);
         // pixel centres are integer multiples of 1/S: for S = 2^k, nd0 + u * (2 LH / S) is exact, i.e. ndc(yi0 + u LH)
