@@ -20,10 +20,11 @@ class _Blend(autograd.Function):
         ctx.save_for_backward(idx, qvalue, scaler, wsum)
         ctx.geometry = geometry
         ctx.num_points = features.shape[0]
-        return out
+        ctx.mark_non_differentiable(wsum)
+        return out, wsum
 
     @staticmethod
-    def backward(ctx, grad_out):
+    def backward(ctx, grad_out, _grad_wsum=None):
         idx, qvalue, scaler, wsum = ctx.saved_tensors
         grad_feat, grad_occ = ops.blend_backward(grad_out.contiguous(), idx, qvalue, scaler, ctx.num_points,
                                                  geometry=ctx.geometry, wsum=wsum)
@@ -43,7 +44,7 @@ class NormWeightedCompositor(torch.nn.Module):
         feat = features.permute(1, 0).contiguous()
         occ = (idx[..., 0] >= 0).float()
         ones = torch.ones(feat.shape[0], device=feat.device)
-        out = _Blend.apply(feat, occ, idx, q, ones, None)
+        out, _ = _Blend.apply(feat, occ, idx, q, ones, None)
         return out[..., :-1].permute(0, 3, 1, 2)
 
 
@@ -68,7 +69,7 @@ class SurfaceSplattingRenderer(torch.nn.Module):
             return None
         fragments = kwargs.get("fragments", None)
         if (fragments is None and self.fused and hasattr(self.rasterizer, "render_fused")
-                and (self.compositor is None or isinstance(self.compositor, NormWeightedCompositor))
+                and isinstance(self.compositor, NormWeightedCompositor)
                 and self.rasterizer.raster_settings.points_per_pixel <= 32):
             kw = {k: v for k, v in kwargs.items() if k != "fragments"}
             images, fragments, point_clouds = self.rasterizer.render_fused(point_clouds, **kw)
@@ -90,8 +91,13 @@ class SurfaceSplattingRenderer(torch.nn.Module):
         else:
             qv = fragments.qvalue
         if self.compositor is None or isinstance(self.compositor, NormWeightedCompositor):
-            images = _Blend.apply(pts_rgb, fragments.occupancy, fragments.idx, qv, scaler,
-                                  getattr(fragments, "geometry", None))
+            images, wsum = _Blend.apply(pts_rgb, fragments.occupancy, fragments.idx, qv, scaler,
+                                        getattr(fragments, "geometry", None))
+            if self.compositor is None:
+                # renderer.py:59-65: without a compositor the reference calls pytorch3d's `weighted_sum`, the
+                # UN-normalised sum_k f_k w_k (weights get no gradient there either).  The kernel divides by
+                # wsum = max(sum_k w_k, 1e-4); multiplying back by the same (constant) wsum undoes exactly that.
+                images = torch.cat([images[..., :-1] * wsum.unsqueeze(-1), images[..., -1:]], dim=-1)
         else:
             # foreign compositor object: call it exactly like renderer.py:53-78
             safe = fragments.idx.clamp_min(0).long()

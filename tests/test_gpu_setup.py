@@ -236,3 +236,35 @@ def test_render_forward_leaves_its_workspace_clean(h_scale):
     idx, zbuf, qv, occ, vis = ops.splat_points(info["pts_screen"], info["ellipse_params"], info["cutoff_threshold"],
                                                info["radii"], first, num, 0.05, S, K, None, None, return_visible=True)
     assert torch.equal(outs[2]["idx"], idx) and torch.equal(outs[2]["zbuf"], zbuf) and torch.equal(outs[2]["visible"], vis)
+
+
+def test_renderer_without_compositor_is_unnormalised_weighted_sum():
+    """renderer.py:59-65: ``compositor=None`` -> pytorch3d ``weighted_sum`` (sum_k f_k w_k, no normalisation, no
+    gradient to the weights).  Checked against the same sum evaluated with plain torch ops on the fragments."""
+    S, K = 96, 4
+    pts, nrm = scenes.load_cloud("teapot")
+    pts = scenes.normalize_unit_sphere(pts)
+    h = scenes.global_h(pts)
+    col = np.random.default_rng(3).uniform(0, 1, pts.shape).astype(np.float32)
+    R, T = look_at_view_transform(2.0, 30.0, [45.0, 160.0])
+    cams = FoVPerspectiveCameras(znear=0.1, R=R, T=T, device=DEV)
+    settings = PointsRasterizationSettings(backface_culling=False, cutoff_threshold=1.0, Vrk_invariant=True,
+                                           radii_backward_scaler=5, image_size=S, points_per_pixel=K, bin_size=None,
+                                           clip_pts_grad=0.05)
+    renderer = SurfaceSplattingRenderer(SurfaceSplatting(cameras=cams, raster_settings=settings), None)
+    C = torch.nn.Parameter(torch.from_numpy(col).to(DEV))
+    cloud = PointClouds3D([torch.from_numpy(pts).to(DEV)], [torch.from_numpy(nrm).to(DEV)], [C])
+    img, fr = renderer(cloud, Vrk_h=torch.tensor([h], device=DEV), verbose=True)
+    feat = torch.cat([C, C], 0)  # camera-extended packed features, the order fragments.idx refers to
+    feat2 = feat.detach().clone().requires_grad_(True)
+    valid = fr.idx >= 0
+    safe = fr.idx.clamp_min(0).long()
+    w = torch.exp(-0.5 * fr.qvalue) * fr.scaler[safe] * valid
+    want = (feat2[safe] * w.unsqueeze(-1)).sum(dim=3)
+    assert torch.allclose(img[..., :3], want, rtol=1e-4, atol=1e-5)
+    assert torch.equal(img[..., 3], fr.occupancy)
+    g = torch.randn_like(img)
+    (img * g).sum().backward()
+    (want * g[..., :3]).sum().backward()
+    g_ref = feat2.grad[:pts.shape[0]] + feat2.grad[pts.shape[0]:]
+    assert (C.grad - g_ref).norm() / g_ref.norm() <= 1e-4
