@@ -64,12 +64,18 @@ class SurfaceSplattingRenderer(torch.nn.Module):
         self.density = density
         self.frnn_radius = frnn_radius
 
+    def _is_norm_weighted(self) -> bool:
+        # ours, or pytorch3d.renderer.NormWeightedCompositor (same semantics: recognised by name so that a
+        # pytorch3d object configured in YAML takes the fused HIP path instead of pytorch3d's CUDA kernels)
+        return isinstance(self.compositor, NormWeightedCompositor) or \
+            type(self.compositor).__name__ == "NormWeightedCompositor"
+
     def forward(self, point_clouds, **kwargs):
         if point_clouds.isempty():
             return None
         fragments = kwargs.get("fragments", None)
         if (fragments is None and self.fused and hasattr(self.rasterizer, "render_fused")
-                and isinstance(self.compositor, NormWeightedCompositor)
+                and self._is_norm_weighted()
                 and self.rasterizer.raster_settings.points_per_pixel <= 32):
             kw = {k: v for k, v in kwargs.items() if k != "fragments"}
             images, fragments, point_clouds = self.rasterizer.render_fused(point_clouds, **kw)
@@ -90,7 +96,7 @@ class SurfaceSplattingRenderer(torch.nn.Module):
             scaler = torch.ones(pts_rgb.shape[0], device=pts_rgb.device)
         else:
             qv = fragments.qvalue
-        if self.compositor is None or isinstance(self.compositor, NormWeightedCompositor):
+        if self.compositor is None or self._is_norm_weighted():
             images, wsum = _Blend.apply(pts_rgb, fragments.occupancy, fragments.idx, qv, scaler,
                                         getattr(fragments, "geometry", None))
             if self.compositor is None:
