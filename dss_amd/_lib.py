@@ -42,7 +42,7 @@ SIGNATURES = {
     "dss_splat_backward": (_c_int, [_c_vp] * 8 + [_c_int, _c_i64, _c_int, _c_int, _c_int, _c_f32, _c_f32,
                                                   _c_vp, _c_vp, _c_vp, _c_sz, _c_vp]),
     "dss_render_forward_workspace": (_c_sz, [_c_int, _c_i64, _c_int, _c_int]),
-    "dss_render_forward": (_c_int, [_c_vp] * 10 + [_c_int, _c_i64, _c_int, _c_int, _c_int, _c_int, _c_f32, _c_f32, _c_f32,
+    "dss_render_forward": (_c_int, [_c_vp] * 12 + [_c_int, _c_i64, _c_int, _c_int, _c_int, _c_int, _c_f32, _c_f32, _c_f32,
                                                   _c_int, _c_int, _c_vp, _c_int] + [_c_vp] * 12 + [_c_i64, _c_i64, _c_vp] + [_c_vp, _c_sz, _c_int, _c_vp]),
     "dss_render_backward_workspace": (_c_sz, [_c_int, _c_i64, _c_int]),
     "dss_render_backward": (_c_int, [_c_vp] * 10 + [_c_int, _c_i64, _c_int, _c_int, _c_int, _c_int, _c_int, _c_f32, _c_f32]
@@ -52,7 +52,8 @@ SIGNATURES = {
     "dss_knn_points": (_c_int, [_c_vp] * 3 + [_c_int, _c_i64, _c_int, _c_vp, _c_vp, _c_vp, _c_sz, _c_vp]),
     "dss_cloud_mean_clamp": (_c_int, [_c_vp] * 3 + [_c_int, _c_f32, _c_f32, _c_f32, _c_f32, _c_int, _c_vp, _c_vp]),
     "dss_blend_forward": (_c_int, [_c_vp] * 5 + [_c_int] * 5 + [_c_vp, _c_vp, _c_vp]),
-    "dss_point_setup": (_c_int, [_c_vp] * 10 + [_c_int, _c_i64, _c_int, _c_int, _c_int, _c_f32, _c_f32]
+    "dss_local_frames": (_c_int, [_c_vp] * 4 + [_c_int, _c_i64, _c_int, _c_vp, _c_vp, _c_vp, _c_vp]),
+    "dss_point_setup": (_c_int, [_c_vp] * 12 + [_c_int, _c_i64, _c_int, _c_int, _c_int, _c_f32, _c_f32]
                         + [_c_vp] * 6 + [_c_vp]),
     "dss_project_backward": (_c_int, [_c_vp] * 5 + [_c_int, _c_i64, _c_int, _c_vp, _c_vp, _c_vp, _c_vp]),
     "dss_blend_backward": (_c_int, [_c_vp] * 10 + [_c_int, _c_i64, _c_int, _c_int, _c_int, _c_int, _c_int, _c_vp, _c_vp]),

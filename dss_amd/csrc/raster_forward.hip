@@ -998,7 +998,7 @@ extern "C" size_t dss_render_forward_workspace(int N, int64_t P, int S, int K)
 }
 
 extern "C" int dss_render_forward(const float *world, const float *normals, const float *h_point, const float *h_cloud,
-                                  const float *M, const float *V, const float *znear, const float *zfar,
+                                  const float *vr6, const float *frame_normals, const float *M, const float *V, const float *znear, const float *zfar,
                                   const int64_t *first_idx, const int64_t *num_pts, int N, int64_t P, int shared_cloud,
                                   int backface_culling, int S, int K, float cutoff_threshold, float antialiasing_sigma,
                                   float merge_thr, int row0, int row1, const float *feat, int C,
@@ -1019,7 +1019,8 @@ extern "C" int dss_render_forward(const float *world, const float *normals, cons
         set_error("dss_render_forward: needs P > 0 and 1 <= C <= 8 (P=%lld C=%d)", (long long)P, C);
         return DSS_ERR_INVALID_ARGUMENT;
     }
-    if (!world || !normals || (!h_point && !h_cloud) || !M || !V || !znear || !zfar || !first_idx || !num_pts || !feat ||
+    if (!world || !normals || (!h_point && !h_cloud && !vr6) || (vr6 && !frame_normals) || !M || !V || !znear || !zfar ||
+        !first_idx || !num_pts || !feat ||
         !pts_screen || !ellipse || !radii || !scaler || !cutoff || !valid || !idx || !zbuf || !qvalue || !occ ||
         !visible || !image || !wsum) {
         set_error("dss_render_forward: NULL tensor pointer");
@@ -1039,6 +1040,7 @@ extern "C" int dss_render_forward(const float *world, const float *normals, cons
     if (!clean && hipMemsetAsync(w.counts, 0, w.count_bytes, st) != hipSuccess) return check_launch("memset tile counts");
     SetupArgs SA;
     SA.world = world; SA.normals = normals; SA.h_point = h_point; SA.h_cloud = h_cloud; SA.M = M; SA.V = V;
+    SA.vr6 = vr6; SA.frame_n = frame_normals;
     SA.znear = znear; SA.zfar = zfar; SA.first_idx = first_idx; SA.num_pts = num_pts; SA.N = N; SA.P = P;
     SA.shared = shared_cloud; SA.backface = backface_culling; SA.S = S; SA.cutoffC = cutoff_threshold;
     SA.sigma = antialiasing_sigma; SA.screen = pts_screen; SA.ellipse = ellipse; SA.radii = radii; SA.scaler = scaler;

@@ -69,12 +69,126 @@ __global__ __launch_bounds__(256) void project_backward_kernel(
     grad_world[3 * wi] = g0; grad_world[3 * wi + 1] = g1; grad_world[3 * wi + 2] = g2;
 }
 
+// PCA frames of the K-neighbourhoods -> anisotropic source variance (rasterizer.py:256-291, mathHelper.py:34-92):
+// covariance of the K nearest points about their mean, cyclic Jacobi in fp32 on the trace-normalised matrix,
+// Vrk = C - c0 e0 e0^T (= the two largest principal components), frame normal e0, curvatures ascending.
+__global__ __launch_bounds__(256) void local_frames_kernel(const float *__restrict__ pts, const int64_t *__restrict__ knn_idx,
+                                                           const int64_t *__restrict__ first_idx,
+                                                           const int64_t *__restrict__ num_pts, int N, int64_t P, int K,
+                                                           float *__restrict__ vr6, float *__restrict__ frame_n,
+                                                           float *__restrict__ curv)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const int n = find_cloud(p, first_idx, num_pts, N);
+    float C[3][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+    float e0[3] = {0.f, 0.f, 1.f}, lam[3] = {0.f, 0.f, 0.f};
+    if (n >= 0) {
+        const int64_t f0 = first_idx[n];
+        const int kk = (int)min((int64_t)K, num_pts[n]);
+        // differences to the query point first: the neighbourhood is tiny compared with the coordinates
+        const float qx = pts[3 * p], qy = pts[3 * p + 1], qz = pts[3 * p + 2];
+        float mx = 0.f, my = 0.f, mz = 0.f;
+        for (int k = 0; k < kk; ++k) {
+            const int64_t j = f0 + knn_idx[p * K + k];
+            mx += pts[3 * j] - qx; my += pts[3 * j + 1] - qy; mz += pts[3 * j + 2] - qz;
+        }
+        const float ik = 1.0f / (float)(kk > 0 ? kk : 1);
+        mx *= ik; my *= ik; mz *= ik;
+        for (int k = 0; k < kk; ++k) {
+            const int64_t j = f0 + knn_idx[p * K + k];
+            const float d[3] = {pts[3 * j] - qx - mx, pts[3 * j + 1] - qy - my, pts[3 * j + 2] - qz - mz};
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b) C[a][b] += d[a] * d[b] * ik;
+        }
+        const float tr = C[0][0] + C[1][1] + C[2][2];
+        if (tr > 0.0f) {
+            const float it = 1.0f / tr;
+            float A[3][3], V[3][3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b) { A[a][b] = C[a][b] * it; V[a][b] = (a == b) ? 1.0f : 0.0f; }
+            for (int sweep = 0; sweep < 8; ++sweep) {
+#pragma unroll
+                for (int pi = 0; pi < 2; ++pi)
+#pragma unroll
+                    for (int qi = pi + 1; qi < 3; ++qi) {
+                        const float apq = A[pi][qi];
+                        if (fabsf(apq) > 1e-20f) {
+                            const float theta = (A[qi][qi] - A[pi][pi]) / (2.0f * apq);
+                            const float t = (theta >= 0.0f ? 1.0f : -1.0f) / (fabsf(theta) + sqrtf(theta * theta + 1.0f));
+                            const float c = 1.0f / sqrtf(t * t + 1.0f), sn = t * c;
+#pragma unroll
+                            for (int k = 0; k < 3; ++k) {
+                                const float akp = A[k][pi], akq = A[k][qi];
+                                A[k][pi] = c * akp - sn * akq;
+                                A[k][qi] = sn * akp + c * akq;
+                            }
+#pragma unroll
+                            for (int k = 0; k < 3; ++k) {
+                                const float apk = A[pi][k], aqk = A[qi][k];
+                                A[pi][k] = c * apk - sn * aqk;
+                                A[qi][k] = sn * apk + c * aqk;
+                            }
+#pragma unroll
+                            for (int k = 0; k < 3; ++k) {
+                                const float vkp = V[k][pi], vkq = V[k][qi];
+                                V[k][pi] = c * vkp - sn * vkq;
+                                V[k][qi] = sn * vkp + c * vkq;
+                            }
+                        }
+                    }
+            }
+            // ascending eigenvalues without dynamic indexing
+            const float l0 = A[0][0], l1 = A[1][1], l2 = A[2][2];
+            const bool m0 = l0 <= l1 && l0 <= l2, m1 = !m0 && l1 <= l2;
+            const float lmin = m0 ? l0 : (m1 ? l1 : l2);
+            const float lmax = fmaxf(l0, fmaxf(l1, l2));
+            const float lmid = (l0 + l1 + l2) - lmin - lmax;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) e0[k] = m0 ? V[k][0] : (m1 ? V[k][1] : V[k][2]);
+            lam[0] = lmin * tr; lam[1] = lmid * tr; lam[2] = lmax * tr;
+        }
+    }
+    vr6[6 * p + 0] = C[0][0] - lam[0] * e0[0] * e0[0];
+    vr6[6 * p + 1] = C[0][1] - lam[0] * e0[0] * e0[1];
+    vr6[6 * p + 2] = C[0][2] - lam[0] * e0[0] * e0[2];
+    vr6[6 * p + 3] = C[1][1] - lam[0] * e0[1] * e0[1];
+    vr6[6 * p + 4] = C[1][2] - lam[0] * e0[1] * e0[2];
+    vr6[6 * p + 5] = C[2][2] - lam[0] * e0[2] * e0[2];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        frame_n[3 * p + k] = e0[k];
+        if (curv) curv[3 * p + k] = lam[k];
+    }
+}
+
 }  // namespace dss
 
 using namespace dss;
 
+extern "C" int dss_local_frames(const float *points, const int64_t *knn_idx, const int64_t *first_idx,
+                                const int64_t *num_pts, int N, int64_t P, int K, float *vr6, float *frame_n,
+                                float *curvature, void *stream)
+{
+    if (N <= 0 || P < 0 || K < 1) {
+        set_error("dss_local_frames: bad sizes N=%d P=%lld K=%d", N, (long long)P, K);
+        return DSS_ERR_INVALID_ARGUMENT;
+    }
+    if (P == 0) return DSS_OK;
+    if (!points || !knn_idx || !first_idx || !num_pts || !vr6 || !frame_n) {
+        set_error("dss_local_frames: NULL tensor pointer");
+        return DSS_ERR_INVALID_ARGUMENT;
+    }
+    hipLaunchKernelGGL(local_frames_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, as_stream(stream), points,
+                       knn_idx, first_idx, num_pts, N, P, K, vr6, frame_n, curvature);
+    return check_launch("dss_local_frames");
+}
 extern "C" int dss_point_setup(const float *world, const float *normals, const float *h_point, const float *h_cloud,
-                               const float *M, const float *V, const float *znear, const float *zfar,
+                               const float *vr6, const float *frame_normals, const float *M, const float *V, const float *znear, const float *zfar,
                                const int64_t *first_idx, const int64_t *num_pts, int N, int64_t P, int shared_cloud,
                                int backface_culling, int S, float cutoff_threshold, float antialiasing_sigma,
                                float *pts_screen, float *ellipse, float *radii, float *scaler, float *cutoff,
@@ -85,13 +199,14 @@ extern "C" int dss_point_setup(const float *world, const float *normals, const f
         return DSS_ERR_INVALID_ARGUMENT;
     }
     if (P == 0) return DSS_OK;
-    if (!world || !normals || (!h_point && !h_cloud) || !M || !V || !znear || !zfar || !first_idx || !num_pts ||
-        !pts_screen || !ellipse || !radii || !scaler || !cutoff || !valid) {
+    if (!world || !normals || (!h_point && !h_cloud && !vr6) || (vr6 && !frame_normals) || !M || !V || !znear || !zfar ||
+        !first_idx || !num_pts || !pts_screen || !ellipse || !radii || !scaler || !cutoff || !valid) {
         set_error("dss_point_setup: NULL tensor pointer");
         return DSS_ERR_INVALID_ARGUMENT;
     }
     SetupArgs A;
     A.world = world; A.normals = normals; A.h_point = h_point; A.h_cloud = h_cloud; A.M = M; A.V = V;
+    A.vr6 = vr6; A.frame_n = frame_normals;
     A.znear = znear; A.zfar = zfar; A.first_idx = first_idx; A.num_pts = num_pts; A.N = N; A.P = P;
     A.shared = shared_cloud; A.backface = backface_culling; A.S = S; A.cutoffC = cutoff_threshold;
     A.sigma = antialiasing_sigma; A.screen = pts_screen; A.ellipse = ellipse; A.radii = radii; A.scaler = scaler;

@@ -16,6 +16,7 @@ struct SetupArgs {
     const float *world, *normals;     // (Pw,3)
     const float *h_point;             // (Pw,) or nullptr
     const float *h_cloud;             // (N,) or nullptr
+    const float *vr6, *frame_n;       // anisotropic mode: (Pw,6) Vrk xx,xy,xz,yy,yz,zz + (Pw,3) PCA normal; or nullptr
     const float *M, *V;               // (N,4,4) row-vector convention
     const float *znear, *zfar;        // (N,)
     const int64_t *first_idx, *num_pts;
@@ -66,17 +67,27 @@ __device__ __forceinline__ void setup_point(const SetupArgs &A, int64_t p, int n
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     WJ[i][j] = m[i * 4 + j] * (1.0f / dw) + m[i * 4 + 3] * (-1.0f / dw2 * clip[j]);
-            const float hh = A.h_point ? A.h_point[wi] : A.h_cloud[n];
+            // anisotropic mode (rasterizer.py:256-291): Vrk is an input and the tangent frame of det(Sk WJk) is
+            // the PCA frame, whose normal replaces the cloud normal below (culling above used the cloud normal)
+            const bool aniso = A.vr6 != nullptr;
+            const float f0 = aniso ? A.frame_n[3 * wi] : n0, f1 = aniso ? A.frame_n[3 * wi + 1] : n1,
+                        f2 = aniso ? A.frame_n[3 * wi + 2] : n2;
+            const float hh = aniso ? 0.0f : (A.h_point ? A.h_point[wi] : A.h_cloud[n]);
             // Sk^T Sk = I - n^ n^^T with the NORMALISED normal (rasterizer.py:337-341); zero normal -> 0
-            const float nlen = sqrtf(n0 * n0 + n1 * n1 + n2 * n2);
+            const float nlen = sqrtf(f0 * f0 + f1 * f1 + f2 * f2);
             const float nden = nlen > 1e-12f ? nlen : 1e-12f;
-            const float nn[3] = {n0 / nden, n1 / nden, n2 / nden};
+            const float nn[3] = {f0 / nden, f1 / nden, f2 / nden};
             const float hv = nlen > 1e-12f ? hh : 0.0f;
             float Vr[3][3];
 #pragma unroll
             for (int i = 0; i < 3; ++i)
 #pragma unroll
                 for (int j = 0; j < 3; ++j) Vr[i][j] = hv * ((i == j ? 1.0f : 0.0f) - nn[i] * nn[j]);
+            if (aniso) {
+                const float *q = A.vr6 + 6 * wi;
+                Vr[0][0] = q[0]; Vr[0][1] = Vr[1][0] = q[1]; Vr[0][2] = Vr[2][0] = q[2];
+                Vr[1][1] = q[3]; Vr[1][2] = Vr[2][1] = q[4]; Vr[2][2] = q[5];
+            }
             float T[3][2];
 #pragma unroll
             for (int i = 0; i < 3; ++i)

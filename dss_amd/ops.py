@@ -281,7 +281,7 @@ def render_forward(world, normals, h, M, V, znear, zfar, cloud_to_packed_first_i
                    image_size: int, points_per_pixel: int, cutoff_threshold: float, depth_merging_thres: float,
                    antialiasing_sigma: float = 1.0, backface_culling: bool = False, shared_cloud: bool = False,
                    rows: Optional[Tuple[int, int]] = None, out_image: Optional[torch.Tensor] = None,
-                   out_visible: Optional[torch.Tensor] = None):
+                   out_visible: Optional[torch.Tensor] = None, vr6=None, frame_normals=None):
     """Fused forward (setup + binning + fine + blend, ``dss_render_forward``).  ``out_image`` (float32
     (N,rows,S,C+1), 16-byte aligned) / ``out_visible`` (uint8 (P,)) let the caller place these two outputs
     in its own buffer (the multi-GPU step points them into one all-gather send buffer).  ``features`` are the
@@ -323,12 +323,13 @@ def render_forward(world, normals, h, M, V, znear, zfar, cloud_to_packed_first_i
                 or tuple(vis.shape) != (P,) or vis.dtype != _u8:
             raise RuntimeError("out_image must be float32 (N,rows,S,C+1), 16-byte aligned, with contiguous rows "
                                "(any camera / row strides that are multiples of 4 floats); out_visible uint8 (P,)")
+        _keep, vr_p, fn_p = _aniso_args(vr6, frame_normals, Pw)
         # dedicated zero-initialised buffer per problem size: the library keeps it clean (no memset launch)
         tag = ("render_forward", N, P, S)
         ws = _lib.clean_workspace(dev, tag, lib.dss_render_forward_workspace(N, P, S, K))
         rc = lib.dss_render_forward(
             _lib.ptr(world), _lib.ptr(normals), _lib.ptr(h) if per_point else None, None if per_point else _lib.ptr(h),
-            _lib.ptr(M), _lib.ptr(V), _lib.ptr(znear), _lib.ptr(zfar), _lib.ptr(first), _lib.ptr(num), N, P,
+            vr_p, fn_p, _lib.ptr(M), _lib.ptr(V), _lib.ptr(znear), _lib.ptr(zfar), _lib.ptr(first), _lib.ptr(num), N, P,
             int(shared_cloud), int(backface_culling), S, K, float(cutoff_threshold), float(antialiasing_sigma),
             float(depth_merging_thres), row0, row1, _lib.ptr(features), C, _lib.ptr(o["pts_screen"]),
             _lib.ptr(o["ellipse_params"]), _lib.ptr(o["radii"]), _lib.ptr(o["scaler"]), _lib.ptr(o["cutoff_threshold"]),
@@ -389,12 +390,47 @@ def render_backward(grad_out, idx, qvalue, wsum, scaler, points, radii, visible,
     return (gf, gp, rs) if return_rs else (gf, gp)
 
 
+def _aniso_args(vr6, frame_normals, Pw):
+    """(ptr(vr6), ptr(frame_normals)) of the anisotropic source variance, or (None, None)."""
+    if vr6 is None:
+        return None, None, None
+    vr6 = _lib.require_gpu(vr6, "vr6", _f32)
+    fn = _lib.require_gpu(frame_normals, "frame_normals", _f32)
+    if tuple(vr6.shape) != (Pw, 6) or tuple(fn.shape) != (Pw, 3):
+        raise RuntimeError("anisotropic mode needs vr6 (%d,6) and frame_normals (%d,3)" % (Pw, Pw))
+    return (vr6, fn), _lib.ptr(vr6), _lib.ptr(fn)
+
+
+def local_frames(points, knn_idx, cloud_to_packed_first_idx, num_points_per_cloud, return_curvature: bool = False):
+    """PCA frames of the K-neighbourhoods (``knn_idx`` from ``knn_points``, self included) -> anisotropic source
+    variance ``vr6 (P,6)`` (xx,xy,xz,yy,yz,zz) and frame normals ``(P,3)`` (rasterizer.py:256-291 +
+    mathHelper.py:34-92 with neighborhood_size = 8)."""
+    lib = _lib.load()
+    points = _lib.require_gpu(points, "points", _f32)
+    dev = points.device
+    knn_idx = _lib.require_gpu(knn_idx, "knn_idx", _i64)
+    first = _lib.require_gpu(cloud_to_packed_first_idx, "cloud_to_packed_first_idx", _i64)
+    num = _lib.require_gpu(num_points_per_cloud, "num_points_per_cloud", _i64)
+    P, K = knn_idx.shape
+    if points.shape[0] != P:
+        raise RuntimeError("knn_idx must be (P,K) for the P packed points")
+    with torch.cuda.device(dev):
+        vr6 = torch.empty((P, 6), dtype=_f32, device=dev)
+        fn = torch.empty((P, 3), dtype=_f32, device=dev)
+        cv = torch.empty((P, 3), dtype=_f32, device=dev) if return_curvature else None
+        rc = lib.dss_local_frames(_lib.ptr(points), _lib.ptr(knn_idx), _lib.ptr(first), _lib.ptr(num), first.shape[0], P,
+                                  int(K), _lib.ptr(vr6), _lib.ptr(fn), _lib.ptr(cv), _lib.stream_ptr(dev))
+    _lib.check(rc, "dss_local_frames")
+    return (vr6, fn, cv) if return_curvature else (vr6, fn)
+
+
 def point_setup(world, normals, h, M, V, znear, zfar, cloud_to_packed_first_idx, num_points_per_cloud,
                 image_size: int, cutoff_threshold: float, antialiasing_sigma: float = 1.0,
-                backface_culling: bool = False, shared_cloud: bool = False):
+                backface_culling: bool = False, shared_cloud: bool = False, vr6=None, frame_normals=None):
     """Fused culling + projection + EWA per-point setup (rasterizer.py:183-254, 443-565, 614).
 
-    ``h`` is either per point ``(Pw,)`` or per cloud ``(N,)``.  Returns a dict with
+    ``h`` is either per point ``(Pw,)`` or per cloud ``(N,)``; with ``vr6`` / ``frame_normals`` (``local_frames``)
+    the anisotropic source variance is used instead and ``h`` is ignored.  Returns a dict with
     ``pts_screen (P,3), ellipse_params (P,3), radii (P,2), scaler (P,), cutoff_threshold (P,),
     valid bool (P,)``.
     """
@@ -425,8 +461,9 @@ def point_setup(world, normals, h, M, V, znear, zfar, cloud_to_packed_first_idx,
                    scaler=torch.empty((P,), dtype=_f32, device=dev),
                    cutoff_threshold=torch.empty((P,), dtype=_f32, device=dev))
         valid = torch.empty((P,), dtype=_u8, device=dev)
+        _keep, vr_p, fn_p = _aniso_args(vr6, frame_normals, Pw)
         rc = lib.dss_point_setup(_lib.ptr(world), _lib.ptr(normals), _lib.ptr(h) if per_point else None,
-                                 None if per_point else _lib.ptr(h), _lib.ptr(M), _lib.ptr(V), _lib.ptr(znear),
+                                 None if per_point else _lib.ptr(h), vr_p, fn_p, _lib.ptr(M), _lib.ptr(V), _lib.ptr(znear),
                                  _lib.ptr(zfar), _lib.ptr(first), _lib.ptr(num), N, P, int(shared_cloud),
                                  int(backface_culling), int(image_size), float(cutoff_threshold),
                                  float(antialiasing_sigma), _lib.ptr(out["pts_screen"]),

@@ -114,9 +114,9 @@ class _ProjectAndSetup(autograd.Function):
 
     @staticmethod
     def forward(ctx, world, normals, h, M, V, znear, zfar, first_idx, num_points, image_size, cutoff, sigma,
-                backface, shared):
+                backface, shared, vr6=None, frame_normals=None):
         info = ops.point_setup(world, normals, h, M, V, znear, zfar, first_idx, num_points, image_size, cutoff,
-                               sigma, backface, shared)
+                               sigma, backface, shared, vr6=vr6, frame_normals=frame_normals)
         ctx.save_for_backward(world, M, V, first_idx, num_points, info["valid"])
         ctx.shared = shared
         outs = (info["pts_screen"], info["ellipse_params"], info["radii"], info["scaler"],
@@ -128,7 +128,7 @@ class _ProjectAndSetup(autograd.Function):
     def backward(ctx, g_screen, *unused):
         world, M, V, first_idx, num_points, valid = ctx.saved_tensors
         gw = ops.project_backward(world, M, V, first_idx, num_points, g_screen.contiguous(), valid, ctx.shared)
-        return (gw,) + (None,) * 13
+        return (gw,) + (None,) * 15
 
 
 def knn_variance_scale(point_clouds, K: int = 7) -> torch.Tensor:
@@ -168,10 +168,18 @@ class SurfaceSplatting(torch.nn.Module):
         elif raster_settings.Vrk_isotropic:
             h = (0.5 * d).clamp_(5e-5, 0.01)  # per point (rasterizer.py:383-388)
         else:
-            raise NotImplementedError("anisotropic Vrk (rasterizer.py:256-291) needs torch-batch-svd local "
-                                      "frames; use Vrk_invariant or Vrk_isotropic")
+            h = torch.zeros_like(d)  # unused: the anisotropic variance comes from _local_frames
         self._Vrk_h = h
         return h
+
+    def _local_frames(self, point_clouds):
+        """Anisotropic source variance (rasterizer.py:256-291): PCA frames of the 8-neighbourhoods
+        (estimate_pointcloud_local_coord_frames(neighborhood_size=8)) -> (vr6 (P,6), frame normals (P,3))."""
+        first, num = point_clouds.cloud_to_packed_first_idx(), point_clouds.num_points_per_cloud()
+        with torch.no_grad():
+            pts = point_clouds.points_packed().detach()
+            _, idx = ops.knn_points(pts, first, num, 8)
+            return ops.local_frames(pts, idx, first, num)
 
     def _empty_fragments(self, batch_size, device, raster_settings):  # rasterizer.py:567-582
         S, K = raster_settings.image_size, raster_settings.points_per_pixel
@@ -198,6 +206,9 @@ class SurfaceSplatting(torch.nn.Module):
         h = kwargs.get("Vrk_h", None)
         if h is None:
             h = self._variance_scale(point_clouds, raster_settings, kwargs.get("refresh", True))
+        vr6 = frame_n = None
+        if not raster_settings.Vrk_invariant and not raster_settings.Vrk_isotropic:
+            vr6, frame_n = self._local_frames(point_clouds)
         world, normals = point_clouds.points_packed(), point_clouds.normals_packed()
         if shared:
             Pc = world.shape[0]
@@ -215,7 +226,7 @@ class SurfaceSplatting(torch.nn.Module):
                                             device=dev).reshape(-1).expand(N).contiguous()
         return dict(N=N, shared=shared, world=world, normals=normals, h=h.to(dev, torch.float32), M=M, V=V,
                     znear=as_n("znear", 1.0), zfar=as_n("zfar", 100.0), first_idx=first_idx, num_points=num_points,
-                    out_clouds=out_clouds, raster_settings=raster_settings)
+                    out_clouds=out_clouds, raster_settings=raster_settings, vr6=vr6, frame_n=frame_n)
 
     def forward(self, point_clouds, point_clouds_filter=None, **kwargs):
         raster_settings = kwargs.get("raster_settings", self.raster_settings)
@@ -228,7 +239,7 @@ class SurfaceSplatting(torch.nn.Module):
         pts_screen, ellipse, radii, scaler, cutoff, valid = _ProjectAndSetup.apply(
             a["world"], a["normals"], a["h"], a["M"], a["V"], a["znear"], a["zfar"], first_idx, num_points,
             raster_settings.image_size, raster_settings.cutoff_threshold, raster_settings.antialiasing_sigma,
-            bool(raster_settings.backface_culling), shared)
+            bool(raster_settings.backface_culling), shared, a["vr6"], a["frame_n"])
 
         idx, zbuf, qvalue_map, occ_map = EllipticalRasterizer.apply(
             pts_screen, ellipse, cutoff, radii, first_idx, num_points, raster_settings.depth_merging_threshold,
@@ -261,7 +272,7 @@ class SurfaceSplatting(torch.nn.Module):
                                   a["M"], a["V"], a["znear"], a["zfar"], a["first_idx"], a["num_points"],
                                   st.image_size, st.points_per_pixel, st.cutoff_threshold, st.depth_merging_threshold,
                                   st.antialiasing_sigma, bool(st.backface_culling), a["shared"],
-                                  st.radii_backward_scaler, st.clip_pts_grad)
+                                  st.radii_backward_scaler, st.clip_pts_grad, a["vr6"], a["frame_n"])
         image, idx, zbuf, qv, occ, scaler, pts_screen, radii, visible = outs
         fragments = PointFragments(idx=idx, zbuf=zbuf, qvalue=qv, scaler=scaler, occupancy=occ,
                                    geometry=(pts_screen, radii, visible, a["first_idx"], a["num_points"]))
@@ -276,9 +287,11 @@ class _RenderFused(autograd.Function):
 
     @staticmethod
     def forward(ctx, world, features, normals, h, M, V, znear, zfar, first_idx, num_points, image_size,
-                points_per_pixel, cutoff, merge_thr, sigma, backface, shared, radii_s, clip):
+                points_per_pixel, cutoff, merge_thr, sigma, backface, shared, radii_s, clip, vr6=None,
+                frame_normals=None):
         f = ops.render_forward(world, normals, h, M, V, znear, zfar, first_idx, num_points, features, image_size,
-                               points_per_pixel, cutoff, merge_thr, sigma, backface, shared)
+                               points_per_pixel, cutoff, merge_thr, sigma, backface, shared, vr6=vr6,
+                               frame_normals=frame_normals)
         ctx.save_for_backward(world, M, V, first_idx, num_points, f["idx"], f["qvalue"], f["wsum"], f["scaler"],
                               f["pts_screen"], f["radii"], f["visible"], f["valid"])
         ctx.shared, ctx.radii_s = shared, float(radii_s)
@@ -294,4 +307,4 @@ class _RenderFused(autograd.Function):
         g_feat, g_pts = ops.render_backward(g_image.contiguous(), idx, qv, wsum, scaler, pts_screen, radii, visible,
                                             first_idx, num_points, ctx.radii_s, ctx.clip)
         g_world = ops.project_backward(world, M, V, first_idx, num_points, g_pts, valid, ctx.shared)
-        return (g_world, g_feat) + (None,) * 17
+        return (g_world, g_feat) + (None,) * 19

@@ -216,7 +216,8 @@ DSS_API int dss_blend_backward_scatter(const float *grad_out, const int32_t *idx
 #define DSS_WS_CLEAN 1
 DSS_API size_t dss_render_forward_workspace(int N, int64_t P, int S, int K);
 DSS_API int dss_render_forward(const float *world, const float *normals, const float *h_point,
-                               const float *h_cloud, const float *M, const float *V, const float *znear,
+                               const float *h_cloud, const float *vr6, const float *frame_normals,
+                               const float *M, const float *V, const float *znear,
                                const float *zfar, const int64_t *first_idx, const int64_t *num_pts,
                                int N, int64_t P, int shared_cloud, int backface_culling, int S, int K,
                                float cutoff_threshold, float antialiasing_sigma, float merge_thr,
@@ -257,6 +258,9 @@ DSS_API int dss_render_backward(const float *grad_out, const int32_t *idx, const
  *   _compute_WJk (:443-496), Vrk = h (I - n n^T) (:293-402), _compute_variance_and_detMk (:404-441),
  *   _get_per_point_info / _get_ellipse_axis_aligned_radius (:525-565, :498-523).
  *   world, normals (Pw,3); h_point (Pw,) or h_cloud (N,) (exactly one may be NULL);
+ *   anisotropic mode (Vrk_invariant = Vrk_isotropic = False, rasterizer.py:256-291): vr6 (Pw,6) = Vrk per point
+ *   (xx,xy,xz,yy,yz,zz) and frame_normals (Pw,3) = normal of the PCA frame, both from dss_local_frames; h is then
+ *   unused and may be NULL;
  *   M, V (N,4,4): cameras.get_full_projection_transform().get_matrix() and
  *   get_world_to_view_transform().get_matrix() (row-vector convention, p_h @ M);
  *   shared_cloud=1: one cloud of Pw points is rendered by all N cameras (Pointclouds.extend(N),
@@ -266,7 +270,9 @@ DSS_API int dss_render_backward(const float *grad_out, const int32_t *idx, const
  * z=-1 (ignored by every kernel), so no host round trip is needed for the new sizes.
  * ------------------------------------------------------------------------------------------- */
 DSS_API int dss_point_setup(const float *world, const float *normals, const float *h_point,
-                            const float *h_cloud, const float *M, const float *V, const float *znear,
+                            const float *h_cloud, const float *vr6 /* (Pw,6) or NULL */,
+                            const float *frame_normals /* (Pw,3) or NULL */,
+                            const float *M, const float *V, const float *znear,
                             const float *zfar, const int64_t *first_idx, const int64_t *num_pts,
                             int N, int64_t P, int shared_cloud, int backface_culling, int S,
                             float cutoff_threshold, float antialiasing_sigma,
@@ -276,6 +282,15 @@ DSS_API int dss_point_setup(const float *world, const float *normals, const floa
 /* Backward of the projection (autograd of pytorch3d's transform, rasterizer.py:614):
  * grad_world[i] = sum over the cameras that see world point i of J^T grad_screen, J = d(ndc_x,
  * ndc_y, view_z)/d(world).  grad_world (Pw,3) is fully written; deterministic. */
+/* PCA frames of the K-neighbourhoods for the anisotropic source variance (rasterizer.py:256-291 +
+ * utils/mathHelper.py:34-92 estimate_pointcloud_local_coord_frames, neighborhood_size = 8): knn_idx (P,K) are the
+ * cloud-local ids of dss_knn_points (self included); covariance of the K points about their mean, eigen-
+ * decomposition (the reference: batched SVD of the centred (K,3) matrix, curvature = sigma^2 / K).  Outputs:
+ * vr6 (P,6) = F diag(c1,c2) F^T with F the two principal tangent directions (= C - c0 e0 e0^T), frame_normals
+ * (P,3) = e0, curvature (P,3) ascending (may be NULL). */
+DSS_API int dss_local_frames(const float *points /* (P,3) */, const int64_t *knn_idx /* (P,K) */,
+                             const int64_t *first_idx, const int64_t *num_pts, int N, int64_t P, int K,
+                             float *vr6, float *frame_normals, float *curvature, void *stream);
 DSS_API int dss_project_backward(const float *world, const float *M, const float *V,
                                  const int64_t *first_idx, const int64_t *num_pts, int N, int64_t Pw,
                                  int shared_cloud, const float *grad_screen /* (P,3) */,

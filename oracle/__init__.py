@@ -188,7 +188,8 @@ def blend_backward(grad_out, idx, qv, scaler, P):
     return gf, go
 
 
-def point_setup(pts_world, normals, h, cloud_of, M, V, S, cutoff, sigma):
+def point_setup(pts_world, normals, h, cloud_of, M, V, S, cutoff, sigma, vr6=None, frame_normals=None):
+    """vr6 (P,6) + frame_normals (P,3): anisotropic source variance (rasterizer.py:256-291), see local_frames."""
     pts_world, normals, h, M, V = _f32(pts_world), _f32(normals), _f32(h), _f32(M), _f32(V)
     cloud_of = np.ascontiguousarray(cloud_of, np.int32)
     P = pts_world.shape[0]
@@ -197,7 +198,24 @@ def point_setup(pts_world, normals, h, cloud_of, M, V, S, cutoff, sigma):
     ra = np.empty((P, 2), np.float32)
     sc = np.empty((P,), np.float32)
     cu = np.empty((P,), np.float32)
+    if vr6 is not None:
+        vr6, frame_normals = _f32(vr6), _f32(frame_normals)
     _lib().oracle_point_setup(_p(pts_world), _p(normals), _p(h), _p(cloud_of), _p(M), _p(V),
                               ctypes.c_int64(P), S, ctypes.c_float(cutoff), ctypes.c_float(sigma),
+                              _p(vr6) if vr6 is not None else None,
+                              _p(frame_normals) if vr6 is not None else None,
                               _p(ps), _p(el), _p(ra), _p(sc), _p(cu))
     return ps, el, ra, sc, cu
+
+
+def local_frames(points, knn_idx_packed):
+    """PCA frames of the K-neighbourhoods (mathHelper.py:34-92) -> (vr6 (P,6), frame normal (P,3), curvature (P,3)
+    ascending).  knn_idx_packed (P,K) int64 holds PACKED point ids (self included)."""
+    points = _f32(points)
+    idx = np.ascontiguousarray(knn_idx_packed, np.int64)
+    P, K = idx.shape
+    vr6 = np.empty((P, 6), np.float32)
+    fn = np.empty((P, 3), np.float32)
+    cv = np.empty((P, 3), np.float32)
+    _lib().oracle_local_frames(_p(points), _p(idx), ctypes.c_int64(P), K, _p(vr6), _p(fn), _p(cv))
+    return vr6, fn, cv

@@ -508,13 +508,91 @@ static inline float eps_denom_py(float d)
 }
 static inline float eps_sqrt_py(float d) { const float a = fabsf(d); return a > 1e-17f ? a : 1e-17f; }
 
+/* ---------------------------------------------------------------------------------------------
+ * Anisotropic source variance (rasterizer.py:256-291 + mathHelper.py:34-92): for every point, the K nearest
+ * points of its cloud (the point itself included, pytorch3d knn_points) are centred on their mean; the
+ * singular values of the (K,3) difference matrix give curvature = sigma^2 / K = eigenvalues of the neighbourhood
+ * covariance C = (1/K) sum d d^T, ascending, with the right singular vectors as frame.  The frame's last two
+ * columns F (tangent directions) and curvatures give Vrk = F diag(c1, c2) F^T = C - c0 e0 e0^T, and Sk = F^T.
+ * Restated with a cyclic Jacobi eigen-solver in double precision (the reference uses an fp32 batched SVD).
+ * knn_idx holds PACKED point ids.  Outputs: vr6 (xx,xy,xz,yy,yz,zz), frame_n = e0, curv (ascending).
+ * ------------------------------------------------------------------------------------------- */
+static void jacobi_eig3(double A[3][3], double V[3][3])
+{
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) V[i][j] = (i == j);
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        const double off = A[0][1] * A[0][1] + A[0][2] * A[0][2] + A[1][2] * A[1][2];
+        if (off < 1e-300) break;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                if (fabs(A[p][q]) < 1e-300) continue;
+                const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+                for (int k = 0; k < 3; ++k) {
+                    const double akp = A[k][p], akq = A[k][q];
+                    A[k][p] = c * akp - sn * akq;
+                    A[k][q] = sn * akp + c * akq;
+                }
+                for (int k = 0; k < 3; ++k) {
+                    const double apk = A[p][k], aqk = A[q][k];
+                    A[p][k] = c * apk - sn * aqk;
+                    A[q][k] = sn * apk + c * aqk;
+                }
+                for (int k = 0; k < 3; ++k) {
+                    const double vkp = V[k][p], vkq = V[k][q];
+                    V[k][p] = c * vkp - sn * vkq;
+                    V[k][q] = sn * vkp + c * vkq;
+                }
+            }
+    }
+}
+
+DSS_ORACLE_API void oracle_local_frames(const float *pts /* (P,3) */, const int64_t *knn_idx /* (P,K) packed ids */,
+                                        int64_t P, int K, float *vr6 /* (P,6) */, float *frame_n /* (P,3) */,
+                                        float *curv /* (P,3) */)
+{
+    for (int64_t p = 0; p < P; ++p) {
+        double mean[3] = {0, 0, 0};
+        for (int k = 0; k < K; ++k)
+            for (int d = 0; d < 3; ++d) mean[d] += (double)pts[3 * knn_idx[p * K + k] + d];
+        for (int d = 0; d < 3; ++d) mean[d] /= K;
+        double C[3][3] = {{0}};
+        for (int k = 0; k < K; ++k) {
+            double df[3];
+            for (int d = 0; d < 3; ++d) df[d] = (double)pts[3 * knn_idx[p * K + k] + d] - mean[d];
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 3; ++j) C[i][j] += df[i] * df[j] / K;
+        }
+        double A[3][3], V[3][3];
+        memcpy(A, C, sizeof(A));
+        jacobi_eig3(A, V);
+        int o[3] = {0, 1, 2};  /* ascending eigenvalues */
+        for (int i = 0; i < 2; ++i)
+            for (int j = i + 1; j < 3; ++j)
+                if (A[o[j]][o[j]] < A[o[i]][o[i]]) { const int t = o[i]; o[i] = o[j]; o[j] = t; }
+        const double l0 = A[o[0]][o[0]];
+        const double e0[3] = {V[0][o[0]], V[1][o[0]], V[2][o[0]]};
+        for (int d = 0; d < 3; ++d) {
+            curv[3 * p + d] = (float)A[o[d]][o[d]];
+            frame_n[3 * p + d] = (float)e0[d];
+        }
+        const int ii[6] = {0, 0, 0, 1, 1, 2}, jj[6] = {0, 1, 2, 1, 2, 2};
+        for (int q = 0; q < 6; ++q) vr6[6 * p + q] = (float)(C[ii[q]][jj[q]] - l0 * e0[ii[q]] * e0[jj[q]]);
+    }
+}
+
 DSS_ORACLE_API void oracle_point_setup(
     const float *pts_world /* (P,3) */, const float *normals /* (P,3) */, const float *h /* (P,) */,
     const int32_t *cloud_of /* (P,) */, const float *M /* (N,4,4) */, const float *V /* (N,4,4) */,
     int64_t P, int S, float cutoffC, float sigma,
+    const float *vr6 /* (P,6) xx,xy,xz,yy,yz,zz or NULL */, const float *frame_n /* (P,3) or NULL */,
     float *pts_screen /* (P,3) */, float *ellipse /* (P,3) */, float *radii /* (P,2) */,
     float *scaler /* (P,) */, float *cutoff /* (P,) */)
 {
+    /* vr6 != NULL: anisotropic source variance (rasterizer.py:256-291): Vrk is given per point and the tangent
+     * frame of det(Sk WJk) is the PCA frame, whose normal is frame_n (the cloud normals are not used). */
     const float pixel = 2.0f / (float)S;
     for (int64_t p = 0; p < P; ++p) {
         const float *m = M + 16 * cloud_of[p];
@@ -538,7 +616,7 @@ DSS_ORACLE_API void oracle_point_setup(
         /* Sk is built from NORMALISED cross products (rasterizer.py:337-341, F.normalize eps 1e-12), so
          * Sk^T Sk = I - n^ n^^T for the unit normal n^ whatever the length of the stored normal
          * (bunny-8000.ply stores |n| = 56.25); a zero normal gives Sk = 0. */
-        const float *nraw = normals + 3 * p;
+        const float *nraw = vr6 ? frame_n + 3 * p : normals + 3 * p;
         const float nlen = sqrtf(nraw[0] * nraw[0] + nraw[1] * nraw[1] + nraw[2] * nraw[2]);
         const float nden = nlen > 1e-12f ? nlen : 1e-12f;
         const float nn[3] = { nraw[0] / nden, nraw[1] / nden, nraw[2] / nden };
@@ -549,6 +627,11 @@ DSS_ORACLE_API void oracle_point_setup(
         for (int i = 0; i < 3; ++i)
             for (int j = 0; j < 3; ++j)
                 Vr[i][j] = hv * ((i == j ? 1.0f : 0.0f) - nn[i] * nn[j]);
+        if (vr6) {
+            const float *q = vr6 + 6 * p;
+            Vr[0][0] = q[0]; Vr[0][1] = Vr[1][0] = q[1]; Vr[0][2] = Vr[2][0] = q[2];
+            Vr[1][1] = q[3]; Vr[1][2] = Vr[2][1] = q[4]; Vr[2][2] = q[5];
+        }
         float T[3][2];
         for (int i = 0; i < 3; ++i)
             for (int j = 0; j < 2; ++j)

@@ -66,16 +66,45 @@ sys.meta_path.insert(0, _StubFinder())
 import pytorch3d.ops as ops3d  # noqa: E402  (the stub)
 
 
-def _knn_points(p1, p2, lengths1=None, lengths2=None, K=1, **kw):
+import collections  # noqa: E402
+_KNN = collections.namedtuple("KNN", "dists idx knn")
+
+
+def _knn_points(p1, p2, lengths1=None, lengths2=None, K=1, return_nn=False, **kw):
     d = torch.cdist(p1.double(), p2.double()).pow(2).float()
     if lengths2 is not None:
         for b in range(p2.shape[0]):
             d[b, :, int(lengths2[b]):] = float("inf")
     vals, idx = d.topk(K, dim=-1, largest=False)
-    return vals, idx, None
+    nn = None
+    if return_nn:  # (N,P1,K,3)
+        nn = torch.stack([p2[b][idx[b]] for b in range(p2.shape[0])], 0)
+    return _KNN(vals, idx, nn)
 
 
 ops3d.knn_points = _knn_points
+import pytorch3d.ops.utils as _ops_utils  # noqa: E402
+
+
+def _convert_pointclouds_to_tensor(pcl):
+    if torch.is_tensor(pcl):
+        return pcl, torch.full((pcl.shape[0],), pcl.shape[1], dtype=torch.int64, device=pcl.device)
+    return pcl.points_padded(), pcl.num_points_per_cloud()
+
+
+_ops_utils.convert_pointclouds_to_tensor = _convert_pointclouds_to_tensor
+ops3d.convert_pointclouds_to_tensor = _convert_pointclouds_to_tensor
+import torch_batch_svd as _tbs  # noqa: E402  (the stub)
+
+
+def _batch_svd(x):
+    """torch_batch_svd.svd returns (U, S, V) with x = U diag(S) V^T: torch.linalg.svd stand-in (fp32, like the
+    reference's CUDA batched SVD)."""
+    U, S, Vh = torch.linalg.svd(x, full_matrices=False)
+    return U, S, Vh.transpose(-1, -2)
+
+
+_tbs.svd = _batch_svd
 
 
 def _padded_to_packed(inputs, first_idxs, num_inputs):
@@ -111,7 +140,8 @@ def main():
         N = len(az)
         cloud = PointClouds3D([torch.from_numpy(pts)] * N, [torch.from_numpy(nrm)] * N)
         for mode, kw in (("global", dict(Vrk_invariant=True, Vrk_isotropic=False)),
-                         ("iso", dict(Vrk_invariant=False, Vrk_isotropic=True))):
+                         ("iso", dict(Vrk_invariant=False, Vrk_isotropic=True)),
+                         ("aniso", dict(Vrk_invariant=False, Vrk_isotropic=False))):
             st = ref_rast.PointsRasterizationSettings(cutoff_threshold=1.0, image_size=S, antialiasing_sigma=1.0, **kw)
             rast = ref_rast.SurfaceSplatting(cameras=cams, raster_settings=st, frnn_radius=-1)
             rast.cameras, rast._Vrk_h = cams, None  # (pytorch3d PointsRasterizer.__init__ would set .cameras)
@@ -119,6 +149,10 @@ def main():
                 info = rast._get_per_point_info(cloud, cameras=cams, raster_settings=st)
             for k, v in info.items():
                 out["%s_%s_%s" % (tag, mode, k)] = v.numpy().astype(np.float32)
+            if mode == "aniso" and tag == "1cam":  # the intermediate the new code is pinned on
+                with torch.no_grad():
+                    Vr, Sk = rast._compute_anisotropic_Vrk(cloud)
+                out["aniso_Vr"], out["aniso_Sk"] = Vr.numpy().astype(np.float32), Sk.numpy().astype(np.float32)
         out[tag + "_M"] = cams.get_full_projection_transform().get_matrix().numpy()
         out[tag + "_V"] = cams.get_world_to_view_transform().get_matrix().numpy()
     out["points"], out["normals"], out["S"] = pts, nrm, np.int32(S)

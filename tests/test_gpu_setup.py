@@ -268,3 +268,81 @@ def test_renderer_without_compositor_is_unnormalised_weighted_sum():
     (want * g[..., :3]).sum().backward()
     g_ref = feat2.grad[:pts.shape[0]] + feat2.grad[pts.shape[0]:]
     assert (C.grad - g_ref).norm() / g_ref.norm() <= 1e-4
+
+
+def test_local_frames_match_oracle_and_reference_golden(golden_dir):
+    """dss_local_frames (fp32 Jacobi) vs the oracle's fp64 restatement and vs the reference's own
+    `_compute_anisotropic_Vrk` (golden, make_golden_setup.py); neighbourhoods from dss_knn_points (K = 8)."""
+    import os
+    z = np.load(os.path.join(golden_dir, "ref_setup_teapot.npz"))
+    pts = z["points"]
+    P = len(pts)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    first = torch.zeros(1, dtype=torch.int64, device=DEV)
+    num = torch.full((1,), P, dtype=torch.int64, device=DEV)
+    _, idx = ops.knn_points(t(pts), first, num, 8)
+    vr6, fn, cv = ops.local_frames(t(pts), idx, first, num, return_curvature=True)
+    o_vr6, o_fn, o_cv = oracle.local_frames(pts, idx.cpu().numpy())
+    scale = np.abs(o_vr6).max()
+    gap = (o_cv[:, 1] - o_cv[:, 0]) / np.maximum(o_cv[:, 2], 1e-30) > 1e-2   # well-defined normal
+    assert np.abs(vr6.cpu().numpy() - o_vr6)[gap].max() <= 1e-4 * scale
+    assert np.allclose(cv.cpu().numpy(), o_cv, rtol=1e-3, atol=1e-5 * o_cv.max())
+    assert (np.abs((fn.cpu().numpy() * o_fn).sum(1))[gap] >= 1 - 1e-4).all()     # same normal up to sign
+    ref_vr = z["aniso_Vr"]
+    got = vr6.cpu().numpy()
+    got33 = np.stack([got[:, [0, 1, 2]], got[:, [1, 3, 4]], got[:, [2, 4, 5]]], 1)
+    assert np.abs(got33 - ref_vr)[gap].max() <= 3e-4 * np.abs(ref_vr).max()
+
+
+@pytest.mark.parametrize("tag", ["1cam", "3cam"])
+def test_anisotropic_rasterizer_matches_reference_python_golden(golden_dir, tag):
+    """End to end through the drop-in class: SurfaceSplatting with Vrk_invariant = Vrk_isotropic = False (kNN-8 ->
+    PCA frames -> fused setup) against the reference's `_get_per_point_info` in the same mode."""
+    import os
+    z = np.load(os.path.join(golden_dir, "ref_setup_teapot.npz"))
+    pts, nrm = z["points"], z["normals"]
+    az = {"1cam": [45.0], "3cam": [10.0, 130.0, 250.0]}[tag]
+    R, T = look_at_view_transform(2.0, 30.0, az)
+    cams = FoVPerspectiveCameras(znear=0.1, R=R, T=T, device=DEV)
+    N, S = len(az), int(z["S"])
+    st = PointsRasterizationSettings(cutoff_threshold=1.0, image_size=S, antialiasing_sigma=1.0, Vrk_invariant=False,
+                                     Vrk_isotropic=False, points_per_pixel=5, backface_culling=False)
+    rast = SurfaceSplatting(cameras=cams, raster_settings=st)
+    cloud = PointClouds3D([torch.from_numpy(pts).to(DEV)], [torch.from_numpy(nrm).to(DEV)],
+                          [torch.ones(len(pts), 3, device=DEV)])
+    frags, out_cloud, info = rast(cloud, verbose=True)
+    ref = lambda k: z["%s_aniso_%s" % (tag, k)]
+    o_vr6, o_fn, o_cv = oracle.local_frames(pts, np.asarray(
+        __import__("scipy.spatial", fromlist=["cKDTree"]).cKDTree(pts.astype(np.float64)).query(pts.astype(np.float64), k=8)[1]))
+    gap = np.tile((o_cv[:, 1] - o_cv[:, 0]) / np.maximum(o_cv[:, 2], 1e-30), N) > 1e-2
+    ra, el, sc = (info[k].cpu().numpy() for k in ("radii", "ellipse_params", "scaler"))
+    assert np.allclose(ra[gap], ref("radii")[gap], rtol=5e-4, atol=0)
+    assert np.abs(el - ref("ellipse_params"))[gap].max() <= 5e-4 * np.abs(ref("ellipse_params")).max()
+    assert np.abs(sc - ref("scaler"))[gap].max() <= 5e-4 * np.abs(ref("scaler")).max()
+    assert frags.occupancy.mean().item() > 0.05
+    # the fused renderer takes the same branch
+    img_a = SurfaceSplattingRenderer(rast, NormWeightedCompositor(), fused=True)(cloud)
+    img_b = SurfaceSplattingRenderer(rast, NormWeightedCompositor(), fused=False)(cloud)
+    assert torch.equal(img_a, img_b)
+
+
+def test_anisotropic_point_setup_matches_oracle_bits():
+    """Same Vrk in -> HIP setup == oracle setup bit for bit (like the other two variance modes)."""
+    pts, nrm, col, M, V, az = _scene()
+    N, Pc, S = M.shape[0], pts.shape[0], 128
+    from scipy.spatial import cKDTree
+    _, nn = cKDTree(pts.astype(np.float64)).query(pts.astype(np.float64), k=8)
+    vr6, fn, _ = oracle.local_frames(pts, nn)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    first = torch.arange(N, device=DEV) * Pc
+    num = torch.full((N,), Pc, device=DEV, dtype=torch.int64)
+    out = ops.point_setup(t(pts), t(nrm), torch.zeros(Pc, device=DEV), t(M), t(V), torch.full((N,), 0.01, device=DEV),
+                          torch.full((N,), 100.0, device=DEV), first, num, S, 1.0, 1.0, False, True, vr6=t(vr6),
+                          frame_normals=t(fn))
+    assert out["valid"].all()
+    tile = lambda a: np.tile(a, (N, 1))
+    ps, el, ra, sc, cu = oracle.point_setup(tile(pts), tile(nrm), np.zeros(N * Pc, np.float32),
+                                            np.repeat(np.arange(N, dtype=np.int32), Pc), M, V, S, 1.0, 1.0,
+                                            vr6=tile(vr6), frame_normals=tile(fn))
+    for mine, want in ((out["pts_screen"], ps), (out["ellipse_params"], el), (out["radii"], ra), (out["scaler"], sc)):
+        assert np.array_equal(mine.cpu().numpy(), want)
