@@ -228,8 +228,18 @@ class SurfaceSplatting(torch.nn.Module):
                     znear=as_n("znear", 1.0), zfar=as_n("zfar", 100.0), first_idx=first_idx, num_points=num_points,
                     out_clouds=out_clouds, raster_settings=raster_settings, vr6=vr6, frame_n=frame_n)
 
+    @staticmethod
+    def _apply_activation_filter(point_clouds, point_clouds_filter):
+        """rasterizer.py:230-234: a PointCloudsFilters object first drops the points whose ``activation`` flag is
+        off (duck-typed: DSS.core.cloud.PointCloudsFilters.filter_with)."""
+        if point_clouds_filter is not None and hasattr(point_clouds_filter, "filter_with"):
+            return point_clouds_filter.filter_with(point_clouds, ("activation",))
+        return point_clouds
+
     def forward(self, point_clouds, point_clouds_filter=None, **kwargs):
         raster_settings = kwargs.get("raster_settings", self.raster_settings)
+        if not point_clouds.isempty():
+            point_clouds = self._apply_activation_filter(point_clouds, point_clouds_filter)
         if point_clouds.isempty():
             cameras = kwargs.get("cameras", self.cameras)
             return self._empty_fragments(cameras.R.shape[0], point_clouds.device, raster_settings), point_clouds
@@ -265,6 +275,7 @@ class SurfaceSplatting(torch.nn.Module):
         -> ``(images (N,S,S,C+1), PointFragments, point_clouds)``.  Same values as ``forward`` + the
         renderer's blend; the autograd graph is one node, so gradients flow to the world points and the
         features only (a loss on ``fragments.zbuf`` needs the unfused path)."""
+        point_clouds = self._apply_activation_filter(point_clouds, point_clouds_filter)
         a = self._prepare(point_clouds, **kwargs)
         st = a["raster_settings"]
         feats = a["out_clouds"].features_packed()
