@@ -550,3 +550,68 @@ def cloud_mean_clamp(values, cloud_to_packed_first_idx, num_points_per_cloud, sc
                                       float(hi), float(fallback), int(min_points), _lib.ptr(out), _lib.stream_ptr(dev))
     _lib.check(rc, "dss_cloud_mean_clamp")
     return out
+
+
+def _phong_common(world, normals, rgb, first, num, shared_cloud, ambient, diffuse_color, specular_color, light_vec,
+                  cam_center):
+    world = _lib.require_gpu(world, "world", _f32)
+    normals = _lib.require_gpu(normals, "normals", _f32)
+    rgb = _lib.require_gpu(rgb, "rgb", _f32)
+    first = _lib.require_gpu(first, "cloud_to_packed_first_idx", _i64)
+    num = _lib.require_gpu(num, "num_points_per_cloud", _i64)
+    N, Pw = first.shape[0], world.shape[0]
+    P = N * Pw if shared_cloud else Pw
+    amb = _lib.require_gpu(ambient, "ambient", _f32)
+    kd = _lib.require_gpu(diffuse_color, "diffuse_color", _f32)
+    ks = _lib.require_gpu(specular_color, "specular_color", _f32)
+    lv = _lib.require_gpu(light_vec, "light_vec", _f32)
+    cam = _lib.require_gpu(cam_center, "cam_center", _f32)
+    L = kd.shape[1] if kd.dim() == 3 else 0
+    if tuple(rgb.shape) != (P, 3) or normals.shape != world.shape or tuple(amb.shape) != (N, 3) \
+            or tuple(kd.shape) != (N, L, 3) or tuple(ks.shape) != (N, L, 3) or tuple(lv.shape) != (N, L, 3) \
+            or tuple(cam.shape) != (N, 3):
+        raise RuntimeError("phong: need rgb (P,3), ambient / cam_center (N,3), light tensors (N,L,3)")
+    return world, normals, rgb, first, num, N, Pw, P, amb, kd, ks, lv, cam, L
+
+
+def phong_forward(world, normals, rgb, cloud_to_packed_first_idx, num_points_per_cloud, ambient, diffuse_color,
+                  specular_color, light_vec, point_lights: bool, cam_center, shininess: float = 64.0,
+                  shared_cloud: bool = False):
+    """Phong shading of the points (LightingTexture.forward, texture.py:65-125; lighting.py:10-172) -> (P,3)."""
+    lib = _lib.load()
+    world, normals, rgb, first, num, N, Pw, P, amb, kd, ks, lv, cam, L = _phong_common(
+        world, normals, rgb, cloud_to_packed_first_idx, num_points_per_cloud, shared_cloud, ambient, diffuse_color,
+        specular_color, light_vec, cam_center)
+    dev = world.device
+    with torch.cuda.device(dev):
+        out = torch.empty((P, 3), dtype=_f32, device=dev)
+        rc = lib.dss_phong_forward(_lib.ptr(world), _lib.ptr(normals), _lib.ptr(rgb), _lib.ptr(first), _lib.ptr(num), N, Pw,
+                                   int(shared_cloud), _lib.ptr(amb), _lib.ptr(kd), _lib.ptr(ks), _lib.ptr(lv), L,
+                                   int(point_lights), _lib.ptr(cam), float(shininess), _lib.ptr(out),
+                                   _lib.stream_ptr(dev))
+    _lib.check(rc, "dss_phong_forward")
+    return out
+
+
+def phong_backward(grad_out, world, normals, rgb, cloud_to_packed_first_idx, num_points_per_cloud, ambient,
+                   diffuse_color, specular_color, light_vec, point_lights: bool, cam_center, shininess: float = 64.0,
+                   shared_cloud: bool = False):
+    """-> (grad_world (Pw,3), grad_normals (Pw,3), grad_rgb (P,3))."""
+    lib = _lib.load()
+    world, normals, rgb, first, num, N, Pw, P, amb, kd, ks, lv, cam, L = _phong_common(
+        world, normals, rgb, cloud_to_packed_first_idx, num_points_per_cloud, shared_cloud, ambient, diffuse_color,
+        specular_color, light_vec, cam_center)
+    grad_out = _lib.require_gpu(grad_out, "grad_out", _f32)
+    if tuple(grad_out.shape) != (P, 3):
+        raise RuntimeError("phong_backward: grad_out must be (P,3)")
+    dev = world.device
+    with torch.cuda.device(dev):
+        gw = torch.empty((Pw, 3), dtype=_f32, device=dev)
+        gn = torch.empty((Pw, 3), dtype=_f32, device=dev)
+        gc = torch.empty((P, 3), dtype=_f32, device=dev)
+        rc = lib.dss_phong_backward(_lib.ptr(grad_out), _lib.ptr(world), _lib.ptr(normals), _lib.ptr(rgb), _lib.ptr(first),
+                                    _lib.ptr(num), N, Pw, int(shared_cloud), _lib.ptr(amb), _lib.ptr(kd), _lib.ptr(ks),
+                                    _lib.ptr(lv), L, int(point_lights), _lib.ptr(cam), float(shininess), _lib.ptr(gw),
+                                    _lib.ptr(gn), _lib.ptr(gc), _lib.stream_ptr(dev))
+    _lib.check(rc, "dss_phong_backward")
+    return gw, gn, gc

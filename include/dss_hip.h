@@ -323,6 +323,33 @@ DSS_API int dss_cloud_mean_clamp(const float *values /* (P,) */, const int64_t *
                                  const int64_t *num_pts, int N, float scale, float lo, float hi,
                                  float fallback, int min_points, float *out /* (N,) */, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Phong shading of the points = LightingTexture.forward (DSS/core/texture.py:65-125):
+ * apply_lighting (:26-63) with lighting.py:10-77 (diffuse) and :80-172 (specular) for L PointLights
+ * (point_lights = 1: light_vec = location, direction = location - point, lighting.py:239-302) or
+ * DirectionalLights (point_lights = 0: light_vec = direction, :175-236) per cloud:
+ *   out[p] = rgb[p] * (ambient[n] + sum_l diffuse_color[n,l] relu(n^.d^))
+ *            + sum_l specular_color[n,l] (relu(v^.(-d^ + 2 (n^.d^) n^)) [n^.d^ > 0])^shininess
+ * with n^, d^, v^ = normalize(normal / direction / camera - point) (F.normalize, eps 1e-6).
+ *   world, normals (Pw,3); rgb, out (P,3) packed per (camera, point); shared_cloud as in dss_point_setup;
+ *   ambient (N,3) (already summed over lights), diffuse_color / specular_color / light_vec (N,L,3),
+ *   cam_center (N,3) = cameras.get_camera_center().
+ * Backward: grad_world / grad_normals (Pw,3) (summed over the cameras of a shared cloud in camera order) and
+ * grad_rgb (P,3); any of the three may be NULL.  This is the path by which an RGB loss reaches the normals.
+ * ------------------------------------------------------------------------------------------- */
+DSS_API int dss_phong_forward(const float *world, const float *normals, const float *rgb,
+                              const int64_t *first_idx, const int64_t *num_pts, int N, int64_t Pw,
+                              int shared_cloud, const float *ambient, const float *diffuse_color,
+                              const float *specular_color, const float *light_vec, int L, int point_lights,
+                              const float *cam_center, float shininess, float *out, void *stream);
+DSS_API int dss_phong_backward(const float *grad_out, const float *world, const float *normals,
+                               const float *rgb, const int64_t *first_idx, const int64_t *num_pts, int N,
+                               int64_t Pw, int shared_cloud, const float *ambient,
+                               const float *diffuse_color, const float *specular_color,
+                               const float *light_vec, int L, int point_lights, const float *cam_center,
+                               float shininess, float *grad_world, float *grad_normals, float *grad_rgb,
+                               void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -219,3 +219,17 @@ def local_frames(points, knn_idx_packed):
     cv = np.empty((P, 3), np.float32)
     _lib().oracle_local_frames(_p(points), _p(idx), ctypes.c_int64(P), K, _p(vr6), _p(fn), _p(cv))
     return vr6, fn, cv
+
+
+def phong_forward(points, normals, rgb, cloud_of, ambient, diffuse_color, specular_color, light_vec, point_lights,
+                  cam_center, shininess):
+    """LightingTexture.forward (texture.py:65-125, lighting.py:10-172) -> (shaded, diffuse, specular), each (P,3)."""
+    points, normals, rgb = _f32(points), _f32(normals), _f32(rgb)
+    ambient, kd, ks, lv, cam = _f32(ambient), _f32(diffuse_color), _f32(specular_color), _f32(light_vec), _f32(cam_center)
+    cloud_of = np.ascontiguousarray(cloud_of, np.int32)
+    P, L = points.shape[0], kd.shape[1]
+    out, dif, spc = (np.empty((P, 3), np.float32) for _ in range(3))
+    _lib().oracle_phong_forward(_p(points), _p(normals), _p(rgb), _p(cloud_of), ctypes.c_int64(P), _p(ambient), _p(kd),
+                                _p(ks), _p(lv), L, int(bool(point_lights)), _p(cam), ctypes.c_float(shininess), _p(out),
+                                _p(dif), _p(spc))
+    return out, dif, spc

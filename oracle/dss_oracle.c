@@ -662,3 +662,57 @@ DSS_ORACLE_API void oracle_point_setup(
         cutoff[p] = cutoffC;
     }
 }
+
+
+/* ---------------------------------------------------------------------------------------------
+ * Phong shading of the points: LightingTexture.forward (DSS/core/texture.py:65-125) = apply_lighting
+ * (:26-63) with `diffuse` (DSS/core/lighting.py:10-77) and `specular` (:80-172), L lights per cloud, as
+ * PointLights (direction = location - point, lighting.py:270-276) or DirectionalLights:
+ *   n^ = n / max(|n|, 1e-6) (F.normalize), same for the light direction d^ and the view direction v^
+ *   diffuse  = sum_l kd_l relu(n^.d^)
+ *   specular = sum_l ks_l (relu(v^.(-d^ + 2 (n^.d^) n^)) [n^.d^ > 0])^shininess
+ *   out = rgb (ambient + diffuse) + specular                                   (texture.py:118-122)
+ * fp32 like the reference.  cloud_of (P,) gives the cloud of every packed point.
+ * ------------------------------------------------------------------------------------------- */
+static void normalize3(const float *v, float *o)
+{
+    float n = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    if (n < 1e-6f) n = 1e-6f;
+    o[0] = v[0] / n; o[1] = v[1] / n; o[2] = v[2] / n;
+}
+
+DSS_ORACLE_API void oracle_phong_forward(const float *pts, const float *normals, const float *rgb, const int32_t *cloud_of,
+                                         int64_t P, const float *ambient /* (N,3) */, const float *kd /* (N,L,3) */,
+                                         const float *ks, const float *lvec, int L, int point_lights,
+                                         const float *cam /* (N,3) */, float shininess, float *out /* (P,3) */,
+                                         float *out_diffuse, float *out_specular /* (P,3) or NULL */)
+{
+    for (int64_t p = 0; p < P; ++p) {
+        const int n = cloud_of[p];
+        float nh[3], v[3], dif[3] = {0, 0, 0}, spec[3] = {0, 0, 0};
+        normalize3(normals + 3 * p, nh);
+        const float w[3] = {cam[3 * n] - pts[3 * p], cam[3 * n + 1] - pts[3 * p + 1], cam[3 * n + 2] - pts[3 * p + 2]};
+        normalize3(w, v);
+        for (int l = 0; l < L; ++l) {
+            const float *lv = lvec + ((size_t)n * L + l) * 3;
+            float u[3] = {lv[0], lv[1], lv[2]}, d[3];
+            if (point_lights) { u[0] -= pts[3 * p]; u[1] -= pts[3 * p + 1]; u[2] -= pts[3 * p + 2]; }
+            normalize3(u, d);
+            const float ca = nh[0] * d[0] + nh[1] * d[1] + nh[2] * d[2];
+            const float r[3] = {-d[0] + 2.0f * (ca * nh[0]), -d[1] + 2.0f * (ca * nh[1]), -d[2] + 2.0f * (ca * nh[2])};
+            float a0 = v[0] * r[0] + v[1] * r[1] + v[2] * r[2];
+            if (a0 < 0) a0 = 0;
+            const float alpha = ca > 0 ? a0 : 0.0f;
+            const float D = ca > 0 ? ca : 0.0f, S = powf(alpha, shininess);
+            for (int ch = 0; ch < 3; ++ch) {
+                dif[ch] += kd[((size_t)n * L + l) * 3 + ch] * D;
+                spec[ch] += ks[((size_t)n * L + l) * 3 + ch] * S;
+            }
+        }
+        for (int ch = 0; ch < 3; ++ch) {
+            out[3 * p + ch] = rgb[3 * p + ch] * (ambient[3 * n + ch] + dif[ch]) + spec[ch];
+            if (out_diffuse) out_diffuse[3 * p + ch] = dif[ch];
+            if (out_specular) out_specular[3 * p + ch] = spec[ch];
+        }
+    }
+}

@@ -161,6 +161,56 @@ def main():
         print(k, getattr(v, "shape", v))
 
 
+def lighting_vectors():
+    """tests/golden/ref_lighting.npz: the reference's own `diffuse` / `specular` (DSS/core/lighting.py:10-172) on
+    packed inputs, combined like LightingTexture.forward (texture.py:118-122), for two clouds with two lights each,
+    as point lights (direction = location - point, lighting.py:270-276) and as directional lights.
+    `convert_to_tensors_and_broadcast` (pytorch3d, absent) is replaced by a stand-in that broadcasts dim 0."""
+    import pytorch3d.renderer as p3r  # the stub
+
+    def _ctb(*args, device="cpu", dtype=torch.float32):
+        ts = [a if torch.is_tensor(a) else torch.as_tensor(a, dtype=dtype) for a in args]
+        n = max(t.shape[0] if t.dim() > 0 else 1 for t in ts)
+        out = []
+        for t in ts:
+            if t.dim() == 0:
+                t = t.reshape(1)
+            out.append(t.expand((n,) + tuple(t.shape[1:])) if t.shape[0] == 1 and n > 1 else t)
+        return out
+
+    p3r.convert_to_tensors_and_broadcast = _ctb
+    import pytorch3d.renderer.lighting as _pl  # stub submodule: its DirectionalLights / PointLights are inert bases
+    p3r.lighting = _pl
+    lighting = importlib.import_module("DSS.core.lighting")
+    lighting.convert_to_tensors_and_broadcast = _ctb
+    g = torch.Generator().manual_seed(7)
+    num = [700, 500]
+    P, N, L = sum(num), 2, 2
+    pts = torch.randn(P, 3, generator=g) * 0.6
+    nrm = torch.randn(P, 3, generator=g)
+    nrm[::7] *= 30.0                      # un-normalised normals, like bunny-8000.ply
+    rgb = torch.rand(P, 3, generator=g)
+    batch = torch.cat([torch.full((n,), i, dtype=torch.int64) for i, n in enumerate(num)])
+    amb = torch.rand(N, 1, 3, generator=g) * 0.5
+    kd = torch.rand(N, L, 3, generator=g)
+    ks = torch.rand(N, L, 3, generator=g)
+    vec = torch.randn(N, L, 3, generator=g) * 2.0
+    cam = torch.randn(N, 3, generator=g) * 3.0
+    out = dict(points=pts.numpy(), normals=nrm.numpy(), rgb=rgb.numpy(), num=np.asarray(num, np.int64),
+               ambient=amb.numpy(), diffuse_color=kd.numpy(), specular_color=ks.numpy(), light_vec=vec.numpy(),
+               cam_center=cam.numpy(), shininess=np.float32(24.0))
+    for tag in ("point", "directional"):
+        direction = vec[batch] - pts[:, None, :] if tag == "point" else vec[batch]
+        dif = lighting.diffuse(normals=nrm, color=kd[batch], direction=direction)
+        spc = lighting.specular(points=pts, normals=nrm, direction=direction, color=ks[batch],
+                                camera_position=cam[batch], shininess=torch.full((P,), 24.0))
+        ambient = amb.sum(1)[batch]
+        out[tag + "_diffuse"], out[tag + "_specular"] = dif.numpy(), spc.numpy()
+        out[tag + "_shaded"] = (rgb * (ambient + dif) + spc).numpy()
+    np.savez_compressed(os.path.join(HERE, "ref_lighting.npz"), **out)
+    print("ref_lighting.npz", {k: getattr(v, "shape", v) for k, v in out.items()})
+
+
 class _Captured(Exception):
     pass
 
@@ -215,5 +265,6 @@ def backward_radius_vectors():
 
 
 if __name__ == "__main__":
+    lighting_vectors()
     main()
     backward_radius_vectors()
