@@ -118,3 +118,26 @@ def test_lighting_texture_module_gradients_reach_normals():
     dl = DirectionalLights(direction=((0.0, 1.0, 1.0),), device=DEV)
     out2 = LightingTexture(cameras=cams, lights=dl)(PointClouds3D([X.detach()], [Nn.detach()], [C.detach()]))
     assert torch.isfinite(out2.features_packed()).all()
+
+
+def test_shaded_render_backpropagates_to_normals():
+    """texture -> renderer chain of train_mvr.py: an image loss reaches the normals through the shading only."""
+    from dss_amd.rasterizer import PointsRasterizationSettings, SurfaceSplatting
+    from dss_amd.renderer import NormWeightedCompositor, SurfaceSplattingRenderer
+    pts, nrm = scenes.load_cloud("teapot")
+    pts = scenes.normalize_unit_sphere(pts)
+    R, T = look_at_view_transform(2.0, 30.0, [45.0, 135.0])
+    cams = FoVPerspectiveCameras(znear=0.1, R=R, T=T, device=DEV)
+    st = PointsRasterizationSettings(cutoff_threshold=1.0, image_size=96, points_per_pixel=5, Vrk_invariant=True,
+                                     radii_backward_scaler=5, clip_pts_grad=0.05)
+    X = torch.nn.Parameter(torch.from_numpy(pts).to(DEV))
+    Nn = torch.nn.Parameter(torch.from_numpy(nrm).to(DEV))
+    C = torch.nn.Parameter(torch.full((len(pts), 3), 0.8, device=DEV))
+    tex = LightingTexture(cameras=cams, lights=PointLights(location=((1.5, 2.0, 1.0),), device=DEV))
+    colored = tex(PointClouds3D([X], [Nn], [C]))
+    renderer = SurfaceSplattingRenderer(SurfaceSplatting(cameras=cams, raster_settings=st), NormWeightedCompositor())
+    img = renderer(colored)
+    assert tuple(img.shape) == (2, 96, 96, 4)
+    (img[..., :3] - 0.5).pow(2).sum().backward()
+    assert Nn.grad.abs().sum() > 0 and X.grad.abs().sum() > 0 and C.grad.abs().sum() > 0
+    assert torch.isfinite(Nn.grad).all() and torch.isfinite(X.grad).all()
