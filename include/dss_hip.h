@@ -82,7 +82,8 @@ DSS_API int dss_splat_forward(const float *points, const float *ellipse, const f
 
 /* The two phases of dss_splat_forward, callable separately (the binned lists in `workspace` stay
  * valid until the next dss_splat_bin on it):
- *   dss_splat_bin   tile binning: count -> exclusive scan -> fill (replaces the coarse kernel
+ *   dss_splat_bin   tile binning: a memset + ONE kernel that appends every splat to the fixed-capacity
+ *                   sub-lists of the 8x8-pixel tiles it overlaps (replaces the coarse kernel
  *                   rasterize_points.cu:293-432 and its dense (N,B,B,M) bin table)
  *   dss_splat_fine  exactly ONE kernel launch: per-tile K-nearest + stores (replaces the fine kernel
  *                   rasterize_points.cu:506-597); workspace==NULL scans whole clouds (naive mode,
@@ -195,8 +196,8 @@ DSS_API int dss_blend_backward_scatter(const float *grad_out, const int32_t *idx
 
 /* ---------------------------------------------------------------------------------------------
  * Fused forward of SurfaceSplattingRenderer.forward (renderer.py:36-82 incl. the whole
- * SurfaceSplatting.forward, rasterizer.py:584-664) in one call and five launches:
- * [setup + tile count] -> scan -> fill -> [fine + blend].  Same inputs as dss_point_setup +
+ * SurfaceSplatting.forward, rasterizer.py:584-664) in one call and two launches (+ one memset unless
+ * DSS_WS_CLEAN): [setup + tile binning] -> [fine + blend].  Same inputs as dss_point_setup +
  * dss_splat_forward + dss_blend_forward, same outputs (all of them are written: the per-point
  * screen-space arrays, the fragments, visibility, the (N,rows,S,C+1) image and wsum), same bits.
  * K <= DSS_MAX_K_FAST, 1 <= C <= 8.
@@ -230,12 +231,14 @@ DSS_API int dss_render_forward(const float *world, const float *normals, const f
 
 /* ---------------------------------------------------------------------------------------------
  * Fused single-GPU backward of renderer + rasterizer: dss_blend_backward + dss_backward_radius +
- * dss_occ_backward + dss_clip_grad in five launches, with the per-point work done by persistent
+ * dss_occ_backward + dss_clip_grad in three launches for P <= 262,144 ([compaction of the visible ids and
+ * radius keys + alpha plane] -> [median] -> [gathers]; six above), with the per-point work done by persistent
  * wavefronts over the compacted list of visible points (the stand-alone kernels are bound by the
  * workgroup dispatch rate at DSS sizes).  No zbuf gradient; the occupancy gradient is the alpha channel
  * of grad_out (N,rows,S,C+1); it is first copied into a dense (N,rows,S) plane in the workspace (the
  * occupancy gather reads ~30 x 30 pixel windows per visible point: at a 16-byte stride it is bound by
- * L2 bandwidth, three quarters of every cache line fetched being colour gradient it does not need).  With a row band (multi-GPU) `visible` must be the union
+ * L2 bandwidth, three quarters of every cache line fetched being colour gradient it does not need).
+ * With a row band (multi-GPU) `visible` must be the union
  * over all ranks, the outputs are this band's partial sums, and clip must be <= 0 (clip after the
  * all-reduce with dss_clip_grad).
  * grad_feat may be NULL (rasterizer backward only).  grad_pts (P,3) and grad_feat (P,C) are fully
