@@ -706,6 +706,24 @@ __global__ __launch_bounds__(256) void render_backward_kernel(
     // wave-uniform, so it is kept in SGPRs (readfirstlane) and fetched with scalar loads; the NEXT task's
     // point id and record are requested before the current task's gathers and arrive during them (the
     // prologue was ~10 % of a task: two dependent round trips before the first gather load could issue).
+    // Cloud of a point without touching memory: every wavefront keeps (first, count, rs) of cloud `lane` in its
+    // lanes; the owner is found with one ballot.  (The scalar-load loop of find_cloud cost ~2 us per TASK at
+    // 8 clouds: two dependent loads per cloud.)  More than 64 clouds fall back to the loop.
+    const int64_t cl_first = lane < N ? first_idx[lane] : (int64_t)0x7fffffffffffffffll;
+    const int64_t cl_count = lane < N ? num_pts[lane] : 0;
+    const float cl_rs = lane < N ? rs[lane] : 0.0f;
+    auto cloud_of = [&](int64_t p, float &rs_n) -> int {
+        int n;
+        if (N <= 64) {
+            const unsigned long long own = __ballot(p >= cl_first && p < cl_first + cl_count);
+            n = own ? (int)__builtin_ctzll(own) : -1;
+        } else {
+            n = find_cloud(p, first_idx, num_pts, N);
+        }
+        rs_n = (n >= 0 && N <= 64) ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cl_rs), n < 0 ? 0 : n))
+                                   : (n >= 0 ? rs[n] : 0.0f);
+        return n;
+    };
     auto task_point = [&](uint32_t t) -> int {
         if (SEG) {
             // last segment that starts at or before t (starts are non-decreasing over lanes; empty segments
@@ -735,26 +753,32 @@ __global__ __launch_bounds__(256) void render_backward_kernel(
     // Static schedule: task t = wave, wave + n_waves, ...  (A dynamic one -- 64 atomic queue heads, one returning
     // atomic per task, next position prefetched -- was measured at HALF the speed on every configuration: a
     // returning global atomic is slower than a whole gather trip and sits in the same in-order return queue as
-    // the gather loads.)  Software pipeline, two tasks deep: point id of task i+2 (scalar load) and record of
-    // task i+1 (requested mid-gather) are in flight during task i.
+    // the gather loads.)  Software pipeline, three tasks deep: during task i the point id of task i+3 (scalar load)
+    // and the records of tasks i+1 and i+2 are in flight.  A record is requested a full task before it is
+    // needed: in a row band (multi-GPU) most tasks are rejected without any gather, and with a shallower
+    // pipeline each of those waited one memory round trip for the next record.
     const uint32_t wave_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave);
     uint32_t t = wave_u;
     if (t >= count) return;
     int p_cur = __builtin_amdgcn_readfirstlane(task_point(t));
     int p_nx = (t + n_waves < count) ? __builtin_amdgcn_readfirstlane(task_point(t + n_waves)) : 0;
+    int p_nx2 = (t + 2 * n_waves < count) ? __builtin_amdgcn_readfirstlane(task_point(t + 2 * n_waves)) : 0;
     SplatRec cur;
     unpack_rec(issue_rec(p_cur), cur);
+    float v_nx = (t + n_waves < count) ? issue_rec(p_nx) : 0.0f;
     for (;;) {
 #ifdef DSS_FINE_TIMING
         const long long tm0 = __builtin_amdgcn_s_memtime();
 #endif
         const uint32_t t_next = t + n_waves;
         const bool have_next = t_next < count;
-        int p_nx2 = 0;
-        float v_nx = 0.0f;
-        if (t_next + n_waves < count) p_nx2 = task_point(t_next + n_waves);
+        const bool have_next2 = t_next + n_waves < count;
+        int p_nx3 = 0;
+        float v_nx2 = 0.0f;
+        if (t_next + 2 * n_waves < count) p_nx3 = task_point(t_next + 2 * n_waves);
         const int64_t p = p_cur;
-        const int n = find_cloud(p, first_idx, num_pts, N);
+        float rs_n;
+        const int n = cloud_of(p, rs_n);
         float gx = 0.0f, gy = 0.0f;
         float acc[CM];
 #pragma unroll
@@ -763,11 +787,21 @@ __global__ __launch_bounds__(256) void render_backward_kernel(
         const long long tm1 = __builtin_amdgcn_s_memtime();
 #endif
         auto mid = [&]() {
-            if (have_next) v_nx = issue_rec(p_nx);
+            if (have_next2) v_nx2 = issue_rec(p_nx2);
         };
-        if (n >= 0) {
+        // Row band (multi-GPU): most visible points cannot reach this rank's rows (7 of 8 at 8 ranks).  One
+        // conservative test on the wave-uniform record skips both gathers for them (~300 of the ~400 fixed
+        // instructions of a task); the reductions then sum zeros and the point's partial is written as zero.
+        bool in_band = true;
+        if (rows < S && n >= 0) {
+            const float reach = fmaxf(rs_n, cur.ry);
+            const float band_lo = -1 + (2 * (S - row0 - rows)) / (float)S;      // lower edge of the lowest pixel row
+            const float band_hi = -1 + (2 * (S - 1 - row0) + 2.0f) / (float)S;  // upper edge of the highest one
+            in_band = !(cur.py + reach < band_lo || cur.py - reach > band_hi);
+        }
+        if (n >= 0 && in_band) {
             // occupancy gradient = dense copy of the alpha channel of the image gradient; blend loads overlapped
-            occ_blend_point_gather<C>(lane, p, n, cur, rs[n], grad_alpha, 1, grad_out, idx, qv, wsum, scaler, S, K, Cn,
+            occ_blend_point_gather<C>(lane, p, n, cur, rs_n, grad_alpha, 1, grad_out, idx, qv, wsum, scaler, S, K, Cn,
                                       row0, rows, grad_feat != nullptr, gx, gy, acc, mid);
         } else {
             mid();
@@ -802,8 +836,10 @@ __global__ __launch_bounds__(256) void render_backward_kernel(
         if (!have_next) break;
         t = t_next;
         p_cur = p_nx;
-        p_nx = __builtin_amdgcn_readfirstlane(p_nx2);
+        p_nx = p_nx2;
+        p_nx2 = __builtin_amdgcn_readfirstlane(p_nx3);
         unpack_rec(v_nx, cur);
+        v_nx = v_nx2;
     }
 #ifdef DSS_FINE_TIMING
     if (g_occ_timing && lane == 0) {
