@@ -214,7 +214,7 @@ struct FineArgs {
 
 // block id -> tile id.  Identity on purpose.  Consecutive workgroup ids are dealt round-robin to the 8
 // XCDs (each with its own L2); an XCD-contiguous mapping (XCD x owns tiles [x*T/8, (x+1)*T/8)) was
-// measured with tools/ab_xcd.py and is SLOWER (512^2 bunny: 37.3 vs 33.4 us; 8 x 1024^2, 1M points: 1.36
+// measured with an A/B build (round 1, not kept) and is SLOWER (512^2 bunny: 37.3 vs 33.4 us; 8 x 1024^2, 1M points: 1.36
 // vs 1.31 ms): the dense screen region then sits on one XCD, and the write traffic is already at the
 // algorithmic minimum (PMC WRITE_SIZE 22.7 MB vs 22.5 MB) so there is nothing for the shared L2 to merge.
 // Round-robin placement doubles as load balancing here.
