@@ -107,9 +107,10 @@ class Workload:
             ops.render_backward(g_band, idx, qv, wsum, info["scaler"], info["pts_screen"], info["radii"], vis_all,
                                 self.first, self.num, RADII_S, -1.0, image_size=S, rows=p.rows, out=(g_feat, g_pts))
             dist.all_reduce(self.bucket, op=dist.ReduceOp.SUM)  # collective 3/3: both gradient partials, one bucket
-            ops.clip_grad_(g_pts, CLIP)
             image = self.fx.finish()  # full render, (N,S,S,4) view of the receive buffer
-        g_world = ops.project_backward(self.world, self.M, self.V, self.first, self.num, g_pts, info["valid"], True)
+        # multi-GPU: the per-point clip follows the reduction and is applied inside the projection kernel
+        g_world = ops.project_backward(self.world, self.M, self.V, self.first, self.num, g_pts, info["valid"], True,
+                                       clip=CLIP if multi else -1.0)
         g_col = g_feat.view(self.N, self.Pc, 3).sum(0) if self.N > 1 else g_feat
         return image, g_world, g_col
 

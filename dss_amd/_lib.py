@@ -59,7 +59,7 @@ SIGNATURES = {
     "dss_local_frames": (_c_int, [_c_vp] * 4 + [_c_int, _c_i64, _c_int, _c_vp, _c_vp, _c_vp, _c_vp]),
     "dss_point_setup": (_c_int, [_c_vp] * 12 + [_c_int, _c_i64, _c_int, _c_int, _c_int, _c_f32, _c_f32]
                         + [_c_vp] * 6 + [_c_vp]),
-    "dss_project_backward": (_c_int, [_c_vp] * 5 + [_c_int, _c_i64, _c_int, _c_vp, _c_vp, _c_vp, _c_vp]),
+    "dss_project_backward": (_c_int, [_c_vp] * 5 + [_c_int, _c_i64, _c_int, _c_vp, _c_vp, _c_f32, _c_vp, _c_vp]),
     "dss_blend_backward": (_c_int, [_c_vp] * 10 + [_c_int, _c_i64, _c_int, _c_int, _c_int, _c_int, _c_int, _c_vp, _c_vp]),
     "dss_blend_backward_scatter": (_c_int, [_c_vp] * 4 + [_c_int] * 5 + [_c_i64, _c_vp, _c_vp]),
 }

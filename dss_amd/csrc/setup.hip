@@ -33,7 +33,8 @@ __global__ __launch_bounds__(256) void point_setup_kernel(const SetupArgs A)
 __global__ __launch_bounds__(256) void project_backward_kernel(
     const float *__restrict__ world, const float *__restrict__ M, const float *__restrict__ V,
     const int64_t *__restrict__ first_idx, const int64_t *__restrict__ num_pts, int N, int64_t Pw, int shared,
-    const float *__restrict__ grad_screen, const uint8_t *__restrict__ valid, float *__restrict__ grad_world)
+    const float *__restrict__ grad_screen, const uint8_t *__restrict__ valid, float clip,
+    float *__restrict__ grad_world)
 {
     const int64_t wi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (wi >= Pw) return;
@@ -55,7 +56,14 @@ __global__ __launch_bounds__(256) void project_backward_kernel(
         const float w = x * m[3] + y * m[7] + z * m[11] + m[15];
         const float iw = 1.0f / w;
         const float nx = cx * iw, ny = cy * iw;
-        const float gx = grad_screen[3 * p], gy = grad_screen[3 * p + 1], gz = grad_screen[3 * p + 2];
+        float gx = grad_screen[3 * p], gy = grad_screen[3 * p + 1], gz = grad_screen[3 * p + 2];
+        if (clip > 0.0f) {  // the per-point norm clip hook (rasterizer.py:667-673), same arithmetic as clip_grad_kernel
+            const float nrm = sqrtf(gx * gx + gy * gy + gz * gz);
+            const float sc = fminf(nrm, clip), den = fmaxf(nrm, 1e-12f);
+            gx = gx / den * sc;
+            gy = gy / den * sc;
+            gz = gz / den * sc;
+        }
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const float jx = (m[i * 4 + 0] - nx * m[i * 4 + 3]) * iw;
@@ -217,7 +225,8 @@ extern "C" int dss_point_setup(const float *world, const float *normals, const f
 
 extern "C" int dss_project_backward(const float *world, const float *M, const float *V, const int64_t *first_idx,
                                     const int64_t *num_pts, int N, int64_t Pw, int shared_cloud,
-                                    const float *grad_screen, const uint8_t *valid, float *grad_world, void *stream)
+                                    const float *grad_screen, const uint8_t *valid, float clip, float *grad_world,
+                                    void *stream)
 {
     if (N <= 0 || Pw < 0) { set_error("dss_project_backward: bad sizes"); return DSS_ERR_INVALID_ARGUMENT; }
     if (Pw == 0) return DSS_OK;
@@ -226,6 +235,6 @@ extern "C" int dss_project_backward(const float *world, const float *M, const fl
         return DSS_ERR_INVALID_ARGUMENT;
     }
     hipLaunchKernelGGL(project_backward_kernel, dim3((unsigned)((Pw + 255) / 256)), dim3(256), 0, as_stream(stream),
-                       world, M, V, first_idx, num_pts, N, Pw, shared_cloud, grad_screen, valid, grad_world);
+                       world, M, V, first_idx, num_pts, N, Pw, shared_cloud, grad_screen, valid, clip, grad_world);
     return check_launch("dss_project_backward");
 }

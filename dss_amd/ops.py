@@ -475,8 +475,9 @@ def point_setup(world, normals, h, M, V, znear, zfar, cloud_to_packed_first_idx,
 
 
 def project_backward(world, M, V, cloud_to_packed_first_idx, num_points_per_cloud, grad_screen, valid,
-                     shared_cloud: bool = False):
-    """grad of (NDC x, NDC y, view z) w.r.t. the world points -> (Pw,3)."""
+                     shared_cloud: bool = False, clip: float = -1.0):
+    """grad of (NDC x, NDC y, view z) w.r.t. the world points -> (Pw,3).  ``clip > 0`` applies the per-point norm
+    clip of ``clip_grad_`` to ``grad_screen`` on the fly (multi-GPU: the clip comes after the all-reduce)."""
     lib = _lib.load()
     world = _lib.require_gpu(world, "world", _f32)
     dev = world.device
@@ -490,8 +491,8 @@ def project_backward(world, M, V, cloud_to_packed_first_idx, num_points_per_clou
     with torch.cuda.device(dev):
         gw = torch.empty((Pw, 3), dtype=_f32, device=dev)
         rc = lib.dss_project_backward(_lib.ptr(world), _lib.ptr(M), _lib.ptr(V), _lib.ptr(first), _lib.ptr(num), N,
-                                      Pw, int(shared_cloud), _lib.ptr(grad_screen), _lib.ptr(vis), _lib.ptr(gw),
-                                      _lib.stream_ptr(dev))
+                                      Pw, int(shared_cloud), _lib.ptr(grad_screen), _lib.ptr(vis), float(clip),
+                                      _lib.ptr(gw), _lib.stream_ptr(dev))
     _lib.check(rc, "dss_project_backward")
     return gw
 

@@ -297,8 +297,9 @@ DSS_API int dss_local_frames(const float *points /* (P,3) */, const int64_t *knn
 DSS_API int dss_project_backward(const float *world, const float *M, const float *V,
                                  const int64_t *first_idx, const int64_t *num_pts, int N, int64_t Pw,
                                  int shared_cloud, const float *grad_screen /* (P,3) */,
-                                 const uint8_t *valid /* (P,) */, float *grad_world /* (Pw,3) */,
-                                 void *stream);
+                                 const uint8_t *valid /* (P,) */,
+                                 float clip /* > 0: apply the per-point norm clip of dss_clip_grad first */,
+                                 float *grad_world /* (Pw,3) */, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * kNN statistic behind the source-space variance scale h (rasterizer.py:310-326, 366-388):

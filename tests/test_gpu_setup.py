@@ -346,3 +346,19 @@ def test_anisotropic_point_setup_matches_oracle_bits():
                                             vr6=tile(vr6), frame_normals=tile(fn))
     for mine, want in ((out["pts_screen"], ps), (out["ellipse_params"], el), (out["radii"], ra), (out["scaler"], sc)):
         assert np.array_equal(mine.cpu().numpy(), want)
+
+
+def test_project_backward_fused_clip_equals_clip_then_project():
+    pts, nrm, col, M, V, az = _scene()
+    N, Pc = M.shape[0], pts.shape[0]
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    first = torch.arange(N, device=DEV) * Pc
+    num = torch.full((N,), Pc, device=DEV, dtype=torch.int64)
+    g = torch.randn(N * Pc, 3, device=DEV) * 0.1
+    valid = torch.rand(N * Pc, device=DEV) > 0.2
+    fused = ops.project_backward(t(pts), t(M), t(V), first, num, g, valid, True, clip=0.05)
+    g2 = g.clone()
+    ops.clip_grad_(g2, 0.05)
+    assert not torch.equal(g2, g)
+    want = ops.project_backward(t(pts), t(M), t(V), first, num, g2, valid, True)
+    assert torch.equal(fused, want)

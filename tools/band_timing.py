@@ -29,8 +29,7 @@ def step():
     f = fwd(part.rows)
     ops.render_backward(g_band, f["idx"], f["qvalue"], f["wsum"], f["scaler"], f["pts_screen"], f["radii"], vis_all, wl.first,
                         wl.num, bench.RADII_S, -1.0, image_size=S, rows=part.rows, out=(gf, gp))
-    ops.clip_grad_(gp, bench.CLIP)
-    return ops.project_backward(wl.world, wl.M, wl.V, wl.first, wl.num, gp, f["valid"], True)
+    return ops.project_backward(wl.world, wl.M, wl.V, wl.first, wl.num, gp, f["valid"], True, clip=bench.CLIP)
 
 for _ in range(10): step()
 torch.cuda.synchronize(); t = time.perf_counter()
