@@ -662,6 +662,77 @@ __global__ __launch_bounds__(PREP_THREADS) void median_visible_kernel(
     if (tid == 0) rs[n] = key_float(prefix) * radii_s;
 }
 
+// Row band (multi-GPU), after the median: drop the visible points that cannot reach this rank's rows from the
+// segment lists, in place (one workgroup per segment: all entries are read into registers before any is
+// written), and zero their gradient rows (this band's partial sum for them is zero).  Same conservative test
+// as the gather kernel.  Without it every rank walks the whole visible list: 35 us of rejected tasks per step
+// at 8 ranks even for a rank whose band is empty.
+template <int PER>
+__global__ __launch_bounds__(PREP_THREADS) void band_filter_kernel(
+    const float *__restrict__ points, const float *__restrict__ radii, const float *__restrict__ rs,
+    const int64_t *__restrict__ first_idx, const int64_t *__restrict__ num_pts, int N, int S, int row0, int rows,
+    uint32_t *__restrict__ seg_count, int32_t *__restrict__ vis_list, float *__restrict__ grad_pts,
+    float *__restrict__ grad_feat, int C)
+{
+    __shared__ uint32_t s_w[PER * PREP_THREADS / 64];
+    constexpr int SEG_PTS = PER * PREP_THREADS;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const unsigned seg = blockIdx.x;
+    const uint32_t count = seg_count[seg];
+    const float band_lo = -1 + (2 * (S - row0 - rows)) / (float)S;      // lower edge of the lowest pixel row
+    const float band_hi = -1 + (2 * (S - 1 - row0) + 2.0f) / (float)S;  // upper edge of the highest one
+    int32_t id[PER];
+    uint32_t keep = 0;
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const uint32_t e = (uint32_t)tid + (uint32_t)u * PREP_THREADS;
+        id[u] = e < count ? vis_list[(size_t)seg * SEG_PTS + e] : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        if (id[u] >= 0) {
+            const int n = find_cloud(id[u], first_idx, num_pts, N);
+            const float py = points[3 * (size_t)id[u] + 1], ry = radii[2 * (size_t)id[u] + 1];
+            const float reach = fmaxf(n >= 0 ? rs[n] : 0.0f, ry);
+            const bool in_band = n >= 0 && !(py + reach < band_lo || py - reach > band_hi);
+            keep |= (in_band ? 1u : 0u) << u;
+        }
+    }
+    uint32_t rank[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const unsigned long long m = __ballot((keep >> u) & 1u);
+        rank[u] = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        if (lane == 0) s_w[u * (PREP_THREADS / 64) + wid] = (uint32_t)__popcll(m);
+    }
+    __syncthreads();  // every entry of the segment has been read
+    uint32_t tot = 0;
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        uint32_t before = tot;
+#pragma unroll
+        for (int w = 0; w < PREP_THREADS / 64; ++w) {
+            const uint32_t c = s_w[u * (PREP_THREADS / 64) + w];
+            if (w < wid) before += c;
+            tot += c;
+        }
+        rank[u] += before;
+    }
+    if (tid == 0) seg_count[seg] = tot;
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        if (id[u] < 0) continue;
+        if ((keep >> u) & 1u) {
+            vis_list[(size_t)seg * SEG_PTS + rank[u]] = id[u];
+        } else {
+            const size_t i = (size_t)id[u];
+            grad_pts[3 * i] = 0.0f; grad_pts[3 * i + 1] = 0.0f; grad_pts[3 * i + 2] = 0.0f;
+            if (grad_feat)
+                for (int ch = 0; ch < C; ++ch) grad_feat[i * C + ch] = 0.0f;
+        }
+    }
+}
+
 template <int C, bool SEG>
 __global__ __launch_bounds__(256) void render_backward_kernel(
     const float *__restrict__ grad_out, const float *__restrict__ grad_alpha /* dense (N,rows,S) */,
@@ -1110,6 +1181,14 @@ extern "C" int dss_render_backward(const float *grad_out, const int32_t *idx, co
         vis_list = reinterpret_cast<int32_t *>(w + L.vis_list);
         rs = rs_out ? rs_out : reinterpret_cast<float *>(w + L.rs);
         launch_prep(radii, visible, first_idx, num_pts, N, P, radii_s, rs, w, L, grad_pts, grad_feat, C, grad_out, npix, st);
+        if (row1 - row0 < S) {  // row band: keep only the points that can reach it
+            if (L.per == 2)
+                hipLaunchKernelGGL(band_filter_kernel<2>, dim3(L.chunks), dim3(PREP_THREADS), 0, st, points, radii, rs,
+                                   first_idx, num_pts, N, S, row0, row1 - row0, vis_count, vis_list, grad_pts, grad_feat, C);
+            else
+                hipLaunchKernelGGL(band_filter_kernel<4>, dim3(L.chunks), dim3(PREP_THREADS), 0, st, points, radii, rs,
+                                   first_idx, num_pts, N, S, row0, row1 - row0, vis_count, vis_list, grad_pts, grad_feat, C);
+        }
     } else {
         const size_t hist_bytes = (size_t)3 * N * MED_BINS * 4;
         uint32_t *hist = reinterpret_cast<uint32_t *>(w);
