@@ -19,34 +19,69 @@ import torch.distributed as dist
 
 
 class RowPartition:
-    """Band of image rows owned by ``rank``.  Bands are equal (``S`` rounded up to a multiple of
-    ``world_size``; the last band may be shorter) so that one fixed-size all-gather reassembles them."""
+    """Band of image rows owned by ``rank``.  By default the bands are equal (``S`` rounded up to a multiple of
+    ``world_size``; the last band may be shorter) so that one fixed-size all-gather reassembles them.  With
+    ``bounds`` (``world_size + 1`` non-decreasing row indices from 0 to S, see ``balanced_bounds``) the bands
+    follow the load instead; ``band`` is then the largest band (the padded exchange size)."""
 
-    def __init__(self, image_size: int, world_size: int = 1, rank: int = 0):
+    def __init__(self, image_size: int, world_size: int = 1, rank: int = 0, bounds=None):
         if not (0 <= rank < world_size):
             raise ValueError("rank %d outside world of %d" % (rank, world_size))
         self.S, self.world_size, self.rank = int(image_size), int(world_size), int(rank)
-        self.band = -(-self.S // self.world_size)  # ceil
-        self.row0 = min(self.rank * self.band, self.S)
-        self.row1 = min(self.row0 + self.band, self.S)
+        if bounds is None:
+            self.band = -(-self.S // self.world_size)  # ceil
+            self._bounds = [min(r * self.band, self.S) for r in range(self.world_size + 1)]
+            self.uniform = True
+        else:
+            b = [int(x) for x in bounds]
+            if len(b) != self.world_size + 1 or b[0] != 0 or b[-1] != self.S or any(b[i] > b[i + 1] for i in range(len(b) - 1)):
+                raise ValueError("bounds must be %d non-decreasing row indices from 0 to %d, got %r" % (self.world_size + 1, self.S, b))
+            self._bounds = b
+            self.band = max(max(b[i + 1] - b[i] for i in range(self.world_size)), 1)
+            self.uniform = False
+        self.row0, self.row1 = self._bounds[self.rank], self._bounds[self.rank + 1]
 
     @property
     def rows(self) -> Tuple[int, int]:
         return self.row0, self.row1
 
     def bounds(self, rank: int) -> Tuple[int, int]:
-        r0 = min(rank * self.band, self.S)
-        return r0, min(r0 + self.band, self.S)
+        return self._bounds[rank], self._bounds[rank + 1]
 
     def slice(self, full: torch.Tensor) -> torch.Tensor:
         """Own band of a full-image tensor (N, S, ...)."""
         return full[:, self.row0:self.row1]
 
 
+def balanced_bounds(row_weight, world_size: int, align: int = 8, min_rows: int = 8):
+    """Band boundaries with (about) equal total ``row_weight`` per rank, multiples of ``align`` rows, every band at
+    least ``min_rows`` high.  ``row_weight`` (S,) is any per-row load estimate that is identical on every rank
+    (e.g. occupied pixels per row of a first render): equal ROW counts leave the middle ranks of a centred
+    object with twice the work of the outer ones."""
+    w = torch.as_tensor(row_weight, dtype=torch.float64).flatten().cpu()
+    S, G = int(w.numel()), int(world_size)
+    if G * min_rows > S:
+        raise ValueError("cannot give %d ranks %d rows each out of %d" % (G, min_rows, S))
+    cum = torch.cumsum(w + 1e-9, 0)
+    total = float(cum[-1])
+    bounds = [0]
+    for g in range(1, G):
+        target = total * g / G
+        r = int(torch.searchsorted(cum, torch.tensor(target, dtype=torch.float64)).item()) + 1
+        r = int(round(r / align)) * align
+        r = max(r, bounds[-1] + min_rows)             # this band is at least min_rows high ...
+        r = min(r, S - (G - g) * min_rows)            # ... and so can every later one be
+        bounds.append(r)
+    bounds.append(S)
+    return bounds
+
+
 def gather_rows(band: torch.Tensor, part: RowPartition, group=None) -> torch.Tensor:
     """All-gather row bands ``(N, rows, S, ch)`` into the full image ``(N, S, S, ch)`` on every rank."""
     if part.world_size == 1:
         return band
+    if not part.uniform:
+        raise ValueError("gather_rows needs equal bands; use OverlappedExchange for load-balanced bounds")
     n, rows = band.shape[0], band.shape[1]
     if rows < part.band:  # short (or empty) last band: pad to the common size
         pad = band.new_zeros((n, part.band - rows) + tuple(band.shape[2:]))
@@ -149,6 +184,15 @@ class OverlappedExchange:
         self.visible = torch.zeros(num_points, dtype=torch.uint8, device=device)
         self.recv_vis = torch.empty((G, num_points), dtype=torch.uint8, device=device)
         self._work = None
+        # load-balanced (unequal) bands travel padded to the largest one; the rows are put in place by ONE gather
+        # kernel on a side stream as soon as the collective completes, i.e. still during the backward
+        self.full_img = self.row_index = self._side = None
+        if not part.uniform:
+            idx = [g * band + j for g in range(G) for j in range(part.bounds(g)[1] - part.bounds(g)[0])]
+            self.row_index = torch.tensor(idx, dtype=torch.int64, device=device)
+            self.full_img = torch.empty((S, n_images, S, channels), dtype=torch.float32, device=device)
+            if torch.device(device).type == "cuda":
+                self._side = torch.cuda.Stream(device=device)
 
     @staticmethod
     def _all_gather(out2d: torch.Tensor, send: torch.Tensor, group, async_op: bool):
@@ -160,14 +204,27 @@ class OverlappedExchange:
         """Issue both exchanges; returns the union of the visibility flags, uint8 (P,)."""
         G = self.part.world_size
         self._work = self._all_gather(self.recv_img.view(G, -1), self.send_img.view(-1), self.image_group, True)
+        if self.row_index is not None and self._side is not None:
+            self._side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._side):
+                self._work.wait()
+                torch.index_select(self.recv_img, 0, self.row_index, out=self.full_img)
         self._all_gather(self.recv_vis, self.visible, self.group, False)
         return self.recv_vis.max(dim=0).values
 
     def finish(self) -> torch.Tensor:
-        """Wait for the image bands; returns the full render (N, S, S, ch) (strided view of the receive buffer)."""
+        """Wait for the image bands; returns the full render (N, S, S, ch) (strided view, no copy for equal bands)."""
         if self._work is not None:
-            self._work.wait()
+            if self.row_index is None:
+                self._work.wait()
+            elif self._side is not None:
+                torch.cuda.current_stream().wait_stream(self._side)
+            else:  # CPU (tests)
+                self._work.wait()
+                torch.index_select(self.recv_img, 0, self.row_index, out=self.full_img)
             self._work = None
+        if self.row_index is not None:
+            return self.full_img.permute(1, 0, 2, 3)
         return self.recv_img[:self.part.S].permute(1, 0, 2, 3)
 
 

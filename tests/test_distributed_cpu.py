@@ -67,6 +67,18 @@ def _worker(rank, world, port, S, tmp):
             assert torch.equal(vis4, vis)
             img4 = ox.finish()
             assert img4.shape == full.shape and torch.equal(img4, torch.from_numpy(full) * (rep + 1))
+        # load-balanced (unequal) bands: padded exchange, rows put in place by one gather
+        from dss_amd.distributed import balanced_bounds
+        wrow = torch.from_numpy(occ.sum(axis=(0, 2)))
+        bnd = balanced_bounds(wrow, world, align=8, min_rows=8)
+        assert bnd[0] == 0 and bnd[-1] == S and all(b % 8 == 0 for b in bnd[:-1])
+        pb = RowPartition(S, world, rank, bounds=bnd)
+        b0, b1 = pb.rows
+        oxb = OverlappedExchange(pb, 2, full.shape[-1], P, "cpu")
+        oxb.image.copy_(torch.from_numpy(full[:, b0:b1].copy()))
+        oxb.visible.copy_(vis_band)
+        oxb.start()
+        assert torch.equal(oxb.finish(), torch.from_numpy(full))
         rs = oracle.backward_radius(sc["radii"], vis.numpy(), sc["first_idx"], sc["num_pts"], 3.0)
         gocc = g_full[..., 3].numpy()
         masked = np.zeros_like(gocc)
