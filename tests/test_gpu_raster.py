@@ -367,23 +367,28 @@ def test_render_backward_search_radius_sweep(radii_s):
     assert _rel_l2(g.cpu().numpy(), o_g) <= 1e-4 and _rel_l2(gf.cpu().numpy(), o_gf) <= 1e-4
 
 
-def test_render_backward_row_bands_sum_to_full():
+@pytest.mark.parametrize("S,bounds", [(96, (0, 40, 96)), (96, (0, 8, 16, 24, 32, 40, 48, 56, 64, 72, 80, 88, 96)),
+                                      (50, (0, 5, 38, 50)), (128, (0, 127, 128))])
+def test_render_backward_row_bands_sum_to_full(S, bounds):
     """Multi-GPU contract of the fused backward: band partial sums (global visibility, no clip) add up to
-    the full-image result."""
-    sc = scenes.random_splats(3000, 96, 2, seed=31)
+    the full-image result -- equal and odd bands, image sizes that are not powers of two or multiples of the
+    tile, a one-row band; the band filter drops the points that cannot reach a band."""
+    sc = scenes.random_splats(3000, S, 2, seed=31)
     d = _dev(sc)
-    idx, zbuf, qv, occ, vis = _fwd(d, 96, 5, 0.3, return_visible=True)
+    idx, zbuf, qv, occ, vis = _fwd(d, S, 5, 0.3, return_visible=True)
     scaler = torch.from_numpy(sc["scaler"]).to(DEV)
     img, wsum = ops.blend_forward(idx, qv, occ, scaler, torch.from_numpy(sc["colors"]).to(DEV), return_wsum=True)
     go = torch.randn_like(img)
     gf, g = ops.render_backward(go, idx, qv, wsum, scaler, d["points"], d["radii"], vis, d["first"], d["num"], 4.0, -1.0)
-    parts = []
-    for a, b in ((0, 40), (40, 96)):
-        parts.append(ops.render_backward(go[:, a:b].contiguous(), idx[:, a:b].contiguous(), qv[:, a:b].contiguous(),
-                                         wsum[:, a:b].contiguous(), scaler, d["points"], d["radii"], vis, d["first"],
-                                         d["num"], 4.0, -1.0, image_size=96, rows=(a, b)))
-    assert _rel_l2((parts[0][1] + parts[1][1]).cpu().numpy(), g.cpu().numpy()) <= 1e-5
-    assert _rel_l2((parts[0][0] + parts[1][0]).cpu().numpy(), gf.cpu().numpy()) <= 1e-5
+    sum_g, sum_gf = torch.zeros_like(g), torch.zeros_like(gf)
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        pf, pg = ops.render_backward(go[:, a:b].contiguous(), idx[:, a:b].contiguous(), qv[:, a:b].contiguous(),
+                                     wsum[:, a:b].contiguous(), scaler, d["points"], d["radii"], vis, d["first"],
+                                     d["num"], 4.0, -1.0, image_size=S, rows=(a, b))
+        sum_g += pg
+        sum_gf += pf
+    assert _rel_l2(sum_g.cpu().numpy(), g.cpu().numpy()) <= 1e-5
+    assert _rel_l2(sum_gf.cpu().numpy(), gf.cpu().numpy()) <= 1e-5
 
 
 @pytest.mark.parametrize("sizes,frac,dist", [
