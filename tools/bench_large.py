@@ -42,4 +42,11 @@ rec = {"config": which, "points_per_cloud": P, "cameras": N, "image_size": S, "m
        "Msplats_per_s": round(wl.P / ms / 1e3, 2), "fine_kernel_ms": round(fine_mean, 4),
        "fine_algorithmic_bytes": alg, "fine_GBps": round(alg / fine_mean / 1e6, 1),
        "fine_frac_of_8TBps": round(alg / fine_mean / 1e6 / 8000, 4), "occupancy_mean": round(float(img[..., 3].mean()), 4), "h": h}
+try:
+    _f = bench.ops.render_forward(wl.world, wl.normals, wl.h, wl.M, wl.V, wl.znear, wl.zfar, wl.first, wl.num, wl.colors, S, K,
+                                 bench.CUTOFF, bench.THR, bench.SIGMA, False, True)
+    rec["visible_points"] = int(_f["visible"].sum())
+    rec["median_radius_px"] = round(float(_f["radii"][_f["visible"]].median()) * S / 2, 2)
+except Exception:
+    pass
 print(json.dumps(rec))
