@@ -100,10 +100,28 @@ __device__ __forceinline__ float wave_sum(float v)
     return (a + b) + (c + d);
 }
 
+// Order-preserving float <-> int map (atomicMin/Max on floats of either sign).
+__device__ __forceinline__ int f2ord(float f)
+{
+    const int i = __float_as_int(f);
+    return i >= 0 ? i : i ^ 0x7fffffff;
+}
+__device__ __forceinline__ float ord2f(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff); }
+
+__device__ __forceinline__ float eps_denom_py(float d)  // DSS/utils/mathHelper.py:10-14
+{
+    const float s = (float)((d > 0) - (d < 0)) + (d == 0.0f ? 1.0f : 0.0f);
+    return s * fmaxf(fabsf(d), 1e-17f);
+}
+
 static inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 int check_launch(const char *what);
+
+// knn.hip: bbox (N,6) ordered ints = min xyz, max xyz of every cloud (NaN coordinates skipped)
+int launch_cloud_bbox(const float *points, const int64_t *first_idx, const int64_t *num_pts, int N, int64_t P, int *bbox,
+                      hipStream_t st);
 
 }  // namespace dss

@@ -11,24 +11,18 @@
 //
 //   knn_bbox      per-cloud bounding box (ordered-int atomics)
 //   knn_count     cell of every point, per-cell counts
-//   knn_scan      exclusive scan of the cell counts (one workgroup per cloud)
+//   knn_scan      exclusive scan of the cell counts: 1024-cell blocks scanned locally, then offset by the block prefix
 //   knn_fill      counting sort: points grouped by cell
-//   knn_query     ring search, K smallest squared distances in registers
+//   knn_query     ring search, K smallest squared distances in registers; one thread per point IN CELL ORDER, so the
+//                 lanes of a wavefront walk the same few cells (same trip counts, broadcast loads)
 //   cloud_mean    deterministic per-cloud mean * scale, clamped (the global-h statistic)
 #include "common.h"
 
 namespace dss {
 
 #define KNN_MAX_K 16
-#define KNN_MAX_RES 64
-#define KNN_STRIDE ((size_t)KNN_MAX_RES * KNN_MAX_RES * KNN_MAX_RES + 1)  // cells per cloud + end sentinel
-
-__device__ __forceinline__ int f2ord(float f)
-{
-    const int i = __float_as_int(f);
-    return i >= 0 ? i : i ^ 0x7fffffff;
-}
-__device__ __forceinline__ float ord2f(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff); }
+#define KNN_MAX_RES 128
+#define KNN_SCAN_BLOCK 1024  // cells per workgroup of the two-level scan
 
 struct KnnGrid {  // per cloud, device resident (8 floats)
     float minx, miny, minz, inv_cell, cell;
@@ -37,8 +31,8 @@ struct KnnGrid {  // per cloud, device resident (8 floats)
 };
 
 // Bounding box per cloud.  Grid (G, N): workgroups of cloud n stride over its points, reduce min/max in
-// registers -> wave (shuffles) -> one atomic set per WAVE.  (One atomic set per POINT, the first version,
-// serialised P same-address atomics: 2.2 ms at 80k points.)
+// registers -> wave (shuffles) -> workgroup (LDS) -> one atomic per bound and WORKGROUP.  (One atomic set per POINT,
+// the first version, serialised P same-address atomics: 2.2 ms at 80k points.)
 __global__ __launch_bounds__(256) void knn_bbox_kernel(const float *__restrict__ pts, const int64_t *__restrict__ first_idx,
                                                        const int64_t *__restrict__ num_pts, int N, int64_t P,
                                                        int *__restrict__ bbox /* (N,6) ordered ints */)
@@ -63,12 +57,20 @@ __global__ __launch_bounds__(256) void knn_bbox_kernel(const float *__restrict__
             lo[d] = min(lo[d], __shfl_xor(lo[d], o));
             hi[d] = max(hi[d], __shfl_xor(hi[d], o));
         }
+    __shared__ int part[4][6];
+    const int wid = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            if (lo[d] != 0x7fffffff) atomicMin(&bbox[6 * n + d], lo[d]);
-            if (hi[d] != (int)0x80000000) atomicMax(&bbox[6 * n + 3 + d], hi[d]);
-        }
+        for (int d = 0; d < 3; ++d) { part[wid][d] = lo[d]; part[wid][3 + d] = hi[d]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {  // one atomic per workgroup and bound
+        const int d = threadIdx.x;
+        int v = part[0][d];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) v = d < 3 ? min(v, part[w][d]) : max(v, part[w][d]);
+        if (d < 3 && v != 0x7fffffff) atomicMin(&bbox[6 * n + d], v);
+        if (d >= 3 && v != (int)0x80000000) atomicMax(&bbox[6 * n + d], v);
     }
 }
 
@@ -78,7 +80,7 @@ __global__ void knn_init_kernel(int N, int *__restrict__ bbox)
     if (i < 6 * N) bbox[i] = (i % 6 < 3) ? 0x7fffffff : (int)0x80000000;  // +inf / -inf in ordered-int space
 }
 
-__global__ void knn_grid_kernel(const int *__restrict__ bbox, const int64_t *__restrict__ num_pts, int N,
+__global__ void knn_grid_kernel(const int *__restrict__ bbox, const int64_t *__restrict__ num_pts, int N, int res_cap,
                                 KnnGrid *__restrict__ grids)
 {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
@@ -89,7 +91,7 @@ __global__ void knn_grid_kernel(const int *__restrict__ bbox, const int64_t *__r
     const float ext = fmaxf(fmaxf(x1 - x0, y1 - y0), fmaxf(z1 - z0, 1e-12f));
     // surface-like clouds occupy ~3 res^2 cells: aim at ~8 points per occupied cell
     int res = (int)ceilf(sqrtf((float)num_pts[n] / 24.0f));
-    res = max(1, min(KNN_MAX_RES, res));
+    res = max(1, min(res_cap, res));  // res_cap: the resolution the workspace was sized for (knn_res_cap)
     g.minx = x0; g.miny = y0; g.minz = z0;
     g.cell = ext / (float)res * 1.0001f;
     g.inv_cell = 1.0f / g.cell;
@@ -106,8 +108,8 @@ __device__ __forceinline__ int cell_coord(float v, float mn, float inv_cell, int
 
 __global__ __launch_bounds__(256) void knn_count_kernel(const float *__restrict__ pts, const int64_t *__restrict__ first_idx,
                                                         const int64_t *__restrict__ num_pts, int N, int64_t P,
-                                                        const KnnGrid *__restrict__ grids, uint32_t *__restrict__ counts,
-                                                        int32_t *__restrict__ cell_of)
+                                                        const KnnGrid *__restrict__ grids, size_t stride,
+                                                        uint32_t *__restrict__ counts, int32_t *__restrict__ cell_of)
 {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= P) return;
@@ -119,50 +121,88 @@ __global__ __launch_bounds__(256) void knn_count_kernel(const float *__restrict_
     const int cz = cell_coord(pts[3 * p + 2], g.minz, g.inv_cell, g.res);
     const int c = (cz * g.res + cy) * g.res + cx;
     cell_of[p] = c;
-    atomicAdd(&counts[(size_t)n * KNN_STRIDE + c], 1u);
+    atomicAdd(&counts[(size_t)n * stride + c], 1u);
 }
 
-// one workgroup per cloud; scans res^3 cells
-__global__ __launch_bounds__(1024) void knn_scan_kernel(const uint32_t *__restrict__ counts,
-                                                        const KnnGrid *__restrict__ grids,
-                                                        uint32_t *__restrict__ offsets, uint32_t *__restrict__ cursor)
+// Two-level exclusive scan of the cell counts.  Grid (blocks, N); block b of cloud n owns cells [1024 b, 1024 b + 1024).
+// Pass 1: local exclusive scan -> offsets, block total -> blk_tot.  Pass 2: every block sums the totals of the blocks
+// before it (at most 2048 values) and adds that prefix; the block holding the last cell also writes the end sentinel.
+// (The first version scanned all res^3 cells with ONE workgroup per cloud: 288 us at res = 64.)
+__device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t *wave_tot /* LDS [4] */, uint32_t &total)
 {
-    __shared__ uint32_t wave_tot[16];
-    __shared__ uint32_t carry_s;
-    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const size_t base_n = (size_t)n * KNN_STRIDE;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    uint32_t incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) wave_tot[wid] = incl;
+    __syncthreads();
+    uint32_t before = 0;
+    total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const uint32_t t = wave_tot[w];
+        before += (w < wid) ? t : 0u;
+        total += t;
+    }
+    return before + incl - v;
+}
+
+__global__ __launch_bounds__(256) void knn_scan_local_kernel(const uint32_t *__restrict__ counts,
+                                                             const KnnGrid *__restrict__ grids, size_t stride, int nblk_max,
+                                                             uint32_t *__restrict__ offsets, uint32_t *__restrict__ blk_tot)
+{
+    __shared__ uint32_t wave_tot[4];
+    const int n = blockIdx.y, b = blockIdx.x, tid = threadIdx.x;
     const int res = grids[n].res;
     const int cells = res * res * res;
-    if (tid == 0) carry_s = 0;
-    __syncthreads();
-    for (int base = 0; base < cells; base += 1024) {
-        const int i = base + tid;
-        const uint32_t v = (i < cells) ? counts[base_n + i] : 0u;
-        uint32_t x = v;
+    if (b * KNN_SCAN_BLOCK >= cells) return;
+    const size_t base = (size_t)n * stride;
+    const int c0 = b * KNN_SCAN_BLOCK + 4 * tid;
+    uint32_t v[4];
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t y = __shfl_up(x, o, 64);
-            if (lane >= o) x += y;
-        }
-        if (lane == 63) wave_tot[wid] = x;
-        __syncthreads();
-        uint32_t woff = 0;
-        for (int w = 0; w < wid; ++w) woff += wave_tot[w];
-        const uint32_t excl = carry_s + woff + x - v;
-        if (i < cells) {
-            offsets[base_n + i] = excl;
-            cursor[base_n + i] = excl;
-        }
-        __syncthreads();
-        if (tid == 1023) carry_s = excl + v;
-        __syncthreads();
+    for (int i = 0; i < 4; ++i) v[i] = (c0 + i < cells) ? counts[base + c0 + i] : 0u;
+    uint32_t total;
+    uint32_t run = block_excl_scan_256(v[0] + v[1] + v[2] + v[3], wave_tot, total);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (c0 + i < cells) offsets[base + c0 + i] = run;
+        run += v[i];
     }
-    if (tid == 0) offsets[base_n + cells] = carry_s;
+    if (tid == 0) blk_tot[(size_t)n * nblk_max + b] = total;
+}
+
+__global__ __launch_bounds__(256) void knn_scan_add_kernel(const KnnGrid *__restrict__ grids, size_t stride, int nblk_max,
+                                                           const uint32_t *__restrict__ blk_tot, uint32_t *__restrict__ offsets,
+                                                           uint32_t *__restrict__ cursor)
+{
+    __shared__ uint32_t wave_tot[4];
+    const int n = blockIdx.y, b = blockIdx.x, tid = threadIdx.x;
+    const int res = grids[n].res;
+    const int cells = res * res * res;
+    if (b * KNN_SCAN_BLOCK >= cells) return;
+    const size_t base = (size_t)n * stride;
+    uint32_t part = 0;
+    for (int i = tid; i < b; i += 256) part += blk_tot[(size_t)n * nblk_max + i];
+    uint32_t prefix;
+    block_excl_scan_256(part, wave_tot, prefix);  // only the total is needed: blocks before b
+    const int c0 = b * KNN_SCAN_BLOCK + 4 * tid;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (c0 + i < cells) {
+            const uint32_t o = offsets[base + c0 + i] + prefix;
+            offsets[base + c0 + i] = o;
+            cursor[base + c0 + i] = o;
+        }
+    if (tid == 0 && (b + 1) * KNN_SCAN_BLOCK >= cells) offsets[base + cells] = prefix + blk_tot[(size_t)n * nblk_max + b];
 }
 
 __global__ __launch_bounds__(256) void knn_fill_kernel(const float *__restrict__ pts, const int64_t *__restrict__ first_idx,
                                                        const int64_t *__restrict__ num_pts, int N, int64_t P,
-                                                       const int32_t *__restrict__ cell_of, uint32_t *__restrict__ cursor,
+                                                       const int32_t *__restrict__ cell_of, size_t stride,
+                                                       uint32_t *__restrict__ cursor,
                                                        float4 *__restrict__ sorted /* (P) xyz + id, grouped by cell */)
 {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -170,7 +210,7 @@ __global__ __launch_bounds__(256) void knn_fill_kernel(const float *__restrict__
     const int c = cell_of[p];
     if (c < 0) return;
     const int n = find_cloud(p, first_idx, num_pts, N);
-    const uint32_t pos = atomicAdd(&cursor[(size_t)n * KNN_STRIDE + c], 1u);
+    const uint32_t pos = atomicAdd(&cursor[(size_t)n * stride + c], 1u);
     sorted[first_idx[n] + pos] = make_float4(pts[3 * p], pts[3 * p + 1], pts[3 * p + 2], __int_as_float((int)p));
 }
 
@@ -180,27 +220,32 @@ __global__ __launch_bounds__(256) void knn_fill_kernel(const float *__restrict__
 template <int K, bool FULL>
 __global__ __launch_bounds__(256) void knn_query_kernel(const float *__restrict__ pts, const int64_t *__restrict__ first_idx,
                                                         const int64_t *__restrict__ num_pts, int N, int64_t P,
-                                                        const KnnGrid *__restrict__ grids, const uint32_t *__restrict__ offsets,
+                                                        const KnnGrid *__restrict__ grids, size_t stride,
+                                                        const uint32_t *__restrict__ offsets,
                                                         const float4 *__restrict__ sorted, int Krt,
                                                         float *__restrict__ kth_sqdist, float *__restrict__ dists,
                                                         int64_t *__restrict__ idx)
 {
-    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= P) return;
-    const int n = find_cloud(p, first_idx, num_pts, N);
-    if (n < 0) {
+    const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= P) return;
+    const int n = find_cloud(slot, first_idx, num_pts, N);
+    if (n < 0) {  // packed slot outside every cloud
         if (FULL) {
-            for (int k = 0; k < Krt; ++k) { dists[p * Krt + k] = 0.0f; idx[p * Krt + k] = 0; }
+            for (int k = 0; k < Krt; ++k) { dists[slot * Krt + k] = 0.0f; idx[slot * Krt + k] = 0; }
         } else {
-            kth_sqdist[p] = 0.0f;
+            kth_sqdist[slot] = 0.0f;
         }
         return;
     }
     const KnnGrid g = grids[n];
     const int64_t f0 = first_idx[n];
     const int64_t cnt_n = num_pts[n];
-    const uint32_t *off = offsets + (size_t)n * KNN_STRIDE;
-    const float qx = pts[3 * p], qy = pts[3 * p + 1], qz = pts[3 * p + 2];
+    const uint32_t *off = offsets + (size_t)n * stride;
+    // the query of this thread is the slot-th point of the cell-sorted order (every slot of a cloud's range holds
+    // exactly one of its points): neighbouring lanes query neighbouring points
+    const float4 self = sorted[slot];
+    const int64_t p = (int64_t)__float_as_int(self.w);
+    const float qx = self.x, qy = self.y, qz = self.z;
     const int cx = cell_coord(qx, g.minx, g.inv_cell, g.res);
     const int cy = cell_coord(qy, g.miny, g.inv_cell, g.res);
     const int cz = cell_coord(qz, g.minz, g.inv_cell, g.res);
@@ -215,48 +260,94 @@ __global__ __launch_bounds__(256) void knn_query_kernel(const float *__restrict_
         if (!FULL) kth_sqdist[p] = 0.0f;
         return;
     }
-    for (int ring = 0; ring < g.res; ++ring) {
+    // One candidate: keep the K best in (distance, id) order (FULL) or by distance (kth only).
+    auto consider = [&](const float4 q) {
+        const float dx = q.x - qx, dy = q.y - qy, dz = q.z - qz;
+        const float d2 = dx * dx + dy * dy + dz * dz;
+        if (FULL) {
+            // total order (distance, id): deterministic lists whatever the cell order
+            const int id = __float_as_int(q.w);
+            if (d2 < best[K - 1] || (d2 == best[K - 1] && id < bid[K - 1])) {
+                bool lt[K];
+#pragma unroll
+                for (int k = 0; k < K; ++k) lt[k] = d2 < best[k] || (d2 == best[k] && id < bid[k]);
+#pragma unroll
+                for (int k = K - 1; k >= 1; --k) {
+                    // the empty asm keeps the operands values: left alone, the compiler rewrites select(c, bid[k-1],
+                    // bid[k]) as a LOAD from select(c, &bid[k-1], &bid[k]), which pins bid[] in scratch memory and
+                    // puts scratch loads/stores into this loop
+                    float pb = best[k - 1];
+                    int pi = bid[k - 1];
+                    asm volatile("" : "+v"(pb), "+v"(pi));
+                    best[k] = lt[k - 1] ? pb : (lt[k] ? d2 : best[k]);
+                    bid[k] = lt[k - 1] ? pi : (lt[k] ? id : bid[k]);
+                }
+                best[0] = lt[0] ? d2 : best[0];
+                bid[0] = lt[0] ? id : bid[0];
+            }
+        } else if (d2 < best[K - 1]) {
+#pragma unroll
+            for (int k = K - 1; k >= 1; --k) {
+                const bool sh = d2 < best[k - 1];
+                best[k] = sh ? best[k - 1] : (d2 < best[k] ? d2 : best[k]);
+            }
+            best[0] = d2 < best[0] ? d2 : best[0];
+        }
+    };
+    // Candidates [s, e) of the cell-sorted array: cells that are consecutive along x are consecutive in memory, so a
+    // whole (z, y) row of the search block is ONE contiguous range.  Four candidates are requested per memory round
+    // trip (clamped, unconditional loads): the walk is latency-bound -- ~100 dependent 16-byte loads per query at
+    // 2 wavefronts per CU took 210 us for 32k points when issued one at a time.
+    auto visit = [&](uint32_t s, uint32_t e) {
+        for (uint32_t j = s; j < e; j += 4) {
+            const float4 q0 = sorted[f0 + j], q1 = sorted[f0 + min(j + 1, e - 1)], q2 = sorted[f0 + min(j + 2, e - 1)],
+                         q3 = sorted[f0 + min(j + 3, e - 1)];
+            const int cnt = (int)min(e - j, 4u);
+#pragma nounroll
+            for (int i = 0; i < cnt; ++i) consider(i == 0 ? q0 : (i == 1 ? q1 : (i == 2 ? q2 : q3)));  // ONE copy of the insert
+        }
+    };
+    // The search starts with the 3x3x3 block (the own cell alone almost never proves K >= 7 neighbours final): the
+    // offsets of its nine rows are requested together and parked in LDS (a register array indexed by a rolled loop
+    // would go to scratch, nine unrolled copies of the walk cost 246 VGPRs).  Further rings, rarely needed, add their
+    // shell: full rows on the y/z faces, the two end cells of the other rows.
+    __shared__ uint32_t row_lo[9][256], row_hi[9][256];
+    {
+        const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.res - 1);
+#pragma unroll
+        for (int r = 0; r < 9; ++r) {
+            const int z = cz + r / 3 - 1, y = cy + r % 3 - 1;
+            const bool in = z >= 0 && z < g.res && y >= 0 && y < g.res;
+            const int c = in ? (z * g.res + y) * g.res : 0;
+            const uint32_t s = off[c + x0], e = off[c + x1 + 1];
+            row_lo[r][threadIdx.x] = in ? s : 0u;
+            row_hi[r][threadIdx.x] = in ? e : 0u;
+        }
+    }
+    for (int ring = 1; ring <= g.res; ++ring) {
         const int x0 = max(cx - ring, 0), x1 = min(cx + ring, g.res - 1);
         const int y0 = max(cy - ring, 0), y1 = min(cy + ring, g.res - 1);
         const int z0 = max(cz - ring, 0), z1 = min(cz + ring, g.res - 1);
-        for (int z = z0; z <= z1; ++z)
-            for (int y = y0; y <= y1; ++y) {
-                const bool shell_zy = (z == cz - ring) || (z == cz + ring) || (y == cy - ring) || (y == cy + ring);
-                for (int x = x0; x <= x1; ++x) {
-                    // only the new shell of this ring
-                    if (!shell_zy && x != cx - ring && x != cx + ring) continue;
-                    const int c = (z * g.res + y) * g.res + x;
-                    const uint32_t s = off[c], e = off[c + 1];
-                    for (uint32_t j = s; j < e; ++j) {
-                        const float4 q = sorted[f0 + j];
-                        const float dx = q.x - qx, dy = q.y - qy, dz = q.z - qz;
-                        const float d2 = dx * dx + dy * dy + dz * dz;
-                        if (FULL) {
-                            // total order (distance, id): deterministic lists whatever the cell order
-                            const int id = __float_as_int(q.w);
-                            if (d2 < best[K - 1] || (d2 == best[K - 1] && id < bid[K - 1])) {
-                                bool lt[K];
-#pragma unroll
-                                for (int k = 0; k < K; ++k) lt[k] = d2 < best[k] || (d2 == best[k] && id < bid[k]);
-#pragma unroll
-                                for (int k = K - 1; k >= 1; --k) {
-                                    best[k] = lt[k - 1] ? best[k - 1] : (lt[k] ? d2 : best[k]);
-                                    bid[k] = lt[k - 1] ? bid[k - 1] : (lt[k] ? id : bid[k]);
-                                }
-                                best[0] = lt[0] ? d2 : best[0];
-                                bid[0] = lt[0] ? id : bid[0];
-                            }
-                        } else if (d2 < best[K - 1]) {
-#pragma unroll
-                            for (int k = K - 1; k >= 1; --k) {
-                                const bool sh = d2 < best[k - 1];
-                                best[k] = sh ? best[k - 1] : (d2 < best[k] ? d2 : best[k]);
-                            }
-                            best[0] = d2 < best[0] ? d2 : best[0];
-                        }
-                    }
-                }
+        const int ny = y1 - y0 + 1;
+        const int walks = ring == 1 ? 9 : 2 * ny * (z1 - z0 + 1);  // rows of the block, or (row, end) pairs of the shell
+#pragma nounroll
+        for (int t = 0; t < walks; ++t) {
+            uint32_t s, e;
+            if (ring == 1) {
+                s = row_lo[t][threadIdx.x];
+                e = row_hi[t][threadIdx.x];
+            } else {
+                const int row = t >> 1, z = z0 + row / ny, y = y0 + row % ny;
+                const int c = (z * g.res + y) * g.res;
+                const bool full = z == cz - ring || z == cz + ring || y == cy - ring || y == cy + ring;
+                const int xa = full ? x0 : ((t & 1) ? cx + ring : cx - ring);
+                const int xb = full ? x1 : xa;
+                if ((full && (t & 1)) || xa < 0 || xb >= g.res) continue;  // a full row is one walk
+                s = off[c + xa];
+                e = off[c + xb + 1];
             }
+            visit(s, e);
+        }
         // distance from the query to the boundary of the visited block (exact lower bound for unvisited points);
         // faces that coincide with the grid boundary have nothing behind them
         float bound = __builtin_huge_valf();
@@ -315,16 +406,39 @@ __global__ __launch_bounds__(1024) void cloud_mean_kernel(const float *__restric
 
 using namespace dss;
 
-static size_t knn_cells(int N) { return (size_t)(N > 0 ? N : 1) * KNN_STRIDE; }
+// Largest grid resolution a cloud of at most P points can ask for (knn_grid_kernel: ~8 points per occupied cell of a
+// surface-like cloud), and the per-cloud stride of the cell arrays it implies (cells + end sentinel).
+static int knn_res_cap(int64_t P)
+{
+    int res = (int)ceil(sqrt((double)(P > 0 ? P : 1) / 24.0));
+    return res < 1 ? 1 : (res > KNN_MAX_RES ? KNN_MAX_RES : res);
+}
+static size_t knn_stride(int64_t P)
+{
+    const size_t r = (size_t)knn_res_cap(P);
+    return r * r * r + 1;
+}
+static size_t knn_cells(int N, int64_t P) { return (size_t)(N > 0 ? N : 1) * knn_stride(P); }
+static int knn_blocks(int64_t P) { return (int)((knn_stride(P) - 1 + KNN_SCAN_BLOCK - 1) / KNN_SCAN_BLOCK); }
 
 extern "C" size_t dss_knn_workspace(int N, int64_t P)
 {
     const size_t n = N > 0 ? N : 1, p = P > 0 ? P : 1;
-    return align_up(n * 6 * 4, 256) + align_up(n * sizeof(KnnGrid), 256) + align_up((knn_cells(N) + 1) * 4, 256) * 3 +
-           align_up(p * 4, 256) + align_up(p * 16, 256);
+    return align_up(n * 6 * 4, 256) + align_up(n * sizeof(KnnGrid), 256) + align_up((knn_cells(N, P) + 1) * 4, 256) * 3 +
+           align_up(n * (size_t)knn_blocks(P) * 4, 256) + align_up(p * 4, 256) + align_up(p * 16, 256);
 }
 
 #define KNN_FULL_MAX_K 40
+
+// Per-cloud bounding boxes as ordered ints (decode with ord2f), for callers outside this file (regularizers.hip).
+int dss::launch_cloud_bbox(const float *points, const int64_t *first_idx, const int64_t *num_pts, int N, int64_t P,
+                           int *bbox, hipStream_t st)
+{
+    hipLaunchKernelGGL(knn_init_kernel, dim3((6 * N + 63) / 64), dim3(64), 0, st, N, bbox);
+    const unsigned bb = (unsigned)((P / N + 2047) / 2048 > 64 ? 64 : (P / N + 2047) / 2048);
+    hipLaunchKernelGGL(knn_bbox_kernel, dim3(bb ? bb : 1, N), dim3(256), 0, st, points, first_idx, num_pts, N, P, bbox);
+    return check_launch("cloud bbox");
+}
 
 // grid build + query; exactly one of (kth_sqdist) / (dists, idx) is written
 static int knn_run(const char *who, const float *points, const int64_t *first_idx, const int64_t *num_pts, int N, int64_t P,
@@ -350,28 +464,34 @@ static int knn_run(const char *who, const float *points, const int64_t *first_id
     size_t off = 0;
     int *bbox = reinterpret_cast<int *>(w + off);                 off += align_up((size_t)N * 6 * 4, 256);
     KnnGrid *grids = reinterpret_cast<KnnGrid *>(w + off);        off += align_up((size_t)N * sizeof(KnnGrid), 256);
-    const size_t cbytes = align_up((knn_cells(N) + 1) * 4, 256);
+    const size_t cbytes = align_up((knn_cells(N, P) + 1) * 4, 256);
+    const size_t stride = knn_stride(P);
+    const int nblk = knn_blocks(P);
     uint32_t *counts = reinterpret_cast<uint32_t *>(w + off);     off += cbytes;
     uint32_t *offsets = reinterpret_cast<uint32_t *>(w + off);    off += cbytes;
     uint32_t *cursor = reinterpret_cast<uint32_t *>(w + off);     off += cbytes;
+    uint32_t *blk_tot = reinterpret_cast<uint32_t *>(w + off);    off += align_up((size_t)N * nblk * 4, 256);
     int32_t *cell_of = reinterpret_cast<int32_t *>(w + off);      off += align_up((size_t)P * 4, 256);
     float4 *sorted = reinterpret_cast<float4 *>(w + off);
-    hipLaunchKernelGGL(knn_init_kernel, dim3((6 * N + 63) / 64), dim3(64), 0, st, N, bbox);
     if (hipMemsetAsync(counts, 0, cbytes, st) != hipSuccess) return check_launch("knn memset");
     const unsigned pb = (unsigned)((P + 255) / 256);
-    const unsigned bb = (unsigned)((P / N + 2047) / 2048 > 64 ? 64 : (P / N + 2047) / 2048);
-    hipLaunchKernelGGL(knn_bbox_kernel, dim3(bb ? bb : 1, N), dim3(256), 0, st, points, first_idx, num_pts, N, P, bbox);
-    hipLaunchKernelGGL(knn_grid_kernel, dim3((N + 63) / 64), dim3(64), 0, st, bbox, num_pts, N, grids);
-    hipLaunchKernelGGL(knn_count_kernel, dim3(pb), dim3(256), 0, st, points, first_idx, num_pts, N, P, grids, counts,
+    if (int rc = launch_cloud_bbox(points, first_idx, num_pts, N, P, bbox, st)) return rc;
+    hipLaunchKernelGGL(knn_grid_kernel, dim3((N + 63) / 64), dim3(64), 0, st, bbox, num_pts, N, knn_res_cap(P), grids);
+    hipLaunchKernelGGL(knn_count_kernel, dim3(pb), dim3(256), 0, st, points, first_idx, num_pts, N, P, grids, stride, counts,
                        cell_of);
-    hipLaunchKernelGGL(knn_scan_kernel, dim3(N), dim3(1024), 0, st, counts, grids, offsets, cursor);
-    hipLaunchKernelGGL(knn_fill_kernel, dim3(pb), dim3(256), 0, st, points, first_idx, num_pts, N, P, cell_of, cursor,
+    hipLaunchKernelGGL(knn_scan_local_kernel, dim3(nblk, N), dim3(256), 0, st, counts, grids, stride, nblk, offsets, blk_tot);
+    hipLaunchKernelGGL(knn_scan_add_kernel, dim3(nblk, N), dim3(256), 0, st, grids, stride, nblk, blk_tot, offsets, cursor);
+    hipLaunchKernelGGL(knn_fill_kernel, dim3(pb), dim3(256), 0, st, points, first_idx, num_pts, N, P, cell_of, stride, cursor,
                        sorted);
+    // small inputs: one wavefront per workgroup, so that the few hundred wavefronts spread over all 256 CUs
+    const unsigned qt = P <= 131072 ? 64u : 256u;
+    const unsigned qb = (unsigned)((P + qt - 1) / qt);
 #define KNN_LAUNCH(KK, FF)                                                                                          \
-    hipLaunchKernelGGL((knn_query_kernel<KK, FF>), dim3(pb), dim3(256), 0, st, points, first_idx, num_pts, N, P, grids,  \
-                       offsets, sorted, K, kth_sqdist, dists, idx)
+    hipLaunchKernelGGL((knn_query_kernel<KK, FF>), dim3(qb), dim3(qt), 0, st, points, first_idx, num_pts, N, P, grids,  \
+                       stride, offsets, sorted, K, kth_sqdist, dists, idx)
     if (full) {
         if (K <= 8) KNN_LAUNCH(8, true);
+        else if (K <= 12) KNN_LAUNCH(12, true);  // the regularisers' knn_k (trainer.py:134-137)
         else if (K <= 16) KNN_LAUNCH(16, true);
         else KNN_LAUNCH(KNN_FULL_MAX_K, true);
     } else {

@@ -5,11 +5,6 @@
 
 namespace dss {
 
-__device__ __forceinline__ float eps_denom_py(float d)  // DSS/utils/mathHelper.py:10-14
-{
-    const float s = (float)((d > 0) - (d < 0)) + (d == 0.0f ? 1.0f : 0.0f);
-    return s * fmaxf(fabsf(d), 1e-17f);
-}
 __device__ __forceinline__ float eps_sqrt_py(float d) { return fmaxf(fabsf(d), 1e-17f); }  // mathHelper.py:16-21
 
 struct SetupArgs {

@@ -1,0 +1,152 @@
+"""Point-cloud regularisers of the training iteration, mirroring DSS/training/losses.py.
+
+`ProjectionLoss` and `RepulsionLoss` (reference losses.py:281-392, :395-492, both on `SurfaceLoss` :145-278) keep the
+reference's constructor arguments, call signature (``loss(point_clouds, points_filter=..., rebuild_knn=True)``),
+reduction handling (`BaseLoss` :24-62) and results; the Trainer builds them with ``reduction='mean',
+filter_scale=2.0, knn_k=12`` (trainer.py:134-137).  The arithmetic runs in three HIP kernels on the packed neighbour
+lists of `dss_knn_points` (dss_amd/csrc/regularizers.hip) instead of ~40 padded torch tensors; the neighbour search
+itself replaces `pytorch3d.ops.knn_points`.  As in the reference, only the points receive a gradient (every weight is
+computed under no_grad there).
+"""
+from typing import Optional
+
+import torch
+from torch import autograd
+
+from . import ops
+
+
+class _Neighbourhood:
+    """Self-query neighbour lists of a batch of clouds (the reference's `knn_tree`, losses.py:155-179), packed."""
+
+    def __init__(self, point_clouds, K: int):
+        self.first = point_clouds.cloud_to_packed_first_idx()
+        self.num = point_clouds.num_points_per_cloud()
+        self.K = int(K)
+        self.dists, self.idx = ops.knn_points(point_clouds.points_packed().detach(), self.first, self.num, self.K)
+
+    def matches(self, point_clouds) -> bool:
+        num = point_clouds.num_points_per_cloud()
+        return num.shape == self.num.shape and bool(torch.equal(num, self.num))
+
+
+def _packed_mask(mask, point_clouds) -> Optional[torch.Tensor]:
+    """(N, Pmax) padded or (P,) packed bool mask -> packed (P,) bool.  A mask with more rows than clouds (one row per
+    camera of a shared cloud) is OR-ed over the rows like losses.py:203-206."""
+    if mask is None:
+        return None
+    num = point_clouds.num_points_per_cloud()
+    P = int(num.sum())
+    if mask.dim() == 1:
+        if mask.numel() != P:
+            raise ValueError("Incompatible point clouds ({} points) and mask {}".format(P, tuple(mask.shape)))
+        return mask.bool()
+    if mask.shape[0] != len(point_clouds):
+        if len(point_clouds) == 1 and mask.shape[0] > 1:
+            mask = mask.any(dim=0, keepdim=True)
+        else:
+            raise ValueError("Incompatible point clouds {} and mask {}".format(len(point_clouds), tuple(mask.shape)))
+    return torch.cat([mask[b, : int(n)] for b, n in enumerate(num.tolist())]).bool()
+
+
+class _Projection(autograd.Function):
+    @staticmethod
+    def forward(ctx, points, mollified, dists, idx, visible, first, num, sigma):
+        loss, _ = ops.projection_loss(points, mollified, dists, idx, visible, first, num, sigma)
+        ctx.save_for_backward(points, mollified, dists, idx, first, num)
+        ctx.visible, ctx.sigma = visible, sigma
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_loss):
+        points, mollified, dists, idx, first, num = ctx.saved_tensors
+        _, grad = ops.projection_loss(points, mollified, dists, idx, ctx.visible, first, num, ctx.sigma,
+                                      grad_loss=grad_loss.contiguous(), want_loss=False, want_grad=True)
+        return (grad,) + (None,) * 7
+
+
+class _Repulsion(autograd.Function):
+    @staticmethod
+    def forward(ctx, points, mollified, idx, first, num, sigma, filter_scale):
+        loss, _ = ops.repulsion_loss(points, mollified, idx, first, num, sigma, filter_scale)
+        ctx.save_for_backward(points, mollified, idx, first, num)
+        ctx.sigma, ctx.filter_scale = sigma, filter_scale
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_loss):
+        points, mollified, idx, first, num = ctx.saved_tensors
+        _, grad = ops.repulsion_loss(points, mollified, idx, first, num, ctx.sigma, ctx.filter_scale,
+                                     grad_loss=grad_loss.contiguous(), want_loss=False, want_grad=True)
+        return (grad,) + (None,) * 6
+
+
+class SurfaceLoss(torch.nn.Module):
+    """Shared state of the two regularisers (reference `SurfaceLoss` + `BaseLoss`)."""
+
+    def __init__(self, reduction: str = "mean", knn_k: int = 33, filter_scale: float = 1.0, sharpness_sigma: float = 0.75):
+        super().__init__()
+        self.reduction = reduction
+        self.channel_dim = None
+        self.knn_tree = None
+        self.knn_k = knn_k
+        self.filter_scale = filter_scale
+        self.sharpness_sigma = sharpness_sigma
+
+    def _reduce(self, loss, reduction=None):  # losses.py:42-52
+        reduction = reduction or self.reduction
+        if reduction == "none":
+            return loss
+        if reduction == "sum":
+            return torch.sum(loss)
+        if reduction == "mean":
+            return torch.mean(loss)
+        raise ValueError("Invalid reduction method ({})".format(reduction))
+
+    def forward(self, *args, **kwargs):  # losses.py:54-61
+        reduction = kwargs.pop("reduction", self.reduction)
+        self.channel_dim = kwargs.pop("channel_dim", self.channel_dim)
+        loss = self.compute(*args, **kwargs)
+        if self.channel_dim is not None:
+            loss = torch.sum(loss, dim=self.channel_dim)
+        return self._reduce(loss, reduction=reduction)
+
+    def _neighbourhood(self, point_clouds, rebuild_knn, kwargs):
+        self.sharpness_sigma = kwargs.get("sharpness_sigma", self.sharpness_sigma)
+        self.filter_scale = kwargs.get("filter_scale", self.filter_scale)
+        self.knn_tree = kwargs.get("knn_tree", self.knn_tree)
+        if rebuild_knn or self.knn_tree is None or not self.knn_tree.matches(point_clouds):
+            self.knn_tree = _Neighbourhood(point_clouds, self.knn_k)
+        return self.knn_tree
+
+    @staticmethod
+    def _mollified(point_clouds, nb, points_filter):
+        keep = None
+        if points_filter is not None:
+            vis, inm = getattr(points_filter, "visibility", None), getattr(points_filter, "inmask", None)
+            if vis is not None and inm is not None:
+                keep = _packed_mask(vis, point_clouds) & _packed_mask(inm, point_clouds)
+        return ops.mollify_normals(point_clouds.normals_packed().detach(), nb.dists, nb.idx, keep, nb.first, nb.num)
+
+
+class ProjectionLoss(SurfaceLoss):
+    """Weighted squared distance of every point to the planes of its neighbours (reference :281-392), (P,) before the
+    reduction."""
+
+    def compute(self, point_clouds, points_filter=None, rebuild_knn=False, **kwargs):
+        nb = self._neighbourhood(point_clouds, rebuild_knn, kwargs)
+        mollified = self._mollified(point_clouds, nb, points_filter)
+        visible = None if points_filter is None else _packed_mask(points_filter.visibility, point_clouds)
+        return _Projection.apply(point_clouds.points_packed(), mollified, nb.dists, nb.idx, visible, nb.first, nb.num,
+                                 float(self.sharpness_sigma))
+
+
+class RepulsionLoss(SurfaceLoss):
+    """exp(-|tangential offset to the weighted neighbourhood|) per coordinate (reference :395-492), (P,3) before the
+    reduction."""
+
+    def compute(self, point_clouds, points_filter=None, rebuild_knn=True, **kwargs):
+        nb = self._neighbourhood(point_clouds, rebuild_knn, kwargs)
+        mollified = self._mollified(point_clouds, nb, points_filter)
+        return _Repulsion.apply(point_clouds.points_packed(), mollified, nb.idx, nb.first, nb.num,
+                                float(self.sharpness_sigma), float(self.filter_scale))

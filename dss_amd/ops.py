@@ -616,3 +616,96 @@ def phong_backward(grad_out, world, normals, rgb, cloud_to_packed_first_idx, num
                                     _lib.ptr(gn), _lib.ptr(gc), _lib.stream_ptr(dev))
     _lib.check(rc, "dss_phong_backward")
     return gw, gn, gc
+
+
+def _mask_u8(mask, name, P, dev):
+    if mask is None:
+        return None
+    mask = _lib.require_gpu(mask, name)
+    if mask.numel() != P:
+        raise RuntimeError("dss_amd: %s must have one entry per packed point (%d), got %d" % (name, P, mask.numel()))
+    return mask.to(torch.uint8).contiguous()
+
+
+def _knn_lists(knn_dists, knn_idx, P, need_dists=True):
+    knn_idx = _lib.require_gpu(knn_idx, "knn_idx", _i64)
+    if knn_idx.dim() != 2 or knn_idx.shape[0] != P:
+        raise RuntimeError("dss_amd: knn_idx must be (P, K) with P = %d, got %s" % (P, tuple(knn_idx.shape)))
+    if need_dists:
+        knn_dists = _lib.require_gpu(knn_dists, "knn_dists", _f32)
+        if knn_dists.shape != knn_idx.shape:
+            raise RuntimeError("dss_amd: knn_dists %s and knn_idx %s differ" % (tuple(knn_dists.shape), tuple(knn_idx.shape)))
+    return knn_dists, knn_idx, int(knn_idx.shape[1])
+
+
+def mollify_normals(normals, knn_dists, knn_idx, keep, cloud_to_packed_first_idx, num_points_per_cloud):
+    """Robust normal mollification of the regularisers (SurfaceLoss._denoise_normals with get_phi weights,
+    losses.py:181-222, 262-278) on the packed neighbour lists of :func:`knn_points` -> (P,3).  ``keep`` (P,) bool marks
+    the points whose own normal is kept (visibility & inmask); None mollifies every point."""
+    lib = _lib.load()
+    normals = _lib.require_gpu(normals, "normals", _f32)
+    dev, P = normals.device, normals.shape[0]
+    knn_dists, knn_idx, K = _knn_lists(knn_dists, knn_idx, P)
+    first = _lib.require_gpu(cloud_to_packed_first_idx, "cloud_to_packed_first_idx", _i64)
+    num = _lib.require_gpu(num_points_per_cloud, "num_points_per_cloud", _i64)
+    keep = _mask_u8(keep, "keep", P, dev)
+    with torch.cuda.device(dev):
+        out = torch.empty_like(normals)
+        rc = lib.dss_mollify_normals(_lib.ptr(normals), _lib.ptr(knn_dists), _lib.ptr(knn_idx), _lib.ptr(keep),
+                                     _lib.ptr(first), _lib.ptr(num), first.shape[0], P, K, _lib.ptr(out),
+                                     _lib.stream_ptr(dev))
+    _lib.check(rc, "dss_mollify_normals")
+    return out
+
+
+def projection_loss(points, mollified, knn_dists, knn_idx, visible, cloud_to_packed_first_idx, num_points_per_cloud,
+                    sharpness_sigma: float, grad_loss=None, want_loss: bool = True, want_grad: bool = False):
+    """ProjectionLoss.compute (losses.py:296-392) per packed point -> (loss (P,) or None, grad_points (P,3) or None);
+    grad_points = d loss_i / d p_i * grad_loss_i (grad_loss None = ones)."""
+    lib = _lib.load()
+    points = _lib.require_gpu(points, "points", _f32)
+    mollified = _lib.require_gpu(mollified, "mollified", _f32)
+    dev, P = points.device, points.shape[0]
+    knn_dists, knn_idx, K = _knn_lists(knn_dists, knn_idx, P)
+    first = _lib.require_gpu(cloud_to_packed_first_idx, "cloud_to_packed_first_idx", _i64)
+    num = _lib.require_gpu(num_points_per_cloud, "num_points_per_cloud", _i64)
+    visible = _mask_u8(visible, "visible", P, dev)
+    if grad_loss is not None:
+        grad_loss = _lib.require_gpu(grad_loss, "grad_loss", _f32)
+        if grad_loss.numel() != P:
+            raise RuntimeError("dss_amd: grad_loss must be (P,)")
+    with torch.cuda.device(dev):
+        loss = torch.empty((P,), dtype=_f32, device=dev) if want_loss else None
+        grad = torch.empty((P, 3), dtype=_f32, device=dev) if want_grad else None
+        rc = lib.dss_projection_loss(_lib.ptr(points), _lib.ptr(mollified), _lib.ptr(knn_dists), _lib.ptr(knn_idx),
+                                     _lib.ptr(visible), _lib.ptr(first), _lib.ptr(num), first.shape[0], P, K,
+                                     float(sharpness_sigma), _lib.ptr(grad_loss), _lib.ptr(loss), _lib.ptr(grad),
+                                     _lib.stream_ptr(dev))
+    _lib.check(rc, "dss_projection_loss")
+    return loss, grad
+
+
+def repulsion_loss(points, mollified, knn_idx, cloud_to_packed_first_idx, num_points_per_cloud, sharpness_sigma: float,
+                   filter_scale: float, grad_loss=None, want_loss: bool = True, want_grad: bool = False):
+    """RepulsionLoss.compute (losses.py:395-492) per packed point -> (loss (P,3) or None, grad_points (P,3) or None)."""
+    lib = _lib.load()
+    points = _lib.require_gpu(points, "points", _f32)
+    mollified = _lib.require_gpu(mollified, "mollified", _f32)
+    dev, P = points.device, points.shape[0]
+    _, knn_idx, K = _knn_lists(None, knn_idx, P, need_dists=False)
+    first = _lib.require_gpu(cloud_to_packed_first_idx, "cloud_to_packed_first_idx", _i64)
+    num = _lib.require_gpu(num_points_per_cloud, "num_points_per_cloud", _i64)
+    if grad_loss is not None:
+        grad_loss = _lib.require_gpu(grad_loss, "grad_loss", _f32)
+        if grad_loss.numel() != 3 * P:
+            raise RuntimeError("dss_amd: grad_loss must be (P,3)")
+    N = first.shape[0]
+    with torch.cuda.device(dev):
+        loss = torch.empty((P, 3), dtype=_f32, device=dev) if want_loss else None
+        grad = torch.empty((P, 3), dtype=_f32, device=dev) if want_grad else None
+        ws = _lib.workspace(dev, 24 * N)
+        rc = lib.dss_repulsion_loss(_lib.ptr(points), _lib.ptr(mollified), _lib.ptr(knn_idx), _lib.ptr(first), _lib.ptr(num),
+                                    N, P, K, float(sharpness_sigma), float(filter_scale), _lib.ptr(grad_loss), _lib.ptr(loss),
+                                    _lib.ptr(grad), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
+    _lib.check(rc, "dss_repulsion_loss")
+    return loss, grad

@@ -354,6 +354,37 @@ DSS_API int dss_phong_backward(const float *grad_out, const float *world, const 
                                float shininess, float *grad_world, float *grad_normals, float *grad_rgb,
                                void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Point-cloud regularisers of the training iteration (the "both regularisers" of SURVEY 8f rank 2): ProjectionLoss
+ * and RepulsionLoss, DSS/training/losses.py:145-459, built by the Trainer with knn_k = 12 (trainer.py:134-137) and
+ * evaluated right after the render (trainer.py:312-330; configs/dss.yml:30 lambda_dr_proj = 0.01).  Inputs are the
+ * packed self-query neighbour lists of dss_knn_points with K = knn_k: knn_d2 (P,K) squared distances, knn_idx (P,K)
+ * cloud-local ids, entry 0 = the point itself (dropped like losses.py:177-179).  2 <= K <= 40.
+ *   dss_mollify_normals  (_denoise_normals + get_phi, :181-222, :262-278): normals_out (P,3) = phi-weighted mean of
+ *       the neighbours' normals; points with keep[p] != 0 (visibility & inmask of the points filter) keep theirs.
+ *       keep may be NULL.  normals_out must not alias normals.
+ *   dss_projection_loss  (:296-392): loss (P,) per point; visible (P,) uint8 or NULL (= all visible).
+ *   dss_repulsion_loss   (:395-492): loss (P,3) per point; the spatial weight uses num_points / bbox_diag^2 *
+ *       filter_scale per cloud (get_spatial_w :248-260; the reference only broadcasts this for a batch of one
+ *       cloud, here every cloud uses its own box).  workspace: 24 bytes per cloud.
+ * Gradients: every weight is a constant for autograd in the reference, so d loss_i / d p_i is closed form.  With
+ * grad_points != NULL the call writes grad_points (P,3) = (d loss_i / d p_i)^T grad_loss_i, recomputed from the
+ * inputs (nothing is saved between forward and backward); grad_loss (P,) resp. (P,3), NULL = ones.  loss and
+ * grad_points may each be NULL (not both).
+ * ------------------------------------------------------------------------------------------- */
+DSS_API int dss_mollify_normals(const float *normals, const float *knn_d2, const int64_t *knn_idx,
+                                const uint8_t *keep, const int64_t *first_idx, const int64_t *num_pts,
+                                int N, int64_t P, int K, float *normals_out, void *stream);
+DSS_API int dss_projection_loss(const float *points, const float *mollified, const float *knn_d2,
+                                const int64_t *knn_idx, const uint8_t *visible, const int64_t *first_idx,
+                                const int64_t *num_pts, int N, int64_t P, int K, float sharpness_sigma,
+                                const float *grad_loss, float *loss, float *grad_points, void *stream);
+DSS_API int dss_repulsion_loss(const float *points, const float *mollified, const int64_t *knn_idx,
+                               const int64_t *first_idx, const int64_t *num_pts, int N, int64_t P, int K,
+                               float sharpness_sigma, float filter_scale, const float *grad_loss,
+                               float *loss, float *grad_points, void *workspace, size_t workspace_bytes,
+                               void *stream);
+
 #ifdef __cplusplus
 }
 #endif

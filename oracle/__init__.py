@@ -233,3 +233,49 @@ def phong_forward(points, normals, rgb, cloud_of, ambient, diffuse_color, specul
                                 _p(ks), _p(lv), L, int(bool(point_lights)), _p(cam), ctypes.c_float(shininess), _p(out),
                                 _p(dif), _p(spc))
     return out, dif, spc
+
+
+def _u8_or_null(a):
+    """(array kept alive, pointer) of an optional uint8 mask."""
+    if a is None:
+        return None, None
+    x = np.ascontiguousarray(a, np.uint8)
+    return x, _p(x)
+
+
+def mollify_normals(normals, knn_d2, knn_idx, keep, first_of):
+    """SurfaceLoss._denoise_normals with get_phi weights (losses.py:181-222, 262-278), packed -> (P,3)."""
+    normals, knn_d2 = _f32(normals), _f32(knn_d2)
+    knn_idx, first_of = np.ascontiguousarray(knn_idx, np.int64), np.ascontiguousarray(first_of, np.int64)
+    P, K = knn_idx.shape
+    out = np.empty((P, 3), np.float32)
+    kp = _u8_or_null(keep)
+    _lib().oracle_mollify_normals(_p(normals), _p(knn_d2), _p(knn_idx), kp[1], _p(first_of), ctypes.c_int64(P), K, _p(out))
+    return out
+
+
+def projection_loss(points, mollified, knn_d2, knn_idx, visible, first_of, sigma, grad_loss=None):
+    """ProjectionLoss.compute (losses.py:296-392) per point -> (loss (P,), grad_points (P,3))."""
+    points, mollified, knn_d2 = _f32(points), _f32(mollified), _f32(knn_d2)
+    knn_idx, first_of = np.ascontiguousarray(knn_idx, np.int64), np.ascontiguousarray(first_of, np.int64)
+    P, K = knn_idx.shape
+    loss, grad = np.empty((P,), np.float32), np.empty((P, 3), np.float32)
+    vp = _u8_or_null(visible)
+    gl = None if grad_loss is None else _f32(grad_loss)
+    _lib().oracle_projection_loss(_p(points), _p(mollified), _p(knn_d2), _p(knn_idx), vp[1], _p(first_of),
+                                  ctypes.c_int64(P), K, ctypes.c_float(sigma), None if gl is None else _p(gl), _p(loss),
+                                  _p(grad))
+    return loss, grad
+
+
+def repulsion_loss(points, mollified, knn_idx, first_of, inv_sigma_of, sigma, grad_loss=None):
+    """RepulsionLoss.compute (losses.py:395-492) per point -> (loss (P,3), grad_points (P,3))."""
+    points, mollified, inv_sigma_of = _f32(points), _f32(mollified), _f32(inv_sigma_of)
+    knn_idx, first_of = np.ascontiguousarray(knn_idx, np.int64), np.ascontiguousarray(first_of, np.int64)
+    P, K = knn_idx.shape
+    loss, grad = np.empty((P, 3), np.float32), np.empty((P, 3), np.float32)
+    gl = None if grad_loss is None else _f32(grad_loss)
+    _lib().oracle_repulsion_loss(_p(points), _p(mollified), _p(knn_idx), _p(first_of), _p(inv_sigma_of),
+                                 ctypes.c_int64(P), K, ctypes.c_float(sigma), None if gl is None else _p(gl), _p(loss),
+                                 _p(grad))
+    return loss, grad

@@ -716,3 +716,142 @@ DSS_ORACLE_API void oracle_phong_forward(const float *pts, const float *normals,
         }
     }
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * Point-cloud regularisers of the training iteration (DSS/training/losses.py:145-459; trainer.py:134-137 builds
+ * both with knn_k = 12, dss.yml:30 weights the projection term with 0.01).  Restated in double precision on the
+ * PACKED layout; the neighbour lists are the self query knn_points(p, p, K = knn_k) with the point itself as entry
+ * 0, entries 1..K-1 are the neighbourhood (losses.py:177-179 drops column 0).  knn_idx are cloud-local ids.
+ *
+ *   phi_k      = max(0, 1 - d_k / (4 mean_k d_k))^4                                  (get_phi, :262-278)
+ *   mollified  = sum_k phi_k n_j / eps_denom(sum_k phi_k); points with keep[p] (visibility & inmask) keep n_p
+ *                (_denoise_normals, :181-222; normals are NOT re-normalised)
+ *   normal_w_k = exp(-|nm_j/|nm_j| - nm_i/|nm_i||^2 / sigma^2)     F.normalize eps 1e-12 (get_normal_w, :224-246)
+ *   projection (:296-392):  w_k = phi_k normal_w_k (visible[j] ? 1 : 0.1);  sdf_k = (x_j - p_i) . nm_j
+ *                loss_i = sum_k w_k sdf_k^2 / eps_denom(sum_k w_k);   only p_i carries gradient
+ *   repulsion  (:395-492):  s_k = exp(-|x_j - p_i|^2 inv_sigma[n])  (get_spatial_w :248-260; inv_sigma = num_points /
+ *                bbox_diag^2 * filter_scale);  w_k = s_k normal_w_k;  density = 1 + sum_k s_k
+ *                proj_k = (p_i - x_j) - ((p_i - x_j) . nm_j) nm_j
+ *                r = sum_k proj_k w_k / eps_denom(sum_k w_k) * density;   loss_ic = exp(-|r_c|)  (3 per point)
+ * Gradients are those autograd produces with every weight detached: d loss_i / d p_i only.
+ * ------------------------------------------------------------------------------------------- */
+static inline double eps_denom_d(double d)
+{
+    const double s = d > 0 ? 1.0 : (d < 0 ? -1.0 : 1.0);
+    const double a = fabs(d);
+    return s * (a > 1e-17 ? a : 1e-17);
+}
+
+DSS_ORACLE_API void oracle_mollify_normals(const float *normals, const float *knn_d2, const int64_t *knn_idx,
+                                           const uint8_t *keep /* or NULL */, const int64_t *first_of /* (P,) packed
+                                           id of the first point of p's cloud */, int64_t P, int K, float *out)
+{
+    for (int64_t p = 0; p < P; ++p) {
+        double mean = 0;
+        for (int k = 1; k < K; ++k) mean += (double)knn_d2[p * K + k];
+        mean /= (K - 1);
+        const double h = 4.0 * mean;
+        double acc[3] = {0, 0, 0}, wsum = 0;
+        for (int k = 1; k < K; ++k) {
+            double w = 1.0 - (double)knn_d2[p * K + k] / h;
+            if (w < 0) w = 0;
+            w = w * w; w = w * w;
+            const int64_t j = first_of[p] + knn_idx[p * K + k];
+            for (int d = 0; d < 3; ++d) acc[d] += w * (double)normals[3 * j + d];
+            wsum += w;
+        }
+        const int kept = keep && keep[p];
+        for (int d = 0; d < 3; ++d) out[3 * p + d] = kept ? normals[3 * p + d] : (float)(acc[d] / eps_denom_d(wsum));
+    }
+}
+
+static void unit3d(const float *v, double *o)
+{
+    double n = sqrt((double)v[0] * v[0] + (double)v[1] * v[1] + (double)v[2] * v[2]);
+    if (n < 1e-12) n = 1e-12;
+    for (int d = 0; d < 3; ++d) o[d] = (double)v[d] / n;
+}
+
+DSS_ORACLE_API void oracle_projection_loss(const float *points, const float *mollified, const float *knn_d2,
+                                           const int64_t *knn_idx, const uint8_t *visible /* or NULL */,
+                                           const int64_t *first_of, int64_t P, int K, float sigma,
+                                           const float *grad_loss /* (P,) or NULL */, float *loss /* (P,) */,
+                                           float *grad_points /* (P,3) or NULL */)
+{
+    const double inv_s = 1.0 / ((double)sigma * (double)sigma);
+    for (int64_t p = 0; p < P; ++p) {
+        double mean = 0;
+        for (int k = 1; k < K; ++k) mean += (double)knn_d2[p * K + k];
+        const double h = 4.0 * mean / (K - 1);
+        double ni[3];
+        unit3d(mollified + 3 * p, ni);
+        double num = 0, den = 0, g[3] = {0, 0, 0};
+        for (int k = 1; k < K; ++k) {
+            double phi = 1.0 - (double)knn_d2[p * K + k] / h;
+            if (phi < 0) phi = 0;
+            phi = phi * phi; phi = phi * phi;
+            const int64_t j = first_of[p] + knn_idx[p * K + k];
+            double nj[3], dn = 0, sdf = 0;
+            unit3d(mollified + 3 * j, nj);
+            for (int d = 0; d < 3; ++d) {
+                dn += (nj[d] - ni[d]) * (nj[d] - ni[d]);
+                sdf += ((double)points[3 * j + d] - (double)points[3 * p + d]) * (double)mollified[3 * j + d];
+            }
+            const double w = phi * exp(-dn * inv_s) * ((!visible || visible[j]) ? 1.0 : (double)0.1f);
+            num += w * sdf * sdf;
+            den += w;
+            for (int d = 0; d < 3; ++d) g[d] += -2.0 * w * sdf * (double)mollified[3 * j + d];
+        }
+        den = eps_denom_d(den);
+        loss[p] = (float)(num / den);
+        if (grad_points)
+            for (int d = 0; d < 3; ++d) grad_points[3 * p + d] = (float)((grad_loss ? grad_loss[p] : 1.0f) * g[d] / den);
+    }
+}
+
+DSS_ORACLE_API void oracle_repulsion_loss(const float *points, const float *mollified, const int64_t *knn_idx,
+                                          const int64_t *first_of, const float *inv_sigma_of /* (P,) per point's
+                                          cloud */, int64_t P, int K, float sigma, const float *grad_loss /* (P,3) or
+                                          NULL */, float *loss /* (P,3) */, float *grad_points /* (P,3) or NULL */)
+{
+    const double inv_s = 1.0 / ((double)sigma * (double)sigma);
+    for (int64_t p = 0; p < P; ++p) {
+        double ni[3];
+        unit3d(mollified + 3 * p, ni);
+        double acc[3] = {0, 0, 0}, wsum = 0, ssum = 0, A[3][3] = {{0}};
+        for (int k = 1; k < K; ++k) {
+            const int64_t j = first_of[p] + knn_idx[p * K + k];
+            double nj[3], dn = 0, d2 = 0, df[3], dot = 0;
+            unit3d(mollified + 3 * j, nj);
+            for (int d = 0; d < 3; ++d) {
+                dn += (nj[d] - ni[d]) * (nj[d] - ni[d]);
+                df[d] = (double)points[3 * p + d] - (double)points[3 * j + d];
+                d2 += df[d] * df[d];
+                dot += df[d] * (double)mollified[3 * j + d];
+            }
+            const double s = exp(-d2 * (double)inv_sigma_of[p]);
+            const double w = s * exp(-dn * inv_s);
+            ssum += s;
+            wsum += w;
+            for (int d = 0; d < 3; ++d) {
+                acc[d] += w * (df[d] - dot * (double)mollified[3 * j + d]);
+                for (int e = 0; e < 3; ++e)
+                    A[d][e] += w * ((d == e ? 1.0 : 0.0) - (double)mollified[3 * j + d] * (double)mollified[3 * j + e]);
+            }
+        }
+        const double den = eps_denom_d(wsum), density = ssum + 1.0;
+        double r[3], dl[3];
+        for (int d = 0; d < 3; ++d) {
+            r[d] = acc[d] / den * density;
+            const double l = exp(-fabs(r[d]));
+            loss[3 * p + d] = (float)l;
+            dl[d] = (grad_loss ? (double)grad_loss[3 * p + d] : 1.0) * (r[d] > 0 ? -l : (r[d] < 0 ? l : 0.0));
+        }
+        if (grad_points)
+            for (int e = 0; e < 3; ++e) {
+                double g = 0;
+                for (int d = 0; d < 3; ++d) g += dl[d] * A[d][e] / den * density;
+                grad_points[3 * p + e] = (float)g;
+            }
+    }
+}

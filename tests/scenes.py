@@ -139,3 +139,20 @@ def random_splats(P, S, N=1, seed=0, negz=5, rmin=1.5, rmax=6.0, ties=False):
                 scaler=rng.uniform(0.5, 2.0, N * P).astype(np.float32),
                 colors=rng.uniform(0, 1, (N * P, 3)).astype(np.float32),
                 first_idx=(np.arange(N) * P).astype(np.int64), num_pts=np.full(N, P, np.int64), S=S)
+
+
+def self_knn(points_list, K):
+    """CPU stand-in of the self query knn_points(p, p, K) on a list of clouds -> packed (dists (P,K) squared fp32,
+    idx (P,K) int64 cloud-local, first_of (P,) packed id of the first point of each point's cloud); the point itself
+    is entry 0, neighbours ascending."""
+    from scipy.spatial import cKDTree
+    d_all, i_all, f_all, first = [], [], [], 0
+    for p in points_list:
+        p64 = np.asarray(p, np.float64)
+        _, idx = cKDTree(p64).query(p64, k=K)
+        idx[:, 0] = np.arange(len(p64))  # coincident points: keep the query itself first
+        d2 = ((p64[:, None, :] - p64[idx]) ** 2).sum(-1)
+        d_all.append(d2.astype(np.float32)); i_all.append(idx.astype(np.int64))
+        f_all.append(np.full(len(p64), first, np.int64))
+        first += len(p64)
+    return np.concatenate(d_all), np.concatenate(i_all), np.concatenate(f_all)
