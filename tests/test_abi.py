@@ -75,9 +75,11 @@ def test_hot_kernels_do_not_spill_to_scratch():
     hot = ["fine_kernelILi%dE" % k for k in (1, 2, 3, 4, 5, 8)] + [
         "render_backward_kernelILi3E", "occ_backward_kernel", "blend_backward_kernelILi3E", "setup_bin_kernel",
         "bin_kernel", "visible_scan_kernel", "median_hist_kernel", "backward_compact_kernel", "median_visible_kernel", "point_setup_kernel", "project_backward_kernel",
-        "blend_forward_kernelILi3E"]
+        "blend_forward_kernelILi3E", "knn_query_kernelILi8ELb0E", "knn_query_kernelILi8ELb1E",
+        "knn_query_kernelILi12ELb1E", "knn_query_kernelILi16ELb1E", "projection_loss_kernel", "repulsion_loss_kernel",
+        "mollify_normals_kernel"]
     seen = {}
-    for src in ("raster_forward.hip", "raster_backward.hip", "blend.hip", "setup.hip"):
+    for src in ("raster_forward.hip", "raster_backward.hip", "blend.hip", "setup.hip", "knn.hip", "regularizers.hip"):
         out = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
                               "-fno-fast-math", "-Rpass-analysis=kernel-resource-usage", "-c",
                               os.path.join(ROOT, "dss_amd", "csrc", src), "-o", os.devnull],
