@@ -267,10 +267,11 @@ __global__ __launch_bounds__(256) void knn_query_kernel(const float *__restrict_
         if (FULL) {
             // total order (distance, id): deterministic lists whatever the cell order
             const int id = __float_as_int(q.w);
-            if (d2 < best[K - 1] || (d2 == best[K - 1] && id < bid[K - 1])) {
+            // bitwise | and &: the short-circuit forms compile to two nested exec-mask branches per comparison
+            if ((d2 < best[K - 1]) | ((d2 == best[K - 1]) & (id < bid[K - 1]))) {
                 bool lt[K];
 #pragma unroll
-                for (int k = 0; k < K; ++k) lt[k] = d2 < best[k] || (d2 == best[k] && id < bid[k]);
+                for (int k = 0; k < K; ++k) lt[k] = (d2 < best[k]) | ((d2 == best[k]) & (id < bid[k]));
 #pragma unroll
                 for (int k = K - 1; k >= 1; --k) {
                     // the empty asm keeps the operands values: left alone, the compiler rewrites select(c, bid[k-1],
