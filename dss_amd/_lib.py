@@ -55,6 +55,11 @@ SIGNATURES = {
     "dss_projection_loss": (_c_int, [_c_vp] * 7 + [_c_int, _c_i64, _c_int, _c_f32, _c_vp, _c_vp, _c_vp, _c_vp]),
     "dss_repulsion_loss": (_c_int, [_c_vp] * 5 + [_c_int, _c_i64, _c_int, _c_f32, _c_f32, _c_vp, _c_vp, _c_vp, _c_vp, _c_sz,
                                                   _c_vp]),
+    "dss_image_loss_workspace": (_c_sz, [_c_int, _c_int, _c_int]),
+    "dss_image_loss_forward": (_c_int, [_c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_i64, _c_vp, _c_int, _c_int, _c_int, _c_f32,
+                                        _c_f32, _c_vp, _c_vp, _c_vp, _c_sz, _c_vp]),
+    "dss_image_loss_backward": (_c_int, [_c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_i64, _c_vp, _c_int, _c_int, _c_int, _c_f32,
+                                         _c_f32, _c_vp, _c_vp, _c_vp, _c_vp]),
     "dss_knn_workspace": (_c_sz, [_c_int, _c_i64]),
     "dss_knn_kth_sqdist": (_c_int, [_c_vp] * 3 + [_c_int, _c_i64, _c_int, _c_vp, _c_vp, _c_sz, _c_vp]),
     "dss_knn_points": (_c_int, [_c_vp] * 3 + [_c_int, _c_i64, _c_int, _c_vp, _c_vp, _c_vp, _c_sz, _c_vp]),

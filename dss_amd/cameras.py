@@ -105,12 +105,34 @@ class FoVPerspectiveCameras:
         device = torch.device(device)
         other = FoVPerspectiveCameras.__new__(FoVPerspectiveCameras)
         other.__dict__.update(self.__dict__)
+        other.__dict__.pop("_matrix_cache", None)
         other.device = device
         for k in ("R", "T", "znear", "zfar", "aspect_ratio", "fov"):
             setattr(other, k, getattr(self, k).to(device))
         return other
 
+    _STATE = ("R", "T", "znear", "zfar", "aspect_ratio", "fov")
+
+    def _cached(self, name, build):
+        """Matrices are rebuilt only when a camera tensor was replaced or modified in place (tensor identity +
+        version counter; the cache keeps the tensors alive so an address cannot be recycled).  A training loop asks
+        for the same matrices every iteration, and each rebuild is ~20 tiny GPU launches (0.3 ms of host time)."""
+        state = tuple(getattr(self, k) for k in self._STATE)
+        key = tuple(t._version for t in state) + (self.degrees,)
+        cache = self.__dict__.setdefault("_matrix_cache", {})
+        hit = cache.get(name)
+        if hit is not None and hit[1] == key and all(a is b for a, b in zip(hit[0], state)):
+            return hit[2]
+        value = build()
+        cache[name] = (state, key, value)
+        return value
+
     def get_world_to_view_transform(self, **kwargs) -> Transform3d:
+        if "R" not in kwargs and "T" not in kwargs:
+            return self._cached("view", self._world_to_view)
+        return self._world_to_view(**kwargs)
+
+    def _world_to_view(self, **kwargs) -> Transform3d:
         R = kwargs.get("R", self.R)
         T = kwargs.get("T", self.T)
         n = R.shape[0]
@@ -121,6 +143,9 @@ class FoVPerspectiveCameras:
         return Transform3d(m)
 
     def get_projection_transform(self, **kwargs) -> Transform3d:
+        return self._cached("projection", self._projection)
+
+    def _projection(self) -> Transform3d:
         n = len(self)
         dev = self.R.device
         fov = self.fov * (math.pi / 180.0) if self.degrees else self.fov
@@ -140,7 +165,9 @@ class FoVPerspectiveCameras:
         return Transform3d(K.transpose(1, 2).contiguous())
 
     def get_full_projection_transform(self, **kwargs) -> Transform3d:
-        return self.get_world_to_view_transform(**kwargs).compose(self.get_projection_transform(**kwargs))
+        if "R" not in kwargs and "T" not in kwargs:
+            return self._cached("full", lambda: self._world_to_view().compose(self._projection()))
+        return self._world_to_view(**kwargs).compose(self.get_projection_transform())
 
     def transform_points(self, points, eps: Optional[float] = None, **kwargs):
         return self.get_full_projection_transform(**kwargs).transform_points(points, eps=eps)

@@ -1,0 +1,203 @@
+// Image loss of the training iteration and its gradient with respect to the rendered RGBA image:
+// Trainer.calc_dr_loss (DSS/training/trainer.py:332-372) with the loss objects of Trainer.__init__ (:138-141):
+//     inside = mask != 0 and alpha != 0                       (mask_img.bool() & mask_img_pred.bool(), :351)
+//     rgb    = sum_inside sum_c |img_c - pred_c| / #inside    (L1Loss losses.py:127-135 + BaseLoss :54-61; 0 if none)
+//     sil    = mean |mask - alpha| + 0.01 mean_n (1 - I_n / eps_denom(U_n))          (:361-367, IouLoss :498-513)
+//     total  = lambda_dr_rgb rgb + lambda_dr_silhouette sil
+// This sits between the render forward and the render backward of every iteration.  As ~20 elementwise / reduction
+// torch kernels (forward + autograd) over (N,H,W,4) images it costs more than the whole 90 us render step at 512^2;
+// here: one reduction pass over the images (per-block partial sums in a fixed order -> deterministic), a one-workgroup
+// finalize (per-image sums in double, the four loss scalars), and ONE pass that writes the gradient image that
+// dss_render_backward consumes.  HBM-bound: 32 B read per pixel per pass, 16 B written by the gradient pass.
+#include "common.h"
+
+namespace dss {
+
+#define IMG_LOSS_MAX_BLOCKS 64   // reduction blocks per image
+#define IMG_LOSS_TERMS 5         // inside count, sum |rgb diff| inside, sum |mask - alpha|, intersection, union
+
+struct TargetView {  // target colours with arbitrary element strides: (N,H,W,3) or a permuted (N,3,H,W) view
+    const float *p;
+    int64_t sn, sh, sw, sc;
+};
+
+__device__ __forceinline__ float sign_of(float v) { return (float)((v > 0.f) - (v < 0.f)); }
+
+__global__ __launch_bounds__(256) void image_loss_reduce_kernel(const float4 *__restrict__ rgba, const TargetView img,
+                                                                const float *__restrict__ mask, int H, int W,
+                                                                double *__restrict__ part /* (N, blocks, 5) */)
+{
+    __shared__ float wave_part[4][IMG_LOSS_TERMS];
+    const int n = blockIdx.y, b = blockIdx.x, nb = gridDim.x;
+    const int64_t HW = (int64_t)H * W;
+    float cnt = 0.f, srgb = 0.f, smask = 0.f, inter = 0.f, uni = 0.f;  // <= a few hundred terms per thread: exact counts
+    for (int64_t i = (int64_t)b * 256 + threadIdx.x; i < HW; i += (int64_t)nb * 256) {
+        const int64_t q = (int64_t)n * HW + i;
+        const float4 px = rgba[q];
+        const float t = mask[q];
+        const int y = (int)(i / W), x = (int)(i - (int64_t)y * W);
+        const float *tp = img.p + n * img.sn + y * img.sh + x * img.sw;
+        const float d = fabsf(tp[0] - px.x) + fabsf(tp[img.sc] - px.y) + fabsf(tp[2 * img.sc] - px.z);
+        const bool inside = t != 0.f && px.w != 0.f;
+        cnt += inside ? 1.f : 0.f;
+        srgb += inside ? d : 0.f;
+        smask += fabsf(t - px.w);
+        inter += px.w * t;
+        uni += px.w + t - px.w * t;
+    }
+    const float v[IMG_LOSS_TERMS] = {wave_sum(cnt), wave_sum(srgb), wave_sum(smask), wave_sum(inter), wave_sum(uni)};
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int k = 0; k < IMG_LOSS_TERMS; ++k) wave_part[threadIdx.x >> 6][k] = v[k];
+    __syncthreads();
+    if (threadIdx.x < IMG_LOSS_TERMS)
+        part[((size_t)n * nb + b) * IMG_LOSS_TERMS + threadIdx.x] =
+            ((double)wave_part[0][threadIdx.x] + (double)wave_part[1][threadIdx.x]) +
+            ((double)wave_part[2][threadIdx.x] + (double)wave_part[3][threadIdx.x]);
+}
+
+// sums (N+1, 5): rows 0..N-1 per image, row N the totals over the batch.  losses (4): total, weighted rgb term,
+// weighted silhouette term, IoU term (mean_n 1 - I/U).
+__global__ __launch_bounds__(64) void image_loss_finalize_kernel(const double *__restrict__ part, int N, int nb, int H, int W,
+                                                                 float lambda_rgb, float lambda_sil,
+                                                                 double *__restrict__ sums, float *__restrict__ losses)
+{
+    __shared__ double tot[IMG_LOSS_TERMS];
+    __shared__ double iou_s;
+    const int k = threadIdx.x;
+    if (k < IMG_LOSS_TERMS) {
+        double all = 0.0;
+        for (int n = 0; n < N; ++n) {
+            double s = 0.0;
+            for (int b = 0; b < nb; ++b) s += part[((size_t)n * nb + b) * IMG_LOSS_TERMS + k];
+            sums[(size_t)n * IMG_LOSS_TERMS + k] = s;
+            all += s;
+        }
+        sums[(size_t)N * IMG_LOSS_TERMS + k] = all;
+        tot[k] = all;
+    }
+    __syncthreads();
+    if (k == 0) {
+        double iou = 0.0;
+        for (int n = 0; n < N; ++n) {
+            const double u = sums[(size_t)n * IMG_LOSS_TERMS + 4];
+            const double den = (u < 0 ? -1.0 : 1.0) * fmax(fabs(u), 1e-17);  // eps_denom, mathHelper.py:10-14
+            iou += 1.0 - sums[(size_t)n * IMG_LOSS_TERMS + 3] / den;
+        }
+        iou_s = iou / N;
+        const double rgb = tot[0] > 0 ? tot[1] / tot[0] : 0.0;  // `if mask_pred.sum() > 0`, trainer.py:352
+        const double sil = tot[2] / ((double)N * H * W) + 0.01 * iou_s;
+        losses[0] = (float)(lambda_rgb * rgb + lambda_sil * sil);
+        losses[1] = (float)(lambda_rgb * rgb);
+        losses[2] = (float)(lambda_sil * sil);
+        losses[3] = (float)iou_s;
+    }
+}
+
+__global__ __launch_bounds__(256) void image_loss_grad_kernel(const float4 *__restrict__ rgba, const TargetView img,
+                                                              const float *__restrict__ mask, int N, int H, int W,
+                                                              float lambda_rgb, float lambda_sil,
+                                                              const double *__restrict__ sums,
+                                                              const float *__restrict__ grad_total,
+                                                              float4 *__restrict__ grad_rgba)
+{
+    const int64_t HW = (int64_t)H * W;
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= (int64_t)N * HW) return;
+    const int n = (int)(q / HW);
+    const int64_t i = q - (int64_t)n * HW;
+    const int y = (int)(i / W), x = (int)(i - (int64_t)y * W);
+    const float up = grad_total ? grad_total[0] : 1.0f;
+    const double cnt = sums[(size_t)N * IMG_LOSS_TERMS];
+    const double I = sums[(size_t)n * IMG_LOSS_TERMS + 3], U = sums[(size_t)n * IMG_LOSS_TERMS + 4];
+    const float w_rgb = cnt > 0 ? (float)((double)lambda_rgb / cnt) : 0.f;
+    const float w_l1 = (float)((double)lambda_sil / ((double)N * (double)HW));
+    const float4 px = rgba[q];
+    const float t = mask[q];
+    const float *tp = img.p + n * img.sn + y * img.sh + x * img.sw;
+    const bool inside = t != 0.f && px.w != 0.f;
+    float4 g;
+    g.x = inside ? w_rgb * sign_of(px.x - tp[0]) * up : 0.f;
+    g.y = inside ? w_rgb * sign_of(px.y - tp[img.sc]) * up : 0.f;
+    g.z = inside ? w_rgb * sign_of(px.z - tp[2 * img.sc]) * up : 0.f;
+    // d(1 - I/U)/d alpha = -(t U - I (1 - t)) / U^2; with the denominator clamped (U == 0) only -t / eps is left
+    const double Ue = (U < 0 ? -1.0 : 1.0) * fmax(fabs(U), 1e-17);
+    const double diou = fabs(U) > 1e-17 ? -((double)t * Ue - I * (1.0 - (double)t)) / (Ue * Ue) : -(double)t / Ue;
+    g.w = (w_l1 * sign_of(px.w - t) + (float)((double)lambda_sil * 0.01 * diou / N)) * up;
+    grad_rgba[q] = g;
+}
+
+static int image_blocks(int H, int W)
+{
+    const int64_t b = ((int64_t)H * W + 4095) / 4096;
+    return (int)(b < 1 ? 1 : (b > IMG_LOSS_MAX_BLOCKS ? IMG_LOSS_MAX_BLOCKS : b));
+}
+
+static int check_image_args(const char *who, const void *rgba, const void *img, const void *mask, int N, int H, int W)
+{
+    if (N <= 0 || H <= 0 || W <= 0) {
+        set_error("%s: bad sizes N=%d H=%d W=%d", who, N, H, W);
+        return DSS_ERR_INVALID_ARGUMENT;
+    }
+    if (!rgba || !img || !mask) {
+        set_error("%s: NULL tensor pointer", who);
+        return DSS_ERR_INVALID_ARGUMENT;
+    }
+    if ((reinterpret_cast<uintptr_t>(rgba) & 15) != 0) {
+        set_error("%s: the RGBA image must be 16-byte aligned", who);
+        return DSS_ERR_INVALID_ARGUMENT;
+    }
+    return DSS_OK;
+}
+
+}  // namespace dss
+
+using namespace dss;
+
+extern "C" size_t dss_image_loss_workspace(int N, int H, int W)
+{
+    return (size_t)(N > 0 ? N : 1) * image_blocks(H, W) * IMG_LOSS_TERMS * sizeof(double);
+}
+
+extern "C" int dss_image_loss_forward(const float *rgba, const float *target_rgb, int64_t t_stride_n, int64_t t_stride_h,
+                                      int64_t t_stride_w, int64_t t_stride_c, const float *target_mask, int N, int H, int W,
+                                      float lambda_rgb, float lambda_silhouette, double *sums, float *losses,
+                                      void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (int rc = check_image_args("dss_image_loss_forward", rgba, target_rgb, target_mask, N, H, W)) return rc;
+    if (!sums || !losses) {
+        set_error("dss_image_loss_forward: NULL output pointer");
+        return DSS_ERR_INVALID_ARGUMENT;
+    }
+    if (!workspace || workspace_bytes < dss_image_loss_workspace(N, H, W)) {
+        set_error("dss_image_loss_forward: workspace too small");
+        return DSS_ERR_WORKSPACE;
+    }
+    hipStream_t st = as_stream(stream);
+    const int nb = image_blocks(H, W);
+    const TargetView tv = {target_rgb, t_stride_n, t_stride_h, t_stride_w, t_stride_c};
+    double *part = reinterpret_cast<double *>(workspace);
+    hipLaunchKernelGGL(image_loss_reduce_kernel, dim3(nb, N), dim3(256), 0, st, reinterpret_cast<const float4 *>(rgba), tv,
+                       target_mask, H, W, part);
+    hipLaunchKernelGGL(image_loss_finalize_kernel, dim3(1), dim3(64), 0, st, part, N, nb, H, W, lambda_rgb,
+                       lambda_silhouette, sums, losses);
+    return check_launch("dss_image_loss_forward");
+}
+
+extern "C" int dss_image_loss_backward(const float *rgba, const float *target_rgb, int64_t t_stride_n, int64_t t_stride_h,
+                                       int64_t t_stride_w, int64_t t_stride_c, const float *target_mask, int N, int H,
+                                       int W, float lambda_rgb, float lambda_silhouette, const double *sums,
+                                       const float *grad_total, float *grad_rgba, void *stream)
+{
+    if (int rc = check_image_args("dss_image_loss_backward", rgba, target_rgb, target_mask, N, H, W)) return rc;
+    if (!sums || !grad_rgba || (reinterpret_cast<uintptr_t>(grad_rgba) & 15) != 0) {
+        set_error("dss_image_loss_backward: sums and a 16-byte aligned grad_rgba are required");
+        return DSS_ERR_INVALID_ARGUMENT;
+    }
+    const TargetView tv = {target_rgb, t_stride_n, t_stride_h, t_stride_w, t_stride_c};
+    const int64_t total = (int64_t)N * H * W;
+    hipLaunchKernelGGL(image_loss_grad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const float4 *>(rgba), tv, target_mask, N, H, W, lambda_rgb, lambda_silhouette, sums,
+                       grad_total, reinterpret_cast<float4 *>(grad_rgba));
+    return check_launch("dss_image_loss_backward");
+}

@@ -150,3 +150,38 @@ class RepulsionLoss(SurfaceLoss):
         mollified = self._mollified(point_clouds, nb, points_filter)
         return _Repulsion.apply(point_clouds.points_packed(), mollified, nb.idx, nb.first, nb.num,
                                 float(self.sharpness_sigma), float(self.filter_scale))
+
+
+class _ImageLoss(autograd.Function):
+    """total, loss_dr_rgb, loss_dr_silhouette, IoU term; only the total is differentiable (the others are what the
+    Trainer logs)."""
+
+    @staticmethod
+    def forward(ctx, rgba, img, mask_img, lambda_rgb, lambda_silhouette):
+        losses, sums = ops.image_loss_forward(rgba, img, mask_img, lambda_rgb, lambda_silhouette)
+        ctx.save_for_backward(rgba, img, mask_img, sums)
+        ctx.lambdas = (lambda_rgb, lambda_silhouette)
+        total, rest = losses[0], losses[1:]
+        ctx.mark_non_differentiable(rest)
+        return total, rest
+
+    @staticmethod
+    def backward(ctx, grad_total, _grad_rest):
+        rgba, img, mask_img, sums = ctx.saved_tensors
+        grad = ops.image_loss_backward(rgba, img, mask_img, ctx.lambdas[0], ctx.lambdas[1], sums,
+                                       grad_total=grad_total.contiguous())
+        return grad, None, None, None, None
+
+
+def calc_dr_loss(rgba_pred, img, mask_img, lambda_dr_rgb: float = 1.0, lambda_dr_silhouette: float = 1.0):
+    """The image loss of `Trainer.calc_dr_loss` (trainer.py:332-372) on the renderer's (N,H,W,4) output
+    (``img_pred = rgba[..., :3]``, ``mask_img_pred = rgba[..., 3]``): masked L1 on RGB + silhouette L1 + 0.01 IoU, as
+    one reduction pass and, in backward, one gradient pass (dss_amd/csrc/image_loss.hip).
+
+    ``img`` (N,H,W,3) float (a permuted NCHW view is fine, as in trainer.py:306), ``mask_img`` (N,H,W) or (N,1,H,W).
+    Returns the Trainer's dictionary entries: ``loss`` (differentiable), ``loss_dr_rgb``, ``loss_dr_silhouette``, plus
+    ``loss_iou`` -- device scalars, no host synchronisation."""
+    if mask_img.dtype != torch.float32:
+        mask_img = mask_img.float()
+    total, rest = _ImageLoss.apply(rgba_pred, img, mask_img, float(lambda_dr_rgb), float(lambda_dr_silhouette))
+    return {"loss": total, "loss_dr_rgb": rest[0], "loss_dr_silhouette": rest[1], "loss_iou": rest[2]}

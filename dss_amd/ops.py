@@ -709,3 +709,57 @@ def repulsion_loss(points, mollified, knn_idx, cloud_to_packed_first_idx, num_po
                                     _lib.ptr(grad), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
     _lib.check(rc, "dss_repulsion_loss")
     return loss, grad
+
+
+def _image_loss_args(rgba, target_rgb, target_mask):
+    rgba = _lib.require_gpu(rgba, "rgba", _f32)
+    if rgba.dim() != 4 or rgba.shape[-1] != 4:
+        raise RuntimeError("dss_amd: rgba must be (N,H,W,4), got %s" % (tuple(rgba.shape),))
+    N, H, W, _ = rgba.shape
+    if not isinstance(target_rgb, torch.Tensor) or not target_rgb.is_cuda or target_rgb.dtype != _f32:
+        raise RuntimeError("dss_amd: target_rgb must be a float32 GPU tensor (no CPU fallback)")
+    if tuple(target_rgb.shape) != (N, H, W, 3):
+        raise RuntimeError("dss_amd: target_rgb must be (N,H,W,3) = %s (a permuted NCHW view is fine), got %s"
+                           % ((N, H, W, 3), tuple(target_rgb.shape)))
+    target_mask = _lib.require_gpu(target_mask, "target_mask", _f32).reshape(N, H, W)
+    return rgba, target_rgb, target_mask, N, H, W
+
+
+def image_loss_forward(rgba, target_rgb, target_mask, lambda_rgb: float, lambda_silhouette: float):
+    """Trainer.calc_dr_loss (trainer.py:332-372) on the rendered (N,H,W,4) image -> (losses (4,) = total, weighted rgb
+    term, weighted silhouette term, IoU term; sums (N+1,5) float64 for :func:`image_loss_backward`).  ``target_rgb``
+    (N,H,W,3) may be any strided view (e.g. ``img.permute(0, 2, 3, 1)``); no host synchronisation."""
+    lib = _lib.load()
+    rgba, target_rgb, target_mask, N, H, W = _image_loss_args(rgba, target_rgb, target_mask)
+    dev = rgba.device
+    sn, sh, sw, sc = target_rgb.stride()
+    with torch.cuda.device(dev):
+        losses = torch.empty((4,), dtype=_f32, device=dev)
+        sums = torch.empty((N + 1, 5), dtype=torch.float64, device=dev)
+        ws = _lib.workspace(dev, lib.dss_image_loss_workspace(N, H, W))
+        rc = lib.dss_image_loss_forward(_lib.ptr(rgba), _lib.ptr(target_rgb), sn, sh, sw, sc, _lib.ptr(target_mask), N, H, W,
+                                        float(lambda_rgb), float(lambda_silhouette), _lib.ptr(sums), _lib.ptr(losses),
+                                        _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
+    _lib.check(rc, "dss_image_loss_forward")
+    return losses, sums
+
+
+def image_loss_backward(rgba, target_rgb, target_mask, lambda_rgb: float, lambda_silhouette: float, sums, grad_total=None):
+    """Gradient of the total image loss w.r.t. the rendered image, (N,H,W,4), scaled by the device scalar
+    ``grad_total`` (None = 1)."""
+    lib = _lib.load()
+    rgba, target_rgb, target_mask, N, H, W = _image_loss_args(rgba, target_rgb, target_mask)
+    dev = rgba.device
+    sums = _lib.require_gpu(sums, "sums", torch.float64)
+    if tuple(sums.shape) != (N + 1, 5):
+        raise RuntimeError("dss_amd: sums must be (N+1,5) from image_loss_forward")
+    if grad_total is not None:
+        grad_total = _lib.require_gpu(grad_total, "grad_total", _f32).reshape(1)
+    sn, sh, sw, sc = target_rgb.stride()
+    with torch.cuda.device(dev):
+        grad = torch.empty_like(rgba)
+        rc = lib.dss_image_loss_backward(_lib.ptr(rgba), _lib.ptr(target_rgb), sn, sh, sw, sc, _lib.ptr(target_mask), N, H, W,
+                                         float(lambda_rgb), float(lambda_silhouette), _lib.ptr(sums), _lib.ptr(grad_total),
+                                         _lib.ptr(grad), _lib.stream_ptr(dev))
+    _lib.check(rc, "dss_image_loss_backward")
+    return grad

@@ -212,8 +212,13 @@ class SurfaceSplatting(torch.nn.Module):
         world, normals = point_clouds.points_packed(), point_clouds.normals_packed()
         if shared:
             Pc = world.shape[0]
-            first_idx = torch.arange(N, device=dev, dtype=torch.int64) * Pc
-            num_points = torch.full((N,), Pc, device=dev, dtype=torch.int64)
+            ranges = self.__dict__.setdefault("_range_cache", {})
+            if (N, Pc, dev) not in ranges:  # constant across iterations: two tiny launches saved per call
+                if len(ranges) > 8:
+                    ranges.clear()
+                ranges[(N, Pc, dev)] = (torch.arange(N, device=dev, dtype=torch.int64) * Pc,
+                                        torch.full((N,), Pc, device=dev, dtype=torch.int64))
+            first_idx, num_points = ranges[(N, Pc, dev)]
             if h.numel() == 1:
                 h = h.reshape(1).expand(N).contiguous()
             out_clouds = point_clouds.extend(N) if N > 1 else point_clouds
@@ -222,8 +227,14 @@ class SurfaceSplatting(torch.nn.Module):
             out_clouds = point_clouds
         M = cameras.get_full_projection_transform().get_matrix().to(dev, torch.float32).contiguous()
         V = cameras.get_world_to_view_transform().get_matrix().to(dev, torch.float32).contiguous()
-        as_n = lambda v, d: torch.as_tensor(getattr(cameras, v, kwargs.get(v, d)), dtype=torch.float32,
-                                            device=dev).reshape(-1).expand(N).contiguous()
+
+        def as_n(v, d):
+            t = getattr(cameras, v, kwargs.get(v, d))
+            if (torch.is_tensor(t) and t.dtype == torch.float32 and t.device == dev and t.dim() == 1
+                    and t.shape[0] == N and t.is_contiguous()):
+                return t  # the usual case: no copy, no launch
+            return torch.as_tensor(t, dtype=torch.float32, device=dev).reshape(-1).expand(N).contiguous()
+
         return dict(N=N, shared=shared, world=world, normals=normals, h=h.to(dev, torch.float32), M=M, V=V,
                     znear=as_n("znear", 1.0), zfar=as_n("zfar", 100.0), first_idx=first_idx, num_points=num_points,
                     out_clouds=out_clouds, raster_settings=raster_settings, vr6=vr6, frame_n=frame_n)

@@ -385,6 +385,34 @@ DSS_API int dss_repulsion_loss(const float *points, const float *mollified, cons
                                float *loss, float *grad_points, void *workspace, size_t workspace_bytes,
                                void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Image loss of the training iteration and its gradient w.r.t. the rendered image: Trainer.calc_dr_loss
+ * (DSS/training/trainer.py:332-372) with the loss objects of Trainer.__init__ (:138-141) -- masked L1 on RGB (L1Loss,
+ * losses.py:127-135; mask = target mask & predicted mask, mean over the pixels inside both of the channel sum, skipped
+ * when empty), silhouette L1 mean + 0.01 * IoU loss (IouLoss :498-513, mean over the batch), weighted by
+ * lambda_dr_rgb / lambda_dr_silhouette (configs/dss.yml:32-33).  Sits between dss_render_forward and
+ * dss_render_backward of every iteration; replaces ~20 torch kernels (forward + autograd) over (N,H,W,4) images.
+ *   rgba (N,H,W,4) contiguous, 16-byte aligned: the renderer's output (alpha = occupancy = mask_img_pred);
+ *   target_rgb with element strides (n,h,w,c): (N,H,W,3) or the permuted (N,3,H,W) view of trainer.py:306;
+ *   target_mask (N,H,W) float.
+ * forward:  sums (N+1,5) double = per image [#inside, sum |rgb diff| inside, sum |mask - alpha|, intersection, union],
+ *           last row = batch totals (deterministic: fixed-order block partials); losses (4) = total, weighted rgb
+ *           term (loss_dr_rgb), weighted silhouette term (loss_dr_silhouette), IoU term.  No host synchronisation.
+ * backward: grad_rgba (N,H,W,4) = d total / d rgba * grad_total[0] (device scalar, NULL = 1), from `sums`; with row
+ *           bands on several GPUs, all-reduce `sums` between the two calls (or evaluate on the gathered image).
+ * ------------------------------------------------------------------------------------------- */
+DSS_API size_t dss_image_loss_workspace(int N, int H, int W);
+DSS_API int dss_image_loss_forward(const float *rgba, const float *target_rgb, int64_t t_stride_n,
+                                   int64_t t_stride_h, int64_t t_stride_w, int64_t t_stride_c,
+                                   const float *target_mask, int N, int H, int W, float lambda_rgb,
+                                   float lambda_silhouette, double *sums, float *losses, void *workspace,
+                                   size_t workspace_bytes, void *stream);
+DSS_API int dss_image_loss_backward(const float *rgba, const float *target_rgb, int64_t t_stride_n,
+                                    int64_t t_stride_h, int64_t t_stride_w, int64_t t_stride_c,
+                                    const float *target_mask, int N, int H, int W, float lambda_rgb,
+                                    float lambda_silhouette, const double *sums, const float *grad_total,
+                                    float *grad_rgba, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

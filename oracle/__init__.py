@@ -279,3 +279,15 @@ def repulsion_loss(points, mollified, knn_idx, first_of, inv_sigma_of, sigma, gr
                                  ctypes.c_int64(P), K, ctypes.c_float(sigma), None if gl is None else _p(gl), _p(loss),
                                  _p(grad))
     return loss, grad
+
+
+def image_loss(rgba, img, mask, lambda_rgb, lambda_sil, want_grad=True):
+    """Trainer.calc_dr_loss (trainer.py:332-372) and its gradient w.r.t. the rendered RGBA image ->
+    (losses (4,) = total, weighted rgb, weighted silhouette, IoU term; grad_rgba (N,H,W,4) or None)."""
+    rgba, img, mask = _f32(rgba), _f32(img), _f32(mask)
+    N, H, W = mask.shape
+    losses = np.empty((4,), np.float32)
+    grad = np.empty((N, H, W, 4), np.float32) if want_grad else None
+    _lib().oracle_image_loss(_p(rgba), _p(img), _p(mask), N, H, W, ctypes.c_float(lambda_rgb), ctypes.c_float(lambda_sil),
+                             _p(losses), None if grad is None else _p(grad))
+    return losses, grad

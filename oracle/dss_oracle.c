@@ -855,3 +855,63 @@ DSS_ORACLE_API void oracle_repulsion_loss(const float *points, const float *moll
             }
     }
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * Image loss of the training iteration: Trainer.calc_dr_loss (DSS/training/trainer.py:332-372) with the loss
+ * objects of Trainer.__init__ (:138-141), restated in double precision together with its gradient with respect
+ * to the rendered RGBA image (what autograd hands to the renderer's backward):
+ *   inside = mask != 0 and alpha != 0                          (mask_img.bool() & mask_img_pred.bool(), :351)
+ *   rgb    = sum_inside sum_c |img_c - pred_c| / #inside       (L1Loss + BaseLoss: channel sum, mean; 0 if none)
+ *   sil    = mean |mask - alpha| + 0.01 mean_n (1 - I_n / eps_denom(U_n)),  I = sum mask alpha,
+ *            U = sum (alpha + mask - alpha mask)                (:361-367, IouLoss losses.py:498-513)
+ *   total  = lambda_rgb rgb + lambda_sil sil
+ * losses[4] = total, lambda_rgb rgb, lambda_sil sil, IoU term (unweighted mean of 1 - I/U).
+ * ------------------------------------------------------------------------------------------- */
+DSS_ORACLE_API void oracle_image_loss(const float *rgba /* (N,H,W,4) */, const float *img /* (N,H,W,3) */,
+                                      const float *mask /* (N,H,W) */, int N, int H, int W, float lambda_rgb,
+                                      float lambda_sil, float *losses /* (4) */, float *grad_rgba /* (N,H,W,4) or NULL */)
+{
+    const int64_t HW = (int64_t)H * W;
+    double cnt = 0, srgb = 0, smask = 0, iou = 0;
+    double *I = (double *)calloc((size_t)N, sizeof(double)), *U = (double *)calloc((size_t)N, sizeof(double));
+    for (int n = 0; n < N; ++n)
+        for (int64_t i = 0; i < HW; ++i) {
+            const int64_t q = n * HW + i;
+            const double a = rgba[4 * q + 3], t = mask[q];
+            if (t != 0 && a != 0) {
+                cnt += 1;
+                for (int c = 0; c < 3; ++c) srgb += fabs((double)img[3 * q + c] - (double)rgba[4 * q + c]);
+            }
+            smask += fabs(t - a);
+            I[n] += a * t;
+            U[n] += a + t - a * t;
+        }
+    for (int n = 0; n < N; ++n) iou += 1.0 - I[n] / eps_denom_d(U[n]);
+    iou /= N;
+    const double rgb = cnt > 0 ? srgb / cnt : 0.0;
+    const double sil = smask / ((double)N * HW) + 0.01 * iou;
+    losses[0] = (float)(lambda_rgb * rgb + lambda_sil * sil);
+    losses[1] = (float)(lambda_rgb * rgb);
+    losses[2] = (float)(lambda_sil * sil);
+    losses[3] = (float)iou;
+    if (grad_rgba)
+        for (int n = 0; n < N; ++n) {
+            const double Un = eps_denom_d(U[n]);
+            for (int64_t i = 0; i < HW; ++i) {
+                const int64_t q = n * HW + i;
+                const double a = rgba[4 * q + 3], t = mask[q];
+                const int inside = t != 0 && a != 0;
+                for (int c = 0; c < 3; ++c) {
+                    const double d = (double)rgba[4 * q + c] - (double)img[3 * q + c];
+                    grad_rgba[4 * q + c] = inside ? (float)(lambda_rgb * (d > 0 ? 1.0 : (d < 0 ? -1.0 : 0.0)) / cnt) : 0.0f;
+                }
+                const double dm = a - t;
+                /* d(1 - I/U)/da = -(t U - I (1 - t)) / U^2; with the denominator clamped (U == 0) only -t / eps is left */
+                const double diou = fabs(U[n]) > 1e-17 ? -(t * Un - I[n] * (1.0 - t)) / (Un * Un) : -t / Un;
+                grad_rgba[4 * q + 3] = (float)(lambda_sil * ((dm > 0 ? 1.0 : (dm < 0 ? -1.0 : 0.0)) / ((double)N * HW) +
+                                                             0.01 * diou / N));
+            }
+        }
+    free(I);
+    free(U);
+}

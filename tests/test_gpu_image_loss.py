@@ -1,0 +1,75 @@
+"""GPU: the fused image loss of the training iteration (Trainer.calc_dr_loss, trainer.py:332-372) through the C ABI,
+against the golden vectors produced by the reference method itself with autograd
+(tests/golden/make_golden_image_loss.py) and against the oracle at full image sizes.  Float reductions: loss values
+to 1e-5 relative, gradients elementwise to 1e-5 relative (they are signs times exact scale factors)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from dss_amd import ops
+from dss_amd.losses import calc_dr_loss
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_image_loss.npz")
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_matches_reference_trainer_golden(tag):
+    z = np.load(GOLD)
+    rgba = _t(np.concatenate([z[tag + "_pred"], z[tag + "_mask_pred"][..., None]], -1)).requires_grad_(True)
+    lam_rgb, lam_sil = (float(v) for v in z[tag + "_lambdas"])
+    # the target arrives as the permuted view of an NCHW tensor, like trainer.py:306
+    img_nchw = _t(z[tag + "_img"].transpose(0, 3, 1, 2))
+    out = calc_dr_loss(rgba, img_nchw.permute(0, 2, 3, 1), _t(z[tag + "_mask"])[:, None], lam_rgb, lam_sil)
+    assert abs(out["loss"].item() - z[tag + "_loss"]) <= 1e-5 * abs(z[tag + "_loss"])
+    assert abs(out["loss_dr_rgb"].item() - z[tag + "_loss_rgb"]) <= 1e-5 * max(abs(z[tag + "_loss_rgb"]), 1e-6)
+    assert abs(out["loss_dr_silhouette"].item() - z[tag + "_loss_sil"]) <= 1e-5 * abs(z[tag + "_loss_sil"])
+    out["loss"].backward()
+    g = rgba.grad.cpu().numpy()
+    assert np.allclose(g[..., :3], z[tag + "_grad_pred"], rtol=1e-5, atol=1e-9)
+    assert np.allclose(g[..., 3], z[tag + "_grad_mask_pred"], rtol=1e-4, atol=1e-9)
+
+
+@pytest.mark.parametrize("N,H,W", [(1, 512, 512), (8, 1024, 1024), (3, 37, 53)])
+def test_matches_oracle_at_image_sizes(N, H, W):
+    rng = np.random.default_rng(N * 1000 + H)
+    img = rng.random((N, H, W, 3)).astype(np.float32)
+    rgba = rng.random((N, H, W, 4)).astype(np.float32)
+    rgba[..., 3] = rng.random((N, H, W)) < 0.4          # hard occupancy like the renderer's alpha
+    mask = (rng.random((N, H, W)) < 0.5).astype(np.float32)
+    losses, sums = ops.image_loss_forward(_t(rgba), _t(img), _t(mask), 1.0, 1.0)
+    up = torch.tensor([0.37], device=DEV)
+    grad = ops.image_loss_backward(_t(rgba), _t(img), _t(mask), 1.0, 1.0, sums, grad_total=up)
+    lo, go = oracle.image_loss(rgba, img, mask, 1.0, 1.0)
+    assert np.allclose(losses.cpu().numpy(), lo, rtol=1e-5)
+    assert np.allclose(grad.cpu().numpy(), 0.37 * go, rtol=1e-5, atol=1e-12)
+    s = sums.cpu().numpy()
+    inside = (mask != 0) & (rgba[..., 3] != 0)
+    assert np.array_equal(s[:N, 0], inside.reshape(N, -1).sum(1).astype(np.float64))     # counts are exact
+    assert s[N, 0] == inside.sum() and np.allclose(s[N], s[:N].sum(0))
+    # bit-reproducible: fixed-order partial sums
+    losses2, sums2 = ops.image_loss_forward(_t(rgba), _t(img), _t(mask), 1.0, 1.0)
+    assert torch.equal(losses, losses2) and torch.equal(sums, sums2)
+
+
+def test_bad_arguments_fail_loudly():
+    rgba = torch.rand(1, 8, 8, 4, device=DEV)
+    img = torch.rand(1, 8, 8, 3, device=DEV)
+    mask = torch.rand(1, 8, 8, device=DEV)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.image_loss_forward(rgba, img.cpu(), mask, 1.0, 1.0)
+    with pytest.raises(RuntimeError, match=r"\(N,H,W,3\)"):
+        ops.image_loss_forward(rgba, img.permute(0, 3, 1, 2), mask, 1.0, 1.0)
+    with pytest.raises(RuntimeError, match="GPU tensors"):
+        ops.image_loss_forward(rgba.cpu(), img, mask, 1.0, 1.0)
+    _, sums = ops.image_loss_forward(rgba, img, mask, 1.0, 1.0)
+    with pytest.raises(RuntimeError, match="sums"):
+        ops.image_loss_backward(rgba, img, mask, 1.0, 1.0, sums[:1])
