@@ -97,3 +97,76 @@ class PointClouds3D:
     def to(self, device):
         mv = lambda lst: None if lst is None else [t.to(device) for t in lst]
         return PointClouds3D(mv(self._points), mv(self._normals), mv(self._features))
+
+    def clone(self) -> "PointClouds3D":
+        cp = lambda lst: None if lst is None else [t.clone() for t in lst]
+        return PointClouds3D(cp(self._points), cp(self._normals), cp(self._features))
+
+    def get_bounding_boxes(self) -> torch.Tensor:
+        """(N, 3, 2) min / max of every cloud (pytorch3d Pointclouds.get_bounding_boxes; losses.py:252)."""
+        lo = torch.stack([p.min(0).values for p in self._points])
+        hi = torch.stack([p.max(0).values for p in self._points])
+        return torch.stack([lo, hi], dim=-1)
+
+
+class PointCloudsFilters:
+    """Per-point boolean filters of a batch of clouds, mirroring `DSS.core.cloud.PointCloudsFilters`
+    (DSS/core/cloud.py:284-351): padded 2-D masks ``inmask`` / ``activation`` / ``visibility`` of shape (N, P_max)
+    (or (1, 1) = everything on), `set_filter(**masks)`, `filter(point_clouds)` and `filter_with(point_clouds, names)`.
+    The rasterizer drops the points whose ``activation`` is off (rasterizer.py:230-234) and stores the per-point
+    ``visibility`` of the last render here (rasterizer.py:639-652); the projection regulariser reads ``visibility`` and
+    ``inmask`` (losses.py:198-212, 337-340)."""
+
+    _NAMES = ("inmask", "activation", "visibility")
+
+    def __init__(self, device="cpu", inmask=None, activation=None, visibility=None, **kwargs):
+        self.device = torch.device(device)
+        on = torch.ones(1, 1, dtype=torch.bool)
+        for name, value in (("inmask", inmask), ("activation", activation), ("visibility", visibility)) + tuple(kwargs.items()):
+            value = on if value is None else torch.as_tensor(value)
+            setattr(self, name, value.to(self.device))
+
+    def _tensors(self):
+        return {k: v for k, v in vars(self).items() if torch.is_tensor(v)}
+
+    def set_filter(self, **kwargs):
+        """Replace / add filters; each should be a 2-D (padded) mask.  The device follows the new tensors."""
+        filters = self._tensors()
+        filters.update(kwargs)
+        for v in filters.values():
+            if torch.is_tensor(v):
+                self.device = v.device
+        self.__init__(device=self.device, **filters)
+
+    def filter(self, point_clouds):
+        return self.filter_with(point_clouds, tuple(self._tensors()))
+
+    def filter_with(self, point_clouds, filter_names):
+        """The clouds reduced to the points for which ALL the named filters are on.  One cloud with N-row filters
+        gives N clouds (the cloud is broadcast), like the reference's convert_to_tensors_and_broadcast."""
+        masks = [getattr(self, k) for k in filter_names if torch.is_tensor(getattr(self, k, None))]
+        masks = [m for m in masks if not (tuple(m.shape) == (1, 1) and bool(m))]   # the default "everything on"
+        if not masks:
+            return point_clouds
+        points, normals, features = point_clouds.points_list(), point_clouds.normals_list(), point_clouds.features_list()
+        n_out = max([len(points)] + [m.shape[0] for m in masks])
+        if any(m.dim() != 2 for m in masks) or any(m.shape[0] not in (1, n_out) for m in masks) or len(points) not in (1, n_out):
+            raise ValueError("filters must be 2-D (N, P_max) masks broadcastable to the %d clouds" % n_out)
+        pick = lambda lst, b: lst[b if len(lst) > 1 else 0]
+        out_p, out_n, out_f = [], [], []
+        for b in range(n_out):
+            pts = pick(points, b)
+            keep = torch.ones(pts.shape[0], dtype=torch.bool, device=pts.device)
+            for m in masks:
+                row = m[b if m.shape[0] > 1 else 0].to(pts.device)
+                if row.shape[0] == 1:
+                    row = row.expand(pts.shape[0])
+                if row.shape[0] < pts.shape[0]:
+                    raise ValueError("filter of %d entries for a cloud of %d points" % (row.shape[0], pts.shape[0]))
+                keep = keep & row[: pts.shape[0]].bool()   # entries at padded positions are ignored
+            out_p.append(pts[keep])
+            if normals is not None:
+                out_n.append(pick(normals, b)[keep])
+            if features is not None:
+                out_f.append(pick(features, b)[keep])
+        return PointClouds3D(out_p, out_n if normals is not None else None, out_f if features is not None else None)

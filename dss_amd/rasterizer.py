@@ -247,8 +247,32 @@ class SurfaceSplatting(torch.nn.Module):
             return point_clouds_filter.filter_with(point_clouds, ("activation",))
         return point_clouds
 
+    @staticmethod
+    def _store_visibility(point_clouds_filter, visible, N, shared, original_clouds):
+        """rasterizer.py:639-652: the per-point visibility of this render goes back into the filter object as a padded
+        (N, P_max) mask over the ORIGINAL clouds -- points the activation filter dropped are never visible."""
+        if point_clouds_filter is None or not hasattr(point_clouds_filter, "set_filter"):
+            return
+        vis = visible.bool()
+        act = getattr(point_clouds_filter, "activation", None)
+        num = original_clouds.num_points_per_cloud()
+        sizes = [p.shape[0] for p in original_clouds.points_list()]
+        p_max = int(max(sizes))
+        dropped = torch.is_tensor(act) and act.dim() == 2 and act.shape[1] > 1
+        if not dropped and min(sizes) == p_max:       # the usual case: nothing to scatter, no host sync
+            point_clouds_filter.set_filter(visibility=vis.view(N, p_max))
+            return
+        # rows = cameras (= rendered clouds); the packed flags are in row-major order of the kept positions
+        keep = (torch.arange(p_max, device=vis.device)[None, :] < num.to(vis.device)[:, None]).expand(N, -1)
+        if dropped:
+            keep = keep & act.to(vis.device).bool()[:, :p_max].expand(N, -1)
+        full = torch.zeros((N, p_max), dtype=torch.bool, device=vis.device)
+        full[keep] = vis
+        point_clouds_filter.set_filter(visibility=full)
+
     def forward(self, point_clouds, point_clouds_filter=None, **kwargs):
         raster_settings = kwargs.get("raster_settings", self.raster_settings)
+        original_clouds = point_clouds
         if not point_clouds.isempty():
             point_clouds = self._apply_activation_filter(point_clouds, point_clouds_filter)
         if point_clouds.isempty():
@@ -274,8 +298,7 @@ class SurfaceSplatting(torch.nn.Module):
         fragments = PointFragments(idx=idx, zbuf=zbuf, qvalue=qvalue_map, scaler=scaler, occupancy=occ_map,
                                    geometry=(pts_screen.detach(), radii, visible, first_idx, num_points))
         self._last_valid = valid
-        if point_clouds_filter is not None and hasattr(point_clouds_filter, "set_filter"):
-            point_clouds_filter.set_filter(visibility=visible.view(N, -1) if shared else visible)
+        self._store_visibility(point_clouds_filter, visible, N, shared, original_clouds)
         if kwargs.get("verbose", False):
             info = {"radii": radii, "ellipse_params": ellipse, "cutoff_threshold": cutoff, "scaler": scaler}
             return fragments, a["out_clouds"], info
@@ -286,6 +309,7 @@ class SurfaceSplatting(torch.nn.Module):
         -> ``(images (N,S,S,C+1), PointFragments, point_clouds)``.  Same values as ``forward`` + the
         renderer's blend; the autograd graph is one node, so gradients flow to the world points and the
         features only (a loss on ``fragments.zbuf`` needs the unfused path)."""
+        original_clouds = point_clouds
         point_clouds = self._apply_activation_filter(point_clouds, point_clouds_filter)
         a = self._prepare(point_clouds, **kwargs)
         st = a["raster_settings"]
@@ -298,8 +322,7 @@ class SurfaceSplatting(torch.nn.Module):
         image, idx, zbuf, qv, occ, scaler, pts_screen, radii, visible = outs
         fragments = PointFragments(idx=idx, zbuf=zbuf, qvalue=qv, scaler=scaler, occupancy=occ,
                                    geometry=(pts_screen, radii, visible, a["first_idx"], a["num_points"]))
-        if point_clouds_filter is not None and hasattr(point_clouds_filter, "set_filter"):
-            point_clouds_filter.set_filter(visibility=visible.view(a["N"], -1) if a["shared"] else visible)
+        self._store_visibility(point_clouds_filter, visible, a["N"], a["shared"], original_clouds)
         return image, fragments, a["out_clouds"]
 
 

@@ -362,3 +362,36 @@ def test_project_backward_fused_clip_equals_clip_then_project():
     assert not torch.equal(g2, g)
     want = ops.project_backward(t(pts), t(M), t(V), first, num, g2, valid, True)
     assert torch.equal(fused, want)
+
+
+def test_filters_object_drops_inactive_points_and_receives_visibility():
+    """`point_clouds_filter` (DSS/core/cloud.py:284-351) through the renderer: inactive points are not rendered
+    (rasterizer.py:230-234) and the per-point visibility comes back as a padded (N, P_max) mask over the ORIGINAL
+    cloud (rasterizer.py:639-652), equal to the visibility of rendering the reduced cloud scattered back."""
+    from dss_amd.cloud import PointCloudsFilters
+    from dss_amd.cameras import FoVPerspectiveCameras, look_at_view_transform
+    from dss_amd.cloud import PointClouds3D
+    from dss_amd.rasterizer import PointsRasterizationSettings, SurfaceSplatting
+    from dss_amd.renderer import NormWeightedCompositor, SurfaceSplattingRenderer
+    pts, nrm = scenes.load_cloud("teapot")
+    pts = scenes.normalize_unit_sphere(pts)
+    P = pts.shape[0]
+    rng = np.random.default_rng(11)
+    act = torch.from_numpy(rng.random(P) < 0.7).to(DEV)
+    R, T = look_at_view_transform(2.0, 25.0, [20.0, 140.0, 260.0])
+    cams = FoVPerspectiveCameras(znear=0.1, R=R, T=T, device=DEV)
+    st = PointsRasterizationSettings(backface_culling=False, image_size=96, points_per_pixel=5, bin_size=None)
+    tp, tn = torch.from_numpy(pts).to(DEV), torch.from_numpy(nrm).to(DEV)
+    col = torch.rand(P, 3, device=DEV)
+    for fused in (False, True):
+        renderer = SurfaceSplattingRenderer(SurfaceSplatting(cameras=cams, raster_settings=st), NormWeightedCompositor(),
+                                            fused=fused)
+        flt = PointCloudsFilters(device=DEV, activation=act[None])
+        img = renderer(PointClouds3D([tp], [tn], [col]), point_clouds_filter=flt)
+        ref_flt = PointCloudsFilters(device=DEV)
+        ref = renderer(PointClouds3D([tp[act]], [tn[act]], [col[act]]), point_clouds_filter=ref_flt)
+        assert torch.equal(img, ref)
+        assert tuple(flt.visibility.shape) == (3, P) and flt.visibility.dtype == torch.bool
+        assert not flt.visibility[:, ~act].any() and flt.visibility.any()
+        assert tuple(ref_flt.visibility.shape) == (3, int(act.sum()))
+        assert torch.equal(flt.visibility[:, act], ref_flt.visibility)

@@ -55,3 +55,39 @@ def test_packed_mask_accepts_padded_per_camera_and_packed_layouts():
     with pytest.raises(ValueError):
         _packed_mask(torch.ones(7, dtype=torch.bool), pc)
     assert _packed_mask(None, pc) is None
+
+
+def test_point_clouds_filters_mirror_the_reference_behaviour():
+    """DSS/core/cloud.py:284-351: default filters keep everything, filter() applies all masks, filter_with() the
+    named ones, padded positions are ignored, one cloud is broadcast over N-row filters, set_filter() replaces."""
+    from dss_amd.cloud import PointCloudsFilters
+    a, b = torch.arange(15.0).reshape(5, 3), torch.arange(9.0).reshape(3, 3) + 100
+    na, nb = a + 0.5, b + 0.5
+    pc = PointClouds3D([a, b], [na, nb])
+    flt = PointCloudsFilters()
+    out = flt.filter(pc)
+    assert [p.shape[0] for p in out.points_list()] == [5, 3]
+    act = torch.tensor([[1, 0, 1, 1, 0], [0, 1, 1, 1, 1]], dtype=torch.bool)    # row 1: entries 3, 4 are padding
+    vis = torch.tensor([[1, 1, 0, 1, 1], [1, 1, 1, 0, 0]], dtype=torch.bool)
+    flt.set_filter(activation=act, visibility=vis)
+    only_act = flt.filter_with(pc, ("activation",))
+    assert torch.equal(only_act.points_list()[0], a[[0, 2, 3]]) and torch.equal(only_act.points_list()[1], b[[1, 2]])
+    assert torch.equal(only_act.normals_list()[1], nb[[1, 2]])
+    both = flt.filter(pc)
+    assert torch.equal(both.points_list()[0], a[[0, 3]]) and torch.equal(both.points_list()[1], b[[1, 2]])
+    # one cloud, per-camera filters: the cloud is broadcast
+    one = PointClouds3D([a], [na])
+    per_cam = PointCloudsFilters(activation=torch.tensor([[1, 1, 0, 0, 0], [0, 0, 0, 1, 1]], dtype=torch.bool))
+    two = per_cam.filter_with(one, ("activation",))
+    assert len(two) == 2 and torch.equal(two.points_list()[0], a[:2]) and torch.equal(two.points_list()[1], a[3:])
+    # set_filter keeps the other masks
+    per_cam.set_filter(visibility=torch.zeros(1, 5, dtype=torch.bool))
+    assert per_cam.activation.shape == (2, 5) and per_cam.filter(one).isempty()
+    with pytest.raises(ValueError):
+        PointCloudsFilters(activation=torch.ones(3, 5, dtype=torch.bool)).filter(pc)
+    # bounding boxes / clone used by the regularisers' host side
+    bb = pc.get_bounding_boxes()
+    assert bb.shape == (2, 3, 2) and torch.equal(bb[0, :, 0], a.min(0).values) and torch.equal(bb[1, :, 1], b.max(0).values)
+    c = pc.clone()
+    c.points_list()[0].add_(1.0)
+    assert torch.equal(pc.points_list()[0], a)
