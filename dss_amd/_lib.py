@@ -55,6 +55,7 @@ SIGNATURES = {
     "dss_projection_loss": (_c_int, [_c_vp] * 7 + [_c_int, _c_i64, _c_int, _c_f32, _c_vp, _c_vp, _c_vp, _c_vp]),
     "dss_repulsion_loss": (_c_int, [_c_vp] * 5 + [_c_int, _c_i64, _c_int, _c_f32, _c_f32, _c_vp, _c_vp, _c_vp, _c_vp, _c_sz,
                                                   _c_vp]),
+    "dss_points_inmask": (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_int, _c_i64, _c_int, _c_int, _c_vp, _c_vp]),
     "dss_image_loss_workspace": (_c_sz, [_c_int, _c_int, _c_int]),
     "dss_image_loss_forward": (_c_int, [_c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_i64, _c_vp, _c_int, _c_int, _c_int, _c_f32,
                                         _c_f32, _c_vp, _c_vp, _c_vp, _c_sz, _c_vp]),

@@ -202,6 +202,47 @@ __global__ __launch_bounds__(256) void repulsion_loss_kernel(const float *__rest
     }
 }
 
+// In-mask filter of the regularisers (DSS/models/point_modeling.py:183-208): a point is "in mask" if, in ANY view, the
+// target mask sampled at its projection is non-zero -- F.grid_sample(mask, -ndc_xy clamped to [-1,1], bilinear,
+// padding_mode='reflection', align_corners=False) (utils/__init__.py:266-317) -- and it is visible.  The reference
+// re-projects all points with pytorch3d (transform_points) and runs grid_sample, any() and & as separate passes over
+// (N, P) tensors; here one thread per point loops over the cameras.  `M` is the full projection matrix of
+// dss_point_setup (row vectors: p_h @ M).  With the sample position inside [-1,1] the reflection is the identity and
+// the unnormalised coordinate is only clipped to [0, size-1]; the bilinear value is non-zero iff a tap with a
+// non-zero weight lies on a non-zero mask pixel.
+__global__ __launch_bounds__(256) void points_inmask_kernel(const float *__restrict__ points, const float *__restrict__ M,
+                                                            const float *__restrict__ mask, const uint8_t *__restrict__ visible,
+                                                            int N, int64_t P, int H, int W, uint8_t *__restrict__ inmask)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    if (visible && !visible[p]) {
+        inmask[p] = 0;
+        return;
+    }
+    const float x = points[3 * p], y = points[3 * p + 1], z = points[3 * p + 2];
+    bool in = false;
+    for (int n = 0; n < N && !in; ++n) {
+        const float *m = M + 16 * n;
+        const float X = ((x * m[0] + y * m[4]) + z * m[8]) + m[12];
+        const float Y = ((x * m[1] + y * m[5]) + z * m[9]) + m[13];
+        const float Wc = ((x * m[3] + y * m[7]) + z * m[11]) + m[15];
+        const float gx = fminf(fmaxf(-(X / Wc), -1.0f), 1.0f), gy = fminf(fmaxf(-(Y / Wc), -1.0f), 1.0f);
+        const float ix = fminf(fmaxf(((gx + 1.0f) * (float)W - 1.0f) / 2.0f, 0.0f), (float)(W - 1));
+        const float iy = fminf(fmaxf(((gy + 1.0f) * (float)H - 1.0f) / 2.0f, 0.0f), (float)(H - 1));
+        if (!(ix == ix && iy == iy)) continue;  // NaN projection (w == 0): never in mask
+        const int x0 = (int)floorf(ix), y0 = (int)floorf(iy);
+        const float fx = ix - (float)x0, fy = iy - (float)y0;  // weight of the +1 taps; 1 - f of the others
+        const float *img = mask + (size_t)n * H * W;
+        float v = img[(size_t)y0 * W + x0] * ((1.0f - fx) * (1.0f - fy));
+        if (x0 + 1 < W) v += img[(size_t)y0 * W + x0 + 1] * (fx * (1.0f - fy));
+        if (y0 + 1 < H) v += img[(size_t)(y0 + 1) * W + x0] * ((1.0f - fx) * fy);
+        if (x0 + 1 < W && y0 + 1 < H) v += img[(size_t)(y0 + 1) * W + x0 + 1] * (fx * fy);
+        in = v != 0.0f;
+    }
+    inmask[p] = in ? 1 : 0;
+}
+
 static int check_common(const char *who, int N, int64_t P, int K, const void *a, const void *b, const void *c, const void *d,
                         const void *e)
 {
@@ -274,4 +315,21 @@ extern "C" int dss_repulsion_loss(const float *points, const float *mollified, c
                        bbox, filter_scale, first_idx, num_pts, N, P, K, 1.0f / (sharpness_sigma * sharpness_sigma), grad_loss,
                        loss, grad_points);
     return check_launch("dss_repulsion_loss");
+}
+
+extern "C" int dss_points_inmask(const float *points, const float *M, const float *mask, const uint8_t *visible, int N,
+                                 int64_t P, int H, int W, uint8_t *inmask, void *stream)
+{
+    if (N <= 0 || P < 0 || H <= 0 || W <= 0) {
+        set_error("dss_points_inmask: bad sizes N=%d P=%lld H=%d W=%d", N, (long long)P, H, W);
+        return DSS_ERR_INVALID_ARGUMENT;
+    }
+    if (P == 0) return DSS_OK;
+    if (!points || !M || !mask || !inmask) {
+        set_error("dss_points_inmask: NULL tensor pointer");
+        return DSS_ERR_INVALID_ARGUMENT;
+    }
+    hipLaunchKernelGGL(points_inmask_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, as_stream(stream), points, M,
+                       mask, visible, N, P, H, W, inmask);
+    return check_launch("dss_points_inmask");
 }

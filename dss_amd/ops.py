@@ -763,3 +763,27 @@ def image_loss_backward(rgba, target_rgb, target_mask, lambda_rgb: float, lambda
                                          _lib.ptr(grad), _lib.stream_ptr(dev))
     _lib.check(rc, "dss_image_loss_backward")
     return grad
+
+
+def points_inmask(points, M, mask_img, visible=None):
+    """In-mask filter of the regularisers (point_modeling.py:183-208): bool (P,) = visible & any over the views of
+    (target mask bilinearly sampled at the point's projection != 0).  ``points`` (P,3) world positions of one cloud,
+    ``M`` (N,4,4) full projection matrices, ``mask_img`` (N,H,W) or (N,1,H,W)."""
+    lib = _lib.load()
+    points = _lib.require_gpu(points, "points", _f32)
+    M = _lib.require_gpu(M, "M", _f32)
+    dev, P, N = points.device, points.shape[0], M.shape[0]
+    if not isinstance(mask_img, torch.Tensor) or not mask_img.is_cuda:
+        raise RuntimeError("dss_amd: mask_img must be a GPU tensor (no CPU fallback)")
+    if mask_img.dim() == 4:
+        mask_img = mask_img[:, 0]
+    if mask_img.dim() != 3 or mask_img.shape[0] != N:
+        raise RuntimeError("dss_amd: mask_img must be (N,H,W) or (N,1,H,W) with N = %d views, got %s" % (N, tuple(mask_img.shape)))
+    mask_img = mask_img.to(_f32).contiguous()
+    visible = _mask_u8(visible, "visible", P, dev)
+    with torch.cuda.device(dev):
+        out = torch.empty((P,), dtype=torch.uint8, device=dev)
+        rc = lib.dss_points_inmask(_lib.ptr(points), _lib.ptr(M), _lib.ptr(mask_img), _lib.ptr(visible), N, P,
+                                   mask_img.shape[1], mask_img.shape[2], _lib.ptr(out), _lib.stream_ptr(dev))
+    _lib.check(rc, "dss_points_inmask")
+    return out.bool()

@@ -385,6 +385,14 @@ DSS_API int dss_repulsion_loss(const float *points, const float *mollified, cons
                                float *loss, float *grad_points, void *workspace, size_t workspace_bytes,
                                void *stream);
 
+/* In-mask filter of the regularisers (DSS/models/point_modeling.py:183-208 with utils/__init__.py:266-317):
+ * inmask[p] = visible[p] && any over the N views of (bilinear grid_sample of the target mask at the point's projection,
+ * position (-ndc_x, -ndc_y) clamped to [-1,1], reflection padding, align_corners=False) != 0.  points (P,3) world
+ * positions of ONE cloud seen by all N cameras, M (N,4,4) full projection matrices (as dss_point_setup), mask (N,H,W)
+ * float, visible (P,) uint8 or NULL (= all), inmask (P,) uint8 out. */
+DSS_API int dss_points_inmask(const float *points, const float *M, const float *mask, const uint8_t *visible,
+                              int N, int64_t P, int H, int W, uint8_t *inmask, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Image loss of the training iteration and its gradient w.r.t. the rendered image: Trainer.calc_dr_loss
  * (DSS/training/trainer.py:332-372) with the loss objects of Trainer.__init__ (:138-141) -- masked L1 on RGB (L1Loss,

@@ -291,3 +291,25 @@ def image_loss(rgba, img, mask, lambda_rgb, lambda_sil, want_grad=True):
     _lib().oracle_image_loss(_p(rgba), _p(img), _p(mask), N, H, W, ctypes.c_float(lambda_rgb), ctypes.c_float(lambda_sil),
                              _p(losses), None if grad is None else _p(grad))
     return losses, grad
+
+
+def grid_sample_points(mask, grid):
+    """F.grid_sample(mask[:, None], grid[:, None], 'bilinear', 'reflection', align_corners=False) restated ->
+    (N,P); mask (N,H,W), grid (N,P,2) in [-1,1] (x, y)."""
+    mask, grid = _f32(mask), _f32(grid)
+    N, H, W = mask.shape
+    P = grid.shape[1]
+    out = np.empty((N, P), np.float32)
+    _lib().oracle_grid_sample_points(_p(mask), _p(grid), N, ctypes.c_int64(P), H, W, _p(out))
+    return out
+
+
+def points_inmask(points, M, mask, visible=None):
+    """In-mask filter of point_modeling.py:183-208 -> uint8 (P,)."""
+    points, M, mask = _f32(points), _f32(M), _f32(mask)
+    N, H, W = mask.shape
+    P = points.shape[0]
+    out = np.empty((P,), np.uint8)
+    vp = _u8_or_null(visible)
+    _lib().oracle_points_inmask(_p(points), _p(M), _p(mask), vp[1], N, ctypes.c_int64(P), H, W, _p(out))
+    return out

@@ -915,3 +915,74 @@ DSS_ORACLE_API void oracle_image_loss(const float *rgba /* (N,H,W,4) */, const f
     free(I);
     free(U);
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * In-mask filter of the regularisers (DSS/models/point_modeling.py:183-208): for every view the target mask is
+ * sampled at the projection of the point with get_tensor_values (DSS/utils/__init__.py:266-317) =
+ * F.grid_sample(mask, p, mode='bilinear', padding_mode='reflection') [align_corners False], p = clamp(-ndc_xy, -1, 1);
+ * inmask = any_n(value != 0) & visibility.  grid_sample is restated from its definition (ATen GridSampler: unnormalise
+ * ((g + 1) size - 1) / 2, reflect about [-0.5, size - 0.5], clip to [0, size - 1], bilinear taps nw/ne/sw/se with
+ * bounds checks); the projection is the row-vector product p_h @ M of pytorch3d's transform_points, in fp32 in the
+ * order the HIP kernel uses (the reference's bmm may round differently: points that project within an ulp of a pixel
+ * boundary can differ, see the pinning test).
+ * ------------------------------------------------------------------------------------------- */
+static float reflect_coord(float in, float twice_low, float twice_high)
+{
+    if (twice_low == twice_high) return 0.0f;
+    const float mn = twice_low / 2, span = (twice_high - twice_low) / 2;
+    in = fabsf(in - mn);
+    const float extra = fmodf(in, span);
+    const int flips = (int)floorf(in / span);
+    return (flips % 2 == 0) ? extra + mn : span - extra + mn;
+}
+
+static float grid_sample_bilinear_reflect(const float *img, int H, int W, float gx, float gy)
+{
+    float ix = ((gx + 1.0f) * (float)W - 1.0f) / 2.0f, iy = ((gy + 1.0f) * (float)H - 1.0f) / 2.0f;
+    ix = reflect_coord(ix, -1.0f, 2.0f * W - 1.0f);
+    iy = reflect_coord(iy, -1.0f, 2.0f * H - 1.0f);
+    ix = fminf((float)(W - 1), fmaxf(ix, 0.0f));
+    iy = fminf((float)(H - 1), fmaxf(iy, 0.0f));
+    const float x_nw = floorf(ix), y_nw = floorf(iy);
+    const float x_se = x_nw + 1, y_se = y_nw + 1;
+    const float nw = (x_se - ix) * (y_se - iy), ne = (ix - x_nw) * (y_se - iy);
+    const float sw = (x_se - ix) * (iy - y_nw), se = (ix - x_nw) * (iy - y_nw);
+    float out = 0.0f;
+    const int x0 = (int)x_nw, y0 = (int)y_nw, x1 = x0 + 1, y1 = y0 + 1;
+#define IN_IMG(yy, xx) ((yy) >= 0 && (yy) < H && (xx) >= 0 && (xx) < W)
+    if (IN_IMG(y0, x0)) out += img[(size_t)y0 * W + x0] * nw;
+    if (IN_IMG(y0, x1)) out += img[(size_t)y0 * W + x1] * ne;
+    if (IN_IMG(y1, x0)) out += img[(size_t)y1 * W + x0] * sw;
+    if (IN_IMG(y1, x1)) out += img[(size_t)y1 * W + x1] * se;
+#undef IN_IMG
+    return out;
+}
+
+DSS_ORACLE_API void oracle_grid_sample_points(const float *mask /* (N,H,W) */, const float *grid /* (N,P,2) */, int N,
+                                              int64_t P, int H, int W, float *out /* (N,P) */)
+{
+    for (int n = 0; n < N; ++n)
+        for (int64_t p = 0; p < P; ++p)
+            out[n * P + p] = grid_sample_bilinear_reflect(mask + (size_t)n * H * W, H, W, grid[(n * P + p) * 2],
+                                                          grid[(n * P + p) * 2 + 1]);
+}
+
+DSS_ORACLE_API void oracle_points_inmask(const float *points /* (P,3) */, const float *M /* (N,4,4) */,
+                                         const float *mask /* (N,H,W) */, const uint8_t *visible /* (P,) or NULL */,
+                                         int N, int64_t P, int H, int W, uint8_t *inmask)
+{
+    for (int64_t p = 0; p < P; ++p) {
+        const float x = points[3 * p], y = points[3 * p + 1], z = points[3 * p + 2];
+        int in = 0;
+        for (int n = 0; n < N && !in; ++n) {
+            const float *m = M + 16 * n;
+            const float X = ((x * m[0] + y * m[4]) + z * m[8]) + m[12];
+            const float Y = ((x * m[1] + y * m[5]) + z * m[9]) + m[13];
+            const float Wc = ((x * m[3] + y * m[7]) + z * m[11]) + m[15];
+            const float gx = fminf(fmaxf(-(X / Wc), -1.0f), 1.0f), gy = fminf(fmaxf(-(Y / Wc), -1.0f), 1.0f);
+            if (!(gx == gx && gy == gy)) continue;
+            in = grid_sample_bilinear_reflect(mask + (size_t)n * H * W, H, W, gx, gy) != 0.0f;
+        }
+        inmask[p] = (uint8_t)(in && (!visible || visible[p]));
+    }
+}

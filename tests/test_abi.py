@@ -77,7 +77,7 @@ def test_hot_kernels_do_not_spill_to_scratch():
         "bin_kernel", "visible_scan_kernel", "median_hist_kernel", "backward_compact_kernel", "median_visible_kernel", "point_setup_kernel", "project_backward_kernel",
         "blend_forward_kernelILi3E", "knn_query_kernelILi8ELb0E", "knn_query_kernelILi8ELb1E",
         "knn_query_kernelILi12ELb1E", "knn_query_kernelILi16ELb1E", "projection_loss_kernel", "repulsion_loss_kernel",
-        "mollify_normals_kernel", "image_loss_reduce_kernel", "image_loss_grad_kernel"]
+        "mollify_normals_kernel", "image_loss_reduce_kernel", "image_loss_grad_kernel", "points_inmask_kernel"]
     seen = {}
     for src in ("raster_forward.hip", "raster_backward.hip", "blend.hip", "setup.hip", "knn.hip", "regularizers.hip", "image_loss.hip"):
         out = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
