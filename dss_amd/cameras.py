@@ -14,7 +14,7 @@ published behaviour, [third party, not under /root/reference]):
 A genuine pytorch3d camera can be passed to ``dss_amd`` instead: only these methods are used.
 """
 import math
-from typing import Optional, Sequence, Union
+from typing import Optional
 
 import torch
 

@@ -3,7 +3,7 @@
 (rasterizer.py:155, 194, 236-240, 275-280, 651; renderer.py:57).  pytorch3d itself is absent here
 [third party]; any object exposing the same accessors can be passed to ``dss_amd`` instead.
 """
-from typing import List, Optional, Sequence, Union
+from typing import List, Optional
 
 import torch
 

@@ -19,7 +19,6 @@ import torch
 import torch.autograd as autograd
 
 from . import ops
-from .cloud import PointClouds3D
 
 __all__ = ["PointFragments", "PointsRasterizationSettings", "SurfaceSplatting", "rasterize_elliptical_points",
            "EllipticalRasterizer", "knn_variance_scale"]

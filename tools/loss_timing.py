@@ -6,7 +6,6 @@ projection loss forward + backward, repulsion loss forward + backward, on one cl
 import json
 import sys
 
-import numpy as np
 import torch
 
 sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))

@@ -1,7 +1,6 @@
 #!/usr/bin/env python3
 """Developer tool: phase timing (100 MHz realtime ticks) inside backward_prep_kernel (GPU box)."""
 import ctypes, os, subprocess, sys
-import numpy as np
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
