@@ -47,9 +47,16 @@ class PointClouds3D:
         lst = getattr(self, "_" + name)
         if lst is None:
             return None
-        if name not in self._packed_cache:
-            self._packed_cache[name] = lst[0] if len(lst) == 1 else torch.cat(lst, dim=0)
-        return self._packed_cache[name]
+        if len(lst) == 1:
+            return lst[0]
+        cached = self._packed_cache.get(name)
+        # a concatenation first built under torch.no_grad() (e.g. for the kNN statistic) is cut off from autograd:
+        # rebuild it when a differentiable one is asked for
+        needs_grad = torch.is_grad_enabled() and any(t.requires_grad for t in lst)
+        if cached is None or (needs_grad and not cached.requires_grad):
+            cached = torch.cat(lst, dim=0)
+            self._packed_cache[name] = cached
+        return cached
 
     def points_list(self):
         return self._points
@@ -154,19 +161,33 @@ class PointCloudsFilters:
             raise ValueError("filters must be 2-D (N, P_max) masks broadcastable to the %d clouds" % n_out)
         pick = lambda lst, b: lst[b if len(lst) > 1 else 0]
         out_p, out_n, out_f = [], [], []
+        keeps, done = {}, {}
+        # Replicated clouds (Pointclouds.extend: the SAME position / normal tensors N times, per-camera colours) are
+        # filtered once per distinct tensor and stay replicated, so the renderer still sees shared geometry.
+
+        def reduced(t, rows, keep):
+            k = (id(t), rows)
+            if k not in done:
+                done[k] = t[keep]
+            return done[k]
+
         for b in range(n_out):
             pts = pick(points, b)
-            keep = torch.ones(pts.shape[0], dtype=torch.bool, device=pts.device)
-            for m in masks:
-                row = m[b if m.shape[0] > 1 else 0].to(pts.device)
-                if row.shape[0] == 1:
-                    row = row.expand(pts.shape[0])
-                if row.shape[0] < pts.shape[0]:
-                    raise ValueError("filter of %d entries for a cloud of %d points" % (row.shape[0], pts.shape[0]))
-                keep = keep & row[: pts.shape[0]].bool()   # entries at padded positions are ignored
-            out_p.append(pts[keep])
+            rows = tuple(b if m.shape[0] > 1 else 0 for m in masks)
+            if (rows, pts.shape[0]) not in keeps:
+                keep = torch.ones(pts.shape[0], dtype=torch.bool, device=pts.device)
+                for m in masks:
+                    row = m[b if m.shape[0] > 1 else 0].to(pts.device)
+                    if row.shape[0] == 1:
+                        row = row.expand(pts.shape[0])
+                    if row.shape[0] < pts.shape[0]:
+                        raise ValueError("filter of %d entries for a cloud of %d points" % (row.shape[0], pts.shape[0]))
+                    keep = keep & row[: pts.shape[0]].bool()   # entries at padded positions are ignored
+                keeps[(rows, pts.shape[0])] = keep
+            keep = keeps[(rows, pts.shape[0])]
+            out_p.append(reduced(pts, rows, keep))
             if normals is not None:
-                out_n.append(pick(normals, b)[keep])
+                out_n.append(reduced(pick(normals, b), rows, keep))
             if features is not None:
-                out_f.append(pick(features, b)[keep])
+                out_f.append(reduced(pick(features, b), rows, keep))
         return PointClouds3D(out_p, out_n if normals is not None else None, out_f if features is not None else None)

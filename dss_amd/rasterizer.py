@@ -19,6 +19,7 @@ import torch
 import torch.autograd as autograd
 
 from . import ops
+from .cloud import PointClouds3D
 
 __all__ = ["PointFragments", "PointsRasterizationSettings", "SurfaceSplatting", "rasterize_elliptical_points",
            "EllipticalRasterizer", "knn_variance_scale"]
@@ -202,13 +203,24 @@ class SurfaceSplatting(torch.nn.Module):
         shared = len(point_clouds) == 1 and N >= 1
         if not shared and len(point_clouds) != N:
             raise ValueError("need 1 or %d point clouds for %d cameras, got %d" % (N, N, len(point_clouds)))
+        # `Pointclouds.extend(N)` (what the texture and the reference renderer hand over) is N references to the SAME
+        # position / normal tensors, only the colours differ per camera: keep one copy of the geometry (shared-cloud
+        # kernels, one kNN instead of N) and the per-camera colours
+        geometry = point_clouds
+        if not shared and N > 1:
+            pl, nl = point_clouds.points_list(), point_clouds.normals_list()
+            if all(t is pl[0] for t in pl) and nl is not None and all(t is nl[0] for t in nl):
+                shared = True
+                geometry = type(point_clouds)([pl[0]], [nl[0]]) if isinstance(point_clouds, PointClouds3D) else None
+                if geometry is None:
+                    shared, geometry = False, point_clouds
         h = kwargs.get("Vrk_h", None)
         if h is None:
-            h = self._variance_scale(point_clouds, raster_settings, kwargs.get("refresh", True))
+            h = self._variance_scale(geometry, raster_settings, kwargs.get("refresh", True))
         vr6 = frame_n = None
         if not raster_settings.Vrk_invariant and not raster_settings.Vrk_isotropic:
-            vr6, frame_n = self._local_frames(point_clouds)
-        world, normals = point_clouds.points_packed(), point_clouds.normals_packed()
+            vr6, frame_n = self._local_frames(geometry)
+        world, normals = geometry.points_packed(), geometry.normals_packed()
         if shared:
             Pc = world.shape[0]
             ranges = self.__dict__.setdefault("_range_cache", {})
@@ -220,7 +232,7 @@ class SurfaceSplatting(torch.nn.Module):
             first_idx, num_points = ranges[(N, Pc, dev)]
             if h.numel() == 1:
                 h = h.reshape(1).expand(N).contiguous()
-            out_clouds = point_clouds.extend(N) if N > 1 else point_clouds
+            out_clouds = point_clouds if len(point_clouds) == N else point_clouds.extend(N)
         else:
             first_idx, num_points = point_clouds.cloud_to_packed_first_idx(), point_clouds.num_points_per_cloud()
             out_clouds = point_clouds

@@ -395,3 +395,33 @@ def test_filters_object_drops_inactive_points_and_receives_visibility():
         assert not flt.visibility[:, ~act].any() and flt.visibility.any()
         assert tuple(ref_flt.visibility.shape) == (3, int(act.sum()))
         assert torch.equal(flt.visibility[:, act], ref_flt.visibility)
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_replicated_clouds_take_the_shared_geometry_path_with_identical_results(fused):
+    """`Pointclouds.extend(N)` = the same position / normal tensors N times with per-camera colours (what the texture
+    hands to the renderer): the geometry is processed once (shared-cloud kernels, one kNN); images and gradients must
+    equal those of N physically separate copies."""
+    from dss_amd.cameras import FoVPerspectiveCameras, look_at_view_transform
+    from dss_amd.cloud import PointClouds3D
+    from dss_amd.rasterizer import PointsRasterizationSettings, SurfaceSplatting
+    from dss_amd.renderer import NormWeightedCompositor, SurfaceSplattingRenderer
+    pts, nrm = scenes.load_cloud("teapot")
+    pts = scenes.normalize_unit_sphere(pts)
+    R, T = look_at_view_transform(2.0, 25.0, [20.0, 140.0, 260.0])
+    cams = FoVPerspectiveCameras(znear=0.1, R=R, T=T, device=DEV)
+    st = PointsRasterizationSettings(backface_culling=False, image_size=96, points_per_pixel=5, bin_size=None,
+                                     radii_backward_scaler=5, clip_pts_grad=0.05)
+    renderer = SurfaceSplattingRenderer(SurfaceSplatting(cameras=cams, raster_settings=st), NormWeightedCompositor(),
+                                        fused=fused)
+    cols = [torch.rand(pts.shape[0], 3, device=DEV) for _ in range(3)]
+    g = torch.randn(3, 96, 96, 4, device=DEV)
+    p1 = torch.from_numpy(pts).to(DEV).requires_grad_(True)
+    n1 = torch.from_numpy(nrm).to(DEV)
+    img1 = renderer(PointClouds3D([p1, p1, p1], [n1, n1, n1], cols))
+    (img1 * g).sum().backward()
+    p2 = torch.from_numpy(pts).to(DEV).requires_grad_(True)
+    img2 = renderer(PointClouds3D([p2 * 1.0, p2 * 1.0, p2 * 1.0], [n1.clone(), n1.clone(), n1.clone()], cols))
+    (img2 * g).sum().backward()
+    assert torch.equal(img1, img2)
+    assert (p1.grad - p2.grad).norm() <= 1e-5 * p2.grad.norm()

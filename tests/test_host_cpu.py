@@ -91,3 +91,20 @@ def test_point_clouds_filters_mirror_the_reference_behaviour():
     c = pc.clone()
     c.points_list()[0].add_(1.0)
     assert torch.equal(pc.points_list()[0], a)
+
+
+def test_packed_tensors_stay_differentiable_after_a_no_grad_access():
+    """The kNN statistic reads points_packed() under no_grad first; the concatenation handed to the differentiable
+    path afterwards must still be connected to the per-cloud tensors (it was cached detached once: multi-cloud inputs
+    silently lost their position gradients)."""
+    p = torch.rand(6, 3, requires_grad=True)
+    pc = PointClouds3D([p * 1.0, p * 2.0], [torch.rand(6, 3), torch.rand(6, 3)])
+    with torch.no_grad():
+        assert not pc.points_packed().requires_grad
+    packed = pc.points_packed()
+    assert packed.requires_grad
+    packed.sum().backward()
+    assert torch.allclose(p.grad, torch.full_like(p, 3.0))
+    assert pc.points_packed() is packed and pc.normals_packed() is pc.normals_packed()      # still cached
+    single = PointClouds3D([p])
+    assert single.points_packed() is p
