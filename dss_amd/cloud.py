@@ -136,6 +136,22 @@ class PointCloudsFilters:
     def _tensors(self):
         return {k: v for k, v in vars(self).items() if torch.is_tensor(v)}
 
+    _all_on_cache = {}
+
+    @classmethod
+    def all_on(cls, mask) -> bool:
+        """True if every entry of ``mask`` is set.  One host synchronisation per (tensor, in-place version): the
+        activation mask of a model changes only when points are pruned, but it is consulted several times per
+        iteration, and an all-on mask lets every consumer skip its boolean indexing (each one a sync of its own)."""
+        hit = cls._all_on_cache.get(id(mask))
+        if hit is not None and hit[0] is mask and hit[1] == mask._version:
+            return hit[2]
+        value = bool(mask.all())
+        if len(cls._all_on_cache) > 64:
+            cls._all_on_cache.clear()
+        cls._all_on_cache[id(mask)] = (mask, mask._version, value)   # keeps the tensor alive: ids are not recycled
+        return value
+
     def set_filter(self, **kwargs):
         """Replace / add filters; each should be a 2-D (padded) mask.  The device follows the new tensors."""
         filters = self._tensors()
@@ -152,10 +168,13 @@ class PointCloudsFilters:
         """The clouds reduced to the points for which ALL the named filters are on.  One cloud with N-row filters
         gives N clouds (the cloud is broadcast), like the reference's convert_to_tensors_and_broadcast."""
         masks = [getattr(self, k) for k in filter_names if torch.is_tensor(getattr(self, k, None))]
-        masks = [m for m in masks if not (tuple(m.shape) == (1, 1) and bool(m))]   # the default "everything on"
-        if not masks:
-            return point_clouds
-        points, normals, features = point_clouds.points_list(), point_clouds.normals_list(), point_clouds.features_list()
+        points = point_clouds.points_list()
+        if all(m.dim() == 2 for m in masks):
+            p_max = max(p.shape[0] for p in points) if points else 0
+            covers = lambda m: m.shape[1] == 1 or m.shape[1] >= p_max
+            if len(points) >= max([1] + [m.shape[0] for m in masks]) and all(covers(m) and self.all_on(m) for m in masks):
+                return point_clouds      # nothing to drop: no indexing, the tensors (and their identities) are kept
+        normals, features = point_clouds.normals_list(), point_clouds.features_list()
         n_out = max([len(points)] + [m.shape[0] for m in masks])
         if any(m.dim() != 2 for m in masks) or any(m.shape[0] not in (1, n_out) for m in masks) or len(points) not in (1, n_out):
             raise ValueError("filters must be 2-D (N, P_max) masks broadcastable to the %d clouds" % n_out)

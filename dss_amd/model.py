@@ -71,7 +71,8 @@ class Model(nn.Module):
         point_clouds = self.get_point_clouds(with_colors=False)
         with torch.no_grad():
             flt = self.points_filter
-            flt.visibility = flt.visibility[flt.activation].unsqueeze(0)
+            if not flt.all_on(flt.activation):       # (1, P) -> (1, P_active); nothing to do when every point is active
+                flt.visibility = flt.visibility[flt.activation].unsqueeze(0)
             if mask_img is not None:
                 M = self.cameras.get_full_projection_transform().get_matrix().to(self.points.device, torch.float32)
                 inmask = ops.points_inmask(point_clouds.points_packed().detach(), M.contiguous(), mask_img,

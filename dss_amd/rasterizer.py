@@ -269,7 +269,8 @@ class SurfaceSplatting(torch.nn.Module):
         num = original_clouds.num_points_per_cloud()
         sizes = [p.shape[0] for p in original_clouds.points_list()]
         p_max = int(max(sizes))
-        dropped = torch.is_tensor(act) and act.dim() == 2 and act.shape[1] > 1
+        dropped = (torch.is_tensor(act) and act.dim() == 2 and act.shape[1] > 1
+                   and not (hasattr(point_clouds_filter, "all_on") and point_clouds_filter.all_on(act)))
         if not dropped and min(sizes) == p_max:       # the usual case: nothing to scatter, no host sync
             point_clouds_filter.set_filter(visibility=vis.view(N, p_max))
             return
