@@ -108,3 +108,33 @@ def test_packed_tensors_stay_differentiable_after_a_no_grad_access():
     assert pc.points_packed() is packed and pc.normals_packed() is pc.normals_packed()      # still cached
     single = PointClouds3D([p])
     assert single.points_packed() is p
+
+
+def test_yaml_seam_builds_our_classes_like_create_renderer():
+    """config.py:241-261 (`create_renderer`): dotted class paths from the YAML, the settings class looked up as
+    `<module of raster_type>.PointsRasterizationSettings`, constructor calls `RasterSetting(**raster_params)`,
+    `Raster(cameras=FoVPerspectiveCameras(), raster_settings=...)`, `Renderer(rasterizer=..., compositor=...)` -- with
+    the raster_params of configs/default.yaml:20-30 merged with configs/dss.yml:14-22."""
+    import importlib
+
+    def get_class_from_string(path):          # DSS/utils/__init__.py:68-73
+        module, name = path.rsplit(".", 1)
+        return getattr(importlib.import_module(module), name)
+
+    opt = dict(renderer_type="dss_amd.renderer.SurfaceSplattingRenderer", raster_type="dss_amd.rasterizer.SurfaceSplatting",
+               compositor_type="dss_amd.renderer.NormWeightedCompositor",
+               raster_params=dict(backface_culling=False, Vrk_isotropic=False, bin_size=None, clip_pts_grad=0.05,
+                                  cutoff_threshold=1.0, depth_merging_threshold=0.05, image_size=512,
+                                  max_points_per_bin=None, points_per_pixel=5, radii_backward_scaler=5, Vrk_invariant=True))
+    Renderer, Raster = get_class_from_string(opt["renderer_type"]), get_class_from_string(opt["raster_type"])
+    RasterSetting = get_class_from_string(opt["raster_type"].rsplit(".", 1)[0] + ".PointsRasterizationSettings")
+    settings = RasterSetting(**opt["raster_params"])
+    renderer = Renderer(rasterizer=Raster(cameras=FoVPerspectiveCameras(), raster_settings=settings),
+                        compositor=get_class_from_string(opt["compositor_type"])())
+    assert renderer.rasterizer.raster_settings is settings and settings.radii_backward_scaler == 5
+    assert settings.Vrk_invariant and settings.image_size == 512 and settings.points_per_pixel == 5
+    # the scheduler mutates the settings object in place (scheduler.py:36-48): the next render reads the new value
+    renderer.rasterizer.raster_settings.radii_backward_scaler = 2.5
+    assert renderer.rasterizer.raster_settings.radii_backward_scaler == 2.5
+    none = Renderer(rasterizer=Raster(cameras=FoVPerspectiveCameras(), raster_settings=settings), compositor=None)
+    assert none.compositor is None
