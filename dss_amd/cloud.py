@@ -18,14 +18,30 @@ def _to_list(x) -> Optional[List[torch.Tensor]]:
     return list(x)
 
 
+_RANGES = {}
+
+
+def _cloud_ranges(sizes, device):
+    """(num_points_per_cloud, cloud_to_packed_first_idx) int64 tensors for a tuple of cloud sizes.  A training loop
+    builds several containers per iteration with the same sizes: the two tiny tensors (a host-to-device copy each
+    time) are made once per (sizes, device) and shared -- they are never written to."""
+    key = (sizes, str(device))
+    hit = _RANGES.get(key)
+    if hit is None:
+        if len(_RANGES) > 256:
+            _RANGES.clear()
+        num = torch.tensor(list(sizes), dtype=torch.int64, device=device)
+        hit = _RANGES[key] = (num, torch.cumsum(num, 0) - num)
+    return hit
+
+
 class PointClouds3D:
     def __init__(self, points, normals=None, features=None):
         self._points = _to_list(points)
         self._normals = _to_list(normals)
         self._features = _to_list(features)
         self.device = self._points[0].device if self._points else torch.device("cpu")
-        self._num = torch.tensor([p.shape[0] for p in self._points], dtype=torch.int64, device=self.device)
-        self._first = torch.cumsum(self._num, 0) - self._num
+        self._num, self._first = _cloud_ranges(tuple(p.shape[0] for p in self._points), self.device)
         self._packed_cache = {}
 
     def __len__(self):

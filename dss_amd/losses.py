@@ -35,8 +35,8 @@ def _packed_mask(mask, point_clouds) -> Optional[torch.Tensor]:
     camera of a shared cloud) is OR-ed over the rows like losses.py:203-206."""
     if mask is None:
         return None
-    num = point_clouds.num_points_per_cloud()
-    P = int(num.sum())
+    sizes = [p.shape[0] for p in point_clouds.points_list()]   # host-side sizes: no device synchronisation
+    P = sum(sizes)
     if mask.dim() == 1:
         if mask.numel() != P:
             raise ValueError("Incompatible point clouds ({} points) and mask {}".format(P, tuple(mask.shape)))
@@ -46,7 +46,9 @@ def _packed_mask(mask, point_clouds) -> Optional[torch.Tensor]:
             mask = mask.any(dim=0, keepdim=True)
         else:
             raise ValueError("Incompatible point clouds {} and mask {}".format(len(point_clouds), tuple(mask.shape)))
-    return torch.cat([mask[b, : int(n)] for b, n in enumerate(num.tolist())]).bool()
+    if len(sizes) == 1:
+        return mask[0, : sizes[0]].bool()
+    return torch.cat([mask[b, :n] for b, n in enumerate(sizes)]).bool()
 
 
 class _Projection(autograd.Function):

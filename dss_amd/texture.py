@@ -129,6 +129,6 @@ class LightingTexture(torch.nn.Module):
         cam = cameras.get_camera_center().to(dev, torch.float32).reshape(-1, 3).expand(N, 3).contiguous()
         shaded = _Phong.apply(world, normals, points_rgb.contiguous(), first, num, amb, kd, ks, vec, cam,
                               isinstance(lights, PointLights), float(shininess), shared)
-        lens = out_clouds.num_points_per_cloud().tolist()
+        lens = [p.shape[0] for p in out_clouds.points_list()]   # host-side sizes: no device synchronisation
         colored = PointClouds3D(out_clouds.points_list(), out_clouds.normals_list(), list(shaded.split(lens, 0)))
         return colored
