@@ -514,6 +514,7 @@ extern "C" int dss_knn_kth_sqdist(const float *points, const int64_t *first_idx,
 extern "C" int dss_knn_points(const float *points, const int64_t *first_idx, const int64_t *num_pts, int N, int64_t P,
                               int K, float *dists, int64_t *idx, void *workspace, size_t workspace_bytes, void *stream)
 {
+    if (P == 0 && N > 0 && K >= 1 && K <= KNN_FULL_MAX_K) return DSS_OK;  // empty input: nothing to write
     if (!dists) {
         set_error("dss_knn_points: NULL tensor pointer");
         return DSS_ERR_INVALID_ARGUMENT;

@@ -73,3 +73,17 @@ def test_bad_arguments_fail_loudly():
     _, sums = ops.image_loss_forward(rgba, img, mask, 1.0, 1.0)
     with pytest.raises(RuntimeError, match="sums"):
         ops.image_loss_backward(rgba, img, mask, 1.0, 1.0, sums[:1])
+
+
+def test_degenerate_images():
+    """All-empty prediction and target (union = 0: IoU term 1 - 0/eps = 1, no rgb term) and a single pixel."""
+    for N, H, W in ((2, 16, 16), (1, 1, 1)):
+        rgba = torch.rand(N, H, W, 4, device=DEV)
+        rgba[..., 3] = 0
+        img = torch.rand(N, H, W, 3, device=DEV)
+        mask = torch.zeros(N, H, W, device=DEV)
+        losses, sums = ops.image_loss_forward(rgba, img, mask, 1.0, 1.0)
+        grad = ops.image_loss_backward(rgba, img, mask, 1.0, 1.0, sums)
+        lo, go = oracle.image_loss(rgba.cpu().numpy(), img.cpu().numpy(), mask.cpu().numpy(), 1.0, 1.0)
+        assert np.allclose(losses.cpu().numpy(), lo, rtol=1e-6) and abs(lo[0] - 0.01) < 1e-7 and lo[1] == 0
+        assert np.allclose(grad.cpu().numpy(), go, rtol=1e-5, atol=1e-12) and torch.isfinite(grad).all()

@@ -191,3 +191,33 @@ def test_bad_arguments_fail_loudly():
         ops.projection_loss(P, P, dists, idx, None, F, L, 0.0)
     with pytest.raises(RuntimeError, match="GPU tensors"):
         ops.projection_loss(P.cpu(), P, dists, idx, None, F, L, 0.75)
+
+
+def test_empty_and_tiny_clouds():
+    """P = 0 is a no-op; a cloud with fewer points than knn_k gets pytorch3d-style zero-padded lists (idx 0, distance 0)
+    and the kernels still agree with the oracle entry by entry (NaN where the reference formula gives 0/0)."""
+    F = torch.zeros(1, dtype=torch.int64, device=DEV)
+    L0 = torch.zeros(1, dtype=torch.int64, device=DEV)
+    empty = torch.zeros(0, 3, device=DEV)
+    d0, i0 = ops.knn_points(empty, F, L0, 12)
+    assert tuple(d0.shape) == (0, 12) and tuple(i0.shape) == (0, 12)
+    assert tuple(ops.mollify_normals(empty, d0, i0, None, F, L0).shape) == (0, 3)
+    l0, g0 = ops.projection_loss(empty, empty, d0, i0, None, F, L0, 0.75, want_grad=True)
+    assert tuple(l0.shape) == (0,) and tuple(g0.shape) == (0, 3)
+    l0, g0 = ops.repulsion_loss(empty, empty, i0, F, L0, 0.75, 2.0, want_grad=True)
+    assert tuple(l0.shape) == (0, 3) and tuple(g0.shape) == (0, 3)
+
+    rng = np.random.default_rng(8)
+    pts = rng.normal(0, 1, (5, 3)).astype(np.float32)
+    nrm = rng.normal(0, 1, (5, 3)).astype(np.float32)
+    L = torch.full((1,), 5, dtype=torch.int64, device=DEV)
+    dists, idx = ops.knn_points(_t(pts), F, L, 12)
+    d_np, i_np = dists.cpu().numpy(), idx.cpu().numpy()
+    assert (d_np[:, 5:] == 0).all() and (i_np[:, 5:] == 0).all() and (i_np[:, 0] == np.arange(5)).all()
+    first_of = np.zeros(5, np.int64)
+    moll = ops.mollify_normals(_t(nrm), dists, idx, None, F, L).cpu().numpy()
+    assert np.allclose(moll, oracle.mollify_normals(nrm, d_np, i_np, None, first_of), rtol=1e-4, atol=1e-6, equal_nan=True)
+    loss, grad = ops.projection_loss(_t(pts), _t(nrm), dists, idx, None, F, L, 0.75, want_grad=True)
+    lo, go = oracle.projection_loss(pts, nrm, d_np, i_np, None, first_of, 0.75)
+    assert np.allclose(loss.cpu().numpy(), lo, rtol=1e-3, atol=1e-7, equal_nan=True)
+    assert np.allclose(grad.cpu().numpy(), go, rtol=1e-3, atol=1e-6, equal_nan=True)
