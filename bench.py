@@ -245,7 +245,9 @@ def main():
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        # capture on the stream the warm-up ran on: the zero-initialised forward workspace is cached per stream, and
+        # a first use on a fresh capture stream would record its one-off torch.zeros fill (5.5 us) into every replay
+        with torch.cuda.graph(g, stream=side):
             wl.step()
         return g
 
