@@ -103,6 +103,9 @@ class FoVPerspectiveCameras:
 
     def to(self, device):
         device = torch.device(device)
+        if all(getattr(self, k).device == device or (device.index is None and getattr(self, k).device.type == device.type)
+               for k in self._STATE):
+            return self  # already there: keep the object (and its matrix cache)
         other = FoVPerspectiveCameras.__new__(FoVPerspectiveCameras)
         other.__dict__.update(self.__dict__)
         other.__dict__.pop("_matrix_cache", None)

@@ -42,6 +42,10 @@ class _Lights:
                 raise ValueError("%s must be an (N,L,3) tensor" % prop)
 
     def to(self, device):
+        device = torch.device(device)
+        if all(getattr(self, k).device == device or (device.index is None and getattr(self, k).device.type == device.type)
+               for k in ("ambient_color", "diffuse_color", "specular_color", self._vec)):
+            return self
         out = object.__new__(type(self))
         out.device = torch.device(device)
         for k in ("ambient_color", "diffuse_color", "specular_color", self._vec):
@@ -49,7 +53,11 @@ class _Lights:
         return out
 
     def clone(self):
-        return self.to(self.device)
+        out = object.__new__(type(self))
+        out.device = self.device
+        for k in ("ambient_color", "diffuse_color", "specular_color", self._vec):
+            setattr(out, k, getattr(self, k).clone())
+        return out
 
     def _packed(self, N):
         """-> ambient (N,3) summed over lights (texture.py:50-54), kd, ks, vec (N,L,3)."""
