@@ -13,7 +13,7 @@ from typing import Optional
 import torch
 from torch import autograd
 
-from . import ops
+from . import neighbours, ops
 
 
 class _Neighbourhood:
@@ -23,7 +23,8 @@ class _Neighbourhood:
         self.first = point_clouds.cloud_to_packed_first_idx()
         self.num = point_clouds.num_points_per_cloud()
         self.K = int(K)
-        self.dists, self.idx = ops.knn_points(point_clouds.points_packed().detach(), self.first, self.num, self.K)
+        self.dists, self.idx = neighbours.self_knn(point_clouds.points_packed(), self.first, self.num,
+                                                   [p.shape[0] for p in point_clouds.points_list()], self.K)
 
     def matches(self, point_clouds) -> bool:
         num = point_clouds.num_points_per_cloud()
@@ -92,6 +93,7 @@ class SurfaceLoss(torch.nn.Module):
         self.channel_dim = None
         self.knn_tree = None
         self.knn_k = knn_k
+        neighbours.request_lists(knn_k)   # the renderer's kNN for `h` will now produce lists this loss can reuse
         self.filter_scale = filter_scale
         self.sharpness_sigma = sharpness_sigma
 

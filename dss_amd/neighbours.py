@@ -1,0 +1,59 @@
+"""One neighbour search per iteration.
+
+`SurfaceSplatting` needs the 7th-nearest squared distance of every point for the variance scale `h`
+(rasterizer.py:310-326) and the regularisers need the kNN-12 lists of the SAME points a moment later
+(losses.py:157-180, trainer.py:319-326 with rebuild_knn=True).  The reference runs two searches (FRNN, then pytorch3d).
+Here a regulariser announces its `knn_k` when it is constructed (`request_lists`); from then on the renderer asks for
+full lists of that size, and whoever comes second is served from the cache -- keyed on the points' storage, shape,
+strides and in-place version counter (the optimiser step bumps it), with the keyed tensor kept alive so that its
+address cannot be recycled by a different tensor.  Results are identical to separate searches: the K-th distance is
+column K-1 of the (distance, id)-sorted lists.
+"""
+import torch
+
+from . import ops
+
+_requested_k = 0
+_last = None  # (key, points_ref, K, dists, idx)
+
+
+def request_lists(k: int) -> None:
+    """Called by a consumer of full neighbour lists: searches for the variance scale will produce (and cache) lists of
+    at least this many entries."""
+    global _requested_k
+    _requested_k = max(_requested_k, int(k))
+
+
+def requested_k() -> int:
+    return _requested_k
+
+
+def _key(points, sizes):
+    return (points.data_ptr(), tuple(points.shape), tuple(points.stride()), points._version, str(points.device), tuple(sizes))
+
+
+def self_knn(points, first, num, sizes, K: int):
+    """(dists (P,K), idx (P,K)) of ``ops.knn_points`` for packed ``points`` (detached), served from the last search of
+    the same, unmodified points when it produced at least K entries."""
+    global _last
+    points = points.detach()
+    key = _key(points, sizes)
+    if _last is not None and _last[0] == key and _last[2] >= K:
+        dists, idx = _last[3], _last[4]
+        if _last[2] == K:
+            return dists, idx
+        return dists[:, :K].contiguous(), idx[:, :K].contiguous()
+    dists, idx = ops.knn_points(points, first, num, int(K))
+    _last = (key, points, int(K), dists, idx)
+    return dists, idx
+
+
+def kth_sqdist(points, first, num, sizes, K: int):
+    """``ops.knn_kth_sqdist`` (K-th smallest squared distance, self included), through the shared lists when a
+    consumer asked for them and every cloud has at least that many points (short clouds differ: farthest point vs
+    zero padding), else by the dedicated kernel."""
+    want = max(int(K), _requested_k)
+    if _requested_k > 0 and sizes and min(sizes) >= want:
+        dists, _ = self_knn(points, first, num, sizes, want)
+        return dists[:, K - 1].contiguous()
+    return ops.knn_kth_sqdist(points.detach(), first, num, int(K))

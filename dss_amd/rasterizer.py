@@ -18,7 +18,7 @@ from typing import NamedTuple, Optional
 import torch
 import torch.autograd as autograd
 
-from . import ops
+from . import neighbours, ops
 from .cloud import PointClouds3D
 
 __all__ = ["PointFragments", "PointsRasterizationSettings", "SurfaceSplatting", "rasterize_elliptical_points",
@@ -160,7 +160,9 @@ class SurfaceSplatting(torch.nn.Module):
             return self._Vrk_h
         first, num = point_clouds.cloud_to_packed_first_idx(), point_clouds.num_points_per_cloud()
         with torch.no_grad():
-            d = ops.knn_kth_sqdist(point_clouds.points_packed().detach(), first, num, 7)
+            # through dss_amd.neighbours: one search serves this statistic and the regularisers of the same iteration
+            d = neighbours.kth_sqdist(point_clouds.points_packed(), first, num,
+                                      [p.shape[0] for p in point_clouds.points_list()], 7)
         if raster_settings.Vrk_invariant:
             # one scalar per cloud: mean_i(0.5 max kNN-7 d^2) clamped to [5e-5, 1e-3]; clouds with fewer than
             # 7 points use sq_dist = 1e-3 (rasterizer.py:320-326)

@@ -221,3 +221,48 @@ def test_empty_and_tiny_clouds():
     lo, go = oracle.projection_loss(pts, nrm, d_np, i_np, None, first_of, 0.75)
     assert np.allclose(loss.cpu().numpy(), lo, rtol=1e-3, atol=1e-7, equal_nan=True)
     assert np.allclose(grad.cpu().numpy(), go, rtol=1e-3, atol=1e-6, equal_nan=True)
+
+
+def test_renderer_and_regulariser_share_one_neighbour_search(monkeypatch):
+    """dss_amd.neighbours: once a regulariser exists, the renderer's kNN for the variance scale produces full lists and
+    the regulariser of the same iteration reuses them; an in-place update of the points invalidates the cache; the
+    variance scale is bit-identical to the dedicated K-th-distance kernel."""
+    from dss_amd import neighbours
+    from dss_amd.rasterizer import PointsRasterizationSettings, SurfaceSplatting
+    monkeypatch.setattr(neighbours, "_requested_k", 0)
+    monkeypatch.setattr(neighbours, "_last", None)
+    calls = {"lists": 0, "kth": 0}
+    real_lists, real_kth = ops.knn_points, ops.knn_kth_sqdist
+
+    def counting_lists(*a, **k):
+        calls["lists"] += 1
+        return real_lists(*a, **k)
+
+    def counting_kth(*a, **k):
+        calls["kth"] += 1
+        return real_kth(*a, **k)
+
+    monkeypatch.setattr(ops, "knn_points", counting_lists)
+    monkeypatch.setattr(ops, "knn_kth_sqdist", counting_kth)
+    pts, nrm = scenes.load_cloud("teapot")
+    P = torch.nn.Parameter(_t(scenes.normalize_unit_sphere(pts))[None])          # (1,P,3) like Model.points
+    normals = _t(nrm)[None]
+    st = PointsRasterizationSettings(Vrk_invariant=True, image_size=64)
+    raster = SurfaceSplatting(raster_settings=st)
+    h_dedicated = raster._variance_scale(PointClouds3D(P, normals), st).clone()
+    assert calls == {"lists": 0, "kth": 1}
+    proj = ProjectionLoss(reduction="mean", filter_scale=2.0, knn_k=12)          # announces knn_k = 12
+    assert neighbours.requested_k() == 12
+    h_shared = raster._variance_scale(PointClouds3D(P, normals), st)
+    assert calls == {"lists": 1, "kth": 1} and torch.equal(h_shared, h_dedicated)
+    loss = proj(PointClouds3D(P, normals), rebuild_knn=True)                     # a different container, same points
+    assert calls == {"lists": 1, "kth": 1}
+    loss.backward()
+    with torch.no_grad():
+        P.add_(0.01 * torch.randn_like(P))                                       # the optimiser step
+    proj(PointClouds3D(P, normals), rebuild_knn=True)
+    assert calls == {"lists": 2, "kth": 1}
+    rep = RepulsionLoss(reduction="mean", knn_k=8)                               # fewer neighbours: a slice of the lists
+    rep(PointClouds3D(P, normals), rebuild_knn=True)
+    assert calls == {"lists": 2, "kth": 1} and rep.knn_tree.idx.shape[1] == 8
+    assert torch.equal(rep.knn_tree.idx, proj.knn_tree.idx[:, :8])
