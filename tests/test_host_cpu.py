@@ -138,3 +138,49 @@ def test_yaml_seam_builds_our_classes_like_create_renderer():
     assert renderer.rasterizer.raster_settings.radii_backward_scaler == 2.5
     none = Renderer(rasterizer=Raster(cameras=FoVPerspectiveCameras(), raster_settings=settings), compositor=None)
     assert none.compositor is None
+
+
+def test_neighbour_cache_logic_with_a_cpu_stand_in(monkeypatch):
+    """dss_amd.neighbours with the two HIP searches replaced by brute-force CPU stand-ins: hits for views of the same
+    storage, misses after an in-place update or for a different tensor, slices for smaller K, the K-th distance served
+    from the lists only once a consumer asked for lists and only when every cloud is large enough."""
+    from dss_amd import neighbours, ops
+    calls = {"lists": 0, "kth": 0}
+
+    def brute(points, K):
+        d = torch.cdist(points.double(), points.double()).pow(2).float()
+        return d.topk(K, dim=1, largest=False)
+
+    def lists(points, first, num, K, **kw):
+        calls["lists"] += 1
+        return brute(points, K)
+
+    def kth(points, first, num, K):
+        calls["kth"] += 1
+        return brute(points, K)[0][:, K - 1].contiguous()
+
+    monkeypatch.setattr(ops, "knn_points", lists)
+    monkeypatch.setattr(ops, "knn_kth_sqdist", kth)
+    monkeypatch.setattr(neighbours, "_requested_k", 0)
+    monkeypatch.setattr(neighbours, "_last", None)
+    base = torch.rand(1, 40, 3)
+    first, num, sizes = torch.zeros(1, dtype=torch.int64), torch.tensor([40]), [40]
+    a = neighbours.kth_sqdist(base[0], first, num, sizes, 7)
+    assert calls == {"lists": 0, "kth": 1}                # no consumer of lists yet: dedicated kernel
+    neighbours.request_lists(12)
+    b = neighbours.kth_sqdist(base[0], first, num, sizes, 7)
+    assert calls["lists"] == 1 and torch.equal(a, b)
+    d12, i12 = neighbours.self_knn(base[0], first, num, sizes, 12)      # another view of the same storage: hit
+    d8, i8 = neighbours.self_knn(base.view(40, 3), first, num, sizes, 8)
+    assert calls["lists"] == 1 and torch.equal(d8, d12[:, :8]) and torch.equal(i8, i12[:, :8])
+    neighbours.self_knn(base[0], first, num, sizes, 16)                  # more neighbours than cached: new search
+    assert calls["lists"] == 2
+    base.add_(0.1)                                                       # in-place update: version counter
+    neighbours.self_knn(base[0], first, num, sizes, 12)
+    assert calls["lists"] == 3
+    neighbours.self_knn(base[0].clone(), first, num, sizes, 12)          # different storage
+    assert calls["lists"] == 4
+    # a cloud with fewer points than the lists would hold: the dedicated kernel (different padding rule)
+    small = torch.rand(9, 3)
+    neighbours.kth_sqdist(small, first, torch.tensor([9]), [9], 7)
+    assert calls["lists"] == 4 and calls["kth"] == 2
