@@ -35,6 +35,13 @@ def _cloud_ranges(sizes, device):
     return hit
 
 
+def shared_cloud_ranges(n_views: int, points_per_cloud: int, device):
+    """(first_idx, num_points) of one cloud of ``points_per_cloud`` points seen by ``n_views`` cameras (the packed
+    layout of Pointclouds.extend), cached like `_cloud_ranges`."""
+    num, first = _cloud_ranges((int(points_per_cloud),) * int(n_views), device)
+    return first, num
+
+
 class PointClouds3D:
     def __init__(self, points, normals=None, features=None):
         self._points = _to_list(points)

@@ -624,6 +624,8 @@ def _mask_u8(mask, name, P, dev):
     mask = _lib.require_gpu(mask, name)
     if mask.numel() != P:
         raise RuntimeError("dss_amd: %s must have one entry per packed point (%d), got %d" % (name, P, mask.numel()))
+    if mask.dtype == torch.bool:
+        return mask.contiguous().view(torch.uint8)   # same bytes: no conversion kernel
     return mask.to(torch.uint8).contiguous()
 
 
@@ -786,4 +788,4 @@ def points_inmask(points, M, mask_img, visible=None):
         rc = lib.dss_points_inmask(_lib.ptr(points), _lib.ptr(M), _lib.ptr(mask_img), _lib.ptr(visible), N, P,
                                    mask_img.shape[1], mask_img.shape[2], _lib.ptr(out), _lib.stream_ptr(dev))
     _lib.check(rc, "dss_points_inmask")
-    return out.bool()
+    return out.view(torch.bool)   # the kernel writes 0 / 1

@@ -19,7 +19,7 @@ import torch
 import torch.autograd as autograd
 
 from . import neighbours, ops
-from .cloud import PointClouds3D
+from .cloud import PointClouds3D, shared_cloud_ranges
 
 __all__ = ["PointFragments", "PointsRasterizationSettings", "SurfaceSplatting", "rasterize_elliptical_points",
            "EllipticalRasterizer", "knn_variance_scale"]
@@ -225,13 +225,7 @@ class SurfaceSplatting(torch.nn.Module):
         world, normals = geometry.points_packed(), geometry.normals_packed()
         if shared:
             Pc = world.shape[0]
-            ranges = self.__dict__.setdefault("_range_cache", {})
-            if (N, Pc, dev) not in ranges:  # constant across iterations: two tiny launches saved per call
-                if len(ranges) > 8:
-                    ranges.clear()
-                ranges[(N, Pc, dev)] = (torch.arange(N, device=dev, dtype=torch.int64) * Pc,
-                                        torch.full((N,), Pc, device=dev, dtype=torch.int64))
-            first_idx, num_points = ranges[(N, Pc, dev)]
+            first_idx, num_points = shared_cloud_ranges(N, Pc, dev)  # cached: constant across iterations
             if h.numel() == 1:
                 h = h.reshape(1).expand(N).contiguous()
             out_clouds = point_clouds if len(point_clouds) == N else point_clouds.extend(N)
@@ -266,7 +260,7 @@ class SurfaceSplatting(torch.nn.Module):
         (N, P_max) mask over the ORIGINAL clouds -- points the activation filter dropped are never visible."""
         if point_clouds_filter is None or not hasattr(point_clouds_filter, "set_filter"):
             return
-        vis = visible.bool()
+        vis = visible.view(torch.bool) if visible.dtype == torch.uint8 else visible.bool()   # 0 / 1 flags: no copy
         act = getattr(point_clouds_filter, "activation", None)
         num = original_clouds.num_points_per_cloud()
         sizes = [p.shape[0] for p in original_clouds.points_list()]

@@ -10,7 +10,7 @@ import torch
 import torch.autograd as autograd
 
 from . import ops
-from .cloud import PointClouds3D
+from .cloud import PointClouds3D, shared_cloud_ranges
 
 __all__ = ["LightingTexture", "PointLights", "DirectionalLights"]
 
@@ -128,9 +128,7 @@ class LightingTexture(torch.nn.Module):
         if points_rgb.shape[-1] != 3:
             raise ValueError("Expected points_rgb to be 3-channel, got %r" % (tuple(points_rgb.shape),))
         if shared:
-            Pc = world.shape[0]
-            first = torch.arange(N, device=dev, dtype=torch.int64) * Pc
-            num = torch.full((N,), Pc, device=dev, dtype=torch.int64)
+            first, num = shared_cloud_ranges(N, world.shape[0], dev)
         else:
             first, num = pointclouds.cloud_to_packed_first_idx(), pointclouds.num_points_per_cloud()
         amb, kd, ks, vec = lights._packed(N)

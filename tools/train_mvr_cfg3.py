@@ -97,8 +97,7 @@ def main():
         cams, lights, img, mask_img = batches[it % len(batches)]
         opt.zero_grad()
         out = model(mask_img=mask_img, cameras=cams, lights=lights)
-        rgba = torch.cat([out["img_pred"], out["mask_img_pred"]], dim=-1)
-        loss = calc_dr_loss(rgba, img.permute(0, 2, 3, 1), mask_img, 1.0, 1.0)["loss"]
+        loss = calc_dr_loss(out["rgba_pred"], img.permute(0, 2, 3, 1), mask_img, 1.0, 1.0)["loss"]
         loss = loss + 0.01 * proj(out["iso_pcl"], rebuild_knn=True, points_filter=model.points_filter)
         loss.backward()
         opt.step()
