@@ -57,6 +57,31 @@ def test_knn_large_cloud_and_global_h():
     assert h == h2  # deterministic
 
 
+def test_knn_at_the_grid_resolution_cap():
+    """500k points per cloud: the per-cloud grid hits its resolution cap (128^3 cells, 2048 scan blocks) and two
+    clouds of different sizes share the cell arrays with the stride of the larger one.  K-th distances and full lists
+    against the KD-tree on a sample of the queries."""
+    from scipy.spatial import cKDTree
+    a, _, _ = scenes.synthetic_cloud(500_000, seed=5)
+    b, _, _ = scenes.synthetic_cloud(30_000, seed=6)
+    pts = np.concatenate([a, b * 0.5 + 0.2]).astype(np.float32)
+    first = torch.tensor([0, len(a)], dtype=torch.int64, device=DEV)
+    num = torch.tensor([len(a), len(b)], dtype=torch.int64, device=DEV)
+    t = torch.from_numpy(pts).to(DEV)
+    kth = ops.knn_kth_sqdist(t, first, num, 7).cpu().numpy()
+    dists, idx = ops.knn_points(t, first, num, 12)
+    dists, idx = dists.cpu().numpy(), idx.cpu().numpy()
+    rng = np.random.default_rng(0)
+    for f, n in ((0, len(a)), (len(a), len(b))):
+        cloud = pts[f: f + n].astype(np.float64)
+        sel = rng.choice(n, 5000, replace=False)
+        d_ref, i_ref = cKDTree(cloud).query(cloud[sel], k=12)
+        assert np.allclose(kth[f + sel], d_ref[:, 6] ** 2, rtol=2e-5, atol=1e-12)
+        assert np.allclose(dists[f + sel], d_ref ** 2, rtol=2e-5, atol=1e-12)
+        assert (idx[f + sel, 0] == sel).all()
+        assert (idx[f + sel] == i_ref).mean() > 0.999        # ties aside, the same neighbours
+
+
 def test_rasterizer_computes_h_itself():
     """SurfaceSplatting without a precomputed Vrk_h: global (Vrk_invariant) and per-point (isotropic) scales."""
     pts, nrm = scenes.load_cloud("teapot")
