@@ -8,6 +8,9 @@ full lists of that size, and whoever comes second is served from the cache -- ke
 strides and in-place version counter (the optimiser step bumps it), with the keyed tensor kept alive so that its
 address cannot be recycled by a different tensor.  Results are identical to separate searches: the K-th distance is
 column K-1 of the (distance, id)-sorted lists.
+
+Caveat: writes that bypass the version counter (``points.data.add_(...)``) are invisible to the key; use in-place ops
+under ``torch.no_grad()`` (what torch.optim does) or call `invalidate()`.
 """
 import torch
 
@@ -26,6 +29,12 @@ def request_lists(k: int) -> None:
 
 def requested_k() -> int:
     return _requested_k
+
+
+def invalidate() -> None:
+    """Forget the cached lists (after modifying points in a way the version counter does not see)."""
+    global _last
+    _last = None
 
 
 def _key(points, sizes):
