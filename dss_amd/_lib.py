@@ -61,6 +61,11 @@ SIGNATURES = {
                                         _c_f32, _c_vp, _c_vp, _c_vp, _c_sz, _c_vp]),
     "dss_image_loss_backward": (_c_int, [_c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_i64, _c_vp, _c_int, _c_int, _c_int, _c_f32,
                                          _c_f32, _c_vp, _c_vp, _c_vp, _c_vp]),
+    "dss_image_loss_band_sums": (_c_int, [_c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_i64, _c_vp, _c_i64, _c_int, _c_int, _c_int,
+                                          _c_vp, _c_vp, _c_sz, _c_vp]),
+    "dss_image_loss_from_sums": (_c_int, [_c_vp, _c_int, _c_int, _c_int, _c_f32, _c_f32, _c_vp, _c_vp]),
+    "dss_image_loss_band_backward": (_c_int, [_c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_i64, _c_vp, _c_i64, _c_int, _c_int,
+                                              _c_int, _c_int, _c_f32, _c_f32, _c_vp, _c_vp, _c_vp, _c_vp]),
     "dss_knn_workspace": (_c_sz, [_c_int, _c_i64]),
     "dss_knn_kth_sqdist": (_c_int, [_c_vp] * 3 + [_c_int, _c_i64, _c_int, _c_vp, _c_vp, _c_sz, _c_vp]),
     "dss_knn_points": (_c_int, [_c_vp] * 3 + [_c_int, _c_i64, _c_int, _c_vp, _c_vp, _c_vp, _c_sz, _c_vp]),

@@ -24,8 +24,8 @@ struct TargetView {  // target colours with arbitrary element strides: (N,H,W,3)
 __device__ __forceinline__ float sign_of(float v) { return (float)((v > 0.f) - (v < 0.f)); }
 
 __global__ __launch_bounds__(256) void image_loss_reduce_kernel(const float4 *__restrict__ rgba, const TargetView img,
-                                                                const float *__restrict__ mask, int H, int W,
-                                                                double *__restrict__ part /* (N, blocks, 5) */)
+                                                                const float *__restrict__ mask, int64_t mask_sn, int H,
+                                                                int W, double *__restrict__ part /* (N, blocks, 5) */)
 {
     __shared__ float wave_part[4][IMG_LOSS_TERMS];
     const int n = blockIdx.y, b = blockIdx.x, nb = gridDim.x;
@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void image_loss_reduce_kernel(const float4 *__
     for (int64_t i = (int64_t)b * 256 + threadIdx.x; i < HW; i += (int64_t)nb * 256) {
         const int64_t q = (int64_t)n * HW + i;
         const float4 px = rgba[q];
-        const float t = mask[q];
+        const float t = mask[(int64_t)n * mask_sn + i];  // mask_sn = H*W, or the full image's stride for a row band
         const int y = (int)(i / W), x = (int)(i - (int64_t)y * W);
         const float *tp = img.p + n * img.sn + y * img.sh + x * img.sw;
         const float d = fabsf(tp[0] - px.x) + fabsf(tp[img.sc] - px.y) + fabsf(tp[2 * img.sc] - px.z);
@@ -68,23 +68,30 @@ __device__ __forceinline__ double shfl_down_f64(double v, int delta)
     return __hiloint2double(hi, lo);
 }
 
-__global__ __launch_bounds__(256) void image_loss_finalize_kernel(const double *__restrict__ part, int N, int nb, int H, int W,
-                                                                  float lambda_rgb, float lambda_sil,
-                                                                  double *__restrict__ sums, float *__restrict__ losses)
+// mode 0: block partials -> per-image sums -> batch totals + losses (one GPU).  Row bands on several GPUs: mode 1 =
+// block partials -> per-image sums of the band only; the caller all-reduces them; mode 2 = (all-reduced) per-image
+// sums -> totals + losses.  pix_per_image = pixels of the FULL image (the mean of the silhouette term runs over it).
+__global__ __launch_bounds__(256) void image_loss_finalize_kernel(const double *__restrict__ part, int N, int nb,
+                                                                  double pix_per_image, float lambda_rgb, float lambda_sil,
+                                                                  double *__restrict__ sums, float *__restrict__ losses,
+                                                                  int mode)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int n = wave; n < N; n += 4) {
-        double v[IMG_LOSS_TERMS];
+    if (mode != 2)
+        for (int n = wave; n < N; n += 4) {
+            double v[IMG_LOSS_TERMS];
 #pragma unroll
-        for (int k = 0; k < IMG_LOSS_TERMS; ++k) v[k] = lane < nb ? part[((size_t)n * nb + lane) * IMG_LOSS_TERMS + k] : 0.0;
+            for (int k = 0; k < IMG_LOSS_TERMS; ++k)
+                v[k] = lane < nb ? part[((size_t)n * nb + lane) * IMG_LOSS_TERMS + k] : 0.0;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1)
+            for (int o = 32; o > 0; o >>= 1)
 #pragma unroll
-            for (int k = 0; k < IMG_LOSS_TERMS; ++k) v[k] += shfl_down_f64(v[k], o);
-        if (lane == 0)
+                for (int k = 0; k < IMG_LOSS_TERMS; ++k) v[k] += shfl_down_f64(v[k], o);
+            if (lane == 0)
 #pragma unroll
-            for (int k = 0; k < IMG_LOSS_TERMS; ++k) sums[(size_t)n * IMG_LOSS_TERMS + k] = v[k];
-    }
+                for (int k = 0; k < IMG_LOSS_TERMS; ++k) sums[(size_t)n * IMG_LOSS_TERMS + k] = v[k];
+        }
+    if (mode == 1) return;
     __threadfence_block();
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -101,7 +108,7 @@ __global__ __launch_bounds__(256) void image_loss_finalize_kernel(const double *
         for (int k = 0; k < IMG_LOSS_TERMS; ++k) sums[(size_t)N * IMG_LOSS_TERMS + k] = tot[k];
         iou /= N;
         const double rgb = tot[0] > 0 ? tot[1] / tot[0] : 0.0;  // `if mask_pred.sum() > 0`, trainer.py:352
-        const double sil = tot[2] / ((double)N * H * W) + 0.01 * iou;
+        const double sil = tot[2] / ((double)N * pix_per_image) + 0.01 * iou;
         losses[0] = (float)(lambda_rgb * rgb + lambda_sil * sil);
         losses[1] = (float)(lambda_rgb * rgb);
         losses[2] = (float)(lambda_sil * sil);
@@ -110,9 +117,9 @@ __global__ __launch_bounds__(256) void image_loss_finalize_kernel(const double *
 }
 
 __global__ __launch_bounds__(256) void image_loss_grad_kernel(const float4 *__restrict__ rgba, const TargetView img,
-                                                              const float *__restrict__ mask, int N, int H, int W,
-                                                              float lambda_rgb, float lambda_sil,
-                                                              const double *__restrict__ sums,
+                                                              const float *__restrict__ mask, int64_t mask_sn, int N, int H,
+                                                              int W, double pix_per_image, float lambda_rgb,
+                                                              float lambda_sil, const double *__restrict__ sums,
                                                               const float *__restrict__ grad_total,
                                                               float4 *__restrict__ grad_rgba)
 {
@@ -126,9 +133,9 @@ __global__ __launch_bounds__(256) void image_loss_grad_kernel(const float4 *__re
     const double cnt = sums[(size_t)N * IMG_LOSS_TERMS];
     const double I = sums[(size_t)n * IMG_LOSS_TERMS + 3], U = sums[(size_t)n * IMG_LOSS_TERMS + 4];
     const float w_rgb = cnt > 0 ? (float)((double)lambda_rgb / cnt) : 0.f;
-    const float w_l1 = (float)((double)lambda_sil / ((double)N * (double)HW));
+    const float w_l1 = (float)((double)lambda_sil / ((double)N * pix_per_image));
     const float4 px = rgba[q];
-    const float t = mask[q];
+    const float t = mask[(int64_t)n * mask_sn + i];
     const float *tp = img.p + n * img.sn + y * img.sh + x * img.sw;
     const bool inside = t != 0.f && px.w != 0.f;
     float4 g;
@@ -193,9 +200,9 @@ extern "C" int dss_image_loss_forward(const float *rgba, const float *target_rgb
     const TargetView tv = {target_rgb, t_stride_n, t_stride_h, t_stride_w, t_stride_c};
     double *part = reinterpret_cast<double *>(workspace);
     hipLaunchKernelGGL(image_loss_reduce_kernel, dim3(nb, N), dim3(256), 0, st, reinterpret_cast<const float4 *>(rgba), tv,
-                       target_mask, H, W, part);
-    hipLaunchKernelGGL(image_loss_finalize_kernel, dim3(1), dim3(256), 0, st, part, N, nb, H, W, lambda_rgb,
-                       lambda_silhouette, sums, losses);
+                       target_mask, (int64_t)H * W, H, W, part);
+    hipLaunchKernelGGL(image_loss_finalize_kernel, dim3(1), dim3(256), 0, st, part, N, nb, (double)H * (double)W, lambda_rgb,
+                       lambda_silhouette, sums, losses, 0);
     return check_launch("dss_image_loss_forward");
 }
 
@@ -212,7 +219,60 @@ extern "C" int dss_image_loss_backward(const float *rgba, const float *target_rg
     const TargetView tv = {target_rgb, t_stride_n, t_stride_h, t_stride_w, t_stride_c};
     const int64_t total = (int64_t)N * H * W;
     hipLaunchKernelGGL(image_loss_grad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream),
-                       reinterpret_cast<const float4 *>(rgba), tv, target_mask, N, H, W, lambda_rgb, lambda_silhouette, sums,
-                       grad_total, reinterpret_cast<float4 *>(grad_rgba));
+                       reinterpret_cast<const float4 *>(rgba), tv, target_mask, (int64_t)H * W, N, H, W, (double)H * (double)W,
+                       lambda_rgb, lambda_silhouette, sums, grad_total, reinterpret_cast<float4 *>(grad_rgba));
     return check_launch("dss_image_loss_backward");
+}
+
+// ---- row bands (multi-GPU): band sums -> [all-reduce by the caller] -> losses from the sums -> band gradient ----------
+extern "C" int dss_image_loss_band_sums(const float *rgba_band, const float *target_rgb, int64_t t_stride_n,
+                                        int64_t t_stride_h, int64_t t_stride_w, int64_t t_stride_c, const float *target_mask,
+                                        int64_t mask_stride_n, int N, int rows, int W, double *sums, void *workspace,
+                                        size_t workspace_bytes, void *stream)
+{
+    if (int rc = check_image_args("dss_image_loss_band_sums", rgba_band, target_rgb, target_mask, N, rows, W)) return rc;
+    if (!sums || !workspace || workspace_bytes < dss_image_loss_workspace(N, rows, W)) {
+        set_error("dss_image_loss_band_sums: sums and a workspace of dss_image_loss_workspace(N, rows, W) bytes are required");
+        return DSS_ERR_WORKSPACE;
+    }
+    hipStream_t st = as_stream(stream);
+    const int nb = image_blocks(rows, W);
+    const TargetView tv = {target_rgb, t_stride_n, t_stride_h, t_stride_w, t_stride_c};
+    double *part = reinterpret_cast<double *>(workspace);
+    hipLaunchKernelGGL(image_loss_reduce_kernel, dim3(nb, N), dim3(256), 0, st, reinterpret_cast<const float4 *>(rgba_band),
+                       tv, target_mask, mask_stride_n, rows, W, part);
+    hipLaunchKernelGGL(image_loss_finalize_kernel, dim3(1), dim3(256), 0, st, part, N, nb, 0.0, 0.f, 0.f, sums, nullptr, 1);
+    return check_launch("dss_image_loss_band_sums");
+}
+
+extern "C" int dss_image_loss_from_sums(double *sums, int N, int H, int W, float lambda_rgb, float lambda_silhouette,
+                                        float *losses, void *stream)
+{
+    if (N <= 0 || H <= 0 || W <= 0 || !sums || !losses) {
+        set_error("dss_image_loss_from_sums: bad arguments");
+        return DSS_ERR_INVALID_ARGUMENT;
+    }
+    hipLaunchKernelGGL(image_loss_finalize_kernel, dim3(1), dim3(256), 0, as_stream(stream), nullptr, N, 0,
+                       (double)H * (double)W, lambda_rgb, lambda_silhouette, sums, losses, 2);
+    return check_launch("dss_image_loss_from_sums");
+}
+
+extern "C" int dss_image_loss_band_backward(const float *rgba_band, const float *target_rgb, int64_t t_stride_n,
+                                            int64_t t_stride_h, int64_t t_stride_w, int64_t t_stride_c,
+                                            const float *target_mask, int64_t mask_stride_n, int N, int rows, int W, int H,
+                                            float lambda_rgb, float lambda_silhouette, const double *sums,
+                                            const float *grad_total, float *grad_band, void *stream)
+{
+    if (int rc = check_image_args("dss_image_loss_band_backward", rgba_band, target_rgb, target_mask, N, rows, W)) return rc;
+    if (H < rows || !sums || !grad_band || (reinterpret_cast<uintptr_t>(grad_band) & 15) != 0) {
+        set_error("dss_image_loss_band_backward: needs H >= rows, sums and a 16-byte aligned grad_band");
+        return DSS_ERR_INVALID_ARGUMENT;
+    }
+    const TargetView tv = {target_rgb, t_stride_n, t_stride_h, t_stride_w, t_stride_c};
+    const int64_t total = (int64_t)N * rows * W;
+    hipLaunchKernelGGL(image_loss_grad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const float4 *>(rgba_band), tv, target_mask, mask_stride_n, N, rows, W,
+                       (double)H * (double)W, lambda_rgb, lambda_silhouette, sums, grad_total,
+                       reinterpret_cast<float4 *>(grad_band));
+    return check_launch("dss_image_loss_band_backward");
 }

@@ -267,3 +267,43 @@ def reduce_grads_(*grads: torch.Tensor, part: RowPartition, group=None):
         g.copy_(flat[off:off + g.numel()].view_as(g))
         off += g.numel()
     return grads
+
+
+class _BandImageLoss(torch.autograd.Function):
+    """Image loss of a row band with the per-image sums all-reduced over the ranks: every rank gets the GLOBAL loss
+    value and the gradient of it with respect to its own band."""
+
+    @staticmethod
+    def forward(ctx, rgba_band, img, mask_img, rows, lambda_rgb, lambda_silhouette, group):
+        from . import ops
+        sums = ops.image_loss_band_sums(rgba_band, img, mask_img, rows)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)   # 40 (N + 1) bytes
+        losses = ops.image_loss_from_sums(sums, (img.shape[1], img.shape[2]), lambda_rgb, lambda_silhouette)
+        ctx.save_for_backward(rgba_band, img, mask_img, sums)
+        ctx.args = (rows, lambda_rgb, lambda_silhouette)
+        total, rest = losses[0], losses[1:]
+        ctx.mark_non_differentiable(rest)
+        return total, rest
+
+    @staticmethod
+    def backward(ctx, grad_total, _grad_rest):
+        from . import ops
+        rgba_band, img, mask_img, sums = ctx.saved_tensors
+        rows, lambda_rgb, lambda_silhouette = ctx.args
+        grad = ops.image_loss_band_backward(rgba_band, img, mask_img, rows, lambda_rgb, lambda_silhouette, sums,
+                                            grad_total=grad_total.contiguous())
+        return grad, None, None, None, None, None, None
+
+
+def band_image_loss(rgba_band, img, mask_img, part: RowPartition, lambda_dr_rgb: float = 1.0,
+                    lambda_dr_silhouette: float = 1.0, group=None):
+    """``Trainer.calc_dr_loss`` (trainer.py:332-372) for a row-partitioned render: ``rgba_band`` (N, rows, S, 4) is this
+    rank's band, ``img`` (N,H,W,3) / ``mask_img`` (N,H,W) the full targets (replicated).  The masked-mean denominators
+    and the IoU intersections / unions are global sums: one all-reduce of 5 doubles per image; the backward
+    then only needs the band.  Returns the same dictionary as `dss_amd.losses.calc_dr_loss`, identical on every rank."""
+    if mask_img.dtype != torch.float32:
+        mask_img = mask_img.float()
+    total, rest = _BandImageLoss.apply(rgba_band, img, mask_img, part.rows, float(lambda_dr_rgb),
+                                       float(lambda_dr_silhouette), group)
+    return {"loss": total, "loss_dr_rgb": rest[0], "loss_dr_silhouette": rest[1], "loss_iou": rest[2]}

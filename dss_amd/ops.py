@@ -789,3 +789,75 @@ def points_inmask(points, M, mask_img, visible=None):
                                    mask_img.shape[1], mask_img.shape[2], _lib.ptr(out), _lib.stream_ptr(dev))
     _lib.check(rc, "dss_points_inmask")
     return out.view(torch.bool)   # the kernel writes 0 / 1
+
+
+def _band_args(rgba_band, target_rgb, target_mask, rows):
+    """Row band [row0, row1) of an image loss: the band render (N,rows,W,4) against the FULL targets (N,H,W,3) /
+    (N,H,W); returns the tensors plus the pointers / strides of the targets' band."""
+    rgba_band = _lib.require_gpu(rgba_band, "rgba_band", _f32)
+    row0, row1 = int(rows[0]), int(rows[1])
+    if rgba_band.dim() != 4 or rgba_band.shape[-1] != 4 or rgba_band.shape[1] != row1 - row0:
+        raise RuntimeError("dss_amd: rgba_band must be (N, row1-row0, W, 4), got %s for rows %s" % (tuple(rgba_band.shape), (row0, row1)))
+    N, nr, W, _ = rgba_band.shape
+    if not isinstance(target_rgb, torch.Tensor) or not target_rgb.is_cuda or target_rgb.dtype != _f32:
+        raise RuntimeError("dss_amd: target_rgb must be a float32 GPU tensor (no CPU fallback)")
+    H = target_rgb.shape[1]
+    if target_rgb.dim() != 4 or tuple(target_rgb.shape) != (N, H, W, 3) or not (0 <= row0 <= row1 <= H):
+        raise RuntimeError("dss_amd: target_rgb must be the full (N,H,W,3) target with 0 <= row0 <= row1 <= H")
+    target_mask = _lib.require_gpu(target_mask, "target_mask", _f32).reshape(N, H, W)
+    band_rgb = target_rgb[:, row0:row1]
+    band_mask = target_mask[:, row0:row1]
+    return rgba_band, band_rgb, band_mask, target_mask, N, nr, W, H
+
+
+def image_loss_band_sums(rgba_band, target_rgb, target_mask, rows):
+    """Per-image sums of ``Trainer.calc_dr_loss`` over the row band ``rows = (row0, row1)`` -> float64 (N+1,5) whose
+    first N rows are filled; all-reduce (SUM) ``sums[:N]`` over the ranks, then :func:`image_loss_from_sums`."""
+    lib = _lib.load()
+    rgba_band, band_rgb, band_mask, _keep, N, nr, W, H = _band_args(rgba_band, target_rgb, target_mask, rows)
+    dev = rgba_band.device
+    with torch.cuda.device(dev):
+        sums = torch.zeros((N + 1, 5), dtype=torch.float64, device=dev)
+        if nr > 0:
+            sn, sh, sw, sc = band_rgb.stride()
+            ws = _lib.workspace(dev, lib.dss_image_loss_workspace(N, nr, W))
+            rc = lib.dss_image_loss_band_sums(_lib.ptr(rgba_band), _lib.ptr(band_rgb), sn, sh, sw, sc,
+                                              _lib.ptr(band_mask), H * W, N, nr, W, _lib.ptr(sums),
+                                              _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
+            _lib.check(rc, "dss_image_loss_band_sums")
+    return sums
+
+
+def image_loss_from_sums(sums, image_size, lambda_rgb: float, lambda_silhouette: float):
+    """Totals row + losses (4,) from the (all-reduced) per-image sums; ``image_size = (H, W)`` of the FULL image."""
+    lib = _lib.load()
+    sums = _lib.require_gpu(sums, "sums", torch.float64)
+    N = sums.shape[0] - 1
+    dev = sums.device
+    with torch.cuda.device(dev):
+        losses = torch.empty((4,), dtype=_f32, device=dev)
+        rc = lib.dss_image_loss_from_sums(_lib.ptr(sums), N, int(image_size[0]), int(image_size[1]), float(lambda_rgb),
+                                          float(lambda_silhouette), _lib.ptr(losses), _lib.stream_ptr(dev))
+    _lib.check(rc, "dss_image_loss_from_sums")
+    return losses
+
+
+def image_loss_band_backward(rgba_band, target_rgb, target_mask, rows, lambda_rgb: float, lambda_silhouette: float, sums,
+                             grad_total=None):
+    """The band ``rows`` of d total / d rgba, (N,rows,W,4), from the reduced ``sums`` (after image_loss_from_sums)."""
+    lib = _lib.load()
+    rgba_band, band_rgb, band_mask, _keep, N, nr, W, H = _band_args(rgba_band, target_rgb, target_mask, rows)
+    dev = rgba_band.device
+    sums = _lib.require_gpu(sums, "sums", torch.float64)
+    if grad_total is not None:
+        grad_total = _lib.require_gpu(grad_total, "grad_total", _f32).reshape(1)
+    with torch.cuda.device(dev):
+        grad = torch.empty_like(rgba_band)
+        if nr > 0:
+            sn, sh, sw, sc = band_rgb.stride()
+            rc = lib.dss_image_loss_band_backward(_lib.ptr(rgba_band), _lib.ptr(band_rgb), sn, sh, sw, sc,
+                                                  _lib.ptr(band_mask), H * W, N, nr, W, H,
+                                                  float(lambda_rgb), float(lambda_silhouette), _lib.ptr(sums),
+                                                  _lib.ptr(grad_total), _lib.ptr(grad), _lib.stream_ptr(dev))
+            _lib.check(rc, "dss_image_loss_band_backward")
+    return grad

@@ -421,6 +421,24 @@ DSS_API int dss_image_loss_backward(const float *rgba, const float *target_rgb, 
                                     float lambda_silhouette, const double *sums, const float *grad_total,
                                     float *grad_rgba, void *stream);
 
+/* Row bands on several GPUs ("loss scalars needing global sums -> tiny all-reduce"): rank g holds rows
+ * [row0, row1) of every image.  dss_image_loss_band_sums: the five per-image sums of the band, sums (N,5) (first N rows
+ * of an (N+1,5) buffer); the caller all-reduces them (SUM, 40 N bytes); dss_image_loss_from_sums: totals row + the
+ * four losses from the reduced sums (H, W = the FULL image); dss_image_loss_band_backward: the band of the gradient
+ * image.  rgba_band (N,rows,W,4) contiguous; target_rgb = the band of the target through its element strides (pointer
+ * at row0); target_mask = pointer at row0 of a (N,H,W) float mask, mask_stride_n = H*W elements. */
+DSS_API int dss_image_loss_band_sums(const float *rgba_band, const float *target_rgb, int64_t t_stride_n,
+                                     int64_t t_stride_h, int64_t t_stride_w, int64_t t_stride_c,
+                                     const float *target_mask, int64_t mask_stride_n, int N, int rows, int W,
+                                     double *sums, void *workspace, size_t workspace_bytes, void *stream);
+DSS_API int dss_image_loss_from_sums(double *sums /* (N+1,5) in/out */, int N, int H, int W, float lambda_rgb,
+                                     float lambda_silhouette, float *losses /* (4) */, void *stream);
+DSS_API int dss_image_loss_band_backward(const float *rgba_band, const float *target_rgb, int64_t t_stride_n,
+                                         int64_t t_stride_h, int64_t t_stride_w, int64_t t_stride_c,
+                                         const float *target_mask, int64_t mask_stride_n, int N, int rows, int W,
+                                         int H, float lambda_rgb, float lambda_silhouette, const double *sums,
+                                         const float *grad_total, float *grad_band, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -116,3 +116,72 @@ def test_row_partition_bounds():
         assert cover == S
         for (a, b), (c, d) in zip(rows[:-1], rows[1:]):
             assert b == c
+
+
+def _band_loss_worker(rank, world, port, tmp):
+    """band_image_loss over gloo with the three HIP calls replaced by numpy stand-ins (same contracts): the all-reduce
+    of the per-image sums and the autograd wiring are what is under test; the expected values come from the oracle on
+    the full image."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle
+    from dss_amd import ops
+    from dss_amd.distributed import RowPartition, band_image_loss
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(4)
+        N, H, W = 2, 24, 20
+        img = rng.random((N, H, W, 3)).astype(np.float32)
+        rgba = rng.random((N, H, W, 4)).astype(np.float32)
+        rgba[..., 3] = rng.random((N, H, W)) < 0.5
+        mask = (rng.random((N, H, W)) < 0.5).astype(np.float32)
+        lam = (0.7, 2.0)
+
+        def band_sums(rgba_band, target_rgb, target_mask, rows):
+            r0, r1 = rows
+            a, t = rgba_band[..., 3].double(), target_mask.reshape(N, H, W)[:, r0:r1].double()
+            inside = (a != 0) & (t != 0)
+            diff = (target_rgb[:, r0:r1].double() - rgba_band[..., :3].double()).abs().sum(-1)
+            s = torch.zeros(N + 1, 5, dtype=torch.float64)
+            s[:N, 0] = inside.sum((1, 2)); s[:N, 1] = (diff * inside).sum((1, 2)); s[:N, 2] = (t - a).abs().sum((1, 2))
+            s[:N, 3] = (a * t).sum((1, 2)); s[:N, 4] = (a + t - a * t).sum((1, 2))
+            return s
+
+        def from_sums(sums, image_size, l_rgb, l_sil):
+            sums[N] = sums[:N].sum(0)
+            iou = (1.0 - sums[:N, 3] / sums[:N, 4].clamp_min(1e-17)).mean()
+            rgb = sums[N, 1] / sums[N, 0] if sums[N, 0] > 0 else torch.tensor(0.0, dtype=torch.float64)
+            sil = sums[N, 2] / (N * image_size[0] * image_size[1]) + 0.01 * iou
+            return torch.stack([l_rgb * rgb + l_sil * sil, l_rgb * rgb, l_sil * sil, iou]).float()
+
+        def band_backward(rgba_band, target_rgb, target_mask, rows, l_rgb, l_sil, sums, grad_total=None):
+            r0, r1 = rows
+            a, t = rgba_band[..., 3].double(), target_mask.reshape(N, H, W)[:, r0:r1].double()
+            inside = ((a != 0) & (t != 0)).double()
+            g = torch.zeros_like(rgba_band, dtype=torch.float64)
+            g[..., :3] = l_rgb * torch.sign(rgba_band[..., :3].double() - target_rgb[:, r0:r1].double()) * inside[..., None] / sums[N, 0]
+            I, U = sums[:N, 3][:, None, None], sums[:N, 4][:, None, None]
+            g[..., 3] = l_sil * (torch.sign(a - t) / (N * H * W) + 0.01 * (-(t * U - I * (1 - t)) / (U * U)) / N)
+            return (g * (1.0 if grad_total is None else float(grad_total))).float()
+
+        ops.image_loss_band_sums, ops.image_loss_from_sums, ops.image_loss_band_backward = band_sums, from_sums, band_backward
+        part = RowPartition(H, world, rank)
+        r0, r1 = part.rows
+        band = torch.from_numpy(rgba[:, r0:r1].copy()).requires_grad_(True)
+        out = band_image_loss(band, torch.from_numpy(img), torch.from_numpy(mask), part, *lam)
+        want, want_grad = oracle.image_loss(rgba, img, mask, *lam)
+        assert abs(out["loss"].item() - want[0]) <= 1e-5 * abs(want[0]), (out["loss"].item(), want[0])
+        assert abs(out["loss_dr_rgb"].item() - want[1]) <= 1e-5 * abs(want[1])
+        (out["loss"] * 1.5).backward()
+        assert np.allclose(band.grad.numpy(), 1.5 * want_grad[:, r0:r1], rtol=1e-5, atol=1e-9)
+        open(os.path.join(tmp, "band_ok%d" % rank), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_band_image_loss_gloo_world2(tmp_path):
+    port = 29850 + (os.getpid() % 100)
+    mp.spawn(_band_loss_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "band_ok0").exists() and (tmp_path / "band_ok1").exists()

@@ -87,3 +87,40 @@ def test_degenerate_images():
         lo, go = oracle.image_loss(rgba.cpu().numpy(), img.cpu().numpy(), mask.cpu().numpy(), 1.0, 1.0)
         assert np.allclose(losses.cpu().numpy(), lo, rtol=1e-6) and abs(lo[0] - 0.01) < 1e-7 and lo[1] == 0
         assert np.allclose(grad.cpu().numpy(), go, rtol=1e-5, atol=1e-12) and torch.isfinite(grad).all()
+
+
+@pytest.mark.parametrize("bounds", [(0, 64, 128), (0, 40, 41, 128), (0, 0, 128)])
+def test_row_bands_reproduce_the_full_image_loss(bounds):
+    """Multi-GPU form: per-band sums added up (what the all-reduce does) give the full-image loss, and each
+    band's gradient is the matching slice of the full-image gradient.  Bands of 64+64, 40+1+87 and an empty band."""
+    from dss_amd.distributed import RowPartition, band_image_loss
+    rng = np.random.default_rng(21)
+    N, H, W = 3, 128, 96
+    img = _t(rng.random((N, 3, H, W)).astype(np.float32)).permute(0, 2, 3, 1)          # NCHW view, like the trainer
+    rgba = rng.random((N, H, W, 4)).astype(np.float32)
+    rgba[..., 3] = rng.random((N, H, W)) < 0.4
+    rgba = _t(rgba)
+    mask = _t((rng.random((N, H, W)) < 0.5).astype(np.float32))
+    losses, sums = ops.image_loss_forward(rgba, img, mask, 0.7, 2.0)
+    up = torch.tensor([1.3], device=DEV)
+    grad = ops.image_loss_backward(rgba, img, mask, 0.7, 2.0, sums, grad_total=up)
+
+    G = len(bounds) - 1
+    band_sums = [ops.image_loss_band_sums(rgba[:, bounds[g]:bounds[g + 1]].contiguous(), img, mask, (bounds[g], bounds[g + 1]))
+                 for g in range(G)]
+    reduced = torch.stack(band_sums).sum(0)                                               # the all-reduce
+    assert torch.allclose(reduced[:N], sums[:N], rtol=1e-6, atol=0) and torch.equal(reduced[:N, 0], sums[:N, 0])
+    losses_b = ops.image_loss_from_sums(reduced, (H, W), 0.7, 2.0)
+    assert torch.allclose(losses_b, losses, rtol=1e-6)
+    for g in range(G):
+        r0, r1 = bounds[g], bounds[g + 1]
+        gb = ops.image_loss_band_backward(rgba[:, r0:r1].contiguous(), img, mask, (r0, r1), 0.7, 2.0, reduced, grad_total=up)
+        assert tuple(gb.shape) == (N, r1 - r0, W, 4)
+        assert torch.allclose(gb, grad[:, r0:r1], rtol=1e-6, atol=1e-12)
+    # the autograd wrapper on a single rank (no process group): the band IS the image
+    part = RowPartition(H, 1, 0)
+    leaf = rgba.clone().requires_grad_(True)
+    out = band_image_loss(leaf, img, mask[:, None], part, 0.7, 2.0)
+    assert torch.allclose(out["loss"], losses[0], rtol=1e-6)
+    (out["loss"] * 1.3).backward()
+    assert torch.allclose(leaf.grad, grad, rtol=1e-6, atol=1e-12)
