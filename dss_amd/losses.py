@@ -119,6 +119,9 @@ class SurfaceLoss(torch.nn.Module):
         self.sharpness_sigma = kwargs.get("sharpness_sigma", self.sharpness_sigma)
         self.filter_scale = kwargs.get("filter_scale", self.filter_scale)
         self.knn_tree = kwargs.get("knn_tree", self.knn_tree)
+        if self.knn_tree is not None and not isinstance(self.knn_tree, _Neighbourhood):
+            raise TypeError("knn_tree must be the packed neighbourhood of a dss_amd loss (its `.knn_tree`), not a padded "
+                            "pytorch3d result; pass rebuild_knn=True to search again")
         if rebuild_knn or self.knn_tree is None or not self.knn_tree.matches(point_clouds):
             self.knn_tree = _Neighbourhood(point_clouds, self.knn_k)
         return self.knn_tree
