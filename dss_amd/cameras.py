@@ -179,3 +179,45 @@ class FoVPerspectiveCameras:
         R = kwargs.get("R", self.R)
         T = kwargs.get("T", self.T)
         return -torch.bmm(R, T[:, :, None])[:, :, 0]
+
+
+class CameraSampler:
+    """Random look-at cameras in batches, mirroring `DSS.core.camera.CameraSampler` (DSS/core/camera.py:6-73): distances
+    uniform in ``distance_range`` (sorted descending when ``sort_distance``), azimuth U[-180, 180), elevation U[-90, 90),
+    look-at point U[-0.05, 0.05)^3 -- drawn from torch's global generator in the reference's order, so the same seed gives
+    the same cameras -- then `look_at_view_transform`; iterating yields ``camera_type(R=..., T=..., **camera_params)`` for
+    ``num_cams_batch`` views at a time."""
+
+    def __init__(self, num_cams_total, num_cams_batch, distance_range=((5.0, 10.0),), sort_distance=True, return_cams=True,
+                 camera_type=None, camera_params=None):
+        self.num_cams_batch = num_cams_batch
+        self.num_cams_total = num_cams_total
+        self.sort_distance = sort_distance
+        self.camera_type = FoVPerspectiveCameras if camera_type is None else camera_type
+        self.camera_params = {} if camera_params is None else camera_params
+        distance_range = torch.as_tensor(distance_range, dtype=torch.float32).reshape(-1, 2)
+        distance_scale = distance_range[:, -1] - distance_range[:, 0]
+        distances = torch.rand(num_cams_total) * distance_scale + distance_range[:, 0]
+        if sort_distance:
+            distances, _ = distances.sort(descending=True)
+        azim = torch.rand(num_cams_total) * 360 - 180
+        elev = torch.rand(num_cams_total) * 180 - 90
+        at = torch.rand((num_cams_total, 3)) * 0.1 - 0.05
+        self.distances, self.azim, self.elev, self.at = distances, azim, elev, at
+        self.R, self.T = look_at_view_transform(distances, elev, azim, at=at, degrees=True)
+        self._idx = 0
+
+    def __len__(self):
+        return (self.R.shape[0] + self.num_cams_batch - 1) // self.num_cams_batch
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        if self._idx >= len(self):
+            raise StopIteration
+        start = self._idx * self.num_cams_batch
+        end = min(start + self.num_cams_batch, self.R.shape[0])
+        cameras = self.camera_type(R=self.R[start:end], T=self.T[start:end], **self.camera_params)
+        self._idx += 1
+        return cameras

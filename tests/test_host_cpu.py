@@ -184,3 +184,26 @@ def test_neighbour_cache_logic_with_a_cpu_stand_in(monkeypatch):
     small = torch.rand(9, 3)
     neighbours.kth_sqdist(small, first, torch.tensor([9]), [9], 7)
     assert calls["lists"] == 4 and calls["kth"] == 2
+
+
+def test_camera_sampler_draws_the_reference_cameras_for_the_same_seed():
+    """`CameraSampler` pinned against the reference class (DSS/core/camera.py:6-73) run by
+    tests/golden/make_golden_camera_sampler.py: same torch seed -> bit-identical distances / elevations / azimuths /
+    look-at points and the same batch sizes; the cameras it yields look at those points from those distances."""
+    import os
+    from dss_amd.cameras import CameraSampler
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_camera_sampler.npz"))
+    for tag in ("a", "b"):
+        seed, total, batch, lo, hi, sort = z[tag + "_args"]
+        torch.manual_seed(int(seed))
+        s = CameraSampler(int(total), int(batch), distance_range=[[lo, hi]], sort_distance=bool(sort),
+                          camera_params={"znear": 0.1})
+        assert np.array_equal(s.distances.numpy(), z[tag + "_dist"]) and np.array_equal(s.elev.numpy(), z[tag + "_elev"])
+        assert np.array_equal(s.azim.numpy(), z[tag + "_azim"]) and np.array_equal(s.at.numpy(), z[tag + "_at"])
+        cams = list(s)
+        assert [len(c) for c in cams] == z[tag + "_batches"].tolist() and len(s) == len(cams)
+        centre = torch.cat([c.get_camera_center() for c in cams])
+        assert torch.allclose((centre - s.at).norm(dim=1), s.distances, atol=1e-5)       # at the drawn distance from `at`
+        assert float(cams[0].znear[0]) == pytest.approx(0.1)
+        if sort:
+            assert (s.distances[:-1] >= s.distances[1:]).all()

@@ -25,7 +25,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import scenes  # noqa: E402
-from dss_amd.cameras import FoVPerspectiveCameras, look_at_view_transform  # noqa: E402
+from dss_amd.cameras import CameraSampler, FoVPerspectiveCameras  # noqa: E402
 from dss_amd.cloud import PointClouds3D  # noqa: E402
 from dss_amd.losses import ProjectionLoss, calc_dr_loss  # noqa: E402
 from dss_amd.model import Model  # noqa: E402
@@ -37,13 +37,11 @@ DEV = "cuda:0"
 S, BATCH, N_CAMS = 512, 8, 128
 
 
-def sample_cameras(g):
-    """CameraSampler.__init__: dist U[1.2, 2.2] sorted descending, azim U[-180, 180], elev U[-90, 90], at U[-.05, .05]^3."""
-    dist = (torch.rand(N_CAMS, generator=g) * 1.0 + 1.2).sort(descending=True).values
-    azim = torch.rand(N_CAMS, generator=g) * 360 - 180
-    elev = torch.rand(N_CAMS, generator=g) * 180 - 90
-    at = torch.rand((N_CAMS, 3), generator=g) * 0.1 - 0.05
-    return look_at_view_transform(dist, elev, azim, at=at)
+def sample_cameras():
+    """128 cameras by the reference's CameraSampler rule (DSS/core/camera.py:41-51), distances in [1.2, 2.2]."""
+    torch.manual_seed(0)
+    sampler = CameraSampler(N_CAMS, BATCH, distance_range=[[1.2, 2.2]], sort_distance=True)
+    return sampler.R, sampler.T
 
 
 def tri_colour_lights(cams, g):
@@ -70,7 +68,7 @@ def main():
     pts, nrm = scenes.load_cloud("bunny")
     pts, nrm = scenes.upsample_jitter(scenes.normalize_unit_sphere(pts) * 0.5, nrm, 12, seed=0)
     P = pts.shape[0]
-    R, T = sample_cameras(g)
+    R, T = sample_cameras()
     st = PointsRasterizationSettings(backface_culling=False, cutoff_threshold=1.0, Vrk_invariant=True,
                                      radii_backward_scaler=5.0, image_size=S, points_per_pixel=5, bin_size=None,
                                      clip_pts_grad=0.05)
