@@ -199,6 +199,25 @@ def cpu_baseline():
                       % (what, P, Sb, Sb, t_f, t_b, os.cpu_count())}
 
 
+def self_launch(n_gpus: int) -> int:
+    """Re-run this command line as `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py ...`
+    (one process per GPU, rendezvous on 127.0.0.1 at a free port).  Returns the launcher's exit code."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < n_gpus and os.environ.get("BENCH_DIST_BACKEND", "nccl") == "nccl":
+        raise SystemExit("bench.py: --gpus %d but only %d GPU(s) are visible" % (n_gpus, have))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL's intra-node transport needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -209,13 +228,16 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: become the launcher (one rank per GPU under torch.distributed.run, the same
+        # command line the driver would use), forward its output and exit code
+        sys.exit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d"
-                             % (args.gpus, args.gpus))
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (start one rank per GPU, or run without a launcher)"
+                         % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     local = local % torch.cuda.device_count()  # (BENCH_DIST_BACKEND=gloo lets two ranks share one GPU in tests)
@@ -311,7 +333,9 @@ def main():
                                    "512x512, K=5, fwd+bwd (setup+raster+blend and their backward), "
                                    "grad_out=randn(seed 1)" % (wl.Pc, wl.N),
                        "points_per_cloud": wl.Pc, "cameras": wl.N, "image_size": S, "points_per_pixel": K,
-                       "parallelism": "rows%d" % world, "launch": mode},
+                       "parallelism": "rows%d" % world, "launch": mode,
+                       "dist": {"world_size": dist.get_world_size(), "backend": dist.get_backend()} if world > 1
+                       else {"world_size": 1, "backend": None}},
             "roofline": {"bound": "hbm", "kernel": "fine_kernel<5> (fine pass + fused blend)", "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                          "traffic": traffic, "algorithmic_bytes": alg_bytes, "kernel_ms_mean": round(fine_mean, 5),

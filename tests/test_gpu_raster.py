@@ -326,6 +326,31 @@ dist.destroy_process_group()
     assert os.path.exists(os.path.join(str(tmp_path), "ok0")) and os.path.exists(os.path.join(str(tmp_path), "ok1"))
 
 
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it must start its two ranks itself (the driver calls the
+    N>1 runs exactly like the N=1 run) and print ONE JSON line that records the world size torch.distributed saw.
+    One GPU here, so the two ranks share cuda:0 over gloo (BENCH_DIST_BACKEND); on a multi-GPU box the default is RCCL."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["BENCH_DIST_BACKEND"] = "gloo"
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                          "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["config"]["dist"] == {"world_size": 2, "backend": "gloo"}
+    assert rec["config"]["cameras"] == 2 and rec["value"] > 0
+    # a launcher whose world size disagrees with --gpus is an error, not a silent mismatch
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True,
+                         timeout=300)
+    assert bad.returncode != 0 and "WORLD_SIZE" in (bad.stdout + bad.stderr)
+
+
 def test_render_backward_multi_cloud_matches_unfused():
     sc = scenes.random_splats(3000, 96, 3, seed=11)
     sc["first_idx"] = np.array([0, 3000, 6500], np.int64)     # ragged clouds + a gap of unowned points
