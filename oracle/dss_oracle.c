@@ -1,7 +1,8 @@
 /*
  * oracle/dss_oracle.c -- TEST INFRASTRUCTURE ONLY.
  *
- * Plain-C, single-threaded CPU restatement of the DSS EWA surface-splatting hot path
+ * Plain-C CPU restatement of the DSS EWA surface-splatting hot path (OpenMP only on loops whose
+ * iterations are independent by construction, so results do not depend on the thread count)
  * (SURVEY.md section 8a).  It is the checker for the HIP library in dss_amd/csrc; it is
  * never linked, imported or called by the product path (only tests/, __graft_entry__.smoke()
  * and bench.py's cpu_baseline leg may use it).
@@ -15,9 +16,12 @@
  *                                    (oracle/_ref, DSS/csrc/rasterize_points_cpu.cpp:27-144)
  *   slow occupancy backward PINNED   bit-exact vs reference CPU (rasterize_points_cpu.cpp:380-477)
  *   zbuf backward           PINNED   bit-exact vs reference CPU (rasterize_points_cpu.cpp:479-513)
- *   fast occupancy backward UNPINNED restated from DSS/csrc/rasterize_points_backward.cu:30-212 and
- *                                    DSS/core/rasterizer.py:853-888 (CUDA only; cannot run here)
- *   blend fwd/bwd           UNPINNED pytorch3d norm_weighted_sum is not under /root/reference
+ *   fast occupancy backward PINNED   vs the reference CUDA kernel itself (rasterize_points_backward.cu:30-212), host-compiled
+ *                                    unmodified by oracle/ref_cuda_host.cpp and EXECUTED inside the reference's own
+ *                                    EllipticalRasterizer.backward (tests/golden/make_golden_fast_backward.py)
+ *   blend fwd/bwd           PINNED   vs the reference's own renderer.py:36-82 + gather_with_neg_idx + its weighted-sum CUDA
+ *                                    kernels (weighted_sum.cu:38-134) host-compiled and executed (make_golden_blend.py);
+ *                                    the 1e-4-clamped normalisation of pytorch3d's NormWeightedCompositor is restated
  *   per-point EWA setup     PINNED   vs the reference's own Python (rasterizer.py:293-565) run with stubbed
  *                                    third-party imports (tests/golden/make_golden_setup.py); the projection
  *                                    itself (pytorch3d cameras) stays unpinned
@@ -28,6 +32,9 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #define DSS_ORACLE_API __attribute__((visibility("default")))
 
@@ -164,6 +171,16 @@ DSS_ORACLE_API int oracle_splat_forward(
     for (int n = 0; n < N; ++n) {
         memset(counts, 0, sizeof(int) * npix);
         const int64_t p0 = first_idx[n], p1 = p0 + num_pts[n];
+        /* row bands: every thread owns the pixels of its rows and visits the splats in index order, so each
+         * pixel's K-list sees exactly the sequence of the serial loop */
+        #pragma omp parallel
+        {
+        int band0 = 0, band1 = S;
+#ifdef _OPENMP
+        const int nt = omp_get_num_threads(), tid = omp_get_thread_num();
+        band0 = (int)((int64_t)S * tid / nt); band1 = (int)((int64_t)S * (tid + 1) / nt);
+#endif
+        if (band0 < band1)
         for (int64_t p = p0; p < p1; ++p) {
             const float px = points[3 * p], py = points[3 * p + 1], pz = points[3 * p + 2];
             const float rx = radii[2 * p], ry = radii[2 * p + 1];
@@ -189,6 +206,8 @@ DSS_ORACLE_API int oracle_splat_forward(
                 if (ihi > S - 1) ihi = S - 1;
                 r_lo = S - 1 - ihi; r_hi = S - 1 - ilo;
             }
+            if (r_lo < band0) r_lo = band0;
+            if (r_hi > band1 - 1) r_hi = band1 - 1;
             for (int r = r_lo; r <= r_hi; ++r) {
                 const float yf = pix_to_ndc(S - 1 - r, S);
                 for (int c = c_lo; c <= c_hi; ++c) {
@@ -203,6 +222,8 @@ DSS_ORACLE_API int oracle_splat_forward(
                 }
             }
         }
+        }  /* omp parallel */
+        #pragma omp parallel for schedule(static)
         for (size_t pix = 0; pix < npix; ++pix) {
             const size_t o = (size_t)n * npix + pix;
             write_pixel(lists + pix * K, counts[pix], K, thr, idx + o * K, zbuf + o * K, qv + o * K, occ + o);
@@ -285,6 +306,7 @@ DSS_ORACLE_API void oracle_occ_backward_fast(
         const int64_t p0 = first_idx[n], p1 = p0 + num_pts[n];
         const float cur_r = rs[n];
         const float cur_r2 = cur_r * cur_r;
+        #pragma omp parallel for schedule(dynamic, 512)
         for (int64_t p = p0; p < p1; ++p) {
             if (!vis[p]) continue;
             const float px = points[3 * p], py = points[3 * p + 1], pz = points[3 * p + 2];
@@ -421,6 +443,7 @@ DSS_ORACLE_API void oracle_blend_forward(
     const float *feat, int N, int S, int K, int C, float *out /* (N,S,S,C+1) */)
 {
     const size_t npix = (size_t)N * S * S;
+    #pragma omp parallel for schedule(static)
     for (size_t i = 0; i < npix; ++i) {
         float cum = 0.0f;
         for (int k = 0; k < K; ++k) {
@@ -594,6 +617,7 @@ DSS_ORACLE_API void oracle_point_setup(
     /* vr6 != NULL: anisotropic source variance (rasterizer.py:256-291): Vrk is given per point and the tangent
      * frame of det(Sk WJk) is the PCA frame, whose normal is frame_n (the cloud normals are not used). */
     const float pixel = 2.0f / (float)S;
+    #pragma omp parallel for schedule(static)
     for (int64_t p = 0; p < P; ++p) {
         const float *m = M + 16 * cloud_of[p];
         const float *v = V + 16 * cloud_of[p];

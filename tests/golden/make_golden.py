@@ -4,7 +4,7 @@
     python tests/golden/make_golden.py
 
 * clouds.npz            point clouds converted from the reference's PLY fixtures
-                        (example_data/pointclouds/{teapot_normal_dense,bunny-8000,point-one}.ply)
+                        (example_data/pointclouds/{teapot_normal_dense,bunny-8000,point-one,yoga6_out}.ply)
 * ref_teapot256.npz     BASELINE config 1: teapot, 1 camera, 256x256, K=5 -- inputs + the outputs of
                         the UNMODIFIED reference CPU rasterizer (oracle/_ref: splat_points bin_size=0,
                         _splat_points_occ_backward, _backward_zbuf)
@@ -81,7 +81,8 @@ def run_ref(sc, K, thr, radii_s, seed):
 
 def main():
     clouds = {}
-    for key, fn in (("teapot", "teapot_normal_dense.ply"), ("bunny", "bunny-8000.ply"), ("one", "point-one.ply")):
+    for key, fn in (("teapot", "teapot_normal_dense.ply"), ("bunny", "bunny-8000.ply"), ("one", "point-one.ply"),
+                    ("yoga6", "yoga6_out.ply")):
         p, n = read_ply(os.path.join(REF_PLY, fn))
         clouds[key + "_points"], clouds[key + "_normals"] = p, n
         print(key, p.shape)
