@@ -103,6 +103,8 @@ def gather_rows_and_visibility(band: torch.Tensor, visible: torch.Tensor, part: 
     matter more than fewer bytes).  Returns (full image (N,S,S,ch), union of the visibility flags uint8 (P,))."""
     if part.world_size == 1:
         return band, visible
+    if not part.uniform:
+        raise ValueError("gather_rows_and_visibility needs equal bands; use OverlappedExchange for load-balanced bounds")
     n, rows = band.shape[0], band.shape[1]
     if rows < part.band:
         pad = band.new_zeros((n, part.band - rows) + tuple(band.shape[2:]))
@@ -127,6 +129,8 @@ class ForwardExchange:
     (``ops.render_forward(out_image=..., out_visible=...)``), so the step issues no packing kernels."""
 
     def __init__(self, part: RowPartition, n_images: int, channels: int, num_points: int, device):
+        if not part.uniform:
+            raise ValueError("ForwardExchange needs equal bands; use OverlappedExchange for load-balanced bounds")
         self.part = part
         self.shape = (n_images, part.band, part.S, channels)
         self.nb = n_images * part.band * part.S * channels * 4

@@ -132,7 +132,10 @@ class SurfaceLoss(torch.nn.Module):
         if points_filter is not None:
             vis, inm = getattr(points_filter, "visibility", None), getattr(points_filter, "inmask", None)
             if vis is not None and inm is not None:
-                keep = _packed_mask(vis, point_clouds) & _packed_mask(inm, point_clouds)
+                # losses.py:198-206: AND first (same view), then OR over the views of a shared cloud
+                both = (vis.bool() & inm.bool()) if vis.shape == inm.shape else None
+                keep = _packed_mask(both, point_clouds) if both is not None else \
+                    _packed_mask(vis, point_clouds) & _packed_mask(inm, point_clouds)
         return ops.mollify_normals(point_clouds.normals_packed().detach(), nb.dists, nb.idx, keep, nb.first, nb.num)
 
 

@@ -192,6 +192,8 @@ def splat_backward(points, radii, visible, idx, grad_occ, grad_zbuf, cloud_to_pa
     radii = _lib.require_gpu(radii, "radii", _f32)
     vis = _lib.require_gpu(_as_u8(visible), "visible", _u8)
     idx = _lib.require_gpu(idx, "idx", _i32)
+    if grad_occ is None:  # (autograd hands over None for an unused output: only then are zeros allocated)
+        grad_occ = torch.zeros(idx.shape[:3], dtype=_f32, device=dev)
     if not grad_occ.is_cuda:
         raise RuntimeError("dss_amd: grad_occ must be a GPU tensor (no CPU fallback)")
     if grad_zbuf is not None:
@@ -301,6 +303,10 @@ def render_forward(world, normals, h, M, V, znear, zfar, cloud_to_packed_first_i
     num = _lib.require_gpu(num_points_per_cloud, "num_points_per_cloud", _i64)
     features = _lib.require_gpu(features, "features", _f32)
     N, Pw = first.shape[0], world.shape[0]
+    if tuple(M.shape) != (N, 4, 4) or tuple(V.shape) != (N, 4, 4) or znear.numel() != N or zfar.numel() != N:
+        raise RuntimeError("camera tensors must be M,V (N,4,4) and znear,zfar (N,) with N=%d" % N)
+    if normals.shape != world.shape:
+        raise RuntimeError("normals must match world points")
     P = N * Pw if shared_cloud else Pw
     if features.shape[0] != P:
         raise RuntimeError("features must be packed (P,C) with P=%d, got %s" % (P, tuple(features.shape)))

@@ -61,6 +61,30 @@ class PointsRasterizationSettings:
         self.antialiasing_sigma = antialiasing_sigma
 
 
+def _raster_forward(ctx, pts_screen, ellipse_param, cutoff_threshold, radii, cloud_to_packed_first_idx,
+                    num_points_per_cloud, depth_merging_threshold, image_size, points_per_pixel, bin_size,
+                    max_points_per_bin, radii_backward_scaler, clip_pts_grad):
+    idx, zbuf, qvalue_map, occ_map, visible = ops.splat_points(
+        pts_screen, ellipse_param, cutoff_threshold, radii, cloud_to_packed_first_idx, num_points_per_cloud,
+        depth_merging_threshold, image_size, points_per_pixel, bin_size, max_points_per_bin, return_visible=True)
+    ctx.radii_backward_scaler = radii_backward_scaler
+    ctx.clip_pts_grad = -1.0 if clip_pts_grad is None else float(clip_pts_grad)
+    ctx.save_for_backward(pts_screen, radii, idx, visible, cloud_to_packed_first_idx, num_points_per_cloud)
+    # unused output gradients arrive as None instead of dense zero tensors: an all-zero zbuf gradient (train_mvr.py:
+    # zbuf feeds no loss) then costs neither an (N,S,S,K) allocation nor the scatter pass + separate clip launch
+    ctx.set_materialize_grads(False)
+    return idx, zbuf, qvalue_map, occ_map, visible
+
+
+def _raster_backward(ctx, zbuf_grad, occ_grad):
+    # qvalue_grad is ignored exactly like the reference (rasterizer.py:788-789)
+    pts_screen, radii, idx, visible, first_idx, num_points = ctx.saved_tensors
+    if occ_grad is None and zbuf_grad is None:
+        return torch.zeros_like(pts_screen)
+    return ops.splat_backward(pts_screen, radii, visible, idx, occ_grad, zbuf_grad, first_idx, num_points,
+                              ctx.radii_backward_scaler, ctx.clip_pts_grad)
+
+
 class EllipticalRasterizer(autograd.Function):
     """rasterizer.py:747-977.  ``apply(pts_screen, ellipse_param, cutoff_threshold, radii,
     cloud_to_packed_first_idx, num_points_per_cloud, depth_merging_threshold, image_size,
@@ -72,25 +96,31 @@ class EllipticalRasterizer(autograd.Function):
     def forward(ctx, pts_screen, ellipse_param, cutoff_threshold, radii, cloud_to_packed_first_idx,
                 num_points_per_cloud, depth_merging_threshold, image_size, points_per_pixel, bin_size=0,
                 max_points_per_bin=0, radii_backward_scaler=10.0, clip_pts_grad=-1.0):
-        idx, zbuf, qvalue_map, occ_map, visible = ops.splat_points(
-            pts_screen, ellipse_param, cutoff_threshold, radii, cloud_to_packed_first_idx, num_points_per_cloud,
-            depth_merging_threshold, image_size, points_per_pixel, bin_size, max_points_per_bin, return_visible=True)
-        EllipticalRasterizer.last_visible = visible  # side channel for SurfaceSplatting (not an autograd output)
-        ctx.radii_backward_scaler = radii_backward_scaler
-        ctx.clip_pts_grad = -1.0 if clip_pts_grad is None else float(clip_pts_grad)
-        ctx.save_for_backward(pts_screen, radii, idx, visible, cloud_to_packed_first_idx, num_points_per_cloud)
-        ctx.mark_non_differentiable(idx)
-        return idx, zbuf, qvalue_map, occ_map
+        outs = _raster_forward(ctx, pts_screen, ellipse_param, cutoff_threshold, radii, cloud_to_packed_first_idx,
+                               num_points_per_cloud, depth_merging_threshold, image_size, points_per_pixel, bin_size,
+                               max_points_per_bin, radii_backward_scaler, clip_pts_grad)
+        ctx.mark_non_differentiable(outs[0])
+        return outs[:4]
 
     @staticmethod
     def backward(ctx, idx_grad, zbuf_grad, qvalue_grad, occ_grad):
-        # qvalue_grad is ignored exactly like the reference (rasterizer.py:788-789)
-        pts_screen, radii, idx, visible, first_idx, num_points = ctx.saved_tensors
-        if occ_grad is None:
-            occ_grad = torch.zeros(idx.shape[:3], dtype=torch.float32, device=idx.device)
-        pts_grad = ops.splat_backward(pts_screen, radii, visible, idx, occ_grad, zbuf_grad, first_idx, num_points,
-                                      ctx.radii_backward_scaler, ctx.clip_pts_grad)
-        return (pts_grad,) + (None,) * 12
+        return (_raster_backward(ctx, zbuf_grad, occ_grad),) + (None,) * 12
+
+
+class _EllipticalRasterizerWithVisibility(autograd.Function):
+    """`EllipticalRasterizer` with the per-point visibility flags of the fine pass (the reference recomputes them with
+    ``idx[mask].unique()``, utils/__init__.py:320-340) as a fifth, non-differentiable OUTPUT: what `SurfaceSplatting`
+    calls, so that nothing travels through module or class state."""
+
+    @staticmethod
+    def forward(ctx, *args):
+        outs = _raster_forward(ctx, *args)
+        ctx.mark_non_differentiable(outs[0], outs[4])
+        return outs
+
+    @staticmethod
+    def backward(ctx, idx_grad, zbuf_grad, qvalue_grad, occ_grad, visible_grad):
+        return (_raster_backward(ctx, zbuf_grad, occ_grad),) + (None,) * 12
 
 
 def rasterize_elliptical_points(pcls_screen, ellipse_params, cutoff_threshold, radii,
@@ -156,7 +186,9 @@ class SurfaceSplatting(torch.nn.Module):
 
     # -- source-space variance scale h (rasterizer.py:293-402) ------------------------------------
     def _variance_scale(self, point_clouds, raster_settings, refresh=True):
-        if not refresh and self._Vrk_h is not None:
+        n_total = sum(p.shape[0] for p in point_clouds.points_list())
+        if not refresh and self._Vrk_h is not None and (raster_settings.Vrk_invariant or
+                                                       self._Vrk_h.shape[0] == n_total):  # rasterizer.py:359-361
             return self._Vrk_h
         first, num = point_clouds.cloud_to_packed_first_idx(), point_clouds.num_points_per_cloud()
         with torch.no_grad():
@@ -169,6 +201,10 @@ class SurfaceSplatting(torch.nn.Module):
             h = ops.cloud_mean_clamp(d, first, num, 0.5, 5e-5, 1e-3, 0.5e-3, 7)
         elif raster_settings.Vrk_isotropic:
             h = (0.5 * d).clamp_(5e-5, 0.01)  # per point (rasterizer.py:383-388)
+            sizes = [p.shape[0] for p in point_clouds.points_list()]
+            if min(sizes) < 7:  # "knn search is unreliable, set sq_dist manually" (rasterizer.py:378-379): 0.5 * 1e-3
+                small = torch.cat([torch.full((n,), n < 7, dtype=torch.bool) for n in sizes]).to(h.device)
+                h = torch.where(small, torch.full_like(h, 0.5e-3), h)
         else:
             h = torch.zeros_like(d)  # unused: the anisotropic variance comes from _local_frames
         self._Vrk_h = h
@@ -294,7 +330,7 @@ class SurfaceSplatting(torch.nn.Module):
             raster_settings.image_size, raster_settings.cutoff_threshold, raster_settings.antialiasing_sigma,
             bool(raster_settings.backface_culling), shared, a["vr6"], a["frame_n"])
 
-        idx, zbuf, qvalue_map, occ_map = EllipticalRasterizer.apply(
+        idx, zbuf, qvalue_map, occ_map, visible = _EllipticalRasterizerWithVisibility.apply(
             pts_screen, ellipse, cutoff, radii, first_idx, num_points, raster_settings.depth_merging_threshold,
             raster_settings.image_size, raster_settings.points_per_pixel, raster_settings.bin_size,
             raster_settings.max_points_per_bin, raster_settings.radii_backward_scaler,
@@ -302,7 +338,6 @@ class SurfaceSplatting(torch.nn.Module):
 
         # the per-fragment scaler gather of rasterizer.py:631-633 is fused into the blend kernel; the
         # fragments carry the per-POINT scaler (P,) instead (renderer consumes either form)
-        visible = EllipticalRasterizer.last_visible
         fragments = PointFragments(idx=idx, zbuf=zbuf, qvalue=qvalue_map, scaler=scaler, occupancy=occ_map,
                                    geometry=(pts_screen.detach(), radii, visible, first_idx, num_points))
         self._last_valid = valid
@@ -318,11 +353,21 @@ class SurfaceSplatting(torch.nn.Module):
         renderer's blend; the autograd graph is one node, so gradients flow to the world points and the
         features only (a loss on ``fragments.zbuf`` needs the unfused path)."""
         original_clouds = point_clouds
-        point_clouds = self._apply_activation_filter(point_clouds, point_clouds_filter)
+        if not point_clouds.isempty():
+            point_clouds = self._apply_activation_filter(point_clouds, point_clouds_filter)
+        if point_clouds.isempty():  # like forward(): empty fragments, zero image
+            st = kwargs.get("raster_settings", self.raster_settings)
+            cameras = kwargs.get("cameras", self.cameras)
+            frag = self._empty_fragments(cameras.R.shape[0], point_clouds.device, st)
+            image = torch.zeros(tuple(frag.occupancy.shape) + (4,), device=point_clouds.device)
+            return image, frag, point_clouds
         a = self._prepare(point_clouds, **kwargs)
         st = a["raster_settings"]
         feats = a["out_clouds"].features_packed()
-        outs = _RenderFused.apply(a["world"], feats[:, :min(feats.shape[1], 8)].contiguous(), a["normals"], a["h"],
+        if feats.shape[1] > 8:
+            raise ValueError("render_fused blends at most 8 feature channels, got %d (use the unfused forward() + "
+                             "renderer for wider features)" % feats.shape[1])
+        outs = _RenderFused.apply(a["world"], feats.contiguous(), a["normals"], a["h"],
                                   a["M"], a["V"], a["znear"], a["zfar"], a["first_idx"], a["num_points"],
                                   st.image_size, st.points_per_pixel, st.cutoff_threshold, st.depth_merging_threshold,
                                   st.antialiasing_sigma, bool(st.backface_culling), a["shared"],
