@@ -35,6 +35,7 @@ SIGNATURES = {
                              + [_c_vp] * 5 + [_c_vp, _c_vp, _c_int, _c_vp, _c_vp] + [_c_vp, _c_sz, _c_vp]),
     "dss_backward_radius_workspace": (_c_sz, [_c_int, _c_i64]),
     "dss_backward_radius": (_c_int, [_c_vp] * 4 + [_c_int, _c_i64, _c_f32, _c_vp, _c_vp, _c_sz, _c_vp]),
+    "dss_occ_backward_box": (_c_int, [_c_vp] * 5 + [_c_int, _c_i64, _c_int, _c_f32, _c_vp, _c_vp]),
     "dss_occ_backward": (_c_int, [_c_vp] * 7 + [_c_int, _c_i64, _c_int, _c_int, _c_int, _c_int, _c_f32, _c_vp, _c_vp]),
     "dss_zbuf_backward": (_c_int, [_c_vp, _c_vp, _c_int, _c_int, _c_int, _c_int, _c_vp, _c_vp]),
     "dss_clip_grad": (_c_int, [_c_vp, _c_i64, _c_f32, _c_vp]),

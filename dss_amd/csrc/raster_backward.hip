@@ -215,6 +215,54 @@ __global__ __launch_bounds__(256) void occ_backward_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
+// `DSS._C._splat_points_occ_backward` on CUDA tensors (ext.cpp:10,16; RasterizePointsOccBackwardCudaKernel,
+// rasterize_points.cu:672-757): the reference's older, box-supported occupancy surrogate.  NOT on the training
+// path (`backward_occ_fast = True`, rasterizer.py:816) -- kept as a same-name mirror, so a plain gather:
+// one wavefront per point over the pixel window |dx| <= rx*s, |dy| <= ry*s.
+//   skip if pz<0 or |px|>1 or |py|>1;  R = radii*radii_s;  skip if |dx|>Rx or |dy|>Ry;
+//   skip if g>0 and (|dx| > Rx/radii_s or |dy| > Ry/radii_s);  grad += (dx,dy)/max(d2,1e-10)*g   (d2 == 0: 0)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void occ_box_backward_kernel(
+    const float *__restrict__ points, const float *__restrict__ radii, const float *__restrict__ grad_occ,
+    const int64_t *__restrict__ first_idx, const int64_t *__restrict__ num_pts, int N, int64_t P, int S, float radii_s,
+    float *__restrict__ grad_xy)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= P) return;
+    float gx = 0.0f, gy = 0.0f;
+    const int n = find_cloud(p, first_idx, num_pts, N);
+    const float px = points[3 * p], py = points[3 * p + 1], pz = points[3 * p + 2];
+    const float Rx = radii[2 * p] * radii_s, Ry = radii[2 * p + 1] * radii_s;
+    int xlo, xhi, ylo, yhi;
+    if (n >= 0 && !(pz < 0 || fabsf(py) > 1.0f || fabsf(px) > 1.0f) && ndc_index_range(px, Rx, S, xlo, xhi) &&
+        ndc_index_range(py, Ry, S, ylo, yhi)) {
+        const int w = xhi - xlo + 1;
+        const int total = w * (yhi - ylo + 1);
+        const float rx1 = Rx / radii_s, ry1 = Ry / radii_s;   // (rasterize_points.cu:741: scaled back, as the reference does)
+        for (int t = lane; t < total; t += 64) {
+            const int yi = ylo + t / w, xi = xlo + t % w;
+            const float g = grad_occ[((size_t)n * S + (S - 1 - yi)) * S + (S - 1 - xi)];
+            if (g == 0.0f) continue;
+            const float dx = pix_to_ndc(xi, S) - px, dy = pix_to_ndc(yi, S) - py;
+            if (fabsf(dx) > Rx || fabsf(dy) > Ry) continue;
+            if (g > 0.0f && (fabsf(dx) > rx1 || fabsf(dy) > ry1)) continue;
+            const float d2 = dx * dx + dy * dy;
+            if (d2 == 0.0f) continue;
+            const float den = fmaxf(d2, 1e-10f);
+            gx += dx / den * g;
+            gy += dy / den * g;
+        }
+    }
+    gx = wave_sum(gx);
+    gy = wave_sum(gy);
+    if (lane == 0) {
+        grad_xy[2 * p] = gx;
+        grad_xy[2 * p + 1] = gy;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Fused single-GPU backward (dss_render_backward): the stand-alone kernels launch one wavefront per
 // packed point, and tools/occ_timing.py shows that at DSS sizes they are bound by the workgroup
 // DISPATCH rate (8171 workgroups take ~26 us to start, 60 % of them only to find their point
@@ -1070,6 +1118,26 @@ extern "C" int dss_occ_backward(const float *points, const float *radii, const u
 {
     return occ_backward_impl(points, radii, visible, rs, grad_occ, first_idx, num_pts, N, P, S, row0, row1,
                              grad_pixel_stride, clip, grad_pts, stream);
+}
+
+extern "C" int dss_occ_backward_box(const float *points, const float *radii, const float *grad_occ,
+                                    const int64_t *first_idx, const int64_t *num_pts, int N, int64_t P, int S,
+                                    float radii_s, float *grad_xy, void *stream)
+{
+    if (N <= 0 || P < 0 || S <= 0 || !(radii_s > 0.0f)) {
+        set_error("dss_occ_backward_box: bad sizes N=%d P=%lld S=%d radii_s=%g", N, (long long)P, S, (double)radii_s);
+        return DSS_ERR_INVALID_ARGUMENT;
+    }
+    if (P == 0) return DSS_OK;
+    if (!points || !radii || !grad_occ || !first_idx || !num_pts || !grad_xy) {
+        set_error("dss_occ_backward_box: NULL tensor pointer");
+        return DSS_ERR_INVALID_ARGUMENT;
+    }
+    const long long blocks = (P + 3) / 4;
+    if (blocks > 0x7fffffffll) { set_error("dss_occ_backward_box: P too large"); return DSS_ERR_UNSUPPORTED; }
+    hipLaunchKernelGGL(occ_box_backward_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), points, radii,
+                       grad_occ, first_idx, num_pts, N, P, S, radii_s, grad_xy);
+    return check_launch("dss_occ_backward_box");
 }
 
 extern "C" int dss_zbuf_backward(const int32_t *idx, const float *grad_zbuf, int N, int rows, int S, int K,

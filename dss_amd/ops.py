@@ -1,5 +1,7 @@
-"""Tensor-level operators over the C ABI: the functions the reference binds in ``DSS._C``
-(DSS/csrc/ext.cpp:5-18), same names and argument meaning, plus the fused blend.
+"""Tensor-level operators over the C ABI: ALL seven functions the reference binds in ``DSS._C``
+(DSS/csrc/ext.cpp:5-18: ``splat_points``, ``_splat_points_naive``, ``_splat_points_occ_backward``,
+``_rasterize_coarse``, ``_rasterize_fine``, ``_splat_points_occ_fast_cuda_backward``, ``_backward_zbuf``), same names and
+argument meaning, plus the fused entry points.
 
 All inputs must be GPU tensors; outputs are freshly allocated on the input's device
 (rasterize_points.cu:632-637) except ``_backward_zbuf`` which accumulates in place
@@ -69,6 +71,11 @@ def splat_points(points, ellipse_params, cutoff_thres, radii, cloud_to_packed_fi
         qv = torch.empty((N, nrows, S, K), dtype=_f32, device=dev)
         occ = torch.empty((N, nrows, S), dtype=_f32, device=dev)
         vis = torch.empty((P,), dtype=_u8, device=dev) if return_visible else None
+        if nrows == 0:  # a rank whose row band is empty (RowPartition with S < world_size * band): nothing to launch
+            if vis is not None:
+                vis.zero_()
+                return idx, zbuf, qv, occ, vis.view(torch.bool)
+            return idx, zbuf, qv, occ
         nbytes = lib.dss_splat_forward_workspace(N, P, S, K, bs)
         ws = _lib.workspace(dev, nbytes)
         rc = lib.dss_splat_forward(_lib.ptr(points), _lib.ptr(ellipse_params), _lib.ptr(cutoff_thres),
@@ -87,6 +94,102 @@ def _splat_points_naive(points, ellipse_params, cutoff_thres, radii, cloud_to_pa
     """``DSS._C._splat_points_naive`` (ext.cpp:9)."""
     return splat_points(points, ellipse_params, cutoff_thres, radii, cloud_to_packed_first_idx,
                         num_points_per_cloud, depth_merging_thres, image_size, points_per_pixel, 0, 0)
+
+
+def _rasterize_coarse(points, radii, cloud_to_packed_first_idx, num_points_per_cloud, image_size: int, bin_size: int,
+                      max_points_per_bin: int):
+    """``DSS._C._rasterize_coarse`` (ext.cpp:11, rasterize_points.h:167-203): the binning pass alone.  The reference
+    returns a dense ``(N, B, B, M)`` int32 table; here ``bin_points`` is an OPAQUE uint8 tensor (the tile-list workspace
+    of ``dss_splat_bin``: per-tile sub-list counters + fixed-capacity id lists over 8x8-pixel tiles) that is only meant
+    to be handed to :func:`_rasterize_fine`.  ``bin_size`` / ``max_points_per_bin`` are accepted and ignored (tile size
+    and list capacity are chosen by the library; lists never truncate)."""
+    lib = _lib.load()
+    points = _lib.require_gpu(points, "points", _f32)
+    dev = points.device
+    radii = _lib.require_gpu(radii, "radii", _f32)
+    first = _lib.require_gpu(cloud_to_packed_first_idx, "cloud_to_packed_first_idx", _i64)
+    num = _lib.require_gpu(num_points_per_cloud, "num_points_per_cloud", _i64)
+    if points.dim() != 2 or points.shape[1] != 3 or tuple(radii.shape) != (points.shape[0], 2):
+        raise RuntimeError("points must be (P,3) and radii (P,2)")
+    N, P, S = first.shape[0], points.shape[0], int(image_size)
+    with torch.cuda.device(dev):
+        nbytes = lib.dss_splat_forward_workspace(N, P, S, 1, 1)
+        bin_points = torch.empty(nbytes, dtype=_u8, device=dev)
+        if P > 0:
+            rc = lib.dss_splat_bin(_lib.ptr(points), _lib.ptr(radii), _lib.ptr(first), _lib.ptr(num), N, P, S, 0, S,
+                                   _lib.ptr(bin_points), nbytes, _lib.stream_ptr(dev))
+            _lib.check(rc, "dss_splat_bin")
+    bin_points._dss_bin = (first, num, N, P, S)   # what the fine pass needs besides the lists
+    return bin_points
+
+
+def _rasterize_fine(points, ellipse_params, cutoff_thres, radii, bin_points, depth_merging_thres: float, image_size: int,
+                    bin_size: int, points_per_pixel: int):
+    """``DSS._C._rasterize_fine`` (ext.cpp:12, rasterize_points.h:257-285) on the ``bin_points`` of
+    :func:`_rasterize_coarse` -> ``(idx, zbuf, qvalue, occupancy)`` like ``splat_points``."""
+    lib = _lib.load()
+    meta = getattr(bin_points, "_dss_bin", None)
+    if meta is None:
+        raise RuntimeError("bin_points must come from dss_amd.ops._rasterize_coarse (opaque tile lists, not the "
+                           "reference's dense (N,B,B,M) table)")
+    first, num, N, P, S = meta
+    if int(image_size) != S or points.shape[0] != P:
+        raise RuntimeError("bin_points were built for image_size=%d and %d points" % (S, P))
+    _check_raster_inputs(points, ellipse_params, cutoff_thres, radii, first, num)
+    points = _lib.require_gpu(points, "points", _f32)
+    dev = points.device
+    ellipse_params = _lib.require_gpu(ellipse_params, "ellipse_params", _f32)
+    cutoff_thres = _lib.require_gpu(cutoff_thres, "cutoff_thres", _f32)
+    radii = _lib.require_gpu(radii, "radii", _f32)
+    K = int(points_per_pixel)
+    with torch.cuda.device(dev):
+        idx = torch.empty((N, S, S, K), dtype=_i32, device=dev)
+        zbuf = torch.empty((N, S, S, K), dtype=_f32, device=dev)
+        qv = torch.empty((N, S, S, K), dtype=_f32, device=dev)
+        occ = torch.empty((N, S, S), dtype=_f32, device=dev)
+        rc = lib.dss_splat_fine(_lib.ptr(points), _lib.ptr(ellipse_params), _lib.ptr(cutoff_thres), _lib.ptr(radii),
+                                _lib.ptr(first), _lib.ptr(num), N, P, float(depth_merging_thres), S, K, 0, S, _lib.ptr(idx),
+                                _lib.ptr(zbuf), _lib.ptr(qv), _lib.ptr(occ), None, _lib.ptr(bin_points) if P > 0 else None,
+                                bin_points.numel(), _lib.stream_ptr(dev))
+    _lib.check(rc, "dss_splat_fine")
+    return idx, zbuf, qv, occ
+
+
+def _splat_points_occ_backward(points, radii, grad_occ, cloud_to_packed_first_idx, num_points_per_cloud, radii_s: float,
+                               depth_merging_thres: float = 0.0):
+    """``DSS._C._splat_points_occ_backward`` on GPU tensors (ext.cpp:10, 16; rasterize_points.cu:672-822): the
+    box-supported occupancy surrogate over ALL points handed in -> (P,2).  Not on the training path
+    (``backward_occ_fast = True``, rasterizer.py:816).  ``depth_merging_thres`` is unused, as in the reference."""
+    lib = _lib.load()
+    points = _lib.require_gpu(points, "points", _f32)
+    dev = points.device
+    radii = _lib.require_gpu(radii, "radii", _f32)
+    grad_occ = _lib.require_gpu(grad_occ, "grad_occ", _f32)
+    first = _lib.require_gpu(cloud_to_packed_first_idx, "cloud_to_packed_first_idx", _i64)
+    num = _lib.require_gpu(num_points_per_cloud, "num_points_per_cloud", _i64)
+    if points.dim() != 2 or points.shape[1] != 3 or tuple(radii.shape) != (points.shape[0], 2) or first.shape != num.shape:
+        raise RuntimeError("points must be (P,3), radii (P,2), first_idx / num_points (N,)")  # rasterize_points.h:357-361
+    N, P = first.shape[0], points.shape[0]
+    if grad_occ.dim() != 3 or grad_occ.shape[0] != N or grad_occ.shape[1] != grad_occ.shape[2]:
+        raise RuntimeError("grad_occ must be (N,S,S) with N=%d, got %s" % (N, tuple(grad_occ.shape)))
+    with torch.cuda.device(dev):
+        grad = torch.empty((P, 2), dtype=_f32, device=dev)
+        rc = lib.dss_occ_backward_box(_lib.ptr(points), _lib.ptr(radii), _lib.ptr(grad_occ), _lib.ptr(first), _lib.ptr(num),
+                                      N, P, grad_occ.shape[1], float(radii_s), _lib.ptr(grad), _lib.stream_ptr(dev))
+    _lib.check(rc, "dss_occ_backward_box")
+    return grad
+
+
+def _splat_points_occ_fast_cuda_backward(points_sorted, radii_sorted, rs, grad_occ, num_points_per_cloud,
+                                         cloud_to_packed_first_idx, points_grid_off=None, grid_params=None):
+    """``DSS._C._splat_points_occ_fast_cuda_backward`` (ext.cpp:14, rasterize_points_backward.cu:227-322) -> (P,2) in the
+    order of ``points_sorted``.  Every point handed in takes part (the reference passes the visible points only,
+    rasterizer.py:863-864, 951-952).  ``points_grid_off`` / ``grid_params`` -- the FRNN grid that only accelerates the
+    reference's pixel-centric search -- are accepted and ignored: the gather kernel needs no grid, so the points need
+    not be sorted either (and the last-cell bug of :124-126 cannot occur)."""
+    all_points = torch.ones(points_sorted.shape[0], dtype=_u8, device=points_sorted.device)
+    return occ_backward(points_sorted, radii_sorted, all_points, rs, grad_occ, cloud_to_packed_first_idx,
+                        num_points_per_cloud)[:, :2].contiguous()
 
 
 def backward_radius(radii, visible, cloud_to_packed_first_idx, num_points_per_cloud, radii_s: float):
@@ -136,6 +239,8 @@ def occ_backward(points, radii, visible, rs, grad_occ, cloud_to_packed_first_idx
     row0, row1 = (0, S) if rows is None else (int(rows[0]), int(rows[1]))
     if tuple(grad_occ.shape) != (N, row1 - row0, S):
         raise RuntimeError("grad_occ must have shape (%d, %d, %d), got %s" % (N, row1 - row0, S, tuple(grad_occ.shape)))
+    if row1 <= row0:  # empty band: no pixel contributes
+        return torch.zeros((P, 3), dtype=_f32, device=dev)
     grad_occ, gstride = _pixel_strided(grad_occ, N, row1 - row0, S)
     with torch.cuda.device(dev):
         grad = torch.empty((P, 3), dtype=_f32, device=dev)
@@ -315,8 +420,16 @@ def render_forward(world, normals, h, M, V, znear, zfar, cloud_to_packed_first_i
         raise RuntimeError("h must have %d (per point) or %d (per cloud) entries" % (Pw, N))
     S, K, C = int(image_size), int(points_per_pixel), features.shape[1]
     row0, row1 = (0, S) if rows is None else (int(rows[0]), int(rows[1]))
-    nr = row1 - row0
+    nr = max(row1 - row0, 0)
     e = lambda *shape, dtype=_f32: torch.empty(shape, dtype=dtype, device=dev)
+    if nr == 0:
+        # empty row band (multi-GPU rank without rows): only the per-point setup runs; no fragments, nothing visible
+        o = point_setup(world, normals, h, M, V, znear, zfar, first, num, S, cutoff_threshold, antialiasing_sigma,
+                        backface_culling, shared_cloud, vr6=vr6, frame_normals=frame_normals)
+        vis = torch.zeros(P, dtype=_u8, device=dev) if out_visible is None else out_visible.zero_()
+        o.update(idx=e(N, 0, S, K, dtype=_i32), zbuf=e(N, 0, S, K), qvalue=e(N, 0, S, K), occupancy=e(N, 0, S),
+                 image=e(N, 0, S, C + 1) if out_image is None else out_image, wsum=e(N, 0, S), visible=vis.view(torch.bool))
+        return o
     with torch.cuda.device(dev):
         o = dict(pts_screen=e(P, 3), ellipse_params=e(P, 3), radii=e(P, 2), scaler=e(P), cutoff_threshold=e(P),
                  idx=e(N, nr, S, K, dtype=_i32), zbuf=e(N, nr, S, K), qvalue=e(N, nr, S, K), occupancy=e(N, nr, S),
@@ -374,7 +487,7 @@ def render_backward(grad_out, idx, qvalue, wsum, scaler, points, radii, visible,
     P = points.shape[0]
     S = int(image_size) if image_size is not None else W
     row0, row1 = (0, S) if rows is None else (int(rows[0]), int(rows[1]))
-    if W != S or H != row1 - row0 or tuple(grad_out.shape[:3]) != (N, H, W):
+    if W != S or H != max(row1 - row0, 0) or tuple(grad_out.shape[:3]) != (N, H, W):
         raise RuntimeError("render_backward needs idx (N,rows,S,K) and grad_out (N,rows,S,C+1)")
     with torch.cuda.device(dev):
         if out is not None:  # caller-provided (P,C) / (P,3) float32 views, e.g. slices of one all-reduce bucket
@@ -385,6 +498,13 @@ def render_backward(grad_out, idx, qvalue, wsum, scaler, points, radii, visible,
         else:
             gf = torch.empty((P, C), dtype=_f32, device=dev) if with_features else None
             gp = torch.empty((P, 3), dtype=_f32, device=dev)
+        if H == 0:  # empty row band: zero partial sums (the search radius still follows the global visibility)
+            if gf is not None:
+                gf.zero_()
+            gp.zero_()
+            if return_rs:
+                return gf, gp, backward_radius(radii, vis, first, num, radii_s)
+            return gf, gp
         rs = torch.empty((N,), dtype=_f32, device=dev)
         ws = _lib.workspace(dev, lib.dss_render_backward_workspace(N, P, S))
         rc = lib.dss_render_backward(_lib.ptr(grad_out), _lib.ptr(idx), _lib.ptr(qvalue), _lib.ptr(wsum),

@@ -139,6 +139,17 @@ DSS_API int dss_occ_backward(const float *points, const float *radii, const uint
                      int row0, int row1, int grad_pixel_stride, float clip,
                      float *grad_pts /* (P,3) */, void *stream);
 
+/* Box-supported occupancy surrogate: DSS._C._splat_points_occ_backward on CUDA tensors (ext.cpp:10, 16;
+ * RasterizePointsOccBackwardCudaKernel, rasterize_points.cu:672-757).  Not on the training path
+ * (`backward_occ_fast = True`, rasterizer.py:816); kept so that every DSS._C export has a counterpart.
+ *   for every pixel with g = grad_occ != 0 and every point p of the same cloud with pz>=0, |px|<=1, |py|<=1,
+ *   R = radii[p]*radii_s, |dx|<=Rx, |dy|<=Ry:  skip if g>0 and (|dx|>Rx/radii_s or |dy|>Ry/radii_s);
+ *   grad_xy[p] += (dx,dy)/max(d2,1e-10)*g     (d2 == 0 contributes 0; the reference yields NaN).
+ * grad_occ dense (N,S,S); grad_xy (P,2) fully written.  One wavefront per point, no atomics. */
+DSS_API int dss_occ_backward_box(const float *points, const float *radii, const float *grad_occ,
+                                 const int64_t *first_idx, const int64_t *num_pts, int N, int64_t P, int S,
+                                 float radii_s, float *grad_xy /* (P,2) */, void *stream);
+
 /* Replaces DSS._C._backward_zbuf (ext.cpp:17, rasterize_points.cu:823-846): accumulates IN PLACE
  * z_grad[idx[n,r,c,k]] += grad_zbuf[n,r,c,k] (zero grads skipped, stop at first idx<0), into the
  * z column of grad_pts (P,3). */

@@ -133,6 +133,18 @@ def occ_backward_slow_cpu(points, radii, grad_occ, first_idx, num_pts, radii_s):
     return g
 
 
+def occ_backward_slow_cuda(points, radii, grad_occ, first_idx, num_pts, radii_s):
+    """RasterizePointsOccBackwardCudaKernel (rasterize_points.cu:672-757) restated -> (P,2)."""
+    points, radii, grad_occ = _f32(points), _f32(radii), _f32(grad_occ)
+    first_idx, num_pts = _i64(first_idx), _i64(num_pts)
+    N, S = grad_occ.shape[0], grad_occ.shape[1]
+    P = points.shape[0]
+    g = np.zeros((P, 2), np.float32)
+    _lib().oracle_occ_backward_slow_cuda(_p(points), _p(radii), _p(grad_occ), _p(first_idx), _p(num_pts),
+                                         N, ctypes.c_int64(P), S, ctypes.c_float(radii_s), _p(g))
+    return g
+
+
 def zbuf_backward(idx, grad_zbuf, P, z_grad=None):
     idx = np.ascontiguousarray(idx, np.int32)
     grad_zbuf = _f32(grad_zbuf)

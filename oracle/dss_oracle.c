@@ -395,6 +395,49 @@ DSS_ORACLE_API void oracle_occ_backward_slow_cpu(
 }
 
 /* ---------------------------------------------------------------------------------------
+ * SLOW occupancy backward, CUDA semantics: RasterizePointsOccBackwardCudaKernel, rasterize_points.cu:672-757
+ * (`DSS._C._splat_points_occ_backward` on CUDA tensors; logical OR in the support test, eps 1e-10, d2 == 0 -> device
+ * eps_denom gives 0/0 = NaN in the reference, 0 here).  Pinned against the kernel itself, host-compiled and executed
+ * (oracle/ref_cuda_host.cpp, tests/golden/make_golden_fast_backward.py).  Double accumulation like the fast form.
+ * ------------------------------------------------------------------------------------- */
+DSS_ORACLE_API void oracle_occ_backward_slow_cuda(
+    const float *points, const float *radii, const float *grad_occ,
+    const int64_t *first_idx, const int64_t *num_pts, int N, int64_t P, int S, float radii_s,
+    float *grad_xy /* (P,2) */)
+{
+    memset(grad_xy, 0, sizeof(float) * (size_t)P * 2);
+    for (int n = 0; n < N; ++n) {
+        const int64_t p0 = first_idx[n], p1 = p0 + num_pts[n];
+        #pragma omp parallel for schedule(dynamic, 64)
+        for (int64_t p = p0; p < p1; ++p) {
+            const float px = points[3 * p], py = points[3 * p + 1], pz = points[3 * p + 2];
+            if (pz < 0 || fabsf(py) > 1.0f || fabsf(px) > 1.0f) continue;
+            const float radiix = radii[2 * p] * radii_s, radiiy = radii[2 * p + 1] * radii_s;
+            double gx = 0.0, gy = 0.0;
+            for (int yi = 0; yi < S; ++yi) {
+                const float yf = pix_to_ndc(yi, S);
+                const float dy = yf - py;
+                if (fabsf(dy) > radiiy) continue;
+                for (int xi = 0; xi < S; ++xi) {
+                    const float g = grad_occ[((size_t)n * S + (S - 1 - yi)) * S + (S - 1 - xi)];
+                    if (g == 0.0f) continue;
+                    const float dx = pix_to_ndc(xi, S) - px;
+                    if (fabsf(dx) > radiix) continue;
+                    const int outside = (fabsf(dx) > radiix / radii_s) || (fabsf(dy) > radiiy / radii_s);
+                    if (g > 0.0f && outside) continue;
+                    const float d2 = dx * dx + dy * dy;
+                    if (d2 == 0.0f) continue;
+                    const float den = fmaxf(d2, 1e-10f);
+                    gx += (double)(dx / den * g);
+                    gy += (double)(dy / den * g);
+                }
+            }
+            grad_xy[2 * p] = (float)gx; grad_xy[2 * p + 1] = (float)gy;
+        }
+    }
+}
+
+/* ---------------------------------------------------------------------------------------
  * zbuf backward: z_grad[idx[n,y,x,k]] += grad_zbuf[n,y,x,k]; zero grads skipped, stop at the
  * first idx<0.  rasterize_points.cu:823-846 == rasterize_points_cpu.cpp:479-513.
  * fp32 accumulation in raster order (bit-exact vs the CPU reference).  Accumulates IN PLACE.

@@ -6,6 +6,8 @@
 //   * RasterizePointsBackwardCudaFastKernel   /root/reference/DSS/csrc/rasterize_points_backward.cu:21-212
 //       the occupancy backward the reference actually trains with (`backward_occ_fast = True`,
 //       DSS/core/rasterizer.py:816, 951-952)
+//   * RasterizePointsOccBackwardCudaKernel    /root/reference/DSS/csrc/rasterize_points.cu:672-757
+//       the older box-supported occupancy backward (`_C._splat_points_occ_backward` on CUDA tensors)
 //   * weightedSumCudaForwardKernel / weightedSumCudaBackwardKernel
 //                                              /root/reference/DSS/csrc/weighted_sum.cu:38-134
 //       the reference's copy of pytorch3d's weighted-sum compositor (`compositor=None`, renderer.py:59-65)
@@ -62,6 +64,7 @@ static inline float atomicAdd(float *addr, float v)
 #include "rasterization_utils.cuh"          // -I$(REF)/DSS/csrc: PixToNdc, eps_denom (unmodified)
 #include "_ref/fast_backward_kernel.inc"    // rasterize_points_backward.cu:21-212 (cut by the Makefile)
 #include "_ref/weighted_sum_kernels.inc"    // weighted_sum.cu:38-134 (cut by the Makefile)
+#include "_ref/slow_backward_kernel.inc"    // rasterize_points.cu:672-757 (cut by the Makefile)
 
 template <typename F>
 static void launch(unsigned gx, unsigned gy, unsigned bx, F &&kernel)
@@ -100,6 +103,19 @@ int ref_fast_backward(const float *points_sorted, const float *radii_sorted, con
                                               points_grid_off, grid_params, grad_occ, N, H, W, B, G, grad_points);
     });
     return B;
+}
+
+// RasterizePointsOccBackwardCuda (rasterize_points.cu:759-822): zeros (P,2) (:787), 1024 blocks x 64 threads (:795-796).
+void ref_slow_backward_cuda(const float *points, const float *radii, const int64_t *cloud_to_packed_first_idx,
+                            const int64_t *num_points_per_cloud, float radii_s, int N, int H, int W, const float *grad_occ,
+                            int64_t P, float *grad_points /* (P,2) */)
+{
+    for (int64_t i = 0; i < 2 * P; ++i) grad_points[i] = 0.0f;
+    if (P == 0) return;
+    launch(1024, 1, 64, [&] {
+        RasterizePointsOccBackwardCudaKernel(points, radii, cloud_to_packed_first_idx, num_points_per_cloud, radii_s, N, H,
+                                             W, grad_occ, grad_points);
+    });
 }
 
 using Acc4f = at::PackedTensorAccessor64<float, 4, at::RestrictPtrTraits>;

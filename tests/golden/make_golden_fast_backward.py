@@ -7,7 +7,10 @@ What runs (in this container, CPU only):
     `RasterizePointsBackwardCudaFastKernel` (DSS/csrc/rasterize_points_backward.cu:30-212) compiled for the host by
     oracle/ref_cuda_host.cpp (`make -C oracle ref` -> oracle/_ref/libref_cuda_host.so), launched 1024 x 64 like
     rasterize_points_backward.cu:306-307;
-  * `_C._backward_zbuf` = the reference CPU build (oracle/_ref/dss_ref_cpu).
+  * `_C._backward_zbuf` = the reference CPU build (oracle/_ref/dss_ref_cpu);
+  * separately (`*_slowcuda_grad`): the older `_C._splat_points_occ_backward` in its CUDA form,
+    RasterizePointsOccBackwardCudaKernel (rasterize_points.cu:672-757), host-compiled the same way, on all points with
+    the radii_s stored in the scene's golden file (ragged3: 2.0).
 Third-party pieces that are absent here are replaced by numpy stand-ins of their published behaviour:
   * frnn._C.insert_points_cuda / counting_sort_cuda (lxxue/FRNN, 2-D grid): cell = floor((p - min) * delta) per axis
     clamped to [0, res-1], linear id x*res_y + y (the id the consumer kernel computes, rasterize_points_backward.cu:119),
@@ -146,6 +149,19 @@ def reference_backward(sc, idx, zbuf, grad_occ, grad_zbuf, radii_s, thr):
     return grad.astype(np.float32), lastcell
 
 
+def slow_cuda_backward(sc, grad_occ, radii_s):
+    """`DSS._C._splat_points_occ_backward` on CUDA tensors = RasterizePointsOccBackwardCudaKernel
+    (rasterize_points.cu:672-757), host-compiled and executed: every point handed in takes part."""
+    pts, radii = (torch.from_numpy(np.ascontiguousarray(sc[k], np.float32)) for k in ("points", "radii"))
+    first, num = (torch.from_numpy(np.ascontiguousarray(sc[k], np.int64)) for k in ("first_idx", "num_pts"))
+    gocc = torch.from_numpy(np.ascontiguousarray(grad_occ, np.float32))
+    N, H, W = gocc.shape
+    grad = torch.empty((pts.shape[0], 2), dtype=torch.float32)
+    HOST.ref_slow_backward_cuda(_p(pts), _p(radii), _p(first), _p(num), ctypes.c_float(radii_s), N, H, W, _p(gocc),
+                                ctypes.c_int64(pts.shape[0]), _p(grad))
+    return grad.numpy()
+
+
 def main():
     out = {}
     # scenes with committed forward goldens (ref_idx = output of the compiled reference CPU rasterizer)
@@ -157,6 +173,7 @@ def main():
                                                 z["thr"])
             out["%s_s%g_grad" % (name, radii_s)] = grad
             out["%s_s%g_lastcell" % (name, radii_s)] = lastcell
+        out[name + "_slowcuda_grad"] = slow_cuda_backward(sc, z["grad_occ"], float(z["radii_s"]))
     # three ragged clouds in one batch (exercises first_idx handling and the last-cell behaviour twice)
     S, K, thr = 80, 4, 0.3
     sc = scenes.random_splats(800, S, 3, seed=21)
@@ -178,6 +195,7 @@ def main():
     for radii_s in (5.0, 2.0):
         grad, lastcell = reference_backward(sc, idx.numpy(), zbuf.numpy(), gocc, gz, radii_s, thr)
         out["ragged3_s%g_grad" % radii_s], out["ragged3_s%g_lastcell" % radii_s] = grad, lastcell
+    out["ragged3_slowcuda_grad"] = slow_cuda_backward(sc, gocc, 2.0)
     # a point exactly on a pixel centre: d^2 == 0 -> NaN in the reference (known divergence)
     S = 16
     c = np.float32(-1) + np.float32(2 * 5 + 1) / np.float32(S)        # centre of NDC index 5 (exact in fp32)

@@ -317,6 +317,46 @@ def test_blend_vs_executed_reference_renderer_golden(golden_dir, name):
         assert np.abs(out4.cpu().numpy() - ref_img).max() <= 1e-4 * max(1.0, float(np.abs(ref_img).max()))
 
 
+def test_dss_c_same_name_mirrors(golden_dir):
+    """The four `DSS._C` exports beyond splat_points / _splat_points_naive / _backward_zbuf (ext.cpp:10-12, 14), under
+    their reference names and argument order in dss_amd.ops: coarse + fine == splat_points bit for bit; the fast CUDA
+    backward on sorted visible points == the executed reference kernel's golden; the box-supported slow backward ==
+    the executed RasterizePointsOccBackwardCudaKernel golden."""
+    g = np.load(os.path.join(golden_dir, "ref_fast_backward.npz"))
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    for name in ("ref_random64x2", "ref_teapot256"):
+        z = np.load(os.path.join(golden_dir, name + ".npz"))
+        S, K, thr = int(z["S"]), int(z["K"]), float(z["thr"])
+        d = _dev(z)
+        bins = ops._rasterize_coarse(d["points"], d["radii"], d["first"], d["num"], S, 16, 10000)
+        out = ops._rasterize_fine(d["points"], d["ellipse"], d["cutoff"], d["radii"], bins, thr, S, 16, K)
+        for a, k in zip(out, ("ref_idx", "ref_zbuf", "ref_qvalue", "ref_occ")):
+            assert np.array_equal(a.cpu().numpy(), z[k]), k
+        with pytest.raises(RuntimeError):
+            ops._rasterize_fine(d["points"], d["ellipse"], d["cutoff"], d["radii"], torch.zeros(8, device=DEV), thr, S, 16, K)
+        # _splat_points_occ_backward (CUDA form): every point, box support radii * radii_s
+        got = ops._splat_points_occ_backward(d["points"], d["radii"], t(z["grad_occ"]), d["first"], d["num"],
+                                             float(z["radii_s"]), thr)
+        assert tuple(got.shape) == (z["points"].shape[0], 2)
+        assert _rel_l2(got.cpu().numpy(), g[name + "_slowcuda_grad"]) <= 1e-5
+        # _splat_points_occ_fast_cuda_backward called like rasterizer.py:951-952: visible points only, any order
+        P = z["points"].shape[0]
+        vis = oracle.visibility(z["ref_idx"], P)
+        ids = np.nonzero(vis)[0]
+        rng = np.random.default_rng(3)
+        first_v = np.concatenate([[0], np.cumsum([vis[f:f + n].sum() for f, n in zip(z["first_idx"], z["num_pts"])])[:-1]])
+        num_v = np.array([vis[f:f + n].sum() for f, n in zip(z["first_idx"], z["num_pts"])], np.int64)
+        order = np.concatenate([f + rng.permutation(n) for f, n in zip(first_v, num_v)]).astype(np.int64)  # "sorted" order
+        sel = ids[order]
+        for radii_s in (5.0, 1.0):
+            rs = oracle.backward_radius(z["radii"], vis, z["first_idx"], z["num_pts"], radii_s)
+            gs = ops._splat_points_occ_fast_cuda_backward(t(z["points"][sel]), t(z["radii"][sel]), t(rs), t(z["grad_occ"]),
+                                                          t(num_v), t(first_v.astype(np.int64)), None, None)
+            ref = g["%s_s%g_grad" % (name, radii_s)]
+            keep = ~g["%s_s%g_lastcell" % (name, radii_s)][sel]
+            assert _rel_l2(gs.cpu().numpy()[keep], ref[sel][keep, :2]) <= 1e-5
+
+
 def test_point_on_pixel_centre_contributes_zero():
     """point-one KAT: a point exactly on a pixel centre (reference: 0/0 = NaN, documented divergence)."""
     S = 8
@@ -488,6 +528,25 @@ def test_render_backward_search_radius_sweep(radii_s):
     o_gf, _ = oracle.blend_backward(go.cpu().numpy(), idx.cpu().numpy(), qv.cpu().numpy(), sc["scaler"], P)
     assert np.array_equal(rs.cpu().numpy(), o_rs)
     assert _rel_l2(g.cpu().numpy(), o_g) <= 1e-4 and _rel_l2(gf.cpu().numpy(), o_gf) <= 1e-4
+
+
+def test_empty_row_band_is_a_no_op():
+    """RowPartition can hand a rank an empty band (e.g. S=10 over 8 ranks gives row0 == row1): every op short-circuits
+    instead of rejecting row0 >= row1 -- no fragments, nothing visible, zero partial gradients."""
+    sc = scenes.random_splats(500, 40, 2, seed=5)
+    d = _dev(sc)
+    idx, zbuf, qv, occ, vis = _fwd(d, 40, 5, 0.3, rows=(16, 16), return_visible=True)
+    assert tuple(idx.shape) == (2, 0, 40, 5) and tuple(occ.shape) == (2, 0, 40) and not bool(vis.any())
+    full = _fwd(d, 40, 5, 0.3, return_visible=True)
+    scaler = torch.from_numpy(sc["scaler"]).to(DEV)
+    go = torch.zeros((2, 0, 40, 4), device=DEV)
+    gf, gp, rs = ops.render_backward(go, idx, qv, None, scaler, d["points"], d["radii"], full[4], d["first"], d["num"], 4.0,
+                                     -1.0, image_size=40, rows=(16, 16), return_rs=True)
+    assert not bool(gf.any()) and not bool(gp.any())
+    assert torch.equal(rs, ops.backward_radius(d["radii"], full[4], d["first"], d["num"], 4.0))
+    g = ops.occ_backward(d["points"], d["radii"], full[4], rs, torch.zeros((2, 0, 40), device=DEV), d["first"], d["num"],
+                         image_size=40, rows=(16, 16))
+    assert not bool(g.any())
 
 
 @pytest.mark.parametrize("S,bounds", [(96, (0, 40, 96)), (96, (0, 8, 16, 24, 32, 40, 48, 56, 64, 72, 80, 88, 96)),
