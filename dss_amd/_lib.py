@@ -26,6 +26,7 @@ SIGNATURES = {
     "dss_version": (_c_int, []),
     "dss_last_error": (ctypes.c_char_p, []),
     "dss_splat_forward_workspace": (_c_sz, [_c_int, _c_i64, _c_int, _c_int, _c_int]),
+    "dss_splat_forward_clean_bytes": (_c_sz, [_c_int, _c_i64, _c_int]),
     "dss_splat_forward": (_c_int, [_c_vp] * 6 + [_c_int, _c_i64, _c_f32, _c_int, _c_int, _c_int, _c_int, _c_int]
                           + [_c_vp] * 5 + [_c_vp, _c_sz, _c_vp]),
     "dss_splat_bin": (_c_int, [_c_vp] * 4 + [_c_int, _c_i64, _c_int, _c_int, _c_int, _c_vp, _c_sz, _c_vp]),

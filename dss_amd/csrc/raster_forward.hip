@@ -25,24 +25,29 @@ namespace dss {
 // Each tile owns DSS_SUB counters / sub-lists, selected by the low bits of the splat id.
 // Same-address global atomics serialise (~50 ns each on MI355X: 523 splats on the hottest 16x16 tile of
 // the bunny scene cost ~30 us); splitting cuts the depth of every hot address by DSS_SUB.
-// Sub-lists have a fixed capacity `cap` (workspace layout: counts (N*tiles*SUB) uint32, then lists
-// (N*tiles*SUB*cap) int32), sized ~32x the mean load (see bin_capacity); a count above `cap` marks the
-// tile as overflowed.
+// Sub-lists have a fixed capacity `cap` >= 32 (workspace layout: counts (N*tiles*SUB) uint32, ..., lists
+// (N*tiles*SUB*cap) int32), see bin_capacity; a count above `cap` marks the tile as overflowed.
 #define DSS_SUB 8
 
-// Heavy-first dispatch.  The fine kernel's duration is set by its slowest workgroups (the densest tiles run
-// 2-3x longer than the mean, tools/fine_timing.py) and a launch needs two occupancy rounds at 512^2, so a
-// dense tile that is dispatched late ends the kernel late.  While binning, the thread that brings sub-list 0
-// of a tile to DSS_HEAVY_SUB0 entries (~8x that in the whole tile) appends the tile to a short queue and
-// flags it; the fine kernel's first DSS_HEAVY_MAX workgroups serve the queue, the others skip flagged
-// tiles.  Queue counter and flags live in the memset region of the tile counters.
-#define DSS_HEAVY_MAX 2048
-#define DSS_HEAVY_SUB0 4
-#define DSS_HEAVY_QUEUES 32  // independent queue heads: ~1100 appends per launch on ONE counter serialise (+6 us)
-struct HeavyQ {
-    uint32_t *count;  // DSS_HEAVY_QUEUES words, zeroed with the tile counters (only the binning pass uses them)
-    int32_t *list;    // DSS_HEAVY_MAX slots holding tile id + 1, 0 = empty; zeroed with the tile counters
-    uint8_t *flag;    // one byte per tile, zeroed with the tile counters
+// Queue of OCCUPIED tiles.  The thread whose append is the first of a sub-list (returned position 0) claims the
+// tile with one atomicExch on its flag word; the winner appends the tile to one of DSS_QUEUES queues.  The fine
+// kernel then launches workgroups for queue slots (occupied tiles only) plus a few fat workgroups that stream the
+// fill values of the EMPTY tiles, 16 tiles each: round 1 launched one 256-thread workgroup per tile + 2048 queue
+// workgroups, and tools/fine_timing.py showed the launch bound by workgroup SLOT turnover (6144 workgroups through
+// 2048 resident slots, 3000 of them only to write 5 KB of fill values after one dependent load: median start time
+// 14 us into a 27 us kernel).
+// Queue of a tile = XCD of its 32x32-pixel super-block + 8 * (parity of the tile
+// coordinates): workgroup b serves queue b % 32 and is placed on XCD b % 8 by the dispatcher (observed, used for
+// speed only), so the tiles of one super-block -- which share most of their splat records -- run on ONE XCD's L2:
+// round-robin tiles made every XCD fetch the whole record set (FETCH 7.5x the unique bytes, r1 profiles), an
+// XCD-contiguous split put the dense screen region on one XCD (slower, round 1).
+#define DSS_QUEUES 32
+#define DSS_SB_SHIFT 2   // super-block = 4x4 tiles (32x32 pixels)
+struct TileQueue {
+    uint32_t *tail;   // DSS_QUEUES append counters (binning only; zero when binning starts)
+    int32_t *list;    // DSS_QUEUES x capq slots holding tile id + 1, 0 = empty (zero when binning starts)
+    uint32_t *flag;   // one word per tile: 1 = occupied and queued (zero when binning starts)
+    uint32_t capq;    // slots per queue
 };
 
 struct TileGrid {
@@ -52,6 +57,24 @@ struct TileGrid {
     int tiles_x;  // tiles per band row
     int tiles_y;  // tile rows in the band
 };
+
+// Super-block (i, j) of camera n goes to XCD (i + 3 j + 5 n) mod 8: neighbours in a row differ by 1, in a column by 3, so
+// any compact screen region is spread evenly over the XCDs (the first version dealt the 64x64-pixel super-blocks of a
+// 512^2 image by COLUMN: a centred object then ran on three of the eight XCDs).
+__host__ __device__ __forceinline__ int sb_cols(const TileGrid &g) { return (g.tiles_x + (1 << DSS_SB_SHIFT) - 1) >> DSS_SB_SHIFT; }
+__host__ __device__ __forceinline__ int sb_rows(const TileGrid &g) { return (g.tiles_y + (1 << DSS_SB_SHIFT) - 1) >> DSS_SB_SHIFT; }
+// slots per queue: in every super-block row each XCD gets at most ceil(cols / 8) super-blocks, and a (super-block,
+// parity) pair holds at most (4 x 4) / 4 tiles
+static inline uint32_t queue_capacity(int N, const TileGrid &g)
+{
+    const long long per_cam = (long long)((sb_cols(g) + 7) / 8) * sb_rows(g);
+    return (uint32_t)(per_cam * N * ((1 << DSS_SB_SHIFT) * (1 << DSS_SB_SHIFT) / 4));
+}
+__device__ __forceinline__ int queue_of(int n, int tx, int ty, const TileGrid &g)
+{
+    const int xcd = ((tx >> DSS_SB_SHIFT) + 3 * (ty >> DSS_SB_SHIFT) + 5 * n) & 7;
+    return xcd + 8 * (((ty & 1) << 1) | (tx & 1));
+}
 
 // ---------------------------------------------------------------------------------------------
 // Splat -> tile rectangle (band-local tile coordinates).  Image column c <-> NDC index S-1-c.
@@ -99,25 +122,21 @@ __device__ __forceinline__ bool splat_tile_rect(float px, float py, float pz, fl
     return true;
 }
 
-// exactly one thread per tile gets here (the one whose atomic brought sub-list 0 to the threshold)
-__device__ __forceinline__ void mark_heavy(const HeavyQ hq, int tile)
+// First entry of one of the tile's sub-lists: claim the tile (at most DSS_SUB threads per tile get here, exactly one
+// wins the exchange) and append it to its queue.
+__device__ __forceinline__ void claim_tile(const TileQueue tq, int n, int tx, int ty, const TileGrid g)
 {
-    if (!hq.count) return;
-    // queue q holds list slots q, q + QUEUES, q + 2 QUEUES, ...: workgroup b of the fine kernel reads slot b,
-    // so the queues drain interleaved
-    const uint32_t q = (uint32_t)tile & (DSS_HEAVY_QUEUES - 1);
-    const uint32_t pos = atomicAdd(&hq.count[q], 1u);
-    const uint32_t slot = pos * DSS_HEAVY_QUEUES + q;
-    if (slot < DSS_HEAVY_MAX) {
-        hq.list[slot] = tile + 1;  // 0 = empty slot
-        hq.flag[tile] = 1;  // only queued tiles are flagged: a full queue leaves the rest to the normal workgroups
-    }
+    const int tile = (n * g.tiles_y + ty) * g.tiles_x + tx;
+    if (atomicExch(&tq.flag[tile], 1u) != 0u) return;
+    const int q = queue_of(n, tx, ty, g);
+    const uint32_t pos = atomicAdd(&tq.tail[q], 1u);
+    if (pos < tq.capq) tq.list[(size_t)q * tq.capq + pos] = tile + 1;  // (always true: queue_capacity)
 }
 
 // append splat p to the sub-list (p mod SUB) of every tile of its rectangle
 __device__ __forceinline__ void bin_point(int64_t p, int n, float px, float py, float pz, float rx, float ry,
                                           const TileGrid g, uint32_t *__restrict__ counts,
-                                          int32_t *__restrict__ lists, uint32_t cap, const HeavyQ hq)
+                                          int32_t *__restrict__ lists, uint32_t cap, const TileQueue tq)
 {
     if (n < 0) return;
     int tx0, tx1, ty0, ty1;
@@ -129,7 +148,7 @@ __device__ __forceinline__ void bin_point(int64_t p, int n, float px, float py, 
         const size_t t00 = sub0 + (size_t)(ty0 * g.tiles_x + tx0) * DSS_SUB;
         const size_t t01 = t00 + DSS_SUB, t10 = t00 + (size_t)g.tiles_x * DSS_SUB, t11 = t10 + DSS_SUB;
         const bool hx = tx1 > tx0, hy = ty1 > ty0;
-        uint32_t p0, p1 = 0, p2 = 0, p3 = 0;
+        uint32_t p0, p1 = 1, p2 = 1, p3 = 1;
         p0 = atomicAdd(&counts[t00], 1u);
         if (hx) p1 = atomicAdd(&counts[t01], 1u);
         if (hy) p2 = atomicAdd(&counts[t10], 1u);
@@ -138,11 +157,11 @@ __device__ __forceinline__ void bin_point(int64_t p, int n, float px, float py, 
         if (hx && p1 < cap) lists[t01 * cap + p1] = (int32_t)p;
         if (hy && p2 < cap) lists[t10 * cap + p2] = (int32_t)p;
         if (hx && hy && p3 < cap) lists[t11 * cap + p3] = (int32_t)p;
-        if (((unsigned)p & (DSS_SUB - 1)) == 0) {  // sub-list 0 decides
-            if (p0 == DSS_HEAVY_SUB0 - 1) mark_heavy(hq, (int)(t00 / DSS_SUB));
-            if (hx && p1 == DSS_HEAVY_SUB0 - 1) mark_heavy(hq, (int)(t01 / DSS_SUB));
-            if (hy && p2 == DSS_HEAVY_SUB0 - 1) mark_heavy(hq, (int)(t10 / DSS_SUB));
-            if (hx && hy && p3 == DSS_HEAVY_SUB0 - 1) mark_heavy(hq, (int)(t11 / DSS_SUB));
+        if (tq.flag) {
+            if (p0 == 0) claim_tile(tq, n, tx0, ty0, g);
+            if (p1 == 0) claim_tile(tq, n, tx1, ty0, g);
+            if (p2 == 0) claim_tile(tq, n, tx0, ty1, g);
+            if (p3 == 0) claim_tile(tq, n, tx1, ty1, g);
         }
         return;
     }
@@ -151,14 +170,14 @@ __device__ __forceinline__ void bin_point(int64_t p, int n, float px, float py, 
             const size_t t = sub0 + (size_t)(ty * g.tiles_x + tx) * DSS_SUB;
             const uint32_t pos = atomicAdd(&counts[t], 1u);
             if (pos < cap) lists[t * cap + pos] = (int32_t)p;
-            if (((unsigned)p & (DSS_SUB - 1)) == 0 && pos == DSS_HEAVY_SUB0 - 1) mark_heavy(hq, (int)(t / DSS_SUB));
+            if (tq.flag && pos == 0) claim_tile(tq, n, tx, ty, g);
         }
 }
 
 __global__ __launch_bounds__(256) void bin_kernel(
     const float *__restrict__ points, const float *__restrict__ radii,
     const int64_t *__restrict__ first_idx, const int64_t *__restrict__ num_pts, int N, int64_t P,
-    TileGrid g, uint32_t *__restrict__ counts, int32_t *__restrict__ lists, uint32_t cap, HeavyQ hq,
+    TileGrid g, uint32_t *__restrict__ counts, int32_t *__restrict__ lists, uint32_t cap, TileQueue tq,
     uint8_t *__restrict__ visible_to_clear /* (P) or nullptr */)
 {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -166,13 +185,13 @@ __global__ __launch_bounds__(256) void bin_kernel(
     if (visible_to_clear) visible_to_clear[p] = 0;  // saves a separate memset launch
     const int n = find_cloud(p, first_idx, num_pts, N);
     bin_point(p, n, points[3 * p], points[3 * p + 1], points[3 * p + 2], radii[2 * p], radii[2 * p + 1], g, counts,
-              lists, cap, hq);
+              lists, cap, tq);
 }
 
 // dss_render_forward: per-point setup (culling + projection + EWA terms) fused with the binning --
 // the screen record goes from registers straight into the tile lists.
 __global__ __launch_bounds__(256) void setup_bin_kernel(const SetupArgs A, TileGrid g, uint32_t *__restrict__ counts,
-                                                        int32_t *__restrict__ lists, uint32_t cap, HeavyQ hq,
+                                                        int32_t *__restrict__ lists, uint32_t cap, TileQueue tq,
                                                         uint8_t *__restrict__ visible_to_clear)
 {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -181,7 +200,7 @@ __global__ __launch_bounds__(256) void setup_bin_kernel(const SetupArgs A, TileG
     const int n = find_cloud(p, A.first_idx, A.num_pts, A.N);
     float px, py, pz, rx, ry;
     setup_point(A, p, n, px, py, pz, rx, ry);
-    bin_point(p, n, px, py, pz, rx, ry, g, counts, lists, cap, hq);
+    bin_point(p, n, px, py, pz, rx, ry, g, counts, lists, cap, tq);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -194,10 +213,12 @@ struct FineArgs {
     const uint32_t *counts;    // (N*tiles*DSS_SUB) sub-list fill counts, or nullptr (naive mode)
     const int32_t *lists;      // (N*tiles*DSS_SUB*cap)
     uint32_t cap;              // sub-list capacity
-    HeavyQ heavy;              // heavy-first queue (count == nullptr: identity order)
+    TileQueue queue;           // occupied tiles (list == nullptr: one workgroup per tile, identity order)
+    uint32_t queue_wgs;        // workgroups serving queue slots (DSS_QUEUES x slots per queue); fill workgroups follow
     uint32_t *clean_counts;    // DSS_WS_CLEAN: == counts, every owner resets what it has read; else nullptr
     int32_t *idx;
-    float *zbuf, *qv, *occ;
+    float *zbuf;               // may be nullptr: the depth plane is not written (the fused backward never reads it)
+    float *qv, *occ;
     uint8_t *visible;
     TileGrid g;
     int N, K;
@@ -210,67 +231,6 @@ struct FineArgs {
     // row are contiguous.  Dense (N,rows,S,C+1): rows*S*(C+1) and S*(C+1).  The multi-GPU send buffer is laid out
     // (row, camera, col, ch) so that the all-gathered bands ARE the full image, no reassembly copy.
     long long img_sn, img_sr;
-};
-
-// block id -> tile id.  Identity on purpose.  Consecutive workgroup ids are dealt round-robin to the 8
-// XCDs (each with its own L2); an XCD-contiguous mapping (XCD x owns tiles [x*T/8, (x+1)*T/8)) was
-// measured with an A/B build (round 1, not kept) and is SLOWER (512^2 bunny: 37.3 vs 33.4 us; 8 x 1024^2, 1M points: 1.36
-// vs 1.31 ms): the dense screen region then sits on one XCD, and the write traffic is already at the
-// algorithmic minimum (PMC WRITE_SIZE 22.7 MB vs 22.5 MB) so there is nothing for the shared L2 to merge.
-// Round-robin placement doubles as load balancing here.
-__device__ __forceinline__ int xcd_tile(unsigned b, int total) { return (int)b < total ? (int)b : -1; }
-
-// Candidate source of one tile: its DSS_SUB fixed-capacity sub-lists (binned mode) or the whole cloud
-// (naive mode, or a tile whose sub-list overflowed).  `at(i)` maps the i-th candidate to a splat id.
-struct TileSource {
-    bool use_list;
-    int64_t first;          // cloud scan: first packed index
-    int64_t count;
-    const int32_t *base;    // binned: &lists[tile*SUB*cap]
-    uint32_t cap;
-    uint32_t ps[DSS_SUB + 1];  // prefix sums of the sub-list lengths
-    __device__ __forceinline__ void init(const FineArgs &A, int n, int tile_id)
-    {
-        use_list = false;
-        if (A.counts != nullptr) {
-            const uint4 *c4 = reinterpret_cast<const uint4 *>(A.counts + (size_t)tile_id * DSS_SUB);
-            uint32_t c[DSS_SUB];
-#pragma unroll
-            for (int q = 0; q < DSS_SUB / 4; ++q) {
-                const uint4 u = c4[q];
-                c[4 * q] = u.x; c[4 * q + 1] = u.y; c[4 * q + 2] = u.z; c[4 * q + 3] = u.w;
-            }
-            bool ok = true;
-            ps[0] = 0;
-#pragma unroll
-            for (int q = 0; q < DSS_SUB; ++q) {
-                ok = ok && (c[q] <= A.cap);
-                ps[q + 1] = ps[q] + c[q];
-            }
-            use_list = ok;
-            count = ps[DSS_SUB];
-            cap = A.cap;
-            base = A.lists + (size_t)tile_id * DSS_SUB * A.cap;
-        }
-        if (!use_list) {
-            first = A.first_idx[n];
-            count = A.num_pts[n];
-        }
-    }
-    __device__ __forceinline__ int64_t at(int64_t i) const
-    {
-        if (!use_list) return first + i;
-        // ps[] is only ever indexed with compile-time constants: a dynamic ps[sub] sends the whole array to
-        // scratch memory (measured: +60 MB of HBM writes per launch at 512^2)
-        uint32_t sub = 0, start = 0;
-#pragma unroll
-        for (int q = 1; q < DSS_SUB; ++q) {
-            const bool ge = (uint32_t)i >= ps[q];
-            sub = ge ? (uint32_t)q : sub;
-            start = ge ? ps[q] : start;
-        }
-        return (int64_t)base[(size_t)sub * cap + ((uint32_t)i - start)];
-    }
 };
 
 // K-nearest bookkeeping: one 64-bit key per slot, (z bits << 32) | idx.  Hits have z >= 0
@@ -314,28 +274,112 @@ __device__ __forceinline__ void klist_insert(unsigned long long (&key)[KMAX], fl
     kq[0] = lt[0] ? eq : kq[0];
 }
 
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_u32(unsigned v)
+{
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
+}
+
+// One merge round of the candidate slices: this lane's ascending K-list with the list of the lane CTRL maps to
+// (quad_perm within the pixel's quad: plain VALU moves, no LDS round trip like ds_bpermute / __shfl_xor).
+// Two ascending K-lists A, B -> the K smallest of their union: min(A[i], B[K-1-i]) over i picks exactly those K (as
+// a bitonic sequence), an odd-even transposition network sorts them.  K(K-1)/2 + K compare-exchanges instead of K
+// insertions of ~12K operations each.  Keys are unique across slices (disjoint candidates) except KEY_EMPTY, whose
+// payload is the same everywhere.
+template <int KMAX, int CTRL>
+__device__ __forceinline__ void merge_round(unsigned long long (&key)[KMAX], float (&kq)[KMAX])
+{
+    unsigned long long okey[KMAX];
+    float oq[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        const unsigned lo = dpp_u32<CTRL>((unsigned)key[k]);
+        const unsigned hi = dpp_u32<CTRL>((unsigned)(key[k] >> 32));
+        okey[k] = ((unsigned long long)hi << 32) | lo;
+        oq[k] = __uint_as_float(dpp_u32<CTRL>(__float_as_uint(kq[k])));
+    }
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        const bool lt = okey[KMAX - 1 - k] < key[k];
+        key[k] = lt ? okey[KMAX - 1 - k] : key[k];
+        kq[k] = lt ? oq[KMAX - 1 - k] : kq[k];
+    }
+#pragma unroll
+    for (int round = 0; round < KMAX; ++round) {
+#pragma unroll
+        for (int k = round & 1; k + 1 < KMAX; k += 2) {
+            const bool sw = key[k + 1] < key[k];
+            const unsigned long long ka = key[k], kb = key[k + 1];
+            const float qa = kq[k], qb = kq[k + 1];
+            key[k] = sw ? kb : ka;
+            key[k + 1] = sw ? ka : kb;
+            kq[k] = sw ? qb : qa;
+            kq[k + 1] = sw ? qa : qb;
+        }
+    }
+}
+
 // Work decomposition of one 8x8 tile (one 256-thread workgroup = 4 wavefronts):
 //   wavefront w  -> 4x4 pixel footprint (w%2, w/2) of the tile
-//   lane l       -> pixel (l%16) of the footprint, candidate slice l/16 (4 slices)
-// A pixel's candidates are split 4 ways across lanes 16 apart; each lane keeps its own K-list and
-// the four lists are merged at the end with two xor-shuffle rounds.  At DSS sizes this kernel is
-// bound by instruction issue on the CUs that host the densest screen regions (tools/fine_timing.py),
-// not by bandwidth: small tiles spread a dense region over several CUs, and the candidate slices cut
-// the serial per-pixel chain 4x.
+//   lane l       -> pixel l/4 of the footprint, candidate slice l%4: a pixel's four slices are one lane QUAD
+// A pixel's candidates are split 4 ways; each lane keeps its own K-list and the four lists are merged at the end with
+// two quad_perm DPP rounds.  At DSS sizes this kernel is bound by latency on the CUs that host the densest screen
+// regions, not by bandwidth: small tiles spread a dense region over several CUs, and the candidate slices cut the
+// serial per-pixel chain 4x.
 #define FOOT 4
 #define FOOT_PER_ROW (DSS_TILE / FOOT)
 #define FINE_WAVES (FOOT_PER_ROW * FOOT_PER_ROW)
 #define FINE_THREADS (FINE_WAVES * 64)
 #define CHUNK FINE_THREADS
+#define SPEC 32   // list entries per sub-list and chunk: DSS_SUB * SPEC == CHUNK
+static_assert(DSS_SUB * SPEC == CHUNK, "one list slot per thread and chunk");
+
+// fill values of the rows [row_begin, valid rows) step row_step of one EMPTY tile, written by one wavefront
+__device__ __forceinline__ void fill_tile_rows(const FineArgs &A, int tile_id, int lane, int row_begin, int row_step)
+{
+    const TileGrid g = A.g;
+    const int tiles = g.tiles_x * g.tiles_y;
+    const int n = tile_id / tiles;
+    const int t = tile_id - n * tiles;
+    const int ty = t / g.tiles_x, tx = t - ty * g.tiles_x;
+    const int S = g.S, K = A.K;
+    const int c0 = tx * DSS_TILE;
+    const int cols = min(DSS_TILE, S - c0);
+    const int valid_cols = cols * K;
+    const int valid_rows = min(DSS_TILE, g.rows - ty * DSS_TILE);
+    const size_t tile_base = (((size_t)n * g.rows + (size_t)ty * DSS_TILE) * S + c0) * K;
+    for (int rr = row_begin; rr < valid_rows; rr += row_step) {
+        const size_t rb = tile_base + (size_t)rr * S * K;
+        for (int cc = lane; cc < valid_cols; cc += 64) {
+            A.idx[rb + cc] = -1;
+            if (A.zbuf) A.zbuf[rb + cc] = -1.0f;
+            A.qv[rb + cc] = -1.0f;
+        }
+        if (lane < cols) {
+            const size_t pix = ((size_t)n * g.rows + (size_t)ty * DSS_TILE + rr) * S + c0 + lane;
+            A.occ[pix] = 0.0f;
+            if (A.image) {  // fused blend of an empty pixel: zeros, weight sum clamped to kEpsilon
+                float *o = A.image + (size_t)n * A.img_sn + (size_t)(ty * DSS_TILE + rr) * A.img_sr +
+                           (size_t)(c0 + lane) * (A.C + 1);
+                if (A.C == 3) {
+                    *reinterpret_cast<float4 *>(o) = make_float4(0.f, 0.f, 0.f, 0.f);
+                } else {
+                    for (int ch = 0; ch <= A.C; ++ch) o[ch] = 0.0f;
+                }
+                A.wsum[pix] = 1e-4f;
+            }
+        }
+    }
+}
 
 template <int KMAX>
-__device__ __forceinline__ void fine_tile(const FineArgs &A, const int tile_id)
+__device__ __forceinline__ void fine_tile(const FineArgs &A, const int tile_id, int32_t *slot_to_clear)
 {
     // candidate chunk: three records per splat -> 2x ds_read_b128 + 1x ds_read_b64 per test
     __shared__ float4 s_geo[CHUNK];   // px, py, rx, ry
     __shared__ float4 s_ell[CHUNK];   // a, b, c, cutoff
     __shared__ float2 s_zid[CHUNK];   // pz, idx (bits)
-    __shared__ unsigned short s_surv[FINE_WAVES][CHUNK];  // per-wavefront compacted survivor slots
+    __shared__ unsigned short s_surv[FINE_WAVES][4][CHUNK / 4];  // per wavefront and slice: compacted survivor slots
     constexpr int PLANES = (KMAX <= 8) ? 3 : 1;   // idx / zbuf / qvalue staged together when they fit
     __shared__ int s_out[PLANES][DSS_TILE_PIX * KMAX];
 
@@ -349,7 +393,7 @@ __device__ __forceinline__ void fine_tile(const FineArgs &A, const int tile_id)
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int fx = wid % FOOT_PER_ROW, fy = wid / FOOT_PER_ROW;  // footprint inside the tile
-    const int pl = lane & 15, slice = lane >> 4;      // pixel inside the footprint, candidate slice
+    const int pl = lane >> 2, slice = lane & 3;       // pixel inside the footprint, candidate slice
     const int tr = fy * FOOT + (pl >> 2), tc = fx * FOOT + (pl & 3);
     const int r = g.row0 + ty * DSS_TILE + tr;        // image row
     const int c = tx * DSS_TILE + tc;                 // image col
@@ -362,12 +406,47 @@ __device__ __forceinline__ void fine_tile(const FineArgs &A, const int tile_id)
     const float f_xmax = ndc(S - 1 - fc0), f_xmin = ndc(S - 1 - (fc0 + 3));
     const float f_ymax = ndc(S - 1 - fr0), f_ymin = ndc(S - 1 - (fr0 + 3));
 
-    // candidate source: tile sub-lists (binned) or the whole cloud (naive / overflowed tile)
-    TileSource src;
-    src.init(A, n, tile_id);
-    const int64_t count = src.count;
+    // ---- candidate source: the tile's DSS_SUB sub-lists (thread -> sub-list tid/32, slot tid%32 of every chunk) or
+    // the whole cloud (naive mode, or a tile with an overflowed sub-list).  The first chunk's list entries are
+    // requested SPECULATIVELY, together with the counters: slot < 32 <= cap is always a legal address, the counters
+    // only decide afterwards which of the entries exist (one dependent round trip less per tile).
+    const uint32_t my_sub = (uint32_t)tid / SPEC, my_slot = (uint32_t)tid % SPEC;
+    bool use_list = false;
+    uint32_t c_mine = 0, cmax = 0;
+    uint32_t cs[DSS_SUB];  // the tile's sub-list counts (wave-uniform)
+    const int32_t *lbase = nullptr;
+    int32_t id_next = 0;
+    if (A.counts != nullptr) {
+        lbase = A.lists + ((size_t)tile_id * DSS_SUB + my_sub) * A.cap;
+        id_next = lbase[my_slot];
+        const uint4 *c4 = reinterpret_cast<const uint4 *>(A.counts + (size_t)tile_id * DSS_SUB);
+#pragma unroll
+        for (int q = 0; q < DSS_SUB / 4; ++q) {
+            const uint4 u = c4[q];  // the same address in every lane: wave-uniform values -> SGPRs
+            cs[4 * q] = (uint32_t)__builtin_amdgcn_readfirstlane((int)u.x);
+            cs[4 * q + 1] = (uint32_t)__builtin_amdgcn_readfirstlane((int)u.y);
+            cs[4 * q + 2] = (uint32_t)__builtin_amdgcn_readfirstlane((int)u.z);
+            cs[4 * q + 3] = (uint32_t)__builtin_amdgcn_readfirstlane((int)u.w);
+        }
+        use_list = true;
+#pragma unroll
+        for (int q = 0; q < DSS_SUB; ++q) {
+            use_list = use_list && (cs[q] <= A.cap);
+            cmax = max(cmax, cs[q]);
+            c_mine = (my_sub == (uint32_t)q) ? cs[q] : c_mine;  // static indices only: a dynamic cs[sub] goes to scratch
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < DSS_SUB; ++q) cs[q] = 0;
+    }
+    int64_t first = 0, count = cmax;
+    if (!use_list) {
+        first = A.first_idx[n];
+        count = A.num_pts[n];
+    }
+    const int step = use_list ? SPEC : CHUNK;
 
-    // rows of the tile are contiguous runs of 16*K dwords in the (N,rows,S,K) tensors
+    // rows of the tile are contiguous runs of 8*K dwords in the (N,rows,S,K) tensors
     const int K = A.K;
     const int run = DSS_TILE * K;
     const int c0 = tx * DSS_TILE;
@@ -378,29 +457,8 @@ __device__ __forceinline__ void fine_tile(const FineArgs &A, const int tile_id)
     FT_MARK(1);
     FT_VAL(10, count);
     if (count <= 0) {
-        // empty tile (most of the screen): stream the fill values, no LDS, no barriers
-        for (int rr = wid; rr < valid_rows; rr += FINE_WAVES) {
-            const size_t rb = tile_base + (size_t)rr * S * K;
-            for (int cc = lane; cc < valid_cols; cc += 64) {
-                A.idx[rb + cc] = -1;
-                A.zbuf[rb + cc] = -1.0f;
-                A.qv[rb + cc] = -1.0f;
-            }
-            if (lane < min(DSS_TILE, S - c0)) {
-                const size_t pix = ((size_t)n * g.rows + (size_t)ty * DSS_TILE + rr) * S + c0 + lane;
-                A.occ[pix] = 0.0f;
-                if (A.image) {  // fused blend of an empty pixel: zeros, weight sum clamped to kEpsilon
-                    float *o = A.image + (size_t)n * A.img_sn + (size_t)(ty * DSS_TILE + rr) * A.img_sr +
-                               (size_t)(c0 + lane) * (A.C + 1);
-                    if (A.C == 3) {
-                        *reinterpret_cast<float4 *>(o) = make_float4(0.f, 0.f, 0.f, 0.f);
-                    } else {
-                        for (int ch = 0; ch <= A.C; ++ch) o[ch] = 0.0f;
-                    }
-                    A.wsum[pix] = 1e-4f;
-                }
-            }
-        }
+        // empty tile in identity order (naive mode with an empty cloud): stream the fill values, no LDS, no barriers
+        fill_tile_rows(A, tile_id, lane, wid, FINE_WAVES);
         FT_MARK(7);
         FT_VAL(9, __builtin_amdgcn_s_memrealtime());
         return;
@@ -413,40 +471,67 @@ __device__ __forceinline__ void fine_tile(const FineArgs &A, const int tile_id)
         key[k] = KEY_EMPTY;
         kq[k] = -1.0f;
     }
-    unsigned short *surv = s_surv[wid];
+    unsigned short *surv = &s_surv[wid][0][0];
 
-    for (int64_t base = 0; base < count; base += CHUNK) {
-        const int m = (int)min((int64_t)CHUNK, count - base);
-        __syncthreads();  // previous chunk fully consumed
-        // DSS_WS_CLEAN: every thread has read the tile's counters (src.init) before this barrier
-        if (base == 0 && A.clean_counts && tid < DSS_SUB) A.clean_counts[(size_t)tile_id * DSS_SUB + tid] = 0;
-        if (tid < m) {
-            const int64_t p = src.at(base + tid);
+    for (int64_t base = 0; base < count; base += step) {
+        // this thread's candidate of the chunk and its slot in the (dense) LDS staging area
+        bool have;
+        int64_t p;
+        int dst, m;
+        if (use_list) {
+            have = (uint32_t)base + my_slot < c_mine;
+            p = id_next;
+            // the next chunk's entry is requested now and arrives while this chunk is processed
+            if ((uint32_t)base + SPEC + my_slot < c_mine) id_next = lbase[(uint32_t)base + SPEC + my_slot];
+            // sub-list q contributes clamp(count - base, 0, 32) entries to this chunk; they are packed in sub-list order
+            uint32_t before = 0, total = 0;
+#pragma unroll
+            for (int q = 0; q < DSS_SUB; ++q) {
+                const uint32_t mq = cs[q] > (uint32_t)base ? min(cs[q] - (uint32_t)base, (uint32_t)SPEC) : 0u;  // scalar
+                before += ((uint32_t)q < my_sub) ? mq : 0u;
+                total += mq;
+            }
+            dst = (int)(before + my_slot);
+            m = (int)total;
+        } else {
+            have = base + tid < count;
+            p = first + base + tid;
+            dst = tid;
+            m = (int)min((int64_t)CHUNK, count - base);
+        }
+        __syncthreads();  // previous chunk fully consumed; first pass: every thread has read the tile's counters
+        if (base == 0) {
+            // DSS_WS_CLEAN: this workgroup is the only reader of the tile's counters and of its queue slot
+            if (A.clean_counts && tid < DSS_SUB) A.clean_counts[(size_t)tile_id * DSS_SUB + tid] = 0;
+            if (slot_to_clear && tid == DSS_SUB) *slot_to_clear = 0;
+        }
+        if (have) {
             const float px = A.points[3 * p], py = A.points[3 * p + 1], pz = A.points[3 * p + 2];
             const float2 rr = reinterpret_cast<const float2 *>(A.radii)[p];
-            s_geo[tid] = make_float4(px, py, rr.x, rr.y);
-            s_ell[tid] = make_float4(A.ellipse[3 * p], A.ellipse[3 * p + 1], A.ellipse[3 * p + 2], A.cutoff[p]);
-            s_zid[tid] = make_float2(pz, __int_as_float((int)p));
+            s_geo[dst] = make_float4(px, py, rr.x, rr.y);
+            s_ell[dst] = make_float4(A.ellipse[3 * p], A.ellipse[3 * p + 1], A.ellipse[3 * p + 2], A.cutoff[p]);
+            s_zid[dst] = make_float2(pz, __int_as_float((int)p));
         }
         __syncthreads();
         if (base == 0) FT_MARK(2);
-        // ---- cull + compact: one candidate per lane, ballot, prefix popcount -> survivor list ----
+        // ---- cull + compact: one candidate per lane, ballot, prefix popcount -> per-slice survivor lists ----
         int nsurv = 0;
-        for (int sub = 0; sub < m; sub += 64) {
-            const int j = sub + lane;
+        for (int sub64 = 0; sub64 < m; sub64 += 64) {
+            const int j = sub64 + lane;
             bool keep = false;
             if (j < m) {
                 const float4 ge = s_geo[j];
-                // conservative, rounding-monotone rejection against the footprint (see splat_tile_rect)
-                const bool out = (s_zid[j].x < 0) || ((f_xmax - ge.x) < -ge.z) || ((f_xmin - ge.x) > ge.z) ||
-                                 ((f_ymax - ge.y) < -ge.w) || ((f_ymin - ge.y) > ge.w);
+                // conservative, rounding-monotone rejection against the footprint (see splat_tile_rect); bitwise on
+                // purpose: short-circuit forms compile to nested exec-mask branches
+                const bool out = (int)(s_zid[j].x < 0) | (int)((f_xmax - ge.x) < -ge.z) | (int)((f_xmin - ge.x) > ge.z) |
+                                 (int)((f_ymax - ge.y) < -ge.w) | (int)((f_ymin - ge.y) > ge.w);
                 keep = !out;
             }
             const unsigned long long mask = __ballot(keep);
             if (keep) {
-                const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
-                                                           __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                surv[nsurv + rank] = (unsigned short)j;
+                const int rank = nsurv + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                                                   __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                surv[(rank & 3) * (CHUNK / 4) + (rank >> 2)] = (unsigned short)j;  // survivor `rank` -> slice rank%4
             }
             nsurv += __popcll(mask);
         }
@@ -454,75 +539,55 @@ __device__ __forceinline__ void fine_tile(const FineArgs &A, const int tile_id)
         // barrier only stops the compiler from moving the reads above the writes
         __builtin_amdgcn_wave_barrier();
         if (base == 0) FT_MARK(3);
-        // ---- test + insert: lane (pixel, slice) takes survivors slice, slice+4, ... ----
+        // ---- test + insert: lane (pixel, slice) takes survivors slice, slice+4, ...; two per pass so that the LDS
+        // reads of both are in flight together ----
         const int trips = (nsurv + 3) >> 2;
-        for (int it = 0; it < trips; ++it) {
-            const int si = it * 4 + slice;
-            const bool live = si < nsurv;
-            const int jj = live ? (int)surv[si] : 0;
-            const float4 ge = s_geo[jj], el = s_ell[jj];
-            const float2 zi = s_zid[jj];
-            const float dx = xf - ge.x;
-            const float dy = yf - ge.y;
-            // rasterize_points.cu:92-101, same expression order (no FMA contraction)
-            const float qval = el.x * dx * dx + el.y * dx * dy + el.z * dy * dy;
-            const bool hit = live && !(fabsf(dx) > ge.z || fabsf(dy) > ge.w) && !(qval > el.w);
-            const unsigned long long ekey =
-                hit ? (((unsigned long long)__float_as_uint(zi.x + 0.0f) << 32) |
-                       (unsigned long long)(unsigned)__float_as_int(zi.y))
-                    : KEY_EMPTY;
-            // A hit can only reach the output if it beats this lane's current K-th entry AND lies within
-            // the depth-merge threshold of the nearest entry seen so far (the final nearest is never
-            // farther, so dropping it now is exact: rasterize_points.cu:586-595 would drop it later).
-            const float znear_now = __uint_as_float((unsigned)(key[0] >> 32));
-            const bool useful = (ekey < key[KMAX - 1]) && !(key[0] != KEY_EMPTY && (zi.x - znear_now > A.thr));
-            if (__ballot(useful) != 0ull) klist_insert<KMAX>(key, kq, useful ? ekey : KEY_EMPTY, qval);
-        }
-    }
-
-    FT_MARK(4);
-    // ---- merge the four candidate slices of every pixel (lanes 16 and 32 apart) ----
-    // Two ascending K-lists A, B -> the K smallest of their union: min(A[i], B[K-1-i]) over i picks exactly
-    // those K (as a bitonic sequence), an odd-even transposition network sorts them.  K(K-1)/2 + K compare-
-    // exchanges of 7 VALU each (90 at K=5) instead of K branch-free insertions of ~12K each (300): the merge
-    // was a third of the kernel's VALU instructions.  Keys are unique across slices (disjoint candidates)
-    // except KEY_EMPTY, whose payload is the same everywhere.
+        const unsigned short *sv = surv + slice * (CHUNK / 4);
+        for (int it = 0; it < trips; it += 2) {
+            const unsigned pair = *reinterpret_cast<const unsigned *>(sv + it);  // entries it, it+1 (it is even)
 #pragma unroll
-    for (int xo = 16; xo <= 32; xo <<= 1) {
-        unsigned long long okey[KMAX];
-        float oq[KMAX];
-#pragma unroll
-        for (int k = 0; k < KMAX; ++k) {
-            const unsigned lo = __shfl_xor((unsigned)key[k], xo, 64);
-            const unsigned hi = __shfl_xor((unsigned)(key[k] >> 32), xo, 64);
-            okey[k] = ((unsigned long long)hi << 32) | lo;
-            oq[k] = __shfl_xor(kq[k], xo, 64);
-        }
-#pragma unroll
-        for (int k = 0; k < KMAX; ++k) {
-            const bool lt = okey[KMAX - 1 - k] < key[k];
-            key[k] = lt ? okey[KMAX - 1 - k] : key[k];
-            kq[k] = lt ? oq[KMAX - 1 - k] : kq[k];
-        }
-#pragma unroll
-        for (int round = 0; round < KMAX; ++round) {
-#pragma unroll
-            for (int k = round & 1; k + 1 < KMAX; k += 2) {
-                const bool sw = key[k + 1] < key[k];
-                const unsigned long long ka = key[k], kb = key[k + 1];
-                const float qa = kq[k], qb = kq[k + 1];
-                key[k] = sw ? kb : ka;
-                key[k + 1] = sw ? ka : kb;
-                kq[k] = sw ? qb : qa;
-                kq[k + 1] = sw ? qa : qb;
+            for (int u = 0; u < 2; ++u) {
+                const int si = (it + u) * 4 + slice;
+                const bool live = si < nsurv;
+                const int jj = live ? (int)((pair >> (16 * u)) & 0xffffu) : 0;
+                const float4 ge = s_geo[jj], el = s_ell[jj];
+                const float2 zi = s_zid[jj];
+                const float dx = xf - ge.x;
+                const float dy = yf - ge.y;
+                // rasterize_points.cu:92-101, same expression order (no FMA contraction)
+                const float qval = el.x * dx * dx + el.y * dx * dy + el.z * dy * dy;
+                const bool hit = (int)live & (int)!(fabsf(dx) > ge.z) & (int)!(fabsf(dy) > ge.w) & (int)!(qval > el.w);
+                const unsigned long long ekey =
+                    hit ? (((unsigned long long)__float_as_uint(zi.x + 0.0f) << 32) |
+                           (unsigned long long)(unsigned)__float_as_int(zi.y))
+                        : KEY_EMPTY;
+                // A hit can only reach the output if it beats this lane's current K-th entry AND lies within
+                // the depth-merge threshold of the nearest entry seen so far (the final nearest is never
+                // farther, so dropping it now is exact: rasterize_points.cu:586-595 would drop it later).
+                const float znear_now = __uint_as_float((unsigned)(key[0] >> 32));
+                const bool useful = (int)(ekey < key[KMAX - 1]) & (int)!((int)(key[0] != KEY_EMPTY) & (int)(zi.x - znear_now > A.thr));
+                if (__ballot(useful) != 0ull) klist_insert<KMAX>(key, kq, useful ? ekey : KEY_EMPTY, qval);
             }
         }
     }
 
+    FT_MARK(4);
+    // ---- merge the four candidate slices of every pixel (the lanes of a quad) ----
+    merge_round<KMAX, 0xB1>(key, kq);  // quad_perm [1,0,3,2]
+    merge_round<KMAX, 0x4E>(key, kq);  // quad_perm [2,3,0,1]
+
     FT_MARK(5);
     // ---- epilogue (slice 0 lanes own the pixel): depth merge, occupancy, visibility, stores ----
-    const bool owner = slice == 0;
-    const bool in_img = owner && (c < S) && (r < g.row0 + g.rows);
+    // Every thread-derived index of the epilogue is recomputed from a laundered thread id: left alone, the compiler
+    // forms the 64-bit store addresses (occupancy, image, weight sum, two rows x three planes) at kernel entry and
+    // keeps ~20 VGPRs alive through the candidate loop and the merge (110 VGPRs -> 4 waves per SIMD).
+    int tid_e = tid;
+    asm volatile("" : "+v"(tid_e));
+    const int lane_e = tid_e & 63, wid_e = tid_e >> 6, pl_e = lane_e >> 2;
+    const int tr_e = (wid_e / FOOT_PER_ROW) * FOOT + (pl_e >> 2), tc_e = (wid_e % FOOT_PER_ROW) * FOOT + (pl_e & 3);
+    const int r_e = g.row0 + ty * DSS_TILE + tr_e, c_e = tx * DSS_TILE + tc_e;
+    const bool owner = (lane_e & 3) == 0;
+    const bool in_img = owner && (c_e < S) && (r_e < g.row0 + g.rows);
     float kz[KMAX];
     int ki[KMAX];
     const float z0 = __uint_as_float((unsigned)(key[0] >> 32));
@@ -537,61 +602,84 @@ __device__ __forceinline__ void fine_tile(const FineArgs &A, const int tile_id)
         kz[k] = alive ? z : -1.0f;
         kq[k] = alive ? kq[k] : -1.0f;
     }
+    const size_t pix = ((size_t)n * g.rows + (r_e - g.row0)) * S + c_e;
+    // blend inputs of the pixel's fragments (scaler + three feature channels): requested BEFORE the tile is staged
+    // and streamed out, consumed after -- the gather's round trip is hidden behind the LDS transpose and the stores
+    constexpr bool PREFETCH_BLEND = false;  // (+20 VGPRs: 110 in total = 4 workgroups per CU; measured slower)
+    const bool blend3 = PREFETCH_BLEND && in_img && A.image != nullptr && A.C == 3;
+    float bsc[PREFETCH_BLEND ? KMAX : 1], bf0[PREFETCH_BLEND ? KMAX : 1], bf1[PREFETCH_BLEND ? KMAX : 1],
+        bf2[PREFETCH_BLEND ? KMAX : 1];
     if (in_img) {
-        const size_t pix = ((size_t)n * g.rows + (r - g.row0)) * S + c;
         A.occ[pix] = any ? 1.0f : 0.0f;
         if (A.visible) {
 #pragma unroll
             for (int k = 0; k < KMAX; ++k)
                 if (k < K && ki[k] >= 0) A.visible[ki[k]] = 1;
         }
-        if (A.image) {
-            // fused blend (same arithmetic and order as blend_forward_kernel): w = exp(-q/2)*scaler,
-            // img = sum f*w/cum, alpha = occupancy
-            float wk[KMAX];
-            float cum = 0.0f;
+    }
+    if (PREFETCH_BLEND) {
 #pragma unroll
-            for (int k = 0; k < KMAX; ++k) {
-                wk[k] = 0.0f;
-                if (k < K && ki[k] >= 0) {
-                    wk[k] = expf(-0.5f * kq[k]) * A.scaler[ki[k]];
-                    cum += wk[k];
-                }
-            }
-            if (cum < 1e-4f) cum = 1e-4f;
-            A.wsum[pix] = cum;
-            // normalised weights once per fragment (K IEEE divides per pixel, not K*C): img = sum f * (w / cum)
-#pragma unroll
-            for (int k = 0; k < KMAX; ++k) wk[k] = wk[k] / cum;
-            float *o = A.image + (size_t)n * A.img_sn + (size_t)(r - g.row0) * A.img_sr + (size_t)c * (A.C + 1);
-            if (A.C == 3) {
-                // RGBA as ONE 16-byte store per pixel (four dword stores at a 16-byte stride quadruple the
-                // write requests the memory side sees)
-                float acc3[3] = {0.0f, 0.0f, 0.0f};
-#pragma unroll
-                for (int k = 0; k < KMAX; ++k)
-                    if (k < K && ki[k] >= 0) {
-                        const float *f = A.feat + (size_t)ki[k] * 3;
-                        acc3[0] += f[0] * wk[k];
-                        acc3[1] += f[1] * wk[k];
-                        acc3[2] += f[2] * wk[k];
-                    }
-                *reinterpret_cast<float4 *>(o) = make_float4(acc3[0], acc3[1], acc3[2], any ? 1.0f : 0.0f);
-            } else {
-                for (int ch = 0; ch < A.C; ++ch) {
-                    float acc = 0.0f;
-#pragma unroll
-                    for (int k = 0; k < KMAX; ++k)
-                        if (k < K && ki[k] >= 0) acc += A.feat[(size_t)ki[k] * A.C + ch] * wk[k];
-                    o[ch] = acc;
-                }
-                o[A.C] = any ? 1.0f : 0.0f;
+        for (int k = 0; k < (PREFETCH_BLEND ? KMAX : 1); ++k) {
+            bsc[k] = 0.0f; bf0[k] = 0.0f; bf1[k] = 0.0f; bf2[k] = 0.0f;
+            if (blend3 && k < K && ki[k] >= 0) {
+                bsc[k] = A.scaler[ki[k]];
+                const float *f = A.feat + (size_t)ki[k] * 3;
+                bf0[k] = f[0]; bf1[k] = f[1]; bf2[k] = f[2];
             }
         }
     }
 
-    // stage the tile through LDS and let each wavefront stream one full image row per plane
-    const int lds_pix = (tr * DSS_TILE + tc) * K;
+    if (in_img && A.image) {
+        // fused blend (same arithmetic and order as blend_forward_kernel): w = exp(-q/2)*scaler,
+        // img = sum f*w/cum, alpha = occupancy
+        float wk[KMAX];
+        float cum = 0.0f;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            wk[k] = 0.0f;
+            if (k < K && ki[k] >= 0) {
+                wk[k] = expf(-0.5f * kq[k]) * (blend3 ? bsc[PREFETCH_BLEND ? k : 0] : A.scaler[ki[k]]);
+                cum += wk[k];
+            }
+        }
+        if (cum < 1e-4f) cum = 1e-4f;
+        A.wsum[pix] = cum;
+        // normalised weights once per fragment (K IEEE divides per pixel, not K*C): img = sum f * (w / cum)
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) wk[k] = wk[k] / cum;
+        float *o = A.image + (size_t)n * A.img_sn + (size_t)(r_e - g.row0) * A.img_sr + (size_t)c_e * (A.C + 1);
+        if (A.C == 3) {
+            // RGBA as ONE 16-byte store per pixel (four dword stores at a 16-byte stride quadruple the
+            // write requests the memory side sees)
+            float acc3[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k)
+                if (k < K && ki[k] >= 0) {
+                    float f0, f1, f2;
+                    if (blend3) {
+                        f0 = bf0[PREFETCH_BLEND ? k : 0]; f1 = bf1[PREFETCH_BLEND ? k : 0]; f2 = bf2[PREFETCH_BLEND ? k : 0];
+                    } else {
+                        const float *f = A.feat + (size_t)ki[k] * 3;
+                        f0 = f[0]; f1 = f[1]; f2 = f[2];
+                    }
+                    acc3[0] += f0 * wk[k];
+                    acc3[1] += f1 * wk[k];
+                    acc3[2] += f2 * wk[k];
+                }
+            *reinterpret_cast<float4 *>(o) = make_float4(acc3[0], acc3[1], acc3[2], any ? 1.0f : 0.0f);
+        } else {
+            for (int ch = 0; ch < A.C; ++ch) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int k = 0; k < KMAX; ++k)
+                    if (k < K && ki[k] >= 0) acc += A.feat[(size_t)ki[k] * A.C + ch] * wk[k];
+                o[ch] = acc;
+            }
+            o[A.C] = any ? 1.0f : 0.0f;
+        }
+    }
+    // stage the tile through LDS and let each wavefront stream full image rows per plane
+    const int lds_pix = (tr_e * DSS_TILE + tc_e) * K;
     if (PLANES == 3) {
         __syncthreads();
         if (owner) {
@@ -604,11 +692,11 @@ __device__ __forceinline__ void fine_tile(const FineArgs &A, const int tile_id)
                 }
         }
         __syncthreads();
-        for (int rr = wid; rr < valid_rows; rr += FINE_WAVES) {
+        for (int rr = wid_e; rr < valid_rows; rr += FINE_WAVES) {
             const size_t rb = tile_base + (size_t)rr * S * K;
-            for (int cc = lane; cc < valid_cols; cc += 64) {
+            for (int cc = lane_e; cc < valid_cols; cc += 64) {
                 A.idx[rb + cc] = s_out[0][rr * run + cc];
-                reinterpret_cast<int *>(A.zbuf)[rb + cc] = s_out[PLANES - 1 > 0 ? 1 : 0][rr * run + cc];
+                if (A.zbuf) reinterpret_cast<int *>(A.zbuf)[rb + cc] = s_out[PLANES - 1 > 0 ? 1 : 0][rr * run + cc];
                 reinterpret_cast<int *>(A.qv)[rb + cc] = s_out[PLANES - 1][rr * run + cc];
             }
         }
@@ -619,70 +707,85 @@ __device__ __forceinline__ void fine_tile(const FineArgs &A, const int tile_id)
         _Pragma("unroll") for (int k = 0; k < KMAX; ++k) if (k < K) s_out[0][lds_pix + k] = CAST(REGS[k]); \
     }                                                                                             \
     __syncthreads();                                                                              \
-    for (int rr = wid; rr < valid_rows; rr += FINE_WAVES) {                                       \
-        for (int cc = lane; cc < valid_cols; cc += 64)                                            \
+    for (int rr = wid_e; rr < valid_rows; rr += FINE_WAVES) {                                       \
+        for (int cc = lane_e; cc < valid_cols; cc += 64)                                            \
             reinterpret_cast<int *>(DST)[tile_base + (size_t)rr * S * K + cc] = s_out[0][rr * run + cc]; \
     }
         DSS_STORE_PLANE(ki, A.idx, (int))
-        DSS_STORE_PLANE(kz, A.zbuf, __float_as_int)
+        if (A.zbuf) { DSS_STORE_PLANE(kz, A.zbuf, __float_as_int) }
         DSS_STORE_PLANE(kq, A.qv, __float_as_int)
 #undef DSS_STORE_PLANE
     }
+
     FT_MARK(7);
     FT_VAL(9, __builtin_amdgcn_s_memrealtime());
 }
 
-// Binned mode: grid = DSS_HEAVY_MAX + tiles.  The first workgroups (dispatched first) take the queued dense
-// tiles, the others their own tile unless it is flagged as queued.  One workgroup per tile on purpose: the
-// hardware dispatcher is the dynamic scheduler.  Both persistent variants were measured and are slower at
-// 512^2 (36 us -> 54 us with a static snake schedule: a workgroup that draws two dense tiles ends the kernel;
-// +38 us with an atomic work counter: ~4600 same-address atomics).
+// Queue mode (binned): grid = ceil(N*tiles / 16) + queue_wgs.  The first workgroups stream the fill values of the empty
+// tiles, 16 tiles each (one wavefront per tile, four tiles per wavefront); queue workgroup qb serves slot qb/32 of queue
+// qb%32 (and exits at once when the slot is empty).  Identity mode (naive): one workgroup per tile.
+// 16 tiles per fill workgroup, rounded up to a multiple of 8 workgroups so that queue workgroup qb still lands on XCD qb % 8
+__host__ __device__ __forceinline__ uint32_t fill_workgroups(int total_tiles)
+{
+    return (((uint32_t)total_tiles + 15u) / 16u + 7u) & ~7u;
+}
+
 template <int KMAX>
 __global__ __launch_bounds__(FINE_THREADS) void fine_kernel(const FineArgs A)
 {
     const int total = A.N * A.g.tiles_x * A.g.tiles_y;
+    const bool qmode = A.queue.list != nullptr;
     const bool clean = A.clean_counts != nullptr;
-    int tile_id;
-    if (A.heavy.count != nullptr) {
-        if (clean && blockIdx.x == 0 && threadIdx.x < DSS_HEAVY_QUEUES) A.heavy.count[threadIdx.x] = 0;  // binning-only state
-        // the resets happen after a barrier: every thread of the workgroup must have read the value first
-        if (blockIdx.x < DSS_HEAVY_MAX) {
-            const int e = A.heavy.list[blockIdx.x];
-            if (clean) {
-                __syncthreads();
-                if (threadIdx.x == 0) A.heavy.list[blockIdx.x] = 0;  // this workgroup is the slot's only reader
-            }
-            if (e == 0) return;
-            tile_id = e - 1;
-        } else {
-            tile_id = xcd_tile(blockIdx.x - DSS_HEAVY_MAX, total);
-            if (tile_id < 0) return;
-            const uint8_t queued = A.heavy.flag[tile_id];
-            if (clean) {
-                __syncthreads();
-                if (queued && threadIdx.x == 0) A.heavy.flag[tile_id] = 0;  // ... and the flag's only reader
-            }
-            if (queued) return;
-        }
-    } else {
-        tile_id = xcd_tile(blockIdx.x, total);
-        if (tile_id < 0) return;
+    // fill workgroups come FIRST in the grid: behind the queue workgroups they started 8-12 us into the kernel (the
+    // dispatcher works through ~3000 workgroups whose slot turns out to be empty at ~3 ns each) and ended it
+    const uint32_t fill_wgs = qmode ? fill_workgroups(total) : 0u;
+    if (blockIdx.x < fill_wgs) {
+        const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+        const int t0 = (int)blockIdx.x * 16 + wid * 4;
+        FT_MARK(0);
+        FT_VAL(8, __builtin_amdgcn_s_memrealtime());
+        FT_VAL(10, -1);
+        // the four flags of this wavefront's tiles in ONE round trip (this wavefront is their only reader)
+        const bool mine = lane < 4 && t0 + lane < total;
+        const uint32_t flag = mine ? A.queue.flag[t0 + lane] : 1u;
+        if (clean && mine && flag) A.queue.flag[t0 + lane] = 0;
+        const unsigned empty = (unsigned)__ballot(flag == 0u) & 0xfu;
+#pragma unroll 1
+        for (int i = 0; i < 4; ++i)
+            if (empty & (1u << i)) fill_tile_rows(A, t0 + i, lane, 0, 1);
+        FT_MARK(7);
+        FT_VAL(9, __builtin_amdgcn_s_memrealtime());
+        return;
     }
-    fine_tile<KMAX>(A, tile_id);
+    const uint32_t qb = blockIdx.x - fill_wgs;  // queue workgroup index (identity mode: tile id)
+    if (!qmode && (int)qb >= total) return;
+    if (qmode && clean && qb == 0 && threadIdx.x < DSS_QUEUES) A.queue.tail[threadIdx.x] = 0;  // binning-only state
+    // one workgroup per queue slot (qb -> queue qb%32, slot qb/32): a loop over several slots per workgroup was tried and
+    // costs 60 VGPRs (values hoisted out of the tile loop), and most slots of a large render hold a tile anyway
+    int tile_id = (int)qb;
+    int32_t *slot = nullptr;
+    if (qmode) {
+        slot = A.queue.list + (size_t)(qb % DSS_QUEUES) * A.queue.capq + qb / DSS_QUEUES;
+        // uniform value, but a vector load (the kernel also writes the slot): tell the compiler, or the tile id and
+        // everything derived from it lives in VGPRs.  Reset (DSS_WS_CLEAN) inside fine_tile once every thread read it.
+        tile_id = __builtin_amdgcn_readfirstlane(*slot) - 1;
+    }
+    if (tile_id < 0 || tile_id >= total) return;
+    fine_tile<KMAX>(A, tile_id, (qmode && clean) ? slot : nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------
 // Generic-K path for DSS_MAX_K_FAST < K <= kMaxPointsPerPixel (=150, rasterization_utils.cuh:18):
 // one wavefront per 8x8 tile, one lane per pixel, the K-list lives in scratch memory (like the
 // reference's thread-local `Pix q[150]`, rasterize_points.cu:177) and is kept sorted by binary
-// insertion.  Rare configuration: correctness over speed.
+// insertion.  Rare configuration: correctness over speed; identity order, every tile scans what it is given.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void fine_generic_kernel(const FineArgs A)
 {
     const TileGrid g = A.g;
     const int tiles = g.tiles_x * g.tiles_y;
-    const int tile_id = xcd_tile(blockIdx.x, A.N * tiles);
-    if (tile_id < 0) return;
+    const int tile_id = (int)blockIdx.x;
+    if (tile_id >= A.N * tiles) return;
     const int n = tile_id / tiles;
     const int t = tile_id - n * tiles;
     const int ty = t / g.tiles_x, tx = t - ty * g.tiles_x;
@@ -692,23 +795,29 @@ __global__ __launch_bounds__(64) void fine_generic_kernel(const FineArgs A)
     const int S = g.S, K = A.K;
     const float xf = pix_to_ndc(S - 1 - c, S);
     const float yf = pix_to_ndc(S - 1 - r, S);
-    TileSource src;
-    src.init(A, n, tile_id);
-    const int64_t count = src.count;
+    // candidates: the tile's sub-lists when none overflowed, else the whole cloud
+    uint32_t cs[DSS_SUB];
+    bool use_list = A.counts != nullptr;
+    if (use_list) {
+        for (int q = 0; q < DSS_SUB; ++q) {
+            cs[q] = A.counts[(size_t)tile_id * DSS_SUB + q];
+            use_list = use_list && cs[q] <= A.cap;
+        }
+    }
+    const int64_t first = A.first_idx[n], npts = A.num_pts[n];
     unsigned long long key[DSS_MAX_K];
     float kq[DSS_MAX_K];
     int cnt = 0;
-    for (int64_t j = 0; j < count; ++j) {
-        const int64_t p = src.at(j);  // wave-uniform
+    auto visit = [&](int64_t p) {  // p is wave-uniform
         const float pz = A.points[3 * p + 2];
-        if (pz < 0) continue;
+        if (pz < 0) return;
         const float dx = xf - A.points[3 * p];
         const float dy = yf - A.points[3 * p + 1];
-        if (fabsf(dx) > A.radii[2 * p] || fabsf(dy) > A.radii[2 * p + 1]) continue;
+        if (fabsf(dx) > A.radii[2 * p] || fabsf(dy) > A.radii[2 * p + 1]) return;
         const float qval = A.ellipse[3 * p] * dx * dx + A.ellipse[3 * p + 1] * dx * dy + A.ellipse[3 * p + 2] * dy * dy;
-        if (qval > A.cutoff[p]) continue;
+        if (qval > A.cutoff[p]) return;
         const unsigned long long ekey = ((unsigned long long)__float_as_uint(pz + 0.0f) << 32) | (unsigned long long)(unsigned)p;
-        if (cnt == K && !(ekey < key[K - 1])) continue;
+        if (cnt == K && !(ekey < key[K - 1])) return;
         int pos = (cnt < K) ? cnt : K - 1;
         while (pos > 0 && ekey < key[pos - 1]) {
             key[pos] = key[pos - 1];
@@ -718,6 +827,14 @@ __global__ __launch_bounds__(64) void fine_generic_kernel(const FineArgs A)
         key[pos] = ekey;
         kq[pos] = qval;
         if (cnt < K) ++cnt;
+    };
+    if (use_list) {
+        for (int q = 0; q < DSS_SUB; ++q) {
+            const int32_t *l = A.lists + ((size_t)tile_id * DSS_SUB + q) * A.cap;
+            for (uint32_t j = 0; j < cs[q]; ++j) visit((int64_t)l[j]);
+        }
+    } else {
+        for (int64_t j = 0; j < npts; ++j) visit(first + j);
     }
     if (c >= S || r >= g.row0 + g.rows) return;
     const size_t pix = ((size_t)n * g.rows + (r - g.row0)) * S + c;
@@ -739,16 +856,20 @@ __global__ __launch_bounds__(64) void fine_generic_kernel(const FineArgs A)
             }
         }
         A.idx[pix * K + k] = id;
-        A.zbuf[pix * K + k] = z;
+        if (A.zbuf) A.zbuf[pix * K + k] = z;
         A.qv[pix * K + k] = qv;
     }
+}
+
+static int fine_grid(const FineArgs &A, int blocks)
+{
+    return A.queue.list ? (int)(A.queue_wgs + fill_workgroups(blocks)) : blocks;
 }
 
 template <int KMAX>
 static void launch_fine(const FineArgs &A, int blocks, hipStream_t st)
 {
-    const int grid = blocks + (A.heavy.count ? DSS_HEAVY_MAX : 0);
-    hipLaunchKernelGGL(fine_kernel<KMAX>, dim3(grid), dim3(FINE_THREADS), 0, st, A);
+    hipLaunchKernelGGL(fine_kernel<KMAX>, dim3(fine_grid(A, blocks)), dim3(FINE_THREADS), 0, st, A);
 }
 
 static bool dispatch_fine(const FineArgs &A, int blocks, hipStream_t st)
@@ -776,13 +897,13 @@ static bool dispatch_fine(const FineArgs &A, int blocks, hipStream_t st)
     return false;
 }
 
-// workspace layout (binned mode): counts | lists
+// workspace layout (binned mode): counts | flags | queue tails | queue slots || lists
 struct FwdWorkspace {
     uint32_t *counts;  // N*tiles*SUB
     int32_t *lists;    // N*tiles*SUB*cap
     uint32_t cap;
-    HeavyQ heavy;
-    size_t count_bytes;  // bytes to zero before binning: tile counters + heavy flags + queue counter
+    TileQueue queue;
+    size_t count_bytes;  // bytes to zero before binning (the DSS_WS_CLEAN region): everything in front of the lists
     size_t bytes;
 };
 
@@ -797,23 +918,43 @@ static uint32_t bin_capacity(int N, int64_t P, int S)
     return cap;
 }
 
+static TileGrid make_grid(int S, int row0, int row1)
+{
+    TileGrid g;
+    g.S = S;
+    g.row0 = row0;
+    g.rows = row1 - row0;
+    g.tiles_x = (S + DSS_TILE - 1) / DSS_TILE;
+    g.tiles_y = (g.rows + DSS_TILE - 1) / DSS_TILE;
+    return g;
+}
+
+// (the layout is sized for the full image: a row band uses a prefix of every region)
 static FwdWorkspace carve_fwd(void *ws, int N, int64_t P, int S)
 {
     FwdWorkspace w;
-    const size_t tiles_max = (size_t)N * ((S + DSS_TILE - 1) / DSS_TILE) * ((S + DSS_TILE - 1) / DSS_TILE);
+    const TileGrid full = make_grid(S, 0, S);
+    const size_t tiles_max = (size_t)N * full.tiles_x * full.tiles_y;
     char *p = reinterpret_cast<char *>(ws);
     w.cap = bin_capacity(N, P, S);
-    const size_t cbytes = align_up(tiles_max * DSS_SUB * 4, 256), fbytes = align_up(tiles_max, 256);
-    const size_t qbytes = align_up((size_t)DSS_HEAVY_MAX * 4, 256);
+    const size_t cbytes = align_up(tiles_max * DSS_SUB * 4, 256), fbytes = align_up(tiles_max * 4, 256);
+    w.queue.capq = queue_capacity(N, full);
+    const size_t qbytes = align_up((size_t)DSS_QUEUES * w.queue.capq * 4, 256);
     w.count_bytes = cbytes + fbytes + 256 + qbytes;
     w.counts = reinterpret_cast<uint32_t *>(p);
-    w.heavy.flag = reinterpret_cast<uint8_t *>(p + cbytes);
-    w.heavy.count = reinterpret_cast<uint32_t *>(p + cbytes + fbytes);
-    w.heavy.list = reinterpret_cast<int32_t *>(p + cbytes + fbytes + 256);
+    w.queue.flag = reinterpret_cast<uint32_t *>(p + cbytes);
+    w.queue.tail = reinterpret_cast<uint32_t *>(p + cbytes + fbytes);
+    w.queue.list = reinterpret_cast<int32_t *>(p + cbytes + fbytes + 256);
     const size_t lists_off = w.count_bytes;
     w.lists = reinterpret_cast<int32_t *>(p + lists_off);
     w.bytes = lists_off + align_up(tiles_max * DSS_SUB * (size_t)w.cap * 4, 256);
     return w;
+}
+
+// queue-serving workgroups of a fine launch over `g` (band): one per slot of the band's queues
+static uint32_t queue_workgroups(int N, const TileGrid &g)
+{
+    return (uint32_t)DSS_QUEUES * queue_capacity(N, g);
 }
 
 }  // namespace dss
@@ -825,6 +966,12 @@ extern "C" size_t dss_splat_forward_workspace(int N, int64_t P, int S, int K, in
     (void)K;
     if (bin_size == 0 || N <= 0 || P <= 0 || S <= 0) return 256;
     return carve_fwd(nullptr, N, P, S).bytes;
+}
+
+extern "C" size_t dss_splat_forward_clean_bytes(int N, int64_t P, int S)
+{
+    if (N <= 0 || P <= 0 || S <= 0) return 0;
+    return carve_fwd(nullptr, N, P, S).count_bytes;
 }
 
 static int validate_fwd(const char *fn, int N, int64_t P, int S, int K, int row0, int row1)
@@ -846,17 +993,6 @@ static int validate_fwd(const char *fn, int N, int64_t P, int S, int K, int row0
         return DSS_ERR_UNSUPPORTED;
     }
     return DSS_OK;
-}
-
-static TileGrid make_grid(int S, int row0, int row1)
-{
-    TileGrid g;
-    g.S = S;
-    g.row0 = row0;
-    g.rows = row1 - row0;
-    g.tiles_x = (S + DSS_TILE - 1) / DSS_TILE;
-    g.tiles_y = (g.rows + DSS_TILE - 1) / DSS_TILE;
-    return g;
 }
 
 static int splat_bin_impl(const float *points, const float *radii, const int64_t *first_idx,
@@ -883,7 +1019,7 @@ static int splat_bin_impl(const float *points, const float *radii, const int64_t
     if (hipMemsetAsync(w.counts, 0, w.count_bytes, st) != hipSuccess) return check_launch("memset tile counts");
     const int pb = (int)((P + 255) / 256);
     hipLaunchKernelGGL(bin_kernel, dim3(pb), dim3(256), 0, st, points, radii, first_idx, num_pts, N, P, g, w.counts,
-                       w.lists, w.cap, w.heavy, visible_to_clear);
+                       w.lists, w.cap, w.queue, visible_to_clear);
     return check_launch("dss_splat_bin");
 }
 
@@ -903,8 +1039,8 @@ static int splat_fine_impl(const float *points, const float *ellipse, const floa
 {
     int rc = validate_fwd("dss_splat_fine", N, P, S, K, row0, row1);
     if (rc) return rc;
-    if (!idx || !zbuf || !qvalue || !occ || !first_idx || !num_pts ||
-        (P > 0 && (!points || !ellipse || !cutoff || !radii))) {
+    if (!idx || !qvalue || !occ || !first_idx || !num_pts ||
+        (P > 0 && (!points || !ellipse || !cutoff || !radii))) {  // zbuf may be NULL: depth plane not written
         set_error("dss_splat_fine: NULL tensor pointer");
         return DSS_ERR_INVALID_ARGUMENT;
     }
@@ -915,7 +1051,8 @@ static int splat_fine_impl(const float *points, const float *ellipse, const floa
     A.points = points; A.ellipse = ellipse; A.cutoff = cutoff; A.radii = radii;
     A.first_idx = first_idx; A.num_pts = num_pts;
     A.counts = nullptr; A.lists = nullptr; A.cap = 0;
-    A.heavy.count = nullptr; A.heavy.list = nullptr; A.heavy.flag = nullptr; A.clean_counts = nullptr;
+    A.queue.tail = nullptr; A.queue.list = nullptr; A.queue.flag = nullptr; A.queue.capq = 0; A.queue_wgs = 0;
+    A.clean_counts = nullptr;
     A.idx = idx; A.zbuf = zbuf; A.qv = qvalue; A.occ = occ; A.visible = visible;
     A.g = g; A.N = N; A.K = K; A.thr = merge_thr;
     A.scaler = scaler; A.feat = feat; A.image = image; A.wsum = wsum; A.C = C;
@@ -926,7 +1063,8 @@ static int splat_fine_impl(const float *points, const float *ellipse, const floa
             return DSS_ERR_WORKSPACE;
         }
         FwdWorkspace w = carve_fwd(const_cast<void *>(workspace), N, P, S);
-        A.counts = w.counts; A.lists = w.lists; A.cap = w.cap; A.heavy = w.heavy;
+        A.counts = w.counts; A.lists = w.lists; A.cap = w.cap; A.queue = w.queue;
+        A.queue_wgs = queue_workgroups(N, g);
     }
     if (!dispatch_fine(A, (int)blocks_ll, as_stream(stream))) {
         set_error("dss_splat_fine: no kernel for K=%d", K);
@@ -1021,7 +1159,7 @@ extern "C" int dss_render_forward(const float *world, const float *normals, cons
     }
     if (!world || !normals || (!h_point && !h_cloud && !vr6) || (vr6 && !frame_normals) || !M || !V || !znear || !zfar ||
         !first_idx || !num_pts || !feat ||
-        !pts_screen || !ellipse || !radii || !scaler || !cutoff || !valid || !idx || !zbuf || !qvalue || !occ ||
+        !pts_screen || !ellipse || !radii || !scaler || !cutoff || !valid || !idx || !qvalue || !occ ||
         !visible || !image || !wsum) {
         set_error("dss_render_forward: NULL tensor pointer");
         return DSS_ERR_INVALID_ARGUMENT;
@@ -1048,11 +1186,12 @@ extern "C" int dss_render_forward(const float *world, const float *normals, cons
     // one wave per workgroup: at DSS sizes (tens of thousands of points) 256-thread groups would occupy only
     // half of the CUs with one wave per SIMD, and this kernel is a chain of dependent latencies
     const int pb = (int)((P + 63) / 64);
-    hipLaunchKernelGGL(setup_bin_kernel, dim3(pb), dim3(64), 0, st, SA, g, w.counts, w.lists, w.cap, w.heavy, visible);
+    hipLaunchKernelGGL(setup_bin_kernel, dim3(pb), dim3(64), 0, st, SA, g, w.counts, w.lists, w.cap, w.queue, visible);
     FineArgs A;
     A.points = pts_screen; A.ellipse = ellipse; A.cutoff = cutoff; A.radii = radii;
     A.first_idx = first_idx; A.num_pts = num_pts;
-    A.counts = w.counts; A.lists = w.lists; A.cap = w.cap; A.heavy = w.heavy;
+    A.counts = w.counts; A.lists = w.lists; A.cap = w.cap; A.queue = w.queue;
+    A.queue_wgs = queue_workgroups(N, g);
     A.clean_counts = clean ? w.counts : nullptr;
     A.idx = idx; A.zbuf = zbuf; A.qv = qvalue; A.occ = occ; A.visible = visible;
     A.g = g; A.N = N; A.K = K; A.thr = merge_thr;

@@ -72,6 +72,9 @@ DSS_API const char *dss_last_error(void);
  * ascending; drop k with z[k]-z[0] > merge_thr; unfilled slots idx=-1, zbuf=-1, qvalue=-1.
  * ------------------------------------------------------------------------------------------- */
 DSS_API size_t dss_splat_forward_workspace(int N, int64_t P, int S, int K, int bin_size);
+/* Leading bytes of that workspace which binning expects zero-filled (tile counters, tile flags, queue tails and queue
+ * slots): the region the DSS_WS_CLEAN contract of dss_render_forward is about. */
+DSS_API size_t dss_splat_forward_clean_bytes(int N, int64_t P, int S);
 
 DSS_API int dss_splat_forward(const float *points, const float *ellipse, const float *cutoff,
                       const float *radii, const int64_t *first_idx, const int64_t *num_pts,
@@ -83,11 +86,14 @@ DSS_API int dss_splat_forward(const float *points, const float *ellipse, const f
 /* The two phases of dss_splat_forward, callable separately (the binned lists in `workspace` stay
  * valid until the next dss_splat_bin on it):
  *   dss_splat_bin   tile binning: a memset + ONE kernel that appends every splat to the fixed-capacity
- *                   sub-lists of the 8x8-pixel tiles it overlaps (replaces the coarse kernel
+ *                   sub-lists of the 8x8-pixel tiles it overlaps and every tile that receives its first
+ *                   splat to a queue of occupied tiles (replaces the coarse kernel
  *                   rasterize_points.cu:293-432 and its dense (N,B,B,M) bin table)
- *   dss_splat_fine  exactly ONE kernel launch: per-tile K-nearest + stores (replaces the fine kernel
- *                   rasterize_points.cu:506-597); workspace==NULL scans whole clouds (naive mode,
- *                   :131-212).  `visible`, if given, must have been zeroed by the caller. */
+ *   dss_splat_fine  exactly ONE kernel launch: per-tile K-nearest + stores for the queued tiles, fill values
+ *                   for the empty ones (replaces the fine kernel rasterize_points.cu:506-597);
+ *                   workspace==NULL scans whole clouds (naive mode, :131-212).  `visible`, if given, must
+ *                   have been zeroed by the caller.  zbuf may be NULL: the depth plane is then not written
+ *                   (the fused backward never reads it; saves 4K of the 12K+24 bytes stored per pixel). */
 DSS_API int dss_splat_bin(const float *points, const float *radii, const int64_t *first_idx,
                           const int64_t *num_pts, int N, int64_t P, int S, int row0, int row1,
                           void *workspace, size_t workspace_bytes, void *stream);

@@ -220,9 +220,8 @@ def test_render_forward_leaves_its_workspace_clean(h_scale):
     num = torch.full((N,), Pc, device=DEV, dtype=torch.int64)
     hh = torch.full((N,), h, device=DEV)
     zn, zf = torch.full((N,), 0.6, device=DEV), torch.full((N,), 100.0, device=DEV)
-    tiles = N * (S // 8) ** 2
-    up = lambda x: (x + 255) // 256 * 256
-    zero_bytes = up(tiles * 8 * 4) + up(tiles) + 256 + up(2048 * 4)  # mirrors carve_fwd (raster_forward.hip)
+    zero_bytes = _lib.load().dss_splat_forward_clean_bytes(N, N * Pc, S)  # the region the contract covers
+    assert zero_bytes >= N * (S // 8) ** 2 * 8 * 4
     outs = []
     for rep in range(3):
         f = ops.render_forward(world, normals, hh, t(M), t(V), zn, zf, first, num, feat, S, K, 1.0, 0.05, 1.0, True, True)

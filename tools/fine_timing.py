@@ -28,25 +28,36 @@ lib = _lib.load()
 lib.dss_debug_set_fine_timing.argtypes = [ctypes.c_void_p]
 wl = bench.Workload(dev, 1, bench.RowPartition(bench.S, 1, 0))
 blocks = (bench.S // 8) ** 2  # DSS_TILE = 8
-buf = torch.zeros((blocks + 2048, 12), dtype=torch.int64, device=dev)  # grid = DSS_HEAVY_MAX + tiles workgroups
+buf = torch.zeros((2 * blocks + 4096, 12), dtype=torch.int64, device=dev)  # grid = queue slots (~tiles) + tiles/16 fill workgroups
 for _ in range(3):
     wl.fine_kernel_ms(iters=5)
 assert lib.dss_debug_set_fine_timing(ctypes.c_void_p(buf.data_ptr())) == 0
 mean, med = wl.fine_kernel_ms(iters=20)
 torch.cuda.synchronize()
 t = buf.cpu().numpy()
-print("fine kernel ms mean %.4f median %.4f" % (mean, med))
+print("fine kernel ms mean %.4f median %.4f (timing build)" % (mean, med))
 cnt = t[:, 10]
 busy = cnt > 0
-t = t[t[:, 0] != 0]  # workgroups that ran a tile (queue slots without work / flagged tiles exit before the first mark)
+fills = t[(t[:, 0] != 0) & (t[:, 10] == -1)]
+if len(fills):
+    f0 = fills[:, 8] - t[t[:, 0] != 0][:, 8].min()
+    f1 = fills[:, 9] - t[t[:, 0] != 0][:, 8].min()
+    print("fill workgroups %d: start p50 %d max %d | end p50 %d p90 %d max %d (ticks) | cycles mean %.0f max %d" % (
+        len(fills), np.percentile(f0, 50), f0.max(), np.percentile(f1, 50), np.percentile(f1, 90), f1.max(),
+        (fills[:, 7] - fills[:, 0]).mean(), (fills[:, 7] - fills[:, 0]).max()))
+t = t[(t[:, 0] != 0) & (t[:, 10] != -1)]  # workgroups that ran a tile (queue slots without work / flagged tiles exit before the first mark)
 cnt = t[:, 10]
 busy = cnt > 0
 rt0, rt1 = t[:, 8], t[:, 9]
 print("realtime span (100MHz ticks): kernel %d, first start %d, last end %d" % (rt1.max() - rt0.min(), 0, rt1.max() - rt0.min()))
 print("WG start spread (ticks): p50 %d p90 %d max %d" % tuple(np.percentile(rt0 - rt0.min(), [50, 90, 100])))
 dur = t[:, 7] - t[:, 0]
-print("WG cycles: empty tiles mean %.0f max %d | occupied mean %.0f p90 %.0f max %d" % (
-    dur[~busy].mean(), dur[~busy].max(), dur[busy].mean(), np.percentile(dur[busy], 90), dur[busy].max()))
+print("tile workgroups %d | cycles mean %.0f p50 %.0f p90 %.0f max %d" % (
+    int(busy.sum()), dur[busy].mean(), np.percentile(dur[busy], 50), np.percentile(dur[busy], 90), dur[busy].max()))
+end = rt1 - rt0.min()
+print("tile WG end time (ticks): p50 %d p90 %d p99 %d max %d" % tuple(np.percentile(end[busy], [50, 90, 99, 100])))
+late = busy & ((rt0 - rt0.min()) > 500)
+print("tile WGs starting later than 5 us: %d, their mean count %.0f" % (int(late.sum()), cnt[late].mean() if late.any() else 0))
 names = ["prologue(offset loads)", "stage chunk0", "cull chunk0", "survivors+rest chunks", "merge", "epilogue"]
 for i, nm in enumerate(names):
     a, b = (i, i + 1) if i < 5 else (5, 7)
