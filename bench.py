@@ -114,8 +114,23 @@ class Workload:
         g_col = g_feat.view(self.N, self.Pc, 3).sum(0) if self.N > 1 else g_feat
         return image, g_world, g_col
 
-    # ---- dominant-kernel timing (fine kernel, exactly one launch per call) ------------------
+    # ---- per-kernel timing with HIP events on the launch stream (torch's current stream) ------
+    @staticmethod
+    def _event_ms(run, iters=50, warm=5):
+        for _ in range(warm):
+            run()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+        for s, e in ev:
+            s.record()
+            run()
+            e.record()
+        torch.cuda.synchronize()
+        ms = sorted(s.elapsed_time(e) for s, e in ev)
+        return float(np.mean(ms)), float(ms[len(ms) // 2])
+
     def fine_kernel_ms(self, iters=50):
+        """The forward's dominant kernel alone: exactly one launch per call (dss_splat_fine_blend = the fine pass with
+        the blend fused into its epilogue, the kernel dss_render_forward launches)."""
         lib = _lib.load()
         S = self.S
         info = ops.point_setup(self.world, self.normals, self.h, self.M, self.V, self.znear, self.zfar, self.first,
@@ -135,24 +150,50 @@ class Workload:
              _lib.ptr(info["radii"]), _lib.ptr(self.first), _lib.ptr(self.num), self.N, self.P)
         _lib.check(lib.dss_splat_bin(a[0], a[3], a[4], a[5], self.N, self.P, S, r0, r1, _lib.ptr(ws), nbytes, st),
                    "dss_splat_bin")
-        # exactly the kernel the step launches: fine pass with the blend fused into its epilogue
         image = torch.empty((self.N, rows, S, 4), device=dev)
         wsum = torch.empty((self.N, rows, S), device=dev)
         run = lambda: lib.dss_splat_fine_blend(*a, THR, S, K, r0, r1, _lib.ptr(idx), _lib.ptr(zbuf), _lib.ptr(qv),
                                                _lib.ptr(occ), _lib.ptr(vis), _lib.ptr(info["scaler"]),
                                                _lib.ptr(self.colors), 3, _lib.ptr(image), _lib.ptr(wsum), _lib.ptr(ws),
                                                nbytes, st)
-        for _ in range(5):
-            _lib.check(run(), "dss_splat_fine")
-        # HIP events on the stream the kernel is launched on (torch's current stream)
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
-        for s, e in ev:
-            s.record()
-            run()
-            e.record()
-        torch.cuda.synchronize()
-        ms = sorted(s.elapsed_time(e) for s, e in ev)
-        return float(np.mean(ms)), float(ms[len(ms) // 2])
+        _lib.check(run(), "dss_splat_fine")
+        return self._event_ms(run, iters)
+
+    def backward_gather_ms(self, iters=50):
+        """The backward's dominant kernel (render_backward_kernel: blend backward + occupancy surrogate per visible
+        point): event time of dss_render_backward (compaction + median + gather) minus the event time of its two
+        preparation launches alone (dss_backward_radius runs exactly those).  Also returns what the VALU roofline needs:
+        the number of (pixel, visible point) pairs inside the search radius."""
+        p, S = self.part, self.S
+        f = ops.render_forward(self.world, self.normals, self.h, self.M, self.V, self.znear, self.zfar, self.first,
+                               self.num, self.colors, S, K, CUTOFF, THR, SIGMA, False, True, rows=p.rows)
+        g = p.slice(self.grad_out).contiguous()
+        full = lambda: ops.render_backward(g, f["idx"], f["qvalue"], f["wsum"], f["scaler"], f["pts_screen"], f["radii"],
+                                           f["visible"], self.first, self.num, RADII_S, CLIP, image_size=S, rows=p.rows)
+        prep = lambda: ops.backward_radius(f["radii"], f["visible"], self.first, self.num, RADII_S)
+        t_full, _ = self._event_ms(full, iters)
+        t_prep, _ = self._event_ms(prep, iters)
+        # (pixel, point) pairs the rule has to evaluate: pixel centres within rs of a visible, on-screen point
+        rs = prep()
+        vis = f["visible"]
+        pts = f["pts_screen"][vis]
+        cloud = (torch.arange(self.P, device=self.dev) // self.Pc)[vis]
+        r = rs[cloud]
+        ok = (pts[:, 2] >= 0) & (pts[:, 0].abs() <= 1) & (pts[:, 1].abs() <= 1)
+        pts, r = pts[ok], r[ok]
+        pairs = 0
+        ndc = -1 + (2 * torch.arange(S, device=self.dev, dtype=torch.float32) + 1) / S
+        r0, r1 = p.rows
+        ys = ndc[S - r1:S - r0] if r1 - r0 < S else ndc       # NDC rows of the band (image row r <-> NDC index S-1-r)
+        for i in range(0, pts.shape[0], 4096):                 # chunked: (points, S) masks per axis, exact disc count
+            q, rr = pts[i:i + 4096], r[i:i + 4096]
+            dx2 = (ndc[None, :] - q[:, 0:1]) ** 2
+            dy2 = (ys[None, :] - q[:, 1:2]) ** 2
+            # pixels with dx^2 + dy^2 <= rs^2: per row, the columns with dx^2 <= rs^2 - dy^2
+            lim = (rr[:, None] ** 2 - dy2).clamp_min(-1.0)     # (pts, rows)
+            dx2s, _ = dx2.sort(dim=1)
+            pairs += int(torch.searchsorted(dx2s, lim.contiguous(), right=True).sum().item())
+        return max(t_full - t_prep, 0.0), t_full, t_prep, pairs, int(vis.sum().item())
 
 
 def cpu_baseline():
@@ -312,18 +353,53 @@ def main():
     splats = wl.P  # cameras * points per cloud submitted per step (whole job)
     value = splats / (ms_step * 1e-3) / 1e6
 
+    # second reported figure (single GPU): the same step with the variance-scale statistic h recomputed inside it -- the
+    # kNN-7 of rasterizer.py:310-326, which the reference reruns every iteration (refresh=True default, :293, :344).  The
+    # headline `value` takes h as an input of the step (SURVEY section 8 files the kNN under "next"); both are reported.
+    value_knn = ms_knn = None
+    if world == 1:
+        one = torch.zeros(1, dtype=torch.int64, device=dev)
+        cnt = torch.full((1,), wl.Pc, dtype=torch.int64, device=dev)
+
+        def step_with_knn():
+            h = ops.cloud_mean_clamp(ops.knn_kth_sqdist(wl.world, one, cnt, 7), one, cnt, 0.5, 5e-5, 1e-3, 0.5e-3, 7)
+            wl.h = h.expand(wl.N).contiguous() if wl.N > 1 else h
+            return wl.step()
+        ms_knn = quick(step_with_knn, n=max(20, args.steps // 4))
+        value_knn = splats / (ms_knn * 1e-3) / 1e6
+
+    # ---- roofline of the dominant kernel, picked from a per-kernel event-timing pass --------------------------------
     fine_mean, fine_med = wl.fine_kernel_ms()
-    traffic = None
-    tfile = os.path.join(ROOT, "profiles", "traffic_fine_kernel.json")
-    if world == 1 and os.path.exists(tfile):
-        # HBM bytes per launch from rocprofv3 PMC passes of this same command (tools/collect_traffic.py)
-        traffic = json.load(open(tfile)).get("traffic_bytes_per_launch")
+    gather_ms, bwd_ms, prep_ms, pairs, n_vis = wl.backward_gather_ms()
     r0, r1 = part.rows
-    # algorithmic bytes of ONE fine-kernel launch: every pixel of the band writes
-    # idx+zbuf+qvalue (12K B) + occ (4 B) + RGBA (16 B) + wsum (4 B); every splat's screen record (pos 12,
-    # ellipse 12, radii 8, cutoff 4) + scaler (4) + colour (12) = 52 B is read once.
+    # HBM: algorithmic bytes of ONE fine-kernel launch: every pixel of the band writes idx+zbuf+qvalue
+    # (12K B) + occ (4 B) + RGBA (16 B) + wsum (4 B); every splat's screen record (pos 12, ellipse 12, radii 8, cutoff 4) +
+    # scaler (4) + colour (12) = 52 B is read once.
     alg_bytes = wl.N * (r1 - r0) * S * (12 * K + 4 + 16 + 4) + wl.P * 52
     achieved = alg_bytes / (fine_mean * 1e-3) / 1e9
+    traffic, traffic_src = None, None
+    tfile = os.path.join(ROOT, "profiles", "traffic_fine_kernel.json")
+    if world == 1 and os.path.exists(tfile):
+        # HBM bytes per launch are PMC counters (FETCH_SIZE / WRITE_SIZE in separate rocprofv3 passes of this same command,
+        # tools/collect_traffic.py); they cannot be read in-process, so the committed measurement is quoted with its source
+        tj = json.load(open(tfile))
+        traffic, traffic_src = tj.get("traffic_bytes_per_launch"), "profiles/traffic_fine_kernel.json (%s)" % tj.get("round", "r1")
+    hbm = {"bound": "hbm", "kernel": "fine_kernel<5> (fine pass + fused blend)", "achieved": round(achieved, 2),
+           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+           "traffic_source": traffic_src, "algorithmic_bytes": alg_bytes, "kernel_ms_mean": round(fine_mean, 5),
+           "kernel_ms_median": round(fine_med, 5)}
+    # VALU: the backward gather evaluates the occupancy rule of rasterize_points_backward.cu:141-178 for every (pixel,
+    # visible point) pair inside the search radius: dx, dy, d2 (fma), two range compares, the g>0 / bbox skip (3), max,
+    # rcp, the product with g and two accumulating fmas = MIN_OPS lane operations.  Peak = 256 CUs x 4 SIMDs x 32 lanes x
+    # 2.4 GHz lane operations per second (= the 157.3 TFLOP/s fp32 vector peak of MI355X_MICROARCH.md with an FMA as two).
+    MIN_OPS, VALU_PEAK = 12, 256 * 4 * 32 * 2.4e9 / 1e12
+    valu_ach = pairs * MIN_OPS / (gather_ms * 1e-3) / 1e12 if gather_ms > 0 else 0.0
+    valu = {"bound": "valu", "kernel": "render_backward_kernel<3> (blend backward + occupancy surrogate per visible point)",
+            "achieved": round(valu_ach, 4), "peak": round(VALU_PEAK, 2), "unit": "Tlaneop/s", "frac": round(valu_ach / VALU_PEAK, 5),
+            "pairs": pairs, "min_ops_per_pair": MIN_OPS, "visible_points": n_vis, "kernel_ms_mean": round(gather_ms, 5),
+            "how": "event time of dss_render_backward (%.5f ms) minus its two preparation launches alone (%.5f ms)"
+                   % (bwd_ms, prep_ms)}
+    dominant, other = (valu, hbm) if gather_ms > fine_mean else (hbm, valu)
     if rank == 0:
         rec = {
             "metric": "Msplats/s fwd+bwd @512^2", "value": round(value, 3), "unit": "Msplats/s",
@@ -331,16 +407,17 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: bunny-8000 x4 jitter = %d pts/cloud, %d camera(s), "
                                    "512x512, K=5, fwd+bwd (setup+raster+blend and their backward), "
-                                   "grad_out=randn(seed 1)" % (wl.Pc, wl.N),
+                                   "grad_out=randn(seed 1), variance scale h precomputed (kNN-7 outside the step; "
+                                   "see value_with_knn)" % (wl.Pc, wl.N),
                        "points_per_cloud": wl.Pc, "cameras": wl.N, "image_size": S, "points_per_pixel": K,
-                       "parallelism": "rows%d" % world, "launch": mode,
+                       "h_precomputed": True, "parallelism": "rows%d" % world, "launch": mode,
                        "dist": {"world_size": dist.get_world_size(), "backend": dist.get_backend()} if world > 1
                        else {"world_size": 1, "backend": None}},
-            "roofline": {"bound": "hbm", "kernel": "fine_kernel<5> (fine pass + fused blend)", "achieved": round(achieved, 2),
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                         "traffic": traffic, "algorithmic_bytes": alg_bytes, "kernel_ms_mean": round(fine_mean, 5),
-                         "kernel_ms_median": round(fine_med, 5)},
+            "roofline": dominant, "roofline_other": other,
         }
+        if value_knn is not None:
+            rec["value_with_knn"] = round(value_knn, 3)
+            rec["ms_per_step_with_knn"] = round(ms_knn, 5)
         for k, v in ms_modes.items():
             rec["config"]["calibration_ms_per_step_" + k] = round(v, 5)
         if not args.no_cpu_baseline:

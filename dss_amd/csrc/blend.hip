@@ -22,10 +22,11 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(
     for (int k = 0; k < K; ++k) {
         const int32_t p = idx[i * K + k];
         if (p < 0) continue;
-        cum += expf(-0.5f * qv[i * K + k]) * scaler[p];
+        cum += ewa_weight(qv[i * K + k], scaler[p]);
     }
     if (cum < 1e-4f) cum = 1e-4f;
     if (wsum) wsum[i] = cum;
+    const float inv_cum = fast_rcp(cum);
     float acc[(C > 0) ? C : BLEND_MAX_C];
 #pragma unroll
     for (int ch = 0; ch < ((C > 0) ? C : BLEND_MAX_C); ++ch) acc[ch] = 0.0f;
@@ -33,7 +34,7 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(
         const int32_t p = idx[i * K + k];
         if (p < 0) continue;
         // normalised weight once per fragment (same arithmetic as the fused epilogue of the fine pass)
-        const float w = expf(-0.5f * qv[i * K + k]) * scaler[p] / cum;
+        const float w = ewa_weight(qv[i * K + k], scaler[p]) * inv_cum;
 #pragma unroll
         for (int ch = 0; ch < ((C > 0) ? C : BLEND_MAX_C); ++ch)
             if (ch < Cn) acc[ch] += feat[(size_t)p * Cn + ch] * w;
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(256) void blend_backward_scatter_kernel(
         const int32_t p = idx[i * K + k];
         if (p < 0) continue;
         any = true;
-        cum += expf(-0.5f * qv[i * K + k]) * scaler[p];
+        cum += ewa_weight(qv[i * K + k], scaler[p]);
     }
     if (!any) return;
     if (cum < 1e-4f) cum = 1e-4f;
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(256) void blend_backward_scatter_kernel(
     for (int k = 0; k < K; ++k) {
         const int32_t p = idx[i * K + k];
         if (p < 0) continue;
-        const float w = expf(-0.5f * qv[i * K + k]) * scaler[p];
+        const float w = ewa_weight(qv[i * K + k], scaler[p]);
 #pragma unroll
         for (int ch = 0; ch < CM; ++ch)
             if (ch < Cn) atomicAdd(&grad_feat[(size_t)p * Cn + ch], g[ch] * w / cum);

@@ -114,6 +114,13 @@ __device__ __forceinline__ float eps_denom_py(float d)  // DSS/utils/mathHelper.
     return s * fmaxf(fabsf(d), 1e-17f);
 }
 
+// EWA fragment weight exp(-Q/2) * scaler (renderer.py:53) on the transcendental unit: exp(-q/2) = 2^(-q/2 * log2 e),
+// one v_exp_f32 (~1 ulp) instead of the ~15-instruction expf; 1/x as one v_rcp_f32 (1 ulp) instead of the IEEE divide
+// sequence.  The image is checked at 1e-4 against the oracle (observed ~3e-7); every kernel that forms weights uses
+// these two helpers, so the fused and the stand-alone blend agree bit for bit.
+__device__ __forceinline__ float ewa_weight(float q, float scaler) { return __builtin_amdgcn_exp2f(-0.72134752f * q) * scaler; }
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
 static inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }

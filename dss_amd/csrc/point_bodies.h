@@ -86,7 +86,7 @@ __device__ __forceinline__ void blend_point_gather(int lane, int64_t p, int n, c
             if (!wsum) {
                 for (int k = 0; k < K; ++k) {
                     const int32_t v = pi[k];
-                    if (v >= 0) cum += expf(-0.5f * qv[pix * K + k]) * scaler[v];
+                    if (v >= 0) cum += ewa_weight(qv[pix * K + k], scaler[v]);
                 }
                 if (cum < 1e-4f) cum = 1e-4f;
             }

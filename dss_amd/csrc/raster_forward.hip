@@ -638,15 +638,16 @@ __device__ __forceinline__ void fine_tile(const FineArgs &A, const int tile_id, 
         for (int k = 0; k < KMAX; ++k) {
             wk[k] = 0.0f;
             if (k < K && ki[k] >= 0) {
-                wk[k] = expf(-0.5f * kq[k]) * (blend3 ? bsc[PREFETCH_BLEND ? k : 0] : A.scaler[ki[k]]);
+                wk[k] = ewa_weight(kq[k], blend3 ? bsc[PREFETCH_BLEND ? k : 0] : A.scaler[ki[k]]);
                 cum += wk[k];
             }
         }
         if (cum < 1e-4f) cum = 1e-4f;
         A.wsum[pix] = cum;
-        // normalised weights once per fragment (K IEEE divides per pixel, not K*C): img = sum f * (w / cum)
+        // normalised weights once per fragment: img = sum f * (w / cum)
+        const float inv_cum = fast_rcp(cum);
 #pragma unroll
-        for (int k = 0; k < KMAX; ++k) wk[k] = wk[k] / cum;
+        for (int k = 0; k < KMAX; ++k) wk[k] = wk[k] * inv_cum;
         float *o = A.image + (size_t)n * A.img_sn + (size_t)(r_e - g.row0) * A.img_sr + (size_t)c_e * (A.C + 1);
         if (A.C == 3) {
             // RGBA as ONE 16-byte store per pixel (four dword stores at a 16-byte stride quadruple the

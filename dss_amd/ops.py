@@ -388,13 +388,13 @@ def render_forward(world, normals, h, M, V, znear, zfar, cloud_to_packed_first_i
                    image_size: int, points_per_pixel: int, cutoff_threshold: float, depth_merging_thres: float,
                    antialiasing_sigma: float = 1.0, backface_culling: bool = False, shared_cloud: bool = False,
                    rows: Optional[Tuple[int, int]] = None, out_image: Optional[torch.Tensor] = None,
-                   out_visible: Optional[torch.Tensor] = None, vr6=None, frame_normals=None):
+                   out_visible: Optional[torch.Tensor] = None, vr6=None, frame_normals=None, want_zbuf: bool = True):
     """Fused forward (setup + binning + fine + blend, ``dss_render_forward``).  ``out_image`` (float32
     (N,rows,S,C+1), 16-byte aligned) / ``out_visible`` (uint8 (P,)) let the caller place these two outputs
     in its own buffer (the multi-GPU step points them into one all-gather send buffer).  ``features`` are the
     packed (P,C) features.  Returns a dict with everything the separate calls produce:
     ``pts_screen, ellipse_params, radii, scaler, cutoff_threshold, valid, idx, zbuf, qvalue, occupancy,
-    visible, image, wsum``."""
+    visible, image, wsum``.  ``want_zbuf=False`` skips the depth plane (``zbuf`` is None): the fused backward never reads it."""
     lib = _lib.load()
     world = _lib.require_gpu(world, "world", _f32)
     dev = world.device
@@ -432,8 +432,8 @@ def render_forward(world, normals, h, M, V, znear, zfar, cloud_to_packed_first_i
         return o
     with torch.cuda.device(dev):
         o = dict(pts_screen=e(P, 3), ellipse_params=e(P, 3), radii=e(P, 2), scaler=e(P), cutoff_threshold=e(P),
-                 idx=e(N, nr, S, K, dtype=_i32), zbuf=e(N, nr, S, K), qvalue=e(N, nr, S, K), occupancy=e(N, nr, S),
-                 image=e(N, nr, S, C + 1) if out_image is None else out_image, wsum=e(N, nr, S))
+                 idx=e(N, nr, S, K, dtype=_i32), zbuf=e(N, nr, S, K) if want_zbuf else None, qvalue=e(N, nr, S, K),
+                 occupancy=e(N, nr, S), image=e(N, nr, S, C + 1) if out_image is None else out_image, wsum=e(N, nr, S))
         valid = e(P, dtype=_u8)
         vis = e(P, dtype=_u8) if out_visible is None else out_visible
         img = o["image"]

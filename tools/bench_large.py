@@ -43,6 +43,12 @@ rec = {"config": which, "points_per_cloud": P, "cameras": N, "image_size": S, "m
        "fine_algorithmic_bytes": alg, "fine_GBps": round(alg / fine_mean / 1e6, 1),
        "fine_frac_of_8TBps": round(alg / fine_mean / 1e6 / 8000, 4), "occupancy_mean": round(float(img[..., 3].mean()), 4), "h": h}
 try:
+    g_ms, b_ms, p_ms, pairs, n_vis = wl.backward_gather_ms(iters=10)
+    rec.update(backward_gather_ms=round(g_ms, 4), backward_total_ms=round(b_ms, 4), backward_prep_ms=round(p_ms, 4),
+               backward_pairs=pairs, backward_valu_frac=round(pairs * 12 / (g_ms * 1e-3) / 1e12 / (256 * 4 * 32 * 2.4e-3), 4))
+except Exception as e:  # noqa: BLE001
+    rec["backward_gather_error"] = str(e)[:200]
+try:
     _f = bench.ops.render_forward(wl.world, wl.normals, wl.h, wl.M, wl.V, wl.znear, wl.zfar, wl.first, wl.num, wl.colors, S, K,
                                  bench.CUTOFF, bench.THR, bench.SIGMA, False, True)
     rec["visible_points"] = int(_f["visible"].sum())

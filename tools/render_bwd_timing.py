@@ -9,7 +9,7 @@ out_dir = os.path.join(ROOT, "gpurun_out"); os.makedirs(out_dir, exist_ok=True)
 so = os.path.join(out_dir, "libdss_hip_timing.so"); src = os.path.join(ROOT, "dss_amd", "csrc")
 subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
                 "-fno-fast-math", "-fvisibility=hidden", "-DDSS_FINE_TIMING",
-                *[os.path.join(src, f) for f in ("api.hip", "raster_forward.hip", "raster_backward.hip", "blend.hip", "setup.hip", "knn.hip")],
+                *sorted(os.path.join(src, f) for f in os.listdir(src) if f.endswith(".hip")),
                 "-o", so], check=True)
 from dss_amd import _lib, ops
 _lib.LIB_PATH = so
