@@ -12,6 +12,7 @@
 //   occ_backward_kernel    occupancy surrogate gradient                   rasterize_points_backward.cu:141-178
 //   zbuf_backward_kernel   z_grad scatter                                 rasterize_points.cu:823-846
 //   clip_grad_kernel       per-point norm clip hook                       rasterizer.py:667-673
+#include <stdlib.h>
 #include "point_bodies.h"
 
 namespace dss {
@@ -781,7 +782,57 @@ __global__ __launch_bounds__(PREP_THREADS) void band_filter_kernel(
     }
 }
 
-template <int C, bool SEG>
+// ---------------------------------------------------------------------------------------------
+// Fused backward gather, TPW visible points per wavefront (TPW = 4, 2 or 1; 64 / TPW lanes each).
+//
+// Round 1 gave every visible point a whole wavefront with wave-uniform bookkeeping: ~840 VALU + ~570 SALU
+// instructions per point, of which the rule itself (rasterize_points_backward.cu:141-178: ~12 operations for each of
+// the ~350 pixels within rs) needs a sixth; the rest was per-task overhead executed redundantly by 64 lanes -- window
+// ranges, lane tilings, record unpacking, five wave reductions, the clip -- plus a third of the lanes idle in 21-wide
+// windows on 32-lane tilings.  Here the overhead is ordinary SIMD work of TPW independent tasks: every value that used
+// to be wave-uniform lives in a VGPR that is uniform within the task's lanes.  A task's lanes are 16 columns x RP row
+// phases (RP = 4 / TPW): the window is swept with two column slots per lane (packed fp32), rows rp, rp + RP, ... per
+// lane row, eight rows of loads in flight per trip; the blend box is walked in 4 x 4 pixel patches, one per lane row.
+// The five sums of a task are reduced with four DPP steps inside each 16-lane row plus RP - 1 scalar adds.
+// Throughput-bound lists (large clouds) run four tasks per wavefront -- 1.9x faster than round 1 at 8 x 1M points --,
+// short lists (a few tasks per wavefront, latency-bound) fewer tasks with more lanes each.  Tasks stay statically
+// dealt (group q = wave, wave + n_waves, ...), ids one group ahead.
+// ---------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float row_add(float v) { return v + dpp_f32<CTRL>(v); }
+// sum over the 16 lanes of a DPP row, left in every lane of the row (fixed order: deterministic)
+__device__ __forceinline__ float row_sum16(float v)
+{
+    v = row_add<0xB1>(v);   // quad_perm [1,0,3,2]
+    v = row_add<0x4E>(v);   // quad_perm [2,3,0,1]
+    v = row_add<0x141>(v);  // row_half_mirror
+    v = row_add<0x140>(v);  // row_mirror
+    return v;
+}
+// sum over the lanes of a task (RP rows of 16), left in every lane of the task
+template <int RP>
+__device__ __forceinline__ float task_sum(float v, int grp)
+{
+    v = row_sum16(v);
+    if (RP == 1) return v;
+    const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    if (RP == 4) return (a + b) + (c + d);
+    return grp == 0 ? a + b : c + d;
+}
+// max over the tasks of a wavefront of an int that is uniform within each task -> wave-uniform (SGPR)
+template <int TPW>
+__device__ __forceinline__ int tasks_max(int v)
+{
+    int m = __builtin_amdgcn_readlane(v, 0);
+    if (TPW >= 2) m = max(m, __builtin_amdgcn_readlane(v, 32));
+    if (TPW >= 4) m = max(m, max(__builtin_amdgcn_readlane(v, 16), __builtin_amdgcn_readlane(v, 48)));
+    return m;
+}
+
+template <int C, bool SEG, int TPW>
 __global__ __launch_bounds__(256) void render_backward_kernel(
     const float *__restrict__ grad_out, const float *__restrict__ grad_alpha /* dense (N,rows,S) */,
     const int32_t *__restrict__ idx, const float *__restrict__ qv,
@@ -792,8 +843,11 @@ __global__ __launch_bounds__(256) void render_backward_kernel(
     int rows, uint32_t large_waves, float *__restrict__ grad_feat, float *__restrict__ grad_pts)
 {
     constexpr int CM = (C > 0) ? C : BLEND_MAX_C;
+    constexpr int KF = 8;            // fragment slots held in registers; deeper lists take the loop
+    constexpr int GS = 64 / TPW;     // lanes per task
+    constexpr int RP = GS / 16;      // row phases per task
     const int Cn = (C > 0) ? C : Crt;
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, grp = lane / GS, rp = (lane % GS) >> 4, l = lane & 15;
     const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6);
     uint32_t n_waves = gridDim.x * 4;
     // SEG: vis_count[0..n_seg) are per-segment counts written by backward_compact_kernel (n_seg <= 64): every
@@ -812,160 +866,219 @@ __global__ __launch_bounds__(256) void render_backward_kernel(
     } else {
         count = *vis_count;
     }
-    // Long lists use 6 workgroups per CU: more resident gathers only evict each other's image rows from L2
-    // (8 x 1M points at 1024^2: 1169 Msplats/s with 6 per CU, 1058 with 7).  Short lists (a few tasks per
-    // wavefront) use every resident wavefront; equalising the task counts (ceil(count / rounds) wavefronts)
-    // was measured and is slower (329 vs 348 Msplats/s on the 512^2 bunny).
-    if (count > 8u * n_waves) n_waves = min(n_waves, large_waves);
+    const uint32_t n_groups = (count + TPW - 1u) / TPW;
+    // long lists use 6 workgroups per CU: more resident gathers only evict each other's image rows from L2
+    if (n_groups > 8u * n_waves) n_waves = min(n_waves, large_waves);
     if (wave >= n_waves) return;
-#ifdef DSS_FINE_TIMING
-    long long tm_rt0 = __builtin_amdgcn_s_memrealtime(), tm_occ = 0, tm_blend = 0, tm_pro = 0, tm_tasks = 0;
-#endif
-    // One task = one visible point, handled by the whole wavefront.  Everything that identifies the task is
-    // wave-uniform, so it is kept in SGPRs (readfirstlane) and fetched with scalar loads; the NEXT task's
-    // point id and record are requested before the current task's gathers and arrive during them (the
-    // prologue was ~10 % of a task: two dependent round trips before the first gather load could issue).
-    // Cloud of a point without touching memory: every wavefront keeps (first, count, rs) of cloud `lane` in its
-    // lanes; the owner is found with one ballot.  (The scalar-load loop of find_cloud cost ~2 us per TASK at
-    // 8 clouds: two dependent loads per cloud.)  More than 64 clouds fall back to the loop.
-    const int64_t cl_first = lane < N ? first_idx[lane] : (int64_t)0x7fffffffffffffffll;
-    const int64_t cl_count = lane < N ? num_pts[lane] : 0;
-    const float cl_rs = lane < N ? rs[lane] : 0.0f;
-    auto cloud_of = [&](int64_t p, float &rs_n) -> int {
-        int n;
-        if (N <= 64) {
-            const unsigned long long own = __ballot(p >= cl_first && p < cl_first + cl_count);
-            n = own ? (int)__builtin_ctzll(own) : -1;
-        } else {
-            n = find_cloud(p, first_idx, num_pts, N);
-        }
-        rs_n = (n >= 0 && N <= 64) ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cl_rs), n < 0 ? 0 : n))
-                                   : (n >= 0 ? rs[n] : 0.0f);
-        return n;
-    };
-    auto task_point = [&](uint32_t t) -> int {
-        if (SEG) {
-            // last segment that starts at or before t (starts are non-decreasing over lanes; empty segments
-            // share their successor's start and lose the tie)
-            const int seg = (int)__popcll(__ballot(seg_excl <= t)) - 1;
-            const uint32_t excl = (uint32_t)__builtin_amdgcn_readlane((int)seg_excl, seg);
-            return vis_list[(size_t)seg * seg_pts + (t - excl)];
-        }
-        return vis_list[t];
-    };
-    // the six floats of a record come from three arrays: ONE vector load with a different address per lane
-    // (six scalar loads per task throttle on the scalar cache once tasks are short, measured on 8 x 1M points)
-    auto issue_rec = [&](int p) -> float {
-        const float *a = lane < 3 ? points + 3 * (size_t)p + lane
-                       : lane < 5 ? radii + 2 * (size_t)p + (lane - 3)
-                                  : (scaler ? scaler + p : points + 3 * (size_t)p);
-        return lane < 6 ? *a : 0.0f;
-    };
-    auto unpack_rec = [&](float v, SplatRec &R) {
-        R.px = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
-        R.py = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 1));
-        R.pz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 2));
-        R.rx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 3));
-        R.ry = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 4));
-        R.sc = scaler ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 5)) : 0.0f;
-    };
-    // Static schedule: task t = wave, wave + n_waves, ...  (A dynamic one -- 64 atomic queue heads, one returning
-    // atomic per task, next position prefetched -- was measured at HALF the speed on every configuration: a
-    // returning global atomic is slower than a whole gather trip and sits in the same in-order return queue as
-    // the gather loads.)  Software pipeline, three tasks deep: during task i the point id of task i+3 (scalar load)
-    // and the records of tasks i+1 and i+2 are in flight.  A record is requested a full task before it is
-    // needed: in a row band (multi-GPU) most tasks are rejected without any gather, and with a shallower
-    // pipeline each of those waited one memory round trip for the next record.
     const uint32_t wave_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave);
-    uint32_t t = wave_u;
-    if (t >= count) return;
-    int p_cur = __builtin_amdgcn_readfirstlane(task_point(t));
-    int p_nx = (t + n_waves < count) ? __builtin_amdgcn_readfirstlane(task_point(t + n_waves)) : 0;
-    int p_nx2 = (t + 2 * n_waves < count) ? __builtin_amdgcn_readfirstlane(task_point(t + 2 * n_waves)) : 0;
-    SplatRec cur;
-    unpack_rec(issue_rec(p_cur), cur);
-    float v_nx = (t + n_waves < count) ? issue_rec(p_nx) : 0.0f;
-    for (;;) {
-#ifdef DSS_FINE_TIMING
-        const long long tm0 = __builtin_amdgcn_s_memtime();
-#endif
-        const uint32_t t_next = t + n_waves;
-        const bool have_next = t_next < count;
-        const bool have_next2 = t_next + n_waves < count;
-        int p_nx3 = 0;
-        float v_nx2 = 0.0f;
-        if (t_next + 2 * n_waves < count) p_nx3 = task_point(t_next + 2 * n_waves);
-        const int64_t p = p_cur;
-        float rs_n;
-        const int n = cloud_of(p, rs_n);
-        float gx = 0.0f, gy = 0.0f;
+    if (wave_u >= n_groups) return;
+
+    // point id of this lane's task in group q (-1 beyond the list); uniform within the task's lanes
+    auto task_ids = [&](uint32_t q) -> int {
+        int off[TPW];
+#pragma unroll
+        for (int g = 0; g < TPW; ++g) {
+            const uint32_t t = (uint32_t)TPW * q + (uint32_t)g;   // uniform
+            off[g] = -1;
+            if (t < count) {
+                if (SEG) {
+                    // last segment that starts at or before t (empty segments share their successor's start)
+                    const int seg = (int)__popcll(__ballot(seg_excl <= t)) - 1;
+                    const uint32_t excl = (uint32_t)__builtin_amdgcn_readlane((int)seg_excl, seg);
+                    off[g] = seg * seg_pts + (int)(t - excl);
+                } else {
+                    off[g] = (int)t;
+                }
+            }
+        }
+        int o = off[0];
+#pragma unroll
+        for (int g = 1; g < TPW; ++g) o = (grp == g) ? off[g] : o;
+        return o >= 0 ? vis_list[o] : -1;
+    };
+    const NdcMap ndc(S);
+    const size_t plane = (size_t)rows * S;
+    int p_nx = task_ids(wave_u);
+    for (uint32_t q = wave_u;; ) {
+        const int p = p_nx;
+        const uint32_t q_next = q + n_waves;
+        const bool more = q_next < n_groups;
+        if (more) p_nx = task_ids(q_next);  // in flight during this group
+        // ---- record + cloud of the task's point ------------------------------------------------------------
+        float px = 0.f, py = 0.f, pz = -1.f, rx = 0.f, ry = 0.f, sc = 0.f, cur_r = 0.f;
+        int n = -1;
+        if (p >= 0) {
+            px = points[3 * (size_t)p]; py = points[3 * (size_t)p + 1]; pz = points[3 * (size_t)p + 2];
+            const float2 rr = reinterpret_cast<const float2 *>(radii)[p];
+            rx = rr.x; ry = rr.y;
+            sc = scaler ? scaler[p] : 0.0f;
+            for (int cld = 0; cld < N; ++cld) {  // scalar loads; N is small
+                const int64_t f = first_idx[cld];
+                const bool own = (int64_t)p >= f && (int64_t)p < f + num_pts[cld];
+                n = own ? cld : n;
+                cur_r = own ? rs[cld] : cur_r;
+            }
+        }
+        const int nn = max(n, 0);
+        // ---- occupancy window (rasterize_points_backward.cu:141-178) ---------------------------------------
+        const float cur_r2 = cur_r * cur_r;
+        int xlo = 0, xhi = -1, ylo = 0, yhi = -1;
+        bool o_ok = n >= 0 && !(pz < 0 || fabsf(py) > 1.0f || fabsf(px) > 1.0f) &&
+                    ndc_index_range_tight(px, cur_r, S, xlo, xhi) && ndc_index_range_tight(py, cur_r, S, ylo, yhi);
+        if (o_ok) {
+            ylo = max(ylo, S - row0 - rows);
+            yhi = min(yhi, S - 1 - row0);
+            o_ok = ylo <= yhi;
+        }
+        if (!o_ok) { xlo = 0; xhi = -1; ylo = 0; yhi = -1; }
+        const int ow = xhi - xlo + 1, oh = yhi - ylo + 1;          // 0 for an empty window
+        const int ncp = (tasks_max<TPW>(ow) + 31) >> 5;             // column-slot pairs: wave-uniform
+        const int nrow = (tasks_max<TPW>(oh) + RP - 1) / RP;        // rows per lane row: wave-uniform
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        f2 gx2 = {0.0f, 0.0f}, gy2 = {0.0f, 0.0f};  // the lane's two column slots, summed at the end
+        const float *__restrict__ gimg = grad_alpha + (size_t)nn * plane;
+        for (int cp = 0; cp < ncp; ++cp) {
+            // this lane's two columns of the pass: x0 = xlo + 32 cp + l, x1 = x0 + 16 (clamped: masked, in bounds)
+            const int x0 = xlo + 32 * cp + l, x1 = x0 + 16;
+            const bool c0 = x0 <= xhi, c1 = x1 <= xhi;
+            const int x0c = c0 ? x0 : max(xhi, 0), x1c = c1 ? x1 : max(xhi, 0);
+            const f2 dx = {ndc(x0c) - px, ndc(x1c) - px};
+            const f2 dx2 = dx * dx;
+            // "g > 0 and outside the splat's box": with ry_eff = -1 for out-of-box columns the row test alone decides
+            const f2 ry_eff = {(fabsf(dx.x) > rx) ? -1.0f : ry, (fabsf(dx.y) > rx) ? -1.0f : ry};
+            // image (row, col) of NDC (y, x) is (S-1-y, S-1-x); band row = S-1-y-row0: one image row up per NDC row
+            const int i0 = (S - 1 - row0 - max(ylo, 0)) * S + (S - 1 - x0c);  // element offsets in the camera's plane
+            const int i1 = (S - 1 - row0 - max(ylo, 0)) * S + (S - 1 - x1c);
+            // RB rows per trip: all their loads are issued before the first is used (one memory round trip per trip; a
+            // row-at-a-time loop spent ~1 us per ROW waiting)
+            constexpr int RB = 8;
+            for (int ib = 0; ib < nrow; ib += RB) {
+                float g0[RB], g1[RB];
+#pragma unroll
+                for (int u = 0; u < RB; ++u) {
+                    const int i = rp + RP * (ib + u);   // window row of this lane row
+                    const bool r_ok = i < oh;
+                    g0[u] = 0.0f;
+                    g1[u] = 0.0f;
+                    if (r_ok && c0) g0[u] = gimg[i0 - i * S];
+                    if (r_ok && c1) g1[u] = gimg[i1 - i * S];
+                }
+#pragma unroll
+                for (int u = 0; u < RB; ++u) {
+                    if (ib + u >= nrow) break;  // uniform
+                    const float dy = ndc(ylo + rp + RP * (ib + u)) - py;
+                    const float dy2 = dy * dy;
+                    const f2 gg = {g0[u], g1[u]};
+                    const f2 d2 = dx2 + dy2;
+                    const bool s0 = (int)(d2.x > cur_r2) | ((int)(gg.x > 0.0f) & (int)(fabsf(dy) > ry_eff.x));
+                    const bool s1 = (int)(d2.y > cur_r2) | ((int)(gg.y > 0.0f) & (int)(fabsf(dy) > ry_eff.y));
+                    // (dx, dy) / max(d2, 1e-10) * g with a 1-ulp reciprocal and fused accumulation; out-of-window slots
+                    // have g = 0, the d2 == 0 pair has dx = dy = 0: both contribute 0 without a test of their own
+                    const f2 rc = {__builtin_amdgcn_rcpf(fmaxf(d2.x, 1e-10f)), __builtin_amdgcn_rcpf(fmaxf(d2.y, 1e-10f))};
+                    f2 sgl = rc * gg;
+                    sgl.x = s0 ? 0.0f : sgl.x;
+                    sgl.y = s1 ? 0.0f : sgl.y;
+                    const f2 dyy = {dy, dy};
+                    gx2 = __builtin_elementwise_fma(dx, sgl, gx2);
+                    gy2 = __builtin_elementwise_fma(dyy, sgl, gy2);
+                }
+            }
+        }
+        float gx = gx2.x + gx2.y, gy = gy2.x + gy2.y;
+        // ---- blend backward over the splat's own bounding box (a fragment with idx == p can only exist there) ---
         float acc[CM];
 #pragma unroll
         for (int ch = 0; ch < CM; ++ch) acc[ch] = 0.0f;
-#ifdef DSS_FINE_TIMING
-        const long long tm1 = __builtin_amdgcn_s_memtime();
-#endif
-        auto mid = [&]() {
-            if (have_next2) v_nx2 = issue_rec(p_nx2);
-        };
-        // Row band (multi-GPU): most visible points cannot reach this rank's rows (7 of 8 at 8 ranks).  One
-        // conservative test on the wave-uniform record skips both gathers for them (~300 of the ~400 fixed
-        // instructions of a task); the reductions then sum zeros and the point's partial is written as zero.
-        bool in_band = true;
-        if (rows < S && n >= 0) {
-            const float reach = fmaxf(rs_n, cur.ry);
-            const float band_lo = -1 + (2 * (S - row0 - rows)) / (float)S;      // lower edge of the lowest pixel row
-            const float band_hi = -1 + (2 * (S - 1 - row0) + 2.0f) / (float)S;  // upper edge of the highest one
-            in_band = !(cur.py + reach < band_lo || cur.py - reach > band_hi);
+        if (grad_feat != nullptr) {
+            int bxlo = 0, bxhi = -1, bylo = 0, byhi = -1;
+            bool b_ok = n >= 0 && ndc_index_range_tight(px, rx, S, bxlo, bxhi) && ndc_index_range_tight(py, ry, S, bylo, byhi);
+            if (b_ok) {
+                bylo = max(bylo, S - row0 - rows);
+                byhi = min(byhi, S - 1 - row0);
+                b_ok = bylo <= byhi;
+            }
+            if (!b_ok) { bxlo = 0; bxhi = -1; bylo = 0; byhi = -1; }
+            // a lane row = a 4 x 4 pixel patch; the task's RP lane rows take patches rp, rp + RP, ... of its box (row-major,
+            // ptx patches per row), all tasks in a common loop over the largest box
+            const int ptx = (bxhi - bxlo + 4) >> 2, pty = (byhi - bylo + 4) >> 2;   // 0 for an empty box
+            const int npatch = (tasks_max<TPW>(ptx * pty) + RP - 1) / RP;
+            const float inv_ptx = 1.0f / (float)max(ptx, 1);
+            for (int it = 0; it < npatch; ++it) {
+                const int pi_ = rp + RP * it;
+                const int pty_i = (int)(((float)pi_ + 0.5f) * inv_ptx);   // pi_ / ptx (exact: small integers)
+                const int ptx_i = pi_ - pty_i * ptx;
+                const int xi = bxlo + 4 * ptx_i + (l & 3), yi = bylo + 4 * pty_i + (l >> 2);
+                if (pi_ >= ptx * pty || xi > bxhi || yi > byhi) continue;
+                const size_t pix = ((size_t)nn * rows + (S - 1 - yi - row0)) * S + (S - 1 - xi);
+                const int32_t *pi = idx + pix * K;
+                const float *pq = qv + pix * K;
+                const float *go = grad_out + pix * (Cn + 1);
+                float q_sel = 0.0f;
+                bool found = false;
+                float cum;
+                float gch[CM];
+                if (K <= KF && wsum != nullptr) {
+                    // everything the pixel needs in ONE round trip (the image gradient is read whether or not the point
+                    // is among the pixel's fragments: it almost always is)
+                    int32_t vi[KF];
+                    float qk[KF];
+#pragma unroll
+                    for (int k = 0; k < KF; ++k) {
+                        vi[k] = -1; qk[k] = 0.0f;
+                        if (k < K) { vi[k] = pi[k]; qk[k] = pq[k]; }
+                    }
+                    cum = wsum[pix];
+#pragma unroll
+                    for (int ch = 0; ch < CM; ++ch) gch[ch] = (ch < Cn) ? go[ch] : 0.0f;
+#pragma unroll
+                    for (int k = 0; k < KF; ++k) {
+                        const bool hit = (k < K) && vi[k] == (int32_t)p;
+                        q_sel = hit ? qk[k] : q_sel;
+                        found = found || hit;
+                    }
+                } else {
+                    cum = 0.0f;
+                    for (int k = 0; k < K; ++k) {
+                        const int32_t v = pi[k];
+                        if (v == (int32_t)p) { found = true; q_sel = pq[k]; }
+                        if (!wsum && v >= 0) cum += ewa_weight(pq[k], scaler[v]);
+                    }
+                    if (wsum) cum = wsum[pix];
+                    else if (cum < 1e-4f) cum = 1e-4f;
+#pragma unroll
+                    for (int ch = 0; ch < CM; ++ch) gch[ch] = (ch < Cn) ? go[ch] : 0.0f;
+                }
+                if (!found) continue;
+                const float wn = ewa_weight(q_sel, sc) * fast_rcp(cum);
+#pragma unroll
+                for (int ch = 0; ch < CM; ++ch)
+                    if (ch < Cn) acc[ch] = fmaf(gch[ch], wn, acc[ch]);
+            }
         }
-        if (n >= 0 && in_band) {
-            // occupancy gradient = dense copy of the alpha channel of the image gradient; blend loads overlapped
-            occ_blend_point_gather<C>(lane, p, n, cur, rs_n, grad_alpha, 1, grad_out, idx, qv, wsum, scaler, S, K, Cn,
-                                      row0, rows, grad_feat != nullptr, gx, gy, acc, mid);
-        } else {
-            mid();
-        }
-#ifdef DSS_FINE_TIMING
-        const long long tm2 = __builtin_amdgcn_s_memtime();
-        tm_pro += tm1 - tm0; tm_occ += tm2 - tm1; tm_tasks += 1;
-#endif
-        gx = wave_sum(gx);
-        gy = wave_sum(gy);
+        // ---- per-task reductions, clip, stores -------------------------------------------------------------
+        gx = task_sum<RP>(gx, grp);
+        gy = task_sum<RP>(gy, grp);
 #pragma unroll
         for (int ch = 0; ch < CM; ++ch)
-            if (ch < Cn) acc[ch] = wave_sum(acc[ch]);
-#ifdef DSS_FINE_TIMING
-        tm_blend += (long long)__builtin_amdgcn_s_memtime() - tm2;
-#endif
-        if (lane == 0 && n >= 0) {
+            if (ch < Cn) acc[ch] = task_sum<RP>(acc[ch], grp);
+        if (l == 0 && rp == 0 && p >= 0 && n >= 0) {
             if (clip > 0.0f) {  // rasterizer.py:667-673 (z gradient is 0 on this path)
                 const float nrm = sqrtf(gx * gx + gy * gy);
                 gx = gx / fmaxf(nrm, 1e-12f) * fminf(nrm, clip);
                 gy = gy / fmaxf(nrm, 1e-12f) * fminf(nrm, clip);
             }
-            grad_pts[3 * p] = gx;
-            grad_pts[3 * p + 1] = gy;
-            grad_pts[3 * p + 2] = 0.0f;
+            grad_pts[3 * (size_t)p] = gx;
+            grad_pts[3 * (size_t)p + 1] = gy;
+            grad_pts[3 * (size_t)p + 2] = 0.0f;
             if (grad_feat) {
 #pragma unroll
                 for (int ch = 0; ch < CM; ++ch)
                     if (ch < Cn) grad_feat[(size_t)p * Cn + ch] = acc[ch];
             }
         }
-        if (!have_next) break;
-        t = t_next;
-        p_cur = p_nx;
-        p_nx = p_nx2;
-        p_nx2 = __builtin_amdgcn_readfirstlane(p_nx3);
-        unpack_rec(v_nx, cur);
-        v_nx = v_nx2;
+        if (!more) break;
+        q = q_next;
     }
-#ifdef DSS_FINE_TIMING
-    if (g_occ_timing && lane == 0) {
-        long long *o = g_occ_timing + (size_t)wave * 6;
-        o[0] = tm_rt0; o[1] = __builtin_amdgcn_s_memrealtime(); o[2] = tm_tasks; o[3] = tm_occ; o[4] = tm_blend; o[5] = tm_pro;
-    }
-#endif
 }
 
 __global__ __launch_bounds__(256) void zbuf_backward_kernel(const int32_t *__restrict__ idx,
@@ -1290,9 +1403,9 @@ extern "C" int dss_render_backward(const float *grad_out, const int32_t *idx, co
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
             cus = prop.multiProcessorCount;
         if (C == 3)
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_backward_kernel<3, true>, 256, 0);
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_backward_kernel<3, true, 4>, 256, 0);
         else
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_backward_kernel<0, true>, 256, 0);
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_backward_kernel<0, true, 4>, 256, 0);
         if (per_cu < 1) per_cu = 1;
         n_cus = cus;
         cap = cus * per_cu;
@@ -1300,15 +1413,31 @@ extern "C" int dss_render_backward(const float *grad_out, const int32_t *idx, co
     }
     const unsigned pgrid = (unsigned)((P + 3) / 4 < cap ? (P + 3) / 4 : cap);
     const uint32_t large_waves = 6u * (uint32_t)n_cus * 4u;
-#define DSS_LAUNCH_RB(CC, SS)                                                                                          \
-    hipLaunchKernelGGL((render_backward_kernel<CC, SS>), dim3(pgrid), dim3(256), 0, st, grad_out, alpha, idx, qvalue, wsum, \
+    // tasks per wavefront: four when the list is long enough to keep every resident wavefront busy with whole groups
+    // (throughput-bound), fewer -- more lanes per task, shorter dependent chains -- for short lists.  The visible count is
+    // only known on the device; P bounds it and the visible fraction of a rendered cloud is 30-60 %.
+    static int tpw_env = -1;
+    if (tpw_env < 0) {
+        const char *e = getenv("DSS_BACKWARD_TPW");
+        tpw_env = e ? atoi(e) : 0;
+    }
+    const long long est_tasks = (long long)P * 2 / 5;
+    int tpw = est_tasks >= 16ll * cap * 4 ? 4 : (est_tasks >= 4ll * cap * 4 ? 2 : 1);
+    if (tpw_env == 1 || tpw_env == 2 || tpw_env == 4) tpw = tpw_env;
+#define DSS_LAUNCH_RB(CC, SS, TT)                                                                                      \
+    hipLaunchKernelGGL((render_backward_kernel<CC, SS, TT>), dim3(pgrid), dim3(256), 0, st, grad_out, alpha, idx, qvalue, wsum, \
                        scaler, points, radii, rs, first_idx, num_pts, vis_count, vis_list, n_seg, seg_pts, N, S, K, C, clip, \
                        row0, row1 - row0, large_waves, grad_feat, grad_pts)
+#define DSS_LAUNCH_RB_T(CC, SS)                                                                                        \
+    do {                                                                                                               \
+        if (tpw == 4) DSS_LAUNCH_RB(CC, SS, 4); else if (tpw == 2) DSS_LAUNCH_RB(CC, SS, 2); else DSS_LAUNCH_RB(CC, SS, 1); \
+    } while (0)
     if (C == 3) {
-        if (small) DSS_LAUNCH_RB(3, true); else DSS_LAUNCH_RB(3, false);
+        if (small) DSS_LAUNCH_RB_T(3, true); else DSS_LAUNCH_RB_T(3, false);
     } else {
-        if (small) DSS_LAUNCH_RB(0, true); else DSS_LAUNCH_RB(0, false);
+        if (small) DSS_LAUNCH_RB_T(0, true); else DSS_LAUNCH_RB_T(0, false);
     }
+#undef DSS_LAUNCH_RB_T
 #undef DSS_LAUNCH_RB
     return check_launch("dss_render_backward");
 }

@@ -171,21 +171,25 @@ def test_cfg2_bunny_512_forward_backward_vs_oracle():
         assert _rel_l2(g.cpu().numpy(), o_g) <= 1e-3, (cl, gz is None)
         assert np.isfinite(g.cpu().numpy()).all()
 
-    # fused single-GPU backward (persistent wavefronts over the compacted visible list): identical bits
+    # fused single-GPU backward (persistent wavefronts over the compacted visible list, four points per wavefront): the
+    # same per-pair terms as the one-wavefront-per-point kernels, summed in a different fixed order
+    def same(a, b, tol=2e-6):
+        return _rel_l2(a.cpu().numpy(), b.cpu().numpy()) <= tol
     g_ref, rs_ref = ops.splat_backward(d["points"], d["radii"], vis, idx, gocc, None, d["first"], d["num"], radii_s,
                                        clip, return_rs=True)
     gf_ref, _ = ops.blend_backward(torch.from_numpy(grad_out).to(DEV), idx, qv, scaler, P, geometry=geom, wsum=wsum)
     for ws_ in (wsum, None):
         gf_f, g_f, rs_f = ops.render_backward(torch.from_numpy(grad_out).to(DEV), idx, qv, ws_, scaler, d["points"],
                                               d["radii"], vis, d["first"], d["num"], radii_s, clip, return_rs=True)
-        assert torch.equal(rs_f, rs_ref) and torch.equal(g_f, g_ref)
+        assert torch.equal(rs_f, rs_ref) and same(g_f, g_ref)
         assert _rel_l2(gf_f.cpu().numpy(), o_gf) <= 1e-3
-    assert torch.equal(gf_f if ws_ is not None else ops.render_backward(
-        torch.from_numpy(grad_out).to(DEV), idx, qv, wsum, scaler, d["points"], d["radii"], vis, d["first"], d["num"],
-        radii_s, clip)[0], gf_ref)
+    assert same(gf_f, gf_ref)
+    again = ops.render_backward(torch.from_numpy(grad_out).to(DEV), idx, qv, None, scaler, d["points"], d["radii"], vis,
+                                d["first"], d["num"], radii_s, clip)
+    assert torch.equal(again[0], gf_f) and torch.equal(again[1], g_f)  # deterministic
     _, g_only = ops.render_backward(torch.from_numpy(grad_out).to(DEV), idx, qv, wsum, scaler, d["points"], d["radii"],
                                     vis, d["first"], d["num"], radii_s, clip, with_features=False)
-    assert torch.equal(g_only, g_ref)
+    assert torch.equal(g_only, g_f)
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -504,7 +508,7 @@ def test_render_backward_multi_cloud_matches_unfused():
     gf_ref, gocc = ops.blend_backward(go, idx, qv, scaler, P, geometry=geom, wsum=wsum)
     g_ref = ops.splat_backward(d["points"], d["radii"], vis, idx, gocc, None, d["first"], d["num"], 4.0, 0.05)
     gf, g = ops.render_backward(go, idx, qv, wsum, scaler, d["points"], d["radii"], vis, d["first"], d["num"], 4.0, 0.05)
-    assert torch.equal(gf, gf_ref) and torch.equal(g, g_ref)
+    assert _rel_l2(gf.cpu().numpy(), gf_ref.cpu().numpy()) <= 2e-6 and _rel_l2(g.cpu().numpy(), g_ref.cpu().numpy()) <= 2e-6
     o_g, _, _ = oracle.splat_backward(sc["points"], sc["radii"], idx.cpu().numpy(), go[..., 3].cpu().numpy(), None,
                                       sc["first_idx"], sc["num_pts"], 4.0, 0.05)
     assert _rel_l2(g.cpu().numpy(), o_g) <= 1e-4
@@ -652,8 +656,8 @@ def test_render_backward_fragment_depths_channels_and_splat_sizes(K, C, rmax):
     o_gf, _ = oracle.blend_backward(go.cpu().numpy(), idx.cpu().numpy(), qv.cpu().numpy(), sc["scaler"], P)
     assert np.array_equal(rs.cpu().numpy(), o_rs)
     assert _rel_l2(g.cpu().numpy(), o_g) <= 1e-4 and _rel_l2(gf.cpu().numpy(), o_gf) <= 1e-4
-    # and the unfused entry points give the same bits
+    # and the unfused entry points give the same values (other summation order)
     geom = (d["points"], d["radii"], vis, d["first"], d["num"])
     gf_ref, gocc = ops.blend_backward(go, idx, qv, scaler, P, geometry=geom, wsum=wsum)
     g_ref = ops.splat_backward(d["points"], d["radii"], vis, idx, gocc, None, d["first"], d["num"], 3.0, 0.05)
-    assert torch.equal(gf, gf_ref) and torch.equal(g, g_ref)
+    assert _rel_l2(gf.cpu().numpy(), gf_ref.cpu().numpy()) <= 2e-6 and _rel_l2(g.cpu().numpy(), g_ref.cpu().numpy()) <= 2e-6
