@@ -129,34 +129,28 @@ class Workload:
         return float(np.mean(ms)), float(ms[len(ms) // 2])
 
     def fine_kernel_ms(self, iters=50):
-        """The forward's dominant kernel alone: exactly one launch per call (dss_splat_fine_blend = the fine pass with
-        the blend fused into its epilogue, the kernel dss_render_forward launches)."""
+        """The forward's dominant kernel alone, exactly as the step launches it: dss_render_forward with DSS_WS_BINNED
+        repeats only its second launch (fine pass + fused blend on the packed splat records) on the tile lists a
+        DSS_WS_UNKNOWN call with the same inputs left in the workspace -- one kernel per timed call, issued through a
+        prebuilt ctypes call so that no host work sits between the two events."""
         lib = _lib.load()
-        S = self.S
-        info = ops.point_setup(self.world, self.normals, self.h, self.M, self.V, self.znear, self.zfar, self.first,
-                               self.num, S, CUTOFF, SIGMA, False, True)
-        r0, r1 = self.part.rows
-        rows = r1 - r0
-        dev = self.dev
-        idx = torch.empty((self.N, rows, S, K), dtype=torch.int32, device=dev)
-        zbuf = torch.empty((self.N, rows, S, K), device=dev)
-        qv = torch.empty_like(zbuf)
-        occ = torch.empty((self.N, rows, S), device=dev)
-        vis = torch.zeros((self.P,), dtype=torch.uint8, device=dev)
-        nbytes = lib.dss_splat_forward_workspace(self.N, self.P, S, K, 1)
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        st = _lib.stream_ptr(dev)
-        a = (_lib.ptr(info["pts_screen"]), _lib.ptr(info["ellipse_params"]), _lib.ptr(info["cutoff_threshold"]),
-             _lib.ptr(info["radii"]), _lib.ptr(self.first), _lib.ptr(self.num), self.N, self.P)
-        _lib.check(lib.dss_splat_bin(a[0], a[3], a[4], a[5], self.N, self.P, S, r0, r1, _lib.ptr(ws), nbytes, st),
-                   "dss_splat_bin")
-        image = torch.empty((self.N, rows, S, 4), device=dev)
-        wsum = torch.empty((self.N, rows, S), device=dev)
-        run = lambda: lib.dss_splat_fine_blend(*a, THR, S, K, r0, r1, _lib.ptr(idx), _lib.ptr(zbuf), _lib.ptr(qv),
-                                               _lib.ptr(occ), _lib.ptr(vis), _lib.ptr(info["scaler"]),
-                                               _lib.ptr(self.colors), 3, _lib.ptr(image), _lib.ptr(wsum), _lib.ptr(ws),
-                                               nbytes, st)
-        _lib.check(run(), "dss_splat_fine")
+        p, S, dev = self.part, self.S, self.dev
+        f = ops.render_forward(self.world, self.normals, self.h, self.M, self.V, self.znear, self.zfar, self.first, self.num,
+                               self.colors, S, K, CUTOFF, THR, SIGMA, False, True, rows=p.rows, workspace_state=0)
+        ws = _lib.clean_workspace(dev, ("render_forward_binned", self.N, self.P, S),
+                                  lib.dss_render_forward_workspace(self.N, self.P, S, K))
+        r0, r1 = p.rows
+        P_ = _lib.ptr
+        valid, vis, img = f["valid"].view(torch.uint8), f["visible"].view(torch.uint8), f["image"]
+        args = (P_(self.world), P_(self.normals), None, P_(self.h), None, None, P_(self.M), P_(self.V), P_(self.znear),
+                P_(self.zfar), P_(self.first), P_(self.num), self.N, self.P, 1, 0, S, K, CUTOFF, SIGMA, THR, r0, r1,
+                P_(self.colors), 3, P_(f["pts_screen"]), P_(f["ellipse_params"]), P_(f["radii"]), P_(f["scaler"]),
+                P_(f["cutoff_threshold"]), P_(valid), P_(f["idx"]), P_(f["zbuf"]), P_(f["qvalue"]), P_(f["occupancy"]),
+                P_(vis), P_(img), int(img.stride(0)), int(img.stride(1)), P_(f["wsum"]), P_(ws), ws.numel(), 2,
+                _lib.stream_ptr(dev))
+        run = lambda: lib.dss_render_forward(*args)
+        _lib.check(run(), "dss_render_forward(DSS_WS_BINNED)")
+        self._keep = (f, ws)
         return self._event_ms(run, iters)
 
     def backward_gather_ms(self, iters=50):

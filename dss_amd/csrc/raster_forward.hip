@@ -209,6 +209,7 @@ __global__ __launch_bounds__(256) void setup_bin_kernel(const SetupArgs A, TileG
 
 struct FineArgs {
     const float *points, *ellipse, *cutoff, *radii;
+    const float4 *rec;         // packed 64-byte splat records (fused forward, see SetupArgs::rec) or nullptr
     const int64_t *first_idx, *num_pts;
     const uint32_t *counts;    // (N*tiles*DSS_SUB) sub-list fill counts, or nullptr (naive mode)
     const int32_t *lists;      // (N*tiles*DSS_SUB*cap)
@@ -372,7 +373,7 @@ __device__ __forceinline__ void fill_tile_rows(const FineArgs &A, int tile_id, i
     }
 }
 
-template <int KMAX>
+template <int KMAX, bool PACKED>
 __device__ __forceinline__ void fine_tile(const FineArgs &A, const int tile_id, int32_t *slot_to_clear)
 {
     // candidate chunk: three records per splat -> 2x ds_read_b128 + 1x ds_read_b64 per test
@@ -506,11 +507,21 @@ __device__ __forceinline__ void fine_tile(const FineArgs &A, const int tile_id, 
             if (slot_to_clear && tid == DSS_SUB) *slot_to_clear = 0;
         }
         if (have) {
-            const float px = A.points[3 * p], py = A.points[3 * p + 1], pz = A.points[3 * p + 2];
-            const float2 rr = reinterpret_cast<const float2 *>(A.radii)[p];
-            s_geo[dst] = make_float4(px, py, rr.x, rr.y);
-            s_ell[dst] = make_float4(A.ellipse[3 * p], A.ellipse[3 * p + 1], A.ellipse[3 * p + 2], A.cutoff[p]);
-            s_zid[dst] = make_float2(pz, __int_as_float((int)p));
+            if (PACKED) {
+                // one 64-byte record = one half cache line per candidate: three loads, one memory transaction (the four
+                // separate arrays cost four transactions, and every XCD ended up fetching every line of all of them:
+                // point ids are spatially random, so each 128-byte line held a point of every screen region)
+                const float4 *R = A.rec + 4 * p;
+                s_geo[dst] = R[0];
+                s_ell[dst] = R[1];
+                s_zid[dst] = make_float2(R[3].x, __int_as_float((int)p));
+            } else {
+                const float px = A.points[3 * p], py = A.points[3 * p + 1], pz = A.points[3 * p + 2];
+                const float2 rr = reinterpret_cast<const float2 *>(A.radii)[p];
+                s_geo[dst] = make_float4(px, py, rr.x, rr.y);
+                s_ell[dst] = make_float4(A.ellipse[3 * p], A.ellipse[3 * p + 1], A.ellipse[3 * p + 2], A.cutoff[p]);
+                s_zid[dst] = make_float2(pz, __int_as_float((int)p));
+            }
         }
         __syncthreads();
         if (base == 0) FT_MARK(2);
@@ -634,11 +645,20 @@ __device__ __forceinline__ void fine_tile(const FineArgs &A, const int tile_id, 
         // img = sum f*w/cum, alpha = occupancy
         float wk[KMAX];
         float cum = 0.0f;
+        float4 br[PACKED ? KMAX : 1];  // packed: {scaler, f0, f1, f2} of the pixel's fragments, one 16-byte load each
+        if (PACKED) {
+#pragma unroll
+            for (int k = 0; k < (PACKED ? KMAX : 1); ++k) {
+                br[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (k < K && ki[k] >= 0) br[k] = A.rec[4 * (size_t)ki[k] + 2];
+            }
+        }
 #pragma unroll
         for (int k = 0; k < KMAX; ++k) {
             wk[k] = 0.0f;
             if (k < K && ki[k] >= 0) {
-                wk[k] = ewa_weight(kq[k], blend3 ? bsc[PREFETCH_BLEND ? k : 0] : A.scaler[ki[k]]);
+                wk[k] = ewa_weight(kq[k], PACKED ? br[PACKED ? k : 0].x
+                                                 : (blend3 ? bsc[PREFETCH_BLEND ? k : 0] : A.scaler[ki[k]]));
                 cum += wk[k];
             }
         }
@@ -657,7 +677,9 @@ __device__ __forceinline__ void fine_tile(const FineArgs &A, const int tile_id, 
             for (int k = 0; k < KMAX; ++k)
                 if (k < K && ki[k] >= 0) {
                     float f0, f1, f2;
-                    if (blend3) {
+                    if (PACKED) {
+                        f0 = br[PACKED ? k : 0].y; f1 = br[PACKED ? k : 0].z; f2 = br[PACKED ? k : 0].w;
+                    } else if (blend3) {
                         f0 = bf0[PREFETCH_BLEND ? k : 0]; f1 = bf1[PREFETCH_BLEND ? k : 0]; f2 = bf2[PREFETCH_BLEND ? k : 0];
                     } else {
                         const float *f = A.feat + (size_t)ki[k] * 3;
@@ -731,7 +753,7 @@ __host__ __device__ __forceinline__ uint32_t fill_workgroups(int total_tiles)
     return (((uint32_t)total_tiles + 15u) / 16u + 7u) & ~7u;
 }
 
-template <int KMAX>
+template <int KMAX, bool PACKED>
 __global__ __launch_bounds__(FINE_THREADS) void fine_kernel(const FineArgs A)
 {
     const int total = A.N * A.g.tiles_x * A.g.tiles_y;
@@ -772,7 +794,7 @@ __global__ __launch_bounds__(FINE_THREADS) void fine_kernel(const FineArgs A)
         tile_id = __builtin_amdgcn_readfirstlane(*slot) - 1;
     }
     if (tile_id < 0 || tile_id >= total) return;
-    fine_tile<KMAX>(A, tile_id, (qmode && clean) ? slot : nullptr);
+    fine_tile<KMAX, PACKED>(A, tile_id, (qmode && clean) ? slot : nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -870,7 +892,10 @@ static int fine_grid(const FineArgs &A, int blocks)
 template <int KMAX>
 static void launch_fine(const FineArgs &A, int blocks, hipStream_t st)
 {
-    hipLaunchKernelGGL(fine_kernel<KMAX>, dim3(fine_grid(A, blocks)), dim3(FINE_THREADS), 0, st, A);
+    if (KMAX <= 8 && A.rec != nullptr && A.image != nullptr && A.C == 3)
+        hipLaunchKernelGGL((fine_kernel<(KMAX <= 8 ? KMAX : 8), true>), dim3(fine_grid(A, blocks)), dim3(FINE_THREADS), 0, st, A);
+    else
+        hipLaunchKernelGGL((fine_kernel<KMAX, false>), dim3(fine_grid(A, blocks)), dim3(FINE_THREADS), 0, st, A);
 }
 
 static bool dispatch_fine(const FineArgs &A, int blocks, hipStream_t st)
@@ -904,6 +929,7 @@ struct FwdWorkspace {
     int32_t *lists;    // N*tiles*SUB*cap
     uint32_t cap;
     TileQueue queue;
+    float4 *rec;         // packed splat records (P x 64 bytes) behind the lists; only carved for the fused forward
     size_t count_bytes;  // bytes to zero before binning (the DSS_WS_CLEAN region): everything in front of the lists
     size_t bytes;
 };
@@ -931,7 +957,7 @@ static TileGrid make_grid(int S, int row0, int row1)
 }
 
 // (the layout is sized for the full image: a row band uses a prefix of every region)
-static FwdWorkspace carve_fwd(void *ws, int N, int64_t P, int S)
+static FwdWorkspace carve_fwd(void *ws, int N, int64_t P, int S, bool with_records = false)
 {
     FwdWorkspace w;
     const TileGrid full = make_grid(S, 0, S);
@@ -949,6 +975,11 @@ static FwdWorkspace carve_fwd(void *ws, int N, int64_t P, int S)
     const size_t lists_off = w.count_bytes;
     w.lists = reinterpret_cast<int32_t *>(p + lists_off);
     w.bytes = lists_off + align_up(tiles_max * DSS_SUB * (size_t)w.cap * 4, 256);
+    w.rec = nullptr;
+    if (with_records) {
+        w.rec = reinterpret_cast<float4 *>(p + w.bytes);
+        w.bytes += align_up((size_t)P * 64, 256);
+    }
     return w;
 }
 
@@ -1049,7 +1080,7 @@ static int splat_fine_impl(const float *points, const float *ellipse, const floa
     const long long blocks_ll = (long long)N * g.tiles_x * g.tiles_y;
     if (blocks_ll > 0x7fffffffll) { set_error("dss_splat_fine: too many tiles"); return DSS_ERR_UNSUPPORTED; }
     FineArgs A;
-    A.points = points; A.ellipse = ellipse; A.cutoff = cutoff; A.radii = radii;
+    A.points = points; A.ellipse = ellipse; A.cutoff = cutoff; A.radii = radii; A.rec = nullptr;
     A.first_idx = first_idx; A.num_pts = num_pts;
     A.counts = nullptr; A.lists = nullptr; A.cap = 0;
     A.queue.tail = nullptr; A.queue.list = nullptr; A.queue.flag = nullptr; A.queue.capq = 0; A.queue_wgs = 0;
@@ -1133,7 +1164,9 @@ extern "C" __attribute__((visibility("default"))) int dss_debug_set_fine_timing(
 // ---------------------------------------------------------------------------------------------
 extern "C" size_t dss_render_forward_workspace(int N, int64_t P, int S, int K)
 {
-    return dss_splat_forward_workspace(N, P, S, K, 1);
+    (void)K;
+    if (N <= 0 || P <= 0 || S <= 0) return 256;
+    return carve_fwd(nullptr, N, P, S, true).bytes;  // tile structures + one 64-byte record per point
 }
 
 extern "C" int dss_render_forward(const float *world, const float *normals, const float *h_point, const float *h_cloud,
@@ -1165,7 +1198,7 @@ extern "C" int dss_render_forward(const float *world, const float *normals, cons
         set_error("dss_render_forward: NULL tensor pointer");
         return DSS_ERR_INVALID_ARGUMENT;
     }
-    const size_t need = dss_splat_forward_workspace(N, P, S, K, 1);
+    const size_t need = dss_render_forward_workspace(N, P, S, K);
     if (!workspace || workspace_bytes < need) {
         set_error("dss_render_forward: workspace %zu bytes < required %zu", workspace_bytes, need);
         return DSS_ERR_WORKSPACE;
@@ -1174,22 +1207,27 @@ extern "C" int dss_render_forward(const float *world, const float *normals, cons
     const TileGrid g = make_grid(S, row0, row1);
     const int tiles = g.tiles_x * g.tiles_y;
     if ((long long)N * tiles > 0x7fffffffll) { set_error("dss_render_forward: too many tiles"); return DSS_ERR_UNSUPPORTED; }
-    FwdWorkspace w = carve_fwd(workspace, N, P, S);
+    FwdWorkspace w = carve_fwd(workspace, N, P, S, true);
+    const bool packed = C == 3;  // the records carry three feature channels
     const bool clean = workspace_state == DSS_WS_CLEAN;
-    if (!clean && hipMemsetAsync(w.counts, 0, w.count_bytes, st) != hipSuccess) return check_launch("memset tile counts");
+    const bool rerun = workspace_state == DSS_WS_BINNED;  // lists + records of this very input are in place: fine pass only
+    if (!clean && !rerun && hipMemsetAsync(w.counts, 0, w.count_bytes, st) != hipSuccess)
+        return check_launch("memset tile counts");
     SetupArgs SA;
     SA.world = world; SA.normals = normals; SA.h_point = h_point; SA.h_cloud = h_cloud; SA.M = M; SA.V = V;
     SA.vr6 = vr6; SA.frame_n = frame_normals;
     SA.znear = znear; SA.zfar = zfar; SA.first_idx = first_idx; SA.num_pts = num_pts; SA.N = N; SA.P = P;
     SA.shared = shared_cloud; SA.backface = backface_culling; SA.S = S; SA.cutoffC = cutoff_threshold;
     SA.sigma = antialiasing_sigma; SA.screen = pts_screen; SA.ellipse = ellipse; SA.radii = radii; SA.scaler = scaler;
-    SA.cutoff = cutoff; SA.valid = valid;
+    SA.cutoff = cutoff; SA.valid = valid; SA.rec = packed ? w.rec : nullptr; SA.feat = feat;
     // one wave per workgroup: at DSS sizes (tens of thousands of points) 256-thread groups would occupy only
     // half of the CUs with one wave per SIMD, and this kernel is a chain of dependent latencies
     const int pb = (int)((P + 63) / 64);
-    hipLaunchKernelGGL(setup_bin_kernel, dim3(pb), dim3(64), 0, st, SA, g, w.counts, w.lists, w.cap, w.queue, visible);
+    if (!rerun)
+        hipLaunchKernelGGL(setup_bin_kernel, dim3(pb), dim3(64), 0, st, SA, g, w.counts, w.lists, w.cap, w.queue, visible);
     FineArgs A;
     A.points = pts_screen; A.ellipse = ellipse; A.cutoff = cutoff; A.radii = radii;
+    A.rec = packed ? w.rec : nullptr;
     A.first_idx = first_idx; A.num_pts = num_pts;
     A.counts = w.counts; A.lists = w.lists; A.cap = w.cap; A.queue = w.queue;
     A.queue_wgs = queue_workgroups(N, g);

@@ -218,7 +218,7 @@ extern "C" int dss_point_setup(const float *world, const float *normals, const f
     A.znear = znear; A.zfar = zfar; A.first_idx = first_idx; A.num_pts = num_pts; A.N = N; A.P = P;
     A.shared = shared_cloud; A.backface = backface_culling; A.S = S; A.cutoffC = cutoff_threshold;
     A.sigma = antialiasing_sigma; A.screen = pts_screen; A.ellipse = ellipse; A.radii = radii; A.scaler = scaler;
-    A.cutoff = cutoff; A.valid = valid;
+    A.cutoff = cutoff; A.valid = valid; A.rec = nullptr; A.feat = nullptr;
     hipLaunchKernelGGL(point_setup_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, as_stream(stream), A);
     return check_launch("dss_point_setup");
 }

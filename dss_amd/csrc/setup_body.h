@@ -23,6 +23,10 @@ struct SetupArgs {
     float cutoffC, sigma;
     float *screen, *ellipse, *radii, *scaler, *cutoff;
     uint8_t *valid;
+    // optional packed splat records for the fine pass of the fused forward (nullptr: not written): 64 bytes per point,
+    // {px,py,rx,ry} {a,b,c,cutoff} {scaler,f0,f1,f2} {pz,-,-,-}; feat = the (P,3) features copied into them
+    float4 *rec;
+    const float *feat;
 };
 
 // Setup of packed point p of cloud n (n < 0: unowned point -> culled).  Writes every output array and
@@ -122,6 +126,14 @@ __device__ __forceinline__ void setup_point(const SetupArgs &A, int64_t p, int n
     A.scaler[p] = sc;
     A.cutoff[p] = A.cutoffC;
     A.valid[p] = ok;
+    if (A.rec) {
+        float4 *R = A.rec + 4 * (size_t)p;
+        const float *f = A.feat + 3 * (size_t)p;
+        R[0] = make_float4(sx, sy, rx, ry);
+        R[1] = make_float4(ea, eb, ec, A.cutoffC);
+        R[2] = make_float4(sc, f[0], f[1], f[2]);
+        R[3] = make_float4(sz, 0.0f, 0.0f, 0.0f);
+    }
     o_px = sx; o_py = sy; o_pz = sz; o_rx = rx; o_ry = ry;
 }
 

@@ -388,13 +388,17 @@ def render_forward(world, normals, h, M, V, znear, zfar, cloud_to_packed_first_i
                    image_size: int, points_per_pixel: int, cutoff_threshold: float, depth_merging_thres: float,
                    antialiasing_sigma: float = 1.0, backface_culling: bool = False, shared_cloud: bool = False,
                    rows: Optional[Tuple[int, int]] = None, out_image: Optional[torch.Tensor] = None,
-                   out_visible: Optional[torch.Tensor] = None, vr6=None, frame_normals=None, want_zbuf: bool = True):
+                   out_visible: Optional[torch.Tensor] = None, vr6=None, frame_normals=None, want_zbuf: bool = True,
+                   workspace_state: int = 1):
     """Fused forward (setup + binning + fine + blend, ``dss_render_forward``).  ``out_image`` (float32
     (N,rows,S,C+1), 16-byte aligned) / ``out_visible`` (uint8 (P,)) let the caller place these two outputs
     in its own buffer (the multi-GPU step points them into one all-gather send buffer).  ``features`` are the
     packed (P,C) features.  Returns a dict with everything the separate calls produce:
     ``pts_screen, ellipse_params, radii, scaler, cutoff_threshold, valid, idx, zbuf, qvalue, occupancy,
-    visible, image, wsum``.  ``want_zbuf=False`` skips the depth plane (``zbuf`` is None): the fused backward never reads it."""
+    visible, image, wsum``.  ``want_zbuf=False`` skips the depth plane (``zbuf`` is None): the fused backward never reads it.
+    ``workspace_state``: 1 = DSS_WS_CLEAN (default: cached zero-initialised workspace, no memset launch), 0 = DSS_WS_UNKNOWN
+    (memset + both launches, lists stay in place), 2 = DSS_WS_BINNED (after a state-0 call with the same inputs: repeat only
+    the fine + blend launch; profiling / timing of the dominant kernel)."""
     lib = _lib.load()
     world = _lib.require_gpu(world, "world", _f32)
     dev = world.device
@@ -444,7 +448,7 @@ def render_forward(world, normals, h, M, V, znear, zfar, cloud_to_packed_first_i
                                "(any camera / row strides that are multiples of 4 floats); out_visible uint8 (P,)")
         _keep, vr_p, fn_p = _aniso_args(vr6, frame_normals, Pw)
         # dedicated zero-initialised buffer per problem size: the library keeps it clean (no memset launch)
-        tag = ("render_forward", N, P, S)
+        tag = ("render_forward" if workspace_state == 1 else "render_forward_binned", N, P, S)
         ws = _lib.clean_workspace(dev, tag, lib.dss_render_forward_workspace(N, P, S, K))
         rc = lib.dss_render_forward(
             _lib.ptr(world), _lib.ptr(normals), _lib.ptr(h) if per_point else None, None if per_point else _lib.ptr(h),
@@ -454,7 +458,7 @@ def render_forward(world, normals, h, M, V, znear, zfar, cloud_to_packed_first_i
             _lib.ptr(o["ellipse_params"]), _lib.ptr(o["radii"]), _lib.ptr(o["scaler"]), _lib.ptr(o["cutoff_threshold"]),
             _lib.ptr(valid), _lib.ptr(o["idx"]), _lib.ptr(o["zbuf"]), _lib.ptr(o["qvalue"]), _lib.ptr(o["occupancy"]),
             _lib.ptr(vis), _lib.ptr(img), int(img.stride(0)), int(img.stride(1)), _lib.ptr(o["wsum"]), _lib.ptr(ws),
-            ws.numel(), 1, _lib.stream_ptr(dev))
+            ws.numel(), int(workspace_state), _lib.stream_ptr(dev))
         if rc:
             _lib.drop_clean_workspace(dev, tag)
     _lib.check(rc, "dss_render_forward")

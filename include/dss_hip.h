@@ -224,14 +224,18 @@ DSS_API int dss_blend_backward_scatter(const float *grad_out, const int32_t *idx
  * passes a (row, camera, col, channel) send buffer so that the all-gathered bands are the full image.
  *
  * workspace_state: DSS_WS_UNKNOWN (0) -- contents arbitrary: the call zeroes the tile counters itself (one
- * memset launch).  DSS_WS_CLEAN (1) -- the caller guarantees that the first dss_render_forward_workspace()
+ * memset launch).  DSS_WS_CLEAN (1) -- the caller guarantees that the first dss_splat_forward_clean_bytes()
  * bytes are either zero-filled (once, after allocation) or were left by a previous SUCCESSFUL
  * DSS_WS_CLEAN call with the same (N, P, S) on this buffer, and that nothing else wrote to them since:
  * the memset launch is skipped and the fine pass restores the all-zero state on its way out (every counter,
  * flag and queue slot has exactly one owning workgroup that resets it after its last read).
+ * DSS_WS_BINNED (2) -- the workspace was last used by a DSS_WS_UNKNOWN call with exactly these inputs (which leaves the
+ * tile lists, the queue and the packed records in place): only the second launch ([fine + blend]) is repeated, e.g. to
+ * time or profile the dominant kernel in isolation.  The per-point outputs are not rewritten.
  * ------------------------------------------------------------------------------------------- */
 #define DSS_WS_UNKNOWN 0
 #define DSS_WS_CLEAN 1
+#define DSS_WS_BINNED 2
 DSS_API size_t dss_render_forward_workspace(int N, int64_t P, int S, int K);
 DSS_API int dss_render_forward(const float *world, const float *normals, const float *h_point,
                                const float *h_cloud, const float *vr6, const float *frame_normals,
