@@ -50,6 +50,29 @@ struct TileQueue {
     uint32_t capq;    // slots per queue
 };
 
+// Spill path of the fixed-capacity sub-lists.  A splat that finds a sub-list full (returned position >= cap) keeps the
+// count going and records WHICH of its (up to 2 x 2) tiles were full in one mask byte of its own.  After the binning
+// launch a second (always launched, normally empty: it exits on one scalar load) launch revisits the marked splats,
+// recomputes their tile rectangle and moves the dropped entries into a shared pool, contiguous per sub-list: the first
+// thread to arrive at a sub-list reserves count - cap pool entries (the count is final by then) and publishes the offset,
+// the others pick it up.  The fine pass reads slots < cap of a sub-list from its primary list and the rest from the
+// pool.  Round 1 rasterized a tile with an overflowed sub-list from its WHOLE cloud (exact but O(64 P) per tile: a far
+// camera put every occupied tile over capacity) and sized the capacity at 32x the mean load to make that rare (1 GB of
+// lists at 4M points); with the spill path the capacity is 4x the mean load.  (A log of (sub-list, id) pairs instead of
+// the mask was tried first: 8 more bytes per point, and its append counter(s) serialised -- 0.9 ms for 83k entries.)
+// Splats larger than 2 x 2 tiles that find a full sub-list only raise a flag: the spilled tiles are then rasterized from
+// their whole cloud as in round 1 (exact; rare: such a splat has a radius above 8 pixels).
+struct Spill {
+    uint32_t *cursor;   // (N*tiles*SUB) arrival counters of the pool pass                  (zero when binning starts)
+    uint32_t *offset;   // (N*tiles*SUB) 1 + first pool entry of an overflowed sub-list      (zero when binning starts)
+    uint8_t *mask;      // (P) bit 0..3: tile (tx0,ty0), (tx1,ty0), (tx0,ty1), (tx1,ty1) was full (zero when binning starts)
+    uint32_t *ctrl;     // [0] some mask is set, [1] pool entries handed out                 (zero when binning starts)
+    uint32_t *fail;     // a large splat overflowed / a waiter gave up: spilled tiles fall back to whole-cloud scans
+                        // (outside the zero region: reset by the binning launch itself)
+    int32_t *pool;
+    uint32_t cap_entries;  // pool capacity in entries
+};
+
 struct TileGrid {
     int S;        // image side
     int row0;     // first image row of the band
@@ -136,7 +159,8 @@ __device__ __forceinline__ void claim_tile(const TileQueue tq, int n, int tx, in
 // append splat p to the sub-list (p mod SUB) of every tile of its rectangle
 __device__ __forceinline__ void bin_point(int64_t p, int n, float px, float py, float pz, float rx, float ry,
                                           const TileGrid g, uint32_t *__restrict__ counts,
-                                          int32_t *__restrict__ lists, uint32_t cap, const TileQueue tq)
+                                          int32_t *__restrict__ lists, uint32_t cap, const TileQueue tq,
+                                          const Spill sp)
 {
     if (n < 0) return;
     int tx0, tx1, ty0, ty1;
@@ -157,6 +181,14 @@ __device__ __forceinline__ void bin_point(int64_t p, int n, float px, float py, 
         if (hx && p1 < cap) lists[t01 * cap + p1] = (int32_t)p;
         if (hy && p2 < cap) lists[t10 * cap + p2] = (int32_t)p;
         if (hx && hy && p3 < cap) lists[t11 * cap + p3] = (int32_t)p;
+        if (sp.ctrl) {
+            const unsigned full = (p0 >= cap ? 1u : 0u) | ((hx && p1 >= cap) ? 2u : 0u) | ((hy && p2 >= cap) ? 4u : 0u) |
+                                  ((hx && hy && p3 >= cap) ? 8u : 0u);
+            if (full) {
+                sp.mask[p] = (uint8_t)full;
+                sp.ctrl[0] = 1u;
+            }
+        }
         if (tq.flag) {
             if (p0 == 0) claim_tile(tq, n, tx0, ty0, g);
             if (p1 == 0) claim_tile(tq, n, tx1, ty0, g);
@@ -170,6 +202,7 @@ __device__ __forceinline__ void bin_point(int64_t p, int n, float px, float py, 
             const size_t t = sub0 + (size_t)(ty * g.tiles_x + tx) * DSS_SUB;
             const uint32_t pos = atomicAdd(&counts[t], 1u);
             if (pos < cap) lists[t * cap + pos] = (int32_t)p;
+            else if (sp.ctrl) *sp.fail = 1u;  // (a splat larger than 2 x 2 tiles: no mask for it)
             if (tq.flag && pos == 0) claim_tile(tq, n, tx, ty, g);
         }
 }
@@ -178,29 +211,76 @@ __global__ __launch_bounds__(256) void bin_kernel(
     const float *__restrict__ points, const float *__restrict__ radii,
     const int64_t *__restrict__ first_idx, const int64_t *__restrict__ num_pts, int N, int64_t P,
     TileGrid g, uint32_t *__restrict__ counts, int32_t *__restrict__ lists, uint32_t cap, TileQueue tq,
-    uint8_t *__restrict__ visible_to_clear /* (P) or nullptr */)
+    Spill sp, uint8_t *__restrict__ visible_to_clear /* (P) or nullptr */)
 {
+    if (sp.ctrl && blockIdx.x == 0 && threadIdx.x == 0) *sp.fail = 0u;
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= P) return;
     if (visible_to_clear) visible_to_clear[p] = 0;  // saves a separate memset launch
     const int n = find_cloud(p, first_idx, num_pts, N);
     bin_point(p, n, points[3 * p], points[3 * p + 1], points[3 * p + 2], radii[2 * p], radii[2 * p + 1], g, counts,
-              lists, cap, tq);
+              lists, cap, tq, sp);
 }
 
 // dss_render_forward: per-point setup (culling + projection + EWA terms) fused with the binning --
 // the screen record goes from registers straight into the tile lists.
 __global__ __launch_bounds__(256) void setup_bin_kernel(const SetupArgs A, TileGrid g, uint32_t *__restrict__ counts,
                                                         int32_t *__restrict__ lists, uint32_t cap, TileQueue tq,
-                                                        uint8_t *__restrict__ visible_to_clear)
+                                                        Spill sp, uint8_t *__restrict__ visible_to_clear)
 {
+    if (sp.ctrl && blockIdx.x == 0 && threadIdx.x == 0) *sp.fail = 0u;
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= A.P) return;
     if (visible_to_clear) visible_to_clear[p] = 0;
     const int n = find_cloud(p, A.first_idx, A.num_pts, A.N);
     float px, py, pz, rx, ry;
     setup_point(A, p, n, px, py, pz, rx, ry);
-    bin_point(p, n, px, py, pz, rx, ry, g, counts, lists, cap, tq);
+    bin_point(p, n, px, py, pz, rx, ry, g, counts, lists, cap, tq, sp);
+}
+
+// Pool pass (see struct Spill): one thread per splat.  Always launched behind the binning launch; unless some splat was
+// marked every workgroup exits on one scalar load.
+__global__ __launch_bounds__(256) void spill_kernel(
+    const float *__restrict__ points, const float *__restrict__ radii, const int64_t *__restrict__ first_idx,
+    const int64_t *__restrict__ num_pts, int N, int64_t P, TileGrid g, const uint32_t *__restrict__ counts, uint32_t cap,
+    Spill sp)
+{
+    if (__builtin_amdgcn_readfirstlane((int)sp.ctrl[0]) == 0) return;
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const unsigned full = sp.mask[p];
+    if (full == 0) return;
+    sp.mask[p] = 0;  // (this thread is the byte's only reader: the DSS_WS_CLEAN state is restored here)
+    const int n = find_cloud(p, first_idx, num_pts, N);
+    int tx0, tx1, ty0, ty1;
+    if (n < 0 || !splat_tile_rect(points[3 * p], points[3 * p + 1], points[3 * p + 2], radii[2 * p], radii[2 * p + 1], g, tx0,
+                                  tx1, ty0, ty1))
+        return;
+    const size_t sub0 = ((size_t)n * g.tiles_x * g.tiles_y) * DSS_SUB + ((unsigned)p & (DSS_SUB - 1));
+#pragma unroll 1
+    for (int k = 0; k < 4; ++k) {
+        if (!(full & (1u << k))) continue;
+        const int tx = (k & 1) ? tx1 : tx0, ty = (k & 2) ? ty1 : ty0;
+        const size_t t = sub0 + (size_t)(ty * g.tiles_x + tx) * DSS_SUB;
+        const uint32_t extra = counts[t] - cap;   // entries of this sub-list that live in the pool (final)
+        const uint32_t pos = atomicAdd(&sp.cursor[t], 1u);
+        uint32_t off1 = 0;
+        // the publisher's branch comes first in program order: a waiter of the same wavefront never spins ahead of it
+        if (pos == 0) {
+            off1 = atomicAdd(&sp.ctrl[1], extra) + 1u;
+            __hip_atomic_store(&sp.offset[t], off1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (pos != 0) {
+            // the thread that drew position 0 has executed its atomic before ours and publishes without waiting for
+            // anyone; the offset is its own tag (non-zero once written)
+            for (int spin = 0; spin < (1 << 22) && off1 == 0; ++spin) {
+                off1 = __hip_atomic_load(&sp.offset[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (off1 == 0) __builtin_amdgcn_s_sleep(2);
+            }
+            if (off1 == 0) *sp.fail = 1u;  // gave up: the fine pass falls back to whole-cloud scans
+        }
+        if (off1 != 0 && (unsigned long long)(off1 - 1u) + pos < sp.cap_entries) sp.pool[(size_t)(off1 - 1u) + pos] = (int32_t)p;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -214,6 +294,7 @@ struct FineArgs {
     const uint32_t *counts;    // (N*tiles*DSS_SUB) sub-list fill counts, or nullptr (naive mode)
     const int32_t *lists;      // (N*tiles*DSS_SUB*cap)
     uint32_t cap;              // sub-list capacity
+    Spill spill;               // overflowed sub-lists re-binned into a pool (pool == nullptr: whole-cloud fallback)
     TileQueue queue;           // occupied tiles (list == nullptr: one workgroup per tile, identity order)
     uint32_t queue_wgs;        // workgroups serving queue slots (DSS_QUEUES x slots per queue); fill workgroups follow
     uint32_t *clean_counts;    // DSS_WS_CLEAN: == counts, every owner resets what it has read; else nullptr
@@ -415,7 +496,7 @@ __device__ __forceinline__ void fine_tile(const FineArgs &A, const int tile_id, 
     bool use_list = false;
     uint32_t c_mine = 0, cmax = 0;
     uint32_t cs[DSS_SUB];  // the tile's sub-list counts (wave-uniform)
-    const int32_t *lbase = nullptr;
+    const int32_t *lbase = nullptr, *pbase = nullptr;  // this thread's sub-list: primary slots [0, cap), pool beyond
     int32_t id_next = 0;
     if (A.counts != nullptr) {
         lbase = A.lists + ((size_t)tile_id * DSS_SUB + my_sub) * A.cap;
@@ -430,11 +511,30 @@ __device__ __forceinline__ void fine_tile(const FineArgs &A, const int tile_id, 
             cs[4 * q + 3] = (uint32_t)__builtin_amdgcn_readfirstlane((int)u.w);
         }
         use_list = true;
+        bool spilled = false;
 #pragma unroll
         for (int q = 0; q < DSS_SUB; ++q) {
-            use_list = use_list && (cs[q] <= A.cap);
+            spilled = spilled || (cs[q] > A.cap);
             cmax = max(cmax, cs[q]);
             c_mine = (my_sub == (uint32_t)q) ? cs[q] : c_mine;  // static indices only: a dynamic cs[sub] goes to scratch
+        }
+        if (spilled) {
+            // rare: some of the tile's sub-lists continue in the spill pool.  Usable if logging and the pool pass completed
+            // and every overflowed sub-list got its whole range inside the pool; otherwise scan the whole cloud (exact, slow)
+            use_list = A.spill.pool != nullptr && __builtin_amdgcn_readfirstlane((int)*A.spill.fail) == 0;
+            if (use_list) {
+#pragma unroll
+                for (int q = 0; q < DSS_SUB; ++q) {
+                    if (cs[q] > A.cap) {
+                        const uint32_t o1 = (uint32_t)__builtin_amdgcn_readfirstlane(
+                            (int)A.spill.offset[(size_t)tile_id * DSS_SUB + q]);
+                        use_list = use_list && o1 != 0u &&
+                                   (unsigned long long)(o1 - 1u) + (cs[q] - A.cap) <= A.spill.cap_entries;
+                    }
+                }
+            }
+            if (use_list && c_mine > A.cap)
+                pbase = A.spill.pool + (A.spill.offset[(size_t)tile_id * DSS_SUB + my_sub] - 1u);
         }
     } else {
 #pragma unroll
@@ -483,7 +583,8 @@ __device__ __forceinline__ void fine_tile(const FineArgs &A, const int tile_id, 
             have = (uint32_t)base + my_slot < c_mine;
             p = id_next;
             // the next chunk's entry is requested now and arrives while this chunk is processed
-            if ((uint32_t)base + SPEC + my_slot < c_mine) id_next = lbase[(uint32_t)base + SPEC + my_slot];
+            const uint32_t nxt = (uint32_t)base + SPEC + my_slot;
+            if (nxt < c_mine) id_next = nxt < A.cap ? lbase[nxt] : pbase[nxt - A.cap];
             // sub-list q contributes clamp(count - base, 0, 32) entries to this chunk; they are packed in sub-list order
             uint32_t before = 0, total = 0;
 #pragma unroll
@@ -503,7 +604,13 @@ __device__ __forceinline__ void fine_tile(const FineArgs &A, const int tile_id, 
         __syncthreads();  // previous chunk fully consumed; first pass: every thread has read the tile's counters
         if (base == 0) {
             // DSS_WS_CLEAN: this workgroup is the only reader of the tile's counters and of its queue slot
-            if (A.clean_counts && tid < DSS_SUB) A.clean_counts[(size_t)tile_id * DSS_SUB + tid] = 0;
+            if (A.clean_counts && tid < DSS_SUB) {
+                A.clean_counts[(size_t)tile_id * DSS_SUB + tid] = 0;
+                if (A.spill.pool && cmax > A.cap) {  // (uniform) the tile used the spill structures: reset them as well
+                    A.spill.cursor[(size_t)tile_id * DSS_SUB + tid] = 0;
+                    A.spill.offset[(size_t)tile_id * DSS_SUB + tid] = 0;
+                }
+            }
             if (slot_to_clear && tid == DSS_SUB) *slot_to_clear = 0;
         }
         if (have) {
@@ -782,7 +889,10 @@ __global__ __launch_bounds__(FINE_THREADS) void fine_kernel(const FineArgs A)
     }
     const uint32_t qb = blockIdx.x - fill_wgs;  // queue workgroup index (identity mode: tile id)
     if (!qmode && (int)qb >= total) return;
-    if (qmode && clean && qb == 0 && threadIdx.x < DSS_QUEUES) A.queue.tail[threadIdx.x] = 0;  // binning-only state
+    if (qmode && clean && qb == 0 && threadIdx.x < DSS_QUEUES + 2) {
+        // state that only binning and the pool pass use: queue tails, "some mask set", pool top (contiguous words)
+        A.queue.tail[threadIdx.x] = 0;
+    }
     // one workgroup per queue slot (qb -> queue qb%32, slot qb/32): a loop over several slots per workgroup was tried and
     // costs 60 VGPRs (values hoisted out of the tile loop), and most slots of a large render hold a tile anyway
     int tile_id = (int)qb;
@@ -929,20 +1039,30 @@ struct FwdWorkspace {
     int32_t *lists;    // N*tiles*SUB*cap
     uint32_t cap;
     TileQueue queue;
+    Spill spill;
     float4 *rec;         // packed splat records (P x 64 bytes) behind the lists; only carved for the fused forward
     size_t count_bytes;  // bytes to zero before binning (the DSS_WS_CLEAN region): everything in front of the lists
     size_t bytes;
 };
 
-// Sub-list capacity: ~32x the mean number of (splat, tile) pairs per sub-list (2 tiles per splat assumed),
-// a power of two in [32, 16384].  Depends only on (N, P, S) so the size query and the launch agree.
+// Sub-list capacity: ~4x the mean number of (splat, tile) pairs per sub-list (2 tiles per splat assumed), a power of two
+// in [64, 16384] (>= SPEC for the speculative first reads; 64 leaves the benchmark scenes -- densest sub-list 42 entries
+// at a mean of 2 -- on the primary lists).  Denser sub-lists go through the spill pool.  Depends only on (N, P, S) so the
+// size query and the launch agree.
 static uint32_t bin_capacity(int N, int64_t P, int S)
 {
     const double tiles = (double)((S + DSS_TILE - 1) / DSS_TILE) * ((S + DSS_TILE - 1) / DSS_TILE);
     const double mean_sub = 2.0 * ((double)P / (N > 0 ? N : 1)) / (tiles * DSS_SUB);
-    uint32_t cap = 32;
-    while (cap < 16384 && (double)cap < 32.0 * mean_sub) cap <<= 1;
+    uint32_t cap = 64;
+    while (cap < 16384 && (double)cap < 4.0 * mean_sub) cap <<= 1;
     return cap;
+}
+// spill pool entries: two per point (at least 64k): a scene with more over-capacity (splat, tile) pairs than that falls
+// back to whole-cloud scans for the tiles that did not fit (seen with 100k points on 25 tiles, 0.5 % of the screen)
+static uint32_t spill_capacity(int64_t P)
+{
+    const int64_t c = 2 * P > 65536 ? 2 * P : 65536;
+    return (uint32_t)(c < 0x7fffff00ll ? c : 0x7fffff00ll);
 }
 
 static TileGrid make_grid(int S, int row0, int row1)
@@ -967,14 +1087,24 @@ static FwdWorkspace carve_fwd(void *ws, int N, int64_t P, int S, bool with_recor
     const size_t cbytes = align_up(tiles_max * DSS_SUB * 4, 256), fbytes = align_up(tiles_max * 4, 256);
     w.queue.capq = queue_capacity(N, full);
     const size_t qbytes = align_up((size_t)DSS_QUEUES * w.queue.capq * 4, 256);
-    w.count_bytes = cbytes + fbytes + 256 + qbytes;
+    const size_t mbytes = align_up((size_t)P, 256);
+    w.count_bytes = 3 * cbytes + fbytes + 256 + qbytes + mbytes;
     w.counts = reinterpret_cast<uint32_t *>(p);
-    w.queue.flag = reinterpret_cast<uint32_t *>(p + cbytes);
-    w.queue.tail = reinterpret_cast<uint32_t *>(p + cbytes + fbytes);
-    w.queue.list = reinterpret_cast<int32_t *>(p + cbytes + fbytes + 256);
+    w.spill.cursor = reinterpret_cast<uint32_t *>(p + cbytes);
+    w.spill.offset = reinterpret_cast<uint32_t *>(p + 2 * cbytes);
+    w.queue.flag = reinterpret_cast<uint32_t *>(p + 3 * cbytes);
+    w.queue.tail = reinterpret_cast<uint32_t *>(p + 3 * cbytes + fbytes);   // 256-byte block: 32 queue tails ...
+    w.spill.ctrl = w.queue.tail + DSS_QUEUES;                               // ... + the two spill control words
+    w.queue.list = reinterpret_cast<int32_t *>(p + 3 * cbytes + fbytes + 256);
+    w.spill.mask = reinterpret_cast<uint8_t *>(p + 3 * cbytes + fbytes + 256 + qbytes);
     const size_t lists_off = w.count_bytes;
     w.lists = reinterpret_cast<int32_t *>(p + lists_off);
     w.bytes = lists_off + align_up(tiles_max * DSS_SUB * (size_t)w.cap * 4, 256);
+    w.spill.cap_entries = spill_capacity(P);
+    w.spill.pool = reinterpret_cast<int32_t *>(p + w.bytes);
+    w.bytes += align_up((size_t)w.spill.cap_entries * 4, 256);
+    w.spill.fail = reinterpret_cast<uint32_t *>(p + w.bytes);
+    w.bytes += 256;
     w.rec = nullptr;
     if (with_records) {
         w.rec = reinterpret_cast<float4 *>(p + w.bytes);
@@ -1051,7 +1181,9 @@ static int splat_bin_impl(const float *points, const float *radii, const int64_t
     if (hipMemsetAsync(w.counts, 0, w.count_bytes, st) != hipSuccess) return check_launch("memset tile counts");
     const int pb = (int)((P + 255) / 256);
     hipLaunchKernelGGL(bin_kernel, dim3(pb), dim3(256), 0, st, points, radii, first_idx, num_pts, N, P, g, w.counts,
-                       w.lists, w.cap, w.queue, visible_to_clear);
+                       w.lists, w.cap, w.queue, w.spill, visible_to_clear);
+    hipLaunchKernelGGL(spill_kernel, dim3(pb), dim3(256), 0, st, points, radii, first_idx, num_pts, N, P, g, w.counts, w.cap,
+                       w.spill);
     return check_launch("dss_splat_bin");
 }
 
@@ -1084,6 +1216,8 @@ static int splat_fine_impl(const float *points, const float *ellipse, const floa
     A.first_idx = first_idx; A.num_pts = num_pts;
     A.counts = nullptr; A.lists = nullptr; A.cap = 0;
     A.queue.tail = nullptr; A.queue.list = nullptr; A.queue.flag = nullptr; A.queue.capq = 0; A.queue_wgs = 0;
+    A.spill.cursor = nullptr; A.spill.offset = nullptr; A.spill.mask = nullptr; A.spill.ctrl = nullptr; A.spill.fail = nullptr;
+    A.spill.pool = nullptr; A.spill.cap_entries = 0;
     A.clean_counts = nullptr;
     A.idx = idx; A.zbuf = zbuf; A.qv = qvalue; A.occ = occ; A.visible = visible;
     A.g = g; A.N = N; A.K = K; A.thr = merge_thr;
@@ -1095,7 +1229,7 @@ static int splat_fine_impl(const float *points, const float *ellipse, const floa
             return DSS_ERR_WORKSPACE;
         }
         FwdWorkspace w = carve_fwd(const_cast<void *>(workspace), N, P, S);
-        A.counts = w.counts; A.lists = w.lists; A.cap = w.cap; A.queue = w.queue;
+        A.counts = w.counts; A.lists = w.lists; A.cap = w.cap; A.queue = w.queue; A.spill = w.spill;
         A.queue_wgs = queue_workgroups(N, g);
     }
     if (!dispatch_fine(A, (int)blocks_ll, as_stream(stream))) {
@@ -1223,13 +1357,17 @@ extern "C" int dss_render_forward(const float *world, const float *normals, cons
     // one wave per workgroup: at DSS sizes (tens of thousands of points) 256-thread groups would occupy only
     // half of the CUs with one wave per SIMD, and this kernel is a chain of dependent latencies
     const int pb = (int)((P + 63) / 64);
-    if (!rerun)
-        hipLaunchKernelGGL(setup_bin_kernel, dim3(pb), dim3(64), 0, st, SA, g, w.counts, w.lists, w.cap, w.queue, visible);
+    if (!rerun) {
+        hipLaunchKernelGGL(setup_bin_kernel, dim3(pb), dim3(64), 0, st, SA, g, w.counts, w.lists, w.cap, w.queue, w.spill,
+                           visible);
+        hipLaunchKernelGGL(spill_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, pts_screen, radii, first_idx,
+                           num_pts, N, P, g, w.counts, w.cap, w.spill);
+    }
     FineArgs A;
     A.points = pts_screen; A.ellipse = ellipse; A.cutoff = cutoff; A.radii = radii;
     A.rec = packed ? w.rec : nullptr;
     A.first_idx = first_idx; A.num_pts = num_pts;
-    A.counts = w.counts; A.lists = w.lists; A.cap = w.cap; A.queue = w.queue;
+    A.counts = w.counts; A.lists = w.lists; A.cap = w.cap; A.queue = w.queue; A.spill = w.spill;
     A.queue_wgs = queue_workgroups(N, g);
     A.clean_counts = clean ? w.counts : nullptr;
     A.idx = idx; A.zbuf = zbuf; A.qv = qvalue; A.occ = occ; A.visible = visible;
