@@ -19,6 +19,8 @@
 // (rasterize_points.cu:64-124) and compiled with -ffp-contract=off, so fragments are bit-identical
 // to the reference CPU/CUDA naive path; the K-set is defined by the total order (z, idx).
 #include "setup_body.h"
+#include <stdlib.h>
+#include <atomic>
 
 namespace dss {
 
@@ -67,10 +69,15 @@ struct Spill {
     uint32_t *offset;   // (N*tiles*SUB) 1 + first pool entry of an overflowed sub-list      (zero when binning starts)
     uint8_t *mask;      // (P) bit 0..3: tile (tx0,ty0), (tx1,ty0), (tx0,ty1), (tx1,ty1) was full (zero when binning starts)
     uint32_t *ctrl;     // [0] some mask is set, [1] pool entries handed out                 (zero when binning starts)
-    uint32_t *fail;     // a large splat overflowed / a waiter gave up: spilled tiles fall back to whole-cloud scans
-                        // (outside the zero region: reset by the binning launch itself)
+    uint32_t *fail;     // fail[0] == fail[1]: a large splat overflowed / a waiter gave up -> spilled tiles fall back to
+                        // whole-cloud scans.  fail[1] = the epoch of the binning launch (written by its first thread),
+                        // fail[0] = that epoch, written by whoever fails.  Never reset: every racing writer of a word
+                        // stores the same value (two different values from two XCDs would leave the outcome to the
+                        // write-back order of their L2s), and a stale or uninitialised fail[0] can only equal the new
+                        // epoch by a 2^-32 accident, which costs speed, not exactness.  Outside the zero region.
     int32_t *pool;
     uint32_t cap_entries;  // pool capacity in entries
+    uint32_t epoch;        // unique per binning launch of this process (host counter)
 };
 
 struct TileGrid {
@@ -202,7 +209,7 @@ __device__ __forceinline__ void bin_point(int64_t p, int n, float px, float py, 
             const size_t t = sub0 + (size_t)(ty * g.tiles_x + tx) * DSS_SUB;
             const uint32_t pos = atomicAdd(&counts[t], 1u);
             if (pos < cap) lists[t * cap + pos] = (int32_t)p;
-            else if (sp.ctrl) *sp.fail = 1u;  // (a splat larger than 2 x 2 tiles: no mask for it)
+            else if (sp.ctrl) sp.fail[0] = sp.epoch;  // (a splat larger than 2 x 2 tiles: no mask for it)
             if (tq.flag && pos == 0) claim_tile(tq, n, tx, ty, g);
         }
 }
@@ -213,7 +220,7 @@ __global__ __launch_bounds__(256) void bin_kernel(
     TileGrid g, uint32_t *__restrict__ counts, int32_t *__restrict__ lists, uint32_t cap, TileQueue tq,
     Spill sp, uint8_t *__restrict__ visible_to_clear /* (P) or nullptr */)
 {
-    if (sp.ctrl && blockIdx.x == 0 && threadIdx.x == 0) *sp.fail = 0u;
+    if (sp.ctrl && blockIdx.x == 0 && threadIdx.x == 0) sp.fail[1] = sp.epoch;
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= P) return;
     if (visible_to_clear) visible_to_clear[p] = 0;  // saves a separate memset launch
@@ -228,7 +235,7 @@ __global__ __launch_bounds__(256) void setup_bin_kernel(const SetupArgs A, TileG
                                                         int32_t *__restrict__ lists, uint32_t cap, TileQueue tq,
                                                         Spill sp, uint8_t *__restrict__ visible_to_clear)
 {
-    if (sp.ctrl && blockIdx.x == 0 && threadIdx.x == 0) *sp.fail = 0u;
+    if (sp.ctrl && blockIdx.x == 0 && threadIdx.x == 0) sp.fail[1] = sp.epoch;
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= A.P) return;
     if (visible_to_clear) visible_to_clear[p] = 0;
@@ -277,7 +284,7 @@ __global__ __launch_bounds__(256) void spill_kernel(
                 off1 = __hip_atomic_load(&sp.offset[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (off1 == 0) __builtin_amdgcn_s_sleep(2);
             }
-            if (off1 == 0) *sp.fail = 1u;  // gave up: the fine pass falls back to whole-cloud scans
+            if (off1 == 0) sp.fail[0] = sp.epoch;  // gave up: the fine pass falls back to whole-cloud scans
         }
         if (off1 != 0 && (unsigned long long)(off1 - 1u) + pos < sp.cap_entries) sp.pool[(size_t)(off1 - 1u) + pos] = (int32_t)p;
     }
@@ -521,7 +528,8 @@ __device__ __forceinline__ void fine_tile(const FineArgs &A, const int tile_id, 
         if (spilled) {
             // rare: some of the tile's sub-lists continue in the spill pool.  Usable if logging and the pool pass completed
             // and every overflowed sub-list got its whole range inside the pool; otherwise scan the whole cloud (exact, slow)
-            use_list = A.spill.pool != nullptr && __builtin_amdgcn_readfirstlane((int)*A.spill.fail) == 0;
+            use_list = A.spill.pool != nullptr && __builtin_amdgcn_readfirstlane((int)A.spill.fail[0]) !=
+                                                       __builtin_amdgcn_readfirstlane((int)A.spill.fail[1]);
             if (use_list) {
 #pragma unroll
                 for (int q = 0; q < DSS_SUB; ++q) {
@@ -1049,12 +1057,22 @@ struct FwdWorkspace {
 // in [64, 16384] (>= SPEC for the speculative first reads; 64 leaves the benchmark scenes -- densest sub-list 42 entries
 // at a mean of 2 -- on the primary lists).  Denser sub-lists go through the spill pool.  Depends only on (N, P, S) so the
 // size query and the launch agree.
+// DSS_LEAN_WORKSPACE=1 (environment, read at every call so the size query and the launch agree): half the sub-list
+// capacity (more splats take the spill pass) and no packed records (the fine pass gathers from the five per-point arrays).
+// Measured cost: +6 % and +6 % of the step at 8 x 1M points @1024^2 and 4M points @2048^2 (fine pass 0.98 -> 1.25 ms without
+// records) for 177+256 -> 110 MB at the latter.  Off by default: 288 GB of HBM make the fast layout the right default.
+static bool lean_workspace()
+{
+    const char *e = getenv("DSS_LEAN_WORKSPACE");
+    return e && e[0] == '1';
+}
 static uint32_t bin_capacity(int N, int64_t P, int S)
 {
     const double tiles = (double)((S + DSS_TILE - 1) / DSS_TILE) * ((S + DSS_TILE - 1) / DSS_TILE);
     const double mean_sub = 2.0 * ((double)P / (N > 0 ? N : 1)) / (tiles * DSS_SUB);
-    uint32_t cap = 64;
-    while (cap < 16384 && (double)cap < 4.0 * mean_sub) cap <<= 1;
+    const bool lean = lean_workspace();
+    uint32_t cap = lean ? 32 : 64;
+    while (cap < 16384 && (double)cap < (lean ? 2.0 : 4.0) * mean_sub) cap <<= 1;
     return cap;
 }
 // spill pool entries: two per point (at least 64k): a scene with more over-capacity (splat, tile) pairs than that falls
@@ -1104,9 +1122,11 @@ static FwdWorkspace carve_fwd(void *ws, int N, int64_t P, int S, bool with_recor
     w.spill.pool = reinterpret_cast<int32_t *>(p + w.bytes);
     w.bytes += align_up((size_t)w.spill.cap_entries * 4, 256);
     w.spill.fail = reinterpret_cast<uint32_t *>(p + w.bytes);
+    static std::atomic<uint32_t> epoch{1};
+    w.spill.epoch = ws ? epoch.fetch_add(1, std::memory_order_relaxed) : 0u;
     w.bytes += 256;
     w.rec = nullptr;
-    if (with_records) {
+    if (with_records && !lean_workspace()) {
         w.rec = reinterpret_cast<float4 *>(p + w.bytes);
         w.bytes += align_up((size_t)P * 64, 256);
     }
@@ -1342,7 +1362,7 @@ extern "C" int dss_render_forward(const float *world, const float *normals, cons
     const int tiles = g.tiles_x * g.tiles_y;
     if ((long long)N * tiles > 0x7fffffffll) { set_error("dss_render_forward: too many tiles"); return DSS_ERR_UNSUPPORTED; }
     FwdWorkspace w = carve_fwd(workspace, N, P, S, true);
-    const bool packed = C == 3;  // the records carry three feature channels
+    const bool packed = C == 3 && !lean_workspace();  // the records carry three feature channels
     const bool clean = workspace_state == DSS_WS_CLEAN;
     const bool rerun = workspace_state == DSS_WS_BINNED;  // lists + records of this very input are in place: fine pass only
     if (!clean && !rerun && hipMemsetAsync(w.counts, 0, w.count_bytes, st) != hipSuccess)

@@ -11,7 +11,7 @@ import torch
 
 import oracle
 import scenes
-from dss_amd import ops
+from dss_amd import _lib, ops
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -103,6 +103,33 @@ def test_forward_list_overflow_goes_through_the_spill_pool():
                                 sc["num_pts"], 128, 5, 10.0)
     for g, w in zip(got, want):
         assert np.array_equal(g.cpu().numpy(), w)
+
+
+def test_lean_workspace_mode_is_exact_and_smaller(monkeypatch):
+    """DSS_LEAN_WORKSPACE=1 halves the sub-list capacity and drops the packed records (raster_forward.hip
+    `lean_workspace`): smaller workspace, same fragments bit for bit, same image."""
+    pts, nrm = scenes.load_cloud("bunny")
+    pts = scenes.normalize_unit_sphere(pts)
+    pts, nrm = scenes.upsample_jitter(pts, nrm, 4, seed=0)
+    h = scenes.global_h(pts)
+    S, K, thr = 256, 5, 0.05
+    M, V, _ = scenes.camera_matrices(2.0, 20.0, 30.0)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    P = pts.shape[0]
+    a = (t(pts), t(nrm), torch.full((1,), h, device=DEV), t(M), t(V), torch.full((1,), 0.1, device=DEV),
+         torch.full((1,), 100.0, device=DEV), torch.zeros(1, dtype=torch.int64, device=DEV),
+         torch.full((1,), P, dtype=torch.int64, device=DEV), torch.rand((P, 3), device=DEV))
+    lib = _lib.load()
+    full_bytes = lib.dss_render_forward_workspace(1, 4_000_000, 2048, K)
+    ref = ops.render_forward(*a, S, K, 1.0, thr, 1.0, False, True, workspace_state=0)
+    monkeypatch.setenv("DSS_LEAN_WORKSPACE", "1")
+    lean_bytes = lib.dss_render_forward_workspace(1, 4_000_000, 2048, K)
+    got = ops.render_forward(*a, S, K, 1.0, thr, 1.0, False, True, workspace_state=0)
+    monkeypatch.delenv("DSS_LEAN_WORKSPACE")
+    assert lean_bytes < 0.3 * full_bytes and lean_bytes <= 128 << 20, (lean_bytes, full_bytes)  # configs[4]: 433 -> 110 MB
+    for k in ("idx", "zbuf", "qvalue", "occupancy", "visible"):
+        assert torch.equal(ref[k], got[k]), k
+    assert float((ref["image"] - got["image"]).abs().max()) <= 1e-6
 
 
 @pytest.mark.parametrize("fused", [False, True])
