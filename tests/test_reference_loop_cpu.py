@@ -1,0 +1,81 @@
+"""the reference's own `train_mvr.py`, `config.py`, `DSS.training.trainer`, `DSS.models.*`,
+`DSS.core.cloud` and `DSS.utils.dataset` -- imported UNMODIFIED from /root/reference -- run on top of the drop-in
+classes, with only the YAML class paths of INTEGRATION.md §2 changed, through the `compat/pytorch3d` namespace package.
+
+The build container has no GPU and the GPU box has no /root/reference, so the one place where both the reference loop and
+this repository exist is here, on the CPU: `tests/ref_loop/launcher.py` answers `dss_amd.ops` with the oracle (a test
+double at the C-ABI seam; the product itself still refuses to run without the HIP library) and the test checks that the
+reference's loop trains: iterations complete, the loss it logs decreases.  With a GPU *and* a reference checkout the same
+launcher runs the real kernels (`python tests/ref_loop/launcher.py --config ... --scalars ...` without `--no-cuda`)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import yaml
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+LAUNCHER = os.path.join(ROOT, "tests", "ref_loop", "launcher.py")
+
+pytestmark = pytest.mark.skipif(not os.path.isfile(os.path.join(REF, "train_mvr.py")),
+                                reason="needs the reference checkout (absent on the GPU box)")
+
+
+def _config(tmp, size):
+    cfg = {
+        "name": "dropin",
+        "data": {"type": "MVR", "data_dir": os.path.join(tmp, "data"), "resolution": [size, size]},
+        "model": {"type": "point", "model_kwargs": {"n_points_per_cloud": 1500, "learn_colors": False,
+                                                    "learn_points": True, "learn_normals": True}},
+        "renderer": {   # the only lines that differ from configs/dss.yml
+            "is_neural_texture": False,
+            "renderer_type": "dss_amd.renderer.SurfaceSplattingRenderer",
+            "raster_type": "dss_amd.rasterizer.SurfaceSplatting",
+            "compositor_type": "dss_amd.renderer.NormWeightedCompositor",
+            "raster_params": {"Vrk_invariant": True, "Vrk_isotropic": False, "clip_pts_grad": 0.05,
+                              "cutoff_threshold": 1.0, "depth_merging_threshold": 0.05, "image_size": size,
+                              "points_per_pixel": 5, "radii_backward_scaler": 5},
+        },
+        "training": {"out_dir": os.path.join(tmp, "exp"), "backup_every": 0, "batch_size": 4, "checkpoint_every": 0,
+                     "debug_every": 0, "visualize_every": 0, "validate_every": 0, "print_every": 1,
+                     "lambda_dr_proj": 0.01, "lambda_dr_repel": 0.0, "lambda_dr_rgb": 1.0, "lambda_dr_silhouette": 1.0,
+                     "n_workers": 0, "steps_dss_backward_radii": 200, "gamma_dss_backward_radii": 0.9,
+                     "limit_dss_backward_radii": 2},
+    }
+    path = os.path.join(tmp, "dropin.yml")
+    with open(path, "w") as f:
+        yaml.safe_dump(cfg, f)
+    return path
+
+
+def _run(args, timeout):
+    env = dict(os.environ, OMP_NUM_THREADS="8")
+    return subprocess.run([sys.executable, LAUNCHER] + args, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                          timeout=timeout, text=True)
+
+
+@pytest.mark.timeout(600)
+def test_reference_train_mvr_runs_unmodified_on_the_drop_in_and_its_loss_decreases(tmp_path):
+    tmp = str(tmp_path)
+    cfg = _config(tmp, 192)   # (at 64^2 the splats and the backward radius rs = 5 x median radius are a quarter of the object:
+    # the surrogate gradient then inflates the silhouette for hundreds of iterations; 192^2 is in the regime of the 512^2 configs)
+    scalars = os.path.join(tmp, "scalars.jsonl")
+    r = _run(["--config", cfg, "--scalars", scalars, "--no-cuda", "--make-dataset", os.path.join(tmp, "data"),
+              "--views", "16", "--target-points", "3000"], 300)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert len(os.listdir(os.path.join(tmp, "data", "image"))) == 16
+    r = _run(["--config", cfg, "--scalars", scalars, "--no-cuda", "--exit-after", "40"], 500)
+    # train_mvr.py:219-228 leaves through exit(3) when its time limit is reached -- after saving model.pt it joins
+    # `trainer._threads`, an attribute only `Trainer.debug` creates (trainer.py:461): without a debug visualisation
+    # (debug_every: 0 here, it needs plotly / trimesh) the unmodified script ends on that AttributeError instead
+    reached_time_limit = r.returncode == 3 or (r.returncode == 1 and "no attribute '_threads'" in r.stdout)
+    assert reached_time_limit, r.stdout[-4000:]
+    loss = [json.loads(l) for l in open(scalars)]
+    loss = [d["value"] for d in loss if d["tag"] == "train/loss"]
+    assert len(loss) >= 100, (len(loss), r.stdout[-2000:])
+    k = len(loss) // 10
+    first, last = sum(loss[:k]) / k, sum(loss[-k:]) / k
+    assert last < 0.9 * first, (first, last)   # observed: 0.46 -> 0.34 after ~450 iterations, 0.21 after 1200
+    assert os.path.isfile(os.path.join(tmp, "exp", "dropin", "model.pt"))  # the reference's CheckpointIO wrote it
