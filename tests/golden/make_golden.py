@@ -15,6 +15,8 @@
 import os
 import sys
 
+
+sys.dont_write_bytecode = True  # the reference checkout is read-only: importing it must not leave __pycache__ there
 import numpy as np
 import torch
 

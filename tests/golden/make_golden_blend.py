@@ -21,6 +21,8 @@ import ctypes
 import importlib
 import os
 import sys
+
+sys.dont_write_bytecode = True  # the reference checkout is read-only: importing it must not leave __pycache__ there
 import types
 
 import numpy as np

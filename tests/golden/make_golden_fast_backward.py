@@ -30,6 +30,8 @@ Known reference behaviour recorded with the vectors (and asserted by tests/test_
 import ctypes
 import os
 import sys
+
+sys.dont_write_bytecode = True  # the reference checkout is read-only: importing it must not leave __pycache__ there
 import types
 
 import numpy as np

@@ -13,6 +13,8 @@ in make_golden_setup.py, plus an inert `torch.utils.tensorboard`.
 import importlib
 import os
 import sys
+
+sys.dont_write_bytecode = True  # the reference checkout is read-only: importing it must not leave __pycache__ there
 import types
 
 import numpy as np

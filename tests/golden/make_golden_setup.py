@@ -19,6 +19,8 @@ import importlib.abc
 import importlib.machinery
 import os
 import sys
+
+sys.dont_write_bytecode = True  # the reference checkout is read-only: importing it must not leave __pycache__ there
 import types
 
 import numpy as np

@@ -21,6 +21,8 @@ import json
 import os
 import runpy
 import sys
+
+sys.dont_write_bytecode = True  # the reference checkout is read-only: importing it must not leave __pycache__ there
 import types
 
 HERE = os.path.dirname(os.path.abspath(__file__))
