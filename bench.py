@@ -293,7 +293,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def capture():
+    def capture(unroll=1):
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -305,7 +305,8 @@ def main():
         # capture on the stream the warm-up ran on: the zero-initialised forward workspace is cached per stream, and
         # a first use on a fresh capture stream would record its one-off torch.zeros fill (5.5 us) into every replay
         with torch.cuda.graph(g, stream=side):
-            wl.step()
+            for _ in range(unroll):
+                wl.step()
         return g
 
     def quick(fn, n=40):
@@ -318,24 +319,32 @@ def main():
         torch.cuda.synchronize()
         return (time.perf_counter() - t) / n * 1e3
 
-    # launch mechanism: plain eager launches or one hipGraph replay per step.  Unless forced with --mode,
-    # a short untimed calibration picks the faster one on a single GPU (both are recorded in `config`);
-    # multi-GPU runs are eager (the RCCL calls stay outside any graph).
-    graph, ms_modes = None, {}
+    # launch mechanism: plain eager launches, one hipGraph replay per step, or UNROLL consecutive steps captured in one
+    # graph (every step is the full, identical launch sequence; between two graph launches the stream idles for ~5-9 us,
+    # which a training loop captured as a whole would not pay per iteration either).  Unless forced with --mode, a short
+    # untimed calibration picks the fastest on a single GPU (all are recorded in `config`); multi-GPU runs are eager
+    # (the RCCL calls stay outside any graph).
+    UNROLL = 10
+    graph, graph_u, ms_modes = None, None, {}
+    unrollable = args.steps % UNROLL == 0 and args.steps >= UNROLL
     mode = args.mode or ("eager" if world > 1 else None)
     if mode is None:
         graph = capture()
         ms_modes = {"eager": quick(wl.step), "graph": quick(graph.replay)}
+        if unrollable:
+            graph_u = capture(UNROLL)
+            ms_modes["graph_x%d" % UNROLL] = quick(graph_u.replay, n=8) / UNROLL
         mode = min(ms_modes, key=ms_modes.get)
     elif mode == "graph":
         graph = capture()
-    run = graph.replay if mode == "graph" else wl.step
+    steps_per_launch = UNROLL if mode.startswith("graph_x") else 1
+    run = graph_u.replay if steps_per_launch > 1 else (graph.replay if mode == "graph" else wl.step)
 
-    for _ in range(args.warmup):
+    for _ in range(-(-args.warmup // steps_per_launch)):
         run()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(args.steps // steps_per_launch):   # exactly args.steps steps (steps_per_launch divides it)
         run()
     barrier()
     dt = time.perf_counter() - t0
@@ -405,6 +414,7 @@ def main():
                                    "see value_with_knn)" % (wl.Pc, wl.N),
                        "points_per_cloud": wl.Pc, "cameras": wl.N, "image_size": S, "points_per_pixel": K,
                        "h_precomputed": True, "parallelism": "rows%d" % world, "launch": mode,
+                       "steps_per_graph_launch": steps_per_launch,
                        "dist": {"world_size": dist.get_world_size(), "backend": dist.get_backend()} if world > 1
                        else {"world_size": 1, "backend": None}},
             "roofline": dominant, "roofline_other": other,

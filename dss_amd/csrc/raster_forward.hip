@@ -1394,8 +1394,10 @@ extern "C" int dss_render_forward(const float *world, const float *normals, cons
     if (!rerun) {
         hipLaunchKernelGGL(setup_bin_kernel, dim3(pb), dim3(64), 0, st, SA, g, w.counts, w.lists, w.cap, w.queue, w.spill,
                            visible);
+#ifndef DSS_EXP_NOSPILL
         hipLaunchKernelGGL(spill_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, pts_screen, radii, first_idx,
                            num_pts, N, P, g, w.counts, w.cap, w.spill);
+#endif
     }
     FineArgs A;
     A.points = pts_screen; A.ellipse = ellipse; A.cutoff = cutoff; A.radii = radii;

@@ -36,8 +36,24 @@ for rep in range(5):
     for _ in range(50 if cfg in ("cfg2", "cfg3") else 10): wl.step()
     torch.cuda.synchronize()
     best = min(best, (time.perf_counter() - t0) / (50 if cfg in ("cfg2", "cfg3") else 10) * 1e3)
+gbest = None
+if cfg == "cfg2":
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3): wl.step()
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        wl.step()
+    gbest = 1e9
+    for rep in range(8):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(200): g.replay()
+        torch.cuda.synchronize()
+        gbest = min(gbest, (time.perf_counter() - t0) / 200 * 1e3)
 fm = [wl.fine_kernel_ms(iters=30) for _ in range(3)]
-print(json.dumps({"step_ms_eager_best": round(best, 5), "fine_ms_mean": round(min(f[0] for f in fm), 5),
+print(json.dumps({"step_ms_graph_best": None if gbest is None else round(gbest, 5), "step_ms_eager_best": round(best, 5), "fine_ms_mean": round(min(f[0] for f in fm), 5),
                   "fine_ms_median": round(min(f[1] for f in fm), 5)}))
 '''
 
