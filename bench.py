@@ -155,20 +155,26 @@ class Workload:
 
     def backward_gather_ms(self, iters=50):
         """The backward's dominant kernel (render_backward_kernel: blend backward + occupancy surrogate per visible
-        point): event time of dss_render_backward (compaction + median + gather) minus the event time of its two
-        preparation launches alone (dss_backward_radius runs exactly those).  Also returns what the VALU roofline needs:
+        point), timed on its own through the staged entry point dss_render_backward_gather (round 2 first subtracted the
+        event time of dss_backward_radius from that of the full call: the stand-alone radius path is slower than the fused
+        preparation, which flattered the gather by a third).  Also returns what the VALU roofline needs:
         the number of (pixel, visible point) pairs inside the search radius."""
         p, S = self.part, self.S
         f = ops.render_forward(self.world, self.normals, self.h, self.M, self.V, self.znear, self.zfar, self.first,
                                self.num, self.colors, S, K, CUTOFF, THR, SIGMA, False, True, rows=p.rows)
         g = p.slice(self.grad_out).contiguous()
-        full = lambda: ops.render_backward(g, f["idx"], f["qvalue"], f["wsum"], f["scaler"], f["pts_screen"], f["radii"],
-                                           f["visible"], self.first, self.num, RADII_S, CLIP, image_size=S, rows=p.rows)
-        prep = lambda: ops.backward_radius(f["radii"], f["visible"], self.first, self.num, RADII_S)
+        args = (g, f["idx"], f["qvalue"], f["wsum"], f["scaler"], f["pts_screen"], f["radii"], f["visible"], self.first,
+                self.num, RADII_S, CLIP)
+        gf, gp, rs0 = ops.render_backward(*args, image_size=S, rows=p.rows, return_rs=True)
+        full = lambda: ops.render_backward(*args, image_size=S, rows=p.rows, out=(gf, gp))
+        # the gather kernel alone, on the lists / alpha plane / rs / zero-filled gradients the full call leaves behind
+        gather = lambda: ops.render_backward(*args, image_size=S, rows=p.rows, out=(gf, gp), gather_only_rs=rs0)
         t_full, _ = self._event_ms(full, iters)
-        t_prep, _ = self._event_ms(prep, iters)
+        full()
+        t_gather, _ = self._event_ms(gather, iters)
+        t_prep = max(t_full - t_gather, 0.0)
         # (pixel, point) pairs the rule has to evaluate: pixel centres within rs of a visible, on-screen point
-        rs = prep()
+        rs = rs0
         vis = f["visible"]
         pts = f["pts_screen"][vis]
         cloud = (torch.arange(self.P, device=self.dev) // self.Pc)[vis]
@@ -187,7 +193,7 @@ class Workload:
             lim = (rr[:, None] ** 2 - dy2).clamp_min(-1.0)     # (pts, rows)
             dx2s, _ = dx2.sort(dim=1)
             pairs += int(torch.searchsorted(dx2s, lim.contiguous(), right=True).sum().item())
-        return max(t_full - t_prep, 0.0), t_full, t_prep, pairs, int(vis.sum().item())
+        return t_gather, t_full, t_prep, pairs, int(vis.sum().item())
 
 
 def cpu_baseline():
@@ -400,8 +406,8 @@ def main():
     valu = {"bound": "valu", "kernel": "render_backward_kernel<3> (blend backward + occupancy surrogate per visible point)",
             "achieved": round(valu_ach, 4), "peak": round(VALU_PEAK, 2), "unit": "Tlaneop/s", "frac": round(valu_ach / VALU_PEAK, 5),
             "pairs": pairs, "min_ops_per_pair": MIN_OPS, "visible_points": n_vis, "kernel_ms_mean": round(gather_ms, 5),
-            "how": "event time of dss_render_backward (%.5f ms) minus its two preparation launches alone (%.5f ms)"
-                   % (bwd_ms, prep_ms)}
+            "how": "HIP events around dss_render_backward_gather alone (second stage of dss_render_backward: %.5f ms for "
+                   "all three launches, i.e. %.5f ms of compaction + median)" % (bwd_ms, prep_ms)}
     dominant, other = (valu, hbm) if gather_ms > fine_mean else (hbm, valu)
     if rank == 0:
         rec = {

@@ -1320,12 +1320,12 @@ extern "C" size_t dss_render_backward_workspace(int N, int64_t P, int S)
            + align_up(n * s * s * 4, 256);                    // dense alpha-gradient plane
 }
 
-extern "C" int dss_render_backward(const float *grad_out, const int32_t *idx, const float *qvalue, const float *wsum,
-                                   const float *scaler, const float *points, const float *radii,
-                                   const uint8_t *visible, const int64_t *first_idx, const int64_t *num_pts, int N,
-                                   int64_t P, int S, int K, int C, int row0, int row1, float radii_s, float clip,
-                                   float *grad_feat, float *grad_pts, float *rs_out, void *workspace,
-                                   size_t workspace_bytes, void *stream)
+static int render_backward_impl(bool run_prep, const float *grad_out, const int32_t *idx, const float *qvalue, const float *wsum,
+                                const float *scaler, const float *points, const float *radii,
+                                const uint8_t *visible, const int64_t *first_idx, const int64_t *num_pts, int N,
+                                int64_t P, int S, int K, int C, int row0, int row1, float radii_s, float clip,
+                                float *grad_feat, float *grad_pts, float *rs_out, void *workspace,
+                                size_t workspace_bytes, void *stream)
 {
     if (N <= 0 || P < 0 || S <= 0 || K <= 0 || C < 1 || C > BLEND_MAX_C || row0 < 0 || row1 > S || row0 >= row1) {
         set_error("dss_render_backward: bad sizes N=%d P=%lld S=%d K=%d C=%d", N, (long long)P, S, K, C);
@@ -1361,8 +1361,9 @@ extern "C" int dss_render_backward(const float *grad_out, const int32_t *idx, co
         vis_count = reinterpret_cast<uint32_t *>(w + L.seg_count);
         vis_list = reinterpret_cast<int32_t *>(w + L.vis_list);
         rs = rs_out ? rs_out : reinterpret_cast<float *>(w + L.rs);
-        launch_prep(radii, visible, first_idx, num_pts, N, P, radii_s, rs, w, L, grad_pts, grad_feat, C, grad_out, npix, st);
-        if (row1 - row0 < S) {  // row band: keep only the points that can reach it
+        if (run_prep)
+            launch_prep(radii, visible, first_idx, num_pts, N, P, radii_s, rs, w, L, grad_pts, grad_feat, C, grad_out, npix, st);
+        if (run_prep && row1 - row0 < S) {  // row band: keep only the points that can reach it
             if (L.per == 2)
                 hipLaunchKernelGGL(band_filter_kernel<2>, dim3(L.chunks), dim3(PREP_THREADS), 0, st, points, radii, rs,
                                    first_idx, num_pts, N, S, row0, row1 - row0, vis_count, vis_list, grad_pts, grad_feat, C);
@@ -1381,6 +1382,7 @@ extern "C" int dss_render_backward(const float *grad_out, const int32_t *idx, co
         off += align_up((size_t)N * 4, 256);
         float *plane = reinterpret_cast<float *>(w + off);
         alpha = plane;
+        if (run_prep) {
         hipLaunchKernelGGL(alpha_plane_kernel, dim3((unsigned)((npix + ALPHA_PIX_PER_WG - 1) / ALPHA_PIX_PER_WG)), dim3(1024),
                            0, st, grad_out, plane, npix, C);
         if (hipMemsetAsync(hist, 0, hist_bytes + 256, st) != hipSuccess) return check_launch("memset render_backward");
@@ -1392,6 +1394,7 @@ extern "C" int dss_render_backward(const float *grad_out, const int32_t *idx, co
         hipLaunchKernelGGL(median_hist_kernel<2>, dim3(blocks), dim3(MED_THREADS), 0, st, radii, visible, first_idx,
                            num_pts, N, P, hist);
         hipLaunchKernelGGL(median_final_kernel, dim3(N), dim3(MED_THREADS), 0, st, hist, N, radii_s, rs);
+        }
     }
     // persistent grid = exactly the resident capacity of the chip for this kernel (a larger grid would
     // leave late workgroups waiting for slots while their share of the list sits idle)
@@ -1440,6 +1443,30 @@ extern "C" int dss_render_backward(const float *grad_out, const int32_t *idx, co
 #undef DSS_LAUNCH_RB_T
 #undef DSS_LAUNCH_RB
     return check_launch("dss_render_backward");
+}
+
+extern "C" int dss_render_backward(const float *grad_out, const int32_t *idx, const float *qvalue, const float *wsum,
+                                   const float *scaler, const float *points, const float *radii,
+                                   const uint8_t *visible, const int64_t *first_idx, const int64_t *num_pts, int N,
+                                   int64_t P, int S, int K, int C, int row0, int row1, float radii_s, float clip,
+                                   float *grad_feat, float *grad_pts, float *rs_out, void *workspace,
+                                   size_t workspace_bytes, void *stream)
+{
+    return render_backward_impl(true, grad_out, idx, qvalue, wsum, scaler, points, radii, visible, first_idx, num_pts, N, P, S,
+                                K, C, row0, row1, radii_s, clip, grad_feat, grad_pts, rs_out, workspace, workspace_bytes, stream);
+}
+
+// Second stage alone (the persistent gather kernel), on the workspace (visible lists, alpha plane, rs) and the zero-filled
+// gradients a preceding dss_render_backward call with the SAME arguments left behind.  For per-kernel timing (bench.py).
+extern "C" int dss_render_backward_gather(const float *grad_out, const int32_t *idx, const float *qvalue, const float *wsum,
+                                          const float *scaler, const float *points, const float *radii,
+                                          const uint8_t *visible, const int64_t *first_idx, const int64_t *num_pts, int N,
+                                          int64_t P, int S, int K, int C, int row0, int row1, float radii_s, float clip,
+                                          float *grad_feat, float *grad_pts, float *rs_out, void *workspace,
+                                          size_t workspace_bytes, void *stream)
+{
+    return render_backward_impl(false, grad_out, idx, qvalue, wsum, scaler, points, radii, visible, first_idx, num_pts, N, P, S,
+                                K, C, row0, row1, radii_s, clip, grad_feat, grad_pts, rs_out, workspace, workspace_bytes, stream);
 }
 
 #ifdef DSS_FINE_TIMING

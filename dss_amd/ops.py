@@ -469,10 +469,13 @@ def render_forward(world, normals, h, M, V, znear, zfar, cloud_to_packed_first_i
 def render_backward(grad_out, idx, qvalue, wsum, scaler, points, radii, visible, cloud_to_packed_first_idx,
                     num_points_per_cloud, radii_s: float, clip: float = -1.0, with_features: bool = True,
                     return_rs: bool = False, image_size: Optional[int] = None,
-                    rows: Optional[Tuple[int, int]] = None, out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
+                    rows: Optional[Tuple[int, int]] = None, out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
+                    gather_only_rs: Optional[torch.Tensor] = None):
     """Fused backward of renderer + rasterizer (blend backward + median radius + occupancy backward +
     clip) -> (grad_features (P,C) or None, grad_pts_screen (P,3)).  With ``rows`` (multi-GPU band) pass the
-    union of the visibility flags and ``clip <= 0``; the results are the band's partial sums."""
+    union of the visibility flags and ``clip <= 0``; the results are the band's partial sums.
+    ``gather_only_rs`` = the ``rs`` a preceding identical call returned (and ``out`` = its outputs): re-runs only the
+    second stage, the gather kernel (``dss_render_backward_gather``; per-kernel timing)."""
     lib = _lib.load()
     grad_out = _lib.require_gpu(grad_out, "grad_out", _f32)
     dev = grad_out.device
@@ -509,13 +512,17 @@ def render_backward(grad_out, idx, qvalue, wsum, scaler, points, radii, visible,
             if return_rs:
                 return gf, gp, backward_radius(radii, vis, first, num, radii_s)
             return gf, gp
-        rs = torch.empty((N,), dtype=_f32, device=dev)
+        rs = torch.empty((N,), dtype=_f32, device=dev) if gather_only_rs is None else \
+            _lib.require_gpu(gather_only_rs, "gather_only_rs", _f32)
+        if gather_only_rs is not None and out is None:
+            raise RuntimeError("gather_only_rs needs out= (the gradients the full call zero-filled)")
         ws = _lib.workspace(dev, lib.dss_render_backward_workspace(N, P, S))
-        rc = lib.dss_render_backward(_lib.ptr(grad_out), _lib.ptr(idx), _lib.ptr(qvalue), _lib.ptr(wsum),
-                                     _lib.ptr(scaler), _lib.ptr(points), _lib.ptr(radii), _lib.ptr(vis),
-                                     _lib.ptr(first), _lib.ptr(num), N, P, S, K, C, row0, row1, float(radii_s),
-                                     float(clip), _lib.ptr(gf), _lib.ptr(gp), _lib.ptr(rs), _lib.ptr(ws), ws.numel(),
-                                     _lib.stream_ptr(dev))
+        entry = lib.dss_render_backward if gather_only_rs is None else lib.dss_render_backward_gather
+        rc = entry(_lib.ptr(grad_out), _lib.ptr(idx), _lib.ptr(qvalue), _lib.ptr(wsum),
+                   _lib.ptr(scaler), _lib.ptr(points), _lib.ptr(radii), _lib.ptr(vis),
+                   _lib.ptr(first), _lib.ptr(num), N, P, S, K, C, row0, row1, float(radii_s),
+                   float(clip), _lib.ptr(gf), _lib.ptr(gp), _lib.ptr(rs), _lib.ptr(ws), ws.numel(),
+                   _lib.stream_ptr(dev))
     _lib.check(rc, "dss_render_backward")
     return (gf, gp, rs) if return_rs else (gf, gp)
 

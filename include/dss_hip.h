@@ -274,6 +274,17 @@ DSS_API int dss_render_backward(const float *grad_out, const int32_t *idx, const
                                 float *grad_feat /* (P,C) or NULL */,
                                 float *grad_pts /* (P,3) */, float *rs_out /* (N,) or NULL */,
                                 void *workspace, size_t workspace_bytes, void *stream);
+/* Second stage of dss_render_backward alone (the persistent gather kernel = blend backward + occupancy surrogate + clip of
+ * every visible point, rasterize_points_backward.cu:30-212): runs on the workspace (visible lists, alpha plane, rs) and the
+ * zero-filled gradients that a preceding dss_render_backward call with the SAME arguments left behind; same result.
+ * Exists so that the kernel can be timed on its own (bench.py roofline_other). */
+DSS_API int dss_render_backward_gather(const float *grad_out, const int32_t *idx, const float *qvalue,
+                                       const float *wsum, const float *scaler, const float *points,
+                                       const float *radii, const uint8_t *visible, const int64_t *first_idx,
+                                       const int64_t *num_pts, int N, int64_t P, int S, int K, int C,
+                                       int row0, int row1, float radii_s, float clip, float *grad_feat,
+                                       float *grad_pts, float *rs_out, void *workspace, size_t workspace_bytes,
+                                       void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused per-point setup = everything SurfaceSplatting.forward does before _C.splat_points:

@@ -654,6 +654,25 @@ def test_render_backward_row_bands_sum_to_full(S, bounds):
     assert _rel_l2(sum_gf.cpu().numpy(), gf.cpu().numpy()) <= 1e-5
 
 
+@pytest.mark.parametrize("P,S", [(3000, 96), (300000, 256)])
+def test_render_backward_gather_stage_alone_reproduces_the_full_call(P, S):
+    """`dss_render_backward_gather` (second stage only, on the workspace and zero-filled gradients of a preceding full
+    call; both preparation paths: P <= 262144 and above) gives the full call's result bit for bit."""
+    sc = scenes.random_splats(P, S, 2, seed=5, rmin=0.6, rmax=2.0) if P > 10000 else scenes.random_splats(P, S, 2, seed=5)
+    d = _dev(sc)
+    idx, zbuf, qv, occ, vis = _fwd(d, S, 5, 0.3, return_visible=True)
+    scaler = torch.from_numpy(sc["scaler"]).to(DEV)
+    img, wsum = ops.blend_forward(idx, qv, occ, scaler, torch.from_numpy(sc["colors"]).to(DEV), return_wsum=True)
+    go = torch.randn_like(img)
+    a = (go, idx, qv, wsum, scaler, d["points"], d["radii"], vis, d["first"], d["num"], 4.0, 0.05)
+    gf, g, rs = ops.render_backward(*a, return_rs=True)
+    want_gf, want_g = gf.clone(), g.clone()
+    g[vis.bool()] = 7.0          # the second stage rewrites every visible row and leaves the zero rows alone
+    gf[vis.bool()] = 7.0
+    gf2, g2 = ops.render_backward(*a, out=(gf, g), gather_only_rs=rs)
+    assert torch.equal(g2, want_g) and torch.equal(gf2, want_gf)
+
+
 @pytest.mark.parametrize("sizes,frac,dist", [
     ((0,), 0.5, "lognormal"),               # empty cloud
     ((1,), 1.0, "lognormal"),               # single point, two radii
