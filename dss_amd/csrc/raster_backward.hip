@@ -13,6 +13,7 @@
 //   zbuf_backward_kernel   z_grad scatter                                 rasterize_points.cu:823-846
 //   clip_grad_kernel       per-point norm clip hook                       rasterizer.py:667-673
 #include <stdlib.h>
+#include <type_traits>
 #include "point_bodies.h"
 
 namespace dss {
@@ -952,6 +953,10 @@ __global__ __launch_bounds__(256) void render_backward_kernel(
             // RB rows per trip: all their loads are issued before the first is used (one memory round trip per trip; a
             // row-at-a-time loop spent ~1 us per ROW waiting)
             constexpr int RB = 8;
+            // NDC y of the lane's rows: for S = 2^k every pixel centre and every centre-to-centre distance is an exact
+            // fp32 multiple of 1/S, so the rows advance by exact additions (one v_add per row instead of convert +
+            // multiply + add behind a branch); other sizes evaluate the reference expression per row
+            const float y_step = (float)(2 * RP) * ndc.invS;          // distance of two consecutive rows of a lane row
             for (int ib = 0; ib < nrow; ib += RB) {
                 float g0[RB], g1[RB];
 #pragma unroll
@@ -963,10 +968,14 @@ __global__ __launch_bounds__(256) void render_backward_kernel(
                     if (r_ok && c0) g0[u] = gimg[i0 - i * S];
                     if (r_ok && c1) g1[u] = gimg[i1 - i * S];
                 }
+                const float y_ib = ndc(ylo + rp + RP * ib);
+                auto consume = [&](auto pow2_tag) {
+                constexpr bool POW2 = decltype(pow2_tag)::value;
 #pragma unroll
                 for (int u = 0; u < RB; ++u) {
                     if (ib + u >= nrow) break;  // uniform
-                    const float dy = ndc(ylo + rp + RP * (ib + u)) - py;
+                    const float yv = POW2 ? y_ib + (float)u * y_step : ndc(ylo + rp + RP * (ib + u));
+                    const float dy = yv - py;
                     const float dy2 = dy * dy;
                     const f2 gg = {g0[u], g1[u]};
                     const f2 d2 = dx2 + dy2;
@@ -982,6 +991,8 @@ __global__ __launch_bounds__(256) void render_backward_kernel(
                     gx2 = __builtin_elementwise_fma(dx, sgl, gx2);
                     gy2 = __builtin_elementwise_fma(dyy, sgl, gy2);
                 }
+                };
+                if (ndc.pow2) consume(std::true_type{}); else consume(std::false_type{});
             }
         }
         float gx = gx2.x + gx2.y, gy = gy2.x + gy2.y;
@@ -1002,7 +1013,7 @@ __global__ __launch_bounds__(256) void render_backward_kernel(
             // ptx patches per row), all tasks in a common loop over the largest box
             const int ptx = (bxhi - bxlo + 4) >> 2, pty = (byhi - bylo + 4) >> 2;   // 0 for an empty box
             const int npatch = (tasks_max<TPW>(ptx * pty) + RP - 1) / RP;
-            const float inv_ptx = 1.0f / (float)max(ptx, 1);
+            const float inv_ptx = fast_rcp((float)max(ptx, 1));   // (pi + 0.5) / ptx is never within 0.5 / ptx of an integer
             for (int it = 0; it < npatch; ++it) {
                 const int pi_ = rp + RP * it;
                 const int pty_i = (int)(((float)pi_ + 0.5f) * inv_ptx);   // pi_ / ptx (exact: small integers)
@@ -1064,8 +1075,9 @@ __global__ __launch_bounds__(256) void render_backward_kernel(
         if (l == 0 && rp == 0 && p >= 0 && n >= 0) {
             if (clip > 0.0f) {  // rasterizer.py:667-673 (z gradient is 0 on this path)
                 const float nrm = sqrtf(gx * gx + gy * gy);
-                gx = gx / fmaxf(nrm, 1e-12f) * fminf(nrm, clip);
-                gy = gy / fmaxf(nrm, 1e-12f) * fminf(nrm, clip);
+                const float k = fminf(nrm, clip) * fast_rcp(fmaxf(nrm, 1e-12f));   // 1-ulp reciprocal instead of two divides
+                gx *= k;
+                gy *= k;
             }
             grad_pts[3 * (size_t)p] = gx;
             grad_pts[3 * (size_t)p + 1] = gy;

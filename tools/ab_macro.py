@@ -53,7 +53,8 @@ if cfg == "cfg2":
         torch.cuda.synchronize()
         gbest = min(gbest, (time.perf_counter() - t0) / 200 * 1e3)
 fm = [wl.fine_kernel_ms(iters=30) for _ in range(3)]
-print(json.dumps({"step_ms_graph_best": None if gbest is None else round(gbest, 5), "step_ms_eager_best": round(best, 5), "fine_ms_mean": round(min(f[0] for f in fm), 5),
+gm = min(wl.backward_gather_ms(iters=30)[0] for _ in range(3))
+print(json.dumps({"gather_ms": round(gm, 5), "step_ms_graph_best": None if gbest is None else round(gbest, 5), "step_ms_eager_best": round(best, 5), "fine_ms_mean": round(min(f[0] for f in fm), 5),
                   "fine_ms_median": round(min(f[1] for f in fm), 5)}))
 '''
 
