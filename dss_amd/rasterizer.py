@@ -10,10 +10,12 @@ the same module, so both are exported here.  All device work goes through the C 
 
 Differences that a caller can observe (documented in DESIGN.md / INTEGRATION.md):
 * culled points are masked, not compacted: the returned point cloud is the cloud extended to the
-  N cameras, ``fragments.idx`` indexes its packed points, culled points simply never appear;
+  N cameras, ``fragments.idx`` indexes its packed points, culled points simply never appear
+  (``SurfaceSplatting(..., compact_culled=True)`` drops them like the reference: same integer labels, h from the
+  filtered clouds -- at the price of boolean indexing with host syncs per call);
 * a point exactly on a pixel centre contributes 0 to the occupancy gradient (reference: NaN).
 """
-from typing import NamedTuple, Optional
+from typing import Optional
 
 import torch
 import torch.autograd as autograd
@@ -25,15 +27,54 @@ __all__ = ["PointFragments", "PointsRasterizationSettings", "SurfaceSplatting", 
            "EllipticalRasterizer", "knn_variance_scale"]
 
 
-class PointFragments(NamedTuple):  # rasterizer.py:31-36 (+ one optional trailing field)
-    idx: torch.Tensor
-    zbuf: torch.Tensor
-    qvalue: torch.Tensor
-    scaler: torch.Tensor
-    occupancy: torch.Tensor
-    # (pts_screen, radii, visible, first_idx, num_points): lets the blend backward run as a
-    # deterministic point-centric gather instead of an atomic scatter.  None is always legal.
-    geometry: Optional[tuple] = None
+class PointFragments:
+    """rasterizer.py:31-36: ``(idx, zbuf, qvalue, scaler, occupancy)`` with the reference's shapes -- a tuple-like object
+    (fields, order, unpacking, ``_replace`` / ``_asdict`` as on the reference's NamedTuple).
+
+    ``scaler`` is the per-FRAGMENT ``(N, H, W, K)`` tensor of rasterizer.py:631-633 (0 where ``idx < 0``), but it is only
+    materialised when somebody reads it: the kernels consume the per-point ``scaler_packed (P,)`` (the gather is fused
+    into the blend).  ``geometry`` = (pts_screen, radii, visible, first_idx, num_points) lets the blend backward run as a
+    deterministic point-centric gather instead of an atomic scatter; None is always legal."""
+    _fields = ("idx", "zbuf", "qvalue", "scaler", "occupancy")
+    __slots__ = ("idx", "zbuf", "qvalue", "_scaler", "occupancy", "geometry", "scaler_packed")
+
+    def __init__(self, idx, zbuf, qvalue, scaler, occupancy, geometry=None):
+        self.idx, self.zbuf, self.qvalue, self.occupancy, self.geometry = idx, zbuf, qvalue, occupancy, geometry
+        if scaler is not None and scaler.dim() == 1:   # per point: keep packed, gather lazily
+            self.scaler_packed, self._scaler = scaler, None
+        else:
+            self.scaler_packed, self._scaler = None, scaler
+
+    @property
+    def scaler(self):
+        if self._scaler is None and self.scaler_packed is not None:
+            valid = self.idx >= 0
+            self._scaler = torch.where(valid, self.scaler_packed[self.idx.clamp_min(0).long()],
+                                       torch.zeros((), dtype=self.scaler_packed.dtype, device=self.idx.device))
+        return self._scaler
+
+    def __iter__(self):
+        return iter((self.idx, self.zbuf, self.qvalue, self.scaler, self.occupancy))
+
+    def __len__(self):
+        return 5
+
+    def __getitem__(self, i):
+        return tuple(self)[i]
+
+    def _asdict(self):
+        return dict(zip(self._fields, tuple(self)))
+
+    def _replace(self, **kw):
+        d = dict(idx=self.idx, zbuf=self.zbuf, qvalue=self.qvalue, occupancy=self.occupancy, geometry=self.geometry,
+                 scaler=self.scaler_packed if self.scaler_packed is not None else self._scaler)
+        d.update(kw)
+        return PointFragments(**d)
+
+    def __repr__(self):
+        return "PointFragments(idx=%r, zbuf=%r, qvalue=%r, scaler=<%s>, occupancy=%r)" % (
+            tuple(self.idx.shape), tuple(self.zbuf.shape), tuple(self.qvalue.shape),
+            "packed (P,)" if self._scaler is None else "per fragment", tuple(self.occupancy.shape))
 
 
 class PointsRasterizationSettings:
@@ -175,13 +216,14 @@ class SurfaceSplatting(torch.nn.Module):
     """rasterizer.py:102-664.  ``forward(point_clouds, point_clouds_filter=None, **kwargs)`` returns the
     tuple ``(PointFragments, point_clouds[, per_point_info])`` (:655-664)."""
 
-    def __init__(self, cameras=None, raster_settings=None, frnn_radius=0.2):
+    def __init__(self, cameras=None, raster_settings=None, frnn_radius=0.2, compact_culled: bool = False):
         super().__init__()
         if raster_settings is None:
             raster_settings = PointsRasterizationSettings()
         self.cameras = cameras
         self.raster_settings = raster_settings
         self.frnn_radius = frnn_radius
+        self.compact_culled = compact_culled   # True: drop culled points like the reference (see _forward_compacted)
         self._Vrk_h = None
 
     # -- source-space variance scale h (rasterizer.py:293-402) ------------------------------------
@@ -314,6 +356,60 @@ class SurfaceSplatting(torch.nn.Module):
         full[keep] = vis
         point_clouds_filter.set_filter(visibility=full)
 
+    def _forward_compacted(self, point_clouds, original_clouds, point_clouds_filter, **kwargs):
+        """``compact_culled=True``: the reference's exact order (rasterizer.py:219-254, 293-402): extend the cloud to the
+        N cameras, DROP the points outside [znear, zfar] (and back faces) -- new, smaller clouds --, compute the variance
+        scale h on those, rasterize them.  ``fragments.idx`` then labels the filtered packed cloud that is returned, integer
+        for integer like the reference.  Costs boolean indexing with host syncs per call, which the default (masked)
+        path avoids; results for every consumer of the (fragments, point_clouds) pair are the same either way."""
+        raster_settings = kwargs.get("raster_settings", self.raster_settings)
+        cameras = kwargs.get("cameras", self.cameras)
+        if cameras is None:
+            raise ValueError("Cameras must be specified either at initialization or in the forward pass")
+        N = cameras.R.shape[0]
+        dev = point_clouds.device
+        pc = point_clouds if len(point_clouds) == N else point_clouds.extend(N)
+        V = cameras.get_world_to_view_transform().get_matrix().to(dev, torch.float32)
+
+        def per_cam(name, default):
+            t = getattr(cameras, name, kwargs.get(name, default))
+            return torch.as_tensor(t, dtype=torch.float32, device=dev).reshape(-1).expand(N)
+        znear, zfar = per_cam("znear", 1.0), per_cam("zfar", 100.0)
+        pl, nl, fl = pc.points_list(), pc.normals_list(), pc.features_list()
+        keeps, pts_f, nrm_f, feat_f = [], [], [], []
+        for n in range(N):
+            with torch.no_grad():
+                zview = pl[n] @ V[n, :3, 2] + V[n, 3, 2]
+                keep = (zview >= znear[n]) & (zview <= zfar[n])
+                if raster_settings.backface_culling:
+                    keep &= (nl[n] @ V[n, :3, 2]) < 0
+            keeps.append(keep)
+            pts_f.append(pl[n][keep])
+            nrm_f.append(nl[n][keep])
+            if fl is not None:
+                feat_f.append(fl[n][keep])
+        try:
+            filtered = type(point_clouds)(pts_f, nrm_f, feat_f if fl is not None else None)
+        except Exception:  # noqa: BLE001  (a foreign cloud class with another constructor)
+            filtered = PointClouds3D(pts_f, nrm_f, feat_f if fl is not None else None)
+        keep_all = torch.cat(keeps)
+        if filtered.isempty():
+            return self._empty_fragments(N, dev, raster_settings), filtered
+        kw = dict(kwargs)
+        kw["verbose"] = True
+        fragments, _, info = self._forward_masked(filtered, filtered, None, **kw)
+        vis_ext = torch.zeros(keep_all.shape[0], dtype=torch.bool, device=dev)
+        vis_ext[keep_all] = fragments.geometry[2].view(torch.bool) if fragments.geometry[2].dtype == torch.uint8 \
+            else fragments.geometry[2].bool()
+        self._store_visibility(point_clouds_filter, vis_ext, N, False, original_clouds)
+        if kwargs.get("verbose", False):
+            full = {}
+            for k, v in info.items():   # rasterizer.py:655-662: per-point info scattered back over the un-filtered points
+                full[k] = v.new_zeros((keep_all.shape[0],) + tuple(v.shape[1:]))
+                full[k][keep_all] = v
+            return fragments, filtered, full
+        return fragments, filtered
+
     def forward(self, point_clouds, point_clouds_filter=None, **kwargs):
         raster_settings = kwargs.get("raster_settings", self.raster_settings)
         original_clouds = point_clouds
@@ -322,6 +418,12 @@ class SurfaceSplatting(torch.nn.Module):
         if point_clouds.isempty():
             cameras = kwargs.get("cameras", self.cameras)
             return self._empty_fragments(cameras.R.shape[0], point_clouds.device, raster_settings), point_clouds
+        if getattr(self, "compact_culled", False):
+            return self._forward_compacted(point_clouds, original_clouds, point_clouds_filter, **kwargs)
+        return self._forward_masked(point_clouds, original_clouds, point_clouds_filter, **kwargs)
+
+    def _forward_masked(self, point_clouds, original_clouds, point_clouds_filter, **kwargs):
+        raster_settings = kwargs.get("raster_settings", self.raster_settings)
         a = self._prepare(point_clouds, **kwargs)
         N, shared, first_idx, num_points = a["N"], a["shared"], a["first_idx"], a["num_points"]
 
@@ -336,8 +438,8 @@ class SurfaceSplatting(torch.nn.Module):
             raster_settings.max_points_per_bin, raster_settings.radii_backward_scaler,
             raster_settings.clip_pts_grad)
 
-        # the per-fragment scaler gather of rasterizer.py:631-633 is fused into the blend kernel; the
-        # fragments carry the per-POINT scaler (P,) instead (renderer consumes either form)
+        # the per-fragment scaler gather of rasterizer.py:631-633 is fused into the blend kernel: the fragments keep
+        # the per-POINT scaler (`scaler_packed`) and materialise the (N,H,W,K) `scaler` only if it is read
         fragments = PointFragments(idx=idx, zbuf=zbuf, qvalue=qvalue_map, scaler=scaler, occupancy=occ_map,
                                    geometry=(pts_screen.detach(), radii, visible, first_idx, num_points))
         self._last_valid = valid

@@ -88,7 +88,9 @@ class SurfaceSplattingRenderer(torch.nn.Module):
             else:
                 fragments, point_clouds = self.rasterizer(point_clouds, **kwargs)
         pts_rgb = point_clouds.features_packed()[:, :3].contiguous()
-        scaler = fragments.scaler
+        scaler = getattr(fragments, "scaler_packed", None)   # ours: per point (the gather is fused into the blend)
+        if scaler is None:
+            scaler = fragments.scaler
         if scaler.dim() != 1:
             # reference-style per-fragment scaler (N,H,W,K): fold it into q (w = exp(-q/2) * s)
             qv = torch.where(fragments.idx >= 0,

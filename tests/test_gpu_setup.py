@@ -258,7 +258,10 @@ def test_renderer_without_compositor_is_unnormalised_weighted_sum():
     feat2 = feat.detach().clone().requires_grad_(True)
     valid = fr.idx >= 0
     safe = fr.idx.clamp_min(0).long()
-    w = torch.exp(-0.5 * fr.qvalue) * fr.scaler[safe] * valid
+    w = torch.exp(-0.5 * fr.qvalue) * fr.scaler_packed[safe] * valid
+    # the per-fragment view has the reference's shape and values (rasterizer.py:631-633: 0 where idx < 0)
+    assert fr.scaler.shape == fr.qvalue.shape and torch.equal(fr.scaler, fr.scaler_packed[safe] * valid)
+    assert len(fr) == 5 and [tuple(t.shape) for t in fr][3] == tuple(fr.qvalue.shape) and fr._fields[3] == "scaler"
     want = (feat2[safe] * w.unsqueeze(-1)).sum(dim=3)
     assert torch.allclose(img[..., :3], want, rtol=1e-4, atol=1e-5)
     assert torch.equal(img[..., 3], fr.occupancy)
@@ -424,3 +427,43 @@ def test_replicated_clouds_take_the_shared_geometry_path_with_identical_results(
     (img2 * g).sum().backward()
     assert torch.equal(img1, img2)
     assert (p1.grad - p2.grad).norm() <= 1e-5 * p2.grad.norm()
+
+
+def test_compact_culled_mode_reproduces_the_reference_labels_under_culling():
+    """Depth-range + back-face culling: by default culled points are masked (labels index the un-filtered cloud); with
+    ``compact_culled=True`` the rasterizer drops them first like rasterizer.py:219-254, computes h on the filtered cloud
+    (:310-326) and returns that cloud -- `fragments.idx` then equals the oracle's (which compacts the same way) integer
+    for integer, and both modes give the same image."""
+    pts, nrm = scenes.load_cloud("bunny")
+    pts = scenes.normalize_unit_sphere(pts)
+    S, K = 96, 5
+    M, V, _ = scenes.camera_matrices(2.0, 20.0, 30.0)
+    znear = 1.9                                   # cuts the front of the object away
+    keep = ((np.concatenate([pts, np.ones((len(pts), 1), np.float32)], 1) @ V[0])[:, 2] >= znear) & \
+        ((nrm @ V[0][:3, :3])[:, 2] < 0)
+    assert 0.2 < keep.mean() < 0.6
+    h = scenes.global_h(pts[keep])               # the reference runs its kNN on the FILTERED cloud
+    sc = scenes.setup_scene(pts, nrm, M, V, S, h=h, znear=znear, backface_culling=True)
+    want = oracle.splat_forward(sc["points"], sc["ellipse"], sc["cutoff"], sc["radii"], sc["first_idx"], sc["num_pts"],
+                                S, K, 0.05)
+    from dss_amd.cameras import FoVPerspectiveCameras, look_at_view_transform
+    R, T = look_at_view_transform(2.0, 20.0, 30.0)
+    cams = FoVPerspectiveCameras(R=R, T=T, znear=znear, zfar=100.0, device=DEV)
+    st = PointsRasterizationSettings(backface_culling=True, cutoff_threshold=1.0, Vrk_invariant=True, Vrk_isotropic=False,
+                                     radii_backward_scaler=5, image_size=S, points_per_pixel=K, bin_size=None)
+    col = torch.rand(len(pts), 3, device=DEV)
+    cloud = PointClouds3D([torch.from_numpy(pts).to(DEV)], [torch.from_numpy(nrm).to(DEV)], [col])
+    strict = SurfaceSplatting(cameras=cams, raster_settings=st, compact_culled=True)
+    fr, out_cloud, info = strict(cloud, verbose=True)
+    assert out_cloud.points_packed().shape[0] == int(keep.sum())
+    assert np.array_equal(out_cloud.points_packed().cpu().numpy(), pts[keep])
+    assert abs(float(strict._Vrk_h.flatten()[0]) - h) <= 1e-6 * h
+    assert np.array_equal(fr.idx.cpu().numpy(), want[0]) and np.array_equal(fr.occupancy.cpu().numpy(), want[3])
+    assert info["radii"].shape[0] == len(pts) and float(info["radii"][~torch.from_numpy(keep).to(DEV)].abs().max()) == 0
+    masked = SurfaceSplatting(cameras=cams, raster_settings=st)
+    fr_m, cloud_m = masked(cloud, Vrk_h=torch.tensor([h], device=DEV))
+    remap = torch.from_numpy(np.nonzero(keep)[0]).to(DEV)
+    assert torch.equal(torch.where(fr.idx >= 0, remap[fr.idx.clamp_min(0).long()].int(), fr.idx), fr_m.idx)
+    img_s = SurfaceSplattingRenderer(strict, None)(cloud)
+    img_m = SurfaceSplattingRenderer(masked, None)(cloud, Vrk_h=torch.tensor([h], device=DEV))
+    assert float((img_s - img_m).abs().max()) <= 1e-5 * max(1.0, float(img_m.abs().max()))
