@@ -784,6 +784,132 @@ __global__ __launch_bounds__(PREP_THREADS) void band_filter_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
+// Screen-cell order of the visible list (long lists only).  The gather of a visible point reads the image-gradient
+// window around it (~20 x 20 pixels) and the fragments of its own box; in point-id order (random on screen) every task
+// pulls its rows from HBM again: 14 GB of fetches per launch at 8 x 1M points @1024^2 for 0.7 GB of distinct data --
+// the kernel was HBM-bound on re-reads.  A counting sort by (camera, 32 x 32-pixel cell) puts tasks that share rows next
+// to each other, and the gather deals whole runs of the sorted list to the same XCD (one L2).  The order of the tasks
+// does not change any result (every task writes only its own point).
+// ---------------------------------------------------------------------------------------------
+struct CellGrid {
+    int shift;      // cell side = 1 << shift pixels
+    int cx, cy;     // cells per image row / column
+    int total;      // N * cx * cy  (<= CELL_MAX: one LDS histogram)
+};
+#define CELL_MAX 16384          // 64 KB of LDS counters
+#define CELL_THREADS 1024
+#define CELL_PER_THREAD 16      // list entries per thread: a workgroup sorts 16384 entries
+#define CELL_CHUNK (CELL_THREADS * CELL_PER_THREAD)
+static CellGrid make_cells(int N, int S)
+{
+    CellGrid c;
+    c.shift = 5;
+    for (;;) {
+        c.cx = ((S - 1) >> c.shift) + 1;
+        c.cy = c.cx;
+        c.total = N * c.cx * c.cy;
+        if (c.total <= CELL_MAX || c.shift >= 14) break;
+        ++c.shift;
+    }
+    return c;
+}
+static inline size_t cell_blocks(int64_t P) { return (size_t)((P + CELL_CHUNK - 1) / CELL_CHUNK); }
+
+// A counting sort without global atomics (they run at ~16 G/s on this part: 2 x 2.4M of them cost 0.45 ms, more than the
+// sort saves): pass 1, per workgroup a histogram of its 16384 list entries in LDS -> block_hist[block][cell]; pass 2, a
+// thread per cell walks the active blocks (running sum = each block's first position within the cell) and one workgroup
+// scans the cell totals; pass 3, every workgroup ranks its entries again in LDS and writes them to
+// cell_start[cell] + block_base[block][cell] + rank.
+__global__ __launch_bounds__(CELL_THREADS) void cell_hist_kernel(
+    const float *__restrict__ points, const int64_t *__restrict__ first_idx, const int64_t *__restrict__ num_pts, int N, int S,
+    CellGrid cg, const uint32_t *__restrict__ vis_count, const int32_t *__restrict__ vis_list,
+    uint32_t *__restrict__ cell_of, uint32_t *__restrict__ block_hist)
+{
+    extern __shared__ uint32_t s_hist[];
+    const uint32_t count = *vis_count;
+    const uint32_t b0 = blockIdx.x * (uint32_t)CELL_CHUNK;
+    if (b0 >= count) return;   // (inactive blocks: pass 2 never reads their rows)
+    for (int c = threadIdx.x; c < cg.total; c += CELL_THREADS) s_hist[c] = 0u;
+    __syncthreads();
+#pragma unroll 4
+    for (int u = 0; u < CELL_PER_THREAD; ++u) {
+        const uint32_t i = b0 + (uint32_t)u * CELL_THREADS + threadIdx.x;
+        if (i < count) {
+            const int32_t p = vis_list[i];
+            const int n = max(find_cloud(p, first_idx, num_pts, N), 0);
+            const float px = points[3 * (size_t)p], py = points[3 * (size_t)p + 1];
+            // pixel column / row of the point (any monotone map of NDC does: only neighbourhood matters)
+            const float fx = (1.0f - px) * 0.5f * (float)S, fy = (1.0f - py) * 0.5f * (float)S;
+            const int ix = min(max((int)fx, 0), S - 1) >> cg.shift, iy = min(max((int)fy, 0), S - 1) >> cg.shift;
+            const uint32_t key = (uint32_t)((n * cg.cy + iy) * cg.cx + ix);
+            cell_of[i] = key;
+            atomicAdd(&s_hist[key], 1u);
+        }
+    }
+    __syncthreads();
+    uint32_t *row = block_hist + (size_t)blockIdx.x * cg.total;
+    for (int c = threadIdx.x; c < cg.total; c += CELL_THREADS) row[c] = s_hist[c];
+}
+// thread per cell: block_hist[b][c] <- number of the cell's entries in blocks < b; cell_total[c]
+__global__ __launch_bounds__(256) void cell_block_scan_kernel(const uint32_t *__restrict__ vis_count, int total,
+                                                              uint32_t *__restrict__ block_hist,
+                                                              uint32_t *__restrict__ cell_total)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= total) return;
+    const uint32_t nb = (*vis_count + (uint32_t)CELL_CHUNK - 1u) / (uint32_t)CELL_CHUNK;
+    uint32_t run = 0;
+    for (uint32_t b = 0; b < nb; ++b) {
+        const uint32_t v = block_hist[(size_t)b * total + c];
+        block_hist[(size_t)b * total + c] = run;
+        run += v;
+    }
+    cell_total[c] = run;
+}
+// one workgroup: exclusive scan of the cell totals -> cell_start
+__global__ __launch_bounds__(1024) void cell_scan_kernel(const uint32_t *__restrict__ cell_total, uint32_t *__restrict__ cell_start,
+                                                         int total)
+{
+    __shared__ uint32_t s_part[1024];
+    const int tid = threadIdx.x;
+    const int per = (total + 1023) / 1024;
+    const int b = tid * per, e = min(b + per, total);
+    uint32_t sum = 0;
+    for (int i = b; i < e; ++i) sum += cell_total[i];
+    s_part[tid] = sum;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const uint32_t v = tid >= o ? s_part[tid - o] : 0u;
+        __syncthreads();
+        s_part[tid] += v;
+        __syncthreads();
+    }
+    uint32_t run = s_part[tid] - sum;
+    for (int i = b; i < e; ++i) {
+        cell_start[i] = run;
+        run += cell_total[i];
+    }
+}
+__global__ __launch_bounds__(CELL_THREADS) void cell_scatter_kernel(
+    CellGrid cg, const uint32_t *__restrict__ vis_count, const int32_t *__restrict__ vis_list,
+    const uint32_t *__restrict__ cell_of, const uint32_t *__restrict__ cell_start, const uint32_t *__restrict__ block_base,
+    int32_t *__restrict__ sorted)
+{
+    extern __shared__ uint32_t s_hist[];
+    const uint32_t count = *vis_count;
+    const uint32_t b0 = blockIdx.x * (uint32_t)CELL_CHUNK;
+    if (b0 >= count) return;
+    const uint32_t *base = block_base + (size_t)blockIdx.x * cg.total;
+    for (int c = threadIdx.x; c < cg.total; c += CELL_THREADS) s_hist[c] = cell_start[c] + base[c];
+    __syncthreads();
+#pragma unroll 4
+    for (int u = 0; u < CELL_PER_THREAD; ++u) {
+        const uint32_t i = b0 + (uint32_t)u * CELL_THREADS + threadIdx.x;
+        if (i < count) sorted[atomicAdd(&s_hist[cell_of[i]], 1u)] = vis_list[i];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Fused backward gather, TPW visible points per wavefront (TPW = 4, 2 or 1; 64 / TPW lanes each).
 //
 // Round 1 gave every visible point a whole wavefront with wave-uniform bookkeeping: ~840 VALU + ~570 SALU
@@ -799,6 +925,13 @@ __global__ __launch_bounds__(PREP_THREADS) void band_filter_kernel(
 // short lists (a few tasks per wavefront, latency-bound) fewer tasks with more lanes each.  Tasks stay statically
 // dealt (group q = wave, wave + n_waves, ...), ids one group ahead.
 // ---------------------------------------------------------------------------------------------
+// load from a uniform (SGPR) base + a 32-bit unsigned BYTE offset: one global_load with saddr + voffset, no 64-bit VALU
+// address arithmetic (a 64-bit index costs v_ashr + v_lshl_add_u64 per load, a 64-bit product much more)
+template <typename T>
+__device__ __forceinline__ T ld_off(const T *__restrict__ base, uint32_t byte_off)
+{
+    return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + byte_off);
+}
 template <int CTRL>
 __device__ __forceinline__ float row_add(float v) { return v + dpp_f32<CTRL>(v); }
 // sum over the 16 lanes of a DPP row, left in every lane of the row (fixed order: deterministic)
@@ -833,7 +966,7 @@ __device__ __forceinline__ int tasks_max(int v)
     return m;
 }
 
-template <int C, bool SEG, int TPW>
+template <int C, bool SEG, int TPW, bool A32>
 __global__ __launch_bounds__(256) void render_backward_kernel(
     const float *__restrict__ grad_out, const float *__restrict__ grad_alpha /* dense (N,rows,S) */,
     const int32_t *__restrict__ idx, const float *__restrict__ qv,
@@ -869,10 +1002,30 @@ __global__ __launch_bounds__(256) void render_backward_kernel(
     }
     const uint32_t n_groups = (count + TPW - 1u) / TPW;
     // long lists use 6 workgroups per CU: more resident gathers only evict each other's image rows from L2
-    if (n_groups > 8u * n_waves) n_waves = min(n_waves, large_waves);
+    const bool long_list = n_groups > 8u * n_waves;
+    if (long_list) n_waves = min(n_waves, large_waves);
     if (wave >= n_waves) return;
-    const uint32_t wave_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave);
+    // Dealing of the groups.  Short lists: group t -> wave t mod n_waves.  Long lists are in screen-cell order (see
+    // cell_count_kernel): runs of CH consecutive groups -- about one cell -- go to ONE XCD (blocks are dispatched to the
+    // XCDs round robin), so that the rows a cell's tasks share are fetched into one L2 instead of eight.
+#ifndef DSS_EXP_CHUNK
+#define DSS_EXP_CHUNK 64u
+#endif
+    constexpr uint32_t CH = DSS_EXP_CHUNK;
+    const bool chunked = !SEG && long_list && CH > 0u && (n_waves >> 2) >= 8u;
+    const uint32_t xcd = blockIdx.x & 7u;
+    uint32_t t_stride = n_waves, t0 = wave;
+    if (chunked) {
+        const uint32_t blocks_eff = n_waves >> 2;
+        t_stride = ((blocks_eff - xcd + 7u) >> 3) * 4u;     // waves of this XCD
+        t0 = (blockIdx.x >> 3) * 4u + (threadIdx.x >> 6);
+    }
+    auto qof = [&](uint32_t t) -> uint32_t {
+        return chunked ? ((t / max(CH, 1u)) * 8u + xcd) * CH + (t % max(CH, 1u)) : t;
+    };
+    const uint32_t wave_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)qof(t0));
     if (wave_u >= n_groups) return;
+    uint32_t t_cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)t0);
 
     // point id of this lane's task in group q (-1 beyond the list); uniform within the task's lanes
     auto task_ids = [&](uint32_t q) -> int {
@@ -900,9 +1053,10 @@ __global__ __launch_bounds__(256) void render_backward_kernel(
     const NdcMap ndc(S);
     const size_t plane = (size_t)rows * S;
     int p_nx = task_ids(wave_u);
-    for (uint32_t q = wave_u;; ) {
+    for (;;) {
         const int p = p_nx;
-        const uint32_t q_next = q + n_waves;
+        const uint32_t t_next = t_cur + t_stride;
+        const uint32_t q_next = qof(t_next);
         const bool more = q_next < n_groups;
         if (more) p_nx = task_ids(q_next);  // in flight during this group
         // ---- record + cloud of the task's point ------------------------------------------------------------
@@ -959,6 +1113,22 @@ __global__ __launch_bounds__(256) void render_backward_kernel(
             const float y_step = (float)(2 * RP) * ndc.invS;          // distance of two consecutive rows of a lane row
             for (int ib = 0; ib < nrow; ib += RB) {
                 float g0[RB], g1[RB];
+                if (A32) {
+                    // unconditional loads from clamped (always valid) addresses, masked afterwards: no exec-mask branch
+                    // around every load, 32-bit byte offsets from the tensor base
+                    const uint32_t S4 = (uint32_t)S * 4u;
+                    const uint32_t w0 = ((uint32_t)nn * (uint32_t)plane + (uint32_t)(o_ok ? i0 : 0)) * 4u;
+                    const uint32_t w1 = ((uint32_t)nn * (uint32_t)plane + (uint32_t)(o_ok ? i1 : 0)) * 4u;
+#pragma unroll
+                    for (int u = 0; u < RB; ++u) {
+                        const int i = rp + RP * (ib + u);   // window row of this lane row
+                        const bool r_ok = i < oh;
+                        const uint32_t back = __umul24((uint32_t)(r_ok ? i : 0), S4);
+                        const float a0 = ld_off(grad_alpha, w0 - back), a1 = ld_off(grad_alpha, w1 - back);
+                        g0[u] = (r_ok && c0) ? a0 : 0.0f;
+                        g1[u] = (r_ok && c1) ? a1 : 0.0f;
+                    }
+                } else {
 #pragma unroll
                 for (int u = 0; u < RB; ++u) {
                     const int i = rp + RP * (ib + u);   // window row of this lane row
@@ -967,6 +1137,7 @@ __global__ __launch_bounds__(256) void render_backward_kernel(
                     g1[u] = 0.0f;
                     if (r_ok && c0) g0[u] = gimg[i0 - i * S];
                     if (r_ok && c1) g1[u] = gimg[i1 - i * S];
+                }
                 }
                 const float y_ib = ndc(ylo + rp + RP * ib);
                 auto consume = [&](auto pow2_tag) {
@@ -1019,6 +1190,39 @@ __global__ __launch_bounds__(256) void render_backward_kernel(
                 const int pty_i = (int)(((float)pi_ + 0.5f) * inv_ptx);   // pi_ / ptx (exact: small integers)
                 const int ptx_i = pi_ - pty_i * ptx;
                 const int xi = bxlo + 4 * ptx_i + (l & 3), yi = bylo + 4 * pty_i + (l >> 2);
+                if (A32 && K <= KF && wsum != nullptr) {
+                    // 32-bit byte offsets from the tensor bases, unconditional loads from pixel 0 of the camera for the
+                    // lanes outside the box (masked by `on` below)
+                    const bool on = !(pi_ >= ptx * pty || xi > bxhi || yi > byhi);
+                    const uint32_t pix32 = on ? ((uint32_t)nn * (uint32_t)rows + (uint32_t)(S - 1 - yi - row0)) * (uint32_t)S +
+                                                    (uint32_t)(S - 1 - xi)
+                                              : (uint32_t)nn * (uint32_t)plane;
+                    const uint32_t oK = pix32 * (uint32_t)K * 4u, oC = pix32 * (uint32_t)(Cn + 1) * 4u;
+                    int32_t vi[KF];
+                    float qk[KF];
+#pragma unroll
+                    for (int k = 0; k < KF; ++k) {
+                        vi[k] = -1; qk[k] = 0.0f;
+                        if (k < K) { vi[k] = ld_off(idx, oK + 4u * k); qk[k] = ld_off(qv, oK + 4u * k); }
+                    }
+                    const float cum32 = ld_off(wsum, pix32 * 4u);
+                    float g32[CM];
+#pragma unroll
+                    for (int ch = 0; ch < CM; ++ch) g32[ch] = (ch < Cn) ? ld_off(grad_out, oC + 4u * ch) : 0.0f;
+                    float q32 = 0.0f;
+                    bool f32_ = false;
+#pragma unroll
+                    for (int k = 0; k < KF; ++k) {
+                        const bool hit = (k < K) && vi[k] == (int32_t)p;
+                        q32 = hit ? qk[k] : q32;
+                        f32_ = f32_ || hit;
+                    }
+                    const float wn32 = (f32_ && on) ? ewa_weight(q32, sc) * fast_rcp(cum32) : 0.0f;
+#pragma unroll
+                    for (int ch = 0; ch < CM; ++ch)
+                        if (ch < Cn) acc[ch] = fmaf(g32[ch], wn32, acc[ch]);
+                    continue;
+                }
                 if (pi_ >= ptx * pty || xi > bxhi || yi > byhi) continue;
                 const size_t pix = ((size_t)nn * rows + (S - 1 - yi - row0)) * S + (S - 1 - xi);
                 const int32_t *pi = idx + pix * K;
@@ -1089,7 +1293,7 @@ __global__ __launch_bounds__(256) void render_backward_kernel(
             }
         }
         if (!more) break;
-        q = q_next;
+        t_cur = t_next;
     }
 }
 
@@ -1326,10 +1530,15 @@ extern "C" size_t dss_render_backward_workspace(int N, int64_t P, int S)
 {
     const size_t n = N > 0 ? N : 1, s = S > 0 ? S : 1;
     if (P <= PREP_MAX_POINTS) return prep_layout(N, P, S).bytes;
+    const size_t cells = (size_t)make_cells(N > 0 ? N : 1, S > 0 ? S : 1).total;
+    const size_t p1 = (size_t)(P > 0 ? P : 1);
     return align_up((size_t)3 * n * MED_BINS * 4 + 256, 256)  // histograms + visible counter
-           + align_up((size_t)(P > 0 ? P : 1) * 4, 256)       // compacted visible list
+           + align_up(p1 * 4, 256)                            // compacted visible list
            + align_up(n * 4, 256)                             // rs
-           + align_up(n * s * s * 4, 256);                    // dense alpha-gradient plane
+           + align_up(n * s * s * 4, 256)                     // dense alpha-gradient plane
+           + 2 * align_up(p1 * 4, 256)                        // cell of every list entry, cell-ordered list
+           + 2 * align_up(cells * 4, 256)                     // entries per cell, first list position of every cell
+           + align_up(cell_blocks(P) * cells * 4, 256);       // per sort block: entries of every cell in earlier blocks
 }
 
 static int render_backward_impl(bool run_prep, const float *grad_out, const int32_t *idx, const float *qvalue, const float *wsum,
@@ -1385,6 +1594,7 @@ static int render_backward_impl(bool run_prep, const float *grad_out, const int3
         }
     } else {
         const size_t hist_bytes = (size_t)3 * N * MED_BINS * 4;
+        const CellGrid cg = make_cells(N, S);
         uint32_t *hist = reinterpret_cast<uint32_t *>(w);
         vis_count = reinterpret_cast<uint32_t *>(w + hist_bytes);
         size_t off = align_up(hist_bytes + 256, 256);
@@ -1394,18 +1604,43 @@ static int render_backward_impl(bool run_prep, const float *grad_out, const int3
         off += align_up((size_t)N * 4, 256);
         float *plane = reinterpret_cast<float *>(w + off);
         alpha = plane;
+        off += align_up((size_t)N * S * S * 4, 256);
+        uint32_t *cell_of = reinterpret_cast<uint32_t *>(w + off);
+        off += align_up((size_t)P * 4, 256);
+        int32_t *sorted = reinterpret_cast<int32_t *>(w + off);
+        off += align_up((size_t)P * 4, 256);
+        uint32_t *cell_start = reinterpret_cast<uint32_t *>(w + off);
+        off += align_up((size_t)cg.total * 4, 256);
+        uint32_t *cell_total = reinterpret_cast<uint32_t *>(w + off);
+        off += align_up((size_t)cg.total * 4, 256);
+        uint32_t *block_hist = reinterpret_cast<uint32_t *>(w + off);
+        int32_t *unsorted = vis_list;
+#ifndef DSS_EXP_NO_CELLSORT
+        vis_list = sorted;
+#endif
         if (run_prep) {
         hipLaunchKernelGGL(alpha_plane_kernel, dim3((unsigned)((npix + ALPHA_PIX_PER_WG - 1) / ALPHA_PIX_PER_WG)), dim3(1024),
                            0, st, grad_out, plane, npix, C);
         if (hipMemsetAsync(hist, 0, hist_bytes + 256, st) != hipSuccess) return check_launch("memset render_backward");
         const unsigned blocks = (unsigned)((P + MED_PTS_PER_WG - 1) / MED_PTS_PER_WG);
         hipLaunchKernelGGL(visible_scan_kernel, dim3(blocks), dim3(MED_THREADS), 0, st, radii, visible, first_idx,
-                           num_pts, N, P, hist, vis_count, vis_list, grad_pts, grad_feat, C);
+                           num_pts, N, P, hist, vis_count, unsorted, grad_pts, grad_feat, C);
         hipLaunchKernelGGL(median_hist_kernel<1>, dim3(blocks), dim3(MED_THREADS), 0, st, radii, visible, first_idx,
                            num_pts, N, P, hist);
         hipLaunchKernelGGL(median_hist_kernel<2>, dim3(blocks), dim3(MED_THREADS), 0, st, radii, visible, first_idx,
                            num_pts, N, P, hist);
         hipLaunchKernelGGL(median_final_kernel, dim3(N), dim3(MED_THREADS), 0, st, hist, N, radii_s, rs);
+#ifndef DSS_EXP_NO_CELLSORT
+        const unsigned cb = (unsigned)cell_blocks(P);   // (the visible count is only known on the device: P bounds it)
+        const size_t lds = (size_t)cg.total * 4;
+        hipLaunchKernelGGL(cell_hist_kernel, dim3(cb), dim3(CELL_THREADS), lds, st, points, first_idx, num_pts, N, S, cg,
+                           vis_count, unsorted, cell_of, block_hist);
+        hipLaunchKernelGGL(cell_block_scan_kernel, dim3((unsigned)((cg.total + 255) / 256)), dim3(256), 0, st, vis_count,
+                           cg.total, block_hist, cell_total);
+        hipLaunchKernelGGL(cell_scan_kernel, dim3(1), dim3(1024), 0, st, cell_total, cell_start, cg.total);
+        hipLaunchKernelGGL(cell_scatter_kernel, dim3(cb), dim3(CELL_THREADS), lds, st, cg, vis_count, unsorted, cell_of,
+                           cell_start, block_hist, sorted);
+#endif
         }
     }
     // persistent grid = exactly the resident capacity of the chip for this kernel (a larger grid would
@@ -1418,16 +1653,19 @@ static int render_backward_impl(bool run_prep, const float *grad_out, const int3
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
             cus = prop.multiProcessorCount;
         if (C == 3)
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_backward_kernel<3, true, 4>, 256, 0);
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_backward_kernel<3, true, 4, true>, 256, 0);
         else
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_backward_kernel<0, true, 4>, 256, 0);
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_backward_kernel<0, true, 4, true>, 256, 0);
         if (per_cu < 1) per_cu = 1;
         n_cus = cus;
         cap = cus * per_cu;
         (void)hipGetLastError();
     }
     const unsigned pgrid = (unsigned)((P + 3) / 4 < cap ? (P + 3) / 4 : cap);
-    const uint32_t large_waves = 6u * (uint32_t)n_cus * 4u;
+#ifndef DSS_EXP_LARGE_WG
+#define DSS_EXP_LARGE_WG 6u
+#endif
+    const uint32_t large_waves = DSS_EXP_LARGE_WG * (uint32_t)n_cus * 4u;
     // tasks per wavefront: four when the list is long enough to keep every resident wavefront busy with whole groups
     // (throughput-bound), fewer -- more lanes per task, shorter dependent chains -- for short lists.  The visible count is
     // only known on the device; P bounds it and the visible fraction of a rendered cloud is 30-60 %.
@@ -1439,13 +1677,25 @@ static int render_backward_impl(bool run_prep, const float *grad_out, const int3
     const long long est_tasks = (long long)P * 2 / 5;
     int tpw = est_tasks >= 16ll * cap * 4 ? 4 : (est_tasks >= 4ll * cap * 4 ? 2 : 1);
     if (tpw_env == 1 || tpw_env == 2 || tpw_env == 4) tpw = tpw_env;
-#define DSS_LAUNCH_RB(CC, SS, TT)                                                                                      \
-    hipLaunchKernelGGL((render_backward_kernel<CC, SS, TT>), dim3(pgrid), dim3(256), 0, st, grad_out, alpha, idx, qvalue, wsum, \
+#define DSS_LAUNCH_RB_A(CC, SS, TT, AA)                                                                                 \
+    hipLaunchKernelGGL((render_backward_kernel<CC, SS, TT, AA>), dim3(pgrid), dim3(256), 0, st, grad_out, alpha, idx, qvalue, wsum, \
                        scaler, points, radii, rs, first_idx, num_pts, vis_count, vis_list, n_seg, seg_pts, N, S, K, C, clip, \
                        row0, row1 - row0, large_waves, grad_feat, grad_pts)
+    // 32-bit byte offsets from the tensor bases (one VALU per gather address instead of 64-bit index arithmetic) whenever
+    // every gathered tensor is smaller than 4 GB; larger problems take the 64-bit addressing, four tasks per wavefront
+    const unsigned long long widest = (unsigned long long)N * (unsigned long long)(row1 - row0) * (unsigned long long)S *
+                                      (unsigned long long)(K > C + 1 ? K : C + 1) * 4ull;
+#ifdef DSS_EXP_NO_A32
+    const bool a32 = false;
+#else
+    const bool a32 = widest < (1ull << 32);
+#endif
+    if (!a32) tpw = 4;
+#define DSS_LAUNCH_RB(CC, SS, TT) DSS_LAUNCH_RB_A(CC, SS, TT, true)
 #define DSS_LAUNCH_RB_T(CC, SS)                                                                                        \
     do {                                                                                                               \
-        if (tpw == 4) DSS_LAUNCH_RB(CC, SS, 4); else if (tpw == 2) DSS_LAUNCH_RB(CC, SS, 2); else DSS_LAUNCH_RB(CC, SS, 1); \
+        if (!a32) DSS_LAUNCH_RB_A(CC, SS, 4, false);                                                                   \
+        else if (tpw == 4) DSS_LAUNCH_RB(CC, SS, 4); else if (tpw == 2) DSS_LAUNCH_RB(CC, SS, 2); else DSS_LAUNCH_RB(CC, SS, 1); \
     } while (0)
     if (C == 3) {
         if (small) DSS_LAUNCH_RB_T(3, true); else DSS_LAUNCH_RB_T(3, false);
@@ -1454,6 +1704,7 @@ static int render_backward_impl(bool run_prep, const float *grad_out, const int3
     }
 #undef DSS_LAUNCH_RB_T
 #undef DSS_LAUNCH_RB
+#undef DSS_LAUNCH_RB_A
     return check_launch("dss_render_backward");
 }
 

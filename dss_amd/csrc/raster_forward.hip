@@ -1390,9 +1390,10 @@ extern "C" int dss_render_forward(const float *world, const float *normals, cons
     SA.cutoff = cutoff; SA.valid = valid; SA.rec = packed ? w.rec : nullptr; SA.feat = feat;
     // one wave per workgroup: at DSS sizes (tens of thousands of points) 256-thread groups would occupy only
     // half of the CUs with one wave per SIMD, and this kernel is a chain of dependent latencies
-    const int pb = (int)((P + 63) / 64);
+    const int tb = 64;   // (64 / 128 / 256 threads measure the same at 8 x 1M and 4M points: not dispatch-bound there either)
+    const int pb = (int)((P + tb - 1) / tb);
     if (!rerun) {
-        hipLaunchKernelGGL(setup_bin_kernel, dim3(pb), dim3(64), 0, st, SA, g, w.counts, w.lists, w.cap, w.queue, w.spill,
+        hipLaunchKernelGGL(setup_bin_kernel, dim3(pb), dim3(tb), 0, st, SA, g, w.counts, w.lists, w.cap, w.queue, w.spill,
                            visible);
 #ifndef DSS_EXP_NOSPILL
         hipLaunchKernelGGL(spill_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, pts_screen, radii, first_idx,
