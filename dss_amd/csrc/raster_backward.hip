@@ -802,8 +802,11 @@ struct CellGrid {
 #define CELL_CHUNK (CELL_THREADS * CELL_PER_THREAD)
 static CellGrid make_cells(int N, int S)
 {
+#ifndef DSS_EXP_CELL_SHIFT
+#define DSS_EXP_CELL_SHIFT 5
+#endif
     CellGrid c;
-    c.shift = 5;
+    c.shift = DSS_EXP_CELL_SHIFT;
     for (;;) {
         c.cx = ((S - 1) >> c.shift) + 1;
         c.cy = c.cx;
