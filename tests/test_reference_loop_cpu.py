@@ -56,7 +56,7 @@ def _run(args, timeout):
                           timeout=timeout, text=True)
 
 
-@pytest.mark.timeout(900)
+@pytest.mark.timeout(1800)
 def test_reference_train_mvr_runs_unmodified_on_the_drop_in_and_its_loss_decreases(tmp_path):
     tmp = str(tmp_path)
     cfg = _config(tmp, 192)   # (at 64^2 the splats and the backward radius rs = 5 x median radius are a quarter of the object:
@@ -66,15 +66,23 @@ def test_reference_train_mvr_runs_unmodified_on_the_drop_in_and_its_loss_decreas
               "--views", "16", "--target-points", "3000"], 300)
     assert r.returncode == 0, r.stdout[-3000:]
     assert len(os.listdir(os.path.join(tmp, "data", "image"))) == 16
-    r = _run(["--config", cfg, "--scalars", scalars, "--no-cuda", "--exit-after", "80"], 600)
-    # train_mvr.py:219-228 leaves through exit(3) when its time limit is reached -- after saving model.pt it joins
-    # `trainer._threads`, an attribute only `Trainer.debug` creates (trainer.py:461): without a debug visualisation
-    # (debug_every: 0 here, it needs plotly / trimesh) the unmodified script ends on that AttributeError instead
-    reached_time_limit = r.returncode == 3 or (r.returncode == 1 and "no attribute '_threads'" in r.stdout)
-    assert reached_time_limit, r.stdout[-4000:]
-    loss = [json.loads(l) for l in open(scalars)]
-    loss = [d["value"] for d in loss if d["tag"] == "train/loss"]
-    assert len(loss) >= 100, (len(loss), r.stdout[-2000:])
+    # train_mvr.py stops on a wall-clock limit, not an iteration count: run legs of 60 s (it resumes from its own model.pt,
+    # train_mvr.py:98-103) until 450 iterations are in, so that a slow or busy machine does not decide the outcome
+    loss, legs = [], 0
+    while len(loss) < 450 and legs < 4:
+        legs += 1
+        r = _run(["--config", cfg, "--scalars", scalars, "--no-cuda", "--exit-after", "60"], 400)
+        # train_mvr.py:219-228 leaves through exit(3) when its time limit is reached -- after saving model.pt it joins
+        # `trainer._threads`, an attribute only `Trainer.debug` creates (trainer.py:461): without a debug visualisation
+        # (debug_every: 0 here, it needs plotly / trimesh) the unmodified script ends on that AttributeError instead
+        reached_time_limit = r.returncode == 3 or (r.returncode == 1 and "no attribute '_threads'" in r.stdout)
+        assert reached_time_limit, r.stdout[-4000:]
+        assert os.path.isfile(os.path.join(tmp, "exp", "dropin", "model.pt"))  # the reference's CheckpointIO wrote it
+        loss = [json.loads(l) for l in open(scalars)]
+        steps = [d["step"] for d in loss if d["tag"] == "train/loss"]
+        loss = [d["value"] for d in loss if d["tag"] == "train/loss"]
+        assert steps == sorted(steps) and len(set(steps)) == len(steps), "a resumed leg continues the iteration count"
+    assert len(loss) >= 300, (len(loss), legs, r.stdout[-2000:])
     # the surrogate gradient first inflates the sphere's silhouette for ~150 iterations, then the loss falls: 0.46 -> 0.34
     # after ~450 iterations, 0.21 after 1200 (6-10 iterations per second here, depending on the load of the machine)
     deciles = [sum(loss[i * len(loss) // 10:(i + 1) * len(loss) // 10]) / max(1, (i + 1) * len(loss) // 10 - i * len(loss) // 10)
