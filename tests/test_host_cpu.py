@@ -207,3 +207,17 @@ def test_camera_sampler_draws_the_reference_cameras_for_the_same_seed():
         assert float(cams[0].znear[0]) == pytest.approx(0.1)
         if sort:
             assert (s.distances[:-1] >= s.distances[1:]).all()
+
+
+def test_spatial_order_is_a_permutation_that_groups_neighbours():
+    from dss_amd.cloud import spatial_order
+    g = torch.Generator().manual_seed(0)
+    pts = torch.rand((5000, 3), generator=g)
+    order = spatial_order(pts)
+    assert order.dtype == torch.int64 and torch.equal(torch.sort(order).values, torch.arange(5000))
+    step_sorted = (pts[order][1:] - pts[order][:-1]).norm(dim=1).mean()
+    step_random = (pts[1:] - pts[:-1]).norm(dim=1).mean()
+    assert float(step_sorted) < 0.2 * float(step_random)          # consecutive points are spatial neighbours
+    assert spatial_order(torch.zeros(0, 3)).numel() == 0 and spatial_order(torch.ones(7, 3)).tolist() == list(range(7))
+    with pytest.raises(ValueError):
+        spatial_order(torch.zeros(4, 2))

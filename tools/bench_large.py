@@ -22,6 +22,11 @@ P, S, N = {"cfg4": (1_000_000, 1024, 8), "cfg5": (4_000_000, 2048, 1), "cfg3": (
 pts, nrm, col = scenes.synthetic_cloud(P, seed=0)
 h = scenes.global_h(pts[:: max(1, P // 200_000)]) * (200_000 / P if P > 200_000 else 1.0)  # density-scaled estimate
 h = float(np.clip(h, 5e-6, 1e-3))
+if os.environ.get("DSS_BENCH_MORTON") == "1":
+    # spatially coherent point order (what a scanned or mesh-sampled cloud usually has; dss_amd.cloud.spatial_order)
+    from dss_amd.cloud import spatial_order
+    order = spatial_order(torch.from_numpy(pts)).numpy()
+    pts, nrm, col = pts[order].copy(), nrm[order].copy(), col[order].copy()
 dev = torch.device("cuda:0")
 wl = bench.Workload(dev, N, bench.RowPartition(S, 1, 0), cloud=(pts, nrm, col, h))
 for _ in range(3):
@@ -38,7 +43,7 @@ K = bench.K
 alg = wl.N * S * S * (12 * K + 4 + 16 + 4) + wl.P * 52
 out = wl.step()
 img = out[0]
-rec = {"config": which, "points_per_cloud": P, "cameras": N, "image_size": S, "ms_per_step_eager": round(ms, 4),
+rec = {"config": which, "point_order": "morton" if os.environ.get("DSS_BENCH_MORTON") == "1" else "random", "points_per_cloud": P, "cameras": N, "image_size": S, "ms_per_step_eager": round(ms, 4),
        "Msplats_per_s": round(wl.P / ms / 1e3, 2), "fine_kernel_ms": round(fine_mean, 4),
        "fine_algorithmic_bytes": alg, "fine_GBps": round(alg / fine_mean / 1e6, 1),
        "fine_frac_of_8TBps": round(alg / fine_mean / 1e6 / 8000, 4), "occupancy_mean": round(float(img[..., 3].mean()), 4), "h": h}
