@@ -71,6 +71,13 @@ def _install_stand_ins(log_path):
         np.float = float
     if not hasattr(np, "int"):
         np.int = int
+    # `mask[mask] = values` (rasterizer.py:641) indexed a tensor with itself: legal in the torch the reference was written
+    # for, refused by current torch ("input tensor and written-to tensor refer to a single memory location")
+    _setitem = torch.Tensor.__setitem__
+
+    def _setitem_self_index(self, idx, val):
+        return _setitem(self, idx.clone() if idx is self else idx, val)
+    torch.Tensor.__setitem__ = _setitem_self_index
     six = types.ModuleType("torch._six")
     six.string_classes = (str, bytes)
     six.int_classes = (int,)
@@ -172,16 +179,72 @@ def make_dataset(args):
     print("dataset:", out, "views", args.views, "coverage", float((rgba[..., 3] > 0).mean()))
 
 
+def check_c_seam(args):
+    """The reference's OWN rasterizer + renderer classes (DSS/core/rasterizer.py, renderer.py, unmodified) on top of
+    `DSS._C = dss_amd.ops` -- the seven same-name mirrors of the compiled extension (ext.cpp:5-18) -- against the
+    drop-in classes on the same cloud and cameras.  Forward only: the reference's backward needs FRNN / prefix_sum."""
+    import numpy as np
+    import torch
+    from dss_amd import ops
+    import DSS
+    DSS._C = ops
+    sys.modules["DSS._C"] = ops
+    import DSS.core.rasterizer as R           # `from .. import _C` now resolves to the mirror
+    from DSS.core.renderer import SurfaceSplattingRenderer as RefRenderer
+    from DSS.core.cloud import PointClouds3D
+    from pytorch3d.renderer import FoVPerspectiveCameras, NormWeightedCompositor, look_at_view_transform
+    import dss_amd.rasterizer as ours_r
+    import dss_amd.renderer as ours_rr
+    dev = torch.device("cpu" if args.no_cuda or not torch.cuda.is_available() else "cuda")
+    z = np.load(os.path.join(ROOT, "tests", "golden", "clouds.npz"))
+    pts, nrm = z["bunny_points"].astype(np.float32), z["bunny_normals"].astype(np.float32)
+    pts = pts - 0.5 * (pts.max(0) + pts.min(0))
+    pts = pts / np.linalg.norm(pts, axis=1).max()
+    nrm = nrm / np.linalg.norm(nrm, axis=1, keepdims=True)
+    pts, nrm = pts[::2].copy(), nrm[::2].copy()
+    g = torch.Generator().manual_seed(0)
+    col = torch.rand((1, len(pts), 3), generator=g).to(dev)
+    cloud = PointClouds3D(torch.from_numpy(pts)[None].to(dev), torch.from_numpy(nrm)[None].to(dev), col)
+    Rm, T = look_at_view_transform((2.0, 2.3), (20.0, -15.0), (30.0, 210.0))
+    # cameras the way DSS builds them: one camera object whose R / T are then replaced by the batch's
+    # (dataset.py:155-165, trainer.py:264-265) -- znear / zfar stay (1,), which rasterizer.py:190-192 relies on
+    cams = FoVPerspectiveCameras(znear=0.1, zfar=100.0, device=dev)
+    cams.R, cams.T = Rm.to(dev), T.to(dev)
+    cams._N = cams.R.shape[0]
+    kw = dict(backface_culling=False, Vrk_invariant=True, Vrk_isotropic=False, cutoff_threshold=1.0,
+              depth_merging_threshold=0.05, image_size=96, points_per_pixel=5, radii_backward_scaler=5, clip_pts_grad=0.05)
+    ref_ras = R.SurfaceSplatting(cameras=cams, raster_settings=R.PointsRasterizationSettings(**kw), frnn_radius=-1)
+    our_ras = ours_r.SurfaceSplatting(cameras=cams, raster_settings=ours_r.PointsRasterizationSettings(**kw))
+    with torch.no_grad():
+        f_ref, pc_ref = ref_ras(cloud)
+        f_our, pc_our = our_ras(cloud)
+        img_ref = RefRenderer(ref_ras, NormWeightedCompositor())(cloud)
+        img_our = ours_rr.SurfaceSplattingRenderer(our_ras, ours_rr.NormWeightedCompositor())(cloud)
+    same = (f_ref.idx == f_our.idx)
+    hit = (f_ref.idx >= 0) & (f_our.idx >= 0) & same
+    out = {"idx_equal_fraction": float(same.float().mean()), "fragments": int((f_ref.idx >= 0).sum()),
+           "occupancy_equal_fraction": float((f_ref.occupancy == f_our.occupancy).float().mean()),
+           "qvalue_max_abs_diff_on_equal": float((f_ref.qvalue - f_our.qvalue)[hit].abs().max()),
+           "zbuf_max_abs_diff_on_equal": float((f_ref.zbuf - f_our.zbuf)[hit].abs().max()),
+           "scaler_rel_max_diff_on_equal": float(((f_ref.scaler - f_our.scaler)[hit].abs() /
+                                                  f_ref.scaler[hit].abs().clamp_min(1e-12)).max()),
+           "image_max_abs_diff": float((img_ref - img_our).abs().max()), "image_mean_abs_diff": float((img_ref - img_our).abs().mean()),
+           "same_cloud_returned": bool(torch.equal(pc_ref.points_packed(), pc_our.points_packed())),
+           "coverage": float((f_ref.occupancy > 0).float().mean())}
+    print("C_SEAM " + json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--check-c-seam", action="store_true", help="run the reference's own rasterizer classes on DSS._C = dss_amd.ops")
     ap.add_argument("--make-dataset", default=None, help="write a synthetic MVR dataset here instead of training")
     ap.add_argument("--views", type=int, default=16)
     ap.add_argument("--target-points", type=int, default=0)
     ap.add_argument("--reference", default="/root/reference")
-    ap.add_argument("--config", required=True)
+    ap.add_argument("--config", default=None)
     ap.add_argument("--exit-after", type=int, default=20)
     ap.add_argument("--no-cuda", action="store_true")
-    ap.add_argument("--scalars", required=True, help="JSON-lines file the SummaryWriter stand-in appends to")
+    ap.add_argument("--scalars", default=os.devnull, help="JSON-lines file the SummaryWriter stand-in appends to")
     args = ap.parse_args()
     for p in (os.path.join(ROOT, "compat"), ROOT, os.path.join(ROOT, "tests"), args.reference):
         if p not in sys.path:
@@ -194,6 +257,8 @@ def main():
         import oracle_ops
         oracle_ops.install(ops)
     os.chdir(args.reference)
+    if args.check_c_seam:
+        return check_c_seam(args)
     if args.make_dataset:
         return make_dataset(args)
     sys.argv = ["train_mvr.py", "--config", args.config, "--exit-after", str(args.exit_after)] + \

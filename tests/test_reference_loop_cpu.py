@@ -89,3 +89,18 @@ def test_reference_train_mvr_runs_unmodified_on_the_drop_in_and_its_loss_decreas
                for i in range(10)]
     assert deciles[-1] < deciles[0] and deciles[-1] <= 0.92 * max(deciles), deciles
     assert os.path.isfile(os.path.join(tmp, "exp", "dropin", "model.pt"))  # the reference's CheckpointIO wrote it
+
+
+def test_reference_rasterizer_classes_run_on_the_c_level_drop_in():
+    """One seam lower: the reference's OWN `DSS.core.rasterizer.SurfaceSplatting` / `EllipticalRasterizer` /
+    `DSS.core.renderer.SurfaceSplattingRenderer` (unmodified) with `DSS._C = dss_amd.ops` -- the same-name mirrors of
+    the compiled extension (ext.cpp:5-18) -- against the drop-in classes: same fragments, same
+    image.  Forward only (the reference's backward builds an FRNN grid first)."""
+    r = _run(["--check-c-seam", "--no-cuda"], 300)
+    line = [l for l in r.stdout.splitlines() if l.startswith("C_SEAM ")]
+    assert r.returncode == 0 and line, r.stdout[-3000:]
+    d = json.loads(line[-1][len("C_SEAM "):])
+    assert d["fragments"] > 10000 and 0.1 < d["coverage"] < 0.5
+    assert d["idx_equal_fraction"] >= 0.9995 and d["occupancy_equal_fraction"] >= 0.9995   # observed: 1.0 and 1.0
+    assert d["qvalue_max_abs_diff_on_equal"] <= 1e-3 and d["zbuf_max_abs_diff_on_equal"] <= 1e-5
+    assert d["scaler_rel_max_diff_on_equal"] <= 1e-3 and d["image_max_abs_diff"] <= 1e-4 and d["same_cloud_returned"]
