@@ -220,6 +220,51 @@ def check_c_seam(args):
         f_our, pc_our = our_ras(cloud)
         img_ref = RefRenderer(ref_ras, NormWeightedCompositor())(cloud)
         img_our = ours_rr.SurfaceSplattingRenderer(our_ras, ours_rr.NormWeightedCompositor())(cloud)
+    # ---- backward: the reference's whole EllipticalRasterizer.backward (rasterizer.py:787-977) with
+    # _C._splat_points_occ_fast_cuda_backward / _C._backward_zbuf = the mirrors.  Its FRNN grid build needs lxxue/FRNN and
+    # lxxue/prefix_sum (absent): stand-ins of their published behaviour (2-D cell = floor((p - min) * delta), linear id
+    # x * res_y + y, slot = arrival order; exclusive scan; counting sort) -- the mirror ignores the grid anyway.
+    def insert_points(pts2d, lengths, grid_params, cnt, cell, slot, G):
+        for n in range(pts2d.shape[0]):
+            L = int(lengths[n])
+            gp = grid_params[n].cpu()
+            g = torch.floor((pts2d[n, :L].cpu() - gp[0:2][None]) * gp[2]).long()
+            g = torch.minimum(g.clamp_min(0), (gp[3:5].long() - 1)[None])
+            c = g[:, 0] * int(gp[4]) + g[:, 1]
+            counts = torch.zeros(G, dtype=torch.int64)
+            s_ = torch.empty(L, dtype=torch.int64)
+            for i, ci in enumerate(c.tolist()):
+                s_[i] = counts[ci]
+                counts[ci] += 1
+            cnt[n] = counts.int().to(cnt.device)
+            cell[n, :L] = c.int().to(cell.device)
+            slot[n, :L] = s_.int().to(slot.device)
+
+    def prefix_sum_cuda(counts, total, out):
+        t = int(total)
+        c = counts[:t].long()
+        out[:t] = (torch.cumsum(c, 0) - c).to(out.dtype)
+
+    def counting_sort(pts2d, lengths, cell, slot, off, sorted_pts, sorted_idx):
+        for n in range(pts2d.shape[0]):
+            L = int(lengths[n])
+            dst = (off[n][cell[n, :L].long()] + slot[n, :L]).long()
+            sorted_pts[n, dst] = pts2d[n, :L]
+            sorted_idx[n, dst] = torch.arange(L, dtype=sorted_idx.dtype, device=sorted_idx.device)
+    R.frnn._C = types.SimpleNamespace(insert_points_cuda=insert_points, counting_sort_cuda=counting_sort)
+    import prefix_sum
+    prefix_sum.prefix_sum_cuda = prefix_sum_cuda
+    gimg = torch.randn((2, 96, 96, 4), generator=torch.Generator().manual_seed(3)).to(dev)
+
+    def grads(renderer):
+        P3 = torch.from_numpy(pts)[None].to(dev).requires_grad_(True)
+        C3 = col.clone().requires_grad_(True)
+        img = renderer(PointClouds3D(P3, torch.from_numpy(nrm)[None].to(dev), C3))
+        (img * gimg).sum().backward()
+        return P3.grad[0], C3.grad[0]
+    gp_ref, gc_ref = grads(RefRenderer(ref_ras, NormWeightedCompositor()))
+    gp_our, gc_our = grads(ours_rr.SurfaceSplattingRenderer(our_ras, ours_rr.NormWeightedCompositor()))
+    rel = lambda a, b: float((a - b).norm() / b.norm().clamp_min(1e-30))
     same = (f_ref.idx == f_our.idx)
     hit = (f_ref.idx >= 0) & (f_our.idx >= 0) & same
     out = {"idx_equal_fraction": float(same.float().mean()), "fragments": int((f_ref.idx >= 0).sum()),
@@ -230,7 +275,9 @@ def check_c_seam(args):
                                                   f_ref.scaler[hit].abs().clamp_min(1e-12)).max()),
            "image_max_abs_diff": float((img_ref - img_our).abs().max()), "image_mean_abs_diff": float((img_ref - img_our).abs().mean()),
            "same_cloud_returned": bool(torch.equal(pc_ref.points_packed(), pc_our.points_packed())),
-           "coverage": float((f_ref.occupancy > 0).float().mean())}
+           "coverage": float((f_ref.occupancy > 0).float().mean()),
+           "grad_points_rel_l2": rel(gp_our, gp_ref), "grad_colors_rel_l2": rel(gc_our, gc_ref),
+           "grad_points_norm": float(gp_ref.norm()), "grad_points_finite": bool(torch.isfinite(gp_ref).all())}
     print("C_SEAM " + json.dumps(out))
 
 

@@ -122,7 +122,27 @@ def cloud_mean_clamp(values, first, num, scale, lo, hi, fallback, min_points):
     return torch.tensor(out, dtype=torch.float32)
 
 
+def _splat_points_occ_fast_cuda_backward(points_sorted, radii_sorted, rs, grad_occ, num_points_per_cloud,
+                                         cloud_to_packed_first_idx, points_grid_off=None, grid_params=None):
+    """ext.cpp:14 -- the reference calls it with the VISIBLE points only; the FRNN grid arguments are not needed"""
+    P = points_sorted.shape[0]
+    pts = _np(points_sorted)
+    if pts.shape[1] == 2:
+        pts = np.concatenate([pts, np.zeros((P, 1), np.float32)], 1)
+    g = oracle.occ_backward_fast(pts, _np(radii_sorted), np.ones(P, bool), _np(rs), _np(grad_occ),
+                                 _np(cloud_to_packed_first_idx), _np(num_points_per_cloud))
+    return torch.from_numpy(np.ascontiguousarray(g[:, :2]))
+
+
+def _backward_zbuf(idx, grad_zbuf, point_z_grad):
+    """ext.cpp:17: in place on (P,1)"""
+    P = point_z_grad.shape[0]
+    gz = np.zeros((P,), np.float32)
+    oracle.zbuf_backward(_np(idx), _np(grad_zbuf), P, gz)
+    point_z_grad += torch.from_numpy(gz)[:, None]
+
+
 def install(ops_module) -> None:
     for name in ("point_setup", "project_backward", "splat_points", "splat_backward", "blend_forward", "blend_backward",
-                 "knn_kth_sqdist", "cloud_mean_clamp"):
+                 "knn_kth_sqdist", "cloud_mean_clamp", "_splat_points_occ_fast_cuda_backward", "_backward_zbuf"):
         setattr(ops_module, name, globals()[name])

@@ -95,7 +95,9 @@ def test_reference_rasterizer_classes_run_on_the_c_level_drop_in():
     """One seam lower: the reference's OWN `DSS.core.rasterizer.SurfaceSplatting` / `EllipticalRasterizer` /
     `DSS.core.renderer.SurfaceSplattingRenderer` (unmodified) with `DSS._C = dss_amd.ops` -- the same-name mirrors of
     the compiled extension (ext.cpp:5-18) -- against the drop-in classes: same fragments, same
-    image.  Forward only (the reference's backward builds an FRNN grid first)."""
+    image, same gradients.  The reference's backward (rasterizer.py:787-977) first builds an FRNN grid with lxxue/FRNN and
+    lxxue/prefix_sum, absent here: the launcher supplies stand-ins of their published behaviour; the mirror of
+    `_splat_points_occ_fast_cuda_backward` ignores the grid arguments anyway."""
     r = _run(["--check-c-seam", "--no-cuda"], 300)
     line = [l for l in r.stdout.splitlines() if l.startswith("C_SEAM ")]
     assert r.returncode == 0 and line, r.stdout[-3000:]
@@ -104,3 +106,6 @@ def test_reference_rasterizer_classes_run_on_the_c_level_drop_in():
     assert d["idx_equal_fraction"] >= 0.9995 and d["occupancy_equal_fraction"] >= 0.9995   # observed: 1.0 and 1.0
     assert d["qvalue_max_abs_diff_on_equal"] <= 1e-3 and d["zbuf_max_abs_diff_on_equal"] <= 1e-5
     assert d["scaler_rel_max_diff_on_equal"] <= 1e-3 and d["image_max_abs_diff"] <= 1e-4 and d["same_cloud_returned"]
+    # backward through the reference's own autograd.Function, clip hook, projection and compositor
+    assert d["grad_points_finite"] and d["grad_points_norm"] > 0.1
+    assert d["grad_points_rel_l2"] <= 1e-3 and d["grad_colors_rel_l2"] <= 1e-3        # observed: 1.2e-5 and 4.5e-7
