@@ -179,6 +179,55 @@ def make_dataset(args):
     print("dataset:", out, "views", args.views, "coverage", float((rgba[..., 3] > 0).mean()))
 
 
+def _install_frnn_stand_ins():
+    """lxxue/FRNN and lxxue/prefix_sum (CUDA extensions the reference's Python calls, absent here) by their published
+    behaviour: 2-D grid insertion (cell = floor((p - min) * delta), linear id x * res_y + y, slot = arrival order),
+    exclusive scan, counting sort; `frnn_grid_points` = K nearest neighbours within radius r (-1 beyond)."""
+    import torch
+    import frnn
+    import prefix_sum
+
+    def insert_points(pts2d, lengths, grid_params, cnt, cell, slot, G):
+        for n in range(pts2d.shape[0]):
+            L = int(lengths[n])
+            gp = grid_params[n].cpu()
+            g = torch.floor((pts2d[n, :L].cpu() - gp[0:2][None]) * gp[2]).long()
+            g = torch.minimum(g.clamp_min(0), (gp[3:5].long() - 1)[None])
+            c = g[:, 0] * int(gp[4]) + g[:, 1]
+            counts = torch.zeros(G, dtype=torch.int64)
+            s_ = torch.empty(L, dtype=torch.int64)
+            for i, ci in enumerate(c.tolist()):
+                s_[i] = counts[ci]
+                counts[ci] += 1
+            cnt[n] = counts.int().to(cnt.device)
+            cell[n, :L] = c.int().to(cell.device)
+            slot[n, :L] = s_.int().to(slot.device)
+
+    def prefix_sum_cuda(counts, total, out):
+        t = int(total)
+        c = counts[:t].long()
+        out[:t] = (torch.cumsum(c, 0) - c).to(out.dtype)
+
+    def counting_sort(pts2d, lengths, cell, slot, off, sorted_pts, sorted_idx):
+        for n in range(pts2d.shape[0]):
+            L = int(lengths[n])
+            dst = (off[n][cell[n, :L].long()] + slot[n, :L]).long()
+            sorted_pts[n, dst] = pts2d[n, :L]
+            sorted_idx[n, dst] = torch.arange(L, dtype=sorted_idx.dtype, device=sorted_idx.device)
+
+    def frnn_grid_points(p1, p2, lengths1=None, lengths2=None, K=-1, r=-1, grid=None, return_nn=False, return_sorted=True,
+                         radius_cell_ratio=2.0):
+        from pytorch3d.ops import knn_points
+        out = knn_points(p1, p2, lengths1, lengths2, K=K, return_nn=return_nn)
+        far = out.dists > float(r) * float(r)
+        dists = torch.where(far, torch.full_like(out.dists, -1.0), out.dists)
+        idx = torch.where(far, torch.full_like(out.idx, -1), out.idx)
+        return dists, idx, out.knn, None
+    frnn._C = types.SimpleNamespace(insert_points_cuda=insert_points, counting_sort_cuda=counting_sort)
+    frnn.frnn_grid_points = frnn_grid_points
+    prefix_sum.prefix_sum_cuda = prefix_sum_cuda
+
+
 def check_c_seam(args):
     """The reference's OWN rasterizer + renderer classes (DSS/core/rasterizer.py, renderer.py, unmodified) on top of
     `DSS._C = dss_amd.ops` -- the seven same-name mirrors of the compiled extension (ext.cpp:5-18) -- against the
@@ -224,36 +273,7 @@ def check_c_seam(args):
     # _C._splat_points_occ_fast_cuda_backward / _C._backward_zbuf = the mirrors.  Its FRNN grid build needs lxxue/FRNN and
     # lxxue/prefix_sum (absent): stand-ins of their published behaviour (2-D cell = floor((p - min) * delta), linear id
     # x * res_y + y, slot = arrival order; exclusive scan; counting sort) -- the mirror ignores the grid anyway.
-    def insert_points(pts2d, lengths, grid_params, cnt, cell, slot, G):
-        for n in range(pts2d.shape[0]):
-            L = int(lengths[n])
-            gp = grid_params[n].cpu()
-            g = torch.floor((pts2d[n, :L].cpu() - gp[0:2][None]) * gp[2]).long()
-            g = torch.minimum(g.clamp_min(0), (gp[3:5].long() - 1)[None])
-            c = g[:, 0] * int(gp[4]) + g[:, 1]
-            counts = torch.zeros(G, dtype=torch.int64)
-            s_ = torch.empty(L, dtype=torch.int64)
-            for i, ci in enumerate(c.tolist()):
-                s_[i] = counts[ci]
-                counts[ci] += 1
-            cnt[n] = counts.int().to(cnt.device)
-            cell[n, :L] = c.int().to(cell.device)
-            slot[n, :L] = s_.int().to(slot.device)
-
-    def prefix_sum_cuda(counts, total, out):
-        t = int(total)
-        c = counts[:t].long()
-        out[:t] = (torch.cumsum(c, 0) - c).to(out.dtype)
-
-    def counting_sort(pts2d, lengths, cell, slot, off, sorted_pts, sorted_idx):
-        for n in range(pts2d.shape[0]):
-            L = int(lengths[n])
-            dst = (off[n][cell[n, :L].long()] + slot[n, :L]).long()
-            sorted_pts[n, dst] = pts2d[n, :L]
-            sorted_idx[n, dst] = torch.arange(L, dtype=sorted_idx.dtype, device=sorted_idx.device)
-    R.frnn._C = types.SimpleNamespace(insert_points_cuda=insert_points, counting_sort_cuda=counting_sort)
-    import prefix_sum
-    prefix_sum.prefix_sum_cuda = prefix_sum_cuda
+    _install_frnn_stand_ins()
     gimg = torch.randn((2, 96, 96, 4), generator=torch.Generator().manual_seed(3)).to(dev)
 
     def grads(renderer):
@@ -284,6 +304,8 @@ def check_c_seam(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--check-c-seam", action="store_true", help="run the reference's own rasterizer classes on DSS._C = dss_amd.ops")
+    ap.add_argument("--c-level", action="store_true",
+                    help="training / dataset modes: leave the YAML class paths alone and provide DSS._C = dss_amd.ops instead")
     ap.add_argument("--make-dataset", default=None, help="write a synthetic MVR dataset here instead of training")
     ap.add_argument("--views", type=int, default=16)
     ap.add_argument("--target-points", type=int, default=0)
@@ -304,6 +326,12 @@ def main():
         import oracle_ops
         oracle_ops.install(ops)
     os.chdir(args.reference)
+    if args.c_level:
+        from dss_amd import ops as _ops
+        import DSS
+        DSS._C = _ops
+        sys.modules["DSS._C"] = _ops
+        _install_frnn_stand_ins()
     if args.check_c_seam:
         return check_c_seam(args)
     if args.make_dataset:
