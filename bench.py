@@ -267,6 +267,8 @@ def main():
     ap.add_argument("--mode", choices=["graph", "eager"], default=None,
                     help="graph: replay the captured step as a hipGraph (default on 1 GPU); eager: plain launches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true",
+                    help="do not spawn the two rocprofv3 counter passes (roofline.traffic then quotes the committed measurement)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -386,13 +388,29 @@ def main():
     # scaler (4) + colour (12) = 52 B is read once.
     alg_bytes = wl.N * (r1 - r0) * S * (12 * K + 4 + 16 + 4) + wl.P * 52
     achieved = alg_bytes / (fine_mean * 1e-3) / 1e9
-    traffic, traffic_src = None, None
+    traffic, traffic_src, gather_traffic = None, None, None
     tfile = os.path.join(ROOT, "profiles", "traffic_fine_kernel.json")
-    if world == 1 and os.path.exists(tfile):
-        # HBM bytes per launch are PMC counters (FETCH_SIZE / WRITE_SIZE in separate rocprofv3 passes of this same command,
-        # tools/collect_traffic.py); they cannot be read in-process, so the committed measurement is quoted with its source
+    if world == 1 and rank == 0 and not args.no_traffic:
+        # HBM bytes per launch are PMC counters: they cannot be read in-process.  tools/collect_traffic.py runs this very
+        # command (eager, 20 steps, --no-traffic) twice under `rocprofv3 --kernel-trace --pmc` (FETCH_SIZE and WRITE_SIZE in
+        # separate passes, no other trace domain) and averages them over the fine_kernel dispatches: measured in THIS run.
+        import shutil
+        import subprocess
+        if shutil.which("rocprofv3"):
+            try:
+                r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "collect_traffic.py")], capture_output=True,
+                                   text=True, timeout=240)
+                tj = json.loads(r.stdout.strip().splitlines()[-1])
+                traffic = int(tj["traffic_bytes_per_launch"])
+                gather_traffic = tj.get("render_backward_kernel_traffic_bytes_per_launch")
+                traffic_src = ("measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes over the "
+                               "same step, FETCH x2 (gfx950), %d + %d fine_kernel dispatches" % tuple(tj["samples"]))
+            except Exception as e:  # noqa: BLE001  (no profiler on the box, counters unavailable, timeout)
+                traffic_src = "live measurement failed (%s); " % type(e).__name__
+    if traffic is None and world == 1 and os.path.exists(tfile):
         tj = json.load(open(tfile))
-        traffic, traffic_src = tj.get("traffic_bytes_per_launch"), "profiles/traffic_fine_kernel.json (%s)" % tj.get("round", "r1")
+        traffic = tj.get("traffic_bytes_per_launch")
+        traffic_src = (traffic_src or "") + "profiles/traffic_fine_kernel.json (%s)" % tj.get("round", "r1")
     hbm = {"bound": "hbm", "kernel": "fine_kernel<5> (fine pass + fused blend)", "achieved": round(achieved, 2),
            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
            "traffic_source": traffic_src, "algorithmic_bytes": alg_bytes, "kernel_ms_mean": round(fine_mean, 5),
@@ -407,7 +425,9 @@ def main():
             "achieved": round(valu_ach, 4), "peak": round(VALU_PEAK, 2), "unit": "Tlaneop/s", "frac": round(valu_ach / VALU_PEAK, 5),
             "pairs": pairs, "min_ops_per_pair": MIN_OPS, "visible_points": n_vis, "kernel_ms_mean": round(gather_ms, 5),
             "how": "HIP events around dss_render_backward_gather alone (second stage of dss_render_backward: %.5f ms for "
-                   "all three launches, i.e. %.5f ms of compaction + median)" % (bwd_ms, prep_ms)}
+                   "all three launches, i.e. %.5f ms of compaction + median)" % (bwd_ms, prep_ms),
+            "traffic": gather_traffic,
+            "traffic_source": traffic_src if gather_traffic is not None else None}
     dominant, other = (valu, hbm) if gather_ms > fine_mean else (hbm, valu)
     if rank == 0:
         rec = {

@@ -18,6 +18,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "gpurun_out", "traffic")
 KERNEL = "fine_kernel"
+OTHER = "render_backward_kernel"   # the backward gather: reported next to it (same passes)
+OTHER_MEAN = {}
 
 
 def one_pass(counter):
@@ -25,16 +27,21 @@ def one_pass(counter):
     os.makedirs(d, exist_ok=True)
     env = dict(os.environ, TMPDIR="/tmp")
     cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "--",
-           sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "eager", "--no-cpu-baseline", "--steps", "20",
+           sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "eager", "--no-cpu-baseline", "--no-traffic", "--steps", "20",
            "--warmup", "5"]
     subprocess.run(cmd, cwd="/tmp", env=env, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-    vals = []
+    vals, other = [], []
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            if KERNEL in r["Kernel_Name"] and r["Counter_Name"] == counter:
+            if r["Counter_Name"] != counter:
+                continue
+            if KERNEL in r["Kernel_Name"]:
                 vals.append(float(r["Counter_Value"]))
+            elif OTHER in r["Kernel_Name"]:
+                other.append(float(r["Counter_Value"]))
     if not vals:
         raise SystemExit("no %s samples for %s" % (counter, KERNEL))
+    OTHER_MEAN[counter] = sum(other) / len(other) if other else None
     return sum(vals) / len(vals), len(vals)
 
 
@@ -45,6 +52,8 @@ def main():
            "FETCH_SIZE_KiB_raw": fetch, "WRITE_SIZE_KiB_raw": write, "samples": [nf, nw],
            "correction": "FETCH_SIZE x2 (gfx950 counts 128-B requests at 64 B), WRITE_SIZE as reported",
            "traffic_bytes_per_launch": int((2.0 * fetch + write) * 1024)}
+    if OTHER_MEAN.get("FETCH_SIZE") is not None and OTHER_MEAN.get("WRITE_SIZE") is not None:
+        rec["render_backward_kernel_traffic_bytes_per_launch"] = int((2.0 * OTHER_MEAN["FETCH_SIZE"] + OTHER_MEAN["WRITE_SIZE"]) * 1024)
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "traffic_fine_kernel.json"), "w") as f:
         json.dump(rec, f, indent=1)

@@ -8,7 +8,7 @@ OUT = os.path.join(ROOT, "gpurun_out", "pmc_sq")
 ctrs = "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD".split()
 os.makedirs(OUT, exist_ok=True)
 cmd = ["rocprofv3", "--kernel-trace", "--pmc", *ctrs, "--output-format", "csv", "-d", OUT, "--",
-       sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "eager", "--no-cpu-baseline", "--steps", "20", "--warmup", "5"]
+       sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "eager", "--no-cpu-baseline", "--no-traffic", "--steps", "20", "--warmup", "5"]
 subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(os.path.join(OUT, "**", "*counter_collection.csv"), recursive=True):
