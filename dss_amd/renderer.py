@@ -75,6 +75,7 @@ class SurfaceSplattingRenderer(torch.nn.Module):
             return None
         fragments = kwargs.get("fragments", None)
         if (fragments is None and self.fused and hasattr(self.rasterizer, "render_fused")
+                and not getattr(self.rasterizer, "compact_culled", False)   # (that mode rebuilds the clouds first: unfused)
                 and self._is_norm_weighted()
                 and self.rasterizer.raster_settings.points_per_pixel <= 32):
             kw = {k: v for k, v in kwargs.items() if k != "fragments"}
