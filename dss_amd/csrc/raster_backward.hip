@@ -1688,11 +1688,9 @@ static int render_backward_impl(bool run_prep, const float *grad_out, const int3
     // every gathered tensor is smaller than 4 GB; larger problems take the 64-bit addressing, four tasks per wavefront
     const unsigned long long widest = (unsigned long long)N * (unsigned long long)(row1 - row0) * (unsigned long long)S *
                                       (unsigned long long)(K > C + 1 ? K : C + 1) * 4ull;
-#ifdef DSS_EXP_NO_A32
-    const bool a32 = false;
-#else
-    const bool a32 = widest < (1ull << 32);
-#endif
+    // (DSS_BACKWARD_ADDR64=1 forces the 64-bit variant: it only exists for tensors nobody allocates in a test)
+    const char *force64 = getenv("DSS_BACKWARD_ADDR64");
+    const bool a32 = widest < (1ull << 32) && !(force64 && force64[0] == '1');
     if (!a32) tpw = 4;
 #define DSS_LAUNCH_RB(CC, SS, TT) DSS_LAUNCH_RB_A(CC, SS, TT, true)
 #define DSS_LAUNCH_RB_T(CC, SS)                                                                                        \

@@ -655,6 +655,24 @@ def test_render_backward_row_bands_sum_to_full(S, bounds):
 
 
 @pytest.mark.parametrize("P,S", [(3000, 96), (300000, 256)])
+def test_render_backward_64_bit_addressing_variant_matches(P, S, monkeypatch):
+    """Gathered tensors of 4 GB and more take a kernel variant with 64-bit addresses (four tasks per wavefront); forced
+    here on small inputs, it must reproduce the 32-bit-offset kernels (both preparation paths)."""
+    sc = scenes.random_splats(P, S, 2, seed=8, rmin=0.6, rmax=2.0) if P > 10000 else scenes.random_splats(P, S, 2, seed=8)
+    d = _dev(sc)
+    idx, zbuf, qv, occ, vis = _fwd(d, S, 5, 0.3, return_visible=True)
+    scaler = torch.from_numpy(sc["scaler"]).to(DEV)
+    img, wsum = ops.blend_forward(idx, qv, occ, scaler, torch.from_numpy(sc["colors"]).to(DEV), return_wsum=True)
+    go = torch.randn_like(img)
+    a = (go, idx, qv, wsum, scaler, d["points"], d["radii"], vis, d["first"], d["num"], 4.0, 0.05)
+    gf, g = ops.render_backward(*a)
+    monkeypatch.setenv("DSS_BACKWARD_ADDR64", "1")
+    gf64, g64 = ops.render_backward(*a)
+    monkeypatch.delenv("DSS_BACKWARD_ADDR64")
+    assert _rel_l2(g64.cpu().numpy(), g.cpu().numpy()) <= 1e-6 and _rel_l2(gf64.cpu().numpy(), gf.cpu().numpy()) <= 1e-6
+
+
+@pytest.mark.parametrize("P,S", [(3000, 96), (300000, 256)])
 def test_render_backward_gather_stage_alone_reproduces_the_full_call(P, S):
     """`dss_render_backward_gather` (second stage only, on the workspace and zero-filled gradients of a preceding full
     call; both preparation paths: P <= 262144 and above) gives the full call's result bit for bit."""
