@@ -654,6 +654,31 @@ def test_render_backward_row_bands_sum_to_full(S, bounds):
     assert _rel_l2(sum_gf.cpu().numpy(), gf.cpu().numpy()) <= 1e-5
 
 
+def test_render_backward_row_bands_sum_to_full_on_the_long_list_path():
+    """The same contract for more than 262,144 points: multi-kernel median, screen-cell order of the visible list, XCD-wise
+    dealing -- what a rank of the 8-GPU run of BASELINE configs[3] executes on its band."""
+    S, bounds = 256, (0, 32, 100, 256)
+    sc = scenes.random_splats(300000, S, 2, seed=33, rmin=0.6, rmax=2.0)
+    d = _dev(sc)
+    idx, zbuf, qv, occ, vis = _fwd(d, S, 5, 0.3, return_visible=True)
+    scaler = torch.from_numpy(sc["scaler"]).to(DEV)
+    img, wsum = ops.blend_forward(idx, qv, occ, scaler, torch.from_numpy(sc["colors"]).to(DEV), return_wsum=True)
+    go = torch.randn_like(img)
+    gf, g = ops.render_backward(go, idx, qv, wsum, scaler, d["points"], d["radii"], vis, d["first"], d["num"], 4.0, -1.0)
+    sum_g, sum_gf = torch.zeros_like(g), torch.zeros_like(gf)
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        pf, pg = ops.render_backward(go[:, a:b].contiguous(), idx[:, a:b].contiguous(), qv[:, a:b].contiguous(),
+                                     wsum[:, a:b].contiguous(), scaler, d["points"], d["radii"], vis, d["first"],
+                                     d["num"], 4.0, -1.0, image_size=S, rows=(a, b))
+        sum_g += pg
+        sum_gf += pf
+    assert _rel_l2(sum_g.cpu().numpy(), g.cpu().numpy()) <= 1e-5
+    assert _rel_l2(sum_gf.cpu().numpy(), gf.cpu().numpy()) <= 1e-5
+    want, _, _ = oracle.splat_backward(sc["points"], sc["radii"], idx.cpu().numpy(), go[..., 3].cpu().numpy(), None,
+                                       sc["first_idx"], sc["num_pts"], 4.0, -1.0)
+    assert _rel_l2(g.cpu().numpy()[:, :2], want[:, :2]) <= 1e-3
+
+
 @pytest.mark.parametrize("P,S", [(3000, 96), (300000, 256)])
 def test_render_backward_64_bit_addressing_variant_matches(P, S, monkeypatch):
     """Gathered tensors of 4 GB and more take a kernel variant with 64-bit addresses (four tasks per wavefront); forced
