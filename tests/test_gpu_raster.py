@@ -438,6 +438,45 @@ def test_dss_c_same_name_mirrors(golden_dir):
             assert _rel_l2(gs.cpu().numpy()[keep], ref[sel][keep, :2]) <= 1e-5
 
 
+def test_integration_stub_file_matches_the_python_mirror(golden_dir):
+    """`integration/DSS_C.py` -- the file INTEGRATION.md section 3 tells a maintainer to drop in as `DSS/_C.py`: plain
+    ctypes on the C ABI, no `dss_amd` import -- executed: all seven `DSS._C` names, with the reference's argument order,
+    give what `dss_amd.ops` gives (which the tests above pin to the reference's goldens)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("DSS_C_stub", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
+        __file__))), "integration", "DSS_C.py"))
+    C = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(C)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    z = np.load(os.path.join(golden_dir, "ref_random64x2.npz"))
+    S, K, thr = int(z["S"]), int(z["K"]), float(z["thr"])
+    d = _dev(z)
+    want = ops.splat_points(d["points"], d["ellipse"], d["cutoff"], d["radii"], d["first"], d["num"], thr, S, K, None, None)
+    for got in (C.splat_points(d["points"], d["ellipse"], d["cutoff"], d["radii"], d["first"], d["num"], thr, S, K, None, None),
+                C._splat_points_naive(d["points"], d["ellipse"], d["cutoff"], d["radii"], d["first"], d["num"], thr, S, K),
+                C._rasterize_fine(d["points"], d["ellipse"], d["cutoff"], d["radii"],
+                                  C._rasterize_coarse(d["points"], d["radii"], d["first"], d["num"], S, 16, 10000), thr, S, 16, K)):
+        for a, b, k in zip(got, want, ("idx", "zbuf", "qvalue", "occupancy")):
+            assert torch.equal(a, b), k
+            assert np.array_equal(a.cpu().numpy(), z["ref_" + ("occ" if k == "occupancy" else k)]), k
+    go = t(z["grad_occ"])
+    assert torch.equal(C._splat_points_occ_backward(d["points"], d["radii"], go, d["first"], d["num"], float(z["radii_s"]), thr),
+                       ops._splat_points_occ_backward(d["points"], d["radii"], go, d["first"], d["num"], float(z["radii_s"]), thr))
+    P = z["points"].shape[0]
+    vis = oracle.visibility(z["ref_idx"], P)
+    sel = np.nonzero(vis)[0]
+    num_v = np.array([vis[f:f + n].sum() for f, n in zip(z["first_idx"], z["num_pts"])], np.int64)
+    first_v = np.cumsum(num_v) - num_v
+    rs = t(oracle.backward_radius(z["radii"], vis, z["first_idx"], z["num_pts"], 5.0))
+    a = (t(z["points"][sel]), t(z["radii"][sel]), rs, go, t(num_v), t(first_v), None, None)
+    assert torch.equal(C._splat_points_occ_fast_cuda_backward(*a), ops._splat_points_occ_fast_cuda_backward(*a))
+    gz = torch.randn((int(z["num_pts"].shape[0]), S, S, K), generator=torch.Generator().manual_seed(2)).to(DEV)
+    za, zb = torch.zeros((P, 1), device=DEV), torch.zeros((P, 1), device=DEV)
+    C._backward_zbuf(want[0], gz, za)
+    ops._backward_zbuf(want[0], gz, zb)
+    assert torch.allclose(za, zb, rtol=1e-5, atol=1e-6) and float(za.abs().sum()) > 0
+
+
 def test_point_on_pixel_centre_contributes_zero():
     """point-one KAT: a point exactly on a pixel centre (reference: 0/0 = NaN, documented divergence)."""
     S = 8
