@@ -304,8 +304,9 @@ def check_c_seam(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--check-c-seam", action="store_true", help="run the reference's own rasterizer classes on DSS._C = dss_amd.ops")
-    ap.add_argument("--c-level", action="store_true",
-                    help="training / dataset modes: leave the YAML class paths alone and provide DSS._C = dss_amd.ops instead")
+    ap.add_argument("--c-level", nargs="?", const="ops", default=None, choices=["ops", "stub"],
+                    help="training / dataset modes: leave the YAML class paths alone and provide DSS._C instead: "
+                         "dss_amd.ops (default) or integration/DSS_C.py (`stub`, GPU only)")
     ap.add_argument("--make-dataset", default=None, help="write a synthetic MVR dataset here instead of training")
     ap.add_argument("--views", type=int, default=16)
     ap.add_argument("--target-points", type=int, default=0)
@@ -327,7 +328,13 @@ def main():
         oracle_ops.install(ops)
     os.chdir(args.reference)
     if args.c_level:
-        from dss_amd import ops as _ops
+        if args.c_level == "stub":   # the ctypes file of INTEGRATION.md section 3 (needs a GPU: it calls the library directly)
+            import importlib.util
+            spec = importlib.util.spec_from_file_location("DSS_C_stub", os.path.join(ROOT, "integration", "DSS_C.py"))
+            _ops = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(_ops)
+        else:
+            from dss_amd import ops as _ops
         import DSS
         DSS._C = _ops
         sys.modules["DSS._C"] = _ops
