@@ -1183,16 +1183,24 @@ __global__ __launch_bounds__(256) void render_backward_kernel(
                 b_ok = bylo <= byhi;
             }
             if (!b_ok) { bxlo = 0; bxhi = -1; bylo = 0; byhi = -1; }
-            // a lane row = a 4 x 4 pixel patch; the task's RP lane rows take patches rp, rp + RP, ... of its box (row-major,
+            // a lane row = one patch of 16 pixels; the task's RP lane rows take patches rp, rp + RP, ... of its box (row-major,
             // ptx patches per row), all tasks in a common loop over the largest box
-            const int ptx = (bxhi - bxlo + 4) >> 2, pty = (byhi - bylo + 4) >> 2;   // 0 for an empty box
+            // patch shape: 4 x 4 pixels per lane row -- 8 x 2 when a task has ONE lane row (TPW = 4): a 5..7-pixel box then
+            // takes 3 patches instead of 4 (the long lists are bound by instruction issue: every iteration counts)
+#ifdef DSS_EXP_PATCH44
+            constexpr int PWS = 2, PHS = 2;
+#else
+            constexpr int PWS = (RP == 1) ? 3 : 2, PHS = 4 - PWS;   // log2 of the patch width / height
+#endif
+            constexpr int PW = 1 << PWS, PH = 1 << PHS;
+            const int ptx = (bxhi - bxlo + PW) >> PWS, pty = (byhi - bylo + PH) >> PHS;   // 0 for an empty box
             const int npatch = (tasks_max<TPW>(ptx * pty) + RP - 1) / RP;
             const float inv_ptx = fast_rcp((float)max(ptx, 1));   // (pi + 0.5) / ptx is never within 0.5 / ptx of an integer
             for (int it = 0; it < npatch; ++it) {
                 const int pi_ = rp + RP * it;
                 const int pty_i = (int)(((float)pi_ + 0.5f) * inv_ptx);   // pi_ / ptx (exact: small integers)
                 const int ptx_i = pi_ - pty_i * ptx;
-                const int xi = bxlo + 4 * ptx_i + (l & 3), yi = bylo + 4 * pty_i + (l >> 2);
+                const int xi = bxlo + PW * ptx_i + (l & (PW - 1)), yi = bylo + PH * pty_i + (l >> PWS);
                 if (A32 && K <= KF && wsum != nullptr) {
                     // 32-bit byte offsets from the tensor bases, unconditional loads from pixel 0 of the camera for the
                     // lanes outside the box (masked by `on` below)
