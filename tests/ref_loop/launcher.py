@@ -21,6 +21,7 @@ import json
 import os
 import runpy
 import sys
+import time
 
 sys.dont_write_bytecode = True  # the reference checkout is read-only: importing it must not leave __pycache__ there
 import types
@@ -120,7 +121,7 @@ def _install_stand_ins(log_path):
             self._f = open(log_path, "a")
 
         def add_scalar(self, tag, value, global_step=None, *a, **k):
-            self._f.write(json.dumps({"tag": tag, "value": float(value), "step": global_step}) + "\n")
+            self._f.write(json.dumps({"tag": tag, "value": float(value), "step": global_step, "t": time.time()}) + "\n")
             self._f.flush()
 
         def add_scalars(self, main_tag, d, global_step=None, *a, **k):
@@ -158,6 +159,9 @@ def make_dataset(args):
     if args.target_points and args.target_points < len(pts):
         keep = np.random.default_rng(0).permutation(len(pts))[: args.target_points]
         pts, nrm = pts[keep], nrm[keep]
+    if args.jitter > 1:   # BASELINE configs[2]: the 9,979-point scan upsampled x10 on its tangent planes = 99,790 points
+        import scenes
+        pts, nrm = scenes.upsample_jitter(pts, nrm, args.jitter, seed=0)
     cloud = PointClouds3D(torch.from_numpy(pts)[None].to(dev), torch.from_numpy(nrm)[None].to(dev),
                           torch.ones(1, len(pts), 3, device=dev))
     texture, lights = LightingTexture(), DirectionalLights(device=dev)
@@ -165,8 +169,15 @@ def make_dataset(args):
     os.makedirs(os.path.join(out, "image"), exist_ok=True)
     os.makedirs(os.path.join(out, "mask"), exist_ok=True)
     mats = []
+    if args.camera_sampler:   # the reference's own sampling rule (DSS/core/camera.py:41-51), unmodified
+        from DSS.core.camera import CameraSampler
+        torch.manual_seed(0)
+        sampler = CameraSampler(args.views, 1, distance_range=torch.tensor([[1.55, 2.0]]), sort_distance=False)
     for i in range(args.views):
-        R, T = look_at_view_transform(1.6, 25.0 * np.sin(1.7 * i), 360.0 * i / args.views)
+        if args.camera_sampler:
+            R, T = sampler.R[i:i + 1], sampler.T[i:i + 1]
+        else:
+            R, T = look_at_view_transform(1.6, 25.0 * np.sin(1.7 * i), 360.0 * i / args.views)
         cams = FoVPerspectiveCameras(R=R, T=T, device=dev)
         with torch.no_grad():
             rgba = renderer(texture(cloud, cameras=cams, lights=lights), cameras=cams)[0].clamp(0, 1).cpu().numpy()
@@ -188,20 +199,20 @@ def _install_frnn_stand_ins():
     import prefix_sum
 
     def insert_points(pts2d, lengths, grid_params, cnt, cell, slot, G):
-        for n in range(pts2d.shape[0]):
+        for n in range(pts2d.shape[0]):   # vectorised per cloud (100k visible points per view at configs[2])
             L = int(lengths[n])
-            gp = grid_params[n].cpu()
-            g = torch.floor((pts2d[n, :L].cpu() - gp[0:2][None]) * gp[2]).long()
+            gp = grid_params[n]
+            g = torch.floor((pts2d[n, :L] - gp[0:2][None]) * gp[2]).long()
             g = torch.minimum(g.clamp_min(0), (gp[3:5].long() - 1)[None])
             c = g[:, 0] * int(gp[4]) + g[:, 1]
-            counts = torch.zeros(G, dtype=torch.int64)
-            s_ = torch.empty(L, dtype=torch.int64)
-            for i, ci in enumerate(c.tolist()):
-                s_[i] = counts[ci]
-                counts[ci] += 1
-            cnt[n] = counts.int().to(cnt.device)
-            cell[n, :L] = c.int().to(cell.device)
-            slot[n, :L] = s_.int().to(slot.device)
+            counts = torch.bincount(c, minlength=G)
+            order = torch.sort(c, stable=True)[1]                 # arrival order inside a cell = point order
+            first = torch.cumsum(counts, 0) - counts
+            s_ = torch.empty(L, dtype=torch.int64, device=c.device)
+            s_[order] = torch.arange(L, device=c.device) - first[c[order]]
+            cnt[n] = counts.int()
+            cell[n, :L] = c.int()
+            slot[n, :L] = s_.int()
 
     def prefix_sum_cuda(counts, total, out):
         t = int(total)
@@ -310,6 +321,8 @@ def main():
     ap.add_argument("--make-dataset", default=None, help="write a synthetic MVR dataset here instead of training")
     ap.add_argument("--views", type=int, default=16)
     ap.add_argument("--target-points", type=int, default=0)
+    ap.add_argument("--jitter", type=int, default=1, help="upsample the target cloud by this factor (tangent-plane jitter)")
+    ap.add_argument("--camera-sampler", action="store_true", help="draw the views with the reference's CameraSampler")
     ap.add_argument("--reference", default="/root/reference")
     ap.add_argument("--config", default=None)
     ap.add_argument("--exit-after", type=int, default=20)

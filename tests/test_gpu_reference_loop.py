@@ -1,0 +1,65 @@
+"""SURVEY §8 row (g), BASELINE configs[2]: the reference's OWN `train_mvr.py` -- unmodified, from the staged archive
+`oracle/_ref/reference_py.tgz` -- on the HIP kernels of one MI355X: 99,790-point target (yoga6 x10) seen from 128
+CameraSampler views at 512^2, a 99,790-point model, batches of 8, dss.yml raster parameters, >= 200 iterations.
+
+Two legs (tests/ref_loop/launcher.py):
+  class level  the YAML names the drop-in classes; everything else is the reference's code;
+  C level      the YAML keeps the reference's own rasterizer / renderer classes and only `DSS._C` is `dss_amd.ops`.
+No oracle, no `--no-cuda`: `dss_amd.ops` is the real library (the launcher installs the oracle double only without a GPU)."""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests", "ref_loop"))
+import cfg3  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.timeout(1500)
+def test_reference_train_mvr_unmodified_on_the_hip_kernels_at_configs2(tmp_path):
+    tmp = str(tmp_path)
+    ref = cfg3.reference_root(tmp)
+    cfg_cls, cfg_c = cfg3.write_configs(tmp)
+    sc_cls, sc_c = os.path.join(tmp, "scalars.jsonl"), os.path.join(tmp, "scalars_native.jsonl")
+    common = ["--reference", ref]
+    r = cfg3.run(common + ["--config", cfg_cls, "--make-dataset", os.path.join(tmp, "data"), "--views", str(cfg3.VIEWS),
+                           "--jitter", str(cfg3.JITTER), "--camera-sampler"], 600)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert "oracle_ops" not in r.stdout
+    assert len(os.listdir(os.path.join(tmp, "data", "image"))) == cfg3.VIEWS
+
+    # ---- class-level leg: >= 200 iterations (train_mvr.py stops on wall clock and resumes from its own model.pt)
+    loss, legs = [], 0
+    while len(loss) < 200 and legs < 5:
+        legs += 1
+        r = cfg3.run(common + ["--config", cfg_cls, "--scalars", sc_cls, "--exit-after", "40"], 600)
+        assert cfg3.reached_time_limit(r), r.stdout[-4000:]
+        loss, steps, times = cfg3.losses(sc_cls)
+        assert steps == sorted(steps) and len(set(steps)) == len(steps)
+    assert len(loss) >= 200, (len(loss), legs, r.stdout[-2000:])
+    assert os.path.isfile(os.path.join(tmp, "exp", "dropin", "model.pt"))
+    n = len(loss)
+    deciles = [sum(loss[i * n // 10:(i + 1) * n // 10]) / ((i + 1) * n // 10 - i * n // 10) for i in range(10)]
+    ms_cls = cfg3.ms_per_iteration(times, steps)
+    print("class-level leg: %d iterations, %.1f ms/iteration, loss deciles %s" % (n, ms_cls, ["%.4f" % d for d in deciles]))
+    assert all(l == l and l < 1e3 for l in loss)
+    assert deciles[-1] < deciles[0] and deciles[-1] <= 0.95 * max(deciles), deciles    # the Trainer's logged loss falls
+
+    # ---- C-level leg: the reference's own classes on DSS._C = dss_amd.ops; the first epoch (128 views / 8 = 16
+    # iterations) draws the same batches (afterwards rasterizer.py:334's torch.rand_like shifts the random stream)
+    native, legs = [], 0
+    while len(native) < 16 and legs < 4:
+        legs += 1
+        r = cfg3.run(common + ["--config", cfg_c, "--scalars", sc_c, "--c-level", "--exit-after", "40"], 900)
+        assert cfg3.reached_time_limit(r), r.stdout[-4000:]
+        native, nsteps, ntimes = cfg3.losses(sc_c)
+    assert len(native) >= 16, (len(native), r.stdout[-2000:])
+    rel = [abs(a - b) / abs(b) for a, b in zip(native[:16], loss[:16])]
+    print("C-level leg: %d iterations, %.1f ms/iteration, first-epoch loss rel. differences max %.2e"
+          % (len(native), cfg3.ms_per_iteration(ntimes, nsteps), max(rel)))
+    print("first epoch, class level:", ["%.6f" % v for v in loss[:16]])
+    print("first epoch, C level    :", ["%.6f" % v for v in native[:16]])
+    assert max(rel) <= 1e-4, rel
