@@ -25,6 +25,8 @@ _c_int, _c_i64, _c_f32, _c_vp, _c_sz = (ctypes.c_int, ctypes.c_int64, ctypes.c_f
 SIGNATURES = {
     "dss_version": (_c_int, []),
     "dss_last_error": (ctypes.c_char_p, []),
+    "dss_set_option": (_c_int, [_c_int, _c_int]),
+    "dss_get_option": (_c_int, [_c_int]),
     "dss_splat_forward_workspace": (_c_sz, [_c_int, _c_i64, _c_int, _c_int, _c_int]),
     "dss_splat_forward_clean_bytes": (_c_sz, [_c_int, _c_i64, _c_int]),
     "dss_splat_forward": (_c_int, [_c_vp] * 6 + [_c_int, _c_i64, _c_f32, _c_int, _c_int, _c_int, _c_int, _c_int]
@@ -103,6 +105,17 @@ def load():
                 fn.argtypes = args
             _lib = lib
     return _lib
+
+
+OPT_LEAN_WORKSPACE, OPT_BACKWARD_TPW, OPT_BACKWARD_ADDR64 = 0, 1, 2   # include/dss_hip.h DSS_OPT_*
+
+
+def set_option(option: int, value: int) -> int:
+    """dss_set_option (explicit process-wide tuning hints; the library reads no environment variable). -> old value"""
+    lib = load()
+    old = lib.dss_get_option(option)
+    check(lib.dss_set_option(option, value), "dss_set_option")
+    return old
 
 
 def check(rc: int, what: str) -> None:

@@ -1,5 +1,6 @@
 // Error reporting and version entry points of libdss_hip.so.
 #include <stdarg.h>
+#include <atomic>
 #include "common.h"
 
 namespace dss {
@@ -26,7 +27,28 @@ int check_launch(const char *what)
     return DSS_OK;
 }
 
+// Process-wide option table of dss_set_option: the ONLY mutable process state besides the thread-local error string.
+// Relaxed atomics: an option is a tuning hint read once per call; callers change it between calls, not during one.
+static std::atomic<int> g_opt[DSS_OPT_COUNT];
+int option(int which) { return (which >= 0 && which < DSS_OPT_COUNT) ? g_opt[which].load(std::memory_order_relaxed) : 0; }
+
+// Per-device cache of (CU count, resident workgroups per CU of the backward gather) -- see raster_backward.hip.
+static std::atomic<int> g_dev_cache[DSS_MAX_DEVICES][4];
+std::atomic<int> *device_cache(int dev) { return (dev >= 0 && dev < DSS_MAX_DEVICES) ? g_dev_cache[dev] : nullptr; }
+
 }  // namespace dss
+
+extern "C" int dss_set_option(int option, int value)
+{
+    if (option < 0 || option >= DSS_OPT_COUNT) { dss::set_error("dss_set_option: unknown option %d", option); return DSS_ERR_INVALID_ARGUMENT; }
+    if (option == DSS_OPT_BACKWARD_TPW && !(value == 0 || value == 1 || value == 2 || value == 4)) {
+        dss::set_error("dss_set_option: DSS_OPT_BACKWARD_TPW takes 0 (automatic), 1, 2 or 4");
+        return DSS_ERR_INVALID_ARGUMENT;
+    }
+    dss::g_opt[option].store(value, std::memory_order_relaxed);
+    return DSS_OK;
+}
+extern "C" int dss_get_option(int option) { return dss::option(option); }
 
 extern "C" int dss_version(void) { return DSS_HIP_VERSION; }
 extern "C" const char *dss_last_error(void) { return dss::g_err; }

@@ -802,11 +802,8 @@ struct CellGrid {
 #define CELL_CHUNK (CELL_THREADS * CELL_PER_THREAD)
 static CellGrid make_cells(int N, int S)
 {
-#ifndef DSS_EXP_CELL_SHIFT
-#define DSS_EXP_CELL_SHIFT 5
-#endif
     CellGrid c;
-    c.shift = DSS_EXP_CELL_SHIFT;
+    c.shift = 5;   // 32 x 32-pixel cells (16 measures the same, 64 is 4 % slower)
     for (;;) {
         c.cx = ((S - 1) >> c.shift) + 1;
         c.cy = c.cx;
@@ -1011,10 +1008,7 @@ __global__ __launch_bounds__(256) void render_backward_kernel(
     // Dealing of the groups.  Short lists: group t -> wave t mod n_waves.  Long lists are in screen-cell order (see
     // cell_count_kernel): runs of CH consecutive groups -- about one cell -- go to ONE XCD (blocks are dispatched to the
     // XCDs round robin), so that the rows a cell's tasks share are fetched into one L2 instead of eight.
-#ifndef DSS_EXP_CHUNK
-#define DSS_EXP_CHUNK 64u
-#endif
-    constexpr uint32_t CH = DSS_EXP_CHUNK;
+    constexpr uint32_t CH = 64u;
     const bool chunked = !SEG && long_list && CH > 0u && (n_waves >> 2) >= 8u;
     const uint32_t xcd = blockIdx.x & 7u;
     uint32_t t_stride = n_waves, t0 = wave;
@@ -1187,11 +1181,7 @@ __global__ __launch_bounds__(256) void render_backward_kernel(
             // ptx patches per row), all tasks in a common loop over the largest box
             // patch shape: 4 x 4 pixels per lane row -- 8 x 2 when a task has ONE lane row (TPW = 4): a 5..7-pixel box then
             // takes 3 patches instead of 4 (the long lists are bound by instruction issue: every iteration counts)
-#ifdef DSS_EXP_PATCH44
-            constexpr int PWS = 2, PHS = 2;
-#else
             constexpr int PWS = (RP == 1) ? 3 : 2, PHS = 4 - PWS;   // log2 of the patch width / height
-#endif
             constexpr int PW = 1 << PWS, PH = 1 << PHS;
             const int ptx = (bxhi - bxlo + PW) >> PWS, pty = (byhi - bylo + PH) >> PHS;   // 0 for an empty box
             const int npatch = (tasks_max<TPW>(ptx * pty) + RP - 1) / RP;
@@ -1626,9 +1616,7 @@ static int render_backward_impl(bool run_prep, const float *grad_out, const int3
         off += align_up((size_t)cg.total * 4, 256);
         uint32_t *block_hist = reinterpret_cast<uint32_t *>(w + off);
         int32_t *unsorted = vis_list;
-#ifndef DSS_EXP_NO_CELLSORT
         vis_list = sorted;
-#endif
         if (run_prep) {
         hipLaunchKernelGGL(alpha_plane_kernel, dim3((unsigned)((npix + ALPHA_PIX_PER_WG - 1) / ALPHA_PIX_PER_WG)), dim3(1024),
                            0, st, grad_out, plane, npix, C);
@@ -1641,7 +1629,6 @@ static int render_backward_impl(bool run_prep, const float *grad_out, const int3
         hipLaunchKernelGGL(median_hist_kernel<2>, dim3(blocks), dim3(MED_THREADS), 0, st, radii, visible, first_idx,
                            num_pts, N, P, hist);
         hipLaunchKernelGGL(median_final_kernel, dim3(N), dim3(MED_THREADS), 0, st, hist, N, radii_s, rs);
-#ifndef DSS_EXP_NO_CELLSORT
         const unsigned cb = (unsigned)cell_blocks(P);   // (the visible count is only known on the device: P bounds it)
         const size_t lds = (size_t)cg.total * 4;
         hipLaunchKernelGGL(cell_hist_kernel, dim3(cb), dim3(CELL_THREADS), lds, st, points, first_idx, num_pts, N, S, cg,
@@ -1651,18 +1638,23 @@ static int render_backward_impl(bool run_prep, const float *grad_out, const int3
         hipLaunchKernelGGL(cell_scan_kernel, dim3(1), dim3(1024), 0, st, cell_total, cell_start, cg.total);
         hipLaunchKernelGGL(cell_scatter_kernel, dim3(cb), dim3(CELL_THREADS), lds, st, cg, vis_count, unsorted, cell_of,
                            cell_start, block_hist, sorted);
-#endif
         }
     }
     // persistent grid = exactly the resident capacity of the chip for this kernel (a larger grid would
     // leave late workgroups waiting for slots while their share of the list sits idle)
-    static int cap3 = 0, cap0 = 0, n_cus = 256;  // benign race: every thread computes the same value
-    int &cap = (C == 3) ? cap3 : cap0;
-    if (cap == 0) {
-        int dev = 0, cus = 256, per_cu = 4;
+    // Cached per DEVICE ordinal (api.hip: four atomic slots per device -- CU count, capacity for C == 3, capacity for the
+    // generic-channel kernel): sized by the <C, true, 4, true> instantiation, the variant with the most registers, so the
+    // grid never exceeds the resident capacity of whichever variant is launched below.  Racing first callers compute and
+    // store the same values.
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::atomic<int> *dc = device_cache(dev);
+    int n_cus = dc ? dc[0].load(std::memory_order_relaxed) : 0;
+    int cap = dc ? dc[C == 3 ? 1 : 2].load(std::memory_order_relaxed) : 0;
+    if (cap == 0 || n_cus == 0) {
+        int cus = 256, per_cu = 4;
         hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-            cus = prop.multiProcessorCount;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
         if (C == 3)
             (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_backward_kernel<3, true, 4, true>, 256, 0);
         else
@@ -1671,23 +1663,20 @@ static int render_backward_impl(bool run_prep, const float *grad_out, const int3
         n_cus = cus;
         cap = cus * per_cu;
         (void)hipGetLastError();
+        if (dc) {
+            dc[0].store(n_cus, std::memory_order_relaxed);
+            dc[C == 3 ? 1 : 2].store(cap, std::memory_order_relaxed);
+        }
     }
     const unsigned pgrid = (unsigned)((P + 3) / 4 < cap ? (P + 3) / 4 : cap);
-#ifndef DSS_EXP_LARGE_WG
-#define DSS_EXP_LARGE_WG 6u
-#endif
-    const uint32_t large_waves = DSS_EXP_LARGE_WG * (uint32_t)n_cus * 4u;
+    const uint32_t large_waves = 6u * (uint32_t)n_cus * 4u;
     // tasks per wavefront: four when the list is long enough to keep every resident wavefront busy with whole groups
     // (throughput-bound), fewer -- more lanes per task, shorter dependent chains -- for short lists.  The visible count is
     // only known on the device; P bounds it and the visible fraction of a rendered cloud is 30-60 %.
-    static int tpw_env = -1;
-    if (tpw_env < 0) {
-        const char *e = getenv("DSS_BACKWARD_TPW");
-        tpw_env = e ? atoi(e) : 0;
-    }
+    const int tpw_opt = option(DSS_OPT_BACKWARD_TPW);
     const long long est_tasks = (long long)P * 2 / 5;
     int tpw = est_tasks >= 16ll * cap * 4 ? 4 : (est_tasks >= 4ll * cap * 4 ? 2 : 1);
-    if (tpw_env == 1 || tpw_env == 2 || tpw_env == 4) tpw = tpw_env;
+    if (tpw_opt == 1 || tpw_opt == 2 || tpw_opt == 4) tpw = tpw_opt;
 #define DSS_LAUNCH_RB_A(CC, SS, TT, AA)                                                                                 \
     hipLaunchKernelGGL((render_backward_kernel<CC, SS, TT, AA>), dim3(pgrid), dim3(256), 0, st, grad_out, alpha, idx, qvalue, wsum, \
                        scaler, points, radii, rs, first_idx, num_pts, vis_count, vis_list, n_seg, seg_pts, N, S, K, C, clip, \
@@ -1696,9 +1685,8 @@ static int render_backward_impl(bool run_prep, const float *grad_out, const int3
     // every gathered tensor is smaller than 4 GB; larger problems take the 64-bit addressing, four tasks per wavefront
     const unsigned long long widest = (unsigned long long)N * (unsigned long long)(row1 - row0) * (unsigned long long)S *
                                       (unsigned long long)(K > C + 1 ? K : C + 1) * 4ull;
-    // (DSS_BACKWARD_ADDR64=1 forces the 64-bit variant: it only exists for tensors nobody allocates in a test)
-    const char *force64 = getenv("DSS_BACKWARD_ADDR64");
-    const bool a32 = widest < (1ull << 32) && !(force64 && force64[0] == '1');
+    // (DSS_OPT_BACKWARD_ADDR64 forces the 64-bit variant: it only exists for tensors nobody allocates in a test)
+    const bool a32 = widest < (1ull << 32) && option(DSS_OPT_BACKWARD_ADDR64) != 1;
     if (!a32) tpw = 4;
 #define DSS_LAUNCH_RB(CC, SS, TT) DSS_LAUNCH_RB_A(CC, SS, TT, true)
 #define DSS_LAUNCH_RB_T(CC, SS)                                                                                        \

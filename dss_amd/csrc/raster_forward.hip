@@ -1070,15 +1070,11 @@ struct FwdWorkspace {
 // in [64, 16384] (>= SPEC for the speculative first reads; 64 leaves the benchmark scenes -- densest sub-list 42 entries
 // at a mean of 2 -- on the primary lists).  Denser sub-lists go through the spill pool.  Depends only on (N, P, S) so the
 // size query and the launch agree.
-// DSS_LEAN_WORKSPACE=1 (environment, read at every call so the size query and the launch agree): half the sub-list
+// dss_set_option(DSS_OPT_LEAN_WORKSPACE, 1) (read at every call; the size query and the launch must see the same value): half the sub-list
 // capacity (more splats take the spill pass) and no packed records (the fine pass gathers from the five per-point arrays).
 // Measured cost: +6 % and +6 % of the step at 8 x 1M points @1024^2 and 4M points @2048^2 (fine pass 0.98 -> 1.25 ms without
 // records) for 177+256 -> 110 MB at the latter.  Off by default: 288 GB of HBM make the fast layout the right default.
-static bool lean_workspace()
-{
-    const char *e = getenv("DSS_LEAN_WORKSPACE");
-    return e && e[0] == '1';
-}
+static bool lean_workspace() { return option(DSS_OPT_LEAN_WORKSPACE) == 1; }
 static uint32_t bin_capacity(int N, int64_t P, int S)
 {
     const double tiles = (double)((S + DSS_TILE - 1) / DSS_TILE) * ((S + DSS_TILE - 1) / DSS_TILE);
@@ -1395,10 +1391,8 @@ extern "C" int dss_render_forward(const float *world, const float *normals, cons
     if (!rerun) {
         hipLaunchKernelGGL(setup_bin_kernel, dim3(pb), dim3(tb), 0, st, SA, g, w.counts, w.lists, w.cap, w.queue, w.spill,
                            visible);
-#ifndef DSS_EXP_NOSPILL
         hipLaunchKernelGGL(spill_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, pts_screen, radii, first_idx,
                            num_pts, N, P, g, w.counts, w.cap, w.spill);
-#endif
     }
     FineArgs A;
     A.points = pts_screen; A.ellipse = ellipse; A.cutoff = cutoff; A.radii = radii;

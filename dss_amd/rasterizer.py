@@ -12,7 +12,8 @@ Differences that a caller can observe (documented in DESIGN.md / INTEGRATION.md)
 * culled points are masked, not compacted: the returned point cloud is the cloud extended to the
   N cameras, ``fragments.idx`` indexes its packed points, culled points simply never appear
   (``SurfaceSplatting(..., compact_culled=True)`` drops them like the reference: same integer labels, h from the
-  filtered clouds -- at the price of boolean indexing with host syncs per call);
+  filtered clouds -- at the price of boolean indexing with host syncs per call; by default that mode is taken exactly
+  when ``raster_settings.backface_culling`` is on, where masking would change h and therefore the image);
 * a point exactly on a pixel centre contributes 0 to the occupancy gradient (reference: NaN).
 """
 from typing import Optional
@@ -216,15 +217,28 @@ class SurfaceSplatting(torch.nn.Module):
     """rasterizer.py:102-664.  ``forward(point_clouds, point_clouds_filter=None, **kwargs)`` returns the
     tuple ``(PointFragments, point_clouds[, per_point_info])`` (:655-664)."""
 
-    def __init__(self, cameras=None, raster_settings=None, frnn_radius=0.2, compact_culled: bool = False):
+    def __init__(self, cameras=None, raster_settings=None, frnn_radius=0.2, compact_culled: Optional[bool] = None):
         super().__init__()
         if raster_settings is None:
             raster_settings = PointsRasterizationSettings()
         self.cameras = cameras
         self.raster_settings = raster_settings
         self.frnn_radius = frnn_radius
-        self.compact_culled = compact_culled   # True: drop culled points like the reference (see _forward_compacted)
+        # True: drop culled points like the reference (see _forward_compacted); False: mask them (no host syncs);
+        # None (default): follow `raster_settings.backface_culling` -- with back-face culling on, roughly half of the
+        # cloud is dropped and the reference's h (hence every splat size, hence the image) comes from the filtered
+        # clouds, so a default-constructed PointsRasterizationSettings() (backface_culling=True like the reference's)
+        # must take the reference's order to give the reference's image; the shipped configs (backface_culling: false)
+        # keep the sync-free masked path.
+        self.compact_culled = compact_culled
         self._Vrk_h = None
+
+    def compacts(self, raster_settings=None) -> bool:
+        """whether a forward with these settings takes the reference's drop-the-culled-points order"""
+        if self.compact_culled is not None:
+            return bool(self.compact_culled)
+        rs = self.raster_settings if raster_settings is None else raster_settings
+        return bool(getattr(rs, "backface_culling", False))
 
     # -- source-space variance scale h (rasterizer.py:293-402) ------------------------------------
     def _variance_scale(self, point_clouds, raster_settings, refresh=True):
@@ -418,7 +432,7 @@ class SurfaceSplatting(torch.nn.Module):
         if point_clouds.isempty():
             cameras = kwargs.get("cameras", self.cameras)
             return self._empty_fragments(cameras.R.shape[0], point_clouds.device, raster_settings), point_clouds
-        if getattr(self, "compact_culled", False):
+        if self.compacts(raster_settings):
             return self._forward_compacted(point_clouds, original_clouds, point_clouds_filter, **kwargs)
         return self._forward_masked(point_clouds, original_clouds, point_clouds_filter, **kwargs)
 

@@ -75,8 +75,9 @@ class SurfaceSplattingRenderer(torch.nn.Module):
             return None
         fragments = kwargs.get("fragments", None)
         if (fragments is None and self.fused and hasattr(self.rasterizer, "render_fused")
-                and not getattr(self.rasterizer, "compact_culled", False)   # (that mode rebuilds the clouds first: unfused)
+                and not self.rasterizer.compacts(kwargs.get("raster_settings"))   # (that mode rebuilds the clouds first: unfused)
                 and self._is_norm_weighted()
+                and (point_clouds.features_packed() is None or point_clouds.features_packed().shape[1] <= 8)  # render_fused: C <= 8
                 and self.rasterizer.raster_settings.points_per_pixel <= 32):
             kw = {k: v for k, v in kwargs.items() if k != "fragments"}
             images, fragments, point_clouds = self.rasterizer.render_fused(point_clouds, **kw)

@@ -10,7 +10,10 @@
  *     torch tensors are laid out after .contiguous() (rasterize_points.cu:648-663);
  *   - the caller owns every buffer (outputs and workspace); nothing is allocated inside;
  *   - work is enqueued asynchronously on `stream` (a hipStream_t; NULL = default stream); no host
- *     synchronisation happens inside the library; no global mutable state; re-entrant;
+ *     synchronisation happens inside the library; re-entrant; no environment variable is read and no
+ *     hidden global state is kept: the only process-wide state is the explicit option table of
+ *     dss_set_option() below (tuning hints, all 0 by default) and a per-device-ordinal cache of
+ *     device properties (CU count, occupancy), filled with atomics on first use;
  *   - return value: 0 on success, negative DSS_ERR_* otherwise (no exceptions cross the ABI);
  *     dss_last_error() returns a thread-local message for the last failing call on this thread;
  *   - `row0,row1` select the image row band [row0,row1) a rank renders (multi-GPU row
@@ -51,6 +54,21 @@ extern "C" {
 
 DSS_API int dss_version(void);
 DSS_API const char *dss_last_error(void);
+
+/* Explicit tuning options (process-wide, relaxed atomics; change them between calls, not during one).  A workspace
+ * size query and the launch it sizes must see the same DSS_OPT_LEAN_WORKSPACE value.
+ *   DSS_OPT_LEAN_WORKSPACE 1: half the tile sub-list capacity and no packed 64-byte records in the forward workspace
+ *                             (433 -> 110 MB at 4M points @2048^2 for ~+13 % step time); 0 (default): the fast layout.
+ *   DSS_OPT_BACKWARD_TPW   visible points per wavefront of the backward gather: 1, 2 or 4; 0 (default) = chosen from P.
+ *   DSS_OPT_BACKWARD_ADDR64 1: force the 64-bit addressing variant of the backward gather (normally only taken when a
+ *                             gathered tensor exceeds 4 GB); exists so that a test can reach that variant.
+ * Returns DSS_ERR_INVALID_ARGUMENT for an unknown option or value. */
+#define DSS_OPT_LEAN_WORKSPACE 0
+#define DSS_OPT_BACKWARD_TPW 1
+#define DSS_OPT_BACKWARD_ADDR64 2
+#define DSS_OPT_COUNT 3
+DSS_API int dss_set_option(int option, int value);
+DSS_API int dss_get_option(int option);
 
 /* ---------------------------------------------------------------------------------------------
  * Forward rasterizer.

@@ -190,6 +190,26 @@ def make_dataset(args):
     print("dataset:", out, "views", args.views, "coverage", float((rgba[..., 3] > 0).mean()))
 
 
+def make_checkpoint(args):
+    """A `model.pt` in the format of the reference's CheckpointIO (DSS/misc/checkpoints.py:28-41, loaded with
+    strict=False by train_mvr.py:98-103 through `resume_from: model.pt`): the dataset's own cloud with Gaussian noise on the
+    positions and normals -- the unmodified script then RESUMES from it (refinement of a noisy scan instead of the
+    sphere of config.py:177-183)."""
+    import numpy as np
+    import torch
+    d = np.load(os.path.join(args.data_dir, "data_dict.npz"), allow_pickle=True)
+    rng = np.random.default_rng(1)
+    pts = d["points"].astype(np.float32)
+    nrm = d["normals"].astype(np.float32)
+    pts = pts + rng.normal(0, args.noise, pts.shape).astype(np.float32)
+    nrm = nrm + rng.normal(0, 0.5, nrm.shape).astype(np.float32)
+    nrm /= np.maximum(np.linalg.norm(nrm, axis=1, keepdims=True), 1e-12)
+    os.makedirs(os.path.dirname(args.make_checkpoint), exist_ok=True)
+    torch.save({"model": {"points": torch.from_numpy(pts)[None], "normals": torch.from_numpy(nrm)[None]},
+                "epoch_it": -1, "it": -1}, args.make_checkpoint)
+    print("checkpoint:", args.make_checkpoint, pts.shape)
+
+
 def _install_frnn_stand_ins():
     """lxxue/FRNN and lxxue/prefix_sum (CUDA extensions the reference's Python calls, absent here) by their published
     behaviour: 2-D grid insertion (cell = floor((p - min) * delta), linear id x * res_y + y, slot = arrival order),
@@ -319,6 +339,10 @@ def main():
                     help="training / dataset modes: leave the YAML class paths alone and provide DSS._C instead: "
                          "dss_amd.ops (default) or integration/DSS_C.py (`stub`, GPU only)")
     ap.add_argument("--make-dataset", default=None, help="write a synthetic MVR dataset here instead of training")
+    ap.add_argument("--make-checkpoint", default=None, help="write a CheckpointIO-format model.pt (noisy copy of the "
+                    "dataset's cloud) here instead of training; needs --data-dir")
+    ap.add_argument("--data-dir", default=None)
+    ap.add_argument("--noise", type=float, default=0.01)
     ap.add_argument("--views", type=int, default=16)
     ap.add_argument("--target-points", type=int, default=0)
     ap.add_argument("--jitter", type=int, default=1, help="upsample the target cloud by this factor (tangent-plane jitter)")
@@ -356,6 +380,8 @@ def main():
         return check_c_seam(args)
     if args.make_dataset:
         return make_dataset(args)
+    if args.make_checkpoint:
+        return make_checkpoint(args)
     sys.argv = ["train_mvr.py", "--config", args.config, "--exit-after", str(args.exit_after)] + \
         (["--no-cuda"] if args.no_cuda else [])
     runpy.run_path(os.path.join(args.reference, "train_mvr.py"), run_name="__main__")

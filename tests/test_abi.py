@@ -39,6 +39,24 @@ def test_version_and_error_channel():
         _lib.check(-1, "dss_splat_forward")
 
 
+def test_library_reads_no_environment_and_options_are_explicit():
+    """include/dss_hip.h: no hidden global state -- the library imports no getenv; tuning goes through dss_set_option."""
+    import subprocess
+    syms = subprocess.run(["nm", "-D", "--undefined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "hipLaunchKernel" in syms or "hipModuleLaunchKernel" in syms or "__hipPushCallConfiguration" in syms
+    assert "getenv" not in syms
+    lib = _lib.load()
+    assert lib.dss_get_option(_lib.OPT_LEAN_WORKSPACE) == 0 and lib.dss_get_option(_lib.OPT_BACKWARD_TPW) == 0
+    full = lib.dss_render_forward_workspace(1, 1 << 22, 2048, 5)
+    assert _lib.set_option(_lib.OPT_LEAN_WORKSPACE, 1) == 0
+    try:
+        assert lib.dss_render_forward_workspace(1, 1 << 22, 2048, 5) < full // 2
+    finally:
+        _lib.set_option(_lib.OPT_LEAN_WORKSPACE, 0)
+    assert lib.dss_set_option(_lib.OPT_BACKWARD_TPW, 3) == -1 and b"DSS_OPT_BACKWARD_TPW" in lib.dss_last_error()
+    assert lib.dss_set_option(99, 1) == -1
+
+
 def test_workspace_query():
     lib = _lib.load()
     assert lib.dss_splat_forward_workspace(1, 32684, 512, 5, 0) == 256

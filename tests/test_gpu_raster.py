@@ -105,8 +105,8 @@ def test_forward_list_overflow_goes_through_the_spill_pool():
         assert np.array_equal(g.cpu().numpy(), w)
 
 
-def test_lean_workspace_mode_is_exact_and_smaller(monkeypatch):
-    """DSS_LEAN_WORKSPACE=1 halves the sub-list capacity and drops the packed records (raster_forward.hip
+def test_lean_workspace_mode_is_exact_and_smaller():
+    """dss_set_option(DSS_OPT_LEAN_WORKSPACE, 1) halves the sub-list capacity and drops the packed records (raster_forward.hip
     `lean_workspace`): smaller workspace, same fragments bit for bit, same image."""
     pts, nrm = scenes.load_cloud("bunny")
     pts = scenes.normalize_unit_sphere(pts)
@@ -122,10 +122,12 @@ def test_lean_workspace_mode_is_exact_and_smaller(monkeypatch):
     lib = _lib.load()
     full_bytes = lib.dss_render_forward_workspace(1, 4_000_000, 2048, K)
     ref = ops.render_forward(*a, S, K, 1.0, thr, 1.0, False, True, workspace_state=0)
-    monkeypatch.setenv("DSS_LEAN_WORKSPACE", "1")
-    lean_bytes = lib.dss_render_forward_workspace(1, 4_000_000, 2048, K)
-    got = ops.render_forward(*a, S, K, 1.0, thr, 1.0, False, True, workspace_state=0)
-    monkeypatch.delenv("DSS_LEAN_WORKSPACE")
+    _lib.set_option(_lib.OPT_LEAN_WORKSPACE, 1)
+    try:
+        lean_bytes = lib.dss_render_forward_workspace(1, 4_000_000, 2048, K)
+        got = ops.render_forward(*a, S, K, 1.0, thr, 1.0, False, True, workspace_state=0)
+    finally:
+        _lib.set_option(_lib.OPT_LEAN_WORKSPACE, 0)
     assert lean_bytes < 0.3 * full_bytes and lean_bytes <= 128 << 20, (lean_bytes, full_bytes)  # configs[4]: 433 -> 110 MB
     for k in ("idx", "zbuf", "qvalue", "occupancy", "visible"):
         assert torch.equal(ref[k], got[k]), k
@@ -719,7 +721,7 @@ def test_render_backward_row_bands_sum_to_full_on_the_long_list_path():
 
 
 @pytest.mark.parametrize("P,S", [(3000, 96), (300000, 256)])
-def test_render_backward_64_bit_addressing_variant_matches(P, S, monkeypatch):
+def test_render_backward_64_bit_addressing_variant_matches(P, S):
     """Gathered tensors of 4 GB and more take a kernel variant with 64-bit addresses (four tasks per wavefront); forced
     here on small inputs, it must reproduce the 32-bit-offset kernels (both preparation paths)."""
     sc = scenes.random_splats(P, S, 2, seed=8, rmin=0.6, rmax=2.0) if P > 10000 else scenes.random_splats(P, S, 2, seed=8)
@@ -730,9 +732,11 @@ def test_render_backward_64_bit_addressing_variant_matches(P, S, monkeypatch):
     go = torch.randn_like(img)
     a = (go, idx, qv, wsum, scaler, d["points"], d["radii"], vis, d["first"], d["num"], 4.0, 0.05)
     gf, g = ops.render_backward(*a)
-    monkeypatch.setenv("DSS_BACKWARD_ADDR64", "1")
-    gf64, g64 = ops.render_backward(*a)
-    monkeypatch.delenv("DSS_BACKWARD_ADDR64")
+    _lib.set_option(_lib.OPT_BACKWARD_ADDR64, 1)
+    try:
+        gf64, g64 = ops.render_backward(*a)
+    finally:
+        _lib.set_option(_lib.OPT_BACKWARD_ADDR64, 0)
     assert _rel_l2(g64.cpu().numpy(), g.cpu().numpy()) <= 1e-6 and _rel_l2(gf64.cpu().numpy(), gf.cpu().numpy()) <= 1e-6
 
 

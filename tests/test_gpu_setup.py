@@ -460,7 +460,14 @@ def test_compact_culled_mode_reproduces_the_reference_labels_under_culling():
     assert abs(float(strict._Vrk_h.flatten()[0]) - h) <= 1e-6 * h
     assert np.array_equal(fr.idx.cpu().numpy(), want[0]) and np.array_equal(fr.occupancy.cpu().numpy(), want[3])
     assert info["radii"].shape[0] == len(pts) and float(info["radii"][~torch.from_numpy(keep).to(DEV)].abs().max()) == 0
-    masked = SurfaceSplatting(cameras=cams, raster_settings=st)
+    # default (compact_culled=None) follows raster_settings.backface_culling: a default-constructed rasterizer gives the
+    # reference's labels and image without being told
+    default = SurfaceSplatting(cameras=cams, raster_settings=st)
+    assert default.compacts() and not SurfaceSplatting(cameras=cams, raster_settings=PointsRasterizationSettings(
+        backface_culling=False)).compacts() and SurfaceSplatting(cameras=cams).compacts()
+    fr_d, cloud_d = default(cloud)
+    assert torch.equal(fr_d.idx, fr.idx) and cloud_d.points_packed().shape[0] == int(keep.sum())
+    masked = SurfaceSplatting(cameras=cams, raster_settings=st, compact_culled=False)
     fr_m, cloud_m = masked(cloud, Vrk_h=torch.tensor([h], device=DEV))
     remap = torch.from_numpy(np.nonzero(keep)[0]).to(DEV)
     assert torch.equal(torch.where(fr.idx >= 0, remap[fr.idx.clamp_min(0).long()].int(), fr.idx), fr_m.idx)

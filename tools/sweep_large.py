@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Developer tool (GPU box): tools/bench_large.py over configurations x DSS_BACKWARD_TPW settings, one summary line each."""
+"""Developer tool (GPU box): tools/bench_large.py over configurations x backward TPW settings (tools/bench_large.py reads BENCH_BACKWARD_TPW and calls dss_set_option), one summary line each."""
 import json
 import os
 import subprocess
@@ -12,7 +12,7 @@ for c in cfgs:
     for t in tpws:
         env = dict(os.environ)
         if t != "0":
-            env["DSS_BACKWARD_TPW"] = t
+            env["BENCH_BACKWARD_TPW"] = t
         out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_large.py"), c], env=env, capture_output=True,
                              text=True, timeout=600)
         line = [x for x in out.stdout.splitlines() if x.startswith("{")]

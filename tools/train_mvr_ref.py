@@ -29,7 +29,10 @@ def main():
         assert r.returncode == 0, r.stdout[-3000:]
     res = {"workload": "reference train_mvr.py (unmodified) on the HIP kernels: %d-point model, %d views, %d^2, batch %d"
                        % (cfg3.POINTS, cfg3.VIEWS, cfg3.SIZE, cfg3.BATCH)}
-    for name, cfg, extra in (("class_level", cfg_cls, []), ("c_level", cfg_c, ["--c-level"])):
+    legs = (("class_level", cfg_cls, []), ("c_level", cfg_c, ["--c-level"]))
+    if os.environ.get("REF_LEGS") == "class":
+        legs = legs[:1]
+    for name, cfg, extra in legs:
         sc = os.path.join(tmp, "scalars_%s.jsonl" % name)
         if os.path.exists(sc):
             os.remove(sc)
@@ -38,8 +41,38 @@ def main():
         assert cfg3.reached_time_limit(r), r.stdout[-3000:]
         loss, steps, times = cfg3.losses(sc)
         ms = cfg3.ms_per_iteration(times, steps)
+        shutil.copy(sc, os.path.join(out, "scalars_%s.jsonl" % name))
+        for sub in ("dropin", "native"):
+            m = os.path.join(tmp, "exp", sub, "model.pt")
+            if os.path.isfile(m):
+                shutil.copy(m, os.path.join(out, "model_%s.pt" % name))
         res[name] = {"iterations": len(loss), "ms_per_iteration": ms, "loss_first": loss[0], "loss_last": loss[-1],
                      "Msplats_per_s": cfg3.BATCH * cfg3.POINTS / ms * 1e-3}
+    # resumed from a noisy copy of the target (see tests/test_gpu_reference_loop.py)
+    import yaml
+    c = yaml.safe_load(open(cfg_cls))
+    c["name"] = "resume"
+    cfg_res, sc = os.path.join(tmp, "resume.yml"), os.path.join(tmp, "scalars_resume.jsonl")
+    yaml.safe_dump(c, open(cfg_res, "w"))
+    if os.path.exists(sc):
+        os.remove(sc)
+    r = cfg3.run(["--reference", ref, "--config", cfg_res, "--make-checkpoint", os.path.join(tmp, "exp", "resume", "model.pt"),
+                  "--data-dir", os.path.join(tmp, "data"), "--noise", "0.01"], 300)
+    assert r.returncode == 0, r.stdout[-3000:]
+    r = cfg3.run(["--reference", ref, "--config", cfg_res, "--scalars", sc, "--exit-after", seconds], 900)
+    assert cfg3.reached_time_limit(r), r.stdout[-3000:]
+    loss, steps, times = cfg3.losses(sc)
+    shutil.copy(sc, os.path.join(out, "scalars_resume.jsonl"))
+    n = len(loss)
+    res["resumed_from_noisy_target"] = {"iterations": n, "ms_per_iteration": cfg3.ms_per_iteration(times, steps),
+                                        "loss_deciles": [sum(loss[i * n // 10:(i + 1) * n // 10]) / max(1, (i + 1) * n // 10 - i * n // 10)
+                                                         for i in range(10)]}
+    for i in (0, 40, 127):
+        for kind in ("image", "mask"):
+            shutil.copy(os.path.join(tmp, "data", kind, "%03d.png" % i), os.path.join(out, "%s_%03d.png" % (kind, i)))
+    if os.environ.get("REF_NO_PROF"):
+        print(json.dumps(res))
+        return
     # the class-level leg once more under rocprofv3 (kernel trace + stats only)
     prof = os.path.join(out, "train_mvr_ref_prof")
     shutil.rmtree(os.path.join(tmp, "exp"), ignore_errors=True)
