@@ -48,6 +48,9 @@ class RowPartition:
     def bounds(self, rank: int) -> Tuple[int, int]:
         return self._bounds[rank], self._bounds[rank + 1]
 
+    def describe(self) -> str:
+        return ("equal bands of %d rows" % self.band) if self.uniform else ("bands %r" % (self._bounds,))
+
     def slice(self, full: torch.Tensor) -> torch.Tensor:
         """Own band of a full-image tensor (N, S, ...)."""
         return full[:, self.row0:self.row1]
@@ -178,8 +181,25 @@ class OverlappedExchange:
                  image_group=None):
         self.part, self.group = part, group
         self.image_group = image_group
+        # `overlap`: the image bands travel on their own communicator, asynchronously.  If the second communicator cannot
+        # be created (or the asynchronous collective later raises) the exchange degrades to ONE communicator and a
+        # blocking all-gather -- slower, same result -- and says so (`overlap` False, `degraded` holds the reason): the
+        # first multi-GPU run of a deployment must produce a diagnosable number rather than a stack trace.
+        self.overlap, self.degraded = True, None
         if image_group is None and part.world_size > 1 and dist.is_initialized():
-            self.image_group = dist.new_group()  # collective: every rank constructs its exchange
+            try:
+                self.image_group = dist.new_group()  # collective: every rank constructs its exchange
+            except Exception as e:  # noqa: BLE001  (RCCL refused a second communicator)
+                self.image_group, self.overlap = group, False
+                self.degraded = "new_group failed: %s: %s" % (type(e).__name__, str(e)[:200])
+            # every rank must take the same path (a rank that degraded alone would issue a different collective
+            # sequence): agree on the minimum over the ranks
+            ok = torch.tensor([1 if self.overlap else 0], dtype=torch.int32,
+                              device=device if dist.get_backend(group) != "gloo" else "cpu")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+            if int(ok.item()) == 0 and self.overlap:
+                self.image_group, self.overlap = group, False
+                self.degraded = "another rank could not create the second communicator"
         G, band, S = part.world_size, part.band, part.S
         self.send_img = torch.zeros((band, n_images, S, channels), dtype=torch.float32, device=device)
         self.recv_img = torch.empty((G * band, n_images, S, channels), dtype=torch.float32, device=device)
@@ -207,7 +227,19 @@ class OverlappedExchange:
     def start(self) -> torch.Tensor:
         """Issue both exchanges; returns the union of the visibility flags, uint8 (P,)."""
         G = self.part.world_size
-        self._work = self._all_gather(self.recv_img.view(G, -1), self.send_img.view(-1), self.image_group, True)
+        if self.overlap:
+            try:
+                self._work = self._all_gather(self.recv_img.view(G, -1), self.send_img.view(-1), self.image_group, True)
+            except Exception as e:  # noqa: BLE001  (asynchronous collective refused: blocking exchange from now on)
+                self.overlap, self._work = False, None
+                self.degraded = "async all_gather failed: %s: %s" % (type(e).__name__, str(e)[:200])
+        if not self.overlap:
+            self._all_gather(self.recv_img.view(G, -1), self.send_img.view(-1), self.image_group, False)
+            self._work = None
+            if self.row_index is not None:
+                torch.index_select(self.recv_img, 0, self.row_index, out=self.full_img)
+            self._all_gather(self.recv_vis, self.visible, self.group, False)
+            return self.recv_vis.max(dim=0).values
         if self.row_index is not None and self._side is not None:
             self._side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self._side):

@@ -50,10 +50,13 @@ class NormWeightedCompositor(torch.nn.Module):
 
 class SurfaceSplattingRenderer(torch.nn.Module):
     def __init__(self, rasterizer, compositor=None, antialiasing_sigma: float = 1.0, density: float = 1e-4,
-                 frnn_radius=-1, fused: bool = False):
-        """``fused=True`` (not in the reference signature) runs rasterizer + blend as ONE autograd node on
-        the fused kernels (dss_render_forward / dss_render_backward): same images, ~2x fewer launches; the
-        only loss of generality is that gradients w.r.t. ``fragments.zbuf`` are not propagated."""
+                 frnn_radius=-1, fused=None):
+        """``fused`` (not in the reference signature): True runs rasterizer + blend as ONE autograd node on the fused
+        kernels (dss_render_forward / dss_render_backward): same images, ~2x fewer launches; the only loss of generality
+        is that gradients w.r.t. ``fragments.zbuf`` are not propagated.  False keeps rasterizer and blend as separate
+        autograd nodes.  None (default -- what `config.create_renderer` builds from the reference's YAML, which cannot
+        name the argument): fused unless the call asks for the fragments (``verbose=True``), the only way a caller can
+        put a loss on ``fragments.zbuf``."""
         super().__init__()
         self.fused = fused
         self.rasterizer = rasterizer
@@ -74,7 +77,8 @@ class SurfaceSplattingRenderer(torch.nn.Module):
         if point_clouds.isempty():
             return None
         fragments = kwargs.get("fragments", None)
-        if (fragments is None and self.fused and hasattr(self.rasterizer, "render_fused")
+        fused = (not kwargs.get("verbose", False)) if self.fused is None else bool(self.fused)
+        if (fragments is None and fused and hasattr(self.rasterizer, "render_fused")
                 and not self.rasterizer.compacts(kwargs.get("raster_settings"))   # (that mode rebuilds the clouds first: unfused)
                 and self._is_norm_weighted()
                 and (point_clouds.features_packed() is None or point_clouds.features_packed().shape[1] <= 8)  # render_fused: C <= 8
