@@ -8,8 +8,9 @@ already resident in HBM:
 Workload at N=1 = BASELINE.json configs[1]: "bunny ~30k" (bunny-8000 x4 tangent-plane jitter =
 32,684 points), 1 camera, 512x512, K=5, fwd+bwd with grad_out = randn(seed 1) on RGBA.
 For N GPUs the batch holds N cameras (ring, azim = 45 deg * k) and every image is row-partitioned
-across the N ranks (weak scaling: rows x cameras per rank is constant); bands are reassembled with
-an RCCL all-gather and gradient partials are all-reduced.
+across the N ranks (weak scaling: rows x cameras per rank is constant; tile-row-cyclic: rank g renders
+the 8-row tile rows g, g + N, ...); bands are reassembled with an RCCL all-gather and gradient
+partials are all-reduced.
 
 Metric: Msplats/s = (cameras * points per cloud) / step time, whole job.
 """
@@ -169,11 +170,11 @@ class Workload:
                                self.colors, S, K, CUTOFF, THR, SIGMA, False, True, rows=p.rows, workspace_state=0)
         ws = _lib.clean_workspace(dev, ("render_forward_binned", self.N, self.P, S),
                                   lib.dss_render_forward_workspace(self.N, self.P, S, K))
-        r0, r1 = p.rows
+        r0, r1, cyc = ops._band(p.rows, S)
         P_ = _lib.ptr
         valid, vis, img = f["valid"].view(torch.uint8), f["visible"].view(torch.uint8), f["image"]
         args = (P_(self.world), P_(self.normals), None, P_(self.h), None, None, P_(self.M), P_(self.V), P_(self.znear),
-                P_(self.zfar), P_(self.first), P_(self.num), self.N, self.P, 1, 0, S, K, CUTOFF, SIGMA, THR, r0, r1,
+                P_(self.zfar), P_(self.first), P_(self.num), self.N, self.P, 1, 0, S, K, CUTOFF, SIGMA, THR, r0, r1, cyc,
                 P_(self.colors), 3, P_(f["pts_screen"]), P_(f["ellipse_params"]), P_(f["radii"]), P_(f["scaler"]),
                 P_(f["cutoff_threshold"]), P_(valid), P_(f["idx"]), P_(f["zbuf"]), P_(f["qvalue"]), P_(f["occupancy"]),
                 P_(vis), P_(img), int(img.stride(0)), int(img.stride(1)), P_(f["wsum"]), P_(ws), ws.numel(), 2,
@@ -213,8 +214,8 @@ class Workload:
         pts, r = pts[ok], r[ok]
         pairs = 0
         ndc = -1 + (2 * torch.arange(S, device=self.dev, dtype=torch.float32) + 1) / S
-        r0, r1 = p.rows
-        ys = ndc[S - r1:S - r0] if r1 - r0 < S else ndc       # NDC rows of the band (image row r <-> NDC index S-1-r)
+        own = torch.tensor(p.row_indices(), device=self.dev, dtype=torch.int64)   # image rows of this rank's band
+        ys = ndc[S - 1 - own]                                  # their NDC rows (image row r <-> NDC index S-1-r)
         for i in range(0, pts.shape[0], 4096):                 # chunked: (points, S) masks per axis, exact disc count
             q, rr = pts[i:i + 4096], r[i:i + 4096]
             dx2 = (ndc[None, :] - q[:, 0:1]) ** 2
@@ -364,7 +365,11 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
-    part = RowPartition(S, world, rank)
+    # multi-GPU: tile-row-cyclic bands (rank g renders the 8-row tile rows g, g + G, ...: balanced for any scene, equal-size
+    # all-gather) whenever the sizes allow it; BENCH_ROW_PARTITION=bands selects the contiguous equal bands of rounds 1-2
+    cyclic = world > 1 and world & (world - 1) == 0 and S % (8 * world) == 0 and \
+        os.environ.get("BENCH_ROW_PARTITION", "cyclic") == "cyclic"
+    part = RowPartition(S, world, rank, cyclic=cyclic)
     wl = Workload(dev, world, part)
 
     def barrier():
@@ -518,7 +523,7 @@ def main():
     # ---- roofline of the dominant kernel, picked from a per-kernel event-timing pass --------------------------------
     fine_mean, fine_med = wl.fine_kernel_ms()
     gather_ms, bwd_ms, prep_ms, pairs, n_vis = wl.backward_gather_ms()
-    r0, r1 = part.rows
+    r0, r1 = 0, part.n_rows
     # HBM: algorithmic bytes of ONE fine-kernel launch: every pixel of the band writes idx+zbuf+qvalue
     # (12K B) + occ (4 B) + RGBA (16 B) + wsum (4 B); every splat's screen record (pos 12, ellipse 12, radii 8, cutoff 4) +
     # scaler (4) + colour (12) = 52 B is read once.

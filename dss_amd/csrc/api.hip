@@ -50,5 +50,16 @@ extern "C" int dss_set_option(int option, int value)
 }
 extern "C" int dss_get_option(int option) { return dss::option(option); }
 
+// rows a band tensor has: the rows of [row0, row1) for a contiguous band; with row_cycle c > 1 the rows of every c-th
+// 8-row tile row of [row0, row1), starting at row0
+extern "C" int dss_band_rows(int row0, int row1, int row_cycle)
+{
+    if (row1 <= row0) return 0;
+    if (row_cycle <= 1) return row1 - row0;
+    const int span = row1 - row0, period = 8 * row_cycle;
+    const int full = span / period, rem = span - full * period;
+    return full * 8 + (rem < 8 ? rem : 8);
+}
+
 extern "C" int dss_version(void) { return DSS_HIP_VERSION; }
 extern "C" const char *dss_last_error(void) { return dss::g_err; }

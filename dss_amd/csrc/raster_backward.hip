@@ -712,6 +712,26 @@ __global__ __launch_bounds__(PREP_THREADS) void median_visible_kernel(
     if (tid == 0) rs[n] = key_float(prefix) * radii_s;
 }
 
+// Band-local row <-> image row of a (possibly tile-row-cyclic) band, see TileGrid::tshift in raster_forward.hip:
+// image row of band row l = row0 + ((l >> 3) << tshift) + (l & 7); contiguous band: tshift = 3, i.e. row0 + l.
+__device__ __forceinline__ int band_image_row(int l, int row0, int tshift) { return row0 + ((l >> 3) << tshift) + (l & 7); }
+// smallest band row whose image row is >= r (may equal `rows`: none)
+__device__ __forceinline__ int band_row_ceil(int r, int row0, int tshift)
+{
+    const int x = r - row0;
+    if (x <= 0) return 0;
+    const int q = x >> tshift, m = x & ((1 << tshift) - 1);
+    return m < 8 ? 8 * q + m : 8 * (q + 1);
+}
+// largest band row whose image row is <= r (-1: none)
+__device__ __forceinline__ int band_row_floor(int r, int row0, int tshift)
+{
+    const int x = r - row0;
+    if (x < 0) return -1;
+    const int q = x >> tshift, m = x & ((1 << tshift) - 1);
+    return 8 * q + min(m, 7);
+}
+
 // Row band (multi-GPU), after the median: drop the visible points that cannot reach this rank's rows from the
 // segment lists, in place (one workgroup per segment: all entries are read into registers before any is
 // written), and zero their gradient rows (this band's partial sum for them is zero).  Same conservative test
@@ -722,14 +742,16 @@ __global__ __launch_bounds__(PREP_THREADS) void band_filter_kernel(
     const float *__restrict__ points, const float *__restrict__ radii, const float *__restrict__ rs,
     const int64_t *__restrict__ first_idx, const int64_t *__restrict__ num_pts, int N, int S, int row0, int rows,
     uint32_t *__restrict__ seg_count, int32_t *__restrict__ vis_list, float *__restrict__ grad_pts,
-    float *__restrict__ grad_feat, int C)
+    float *__restrict__ grad_feat, int C, int tshift)
 {
     __shared__ uint32_t s_w[PER * PREP_THREADS / 64];
     constexpr int SEG_PTS = PER * PREP_THREADS;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const unsigned seg = blockIdx.x;
     const uint32_t count = seg_count[seg];
-    const float band_lo = -1 + (2 * (S - row0 - rows)) / (float)S;      // lower edge of the lowest pixel row
+    // (tile-row-cyclic band: the last band row's image row bounds the band from below; the owned-row test follows)
+    const int last_row = row0 + (((rows - 1) >> 3) << tshift) + ((rows - 1) & 7);
+    const float band_lo = -1 + (2 * (S - 1 - last_row)) / (float)S;     // lower edge of the lowest pixel row
     const float band_hi = -1 + (2 * (S - 1 - row0) + 2.0f) / (float)S;  // upper edge of the highest one
     int32_t id[PER];
     uint32_t keep = 0;
@@ -744,7 +766,13 @@ __global__ __launch_bounds__(PREP_THREADS) void band_filter_kernel(
             const int n = find_cloud(id[u], first_idx, num_pts, N);
             const float py = points[3 * (size_t)id[u] + 1], ry = radii[2 * (size_t)id[u] + 1];
             const float reach = fmaxf(n >= 0 ? rs[n] : 0.0f, ry);
-            const bool in_band = n >= 0 && !(py + reach < band_lo || py - reach > band_hi);
+            bool in_band = n >= 0 && !(py + reach < band_lo || py - reach > band_hi);
+            if (in_band && tshift > 3) {
+                // cyclic band: some OWNED row must lie within reach (conservative pixel range, one pixel of slack each side)
+                int ylo, yhi;
+                in_band = ndc_index_range(py, reach, S, ylo, yhi) &&
+                          band_row_ceil(S - 1 - yhi, row0, tshift) <= min(band_row_floor(S - 1 - ylo, row0, tshift), rows - 1);
+            }
             keep |= (in_band ? 1u : 0u) << u;
         }
     }
@@ -966,7 +994,9 @@ __device__ __forceinline__ int tasks_max(int v)
     return m;
 }
 
-template <int C, bool SEG, int TPW, bool A32>
+// CYC: tile-row-cyclic band (tshift > 3): the windows are walked in BAND rows (the owned rows of a window are a
+// contiguous range of band rows), the NDC y of each comes from band_image_row.  CYC = false is the contiguous band.
+template <int C, bool SEG, int TPW, bool A32, bool CYC = false>
 __global__ __launch_bounds__(256) void render_backward_kernel(
     const float *__restrict__ grad_out, const float *__restrict__ grad_alpha /* dense (N,rows,S) */,
     const int32_t *__restrict__ idx, const float *__restrict__ qv,
@@ -974,7 +1004,7 @@ __global__ __launch_bounds__(256) void render_backward_kernel(
     const float *__restrict__ radii, const float *__restrict__ rs, const int64_t *__restrict__ first_idx,
     const int64_t *__restrict__ num_pts, const uint32_t *__restrict__ vis_count,
     const int32_t *__restrict__ vis_list, int n_seg, int seg_pts, int N, int S, int K, int Crt, float clip, int row0,
-    int rows, uint32_t large_waves, float *__restrict__ grad_feat, float *__restrict__ grad_pts)
+    int rows, uint32_t large_waves, float *__restrict__ grad_feat, float *__restrict__ grad_pts, int tshift = 3)
 {
     constexpr int CM = (C > 0) ? C : BLEND_MAX_C;
     constexpr int KF = 8;            // fragment slots held in registers; deeper lists take the loop
@@ -1077,12 +1107,22 @@ __global__ __launch_bounds__(256) void render_backward_kernel(
         int xlo = 0, xhi = -1, ylo = 0, yhi = -1;
         bool o_ok = n >= 0 && !(pz < 0 || fabsf(py) > 1.0f || fabsf(px) > 1.0f) &&
                     ndc_index_range_tight(px, cur_r, S, xlo, xhi) && ndc_index_range_tight(py, cur_r, S, ylo, yhi);
+        int l_hi = -1;   // CYC: band row of window row 0 (the window's rows are band rows l_hi, l_hi - 1, ..., l_hi - oh + 1)
         if (o_ok) {
-            ylo = max(ylo, S - row0 - rows);
-            yhi = min(yhi, S - 1 - row0);
-            o_ok = ylo <= yhi;
+            if (CYC) {
+                // image rows S-1-yhi .. S-1-ylo -> the band rows among them
+                const int l_lo = band_row_ceil(S - 1 - yhi, row0, tshift);
+                l_hi = min(band_row_floor(S - 1 - ylo, row0, tshift), rows - 1);
+                o_ok = l_lo <= l_hi;
+                ylo = 0;
+                yhi = l_hi - l_lo;   // (only yhi - ylo + 1 = the number of window rows is used below)
+            } else {
+                ylo = max(ylo, S - row0 - rows);
+                yhi = min(yhi, S - 1 - row0);
+                o_ok = ylo <= yhi;
+            }
         }
-        if (!o_ok) { xlo = 0; xhi = -1; ylo = 0; yhi = -1; }
+        if (!o_ok) { xlo = 0; xhi = -1; ylo = 0; yhi = -1; l_hi = 0; }
         const int ow = xhi - xlo + 1, oh = yhi - ylo + 1;          // 0 for an empty window
         const int ncp = (tasks_max<TPW>(ow) + 31) >> 5;             // column-slot pairs: wave-uniform
         const int nrow = (tasks_max<TPW>(oh) + RP - 1) / RP;        // rows per lane row: wave-uniform
@@ -1099,8 +1139,9 @@ __global__ __launch_bounds__(256) void render_backward_kernel(
             // "g > 0 and outside the splat's box": with ry_eff = -1 for out-of-box columns the row test alone decides
             const f2 ry_eff = {(fabsf(dx.x) > rx) ? -1.0f : ry, (fabsf(dx.y) > rx) ? -1.0f : ry};
             // image (row, col) of NDC (y, x) is (S-1-y, S-1-x); band row = S-1-y-row0: one image row up per NDC row
-            const int i0 = (S - 1 - row0 - max(ylo, 0)) * S + (S - 1 - x0c);  // element offsets in the camera's plane
-            const int i1 = (S - 1 - row0 - max(ylo, 0)) * S + (S - 1 - x1c);
+            const int top = CYC ? max(l_hi, 0) : (S - 1 - row0 - max(ylo, 0));   // band row of window row 0
+            const int i0 = top * S + (S - 1 - x0c);  // element offsets in the camera's plane
+            const int i1 = top * S + (S - 1 - x1c);
             // RB rows per trip: all their loads are issued before the first is used (one memory round trip per trip; a
             // row-at-a-time loop spent ~1 us per ROW waiting)
             constexpr int RB = 8;
@@ -1142,7 +1183,9 @@ __global__ __launch_bounds__(256) void render_backward_kernel(
 #pragma unroll
                 for (int u = 0; u < RB; ++u) {
                     if (ib + u >= nrow) break;  // uniform
-                    const float yv = POW2 ? y_ib + (float)u * y_step : ndc(ylo + rp + RP * (ib + u));
+                    // CYC: window row i is band row l_hi - i; its image row comes from the band map
+                    const float yv = CYC ? ndc(S - 1 - band_image_row(max(l_hi - (rp + RP * (ib + u)), 0), row0, tshift))
+                                         : (POW2 ? y_ib + (float)u * y_step : ndc(ylo + rp + RP * (ib + u)));
                     const float dy = yv - py;
                     const float dy2 = dy * dy;
                     const f2 gg = {g0[u], g1[u]};
@@ -1171,12 +1214,21 @@ __global__ __launch_bounds__(256) void render_backward_kernel(
         if (grad_feat != nullptr) {
             int bxlo = 0, bxhi = -1, bylo = 0, byhi = -1;
             bool b_ok = n >= 0 && ndc_index_range_tight(px, rx, S, bxlo, bxhi) && ndc_index_range_tight(py, ry, S, bylo, byhi);
+            int bl_hi = 0;   // CYC: band row of box row bylo (box rows are band rows bl_hi, bl_hi - 1, ...)
             if (b_ok) {
-                bylo = max(bylo, S - row0 - rows);
-                byhi = min(byhi, S - 1 - row0);
-                b_ok = bylo <= byhi;
+                if (CYC) {
+                    const int bl_lo = band_row_ceil(S - 1 - byhi, row0, tshift);
+                    bl_hi = min(band_row_floor(S - 1 - bylo, row0, tshift), rows - 1);
+                    b_ok = bl_lo <= bl_hi;
+                    bylo = 0;
+                    byhi = bl_hi - bl_lo;
+                } else {
+                    bylo = max(bylo, S - row0 - rows);
+                    byhi = min(byhi, S - 1 - row0);
+                    b_ok = bylo <= byhi;
+                }
             }
-            if (!b_ok) { bxlo = 0; bxhi = -1; bylo = 0; byhi = -1; }
+            if (!b_ok) { bxlo = 0; bxhi = -1; bylo = 0; byhi = -1; bl_hi = 0; }
             // a lane row = one patch of 16 pixels; the task's RP lane rows take patches rp, rp + RP, ... of its box (row-major,
             // ptx patches per row), all tasks in a common loop over the largest box
             // patch shape: 4 x 4 pixels per lane row -- 8 x 2 when a task has ONE lane row (TPW = 4): a 5..7-pixel box then
@@ -1195,7 +1247,7 @@ __global__ __launch_bounds__(256) void render_backward_kernel(
                     // 32-bit byte offsets from the tensor bases, unconditional loads from pixel 0 of the camera for the
                     // lanes outside the box (masked by `on` below)
                     const bool on = !(pi_ >= ptx * pty || xi > bxhi || yi > byhi);
-                    const uint32_t pix32 = on ? ((uint32_t)nn * (uint32_t)rows + (uint32_t)(S - 1 - yi - row0)) * (uint32_t)S +
+                    const uint32_t pix32 = on ? ((uint32_t)nn * (uint32_t)rows + (uint32_t)(CYC ? bl_hi - yi : S - 1 - yi - row0)) * (uint32_t)S +
                                                     (uint32_t)(S - 1 - xi)
                                               : (uint32_t)nn * (uint32_t)plane;
                     const uint32_t oK = pix32 * (uint32_t)K * 4u, oC = pix32 * (uint32_t)(Cn + 1) * 4u;
@@ -1225,7 +1277,7 @@ __global__ __launch_bounds__(256) void render_backward_kernel(
                     continue;
                 }
                 if (pi_ >= ptx * pty || xi > bxhi || yi > byhi) continue;
-                const size_t pix = ((size_t)nn * rows + (S - 1 - yi - row0)) * S + (S - 1 - xi);
+                const size_t pix = ((size_t)nn * rows + (CYC ? bl_hi - yi : S - 1 - yi - row0)) * S + (S - 1 - xi);
                 const int32_t *pi = idx + pix * K;
                 const float *pq = qv + pix * K;
                 const float *go = grad_out + pix * (Cn + 1);
@@ -1545,14 +1597,20 @@ extern "C" size_t dss_render_backward_workspace(int N, int64_t P, int S)
 static int render_backward_impl(bool run_prep, const float *grad_out, const int32_t *idx, const float *qvalue, const float *wsum,
                                 const float *scaler, const float *points, const float *radii,
                                 const uint8_t *visible, const int64_t *first_idx, const int64_t *num_pts, int N,
-                                int64_t P, int S, int K, int C, int row0, int row1, float radii_s, float clip,
+                                int64_t P, int S, int K, int C, int row0, int row1, int row_cycle, float radii_s, float clip,
                                 float *grad_feat, float *grad_pts, float *rs_out, void *workspace,
                                 size_t workspace_bytes, void *stream)
 {
-    if (N <= 0 || P < 0 || S <= 0 || K <= 0 || C < 1 || C > BLEND_MAX_C || row0 < 0 || row1 > S || row0 >= row1) {
-        set_error("dss_render_backward: bad sizes N=%d P=%lld S=%d K=%d C=%d", N, (long long)P, S, K, C);
+    if (N <= 0 || P < 0 || S <= 0 || K <= 0 || C < 1 || C > BLEND_MAX_C || row0 < 0 || row1 > S || row0 >= row1 ||
+        row_cycle < 1 || (row_cycle & (row_cycle - 1)) || row_cycle > 4096) {
+        set_error("dss_render_backward: bad sizes N=%d P=%lld S=%d K=%d C=%d rows=[%d,%d) cycle %d", N, (long long)P, S, K, C,
+                  row0, row1, row_cycle);
         return DSS_ERR_INVALID_ARGUMENT;
     }
+    const int rows = dss_band_rows(row0, row1, row_cycle);   // band-local rows
+    int tshift = 3;
+    for (int c = row_cycle; c > 1; c >>= 1) ++tshift;
+    const bool cyc = row_cycle > 1;
     if (P == 0) return DSS_OK;
     if (P > 0x7ffffff0ll) { set_error("dss_render_backward: P too large"); return DSS_ERR_UNSUPPORTED; }
     if (!grad_out || !points || !radii || !visible || !first_idx || !num_pts || !grad_pts ||
@@ -1572,7 +1630,7 @@ static int render_backward_impl(bool run_prep, const float *grad_out, const int3
     uint32_t *vis_count;  // small: PREP_MAX_SEG per-segment counters; otherwise one global counter
     int32_t *vis_list;
     float *rs;
-    const size_t npix = (size_t)N * (row1 - row0) * S;
+    const size_t npix = (size_t)N * rows * S;
     const float *alpha;
     if (((uintptr_t)grad_out & 15u) && C == 3) { set_error("dss_render_backward: grad_out must be 16-byte aligned"); return DSS_ERR_INVALID_ARGUMENT; }
     if (small) {
@@ -1585,13 +1643,13 @@ static int render_backward_impl(bool run_prep, const float *grad_out, const int3
         rs = rs_out ? rs_out : reinterpret_cast<float *>(w + L.rs);
         if (run_prep)
             launch_prep(radii, visible, first_idx, num_pts, N, P, radii_s, rs, w, L, grad_pts, grad_feat, C, grad_out, npix, st);
-        if (run_prep && row1 - row0 < S) {  // row band: keep only the points that can reach it
+        if (run_prep && rows < S) {  // row band: keep only the points that can reach it
             if (L.per == 2)
                 hipLaunchKernelGGL(band_filter_kernel<2>, dim3(L.chunks), dim3(PREP_THREADS), 0, st, points, radii, rs,
-                                   first_idx, num_pts, N, S, row0, row1 - row0, vis_count, vis_list, grad_pts, grad_feat, C);
+                                   first_idx, num_pts, N, S, row0, rows, vis_count, vis_list, grad_pts, grad_feat, C, tshift);
             else
                 hipLaunchKernelGGL(band_filter_kernel<4>, dim3(L.chunks), dim3(PREP_THREADS), 0, st, points, radii, rs,
-                                   first_idx, num_pts, N, S, row0, row1 - row0, vis_count, vis_list, grad_pts, grad_feat, C);
+                                   first_idx, num_pts, N, S, row0, rows, vis_count, vis_list, grad_pts, grad_feat, C, tshift);
         }
     } else {
         const size_t hist_bytes = (size_t)3 * N * MED_BINS * 4;
@@ -1680,10 +1738,10 @@ static int render_backward_impl(bool run_prep, const float *grad_out, const int3
 #define DSS_LAUNCH_RB_A(CC, SS, TT, AA)                                                                                 \
     hipLaunchKernelGGL((render_backward_kernel<CC, SS, TT, AA>), dim3(pgrid), dim3(256), 0, st, grad_out, alpha, idx, qvalue, wsum, \
                        scaler, points, radii, rs, first_idx, num_pts, vis_count, vis_list, n_seg, seg_pts, N, S, K, C, clip, \
-                       row0, row1 - row0, large_waves, grad_feat, grad_pts)
+                       row0, rows, large_waves, grad_feat, grad_pts)
     // 32-bit byte offsets from the tensor bases (one VALU per gather address instead of 64-bit index arithmetic) whenever
     // every gathered tensor is smaller than 4 GB; larger problems take the 64-bit addressing, four tasks per wavefront
-    const unsigned long long widest = (unsigned long long)N * (unsigned long long)(row1 - row0) * (unsigned long long)S *
+    const unsigned long long widest = (unsigned long long)N * (unsigned long long)rows * (unsigned long long)S *
                                       (unsigned long long)(K > C + 1 ? K : C + 1) * 4ull;
     // (DSS_OPT_BACKWARD_ADDR64 forces the 64-bit variant: it only exists for tensors nobody allocates in a test)
     const bool a32 = widest < (1ull << 32) && option(DSS_OPT_BACKWARD_ADDR64) != 1;
@@ -1694,7 +1752,20 @@ static int render_backward_impl(bool run_prep, const float *grad_out, const int3
         if (!a32) DSS_LAUNCH_RB_A(CC, SS, 4, false);                                                                   \
         else if (tpw == 4) DSS_LAUNCH_RB(CC, SS, 4); else if (tpw == 2) DSS_LAUNCH_RB(CC, SS, 2); else DSS_LAUNCH_RB(CC, SS, 1); \
     } while (0)
-    if (C == 3) {
+    if (cyc) {
+        // tile-row-cyclic band (multi-GPU): built for the training configuration (RGB features, 32-bit offsets)
+        if (C != 3 || !a32) {
+            set_error("dss_render_backward: a tile-row-cyclic band needs C == 3 and gathered tensors below 4 GB");
+            return DSS_ERR_UNSUPPORTED;
+        }
+#define DSS_LAUNCH_RB_C(SS, TT)                                                                                          \
+    hipLaunchKernelGGL((render_backward_kernel<3, SS, TT, true, true>), dim3(pgrid), dim3(256), 0, st, grad_out, alpha, idx, qvalue, \
+                       wsum, scaler, points, radii, rs, first_idx, num_pts, vis_count, vis_list, n_seg, seg_pts, N, S, K, C, clip, \
+                       row0, rows, large_waves, grad_feat, grad_pts, tshift)
+        if (small) { if (tpw == 4) DSS_LAUNCH_RB_C(true, 4); else if (tpw == 2) DSS_LAUNCH_RB_C(true, 2); else DSS_LAUNCH_RB_C(true, 1); }
+        else { if (tpw == 4) DSS_LAUNCH_RB_C(false, 4); else if (tpw == 2) DSS_LAUNCH_RB_C(false, 2); else DSS_LAUNCH_RB_C(false, 1); }
+#undef DSS_LAUNCH_RB_C
+    } else if (C == 3) {
         if (small) DSS_LAUNCH_RB_T(3, true); else DSS_LAUNCH_RB_T(3, false);
     } else {
         if (small) DSS_LAUNCH_RB_T(0, true); else DSS_LAUNCH_RB_T(0, false);
@@ -1708,12 +1779,12 @@ static int render_backward_impl(bool run_prep, const float *grad_out, const int3
 extern "C" int dss_render_backward(const float *grad_out, const int32_t *idx, const float *qvalue, const float *wsum,
                                    const float *scaler, const float *points, const float *radii,
                                    const uint8_t *visible, const int64_t *first_idx, const int64_t *num_pts, int N,
-                                   int64_t P, int S, int K, int C, int row0, int row1, float radii_s, float clip,
+                                   int64_t P, int S, int K, int C, int row0, int row1, int row_cycle, float radii_s, float clip,
                                    float *grad_feat, float *grad_pts, float *rs_out, void *workspace,
                                    size_t workspace_bytes, void *stream)
 {
     return render_backward_impl(true, grad_out, idx, qvalue, wsum, scaler, points, radii, visible, first_idx, num_pts, N, P, S,
-                                K, C, row0, row1, radii_s, clip, grad_feat, grad_pts, rs_out, workspace, workspace_bytes, stream);
+                                K, C, row0, row1, row_cycle, radii_s, clip, grad_feat, grad_pts, rs_out, workspace, workspace_bytes, stream);
 }
 
 // Second stage alone (the persistent gather kernel), on the workspace (visible lists, alpha plane, rs) and the zero-filled
@@ -1721,12 +1792,12 @@ extern "C" int dss_render_backward(const float *grad_out, const int32_t *idx, co
 extern "C" int dss_render_backward_gather(const float *grad_out, const int32_t *idx, const float *qvalue, const float *wsum,
                                           const float *scaler, const float *points, const float *radii,
                                           const uint8_t *visible, const int64_t *first_idx, const int64_t *num_pts, int N,
-                                          int64_t P, int S, int K, int C, int row0, int row1, float radii_s, float clip,
+                                          int64_t P, int S, int K, int C, int row0, int row1, int row_cycle, float radii_s, float clip,
                                           float *grad_feat, float *grad_pts, float *rs_out, void *workspace,
                                           size_t workspace_bytes, void *stream)
 {
     return render_backward_impl(false, grad_out, idx, qvalue, wsum, scaler, points, radii, visible, first_idx, num_pts, N, P, S,
-                                K, C, row0, row1, radii_s, clip, grad_feat, grad_pts, rs_out, workspace, workspace_bytes, stream);
+                                K, C, row0, row1, row_cycle, radii_s, clip, grad_feat, grad_pts, rs_out, workspace, workspace_bytes, stream);
 }
 
 #ifdef DSS_FINE_TIMING

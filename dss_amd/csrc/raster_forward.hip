@@ -83,10 +83,16 @@ struct Spill {
 struct TileGrid {
     int S;        // image side
     int row0;     // first image row of the band
-    int rows;     // rows in the band
+    int rows;     // rows in the band (band-local rows: the band tensors have this many rows)
     int tiles_x;  // tiles per band row
     int tiles_y;  // tile rows in the band
+    int tshift;   // log2 of the image-row distance of two consecutive band tile rows: 3 for a contiguous band; 3 + log2(c)
+                  // for a tile-row-CYCLIC band (multi-GPU: a rank owns every c-th 8-row tile row starting at row0, so that
+                  // every rank gets the same mix of dense and empty screen regions).  Band-local row l <-> image row
+                  // row0 + ((l >> 3) << tshift) + (l & 7).
 };
+// first image row of band tile row ty
+__host__ __device__ __forceinline__ int tile_row0(const TileGrid &g, int ty) { return g.row0 + (ty << g.tshift); }
 
 // Super-block (i, j) of camera n goes to XCD (i + 3 j + 5 n) mod 8: neighbours in a row differ by 1, in a column by 3, so
 // any compact screen region is spread evenly over the XCDs (the first version dealt the 64x64-pixel super-blocks of a
@@ -142,14 +148,18 @@ __device__ __forceinline__ bool splat_tile_rect(float px, float py, float pz, fl
     if (xlo > xhi || ylo > yhi) return false;
     const int c0 = g.S - 1 - xhi, c1 = g.S - 1 - xlo;
     int r0 = g.S - 1 - yhi, r1 = g.S - 1 - ylo;
+    // band tile rows whose 8 image rows [R, R + 7], R = row0 + (ty << tshift), meet [r0, r1] (contiguous band, tshift = 3:
+    // ty = (r - row0) / 8 as before; the last tile row of a band may be short: rows beyond g.rows are never stored)
     r0 = max(r0, g.row0);
-    r1 = min(r1, g.row0 + g.rows - 1);
+    r1 = min(r1, tile_row0(g, g.tiles_y - 1) + (g.rows - 1 - (g.tiles_y - 1) * DSS_TILE));   // last image row of the band
     if (r0 > r1) return false;
     tx0 = c0 / DSS_TILE;
     tx1 = c1 / DSS_TILE;
-    ty0 = (r0 - g.row0) / DSS_TILE;
-    ty1 = (r1 - g.row0) / DSS_TILE;
-    return true;
+    const int step = 1 << g.tshift;
+    ty0 = (r0 - g.row0 - (DSS_TILE - 1) + step - 1) >> g.tshift;   // ceil((r0 - row0 - 7) / step), numerator + step - 1 >= 0
+    ty0 = max(ty0, 0);
+    ty1 = min((r1 - g.row0) >> g.tshift, g.tiles_y - 1);
+    return ty0 <= ty1;
 }
 
 // First entry of one of the tile's sub-lists: claim the tile (at most DSS_SUB threads per tile get here, exactly one
@@ -485,14 +495,14 @@ __device__ __forceinline__ void fine_tile(const FineArgs &A, const int tile_id, 
     const int fx = wid % FOOT_PER_ROW, fy = wid / FOOT_PER_ROW;  // footprint inside the tile
     const int pl = lane >> 2, slice = lane & 3;       // pixel inside the footprint, candidate slice
     const int tr = fy * FOOT + (pl >> 2), tc = fx * FOOT + (pl & 3);
-    const int r = g.row0 + ty * DSS_TILE + tr;        // image row
+    const int r = tile_row0(g, ty) + tr;              // image row
     const int c = tx * DSS_TILE + tc;                 // image col
     const int S = g.S;
     const NdcMap ndc(S);  // same values as pix_to_ndc; one multiply instead of an IEEE divide when S = 2^k
     const float xf = ndc(S - 1 - c);
     const float yf = ndc(S - 1 - r);
     // NDC extent of this wavefront's footprint (pixel centres).  NDC decreases with the image index.
-    const int fc0 = tx * DSS_TILE + fx * FOOT, fr0 = g.row0 + ty * DSS_TILE + fy * FOOT;
+    const int fc0 = tx * DSS_TILE + fx * FOOT, fr0 = tile_row0(g, ty) + fy * FOOT;
     const float f_xmax = ndc(S - 1 - fc0), f_xmin = ndc(S - 1 - (fc0 + 3));
     const float f_ymax = ndc(S - 1 - fr0), f_ymin = ndc(S - 1 - (fr0 + 3));
 
@@ -724,9 +734,9 @@ __device__ __forceinline__ void fine_tile(const FineArgs &A, const int tile_id, 
     asm volatile("" : "+v"(tid_e));
     const int lane_e = tid_e & 63, wid_e = tid_e >> 6, pl_e = lane_e >> 2;
     const int tr_e = (wid_e / FOOT_PER_ROW) * FOOT + (pl_e >> 2), tc_e = (wid_e % FOOT_PER_ROW) * FOOT + (pl_e & 3);
-    const int r_e = g.row0 + ty * DSS_TILE + tr_e, c_e = tx * DSS_TILE + tc_e;
+    const int lr_e = ty * DSS_TILE + tr_e, c_e = tx * DSS_TILE + tc_e;   // band-local row, image column
     const bool owner = (lane_e & 3) == 0;
-    const bool in_img = owner && (c_e < S) && (r_e < g.row0 + g.rows);
+    const bool in_img = owner && (c_e < S) && (lr_e < g.rows);
     float kz[KMAX];
     int ki[KMAX];
     const float z0 = __uint_as_float((unsigned)(key[0] >> 32));
@@ -741,7 +751,7 @@ __device__ __forceinline__ void fine_tile(const FineArgs &A, const int tile_id, 
         kz[k] = alive ? z : -1.0f;
         kq[k] = alive ? kq[k] : -1.0f;
     }
-    const size_t pix = ((size_t)n * g.rows + (r_e - g.row0)) * S + c_e;
+    const size_t pix = ((size_t)n * g.rows + lr_e) * S + c_e;
     // blend inputs of the pixel's fragments (scaler + three feature channels): requested BEFORE the tile is staged
     // and streamed out, consumed after -- the gather's round trip is hidden behind the LDS transpose and the stores
     constexpr bool PREFETCH_BLEND = false;  // (+20 VGPRs: 110 in total = 4 workgroups per CU; measured slower)
@@ -796,7 +806,7 @@ __device__ __forceinline__ void fine_tile(const FineArgs &A, const int tile_id, 
         const float inv_cum = fast_rcp(cum);
 #pragma unroll
         for (int k = 0; k < KMAX; ++k) wk[k] = wk[k] * inv_cum;
-        float *o = A.image + (size_t)n * A.img_sn + (size_t)(r_e - g.row0) * A.img_sr + (size_t)c_e * (A.C + 1);
+        float *o = A.image + (size_t)n * A.img_sn + (size_t)lr_e * A.img_sr + (size_t)c_e * (A.C + 1);
         if (A.C == 3) {
             // RGBA as ONE 16-byte store per pixel (four dword stores at a 16-byte stride quadruple the
             // write requests the memory side sees)
@@ -944,7 +954,8 @@ __global__ __launch_bounds__(64) void fine_generic_kernel(const FineArgs A)
     const int t = tile_id - n * tiles;
     const int ty = t / g.tiles_x, tx = t - ty * g.tiles_x;
     const int lane = threadIdx.x;
-    const int r = g.row0 + ty * DSS_TILE + (lane >> 3);
+    const int lr = ty * DSS_TILE + (lane >> 3);   // band-local row
+    const int r = tile_row0(g, ty) + (lane >> 3);
     const int c = tx * DSS_TILE + (lane & 7);
     const int S = g.S, K = A.K;
     const float xf = pix_to_ndc(S - 1 - c, S);
@@ -990,8 +1001,8 @@ __global__ __launch_bounds__(64) void fine_generic_kernel(const FineArgs A)
     } else {
         for (int64_t j = 0; j < npts; ++j) visit(first + j);
     }
-    if (c >= S || r >= g.row0 + g.rows) return;
-    const size_t pix = ((size_t)n * g.rows + (r - g.row0)) * S + c;
+    if (c >= S || lr >= g.rows) return;
+    const size_t pix = ((size_t)n * g.rows + lr) * S + c;
     A.occ[pix] = cnt > 0 ? 1.0f : 0.0f;
     const float z0 = cnt > 0 ? __uint_as_float((unsigned)(key[0] >> 32)) : 0.0f;
     bool alive = cnt > 0;
@@ -1092,14 +1103,17 @@ static uint32_t spill_capacity(int64_t P)
     return (uint32_t)(c < 0x7fffff00ll ? c : 0x7fffff00ll);
 }
 
-static TileGrid make_grid(int S, int row0, int row1)
+// band of image rows [row0, row1); row_cycle c > 1: only every c-th 8-row tile row of it, starting at row0 (c a power of two)
+static TileGrid make_grid(int S, int row0, int row1, int row_cycle = 1)
 {
     TileGrid g;
     g.S = S;
     g.row0 = row0;
-    g.rows = row1 - row0;
+    g.rows = dss_band_rows(row0, row1, row_cycle);
     g.tiles_x = (S + DSS_TILE - 1) / DSS_TILE;
     g.tiles_y = (g.rows + DSS_TILE - 1) / DSS_TILE;
+    g.tshift = 3;
+    for (int c = row_cycle; c > 1; c >>= 1) ++g.tshift;
     return g;
 }
 
@@ -1165,8 +1179,12 @@ extern "C" size_t dss_splat_forward_clean_bytes(int N, int64_t P, int S)
     return carve_fwd(nullptr, N, P, S).count_bytes;
 }
 
-static int validate_fwd(const char *fn, int N, int64_t P, int S, int K, int row0, int row1)
+static int validate_fwd(const char *fn, int N, int64_t P, int S, int K, int row0, int row1, int row_cycle = 1)
 {
+    if (row_cycle < 1 || (row_cycle & (row_cycle - 1)) || row_cycle > 4096) {
+        set_error("%s: row_cycle %d must be a power of two (1 = contiguous band)", fn, row_cycle);
+        return DSS_ERR_INVALID_ARGUMENT;
+    }
     if (N <= 0 || P < 0 || S <= 0 || K <= 0) {
         set_error("%s: N=%d P=%lld S=%d K=%d must be positive", fn, N, (long long)P, S, K);
         return DSS_ERR_INVALID_ARGUMENT;
@@ -1337,14 +1355,14 @@ extern "C" int dss_render_forward(const float *world, const float *normals, cons
                                   const float *vr6, const float *frame_normals, const float *M, const float *V, const float *znear, const float *zfar,
                                   const int64_t *first_idx, const int64_t *num_pts, int N, int64_t P, int shared_cloud,
                                   int backface_culling, int S, int K, float cutoff_threshold, float antialiasing_sigma,
-                                  float merge_thr, int row0, int row1, const float *feat, int C,
+                                  float merge_thr, int row0, int row1, int row_cycle, const float *feat, int C,
                                   float *pts_screen, float *ellipse, float *radii, float *scaler, float *cutoff,
                                   uint8_t *valid, int32_t *idx, float *zbuf, float *qvalue, float *occ,
                                   uint8_t *visible, float *image, int64_t image_cam_stride, int64_t image_row_stride,
                                   float *wsum, void *workspace, size_t workspace_bytes, int workspace_state,
                                   void *stream)
 {
-    int rc = validate_fwd("dss_render_forward", N, P, S, K, row0, row1);
+    int rc = validate_fwd("dss_render_forward", N, P, S, K, row0, row1, row_cycle);
     if (rc) return rc;
     if (K > DSS_MAX_K_FAST) {
         set_error("dss_render_forward: fused path needs points_per_pixel <= %d (use the separate entry points)",
@@ -1368,7 +1386,7 @@ extern "C" int dss_render_forward(const float *world, const float *normals, cons
         return DSS_ERR_WORKSPACE;
     }
     hipStream_t st = as_stream(stream);
-    const TileGrid g = make_grid(S, row0, row1);
+    const TileGrid g = make_grid(S, row0, row1, row_cycle);
     const int tiles = g.tiles_x * g.tiles_y;
     if ((long long)N * tiles > 0x7fffffffll) { set_error("dss_render_forward: too many tiles"); return DSS_ERR_UNSUPPORTED; }
     FwdWorkspace w = carve_fwd(workspace, N, P, S, true);

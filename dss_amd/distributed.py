@@ -19,15 +19,36 @@ import torch.distributed as dist
 
 
 class RowPartition:
-    """Band of image rows owned by ``rank``.  By default the bands are equal (``S`` rounded up to a multiple of
-    ``world_size``; the last band may be shorter) so that one fixed-size all-gather reassembles them.  With
-    ``bounds`` (``world_size + 1`` non-decreasing row indices from 0 to S, see ``balanced_bounds``) the bands
-    follow the load instead; ``band`` is then the largest band (the padded exchange size)."""
+    """Image rows owned by ``rank``.  Three layouts:
 
-    def __init__(self, image_size: int, world_size: int = 1, rank: int = 0, bounds=None):
+    * equal bands (default): ``S`` rounded up to a multiple of ``world_size``; the last band may be shorter; one
+      fixed-size all-gather reassembles them;
+    * ``bounds`` (``world_size + 1`` non-decreasing row indices from 0 to S, see ``balanced_bounds``): contiguous bands
+      that follow a load estimate; ``band`` is then the largest band (the padded exchange size);
+    * ``cyclic=True``: TILE-ROW-CYCLIC -- rank g owns the 8-row tile rows g, g + G, g + 2G, ... (``world_size`` a power
+      of two).  Every rank gets the same mix of dense and empty screen regions, so the per-rank load is balanced for
+      any scene without a load estimate, the bands have equal size when ``S`` is a multiple of ``8 * world_size`` (one
+      fixed-size all-gather, no padding; otherwise they differ by at most one tile row and travel padded to ``band``),
+      and nothing has to be re-balanced when the object moves.  ``rows`` is then
+      the triple ``(8 * rank, S, world_size)`` the fused entry points take (``row_cycle``, include/dss_hip.h); band
+      tensors hold the owned rows in image order."""
+
+    def __init__(self, image_size: int, world_size: int = 1, rank: int = 0, bounds=None, cyclic: bool = False):
         if not (0 <= rank < world_size):
             raise ValueError("rank %d outside world of %d" % (rank, world_size))
         self.S, self.world_size, self.rank = int(image_size), int(world_size), int(rank)
+        self.cyclic = bool(cyclic) and self.world_size > 1
+        if self.cyclic:
+            G = self.world_size
+            if bounds is not None:
+                raise ValueError("cyclic and bounds are exclusive")
+            if G & (G - 1):
+                raise ValueError("a tile-row-cyclic partition needs a power-of-two world size, got %d" % G)
+            self._bounds = None
+            self.band = max(max(len(self.row_indices(g)) for g in range(G)), 1)
+            self.uniform = False          # (not a contiguous band: the contiguous helpers refuse it)
+            self.row0, self.row1 = min(8 * self.rank, self.S), self.S
+            return
         if bounds is None:
             self.band = -(-self.S // self.world_size)  # ceil
             self._bounds = [min(r * self.band, self.S) for r in range(self.world_size + 1)]
@@ -42,17 +63,49 @@ class RowPartition:
         self.row0, self.row1 = self._bounds[self.rank], self._bounds[self.rank + 1]
 
     @property
-    def rows(self) -> Tuple[int, int]:
-        return self.row0, self.row1
+    def rows(self):
+        """what the kernels take as `rows`: (row0, row1) for a contiguous band, (row0, row1, cycle) for a cyclic one"""
+        return (self.row0, self.row1, self.world_size) if self.cyclic else (self.row0, self.row1)
+
+    @property
+    def n_rows(self) -> int:
+        return len(self.row_indices()) if self.cyclic else self.row1 - self.row0
 
     def bounds(self, rank: int) -> Tuple[int, int]:
+        if self.cyclic:
+            raise ValueError("a cyclic partition has no contiguous bounds")
         return self._bounds[rank], self._bounds[rank + 1]
 
+    def row_indices(self, rank: Optional[int] = None):
+        """image rows owned by `rank` (default: this rank), in band order"""
+        g = self.rank if rank is None else rank
+        if self.cyclic:
+            G = self.world_size
+            return [t * 8 + i for t in range(g, -(-self.S // 8), G) for i in range(8) if t * 8 + i < self.S]
+        r0, r1 = self._bounds[g], self._bounds[g + 1]
+        return list(range(r0, r1))
+
+    def gather_index(self):
+        """for every image row r: its position in the all-gathered (world_size * band, ...) buffer"""
+        pos = [0] * self.S
+        for g in range(self.world_size):
+            for l, r in enumerate(self.row_indices(g)):
+                pos[r] = g * self.band + l
+        return pos
+
     def describe(self) -> str:
+        if self.cyclic:
+            return "tile-row-cyclic: rank g owns the 8-row tile rows g, g+%d, ... (%d rows each)" % (self.world_size, self.band)
         return ("equal bands of %d rows" % self.band) if self.uniform else ("bands %r" % (self._bounds,))
 
     def slice(self, full: torch.Tensor) -> torch.Tensor:
-        """Own band of a full-image tensor (N, S, ...)."""
+        """Own rows of a full-image tensor (N, S, ...) (a view for contiguous bands, a gather for the cyclic layout)."""
+        if self.cyclic:
+            if self.S % (8 * self.world_size) == 0:
+                N = full.shape[0]
+                t = full.reshape((N, self.S // (8 * self.world_size), self.world_size, 8) + tuple(full.shape[2:]))
+                return t[:, :, self.rank].reshape((N, self.band) + tuple(full.shape[2:]))
+            return full.index_select(1, torch.tensor(self.row_indices(), dtype=torch.int64, device=full.device))
         return full[:, self.row0:self.row1]
 
 
@@ -203,7 +256,7 @@ class OverlappedExchange:
         G, band, S = part.world_size, part.band, part.S
         self.send_img = torch.zeros((band, n_images, S, channels), dtype=torch.float32, device=device)
         self.recv_img = torch.empty((G * band, n_images, S, channels), dtype=torch.float32, device=device)
-        rows = part.row1 - part.row0
+        rows = part.n_rows
         self.image = self.send_img[:rows].permute(1, 0, 2, 3)  # (N, rows, S, ch), strided
         self.visible = torch.zeros(num_points, dtype=torch.uint8, device=device)
         self.recv_vis = torch.empty((G, num_points), dtype=torch.uint8, device=device)
@@ -212,8 +265,9 @@ class OverlappedExchange:
         # kernel on a side stream as soon as the collective completes, i.e. still during the backward
         self.full_img = self.row_index = self._side = None
         if not part.uniform:
-            idx = [g * band + j for g in range(G) for j in range(part.bounds(g)[1] - part.bounds(g)[0])]
-            self.row_index = torch.tensor(idx, dtype=torch.int64, device=device)
+            # image row r sits at gather_index()[r] of the gathered buffer (unequal bands travel padded to the largest
+            # one; a cyclic partition interleaves the ranks' tile rows)
+            self.row_index = torch.tensor(part.gather_index(), dtype=torch.int64, device=device)
             self.full_img = torch.empty((S, n_images, S, channels), dtype=torch.float32, device=device)
             if torch.device(device).type == "cuda":
                 self._side = torch.cuda.Stream(device=device)

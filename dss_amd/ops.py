@@ -384,6 +384,24 @@ def blend_backward(grad_out, idx, qvalue, scaler, num_points: int, geometry=None
     return gf, grad_out[..., C]
 
 
+def _band(rows, S):
+    """`rows` of the fused entry points: None = whole image; (row0, row1) = contiguous band; (row0, row1, c) = of that
+    band only every c-th 8-row tile row starting at row0 (tile-row-cyclic multi-GPU partition, include/dss_hip.h)."""
+    if rows is None:
+        return 0, int(S), 1
+    return int(rows[0]), int(rows[1]), (int(rows[2]) if len(rows) > 2 else 1)
+
+
+def band_rows(row0: int, row1: int, cycle: int = 1) -> int:
+    """rows of a band tensor (dss_band_rows)"""
+    if row1 <= row0:
+        return 0
+    if cycle <= 1:
+        return row1 - row0
+    full, rem = divmod(row1 - row0, 8 * cycle)
+    return full * 8 + min(rem, 8)
+
+
 def render_forward(world, normals, h, M, V, znear, zfar, cloud_to_packed_first_idx, num_points_per_cloud, features,
                    image_size: int, points_per_pixel: int, cutoff_threshold: float, depth_merging_thres: float,
                    antialiasing_sigma: float = 1.0, backface_culling: bool = False, shared_cloud: bool = False,
@@ -423,8 +441,8 @@ def render_forward(world, normals, h, M, V, znear, zfar, cloud_to_packed_first_i
     if not per_point and h.numel() != N:
         raise RuntimeError("h must have %d (per point) or %d (per cloud) entries" % (Pw, N))
     S, K, C = int(image_size), int(points_per_pixel), features.shape[1]
-    row0, row1 = (0, S) if rows is None else (int(rows[0]), int(rows[1]))
-    nr = max(row1 - row0, 0)
+    row0, row1, cyc = _band(rows, S)
+    nr = band_rows(row0, row1, cyc)
     e = lambda *shape, dtype=_f32: torch.empty(shape, dtype=dtype, device=dev)
     if nr == 0:
         # empty row band (multi-GPU rank without rows): only the per-point setup runs; no fragments, nothing visible
@@ -454,7 +472,7 @@ def render_forward(world, normals, h, M, V, znear, zfar, cloud_to_packed_first_i
             _lib.ptr(world), _lib.ptr(normals), _lib.ptr(h) if per_point else None, None if per_point else _lib.ptr(h),
             vr_p, fn_p, _lib.ptr(M), _lib.ptr(V), _lib.ptr(znear), _lib.ptr(zfar), _lib.ptr(first), _lib.ptr(num), N, P,
             int(shared_cloud), int(backface_culling), S, K, float(cutoff_threshold), float(antialiasing_sigma),
-            float(depth_merging_thres), row0, row1, _lib.ptr(features), C, _lib.ptr(o["pts_screen"]),
+            float(depth_merging_thres), row0, row1, cyc, _lib.ptr(features), C, _lib.ptr(o["pts_screen"]),
             _lib.ptr(o["ellipse_params"]), _lib.ptr(o["radii"]), _lib.ptr(o["scaler"]), _lib.ptr(o["cutoff_threshold"]),
             _lib.ptr(valid), _lib.ptr(o["idx"]), _lib.ptr(o["zbuf"]), _lib.ptr(o["qvalue"]), _lib.ptr(o["occupancy"]),
             _lib.ptr(vis), _lib.ptr(img), int(img.stride(0)), int(img.stride(1)), _lib.ptr(o["wsum"]), _lib.ptr(ws),
@@ -493,8 +511,8 @@ def render_backward(grad_out, idx, qvalue, wsum, scaler, points, radii, visible,
     C = grad_out.shape[-1] - 1
     P = points.shape[0]
     S = int(image_size) if image_size is not None else W
-    row0, row1 = (0, S) if rows is None else (int(rows[0]), int(rows[1]))
-    if W != S or H != max(row1 - row0, 0) or tuple(grad_out.shape[:3]) != (N, H, W):
+    row0, row1, cyc = _band(rows, S)
+    if W != S or H != band_rows(row0, row1, cyc) or tuple(grad_out.shape[:3]) != (N, H, W):
         raise RuntimeError("render_backward needs idx (N,rows,S,K) and grad_out (N,rows,S,C+1)")
     with torch.cuda.device(dev):
         if out is not None:  # caller-provided (P,C) / (P,3) float32 views, e.g. slices of one all-reduce bucket
@@ -520,7 +538,7 @@ def render_backward(grad_out, idx, qvalue, wsum, scaler, points, radii, visible,
         entry = lib.dss_render_backward if gather_only_rs is None else lib.dss_render_backward_gather
         rc = entry(_lib.ptr(grad_out), _lib.ptr(idx), _lib.ptr(qvalue), _lib.ptr(wsum),
                    _lib.ptr(scaler), _lib.ptr(points), _lib.ptr(radii), _lib.ptr(vis),
-                   _lib.ptr(first), _lib.ptr(num), N, P, S, K, C, row0, row1, float(radii_s),
+                   _lib.ptr(first), _lib.ptr(num), N, P, S, K, C, row0, row1, cyc, float(radii_s),
                    float(clip), _lib.ptr(gf), _lib.ptr(gp), _lib.ptr(rs), _lib.ptr(ws), ws.numel(),
                    _lib.stream_ptr(dev))
     _lib.check(rc, "dss_render_backward")

@@ -18,6 +18,12 @@
  *     dss_last_error() returns a thread-local message for the last failing call on this thread;
  *   - `row0,row1` select the image row band [row0,row1) a rank renders (multi-GPU row
  *     partitioning); band-shaped tensors have `rows = row1-row0` rows.  Single GPU: 0, S.
+ *     The fused training entry points (dss_render_forward / dss_render_backward) also take `row_cycle`:
+ *     1 = that contiguous band; c > 1 (a power of two) = TILE-ROW-CYCLIC band: of [row0,row1) only every
+ *     c-th 8-row tile row, starting at row0 (rank g of c ranks passes row0 = 8 g, row1 = S, row_cycle = c:
+ *     every rank gets the same mix of dense and empty screen regions instead of one contiguous strip).
+ *     Band tensors then have dss_band_rows(row0,row1,row_cycle) rows; band row l is image row
+ *     row0 + (l / 8) * 8 c + l % 8.
  *
  * Image convention (rasterization_utils.cuh:8-11, rasterize_points.cu:160-164, 577-580):
  * image pixel [row r, col c] has NDC centre ( -1+(2*(S-1-c)+1)/S , -1+(2*(S-1-r)+1)/S ).
@@ -32,7 +38,7 @@
 extern "C" {
 #endif
 
-#define DSS_HIP_VERSION 100
+#define DSS_HIP_VERSION 101
 
 #if defined(__GNUC__)
 #define DSS_API __attribute__((visibility("default")))
@@ -67,6 +73,7 @@ DSS_API const char *dss_last_error(void);
 #define DSS_OPT_BACKWARD_TPW 1
 #define DSS_OPT_BACKWARD_ADDR64 2
 #define DSS_OPT_COUNT 3
+DSS_API int dss_band_rows(int row0, int row1, int row_cycle); /* rows of a band tensor (see `row_cycle` above) */
 DSS_API int dss_set_option(int option, int value);
 DSS_API int dss_get_option(int option);
 
@@ -261,7 +268,7 @@ DSS_API int dss_render_forward(const float *world, const float *normals, const f
                                const float *zfar, const int64_t *first_idx, const int64_t *num_pts,
                                int N, int64_t P, int shared_cloud, int backface_culling, int S, int K,
                                float cutoff_threshold, float antialiasing_sigma, float merge_thr,
-                               int row0, int row1, const float *feat /* (P,C) */, int C,
+                               int row0, int row1, int row_cycle, const float *feat /* (P,C) */, int C,
                                float *pts_screen, float *ellipse, float *radii, float *scaler,
                                float *cutoff, uint8_t *valid, int32_t *idx, float *zbuf, float *qvalue,
                                float *occ, uint8_t *visible, float *image,
@@ -288,7 +295,7 @@ DSS_API int dss_render_backward(const float *grad_out, const int32_t *idx, const
                                 const float *wsum, const float *scaler, const float *points,
                                 const float *radii, const uint8_t *visible, const int64_t *first_idx,
                                 const int64_t *num_pts, int N, int64_t P, int S, int K, int C,
-                                int row0, int row1, float radii_s, float clip,
+                                int row0, int row1, int row_cycle, float radii_s, float clip,
                                 float *grad_feat /* (P,C) or NULL */,
                                 float *grad_pts /* (P,3) */, float *rs_out /* (N,) or NULL */,
                                 void *workspace, size_t workspace_bytes, void *stream);
@@ -300,7 +307,7 @@ DSS_API int dss_render_backward_gather(const float *grad_out, const int32_t *idx
                                        const float *wsum, const float *scaler, const float *points,
                                        const float *radii, const uint8_t *visible, const int64_t *first_idx,
                                        const int64_t *num_pts, int N, int64_t P, int S, int K, int C,
-                                       int row0, int row1, float radii_s, float clip, float *grad_feat,
+                                       int row0, int row1, int row_cycle, float radii_s, float clip, float *grad_feat,
                                        float *grad_pts, float *rs_out, void *workspace, size_t workspace_bytes,
                                        void *stream);
 

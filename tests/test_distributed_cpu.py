@@ -79,8 +79,32 @@ def _worker(rank, world, port, S, tmp):
         oxb.visible.copy_(vis_band)
         oxb.start()
         assert torch.equal(oxb.finish(), torch.from_numpy(full))
+        # tile-row-cyclic layout (rank g owns the 8-row tile rows g, g + G, ...): bands written through the strided send
+        # view, interleaved back by the exchange; visibility union and gradient partial sums as for contiguous bands
+        pc = RowPartition(S, world, rank, cyclic=True)
+        own = np.array(pc.row_indices(), np.int64)
+        assert pc.rows == (8 * rank, S, world) and len(own) == pc.n_rows and pc.band >= pc.n_rows
+        full_t = torch.from_numpy(full)
+        assert torch.equal(pc.slice(full_t), full_t[:, own])
+        oxc = OverlappedExchange(pc, 2, full.shape[-1], P, "cpu")
+        assert oxc.image.shape == (2, len(own), S, full.shape[-1])
+        idx_c = np.full_like(idx, -1)
+        idx_c[:, own] = idx[:, own]
+        vis_c = torch.from_numpy(oracle.visibility(idx_c, P).astype(np.uint8))
+        for rep in range(2):
+            oxc.image.copy_(full_t[:, own] * (rep + 1))
+            oxc.visible.copy_(vis_c)
+            assert torch.equal(oxc.start(), vis)
+            assert torch.equal(oxc.finish(), full_t * (rep + 1))
         rs = oracle.backward_radius(sc["radii"], vis.numpy(), sc["first_idx"], sc["num_pts"], 3.0)
         gocc = g_full[..., 3].numpy()
+        masked_c = np.zeros_like(gocc)
+        masked_c[:, own] = gocc[:, own]
+        g_c = torch.from_numpy(oracle.occ_backward_fast(sc["points"], sc["radii"], vis.numpy(), rs, masked_c,
+                                                        sc["first_idx"], sc["num_pts"]))
+        reduce_grads_(g_c, part=pc)
+        assert np.allclose(g_c.numpy(), oracle.occ_backward_fast(sc["points"], sc["radii"], vis.numpy(), rs, gocc,
+                                                                 sc["first_idx"], sc["num_pts"]), rtol=1e-4, atol=1e-4)
         masked = np.zeros_like(gocc)
         masked[:, r0:r1] = gocc[:, r0:r1]
         g_part = torch.from_numpy(oracle.occ_backward_fast(sc["points"], sc["radii"], vis.numpy(), rs, masked,
@@ -116,6 +140,34 @@ def test_row_partition_bounds():
         assert cover == S
         for (a, b), (c, d) in zip(rows[:-1], rows[1:]):
             assert b == c
+
+
+def test_cyclic_row_partition_layout():
+    """tile-row-cyclic partition: every image row has exactly one owner, band sizes agree with dss_band_rows' formula
+    (ops.band_rows), the gather index inverts the rank-major concatenation of the bands"""
+    sys.path.insert(0, ROOT)
+    from dss_amd import ops
+    from dss_amd.distributed import RowPartition
+    for S, G in ((512, 8), (512, 2), (37, 2), (37, 4), (40, 4), (8, 4), (1024, 8)):
+        parts = [RowPartition(S, G, g, cyclic=True) for g in range(G)]
+        owned = sorted(r for p in parts for r in p.row_indices())
+        assert owned == list(range(S))
+        for g, p in enumerate(parts):
+            ri = p.row_indices()
+            assert len(ri) == p.n_rows == ops.band_rows(*p.rows) <= p.band
+            assert all((r // 8) % G == g for r in ri) and ri == sorted(ri)
+            # band row l <-> image row row0 + (l // 8) * 8 G + l % 8  (include/dss_hip.h)
+            assert ri == [p.rows[0] + (l // 8) * 8 * G + l % 8 for l in range(len(ri))]
+        if S % (8 * G) == 0:
+            assert len({p.n_rows for p in parts}) == 1 and parts[0].band == S // G      # equal bands: no padding
+        full = torch.arange(S * 3, dtype=torch.float32).reshape(1, S, 3)
+        recv = torch.zeros((G * parts[0].band, 1, 3))
+        for g, p in enumerate(parts):
+            recv[g * p.band:g * p.band + p.n_rows] = p.slice(full).permute(1, 0, 2)
+        assert torch.equal(recv[torch.tensor(parts[0].gather_index())].permute(1, 0, 2), full)
+    with pytest.raises(ValueError):
+        RowPartition(64, 3, 0, cyclic=True)       # power-of-two world sizes only (the kernels shift)
+    assert RowPartition(64, 1, 0, cyclic=True).rows == (0, 64)      # one rank: the whole image, contiguous
 
 
 def _band_loss_worker(rank, world, port, tmp):

@@ -1,41 +1,78 @@
 #!/usr/bin/env python3
-"""Developer tool (GPU box): per-rank COMPUTE time of the multi-GPU bench step, emulated on one GPU: G cameras,
-rank r's row band, visibility = union over all bands (computed by rendering every band once, untimed).
-No collectives: this is the part of the 8-GPU step that RCCL time is added to."""
-import sys, os, time
+"""Developer tool (GPU box): per-rank COMPUTE time of the multi-GPU bench step, emulated on one GPU: G cameras, each
+rank's rows (contiguous equal bands and the tile-row-cyclic partition), visibility = union over all ranks (computed by
+rendering every rank's rows once, untimed).  No collectives: this is the part of the G-GPU step that RCCL time is added
+to.  Per rank the step is timed twice: eager launches (host-bound at these sizes) and as a hipGraph replay (device time).
+
+    python tools/band_timing.py [G] -> one JSON line: per-rank microseconds, max / min spread, for both layouts"""
+import json
+import os
+import sys
+import time
+
 import torch
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import bench
-from dss_amd import ops
-from dss_amd.distributed import RowPartition
+import bench  # noqa: E402
+from dss_amd import ops  # noqa: E402
+from dss_amd.distributed import RowPartition  # noqa: E402
 
 G = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-rank = int(sys.argv[2]) if len(sys.argv) > 2 else G // 2
 dev = torch.device("cuda:0")
 S, K = bench.S, bench.K
 wl = bench.Workload(dev, G, RowPartition(S, 1, 0))   # G cameras, single-rank object (no process group needed)
-part = RowPartition(S, G, rank)
-fwd = lambda rows: ops.render_forward(wl.world, wl.normals, wl.h, wl.M, wl.V, wl.znear, wl.zfar, wl.first, wl.num, wl.colors,
-                                      S, K, bench.CUTOFF, bench.THR, bench.SIGMA, False, True, rows=rows)
-vis_all = torch.zeros(wl.P, dtype=torch.bool, device=dev)
-for r in range(G):
-    vis_all |= fwd(RowPartition(S, G, r).rows)["visible"]
-g_band = part.slice(wl.grad_out).contiguous()
-bucket = torch.empty(wl.P * 6, device=dev)
-gf, gp = bucket[:wl.P * 3].view(wl.P, 3), bucket[wl.P * 3:].view(wl.P, 3)
 
-def step():
-    f = fwd(part.rows)
-    ops.render_backward(g_band, f["idx"], f["qvalue"], f["wsum"], f["scaler"], f["pts_screen"], f["radii"], vis_all, wl.first,
-                        wl.num, bench.RADII_S, -1.0, image_size=S, rows=part.rows, out=(gf, gp))
-    return ops.project_backward(wl.world, wl.M, wl.V, wl.first, wl.num, gp, f["valid"], True, clip=bench.CLIP)
 
-for _ in range(10): step()
-torch.cuda.synchronize(); t = time.perf_counter()
-n = 100
-for _ in range(n): step()
-torch.cuda.synchronize()
-ms = (time.perf_counter() - t) / n * 1e3
-print("G=%d rank %d: per-rank compute %.1f us/step (%d cameras x %d points, band rows %s, %d visible of %d)" % (
-    G, rank, ms * 1e3, G, wl.Pc, part.rows, int(vis_all.sum()), wl.P))
+def fwd(rows):
+    return ops.render_forward(wl.world, wl.normals, wl.h, wl.M, wl.V, wl.znear, wl.zfar, wl.first, wl.num, wl.colors, S, K,
+                              bench.CUTOFF, bench.THR, bench.SIGMA, False, True, rows=rows)
+
+
+def quick(fn, n=60):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t) / n * 1e6
+
+
+out = {"G": G, "cameras": G, "points_per_cloud": wl.Pc, "image_size": S}
+for layout in ("bands", "cyclic"):
+    parts = [RowPartition(S, G, r, cyclic=(layout == "cyclic")) for r in range(G)]
+    vis_all = torch.zeros(wl.P, dtype=torch.bool, device=dev)
+    for p in parts:
+        vis_all |= fwd(p.rows)["visible"]
+    eager, graph = [], []
+    for p in parts:
+        g_band = p.slice(wl.grad_out).contiguous()
+        bucket = torch.empty(wl.P * 6, device=dev)
+        gf, gp = bucket[:wl.P * 3].view(wl.P, 3), bucket[wl.P * 3:].view(wl.P, 3)
+
+        def step():
+            f = fwd(p.rows)
+            ops.render_backward(g_band, f["idx"], f["qvalue"], f["wsum"], f["scaler"], f["pts_screen"], f["radii"], vis_all,
+                                wl.first, wl.num, bench.RADII_S, -1.0, image_size=S, rows=p.rows, out=(gf, gp))
+            return ops.project_backward(wl.world, wl.M, wl.V, wl.first, wl.num, gp, f["valid"], True, clip=bench.CLIP)
+        eager.append(quick(step))
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        cg = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(cg, stream=side):
+            step()
+        graph.append(quick(cg.replay))
+    out[layout] = {"eager_us": [round(x, 1) for x in eager], "graph_us": [round(x, 1) for x in graph],
+                   "graph_max_over_min": round(max(graph) / min(graph), 3), "graph_max_us": round(max(graph), 1),
+                   "eager_max_us": round(max(eager), 1)}
+one = RowPartition(S, 1, 0)
+wl1 = bench.Workload(dev, 1, one)
+out["single_gpu_step_us"] = {"eager": round(quick(wl1.step), 1)}
+print(json.dumps(out))
