@@ -103,8 +103,13 @@ class Workload:
         if not multi:
             image = gather_rows(band, p)
             # fused backward: persistent wavefronts over the compacted visible list (dss_render_backward)
+            # (one camera: packed index == world index, so the projection backward rides in the gather's epilogue)
             g_feat, g_pts = ops.render_backward(self.grad_out, idx, qv, wsum, info["scaler"], info["pts_screen"],
-                                                info["radii"], vis, self.first, self.num, RADII_S, CLIP)
+                                                info["radii"], vis, self.first, self.num, RADII_S, CLIP,
+                                                project=(self.world, self.M) if self.N == 1 else None)
+            if self.N == 1:
+                mark("projection_compute")
+                return image, g_pts, g_feat
         else:
             # collectives 1-2/3: the RGBA bands leave on their own communicator and arrive during the backward;
             # only the small visibility all-gather is waited for here

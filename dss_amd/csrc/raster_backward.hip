@@ -1004,7 +1004,9 @@ __global__ __launch_bounds__(256) void render_backward_kernel(
     const float *__restrict__ radii, const float *__restrict__ rs, const int64_t *__restrict__ first_idx,
     const int64_t *__restrict__ num_pts, const uint32_t *__restrict__ vis_count,
     const int32_t *__restrict__ vis_list, int n_seg, int seg_pts, int N, int S, int K, int Crt, float clip, int row0,
-    int rows, uint32_t large_waves, float *__restrict__ grad_feat, float *__restrict__ grad_pts, int tshift = 3)
+    int rows, uint32_t large_waves, float *__restrict__ grad_feat, float *__restrict__ grad_pts, int tshift = 3,
+    const float *__restrict__ world = nullptr /* (P,3): fused projection backward, see the epilogue */,
+    const float *__restrict__ Mproj = nullptr /* (N,4,4) */)
 {
     constexpr int CM = (C > 0) ? C : BLEND_MAX_C;
     constexpr int KF = 8;            // fragment slots held in registers; deeper lists take the loop
@@ -1088,12 +1090,14 @@ __global__ __launch_bounds__(256) void render_backward_kernel(
         if (more) p_nx = task_ids(q_next);  // in flight during this group
         // ---- record + cloud of the task's point ------------------------------------------------------------
         float px = 0.f, py = 0.f, pz = -1.f, rx = 0.f, ry = 0.f, sc = 0.f, cur_r = 0.f;
+        float wx = 0.f, wy = 0.f, wz = 0.f;   // world position (fused projection backward only)
         int n = -1;
         if (p >= 0) {
             px = points[3 * (size_t)p]; py = points[3 * (size_t)p + 1]; pz = points[3 * (size_t)p + 2];
             const float2 rr = reinterpret_cast<const float2 *>(radii)[p];
             rx = rr.x; ry = rr.y;
             sc = scaler ? scaler[p] : 0.0f;
+            if (world) { wx = world[3 * (size_t)p]; wy = world[3 * (size_t)p + 1]; wz = world[3 * (size_t)p + 2]; }
             for (int cld = 0; cld < N; ++cld) {  // scalar loads; N is small
                 const int64_t f = first_idx[cld];
                 const bool own = (int64_t)p >= f && (int64_t)p < f + num_pts[cld];
@@ -1336,9 +1340,31 @@ __global__ __launch_bounds__(256) void render_backward_kernel(
                 gx *= k;
                 gy *= k;
             }
-            grad_pts[3 * (size_t)p] = gx;
-            grad_pts[3 * (size_t)p + 1] = gy;
-            grad_pts[3 * (size_t)p + 2] = 0.0f;
+            float o0 = gx, o1 = gy, o2 = 0.0f;
+            if (world) {
+                // Fused backward of the projection (project_backward_kernel, setup.hip, operation for operation; the z
+                // gradient is 0 on this path): the task already holds its point's clipped screen-space gradient, so the
+                // world-space gradient leaves from here and the separate launch (4 us of the 80 us step at 32k points)
+                // disappears.  Only for clouds that are not shared between cameras (packed index == world index): a
+                // shared cloud sums over its cameras in a fixed order in the separate kernel.
+                const float *m = Mproj + 16 * nn;
+                const float cx = wx * m[0] + wy * m[4] + wz * m[8] + m[12];
+                const float cy = wx * m[1] + wy * m[5] + wz * m[9] + m[13];
+                const float w = wx * m[3] + wy * m[7] + wz * m[11] + m[15];
+                const float iw = 1.0f / w;
+                const float nx = cx * iw, ny = cy * iw;
+                float t3[3];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const float jx = (m[i * 4 + 0] - nx * m[i * 4 + 3]) * iw;
+                    const float jy = (m[i * 4 + 1] - ny * m[i * 4 + 3]) * iw;
+                    t3[i] = jx * gx + jy * gy + 0.0f;
+                }
+                o0 = t3[0]; o1 = t3[1]; o2 = t3[2];
+            }
+            grad_pts[3 * (size_t)p] = o0;
+            grad_pts[3 * (size_t)p + 1] = o1;
+            grad_pts[3 * (size_t)p + 2] = o2;
             if (grad_feat) {
 #pragma unroll
                 for (int ch = 0; ch < CM; ++ch)
@@ -1598,14 +1624,21 @@ static int render_backward_impl(bool run_prep, const float *grad_out, const int3
                                 const float *scaler, const float *points, const float *radii,
                                 const uint8_t *visible, const int64_t *first_idx, const int64_t *num_pts, int N,
                                 int64_t P, int S, int K, int C, int row0, int row1, int row_cycle, float radii_s, float clip,
-                                float *grad_feat, float *grad_pts, float *rs_out, void *workspace,
-                                size_t workspace_bytes, void *stream)
+                                float *grad_feat, float *grad_pts, float *rs_out, const float *world, const float *Mproj,
+                                void *workspace, size_t workspace_bytes, void *stream)
 {
     if (N <= 0 || P < 0 || S <= 0 || K <= 0 || C < 1 || C > BLEND_MAX_C || row0 < 0 || row1 > S || row0 >= row1 ||
         row_cycle < 1 || (row_cycle & (row_cycle - 1)) || row_cycle > 4096) {
         set_error("dss_render_backward: bad sizes N=%d P=%lld S=%d K=%d C=%d rows=[%d,%d) cycle %d", N, (long long)P, S, K, C,
                   row0, row1, row_cycle);
         return DSS_ERR_INVALID_ARGUMENT;
+    }
+    if (world != nullptr) {
+        // fused projection backward: grad_pts then receives WORLD-space gradients (see the kernel's epilogue)
+        if (!Mproj || row0 != 0 || row1 != S || row_cycle > 1 || C != 3) {
+            set_error("dss_render_backward: the fused projection needs M, the whole image (no row band) and C == 3");
+            return DSS_ERR_INVALID_ARGUMENT;
+        }
     }
     const int rows = dss_band_rows(row0, row1, row_cycle);   // band-local rows
     int tshift = 3;
@@ -1738,7 +1771,7 @@ static int render_backward_impl(bool run_prep, const float *grad_out, const int3
 #define DSS_LAUNCH_RB_A(CC, SS, TT, AA)                                                                                 \
     hipLaunchKernelGGL((render_backward_kernel<CC, SS, TT, AA>), dim3(pgrid), dim3(256), 0, st, grad_out, alpha, idx, qvalue, wsum, \
                        scaler, points, radii, rs, first_idx, num_pts, vis_count, vis_list, n_seg, seg_pts, N, S, K, C, clip, \
-                       row0, rows, large_waves, grad_feat, grad_pts)
+                       row0, rows, large_waves, grad_feat, grad_pts, 3, world, Mproj)
     // 32-bit byte offsets from the tensor bases (one VALU per gather address instead of 64-bit index arithmetic) whenever
     // every gathered tensor is smaller than 4 GB; larger problems take the 64-bit addressing, four tasks per wavefront
     const unsigned long long widest = (unsigned long long)N * (unsigned long long)rows * (unsigned long long)S *
@@ -1746,6 +1779,7 @@ static int render_backward_impl(bool run_prep, const float *grad_out, const int3
     // (DSS_OPT_BACKWARD_ADDR64 forces the 64-bit variant: it only exists for tensors nobody allocates in a test)
     const bool a32 = widest < (1ull << 32) && option(DSS_OPT_BACKWARD_ADDR64) != 1;
     if (!a32) tpw = 4;
+    if (!a32 && world) { set_error("dss_render_backward: the fused projection needs gathered tensors below 4 GB"); return DSS_ERR_UNSUPPORTED; }
 #define DSS_LAUNCH_RB(CC, SS, TT) DSS_LAUNCH_RB_A(CC, SS, TT, true)
 #define DSS_LAUNCH_RB_T(CC, SS)                                                                                        \
     do {                                                                                                               \
@@ -1780,11 +1814,11 @@ extern "C" int dss_render_backward(const float *grad_out, const int32_t *idx, co
                                    const float *scaler, const float *points, const float *radii,
                                    const uint8_t *visible, const int64_t *first_idx, const int64_t *num_pts, int N,
                                    int64_t P, int S, int K, int C, int row0, int row1, int row_cycle, float radii_s, float clip,
-                                   float *grad_feat, float *grad_pts, float *rs_out, void *workspace,
+                                   float *grad_feat, float *grad_pts, float *rs_out, const float *world, const float *M, void *workspace,
                                    size_t workspace_bytes, void *stream)
 {
     return render_backward_impl(true, grad_out, idx, qvalue, wsum, scaler, points, radii, visible, first_idx, num_pts, N, P, S,
-                                K, C, row0, row1, row_cycle, radii_s, clip, grad_feat, grad_pts, rs_out, workspace, workspace_bytes, stream);
+                                K, C, row0, row1, row_cycle, radii_s, clip, grad_feat, grad_pts, rs_out, world, M, workspace, workspace_bytes, stream);
 }
 
 // Second stage alone (the persistent gather kernel), on the workspace (visible lists, alpha plane, rs) and the zero-filled
@@ -1793,11 +1827,11 @@ extern "C" int dss_render_backward_gather(const float *grad_out, const int32_t *
                                           const float *scaler, const float *points, const float *radii,
                                           const uint8_t *visible, const int64_t *first_idx, const int64_t *num_pts, int N,
                                           int64_t P, int S, int K, int C, int row0, int row1, int row_cycle, float radii_s, float clip,
-                                          float *grad_feat, float *grad_pts, float *rs_out, void *workspace,
+                                          float *grad_feat, float *grad_pts, float *rs_out, const float *world, const float *M, void *workspace,
                                           size_t workspace_bytes, void *stream)
 {
     return render_backward_impl(false, grad_out, idx, qvalue, wsum, scaler, points, radii, visible, first_idx, num_pts, N, P, S,
-                                K, C, row0, row1, row_cycle, radii_s, clip, grad_feat, grad_pts, rs_out, workspace, workspace_bytes, stream);
+                                K, C, row0, row1, row_cycle, radii_s, clip, grad_feat, grad_pts, rs_out, world, M, workspace, workspace_bytes, stream);
 }
 
 #ifdef DSS_FINE_TIMING

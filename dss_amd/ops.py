@@ -488,10 +488,12 @@ def render_backward(grad_out, idx, qvalue, wsum, scaler, points, radii, visible,
                     num_points_per_cloud, radii_s: float, clip: float = -1.0, with_features: bool = True,
                     return_rs: bool = False, image_size: Optional[int] = None,
                     rows: Optional[Tuple[int, int]] = None, out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
-                    gather_only_rs: Optional[torch.Tensor] = None):
+                    gather_only_rs: Optional[torch.Tensor] = None, project=None):
     """Fused backward of renderer + rasterizer (blend backward + median radius + occupancy backward +
     clip) -> (grad_features (P,C) or None, grad_pts_screen (P,3)).  With ``rows`` (multi-GPU band) pass the
     union of the visibility flags and ``clip <= 0``; the results are the band's partial sums.
+    ``project=(world (P,3), M (N,4,4))`` also fuses `project_backward` into the launch: the second result is then the
+    WORLD-space position gradient (clouds that are not shared between cameras, whole image, 3 feature channels).
     ``gather_only_rs`` = the ``rs`` a preceding identical call returned (and ``out`` = its outputs): re-runs only the
     second stage, the gather kernel (``dss_render_backward_gather``; per-kernel timing)."""
     lib = _lib.load()
@@ -534,12 +536,19 @@ def render_backward(grad_out, idx, qvalue, wsum, scaler, points, radii, visible,
             _lib.require_gpu(gather_only_rs, "gather_only_rs", _f32)
         if gather_only_rs is not None and out is None:
             raise RuntimeError("gather_only_rs needs out= (the gradients the full call zero-filled)")
+        w_p = m_p = None
+        if project is not None:
+            w_t, m_t = _lib.require_gpu(project[0], "world", _f32), _lib.require_gpu(project[1], "M", _f32)
+            if tuple(w_t.shape) != (P, 3) or tuple(m_t.shape) != (N, 4, 4):
+                raise RuntimeError("project=(world (P,3), M (N,4,4)) with P=%d N=%d, got %s %s"
+                                   % (P, N, tuple(w_t.shape), tuple(m_t.shape)))
+            w_p, m_p = _lib.ptr(w_t), _lib.ptr(m_t)
         ws = _lib.workspace(dev, lib.dss_render_backward_workspace(N, P, S))
         entry = lib.dss_render_backward if gather_only_rs is None else lib.dss_render_backward_gather
         rc = entry(_lib.ptr(grad_out), _lib.ptr(idx), _lib.ptr(qvalue), _lib.ptr(wsum),
                    _lib.ptr(scaler), _lib.ptr(points), _lib.ptr(radii), _lib.ptr(vis),
                    _lib.ptr(first), _lib.ptr(num), N, P, S, K, C, row0, row1, cyc, float(radii_s),
-                   float(clip), _lib.ptr(gf), _lib.ptr(gp), _lib.ptr(rs), _lib.ptr(ws), ws.numel(),
+                   float(clip), _lib.ptr(gf), _lib.ptr(gp), _lib.ptr(rs), w_p, m_p, _lib.ptr(ws), ws.numel(),
                    _lib.stream_ptr(dev))
     _lib.check(rc, "dss_render_backward")
     return (gf, gp, rs) if return_rs else (gf, gp)

@@ -518,7 +518,11 @@ class _RenderFused(autograd.Function):
     @staticmethod
     def backward(ctx, g_image, *unused):
         world, M, V, first_idx, num_points, idx, qv, wsum, scaler, pts_screen, radii, visible, valid = ctx.saved_tensors
+        fuse = (not ctx.shared or M.shape[0] == 1) and g_image.shape[-1] == 4 and world.shape[0] == pts_screen.shape[0]
         g_feat, g_pts = ops.render_backward(g_image.contiguous(), idx, qv, wsum, scaler, pts_screen, radii, visible,
-                                            first_idx, num_points, ctx.radii_s, ctx.clip)
-        g_world = ops.project_backward(world, M, V, first_idx, num_points, g_pts, valid, ctx.shared)
+                                            first_idx, num_points, ctx.radii_s, ctx.clip,
+                                            project=(world, M) if fuse else None)
+        # clouds that are not shared between cameras: the projection backward ran in the gather's epilogue (g_pts is
+        # already the world-space gradient); a shared cloud sums its cameras in the separate kernel
+        g_world = g_pts if fuse else ops.project_backward(world, M, V, first_idx, num_points, g_pts, valid, ctx.shared)
         return (g_world, g_feat) + (None,) * 19

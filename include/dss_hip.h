@@ -290,6 +290,9 @@ DSS_API int dss_render_forward(const float *world, const float *normals, const f
  * grad_feat may be NULL (rasterizer backward only).  grad_pts (P,3) and grad_feat (P,C) are fully
  * written.  Same results as the unfused entry points (same per-point arithmetic and reduction order).
  * ------------------------------------------------------------------------------------------- */
+/* `world` != NULL fuses the backward of the projection (dss_project_backward, pytorch3d transform at rasterizer.py:614)
+ * into the same launch: grad_pts then receives the WORLD-space position gradients (clip applied first, like the separate
+ * kernel).  For clouds that are not shared between cameras only (packed index == world index), whole image, C == 3. */
 DSS_API size_t dss_render_backward_workspace(int N, int64_t P, int S);
 DSS_API int dss_render_backward(const float *grad_out, const int32_t *idx, const float *qvalue,
                                 const float *wsum, const float *scaler, const float *points,
@@ -298,6 +301,7 @@ DSS_API int dss_render_backward(const float *grad_out, const int32_t *idx, const
                                 int row0, int row1, int row_cycle, float radii_s, float clip,
                                 float *grad_feat /* (P,C) or NULL */,
                                 float *grad_pts /* (P,3) */, float *rs_out /* (N,) or NULL */,
+                                const float *world /* NULL, or (P,3): see below */, const float *M /* (N,4,4) with world */,
                                 void *workspace, size_t workspace_bytes, void *stream);
 /* Second stage of dss_render_backward alone (the persistent gather kernel = blend backward + occupancy surrogate + clip of
  * every visible point, rasterize_points_backward.cu:30-212): runs on the workspace (visible lists, alpha plane, rs) and the
@@ -308,8 +312,8 @@ DSS_API int dss_render_backward_gather(const float *grad_out, const int32_t *idx
                                        const float *radii, const uint8_t *visible, const int64_t *first_idx,
                                        const int64_t *num_pts, int N, int64_t P, int S, int K, int C,
                                        int row0, int row1, int row_cycle, float radii_s, float clip, float *grad_feat,
-                                       float *grad_pts, float *rs_out, void *workspace, size_t workspace_bytes,
-                                       void *stream);
+                                       float *grad_pts, float *rs_out, const float *world, const float *M,
+                                       void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused per-point setup = everything SurfaceSplatting.forward does before _C.splat_points:

@@ -762,6 +762,48 @@ def test_tile_row_cyclic_bands_reproduce_the_full_render_and_its_gradients(S, G,
         assert _rel_l2(sum_f.cpu().numpy(), gf_full.cpu().numpy()) <= 1e-5, tpw
 
 
+@pytest.mark.parametrize("P,S,N", [(4000, 128, 1), (3000, 96, 3), (300000, 256, 2)])
+def test_render_backward_with_fused_projection_equals_project_backward(P, S, N):
+    """`project=(world, M)`: the backward of the projection (dss_project_backward) evaluated in the gather's epilogue --
+    same arithmetic, so the world-space gradients equal the two-launch path bit for bit (clip applied first); clouds that
+    are not shared between cameras, every tasks-per-wavefront variant, both preparation paths."""
+    pts, nrm = scenes.load_cloud("bunny")
+    pts = scenes.normalize_unit_sphere(pts)
+    reps = max(1, -(-P // len(pts)))
+    if reps > 1:
+        pts, nrm = scenes.upsample_jitter(pts, nrm, reps, seed=4)
+    pts, nrm = pts[:P], nrm[:P]
+    Pc = len(pts)
+    h = scenes.global_h(pts[:: max(1, Pc // 20000)]) * (20000.0 / Pc if Pc > 20000 else 1.0)
+    az = [30.0, 150.0, 260.0][:N]
+    M = np.concatenate([scenes.camera_matrices(2.0, 20.0, a)[0] for a in az])
+    V = np.concatenate([scenes.camera_matrices(2.0, 20.0, a)[1] for a in az])
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    world = t(np.tile(pts, (N, 1)) + np.repeat(np.arange(N, dtype=np.float32)[:, None] * 0.01, Pc, 0))   # N distinct clouds
+    normals = t(np.tile(nrm, (N, 1)))
+    first = torch.arange(N, device=DEV, dtype=torch.int64) * Pc
+    num = torch.full((N,), Pc, dtype=torch.int64, device=DEV)
+    feat = torch.rand((N * Pc, 3), device=DEV)
+    f = ops.render_forward(world, normals, torch.full((N,), float(h), device=DEV), t(M), t(V),
+                           torch.full((N,), 0.1, device=DEV), torch.full((N,), 100.0, device=DEV), first, num, feat, S, 5, 1.0,
+                           0.05, 1.0, False, False)
+    go = torch.randn((N, S, S, 4), device=DEV)
+    a = (go, f["idx"], f["qvalue"], f["wsum"], f["scaler"], f["pts_screen"], f["radii"], f["visible"], first, num, 4.0, 0.05)
+    for tpw in (0, 1, 2, 4):   # (the lane tiling, hence the summation order, differs between the variants: compare per variant)
+        _lib.set_option(_lib.OPT_BACKWARD_TPW, tpw)
+        try:
+            gf, gs = ops.render_backward(*a)
+            want = ops.project_backward(world, t(M), t(V), first, num, gs, f["valid"], False)
+            gf2, gw = ops.render_backward(*a, project=(world, t(M)))
+        finally:
+            _lib.set_option(_lib.OPT_BACKWARD_TPW, 0)
+        assert float(want.abs().max()) > 0
+        assert torch.equal(gf2, gf) and torch.equal(gw, want), tpw
+    with pytest.raises(RuntimeError, match="fused projection"):
+        ops.render_backward(go[:, :S // 2].contiguous(), f["idx"][:, :S // 2].contiguous(), f["qvalue"][:, :S // 2].contiguous(),
+                            f["wsum"][:, :S // 2].contiguous(), *a[4:], image_size=S, rows=(0, S // 2), project=(world, t(M)))
+
+
 def test_render_backward_row_bands_sum_to_full_on_the_long_list_path():
     """The same contract for more than 262,144 points: multi-kernel median, screen-cell order of the visible list, XCD-wise
     dealing -- what a rank of the 8-GPU run of BASELINE configs[3] executes on its band."""
