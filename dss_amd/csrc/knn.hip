@@ -214,6 +214,138 @@ __global__ __launch_bounds__(256) void knn_fill_kernel(const float *__restrict__
     sorted[first_idx[n] + pos] = make_float4(pts[3 * p], pts[3 * p + 1], pts[3 * p + 2], __int_as_float((int)p));
 }
 
+// Whole grid build of ONE cloud in ONE workgroup (small inputs: P <= KNN_SMALL_P packed points): bounding box -> grid
+// parameters -> zeroed cell counts -> counting (cell of every point) -> exclusive scan of the cells -> counting-sort fill.
+// Replaces eight launches (memset, init, bbox, grid, count, scan x 2, fill: ~40 us of launch latencies at 32k points
+// for ~6 us of work) by one; the cell arrays stay in global memory (L2), every phase is separated by a workgroup barrier,
+// values written by atomics are read back with agent-scope atomic loads (they live in L2, not in this CU's vector cache).
+#define KNN_SMALL_P 65536
+#define KNN_BUILD_THREADS 1024
+__global__ __launch_bounds__(KNN_BUILD_THREADS) void knn_build_small_kernel(
+    const float *__restrict__ pts, const int64_t *__restrict__ first_idx, const int64_t *__restrict__ num_pts, int64_t P,
+    int res_cap, size_t stride, KnnGrid *__restrict__ grids, uint32_t *__restrict__ counts, uint32_t *__restrict__ offsets,
+    uint32_t *__restrict__ cursor, float4 *__restrict__ sorted)
+{
+    __shared__ int s_red[KNN_BUILD_THREADS / 64][6];
+    __shared__ uint32_t s_wave[KNN_BUILD_THREADS / 64];
+    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int64_t f = first_idx[n];
+    const int64_t cnt = max((int64_t)0, min(num_pts[n], P - f));
+    // ---- bounding box (NaN coordinates skipped), same ordered-int reduction as knn_bbox_kernel
+    int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff};
+    int hi[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
+    for (int64_t i = tid; i < cnt; i += KNN_BUILD_THREADS) {
+        const int64_t p = f + i;
+        const float x = pts[3 * p], y = pts[3 * p + 1], z = pts[3 * p + 2];
+        if (!(x == x && y == y && z == z)) continue;
+        const int ox = f2ord(x), oy = f2ord(y), oz = f2ord(z);
+        lo[0] = min(lo[0], ox); lo[1] = min(lo[1], oy); lo[2] = min(lo[2], oz);
+        hi[0] = max(hi[0], ox); hi[1] = max(hi[1], oy); hi[2] = max(hi[2], oz);
+    }
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            lo[d] = min(lo[d], __shfl_xor(lo[d], o));
+            hi[d] = max(hi[d], __shfl_xor(hi[d], o));
+        }
+    if (lane == 0) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { s_red[wid][d] = lo[d]; s_red[wid][3 + d] = hi[d]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        lo[d] = 0x7fffffff;
+        hi[d] = (int)0x80000000;
+        for (int w = 0; w < KNN_BUILD_THREADS / 64; ++w) { lo[d] = min(lo[d], s_red[w][d]); hi[d] = max(hi[d], s_red[w][3 + d]); }
+    }
+    // ---- grid parameters (knn_grid_kernel): every thread derives the same values
+    KnnGrid g;
+    {
+        const float x0 = ord2f(lo[0]), y0 = ord2f(lo[1]), z0 = ord2f(lo[2]);
+        const float x1 = ord2f(hi[0]), y1 = ord2f(hi[1]), z1 = ord2f(hi[2]);
+        const float ext = fmaxf(fmaxf(x1 - x0, y1 - y0), fmaxf(z1 - z0, 1e-12f));
+        int res = (int)ceilf(sqrtf((float)num_pts[n] / 24.0f));
+        res = max(1, min(res_cap, res));
+        g.minx = x0; g.miny = y0; g.minz = z0;
+        g.cell = ext / (float)res * 1.0001f;
+        g.inv_cell = 1.0f / g.cell;
+        g.res = res;
+        g.pad0 = g.pad1 = 0;
+    }
+    if (tid == 0) grids[n] = g;
+    const int cells = g.res * g.res * g.res;
+    uint32_t *cn = counts + (size_t)n * stride, *of = offsets + (size_t)n * stride, *cu = cursor + (size_t)n * stride;
+    for (int c = tid; c < cells; c += KNN_BUILD_THREADS) cn[c] = 0u;
+    __syncthreads();
+    // ---- count
+    for (int64_t i = tid; i < cnt; i += KNN_BUILD_THREADS) {
+        const int64_t p = f + i;
+        const int cx = cell_coord(pts[3 * p], g.minx, g.inv_cell, g.res);
+        const int cy = cell_coord(pts[3 * p + 1], g.miny, g.inv_cell, g.res);
+        const int cz = cell_coord(pts[3 * p + 2], g.minz, g.inv_cell, g.res);
+        atomicAdd(&cn[(cz * g.res + cy) * g.res + cx], 1u);
+    }
+    __syncthreads();
+    // ---- exclusive scan of the cell counts.  Every wavefront owns a contiguous segment of the cells (a multiple of 256):
+    // pass A sums it (independent coalesced loads), one workgroup barrier turns the 16 totals into segment prefixes, pass B
+    // re-reads the segment 256 cells at a time and writes the running offsets (wave scan on shuffles, carry in a register).
+    {
+        constexpr int NW = KNN_BUILD_THREADS / 64;
+        const int seg = ((cells + NW * 256 - 1) / (NW * 256)) * 256;   // cells per wavefront
+        const int c_lo = wid * seg, c_hi = min(c_lo + seg, cells);
+        uint32_t sum = 0;
+        for (int c = c_lo + 4 * lane; c < c_hi; c += 256) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (c + i < c_hi) sum += __hip_atomic_load(&cn[c + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        if (lane == 0) s_wave[wid] = sum;
+        __syncthreads();
+        uint32_t carry = 0, total = 0;
+        for (int w = 0; w < NW; ++w) {
+            const uint32_t t = s_wave[w];
+            carry += (w < wid) ? t : 0u;
+            total += t;
+        }
+        for (int c = c_lo + 4 * lane; c - 4 * lane < c_hi; c += 256) {   // (wave-uniform trip count)
+            uint32_t v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                v[i] = (c + i < c_hi) ? __hip_atomic_load(&cn[c + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            const uint32_t mine = v[0] + v[1] + v[2] + v[3];
+            uint32_t incl = mine;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t t = __shfl_up(incl, o);
+                if (lane >= o) incl += t;
+            }
+            uint32_t run = carry + incl - mine;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (c + i < c_hi) { of[c + i] = run; cu[c + i] = run; }
+                run += v[i];
+            }
+            carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        }
+        if (tid == 0) of[cells] = total;   // end sentinel
+    }
+    __syncthreads();
+    // ---- counting-sort fill (cell order; the order inside a cell is the arrival order, as in knn_fill_kernel)
+    for (int64_t i = tid; i < cnt; i += KNN_BUILD_THREADS) {
+        const int64_t p = f + i;
+        const float x = pts[3 * p], y = pts[3 * p + 1], z = pts[3 * p + 2];
+        const int cx = cell_coord(x, g.minx, g.inv_cell, g.res);
+        const int cy = cell_coord(y, g.miny, g.inv_cell, g.res);
+        const int cz = cell_coord(z, g.minz, g.inv_cell, g.res);
+        const uint32_t pos = atomicAdd(&cu[(cz * g.res + cy) * g.res + cx], 1u);
+        sorted[f + pos] = make_float4(x, y, z, __int_as_float((int)p));
+    }
+}
+
 // FULL = false: K-th squared distance only (kth_sqdist (P,)).  FULL = true: the whole neighbour list, ascending in
 // (distance, id): dists (P,Krt) squared distances and idx (P,Krt) cloud-local ids, zero-padded when the cloud has
 // fewer than Krt points (the layout pytorch3d.ops.knn_points returns for a self query, losses.py:157-180).
@@ -380,6 +512,223 @@ __global__ __launch_bounds__(256) void knn_query_kernel(const float *__restrict_
     kth_sqdist[p] = kth;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Cooperative query: KNN_LPQ = 16 lanes (one DPP row) per query point.  The one-thread-per-point kernel above is a chain
+// of ~100 dependent 16-byte loads per query with two wavefronts per CU at DSS sizes (32k points = 512 wavefronts): 58 us,
+// the slowest kernel of a training iteration.  Here the 16 lanes of a group take every 16th
+// candidate of each row range -- one coalesced 256-byte request per trip, ~18 dependent trips per query, 16 x the
+// wavefronts to hide them behind --, keep their own sorted K-lists and merge them with four DPP rounds (quad_perm x 2,
+// row_half_mirror, row_mirror: plain VALU moves inside the row, no LDS round trip), after which every lane holds the
+// group's K best.  Same candidates, same (distance, id) order, same ring termination rule: identical results.
+// Further rings (rare) start from the merged list in lane 0 and empty lists elsewhere, so nothing is counted twice.
+// ---------------------------------------------------------------------------------------------------------------
+#define KNN_LPQ 16
+template <int CTRL>
+__device__ __forceinline__ float knn_dpp_f(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL>
+__device__ __forceinline__ int knn_dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
+
+// (distance, id) total order; ids are unique within a cloud, the padding entries (inf, 0x7fffffff) compare equal
+__device__ __forceinline__ bool knn_less(float da, int ia, float db, int ib) { return (da < db) | ((da == db) & (ia < ib)); }
+
+// this lane's ascending K-list merged with the list of the lane CTRL maps to: min(A[i], B[K-1-i]) picks the K smallest of
+// the union as a bitonic sequence, an odd-even transposition network sorts it (see merge_round in raster_forward.hip)
+template <int K, bool FULL, int CTRL>
+__device__ __forceinline__ void knn_merge_round(float (&best)[K], int (&bid)[FULL ? K : 1])
+{
+    float ob[K];
+    int oi[FULL ? K : 1];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        ob[k] = knn_dpp_f<CTRL>(best[k]);
+        if (FULL) oi[FULL ? k : 0] = knn_dpp_i<CTRL>(bid[FULL ? k : 0]);
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const bool lt = FULL ? knn_less(ob[K - 1 - k], oi[FULL ? K - 1 - k : 0], best[k], bid[FULL ? k : 0]) : ob[K - 1 - k] < best[k];
+        best[k] = lt ? ob[K - 1 - k] : best[k];
+        if (FULL) bid[FULL ? k : 0] = lt ? oi[FULL ? K - 1 - k : 0] : bid[FULL ? k : 0];
+    }
+#pragma unroll
+    for (int round = 0; round < K; ++round) {
+#pragma unroll
+        for (int k = round & 1; k + 1 < K; k += 2) {
+            const bool sw = FULL ? knn_less(best[k + 1], bid[FULL ? k + 1 : 0], best[k], bid[FULL ? k : 0]) : best[k + 1] < best[k];
+            const float a = best[k], b = best[k + 1];
+            best[k] = sw ? b : a;
+            best[k + 1] = sw ? a : b;
+            if (FULL) {
+                const int x = bid[FULL ? k : 0], y = bid[FULL ? k + 1 : 0];
+                bid[FULL ? k : 0] = sw ? y : x;
+                bid[FULL ? k + 1 : 0] = sw ? x : y;
+            }
+        }
+    }
+}
+
+template <int K, bool FULL>
+__global__ __launch_bounds__(256) void knn_query_coop_kernel(const float *__restrict__ pts, const int64_t *__restrict__ first_idx,
+                                                             const int64_t *__restrict__ num_pts, int N, int64_t P,
+                                                             const KnnGrid *__restrict__ grids, size_t stride,
+                                                             const uint32_t *__restrict__ offsets,
+                                                             const float4 *__restrict__ sorted, int Krt,
+                                                             float *__restrict__ kth_sqdist, float *__restrict__ dists,
+                                                             int64_t *__restrict__ idx)
+{
+    constexpr int GPB = 256 / KNN_LPQ;   // query groups per workgroup
+    const int grp = threadIdx.x / KNN_LPQ, sub = threadIdx.x % KNN_LPQ;
+    const int64_t slot = (int64_t)blockIdx.x * GPB + grp;
+    if (slot >= P) return;   // (whole DPP rows leave together)
+    const int n = find_cloud(slot, first_idx, num_pts, N);
+    if (n < 0) {  // packed slot outside every cloud
+        if (sub == 0) {
+            if (FULL) {
+                for (int k = 0; k < Krt; ++k) { dists[slot * Krt + k] = 0.0f; idx[slot * Krt + k] = 0; }
+            } else {
+                kth_sqdist[slot] = 0.0f;
+            }
+        }
+        return;
+    }
+    const KnnGrid g = grids[n];
+    const int64_t f0 = first_idx[n];
+    const int64_t cnt_n = num_pts[n];
+    const uint32_t *off = offsets + (size_t)n * stride;
+    const float4 self = sorted[slot];   // the slot-th point of the cell-sorted order
+    const int64_t p = (int64_t)__float_as_int(self.w);
+    const float qx = self.x, qy = self.y, qz = self.z;
+    const int cx = cell_coord(qx, g.minx, g.inv_cell, g.res);
+    const int cy = cell_coord(qy, g.miny, g.inv_cell, g.res);
+    const int cz = cell_coord(qz, g.minz, g.inv_cell, g.res);
+    float best[K];
+    int bid[FULL ? K : 1];
+#pragma unroll
+    for (int k = 0; k < K; ++k) best[k] = __builtin_huge_valf();
+#pragma unroll
+    for (int k = 0; k < (FULL ? K : 1); ++k) bid[k] = 0x7fffffff;
+    const int kk = (int)min((int64_t)Krt, cnt_n);
+    if (kk <= 0) {
+        if (!FULL && sub == 0) kth_sqdist[p] = 0.0f;
+        return;
+    }
+    auto consider = [&](const float4 q, bool on) {
+        const float dx = q.x - qx, dy = q.y - qy, dz = q.z - qz;
+        const float d2 = on ? dx * dx + dy * dy + dz * dz : __builtin_huge_valf();
+        if (FULL) {
+            const int id = on ? __float_as_int(q.w) : 0x7fffffff;
+            if (knn_less(d2, id, best[K - 1], bid[FULL ? K - 1 : 0])) {
+                bool lt[K];
+#pragma unroll
+                for (int k = 0; k < K; ++k) lt[k] = knn_less(d2, id, best[k], bid[FULL ? k : 0]);
+#pragma unroll
+                for (int k = K - 1; k >= 1; --k) {
+                    float pb = best[k - 1];
+                    int pi = bid[FULL ? k - 1 : 0];
+                    asm volatile("" : "+v"(pb), "+v"(pi));   // (keeps bid[] out of scratch, see knn_query_kernel)
+                    best[k] = lt[k - 1] ? pb : (lt[k] ? d2 : best[k]);
+                    bid[FULL ? k : 0] = lt[k - 1] ? pi : (lt[k] ? id : bid[FULL ? k : 0]);
+                }
+                best[0] = lt[0] ? d2 : best[0];
+                bid[0] = lt[0] ? id : bid[0];
+            }
+        } else if (d2 < best[K - 1]) {
+#pragma unroll
+            for (int k = K - 1; k >= 1; --k) {
+                const bool sh = d2 < best[k - 1];
+                best[k] = sh ? best[k - 1] : (d2 < best[k] ? d2 : best[k]);
+            }
+            best[0] = d2 < best[0] ? d2 : best[0];
+        }
+    };
+    // candidates [s, e) of the cell-sorted array, every KNN_LPQ-th one for this lane: the group's 16 loads of a trip are
+    // one contiguous 256-byte run; two trips are requested together
+    auto visit = [&](uint32_t s, uint32_t e) {
+        for (uint32_t base = s; base < e; base += 2 * KNN_LPQ) {   // (group-uniform trip count)
+            const uint32_t j0 = base + (uint32_t)sub, j1 = j0 + KNN_LPQ;
+            const bool on0 = j0 < e, on1 = j1 < e;
+            const float4 q0 = sorted[f0 + (on0 ? j0 : s)], q1 = sorted[f0 + (on1 ? j1 : s)];   // clamped, unconditional
+            consider(q0, on0);
+            consider(q1, on1);
+        }
+    };
+    __shared__ uint32_t row_lo[9][GPB], row_hi[9][GPB];
+    if (sub < 9) {   // lane r of the group fetches the offsets of row r of the 3 x 3 x 3 block
+        const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.res - 1);
+        const int z = cz + sub / 3 - 1, y = cy + sub % 3 - 1;
+        const bool in = z >= 0 && z < g.res && y >= 0 && y < g.res;
+        const int c = in ? (z * g.res + y) * g.res : 0;
+        const uint32_t s = off[c + x0], e = off[c + x1 + 1];
+        row_lo[sub][grp] = in ? s : 0u;
+        row_hi[sub][grp] = in ? e : 0u;
+    }
+    __builtin_amdgcn_wave_barrier();   // same wavefront wrote and reads the row table (LDS operations of a wave complete in order)
+    for (int ring = 1; ring <= g.res; ++ring) {
+        const int x0 = max(cx - ring, 0), x1 = min(cx + ring, g.res - 1);
+        const int y0 = max(cy - ring, 0), y1 = min(cy + ring, g.res - 1);
+        const int z0 = max(cz - ring, 0), z1 = min(cz + ring, g.res - 1);
+        const int ny = y1 - y0 + 1;
+        const int walks = ring == 1 ? 9 : 2 * ny * (z1 - z0 + 1);
+#pragma nounroll
+        for (int t = 0; t < walks; ++t) {
+            uint32_t s, e;
+            if (ring == 1) {
+                s = row_lo[t][grp];
+                e = row_hi[t][grp];
+            } else {
+                const int row = t >> 1, z = z0 + row / ny, y = y0 + row % ny;
+                const int c = (z * g.res + y) * g.res;
+                const bool full = z == cz - ring || z == cz + ring || y == cy - ring || y == cy + ring;
+                const int xa = full ? x0 : ((t & 1) ? cx + ring : cx - ring);
+                const int xb = full ? x1 : xa;
+                if ((full && (t & 1)) || xa < 0 || xb >= g.res) continue;
+                s = off[c + xa];
+                e = off[c + xb + 1];
+            }
+            visit(s, e);
+        }
+        // the group's K best: four merge rounds inside the DPP row, every lane ends with the same list
+        knn_merge_round<K, FULL, 0xB1>(best, bid);    // quad_perm [1,0,3,2]
+        knn_merge_round<K, FULL, 0x4E>(best, bid);    // quad_perm [2,3,0,1]
+        knn_merge_round<K, FULL, 0x141>(best, bid);   // row_half_mirror
+        knn_merge_round<K, FULL, 0x140>(best, bid);   // row_mirror
+        float bound = __builtin_huge_valf();
+        if (cx - ring > 0) bound = fminf(bound, qx - (g.minx + (float)(cx - ring) * g.cell));
+        if (cx + ring < g.res - 1) bound = fminf(bound, (g.minx + (float)(cx + ring + 1) * g.cell) - qx);
+        if (cy - ring > 0) bound = fminf(bound, qy - (g.miny + (float)(cy - ring) * g.cell));
+        if (cy + ring < g.res - 1) bound = fminf(bound, (g.miny + (float)(cy + ring + 1) * g.cell) - qy);
+        if (cz - ring > 0) bound = fminf(bound, qz - (g.minz + (float)(cz - ring) * g.cell));
+        if (cz + ring < g.res - 1) bound = fminf(bound, (g.minz + (float)(cz + ring + 1) * g.cell) - qz);
+        bound = bound - 1e-6f * fmaxf(fabsf(bound), g.cell);
+        float kth = best[0];
+#pragma unroll
+        for (int k = 1; k < K; ++k) kth = (k < kk) ? best[k] : kth;
+        if (bound == __builtin_huge_valf() || (bound > 0.0f && kth <= bound * bound)) break;
+        if (sub != 0) {   // next ring: lane 0 carries the merged list, the others start empty (nothing is counted twice)
+#pragma unroll
+            for (int k = 0; k < K; ++k) best[k] = __builtin_huge_valf();
+#pragma unroll
+            for (int k = 0; k < (FULL ? K : 1); ++k) bid[k] = 0x7fffffff;
+        }
+    }
+    if (sub != 0) return;
+    if (FULL) {
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+            if (k < Krt) {
+                dists[p * Krt + k] = k < kk ? best[k] : 0.0f;
+                idx[p * Krt + k] = k < kk ? (int64_t)bid[FULL ? k : 0] - f0 : 0;
+            }
+        return;
+    }
+    float kth = best[0];
+#pragma unroll
+    for (int k = 1; k < K; ++k) kth = (k < kk) ? best[k] : kth;
+    kth_sqdist[p] = kth;
+}
+
 // deterministic per-cloud mean of values*scale clamped to [lo,hi]: one workgroup per cloud, fixed order
 __global__ __launch_bounds__(1024) void cloud_mean_kernel(const float *__restrict__ vals, const int64_t *__restrict__ first_idx,
                                                           const int64_t *__restrict__ num_pts, float scale, float lo,
@@ -474,31 +823,44 @@ static int knn_run(const char *who, const float *points, const int64_t *first_id
     uint32_t *blk_tot = reinterpret_cast<uint32_t *>(w + off);    off += align_up((size_t)N * nblk * 4, 256);
     int32_t *cell_of = reinterpret_cast<int32_t *>(w + off);      off += align_up((size_t)P * 4, 256);
     float4 *sorted = reinterpret_cast<float4 *>(w + off);
-    if (hipMemsetAsync(counts, 0, cbytes, st) != hipSuccess) return check_launch("knn memset");
-    const unsigned pb = (unsigned)((P + 255) / 256);
-    if (int rc = launch_cloud_bbox(points, first_idx, num_pts, N, P, bbox, st)) return rc;
-    hipLaunchKernelGGL(knn_grid_kernel, dim3((N + 63) / 64), dim3(64), 0, st, bbox, num_pts, N, knn_res_cap(P), grids);
-    hipLaunchKernelGGL(knn_count_kernel, dim3(pb), dim3(256), 0, st, points, first_idx, num_pts, N, P, grids, stride, counts,
-                       cell_of);
-    hipLaunchKernelGGL(knn_scan_local_kernel, dim3(nblk, N), dim3(256), 0, st, counts, grids, stride, nblk, offsets, blk_tot);
-    hipLaunchKernelGGL(knn_scan_add_kernel, dim3(nblk, N), dim3(256), 0, st, grids, stride, nblk, blk_tot, offsets, cursor);
-    hipLaunchKernelGGL(knn_fill_kernel, dim3(pb), dim3(256), 0, st, points, first_idx, num_pts, N, P, cell_of, stride, cursor,
-                       sorted);
+    if (P <= KNN_SMALL_P) {
+        // small inputs: the whole build of a cloud in one workgroup, one launch
+        hipLaunchKernelGGL(knn_build_small_kernel, dim3(N), dim3(KNN_BUILD_THREADS), 0, st, points, first_idx, num_pts, P,
+                           knn_res_cap(P), stride, grids, counts, offsets, cursor, sorted);
+    } else {
+        if (hipMemsetAsync(counts, 0, cbytes, st) != hipSuccess) return check_launch("knn memset");
+        const unsigned pb = (unsigned)((P + 255) / 256);
+        if (int rc = launch_cloud_bbox(points, first_idx, num_pts, N, P, bbox, st)) return rc;
+        hipLaunchKernelGGL(knn_grid_kernel, dim3((N + 63) / 64), dim3(64), 0, st, bbox, num_pts, N, knn_res_cap(P), grids);
+        hipLaunchKernelGGL(knn_count_kernel, dim3(pb), dim3(256), 0, st, points, first_idx, num_pts, N, P, grids, stride,
+                           counts, cell_of);
+        hipLaunchKernelGGL(knn_scan_local_kernel, dim3(nblk, N), dim3(256), 0, st, counts, grids, stride, nblk, offsets,
+                           blk_tot);
+        hipLaunchKernelGGL(knn_scan_add_kernel, dim3(nblk, N), dim3(256), 0, st, grids, stride, nblk, blk_tot, offsets, cursor);
+        hipLaunchKernelGGL(knn_fill_kernel, dim3(pb), dim3(256), 0, st, points, first_idx, num_pts, N, P, cell_of, stride,
+                           cursor, sorted);
+    }
     // small inputs: one wavefront per workgroup, so that the few hundred wavefronts spread over all 256 CUs
     const unsigned qt = P <= 131072 ? 64u : 256u;
     const unsigned qb = (unsigned)((P + qt - 1) / qt);
 #define KNN_LAUNCH(KK, FF)                                                                                          \
     hipLaunchKernelGGL((knn_query_kernel<KK, FF>), dim3(qb), dim3(qt), 0, st, points, first_idx, num_pts, N, P, grids,  \
                        stride, offsets, sorted, K, kth_sqdist, dists, idx)
+    // cooperative kernel: 16 lanes per query (K <= 16); the one-thread-per-query kernel keeps the deep lists
+    const unsigned cb = (unsigned)((P + (256 / KNN_LPQ) - 1) / (256 / KNN_LPQ));
+#define KNN_LAUNCH_COOP(KK, FF)                                                                                     \
+    hipLaunchKernelGGL((knn_query_coop_kernel<KK, FF>), dim3(cb), dim3(256), 0, st, points, first_idx, num_pts, N, P, grids, \
+                       stride, offsets, sorted, K, kth_sqdist, dists, idx)
     if (full) {
-        if (K <= 8) KNN_LAUNCH(8, true);
-        else if (K <= 12) KNN_LAUNCH(12, true);  // the regularisers' knn_k (trainer.py:134-137)
-        else if (K <= 16) KNN_LAUNCH(16, true);
+        if (K <= 8) KNN_LAUNCH_COOP(8, true);
+        else if (K <= 12) KNN_LAUNCH_COOP(12, true);  // the regularisers' knn_k (trainer.py:134-137)
+        else if (K <= 16) KNN_LAUNCH_COOP(16, true);
         else KNN_LAUNCH(KNN_FULL_MAX_K, true);
     } else {
-        if (K <= 8) KNN_LAUNCH(8, false);
-        else KNN_LAUNCH(KNN_MAX_K, false);
+        if (K <= 8) KNN_LAUNCH_COOP(8, false);
+        else KNN_LAUNCH_COOP(KNN_MAX_K, false);
     }
+#undef KNN_LAUNCH_COOP
 #undef KNN_LAUNCH
     return check_launch(who);
 }
