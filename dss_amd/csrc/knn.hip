@@ -214,28 +214,34 @@ __global__ __launch_bounds__(256) void knn_fill_kernel(const float *__restrict__
     sorted[first_idx[n] + pos] = make_float4(pts[3 * p], pts[3 * p + 1], pts[3 * p + 2], __int_as_float((int)p));
 }
 
-// Whole grid build of ONE cloud in ONE workgroup (small inputs: P <= KNN_SMALL_P packed points): bounding box -> grid
-// parameters -> zeroed cell counts -> counting (cell of every point) -> exclusive scan of the cells -> counting-sort fill.
-// Replaces eight launches (memset, init, bbox, grid, count, scan x 2, fill: ~40 us of launch latencies at 32k points
-// for ~6 us of work) by one; the cell arrays stay in global memory (L2), every phase is separated by a workgroup barrier,
-// values written by atomics are read back with agent-scope atomic loads (they live in L2, not in this CU's vector cache).
-#define KNN_SMALL_P 65536
-#define KNN_BUILD_THREADS 1024
-__global__ __launch_bounds__(KNN_BUILD_THREADS) void knn_build_small_kernel(
-    const float *__restrict__ pts, const int64_t *__restrict__ first_idx, const int64_t *__restrict__ num_pts, int64_t P,
-    int res_cap, size_t stride, KnnGrid *__restrict__ grids, uint32_t *__restrict__ counts, uint32_t *__restrict__ offsets,
-    uint32_t *__restrict__ cursor, float4 *__restrict__ sorted)
+// ---------------------------------------------------------------------------------------------------------------
+// Small inputs (P <= KNN_SMALL_P): the grid build is a chain of launch latencies (ten launches, ~45 us at 32k points for
+// a few us of work).  Three of them disappear here: [bbox partials + zeroed counts] -> [grid + count] -> [scan, one
+// launch] -> [fill] instead of memset, init, bbox, grid, count, scan x 2, fill.  (A whole-build-in-one-workgroup kernel was
+// tried first: 180 us -- 32 points per thread through dependent load -> returning atomic -> store chains on ONE CU.)
+// ---------------------------------------------------------------------------------------------------------------
+#define KNN_SMALL_P 131072
+#define KNN_BB_WGS 32           // bounding-box workgroups per cloud
+// grid (KNN_BB_WGS + zero workgroups, N): the first KNN_BB_WGS workgroups of cloud n reduce their share of its points to
+// one partial box each (plain stores: no init, no atomics); the others zero the cell counts of cloud n
+__global__ __launch_bounds__(256) void knn_bbox_partial_kernel(const float *__restrict__ pts, const int64_t *__restrict__ first_idx,
+                                                               const int64_t *__restrict__ num_pts, int64_t P,
+                                                               int *__restrict__ partial /* (N, KNN_BB_WGS, 6) */,
+                                                               uint32_t *__restrict__ counts, size_t stride)
 {
-    __shared__ int s_red[KNN_BUILD_THREADS / 64][6];
-    __shared__ uint32_t s_wave[KNN_BUILD_THREADS / 64];
-    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int64_t f = first_idx[n];
-    const int64_t cnt = max((int64_t)0, min(num_pts[n], P - f));
-    // ---- bounding box (NaN coordinates skipped), same ordered-int reduction as knn_bbox_kernel
+    const int n = blockIdx.y;
+    if (blockIdx.x >= KNN_BB_WGS) {
+        const size_t zw = gridDim.x - KNN_BB_WGS;
+        uint32_t *c = counts + (size_t)n * stride;
+        for (size_t i = (size_t)(blockIdx.x - KNN_BB_WGS) * 256 + threadIdx.x; i < stride; i += zw * 256) c[i] = 0u;
+        return;
+    }
+    const int64_t f = first_idx[n], cnt = num_pts[n];
     int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff};
     int hi[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
-    for (int64_t i = tid; i < cnt; i += KNN_BUILD_THREADS) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < cnt; i += (int64_t)KNN_BB_WGS * 256) {
         const int64_t p = f + i;
+        if (p >= P) break;
         const float x = pts[3 * p], y = pts[3 * p + 1], z = pts[3 * p + 2];
         if (!(x == x && y == y && z == z)) continue;
         const int ox = f2ord(x), oy = f2ord(y), oz = f2ord(z);
@@ -249,101 +255,134 @@ __global__ __launch_bounds__(KNN_BUILD_THREADS) void knn_build_small_kernel(
             lo[d] = min(lo[d], __shfl_xor(lo[d], o));
             hi[d] = max(hi[d], __shfl_xor(hi[d], o));
         }
-    if (lane == 0) {
+    __shared__ int part[4][6];
+    const int wid = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-        for (int d = 0; d < 3; ++d) { s_red[wid][d] = lo[d]; s_red[wid][3 + d] = hi[d]; }
+        for (int d = 0; d < 3; ++d) { part[wid][d] = lo[d]; part[wid][3 + d] = hi[d]; }
     }
     __syncthreads();
+    if (threadIdx.x < 6) {
+        const int d = threadIdx.x;
+        int v = part[0][d];
 #pragma unroll
-    for (int d = 0; d < 3; ++d) {
-        lo[d] = 0x7fffffff;
-        hi[d] = (int)0x80000000;
-        for (int w = 0; w < KNN_BUILD_THREADS / 64; ++w) { lo[d] = min(lo[d], s_red[w][d]); hi[d] = max(hi[d], s_red[w][3 + d]); }
+        for (int w = 1; w < 4; ++w) v = d < 3 ? min(v, part[w][d]) : max(v, part[w][d]);
+        partial[((size_t)n * KNN_BB_WGS + blockIdx.x) * 6 + d] = v;
     }
-    // ---- grid parameters (knn_grid_kernel): every thread derives the same values
+}
+
+// grid parameters of cloud n from the partial boxes (the arithmetic of knn_grid_kernel)
+__device__ __forceinline__ KnnGrid knn_grid_from_partials(const int *__restrict__ partial, int n, int64_t npts, int res_cap, int lane)
+{
+    int v[6];
+#pragma unroll
+    for (int d = 0; d < 6; ++d) {
+        v[d] = lane < KNN_BB_WGS ? partial[((size_t)n * KNN_BB_WGS + lane) * 6 + d] : (d < 3 ? 0x7fffffff : (int)0x80000000);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const int t = __shfl_xor(v[d], o);
+            v[d] = d < 3 ? min(v[d], t) : max(v[d], t);
+        }
+    }
     KnnGrid g;
-    {
-        const float x0 = ord2f(lo[0]), y0 = ord2f(lo[1]), z0 = ord2f(lo[2]);
-        const float x1 = ord2f(hi[0]), y1 = ord2f(hi[1]), z1 = ord2f(hi[2]);
-        const float ext = fmaxf(fmaxf(x1 - x0, y1 - y0), fmaxf(z1 - z0, 1e-12f));
-        int res = (int)ceilf(sqrtf((float)num_pts[n] / 24.0f));
-        res = max(1, min(res_cap, res));
-        g.minx = x0; g.miny = y0; g.minz = z0;
-        g.cell = ext / (float)res * 1.0001f;
-        g.inv_cell = 1.0f / g.cell;
-        g.res = res;
-        g.pad0 = g.pad1 = 0;
-    }
-    if (tid == 0) grids[n] = g;
-    const int cells = g.res * g.res * g.res;
-    uint32_t *cn = counts + (size_t)n * stride, *of = offsets + (size_t)n * stride, *cu = cursor + (size_t)n * stride;
-    for (int c = tid; c < cells; c += KNN_BUILD_THREADS) cn[c] = 0u;
-    __syncthreads();
-    // ---- count
-    for (int64_t i = tid; i < cnt; i += KNN_BUILD_THREADS) {
-        const int64_t p = f + i;
-        const int cx = cell_coord(pts[3 * p], g.minx, g.inv_cell, g.res);
-        const int cy = cell_coord(pts[3 * p + 1], g.miny, g.inv_cell, g.res);
-        const int cz = cell_coord(pts[3 * p + 2], g.minz, g.inv_cell, g.res);
-        atomicAdd(&cn[(cz * g.res + cy) * g.res + cx], 1u);
-    }
-    __syncthreads();
-    // ---- exclusive scan of the cell counts.  Every wavefront owns a contiguous segment of the cells (a multiple of 256):
-    // pass A sums it (independent coalesced loads), one workgroup barrier turns the 16 totals into segment prefixes, pass B
-    // re-reads the segment 256 cells at a time and writes the running offsets (wave scan on shuffles, carry in a register).
-    {
-        constexpr int NW = KNN_BUILD_THREADS / 64;
-        const int seg = ((cells + NW * 256 - 1) / (NW * 256)) * 256;   // cells per wavefront
-        const int c_lo = wid * seg, c_hi = min(c_lo + seg, cells);
-        uint32_t sum = 0;
-        for (int c = c_lo + 4 * lane; c < c_hi; c += 256) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (c + i < c_hi) sum += __hip_atomic_load(&cn[c + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-        if (lane == 0) s_wave[wid] = sum;
-        __syncthreads();
-        uint32_t carry = 0, total = 0;
-        for (int w = 0; w < NW; ++w) {
-            const uint32_t t = s_wave[w];
-            carry += (w < wid) ? t : 0u;
-            total += t;
-        }
-        for (int c = c_lo + 4 * lane; c - 4 * lane < c_hi; c += 256) {   // (wave-uniform trip count)
-            uint32_t v[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                v[i] = (c + i < c_hi) ? __hip_atomic_load(&cn[c + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-            const uint32_t mine = v[0] + v[1] + v[2] + v[3];
-            uint32_t incl = mine;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const uint32_t t = __shfl_up(incl, o);
-                if (lane >= o) incl += t;
+    const float x0 = ord2f(v[0]), y0 = ord2f(v[1]), z0 = ord2f(v[2]);
+    const float x1 = ord2f(v[3]), y1 = ord2f(v[4]), z1 = ord2f(v[5]);
+    const float ext = fmaxf(fmaxf(x1 - x0, y1 - y0), fmaxf(z1 - z0, 1e-12f));
+    int res = (int)ceilf(sqrtf((float)npts / 24.0f));
+    res = max(1, min(res_cap, res));
+    g.minx = x0; g.miny = y0; g.minz = z0;
+    g.cell = ext / (float)res * 1.0001f;
+    g.inv_cell = 1.0f / g.cell;
+    g.res = res;
+    g.pad0 = g.pad1 = 0;
+    return g;
+}
+
+// count with the grid derived in place: one workgroup handles 256 consecutive packed points, its first wavefront reduces
+// the partial boxes of the (at most KNN_GRID_LDS) clouds it touches into LDS; workgroup 0 also publishes grids[] for the
+// later launches.  Clouds beyond KNN_GRID_LDS fall back to the separate grid kernel (host side).
+#define KNN_GRID_LDS 16
+__global__ __launch_bounds__(256) void knn_count_grid_kernel(const float *__restrict__ pts, const int64_t *__restrict__ first_idx,
+                                                             const int64_t *__restrict__ num_pts, int N, int64_t P,
+                                                             const int *__restrict__ partial, int res_cap,
+                                                             KnnGrid *__restrict__ grids, size_t stride,
+                                                             uint32_t *__restrict__ counts, int32_t *__restrict__ cell_of)
+{
+    __shared__ KnnGrid s_g[KNN_GRID_LDS];
+    if (threadIdx.x < 64) {
+        for (int n = 0; n < N; ++n) {
+            const KnnGrid g = knn_grid_from_partials(partial, n, num_pts[n], res_cap, threadIdx.x);
+            if (threadIdx.x == 0) {
+                s_g[n] = g;
+                if (blockIdx.x == 0) grids[n] = g;
             }
-            uint32_t run = carry + incl - mine;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (c + i < c_hi) { of[c + i] = run; cu[c + i] = run; }
-                run += v[i];
-            }
-            carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         }
-        if (tid == 0) of[cells] = total;   // end sentinel
     }
     __syncthreads();
-    // ---- counting-sort fill (cell order; the order inside a cell is the arrival order, as in knn_fill_kernel)
-    for (int64_t i = tid; i < cnt; i += KNN_BUILD_THREADS) {
-        const int64_t p = f + i;
-        const float x = pts[3 * p], y = pts[3 * p + 1], z = pts[3 * p + 2];
-        const int cx = cell_coord(x, g.minx, g.inv_cell, g.res);
-        const int cy = cell_coord(y, g.miny, g.inv_cell, g.res);
-        const int cz = cell_coord(z, g.minz, g.inv_cell, g.res);
-        const uint32_t pos = atomicAdd(&cu[(cz * g.res + cy) * g.res + cx], 1u);
-        sorted[f + pos] = make_float4(x, y, z, __int_as_float((int)p));
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const int n = find_cloud(p, first_idx, num_pts, N);
+    if (n < 0) { cell_of[p] = -1; return; }
+    const KnnGrid g = s_g[n];
+    const int cx = cell_coord(pts[3 * p], g.minx, g.inv_cell, g.res);
+    const int cy = cell_coord(pts[3 * p + 1], g.miny, g.inv_cell, g.res);
+    const int cz = cell_coord(pts[3 * p + 2], g.minz, g.inv_cell, g.res);
+    const int c = (cz * g.res + cy) * g.res + cx;
+    cell_of[p] = c;
+    atomicAdd(&counts[(size_t)n * stride + c], 1u);
+}
+
+// exclusive scan of the cell counts in ONE launch (at most KNN_SCAN1_BLOCKS blocks of 1024 cells per cloud): block b first
+// sums the counts of all the cells in front of it (coalesced, eight independent loads in flight per thread: with 256
+// threads and one load at a time the last block of 50 took 28 us), then scans its own 1024 cells, one per thread
+#define KNN_SCAN1_BLOCKS 160
+__global__ __launch_bounds__(1024) void knn_scan_single_kernel(const uint32_t *__restrict__ counts,
+                                                               const KnnGrid *__restrict__ grids, size_t stride,
+                                                               uint32_t *__restrict__ offsets, uint32_t *__restrict__ cursor)
+{
+    __shared__ uint32_t wave_tot[16];
+    __shared__ uint32_t wave_pre[16];
+    const int n = blockIdx.y, b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int res = grids[n].res;
+    const int cells = res * res * res;
+    if (b * KNN_SCAN_BLOCK >= cells) return;
+    const uint32_t *c = counts + (size_t)n * stride;
+    const int lim = b * KNN_SCAN_BLOCK;
+    uint32_t p0 = 0, p1 = 0, p2 = 0, p3 = 0, p4 = 0, p5 = 0, p6 = 0, p7 = 0;
+    int i = tid;
+    for (; i + 7 * 1024 < lim; i += 8 * 1024) {
+        p0 += c[i]; p1 += c[i + 1024]; p2 += c[i + 2048]; p3 += c[i + 3072];
+        p4 += c[i + 4096]; p5 += c[i + 5120]; p6 += c[i + 6144]; p7 += c[i + 7168];
     }
+    for (; i < lim; i += 1024) p0 += c[i];
+    uint32_t part = ((p0 + p1) + (p2 + p3)) + ((p4 + p5) + (p6 + p7));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+    const int c0 = lim + tid;
+    const uint32_t v = c0 < cells ? c[c0] : 0u;
+    uint32_t incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) wave_tot[wid] = incl;
+    if (lane == 0) wave_pre[wid] = part;
+    __syncthreads();
+    uint32_t before = 0, total = 0, prefix = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        const uint32_t t = wave_tot[w];
+        before += (w < wid) ? t : 0u;
+        total += t;
+        prefix += wave_pre[w];
+    }
+    const uint32_t run = prefix + before + incl - v;
+    if (c0 < cells) {
+        offsets[(size_t)n * stride + c0] = run;
+        cursor[(size_t)n * stride + c0] = run;
+    }
+    if (tid == 0 && (b + 1) * KNN_SCAN_BLOCK >= cells) offsets[(size_t)n * stride + cells] = prefix + total;
 }
 
 // FULL = false: K-th squared distance only (kth_sqdist (P,)).  FULL = true: the whole neighbour list, ascending in
@@ -729,25 +768,32 @@ __global__ __launch_bounds__(256) void knn_query_coop_kernel(const float *__rest
     kth_sqdist[p] = kth;
 }
 
-// deterministic per-cloud mean of values*scale clamped to [lo,hi]: one workgroup per cloud, fixed order
+// deterministic per-cloud mean of values*scale clamped to [lo,hi]: one workgroup per cloud, fixed order (four independent
+// partial sums per thread, wave reduction on shuffles, 16 wave totals: the 10-step LDS tree of round 1 took 19 us)
 __global__ __launch_bounds__(1024) void cloud_mean_kernel(const float *__restrict__ vals, const int64_t *__restrict__ first_idx,
                                                           const int64_t *__restrict__ num_pts, float scale, float lo,
                                                           float hi, float fallback, int min_points,
                                                           float *__restrict__ out)
 {
-    __shared__ double part[1024];
+    __shared__ double part[16];
     const int n = blockIdx.x, tid = threadIdx.x;
     const int64_t f0 = first_idx[n], cnt = num_pts[n];
-    double acc = 0.0;
-    for (int64_t i = tid; i < cnt; i += 1024) acc += (double)(vals[f0 + i] * scale);
-    part[tid] = acc;
-    __syncthreads();
-    for (int s = 512; s > 0; s >>= 1) {
-        if (tid < s) part[tid] += part[tid + s];
-        __syncthreads();
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int64_t i = tid;
+    for (; i + 3 * 1024 < cnt; i += 4 * 1024) {
+        const float v0 = vals[f0 + i], v1 = vals[f0 + i + 1024], v2 = vals[f0 + i + 2048], v3 = vals[f0 + i + 3072];
+        a0 += (double)(v0 * scale); a1 += (double)(v1 * scale); a2 += (double)(v2 * scale); a3 += (double)(v3 * scale);
     }
+    for (; i < cnt; i += 1024) a0 += (double)(vals[f0 + i] * scale);
+    double acc = (a0 + a1) + (a2 + a3);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((tid & 63) == 0) part[tid >> 6] = acc;
+    __syncthreads();
     if (tid == 0) {
-        float m = (cnt >= min_points && cnt > 0) ? (float)(part[0] / (double)cnt) : fallback;
+        double t = 0.0;
+        for (int w = 0; w < 16; ++w) t += part[w];
+        float m = (cnt >= min_points && cnt > 0) ? (float)(t / (double)cnt) : fallback;
         out[n] = fminf(fmaxf(m, lo), hi);
     }
 }
@@ -774,7 +820,7 @@ static int knn_blocks(int64_t P) { return (int)((knn_stride(P) - 1 + KNN_SCAN_BL
 extern "C" size_t dss_knn_workspace(int N, int64_t P)
 {
     const size_t n = N > 0 ? N : 1, p = P > 0 ? P : 1;
-    return align_up(n * 6 * 4, 256) + align_up(n * sizeof(KnnGrid), 256) + align_up((knn_cells(N, P) + 1) * 4, 256) * 3 +
+    return align_up(n * 6 * 4 * KNN_BB_WGS, 256) + align_up(n * sizeof(KnnGrid), 256) + align_up((knn_cells(N, P) + 1) * 4, 256) * 3 +
            align_up(n * (size_t)knn_blocks(P) * 4, 256) + align_up(p * 4, 256) + align_up(p * 16, 256);
 }
 
@@ -812,7 +858,7 @@ static int knn_run(const char *who, const float *points, const int64_t *first_id
     hipStream_t st = as_stream(stream);
     char *w = reinterpret_cast<char *>(workspace);
     size_t off = 0;
-    int *bbox = reinterpret_cast<int *>(w + off);                 off += align_up((size_t)N * 6 * 4, 256);
+    int *bbox = reinterpret_cast<int *>(w + off);                 off += align_up((size_t)N * 6 * 4 * KNN_BB_WGS, 256);  // box, or the partial boxes
     KnnGrid *grids = reinterpret_cast<KnnGrid *>(w + off);        off += align_up((size_t)N * sizeof(KnnGrid), 256);
     const size_t cbytes = align_up((knn_cells(N, P) + 1) * 4, 256);
     const size_t stride = knn_stride(P);
@@ -823,10 +869,18 @@ static int knn_run(const char *who, const float *points, const int64_t *first_id
     uint32_t *blk_tot = reinterpret_cast<uint32_t *>(w + off);    off += align_up((size_t)N * nblk * 4, 256);
     int32_t *cell_of = reinterpret_cast<int32_t *>(w + off);      off += align_up((size_t)P * 4, 256);
     float4 *sorted = reinterpret_cast<float4 *>(w + off);
-    if (P <= KNN_SMALL_P) {
-        // small inputs: the whole build of a cloud in one workgroup, one launch
-        hipLaunchKernelGGL(knn_build_small_kernel, dim3(N), dim3(KNN_BUILD_THREADS), 0, st, points, first_idx, num_pts, P,
-                           knn_res_cap(P), stride, grids, counts, offsets, cursor, sorted);
+    const unsigned pb_s = (unsigned)((P + 255) / 256);
+    if (P <= KNN_SMALL_P && N <= KNN_GRID_LDS && nblk <= KNN_SCAN1_BLOCKS) {
+        // small inputs: four launches instead of eight (see knn_bbox_partial_kernel)
+        int *partial = bbox;   // (N, KNN_BB_WGS, 6)
+        const unsigned zero_wgs = (unsigned)((stride + 4095) / 4096);
+        hipLaunchKernelGGL(knn_bbox_partial_kernel, dim3(KNN_BB_WGS + (zero_wgs ? zero_wgs : 1), N), dim3(256), 0, st, points,
+                           first_idx, num_pts, P, partial, counts, stride);
+        hipLaunchKernelGGL(knn_count_grid_kernel, dim3(pb_s), dim3(256), 0, st, points, first_idx, num_pts, N, P, partial,
+                           knn_res_cap(P), grids, stride, counts, cell_of);
+        hipLaunchKernelGGL(knn_scan_single_kernel, dim3(nblk, N), dim3(1024), 0, st, counts, grids, stride, offsets, cursor);
+        hipLaunchKernelGGL(knn_fill_kernel, dim3(pb_s), dim3(256), 0, st, points, first_idx, num_pts, N, P, cell_of, stride,
+                           cursor, sorted);
     } else {
         if (hipMemsetAsync(counts, 0, cbytes, st) != hipSuccess) return check_launch("knn memset");
         const unsigned pb = (unsigned)((P + 255) / 256);
@@ -852,9 +906,12 @@ static int knn_run(const char *who, const float *points, const int64_t *first_id
     hipLaunchKernelGGL((knn_query_coop_kernel<KK, FF>), dim3(cb), dim3(256), 0, st, points, first_idx, num_pts, N, P, grids, \
                        stride, offsets, sorted, K, kth_sqdist, dists, idx)
     if (full) {
-        if (K <= 8) KNN_LAUNCH_COOP(8, true);
-        else if (K <= 12) KNN_LAUNCH_COOP(12, true);  // the regularisers' knn_k (trainer.py:134-137)
-        else if (K <= 16) KNN_LAUNCH_COOP(16, true);
+        // full lists: the cooperative kernel wins while the launch is latency-bound (32k points, K = 12: 58 us against
+        // ~100); at 100k points the merges of (distance, id) lists cost more than the shorter chains save (182 vs 155 us)
+        const bool coop = P <= 65536;
+        if (K <= 8) { if (coop) KNN_LAUNCH_COOP(8, true); else KNN_LAUNCH(8, true); }
+        else if (K <= 12) { if (coop) KNN_LAUNCH_COOP(12, true); else KNN_LAUNCH(12, true); }  // the regularisers' knn_k (trainer.py:134-137)
+        else if (K <= 16) { if (coop) KNN_LAUNCH_COOP(16, true); else KNN_LAUNCH(16, true); }
         else KNN_LAUNCH(KNN_FULL_MAX_K, true);
     } else {
         if (K <= 8) KNN_LAUNCH_COOP(8, false);

@@ -93,8 +93,9 @@ def test_hot_kernels_do_not_spill_to_scratch():
     hot = ["fine_kernelILi%dE" % k for k in (1, 2, 3, 4, 5, 8)] + [
         "render_backward_kernelILi3E", "occ_backward_kernel", "blend_backward_kernelILi3E", "setup_bin_kernel",
         "bin_kernel", "spill_kernel", "occ_box_backward_kernel", "visible_scan_kernel", "median_hist_kernel", "backward_compact_kernel", "median_visible_kernel", "point_setup_kernel", "project_backward_kernel",
-        "blend_forward_kernelILi3E", "knn_query_kernelILi8ELb0E", "knn_query_kernelILi8ELb1E",
-        "knn_query_kernelILi12ELb1E", "knn_query_kernelILi16ELb1E", "projection_loss_kernel", "repulsion_loss_kernel",
+        "blend_forward_kernelILi3E", "knn_query_coop_kernelILi8ELb0E", "knn_query_coop_kernelILi16ELb0E",
+        "knn_query_coop_kernelILi12ELb1E", "knn_query_kernelILi8ELb1E", "knn_query_kernelILi12ELb1E", "knn_query_kernelILi16ELb1E",
+        "knn_scan_single_kernel", "knn_count_grid_kernel", "knn_bbox_partial_kernel", "projection_loss_kernel", "repulsion_loss_kernel",
         "mollify_normals_kernel", "image_loss_reduce_kernel", "image_loss_grad_kernel", "points_inmask_kernel"]
     seen = {}
     for src in ("raster_forward.hip", "raster_backward.hip", "blend.hip", "setup.hip", "knn.hip", "regularizers.hip", "image_loss.hip"):
