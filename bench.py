@@ -134,16 +134,81 @@ class Workload:
         mark("projection_compute")
         return image, g_world, g_col
 
+    # ---- multi-GPU: the compute between the collectives as hipGraphs ---------------------------------
+    def capture_segments(self):
+        """Three graphs -- [setup + binning + fine + blend], [compaction + median + band filter + gather],
+        [clip + projection backward] -- replayed around the three collectives of `step`: the multi-rank step then costs the
+        host three graph launches + three collective calls instead of ~10 kernel launches through Python."""
+        p, S = self.part, self.S
+        self.g_band = p.slice(self.grad_out).contiguous()
+        self.vis_all = torch.zeros(self.P, dtype=torch.uint8, device=self.dev)
+        g_feat = self.bucket[:self.P * 3].view(self.P, 3)
+        g_pts = self.bucket[self.P * 3:].view(self.P, 3)
+        seg = {}
+
+        def fwd():
+            seg["f"] = ops.render_forward(self.world, self.normals, self.h, self.M, self.V, self.znear, self.zfar, self.first,
+                                          self.num, self.colors, S, K, CUTOFF, THR, SIGMA, False, True, rows=p.rows,
+                                          out_image=self.fx.image, out_visible=self.fx.visible)
+
+        def bwd():
+            f = seg["f"]
+            ops.render_backward(self.g_band, f["idx"], f["qvalue"], f["wsum"], f["scaler"], f["pts_screen"], f["radii"],
+                                self.vis_all, self.first, self.num, RADII_S, -1.0, image_size=S, rows=p.rows,
+                                out=(g_feat, g_pts))
+
+        def proj():
+            seg["g_world"] = ops.project_backward(self.world, self.M, self.V, self.first, self.num, g_pts, seg["f"]["valid"],
+                                                  True, clip=CLIP)
+            seg["g_col"] = g_feat.view(self.N, self.Pc, 3).sum(0)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                fwd(); bwd(); proj()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graphs = []
+        for fn in (fwd, bwd, proj):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side):
+                fn()
+            graphs.append(g)
+        self._seg, self._graphs = seg, graphs
+
+    def step_segments(self, ev=None):
+        """`step` for N > 1 with the compute segments replayed as graphs (same launches, same collectives)"""
+        def mark(label):
+            if ev is not None:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                ev.append((label, e))
+        mark("start")
+        self._graphs[0].replay()
+        mark("forward_compute")
+        self.fx.start(out=self.vis_all)
+        mark("wait_visibility_allgather")
+        self._graphs[1].replay()
+        mark("backward_compute")
+        dist.all_reduce(self.bucket, op=dist.ReduceOp.SUM)
+        mark("wait_gradient_allreduce")
+        image = self.fx.finish()
+        mark("wait_image_allgather")
+        self._graphs[2].replay()
+        mark("projection_compute")
+        return image, self._seg["g_world"], self._seg["g_col"]
+
     def dist_timing(self, iters=20):
         """Where a multi-GPU step spends its time, per rank: event-timed segments of `iters` eager steps (microseconds,
         means).  compute = forward + backward + projection kernels of this rank's band; wait_* = time the stream spends in
         (waiting for) each of the three collectives.  -> dict of label -> us, plus 'compute_us'."""
+        step = self.step_segments if getattr(self, "_graphs", None) else self.step
         for _ in range(3):
-            self.step()
+            step()
         acc = {}
         for _ in range(iters):
             ev = []
-            self.step(ev)
+            step(ev)
             torch.cuda.synchronize()
             for (l0, e0), (l1, e1) in zip(ev[:-1], ev[1:]):
                 acc[l1] = acc.get(l1, 0.0) + e0.elapsed_time(e1) * 1e3 / iters
@@ -417,6 +482,15 @@ def main():
     graph, graph_u, ms_modes = None, None, {}
     unrollable = args.steps % UNROLL == 0 and args.steps >= UNROLL
     mode = args.mode or ("eager" if world > 1 else None)
+    seg_note = None
+    if world > 1 and args.mode != "eager":
+        # multi-GPU: the RCCL calls stay outside any graph, the compute segments between them are graphs
+        try:
+            wl.capture_segments()
+            mode = "graph_segments"
+        except Exception as e:  # noqa: BLE001  (capture refused: plain launches, and say so)
+            seg_note = "segment capture failed: %s: %s" % (type(e).__name__, str(e)[:160])
+            mode = "eager"
     if mode is None:
         graph = capture()
         ms_modes = {"eager": quick(wl.step), "graph": quick(graph.replay)}
@@ -427,7 +501,8 @@ def main():
     elif mode == "graph":
         graph = capture()
     steps_per_launch = UNROLL if mode.startswith("graph_x") else 1
-    run = graph_u.replay if steps_per_launch > 1 else (graph.replay if mode == "graph" else wl.step)
+    run = graph_u.replay if steps_per_launch > 1 else (graph.replay if mode == "graph" else
+                                                         (wl.step_segments if mode == "graph_segments" else wl.step))
 
     for _ in range(-(-args.warmup // steps_per_launch)):
         run()
@@ -519,7 +594,7 @@ def main():
             pass
         dist_block = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "rccl_version": nccl_v,
                       "visible_devices": torch.cuda.device_count(), "partition": part.describe(),
-                      "overlap": bool(wl.fx.overlap), "degraded": wl.fx.degraded,
+                      "overlap": bool(wl.fx.overlap), "degraded": wl.fx.degraded, "segment_capture": seg_note or "ok",
                       "timing_us": {k: {"min": round(float(allt[:, i].min()), 1), "max": round(float(allt[:, i].max()), 1),
                                         "mean": round(float(allt[:, i].mean()), 1)} for i, k in enumerate(keys)},
                       "timing_how": "HIP events on the compute stream around each segment of 20 eager steps, per rank; "

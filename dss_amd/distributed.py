@@ -278,8 +278,16 @@ class OverlappedExchange:
             return dist.all_gather(list(out2d.unbind(0)), send, group=group, async_op=async_op)
         return dist.all_gather_into_tensor(out2d, send, group=group, async_op=async_op)
 
-    def start(self) -> torch.Tensor:
-        """Issue both exchanges; returns the union of the visibility flags, uint8 (P,)."""
+    def start(self, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Issue both exchanges; returns the union of the visibility flags, uint8 (P,) (written into `out` if given: a
+        static buffer that captured graphs read)."""
+        vis = self._start()
+        if out is not None:
+            out.copy_(vis)
+            return out
+        return vis
+
+    def _start(self) -> torch.Tensor:
         G = self.part.world_size
         if self.overlap:
             try:

@@ -567,14 +567,22 @@ import bench
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dev = torch.device("cuda:0"); torch.cuda.set_device(dev)
 dist.init_process_group("gloo")
-wl = bench.Workload(dev, world, bench.RowPartition(bench.S, world, rank))
-img, gw, gc = wl.step()
 ref = bench.Workload(dev, world, bench.RowPartition(bench.S, 1, 0))
 img1, gw1, gc1 = ref.step()
-torch.cuda.synchronize()
-assert torch.equal(img, img1), "gathered image differs from the single-rank render"
 rel = lambda a, b: float((a - b).norm() / b.norm())
-assert rel(gw, gw1) < 1e-5 and rel(gc, gc1) < 1e-5, (rel(gw, gw1), rel(gc, gc1))
+for cyclic in (False, True):       # contiguous equal bands, and the tile-row-cyclic partition bench.py --gpus N uses
+    wl = bench.Workload(dev, world, bench.RowPartition(bench.S, world, rank, cyclic=cyclic))
+    img, gw, gc = wl.step()
+    torch.cuda.synchronize()
+    assert torch.equal(img, img1), "gathered image differs from the single-rank render (cyclic=%%s)" %% cyclic
+    assert rel(gw, gw1) < 1e-5 and rel(gc, gc1) < 1e-5, (cyclic, rel(gw, gw1), rel(gc, gc1))
+    # the same step with its compute segments replayed as graphs around the collectives
+    wl.capture_segments()
+    for _ in range(2):
+        img, gw, gc = wl.step_segments()
+    torch.cuda.synchronize()
+    assert torch.equal(img, img1), "graph-segment step: image differs (cyclic=%%s)" %% cyclic
+    assert rel(gw, gw1) < 1e-5 and rel(gc, gc1) < 1e-5, ("segments", cyclic, rel(gw, gw1), rel(gc, gc1))
 open(os.path.join(%r, "ok%%d" %% rank), "w").write("%%g %%g" %% (rel(gw, gw1), rel(gc, gc1)))
 dist.destroy_process_group()
 ''' % (root, str(tmp_path)))
@@ -605,7 +613,8 @@ def test_bench_launches_its_own_ranks():
     d = rec["config"]["dist"]
     assert rec["n_gpus"] == 2 and d["world_size"] == 2 and d["backend"] == "gloo"
     # diagnosable multi-GPU line: the communicator set-up that was used and where the step's time went, per rank
-    assert d["overlap"] is True and d["degraded"] is None and d["visible_devices"] >= 1 and "partition" in d
+    assert d["overlap"] is True and d["degraded"] is None and d["visible_devices"] >= 1 and "cyclic" in d["partition"]
+    assert rec["config"]["launch"] == "graph_segments" and d["segment_capture"] == "ok"
     t = d["timing_us"]
     for k in ("forward_compute", "backward_compute", "projection_compute", "compute_us", "wait_visibility_allgather",
               "wait_gradient_allreduce", "wait_image_allgather"):
