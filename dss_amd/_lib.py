@@ -13,7 +13,8 @@ import threading
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libdss_hip.so")
+# (DSS_HIP_LIBRARY: another build of the same library -- development A/B runs; the default is the in-tree build)
+LIB_PATH = os.environ.get("DSS_HIP_LIBRARY") or os.path.join(_HERE, "csrc", "libdss_hip.so")
 
 _lib = None
 _lock = threading.Lock()

@@ -887,7 +887,19 @@ __global__ __launch_bounds__(256) void cell_block_scan_kernel(const uint32_t *__
     if (c >= total) return;
     const uint32_t nb = (*vis_count + (uint32_t)CELL_CHUNK - 1u) / (uint32_t)CELL_CHUNK;
     uint32_t run = 0;
-    for (uint32_t b = 0; b < nb; ++b) {
+    uint32_t b = 0;
+    // eight independent loads in flight per trip (one at a time the walk over ~150 blocks was 40 us of load latencies)
+    for (; b + 8 <= nb; b += 8) {
+        uint32_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = block_hist[(size_t)(b + u) * total + c];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            block_hist[(size_t)(b + u) * total + c] = run;
+            run += v[u];
+        }
+    }
+    for (; b < nb; ++b) {
         const uint32_t v = block_hist[(size_t)b * total + c];
         block_hist[(size_t)b * total + c] = run;
         run += v;
@@ -955,6 +967,7 @@ __global__ __launch_bounds__(CELL_THREADS) void cell_scatter_kernel(
 // ---------------------------------------------------------------------------------------------
 // load from a uniform (SGPR) base + a 32-bit unsigned BYTE offset: one global_load with saddr + voffset, no 64-bit VALU
 // address arithmetic (a 64-bit index costs v_ashr + v_lshl_add_u64 per load, a 64-bit product much more)
+struct __attribute__((packed, aligned(4))) Frag4 { int32_t a, b, c, d; };   // four consecutive dwords, 4-byte aligned
 template <typename T>
 __device__ __forceinline__ T ld_off(const T *__restrict__ base, uint32_t byte_off)
 {
@@ -1255,15 +1268,62 @@ __global__ __launch_bounds__(256) void render_backward_kernel(
                                                     (uint32_t)(S - 1 - xi)
                                               : (uint32_t)nn * (uint32_t)plane;
                     const uint32_t oK = pix32 * (uint32_t)K * 4u, oC = pix32 * (uint32_t)(Cn + 1) * 4u;
+                    if (TPW >= 2) {
+                        // Throughput-bound lists: two dependent rounds with fewer loads -- the K fragment ids first, then
+                        // ONLY the matching slot's Q value, the weight sum and the image gradient (10 loads per pixel slot
+                        // instead of 14; the extra round trip hides behind the other resident wavefronts)
+                        int hitk = -1;
+                        if (K == 5) {
+                            // the K = 5 ids of a pixel as one 16-byte + one 4-byte load (4-byte aligned: global memory takes
+                            // unaligned vector accesses) instead of five dword loads
+                            const Frag4 v4 = ld_off(reinterpret_cast<const Frag4 *>(idx), oK);
+                            const int32_t v5 = ld_off(idx, oK + 16u);
+                            hitk = v4.a == (int32_t)p ? 0 : hitk;
+                            hitk = v4.b == (int32_t)p ? 1 : hitk;
+                            hitk = v4.c == (int32_t)p ? 2 : hitk;
+                            hitk = v4.d == (int32_t)p ? 3 : hitk;
+                            hitk = v5 == (int32_t)p ? 4 : hitk;
+                        } else
+#pragma unroll
+                        for (int k = 0; k < KF; ++k)
+                            if (k < K) hitk = (ld_off(idx, oK + 4u * k) == (int32_t)p) ? k : hitk;
+                        const bool f2 = on && hitk >= 0;
+                        const float q2 = ld_off(qv, oK + 4u * (uint32_t)max(hitk, 0));
+                        const float cum2 = ld_off(wsum, pix32 * 4u);
+                        float g2[CM];
+                        if (C == 3) {   // RGBA pixel of the image gradient: one aligned 16-byte load
+                            const float4 gg4 = ld_off(reinterpret_cast<const float4 *>(grad_out), oC);
+                            g2[0] = gg4.x; g2[CM > 1 ? 1 : 0] = gg4.y; g2[CM > 2 ? 2 : 0] = gg4.z;
+                        } else {
+#pragma unroll
+                            for (int ch = 0; ch < CM; ++ch) g2[ch] = (ch < Cn) ? ld_off(grad_out, oC + 4u * ch) : 0.0f;
+                        }
+                        const float wn2 = f2 ? ewa_weight(q2, sc) * fast_rcp(cum2) : 0.0f;
+#pragma unroll
+                        for (int ch = 0; ch < CM; ++ch)
+                            if (ch < Cn) acc[ch] = fmaf(g2[ch], wn2, acc[ch]);
+                        continue;
+                    }
                     int32_t vi[KF];
                     float qk[KF];
 #pragma unroll
-                    for (int k = 0; k < KF; ++k) {
-                        vi[k] = -1; qk[k] = 0.0f;
+                    for (int k = 0; k < KF; ++k) { vi[k] = -1; qk[k] = 0.0f; }
+                    if (K == 5) {   // 2 x (16 + 4)-byte loads instead of ten dword loads (4-byte aligned vector accesses)
+                        const Frag4 v4 = ld_off(reinterpret_cast<const Frag4 *>(idx), oK);
+                        const Frag4 q4 = ld_off(reinterpret_cast<const Frag4 *>(qv), oK);
+                        vi[0] = v4.a; vi[1] = v4.b; vi[2] = v4.c; vi[3] = v4.d; vi[4] = ld_off(idx, oK + 16u);
+                        qk[0] = __int_as_float(q4.a); qk[1] = __int_as_float(q4.b); qk[2] = __int_as_float(q4.c);
+                        qk[3] = __int_as_float(q4.d); qk[4] = ld_off(qv, oK + 16u);
+                    } else
+#pragma unroll
+                    for (int k = 0; k < KF; ++k)
                         if (k < K) { vi[k] = ld_off(idx, oK + 4u * k); qk[k] = ld_off(qv, oK + 4u * k); }
-                    }
                     const float cum32 = ld_off(wsum, pix32 * 4u);
                     float g32[CM];
+                    if (C == 3) {
+                        const float4 gg4 = ld_off(reinterpret_cast<const float4 *>(grad_out), oC);
+                        g32[0] = gg4.x; g32[CM > 1 ? 1 : 0] = gg4.y; g32[CM > 2 ? 2 : 0] = gg4.z;
+                    } else
 #pragma unroll
                     for (int ch = 0; ch < CM; ++ch) g32[ch] = (ch < Cn) ? ld_off(grad_out, oC + 4u * ch) : 0.0f;
                     float q32 = 0.0f;

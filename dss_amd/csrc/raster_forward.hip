@@ -263,16 +263,17 @@ __global__ __launch_bounds__(256) void spill_kernel(
     Spill sp)
 {
     if (__builtin_amdgcn_readfirstlane((int)sp.ctrl[0]) == 0) return;
-    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= P) return;
+    // grid-stride over the splats: the grid is bounded (spill_grid) because the launch is almost always empty, and an empty
+    // launch costs its workgroup count (32k workgroups at 8M splats: 126 us of dispatch for one scalar load each)
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (int64_t)gridDim.x * blockDim.x) {
     const unsigned full = sp.mask[p];
-    if (full == 0) return;
+    if (full == 0) continue;
     sp.mask[p] = 0;  // (this thread is the byte's only reader: the DSS_WS_CLEAN state is restored here)
     const int n = find_cloud(p, first_idx, num_pts, N);
     int tx0, tx1, ty0, ty1;
     if (n < 0 || !splat_tile_rect(points[3 * p], points[3 * p + 1], points[3 * p + 2], radii[2 * p], radii[2 * p + 1], g, tx0,
                                   tx1, ty0, ty1))
-        return;
+        continue;
     const size_t sub0 = ((size_t)n * g.tiles_x * g.tiles_y) * DSS_SUB + ((unsigned)p & (DSS_SUB - 1));
 #pragma unroll 1
     for (int k = 0; k < 4; ++k) {
@@ -297,6 +298,7 @@ __global__ __launch_bounds__(256) void spill_kernel(
             if (off1 == 0) sp.fail[0] = sp.epoch;  // gave up: the fine pass falls back to whole-cloud scans
         }
         if (off1 != 0 && (unsigned long long)(off1 - 1u) + pos < sp.cap_entries) sp.pool[(size_t)(off1 - 1u) + pos] = (int32_t)p;
+    }
     }
 }
 
@@ -1156,6 +1158,13 @@ static FwdWorkspace carve_fwd(void *ws, int N, int64_t P, int S, bool with_recor
     return w;
 }
 
+// workgroups of the (normally empty) pool pass: at most 2048 x 256 threads, grid-stride beyond
+static unsigned spill_grid(int64_t P)
+{
+    const int64_t wgs = (P + 255) / 256;
+    return (unsigned)(wgs < 2048 ? (wgs > 0 ? wgs : 1) : 2048);
+}
+
 // queue-serving workgroups of a fine launch over `g` (band): one per slot of the band's queues
 static uint32_t queue_workgroups(int N, const TileGrid &g)
 {
@@ -1229,7 +1238,7 @@ static int splat_bin_impl(const float *points, const float *radii, const int64_t
     const int pb = (int)((P + 255) / 256);
     hipLaunchKernelGGL(bin_kernel, dim3(pb), dim3(256), 0, st, points, radii, first_idx, num_pts, N, P, g, w.counts,
                        w.lists, w.cap, w.queue, w.spill, visible_to_clear);
-    hipLaunchKernelGGL(spill_kernel, dim3(pb), dim3(256), 0, st, points, radii, first_idx, num_pts, N, P, g, w.counts, w.cap,
+    hipLaunchKernelGGL(spill_kernel, dim3(spill_grid(P)), dim3(256), 0, st, points, radii, first_idx, num_pts, N, P, g, w.counts, w.cap,
                        w.spill);
     return check_launch("dss_splat_bin");
 }
@@ -1409,7 +1418,7 @@ extern "C" int dss_render_forward(const float *world, const float *normals, cons
     if (!rerun) {
         hipLaunchKernelGGL(setup_bin_kernel, dim3(pb), dim3(tb), 0, st, SA, g, w.counts, w.lists, w.cap, w.queue, w.spill,
                            visible);
-        hipLaunchKernelGGL(spill_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, pts_screen, radii, first_idx,
+        hipLaunchKernelGGL(spill_kernel, dim3(spill_grid(P)), dim3(256), 0, st, pts_screen, radii, first_idx,
                            num_pts, N, P, g, w.counts, w.cap, w.spill);
     }
     FineArgs A;
