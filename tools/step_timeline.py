@@ -22,7 +22,9 @@ for f in glob.glob(os.path.join(OUT, "**", "*kernel_trace.csv"), recursive=True)
 rows.sort()
 # the timed region is the longest run of back-to-back steps: find step starts = setup_bin_kernel
 starts = [i for i, r in enumerate(rows) if r[2].startswith("setup_bin_kernel")]
-steps = [rows[a:b] for a, b in zip(starts[:-1], starts[1:]) if b - a == 7]
+lens = collections.Counter(b - a for a, b in zip(starts[:-1], starts[1:]))
+per_step = lens.most_common(1)[0][0]     # launches per step (6 since the projection backward rides in the gather)
+steps = [rows[a:b] for a, b in zip(starts[:-1], starts[1:]) if b - a == per_step]
 steps = steps[-100:]
 acc = collections.OrderedDict()
 period = []
