@@ -263,8 +263,8 @@ __global__ __launch_bounds__(256) void spill_kernel(
     Spill sp)
 {
     if (__builtin_amdgcn_readfirstlane((int)sp.ctrl[0]) == 0) return;
-    // grid-stride over the splats: the grid is bounded (spill_grid) because the launch is almost always empty, and an empty
-    // launch costs its workgroup count (32k workgroups at 8M splats: 126 us of dispatch for one scalar load each)
+    // grid-stride over the splats: the grid is bounded (spill_grid), so that the usual empty launch costs at most 2048
+    // workgroup dispatches whatever P is
     for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (int64_t)gridDim.x * blockDim.x) {
     const unsigned full = sp.mask[p];
     if (full == 0) continue;
@@ -1079,7 +1079,8 @@ struct FwdWorkspace {
     size_t bytes;
 };
 
-// Sub-list capacity: ~4x the mean number of (splat, tile) pairs per sub-list (2 tiles per splat assumed), a power of two
+// Sub-list capacity: ~8x the mean number of (splat, tile) pairs per sub-list (2 tiles per splat assumed; round 2 used 4x:
+// at 8 x 1M points @1024^2 the limb of the object then overflowed and the pool pass cost 0.11 ms, 3 % of the step), a power of two
 // in [64, 16384] (>= SPEC for the speculative first reads; 64 leaves the benchmark scenes -- densest sub-list 42 entries
 // at a mean of 2 -- on the primary lists).  Denser sub-lists go through the spill pool.  Depends only on (N, P, S) so the
 // size query and the launch agree.
@@ -1094,7 +1095,7 @@ static uint32_t bin_capacity(int N, int64_t P, int S)
     const double mean_sub = 2.0 * ((double)P / (N > 0 ? N : 1)) / (tiles * DSS_SUB);
     const bool lean = lean_workspace();
     uint32_t cap = lean ? 32 : 64;
-    while (cap < 16384 && (double)cap < (lean ? 2.0 : 4.0) * mean_sub) cap <<= 1;
+    while (cap < 16384 && (double)cap < (lean ? 2.0 : 8.0) * mean_sub) cap <<= 1;
     return cap;
 }
 // spill pool entries: two per point (at least 64k): a scene with more over-capacity (splat, tile) pairs than that falls
