@@ -1,4 +1,5 @@
-"""TEST DOUBLE (CPU): the handful of `dss_amd.ops` entry points the drop-in renderer calls, answered by the oracle.
+"""TEST DOUBLE (CPU): the handful of `dss_amd.ops` entry points the drop-in renderer calls (the fused pair included: it is
+the renderer's default path), answered by the oracle.
 
 Only `tests/` may use the oracle, and only as a checker -- here it stands in for `libdss_hip.so` on the GPU-less build
 container so that the reference's own `train_mvr.py` can be driven through the drop-in classes end to end
@@ -142,7 +143,37 @@ def _backward_zbuf(idx, grad_zbuf, point_z_grad):
     point_z_grad += torch.from_numpy(gz)[:, None]
 
 
+def render_forward(world, normals, h, M, V, znear, zfar, first, num, features, image_size, points_per_pixel,
+                   cutoff_threshold, depth_merging_thres, antialiasing_sigma=1.0, backface_culling=False, shared_cloud=False,
+                   rows=None, out_image=None, out_visible=None, vr6=None, frame_normals=None, want_zbuf=True,
+                   workspace_state=1):
+    """the fused forward (dss_render_forward) = setup -> rasterizer -> blend, composed from the doubles above"""
+    assert rows is None and out_image is None and vr6 is None
+    o = point_setup(world, normals, h, M, V, znear, zfar, first, num, image_size, cutoff_threshold, antialiasing_sigma,
+                    backface_culling, shared_cloud)
+    idx, zbuf, qv, occ, vis = splat_points(o["pts_screen"], o["ellipse_params"], o["cutoff_threshold"], o["radii"], first, num,
+                                           depth_merging_thres, image_size, points_per_pixel, return_visible=True)
+    image, wsum = blend_forward(idx, qv, occ, o["scaler"], features, return_wsum=True)
+    o.update(idx=idx, zbuf=zbuf, qvalue=qv, occupancy=occ, visible=vis, image=image, wsum=wsum)
+    return o
+
+
+def render_backward(grad_out, idx, qvalue, wsum, scaler, points, radii, visible, first, num, radii_s, clip=-1.0,
+                    with_features=True, return_rs=False, image_size=None, rows=None, out=None, gather_only_rs=None,
+                    project=None):
+    """the fused backward (dss_render_backward): blend backward + occupancy surrogate (+ clip, + projection backward)"""
+    assert rows is None and out is None and gather_only_rs is None
+    gf, gocc = blend_backward(grad_out, idx, qvalue, scaler, points.shape[0])
+    g = splat_backward(points, radii, visible, idx, gocc, None, first, num, radii_s, clip)
+    if project is not None:
+        world, M = project
+        ident = torch.eye(4).expand(M.shape[0], 4, 4).contiguous()   # (the z gradient is 0 on this path: V is not needed)
+        g = project_backward(world, M, ident, first, num, g, torch.ones(points.shape[0], dtype=torch.bool), False)
+    return (gf if with_features else None, g)
+
+
 def install(ops_module) -> None:
     for name in ("point_setup", "project_backward", "splat_points", "splat_backward", "blend_forward", "blend_backward",
-                 "knn_kth_sqdist", "cloud_mean_clamp", "_splat_points_occ_fast_cuda_backward", "_backward_zbuf"):
+                 "knn_kth_sqdist", "cloud_mean_clamp", "_splat_points_occ_fast_cuda_backward", "_backward_zbuf",
+                 "render_forward", "render_backward"):
         setattr(ops_module, name, globals()[name])
