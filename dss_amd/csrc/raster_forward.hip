@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256) void setup_bin_kernel(const SetupArgs A, TileG
 __global__ __launch_bounds__(256) void spill_kernel(
     const float *__restrict__ points, const float *__restrict__ radii, const int64_t *__restrict__ first_idx,
     const int64_t *__restrict__ num_pts, int N, int64_t P, TileGrid g, const uint32_t *__restrict__ counts, uint32_t cap,
-    Spill sp)
+    Spill sp, int sorted /* 1: the lists were filled by bin_sorted_kernel (sub-list in bits 4..6 of the mask byte) */)
 {
     if (__builtin_amdgcn_readfirstlane((int)sp.ctrl[0]) == 0) return;
     // grid-stride over the splats: the grid is bounded (spill_grid), so that the usual empty launch costs at most 2048
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256) void spill_kernel(
     if (n < 0 || !splat_tile_rect(points[3 * p], points[3 * p + 1], points[3 * p + 2], radii[2 * p], radii[2 * p + 1], g, tx0,
                                   tx1, ty0, ty1))
         continue;
-    const size_t sub0 = ((size_t)n * g.tiles_x * g.tiles_y) * DSS_SUB + ((unsigned)p & (DSS_SUB - 1));
+    const size_t sub0 = ((size_t)n * g.tiles_x * g.tiles_y) * DSS_SUB + (sorted ? ((full >> 4) & (DSS_SUB - 1)) : ((unsigned)p & (DSS_SUB - 1)));
 #pragma unroll 1
     for (int k = 0; k < 4; ++k) {
         if (!(full & (1u << k))) continue;
@@ -299,6 +299,328 @@ __global__ __launch_bounds__(256) void spill_kernel(
         }
         if (off1 != 0 && (unsigned long long)(off1 - 1u) + pos < sp.cap_entries) sp.pool[(size_t)(off1 - 1u) + pos] = (int32_t)p;
     }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Cell-ordered binning for large inputs (P > SORT_MIN_P).
+//
+// setup_bin_kernel on a randomly ordered cloud of 8M splats costs 1.0 ms: 0.35 ms of per-point setup traffic, 0.24 ms of
+// 4-byte list appends that each dirty their own 64-byte sector (1.7 GB written for 0.9 GB of output) and 0.4 ms of
+// returning global atomics (~2.2 per splat at ~16 G/s) -- measured by removing each in turn.  A cloud in Morton order pays
+// 0.65 ms for the same work, because neighbouring threads then append to the same few lists.  Here the renderer creates
+// that order itself, without global atomics:
+//   setup_cell_kernel   per-point setup (same body) + the 32 x 32-pixel screen cell of every splat's centre + a histogram
+//                       of the workgroup's 16,384 splats in LDS -> block_hist[block][cell]
+//   sort_block_scan / sort_cell_scan   exclusive prefix of every cell over the blocks, of the cells over the image
+//   sort_scatter_kernel every workgroup ranks its splats again in LDS and writes (px, py, rx, ry | id) in cell order
+//   bin_sorted_kernel   1024 consecutive sorted splats per workgroup -- one or two cells -- : the (tile, sub-list) keys of
+//                       their pairs are counted in an LDS hash table, ONE global atomicAdd per key reserves the run, the
+//                       ids are written behind it: ~8x fewer global atomics, list appends in contiguous runs
+//   queue_build_kernel  the occupied-tile queues of the fine pass from the finished counters (no per-tile claims)
+// Measured (same-run A/B against the direct binning, tools/ab_libs.py): 8 x 1M splats @1024^2 setup 0.40 + scans 0.05 +
+// scatter 0.27 + binning 0.18 ms against 1.01 ms, step +2 %; 4M splats @2048^2 step +4 %; 8 x 99,790 splats -5 % (hence
+// SORT_MIN_P).  The order costs what the atomics cost: the scatter of 20 bytes per splat to random positions is the
+// same partial-sector traffic the list appends were.
+// The tile lists, counters, flags, queues and the spill path are the ones of the direct binning: the fine pass does not
+// know which of the two filled them (the K-set of a pixel does not depend on the order of its candidates).
+// ---------------------------------------------------------------------------------------------
+#define SORT_MIN_P 2000000      // below ~2M splats the direct binning wins (8 x 99,790 points: 0.69 vs 0.73 ms per step)
+#define SORT_THREADS 1024
+#define SORT_PER_THREAD 16                            // at most: 16,384 splats per workgroup of the histogram pass
+#define SORT_CELL_MAX 16384                           // 64 KB of LDS counters
+#define SORT_NO_CELL 0xffffffffu
+struct SortGrid {
+    int shift;     // cell side = 1 << shift pixels
+    int cx, cy;    // cells per image row / column
+    int total;     // N * cx * cy (<= SORT_CELL_MAX)
+};
+static SortGrid make_sort_grid(int N, int S)
+{
+    SortGrid c;
+    c.shift = 5;
+    for (;;) {
+        c.cx = ((S - 1) >> c.shift) + 1;
+        c.cy = c.cx;
+        c.total = N * c.cx * c.cy;
+        if (c.total <= SORT_CELL_MAX || c.shift >= 14) break;
+        ++c.shift;
+    }
+    return c;
+}
+// splats per thread of the histogram pass: at least ~2 workgroups per CU (49 workgroups of 16,384 splats left four fifths of
+// the chip idle at 8 x 99,790 points), at most SORT_PER_THREAD
+static inline int sort_per_thread(int64_t P)
+{
+    int64_t per = P / ((int64_t)SORT_THREADS * 512);
+    return (int)(per < 1 ? 1 : (per > SORT_PER_THREAD ? SORT_PER_THREAD : per));
+}
+static inline size_t sort_blocks(int64_t P)
+{
+    const int64_t chunk = (int64_t)SORT_THREADS * sort_per_thread(P);
+    return (size_t)((P + chunk - 1) / chunk);
+}
+__global__ __launch_bounds__(SORT_THREADS) void setup_cell_kernel(const SetupArgs A, SortGrid sg, int per_thread,
+                                                                   uint32_t *__restrict__ cell_of,
+                                                                   uint32_t *__restrict__ block_hist, Spill sp,
+                                                                   uint8_t *__restrict__ visible_to_clear)
+{
+    extern __shared__ uint32_t s_hist[];
+    if (sp.ctrl && blockIdx.x == 0 && threadIdx.x == 0) sp.fail[1] = sp.epoch;
+    for (int c = threadIdx.x; c < sg.total; c += SORT_THREADS) s_hist[c] = 0u;
+    __syncthreads();
+    const int64_t b0 = (int64_t)blockIdx.x * SORT_THREADS * per_thread;
+#pragma unroll 1
+    for (int u = 0; u < per_thread; ++u) {
+        const int64_t p = b0 + (int64_t)u * SORT_THREADS + threadIdx.x;
+        if (p >= A.P) break;
+        if (visible_to_clear) visible_to_clear[p] = 0;
+        const int n = find_cloud(p, A.first_idx, A.num_pts, A.N);
+        float px, py, pz, rx, ry;
+        setup_point(A, p, n, px, py, pz, rx, ry);
+        uint32_t key = SORT_NO_CELL;
+        if (n >= 0 && !(pz < 0)) {   // culled splats (pz = -1) never reach a tile list: they are left out of the order
+            // pixel column / row of the centre (any monotone map of NDC does: only neighbourhood matters); NaN -> cell 0
+            const float fx = (1.0f - px) * 0.5f * (float)A.S, fy = (1.0f - py) * 0.5f * (float)A.S;
+            const int ix = min(max((int)fx, 0), A.S - 1) >> sg.shift, iy = min(max((int)fy, 0), A.S - 1) >> sg.shift;
+            key = (uint32_t)((n * sg.cy + iy) * sg.cx + ix);
+            atomicAdd(&s_hist[key], 1u);
+        }
+        cell_of[p] = key;
+    }
+    __syncthreads();
+    uint32_t *row = block_hist + (size_t)blockIdx.x * sg.total;
+    for (int c = threadIdx.x; c < sg.total; c += SORT_THREADS) row[c] = s_hist[c];
+}
+// thread per cell: block_hist[b][c] <- number of the cell's splats in blocks < b; cell_total[c]
+__global__ __launch_bounds__(256) void sort_block_scan_kernel(uint32_t nb, int total, uint32_t *__restrict__ block_hist,
+                                                              uint32_t *__restrict__ cell_total)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= total) return;
+    uint32_t run = 0, b = 0;
+    for (; b + 8 <= nb; b += 8) {   // eight independent loads in flight per trip
+        uint32_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = block_hist[(size_t)(b + u) * total + c];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            block_hist[(size_t)(b + u) * total + c] = run;
+            run += v[u];
+        }
+    }
+    for (; b < nb; ++b) {
+        const uint32_t v = block_hist[(size_t)b * total + c];
+        block_hist[(size_t)b * total + c] = run;
+        run += v;
+    }
+    cell_total[c] = run;
+}
+// one workgroup: exclusive scan of the cell totals -> cell_start; the number of sorted splats -> *sorted_count
+__global__ __launch_bounds__(1024) void sort_cell_scan_kernel(const uint32_t *__restrict__ cell_total, uint32_t *__restrict__ cell_start,
+                                                              int total, uint32_t *__restrict__ sorted_count)
+{
+    __shared__ uint32_t s_part[1024];
+    const int tid = threadIdx.x;
+    const int per = (total + 1023) / 1024;
+    const int b = tid * per, e = min(b + per, total);
+    uint32_t sum = 0;
+    for (int i = b; i < e; ++i) sum += cell_total[i];
+    s_part[tid] = sum;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const uint32_t v = tid >= o ? s_part[tid - o] : 0u;
+        __syncthreads();
+        s_part[tid] += v;
+        __syncthreads();
+    }
+    uint32_t run = s_part[tid] - sum;
+    for (int i = b; i < e; ++i) {
+        cell_start[i] = run;
+        run += cell_total[i];
+    }
+    if (tid == 1023) *sorted_count = s_part[1023];
+}
+__global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(
+    const float *__restrict__ points, const float *__restrict__ radii, int64_t P, SortGrid sg, int per_thread,
+    const uint32_t *__restrict__ cell_of,
+    const uint32_t *__restrict__ cell_start, const uint32_t *__restrict__ block_base, float4 *__restrict__ s_geo,
+    int32_t *__restrict__ s_id)
+{
+    extern __shared__ uint32_t s_hist[];
+    // (merging two or four histogram blocks per scatter workgroup -- longer runs per cell -- measured 2-4 % slower)
+    const uint32_t *base = block_base + (size_t)blockIdx.x * sg.total;
+    for (int c = threadIdx.x; c < sg.total; c += SORT_THREADS) s_hist[c] = cell_start[c] + base[c];
+    __syncthreads();
+    const int64_t b0 = (int64_t)blockIdx.x * SORT_THREADS * per_thread;
+#pragma unroll 4
+    for (int u = 0; u < per_thread; ++u) {
+        const int64_t p = b0 + (int64_t)u * SORT_THREADS + threadIdx.x;
+        if (p >= P) break;
+        const uint32_t key = cell_of[p];
+        if (key == SORT_NO_CELL) continue;
+        const float2 rr = reinterpret_cast<const float2 *>(radii)[p];
+        const float4 ge = make_float4(points[3 * p], points[3 * p + 1], rr.x, rr.y);
+        const uint32_t pos = atomicAdd(&s_hist[key], 1u);
+        s_geo[pos] = ge;
+        s_id[pos] = (int32_t)p;
+    }
+}
+
+// Binning in cell order.  Workgroup b handles the sorted splats [1024 b, 1024 b + 1024), four per thread.  Splat j of thread t
+// goes to sub-list sub(t, j) = (j + 4 (t mod 2)) of each of its tiles: the (at most 2 x 2) pairs of a splat share the sub-list -- the
+// spill pass finds it in bits 4..6 of the splat's mask byte --, a workgroup spreads a tile's entries over all eight
+// sub-lists (four per workgroup concentrated a dense tile's entries and made the pool pass do real work).  Keys (tile, sub) are counted in an open-addressing LDS table
+// (SORT_HASH slots >= the 4096 pairs a workgroup can have), one global atomicAdd per key reserves its run.
+#define SORT_BIN_THREADS 256
+#define SORT_BIN_PER_THREAD 4
+#define SORT_BIN_CHUNK (SORT_BIN_THREADS * SORT_BIN_PER_THREAD)   // sorted splats per workgroup
+#define SORT_HASH 4096
+#define SORT_EMPTY 0xffffffffu
+// (256 threads x 4 splats: a 1024-thread workgroup with one splat per thread ran one workgroup per CU -- four barrier-
+// separated phases of dependent latencies with nothing else resident to hide them: 508 us at 8M splats)
+__global__ __launch_bounds__(SORT_BIN_THREADS) void bin_sorted_kernel(
+    const float4 *__restrict__ s_geo, const int32_t *__restrict__ s_id, const uint32_t *__restrict__ sorted_count,
+    const int64_t *__restrict__ first_idx, const int64_t *__restrict__ num_pts, int N, TileGrid g,
+    uint32_t *__restrict__ counts, int32_t *__restrict__ lists, uint32_t cap, TileQueue tq, Spill sp)
+{
+    __shared__ uint32_t h_key[SORT_HASH];
+    __shared__ uint32_t h_cnt[SORT_HASH];   // count of the key, then (after the reservation) the run's first list position
+    const uint32_t count = *sorted_count;
+    const uint32_t b0 = blockIdx.x * SORT_BIN_CHUNK;
+    if (b0 >= count) return;
+    for (int k = threadIdx.x; k < SORT_HASH; k += SORT_BIN_THREADS) { h_key[k] = SORT_EMPTY; h_cnt[k] = 0u; }
+    const int tiles = g.tiles_x * g.tiles_y;
+    // the four splats of this thread: entries b0 + j * 256 + tid; all loads first
+    int pid[SORT_BIN_PER_THREAD];
+    float4 ge[SORT_BIN_PER_THREAD];
+#pragma unroll
+    for (int j = 0; j < SORT_BIN_PER_THREAD; ++j) {
+        const uint32_t i = b0 + (uint32_t)j * SORT_BIN_THREADS + threadIdx.x;
+        const uint32_t ic = i < count ? i : count - 1u;
+        pid[j] = i < count ? s_id[ic] : -1;
+        ge[j] = s_geo[ic];
+    }
+    __syncthreads();
+    int cl[SORT_BIN_PER_THREAD], rx0[SORT_BIN_PER_THREAD], rx1[SORT_BIN_PER_THREAD], ry0[SORT_BIN_PER_THREAD], ry1[SORT_BIN_PER_THREAD];
+    uint32_t slot[SORT_BIN_PER_THREAD][4], rank[SORT_BIN_PER_THREAD][4];
+    unsigned onm[SORT_BIN_PER_THREAD];   // bit k: pair k of the splat is aggregated; bit 4: larger than 2 x 2 tiles
+#pragma unroll
+    for (int j = 0; j < SORT_BIN_PER_THREAD; ++j) {
+        const uint32_t sub = ((uint32_t)j + 4u * (threadIdx.x & 1u)) & (DSS_SUB - 1);
+        int tx0 = 0, tx1 = -1, ty0 = 0, ty1 = -1;
+        cl[j] = pid[j] >= 0 ? find_cloud(pid[j], first_idx, num_pts, N) : -1;
+        bool any = cl[j] >= 0 && splat_tile_rect(ge[j].x, ge[j].y, 0.0f, ge[j].z, ge[j].w, g, tx0, tx1, ty0, ty1);
+        const bool small = any && tx1 - tx0 <= 1 && ty1 - ty0 <= 1;
+        rx0[j] = tx0; rx1[j] = tx1; ry0[j] = ty0; ry1[j] = ty1;
+        onm[j] = (any && !small) ? 16u : 0u;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int tx = (k & 1) ? tx1 : tx0, ty = (k & 2) ? ty1 : ty0;
+            const bool on = small && (!(k & 1) || tx1 > tx0) && (!(k & 2) || ty1 > ty0);
+            slot[j][k] = 0; rank[j][k] = 0;
+            if (on) {
+                onm[j] |= 1u << k;
+                const uint32_t key = (uint32_t)((cl[j] * tiles + ty * g.tiles_x + tx) * DSS_SUB) + sub;
+                uint32_t h = (key * 2654435761u) >> 20;   // 12 bits
+                for (;;) {
+                    const uint32_t old = atomicCAS(&h_key[h], SORT_EMPTY, key);
+                    if (old == SORT_EMPTY || old == key) break;
+                    h = (h + 1u) & (SORT_HASH - 1);
+                }
+                slot[j][k] = h;
+                rank[j][k] = atomicAdd(&h_cnt[h], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    // one reservation per key: the run [base, base + n) of its sub-list.  The returning atomics of a thread's slots are
+    // issued together.  (No tile is claimed here: the direct binning appends a tile to its queue when a sub-list receives
+    // its first entry -- ~60k appends to 32 queue tails, hidden inside a 1 ms kernel; inside this 0.15 ms kernel the same
+    // appends serialised on the tails for 0.36 ms.)
+    {
+        constexpr int SLOTS = SORT_HASH / SORT_BIN_THREADS;
+        uint32_t kk[SLOTS], bb[SLOTS];
+#pragma unroll
+        for (int u = 0; u < SLOTS; ++u) {
+            const int k = threadIdx.x + u * SORT_BIN_THREADS;
+            kk[u] = h_key[k];
+            bb[u] = 1u;
+            if (kk[u] != SORT_EMPTY) bb[u] = atomicAdd(&counts[kk[u]], h_cnt[k]);
+        }
+#pragma unroll
+        for (int u = 0; u < SLOTS; ++u) {
+            if (kk[u] == SORT_EMPTY) continue;
+            h_cnt[threadIdx.x + u * SORT_BIN_THREADS] = bb[u];   // (the occupied-tile queues are built afterwards: queue_build_kernel)
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < SORT_BIN_PER_THREAD; ++j) {
+        const uint32_t sub = ((uint32_t)j + 4u * (threadIdx.x & 1u)) & (DSS_SUB - 1);
+        unsigned full = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (!(onm[j] & (1u << k))) continue;
+            const uint32_t key = h_key[slot[j][k]];
+            const uint32_t pos = h_cnt[slot[j][k]] + rank[j][k];
+            if (pos < cap) lists[(size_t)key * cap + pos] = (int32_t)pid[j];
+            else full |= 1u << k;
+        }
+        if (full && sp.ctrl) {
+            sp.mask[pid[j]] = (uint8_t)(full | (sub << 4));
+            sp.ctrl[0] = 1u;
+        }
+        if (onm[j] & 16u) {
+            // a splat larger than 2 x 2 tiles (radius above 8 pixels): one returning atomic per tile, like the direct binning
+            for (int ty = ry0[j]; ty <= ry1[j]; ++ty)
+                for (int tx = rx0[j]; tx <= rx1[j]; ++tx) {
+                    const size_t t = (size_t)(cl[j] * tiles + ty * g.tiles_x + tx) * DSS_SUB + sub;
+                    const uint32_t pos = atomicAdd(&counts[t], 1u);
+                    if (pos < cap) lists[t * cap + pos] = (int32_t)pid[j];
+                    else if (sp.ctrl) sp.fail[0] = sp.epoch;
+                }
+        }
+    }
+}
+
+// Occupied-tile queues of the cell-ordered path: one thread per tile looks at its eight sub-list counters; the occupied
+// tiles of a workgroup are ranked per queue with ballots and appended with ONE atomicAdd per (workgroup, queue).
+__global__ __launch_bounds__(1024) void queue_build_kernel(const uint32_t *__restrict__ counts, int total_tiles, TileGrid g,
+                                                           TileQueue tq)
+{
+    __shared__ uint32_t s_cnt[DSS_QUEUES];    // occupied tiles of this workgroup per queue, then the reserved base
+    __shared__ uint32_t s_wave[16][DSS_QUEUES];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tile = blockIdx.x * 1024 + tid;
+    bool occ = false;
+    int q = 0;
+    if (tile < total_tiles) {
+        const uint4 *c4 = reinterpret_cast<const uint4 *>(counts + (size_t)tile * DSS_SUB);
+        const uint4 a = c4[0], b = c4[1];
+        occ = (a.x | a.y | a.z | a.w | b.x | b.y | b.z | b.w) != 0u;
+        const int tiles = g.tiles_x * g.tiles_y;
+        const int n = tile / tiles, t = tile - n * tiles;
+        q = queue_of(n, t % g.tiles_x, t / g.tiles_x, g);
+    }
+    // rank of this tile among the wave's occupied tiles of the same queue; per-wave totals per queue
+    uint32_t my_rank = 0;
+    for (int qq = 0; qq < DSS_QUEUES; ++qq) {
+        const unsigned long long m = __ballot(occ && q == qq);
+        if (occ && q == qq) my_rank = (uint32_t)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        if (lane == 0) s_wave[wid][qq] = (uint32_t)__popcll(m);
+    }
+    __syncthreads();
+    if (tid < DSS_QUEUES) {
+        uint32_t tot = 0;
+        for (int w = 0; w < 16; ++w) { const uint32_t c = s_wave[w][tid]; s_wave[w][tid] = tot; tot += c; }   // exclusive over the waves
+        s_cnt[tid] = tot ? atomicAdd(&tq.tail[tid], tot) : 0u;
+    }
+    __syncthreads();
+    if (occ) {
+        tq.flag[tile] = 1u;
+        const uint32_t pos = s_cnt[q] + s_wave[wid][q] + my_rank;
+        if (pos < tq.capq) tq.list[(size_t)q * tq.capq + pos] = tile + 1;
     }
 }
 
@@ -1075,6 +1397,13 @@ struct FwdWorkspace {
     TileQueue queue;
     Spill spill;
     float4 *rec;         // packed splat records (P x 64 bytes) behind the lists; only carved for the fused forward
+    // cell-ordered binning (fused forward, P > SORT_MIN_P; nullptr otherwise): every region is fully rewritten per call
+    uint32_t *sort_cell_of;      // (P) cell of every splat, SORT_NO_CELL for culled ones
+    uint32_t *sort_block_hist;   // (blocks, cells) per-block histogram, then per-block offsets
+    uint32_t *sort_cell_total, *sort_cell_start;   // (cells)
+    uint32_t *sort_count;        // number of sorted (= not culled) splats
+    float4 *sort_geo;            // (P) px, py, rx, ry in cell order
+    int32_t *sort_id;            // (P) splat id in cell order
     size_t count_bytes;  // bytes to zero before binning (the DSS_WS_CLEAN region): everything in front of the lists
     size_t bytes;
 };
@@ -1155,6 +1484,17 @@ static FwdWorkspace carve_fwd(void *ws, int N, int64_t P, int S, bool with_recor
     if (with_records && !lean_workspace()) {
         w.rec = reinterpret_cast<float4 *>(p + w.bytes);
         w.bytes += align_up((size_t)P * 64, 256);
+    }
+    w.sort_cell_of = nullptr;
+    if (with_records && !lean_workspace() && P > SORT_MIN_P) {
+        const SortGrid sg = make_sort_grid(N, S);
+        w.sort_cell_of = reinterpret_cast<uint32_t *>(p + w.bytes);      w.bytes += align_up((size_t)P * 4, 256);
+        w.sort_block_hist = reinterpret_cast<uint32_t *>(p + w.bytes);   w.bytes += align_up(sort_blocks(P) * (size_t)sg.total * 4, 256);
+        w.sort_cell_total = reinterpret_cast<uint32_t *>(p + w.bytes);   w.bytes += align_up((size_t)sg.total * 4, 256);
+        w.sort_cell_start = reinterpret_cast<uint32_t *>(p + w.bytes);   w.bytes += align_up((size_t)sg.total * 4, 256);
+        w.sort_count = reinterpret_cast<uint32_t *>(p + w.bytes);        w.bytes += 256;
+        w.sort_geo = reinterpret_cast<float4 *>(p + w.bytes);            w.bytes += align_up((size_t)P * 16, 256);
+        w.sort_id = reinterpret_cast<int32_t *>(p + w.bytes);            w.bytes += align_up((size_t)P * 4, 256);
     }
     return w;
 }
@@ -1240,7 +1580,7 @@ static int splat_bin_impl(const float *points, const float *radii, const int64_t
     hipLaunchKernelGGL(bin_kernel, dim3(pb), dim3(256), 0, st, points, radii, first_idx, num_pts, N, P, g, w.counts,
                        w.lists, w.cap, w.queue, w.spill, visible_to_clear);
     hipLaunchKernelGGL(spill_kernel, dim3(spill_grid(P)), dim3(256), 0, st, points, radii, first_idx, num_pts, N, P, g, w.counts, w.cap,
-                       w.spill);
+                       w.spill, 0);
     return check_launch("dss_splat_bin");
 }
 
@@ -1416,11 +1756,32 @@ extern "C" int dss_render_forward(const float *world, const float *normals, cons
     // half of the CUs with one wave per SIMD, and this kernel is a chain of dependent latencies
     const int tb = 64;   // (64 / 128 / 256 threads measure the same at 8 x 1M and 4M points: not dispatch-bound there either)
     const int pb = (int)((P + tb - 1) / tb);
-    if (!rerun) {
+    const bool sorted = w.sort_cell_of != nullptr;   // large inputs: cell-ordered binning (see setup_cell_kernel)
+    if (!rerun && sorted) {
+        const SortGrid sg = make_sort_grid(N, S);
+        const unsigned sb = (unsigned)sort_blocks(P);
+        const int per = sort_per_thread(P);
+        const size_t lds = (size_t)sg.total * 4;
+        hipLaunchKernelGGL(setup_cell_kernel, dim3(sb), dim3(SORT_THREADS), lds, st, SA, sg, per, w.sort_cell_of,
+                           w.sort_block_hist, w.spill, visible);
+        hipLaunchKernelGGL(sort_block_scan_kernel, dim3((unsigned)((sg.total + 255) / 256)), dim3(256), 0, st, sb, sg.total,
+                           w.sort_block_hist, w.sort_cell_total);
+        hipLaunchKernelGGL(sort_cell_scan_kernel, dim3(1), dim3(1024), 0, st, w.sort_cell_total, w.sort_cell_start, sg.total,
+                           w.sort_count);
+        hipLaunchKernelGGL(sort_scatter_kernel, dim3(sb), dim3(SORT_THREADS), lds, st, pts_screen, radii, P, sg, per,
+                           w.sort_cell_of, w.sort_cell_start, w.sort_block_hist, w.sort_geo, w.sort_id);
+        hipLaunchKernelGGL(bin_sorted_kernel, dim3((unsigned)((P + SORT_BIN_CHUNK - 1) / SORT_BIN_CHUNK)),
+                           dim3(SORT_BIN_THREADS), 0, st, w.sort_geo, w.sort_id, w.sort_count, first_idx, num_pts, N, g, w.counts,
+                           w.lists, w.cap, w.queue, w.spill);
+        hipLaunchKernelGGL(queue_build_kernel, dim3((unsigned)((N * tiles + 1023) / 1024)), dim3(1024), 0, st, w.counts,
+                           N * tiles, g, w.queue);
+        hipLaunchKernelGGL(spill_kernel, dim3(spill_grid(P)), dim3(256), 0, st, pts_screen, radii, first_idx,
+                           num_pts, N, P, g, w.counts, w.cap, w.spill, 1);
+    } else if (!rerun) {
         hipLaunchKernelGGL(setup_bin_kernel, dim3(pb), dim3(tb), 0, st, SA, g, w.counts, w.lists, w.cap, w.queue, w.spill,
                            visible);
         hipLaunchKernelGGL(spill_kernel, dim3(spill_grid(P)), dim3(256), 0, st, pts_screen, radii, first_idx,
-                           num_pts, N, P, g, w.counts, w.cap, w.spill);
+                           num_pts, N, P, g, w.counts, w.cap, w.spill, 0);
     }
     FineArgs A;
     A.points = pts_screen; A.ellipse = ellipse; A.cutoff = cutoff; A.radii = radii;

@@ -9,6 +9,8 @@ All inputs must be GPU tensors; outputs are freshly allocated on the input's dev
 """
 from typing import Optional, Tuple
 
+import weakref
+
 import torch
 
 from . import _lib
@@ -119,8 +121,18 @@ def _rasterize_coarse(points, radii, cloud_to_packed_first_idx, num_points_per_c
             rc = lib.dss_splat_bin(_lib.ptr(points), _lib.ptr(radii), _lib.ptr(first), _lib.ptr(num), N, P, S, 0, S,
                                    _lib.ptr(bin_points), nbytes, _lib.stream_ptr(dev))
             _lib.check(rc, "dss_splat_bin")
-    bin_points._dss_bin = (first, num, N, P, S)   # what the fine pass needs besides the lists
+    # what the fine pass needs besides the lists, and what the lists were built from.  Kept in a registry keyed by the
+    # buffer's address (not as a Python attribute of the tensor, which views, autograd saves and `detach()` drop): any
+    # tensor that still refers to this storage finds it; a copy (clone / to) does not and is refused with a clear message.
+    _bin_registry[bin_points.data_ptr()] = (weakref.ref(bin_points), first, num, N, P, S,
+                                            (points.data_ptr(), points._version, radii.data_ptr(), radii._version))
+    if len(_bin_registry) > 64:
+        for k in [k for k, v in _bin_registry.items() if v[0]() is None]:
+            del _bin_registry[k]
     return bin_points
+
+
+_bin_registry = {}
 
 
 def _rasterize_fine(points, ellipse_params, cutoff_thres, radii, bin_points, depth_merging_thres: float, image_size: int,
@@ -128,13 +140,15 @@ def _rasterize_fine(points, ellipse_params, cutoff_thres, radii, bin_points, dep
     """``DSS._C._rasterize_fine`` (ext.cpp:12, rasterize_points.h:257-285) on the ``bin_points`` of
     :func:`_rasterize_coarse` -> ``(idx, zbuf, qvalue, occupancy)`` like ``splat_points``."""
     lib = _lib.load()
-    meta = getattr(bin_points, "_dss_bin", None)
-    if meta is None:
-        raise RuntimeError("bin_points must come from dss_amd.ops._rasterize_coarse (opaque tile lists, not the "
-                           "reference's dense (N,B,B,M) table)")
-    first, num, N, P, S = meta
+    meta = _bin_registry.get(bin_points.data_ptr()) if isinstance(bin_points, torch.Tensor) and bin_points.is_cuda else None
+    if meta is None or meta[0]() is None:
+        raise RuntimeError("bin_points must be the tensor dss_amd.ops._rasterize_coarse returned, or a view of it (opaque "
+                           "tile lists, not the reference's dense (N,B,B,M) table; a clone / device copy is not accepted)")
+    _, first, num, N, P, S, src = meta
     if int(image_size) != S or points.shape[0] != P:
         raise RuntimeError("bin_points were built for image_size=%d and %d points" % (S, P))
+    if src != (points.data_ptr(), points._version, radii.data_ptr(), radii._version):
+        raise RuntimeError("bin_points were built from other points / radii tensors (or these were modified since)")
     _check_raster_inputs(points, ellipse_params, cutoff_thres, radii, first, num)
     points = _lib.require_gpu(points, "points", _f32)
     dev = points.device

@@ -183,6 +183,41 @@ def test_far_camera_overflow_is_exact_and_not_a_cliff(fused):
     assert times["far"] <= 2.0 * times["near"], times
 
 
+@pytest.mark.parametrize("dist", [2.0, 5.0])
+def test_cell_ordered_binning_of_large_inputs_is_exact(dist):
+    """More than 2,000,000 splats take the cell-ordered binning of dss_render_forward (setup + cell histogram -> scans ->
+    scatter -> LDS-aggregated binning -> queue build, raster_forward.hip `bin_sorted_kernel`); the direct binning of
+    `splat_points` fills the same lists in another order.  Same fragments bit for bit -- near camera (primary lists), far camera (the whole
+    cloud on a few tiles: the sub-lists overflow and the spill pool is filled by the sorted path's mask bytes) and a
+    second cloud with a gap of unowned points."""
+    pts, nrm = scenes.load_cloud("yoga6")
+    pts = scenes.normalize_unit_sphere(pts)
+    pts, nrm = scenes.upsample_jitter(pts, nrm, 106, seed=0)     # 1,057,774 points per cloud, two clouds
+    h = scenes.global_h(pts[::40]) / 40.0
+    S, K, thr = 512, 5, 0.05
+    M = np.concatenate([scenes.camera_matrices(dist, 20.0, a)[0] for a in (30.0, 170.0)])
+    V = np.concatenate([scenes.camera_matrices(dist, 20.0, a)[1] for a in (30.0, 170.0)])
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    Pc = len(pts)
+    first = torch.tensor([0, Pc], dtype=torch.int64, device=DEV)
+    num = torch.tensor([Pc, Pc - 1000], dtype=torch.int64, device=DEV)     # the last 1000 packed points belong to no cloud
+    f = ops.render_forward(t(pts), t(nrm), torch.full((2,), float(h), device=DEV), t(M), t(V), torch.full((2,), 0.1, device=DEV),
+                           torch.full((2,), 100.0, device=DEV), first, num, torch.rand((2 * Pc, 3), device=DEV), S, K, 1.0, thr,
+                           1.0, False, True)
+    want = ops.splat_points(f["pts_screen"], f["ellipse_params"], f["cutoff_threshold"], f["radii"], first, num, thr, S, K,
+                            return_visible=True)
+    assert float(want[3].mean()) > 0.005
+    if dist > 4.0:
+        assert float(want[3].mean()) < 1.0 / 16, "the far view is meant to cover a small part of the screen"
+    for k, w_ in zip(("idx", "zbuf", "qvalue", "occupancy", "visible"), want):
+        assert torch.equal(f[k], w_), (k, dist)
+    # the workspace is left clean by the sorted path as well: a second call gives the same result
+    f2 = ops.render_forward(t(pts), t(nrm), torch.full((2,), float(h), device=DEV), t(M), t(V), torch.full((2,), 0.1, device=DEV),
+                            torch.full((2,), 100.0, device=DEV), first, num, torch.rand((2 * Pc, 3), device=DEV), S, K, 1.0, thr,
+                            1.0, False, True)
+    assert torch.equal(f2["idx"], f["idx"]) and torch.equal(f2["occupancy"], f["occupancy"])
+
+
 def test_row_bands_concatenate_to_full_image():
     sc = scenes.random_splats(2000, 96, 2, seed=6)
     d = _dev(sc)
@@ -417,6 +452,14 @@ def test_dss_c_same_name_mirrors(golden_dir):
             assert np.array_equal(a.cpu().numpy(), z[k]), k
         with pytest.raises(RuntimeError):
             ops._rasterize_fine(d["points"], d["ellipse"], d["cutoff"], d["radii"], torch.zeros(8, device=DEV), thr, S, 16, K)
+        # the lists' metadata follows the STORAGE (views, detach(), autograd saves keep working); a copy is refused, and so
+        # are lists built from other points
+        out_v = ops._rasterize_fine(d["points"], d["ellipse"], d["cutoff"], d["radii"], bins.detach().view(-1), thr, S, 16, K)
+        assert torch.equal(out_v[0], out[0])
+        with pytest.raises(RuntimeError, match="view of it"):
+            ops._rasterize_fine(d["points"], d["ellipse"], d["cutoff"], d["radii"], bins.clone(), thr, S, 16, K)
+        with pytest.raises(RuntimeError, match="other points"):
+            ops._rasterize_fine(d["points"].clone(), d["ellipse"], d["cutoff"], d["radii"], bins, thr, S, 16, K)
         # _splat_points_occ_backward (CUDA form): every point, box support radii * radii_s
         got = ops._splat_points_occ_backward(d["points"], d["radii"], t(z["grad_occ"]), d["first"], d["num"],
                                              float(z["radii_s"]), thr)
