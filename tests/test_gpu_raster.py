@@ -216,6 +216,15 @@ def test_cell_ordered_binning_of_large_inputs_is_exact(dist):
                             torch.full((2,), 100.0, device=DEV), first, num, torch.rand((2 * Pc, 3), device=DEV), S, K, 1.0, thr,
                             1.0, False, True)
     assert torch.equal(f2["idx"], f["idx"]) and torch.equal(f2["occupancy"], f["occupancy"])
+    # row bands (multi-GPU) on the same path: a contiguous band and a tile-row-cyclic one are rows of the full render
+    from dss_amd.distributed import RowPartition
+    feat = torch.rand((2 * Pc, 3), device=DEV)
+    args = (t(pts), t(nrm), torch.full((2,), float(h), device=DEV), t(M), t(V), torch.full((2,), 0.1, device=DEV),
+            torch.full((2,), 100.0, device=DEV), first, num, feat, S, K, 1.0, thr, 1.0, False, True)
+    for part in (RowPartition(S, 4, 1), RowPartition(S, 4, 2, cyclic=True)):
+        fb = ops.render_forward(*args, rows=part.rows)
+        own = torch.tensor(part.row_indices(), device=DEV, dtype=torch.int64)
+        assert torch.equal(fb["idx"], f["idx"][:, own]) and torch.equal(fb["qvalue"], f["qvalue"][:, own]), part.describe()
 
 
 def test_row_bands_concatenate_to_full_image():
