@@ -312,7 +312,8 @@ __global__ __launch_bounds__(256) void spill_kernel(
 // that order itself, without global atomics:
 //   setup_cell_kernel   per-point setup (same body) + the 32 x 32-pixel screen cell of every splat's centre + a histogram
 //                       of the workgroup's 16,384 splats in LDS -> block_hist[block][cell]
-//   sort_block_scan / sort_cell_scan   exclusive prefix of every cell over the blocks, of the cells over the image
+//   sort_block_scan / sort_seg_scan / sort_cell_scan   exclusive prefix of every cell over the blocks (two levels), of the
+//                       cells over the image
 //   sort_scatter_kernel every workgroup ranks its splats again in LDS and writes (px, py, rx, ry | id) in cell order
 //   bin_sorted_kernel   1024 consecutive sorted splats per workgroup -- one or two cells -- : the (tile, sub-list) keys of
 //                       their pairs are counted in an LDS hash table, ONE global atomicAdd per key reserves the run, the
@@ -392,26 +393,47 @@ __global__ __launch_bounds__(SORT_THREADS) void setup_cell_kernel(const SetupArg
     uint32_t *row = block_hist + (size_t)blockIdx.x * sg.total;
     for (int c = threadIdx.x; c < sg.total; c += SORT_THREADS) row[c] = s_hist[c];
 }
-// thread per cell: block_hist[b][c] <- number of the cell's splats in blocks < b; cell_total[c]
+// Prefix of every cell over the blocks, two levels (one thread per cell walking 500+ blocks was 36-39 us of load latency):
+// sort_block_scan_kernel, grid (cells / 256, segments of SORT_SEG blocks): block_hist[b][c] <- the cell's splats in the
+// earlier blocks of b's segment, seg_tot[seg][c] <- the segment's total; sort_seg_scan_kernel, one thread per cell:
+// seg_tot[seg][c] <- the cell's splats in earlier segments, cell_total[c].
+#define SORT_SEG 8
 __global__ __launch_bounds__(256) void sort_block_scan_kernel(uint32_t nb, int total, uint32_t *__restrict__ block_hist,
-                                                              uint32_t *__restrict__ cell_total)
+                                                              uint32_t *__restrict__ seg_tot)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= total) return;
-    uint32_t run = 0, b = 0;
-    for (; b + 8 <= nb; b += 8) {   // eight independent loads in flight per trip
+    const uint32_t b0 = blockIdx.y * SORT_SEG;
+    uint32_t v[SORT_SEG];
+#pragma unroll
+    for (int u = 0; u < SORT_SEG; ++u) v[u] = (b0 + u < nb) ? block_hist[(size_t)(b0 + u) * total + c] : 0u;
+    uint32_t run = 0;
+#pragma unroll
+    for (int u = 0; u < SORT_SEG; ++u) {
+        if (b0 + u < nb) block_hist[(size_t)(b0 + u) * total + c] = run;
+        run += v[u];
+    }
+    seg_tot[(size_t)blockIdx.y * total + c] = run;
+}
+__global__ __launch_bounds__(256) void sort_seg_scan_kernel(uint32_t nseg, int total, uint32_t *__restrict__ seg_tot,
+                                                            uint32_t *__restrict__ cell_total)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= total) return;
+    uint32_t run = 0, sg = 0;
+    for (; sg + 8 <= nseg; sg += 8) {   // eight independent loads in flight per trip
         uint32_t v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = block_hist[(size_t)(b + u) * total + c];
+        for (int u = 0; u < 8; ++u) v[u] = seg_tot[(size_t)(sg + u) * total + c];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            block_hist[(size_t)(b + u) * total + c] = run;
+            seg_tot[(size_t)(sg + u) * total + c] = run;
             run += v[u];
         }
     }
-    for (; b < nb; ++b) {
-        const uint32_t v = block_hist[(size_t)b * total + c];
-        block_hist[(size_t)b * total + c] = run;
+    for (; sg < nseg; ++sg) {
+        const uint32_t v = seg_tot[(size_t)sg * total + c];
+        seg_tot[(size_t)sg * total + c] = run;
         run += v;
     }
     cell_total[c] = run;
@@ -444,13 +466,14 @@ __global__ __launch_bounds__(1024) void sort_cell_scan_kernel(const uint32_t *__
 __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(
     const float *__restrict__ points, const float *__restrict__ radii, int64_t P, SortGrid sg, int per_thread,
     const uint32_t *__restrict__ cell_of,
-    const uint32_t *__restrict__ cell_start, const uint32_t *__restrict__ block_base, float4 *__restrict__ s_geo,
-    int32_t *__restrict__ s_id)
+    const uint32_t *__restrict__ cell_start, const uint32_t *__restrict__ block_base, const uint32_t *__restrict__ seg_base,
+    float4 *__restrict__ s_geo, int32_t *__restrict__ s_id)
 {
     extern __shared__ uint32_t s_hist[];
     // (merging two or four histogram blocks per scatter workgroup -- longer runs per cell -- measured 2-4 % slower)
     const uint32_t *base = block_base + (size_t)blockIdx.x * sg.total;
-    for (int c = threadIdx.x; c < sg.total; c += SORT_THREADS) s_hist[c] = cell_start[c] + base[c];
+    const uint32_t *sbase = seg_base + (size_t)(blockIdx.x / SORT_SEG) * sg.total;
+    for (int c = threadIdx.x; c < sg.total; c += SORT_THREADS) s_hist[c] = cell_start[c] + sbase[c] + base[c];
     __syncthreads();
     const int64_t b0 = (int64_t)blockIdx.x * SORT_THREADS * per_thread;
 #pragma unroll 4
@@ -1401,6 +1424,7 @@ struct FwdWorkspace {
     uint32_t *sort_cell_of;      // (P) cell of every splat, SORT_NO_CELL for culled ones
     uint32_t *sort_block_hist;   // (blocks, cells) per-block histogram, then per-block offsets
     uint32_t *sort_cell_total, *sort_cell_start;   // (cells)
+    uint32_t *sort_seg_tot;      // (segments of SORT_SEG blocks, cells)
     uint32_t *sort_count;        // number of sorted (= not culled) splats
     float4 *sort_geo;            // (P) px, py, rx, ry in cell order
     int32_t *sort_id;            // (P) splat id in cell order
@@ -1490,6 +1514,8 @@ static FwdWorkspace carve_fwd(void *ws, int N, int64_t P, int S, bool with_recor
         const SortGrid sg = make_sort_grid(N, S);
         w.sort_cell_of = reinterpret_cast<uint32_t *>(p + w.bytes);      w.bytes += align_up((size_t)P * 4, 256);
         w.sort_block_hist = reinterpret_cast<uint32_t *>(p + w.bytes);   w.bytes += align_up(sort_blocks(P) * (size_t)sg.total * 4, 256);
+        w.sort_seg_tot = reinterpret_cast<uint32_t *>(p + w.bytes);
+        w.bytes += align_up(((sort_blocks(P) + SORT_SEG - 1) / SORT_SEG) * (size_t)sg.total * 4, 256);
         w.sort_cell_total = reinterpret_cast<uint32_t *>(p + w.bytes);   w.bytes += align_up((size_t)sg.total * 4, 256);
         w.sort_cell_start = reinterpret_cast<uint32_t *>(p + w.bytes);   w.bytes += align_up((size_t)sg.total * 4, 256);
         w.sort_count = reinterpret_cast<uint32_t *>(p + w.bytes);        w.bytes += 256;
@@ -1764,12 +1790,15 @@ extern "C" int dss_render_forward(const float *world, const float *normals, cons
         const size_t lds = (size_t)sg.total * 4;
         hipLaunchKernelGGL(setup_cell_kernel, dim3(sb), dim3(SORT_THREADS), lds, st, SA, sg, per, w.sort_cell_of,
                            w.sort_block_hist, w.spill, visible);
-        hipLaunchKernelGGL(sort_block_scan_kernel, dim3((unsigned)((sg.total + 255) / 256)), dim3(256), 0, st, sb, sg.total,
-                           w.sort_block_hist, w.sort_cell_total);
+        const unsigned nseg = (sb + SORT_SEG - 1) / SORT_SEG;
+        hipLaunchKernelGGL(sort_block_scan_kernel, dim3((unsigned)((sg.total + 255) / 256), nseg), dim3(256), 0, st, sb,
+                           sg.total, w.sort_block_hist, w.sort_seg_tot);
+        hipLaunchKernelGGL(sort_seg_scan_kernel, dim3((unsigned)((sg.total + 255) / 256)), dim3(256), 0, st, nseg, sg.total,
+                           w.sort_seg_tot, w.sort_cell_total);
         hipLaunchKernelGGL(sort_cell_scan_kernel, dim3(1), dim3(1024), 0, st, w.sort_cell_total, w.sort_cell_start, sg.total,
                            w.sort_count);
         hipLaunchKernelGGL(sort_scatter_kernel, dim3(sb), dim3(SORT_THREADS), lds, st, pts_screen, radii, P, sg, per,
-                           w.sort_cell_of, w.sort_cell_start, w.sort_block_hist, w.sort_geo, w.sort_id);
+                           w.sort_cell_of, w.sort_cell_start, w.sort_block_hist, w.sort_seg_tot, w.sort_geo, w.sort_id);
         hipLaunchKernelGGL(bin_sorted_kernel, dim3((unsigned)((P + SORT_BIN_CHUNK - 1) / SORT_BIN_CHUNK)),
                            dim3(SORT_BIN_THREADS), 0, st, w.sort_geo, w.sort_id, w.sort_count, first_idx, num_pts, N, g, w.counts,
                            w.lists, w.cap, w.queue, w.spill);
