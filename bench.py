@@ -169,9 +169,11 @@ class Workload:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         graphs = []
+        # thread-local capture mode: the process group's watchdog thread may query events while this thread captures; in
+        # the default (global) mode such a call from ANOTHER thread invalidates the capture
         for fn in (fwd, bwd, proj):
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=side):
+            with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
                 fn()
             graphs.append(g)
         self._seg, self._graphs = seg, graphs
@@ -435,17 +437,18 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
     # multi-GPU: tile-row-cyclic bands (rank g renders the 8-row tile rows g, g + G, ...: balanced for any scene, equal-size
     # all-gather) whenever the sizes allow it; BENCH_ROW_PARTITION=bands selects the contiguous equal bands of rounds 1-2
     cyclic = world > 1 and world & (world - 1) == 0 and S % (8 * world) == 0 and \
         os.environ.get("BENCH_ROW_PARTITION", "cyclic") == "cyclic"
     part = RowPartition(S, world, rank, cyclic=cyclic)
     wl = Workload(dev, world, part)
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
 
     def capture(unroll=1):
         side = torch.cuda.Stream()
@@ -486,6 +489,7 @@ def main():
     if world > 1 and args.mode != "eager":
         # multi-GPU: the RCCL calls stay outside any graph, the compute segments between them are graphs
         try:
+            barrier()   # (no collective in flight while capturing)
             wl.capture_segments()
             mode = "graph_segments"
         except Exception as e:  # noqa: BLE001  (capture refused: plain launches, and say so)

@@ -30,7 +30,9 @@ __all__ = ["PointFragments", "PointsRasterizationSettings", "SurfaceSplatting", 
 
 class PointFragments:
     """rasterizer.py:31-36: ``(idx, zbuf, qvalue, scaler, occupancy)`` with the reference's shapes -- a tuple-like object
-    (fields, order, unpacking, ``_replace`` / ``_asdict`` as on the reference's NamedTuple).
+    (fields, order, unpacking, ``_replace`` / ``_asdict`` as on the reference's NamedTuple).  Not a ``tuple`` SUBCLASS (the
+    lazily materialised ``scaler`` needs a mutable slot): ``isinstance(fragments, tuple)`` is False, ``tuple(fragments)``
+    converts.
 
     ``scaler`` is the per-FRAGMENT ``(N, H, W, K)`` tensor of rasterizer.py:631-633 (0 where ``idx < 0``), but it is only
     materialised when somebody reads it: the kernels consume the per-point ``scaler_packed (P,)`` (the gather is fused
