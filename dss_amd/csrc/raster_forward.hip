@@ -704,21 +704,19 @@ __device__ long long *g_fine_timing = nullptr;  // (blocks, 12) int64
 #define FT_VAL(slot, v)
 #endif
 
-// sorted insertion of (ekey, eq) into an ascending K-list held in registers; branch-free.
+// sorted insertion of ekey into an ascending K-list held in registers; branch-free.  The list holds the 64-bit keys only:
+// the Q value of a fragment is recomputed from its record in the epilogue, for the K survivors of a pixel instead of being
+// carried through every insertion and both merge rounds (two of the six v_cndmask per slot and insertion; the kernel is
+// bound by VALU issue at scale).
 template <int KMAX>
-__device__ __forceinline__ void klist_insert(unsigned long long (&key)[KMAX], float (&kq)[KMAX],
-                                             unsigned long long ekey, float eq)
+__device__ __forceinline__ void klist_insert(unsigned long long (&key)[KMAX], unsigned long long ekey)
 {
     bool lt[KMAX];  // e < slot[k] on the old list (monotone in k)
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) lt[k] = ekey < key[k];
 #pragma unroll
-    for (int k = KMAX - 1; k >= 1; --k) {
-        key[k] = lt[k - 1] ? key[k - 1] : (lt[k] ? ekey : key[k]);
-        kq[k] = lt[k - 1] ? kq[k - 1] : (lt[k] ? eq : kq[k]);
-    }
+    for (int k = KMAX - 1; k >= 1; --k) key[k] = lt[k - 1] ? key[k - 1] : (lt[k] ? ekey : key[k]);
     key[0] = lt[0] ? ekey : key[0];
-    kq[0] = lt[0] ? eq : kq[0];
 }
 
 template <int CTRL>
@@ -734,22 +732,19 @@ __device__ __forceinline__ unsigned dpp_u32(unsigned v)
 // insertions of ~12K operations each.  Keys are unique across slices (disjoint candidates) except KEY_EMPTY, whose
 // payload is the same everywhere.
 template <int KMAX, int CTRL>
-__device__ __forceinline__ void merge_round(unsigned long long (&key)[KMAX], float (&kq)[KMAX])
+__device__ __forceinline__ void merge_round(unsigned long long (&key)[KMAX])
 {
     unsigned long long okey[KMAX];
-    float oq[KMAX];
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) {
         const unsigned lo = dpp_u32<CTRL>((unsigned)key[k]);
         const unsigned hi = dpp_u32<CTRL>((unsigned)(key[k] >> 32));
         okey[k] = ((unsigned long long)hi << 32) | lo;
-        oq[k] = __uint_as_float(dpp_u32<CTRL>(__float_as_uint(kq[k])));
     }
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) {
         const bool lt = okey[KMAX - 1 - k] < key[k];
         key[k] = lt ? okey[KMAX - 1 - k] : key[k];
-        kq[k] = lt ? oq[KMAX - 1 - k] : kq[k];
     }
 #pragma unroll
     for (int round = 0; round < KMAX; ++round) {
@@ -757,11 +752,8 @@ __device__ __forceinline__ void merge_round(unsigned long long (&key)[KMAX], flo
         for (int k = round & 1; k + 1 < KMAX; k += 2) {
             const bool sw = key[k + 1] < key[k];
             const unsigned long long ka = key[k], kb = key[k + 1];
-            const float qa = kq[k], qb = kq[k + 1];
             key[k] = sw ? kb : ka;
             key[k + 1] = sw ? ka : kb;
-            kq[k] = sw ? qb : qa;
-            kq[k + 1] = sw ? qa : qb;
         }
     }
 }
@@ -944,12 +936,8 @@ __device__ __forceinline__ void fine_tile(const FineArgs &A, const int tile_id, 
     }
 
     unsigned long long key[KMAX];
-    float kq[KMAX];
 #pragma unroll
-    for (int k = 0; k < KMAX; ++k) {
-        key[k] = KEY_EMPTY;
-        kq[k] = -1.0f;
-    }
+    for (int k = 0; k < KMAX; ++k) key[k] = KEY_EMPTY;
     unsigned short *surv = &s_surv[wid][0][0];
 
     for (int64_t base = 0; base < count; base += step) {
@@ -1062,15 +1050,15 @@ __device__ __forceinline__ void fine_tile(const FineArgs &A, const int tile_id, 
                 // farther, so dropping it now is exact: rasterize_points.cu:586-595 would drop it later).
                 const float znear_now = __uint_as_float((unsigned)(key[0] >> 32));
                 const bool useful = (int)(ekey < key[KMAX - 1]) & (int)!((int)(key[0] != KEY_EMPTY) & (int)(zi.x - znear_now > A.thr));
-                if (__ballot(useful) != 0ull) klist_insert<KMAX>(key, kq, useful ? ekey : KEY_EMPTY, qval);
+                if (__ballot(useful) != 0ull) klist_insert<KMAX>(key, useful ? ekey : KEY_EMPTY);
             }
         }
     }
 
     FT_MARK(4);
     // ---- merge the four candidate slices of every pixel (the lanes of a quad) ----
-    merge_round<KMAX, 0xB1>(key, kq);  // quad_perm [1,0,3,2]
-    merge_round<KMAX, 0x4E>(key, kq);  // quad_perm [2,3,0,1]
+    merge_round<KMAX, 0xB1>(key);  // quad_perm [1,0,3,2]
+    merge_round<KMAX, 0x4E>(key);  // quad_perm [2,3,0,1]
 
     FT_MARK(5);
     // ---- epilogue (slice 0 lanes own the pixel): depth merge, occupancy, visibility, stores ----
@@ -1084,7 +1072,7 @@ __device__ __forceinline__ void fine_tile(const FineArgs &A, const int tile_id, 
     const int lr_e = ty * DSS_TILE + tr_e, c_e = tx * DSS_TILE + tc_e;   // band-local row, image column
     const bool owner = (lane_e & 3) == 0;
     const bool in_img = owner && (c_e < S) && (lr_e < g.rows);
-    float kz[KMAX];
+    float kz[KMAX], kq[KMAX];
     int ki[KMAX];
     const float z0 = __uint_as_float((unsigned)(key[0] >> 32));
     const bool any = key[0] != KEY_EMPTY;
@@ -1096,7 +1084,37 @@ __device__ __forceinline__ void fine_tile(const FineArgs &A, const int tile_id, 
         alive = alive && (key[k] != KEY_EMPTY) && !(z - z0 > A.thr);
         ki[k] = alive ? (int)(unsigned)(key[k] & 0xffffffffull) : -1;
         kz[k] = alive ? z : -1.0f;
-        kq[k] = alive ? kq[k] : -1.0f;
+        kq[k] = -1.0f;
+    }
+    // Q of the surviving fragments, recomputed from their records with the expression of the hit test (same operands, same
+    // order, no contraction: the same bits)
+    if (in_img) {
+        const float xf_e = ndc(S - 1 - c_e), yf_e = ndc(S - 1 - (tile_row0(g, ty) + tr_e));
+        float2 gp[KMAX];
+        float4 ge[KMAX];
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            gp[k] = make_float2(0.f, 0.f);
+            ge[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k < K && ki[k] >= 0) {
+                if (PACKED) {
+                    const float4 *R = A.rec + 4 * (size_t)ki[k];
+                    gp[k] = *reinterpret_cast<const float2 *>(R);
+                    ge[k] = R[1];
+                } else {
+                    const size_t q = (size_t)ki[k];
+                    gp[k] = make_float2(A.points[3 * q], A.points[3 * q + 1]);
+                    ge[k] = make_float4(A.ellipse[3 * q], A.ellipse[3 * q + 1], A.ellipse[3 * q + 2], 0.f);
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k)
+            if (k < K && ki[k] >= 0) {
+                const float dx = xf_e - gp[k].x;
+                const float dy = yf_e - gp[k].y;
+                kq[k] = ge[k].x * dx * dx + ge[k].y * dx * dy + ge[k].z * dy * dy;  // rasterize_points.cu:92-101
+            }
     }
     const size_t pix = ((size_t)n * g.rows + lr_e) * S + c_e;
     // blend inputs of the pixel's fragments (scaler + three feature channels): requested BEFORE the tile is staged
