@@ -699,9 +699,13 @@ __device__ long long *g_fine_timing = nullptr;  // (blocks, 12) int64
     do {                                                                                \
         if (g_fine_timing && threadIdx.x == 0) g_fine_timing[(size_t)blockIdx.x * 12 + (slot)] = (long long)(v); \
     } while (0)
+#define FT_DECL(var) long long var = 0
+#define FT_ACC(var, v) var += (v)
 #else
 #define FT_MARK(slot)
 #define FT_VAL(slot, v)
+#define FT_DECL(var)
+#define FT_ACC(var, v)
 #endif
 
 // sorted insertion of ekey into an ascending K-list held in registers; branch-free.  The list holds the 64-bit keys only:
@@ -709,14 +713,20 @@ __device__ long long *g_fine_timing = nullptr;  // (blocks, 12) int64
 // carried through every insertion and both merge rounds (two of the six v_cndmask per slot and insertion; the kernel is
 // bound by VALU issue at scale).
 template <int KMAX>
-__device__ __forceinline__ void klist_insert(unsigned long long (&key)[KMAX], unsigned long long ekey)
+__device__ __forceinline__ void klist_insert(unsigned long long (&key)[KMAX], unsigned long long ekey, bool useful)
 {
+    // `useful` implies ekey < key[KMAX - 1]; lanes without it keep their list (the lane masks are combined on the scalar unit)
     bool lt[KMAX];  // e < slot[k] on the old list (monotone in k)
 #pragma unroll
-    for (int k = 0; k < KMAX; ++k) lt[k] = ekey < key[k];
+    for (int k = 0; k < KMAX - 1; ++k) lt[k] = (int)useful & (int)(ekey < key[k]);
+    lt[KMAX - 1] = useful;
 #pragma unroll
-    for (int k = KMAX - 1; k >= 1; --k) key[k] = lt[k - 1] ? key[k - 1] : (lt[k] ? ekey : key[k]);
+    for (int k = KMAX - 1; k >= 1; --k) {
+        key[k] = lt[k - 1] ? key[k - 1] : (lt[k] ? ekey : key[k]);
+        asm volatile("" : "+v"(key[k]));   // slot by slot, in place: no renamed copy of the list for the skip path to mirror
+    }
     key[0] = lt[0] ? ekey : key[0];
+    asm volatile("" : "+v"(key[0]));
 }
 
 template <int CTRL>
@@ -815,9 +825,10 @@ template <int KMAX, bool PACKED>
 __device__ __forceinline__ void fine_tile(const FineArgs &A, const int tile_id, int32_t *slot_to_clear)
 {
     // candidate chunk: three records per splat -> 2x ds_read_b128 + 1x ds_read_b64 per test
-    __shared__ float4 s_geo[CHUNK];   // px, py, rx, ry
-    __shared__ float4 s_ell[CHUNK];   // a, b, c, cutoff
-    __shared__ float2 s_zid[CHUNK];   // pz, idx (bits)
+    // slot CHUNK of each array is a sentinel that no pixel hits (negative radii): it pads the survivor lists to whole passes
+    __shared__ float4 s_geo[CHUNK + 1];   // px, py, rx, ry
+    __shared__ float4 s_ell[CHUNK + 1];   // a, b, c, cutoff
+    __shared__ float2 s_zid[CHUNK + 1];   // idx (bits), pz + 0.0f: read as ONE 64-bit word this is the fragment's sort key
     __shared__ unsigned short s_surv[FINE_WAVES][4][CHUNK / 4];  // per wavefront and slice: compacted survivor slots
     constexpr int PLANES = (KMAX <= 8) ? 3 : 1;   // idx / zbuf / qvalue staged together when they fit
     __shared__ int s_out[PLANES][DSS_TILE_PIX * KMAX];
@@ -830,7 +841,8 @@ __device__ __forceinline__ void fine_tile(const FineArgs &A, const int tile_id, 
     const int t = tile_id - n * tiles;
     const int ty = t / g.tiles_x, tx = t - ty * g.tiles_x;
 
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    // the wavefront index through readfirstlane: everything derived from it (footprint bounds, survivor-list base) lives in SGPRs
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fx = wid % FOOT_PER_ROW, fy = wid / FOOT_PER_ROW;  // footprint inside the tile
     const int pl = lane >> 2, slice = lane & 3;       // pixel inside the footprint, candidate slice
     const int tr = fy * FOOT + (pl >> 2), tc = fx * FOOT + (pl & 3);
@@ -926,7 +938,16 @@ __device__ __forceinline__ void fine_tile(const FineArgs &A, const int tile_id, 
     const size_t tile_base = (((size_t)n * g.rows + (size_t)ty * DSS_TILE) * S + c0) * K;
 
     FT_MARK(1);
-    FT_VAL(10, count);
+#ifdef DSS_FINE_TIMING
+    {
+        long long ft_total = count;   // candidates of the tile: all sub-lists together
+        if (use_list) {
+            ft_total = 0;
+            for (int q = 0; q < DSS_SUB; ++q) ft_total += cs[q];
+        }
+        FT_VAL(10, ft_total);
+    }
+#endif
     if (count <= 0) {
         // empty tile in identity order (naive mode with an empty cloud): stream the fill values, no LDS, no barriers
         fill_tile_rows(A, tile_id, lane, wid, FINE_WAVES);
@@ -939,6 +960,12 @@ __device__ __forceinline__ void fine_tile(const FineArgs &A, const int tile_id, 
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) key[k] = KEY_EMPTY;
     unsigned short *surv = &s_surv[wid][0][0];
+    FT_DECL(ft_surv);
+    if (tid == 0) {   // visible to every wavefront after the first barrier of the chunk loop
+        s_geo[CHUNK] = make_float4(0.f, 0.f, -1.f, -1.f);
+        s_ell[CHUNK] = make_float4(0.f, 0.f, 0.f, 0.f);
+        s_zid[CHUNK] = make_float2(0.f, 0.f);
+    }
 
     for (int64_t base = 0; base < count; base += step) {
         // this thread's candidate of the chunk and its slot in the (dense) LDS staging area
@@ -987,13 +1014,13 @@ __device__ __forceinline__ void fine_tile(const FineArgs &A, const int tile_id, 
                 const float4 *R = A.rec + 4 * p;
                 s_geo[dst] = R[0];
                 s_ell[dst] = R[1];
-                s_zid[dst] = make_float2(R[3].x, __int_as_float((int)p));
+                s_zid[dst] = make_float2(__int_as_float((int)p), R[3].x + 0.0f);
             } else {
                 const float px = A.points[3 * p], py = A.points[3 * p + 1], pz = A.points[3 * p + 2];
                 const float2 rr = reinterpret_cast<const float2 *>(A.radii)[p];
                 s_geo[dst] = make_float4(px, py, rr.x, rr.y);
                 s_ell[dst] = make_float4(A.ellipse[3 * p], A.ellipse[3 * p + 1], A.ellipse[3 * p + 2], A.cutoff[p]);
-                s_zid[dst] = make_float2(pz, __int_as_float((int)p));
+                s_zid[dst] = make_float2(__int_as_float((int)p), pz + 0.0f);
             }
         }
         __syncthreads();
@@ -1007,7 +1034,7 @@ __device__ __forceinline__ void fine_tile(const FineArgs &A, const int tile_id, 
                 const float4 ge = s_geo[j];
                 // conservative, rounding-monotone rejection against the footprint (see splat_tile_rect); bitwise on
                 // purpose: short-circuit forms compile to nested exec-mask branches
-                const bool out = (int)(s_zid[j].x < 0) | (int)((f_xmax - ge.x) < -ge.z) | (int)((f_xmin - ge.x) > ge.z) |
+                const bool out = (int)(s_zid[j].y < 0) | (int)((f_xmax - ge.x) < -ge.z) | (int)((f_xmin - ge.x) > ge.z) |
                                  (int)((f_ymax - ge.y) < -ge.w) | (int)((f_ymin - ge.y) > ge.w);
                 keep = !out;
             }
@@ -1015,47 +1042,64 @@ __device__ __forceinline__ void fine_tile(const FineArgs &A, const int tile_id, 
             if (keep) {
                 const int rank = nsurv + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
                                                                    __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                surv[(rank & 3) * (CHUNK / 4) + (rank >> 2)] = (unsigned short)j;  // survivor `rank` -> slice rank%4
+                // survivor `rank` -> slice rank%4; stored as the byte offset of its 16-byte records
+                surv[(rank & 3) * (CHUNK / 4) + (rank >> 2)] = (unsigned short)(j * 16);
             }
             nsurv += __popcll(mask);
+        }
+        {   // pad to a whole number of two-survivor passes of all four slices with the sentinel slot
+            const int rank = nsurv + lane;
+            if (lane < 8 && rank < ((nsurv + 7) & ~7)) surv[(rank & 3) * (CHUNK / 4) + (rank >> 2)] = (unsigned short)(CHUNK * 16);
         }
         // same wavefront wrote and now reads `surv`: LDS ops of one wave complete in order; the wave
         // barrier only stops the compiler from moving the reads above the writes
         __builtin_amdgcn_wave_barrier();
         if (base == 0) FT_MARK(3);
+        FT_ACC(ft_surv, nsurv);
         // ---- test + insert: lane (pixel, slice) takes survivors slice, slice+4, ...; two per pass so that the LDS
         // reads of both are in flight together ----
         const int trips = (nsurv + 3) >> 2;
         const unsigned short *sv = surv + slice * (CHUNK / 4);
+        unsigned pair = *reinterpret_cast<const unsigned *>(sv);  // entries it, it+1 (it is even)
         for (int it = 0; it < trips; it += 2) {
-            const unsigned pair = *reinterpret_cast<const unsigned *>(sv + it);  // entries it, it+1 (it is even)
+            // all seven LDS reads of the pass are issued before the first test: the records of both survivors and the next
+            // pass's pair of offsets (past the end of the list it is a harmless read inside the workgroup's LDS).  The empty
+            // asm keeps the second survivor's reads above the first survivor's insertion branch (the compiler sinks them
+            // below it otherwise: three dependent LDS round trips per pass instead of one).
+            const unsigned off0 = pair & 0xffffu, off1 = pair >> 16;
+            typedef float vec4 __attribute__((ext_vector_type(4)));   // a register quadruple the asm constraint can name
+            vec4 ge[2], el[2];
+            unsigned long long ek[2];
+            ge[0] = *reinterpret_cast<const vec4 *>(reinterpret_cast<const char *>(s_geo) + off0);
+            el[0] = *reinterpret_cast<const vec4 *>(reinterpret_cast<const char *>(s_ell) + off0);
+            ek[0] = *reinterpret_cast<const unsigned long long *>(reinterpret_cast<const char *>(s_zid) + (off0 >> 1));
+            ge[1] = *reinterpret_cast<const vec4 *>(reinterpret_cast<const char *>(s_geo) + off1);
+            el[1] = *reinterpret_cast<const vec4 *>(reinterpret_cast<const char *>(s_ell) + off1);
+            ek[1] = *reinterpret_cast<const unsigned long long *>(reinterpret_cast<const char *>(s_zid) + (off1 >> 1));
+            pair = *reinterpret_cast<const unsigned *>(sv + it + 2);
+            asm volatile("" : "+v"(ge[1]), "+v"(el[1]), "+v"(ek[1]), "+v"(pair));
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const int si = (it + u) * 4 + slice;
-                const bool live = si < nsurv;
-                const int jj = live ? (int)((pair >> (16 * u)) & 0xffffu) : 0;
-                const float4 ge = s_geo[jj], el = s_ell[jj];
-                const float2 zi = s_zid[jj];
-                const float dx = xf - ge.x;
-                const float dy = yf - ge.y;
+                const unsigned long long ekey = ek[u];
+                const float ez = __uint_as_float((unsigned)(ekey >> 32));
+                const float dx = xf - ge[u].x;
+                const float dy = yf - ge[u].y;
                 // rasterize_points.cu:92-101, same expression order (no FMA contraction)
-                const float qval = el.x * dx * dx + el.y * dx * dy + el.z * dy * dy;
-                const bool hit = (int)live & (int)!(fabsf(dx) > ge.z) & (int)!(fabsf(dy) > ge.w) & (int)!(qval > el.w);
-                const unsigned long long ekey =
-                    hit ? (((unsigned long long)__float_as_uint(zi.x + 0.0f) << 32) |
-                           (unsigned long long)(unsigned)__float_as_int(zi.y))
-                        : KEY_EMPTY;
+                const float qval = el[u].x * dx * dx + el[u].y * dx * dy + el[u].z * dy * dy;
+                const bool hit = (int)!(fabsf(dx) > ge[u].z) & (int)!(fabsf(dy) > ge[u].w) & (int)!(qval > el[u].w);
                 // A hit can only reach the output if it beats this lane's current K-th entry AND lies within
                 // the depth-merge threshold of the nearest entry seen so far (the final nearest is never
-                // farther, so dropping it now is exact: rasterize_points.cu:586-595 would drop it later).
+                // farther, so dropping it now is exact: rasterize_points.cu:586-595 would drop it later).  An empty
+                // list has the NaN pattern in the place of the nearest depth: the comparison is false, as it has to be.
                 const float znear_now = __uint_as_float((unsigned)(key[0] >> 32));
-                const bool useful = (int)(ekey < key[KMAX - 1]) & (int)!((int)(key[0] != KEY_EMPTY) & (int)(zi.x - znear_now > A.thr));
-                if (__ballot(useful) != 0ull) klist_insert<KMAX>(key, useful ? ekey : KEY_EMPTY);
+                const bool useful = (int)hit & (int)(ekey < key[KMAX - 1]) & (int)!(ez - znear_now > A.thr);
+                if (__ballot(useful) != 0ull) klist_insert<KMAX>(key, ekey, useful);
             }
         }
     }
 
     FT_MARK(4);
+    FT_VAL(11, ft_surv);
     // ---- merge the four candidate slices of every pixel (the lanes of a quad) ----
     merge_round<KMAX, 0xB1>(key);  // quad_perm [1,0,3,2]
     merge_round<KMAX, 0x4E>(key);  // quad_perm [2,3,0,1]

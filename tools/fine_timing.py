@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Developer tool: per-workgroup phase timestamps of the fine kernel (s_memtime) on the bench scene.
-Builds a private -DDSS_FINE_TIMING copy of the library under gpurun_out/ and never touches the
-shipped libdss_hip.so.  Usage (GPU box): python tools/fine_timing.py"""
+"""Developer tool: per-workgroup phase timestamps of the fine kernel (s_memtime) on the bench scene (or cfg3 / cfg4 / cfg5 of
+tools/bench_large.py).  Builds a private -DDSS_FINE_TIMING copy of the library under gpurun_out/ and never touches the
+shipped libdss_hip.so.  Usage (GPU box): python tools/fine_timing.py [cfg3|cfg4|cfg5]"""
 import ctypes
 import os
 import subprocess
@@ -17,7 +17,7 @@ os.makedirs(out_dir, exist_ok=True)
 so = os.path.join(out_dir, "libdss_hip_timing.so")
 src = os.path.join(ROOT, "dss_amd", "csrc")
 subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-                "-ffp-contract=off", "-fno-fast-math", "-fvisibility=hidden", "-DDSS_FINE_TIMING",
+                "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize", "-fvisibility=hidden", "-DDSS_FINE_TIMING",
                 *sorted(os.path.join(src, f) for f in os.listdir(src) if f.endswith(".hip")), "-o", so], check=True)
 from dss_amd import _lib  # noqa: E402
 _lib.LIB_PATH = so
@@ -26,8 +26,19 @@ import bench  # noqa: E402
 dev = torch.device("cuda:0")
 lib = _lib.load()
 lib.dss_debug_set_fine_timing.argtypes = [ctypes.c_void_p]
-wl = bench.Workload(dev, 1, bench.RowPartition(bench.S, 1, 0))
-blocks = (bench.S // 8) ** 2  # DSS_TILE = 8
+which = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
+if which == "cfg2":
+    wl = bench.Workload(dev, 1, bench.RowPartition(bench.S, 1, 0))
+    blocks = (bench.S // 8) ** 2  # DSS_TILE = 8
+else:
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import scenes  # noqa: E402
+    P, S, N = {"cfg4": (1_000_000, 1024, 8), "cfg5": (4_000_000, 2048, 1), "cfg3": (99_790, 512, 8)}[which]
+    pts, nrm, col = scenes.synthetic_cloud(P, seed=0)
+    h = scenes.global_h(pts[:: max(1, P // 200_000)]) * (200_000 / P if P > 200_000 else 1.0)
+    h = float(np.clip(h, 5e-6, 1e-3))
+    wl = bench.Workload(dev, N, bench.RowPartition(S, 1, 0), cloud=(pts, nrm, col, h))
+    blocks = N * (S // 8) ** 2
 buf = torch.zeros((2 * blocks + 4096, 12), dtype=torch.int64, device=dev)  # grid = queue slots (~tiles) + tiles/16 fill workgroups
 for _ in range(3):
     wl.fine_kernel_ms(iters=5)
@@ -48,6 +59,9 @@ if len(fills):
 t = t[(t[:, 0] != 0) & (t[:, 10] != -1)]  # workgroups that ran a tile (queue slots without work / flagged tiles exit before the first mark)
 cnt = t[:, 10]
 busy = cnt > 0
+print("candidates per occupied tile: mean %.1f p50 %d p90 %d max %d | survivors of footprint 0: mean %.1f (%.2f of the candidates)" % (
+    cnt[busy].mean(), np.percentile(cnt[busy], 50), np.percentile(cnt[busy], 90), cnt[busy].max(), t[busy, 11].mean(),
+    t[busy, 11].sum() / max(cnt[busy].sum(), 1)))
 rt0, rt1 = t[:, 8], t[:, 9]
 print("realtime span (100MHz ticks): kernel %d, first start %d, last end %d" % (rt1.max() - rt0.min(), 0, rt1.max() - rt0.min()))
 print("WG start spread (ticks): p50 %d p90 %d max %d" % tuple(np.percentile(rt0 - rt0.min(), [50, 90, 100])))
