@@ -821,6 +821,60 @@ __device__ __forceinline__ void fill_tile_rows(const FineArgs &A, int tile_id, i
     }
 }
 
+// fill values of up to 16 consecutive EMPTY tiles (bit i of `empty`: tile t0 + i), written by one 256-thread workgroup in
+// 16-byte pieces: thread -> (tile, piece of a tile row), then down the 8 rows.  Needs S % 8 == 0 (every tile full width, every
+// piece 16-byte aligned) and, with the fused blend, RGBA output; the caller falls back to fill_tile_rows otherwise.
+// (The per-wavefront row loop of fill_tile_rows issues 48 partly filled store instructions per tile; a fill workgroup
+// lived 13 us at 512^2 and kept its slot from the occupied tiles of a crowded XCD: tools/fine_timing.py.)
+__device__ __forceinline__ void fill_tiles16(const FineArgs &A, int t0, unsigned empty, int tid)
+{
+    const TileGrid g = A.g;
+    const int tiles = g.tiles_x * g.tiles_y;
+    const int S = g.S, K = A.K;
+    const int q4 = 2 * K;   // 16-byte pieces of one tile row in a (.., K) plane
+    const int4 m1i = make_int4(-1, -1, -1, -1);
+    const float4 m1f = make_float4(-1.f, -1.f, -1.f, -1.f);
+    for (int j = tid; j < 16 * q4; j += FINE_THREADS) {
+        const int i = j / q4, e = j - i * q4;
+        if (!((empty >> i) & 1u)) continue;
+        const int tile_id = t0 + i;
+        const int n = tile_id / tiles;
+        const int t = tile_id - n * tiles;
+        const int ty = t / g.tiles_x, tx = t - ty * g.tiles_x;
+        const int valid_rows = min(DSS_TILE, g.rows - ty * DSS_TILE);
+        size_t o = (((size_t)n * g.rows + (size_t)ty * DSS_TILE) * S + (size_t)tx * DSS_TILE) * K + (size_t)e * 4;
+        for (int r = 0; r < valid_rows; ++r, o += (size_t)S * K) {
+            *reinterpret_cast<int4 *>(A.idx + o) = m1i;
+            if (A.zbuf) *reinterpret_cast<float4 *>(A.zbuf + o) = m1f;
+            *reinterpret_cast<float4 *>(A.qv + o) = m1f;
+        }
+    }
+    // per-pixel planes: occupancy (2 pieces per tile row) and, with the fused blend, weight sum (2) + RGBA (8)
+    const int per = A.image ? 12 : 2;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 w4 = make_float4(1e-4f, 1e-4f, 1e-4f, 1e-4f);   // weight sum clamped to kEpsilon
+    for (int j = tid; j < 16 * per; j += FINE_THREADS) {
+        const int i = j / per, e = j - i * per;
+        if (!((empty >> i) & 1u)) continue;
+        const int tile_id = t0 + i;
+        const int n = tile_id / tiles;
+        const int t = tile_id - n * tiles;
+        const int ty = t / g.tiles_x, tx = t - ty * g.tiles_x;
+        const int valid_rows = min(DSS_TILE, g.rows - ty * DSS_TILE);
+        const size_t pix = ((size_t)n * g.rows + (size_t)ty * DSS_TILE) * S + (size_t)tx * DSS_TILE;
+        if (e < 2) {
+            float *o = A.occ + pix + 4 * e;
+            for (int r = 0; r < valid_rows; ++r, o += S) *reinterpret_cast<float4 *>(o) = z4;
+        } else if (e < 4) {
+            float *o = A.wsum + pix + 4 * (e - 2);
+            for (int r = 0; r < valid_rows; ++r, o += S) *reinterpret_cast<float4 *>(o) = w4;
+        } else {
+            float *o = A.image + (size_t)n * A.img_sn + (size_t)(ty * DSS_TILE) * A.img_sr + (size_t)(tx * DSS_TILE + (e - 4)) * 4;
+            for (int r = 0; r < valid_rows; ++r, o += A.img_sr) *reinterpret_cast<float4 *>(o) = z4;
+        }
+    }
+}
+
 template <int KMAX, bool PACKED>
 __device__ __forceinline__ void fine_tile(const FineArgs &A, const int tile_id, int32_t *slot_to_clear)
 {
@@ -1310,19 +1364,30 @@ __global__ __launch_bounds__(FINE_THREADS) void fine_kernel(const FineArgs A)
     // dispatcher works through ~3000 workgroups whose slot turns out to be empty at ~3 ns each) and ended it
     const uint32_t fill_wgs = qmode ? fill_workgroups(total) : 0u;
     if (blockIdx.x < fill_wgs) {
-        const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-        const int t0 = (int)blockIdx.x * 16 + wid * 4;
+        const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+        const int t0 = (int)blockIdx.x * 16;
         FT_MARK(0);
         FT_VAL(8, __builtin_amdgcn_s_memrealtime());
         FT_VAL(10, -1);
-        // the four flags of this wavefront's tiles in ONE round trip (this wavefront is their only reader)
-        const bool mine = lane < 4 && t0 + lane < total;
+        // the sixteen flags in ONE round trip, by every wavefront (this workgroup is their only reader; wavefront 0 resets
+        // them once all four have read)
+        const bool mine = lane < 16 && t0 + lane < total;
         const uint32_t flag = mine ? A.queue.flag[t0 + lane] : 1u;
-        if (clean && mine && flag) A.queue.flag[t0 + lane] = 0;
-        const unsigned empty = (unsigned)__ballot(flag == 0u) & 0xfu;
+        const unsigned empty = (unsigned)__ballot(flag == 0u) & 0xffffu;
+        if (clean) {
+            __syncthreads();
+            if (wid == 0 && mine && flag) A.queue.flag[t0 + lane] = 0;
+        }
+        if (empty == 0u) return;
+        const uintptr_t bits = (uintptr_t)A.idx | (uintptr_t)A.zbuf | (uintptr_t)A.qv | (uintptr_t)A.occ | (uintptr_t)A.image |
+                               (uintptr_t)A.wsum | (uintptr_t)((A.img_sn | A.img_sr) * 4);
+        if ((A.g.S & 7) == 0 && (bits & 15) == 0 && (A.image == nullptr || A.C == 3)) {
+            fill_tiles16(A, t0, empty, tid);
+        } else {
 #pragma unroll 1
-        for (int i = 0; i < 4; ++i)
-            if (empty & (1u << i)) fill_tile_rows(A, t0 + i, lane, 0, 1);
+            for (int i = 0; i < 4; ++i)
+                if (empty & (1u << (wid * 4 + i))) fill_tile_rows(A, t0 + wid * 4 + i, lane, 0, 1);
+        }
         FT_MARK(7);
         FT_VAL(9, __builtin_amdgcn_s_memrealtime());
         return;

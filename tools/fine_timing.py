@@ -56,7 +56,12 @@ if len(fills):
     print("fill workgroups %d: start p50 %d max %d | end p50 %d p90 %d max %d (ticks) | cycles mean %.0f max %d" % (
         len(fills), np.percentile(f0, 50), f0.max(), np.percentile(f1, 50), np.percentile(f1, 90), f1.max(),
         (fills[:, 7] - fills[:, 0]).mean(), (fills[:, 7] - fills[:, 0]).max()))
-t = t[(t[:, 0] != 0) & (t[:, 10] != -1)]  # workgroups that ran a tile (queue slots without work / flagged tiles exit before the first mark)
+blk = np.arange(len(t))
+sel = (t[:, 0] != 0) & (t[:, 10] != -1)
+xcd = blk[sel] % 8   # observed placement: workgroup b runs on XCD b mod 8
+print("tile workgroups per XCD:", np.bincount(xcd, minlength=8).tolist(), "| starting later than 3 us per XCD:",
+      np.bincount(xcd[(t[sel, 8] - t[t[:, 0] != 0][:, 8].min()) > 300], minlength=8).tolist())
+t = t[sel]  # workgroups that ran a tile (queue slots without work / flagged tiles exit before the first mark)
 cnt = t[:, 10]
 busy = cnt > 0
 print("candidates per occupied tile: mean %.1f p50 %d p90 %d max %d | survivors of footprint 0: mean %.1f (%.2f of the candidates)" % (
