@@ -821,12 +821,13 @@ __device__ __forceinline__ void fill_tile_rows(const FineArgs &A, int tile_id, i
     }
 }
 
-// fill values of up to 16 consecutive EMPTY tiles (bit i of `empty`: tile t0 + i), written by one 256-thread workgroup in
+#define FILL_TILES 32   // tiles per fill workgroup (<= 32: one flag bit each)
+// fill values of up to FILL_TILES consecutive EMPTY tiles (bit i of `empty`: tile t0 + i), written by one 256-thread workgroup in
 // 16-byte pieces: thread -> (tile, piece of a tile row), then down the 8 rows.  Needs S % 8 == 0 (every tile full width, every
 // piece 16-byte aligned) and, with the fused blend, RGBA output; the caller falls back to fill_tile_rows otherwise.
 // (The per-wavefront row loop of fill_tile_rows issues 48 partly filled store instructions per tile; a fill workgroup
 // lived 13 us at 512^2 and kept its slot from the occupied tiles of a crowded XCD: tools/fine_timing.py.)
-__device__ __forceinline__ void fill_tiles16(const FineArgs &A, int t0, unsigned empty, int tid)
+__device__ __forceinline__ void fill_tiles(const FineArgs &A, int t0, unsigned empty, int tid)
 {
     const TileGrid g = A.g;
     const int tiles = g.tiles_x * g.tiles_y;
@@ -834,7 +835,7 @@ __device__ __forceinline__ void fill_tiles16(const FineArgs &A, int t0, unsigned
     const int q4 = 2 * K;   // 16-byte pieces of one tile row in a (.., K) plane
     const int4 m1i = make_int4(-1, -1, -1, -1);
     const float4 m1f = make_float4(-1.f, -1.f, -1.f, -1.f);
-    for (int j = tid; j < 16 * q4; j += FINE_THREADS) {
+    for (int j = tid; j < FILL_TILES * q4; j += FINE_THREADS) {
         const int i = j / q4, e = j - i * q4;
         if (!((empty >> i) & 1u)) continue;
         const int tile_id = t0 + i;
@@ -853,7 +854,7 @@ __device__ __forceinline__ void fill_tiles16(const FineArgs &A, int t0, unsigned
     const int per = A.image ? 12 : 2;
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     const float4 w4 = make_float4(1e-4f, 1e-4f, 1e-4f, 1e-4f);   // weight sum clamped to kEpsilon
-    for (int j = tid; j < 16 * per; j += FINE_THREADS) {
+    for (int j = tid; j < FILL_TILES * per; j += FINE_THREADS) {
         const int i = j / per, e = j - i * per;
         if (!((empty >> i) & 1u)) continue;
         const int tile_id = t0 + i;
@@ -1345,13 +1346,13 @@ __device__ __forceinline__ void fine_tile(const FineArgs &A, const int tile_id, 
     FT_VAL(9, __builtin_amdgcn_s_memrealtime());
 }
 
-// Queue mode (binned): grid = ceil(N*tiles / 16) + queue_wgs.  The first workgroups stream the fill values of the empty
-// tiles, 16 tiles each (one wavefront per tile, four tiles per wavefront); queue workgroup qb serves slot qb/32 of queue
+// Queue mode (binned): grid = ceil(N*tiles / FILL_TILES) + queue_wgs.  The first workgroups stream the fill values of the empty
+// tiles, FILL_TILES tiles each; queue workgroup qb serves slot qb/32 of queue
 // qb%32 (and exits at once when the slot is empty).  Identity mode (naive): one workgroup per tile.
-// 16 tiles per fill workgroup, rounded up to a multiple of 8 workgroups so that queue workgroup qb still lands on XCD qb % 8
+// rounded up to a multiple of 8 workgroups so that queue workgroup qb still lands on XCD qb % 8
 __host__ __device__ __forceinline__ uint32_t fill_workgroups(int total_tiles)
 {
-    return (((uint32_t)total_tiles + 15u) / 16u + 7u) & ~7u;
+    return (((uint32_t)total_tiles + FILL_TILES - 1u) / FILL_TILES + 7u) & ~7u;
 }
 
 template <int KMAX, bool PACKED>
@@ -1365,15 +1366,15 @@ __global__ __launch_bounds__(FINE_THREADS) void fine_kernel(const FineArgs A)
     const uint32_t fill_wgs = qmode ? fill_workgroups(total) : 0u;
     if (blockIdx.x < fill_wgs) {
         const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-        const int t0 = (int)blockIdx.x * 16;
+        const int t0 = (int)blockIdx.x * FILL_TILES;
         FT_MARK(0);
         FT_VAL(8, __builtin_amdgcn_s_memrealtime());
         FT_VAL(10, -1);
-        // the sixteen flags in ONE round trip, by every wavefront (this workgroup is their only reader; wavefront 0 resets
+        // the workgroup's flags in ONE round trip, by every wavefront (this workgroup is their only reader; wavefront 0 resets
         // them once all four have read)
-        const bool mine = lane < 16 && t0 + lane < total;
+        const bool mine = lane < FILL_TILES && t0 + lane < total;
         const uint32_t flag = mine ? A.queue.flag[t0 + lane] : 1u;
-        const unsigned empty = (unsigned)__ballot(flag == 0u) & 0xffffu;
+        const unsigned empty = (unsigned)__ballot(flag == 0u);   // (lanes >= FILL_TILES hold 1)
         if (clean) {
             __syncthreads();
             if (wid == 0 && mine && flag) A.queue.flag[t0 + lane] = 0;
@@ -1382,11 +1383,11 @@ __global__ __launch_bounds__(FINE_THREADS) void fine_kernel(const FineArgs A)
         const uintptr_t bits = (uintptr_t)A.idx | (uintptr_t)A.zbuf | (uintptr_t)A.qv | (uintptr_t)A.occ | (uintptr_t)A.image |
                                (uintptr_t)A.wsum | (uintptr_t)((A.img_sn | A.img_sr) * 4);
         if ((A.g.S & 7) == 0 && (bits & 15) == 0 && (A.image == nullptr || A.C == 3)) {
-            fill_tiles16(A, t0, empty, tid);
+            fill_tiles(A, t0, empty, tid);
         } else {
 #pragma unroll 1
-            for (int i = 0; i < 4; ++i)
-                if (empty & (1u << (wid * 4 + i))) fill_tile_rows(A, t0 + wid * 4 + i, lane, 0, 1);
+            for (int i = wid; i < FILL_TILES; i += FINE_WAVES)
+                if (empty & (1u << i)) fill_tile_rows(A, t0 + i, lane, 0, 1);
         }
         FT_MARK(7);
         FT_VAL(9, __builtin_amdgcn_s_memrealtime());
