@@ -876,9 +876,19 @@ __device__ __forceinline__ void fill_tiles(const FineArgs &A, int t0, unsigned e
     }
 }
 
-template <int KMAX, bool PACKED>
-__device__ __forceinline__ void fine_tile(const FineArgs &A, const int tile_id, int32_t *slot_to_clear)
+// The kernel's (only) argument, re-read from the kernarg segment.  `entry` is the by-value parameter: same bytes.
+__device__ __forceinline__ const FineArgs &reloaded_args(const FineArgs &entry)
 {
+    auto kp = (const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kp));
+    (void)entry;
+    return *(const FineArgs *)(const char *)kp;
+}
+
+template <int KMAX, bool PACKED>
+__device__ __forceinline__ void fine_tile(const FineArgs &A_entry, const int tile_id, int32_t *slot_to_clear)
+{
+    const FineArgs &A = A_entry;
     // candidate chunk: three records per splat -> 2x ds_read_b128 + 1x ds_read_b64 per test
     // slot CHUNK of each array is a sentinel that no pixel hits (negative radii): it pads the survivor lists to whole passes
     __shared__ float4 s_geo[CHUNK + 1];   // px, py, rx, ry
@@ -1049,18 +1059,7 @@ __device__ __forceinline__ void fine_tile(const FineArgs &A, const int tile_id, 
             dst = tid;
             m = (int)min((int64_t)CHUNK, count - base);
         }
-        __syncthreads();  // previous chunk fully consumed; first pass: every thread has read the tile's counters
-        if (base == 0) {
-            // DSS_WS_CLEAN: this workgroup is the only reader of the tile's counters and of its queue slot
-            if (A.clean_counts && tid < DSS_SUB) {
-                A.clean_counts[(size_t)tile_id * DSS_SUB + tid] = 0;
-                if (A.spill.pool && cmax > A.cap) {  // (uniform) the tile used the spill structures: reset them as well
-                    A.spill.cursor[(size_t)tile_id * DSS_SUB + tid] = 0;
-                    A.spill.offset[(size_t)tile_id * DSS_SUB + tid] = 0;
-                }
-            }
-            if (slot_to_clear && tid == DSS_SUB) *slot_to_clear = 0;
-        }
+        __syncthreads();  // previous chunk fully consumed
         if (have) {
             if (PACKED) {
                 // one 64-byte record = one half cache line per candidate: three loads, one memory transaction (the four
@@ -1153,6 +1152,25 @@ __device__ __forceinline__ void fine_tile(const FineArgs &A, const int tile_id, 
         }
     }
 
+    // Everything below reads the kernel arguments again from the kernarg segment (scalar loads through a laundered
+    // pointer) instead of keeping the ~25 output / blend pointers in SGPRs through the candidate loop: with them the kernel
+    // needed 106 SGPRs (+16 spilled to VGPR lanes), which caps a SIMD at 6 wavefronts whatever the VGPR count says.
+    const FineArgs &E = reloaded_args(A_entry);
+    {
+        // DSS_WS_CLEAN: this workgroup is the only reader of the tile's counters and of its queue slot, and every thread has
+        // read them by now (at least one barrier ago).  Done here, not inside the chunk loop: the three store addresses
+        // were live through it (7 VGPRs).
+        int tid_c = tid;
+        asm volatile("" : "+v"(tid_c));
+        if (E.clean_counts && tid_c < DSS_SUB) {
+            E.clean_counts[(size_t)tile_id * DSS_SUB + tid_c] = 0;
+            if (E.spill.pool && cmax > E.cap) {  // (uniform) the tile used the spill structures: reset them as well
+                E.spill.cursor[(size_t)tile_id * DSS_SUB + tid_c] = 0;
+                E.spill.offset[(size_t)tile_id * DSS_SUB + tid_c] = 0;
+            }
+        }
+        if (slot_to_clear && tid_c == DSS_SUB) *slot_to_clear = 0;
+    }
     FT_MARK(4);
     FT_VAL(11, ft_surv);
     // ---- merge the four candidate slices of every pixel (the lanes of a quad) ----
@@ -1180,7 +1198,7 @@ __device__ __forceinline__ void fine_tile(const FineArgs &A, const int tile_id, 
     for (int k = 0; k < KMAX; ++k) {
         const float z = __uint_as_float((unsigned)(key[k] >> 32));
         // rasterize_points.cu:586-595: stop at the first k with z[k]-z[0] > thr
-        alive = alive && (key[k] != KEY_EMPTY) && !(z - z0 > A.thr);
+        alive = alive && (key[k] != KEY_EMPTY) && !(z - z0 > E.thr);
         ki[k] = alive ? (int)(unsigned)(key[k] & 0xffffffffull) : -1;
         kz[k] = alive ? z : -1.0f;
         kq[k] = -1.0f;
@@ -1197,13 +1215,13 @@ __device__ __forceinline__ void fine_tile(const FineArgs &A, const int tile_id, 
             ge[k] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (k < K && ki[k] >= 0) {
                 if (PACKED) {
-                    const float4 *R = A.rec + 4 * (size_t)ki[k];
+                    const float4 *R = E.rec + 4 * (size_t)ki[k];
                     gp[k] = *reinterpret_cast<const float2 *>(R);
                     ge[k] = R[1];
                 } else {
                     const size_t q = (size_t)ki[k];
-                    gp[k] = make_float2(A.points[3 * q], A.points[3 * q + 1]);
-                    ge[k] = make_float4(A.ellipse[3 * q], A.ellipse[3 * q + 1], A.ellipse[3 * q + 2], 0.f);
+                    gp[k] = make_float2(E.points[3 * q], E.points[3 * q + 1]);
+                    ge[k] = make_float4(E.ellipse[3 * q], E.ellipse[3 * q + 1], E.ellipse[3 * q + 2], 0.f);
                 }
             }
         }
@@ -1219,15 +1237,15 @@ __device__ __forceinline__ void fine_tile(const FineArgs &A, const int tile_id, 
     // blend inputs of the pixel's fragments (scaler + three feature channels): requested BEFORE the tile is staged
     // and streamed out, consumed after -- the gather's round trip is hidden behind the LDS transpose and the stores
     constexpr bool PREFETCH_BLEND = false;  // (+20 VGPRs: 110 in total = 4 workgroups per CU; measured slower)
-    const bool blend3 = PREFETCH_BLEND && in_img && A.image != nullptr && A.C == 3;
+    const bool blend3 = PREFETCH_BLEND && in_img && E.image != nullptr && E.C == 3;
     float bsc[PREFETCH_BLEND ? KMAX : 1], bf0[PREFETCH_BLEND ? KMAX : 1], bf1[PREFETCH_BLEND ? KMAX : 1],
         bf2[PREFETCH_BLEND ? KMAX : 1];
     if (in_img) {
-        A.occ[pix] = any ? 1.0f : 0.0f;
-        if (A.visible) {
+        E.occ[pix] = any ? 1.0f : 0.0f;
+        if (E.visible) {
 #pragma unroll
             for (int k = 0; k < KMAX; ++k)
-                if (k < K && ki[k] >= 0) A.visible[ki[k]] = 1;
+                if (k < K && ki[k] >= 0) E.visible[ki[k]] = 1;
         }
     }
     if (PREFETCH_BLEND) {
@@ -1235,14 +1253,14 @@ __device__ __forceinline__ void fine_tile(const FineArgs &A, const int tile_id, 
         for (int k = 0; k < (PREFETCH_BLEND ? KMAX : 1); ++k) {
             bsc[k] = 0.0f; bf0[k] = 0.0f; bf1[k] = 0.0f; bf2[k] = 0.0f;
             if (blend3 && k < K && ki[k] >= 0) {
-                bsc[k] = A.scaler[ki[k]];
-                const float *f = A.feat + (size_t)ki[k] * 3;
+                bsc[k] = E.scaler[ki[k]];
+                const float *f = E.feat + (size_t)ki[k] * 3;
                 bf0[k] = f[0]; bf1[k] = f[1]; bf2[k] = f[2];
             }
         }
     }
 
-    if (in_img && A.image) {
+    if (in_img && E.image) {
         // fused blend (same arithmetic and order as blend_forward_kernel): w = exp(-q/2)*scaler,
         // img = sum f*w/cum, alpha = occupancy
         float wk[KMAX];
@@ -1252,7 +1270,7 @@ __device__ __forceinline__ void fine_tile(const FineArgs &A, const int tile_id, 
 #pragma unroll
             for (int k = 0; k < (PACKED ? KMAX : 1); ++k) {
                 br[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (k < K && ki[k] >= 0) br[k] = A.rec[4 * (size_t)ki[k] + 2];
+                if (k < K && ki[k] >= 0) br[k] = E.rec[4 * (size_t)ki[k] + 2];
             }
         }
 #pragma unroll
@@ -1260,18 +1278,18 @@ __device__ __forceinline__ void fine_tile(const FineArgs &A, const int tile_id, 
             wk[k] = 0.0f;
             if (k < K && ki[k] >= 0) {
                 wk[k] = ewa_weight(kq[k], PACKED ? br[PACKED ? k : 0].x
-                                                 : (blend3 ? bsc[PREFETCH_BLEND ? k : 0] : A.scaler[ki[k]]));
+                                                 : (blend3 ? bsc[PREFETCH_BLEND ? k : 0] : E.scaler[ki[k]]));
                 cum += wk[k];
             }
         }
         if (cum < 1e-4f) cum = 1e-4f;
-        A.wsum[pix] = cum;
+        E.wsum[pix] = cum;
         // normalised weights once per fragment: img = sum f * (w / cum)
         const float inv_cum = fast_rcp(cum);
 #pragma unroll
         for (int k = 0; k < KMAX; ++k) wk[k] = wk[k] * inv_cum;
-        float *o = A.image + (size_t)n * A.img_sn + (size_t)lr_e * A.img_sr + (size_t)c_e * (A.C + 1);
-        if (A.C == 3) {
+        float *o = E.image + (size_t)n * E.img_sn + (size_t)lr_e * E.img_sr + (size_t)c_e * (E.C + 1);
+        if (E.C == 3) {
             // RGBA as ONE 16-byte store per pixel (four dword stores at a 16-byte stride quadruple the
             // write requests the memory side sees)
             float acc3[3] = {0.0f, 0.0f, 0.0f};
@@ -1284,7 +1302,7 @@ __device__ __forceinline__ void fine_tile(const FineArgs &A, const int tile_id, 
                     } else if (blend3) {
                         f0 = bf0[PREFETCH_BLEND ? k : 0]; f1 = bf1[PREFETCH_BLEND ? k : 0]; f2 = bf2[PREFETCH_BLEND ? k : 0];
                     } else {
-                        const float *f = A.feat + (size_t)ki[k] * 3;
+                        const float *f = E.feat + (size_t)ki[k] * 3;
                         f0 = f[0]; f1 = f[1]; f2 = f[2];
                     }
                     acc3[0] += f0 * wk[k];
@@ -1293,14 +1311,14 @@ __device__ __forceinline__ void fine_tile(const FineArgs &A, const int tile_id, 
                 }
             *reinterpret_cast<float4 *>(o) = make_float4(acc3[0], acc3[1], acc3[2], any ? 1.0f : 0.0f);
         } else {
-            for (int ch = 0; ch < A.C; ++ch) {
+            for (int ch = 0; ch < E.C; ++ch) {
                 float acc = 0.0f;
 #pragma unroll
                 for (int k = 0; k < KMAX; ++k)
-                    if (k < K && ki[k] >= 0) acc += A.feat[(size_t)ki[k] * A.C + ch] * wk[k];
+                    if (k < K && ki[k] >= 0) acc += E.feat[(size_t)ki[k] * E.C + ch] * wk[k];
                 o[ch] = acc;
             }
-            o[A.C] = any ? 1.0f : 0.0f;
+            o[E.C] = any ? 1.0f : 0.0f;
         }
     }
     // stage the tile through LDS and let each wavefront stream full image rows per plane
@@ -1320,9 +1338,9 @@ __device__ __forceinline__ void fine_tile(const FineArgs &A, const int tile_id, 
         for (int rr = wid_e; rr < valid_rows; rr += FINE_WAVES) {
             const size_t rb = tile_base + (size_t)rr * S * K;
             for (int cc = lane_e; cc < valid_cols; cc += 64) {
-                A.idx[rb + cc] = s_out[0][rr * run + cc];
-                if (A.zbuf) reinterpret_cast<int *>(A.zbuf)[rb + cc] = s_out[PLANES - 1 > 0 ? 1 : 0][rr * run + cc];
-                reinterpret_cast<int *>(A.qv)[rb + cc] = s_out[PLANES - 1][rr * run + cc];
+                E.idx[rb + cc] = s_out[0][rr * run + cc];
+                if (E.zbuf) reinterpret_cast<int *>(E.zbuf)[rb + cc] = s_out[PLANES - 1 > 0 ? 1 : 0][rr * run + cc];
+                reinterpret_cast<int *>(E.qv)[rb + cc] = s_out[PLANES - 1][rr * run + cc];
             }
         }
     } else {
@@ -1336,9 +1354,9 @@ __device__ __forceinline__ void fine_tile(const FineArgs &A, const int tile_id, 
         for (int cc = lane_e; cc < valid_cols; cc += 64)                                            \
             reinterpret_cast<int *>(DST)[tile_base + (size_t)rr * S * K + cc] = s_out[0][rr * run + cc]; \
     }
-        DSS_STORE_PLANE(ki, A.idx, (int))
-        if (A.zbuf) { DSS_STORE_PLANE(kz, A.zbuf, __float_as_int) }
-        DSS_STORE_PLANE(kq, A.qv, __float_as_int)
+        DSS_STORE_PLANE(ki, E.idx, (int))
+        if (E.zbuf) { DSS_STORE_PLANE(kz, E.zbuf, __float_as_int) }
+        DSS_STORE_PLANE(kq, E.qv, __float_as_int)
 #undef DSS_STORE_PLANE
     }
 
@@ -1356,7 +1374,7 @@ __host__ __device__ __forceinline__ uint32_t fill_workgroups(int total_tiles)
 }
 
 template <int KMAX, bool PACKED>
-__global__ __launch_bounds__(FINE_THREADS) void fine_kernel(const FineArgs A)
+__global__ __launch_bounds__(FINE_THREADS) __attribute__((amdgpu_num_sgpr(96))) void fine_kernel(const FineArgs A)
 {
     const int total = A.N * A.g.tiles_x * A.g.tiles_y;
     const bool qmode = A.queue.list != nullptr;
