@@ -19,10 +19,13 @@ for c in cfg4 cfg5; do
 done
 python tools/fetch_large.py cfg4 > $out/fetch_cfg4.txt 2>&1
 python tools/pmc_large.py cfg4 > $out/pmc_sq_cfg4.txt 2>&1
+python tools/fine_timing.py cfg2 > $out/fine_timing_cfg2.txt 2>&1
+python tools/fine_timing.py cfg4 > $out/fine_timing_cfg4.txt 2>&1
+build_ab/valu_rate > $out/valu_rate.txt 2>&1
 python tools/band_timing.py 8 > $out/band_timing.json 2>/dev/null
 python tools/knn_timing.py > $out/knn_timing.json 2>/dev/null
 for c in cfg2 cfg3 cfg4 cfg5; do python tools/gather_split.py $c >> $out/gather_split.jsonl 2>/dev/null; done
 BENCH_DIST_BACKEND=gloo python bench.py --gpus 2 --no-cpu-baseline 2>/dev/null | grep '^{' > $out/bench_2ranks_gloo_one_gpu.json
-python tools/train_mvr_ref.py $out/ref 30 > $out/train_mvr_ref.log 2>&1
-rm -rf $out/ref/train_mvr_ref_prof $out/ref/*.pt $out/ref/*.png gpurun_out/timeline gpurun_out/pmc_sq gpurun_out/pmc_large gpurun_out/fetch_large gpurun_out/traffic
+[ -n "$COLLECT_REF_LOOP" ] && python tools/train_mvr_ref.py $out/ref 30 > $out/train_mvr_ref.log 2>&1
+rm -rf gpurun_out/libdss_hip_timing.so gpurun_out/fine_timing.npy $out/ref/train_mvr_ref_prof $out/ref/*.pt $out/ref/*.png gpurun_out/timeline gpurun_out/pmc_sq gpurun_out/pmc_large gpurun_out/fetch_large gpurun_out/traffic
 ls -la $out
