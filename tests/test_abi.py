@@ -97,10 +97,11 @@ def test_hot_kernels_do_not_spill_to_scratch():
         "knn_query_coop_kernelILi12ELb1E", "knn_query_kernelILi8ELb1E", "knn_query_kernelILi12ELb1E", "knn_query_kernelILi16ELb1E",
         "knn_scan_single_kernel", "knn_count_grid_kernel", "knn_bbox_partial_kernel", "projection_loss_kernel", "repulsion_loss_kernel",
         "mollify_normals_kernel", "image_loss_reduce_kernel", "image_loss_grad_kernel", "points_inmask_kernel"]
-    seen = {}
+    seen, sgprs, vgprs = {}, {}, {}
+    per_file = {"raster_forward.hip": ["-fno-slp-vectorize"]}   # FLAGS_raster_forward of dss_amd/csrc/Makefile
     for src in ("raster_forward.hip", "raster_backward.hip", "blend.hip", "setup.hip", "knn.hip", "regularizers.hip", "image_loss.hip"):
         out = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
-                              "-fno-fast-math", "-Rpass-analysis=kernel-resource-usage", "-c",
+                              "-fno-fast-math", *per_file.get(src, []), "-Rpass-analysis=kernel-resource-usage", "-c",
                               os.path.join(ROOT, "dss_amd", "csrc", src), "-o", os.devnull],
                              capture_output=True, text=True, timeout=600)
         assert out.returncode == 0, out.stderr[-2000:]
@@ -112,7 +113,18 @@ def test_hot_kernels_do_not_spill_to_scratch():
             m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", line)
             if m and name:
                 seen[name] = int(m.group(1))
+            m = re.search(r"TotalSGPRs: (\d+)", line)
+            if m and name:
+                sgprs[name] = int(m.group(1))
+            m = re.search(r" VGPRs: (\d+)", line)
+            if m and name:
+                vgprs[name] = int(m.group(1))
     for h in hot:
         hits = {k: v for k, v in seen.items() if h in k}
         assert hits, "kernel %s not found in the resource report" % h
         assert all(v == 0 for v in hits.values()), hits
+    # register budget of the dominant kernel: 7 wavefronts per SIMD need <= 72 VGPRs AND <= 96 SGPRs
+    # (a SIMD holds floor(800 / (SGPRs rounded up to 16, + 16)) wavefronts whatever the VGPR count allows)
+    for k in (1, 2, 3, 4, 5):
+        for name in [n for n in vgprs if "fine_kernelILi%dE" % k in n]:
+            assert vgprs[name] <= 72 and sgprs[name] <= 96, (name, vgprs[name], sgprs[name])
