@@ -735,12 +735,43 @@ __device__ __forceinline__ unsigned dpp_u32(unsigned v)
     return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
 }
 
+// Comparator networks that sort every UNIMODAL sequence -- ascending, then
+// descending -- of K keys: the minimum-size networks found by exhaustive search over the thresholded inputs 0^a 1^b 0^c
+// (0-1 principle on a class closed under monotone maps).  5 compare-exchanges at K = 5, where the odd-even transposition
+// network that sorts ANY input needs 10.
+template <int I, int J, int K>
+__device__ __forceinline__ void compare_exchange(unsigned long long (&key)[K])   // smaller key to slot I
+{
+    const bool sw = key[J] < key[I];
+    const unsigned long long ka = key[I], kb = key[J];
+    key[I] = sw ? kb : ka;
+    key[J] = sw ? ka : kb;
+}
+template <int K>
+__device__ __forceinline__ void sort_unimodal(unsigned long long (&key)[K])
+{
+    static_assert(K >= 1 && K <= 6, "networks found for K <= 6");
+    if constexpr (K == 2) {
+        compare_exchange<0, 1>(key);
+    } else if constexpr (K == 3) {
+        compare_exchange<0, 2>(key); compare_exchange<1, 2>(key);
+    } else if constexpr (K == 4) {
+        compare_exchange<0, 2>(key); compare_exchange<0, 3>(key); compare_exchange<1, 3>(key); compare_exchange<2, 3>(key);
+    } else if constexpr (K == 5) {
+        compare_exchange<0, 4>(key); compare_exchange<1, 3>(key); compare_exchange<1, 4>(key); compare_exchange<2, 4>(key);
+        compare_exchange<3, 4>(key);
+    } else if constexpr (K == 6) {
+        compare_exchange<0, 4>(key); compare_exchange<0, 5>(key); compare_exchange<1, 5>(key); compare_exchange<2, 4>(key);
+        compare_exchange<3, 5>(key); compare_exchange<2, 3>(key); compare_exchange<4, 5>(key);
+    }
+}
+
 // One merge round of the candidate slices: this lane's ascending K-list with the list of the lane CTRL maps to
 // (quad_perm within the pixel's quad: plain VALU moves, no LDS round trip like ds_bpermute / __shfl_xor).
-// Two ascending K-lists A, B -> the K smallest of their union: min(A[i], B[K-1-i]) over i picks exactly those K (as
-// a bitonic sequence), an odd-even transposition network sorts them.  K(K-1)/2 + K compare-exchanges instead of K
-// insertions of ~12K operations each.  Keys are unique across slices (disjoint candidates) except KEY_EMPTY, whose
-// payload is the same everywhere.
+// Two ascending K-lists A, B -> the K smallest of their union: min(A[i], B[K-1-i]) over i picks exactly those K, as an
+// ascending-then-descending sequence (A[i] wins while it is below B[K-1-i] and never again after); the network above
+// sorts it (K <= 6; an odd-even transposition network beyond).  Keys are unique across slices (disjoint candidates)
+// except KEY_EMPTY, whose payload is the same everywhere.
 template <int KMAX, int CTRL>
 __device__ __forceinline__ void merge_round(unsigned long long (&key)[KMAX])
 {
@@ -756,14 +787,18 @@ __device__ __forceinline__ void merge_round(unsigned long long (&key)[KMAX])
         const bool lt = okey[KMAX - 1 - k] < key[k];
         key[k] = lt ? okey[KMAX - 1 - k] : key[k];
     }
+    if constexpr (KMAX <= 6) {
+        sort_unimodal<KMAX>(key);
+    } else {
 #pragma unroll
-    for (int round = 0; round < KMAX; ++round) {
+        for (int round = 0; round < KMAX; ++round) {
 #pragma unroll
-        for (int k = round & 1; k + 1 < KMAX; k += 2) {
-            const bool sw = key[k + 1] < key[k];
-            const unsigned long long ka = key[k], kb = key[k + 1];
-            key[k] = sw ? kb : ka;
-            key[k + 1] = sw ? ka : kb;
+            for (int k = round & 1; k + 1 < KMAX; k += 2) {
+                const bool sw = key[k + 1] < key[k];
+                const unsigned long long ka = key[k], kb = key[k + 1];
+                key[k] = sw ? kb : ka;
+                key[k + 1] = sw ? ka : kb;
+            }
         }
     }
 }
