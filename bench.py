@@ -296,6 +296,27 @@ class Workload:
         t_full, _ = self._event_ms(full, iters)
         full()
         t_gather, _ = self._event_ms(gather, iters)
+        self.gather_single_ms, self.gather_batch_ms = t_gather, None
+        try:
+            # the same launch through a prebuilt ctypes call (the ops wrapper spends more host time per call than the kernel
+            # runs): 20 back-to-back launches per event pair, like the fine kernel
+            lib, P_ = _lib.load(), _lib.ptr
+            r0, r1, cyc = ops._band(p.rows, S)
+            ws = _lib.workspace(self.dev, lib.dss_render_backward_workspace(self.N, self.P, S))   # the buffer `full` filled
+            vis8 = f["visible"].view(torch.uint8)
+            gargs = (P_(g), P_(f["idx"]), P_(f["qvalue"]), P_(f["wsum"]), P_(f["scaler"]), P_(f["pts_screen"]),
+                     P_(f["radii"]), P_(vis8), P_(self.first), P_(self.num), self.N, self.P, S, K, 3, r0, r1, cyc,
+                     float(RADII_S), float(CLIP), P_(gf), P_(gp), P_(rs0), None, None, P_(ws), ws.numel(),
+                     _lib.stream_ptr(self.dev))
+            fast = lambda: lib.dss_render_backward_gather(*gargs)
+            full()
+            _lib.check(fast(), "dss_render_backward_gather")
+            self.gather_batch_ms = self._batch_ms(fast)
+            self._keep_gather = (g, f, gf, gp, rs0, ws, vis8)
+            if 0.5 * t_gather < self.gather_batch_ms < t_gather:   # (a batch that is implausibly short did not run the kernel)
+                t_gather = self.gather_batch_ms
+        except Exception:  # noqa: BLE001  (keep the per-launch figure)
+            torch.cuda.synchronize()
         t_prep = max(t_full - t_gather, 0.0)
         # (pixel, point) pairs the rule has to evaluate: pixel centres within rs of a visible, on-screen point
         rs = rs0
@@ -681,8 +702,10 @@ def main():
             "frac_valu": round(valu_ach / VALU_PEAK, 5), "frac_hbm": round(bwd_hbm / HBM_PEAK_GBS, 5),
             "algorithmic_bytes": bwd_alg_bytes, "achieved_hbm_GBps": round(bwd_hbm, 2),
             "pairs": pairs, "min_ops_per_pair": MIN_OPS, "visible_points": n_vis, "kernel_ms_mean": round(gather_ms, 5),
-            "how": "HIP events around dss_render_backward_gather alone, one pair per launch (the pair adds 3-4 us to what "
-                   "rocprofv3 reports for the kernel) (second stage of dss_render_backward: %.5f ms for "
+            "kernel_ms_single_events": round(wl.gather_single_ms, 5),
+            "kernel_ms_batch_of_20": None if wl.gather_batch_ms is None else round(wl.gather_batch_ms, 5),
+            "how": "HIP events around dss_render_backward_gather alone: the smaller of one pair per launch (mean of 50) and "
+                   "one pair around 20 back-to-back launches / 20 (a pair adds 3-4 us to a 20 us kernel) (second stage of dss_render_backward: %.5f ms for "
                    "all three launches, i.e. %.5f ms of compaction + median)" % (bwd_ms, prep_ms),
             "traffic": gather_traffic,
             "traffic_source": traffic_src if gather_traffic is not None else None}
