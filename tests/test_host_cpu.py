@@ -221,3 +221,40 @@ def test_spatial_order_is_a_permutation_that_groups_neighbours():
     assert spatial_order(torch.zeros(0, 3)).numel() == 0 and spatial_order(torch.ones(7, 3)).tolist() == list(range(7))
     with pytest.raises(ValueError):
         spatial_order(torch.zeros(4, 2))
+
+
+def test_merge_networks_of_the_fine_kernel_sort_every_unimodal_sequence():
+    """The slice merge of raster_forward.hip (merge_round / sort_unimodal) replaces a general sorting network by smaller
+    ones that only sort ascending-then-descending inputs: read the compare-exchange sequences out of the source and check
+    them (a) on every thresholded unimodal input 0^a 1^b 0^c (0-1 principle on a class closed under monotone maps) and (b)
+    as the merge they implement: min(A[i], B[K-1-i]) of two ascending lists with ties -> the K smallest of the union."""
+    import os
+    import random
+    import re
+
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dss_amd", "csrc",
+                            "raster_forward.hip")).read()
+    body = src[src.index("void sort_unimodal("):]
+    body = body[:body.index("\n}\n")]
+    nets = {}
+    for m in re.finditer(r"K == (\d+)\) \{(.*?)\}", body, re.S):
+        nets[int(m.group(1))] = [(int(i), int(j)) for i, j in re.findall(r"compare_exchange<(\d+), (\d+)>", m.group(2))]
+    assert sorted(nets) == [2, 3, 4, 5, 6] and len(nets[5]) == 5
+
+    def run(net, s):
+        s = list(s)
+        for i, j in net:
+            assert i < j
+            if s[i] > s[j]:
+                s[i], s[j] = s[j], s[i]
+        return s
+
+    rng = random.Random(0)
+    for n, net in nets.items():
+        for a in range(n + 1):
+            for b in range(n + 1 - a):
+                s = [0] * a + [1] * b + [0] * (n - a - b)
+                assert run(net, s) == sorted(s), (n, s)
+        for _ in range(5000):
+            x, y = sorted(rng.choices(range(9), k=n)), sorted(rng.choices(range(9), k=n))
+            assert run(net, [min(x[k], y[n - 1 - k]) for k in range(n)]) == sorted(x + y)[:n]
