@@ -237,3 +237,19 @@ def test_band_image_loss_gloo_world2(tmp_path):
     port = 29850 + (os.getpid() % 100)
     mp.spawn(_band_loss_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert (tmp_path / "band_ok0").exists() and (tmp_path / "band_ok1").exists()
+
+
+@pytest.mark.parametrize("world,S", [(4, 40), (4, 70), (8, 72)])
+def test_row_partition_gloo_larger_worlds(tmp_path, world, S):
+    """The same exchange steps at world sizes 4 and 8 (the first 8-GPU run should not be the first time a partition with
+    more than two ranks is exercised): S = 40 / 70 leave ranks with one, two or three tile rows and a short last tile
+    row, S = 72 at 8 ranks gives rank 0 two tile rows and every other rank one."""
+    port = 29900 + (os.getpid() % 150) + S + world
+    mp.spawn(_worker, args=(world, port, S, str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / ("ok%d" % r)).exists() for r in range(world))
+
+
+def test_band_image_loss_gloo_world4(tmp_path):
+    port = 29750 + (os.getpid() % 90)
+    mp.spawn(_band_loss_worker, args=(4, port, str(tmp_path)), nprocs=4, join=True)
+    assert all((tmp_path / ("band_ok%d" % r)).exists() for r in range(4))
