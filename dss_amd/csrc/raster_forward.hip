@@ -911,12 +911,12 @@ __device__ __forceinline__ void fill_tiles(const FineArgs &A, int t0, unsigned e
     }
 }
 
-// The kernel's (only) argument, re-read from the kernarg segment.  `entry` is the by-value parameter: same bytes.
-__device__ __forceinline__ const FineArgs &reloaded_args(const FineArgs &entry)
+// The fine kernel's (only) by-value argument, re-read from the kernarg segment (offset 0): same bytes as the parameter,
+// but loaded where they are used instead of living in SGPRs from the kernel's entry on.
+__device__ __forceinline__ const FineArgs &reloaded_args()
 {
     auto kp = (const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(kp));
-    (void)entry;
     return *(const FineArgs *)(const char *)kp;
 }
 
@@ -1190,7 +1190,7 @@ __device__ __forceinline__ void fine_tile(const FineArgs &A_entry, const int til
     // Everything below reads the kernel arguments again from the kernarg segment (scalar loads through a laundered
     // pointer) instead of keeping the ~25 output / blend pointers in SGPRs through the candidate loop: with them the kernel
     // needed 106 SGPRs (+16 spilled to VGPR lanes), which caps a SIMD at 6 wavefronts whatever the VGPR count says.
-    const FineArgs &E = reloaded_args(A_entry);
+    const FineArgs &E = reloaded_args();
     {
         // DSS_WS_CLEAN: this workgroup is the only reader of the tile's counters and of its queue slot, and every thread has
         // read them by now (at least one barrier ago).  Done here, not inside the chunk loop: the three store addresses
