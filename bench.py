@@ -46,10 +46,36 @@ def bunny_cloud():
     return pts, nrm, col, None  # h (variance scale) is computed on the GPU by the HIP kNN in Workload
 
 
+# --workload: the other two BASELINE configs that name multi-GPU row sharding (points per cloud, image side, cameras);
+# the camera count is FIXED there (strong scaling: N ranks share the rows of the same job), unlike the headline workload
+LARGE_WORKLOADS = {"cfg4": (1_000_000, 1024, 8), "cfg5": (4_000_000, 2048, 1), "cfg3": (99_790, 512, 8)}
+
+
+def large_cloud(which, morton=False):
+    """BASELINE configs[3] / configs[4] (and the size of configs[2]): the synthetic generator of SURVEY 8(d)
+    (tests/scenes.py::synthetic_cloud), randomly ordered, with a density-scaled variance scale h (kNN-7 statistic of a
+    200k-point subsample scaled by the density ratio: the reference's clamp [5e-5, 1e-3] would turn a 4M-point cloud
+    into 20-pixel splats).  -> (points, normals, colours, h), S, cameras"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import scenes
+    P, S_, N = LARGE_WORKLOADS[which]
+    pts, nrm, col = scenes.synthetic_cloud(P, seed=0)
+    h = scenes.global_h(pts[:: max(1, P // 200_000)]) * (200_000 / P if P > 200_000 else 1.0)
+    h = float(np.clip(h, 5e-6, 1e-3))
+    if morton:
+        from dss_amd.cloud import spatial_order
+        order = spatial_order(torch.from_numpy(pts)).numpy()
+        pts, nrm, col = pts[order].copy(), nrm[order].copy(), col[order].copy()
+    return (pts, nrm, col, h), S_, N
+
+
 class Workload:
-    def __init__(self, device, n_cams, part: RowPartition, cloud=None):
+    def __init__(self, device, n_cams, part: RowPartition, cloud=None, multi=None):
         pts, nrm, col, h = bunny_cloud() if cloud is None else cloud
         self.dev, self.N, self.part = device, n_cams, part
+        # multi: take the multi-GPU path (send buffers, three collectives, gradient bucket); forced at world size 1 by
+        # BENCH_FORCE_DIST=1 so that a one-GPU box executes the RCCL code path
+        self.multi = part.world_size > 1 if multi is None else bool(multi)
         S = part.S  # image side (module constant S for the benchmark; tools/bench_large.py passes others)
         self.Pc = pts.shape[0]
         self.P = self.N * self.Pc
@@ -75,10 +101,10 @@ class Workload:
         g = torch.Generator(device="cpu").manual_seed(1)
         self.grad_out = torch.randn((self.N, S, S, 4), generator=g).to(device)  # d loss / d RGBA
         self.S = S
-        if part.world_size > 1:
+        if self.multi:
             # multi-GPU: the forward kernel writes its RGBA band and visibility flags straight into the
             # all-gather send buffers; the backward writes both gradients into one all-reduce bucket
-            self.fx = OverlappedExchange(part, self.N, 4, self.P, device)
+            self.fx = OverlappedExchange(part, self.N, 4, self.P, device, force=self.multi)
             self.bucket = torch.empty(self.P * 6, device=device)
 
     def step(self, ev=None):
@@ -91,7 +117,7 @@ class Workload:
                 ev.append((label, e))
         p = self.part
         S = self.S
-        multi = p.world_size > 1
+        multi = self.multi
         mark("start")
         # fused forward: [setup + binning] -> [fine + blend]
         f = ops.render_forward(self.world, self.normals, self.h, self.M, self.V, self.znear, self.zfar, self.first,
@@ -341,10 +367,13 @@ class Workload:
         return t_gather, t_full, t_prep, pairs, int(vis.sum().item())
 
 
-def api_path_ms(wl, n=60):
+def api_path_ms(wl, n=60, graphed=False):
     """The same workload through the drop-in API a train_mvr.py user calls (DSS/core/renderer.py:36-82):
     `SurfaceSplattingRenderer(SurfaceSplatting(...), NormWeightedCompositor(), fused=True)(cloud)` + `.backward()`,
-    eager, autograd and Python object handling included; h precomputed like the headline. -> ms per fwd+bwd"""
+    eager, autograd and Python object handling included; h precomputed like the headline. -> ms per fwd+bwd
+    (`graphed`: the renderer's graphed mode -- forward and backward replayed as two hipGraphs over static buffers; None if
+    this build of the renderer has no such mode)"""
+    import inspect
     from dss_amd.cloud import PointClouds3D
     from dss_amd.rasterizer import PointsRasterizationSettings, SurfaceSplatting
     from dss_amd.renderer import NormWeightedCompositor, SurfaceSplattingRenderer
@@ -355,8 +384,13 @@ def api_path_ms(wl, n=60):
                                      Vrk_invariant=True, Vrk_isotropic=False, radii_backward_scaler=RADII_S,
                                      image_size=wl.S, points_per_pixel=K, bin_size=None, clip_pts_grad=CLIP,
                                      antialiasing_sigma=SIGMA)
+    kw = {}
+    if graphed:
+        if "graphed" not in inspect.signature(SurfaceSplattingRenderer.__init__).parameters:
+            return None
+        kw["graphed"] = True
     renderer = SurfaceSplattingRenderer(SurfaceSplatting(cameras=cams, raster_settings=st), NormWeightedCompositor(),
-                                        fused=True)
+                                        fused=True, **kw)
     X = torch.nn.Parameter(wl.world.clone())
     C = torch.nn.Parameter(wl.colors[:wl.Pc].clone())
     h = wl.h[:1].clone()
@@ -444,14 +478,26 @@ def self_launch(n_gpus: int) -> int:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--mode", choices=["graph", "eager"], default=None,
                     help="graph: replay the captured step as a hipGraph (default on 1 GPU); eager: plain launches")
+    ap.add_argument("--workload", choices=["cfg2", "cfg4", "cfg5"], default="cfg2",
+                    help="cfg2 (default, the metric's configuration): BASELINE configs[1], one camera per rank (weak scaling). "
+                         "cfg4 / cfg5: BASELINE configs[3] (1M points x 8 cameras @1024^2) / configs[4] (4M points @2048^2), "
+                         "image rows sharded over the ranks (strong scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--timed-only", action="store_true",
+                    help="profiler passes: run warm-up + the timed region only (no per-kernel event timing, no API / kNN legs), "
+                         "print a short JSON line")
     ap.add_argument("--no-traffic", action="store_true",
                     help="do not spawn the two rocprofv3 counter passes (roofline.traffic then quotes the committed measurement)")
     args = ap.parse_args()
+    large = args.workload != "cfg2"
+    if args.steps is None:
+        args.steps = 20 if large else 200
+    if args.warmup is None:
+        args.warmup = 5 if large else 20
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # plain `python bench.py --gpus N`: become the launcher (one rank per GPU under torch.distributed.run, the same
@@ -468,29 +514,46 @@ def main():
     local = local % torch.cuda.device_count()  # (BENCH_DIST_BACKEND=gloo lets two ranks share one GPU in tests)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    # BENCH_FORCE_DIST=1: take the multi-GPU code path -- process group (RCCL), second communicator, asynchronous image
+    # all-gather, visibility all-gather, bucketed gradient all-reduce, graph segments beside the watchdog -- at ANY world
+    # size, world size 1 included: a one-GPU box then executes every line a first 8-GPU run would
+    force_dist = os.environ.get("BENCH_FORCE_DIST") == "1"
+    multi = world > 1 or force_dist
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:   # (no launcher: forced world of one)
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
         if rank == 0:
-            print("bench.py: world %d, backend %s, %d visible device(s), torch %s, HSA_ENABLE_IPC_MODE_LEGACY=%s"
+            print("bench.py: world %d, backend %s, %d visible device(s), torch %s, HSA_ENABLE_IPC_MODE_LEGACY=%s%s"
                   % (world, backend, torch.cuda.device_count(), torch.__version__,
-                     os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")), file=sys.stderr, flush=True)
+                     os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"), " (BENCH_FORCE_DIST)" if force_dist else ""),
+                  file=sys.stderr, flush=True)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
 
     def barrier():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
+    # workload: cfg2 = one 32,684-point camera per rank at 512^2; cfg4 / cfg5 = a fixed job whose rows are shared
+    cloud, S, cams = None, globals()["S"], world
+    if large:
+        cloud, S, cams = large_cloud(args.workload)
     # multi-GPU: tile-row-cyclic bands (rank g renders the 8-row tile rows g, g + G, ...: balanced for any scene, equal-size
     # all-gather) whenever the sizes allow it; BENCH_ROW_PARTITION=bands selects the contiguous equal bands of rounds 1-2
     cyclic = world > 1 and world & (world - 1) == 0 and S % (8 * world) == 0 and \
         os.environ.get("BENCH_ROW_PARTITION", "cyclic") == "cyclic"
     part = RowPartition(S, world, rank, cyclic=cyclic)
-    wl = Workload(dev, world, part)
+    wl = Workload(dev, cams, part, cloud=cloud, multi=multi)
 
     def capture(unroll=1):
         side = torch.cuda.Stream()
@@ -526,9 +589,9 @@ def main():
     UNROLL = 10
     graph, graph_u, ms_modes = None, None, {}
     unrollable = args.steps % UNROLL == 0 and args.steps >= UNROLL
-    mode = args.mode or ("eager" if world > 1 else None)
+    mode = args.mode or ("eager" if multi else None)
     seg_note = None
-    if world > 1 and args.mode != "eager":
+    if multi and args.mode != "eager":
         # multi-GPU: the RCCL calls stay outside any graph, the compute segments between them are graphs
         try:
             barrier()   # (no collective in flight while capturing)
@@ -539,8 +602,8 @@ def main():
             mode = "eager"
     if mode is None:
         graph = capture()
-        ms_modes = {"eager": quick(wl.step), "graph": quick(graph.replay)}
-        if unrollable:
+        ms_modes = {"eager": quick(wl.step, n=8 if large else 40), "graph": quick(graph.replay, n=8 if large else 40)}
+        if unrollable and not large:
             graph_u = capture(UNROLL)
             ms_modes["graph_x%d" % UNROLL] = quick(graph_u.replay, n=8) / UNROLL
         mode = min(ms_modes, key=ms_modes.get)
@@ -561,7 +624,7 @@ def main():
             run()
         barrier()
         dt = time.perf_counter() - t0
-        if world > 1:
+        if multi:
             tt = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
@@ -579,11 +642,20 @@ def main():
     splats = wl.P  # cameras * points per cloud submitted per step (whole job)
     value = splats / (ms_step * 1e-3) / 1e6
 
+    if args.timed_only:
+        if rank == 0:
+            print(json.dumps({"metric": "Msplats/s fwd+bwd @%d^2" % S, "value": round(value, 3), "ms_per_step": round(ms_step, 5),
+                              "launch": mode, "timed_only": True}))
+        if multi:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
     # second reported figure (single GPU): the same step with the variance-scale statistic h recomputed inside it -- the
     # kNN-7 of rasterizer.py:310-326, which the reference reruns every iteration (refresh=True default, :293, :344).  The
     # headline `value` takes h as an input of the step (SURVEY section 8 files the kNN under "next"); both are reported.
     value_knn = ms_knn = knn_mode = None
-    if world == 1:
+    if not multi and not large:
         one = torch.zeros(1, dtype=torch.int64, device=dev)
         cnt = torch.full((1,), wl.Pc, dtype=torch.int64, device=dev)
 
@@ -621,10 +693,11 @@ def main():
             except Exception as e:  # noqa: BLE001  (capture refused: keep the eager figure)
                 knn_mode = "eager (graph capture failed: %s)" % type(e).__name__
         value_knn = splats / (ms_knn * 1e-3) / 1e6
-    ms_api = api_path_ms(wl) if world == 1 else None
+    ms_api = api_path_ms(wl) if (not multi and not large) else None
+    ms_api_graphed = api_path_ms(wl, graphed=True) if (not multi and not large) else None
 
     dist_block = {"world_size": 1, "backend": None}
-    if world > 1:
+    if multi:
         # diagnosable multi-GPU line: per-rank compute min / max, time in each collective, the
         # communicator set-up that was actually used, library versions
         tm = wl.dist_timing()
@@ -638,7 +711,8 @@ def main():
             nccl_v = ".".join(str(x) for x in torch.cuda.nccl.version())
         except Exception:  # noqa: BLE001
             pass
-        dist_block = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "rccl_version": nccl_v,
+        dist_block = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "forced": force_dist,
+                      "rccl_version": nccl_v,
                       "visible_devices": torch.cuda.device_count(), "partition": part.describe(),
                       "overlap": bool(wl.fx.overlap), "degraded": wl.fx.degraded, "segment_capture": seg_note or "ok",
                       "timing_us": {k: {"min": round(float(allt[:, i].min()), 1), "max": round(float(allt[:, i].max()), 1),
@@ -647,20 +721,22 @@ def main():
                                     "min / max / mean over the ranks"}
 
     # ---- roofline of the dominant kernel, picked from a per-kernel event-timing pass --------------------------------
-    fine_mean, fine_med = wl.fine_kernel_ms()
-    gather_ms, bwd_ms, prep_ms, pairs, n_vis = wl.backward_gather_ms()
+    kit = 10 if large else 50
+    fine_mean, fine_med = wl.fine_kernel_ms(iters=kit)
+    gather_ms, bwd_ms, prep_ms, pairs, n_vis = wl.backward_gather_ms(iters=kit)
     r0, r1 = 0, part.n_rows
     # HBM: algorithmic bytes of ONE fine-kernel launch: every pixel of the band writes idx+zbuf+qvalue
     # (12K B) + occ (4 B) + RGBA (16 B) + wsum (4 B); every splat's screen record (pos 12, ellipse 12, radii 8, cutoff 4) +
     # scaler (4) + colour (12) = 52 B is read once.
     alg_bytes = wl.N * (r1 - r0) * S * (12 * K + 4 + 16 + 4) + wl.P * 52
     achieved = alg_bytes / (fine_mean * 1e-3) / 1e9
-    traffic, traffic_src, gather_traffic = None, None, None
+    traffic, traffic_src, gather_traffic, prof_ms = None, None, None, {}
     tfile = os.path.join(ROOT, "profiles", "traffic_fine_kernel.json")
-    if world == 1 and rank == 0 and not args.no_traffic:
+    if not multi and not large and rank == 0 and not args.no_traffic:
         # HBM bytes per launch are PMC counters: they cannot be read in-process.  tools/collect_traffic.py runs this very
         # command (eager, 20 steps, --no-traffic) twice under `rocprofv3 --kernel-trace --pmc` (FETCH_SIZE and WRITE_SIZE in
         # separate passes, no other trace domain) and averages them over the fine_kernel dispatches: measured in THIS run.
+        # The same two passes carry the kernel trace, i.e. the rocprofv3 average duration of both roofline kernels.
         import shutil
         import subprocess
         if shutil.which("rocprofv3"):
@@ -670,55 +746,78 @@ def main():
                 tj = json.loads(r.stdout.strip().splitlines()[-1])
                 traffic = int(tj["traffic_bytes_per_launch"])
                 gather_traffic = tj.get("render_backward_kernel_traffic_bytes_per_launch")
+                prof_ms = tj.get("rocprof_kernel_ms") or {}
                 traffic_src = ("measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes over the "
                                "same step, FETCH x2 (gfx950), %d + %d fine_kernel dispatches" % tuple(tj["samples"]))
             except Exception as e:  # noqa: BLE001  (no profiler on the box, counters unavailable, timeout)
                 traffic_src = "live measurement failed (%s); " % type(e).__name__
-    if traffic is None and world == 1 and os.path.exists(tfile):
+    if traffic is None and not multi and not large and os.path.exists(tfile):
         tj = json.load(open(tfile))
         traffic = tj.get("traffic_bytes_per_launch")
         traffic_src = (traffic_src or "") + "profiles/traffic_fine_kernel.json (%s)" % tj.get("round", "r1")
+    # the fractions are computed from the rocprofv3 average of the kernel whenever this run measured it
+    # (`kernel_ms_rocprofv3`); the event timings stay in the line beside it
+    fine_prof = prof_ms.get("fine_kernel")
+    fine_t = fine_prof if fine_prof else fine_mean
+    achieved = alg_bytes / (fine_t * 1e-3) / 1e9
     hbm = {"bound": "hbm", "kernel": "fine_kernel<5> (fine pass + fused blend)", "achieved": round(achieved, 2),
            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
            "frac_hbm": round(achieved / HBM_PEAK_GBS, 5), "frac_valu": None, "traffic": traffic,
-           "traffic_source": traffic_src, "algorithmic_bytes": alg_bytes, "kernel_ms_mean": round(fine_mean, 5),
+           "traffic_source": traffic_src, "algorithmic_bytes": alg_bytes,
+           "kernel_ms_rocprofv3": None if fine_prof is None else round(fine_prof, 5),
+           "kernel_ms_mean": round(fine_mean, 5),
            "kernel_ms_median": round(fine_med, 5), "kernel_ms_single_events": round(wl.fine_single_ms, 5),
            "kernel_ms_batch_of_20": round(wl.fine_batch_ms, 5),
-           "how": "HIP events on the launch stream: the smaller of (a) one event pair per launch, mean of 50, and (b) one "
-                  "event pair around 20 back-to-back launches, / 20 (the event pair itself costs 3-4 us on a 17 us kernel; "
-                  "profiles/ holds the rocprofv3 average of the same kernel)"}
+           "frac_from": "kernel_ms_rocprofv3" if fine_prof else "kernel_ms_mean",
+           "how": "achieved / frac use the rocprofv3 --kernel-trace average of the kernel measured in this run when available "
+                  "(kernel_ms_rocprofv3), else HIP events on the launch stream: the smaller of (a) one event pair per launch, "
+                  "mean of 50, and (b) one event pair around 20 back-to-back launches, / 20 (the event pair itself costs "
+                  "3-4 us on a 17 us kernel)"}
     # VALU: the backward gather evaluates the occupancy rule of rasterize_points_backward.cu:141-178 for every (pixel,
     # visible point) pair inside the search radius: dx, dy, d2 (fma), two range compares, the g>0 / bbox skip (3), max,
     # rcp, the product with g and two accumulating fmas = MIN_OPS lane operations.  Peak = 256 CUs x 4 SIMDs x 32 lanes x
     # 2.4 GHz lane operations per second (= the 157.3 TFLOP/s fp32 vector peak of MI355X_MICROARCH.md with an FMA as two).
     MIN_OPS, VALU_PEAK = 12, 256 * 4 * 32 * 2.4e9 / 1e12
-    valu_ach = pairs * MIN_OPS / (gather_ms * 1e-3) / 1e12 if gather_ms > 0 else 0.0
+    gather_prof = prof_ms.get("render_backward_kernel")
+    gather_t = gather_prof if gather_prof else gather_ms
+    valu_ach = pairs * MIN_OPS / (gather_t * 1e-3) / 1e12 if gather_t > 0 else 0.0
     # the same kernel read against HBM with SURVEY 8(d)'s backward bytes: N S^2 (16 + 4 + 12K) [grad RGBA, grad_occ,
     # fragments re-read] + N P (48 + 24) [record re-read, gradients written]
     bwd_alg_bytes = wl.N * (r1 - r0) * S * (16 + 4 + 12 * K) + wl.P * 72
-    bwd_hbm = bwd_alg_bytes / (gather_ms * 1e-3) / 1e9 if gather_ms > 0 else 0.0
+    bwd_hbm = bwd_alg_bytes / (gather_t * 1e-3) / 1e9 if gather_t > 0 else 0.0
     valu = {"bound": "valu", "kernel": "render_backward_kernel<3> (blend backward + occupancy surrogate per visible point)",
             "achieved": round(valu_ach, 4), "peak": round(VALU_PEAK, 2), "unit": "Tlaneop/s", "frac": round(valu_ach / VALU_PEAK, 5),
             "frac_valu": round(valu_ach / VALU_PEAK, 5), "frac_hbm": round(bwd_hbm / HBM_PEAK_GBS, 5),
             "algorithmic_bytes": bwd_alg_bytes, "achieved_hbm_GBps": round(bwd_hbm, 2),
-            "pairs": pairs, "min_ops_per_pair": MIN_OPS, "visible_points": n_vis, "kernel_ms_mean": round(gather_ms, 5),
+            "pairs": pairs, "min_ops_per_pair": MIN_OPS, "visible_points": n_vis,
+            "kernel_ms_rocprofv3": None if gather_prof is None else round(gather_prof, 5),
+            "kernel_ms_mean": round(gather_ms, 5),
             "kernel_ms_single_events": round(wl.gather_single_ms, 5),
             "kernel_ms_batch_of_20": None if wl.gather_batch_ms is None else round(wl.gather_batch_ms, 5),
-            "how": "HIP events around dss_render_backward_gather alone: the smaller of one pair per launch (mean of 50) and "
-                   "one pair around 20 back-to-back launches / 20 (a pair adds 3-4 us to a 20 us kernel) (second stage of dss_render_backward: %.5f ms for "
-                   "all three launches, i.e. %.5f ms of compaction + median)" % (bwd_ms, prep_ms),
+            "frac_from": "kernel_ms_rocprofv3" if gather_prof else "kernel_ms_mean",
+            "how": "fractions from the rocprofv3 average of the kernel in the step when this run measured it, else HIP events "
+                   "around dss_render_backward_gather alone: the smaller of one pair per launch (mean of 50) and "
+                   "one pair around 20 back-to-back launches / 20 (a pair adds 3-4 us to a 20 us kernel) (whole "
+                   "dss_render_backward: %.5f ms, i.e. %.5f ms outside the gather stage)" % (bwd_ms, prep_ms),
             "traffic": gather_traffic,
             "traffic_source": traffic_src if gather_traffic is not None else None}
-    dominant, other = (valu, hbm) if gather_ms > fine_mean else (hbm, valu)
+    dominant, other = (valu, hbm) if gather_t > fine_t else (hbm, valu)
     if rank == 0:
+        if large:
+            wtxt = ("BASELINE configs[%d]: synthetic %d-point cloud, %d camera(s), %dx%d, K=5, fwd+bwd, image rows sharded "
+                    "over %d rank(s), randomly ordered points, density-scaled h" % (3 if args.workload == "cfg4" else 4,
+                                                                                   wl.Pc, wl.N, S, S, world))
+        else:
+            wtxt = ("BASELINE configs[1]: bunny-8000 x4 jitter = %d pts/cloud, %d camera(s), "
+                    "512x512, K=5, fwd+bwd (setup+raster+blend and their backward), "
+                    "grad_out=randn(seed 1), variance scale h precomputed (kNN-7 outside the step; "
+                    "see value_with_knn)" % (wl.Pc, wl.N))
         rec = {
-            "metric": "Msplats/s fwd+bwd @512^2", "value": round(value, 3), "unit": "Msplats/s",
+            "metric": "Msplats/s fwd+bwd @%d^2" % S, "value": round(value, 3), "unit": "Msplats/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 5),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: bunny-8000 x4 jitter = %d pts/cloud, %d camera(s), "
-                                   "512x512, K=5, fwd+bwd (setup+raster+blend and their backward), "
-                                   "grad_out=randn(seed 1), variance scale h precomputed (kNN-7 outside the step; "
-                                   "see value_with_knn)" % (wl.Pc, wl.N),
+            "higher_is_better": True, "scaling": "strong" if large else "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": wtxt,
                        "points_per_cloud": wl.Pc, "cameras": wl.N, "image_size": S, "points_per_pixel": K,
                        "h_precomputed": True, "parallelism": "rows%d" % world, "launch": mode,
                        "steps_per_graph_launch": steps_per_launch,
@@ -737,12 +836,15 @@ def main():
             rec["value_via_api"] = round(splats / (ms_api * 1e-3) / 1e6, 3)
             rec["ms_per_step_via_api"] = round(ms_api, 5)
             rec["via_api"] = "SurfaceSplattingRenderer(fused=True)(cloud) + .backward(), eager, autograd included, h precomputed"
+        if ms_api_graphed is not None:
+            rec["value_via_api_graphed"] = round(splats / (ms_api_graphed * 1e-3) / 1e6, 3)
+            rec["ms_per_step_via_api_graphed"] = round(ms_api_graphed, 5)
         for k, v in ms_modes.items():
             rec["config"]["calibration_ms_per_step_" + k] = round(v, 5)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and not large and not force_dist:
             rec["cpu_baseline"] = cpu_baseline()
         print(json.dumps(rec))
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -231,7 +231,9 @@ class OverlappedExchange:
     (``ops.render_forward(out_image=...)`` takes camera / row strides)."""
 
     def __init__(self, part: RowPartition, n_images: int, channels: int, num_points: int, device, group=None,
-                 image_group=None):
+                 image_group=None, force: bool = False):
+        # force: build the second communicator and issue every collective even in a world of ONE rank (a one-GPU box
+        # then executes the RCCL code path line for line: bench.py BENCH_FORCE_DIST=1)
         self.part, self.group = part, group
         self.image_group = image_group
         # `overlap`: the image bands travel on their own communicator, asynchronously.  If the second communicator cannot
@@ -239,7 +241,7 @@ class OverlappedExchange:
         # blocking all-gather -- slower, same result -- and says so (`overlap` False, `degraded` holds the reason): the
         # first multi-GPU run of a deployment must produce a diagnosable number rather than a stack trace.
         self.overlap, self.degraded = True, None
-        if image_group is None and part.world_size > 1 and dist.is_initialized():
+        if image_group is None and (part.world_size > 1 or force) and dist.is_initialized():
             try:
                 self.image_group = dist.new_group()  # collective: every rank constructs its exchange
             except Exception as e:  # noqa: BLE001  (RCCL refused a second communicator)

@@ -398,6 +398,11 @@ def blend_backward(grad_out, idx, qvalue, scaler, num_points: int, geometry=None
     return gf, grad_out[..., C]
 
 
+def backward_addr64() -> int:
+    """current value of DSS_OPT_BACKWARD_ADDR64 (1 forces the 64-bit gather, which has no fused projection)"""
+    return int(_lib.load().dss_get_option(_lib.OPT_BACKWARD_ADDR64))
+
+
 def _band(rows, S):
     """`rows` of the fused entry points: None = whole image; (row0, row1) = contiguous band; (row0, row1, c) = of that
     band only every c-th 8-row tile row starting at row0 (tile-row-cyclic multi-GPU partition, include/dss_hip.h)."""
@@ -969,13 +974,31 @@ def points_inmask(points, M, mask_img, visible=None):
     return out.view(torch.bool)   # the kernel writes 0 / 1
 
 
+_band_row_cache = {}
+
+
+def _band_row_index(row0, row1, cyc, device):
+    """image rows of the tile-row-cyclic band (row0, row1, cyc), in band order, as a cached int64 device tensor"""
+    key = (row0, row1, cyc, device)
+    t = _band_row_cache.get(key)
+    if t is None:
+        if len(_band_row_cache) > 64:
+            _band_row_cache.clear()
+        rows = [r0 + i for r0 in range(row0, row1, 8 * cyc) for i in range(8) if r0 + i < row1]
+        t = _band_row_cache[key] = torch.tensor(rows, dtype=_i64, device=device)
+    return t
+
+
 def _band_args(rgba_band, target_rgb, target_mask, rows):
-    """Row band [row0, row1) of an image loss: the band render (N,rows,W,4) against the FULL targets (N,H,W,3) /
-    (N,H,W); returns the tensors plus the pointers / strides of the targets' band."""
+    """Row band of an image loss: the band render (N,rows,W,4) against the FULL targets (N,H,W,3) / (N,H,W); returns the
+    tensors plus the targets' band and the image stride of its mask.  ``rows`` = (row0, row1) for a contiguous band (views of
+    the targets, no copy) or (row0, row1, cycle) for a tile-row-cyclic one (`RowPartition(cyclic=True).rows`: the owned
+    rows of the targets are gathered once per call)."""
     rgba_band = _lib.require_gpu(rgba_band, "rgba_band", _f32)
-    row0, row1 = int(rows[0]), int(rows[1])
-    if rgba_band.dim() != 4 or rgba_band.shape[-1] != 4 or rgba_band.shape[1] != row1 - row0:
-        raise RuntimeError("dss_amd: rgba_band must be (N, row1-row0, W, 4), got %s for rows %s" % (tuple(rgba_band.shape), (row0, row1)))
+    row0, row1, cyc = _band(rows, None) if rows is not None and len(rows) > 2 else (int(rows[0]), int(rows[1]), 1)
+    want = band_rows(row0, row1, cyc)
+    if rgba_band.dim() != 4 or rgba_band.shape[-1] != 4 or rgba_band.shape[1] != want:
+        raise RuntimeError("dss_amd: rgba_band must be (N, %d, W, 4) for rows %s, got %s" % (want, tuple(rows), tuple(rgba_band.shape)))
     N, nr, W, _ = rgba_band.shape
     if not isinstance(target_rgb, torch.Tensor) or not target_rgb.is_cuda or target_rgb.dtype != _f32:
         raise RuntimeError("dss_amd: target_rgb must be a float32 GPU tensor (no CPU fallback)")
@@ -983,16 +1006,21 @@ def _band_args(rgba_band, target_rgb, target_mask, rows):
     if target_rgb.dim() != 4 or tuple(target_rgb.shape) != (N, H, W, 3) or not (0 <= row0 <= row1 <= H):
         raise RuntimeError("dss_amd: target_rgb must be the full (N,H,W,3) target with 0 <= row0 <= row1 <= H")
     target_mask = _lib.require_gpu(target_mask, "target_mask", _f32).reshape(N, H, W)
+    if cyc > 1:
+        ri = _band_row_index(row0, row1, cyc, rgba_band.device)
+        band_rgb = target_rgb.index_select(1, ri)
+        band_mask = target_mask.index_select(1, ri)
+        return rgba_band, band_rgb, band_mask, target_mask, N, nr, W, H, nr * W
     band_rgb = target_rgb[:, row0:row1]
     band_mask = target_mask[:, row0:row1]
-    return rgba_band, band_rgb, band_mask, target_mask, N, nr, W, H
+    return rgba_band, band_rgb, band_mask, target_mask, N, nr, W, H, H * W
 
 
 def image_loss_band_sums(rgba_band, target_rgb, target_mask, rows):
     """Per-image sums of ``Trainer.calc_dr_loss`` over the row band ``rows = (row0, row1)`` -> float64 (N+1,5) whose
     first N rows are filled; all-reduce (SUM) ``sums[:N]`` over the ranks, then :func:`image_loss_from_sums`."""
     lib = _lib.load()
-    rgba_band, band_rgb, band_mask, _keep, N, nr, W, H = _band_args(rgba_band, target_rgb, target_mask, rows)
+    rgba_band, band_rgb, band_mask, _keep, N, nr, W, H, mstride = _band_args(rgba_band, target_rgb, target_mask, rows)
     dev = rgba_band.device
     with torch.cuda.device(dev):
         sums = torch.zeros((N + 1, 5), dtype=torch.float64, device=dev)
@@ -1000,7 +1028,7 @@ def image_loss_band_sums(rgba_band, target_rgb, target_mask, rows):
             sn, sh, sw, sc = band_rgb.stride()
             ws = _lib.workspace(dev, lib.dss_image_loss_workspace(N, nr, W))
             rc = lib.dss_image_loss_band_sums(_lib.ptr(rgba_band), _lib.ptr(band_rgb), sn, sh, sw, sc,
-                                              _lib.ptr(band_mask), H * W, N, nr, W, _lib.ptr(sums),
+                                              _lib.ptr(band_mask), mstride, N, nr, W, _lib.ptr(sums),
                                               _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
             _lib.check(rc, "dss_image_loss_band_sums")
     return sums
@@ -1024,7 +1052,7 @@ def image_loss_band_backward(rgba_band, target_rgb, target_mask, rows, lambda_rg
                              grad_total=None):
     """The band ``rows`` of d total / d rgba, (N,rows,W,4), from the reduced ``sums`` (after image_loss_from_sums)."""
     lib = _lib.load()
-    rgba_band, band_rgb, band_mask, _keep, N, nr, W, H = _band_args(rgba_band, target_rgb, target_mask, rows)
+    rgba_band, band_rgb, band_mask, _keep, N, nr, W, H, mstride = _band_args(rgba_band, target_rgb, target_mask, rows)
     dev = rgba_band.device
     sums = _lib.require_gpu(sums, "sums", torch.float64)
     if grad_total is not None:
@@ -1034,7 +1062,7 @@ def image_loss_band_backward(rgba_band, target_rgb, target_mask, rows, lambda_rg
         if nr > 0:
             sn, sh, sw, sc = band_rgb.stride()
             rc = lib.dss_image_loss_band_backward(_lib.ptr(rgba_band), _lib.ptr(band_rgb), sn, sh, sw, sc,
-                                                  _lib.ptr(band_mask), H * W, N, nr, W, H,
+                                                  _lib.ptr(band_mask), mstride, N, nr, W, H,
                                                   float(lambda_rgb), float(lambda_silhouette), _lib.ptr(sums),
                                                   _lib.ptr(grad_total), _lib.ptr(grad), _lib.stream_ptr(dev))
             _lib.check(rc, "dss_image_loss_band_backward")

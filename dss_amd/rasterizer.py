@@ -520,7 +520,12 @@ class _RenderFused(autograd.Function):
     @staticmethod
     def backward(ctx, g_image, *unused):
         world, M, V, first_idx, num_points, idx, qv, wsum, scaler, pts_screen, radii, visible, valid = ctx.saved_tensors
-        fuse = (not ctx.shared or M.shape[0] == 1) and g_image.shape[-1] == 4 and world.shape[0] == pts_screen.shape[0]
+        # the projection rides in the gather's epilogue only on the 32-bit-offset variants of the kernel (every gathered
+        # tensor below 4 GB and DSS_OPT_BACKWARD_ADDR64 off, raster_backward.hip): larger renders take the 64-bit gather
+        # and the separate projection kernel instead of failing inside autograd
+        widest = idx.numel() // idx.shape[-1] * max(idx.shape[-1], g_image.shape[-1]) * 4
+        fuse = (not ctx.shared or M.shape[0] == 1) and g_image.shape[-1] == 4 and world.shape[0] == pts_screen.shape[0] \
+            and widest < (1 << 32) and ops.backward_addr64() != 1
         g_feat, g_pts = ops.render_backward(g_image.contiguous(), idx, qv, wsum, scaler, pts_screen, radii, visible,
                                             first_idx, num_points, ctx.radii_s, ctx.clip,
                                             project=(world, M) if fuse else None)

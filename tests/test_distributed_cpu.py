@@ -170,7 +170,7 @@ def test_cyclic_row_partition_layout():
     assert RowPartition(64, 1, 0, cyclic=True).rows == (0, 64)      # one rank: the whole image, contiguous
 
 
-def _band_loss_worker(rank, world, port, tmp):
+def _band_loss_worker(rank, world, port, tmp, cyclic=False):
     """band_image_loss over gloo with the three HIP calls replaced by numpy stand-ins (same contracts): the all-reduce
     of the per-image sums and the autograd wiring are what is under test; the expected values come from the oracle on
     the full image."""
@@ -191,11 +191,16 @@ def _band_loss_worker(rank, world, port, tmp):
         mask = (rng.random((N, H, W)) < 0.5).astype(np.float32)
         lam = (0.7, 2.0)
 
+        def owned(rows):   # image rows of (row0, row1[, cycle]) in band order
+            c = rows[2] if len(rows) > 2 else 1
+            return [r + i for r in range(rows[0], rows[1], 8 * c) for i in range(8) if r + i < rows[1]] if c > 1 \
+                else list(range(rows[0], rows[1]))
+
         def band_sums(rgba_band, target_rgb, target_mask, rows):
-            r0, r1 = rows
-            a, t = rgba_band[..., 3].double(), target_mask.reshape(N, H, W)[:, r0:r1].double()
+            ri = owned(rows)
+            a, t = rgba_band[..., 3].double(), target_mask.reshape(N, H, W)[:, ri].double()
             inside = (a != 0) & (t != 0)
-            diff = (target_rgb[:, r0:r1].double() - rgba_band[..., :3].double()).abs().sum(-1)
+            diff = (target_rgb[:, ri].double() - rgba_band[..., :3].double()).abs().sum(-1)
             s = torch.zeros(N + 1, 5, dtype=torch.float64)
             s[:N, 0] = inside.sum((1, 2)); s[:N, 1] = (diff * inside).sum((1, 2)); s[:N, 2] = (t - a).abs().sum((1, 2))
             s[:N, 3] = (a * t).sum((1, 2)); s[:N, 4] = (a + t - a * t).sum((1, 2))
@@ -209,25 +214,25 @@ def _band_loss_worker(rank, world, port, tmp):
             return torch.stack([l_rgb * rgb + l_sil * sil, l_rgb * rgb, l_sil * sil, iou]).float()
 
         def band_backward(rgba_band, target_rgb, target_mask, rows, l_rgb, l_sil, sums, grad_total=None):
-            r0, r1 = rows
-            a, t = rgba_band[..., 3].double(), target_mask.reshape(N, H, W)[:, r0:r1].double()
+            ri = owned(rows)
+            a, t = rgba_band[..., 3].double(), target_mask.reshape(N, H, W)[:, ri].double()
             inside = ((a != 0) & (t != 0)).double()
             g = torch.zeros_like(rgba_band, dtype=torch.float64)
-            g[..., :3] = l_rgb * torch.sign(rgba_band[..., :3].double() - target_rgb[:, r0:r1].double()) * inside[..., None] / sums[N, 0]
+            g[..., :3] = l_rgb * torch.sign(rgba_band[..., :3].double() - target_rgb[:, ri].double()) * inside[..., None] / sums[N, 0]
             I, U = sums[:N, 3][:, None, None], sums[:N, 4][:, None, None]
             g[..., 3] = l_sil * (torch.sign(a - t) / (N * H * W) + 0.01 * (-(t * U - I * (1 - t)) / (U * U)) / N)
             return (g * (1.0 if grad_total is None else float(grad_total))).float()
 
         ops.image_loss_band_sums, ops.image_loss_from_sums, ops.image_loss_band_backward = band_sums, from_sums, band_backward
-        part = RowPartition(H, world, rank)
-        r0, r1 = part.rows
-        band = torch.from_numpy(rgba[:, r0:r1].copy()).requires_grad_(True)
+        part = RowPartition(H, world, rank, cyclic=cyclic)
+        ri = part.row_indices()
+        band = torch.from_numpy(rgba[:, ri].copy()).requires_grad_(True)
         out = band_image_loss(band, torch.from_numpy(img), torch.from_numpy(mask), part, *lam)
         want, want_grad = oracle.image_loss(rgba, img, mask, *lam)
         assert abs(out["loss"].item() - want[0]) <= 1e-5 * abs(want[0]), (out["loss"].item(), want[0])
         assert abs(out["loss_dr_rgb"].item() - want[1]) <= 1e-5 * abs(want[1])
         (out["loss"] * 1.5).backward()
-        assert np.allclose(band.grad.numpy(), 1.5 * want_grad[:, r0:r1], rtol=1e-5, atol=1e-9)
+        assert np.allclose(band.grad.numpy(), 1.5 * want_grad[:, ri], rtol=1e-5, atol=1e-9)
         open(os.path.join(tmp, "band_ok%d" % rank), "w").write("ok")
     finally:
         dist.destroy_process_group()
@@ -253,3 +258,10 @@ def test_band_image_loss_gloo_world4(tmp_path):
     port = 29750 + (os.getpid() % 90)
     mp.spawn(_band_loss_worker, args=(4, port, str(tmp_path)), nprocs=4, join=True)
     assert all((tmp_path / ("band_ok%d" % r)).exists() for r in range(4))
+
+
+def test_band_image_loss_gloo_world2_cyclic(tmp_path):
+    """the layout `bench.py --gpus N` defaults to: `part.rows` is the triple (8 rank, S, G)"""
+    port = 29650 + (os.getpid() % 90)
+    mp.spawn(_band_loss_worker, args=(2, port, str(tmp_path), True), nprocs=2, join=True)
+    assert (tmp_path / "band_ok0").exists() and (tmp_path / "band_ok1").exists()

@@ -124,3 +124,30 @@ def test_row_bands_reproduce_the_full_image_loss(bounds):
     assert torch.allclose(out["loss"], losses[0], rtol=1e-6)
     (out["loss"] * 1.3).backward()
     assert torch.allclose(leaf.grad, grad, rtol=1e-6, atol=1e-12)
+
+
+@pytest.mark.parametrize("G,H", [(2, 128), (4, 128), (4, 72)])
+def test_tile_row_cyclic_bands_reproduce_the_full_image_loss(G, H):
+    """ADVICE r3: `bench.py --gpus N` partitions tile-row-CYCLICALLY (`RowPartition(cyclic=True).rows` = (8 rank, S, G));
+    the band loss must take that triple: per-band sums add up to the full-image sums, every band's gradient is the
+    owned rows of the full-image gradient (H = 72 at G = 4: bands of 24 / 16 / 16 / 16 rows)."""
+    from dss_amd.distributed import RowPartition
+    rng = np.random.default_rng(33)
+    N, W = 2, 96
+    img = _t(rng.random((N, 3, H, W)).astype(np.float32)).permute(0, 2, 3, 1)
+    rgba = rng.random((N, H, W, 4)).astype(np.float32)
+    rgba[..., 3] = rng.random((N, H, W)) < 0.4
+    rgba = _t(rgba)
+    mask = _t((rng.random((N, H, W)) < 0.5).astype(np.float32))
+    losses, sums = ops.image_loss_forward(rgba, img, mask, 0.7, 2.0)
+    up = torch.tensor([1.3], device=DEV)
+    grad = ops.image_loss_backward(rgba, img, mask, 0.7, 2.0, sums, grad_total=up)
+    parts = [RowPartition(H, G, g, cyclic=True) for g in range(G)]
+    bands = [p.slice(rgba).contiguous() for p in parts]
+    reduced = torch.stack([ops.image_loss_band_sums(b, img, mask, p.rows) for b, p in zip(bands, parts)]).sum(0)
+    assert torch.allclose(reduced[:N], sums[:N], rtol=1e-6, atol=0) and torch.equal(reduced[:N, 0], sums[:N, 0])
+    assert torch.allclose(ops.image_loss_from_sums(reduced, (H, W), 0.7, 2.0), losses, rtol=1e-6)
+    for b, p in zip(bands, parts):
+        gb = ops.image_loss_band_backward(b, img, mask, p.rows, 0.7, 2.0, reduced, grad_total=up)
+        assert tuple(gb.shape) == (N, p.n_rows, W, 4)
+        assert torch.allclose(gb, p.slice(grad), rtol=1e-6, atol=1e-12)

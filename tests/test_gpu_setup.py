@@ -185,6 +185,38 @@ def test_fused_renderer_matches_unfused(n_cams):
     assert rel(res[1][2], res[0][2]) < 1e-5 and rel(res[1][3], res[0][3]) < 1e-5
 
 
+def test_fused_renderer_backward_with_64_bit_gather_falls_back_to_the_separate_projection():
+    """with DSS_OPT_BACKWARD_ADDR64 (or gathered tensors of 4 GB and more) the gather kernel has no fused
+    projection epilogue; the autograd node must then run the separate projection kernel, not raise inside backward."""
+    from dss_amd import _lib
+    S, K = 96, 5
+    pts, nrm = scenes.load_cloud("teapot")
+    pts = scenes.normalize_unit_sphere(pts)
+    h = scenes.global_h(pts)
+    col = np.random.default_rng(0).uniform(0, 1, pts.shape).astype(np.float32)
+    R, T = look_at_view_transform(2.0, 30.0, [45.0])
+    cams = FoVPerspectiveCameras(znear=0.1, R=R, T=T, device=DEV)
+    st = PointsRasterizationSettings(backface_culling=False, cutoff_threshold=1.0, Vrk_invariant=True,
+                                     radii_backward_scaler=5, image_size=S, points_per_pixel=K, bin_size=None,
+                                     clip_pts_grad=0.05)
+    g = torch.from_numpy(np.random.default_rng(1).standard_normal((1, S, S, 4)).astype(np.float32)).to(DEV)
+    res = []
+    for addr64 in (0, 1):
+        old = _lib.set_option(_lib.OPT_BACKWARD_ADDR64, addr64)
+        try:
+            renderer = SurfaceSplattingRenderer(SurfaceSplatting(cameras=cams, raster_settings=st), NormWeightedCompositor(),
+                                                fused=True)
+            P = torch.nn.Parameter(torch.from_numpy(pts).to(DEV))
+            C = torch.nn.Parameter(torch.from_numpy(col).to(DEV))
+            img = renderer(PointClouds3D([P], [torch.from_numpy(nrm).to(DEV)], [C]), Vrk_h=torch.tensor([h], device=DEV))
+            (img * g).sum().backward()
+            res.append((P.grad.clone(), C.grad.clone()))
+        finally:
+            _lib.set_option(_lib.OPT_BACKWARD_ADDR64, old)
+    rel = lambda a, b: float((a - b).norm() / b.norm())
+    assert rel(res[1][0], res[0][0]) < 1e-5 and rel(res[1][1], res[0][1]) < 1e-5
+
+
 @pytest.mark.parametrize("mode", ["global", "iso"])
 @pytest.mark.parametrize("tag", ["1cam", "3cam"])
 def test_point_setup_matches_reference_python_golden(golden_dir, tag, mode):

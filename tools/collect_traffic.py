@@ -27,8 +27,7 @@ def one_pass(counter):
     os.makedirs(d, exist_ok=True)
     env = dict(os.environ, TMPDIR="/tmp")
     cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "--",
-           sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "eager", "--no-cpu-baseline", "--no-traffic", "--steps", "20",
-           "--warmup", "5"]
+           sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "eager", "--timed-only", "--steps", "20", "--warmup", "5"]
     subprocess.run(cmd, cwd="/tmp", env=env, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     vals, other = [], []
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
@@ -45,15 +44,40 @@ def one_pass(counter):
     return sum(vals) / len(vals), len(vals)
 
 
+def trace_pass():
+    """Third pass, kernel trace only (no counters: a PMC pass serialises and perturbs the kernels): the rocprofv3 average
+    duration of both roofline kernels inside the very step bench.py times -> {kernel: ms}"""
+    d = os.path.join(OUT, "trace")
+    os.makedirs(d, exist_ok=True)
+    env = dict(os.environ, TMPDIR="/tmp")
+    cmd = ["rocprofv3", "--kernel-trace", "--output-format", "csv", "-d", d, "--",
+           sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "graph", "--timed-only", "--steps", "100", "--warmup", "10"]
+    subprocess.run(cmd, cwd="/tmp", env=env, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    acc = {}
+    for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            for k in (KERNEL, OTHER):
+                if k in r["Kernel_Name"]:
+                    acc.setdefault(k, []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+    return {k: sum(v) / len(v) for k, v in acc.items() if v}, {k: len(v) for k, v in acc.items()}
+
+
 def main():
     fetch, nf = one_pass("FETCH_SIZE")
     write, nw = one_pass("WRITE_SIZE")
+    try:
+        prof_ms, prof_n = trace_pass()
+    except Exception:  # noqa: BLE001  (the traffic numbers stand on their own)
+        prof_ms, prof_n = {}, {}
     rec = {"kernel": "fine_kernel<5>", "command": "bench.py --mode eager --steps 20 (BASELINE configs[1])",
            "FETCH_SIZE_KiB_raw": fetch, "WRITE_SIZE_KiB_raw": write, "samples": [nf, nw],
            "correction": "FETCH_SIZE x2 (gfx950 counts 128-B requests at 64 B), WRITE_SIZE as reported",
            "traffic_bytes_per_launch": int((2.0 * fetch + write) * 1024)}
     if OTHER_MEAN.get("FETCH_SIZE") is not None and OTHER_MEAN.get("WRITE_SIZE") is not None:
         rec["render_backward_kernel_traffic_bytes_per_launch"] = int((2.0 * OTHER_MEAN["FETCH_SIZE"] + OTHER_MEAN["WRITE_SIZE"]) * 1024)
+    rec["rocprof_kernel_ms"] = prof_ms
+    rec["rocprof_kernel_dispatches"] = prof_n
+    rec["rocprof_kernel_ms_how"] = "rocprofv3 --kernel-trace (no counters) over bench.py --mode graph --steps 100: mean End - Start"
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "traffic_fine_kernel.json"), "w") as f:
         json.dump(rec, f, indent=1)
