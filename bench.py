@@ -511,6 +511,8 @@ def main():
                          % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    if os.environ.get("BENCH_BACKWARD_FUSED"):   # development A/B: DSS_OPT_BACKWARD_FUSED (include/dss_hip.h)
+        _lib.set_option(_lib.OPT_BACKWARD_FUSED, int(os.environ["BENCH_BACKWARD_FUSED"]))
     local = local % torch.cuda.device_count()  # (BENCH_DIST_BACKEND=gloo lets two ranks share one GPU in tests)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)

@@ -109,7 +109,7 @@ def load():
     return _lib
 
 
-OPT_LEAN_WORKSPACE, OPT_BACKWARD_TPW, OPT_BACKWARD_ADDR64 = 0, 1, 2   # include/dss_hip.h DSS_OPT_*
+OPT_LEAN_WORKSPACE, OPT_BACKWARD_TPW, OPT_BACKWARD_ADDR64, OPT_BACKWARD_FUSED = 0, 1, 2, 3   # include/dss_hip.h DSS_OPT_*
 
 
 def set_option(option: int, value: int) -> int:

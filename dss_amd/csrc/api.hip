@@ -33,7 +33,7 @@ static std::atomic<int> g_opt[DSS_OPT_COUNT];
 int option(int which) { return (which >= 0 && which < DSS_OPT_COUNT) ? g_opt[which].load(std::memory_order_relaxed) : 0; }
 
 // Per-device cache of (CU count, resident workgroups per CU of the backward gather) -- see raster_backward.hip.
-static std::atomic<int> g_dev_cache[DSS_MAX_DEVICES][4];
+static std::atomic<int> g_dev_cache[DSS_MAX_DEVICES][DSS_DEV_CACHE_SLOTS];
 std::atomic<int> *device_cache(int dev) { return (dev >= 0 && dev < DSS_MAX_DEVICES) ? g_dev_cache[dev] : nullptr; }
 
 }  // namespace dss

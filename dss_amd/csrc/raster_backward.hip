@@ -1007,11 +1007,426 @@ __device__ __forceinline__ int tasks_max(int v)
     return m;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Backward preparation of short lists, round 4: bucket-sorted radius keys, a median that only touches one bucket, and
+// the median inside the gather launch.
+//
+// Round 3: backward_compact_kernel (5.1 us) -> median_visible_kernel (10.6 us: ONE workgroup radix-selects over all
+// ~52k radius keys, bound by the instruction issue of one CU) -> gather (20.2 us).  Now:
+//   fb_prep_kernel    one 256-thread workgroup per segment of P/64 points (64 workgroups instead of 16): visible ids in id
+//                     order, zero rows for invisible points, and per cloud the segment's radius keys counting-sorted into
+//                     256 monotone buckets of 1/16 octave + the exclusive prefix of the bucket counts; extra workgroups
+//                     copy the alpha channel of the image gradient into its dense plane
+//   fb_median         sums the 64 prefix rows -> bucket of the median -> reads ONLY that bucket's keys (a contiguous run of
+//                     every segment, ~1/24 of all keys) -> exact selection by 1024-bin refinement passes in LDS
+// and the medians run in the first N workgroups of the GATHER launch (DSS_OPT_BACKWARD_FUSED 4; 5 = a launch of their own):
+// the gather's persistent workgroups are resident from the start, do the half of every task that does not need the search
+// radius (the blend backward over the splat's own box) while workgroup n selects the median of cloud n, pick rs up
+// through memory and continue with the occupancy sweep.
+// Synchronisation is by TAG words: the median workgroup stores the launch's tag behind rs; the others poll until the
+// word equals the tag.  The tag is the AQL dispatch id of the launch mixed with its queue address: unique per launch --
+// also per replay of a captured graph, where the kernel arguments are frozen -- so no word is ever reset, no memset
+// precedes the launch and a workspace may hold anything (a stale word equals the new tag only if this very dispatch wrote
+// it).  The median workgroups are the first of the grid and wait for nobody: no deadlock even if the grid exceeded the
+// resident capacity.  The wait is bounded (a lost producer gives wrong numbers, not a hung GPU).
+// The L2s of the eight XCDs are not coherent, and agent-scope fences (L2 write-back / invalidate) cost tens of microseconds
+// here (measured: a launch that also held the compaction and synchronised it with fences took 56 us against 36 us for the
+// three round-3 launches; with the alpha plane behind an acquire in every workgroup 103 us): rs and its tag are WRITTEN
+// with agent-scope (write-through) stores and READ with agent-scope loads, nothing else crosses workgroups in a launch.
+// ---------------------------------------------------------------------------------------------
+extern "C" __device__ unsigned long long dss_dispatch_id(void) __asm("llvm.amdgcn.dispatch.id");
+
+#define DSS_BACKWARD_FUSED_DEFAULT 4   // automatic choice of DSS_OPT_BACKWARD_FUSED (see render_backward_impl)
+#define FB_THREADS 256
+#define FB_BUCKETS 256          // level-0 buckets of the radius keys
+#define FB_CAND_MAX 4096        // candidate keys of the median bucket held in LDS (more: streamed from memory per pass)
+#define FB_HIST 1024            // bins of a refinement pass
+#define FB_TAG_RS 0             // 8 copies (one per XCD of the polling workgroup, each on its own cache lines) x 64 clouds
+#define FB_TAGS (8 * 64)
+#define FB_SPIN_LIMIT (1 << 20)
+#define FB_ALPHA_PER_WG 2048    // pixels of the alpha plane per (256-thread) workgroup of fb_prep_kernel
+// level-0 bucket of an order-preserving radius key: 16 octaves [2^-16, 1) of NDC radius in 256 buckets (1/16 octave each;
+// everything below / above lands in the end buckets: any monotone map keeps the selection exact)
+#define FB_KEY_LO 0xB7800000u   // float_key(2^-16)
+#define FB_KEY_HI 0xBF800000u   // float_key(1.0)
+__device__ __forceinline__ uint32_t fb_bucket(uint32_t key)
+{
+    const uint32_t c = min(max(key, FB_KEY_LO), FB_KEY_HI - 1u);
+    return (c - FB_KEY_LO) >> 19;
+}
+
+struct FusedPrep {
+    const uint8_t *visible;       // (P)
+    uint32_t *seg_count;          // (chunks) visible points per segment
+    int32_t *vis_list;            // (P) per segment: visible ids, ascending
+    uint32_t *keys;               // (2 P) per (cloud, segment): radius keys counting-sorted by level-0 bucket
+    uint32_t *chunk_hist;         // (N, chunks, FB_BUCKETS): EXCLUSIVE prefix of the bucket counts of (cloud, segment)
+    uint2 *seg_range;             // (N, chunks): first entry / entries of cloud n inside segment c
+    unsigned long long *tags;     // FB_TAGS words
+    float *rs;                    // (N) out
+    int64_t P;
+    int chunks, per;              // segments (<= 64); points per thread of a segment (segment = per * 256 points)
+    float radii_s;
+};
+
+__device__ __forceinline__ unsigned long long fb_launch_tag()
+{
+    const unsigned long long q = (unsigned long long)__builtin_amdgcn_queue_ptr();
+    return dss_dispatch_id() * 0x9E3779B97F4A7C15ull ^ (q << 17) ^ (q >> 7) ^ 0x5851F42D4C957F2Dull;
+}
+
+// exclusive scan over the FB_THREADS threads of a workgroup (4 wavefronts); total left in every thread
+__device__ __forceinline__ uint32_t fb_block_excl_scan(uint32_t v, uint32_t *s_w /*[4]*/, uint32_t &total)
+{
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const uint32_t x = wave_incl_scan(v);
+    __syncthreads();
+    if (lane == 63) s_w[wid] = x;
+    __syncthreads();
+    uint32_t woff = 0;
+    total = 0;
+#pragma unroll
+    for (int w = 0; w < FB_THREADS / 64; ++w) {
+        const uint32_t c = s_w[w];
+        if (w < wid) woff += c;
+        total += c;
+    }
+    return woff + x - v;
+}
+
+// Segment `c`: compaction + per-cloud bucket-sorted keys / bucket prefix.  s_mem: >= 2 * FB_BUCKETS + 160 words.
+// PER (= F.per) is a template parameter so that the loops over a thread's points unroll: all of their loads in flight
+// (as a runtime loop every load waited for the previous one: 5.5 us per segment instead of 3.5).
+template <int PER>
+__device__ __forceinline__ void fb_prep_segment(const FusedPrep &F, int c, const float *__restrict__ radii,
+                                                const int64_t *__restrict__ first_idx, const int64_t *__restrict__ num_pts,
+                                                int N, float *__restrict__ grad_pts, float *__restrict__ grad_feat, int C,
+                                                uint32_t *s_mem)
+{
+    uint32_t *s_hist = s_mem, *s_cur = s_mem + FB_BUCKETS, *s_w = s_mem + 2 * FB_BUCKETS /*[64]*/,
+             *s_pre = s_mem + 2 * FB_BUCKETS + 64 /*[64]*/, *s_tot = s_mem + 2 * FB_BUCKETS + 128;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    constexpr int per = PER;
+    const int64_t seg = (int64_t)per * FB_THREADS;
+    const int64_t c0 = (int64_t)c * seg, c1 = min(c0 + seg, F.P);
+    uint32_t vmask = 0;   // bit u: point c0 + u * 256 + tid is visible
+#pragma unroll
+    for (int u = 0; u < per; ++u) {
+        const int64_t i = c0 + (int64_t)u * FB_THREADS + tid;
+        const uint8_t v = F.visible[min(i, F.P - 1)];
+        vmask |= ((i < c1 && v != 0) ? 1u : 0u) << u;
+    }
+    // visible points per (u, wavefront), in list order
+#pragma unroll
+    for (int u = 0; u < per; ++u) {
+        const unsigned long long m = __ballot((vmask >> u) & 1u);
+        if (lane == 0) s_w[u * 4 + wid] = (uint32_t)__popcll(m);
+    }
+    __syncthreads();
+    if (wid == 0) {
+        const uint32_t v = lane < per * 4 ? s_w[lane] : 0u;
+        const uint32_t x = wave_incl_scan(v);
+        s_pre[lane] = x - v;
+        if (lane == 63) s_tot[0] = x;
+    }
+    __syncthreads();
+    const uint32_t tot = s_tot[0];
+    if (tid == 0) F.seg_count[c] = tot;
+#pragma unroll
+    for (int u = 0; u < per; ++u) {
+        const int64_t i = c0 + (int64_t)u * FB_THREADS + tid;
+        const bool vis = (vmask >> u) & 1u;
+        const unsigned long long m = __ballot(vis);
+        if (vis) {
+            const uint32_t pos = s_pre[u * 4 + wid] +
+                                 __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+            F.vis_list[c0 + pos] = (int32_t)i;
+        } else if (i < c1 && grad_pts) {
+            grad_pts[3 * i] = 0.0f; grad_pts[3 * i + 1] = 0.0f; grad_pts[3 * i + 2] = 0.0f;
+            if (grad_feat)
+                for (int ch = 0; ch < C; ++ch) grad_feat[(size_t)i * C + ch] = 0.0f;
+        }
+    }
+    // per cloud that overlaps the segment (normally one): bucket counts, their prefix, then the keys in bucket order
+    const float2 *r2 = reinterpret_cast<const float2 *>(radii);
+    for (int n = 0; n < N; ++n) {
+        const int64_t lo = max(c0, first_idx[n]), hi = min(c1, first_idx[n] + num_pts[n]);
+        if (lo >= hi) continue;  // uniform
+        __syncthreads();         // previous cloud's cursors consumed
+        s_hist[tid] = 0;
+        if (tid < 2) s_w[tid] = 0;
+        __syncthreads();
+    #pragma unroll
+    for (int u = 0; u < per; ++u) {
+            const int64_t i = c0 + (int64_t)u * FB_THREADS + tid;
+            const bool vis = (vmask >> u) & 1u;
+            const bool mine = vis && i >= lo && i < hi;
+            const unsigned long long mb = __ballot(vis && i < lo), mi = __ballot(mine);
+            if (lane == 0) {
+                if (mb) atomicAdd(&s_w[0], (uint32_t)__popcll(mb));
+                if (mi) atomicAdd(&s_w[1], (uint32_t)__popcll(mi));
+            }
+            if (mine) {
+                const float2 r = r2[i];
+                atomicAdd(&s_hist[fb_bucket(float_key(r.x))], 1u);
+                atomicAdd(&s_hist[fb_bucket(float_key(r.y))], 1u);
+            }
+        }
+        __syncthreads();
+        const uint32_t h = s_hist[tid];
+        const uint32_t first_entry = s_w[0], entries = s_w[1];
+        uint32_t total;
+        const uint32_t excl = fb_block_excl_scan(h, s_w + 4, total);
+        F.chunk_hist[((size_t)n * F.chunks + c) * FB_BUCKETS + tid] = excl;
+        s_cur[tid] = excl;
+        if (tid == 0) F.seg_range[(size_t)n * F.chunks + c] = make_uint2(first_entry, entries);
+        __syncthreads();
+        uint32_t *kb = F.keys + 2 * ((size_t)c0 + first_entry);
+    #pragma unroll
+    for (int u = 0; u < per; ++u) {
+            const int64_t i = c0 + (int64_t)u * FB_THREADS + tid;
+            if (((vmask >> u) & 1u) && i >= lo && i < hi) {
+                const float2 r = r2[i];
+                const uint32_t kx = float_key(r.x), ky = float_key(r.y);
+                kb[atomicAdd(&s_cur[fb_bucket(kx)], 1u)] = kx;
+                kb[atomicAdd(&s_cur[fb_bucket(ky)], 1u)] = ky;
+            }
+        }
+    }
+}
+
+// rank-k bin of a histogram held as h[NB] consecutive bins per thread (first bin of the thread: NB * tid)
+template <int NB>
+__device__ __forceinline__ void fb_select(const uint32_t (&h)[NB], uint32_t k, uint32_t *s_w /*[8]*/, uint32_t &bin_out,
+                                          uint32_t &k_out)
+{
+    uint32_t v = 0;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) v += h[i];
+    uint32_t total;
+    uint32_t excl = fb_block_excl_scan(v, s_w, total);
+    __syncthreads();
+    if (total > 0 && k >= excl && k < excl + v) {
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            if (k >= excl && k < excl + h[i]) {
+                s_w[4] = (uint32_t)(NB * threadIdx.x + i);
+                s_w[5] = k - excl;
+            }
+            excl += h[i];
+        }
+    }
+    __syncthreads();
+    bin_out = s_w[4];
+    k_out = s_w[5];
+}
+
+// Median of cloud n (lower median of the radius keys of its visible points, rasterizer.py:885-888) from the segments'
+// bucket prefixes and bucket-sorted keys (written by an EARLIER launch: plain loads).  s_mem: FB_CAND_MAX + FB_HIST + 4 * 64 +
+// 16 words.  Every global load of a step is issued before the first is used (a loop of dependent single loads took 25 us).
+__device__ __forceinline__ float fb_median(const FusedPrep &F, int n, const int64_t *__restrict__ first_idx,
+                                           const int64_t *__restrict__ num_pts, uint32_t *s_mem)
+{
+    uint32_t *s_cand = s_mem /* also: 4 x 256 partial sums */, *s_hist = s_mem + FB_CAND_MAX /* also: 257 prefix sums */,
+             *s_cnt = s_hist + FB_HIST, *s_dst = s_cnt + 64, *s_base = s_dst + 64, *s_spare = s_base + 64, *s_w = s_spare + 64;
+    (void)s_spare;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int64_t f = first_idx[n];
+    const int64_t cnt = max((int64_t)0, min(num_pts[n], F.P - f));
+    if (cnt <= 0) return 0.0f;   // uniform
+    const int64_t seg = (int64_t)F.per * FB_THREADS;
+    const int c_lo = (int)(f / seg), c_hi = (int)((f + cnt - 1) / seg);
+    const int n_c = c_hi - c_lo + 1;   // <= 64
+    const uint32_t *H = F.chunk_hist + ((size_t)n * F.chunks + c_lo) * FB_BUCKETS;
+    const uint2 *R = F.seg_range + (size_t)n * F.chunks + c_lo;
+    PREP_MARK(4);
+    // ---- level 0: S[b] = keys of the cloud in buckets < b, summed over the segments' prefix rows.  Thread = (group of 16
+    // segments, four consecutive buckets): sixteen 16-byte loads in flight ----
+    {
+        const int g = wid, qd = lane;
+        uint4 v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int c = g * 16 + u;
+            v[u] = make_uint4(0u, 0u, 0u, 0u);
+            if (c < n_c) v[u] = reinterpret_cast<const uint4 *>(H + (size_t)c * FB_BUCKETS)[qd];
+        }
+        const uint2 rg = tid < n_c ? R[tid] : make_uint2(0u, 0u);   // (first entry, entries) of segment tid
+        uint4 acc = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+        reinterpret_cast<uint4 *>(s_cand + g * FB_BUCKETS)[qd] = acc;
+        if (wid == 0) {
+            const uint32_t x = wave_incl_scan(2u * rg.y);   // two keys per visible point
+            if (lane == 63) s_hist[FB_BUCKETS] = x;          // all keys of the cloud
+            s_cnt[lane] = 2u * rg.y;                         // (keys of the segment, for the last bucket's end)
+            s_base[lane] = 2u * (uint32_t)((int64_t)(c_lo + lane) * seg) + 2u * rg.x;   // first key of (cloud, segment) in F.keys
+        }
+    }
+    __syncthreads();
+    s_hist[tid] = (s_cand[tid] + s_cand[FB_BUCKETS + tid]) + (s_cand[2 * FB_BUCKETS + tid] + s_cand[3 * FB_BUCKETS + tid]);
+    __syncthreads();
+    const uint32_t total0 = s_hist[FB_BUCKETS];
+    if (total0 == 0) return 0.0f;   // uniform: nothing visible in this cloud
+    uint32_t k = (total0 - 1) / 2;  // torch.median = lower median
+    {
+        const uint32_t lo_b = s_hist[tid], hi_b = s_hist[tid + 1];
+        if (lo_b <= k && k < hi_b) { s_w[4] = (uint32_t)tid; s_w[5] = k - lo_b; s_w[6] = hi_b - lo_b; }
+    }
+    __syncthreads();
+    const uint32_t b1 = s_w[4], m = s_w[6];   // bucket of the median, its keys
+    k = s_w[5];
+    PREP_MARK(5);
+    // ---- the bucket's keys: a contiguous run of every segment's sorted keys ----
+    if (wid == 0) {
+        uint32_t e0 = 0, e1 = 0;
+        if (lane < n_c) {
+            const uint32_t *hc = H + (size_t)lane * FB_BUCKETS;
+            e0 = hc[b1];
+            e1 = b1 + 1 < FB_BUCKETS ? hc[b1 + 1] : s_cnt[lane];
+        }
+        const uint32_t v = e1 - e0;
+        const uint32_t x = wave_incl_scan(v);
+        s_dst[lane] = x - v;
+        s_cnt[lane] = v;
+        s_base[lane] += e0;
+    }
+    __syncthreads();
+    const bool in_lds = m <= FB_CAND_MAX;
+    const int cc = tid >> 2, q = tid & 3;   // 4 threads per segment
+    const uint32_t my_cnt = s_cnt[cc];
+    const uint32_t *my_keys = F.keys + (size_t)s_base[cc];
+    uint32_t kmin = 0xffffffffu, kmax = 0u;
+    for (uint32_t j0 = q; j0 < my_cnt; j0 += 16) {   // four loads in flight per thread
+        uint32_t key[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) key[u] = my_keys[min(j0 + 4u * u, my_cnt - 1u)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (j0 + 4u * u < my_cnt) {
+                if (in_lds) s_cand[s_dst[cc] + j0 + 4u * u] = key[u];
+                kmin = min(kmin, key[u]);
+                kmax = max(kmax, key[u]);
+            }
+        }
+    }
+    // min / max over the workgroup
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, o, 64));
+        kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, o, 64));
+    }
+    __syncthreads();
+    if (lane == 0) { s_w[8 + wid] = kmin; s_w[12 + wid] = kmax; }
+    __syncthreads();
+    uint32_t lo = min(min(s_w[8], s_w[9]), min(s_w[10], s_w[11]));
+    uint32_t hi = max(max(s_w[12], s_w[13]), max(s_w[14], s_w[15]));
+    PREP_MARK(6);
+    // ---- refinement: 1024-bin passes over the candidates inside [lo, hi] until one key value is left ----
+    while (lo != hi) {   // uniform
+        const uint32_t range = hi - lo;
+        const int bits = 32 - __builtin_clz(range);
+        const int shift = bits > 10 ? bits - 10 : 0;
+        for (int i = tid; i < FB_HIST; i += FB_THREADS) s_hist[i] = 0;
+        __syncthreads();
+        if (in_lds) {
+            for (uint32_t j = tid; j < m; j += FB_THREADS) {
+                const uint32_t key = s_cand[j];
+                if (key >= lo && key <= hi) atomicAdd(&s_hist[(key - lo) >> shift], 1u);
+            }
+        } else {
+            for (uint32_t j = q; j < my_cnt; j += 4) {
+                const uint32_t key = my_keys[j];
+                if (key >= lo && key <= hi) atomicAdd(&s_hist[(key - lo) >> shift], 1u);
+            }
+        }
+        __syncthreads();
+        const uint4 hq = reinterpret_cast<const uint4 *>(s_hist)[tid];
+        const uint32_t h[4] = {hq.x, hq.y, hq.z, hq.w};
+        uint32_t bin;
+        fb_select<4>(h, k, s_w, bin, k);
+        const uint32_t nlo = lo + (bin << shift);
+        const uint32_t span = (1u << shift) - 1u;
+        hi = min(hi, nlo + span < nlo ? 0xffffffffu : nlo + span);
+        lo = nlo;
+        __syncthreads();
+    }
+    PREP_MARK(7);
+    return key_float(lo) * F.radii_s;
+}
+
+// rs[n] and, behind it, the eight copies of its tag (median workgroup of a fused launch)
+__device__ __forceinline__ void fb_publish_rs(const FusedPrep &F, int n, float value, unsigned long long tag)
+{
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(&F.rs[n], value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // s_waitcnt vmcnt(0): the write-through store has completed
+    }
+    __syncthreads();
+    if (threadIdx.x < 8)
+        __hip_atomic_store(&F.tags[FB_TAG_RS + (size_t)threadIdx.x * 64 + n], tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// every other workgroup of a fused launch: wait until the search radius of every cloud is published (N <= 64).  Workgroup b
+// runs on XCD b mod 8 and polls that XCD's copy of the tags (eight cache lines instead of one under ~1500 pollers).
+__device__ __forceinline__ void fb_wait_rs(const FusedPrep &F, int N, unsigned long long tag)
+{
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        const unsigned long long *t = F.tags + FB_TAG_RS + (size_t)(blockIdx.x & 7u) * 64;
+        for (int spin = 0; spin < FB_SPIN_LIMIT; ++spin) {
+            const bool ok = lane >= N || __hip_atomic_load(&t[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == tag;
+            if (__ballot(!ok) == 0ull) break;
+            __builtin_amdgcn_s_sleep(8);
+        }
+    }
+    __syncthreads();
+}
+
+// the two preparation stages as launches of their own
+template <int PER>
+__global__ __launch_bounds__(FB_THREADS) void fb_prep_kernel(const FusedPrep F, const float *__restrict__ radii,
+                                                             const int64_t *__restrict__ first_idx,
+                                                             const int64_t *__restrict__ num_pts, int N,
+                                                             float *__restrict__ grad_pts, float *__restrict__ grad_feat, int C,
+                                                             const float *__restrict__ grad_out, float *__restrict__ alpha_plane,
+                                                             size_t npix)
+{
+    if ((int)blockIdx.x >= F.chunks) {  // extra workgroups of the launch: dense alpha plane for the gather kernel
+        const size_t i0 = (size_t)(blockIdx.x - F.chunks) * FB_ALPHA_PER_WG + threadIdx.x;
+        if (C == 3) {   // (N,rows,S,4): 16-byte aligned pixels; all eight loads of the thread in flight
+            const float4 *g4 = reinterpret_cast<const float4 *>(grad_out);
+            float a[FB_ALPHA_PER_WG / FB_THREADS];
+#pragma unroll
+            for (int u = 0; u < FB_ALPHA_PER_WG / FB_THREADS; ++u) a[u] = g4[min(i0 + (size_t)u * FB_THREADS, npix - 1)].w;
+#pragma unroll
+            for (int u = 0; u < FB_ALPHA_PER_WG / FB_THREADS; ++u)
+                if (i0 + (size_t)u * FB_THREADS < npix) alpha_plane[i0 + (size_t)u * FB_THREADS] = a[u];
+        } else {
+            for (int u = 0; u < FB_ALPHA_PER_WG / FB_THREADS; ++u) {
+                const size_t i = i0 + (size_t)u * FB_THREADS;
+                if (i < npix) alpha_plane[i] = grad_out[i * (C + 1) + C];
+            }
+        }
+        return;
+    }
+    __shared__ uint32_t s_fb[2 * FB_BUCKETS + 160];
+    fb_prep_segment<PER>(F, (int)blockIdx.x, radii, first_idx, num_pts, N, grad_pts, grad_feat, C, s_fb);
+}
+__global__ __launch_bounds__(FB_THREADS) void fb_median_kernel(const FusedPrep F, const int64_t *__restrict__ first_idx,
+                                                               const int64_t *__restrict__ num_pts)
+{
+    __shared__ uint32_t s_fb[FB_CAND_MAX + FB_HIST + 4 * 64 + 16];
+    const float v = fb_median(F, (int)blockIdx.x, first_idx, num_pts, s_fb);
+    if (threadIdx.x == 0) F.rs[blockIdx.x] = v;
+}
+
 // CYC: tile-row-cyclic band (tshift > 3): the windows are walked in BAND rows (the owned rows of a window are a
 // contiguous range of band rows), the NDC y of each comes from band_image_row.  CYC = false is the contiguous band.
-template <int C, bool SEG, int TPW, bool A32, bool CYC = false>
+template <int C, bool SEG, int TPW, bool A32, bool CYC = false, bool PREP = false>
 __global__ __launch_bounds__(256) void render_backward_kernel(
-    const float *__restrict__ grad_out, const float *__restrict__ grad_alpha /* dense (N,rows,S) */,
+    const float *__restrict__ grad_out, const float *__restrict__ grad_alpha /* dense (N,rows,S); PREP: or grad_out + C, see astride */,
     const int32_t *__restrict__ idx, const float *__restrict__ qv,
     const float *__restrict__ wsum, const float *__restrict__ scaler, const float *__restrict__ points,
     const float *__restrict__ radii, const float *__restrict__ rs, const int64_t *__restrict__ first_idx,
@@ -1019,7 +1434,9 @@ __global__ __launch_bounds__(256) void render_backward_kernel(
     const int32_t *__restrict__ vis_list, int n_seg, int seg_pts, int N, int S, int K, int Crt, float clip, int row0,
     int rows, uint32_t large_waves, float *__restrict__ grad_feat, float *__restrict__ grad_pts, int tshift = 3,
     const float *__restrict__ world = nullptr /* (P,3): fused projection backward, see the epilogue */,
-    const float *__restrict__ Mproj = nullptr /* (N,4,4) */)
+    const float *__restrict__ Mproj = nullptr /* (N,4,4) */,
+    const FusedPrep F = FusedPrep() /* PREP: preparation stages inside this launch, see fb_prep_segment */,
+    int astride = 1 /* elements between two pixels of grad_alpha: 1 = dense plane, C + 1 = the alpha channel of grad_out in place */)
 {
     constexpr int CM = (C > 0) ? C : BLEND_MAX_C;
     constexpr int KF = 8;            // fragment slots held in registers; deeper lists take the loop
@@ -1027,8 +1444,18 @@ __global__ __launch_bounds__(256) void render_backward_kernel(
     constexpr int RP = GS / 16;      // row phases per task
     const int Cn = (C > 0) ? C : Crt;
     const int lane = threadIdx.x & 63, grp = lane / GS, rp = (lane % GS) >> 4, l = lane & 15;
-    const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6);
-    uint32_t n_waves = gridDim.x * 4;
+    // PREP: the first N workgroups select the medians (fb_median) and take no gather tasks
+    const uint32_t first_block = PREP ? (uint32_t)N : 0u;
+    if (PREP && blockIdx.x < first_block) {
+        __shared__ uint32_t s_fb[FB_CAND_MAX + FB_HIST + 4 * 64 + 16];
+        PREP_MARK(0);
+        const float v = fb_median(F, (int)blockIdx.x, first_idx, num_pts, s_fb);
+        fb_publish_rs(F, (int)blockIdx.x, v, fb_launch_tag());
+        PREP_MARK(1);
+        return;
+    }
+    const uint32_t wave = (blockIdx.x - first_block) * 4 + (threadIdx.x >> 6);
+    uint32_t n_waves = (gridDim.x - first_block) * 4;
     // SEG: vis_count[0..n_seg) are per-segment counts written by backward_compact_kernel (n_seg <= 64): every
     // wavefront scans them in registers once; a task index t maps to (segment, offset) with one ballot.
     uint32_t count, seg_excl = 0;  // first task index of segment `lane`
@@ -1049,7 +1476,7 @@ __global__ __launch_bounds__(256) void render_backward_kernel(
     // long lists use 6 workgroups per CU: more resident gathers only evict each other's image rows from L2
     const bool long_list = n_groups > 8u * n_waves;
     if (long_list) n_waves = min(n_waves, large_waves);
-    if (wave >= n_waves) return;
+    if (!PREP && wave >= n_waves) return;
     // Dealing of the groups.  Short lists: group t -> wave t mod n_waves.  Long lists are in screen-cell order (see
     // cell_count_kernel): runs of CH consecutive groups -- about one cell -- go to ONE XCD (blocks are dispatched to the
     // XCDs round robin), so that the rows a cell's tasks share are fetched into one L2 instead of eight.
@@ -1066,8 +1493,9 @@ __global__ __launch_bounds__(256) void render_backward_kernel(
         return chunked ? ((t / max(CH, 1u)) * 8u + xcd) * CH + (t % max(CH, 1u)) : t;
     };
     const uint32_t wave_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)qof(t0));
-    if (wave_u >= n_groups) return;
-    uint32_t t_cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)t0);
+    if (!PREP && wave_u >= n_groups) return;
+    const bool has_tasks = wave < n_waves && wave_u < n_groups;   // (PREP: wavefronts without tasks still take part in the wait)
+    const uint32_t t_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)t0);
 
     // point id of this lane's task in group q (-1 beyond the list); uniform within the task's lanes
     auto task_ids = [&](uint32_t q) -> int {
@@ -1094,6 +1522,10 @@ __global__ __launch_bounds__(256) void render_backward_kernel(
     };
     const NdcMap ndc(S);
     const size_t plane = (size_t)rows * S;
+    // PH 0: whole tasks; 1: the blend half only (needs no search radius); 2: the occupancy half only
+    auto run_tasks = [&](auto phase_tag) {
+    constexpr int PH = decltype(phase_tag)::value;
+    uint32_t t_cur = t_first;
     int p_nx = task_ids(wave_u);
     for (;;) {
         const int p = p_nx;
@@ -1115,10 +1547,13 @@ __global__ __launch_bounds__(256) void render_backward_kernel(
                 const int64_t f = first_idx[cld];
                 const bool own = (int64_t)p >= f && (int64_t)p < f + num_pts[cld];
                 n = own ? cld : n;
-                cur_r = own ? rs[cld] : cur_r;
+                if (PH != 1) cur_r = own ? (PREP ? __hip_atomic_load(&rs[cld], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : rs[cld]) : cur_r;
             }
         }
         const int nn = max(n, 0);
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        f2 gx2 = {0.0f, 0.0f}, gy2 = {0.0f, 0.0f};  // the lane's two column slots, summed at the end
+        if constexpr (PH != 1) {
         // ---- occupancy window (rasterize_points_backward.cu:141-178) ---------------------------------------
         const float cur_r2 = cur_r * cur_r;
         int xlo = 0, xhi = -1, ylo = 0, yhi = -1;
@@ -1143,9 +1578,7 @@ __global__ __launch_bounds__(256) void render_backward_kernel(
         const int ow = xhi - xlo + 1, oh = yhi - ylo + 1;          // 0 for an empty window
         const int ncp = (tasks_max<TPW>(ow) + 31) >> 5;             // column-slot pairs: wave-uniform
         const int nrow = (tasks_max<TPW>(oh) + RP - 1) / RP;        // rows per lane row: wave-uniform
-        typedef float f2 __attribute__((ext_vector_type(2)));
-        f2 gx2 = {0.0f, 0.0f}, gy2 = {0.0f, 0.0f};  // the lane's two column slots, summed at the end
-        const float *__restrict__ gimg = grad_alpha + (size_t)nn * plane;
+        const float *__restrict__ gimg = grad_alpha + (size_t)nn * plane * astride;
         for (int cp = 0; cp < ncp; ++cp) {
             // this lane's two columns of the pass: x0 = xlo + 32 cp + l, x1 = x0 + 16 (clamped: masked, in bounds)
             const int x0 = xlo + 32 * cp + l, x1 = x0 + 16;
@@ -1171,9 +1604,11 @@ __global__ __launch_bounds__(256) void render_backward_kernel(
                 if (A32) {
                     // unconditional loads from clamped (always valid) addresses, masked afterwards: no exec-mask branch
                     // around every load, 32-bit byte offsets from the tensor base
-                    const uint32_t S4 = (uint32_t)S * 4u;
-                    const uint32_t w0 = ((uint32_t)nn * (uint32_t)plane + (uint32_t)(o_ok ? i0 : 0)) * 4u;
-                    const uint32_t w1 = ((uint32_t)nn * (uint32_t)plane + (uint32_t)(o_ok ? i1 : 0)) * 4u;
+                    // (without the dense plane: the alpha channel of grad_out in place, `astride` floats per pixel)
+                    const uint32_t e4 = 4u * (uint32_t)astride;
+                    const uint32_t S4 = (uint32_t)S * e4;
+                    const uint32_t w0 = ((uint32_t)nn * (uint32_t)plane + (uint32_t)(o_ok ? i0 : 0)) * e4;
+                    const uint32_t w1 = ((uint32_t)nn * (uint32_t)plane + (uint32_t)(o_ok ? i1 : 0)) * e4;
 #pragma unroll
                     for (int u = 0; u < RB; ++u) {
                         const int i = rp + RP * (ib + u);   // window row of this lane row
@@ -1190,8 +1625,8 @@ __global__ __launch_bounds__(256) void render_backward_kernel(
                     const bool r_ok = i < oh;
                     g0[u] = 0.0f;
                     g1[u] = 0.0f;
-                    if (r_ok && c0) g0[u] = gimg[i0 - i * S];
-                    if (r_ok && c1) g1[u] = gimg[i1 - i * S];
+                    if (r_ok && c0) g0[u] = gimg[(size_t)(i0 - i * S) * astride];
+                    if (r_ok && c1) g1[u] = gimg[(size_t)(i1 - i * S) * astride];
                 }
                 }
                 const float y_ib = ndc(ylo + rp + RP * ib);
@@ -1223,12 +1658,13 @@ __global__ __launch_bounds__(256) void render_backward_kernel(
                 if (ndc.pow2) consume(std::true_type{}); else consume(std::false_type{});
             }
         }
+        }
         float gx = gx2.x + gx2.y, gy = gy2.x + gy2.y;
         // ---- blend backward over the splat's own bounding box (a fragment with idx == p can only exist there) ---
         float acc[CM];
 #pragma unroll
         for (int ch = 0; ch < CM; ++ch) acc[ch] = 0.0f;
-        if (grad_feat != nullptr) {
+        if (PH != 2 && grad_feat != nullptr) {
             int bxlo = 0, bxhi = -1, bylo = 0, byhi = -1;
             bool b_ok = n >= 0 && ndc_index_range_tight(px, rx, S, bxlo, bxhi) && ndc_index_range_tight(py, ry, S, bylo, byhi);
             int bl_hi = 0;   // CYC: band row of box row bylo (box rows are band rows bl_hi, bl_hi - 1, ...)
@@ -1388,12 +1824,22 @@ __global__ __launch_bounds__(256) void render_backward_kernel(
             }
         }
         // ---- per-task reductions, clip, stores -------------------------------------------------------------
-        gx = task_sum<RP>(gx, grp);
-        gy = task_sum<RP>(gy, grp);
+        if (PH != 1) {
+            gx = task_sum<RP>(gx, grp);
+            gy = task_sum<RP>(gy, grp);
+        }
+        if (PH != 2) {
 #pragma unroll
-        for (int ch = 0; ch < CM; ++ch)
-            if (ch < Cn) acc[ch] = task_sum<RP>(acc[ch], grp);
-        if (l == 0 && rp == 0 && p >= 0 && n >= 0) {
+            for (int ch = 0; ch < CM; ++ch)
+                if (ch < Cn) acc[ch] = task_sum<RP>(acc[ch], grp);
+        }
+        if (PH == 1) {
+            if (l == 0 && rp == 0 && p >= 0 && n >= 0 && grad_feat) {
+#pragma unroll
+                for (int ch = 0; ch < CM; ++ch)
+                    if (ch < Cn) grad_feat[(size_t)p * Cn + ch] = acc[ch];
+            }
+        } else if (l == 0 && rp == 0 && p >= 0 && n >= 0) {
             if (clip > 0.0f) {  // rasterizer.py:667-673 (z gradient is 0 on this path)
                 const float nrm = sqrtf(gx * gx + gy * gy);
                 const float k = fminf(nrm, clip) * fast_rcp(fmaxf(nrm, 1e-12f));   // 1-ulp reciprocal instead of two divides
@@ -1425,7 +1871,7 @@ __global__ __launch_bounds__(256) void render_backward_kernel(
             grad_pts[3 * (size_t)p] = o0;
             grad_pts[3 * (size_t)p + 1] = o1;
             grad_pts[3 * (size_t)p + 2] = o2;
-            if (grad_feat) {
+            if (PH == 0 && grad_feat) {
 #pragma unroll
                 for (int ch = 0; ch < CM; ++ch)
                     if (ch < Cn) grad_feat[(size_t)p * Cn + ch] = acc[ch];
@@ -1433,6 +1879,19 @@ __global__ __launch_bounds__(256) void render_backward_kernel(
         }
         if (!more) break;
         t_cur = t_next;
+    }
+    };
+    if (!PREP) {
+        run_tasks(std::integral_constant<int, 0>{});
+    } else {
+        // the half of every task that needs no search radius, while the first workgroups select the medians
+        PREP_MARK(0);
+        if (has_tasks) run_tasks(std::integral_constant<int, 1>{});
+        PREP_MARK(1);
+        fb_wait_rs(F, N, fb_launch_tag());
+        PREP_MARK(2);
+        if (has_tasks) run_tasks(std::integral_constant<int, 2>{});
+        PREP_MARK(3);
     }
 }
 
@@ -1470,8 +1929,9 @@ using namespace dss;
 
 // Workspace of the two-launch preparation (P <= PREP_MAX_POINTS), relative to its own base.
 struct PrepLayout {
-    size_t seg_count, vis_list, vis_keys, chunk_hist, seg_range, rs, alpha, bytes;
+    size_t seg_count, vis_list, vis_keys, chunk_hist, seg_range, rs, alpha, tags, bytes;
     int chunks, per;  // segments, points per thread of the compaction kernel (segment = per * 1024 points)
+    int f_chunks, f_per;  // single-launch backward (fb_prep_segment): segments of f_per * 256 points, at most 64
 };
 static PrepLayout prep_layout(int N, int64_t P, int S)
 {
@@ -1480,12 +1940,16 @@ static PrepLayout prep_layout(int N, int64_t P, int S)
     L.per = prep_points_per_thread(P);
     const size_t seg = (size_t)L.per * PREP_THREADS;
     L.chunks = (int)((p + seg - 1) / seg);
+    L.f_per = 1;
+    while (L.f_per < 16 && (size_t)L.f_per * FB_THREADS * PREP_MAX_SEG < p) L.f_per *= 2;
+    L.f_chunks = (int)((p + (size_t)L.f_per * FB_THREADS - 1) / ((size_t)L.f_per * FB_THREADS));
     size_t off = 0;
     L.seg_count = off;  off += 256;                                              // PREP_MAX_SEG counters
     L.vis_list = off;   off += align_up(p * 4, 256);
     L.vis_keys = off;   off += align_up(p * 8, 256);
-    L.chunk_hist = off; off += align_up(n * (size_t)L.chunks * 256 * 4, 256);
-    L.seg_range = off;  off += align_up(n * (size_t)L.chunks * 8, 256);
+    L.chunk_hist = off; off += align_up(n * (size_t)PREP_MAX_SEG * 256 * 4, 256);   // (either segmentation: <= 64 segments)
+    L.seg_range = off;  off += align_up(n * (size_t)PREP_MAX_SEG * 8, 256);
+    L.tags = off;       off += align_up((size_t)FB_TAGS * 8, 256);   // rs tags of the fused gather launch
     L.rs = off;         off += align_up(n * 4, 256);
     L.alpha = off;      off += align_up(n * (size_t)(S > 0 ? S : 0) * (size_t)(S > 0 ? S : 0) * 4, 256);  // S = 0: none
     L.bytes = off;
@@ -1726,7 +2190,97 @@ static int render_backward_impl(bool run_prep, const float *grad_out, const int3
     const size_t npix = (size_t)N * rows * S;
     const float *alpha;
     if (((uintptr_t)grad_out & 15u) && C == 3) { set_error("dss_render_backward: grad_out must be 16-byte aligned"); return DSS_ERR_INVALID_ARGUMENT; }
+    // persistent grid = exactly the resident capacity of the chip for this kernel (a larger grid would
+    // leave late workgroups waiting for slots while their share of the list sits idle)
+    // Cached per DEVICE ordinal (api.hip: four atomic slots per device -- CU count, capacity for C == 3, capacity for the
+    // generic-channel kernel): sized by the <C, true, 4, true> instantiation, the variant with the most registers, so the
+    // grid never exceeds the resident capacity of whichever variant is launched below.  Racing first callers compute and
+    // store the same values.
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::atomic<int> *dc = device_cache(dev);
+    int n_cus = dc ? dc[0].load(std::memory_order_relaxed) : 0;
+    int cap = dc ? dc[C == 3 ? 1 : 2].load(std::memory_order_relaxed) : 0;
+    if (cap == 0 || n_cus == 0) {
+        int cus = 256, per_cu = 4;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        if (C == 3)
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_backward_kernel<3, true, 4, true>, 256, 0);
+        else
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_backward_kernel<0, true, 4, true>, 256, 0);
+        if (per_cu < 1) per_cu = 1;
+        n_cus = cus;
+        cap = cus * per_cu;
+        (void)hipGetLastError();
+        if (dc) {
+            dc[0].store(n_cus, std::memory_order_relaxed);
+            dc[C == 3 ? 1 : 2].store(cap, std::memory_order_relaxed);
+        }
+    }
+    const unsigned pgrid = (unsigned)((P + 3) / 4 < cap ? (P + 3) / 4 : cap);
+    const uint32_t large_waves = 6u * (uint32_t)n_cus * 4u;
+    // tasks per wavefront: four when the list is long enough to keep every resident wavefront busy with whole groups
+    // (throughput-bound), fewer -- more lanes per task, shorter dependent chains -- for short lists.  The visible count is
+    // only known on the device; P bounds it and the visible fraction of a rendered cloud is 30-60 %.
+    const int tpw_opt = option(DSS_OPT_BACKWARD_TPW);
+    const long long est_tasks = (long long)P * 2 / 5;
+    int tpw = est_tasks >= 16ll * cap * 4 ? 4 : (est_tasks >= 4ll * cap * 4 ? 2 : 1);
+    if (tpw_opt == 1 || tpw_opt == 2 || tpw_opt == 4) tpw = tpw_opt;
+    // 32-bit byte offsets from the tensor bases (one VALU per gather address instead of 64-bit index arithmetic) whenever
+    // every gathered tensor is smaller than 4 GB; larger problems take the 64-bit addressing, four tasks per wavefront
+    const unsigned long long widest = (unsigned long long)N * (unsigned long long)rows * (unsigned long long)S *
+                                      (unsigned long long)(K > C + 1 ? K : C + 1) * 4ull;
+    // (DSS_OPT_BACKWARD_ADDR64 forces the 64-bit variant: it only exists for tensors nobody allocates in a test)
+    const bool a32 = widest < (1ull << 32) && option(DSS_OPT_BACKWARD_ADDR64) != 1;
+    if (!a32) tpw = 4;
+    if (!a32 && world) { set_error("dss_render_backward: the fused projection needs gathered tensors below 4 GB"); return DSS_ERR_UNSUPPORTED; }
+    // Round-4 preparation of short lists (fb_prep_kernel / fb_median): whole image, 32-bit offsets, at most 64 clouds.
+    // DSS_OPT_BACKWARD_FUSED: 0 = automatic, 1 = the round-3 launch sequence, 4 = two launches (segments + alpha plane |
+    // medians + gather), 5 = three (segments + alpha plane | medians | gather).
+    int fused_opt = option(DSS_OPT_BACKWARD_FUSED);
+    if (fused_opt == 0) fused_opt = DSS_BACKWARD_FUSED_DEFAULT;
+    FusedPrep FP = FusedPrep();
+    const int astride = 1;
+    bool fused = false;
     if (small) {
+        const PrepLayout L = prep_layout(N, P, S);
+        fused = (fused_opt == 4 || fused_opt == 5) && rows == S && !cyc && a32 && N <= 64 && (unsigned)N + 8u <= pgrid;
+        if (fused) {
+            n_seg = L.f_chunks;
+            seg_pts = L.f_per * FB_THREADS;
+            vis_count = reinterpret_cast<uint32_t *>(w + L.seg_count);
+            vis_list = reinterpret_cast<int32_t *>(w + L.vis_list);
+            rs = rs_out ? rs_out : reinterpret_cast<float *>(w + L.rs);
+            FP.visible = visible; FP.seg_count = vis_count; FP.vis_list = vis_list;
+            FP.keys = reinterpret_cast<uint32_t *>(w + L.vis_keys);
+            FP.chunk_hist = reinterpret_cast<uint32_t *>(w + L.chunk_hist);
+            FP.seg_range = reinterpret_cast<uint2 *>(w + L.seg_range);
+            FP.tags = reinterpret_cast<unsigned long long *>(w + L.tags);
+            FP.rs = rs; FP.P = P;
+            FP.chunks = L.f_chunks; FP.per = L.f_per; FP.radii_s = radii_s;
+            float *plane = reinterpret_cast<float *>(w + L.alpha);
+            alpha = plane;
+            if (run_prep) {
+                // stage 1: one workgroup per segment + the dense alpha plane in extra workgroups
+                const unsigned alpha_wgs = (unsigned)((npix + FB_ALPHA_PER_WG - 1) / FB_ALPHA_PER_WG);
+#define DSS_LAUNCH_FB_PREP(PER_)                                                                                          \
+    hipLaunchKernelGGL(fb_prep_kernel<PER_>, dim3((unsigned)L.f_chunks + alpha_wgs), dim3(FB_THREADS), 0, st, FP, radii,   \
+                       first_idx, num_pts, N, grad_pts, grad_feat, C, grad_out, plane, npix)
+                switch (L.f_per) {
+                    case 1: DSS_LAUNCH_FB_PREP(1); break;
+                    case 2: DSS_LAUNCH_FB_PREP(2); break;
+                    case 4: DSS_LAUNCH_FB_PREP(4); break;
+                    case 8: DSS_LAUNCH_FB_PREP(8); break;
+                    default: DSS_LAUNCH_FB_PREP(16); break;
+                }
+#undef DSS_LAUNCH_FB_PREP
+                if (fused_opt == 5)
+                    hipLaunchKernelGGL(fb_median_kernel, dim3((unsigned)N), dim3(FB_THREADS), 0, st, FP, first_idx, num_pts);
+            }
+        }
+    }
+    if (small && !fused) {
         const PrepLayout L = prep_layout(N, P, S);
         n_seg = L.chunks;
         seg_pts = L.per * PREP_THREADS;
@@ -1744,7 +2298,7 @@ static int render_backward_impl(bool run_prep, const float *grad_out, const int3
                 hipLaunchKernelGGL(band_filter_kernel<4>, dim3(L.chunks), dim3(PREP_THREADS), 0, st, points, radii, rs,
                                    first_idx, num_pts, N, S, row0, rows, vis_count, vis_list, grad_pts, grad_feat, C, tshift);
         }
-    } else {
+    } else if (!small) {
         const size_t hist_bytes = (size_t)3 * N * MED_BINS * 4;
         const CellGrid cg = make_cells(N, S);
         uint32_t *hist = reinterpret_cast<uint32_t *>(w);
@@ -1791,55 +2345,47 @@ static int render_backward_impl(bool run_prep, const float *grad_out, const int3
                            cell_start, block_hist, sorted);
         }
     }
-    // persistent grid = exactly the resident capacity of the chip for this kernel (a larger grid would
-    // leave late workgroups waiting for slots while their share of the list sits idle)
-    // Cached per DEVICE ordinal (api.hip: four atomic slots per device -- CU count, capacity for C == 3, capacity for the
-    // generic-channel kernel): sized by the <C, true, 4, true> instantiation, the variant with the most registers, so the
-    // grid never exceeds the resident capacity of whichever variant is launched below.  Racing first callers compute and
-    // store the same values.
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    std::atomic<int> *dc = device_cache(dev);
-    int n_cus = dc ? dc[0].load(std::memory_order_relaxed) : 0;
-    int cap = dc ? dc[C == 3 ? 1 : 2].load(std::memory_order_relaxed) : 0;
-    if (cap == 0 || n_cus == 0) {
-        int cus = 256, per_cu = 4;
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-        if (C == 3)
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_backward_kernel<3, true, 4, true>, 256, 0);
-        else
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_backward_kernel<0, true, 4, true>, 256, 0);
-        if (per_cu < 1) per_cu = 1;
-        n_cus = cus;
-        cap = cus * per_cu;
-        (void)hipGetLastError();
-        if (dc) {
-            dc[0].store(n_cus, std::memory_order_relaxed);
-            dc[C == 3 ? 1 : 2].store(cap, std::memory_order_relaxed);
+    if (fused) {
+        // the gather launch, with the preparation stages the mode puts inside it (run_prep false: the gather stage alone,
+        // on what a preceding full call left in the workspace)
+        // Its workgroups WAIT for the medians, so the grid must not exceed what is resident at once for THIS instantiation
+        // (a late workgroup would start its two halves when the others end theirs): capacity per variant, cached in
+        // slots 4.. of the device cache.
+        unsigned fgrid = pgrid;
+        if (run_prep && fused_opt != 5) {
+            const int slot = 4 + (C == 3 ? 0 : 3) + (tpw == 4 ? 2 : (tpw == 2 ? 1 : 0));
+            int fcap = dc ? dc[slot].load(std::memory_order_relaxed) : 0;
+            if (fcap == 0) {
+                int per_cu = 0;
+#define DSS_OCC_F(CC, TT) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_backward_kernel<CC, true, TT, true, false, true>, 256, 0)
+                if (C == 3) { if (tpw == 4) DSS_OCC_F(3, 4); else if (tpw == 2) DSS_OCC_F(3, 2); else DSS_OCC_F(3, 1); }
+                else { if (tpw == 4) DSS_OCC_F(0, 4); else if (tpw == 2) DSS_OCC_F(0, 2); else DSS_OCC_F(0, 1); }
+#undef DSS_OCC_F
+                (void)hipGetLastError();
+                fcap = n_cus * (per_cu > 0 ? per_cu : 1);
+                if (dc) dc[slot].store(fcap, std::memory_order_relaxed);
+            }
+            if ((unsigned)fcap < fgrid) fgrid = (unsigned)fcap;
+            if (fgrid < (unsigned)N + 8u) fgrid = (unsigned)N + 8u;
         }
+#define DSS_LAUNCH_RB_F(CC, TT, PP)                                                                                         \
+    hipLaunchKernelGGL((render_backward_kernel<CC, true, TT, true, false, PP>), dim3(fgrid), dim3(256), 0, st, grad_out, alpha, idx, \
+                       qvalue, wsum, scaler, points, radii, rs, first_idx, num_pts, vis_count, vis_list, n_seg, seg_pts, N, S, K, C, \
+                       clip, row0, rows, large_waves, grad_feat, grad_pts, 3, world, Mproj, FP, astride)
+#define DSS_LAUNCH_RB_FT(CC, PP)                                                                                            \
+    do {                                                                                                                   \
+        if (tpw == 4) DSS_LAUNCH_RB_F(CC, 4, PP); else if (tpw == 2) DSS_LAUNCH_RB_F(CC, 2, PP); else DSS_LAUNCH_RB_F(CC, 1, PP); \
+    } while (0)
+        if (run_prep && fused_opt != 5) { if (C == 3) DSS_LAUNCH_RB_FT(3, true); else DSS_LAUNCH_RB_FT(0, true); }
+        else { if (C == 3) DSS_LAUNCH_RB_FT(3, false); else DSS_LAUNCH_RB_FT(0, false); }
+#undef DSS_LAUNCH_RB_FT
+#undef DSS_LAUNCH_RB_F
+        return check_launch("dss_render_backward");
     }
-    const unsigned pgrid = (unsigned)((P + 3) / 4 < cap ? (P + 3) / 4 : cap);
-    const uint32_t large_waves = 6u * (uint32_t)n_cus * 4u;
-    // tasks per wavefront: four when the list is long enough to keep every resident wavefront busy with whole groups
-    // (throughput-bound), fewer -- more lanes per task, shorter dependent chains -- for short lists.  The visible count is
-    // only known on the device; P bounds it and the visible fraction of a rendered cloud is 30-60 %.
-    const int tpw_opt = option(DSS_OPT_BACKWARD_TPW);
-    const long long est_tasks = (long long)P * 2 / 5;
-    int tpw = est_tasks >= 16ll * cap * 4 ? 4 : (est_tasks >= 4ll * cap * 4 ? 2 : 1);
-    if (tpw_opt == 1 || tpw_opt == 2 || tpw_opt == 4) tpw = tpw_opt;
 #define DSS_LAUNCH_RB_A(CC, SS, TT, AA)                                                                                 \
     hipLaunchKernelGGL((render_backward_kernel<CC, SS, TT, AA>), dim3(pgrid), dim3(256), 0, st, grad_out, alpha, idx, qvalue, wsum, \
                        scaler, points, radii, rs, first_idx, num_pts, vis_count, vis_list, n_seg, seg_pts, N, S, K, C, clip, \
                        row0, rows, large_waves, grad_feat, grad_pts, 3, world, Mproj)
-    // 32-bit byte offsets from the tensor bases (one VALU per gather address instead of 64-bit index arithmetic) whenever
-    // every gathered tensor is smaller than 4 GB; larger problems take the 64-bit addressing, four tasks per wavefront
-    const unsigned long long widest = (unsigned long long)N * (unsigned long long)rows * (unsigned long long)S *
-                                      (unsigned long long)(K > C + 1 ? K : C + 1) * 4ull;
-    // (DSS_OPT_BACKWARD_ADDR64 forces the 64-bit variant: it only exists for tensors nobody allocates in a test)
-    const bool a32 = widest < (1ull << 32) && option(DSS_OPT_BACKWARD_ADDR64) != 1;
-    if (!a32) tpw = 4;
-    if (!a32 && world) { set_error("dss_render_backward: the fused projection needs gathered tensors below 4 GB"); return DSS_ERR_UNSUPPORTED; }
 #define DSS_LAUNCH_RB(CC, SS, TT) DSS_LAUNCH_RB_A(CC, SS, TT, true)
 #define DSS_LAUNCH_RB_T(CC, SS)                                                                                        \
     do {                                                                                                               \

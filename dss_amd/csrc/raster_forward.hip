@@ -80,6 +80,16 @@ struct Spill {
     uint32_t epoch;        // unique per binning launch of this process (host counter)
 };
 
+// first thread of a binning launch: the launch's epoch, and -- for a pool pass that runs INSIDE the fine launch -- the value
+// of the pass's completion counter before this call (fail[2] counts finished pool-pass workgroups and is never reset;
+// fail[3] is what it was when the call started: the fine workgroups of spilled tiles wait for fail[2] - fail[3] to reach the
+// number of pool-pass workgroups.  Both live behind the zero region like fail[0..1]: any initial value works.)
+__device__ __forceinline__ void spill_begin(const Spill sp)
+{
+    sp.fail[1] = sp.epoch;
+    sp.fail[3] = sp.fail[2];
+}
+
 struct TileGrid {
     int S;        // image side
     int row0;     // first image row of the band
@@ -230,7 +240,7 @@ __global__ __launch_bounds__(256) void bin_kernel(
     TileGrid g, uint32_t *__restrict__ counts, int32_t *__restrict__ lists, uint32_t cap, TileQueue tq,
     Spill sp, uint8_t *__restrict__ visible_to_clear /* (P) or nullptr */)
 {
-    if (sp.ctrl && blockIdx.x == 0 && threadIdx.x == 0) sp.fail[1] = sp.epoch;
+    if (sp.ctrl && blockIdx.x == 0 && threadIdx.x == 0) spill_begin(sp);
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= P) return;
     if (visible_to_clear) visible_to_clear[p] = 0;  // saves a separate memset launch
@@ -245,7 +255,7 @@ __global__ __launch_bounds__(256) void setup_bin_kernel(const SetupArgs A, TileG
                                                         int32_t *__restrict__ lists, uint32_t cap, TileQueue tq,
                                                         Spill sp, uint8_t *__restrict__ visible_to_clear)
 {
-    if (sp.ctrl && blockIdx.x == 0 && threadIdx.x == 0) sp.fail[1] = sp.epoch;
+    if (sp.ctrl && blockIdx.x == 0 && threadIdx.x == 0) spill_begin(sp);
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= A.P) return;
     if (visible_to_clear) visible_to_clear[p] = 0;
@@ -255,17 +265,18 @@ __global__ __launch_bounds__(256) void setup_bin_kernel(const SetupArgs A, TileG
     bin_point(p, n, px, py, pz, rx, ry, g, counts, lists, cap, tq, sp);
 }
 
-// Pool pass (see struct Spill): one thread per splat.  Always launched behind the binning launch; unless some splat was
-// marked every workgroup exits on one scalar load.
-__global__ __launch_bounds__(256) void spill_kernel(
+// Pool pass (see struct Spill): workgroup `block` of `nblocks`, 256 threads, grid-stride over the splats.  Unless some splat
+// was marked every workgroup returns after one scalar load.  Runs either as the first workgroups of the fine launch
+// (dss_render_forward: fine_kernel, FineArgs::spill_wgs) or as a launch of its own behind the binning (dss_splat_bin).
+// Returns false when nothing was marked.
+__device__ __forceinline__ bool spill_pass(
     const float *__restrict__ points, const float *__restrict__ radii, const int64_t *__restrict__ first_idx,
-    const int64_t *__restrict__ num_pts, int N, int64_t P, TileGrid g, const uint32_t *__restrict__ counts, uint32_t cap,
-    Spill sp, int sorted /* 1: the lists were filled by bin_sorted_kernel (sub-list in bits 4..6 of the mask byte) */)
+    const int64_t *__restrict__ num_pts, int N, int64_t P, const TileGrid g, const uint32_t *__restrict__ counts, uint32_t cap,
+    const Spill sp, int sorted /* 1: the lists were filled by bin_sorted_kernel (sub-list in bits 4..6 of the mask byte) */,
+    unsigned block, unsigned nblocks)
 {
-    if (__builtin_amdgcn_readfirstlane((int)sp.ctrl[0]) == 0) return;
-    // grid-stride over the splats: the grid is bounded (spill_grid), so that the usual empty launch costs at most 2048
-    // workgroup dispatches whatever P is
-    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (int64_t)gridDim.x * blockDim.x) {
+    if (__builtin_amdgcn_readfirstlane((int)sp.ctrl[0]) == 0) return false;
+    for (int64_t p = (int64_t)block * blockDim.x + threadIdx.x; p < P; p += (int64_t)nblocks * blockDim.x) {
     const unsigned full = sp.mask[p];
     if (full == 0) continue;
     sp.mask[p] = 0;  // (this thread is the byte's only reader: the DSS_WS_CLEAN state is restored here)
@@ -300,6 +311,17 @@ __global__ __launch_bounds__(256) void spill_kernel(
         if (off1 != 0 && (unsigned long long)(off1 - 1u) + pos < sp.cap_entries) sp.pool[(size_t)(off1 - 1u) + pos] = (int32_t)p;
     }
     }
+    return true;
+}
+
+__global__ __launch_bounds__(256) void spill_kernel(
+    const float *__restrict__ points, const float *__restrict__ radii, const int64_t *__restrict__ first_idx,
+    const int64_t *__restrict__ num_pts, int N, int64_t P, TileGrid g, const uint32_t *__restrict__ counts, uint32_t cap,
+    Spill sp, int sorted)
+{
+    // grid-stride over the splats: the grid is bounded (spill_grid), so that the usual empty launch costs at most 2048
+    // workgroup dispatches whatever P is
+    spill_pass(points, radii, first_idx, num_pts, N, P, g, counts, cap, sp, sorted, blockIdx.x, gridDim.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -367,7 +389,7 @@ __global__ __launch_bounds__(SORT_THREADS) void setup_cell_kernel(const SetupArg
                                                                    uint8_t *__restrict__ visible_to_clear)
 {
     extern __shared__ uint32_t s_hist[];
-    if (sp.ctrl && blockIdx.x == 0 && threadIdx.x == 0) sp.fail[1] = sp.epoch;
+    if (sp.ctrl && blockIdx.x == 0 && threadIdx.x == 0) spill_begin(sp);
     for (int c = threadIdx.x; c < sg.total; c += SORT_THREADS) s_hist[c] = 0u;
     __syncthreads();
     const int64_t b0 = (int64_t)blockIdx.x * SORT_THREADS * per_thread;
@@ -663,6 +685,9 @@ struct FineArgs {
     int prio;                  // 1: raise the wave priority of heavy tiles (latency-bound launches)
     uint32_t queue_wgs;        // workgroups serving queue slots (DSS_QUEUES x slots per queue); fill workgroups follow
     uint32_t *clean_counts;    // DSS_WS_CLEAN: == counts, every owner resets what it has read; else nullptr
+    uint32_t spill_wgs;        // > 0: the first spill_wgs workgroups of the launch are the pool pass (spill_pass) over the P
+    int spill_sorted;          //      splats below; spilled tiles wait for them.  0: a launch of its own did it (or nobody)
+    int64_t P;
     int32_t *idx;
     float *zbuf;               // may be nullptr: the depth plane is not written (the fused backward never reads it)
     float *qv, *occ;
@@ -990,8 +1015,30 @@ __device__ __forceinline__ void fine_tile(const FineArgs &A_entry, const int til
         if (spilled) {
             // rare: some of the tile's sub-lists continue in the spill pool.  Usable if logging and the pool pass completed
             // and every overflowed sub-list got its whole range inside the pool; otherwise scan the whole cloud (exact, slow)
-            use_list = A.spill.pool != nullptr && __builtin_amdgcn_readfirstlane((int)A.spill.fail[0]) !=
-                                                       __builtin_amdgcn_readfirstlane((int)A.spill.fail[1]);
+            use_list = A.spill.pool != nullptr;
+            if (use_list && A.spill_wgs != 0u) {
+                // The pool pass runs in THIS launch (its first spill_wgs workgroups, dispatched before any tile): if it was
+                // needed at all -- "some mask set", read BEFORE the counter: the pass's last workgroup resets the word once
+                // the counter is complete -- wait until every one of its workgroups has finished; then make their plain
+                // stores (pool entries; released by each of them with an agent-scope fence: the XCDs' L2s are not coherent)
+                // visible to this workgroup's loads.
+                const uint32_t flagged = (uint32_t)__builtin_amdgcn_readfirstlane(
+                    (int)__hip_atomic_load(&A.spill.ctrl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                const uint32_t done0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)A.spill.fail[3]);
+                uint32_t done = (uint32_t)__builtin_amdgcn_readfirstlane(
+                    (int)__hip_atomic_load(&A.spill.fail[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) - done0;
+                if (flagged != 0u) {
+                    for (int spin = 0; spin < (1 << 24) && done < A.spill_wgs; ++spin) {
+                        __builtin_amdgcn_s_sleep(8);
+                        done = (uint32_t)__builtin_amdgcn_readfirstlane(
+                            (int)__hip_atomic_load(&A.spill.fail[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) - done0;
+                    }
+                }
+                use_list = done >= A.spill_wgs;   // (not flagged, or gave up: whole-cloud scan -- exact, slow)
+                if (use_list) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+            use_list = use_list && __builtin_amdgcn_readfirstlane((int)A.spill.fail[0]) !=
+                                       __builtin_amdgcn_readfirstlane((int)A.spill.fail[1]);
             if (use_list) {
 #pragma unroll
                 for (int q = 0; q < DSS_SUB; ++q) {
@@ -1417,9 +1464,29 @@ __global__ __launch_bounds__(FINE_THREADS) __attribute__((amdgpu_num_sgpr(96))) 
     // fill workgroups come FIRST in the grid: behind the queue workgroups they started 8-12 us into the kernel (the
     // dispatcher works through ~3000 workgroups whose slot turns out to be empty at ~3 ns each) and ended it
     const uint32_t fill_wgs = qmode ? fill_workgroups(total) : 0u;
-    if (blockIdx.x < fill_wgs) {
+    const uint32_t spill_wgs = A.spill_wgs;
+    if (blockIdx.x < spill_wgs) {
+        // Pool pass inside the fine launch (a launch of its own cost 4.7 us per step although it is empty in the common case:
+        // every workgroup returns after one scalar load).  When it did run: release this workgroup's stores (pool entries)
+        // to the other XCDs, then count it as finished; the last one to finish resets the two words only this pass and
+        // the binning use (all of its workgroups have read ctrl[0] by then).
+        const bool ran = spill_pass(A.points, A.radii, A.first_idx, A.num_pts, A.N, A.P, A.g, A.counts, A.cap, A.spill,
+                                    A.spill_sorted, blockIdx.x, spill_wgs);
+        if (!ran) return;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t before = __hip_atomic_fetch_add(&A.spill.fail[2], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            if (before - A.spill.fail[3] == spill_wgs - 1u) {
+                __hip_atomic_store(&A.spill.ctrl[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&A.spill.ctrl[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        return;
+    }
+    if (blockIdx.x - spill_wgs < fill_wgs) {
         const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-        const int t0 = (int)blockIdx.x * FILL_TILES;
+        const int t0 = (int)(blockIdx.x - spill_wgs) * FILL_TILES;
         FT_MARK(0);
         FT_VAL(8, __builtin_amdgcn_s_memrealtime());
         FT_VAL(10, -1);
@@ -1446,10 +1513,11 @@ __global__ __launch_bounds__(FINE_THREADS) __attribute__((amdgpu_num_sgpr(96))) 
         FT_VAL(9, __builtin_amdgcn_s_memrealtime());
         return;
     }
-    const uint32_t qb = blockIdx.x - fill_wgs;  // queue workgroup index (identity mode: tile id)
+    const uint32_t qb = blockIdx.x - fill_wgs - spill_wgs;  // queue workgroup index (identity mode: tile id)
     if (!qmode && (int)qb >= total) return;
-    if (qmode && clean && qb == 0 && threadIdx.x < DSS_QUEUES + 2) {
-        // state that only binning and the pool pass use: queue tails, "some mask set", pool top (contiguous words)
+    if (qmode && clean && qb == 0 && threadIdx.x < DSS_QUEUES + (spill_wgs ? 0 : 2)) {
+        // state that only binning and the pool pass use: queue tails, and -- unless the pool pass runs in this launch and
+        // resets them itself -- "some mask set", pool top (contiguous words)
         A.queue.tail[threadIdx.x] = 0;
     }
     // one workgroup per queue slot (qb -> queue qb%32, slot qb/32): a loop over several slots per workgroup was tried and
@@ -1556,7 +1624,7 @@ __global__ __launch_bounds__(64) void fine_generic_kernel(const FineArgs A)
 
 static int fine_grid(const FineArgs &A, int blocks)
 {
-    return A.queue.list ? (int)(A.queue_wgs + fill_workgroups(blocks)) : blocks;
+    return A.queue.list ? (int)(A.spill_wgs + A.queue_wgs + fill_workgroups(blocks)) : blocks;
 }
 
 template <int KMAX>
@@ -1713,6 +1781,16 @@ static unsigned spill_grid(int64_t P)
     return (unsigned)(wgs < 2048 ? (wgs > 0 ? wgs : 1) : 2048);
 }
 
+// pool-pass workgroups at the front of a fine launch: 1024 splats per 256-thread workgroup (grid-stride), at most 512 -- all
+// resident at once, so the pass's internal waits (on a publisher of the same pass) cannot starve --, a multiple of 8 so that
+// the queue workgroups keep their XCD (block b runs on XCD b mod 8)
+static uint32_t spill_workgroups_in_fine(int64_t P)
+{
+    const int64_t wgs = (P + 1023) / 1024;
+    const uint32_t n = (uint32_t)(wgs < 512 ? (wgs > 0 ? wgs : 1) : 512);
+    return (n + 7u) & ~7u;
+}
+
 // queue-serving workgroups of a fine launch over `g` (band): one per slot of the band's queues
 static uint32_t queue_workgroups(int N, const TileGrid &g)
 {
@@ -1823,6 +1901,7 @@ static int splat_fine_impl(const float *points, const float *ellipse, const floa
     A.spill.cursor = nullptr; A.spill.offset = nullptr; A.spill.mask = nullptr; A.spill.ctrl = nullptr; A.spill.fail = nullptr;
     A.spill.pool = nullptr; A.spill.cap_entries = 0;
     A.clean_counts = nullptr;
+    A.spill_wgs = 0; A.spill_sorted = 0; A.P = P;   // (the pool pass ran behind the binning: dss_splat_bin)
     A.idx = idx; A.zbuf = zbuf; A.qv = qvalue; A.occ = occ; A.visible = visible;
     A.g = g; A.N = N; A.K = K; A.thr = merge_thr;
     A.scaler = scaler; A.feat = feat; A.image = image; A.wsum = wsum; A.C = C;
@@ -1985,13 +2064,9 @@ extern "C" int dss_render_forward(const float *world, const float *normals, cons
                            w.lists, w.cap, w.queue, w.spill);
         hipLaunchKernelGGL(queue_build_kernel, dim3((unsigned)((N * tiles + 1023) / 1024)), dim3(1024), 0, st, w.counts,
                            N * tiles, g, w.queue);
-        hipLaunchKernelGGL(spill_kernel, dim3(spill_grid(P)), dim3(256), 0, st, pts_screen, radii, first_idx,
-                           num_pts, N, P, g, w.counts, w.cap, w.spill, 1);
     } else if (!rerun) {
         hipLaunchKernelGGL(setup_bin_kernel, dim3(pb), dim3(tb), 0, st, SA, g, w.counts, w.lists, w.cap, w.queue, w.spill,
                            visible);
-        hipLaunchKernelGGL(spill_kernel, dim3(spill_grid(P)), dim3(256), 0, st, pts_screen, radii, first_idx,
-                           num_pts, N, P, g, w.counts, w.cap, w.spill, 0);
     }
     FineArgs A;
     A.points = pts_screen; A.ellipse = ellipse; A.cutoff = cutoff; A.radii = radii;
@@ -2001,6 +2076,11 @@ extern "C" int dss_render_forward(const float *world, const float *normals, cons
     A.queue_wgs = queue_workgroups(N, g);
     A.prio = (long long)N * tiles <= 4096;
     A.clean_counts = clean ? w.counts : nullptr;
+    // the pool pass of the sub-list overflow rides at the front of the fine launch (round 3 launched it on its own: 4.7 us
+    // per step for a pass that is empty in the common case); a fine-only re-run finds the pool filled
+    A.spill_wgs = rerun ? 0u : spill_workgroups_in_fine(P);
+    A.spill_sorted = sorted ? 1 : 0;
+    A.P = P;
     A.idx = idx; A.zbuf = zbuf; A.qv = qvalue; A.occ = occ; A.visible = visible;
     A.g = g; A.N = N; A.K = K; A.thr = merge_thr;
     A.scaler = scaler; A.feat = feat; A.image = image; A.wsum = wsum; A.C = C;

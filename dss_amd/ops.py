@@ -573,6 +573,99 @@ def render_backward(grad_out, idx, qvalue, wsum, scaler, points, radii, visible,
     return (gf, gp, rs) if return_rs else (gf, gp)
 
 
+class FusedPlan:
+    """Host-lean form of ``render_forward`` + ``render_backward`` for one problem shape (the drop-in renderer's hot path,
+    DSS/core/renderer.py:36-82 + rasterizer.py:584-664): ONE arena allocation per forward carved into the 13 output
+    tensors (only the ones somebody reads become tensor objects), the workspace looked up once, the ~45 arguments of the
+    two C entry points prebuilt with only the pointers refreshed per call.  Same kernels, same results; the general
+    functions above stay the reference for argument checking (a plan is only built from inputs they would accept)."""
+
+    _ALIGN = 256
+
+    def __init__(self, device, N, Pw, P, S, K, C, shared, per_point_h, aniso, backface, cutoff, sigma, thr, want_zbuf=True):
+        self.lib = _lib.load()
+        self.dev, self.N, self.Pw, self.P, self.S, self.K, self.C = device, N, Pw, P, S, K, C
+        self.shared, self.per_point_h, self.aniso = bool(shared), bool(per_point_h), bool(aniso)
+        off = [0]
+
+        def take(nbytes):
+            o = off[0]
+            off[0] += (int(nbytes) + self._ALIGN - 1) // self._ALIGN * self._ALIGN
+            return o
+        px = N * S * S
+        self.layout = {}   # name -> (offset, bytes, dtype, shape)
+        for name, nbytes, dt, shape in (
+                ("image", px * (C + 1) * 4, _f32, (N, S, S, C + 1)), ("pts_screen", P * 12, _f32, (P, 3)),
+                ("ellipse_params", P * 12, _f32, (P, 3)), ("radii", P * 8, _f32, (P, 2)), ("scaler", P * 4, _f32, (P,)),
+                ("cutoff_threshold", P * 4, _f32, (P,)), ("valid", P, _u8, (P,)), ("visible", P, _u8, (P,)),
+                ("idx", px * K * 4, _i32, (N, S, S, K)), ("qvalue", px * K * 4, _f32, (N, S, S, K)),
+                ("occupancy", px * 4, _f32, (N, S, S)), ("wsum", px * 4, _f32, (N, S, S))) + (
+                (("zbuf", px * K * 4, _f32, (N, S, S, K)),) if want_zbuf else ()):
+            self.layout[name] = (take(nbytes), int(nbytes), dt, shape)
+        self.total = off[0]
+        self.want_zbuf = want_zbuf
+        self.fwd_ws_bytes = self.lib.dss_render_forward_workspace(N, P, S, K)
+        self.bwd_ws_bytes = self.lib.dss_render_backward_workspace(N, P, S)
+        self.tag = ("render_forward", N, P, S)
+        self.consts = (int(shared), int(backface), S, K, float(cutoff), float(sigma), float(thr))
+        self._o = {k: v[0] for k, v in self.layout.items()}
+
+    @staticmethod
+    def lean_input(t, dtype=_f32):
+        return t is not None and t.is_cuda and t.dtype == dtype and t.is_contiguous()
+
+    def view(self, arena, name):
+        o, n, dt, shape = self.layout[name]
+        return arena[o:o + n].view(dt).view(shape)
+
+    def forward(self, world, normals, h, M, V, znear, zfar, first, num, feats, vr6=None, frame_n=None):
+        """-> arena (uint8): every output of dss_render_forward at its offset (see `view`)."""
+        lib, dev, o = self.lib, self.dev, self._o
+        N, P, S, K, C = self.N, self.P, self.S, self.K, self.C
+        shared, backface, _, _, cutoff, sigma, thr = self.consts
+        with torch.cuda.device(dev):
+            arena = torch.empty(self.total, dtype=_u8, device=dev)
+            ws = _lib.clean_workspace(dev, self.tag, self.fwd_ws_bytes)
+            b = arena.data_ptr()
+            hp = h.data_ptr()
+            rc = lib.dss_render_forward(
+                world.data_ptr(), normals.data_ptr(), hp if self.per_point_h else None, None if self.per_point_h else hp,
+                None if vr6 is None else vr6.data_ptr(), None if frame_n is None else frame_n.data_ptr(),
+                M.data_ptr(), V.data_ptr(), znear.data_ptr(), zfar.data_ptr(), first.data_ptr(), num.data_ptr(), N, P,
+                shared, backface, S, K, cutoff, sigma, thr, 0, S, 1, feats.data_ptr(), C,
+                b + o["pts_screen"], b + o["ellipse_params"], b + o["radii"], b + o["scaler"], b + o["cutoff_threshold"],
+                b + o["valid"], b + o["idx"], (b + o["zbuf"]) if self.want_zbuf else None, b + o["qvalue"], b + o["occupancy"],
+                b + o["visible"], b + o["image"], 0, 0, b + o["wsum"], ws.data_ptr(), ws.numel(), 1,
+                torch.cuda.current_stream(dev).cuda_stream)
+            if rc:
+                _lib.drop_clean_workspace(dev, self.tag)
+        _lib.check(rc, "dss_render_forward")
+        return arena
+
+    def backward(self, arena, g_image, first, num, radii_s, clip, world=None, M=None):
+        """-> (grad_features (P,C), grad_pts (P,3)) -- world-space position gradients when (world, M) are given (fused
+        projection, see render_backward)."""
+        lib, dev, o = self.lib, self.dev, self._o
+        N, P, S, K, C = self.N, self.P, self.S, self.K, self.C
+        with torch.cuda.device(dev):
+            if C == 3:
+                both = torch.empty((2, P, 3), dtype=_f32, device=dev)
+                gf, gp = both[0], both[1]
+            else:
+                gf = torch.empty((P, C), dtype=_f32, device=dev)
+                gp = torch.empty((P, 3), dtype=_f32, device=dev)
+            rs = torch.empty((N,), dtype=_f32, device=dev)
+            ws = _lib.workspace(dev, self.bwd_ws_bytes)
+            b = arena.data_ptr()
+            rc = lib.dss_render_backward(
+                g_image.data_ptr(), b + o["idx"], b + o["qvalue"], b + o["wsum"], b + o["scaler"], b + o["pts_screen"],
+                b + o["radii"], b + o["visible"], first.data_ptr(), num.data_ptr(), N, P, S, K, C, 0, S, 1, float(radii_s),
+                float(clip), gf.data_ptr(), gp.data_ptr(), rs.data_ptr(), None if world is None else world.data_ptr(),
+                None if M is None else M.data_ptr(), ws.data_ptr(), ws.numel(), torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(rc, "dss_render_backward")
+        return gf, gp
+
+
 def _aniso_args(vr6, frame_normals, Pw):
     """(ptr(vr6), ptr(frame_normals)) of the anisotropic source variance, or (None, None)."""
     if vr6 is None:

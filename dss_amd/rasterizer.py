@@ -288,12 +288,35 @@ class SurfaceSplatting(torch.nn.Module):
     def _prepare(self, point_clouds, **kwargs):
         """Everything the kernels need from the (camera, cloud) objects: packed world points / normals,
         variance scale, camera matrices, cloud ranges.  One cloud is shared by all N cameras
-        (Pointclouds.extend, rasterizer.py:236-240) or there are N clouds."""
+        (Pointclouds.extend, rasterizer.py:236-240) or there are N clouds.
+
+        A training loop calls this every iteration with the same tensors in a fresh cloud object: everything that
+        only depends on WHICH tensors / cameras / settings these are (not on their values) is memoised on their
+        identities (+ the cameras' version counters); a caller-supplied ``Vrk_h`` then makes the call free of launches."""
         raster_settings = kwargs.get("raster_settings", self.raster_settings)
         cameras = kwargs.get("cameras", self.cameras)
         if cameras is None:
             raise ValueError("Cameras must be specified either at initialization or in the forward pass")
         self.cameras = cameras
+        h_given = kwargs.get("Vrk_h", None)
+        memo_key = None
+        pl, nl = point_clouds.points_list(), point_clouds.normals_list()
+        # (only when the packed geometry IS the caller's tensor -- one cloud, or one tensor extended to the cameras: a
+        # concatenation of several tensors is a copy that has to be rebuilt from their current values)
+        if h_given is not None and (raster_settings.Vrk_invariant or raster_settings.Vrk_isotropic) and len(pl) >= 1 \
+                and all(t is pl[0] for t in pl) and nl is not None and all(t is nl[0] for t in nl):
+            cam_state = tuple(getattr(cameras, k, None) for k in ("R", "T", "znear", "zfar", "fov", "aspect_ratio"))
+            memo_key = (id(cameras), tuple(id(t) for t in cam_state), tuple(getattr(t, "_version", 0) for t in cam_state),
+                        tuple(id(t) for t in pl), None if nl is None else tuple(id(t) for t in nl),
+                        tuple(t.shape[0] for t in pl), id(h_given), h_given._version, id(raster_settings),
+                        kwargs.get("znear", None) is None, kwargs.get("zfar", None) is None)
+            hit = getattr(self, "_prepare_memo", None)
+            if hit is not None and hit[0] == memo_key:
+                a = dict(hit[1])
+                N = a["N"]
+                a["out_clouds"] = point_clouds if (not a["shared"] or len(point_clouds) == N) else point_clouds.extend(N)
+                a["raster_settings"] = raster_settings
+                return a
         N = cameras.R.shape[0]
         dev = point_clouds.device
         shared = len(point_clouds) == 1 and N >= 1
@@ -336,9 +359,14 @@ class SurfaceSplatting(torch.nn.Module):
                 return t  # the usual case: no copy, no launch
             return torch.as_tensor(t, dtype=torch.float32, device=dev).reshape(-1).expand(N).contiguous()
 
-        return dict(N=N, shared=shared, world=world, normals=normals, h=h.to(dev, torch.float32), M=M, V=V,
-                    znear=as_n("znear", 1.0), zfar=as_n("zfar", 100.0), first_idx=first_idx, num_points=num_points,
-                    out_clouds=out_clouds, raster_settings=raster_settings, vr6=vr6, frame_n=frame_n)
+        a = dict(N=N, shared=shared, world=world, normals=normals, h=h.to(dev, torch.float32), M=M, V=V,
+                 znear=as_n("znear", 1.0), zfar=as_n("zfar", 100.0), first_idx=first_idx, num_points=num_points,
+                 out_clouds=out_clouds, raster_settings=raster_settings, vr6=vr6, frame_n=frame_n)
+        if memo_key is not None:
+            # (the memo keeps the keyed objects alive -- an id cannot be recycled while it is the current entry)
+            keep = (cameras, cam_state, pl, nl, h_given, raster_settings)
+            self._prepare_memo = (memo_key, {k: v for k, v in a.items() if k not in ("out_clouds", "raster_settings")}, keep)
+        return a
 
     @staticmethod
     def _apply_activation_filter(point_clouds, point_clouds_filter):
@@ -465,6 +493,34 @@ class SurfaceSplatting(torch.nn.Module):
             return fragments, a["out_clouds"], info
         return fragments, a["out_clouds"]
 
+    def _lean_plan(self, a, feats, st):
+        """The ops.FusedPlan of this call's shape, or None when the inputs need the general (checking, converting) path."""
+        from .ops import FusedPlan
+        tensors = (a["world"], a["normals"], a["h"], a["M"], a["V"], a["znear"], a["zfar"], feats)
+        if not all(FusedPlan.lean_input(t) for t in tensors) or st.points_per_pixel > 32 or \
+                not FusedPlan.lean_input(a["first_idx"], torch.int64) or not FusedPlan.lean_input(a["num_points"], torch.int64) or \
+                (a["vr6"] is not None and not (FusedPlan.lean_input(a["vr6"]) and FusedPlan.lean_input(a["frame_n"]))):
+            return None
+        dev, N, Pw = a["world"].device, a["N"], a["world"].shape[0]
+        if a["normals"].shape != a["world"].shape or tuple(a["M"].shape) != (N, 4, 4) or tuple(a["V"].shape) != (N, 4, 4) or \
+                a["znear"].numel() != N or a["zfar"].numel() != N or a["first_idx"].numel() != N:
+            return None
+        P = N * Pw if a["shared"] else Pw
+        h = a["h"]
+        per_point = h.numel() == Pw and not (h.numel() == N and Pw == N)
+        if feats.shape[0] != P or (not per_point and h.numel() != N) or P == 0:
+            return None
+        key = (dev, N, Pw, P, int(st.image_size), int(st.points_per_pixel), feats.shape[1], bool(a["shared"]), per_point,
+               a["vr6"] is not None, bool(st.backface_culling), float(st.cutoff_threshold), float(st.antialiasing_sigma),
+               float(st.depth_merging_threshold))
+        plans = self.__dict__.setdefault("_plans", {})
+        plan = plans.get(key)
+        if plan is None:
+            if len(plans) > 8:
+                plans.clear()
+            plan = plans[key] = FusedPlan(*key)
+        return plan
+
     def render_fused(self, point_clouds, point_clouds_filter=None, **kwargs):
         """Rasterize AND blend in the fused kernels (``dss_render_forward`` / ``dss_render_backward``):
         -> ``(images (N,S,S,C+1), PointFragments, point_clouds)``.  Same values as ``forward`` + the
@@ -485,6 +541,36 @@ class SurfaceSplatting(torch.nn.Module):
         if feats.shape[1] > 8:
             raise ValueError("render_fused blends at most 8 feature channels, got %d (use the unfused forward() + "
                              "renderer for wider features)" % feats.shape[1])
+        lean = self._lean_plan(a, feats, st)
+        if lean is not None and kwargs.get("graphed", False):
+            inputs = (a["world"], a["normals"], a["h"], a["M"], a["V"], a["znear"], a["zfar"], a["first_idx"], a["num_points"],
+                      feats, a["vr6"], a["frame_n"])
+            radii_s = float(st.radii_backward_scaler)
+            clip = -1.0 if st.clip_pts_grad is None else float(st.clip_pts_grad)
+            G = self.__dict__.get("_graphed")
+            if G is None or G.plan is not lean or G.ptrs != _GraphedRender.signature(inputs) or G.radii_s != radii_s \
+                    or G.clip != clip:
+                G = self._graphed = _GraphedRender(lean, inputs, radii_s, clip, a["shared"])
+            image = _RenderFusedGraphed.apply(a["world"], feats, G)
+            arena = G.arena
+        elif lean is not None:
+            aux = (a["normals"], a["h"], a["M"], a["V"], a["znear"], a["zfar"], a["first_idx"], a["num_points"], a["vr6"],
+                   a["frame_n"], float(st.radii_backward_scaler), -1.0 if st.clip_pts_grad is None else float(st.clip_pts_grad),
+                   a["shared"])
+            image, arena = _RenderFusedLean.apply(a["world"], feats, lean, aux)
+        if lean is not None:
+            want = kwargs.get("want_fragments", True)
+            fragments = None
+            if want or (point_clouds_filter is not None and hasattr(point_clouds_filter, "set_filter")):
+                visible = lean.view(arena, "visible").view(torch.bool)
+                if want:
+                    fragments = PointFragments(idx=lean.view(arena, "idx"), zbuf=lean.view(arena, "zbuf"),
+                                               qvalue=lean.view(arena, "qvalue"), scaler=lean.view(arena, "scaler"),
+                                               occupancy=lean.view(arena, "occupancy"),
+                                               geometry=(lean.view(arena, "pts_screen"), lean.view(arena, "radii"), visible,
+                                                         a["first_idx"], a["num_points"]))
+                self._store_visibility(point_clouds_filter, visible, a["N"], a["shared"], original_clouds)
+            return image, fragments, a["out_clouds"]
         outs = _RenderFused.apply(a["world"], feats.contiguous(), a["normals"], a["h"],
                                   a["M"], a["V"], a["znear"], a["zfar"], a["first_idx"], a["num_points"],
                                   st.image_size, st.points_per_pixel, st.cutoff_threshold, st.depth_merging_threshold,
@@ -495,6 +581,98 @@ class SurfaceSplatting(torch.nn.Module):
                                    geometry=(pts_screen, radii, visible, a["first_idx"], a["num_points"]))
         self._store_visibility(point_clouds_filter, visible, a["N"], a["shared"], original_clouds)
         return image, fragments, a["out_clouds"]
+
+
+class _GraphedRender:
+    """``SurfaceSplattingRenderer(..., graphed=True)``: forward and backward of the fused renderer as two hipGraphs over
+    static buffers -- per iteration the host issues two graph launches, one copy of the incoming image gradient and two
+    small clones instead of ~10 kernel launches with their Python around them.  The graphs read the caller's tensors IN
+    PLACE (parameters updated in place by an optimiser keep their address); a changed address or shape re-captures.
+    Contract (as with any captured training step): ONE render in flight per renderer -- the image and the fragments of
+    a forward are overwritten by the next forward; backward before rendering again."""
+
+    def __init__(self, plan, inputs, radii_s, clip, shared):
+        self.plan, self.radii_s, self.clip, self.shared = plan, radii_s, clip, shared
+        self.inputs = inputs              # (world, normals, h, M, V, znear, zfar, first, num, feats, vr6, frame_n): kept alive
+        self.ptrs = self.signature(inputs)
+        world, normals, h, M, V, znear, zfar, first, num, feats, vr6, frame_n = inputs
+        dev = world.device
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.no_grad(), torch.cuda.stream(side):
+            for _ in range(2):   # warm-up on the capture stream (its clean workspace is created and zeroed here)
+                arena = plan.forward(world, normals, h, M, V, znear, zfar, first, num, feats, vr6, frame_n)
+            self.g_static = torch.zeros(plan.layout["image"][3], dtype=torch.float32, device=dev)
+            fuse = self._fuse(world)
+            plan.backward(arena, self.g_static, first, num, radii_s, clip, world if fuse else None, M if fuse else None)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph_f = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(self.graph_f, stream=side):
+            self.arena = plan.forward(world, normals, h, M, V, znear, zfar, first, num, feats, vr6, frame_n)
+        self.graph_b = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(self.graph_b, stream=side):
+            g_feat, g_pts = plan.backward(self.arena, self.g_static, first, num, radii_s, clip, world if fuse else None,
+                                          M if fuse else None)
+            if not fuse:
+                g_pts = ops.project_backward(world, M, V, first, num, g_pts, plan.view(self.arena, "valid").view(torch.bool), shared)
+            self.g_feat, self.g_world = g_feat, g_pts
+        self.image = plan.view(self.arena, "image")
+
+    def _fuse(self, world):
+        plan = self.plan
+        widest = plan.N * plan.S * plan.S * max(plan.K, plan.C + 1) * 4
+        return (not self.shared or plan.N == 1) and plan.C == 3 and world.shape[0] == plan.P and widest < (1 << 32) \
+            and ops.backward_addr64() != 1
+
+    @staticmethod
+    def signature(inputs):
+        return tuple((t.data_ptr(), tuple(t.shape)) if t is not None else None for t in inputs)
+
+
+class _RenderFusedGraphed(autograd.Function):
+    @staticmethod
+    def forward(ctx, world, features, graphed):
+        graphed.graph_f.replay()
+        ctx.graphed = graphed
+        return graphed.image.view(graphed.image.shape)
+
+    @staticmethod
+    def backward(ctx, g_image):
+        G = ctx.graphed
+        G.g_static.copy_(g_image)
+        G.graph_b.replay()
+        return G.g_world.clone(), G.g_feat.clone(), None
+
+
+class _RenderFusedLean(autograd.Function):
+    """`_RenderFused` with the host work of a call cut down (ops.FusedPlan): one arena instead of 13 output tensors, two
+    autograd outputs instead of nine, prebuilt argument lists.  Same kernels, same numbers."""
+
+    @staticmethod
+    def forward(ctx, world, features, plan, aux):
+        normals, h, M, V, znear, zfar, first, num, vr6, frame_n, radii_s, clip, shared = aux
+        arena = plan.forward(world, normals, h, M, V, znear, zfar, first, num, features, vr6, frame_n)
+        ctx.save_for_backward(world)
+        ctx.plan, ctx.arena, ctx.aux = plan, arena, (M, V, first, num, radii_s, clip, shared)
+        image = plan.view(arena, "image")
+        ctx.mark_non_differentiable(arena)
+        return image, arena
+
+    @staticmethod
+    def backward(ctx, g_image, _g_arena=None):
+        (world,) = ctx.saved_tensors
+        plan, arena = ctx.plan, ctx.arena
+        M, V, first, num, radii_s, clip, shared = ctx.aux
+        if not g_image.is_contiguous():
+            g_image = g_image.contiguous()
+        widest = plan.N * plan.S * plan.S * max(plan.K, plan.C + 1) * 4
+        fuse = (not shared or plan.N == 1) and plan.C == 3 and world.shape[0] == plan.P and widest < (1 << 32) \
+            and ops.backward_addr64() != 1
+        g_feat, g_pts = plan.backward(arena, g_image, first, num, radii_s, clip, world if fuse else None, M if fuse else None)
+        if not fuse:
+            g_pts = ops.project_backward(world, M, V, first, num, g_pts, plan.view(arena, "valid").view(torch.bool), shared)
+        return g_pts, g_feat, None, None
 
 
 class _RenderFused(autograd.Function):

@@ -50,15 +50,21 @@ class NormWeightedCompositor(torch.nn.Module):
 
 class SurfaceSplattingRenderer(torch.nn.Module):
     def __init__(self, rasterizer, compositor=None, antialiasing_sigma: float = 1.0, density: float = 1e-4,
-                 frnn_radius=-1, fused=None):
+                 frnn_radius=-1, fused=None, graphed: bool = False):
         """``fused`` (not in the reference signature): True runs rasterizer + blend as ONE autograd node on the fused
         kernels (dss_render_forward / dss_render_backward): same images, ~2x fewer launches; the only loss of generality
         is that gradients w.r.t. ``fragments.zbuf`` are not propagated.  False keeps rasterizer and blend as separate
         autograd nodes.  None (default -- what `config.create_renderer` builds from the reference's YAML, which cannot
         name the argument): fused unless the call asks for the fragments (``verbose=True``), the only way a caller can
-        put a loss on ``fragments.zbuf``."""
+        put a loss on ``fragments.zbuf``.
+        ``graphed`` (not in the reference signature either; implies the fused path): forward and backward replay as two
+        hipGraphs over static buffers (`dss_amd.rasterizer._GraphedRender`): the host cost of an iteration drops to two graph
+        launches.  The graphs read the point / normal / colour tensors in place, so keep handing over the SAME tensors
+        (parameters updated in place); one render in flight per renderer: the returned image is overwritten by the
+        next call."""
         super().__init__()
         self.fused = fused
+        self.graphed = bool(graphed)
         self.rasterizer = rasterizer
         self.compositor = compositor
         self.cameras = self.rasterizer.cameras
@@ -84,6 +90,9 @@ class SurfaceSplattingRenderer(torch.nn.Module):
                 and (point_clouds.features_packed() is None or point_clouds.features_packed().shape[1] <= 8)  # render_fused: C <= 8
                 and self.rasterizer.raster_settings.points_per_pixel <= 32):
             kw = {k: v for k, v in kwargs.items() if k != "fragments"}
+            kw["want_fragments"] = bool(kwargs.get("verbose", False))   # (only then are the fragment tensors materialised)
+            if self.graphed:
+                kw["graphed"] = True
             images, fragments, point_clouds = self.rasterizer.render_fused(point_clouds, **kw)
             if images.shape[-1] != 4:  # RGBA contract of renderer.py:75-78: first three feature channels + occupancy
                 images = torch.cat([images[..., :3], images[..., -1:]], dim=-1)

@@ -27,6 +27,17 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _backward_launch_form():
+    """DSS_TEST_BACKWARD_FUSED=1|3|4|5: run the whole session with that launch form of dss_render_backward
+    (DSS_OPT_BACKWARD_FUSED, include/dss_hip.h) instead of the automatic one -- every form must pass the same tests."""
+    v = os.environ.get("DSS_TEST_BACKWARD_FUSED")
+    if v:
+        from dss_amd import _lib
+        _lib.set_option(_lib.OPT_BACKWARD_FUSED, int(v))
+    yield
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")

@@ -185,6 +185,46 @@ def test_fused_renderer_matches_unfused(n_cams):
     assert rel(res[1][2], res[0][2]) < 1e-5 and rel(res[1][3], res[0][3]) < 1e-5
 
 
+@pytest.mark.parametrize("n_cams", [1, 2])
+def test_graphed_renderer_matches_eager_over_parameter_updates(n_cams):
+    """SurfaceSplattingRenderer(graphed=True): forward / backward replayed as two hipGraphs that read the parameters in
+    place -- three iterations with in-place updates between them must give the eager fused renderer's images and gradients
+    bit for bit (same kernels, same inputs), and a changed tensor address must re-capture instead of reading stale memory."""
+    S, K = 128, 5
+    pts, nrm = scenes.load_cloud("teapot")
+    pts = scenes.normalize_unit_sphere(pts)
+    h = torch.tensor([scenes.global_h(pts)], device=DEV)
+    col = np.random.default_rng(0).uniform(0, 1, pts.shape).astype(np.float32)
+    R, T = look_at_view_transform(2.0, 30.0, [45.0 + 100.0 * k for k in range(n_cams)])
+    cams = FoVPerspectiveCameras(znear=0.1, R=R, T=T, device=DEV)
+    st = PointsRasterizationSettings(backface_culling=False, cutoff_threshold=1.0, Vrk_invariant=True,
+                                     radii_backward_scaler=5, image_size=S, points_per_pixel=K, bin_size=None,
+                                     clip_pts_grad=0.05)
+    g = torch.from_numpy(np.random.default_rng(1).standard_normal((n_cams, S, S, 4)).astype(np.float32)).to(DEV)
+    nrm_t = torch.from_numpy(nrm).to(DEV)
+    runs = {}
+    for graphed in (False, True):
+        renderer = SurfaceSplattingRenderer(SurfaceSplatting(cameras=cams, raster_settings=st), NormWeightedCompositor(),
+                                            fused=True, graphed=graphed)
+        P = torch.nn.Parameter(torch.from_numpy(pts).to(DEV))
+        C = torch.nn.Parameter(torch.from_numpy(col).to(DEV))
+        out = []
+        for it in range(4):
+            if it == 3:   # a new tensor (new address) for the colours: the graphed mode has to notice
+                C = torch.nn.Parameter(C.detach().clone() * 0.5)
+            P.grad = C.grad = None
+            img = renderer(PointClouds3D([P], [nrm_t], [C]), Vrk_h=h)
+            (img * g).sum().backward()
+            out.append((img.detach().clone(), P.grad.clone(), C.grad.clone()))
+            with torch.no_grad():   # in-place update, like an optimiser step
+                P -= 1e-3 * P.grad
+                C -= 1e-2 * C.grad
+        runs[graphed] = out
+    for a, b in zip(runs[False], runs[True]):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    assert not torch.equal(runs[True][0][0], runs[True][1][0])   # the updates did change the render
+
+
 def test_fused_renderer_backward_with_64_bit_gather_falls_back_to_the_separate_projection():
     """with DSS_OPT_BACKWARD_ADDR64 (or gathered tensors of 4 GB and more) the gather kernel has no fused
     projection epilogue; the autograd node must then run the separate projection kernel, not raise inside backward."""

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "gpurun_out", "timeline")
 mode = sys.argv[1] if len(sys.argv) > 1 else "graph"
 subprocess.run(["rocprofv3", "--kernel-trace", "--output-format", "csv", "-d", OUT, "--", sys.executable,
-                os.path.join(ROOT, "bench.py"), "--mode", mode, "--no-cpu-baseline", "--no-traffic", "--steps", "100", "--warmup", "10"],
+                os.path.join(ROOT, "bench.py"), "--mode", mode, "--timed-only", "--steps", "100", "--warmup", "10"],
                cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
 rows = []
 for f in glob.glob(os.path.join(OUT, "**", "*kernel_trace.csv"), recursive=True):
