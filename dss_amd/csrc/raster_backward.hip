@@ -1199,7 +1199,7 @@ __device__ __forceinline__ void fb_prep_segment(const FusedPrep &F, int c, const
 // rank-k bin of a histogram held as h[NB] consecutive bins per thread (first bin of the thread: NB * tid)
 template <int NB>
 __device__ __forceinline__ void fb_select(const uint32_t (&h)[NB], uint32_t k, uint32_t *s_w /*[8]*/, uint32_t &bin_out,
-                                          uint32_t &k_out)
+                                          uint32_t &k_out, uint32_t &cnt_out)
 {
     uint32_t v = 0;
 #pragma unroll
@@ -1213,6 +1213,7 @@ __device__ __forceinline__ void fb_select(const uint32_t (&h)[NB], uint32_t k, u
             if (k >= excl && k < excl + h[i]) {
                 s_w[4] = (uint32_t)(NB * threadIdx.x + i);
                 s_w[5] = k - excl;
+                s_w[7] = h[i];
             }
             excl += h[i];
         }
@@ -1220,6 +1221,7 @@ __device__ __forceinline__ void fb_select(const uint32_t (&h)[NB], uint32_t k, u
     __syncthreads();
     bin_out = s_w[4];
     k_out = s_w[5];
+    cnt_out = s_w[7];
 }
 
 // Median of cloud n (lower median of the radius keys of its visible points, rasterizer.py:885-888) from the segments'
@@ -1298,12 +1300,13 @@ __device__ __forceinline__ float fb_median(const FusedPrep &F, int n, const int6
     const uint32_t my_cnt = s_cnt[cc];
     const uint32_t *my_keys = F.keys + (size_t)s_base[cc];
     uint32_t kmin = 0xffffffffu, kmax = 0u;
-    for (uint32_t j0 = q; j0 < my_cnt; j0 += 16) {   // four loads in flight per thread
-        uint32_t key[4];
+    constexpr int KB = 12;   // loads in flight per thread: a segment's ~40 keys of the bucket in ONE round trip
+    for (uint32_t j0 = q; j0 < my_cnt; j0 += 4 * KB) {
+        uint32_t key[KB];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) key[u] = my_keys[min(j0 + 4u * u, my_cnt - 1u)];
+        for (int u = 0; u < KB; ++u) key[u] = my_keys[min(j0 + 4u * u, my_cnt - 1u)];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < KB; ++u) {
             if (j0 + 4u * u < my_cnt) {
                 if (in_lds) s_cand[s_dst[cc] + j0 + 4u * u] = key[u];
                 kmin = min(kmin, key[u]);
@@ -1344,13 +1347,35 @@ __device__ __forceinline__ float fb_median(const FusedPrep &F, int n, const int6
         __syncthreads();
         const uint4 hq = reinterpret_cast<const uint4 *>(s_hist)[tid];
         const uint32_t h[4] = {hq.x, hq.y, hq.z, hq.w};
-        uint32_t bin;
-        fb_select<4>(h, k, s_w, bin, k);
+        uint32_t bin, left;
+        fb_select<4>(h, k, s_w, bin, k, left);
         const uint32_t nlo = lo + (bin << shift);
         const uint32_t span = (1u << shift) - 1u;
         hi = min(hi, nlo + span < nlo ? 0xffffffffu : nlo + span);
         lo = nlo;
         __syncthreads();
+        if (lo != hi && left <= 64u && in_lds) {
+            // few keys left (the usual second step: ~3 of ~2500): collect them and rank them in one wavefront instead of
+            // another histogram pass
+            if (tid == 0) s_w[6] = 0;
+            __syncthreads();
+            for (uint32_t j = tid; j < m; j += FB_THREADS) {
+                const uint32_t key = s_cand[j];
+                if (key >= lo && key <= hi) s_hist[atomicAdd(&s_w[6], 1u)] = key;
+            }
+            __syncthreads();
+            if (wid == 0) {
+                const uint32_t mine = (uint32_t)lane < left ? s_hist[lane] : 0xffffffffu;
+                uint32_t rank = 0;
+                for (uint32_t j = 0; j < left; ++j) {
+                    const uint32_t kj = (uint32_t)__builtin_amdgcn_readlane((int)mine, (int)j);
+                    rank += (kj < mine || (kj == mine && j < (uint32_t)lane)) ? 1u : 0u;
+                }
+                if ((uint32_t)lane < left && rank == k) s_w[6] = mine;
+            }
+            __syncthreads();
+            lo = hi = s_w[6];
+        }
     }
     PREP_MARK(7);
     return key_float(lo) * F.radii_s;
@@ -1523,14 +1548,32 @@ __global__ __launch_bounds__(256) void render_backward_kernel(
     const NdcMap ndc(S);
     const size_t plane = (size_t)rows * S;
     // PH 0: whole tasks; 1: the blend half only (needs no search radius); 2: the occupancy half only
+    // PREP: the groups of a WORKGROUP (those its four wavefronts would take statically: 4 b + w + k n_waves) are shared by
+    // its wavefronts through an LDS counter -- with ~4.3 groups per wavefront at the DSS sizes a static deal leaves every
+    // fourth wavefront one group (25 %) more than its neighbours and the launch ends with them.  i-th group of the
+    // workgroup: 4 b + (i & 3) + (i >> 2) n_waves (increasing in i).
+    __shared__ uint32_t s_deal[2];
+    const uint32_t blk4 = (blockIdx.x - first_block) * 4u;
+    auto dyn_group = [&](uint32_t i) -> uint32_t { return blk4 + (i & 3u) + (i >> 2) * n_waves; };
+    if (PREP) {
+        if (threadIdx.x < 2) s_deal[threadIdx.x] = 4u;   // (indices 0..3 are the wavefronts' first groups)
+        __syncthreads();
+    }
     auto run_tasks = [&](auto phase_tag) {
     constexpr int PH = decltype(phase_tag)::value;
     uint32_t t_cur = t_first;
     int p_nx = task_ids(wave_u);
     for (;;) {
         const int p = p_nx;
-        const uint32_t t_next = t_cur + t_stride;
-        const uint32_t q_next = qof(t_next);
+        uint32_t t_next, q_next;
+        if (PREP) {
+            uint32_t i_next = 0;
+            if (lane == 0) i_next = atomicAdd(&s_deal[PH == 2 ? 1 : 0], 1u);
+            q_next = t_next = dyn_group((uint32_t)__builtin_amdgcn_readfirstlane((int)i_next));
+        } else {
+            t_next = t_cur + t_stride;
+            q_next = qof(t_next);
+        }
         const bool more = q_next < n_groups;
         if (more) p_nx = task_ids(q_next);  // in flight during this group
         // ---- record + cloud of the task's point ------------------------------------------------------------

@@ -573,6 +573,22 @@ def render_backward(grad_out, idx, qvalue, wsum, scaler, points, radii, visible,
     return (gf, gp, rs) if return_rs else (gf, gp)
 
 
+class _NoSwitch:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+_NO_SWITCH = _NoSwitch()
+
+
+def _on_device(dev):
+    """`torch.cuda.device(dev)` only when `dev` is not already the current device (the context manager costs ~5 us)"""
+    return _NO_SWITCH if torch.cuda.current_device() == dev.index else torch.cuda.device(dev)
+
+
 class FusedPlan:
     """Host-lean form of ``render_forward`` + ``render_backward`` for one problem shape (the drop-in renderer's hot path,
     DSS/core/renderer.py:36-82 + rasterizer.py:584-664): ONE arena allocation per forward carved into the 13 output
@@ -618,12 +634,17 @@ class FusedPlan:
         o, n, dt, shape = self.layout[name]
         return arena[o:o + n].view(dt).view(shape)
 
+    def image(self, arena):
+        """the (N,S,S,C+1) image at offset 0 of the arena"""
+        n, shape = self.layout["image"][1], self.layout["image"][3]
+        return arena[:n].view(_f32).view(shape)
+
     def forward(self, world, normals, h, M, V, znear, zfar, first, num, feats, vr6=None, frame_n=None):
         """-> arena (uint8): every output of dss_render_forward at its offset (see `view`)."""
         lib, dev, o = self.lib, self.dev, self._o
         N, P, S, K, C = self.N, self.P, self.S, self.K, self.C
         shared, backface, _, _, cutoff, sigma, thr = self.consts
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             arena = torch.empty(self.total, dtype=_u8, device=dev)
             ws = _lib.clean_workspace(dev, self.tag, self.fwd_ws_bytes)
             b = arena.data_ptr()
@@ -647,7 +668,7 @@ class FusedPlan:
         projection, see render_backward)."""
         lib, dev, o = self.lib, self.dev, self._o
         N, P, S, K, C = self.N, self.P, self.S, self.K, self.C
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             if C == 3:
                 both = torch.empty((2, P, 3), dtype=_f32, device=dev)
                 gf, gp = both[0], both[1]

@@ -28,45 +28,59 @@ __all__ = ["PointFragments", "PointsRasterizationSettings", "SurfaceSplatting", 
            "EllipticalRasterizer", "knn_variance_scale"]
 
 
-class PointFragments:
-    """rasterizer.py:31-36: ``(idx, zbuf, qvalue, scaler, occupancy)`` with the reference's shapes -- a tuple-like object
-    (fields, order, unpacking, ``_replace`` / ``_asdict`` as on the reference's NamedTuple).  Not a ``tuple`` SUBCLASS (the
-    lazily materialised ``scaler`` needs a mutable slot): ``isinstance(fragments, tuple)`` is False, ``tuple(fragments)``
-    converts.
+class PointFragments(tuple):
+    """rasterizer.py:31-36: ``(idx, zbuf, qvalue, scaler, occupancy)`` with the reference's shapes -- a real ``tuple``
+    subclass like the reference's NamedTuple (``isinstance(fragments, tuple)``, unpacking, indexing, ``len``, ``_fields``,
+    ``_replace`` / ``_asdict``), with named fields.
 
     ``scaler`` is the per-FRAGMENT ``(N, H, W, K)`` tensor of rasterizer.py:631-633 (0 where ``idx < 0``), but it is only
-    materialised when somebody reads it: the kernels consume the per-point ``scaler_packed (P,)`` (the gather is fused
-    into the blend).  ``geometry`` = (pts_screen, radii, visible, first_idx, num_points) lets the blend backward run as a
-    deterministic point-centric gather instead of an atomic scatter; None is always legal."""
+    materialised when somebody reads it (field, index 3, iteration): the kernels consume the per-point ``scaler_packed
+    (P,)`` (the gather is fused into the blend).  ``geometry`` = (pts_screen, radii, visible, first_idx, num_points) lets
+    the blend backward run as a deterministic point-centric gather instead of an atomic scatter; None is always legal."""
     _fields = ("idx", "zbuf", "qvalue", "scaler", "occupancy")
-    __slots__ = ("idx", "zbuf", "qvalue", "_scaler", "occupancy", "geometry", "scaler_packed")
 
-    def __init__(self, idx, zbuf, qvalue, scaler, occupancy, geometry=None):
-        self.idx, self.zbuf, self.qvalue, self.occupancy, self.geometry = idx, zbuf, qvalue, occupancy, geometry
-        if scaler is not None and scaler.dim() == 1:   # per point: keep packed, gather lazily
-            self.scaler_packed, self._scaler = scaler, None
-        else:
-            self.scaler_packed, self._scaler = None, scaler
+    def __new__(cls, idx, zbuf, qvalue, scaler, occupancy, geometry=None):
+        packed = scaler is not None and scaler.dim() == 1   # per point: keep packed, gather lazily
+        self = tuple.__new__(cls, (idx, zbuf, qvalue, None if packed else scaler, occupancy))
+        self.geometry = geometry
+        self.scaler_packed = scaler if packed else None
+        self._scaler = None if packed else scaler
+        return self
+
+    idx = property(lambda self: tuple.__getitem__(self, 0))
+    zbuf = property(lambda self: tuple.__getitem__(self, 1))
+    qvalue = property(lambda self: tuple.__getitem__(self, 2))
+    occupancy = property(lambda self: tuple.__getitem__(self, 4))
 
     @property
     def scaler(self):
         if self._scaler is None and self.scaler_packed is not None:
-            valid = self.idx >= 0
-            self._scaler = torch.where(valid, self.scaler_packed[self.idx.clamp_min(0).long()],
-                                       torch.zeros((), dtype=self.scaler_packed.dtype, device=self.idx.device))
+            idx = self.idx
+            self._scaler = torch.where(idx >= 0, self.scaler_packed[idx.clamp_min(0).long()],
+                                       torch.zeros((), dtype=self.scaler_packed.dtype, device=idx.device))
         return self._scaler
 
     def __iter__(self):
         return iter((self.idx, self.zbuf, self.qvalue, self.scaler, self.occupancy))
 
-    def __len__(self):
-        return 5
-
     def __getitem__(self, i):
-        return tuple(self)[i]
+        return (self.idx, self.zbuf, self.qvalue, self.scaler, self.occupancy)[i]
+
+    def __eq__(self, other):
+        return self is other
+
+    def __ne__(self, other):
+        return self is not other
+
+    __hash__ = object.__hash__
+
+    def __reduce__(self):   # (pickling / copy: the materialised form)
+        return (PointFragments, (self.idx, self.zbuf, self.qvalue,
+                                 self.scaler_packed if self.scaler_packed is not None else self._scaler, self.occupancy,
+                                 self.geometry))
 
     def _asdict(self):
-        return dict(zip(self._fields, tuple(self)))
+        return dict(zip(self._fields, tuple(iter(self))))
 
     def _replace(self, **kw):
         d = dict(idx=self.idx, zbuf=self.zbuf, qvalue=self.qvalue, occupancy=self.occupancy, geometry=self.geometry,
@@ -76,7 +90,7 @@ class PointFragments:
 
     def __repr__(self):
         return "PointFragments(idx=%r, zbuf=%r, qvalue=%r, scaler=<%s>, occupancy=%r)" % (
-            tuple(self.idx.shape), tuple(self.zbuf.shape), tuple(self.qvalue.shape),
+            tuple(self.idx.shape), None if self.zbuf is None else tuple(self.zbuf.shape), tuple(self.qvalue.shape),
             "packed (P,)" if self._scaler is None else "per fragment", tuple(self.occupancy.shape))
 
 
@@ -617,7 +631,7 @@ class _GraphedRender:
             if not fuse:
                 g_pts = ops.project_backward(world, M, V, first, num, g_pts, plan.view(self.arena, "valid").view(torch.bool), shared)
             self.g_feat, self.g_world = g_feat, g_pts
-        self.image = plan.view(self.arena, "image")
+        self.image = plan.image(self.arena)
 
     def _fuse(self, world):
         plan = self.plan
@@ -627,7 +641,7 @@ class _GraphedRender:
 
     @staticmethod
     def signature(inputs):
-        return tuple((t.data_ptr(), tuple(t.shape)) if t is not None else None for t in inputs)
+        return tuple((t.data_ptr(), t.shape[0]) if t is not None else None for t in inputs)
 
 
 class _RenderFusedGraphed(autograd.Function):
@@ -642,7 +656,9 @@ class _RenderFusedGraphed(autograd.Function):
         G = ctx.graphed
         G.g_static.copy_(g_image)
         G.graph_b.replay()
-        return G.g_world.clone(), G.g_feat.clone(), None
+        # the static gradient buffers themselves: AccumulateGrad copies a gradient it cannot take ownership of (these are
+        # referenced by the graph object) or adds it into an existing .grad -- no clone here
+        return G.g_world, G.g_feat, None
 
 
 class _RenderFusedLean(autograd.Function):
@@ -655,7 +671,7 @@ class _RenderFusedLean(autograd.Function):
         arena = plan.forward(world, normals, h, M, V, znear, zfar, first, num, features, vr6, frame_n)
         ctx.save_for_backward(world)
         ctx.plan, ctx.arena, ctx.aux = plan, arena, (M, V, first, num, radii_s, clip, shared)
-        image = plan.view(arena, "image")
+        image = plan.image(arena)
         ctx.mark_non_differentiable(arena)
         return image, arena
 

@@ -95,3 +95,70 @@ def test_reference_train_mvr_unmodified_on_the_hip_kernels_at_configs2(tmp_path)
     print("resumed leg: %d iterations, %.1f ms/iteration, loss deciles %s"
           % (n, cfg3.ms_per_iteration(rtimes, rsteps), ["%.4f" % d for d in deciles]))
     assert deciles[-1] < 0.93 * deciles[0] and min(deciles[5:]) < 0.9 * deciles[0], deciles   # measured: 0.253 -> 0.21
+
+
+@pytest.mark.timeout(1200)
+def test_reference_train_mvr_converges_from_the_sphere_at_the_size_of_dss_yml(tmp_path):
+    """the configs[2]-sized model above is 20x larger than what the reference's own `configs/dss.yml:8`
+    trains (`n_points_per_cloud: 5000`), and from the sphere its loss rises.  Here the SAME unmodified script and dataset
+    (99,790-point yoga6 target, 128 CameraSampler views at 512^2, batches of 8, dss.yml raster parameters and weights) with
+    dss.yml's own model size: the loss the reference's Trainer logs must FALL (last decile < 0.8 x first decile) and the
+    model must move towards the target surface (symmetric chamfer distance to the target cloud, the quantity
+    `Trainer.evaluate_3d` (trainer.py:144) reports, lower at the end than after the first iterations)."""
+    import json
+    import numpy as np
+    import torch
+    from scipy.spatial import cKDTree
+    tmp = str(tmp_path)
+    ref = cfg3.reference_root(tmp)
+    cfg_cls, _ = cfg3.write_configs(tmp, points=5000)
+    sc = os.path.join(tmp, "scalars_5000.jsonl")
+    common = ["--reference", ref]
+    r = cfg3.run(common + ["--config", cfg_cls, "--make-dataset", os.path.join(tmp, "data"), "--views", str(cfg3.VIEWS),
+                           "--jitter", str(cfg3.JITTER), "--camera-sampler"], 600)
+    assert r.returncode == 0, r.stdout[-3000:]
+    target = np.load(os.path.join(tmp, "data", "data_dict.npz"), allow_pickle=True)["points"].astype(np.float64)
+    tree_t = cKDTree(target)
+
+    def chamfer(model_pt):
+        """squared-distance statistics between the model's points and the target cloud: the symmetric chamfer distance
+        (mean over both directions), its two halves, and the median model -> target distance"""
+        pts = torch.load(model_pt, map_location="cpu")["model"]["points"].reshape(-1, 3).double().numpy()
+        d_mt, _ = tree_t.query(pts)
+        d_tm, _ = cKDTree(pts).query(target)
+        return {"chamfer": float((d_mt ** 2).mean() + (d_tm ** 2).mean()), "target_to_model": float((d_tm ** 2).mean()),
+                "model_to_target": float((d_mt ** 2).mean()), "model_to_target_median": float(np.median(d_mt)),
+                "model_points_farther_than_0.2": float((d_mt > 0.2).mean())}
+
+    model_pt = os.path.join(tmp, "exp", "dropin", "model.pt")
+    r = cfg3.run(common + ["--config", cfg_cls, "--scalars", sc, "--exit-after", "3"], 600)   # a few iterations from the sphere
+    assert cfg3.reached_time_limit(r), r.stdout[-4000:]
+    cd_early = chamfer(model_pt)
+    loss, legs = [], 0
+    while len(loss) < 1200 and legs < 4:   # resumes from its own model.pt (train_mvr.py:98-103)
+        legs += 1
+        r = cfg3.run(common + ["--config", cfg_cls, "--scalars", sc, "--exit-after", "45"], 600)
+        assert cfg3.reached_time_limit(r), r.stdout[-4000:]
+        loss, steps, times = cfg3.losses(sc)
+    cd_late = chamfer(model_pt)
+    n = len(loss)
+    assert n >= 600, (n, legs)
+    deciles = [sum(loss[i * n // 10:(i + 1) * n // 10]) / ((i + 1) * n // 10 - i * n // 10) for i in range(10)]
+    rec = {"points_per_cloud": 5000, "iterations": n, "ms_per_iteration": cfg3.ms_per_iteration(times, steps),
+           "loss_deciles": deciles, "chamfer_after_first_iterations": cd_early, "chamfer_at_end": cd_late}
+    print("dss.yml-sized model from the sphere:", json.dumps(rec))
+    print("distances after the first iterations:", cd_early)
+    print("distances at the end               :", cd_late)
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        json.dump(rec, open(os.path.join(ROOT, "gpurun_out", "train_mvr_ref_5000.json"), "w"), indent=1)
+    except OSError:
+        pass
+    assert all(l == l and l < 1e3 for l in loss)
+    assert deciles[-1] < 0.8 * deciles[0], deciles
+    # the model moves onto the target: the target's surface gets covered (target -> model) and the typical model point sits
+    # closer to it (median).  The MEAN model -> target distance is not asserted: the reference neither prunes nor bounds its
+    # points (point_modeling.py:131-132 is commented out), and Adam(0.01) carries the handful of points whose silhouette
+    # gradient keeps its sign straight out of the view volume; both halves are recorded.
+    assert cd_late["target_to_model"] < 0.5 * cd_early["target_to_model"], (cd_early, cd_late)
+    assert cd_late["model_to_target_median"] < cd_early["model_to_target_median"], (cd_early, cd_late)

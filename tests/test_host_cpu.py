@@ -258,3 +258,22 @@ def test_merge_networks_of_the_fine_kernel_sort_every_unimodal_sequence():
         for _ in range(5000):
             x, y = sorted(rng.choices(range(9), k=n)), sorted(rng.choices(range(9), k=n))
             assert run(net, [min(x[k], y[n - 1 - k]) for k in range(n)]) == sorted(x + y)[:n]
+
+
+def test_point_fragments_is_a_tuple_like_the_reference_named_tuple():
+    """rasterizer.py:31-36 is a NamedTuple: a caller may test `isinstance(x, tuple)`, unpack, index, take `len`, use
+    `_fields` / `_asdict` / `_replace`.  The per-fragment `scaler` is materialised lazily from the per-point tensor."""
+    import pickle
+    import torch
+    from dss_amd.rasterizer import PointFragments
+    idx = torch.tensor([[[[1, 0, -1]]]], dtype=torch.int32)
+    z, q, occ = torch.zeros(1, 1, 1, 3), torch.ones(1, 1, 1, 3), torch.ones(1, 1, 1)
+    f = PointFragments(idx, z, q, torch.tensor([3.0, 4.0]), occ)
+    assert isinstance(f, tuple) and len(f) == 5 and f._fields == ("idx", "zbuf", "qvalue", "scaler", "occupancy")
+    a, b, c, d, e = f
+    assert a is idx and b is z and c is q and e is occ
+    assert d.tolist() == [[[[4.0, 3.0, 0.0]]]] and f[3] is d and f.scaler is d and tuple(f)[3] is d and f[-1] is occ
+    assert f._asdict()["scaler"] is d and f._replace(zbuf=None).zbuf is None
+    g = PointFragments(idx, z, q, d, occ)           # reference-style per-fragment scaler
+    assert g.scaler is d and g.scaler_packed is None
+    assert isinstance(pickle.loads(pickle.dumps(f)), PointFragments)

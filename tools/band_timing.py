@@ -4,7 +4,9 @@ rank's rows (contiguous equal bands and the tile-row-cyclic partition), visibili
 rendering every rank's rows once, untimed).  No collectives: this is the part of the G-GPU step that RCCL time is added
 to.  Per rank the step is timed twice: eager launches (host-bound at these sizes) and as a hipGraph replay (device time).
 
-    python tools/band_timing.py [G] -> one JSON line: per-rank microseconds, max / min spread, for both layouts"""
+    python tools/band_timing.py [G] [cfg2|cfg4|cfg5] -> one JSON line: per-rank microseconds, max / min spread, for both layouts
+(cfg2: G cameras x 32,684 points @512^2, the weak-scaling workload of `bench.py --gpus G`; cfg4 / cfg5: BASELINE configs[3] /
+configs[4] -- 8 x 1M points @1024^2 / 4M points @2048^2 -- with their rows shared by G ranks, `bench.py --gpus G --workload`)"""
 import json
 import os
 import sys
@@ -19,9 +21,14 @@ from dss_amd import ops  # noqa: E402
 from dss_amd.distributed import RowPartition  # noqa: E402
 
 G = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+which = sys.argv[2] if len(sys.argv) > 2 else "cfg2"
 dev = torch.device("cuda:0")
 S, K = bench.S, bench.K
-wl = bench.Workload(dev, G, RowPartition(S, 1, 0))   # G cameras, single-rank object (no process group needed)
+if which == "cfg2":
+    wl = bench.Workload(dev, G, RowPartition(S, 1, 0))   # G cameras, single-rank object (no process group needed)
+else:
+    cloud, S, cams = bench.large_cloud(which)
+    wl = bench.Workload(dev, cams, RowPartition(S, 1, 0), cloud=cloud)
 
 
 def fwd(rows):
@@ -40,7 +47,8 @@ def quick(fn, n=60):
     return (time.perf_counter() - t) / n * 1e6
 
 
-out = {"G": G, "cameras": G, "points_per_cloud": wl.Pc, "image_size": S}
+out = {"G": G, "workload": which, "cameras": wl.N, "points_per_cloud": wl.Pc, "image_size": S}
+N_IT = 60 if which == "cfg2" else 8
 for layout in ("bands", "cyclic"):
     parts = [RowPartition(S, G, r, cyclic=(layout == "cyclic")) for r in range(G)]
     vis_all = torch.zeros(wl.P, dtype=torch.bool, device=dev)
@@ -57,7 +65,7 @@ for layout in ("bands", "cyclic"):
             ops.render_backward(g_band, f["idx"], f["qvalue"], f["wsum"], f["scaler"], f["pts_screen"], f["radii"], vis_all,
                                 wl.first, wl.num, bench.RADII_S, -1.0, image_size=S, rows=p.rows, out=(gf, gp))
             return ops.project_backward(wl.world, wl.M, wl.V, wl.first, wl.num, gp, f["valid"], True, clip=bench.CLIP)
-        eager.append(quick(step))
+        eager.append(quick(step, N_IT))
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -68,11 +76,11 @@ for layout in ("bands", "cyclic"):
         cg = torch.cuda.CUDAGraph()
         with torch.cuda.graph(cg, stream=side):
             step()
-        graph.append(quick(cg.replay))
+        graph.append(quick(cg.replay, N_IT))
     out[layout] = {"eager_us": [round(x, 1) for x in eager], "graph_us": [round(x, 1) for x in graph],
                    "graph_max_over_min": round(max(graph) / min(graph), 3), "graph_max_us": round(max(graph), 1),
                    "eager_max_us": round(max(eager), 1)}
 one = RowPartition(S, 1, 0)
-wl1 = bench.Workload(dev, 1, one)
-out["single_gpu_step_us"] = {"eager": round(quick(wl1.step), 1)}
+wl1 = bench.Workload(dev, 1, one) if which == "cfg2" else wl
+out["single_gpu_step_us"] = {"eager": round(quick(wl1.step, N_IT), 1)}
 print(json.dumps(out))
