@@ -513,6 +513,8 @@ def main():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     if os.environ.get("BENCH_BACKWARD_FUSED"):   # development A/B: DSS_OPT_BACKWARD_FUSED (include/dss_hip.h)
         _lib.set_option(_lib.OPT_BACKWARD_FUSED, int(os.environ["BENCH_BACKWARD_FUSED"]))
+    if os.environ.get("BENCH_BACKWARD_TPW"):     # development A/B: DSS_OPT_BACKWARD_TPW
+        _lib.set_option(_lib.OPT_BACKWARD_TPW, int(os.environ["BENCH_BACKWARD_TPW"]))
     local = local % torch.cuda.device_count()  # (BENCH_DIST_BACKEND=gloo lets two ranks share one GPU in tests)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)

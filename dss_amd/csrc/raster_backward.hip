@@ -1111,10 +1111,16 @@ __device__ __forceinline__ void fb_prep_segment(const FusedPrep &F, int c, const
     const int64_t seg = (int64_t)per * FB_THREADS;
     const int64_t c0 = (int64_t)c * seg, c1 = min(c0 + seg, F.P);
     uint32_t vmask = 0;   // bit u: point c0 + u * 256 + tid is visible
+    // the radius keys of the thread's points: requested together with the flags (one memory round trip less) and kept in
+    // registers when there are few of them; larger segments re-read them where they are used
+    constexpr bool KEEP = PER <= 4;
+    const float2 *r2 = reinterpret_cast<const float2 *>(radii);
+    float2 rr[KEEP ? PER : 1];
 #pragma unroll
     for (int u = 0; u < per; ++u) {
         const int64_t i = c0 + (int64_t)u * FB_THREADS + tid;
         const uint8_t v = F.visible[min(i, F.P - 1)];
+        if (KEEP) rr[KEEP ? u : 0] = r2[min(i, F.P - 1)];
         vmask |= ((i < c1 && v != 0) ? 1u : 0u) << u;
     }
     // visible points per (u, wavefront), in list order
@@ -1149,7 +1155,6 @@ __device__ __forceinline__ void fb_prep_segment(const FusedPrep &F, int c, const
         }
     }
     // per cloud that overlaps the segment (normally one): bucket counts, their prefix, then the keys in bucket order
-    const float2 *r2 = reinterpret_cast<const float2 *>(radii);
     for (int n = 0; n < N; ++n) {
         const int64_t lo = max(c0, first_idx[n]), hi = min(c1, first_idx[n] + num_pts[n]);
         if (lo >= hi) continue;  // uniform
@@ -1168,7 +1173,7 @@ __device__ __forceinline__ void fb_prep_segment(const FusedPrep &F, int c, const
                 if (mi) atomicAdd(&s_w[1], (uint32_t)__popcll(mi));
             }
             if (mine) {
-                const float2 r = r2[i];
+                const float2 r = KEEP ? rr[KEEP ? u : 0] : r2[i];
                 atomicAdd(&s_hist[fb_bucket(float_key(r.x))], 1u);
                 atomicAdd(&s_hist[fb_bucket(float_key(r.y))], 1u);
             }
@@ -1187,7 +1192,7 @@ __device__ __forceinline__ void fb_prep_segment(const FusedPrep &F, int c, const
     for (int u = 0; u < per; ++u) {
             const int64_t i = c0 + (int64_t)u * FB_THREADS + tid;
             if (((vmask >> u) & 1u) && i >= lo && i < hi) {
-                const float2 r = r2[i];
+                const float2 r = KEEP ? rr[KEEP ? u : 0] : r2[i];
                 const uint32_t kx = float_key(r.x), ky = float_key(r.y);
                 kb[atomicAdd(&s_cur[fb_bucket(kx)], 1u)] = kx;
                 kb[atomicAdd(&s_cur[fb_bucket(ky)], 1u)] = ky;
@@ -2289,6 +2294,11 @@ static int render_backward_impl(bool run_prep, const float *grad_out, const int3
     if (small) {
         const PrepLayout L = prep_layout(N, P, S);
         fused = (fused_opt == 4 || fused_opt == 5) && rows == S && !cyc && a32 && N <= 64 && (unsigned)N + 8u <= pgrid;
+        if (fused && fused_opt == 4 && !(tpw_opt == 1 || tpw_opt == 2 || tpw_opt == 4)) {
+            // two-phase gather with its groups dealt per workgroup: two tasks per wavefront win as soon as there is about a
+            // task per resident wavefront (32,684 points @512^2: 58.7 us per step against 60.5 with one, 59.3 with four)
+            tpw = est_tasks >= 16ll * cap * 4 ? 4 : (est_tasks >= 1ll * cap * 4 ? 2 : 1);
+        }
         if (fused) {
             n_seg = L.f_chunks;
             seg_pts = L.f_per * FB_THREADS;
