@@ -101,6 +101,9 @@ class Workload:
         g = torch.Generator(device="cpu").manual_seed(1)
         self.grad_out = torch.randn((self.N, S, S, 4), generator=g).to(device)  # d loss / d RGBA
         self.S = S
+        if not self.multi and self.N == 1 and part.world_size == 1:
+            self._plan = ops.FusedPlan(device, 1, self.Pc, self.P, S, K, 3, True, False, False, False, CUTOFF, SIGMA, THR,
+                                       want_zbuf=True)
         if self.multi:
             # multi-GPU: the forward kernel writes its RGBA band and visibility flags straight into the
             # all-gather send buffers; the backward writes both gradients into one all-reduce bucket
@@ -119,6 +122,16 @@ class Workload:
         S = self.S
         multi = self.multi
         mark("start")
+        if not multi and self.N == 1 and p.world_size == 1:
+            # one GPU, one camera (the metric's configuration): the two fused entry points through ops.FusedPlan -- the same
+            # C calls as ops.render_forward / ops.render_backward below with the host work of a call cut down (one arena for the
+            # 13 outputs, prebuilt argument lists): what `SurfaceSplattingRenderer` itself uses
+            plan = self._plan
+            arena = plan.forward(self.world, self.normals, self.h, self.M, self.V, self.znear, self.zfar, self.first, self.num,
+                                 self.colors)
+            g_feat, g_world = plan.backward(arena, self.grad_out, self.first, self.num, RADII_S, CLIP, self.world, self.M)
+            mark("projection_compute")
+            return plan.image(arena), g_world, g_feat
         # fused forward: [setup + binning] -> [fine + blend]
         f = ops.render_forward(self.world, self.normals, self.h, self.M, self.V, self.znear, self.zfar, self.first,
                                self.num, self.colors, S, K, CUTOFF, THR, SIGMA, False, True, rows=p.rows,
