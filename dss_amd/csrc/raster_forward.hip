@@ -24,6 +24,36 @@
 
 namespace dss {
 
+// Optional per-workgroup phase timestamps (tools/fine_timing.py builds a -DDSS_FINE_TIMING copy of the
+// library; never compiled into the shipped libdss_hip.so).
+#ifdef DSS_FINE_TIMING
+__device__ long long *g_fine_timing = nullptr;  // (blocks, 12) int64
+#define FT_MARK(slot)                                                                   \
+    do {                                                                                \
+        if (g_fine_timing && threadIdx.x == 0)                                          \
+            g_fine_timing[(size_t)blockIdx.x * 12 + (slot)] = (long long)__builtin_amdgcn_s_memtime(); \
+    } while (0)
+#define FT_VAL(slot, v)                                                                 \
+    do {                                                                                \
+        if (g_fine_timing && threadIdx.x == 0) g_fine_timing[(size_t)blockIdx.x * 12 + (slot)] = (long long)(v); \
+    } while (0)
+#define FT_DECL(var) long long var = 0
+#define FT_ACC(var, v) var += (v)
+// the binning launch stamps into rows 8192.. of the same buffer (tools/setup_timing.py; the compiler may move arithmetic
+// across a stamp: read them as "issued by", not "finished by")
+#define FT_MARK_S(slot)                                                                 \
+    do {                                                                                \
+        if (g_fine_timing && threadIdx.x == 0)                                          \
+            g_fine_timing[((size_t)blockIdx.x + 8192) * 12 + (slot)] = (long long)__builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#else
+#define FT_MARK_S(slot)
+#define FT_MARK(slot)
+#define FT_VAL(slot, v)
+#define FT_DECL(var)
+#define FT_ACC(var, v)
+#endif
+
 // Each tile owns DSS_SUB counters / sub-lists, selected by the low bits of the splat id.
 // Same-address global atomics serialise (~50 ns each on MI355X: 523 splats on the hottest 16x16 tile of
 // the bunny scene cost ~30 us); splitting cuts the depth of every hot address by DSS_SUB.
@@ -204,7 +234,11 @@ __device__ __forceinline__ void bin_point(int64_t p, int n, float px, float py, 
         if (hx) p1 = atomicAdd(&counts[t01], 1u);
         if (hy) p2 = atomicAdd(&counts[t10], 1u);
         if (hx && hy) p3 = atomicAdd(&counts[t11], 1u);
+        FT_MARK_S(3);
         if (p0 < cap) lists[t00 * cap + p0] = (int32_t)p;
+#ifdef DSS_FINE_TIMING
+        if (g_fine_timing && threadIdx.x == 0 && (p0 | p1 | p2 | p3) != 0xffffffffu) FT_MARK_S(4);   // (atomics returned)
+#endif
         if (hx && p1 < cap) lists[t01 * cap + p1] = (int32_t)p;
         if (hy && p2 < cap) lists[t10 * cap + p2] = (int32_t)p;
         if (hx && hy && p3 < cap) lists[t11 * cap + p3] = (int32_t)p;
@@ -259,10 +293,14 @@ __global__ __launch_bounds__(256) void setup_bin_kernel(const SetupArgs A, TileG
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= A.P) return;
     if (visible_to_clear) visible_to_clear[p] = 0;
+    FT_MARK_S(0);
     const int n = find_cloud(p, A.first_idx, A.num_pts, A.N);
+    FT_MARK_S(1);
     float px, py, pz, rx, ry;
     setup_point(A, p, n, px, py, pz, rx, ry);
+    FT_MARK_S(2);
     bin_point(p, n, px, py, pz, rx, ry, g, counts, lists, cap, tq, sp);
+    FT_MARK_S(5);
 }
 
 // Pool pass (see struct Spill): workgroup `block` of `nblocks`, 256 threads, grid-stride over the splats.  Unless some splat
@@ -710,28 +748,6 @@ struct FineArgs {
 // one unsigned 64-bit compare implements the strict total order (z, idx) of
 // rasterize_points_cpu.cpp:85 / oracle frag_less.  Empty slots hold ~0.
 #define KEY_EMPTY 0xffffffffffffffffull
-
-// Optional per-workgroup phase timestamps (tools/fine_timing.py builds a -DDSS_FINE_TIMING copy of the
-// library; never compiled into the shipped libdss_hip.so).
-#ifdef DSS_FINE_TIMING
-__device__ long long *g_fine_timing = nullptr;  // (blocks, 12) int64
-#define FT_MARK(slot)                                                                   \
-    do {                                                                                \
-        if (g_fine_timing && threadIdx.x == 0)                                          \
-            g_fine_timing[(size_t)blockIdx.x * 12 + (slot)] = (long long)__builtin_amdgcn_s_memtime(); \
-    } while (0)
-#define FT_VAL(slot, v)                                                                 \
-    do {                                                                                \
-        if (g_fine_timing && threadIdx.x == 0) g_fine_timing[(size_t)blockIdx.x * 12 + (slot)] = (long long)(v); \
-    } while (0)
-#define FT_DECL(var) long long var = 0
-#define FT_ACC(var, v) var += (v)
-#else
-#define FT_MARK(slot)
-#define FT_VAL(slot, v)
-#define FT_DECL(var)
-#define FT_ACC(var, v)
-#endif
 
 // sorted insertion of ekey into an ascending K-list held in registers; branch-free.  The list holds the 64-bit keys only:
 // the Q value of a fragment is recomputed from its record in the epilogue, for the K survivors of a pixel instead of being

@@ -541,6 +541,20 @@ class SurfaceSplatting(torch.nn.Module):
         renderer's blend; the autograd graph is one node, so gradients flow to the world points and the
         features only (a loss on ``fragments.zbuf`` needs the unfused path)."""
         original_clouds = point_clouds
+        if kwargs.get("graphed", False) and point_clouds_filter is None and not kwargs.get("want_fragments", True):
+            # graphed replay of the SAME call as last time (same tensor objects, cameras, settings, h: the steady state of
+            # a training loop): nothing to prepare, nothing to check but the two addresses an optimiser could have replaced
+            G = self.__dict__.get("_graphed")
+            if G is not None and G.call_key is not None:
+                pl, nl, fl = point_clouds.points_list(), point_clouds.normals_list(), point_clouds.features_list()
+                k = G.call_key
+                if len(pl) == 1 and pl[0] is k[0] and nl is not None and nl[0] is k[1] and fl is not None and fl[0] is k[2] \
+                        and kwargs.get("Vrk_h", None) is k[3] and kwargs.get("cameras", self.cameras) is k[4] \
+                        and kwargs.get("raster_settings", self.raster_settings) is k[5] and k[3]._version == k[6] \
+                        and pl[0].data_ptr() == G.ptrs[0][0] and fl[0].data_ptr() == G.ptrs[9][0] \
+                        and k[7] == tuple(getattr(k[4], n)._version for n in ("R", "T")) \
+                        and k[8] == tuple(getattr(k[5], n, None) for n in PointsRasterizationSettings.__slots__):
+                    return _RenderFusedGraphed.apply(pl[0], fl[0], G), None, point_clouds
         if not point_clouds.isempty():
             point_clouds = self._apply_activation_filter(point_clouds, point_clouds_filter)
         if point_clouds.isempty():  # like forward(): empty fragments, zero image
@@ -565,6 +579,15 @@ class SurfaceSplatting(torch.nn.Module):
             if G is None or G.plan is not lean or G.ptrs != _GraphedRender.signature(inputs) or G.radii_s != radii_s \
                     or G.clip != clip:
                 G = self._graphed = _GraphedRender(lean, inputs, radii_s, clip, a["shared"])
+            # key of the steady-state shortcut at the top: only for one un-extended cloud whose tensors ARE the graph's inputs
+            pl, nl, fl = point_clouds.points_list(), point_clouds.normals_list(), point_clouds.features_list()
+            h_given, cams = kwargs.get("Vrk_h", None), kwargs.get("cameras", self.cameras)
+            G.call_key = None
+            if len(pl) == 1 and a["N"] == 1 and h_given is not None and nl is not None and fl is not None \
+                    and pl[0] is a["world"] and fl[0] is feats and hasattr(cams, "R") and hasattr(cams, "T"):
+                G.call_key = (pl[0], nl[0], fl[0], h_given, cams, st, h_given._version,
+                              tuple(getattr(cams, n)._version for n in ("R", "T")),
+                              tuple(getattr(st, n, None) for n in PointsRasterizationSettings.__slots__))   # (settings mutate in place)
             image = _RenderFusedGraphed.apply(a["world"], feats, G)
             arena = G.arena
         elif lean is not None:
@@ -607,6 +630,7 @@ class _GraphedRender:
 
     def __init__(self, plan, inputs, radii_s, clip, shared):
         self.plan, self.radii_s, self.clip, self.shared = plan, radii_s, clip, shared
+        self.call_key = None              # (see SurfaceSplatting.render_fused)
         self.inputs = inputs              # (world, normals, h, M, V, znear, zfar, first, num, feats, vr6, frame_n): kept alive
         self.ptrs = self.signature(inputs)
         world, normals, h, M, V, znear, zfar, first, num, feats, vr6, frame_n = inputs
