@@ -27,6 +27,9 @@ if os.environ.get("DSS_BENCH_MORTON") == "1":
     from dss_amd.cloud import spatial_order
     order = spatial_order(torch.from_numpy(pts)).numpy()
     pts, nrm, col = pts[order].copy(), nrm[order].copy(), col[order].copy()
+if os.environ.get("BENCH_BACKWARD_TPW"):   # development A/B: DSS_OPT_BACKWARD_TPW
+    from dss_amd import _lib
+    _lib.set_option(_lib.OPT_BACKWARD_TPW, int(os.environ["BENCH_BACKWARD_TPW"]))
 dev = torch.device("cuda:0")
 wl = bench.Workload(dev, N, bench.RowPartition(S, 1, 0), cloud=(pts, nrm, col, h))
 for _ in range(3):

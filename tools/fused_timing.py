@@ -47,3 +47,18 @@ for rep in range(3):
     print("  blend half done: min %.2f mean %.2f max %.2f us" % (a1.min(), a1.mean(), a1.max()))
     print("  released (rs seen): min %.2f mean %.2f max %.2f us" % (rel.min(), rel.mean(), rel.max()))
     print("  occupancy half done: min %.2f mean %.2f max %.2f us" % (end.min(), end.mean(), end.max()))
+    if rep == 2:
+        idx = np.where(g)[0]
+        d2 = (t[g, 3] - t[g, 2]) / 100.0     # occupancy half per workgroup
+        d1 = (t[g, 1] - t[g, 0]) / 100.0     # blend half per workgroup
+        print("  occupancy half per workgroup: deciles", " ".join("%.2f" % np.percentile(d2, q) for q in range(0, 101, 10)))
+        print("  blend half per workgroup    : deciles", " ".join("%.2f" % np.percentile(d1, q) for q in range(0, 101, 10)))
+        for x in range(8):
+            m = (idx % 8) == x
+            print("    XCD %d: %4d workgroups, occupancy half mean %.2f max %.2f | blend half mean %.2f max %.2f" % (
+                x, int(m.sum()), d2[m].mean(), d2[m].max(), d1[m].mean(), d1[m].max()))
+        # by position in the grid (dispatch order): eighths of the workgroup index
+        for o in range(8):
+            m = (idx * 8 // (idx.max() + 1)) == o
+            print("    grid eighth %d: occupancy half mean %.2f max %.2f | blend half mean %.2f" % (o, d2[m].mean(), d2[m].max(), d1[m].mean()))
+        print("  correlation blend-half vs occupancy-half duration per workgroup: %.3f" % np.corrcoef(d1, d2)[0, 1])
