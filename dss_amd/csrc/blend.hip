@@ -18,27 +18,48 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= npix) return;
     const int Cn = (C > 0) ? C : Crt;
-    float cum = 0.0f;
-    for (int k = 0; k < K; ++k) {
-        const int32_t p = idx[i * K + k];
-        if (p < 0) continue;
-        cum += ewa_weight(qv[i * K + k], scaler[p]);
+    constexpr int CM = (C > 0) ? C : BLEND_MAX_C;
+    // Summation order = the fused epilogue's (fine_tile, raster_forward.hip): lane j of a pixel's quad sums the fragments
+    // k = j, j + 4, ... in ascending k, the four partial sums are combined as (p0 + p1) + (p2 + p3) -- bit-identical results.
+    float pc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int k0 = 0; k0 < K; k0 += 4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = k0 + j;
+            if (k < K) {
+                const int32_t p = idx[i * K + k];
+                if (p >= 0) pc[j] += ewa_weight(qv[i * K + k], scaler[p]);
+            }
+        }
     }
+    float cum = (pc[0] + pc[1]) + (pc[2] + pc[3]);
     if (cum < 1e-4f) cum = 1e-4f;
     if (wsum) wsum[i] = cum;
     const float inv_cum = fast_rcp(cum);
-    float acc[(C > 0) ? C : BLEND_MAX_C];
+    float pa[4][CM];
 #pragma unroll
-    for (int ch = 0; ch < ((C > 0) ? C : BLEND_MAX_C); ++ch) acc[ch] = 0.0f;
-    for (int k = 0; k < K; ++k) {
-        const int32_t p = idx[i * K + k];
-        if (p < 0) continue;
-        // normalised weight once per fragment (same arithmetic as the fused epilogue of the fine pass)
-        const float w = ewa_weight(qv[i * K + k], scaler[p]) * inv_cum;
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int ch = 0; ch < ((C > 0) ? C : BLEND_MAX_C); ++ch)
-            if (ch < Cn) acc[ch] += feat[(size_t)p * Cn + ch] * w;
+        for (int ch = 0; ch < CM; ++ch) pa[j][ch] = 0.0f;
+    for (int k0 = 0; k0 < K; k0 += 4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = k0 + j;
+            if (k < K) {
+                const int32_t p = idx[i * K + k];
+                if (p >= 0) {
+                    // normalised weight once per fragment (same arithmetic as the fused epilogue of the fine pass)
+                    const float w = ewa_weight(qv[i * K + k], scaler[p]) * inv_cum;
+#pragma unroll
+                    for (int ch = 0; ch < CM; ++ch)
+                        if (ch < Cn) pa[j][ch] += feat[(size_t)p * Cn + ch] * w;
+                }
+            }
+        }
     }
+    float acc[CM];
+#pragma unroll
+    for (int ch = 0; ch < CM; ++ch) acc[ch] = (pa[0][ch] + pa[1][ch]) + (pa[2][ch] + pa[3][ch]);
     float *o = out + i * (Cn + 1);
     if (C == 3) {
         *reinterpret_cast<float4 *>(o) = make_float4(acc[0], acc[1], acc[2], occ[i]);

@@ -1276,161 +1276,162 @@ __device__ __forceinline__ void fine_tile(const FineArgs &A_entry, const int til
     merge_round<KMAX, 0x4E>(key);  // quad_perm [2,3,0,1]
 
     FT_MARK(5);
-    // ---- epilogue (slice 0 lanes own the pixel): depth merge, occupancy, visibility, stores ----
+    // ---- epilogue: depth merge, occupancy, visibility, Q, blend, stores -- by ALL FOUR lanes of a pixel's quad ----
+    // After the two merge rounds the four lanes of a quad hold the same K-list.  Round 3 let lane 0 of the quad do the whole
+    // epilogue (K serial fragments: records, Q, weight, colour sums, staging stores) with the other three lanes masked off:
+    // a quarter of the lanes active through ~25 % of the kernel's instructions.  Now lane j of the quad takes the fragments
+    // k = j, j + 4, ... (two for K = 5..8), requests their Q AND blend records in ONE round trip, and the weight / colour sums
+    // are reduced over the quad with two DPP steps: sum = (p0 + p1) + (p2 + p3) with p_j the lane's partial in ascending k --
+    // the summation order blend_forward_kernel (blend.hip) uses too, so the fused and the stand-alone blend stay bit-identical.
     // Every thread-derived index of the epilogue is recomputed from a laundered thread id: left alone, the compiler
     // forms the 64-bit store addresses (occupancy, image, weight sum, two rows x three planes) at kernel entry and
     // keeps ~20 VGPRs alive through the candidate loop and the merge (110 VGPRs -> 4 waves per SIMD).
     int tid_e = tid;
     asm volatile("" : "+v"(tid_e));
-    const int lane_e = tid_e & 63, wid_e = tid_e >> 6, pl_e = lane_e >> 2;
+    const int lane_e = tid_e & 63, wid_e = tid_e >> 6, pl_e = lane_e >> 2, j4 = lane_e & 3;
     const int tr_e = (wid_e / FOOT_PER_ROW) * FOOT + (pl_e >> 2), tc_e = (wid_e % FOOT_PER_ROW) * FOOT + (pl_e & 3);
     const int lr_e = ty * DSS_TILE + tr_e, c_e = tx * DSS_TILE + tc_e;   // band-local row, image column
-    const bool owner = (lane_e & 3) == 0;
-    const bool in_img = owner && (c_e < S) && (lr_e < g.rows);
-    float kz[KMAX], kq[KMAX];
-    int ki[KMAX];
+    const bool owner = j4 == 0;
+    const bool in_px = (c_e < S) && (lr_e < g.rows);   // the quad's pixel lies inside the image / band
+    const bool in_img = owner && in_px;
+    // depth merge (rasterize_points.cu:586-595: stop at the first k with z[k] - z[0] > thr), evaluated by every lane
     const float z0 = __uint_as_float((unsigned)(key[0] >> 32));
     const bool any = key[0] != KEY_EMPTY;
-    bool alive = any;
-#pragma unroll
-    for (int k = 0; k < KMAX; ++k) {
-        const float z = __uint_as_float((unsigned)(key[k] >> 32));
-        // rasterize_points.cu:586-595: stop at the first k with z[k]-z[0] > thr
-        alive = alive && (key[k] != KEY_EMPTY) && !(z - z0 > E.thr);
-        ki[k] = alive ? (int)(unsigned)(key[k] & 0xffffffffull) : -1;
-        kz[k] = alive ? z : -1.0f;
-        kq[k] = -1.0f;
-    }
-    // Q of the surviving fragments, recomputed from their records with the expression of the hit test (same operands, same
-    // order, no contraction: the same bits)
-    if (in_img) {
-        const float xf_e = ndc(S - 1 - c_e), yf_e = ndc(S - 1 - (tile_row0(g, ty) + tr_e));
-        float2 gp[KMAX];
-        float4 ge[KMAX];
+    unsigned alive_bits = 0;
+    {
+        bool alive = any;
 #pragma unroll
         for (int k = 0; k < KMAX; ++k) {
-            gp[k] = make_float2(0.f, 0.f);
-            ge[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (k < K && ki[k] >= 0) {
-                if (PACKED) {
-                    const float4 *R = E.rec + 4 * (size_t)ki[k];
-                    gp[k] = *reinterpret_cast<const float2 *>(R);
-                    ge[k] = R[1];
-                } else {
-                    const size_t q = (size_t)ki[k];
-                    gp[k] = make_float2(E.points[3 * q], E.points[3 * q + 1]);
-                    ge[k] = make_float4(E.ellipse[3 * q], E.ellipse[3 * q + 1], E.ellipse[3 * q + 2], 0.f);
-                }
-            }
+            const float z = __uint_as_float((unsigned)(key[k] >> 32));
+            alive = alive && (key[k] != KEY_EMPTY) && !(z - z0 > E.thr) && (k < K);
+            alive_bits |= (alive ? 1u : 0u) << k;
         }
+    }
+    // this lane's fragments: k = j4 + 4 m
+    constexpr int MQ = (KMAX + 3) / 4;
+    int mi[MQ];      // point id or -1
+    float mz[MQ], mq[MQ];
 #pragma unroll
-        for (int k = 0; k < KMAX; ++k)
-            if (k < K && ki[k] >= 0) {
-                const float dx = xf_e - gp[k].x;
-                const float dy = yf_e - gp[k].y;
-                kq[k] = ge[k].x * dx * dx + ge[k].y * dx * dy + ge[k].z * dy * dy;  // rasterize_points.cu:92-101
-            }
+    for (int m = 0; m < MQ; ++m) {
+        unsigned long long kk = KEY_EMPTY;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+            if (4 * m + jj < KMAX) kk = (j4 == jj) ? key[4 * m + jj] : kk;
+        const bool live = in_px && ((alive_bits >> (4 * m + j4)) & 1u) && (4 * m + j4 < KMAX);
+        mi[m] = live ? (int)(unsigned)(kk & 0xffffffffull) : -1;
+        mz[m] = live ? __uint_as_float((unsigned)(kk >> 32)) : -1.0f;
+        mq[m] = -1.0f;
     }
     const size_t pix = ((size_t)n * g.rows + lr_e) * S + c_e;
-    // blend inputs of the pixel's fragments (scaler + three feature channels): requested BEFORE the tile is staged
-    // and streamed out, consumed after -- the gather's round trip is hidden behind the LDS transpose and the stores
-    constexpr bool PREFETCH_BLEND = false;  // (+20 VGPRs: 110 in total = 4 workgroups per CU; measured slower)
-    const bool blend3 = PREFETCH_BLEND && in_img && E.image != nullptr && E.C == 3;
-    float bsc[PREFETCH_BLEND ? KMAX : 1], bf0[PREFETCH_BLEND ? KMAX : 1], bf1[PREFETCH_BLEND ? KMAX : 1],
-        bf2[PREFETCH_BLEND ? KMAX : 1];
-    if (in_img) {
-        E.occ[pix] = any ? 1.0f : 0.0f;
-        if (E.visible) {
+    const bool blend = E.image != nullptr;
+    const float xf_e = ndc(S - 1 - c_e), yf_e = ndc(S - 1 - (tile_row0(g, ty) + tr_e));
+    float wk[MQ];
+    float cum = 0.0f;
+    if (PACKED) {
+        // records of the lane's fragments: {px,py,..} {a,b,c,..} for Q and {scaler,f0,f1,f2} for the blend, one round trip
+        float2 gp[MQ];
+        float4 ge[MQ], br[MQ];
 #pragma unroll
-            for (int k = 0; k < KMAX; ++k)
-                if (k < K && ki[k] >= 0) E.visible[ki[k]] = 1;
-        }
-    }
-    if (PREFETCH_BLEND) {
-#pragma unroll
-        for (int k = 0; k < (PREFETCH_BLEND ? KMAX : 1); ++k) {
-            bsc[k] = 0.0f; bf0[k] = 0.0f; bf1[k] = 0.0f; bf2[k] = 0.0f;
-            if (blend3 && k < K && ki[k] >= 0) {
-                bsc[k] = E.scaler[ki[k]];
-                const float *f = E.feat + (size_t)ki[k] * 3;
-                bf0[k] = f[0]; bf1[k] = f[1]; bf2[k] = f[2];
-            }
-        }
-    }
-
-    if (in_img && E.image) {
-        // fused blend (same arithmetic and order as blend_forward_kernel): w = exp(-q/2)*scaler,
-        // img = sum f*w/cum, alpha = occupancy
-        float wk[KMAX];
-        float cum = 0.0f;
-        float4 br[PACKED ? KMAX : 1];  // packed: {scaler, f0, f1, f2} of the pixel's fragments, one 16-byte load each
-        if (PACKED) {
-#pragma unroll
-            for (int k = 0; k < (PACKED ? KMAX : 1); ++k) {
-                br[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (k < K && ki[k] >= 0) br[k] = E.rec[4 * (size_t)ki[k] + 2];
+        for (int m = 0; m < MQ; ++m) {
+            gp[m] = make_float2(0.f, 0.f);
+            ge[m] = make_float4(0.f, 0.f, 0.f, 0.f);
+            br[m] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (mi[m] >= 0) {
+                const float4 *R = E.rec + 4 * (size_t)mi[m];
+                gp[m] = *reinterpret_cast<const float2 *>(R);
+                ge[m] = R[1];
+                br[m] = R[2];
             }
         }
 #pragma unroll
-        for (int k = 0; k < KMAX; ++k) {
-            wk[k] = 0.0f;
-            if (k < K && ki[k] >= 0) {
-                wk[k] = ewa_weight(kq[k], PACKED ? br[PACKED ? k : 0].x
-                                                 : (blend3 ? bsc[PREFETCH_BLEND ? k : 0] : E.scaler[ki[k]]));
-                cum += wk[k];
+        for (int m = 0; m < MQ; ++m) {
+            wk[m] = 0.0f;
+            if (mi[m] >= 0) {
+                const float dx = xf_e - gp[m].x;
+                const float dy = yf_e - gp[m].y;
+                mq[m] = ge[m].x * dx * dx + ge[m].y * dx * dy + ge[m].z * dy * dy;  // rasterize_points.cu:92-101
+                if (E.visible) E.visible[mi[m]] = 1;
+                wk[m] = ewa_weight(mq[m], br[m].x);
+                cum += wk[m];
             }
         }
+        // fused blend (same arithmetic and order as blend_forward_kernel): w = exp(-q/2) * scaler, img = sum f * (w / cum)
+        cum += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(cum), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+        cum += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(cum), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
         if (cum < 1e-4f) cum = 1e-4f;
-        E.wsum[pix] = cum;
-        // normalised weights once per fragment: img = sum f * (w / cum)
         const float inv_cum = fast_rcp(cum);
+        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
 #pragma unroll
-        for (int k = 0; k < KMAX; ++k) wk[k] = wk[k] * inv_cum;
-        float *o = E.image + (size_t)n * E.img_sn + (size_t)lr_e * E.img_sr + (size_t)c_e * (E.C + 1);
-        if (E.C == 3) {
-            // RGBA as ONE 16-byte store per pixel (four dword stores at a 16-byte stride quadruple the
-            // write requests the memory side sees)
-            float acc3[3] = {0.0f, 0.0f, 0.0f};
+        for (int m = 0; m < MQ; ++m) {
+            if (mi[m] >= 0) {
+                const float wn = wk[m] * inv_cum;
+                a0 += br[m].y * wn;
+                a1 += br[m].z * wn;
+                a2 += br[m].w * wn;
+            }
+        }
+        a0 += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a0), 0xB1, 0xf, 0xf, true));
+        a1 += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a1), 0xB1, 0xf, 0xf, true));
+        a2 += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a2), 0xB1, 0xf, 0xf, true));
+        a0 += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a0), 0x4E, 0xf, 0xf, true));
+        a1 += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a1), 0x4E, 0xf, 0xf, true));
+        a2 += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a2), 0x4E, 0xf, 0xf, true));
+        if (in_img) {
+            E.occ[pix] = any ? 1.0f : 0.0f;
+            E.wsum[pix] = cum;
+            float *o = E.image + (size_t)n * E.img_sn + (size_t)lr_e * E.img_sr + (size_t)c_e * 4;
+            // RGBA as ONE 16-byte store per pixel (four dword stores at a 16-byte stride quadruple the write requests)
+            *reinterpret_cast<float4 *>(o) = make_float4(a0, a1, a2, any ? 1.0f : 0.0f);
+        }
+    } else {
+        // separate per-point arrays (no packed records: another channel count, the lean workspace, or no fused blend)
 #pragma unroll
-            for (int k = 0; k < KMAX; ++k)
-                if (k < K && ki[k] >= 0) {
-                    float f0, f1, f2;
-                    if (PACKED) {
-                        f0 = br[PACKED ? k : 0].y; f1 = br[PACKED ? k : 0].z; f2 = br[PACKED ? k : 0].w;
-                    } else if (blend3) {
-                        f0 = bf0[PREFETCH_BLEND ? k : 0]; f1 = bf1[PREFETCH_BLEND ? k : 0]; f2 = bf2[PREFETCH_BLEND ? k : 0];
-                    } else {
-                        const float *f = E.feat + (size_t)ki[k] * 3;
-                        f0 = f[0]; f1 = f[1]; f2 = f[2];
-                    }
-                    acc3[0] += f0 * wk[k];
-                    acc3[1] += f1 * wk[k];
-                    acc3[2] += f2 * wk[k];
+        for (int m = 0; m < MQ; ++m) {
+            wk[m] = 0.0f;
+            if (mi[m] >= 0) {
+                const size_t q = (size_t)mi[m];
+                const float dx = xf_e - E.points[3 * q];
+                const float dy = yf_e - E.points[3 * q + 1];
+                mq[m] = E.ellipse[3 * q] * dx * dx + E.ellipse[3 * q + 1] * dx * dy + E.ellipse[3 * q + 2] * dy * dy;
+                if (E.visible) E.visible[q] = 1;
+                if (blend) {
+                    wk[m] = ewa_weight(mq[m], E.scaler[q]);
+                    cum += wk[m];
                 }
-            *reinterpret_cast<float4 *>(o) = make_float4(acc3[0], acc3[1], acc3[2], any ? 1.0f : 0.0f);
-        } else {
+            }
+        }
+        if (in_img) E.occ[pix] = any ? 1.0f : 0.0f;
+        if (blend) {
+            cum += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(cum), 0xB1, 0xf, 0xf, true));
+            cum += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(cum), 0x4E, 0xf, 0xf, true));
+            if (cum < 1e-4f) cum = 1e-4f;
+            const float inv_cum = fast_rcp(cum);
+            if (in_img) E.wsum[pix] = cum;
+            float *o = E.image + (size_t)n * E.img_sn + (size_t)lr_e * E.img_sr + (size_t)c_e * (E.C + 1);
             for (int ch = 0; ch < E.C; ++ch) {
                 float acc = 0.0f;
 #pragma unroll
-                for (int k = 0; k < KMAX; ++k)
-                    if (k < K && ki[k] >= 0) acc += E.feat[(size_t)ki[k] * E.C + ch] * wk[k];
-                o[ch] = acc;
+                for (int m = 0; m < MQ; ++m)
+                    if (mi[m] >= 0) acc += E.feat[(size_t)mi[m] * E.C + ch] * (wk[m] * inv_cum);
+                acc += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc), 0xB1, 0xf, 0xf, true));
+                acc += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc), 0x4E, 0xf, 0xf, true));
+                if (in_img) o[ch] = acc;
             }
-            o[E.C] = any ? 1.0f : 0.0f;
+            if (in_img) o[E.C] = any ? 1.0f : 0.0f;
         }
     }
-    // stage the tile through LDS and let each wavefront stream full image rows per plane
+    // stage the tile through LDS and let each wavefront stream full image rows per plane; every lane stores its own fragments
     const int lds_pix = (tr_e * DSS_TILE + tc_e) * K;
     if (PLANES == 3) {
         __syncthreads();
-        if (owner) {
 #pragma unroll
-            for (int k = 0; k < KMAX; ++k)
-                if (k < K) {
-                    s_out[0][lds_pix + k] = ki[k];
-                    s_out[PLANES - 1 > 0 ? 1 : 0][lds_pix + k] = __float_as_int(kz[k]);
-                    s_out[PLANES - 1][lds_pix + k] = __float_as_int(kq[k]);
-                }
+        for (int m = 0; m < MQ; ++m) {
+            const int k = 4 * m + j4;
+            if (k < K) {
+                s_out[0][lds_pix + k] = mi[m];
+                s_out[PLANES - 1 > 0 ? 1 : 0][lds_pix + k] = __float_as_int(mz[m]);
+                s_out[PLANES - 1][lds_pix + k] = __float_as_int(mq[m]);
+            }
         }
         __syncthreads();
         for (int rr = wid_e; rr < valid_rows; rr += FINE_WAVES) {
@@ -1444,17 +1445,15 @@ __device__ __forceinline__ void fine_tile(const FineArgs &A_entry, const int til
     } else {
 #define DSS_STORE_PLANE(REGS, DST, CAST)                                                          \
     __syncthreads();                                                                              \
-    if (owner) {                                                                                  \
-        _Pragma("unroll") for (int k = 0; k < KMAX; ++k) if (k < K) s_out[0][lds_pix + k] = CAST(REGS[k]); \
-    }                                                                                             \
+    _Pragma("unroll") for (int m = 0; m < MQ; ++m) if (4 * m + j4 < K) s_out[0][lds_pix + 4 * m + j4] = CAST(REGS[m]); \
     __syncthreads();                                                                              \
     for (int rr = wid_e; rr < valid_rows; rr += FINE_WAVES) {                                       \
         for (int cc = lane_e; cc < valid_cols; cc += 64)                                            \
             reinterpret_cast<int *>(DST)[tile_base + (size_t)rr * S * K + cc] = s_out[0][rr * run + cc]; \
     }
-        DSS_STORE_PLANE(ki, E.idx, (int))
-        if (E.zbuf) { DSS_STORE_PLANE(kz, E.zbuf, __float_as_int) }
-        DSS_STORE_PLANE(kq, E.qv, __float_as_int)
+        DSS_STORE_PLANE(mi, E.idx, (int))
+        if (E.zbuf) { DSS_STORE_PLANE(mz, E.zbuf, __float_as_int) }
+        DSS_STORE_PLANE(mq, E.qv, __float_as_int)
 #undef DSS_STORE_PLANE
     }
 
