@@ -151,9 +151,9 @@ class Workload:
                 return image, g_pts, g_feat
         else:
             # collectives 1-2/3: the RGBA bands leave on their own communicator and arrive during the backward;
-            # only the small visibility all-gather is waited for here
+            # only the small visibility all-reduce is waited for here (the band collective is issued behind the backward)
             mark("forward_compute")
-            vis_all = self.fx.start()
+            vis_all = self.fx.start_visibility()
             mark("wait_visibility_allgather")
             g_band = p.slice(self.grad_out).contiguous()
             g_feat = self.bucket[:self.P * 3].view(self.P, 3)
@@ -161,6 +161,7 @@ class Workload:
             # same fused kernel on the band; visibility = union over ranks, clip after the reduction
             ops.render_backward(g_band, idx, qv, wsum, info["scaler"], info["pts_screen"], info["radii"], vis_all,
                                 self.first, self.num, RADII_S, -1.0, image_size=S, rows=p.rows, out=(g_feat, g_pts))
+            self.fx.start_image()   # issued behind the backward's launches, from a side stream that only waits for the forward
             mark("backward_compute")
             dist.all_reduce(self.bucket, op=dist.ReduceOp.SUM)  # collective 3/3: both gradient partials, one bucket
             mark("wait_gradient_allreduce")
@@ -180,7 +181,7 @@ class Workload:
         host three graph launches + three collective calls instead of ~10 kernel launches through Python."""
         p, S = self.part, self.S
         self.g_band = p.slice(self.grad_out).contiguous()
-        self.vis_all = torch.zeros(self.P, dtype=torch.uint8, device=self.dev)
+        self.vis_all = self.fx.visible   # the forward kernel writes it, the all-reduce (MAX) of fx.start() unions it in place
         g_feat = self.bucket[:self.P * 3].view(self.P, 3)
         g_pts = self.bucket[self.P * 3:].view(self.P, 3)
         seg = {}
@@ -227,9 +228,10 @@ class Workload:
         mark("start")
         self._graphs[0].replay()
         mark("forward_compute")
-        self.fx.start(out=self.vis_all)
+        self.fx.start_visibility(out=self.vis_all)
         mark("wait_visibility_allgather")
         self._graphs[1].replay()
+        self.fx.start_image()   # host issue hidden behind the backward graph; the collective itself only waits for the forward
         mark("backward_compute")
         dist.all_reduce(self.bucket, op=dist.ReduceOp.SUM)
         mark("wait_gradient_allreduce")

@@ -954,6 +954,8 @@ __device__ __forceinline__ void fill_tiles(const FineArgs &A, int t0, unsigned e
 
 // The fine kernel's (only) by-value argument, re-read from the kernarg segment (offset 0): same bytes as the parameter,
 // but loaded where they are used instead of living in SGPRs from the kernel's entry on.
+// REQUIRES: every kernel that inlines fine_tile takes `const FineArgs` as its FIRST by-value parameter (kernarg offset 0):
+// fine_kernel below is the only one.  A kernel with another leading argument would read garbage here.
 __device__ __forceinline__ const FineArgs &reloaded_args()
 {
     auto kp = (const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr();

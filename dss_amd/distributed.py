@@ -216,9 +216,9 @@ class ForwardExchange:
 class OverlappedExchange:
     """End-of-forward exchanges arranged for overlap with the backward (bench.py, multi-GPU):
 
-    * visibility flags (P bytes per rank) -- a small all-gather on ``group``; the backward needs the union
-      before its first kernel (``rs`` is the median radius of the GLOBALLY visible points), so this one is
-      on the critical path and latency-bound;
+    * visibility flags (P bytes per rank) -- ONE in-place all-reduce (MAX over 0/1 bytes) on ``group``; the backward
+      needs the union before its first kernel (``rs`` is the median radius of the GLOBALLY visible points), so this one
+      is on the critical path and latency-bound;
     * RGBA bands (N * band * S * ch * 4 bytes per rank, 4 MB at 8 cameras x 512^2) -- an ASYNCHRONOUS
       all-gather on ``image_group``, a second process group (= its own RCCL communicator, so it neither
       orders with nor blocks the gradient all-reduce); it completes while the backward runs and is
@@ -261,18 +261,19 @@ class OverlappedExchange:
         rows = part.n_rows
         self.image = self.send_img[:rows].permute(1, 0, 2, 3)  # (N, rows, S, ch), strided
         self.visible = torch.zeros(num_points, dtype=torch.uint8, device=device)
-        self.recv_vis = torch.empty((G, num_points), dtype=torch.uint8, device=device)
         self._work = None
+        on_gpu = torch.device(device).type == "cuda"
+        self._side_img = torch.cuda.Stream(device=device) if on_gpu else None   # issue stream of the image collective
+        self._fwd_event = torch.cuda.Event() if on_gpu else None
+        self._fwd_done = None
         # load-balanced (unequal) bands travel padded to the largest one; the rows are put in place by ONE gather
-        # kernel on a side stream as soon as the collective completes, i.e. still during the backward
-        self.full_img = self.row_index = self._side = None
+        # kernel on the side stream as soon as the collective completes, i.e. still during the backward
+        self.full_img = self.row_index = None
         if not part.uniform:
             # image row r sits at gather_index()[r] of the gathered buffer (unequal bands travel padded to the largest
             # one; a cyclic partition interleaves the ranks' tile rows)
             self.row_index = torch.tensor(part.gather_index(), dtype=torch.int64, device=device)
             self.full_img = torch.empty((S, n_images, S, channels), dtype=torch.float32, device=device)
-            if torch.device(device).type == "cuda":
-                self._side = torch.cuda.Stream(device=device)
 
     @staticmethod
     def _all_gather(out2d: torch.Tensor, send: torch.Tensor, group, async_op: bool):
@@ -281,44 +282,66 @@ class OverlappedExchange:
         return dist.all_gather_into_tensor(out2d, send, group=group, async_op=async_op)
 
     def start(self, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """Issue both exchanges; returns the union of the visibility flags, uint8 (P,) (written into `out` if given: a
-        static buffer that captured graphs read)."""
-        vis = self._start()
-        if out is not None:
+        """Issue both exchanges (visibility first: it is the one the backward waits for); returns the union of the
+        visibility flags, uint8 (P,) (written into `out` if given: a static buffer that captured graphs read)."""
+        vis = self.start_visibility(out)
+        self.start_image()
+        return vis
+
+    def start_visibility(self, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """The critical exchange alone (call `start_image` after the backward has been launched: an RCCL call costs the
+        host ~15-20 us, and the GPU would sit idle behind the visibility union while the image collective is being issued).
+        Records the point of the stream up to which the image bands are complete."""
+        self._fwd_done = None
+        if self._fwd_event is not None:
+            self._fwd_done = self._fwd_event
+            self._fwd_done.record()
+        vis = self._union_visibility()
+        if out is not None and out.data_ptr() != vis.data_ptr():
             out.copy_(vis)
             return out
         return vis
 
-    def _start(self) -> torch.Tensor:
+    def start_image(self) -> None:
+        """The all-gather of the RGBA bands, asynchronous on its own communicator.  It is issued from a side stream that only
+        waits for the END OF THE FORWARD (the event of `start_visibility`), so that it overlaps with a backward that has
+        already been launched on the compute stream."""
         G = self.part.world_size
-        if self.overlap:
-            try:
-                self._work = self._all_gather(self.recv_img.view(G, -1), self.send_img.view(-1), self.image_group, True)
-            except Exception as e:  # noqa: BLE001  (asynchronous collective refused: blocking exchange from now on)
-                self.overlap, self._work = False, None
-                self.degraded = "async all_gather failed: %s: %s" % (type(e).__name__, str(e)[:200])
-        if not self.overlap:
-            self._all_gather(self.recv_img.view(G, -1), self.send_img.view(-1), self.image_group, False)
-            self._work = None
-            if self.row_index is not None:
+        side = self._side_img
+        if side is not None and self._fwd_done is not None:
+            side.wait_event(self._fwd_done)
+        ctx = torch.cuda.stream(side) if side is not None else _null_context()
+        with ctx:
+            if self.overlap:
+                try:
+                    self._work = self._all_gather(self.recv_img.view(G, -1), self.send_img.view(-1), self.image_group, True)
+                except Exception as e:  # noqa: BLE001  (asynchronous collective refused: blocking exchange from now on)
+                    self.overlap, self._work = False, None
+                    self.degraded = "async all_gather failed: %s: %s" % (type(e).__name__, str(e)[:200])
+            if not self.overlap:
+                self._all_gather(self.recv_img.view(G, -1), self.send_img.view(-1), self.image_group, False)
+                self._work = None
+                if self.row_index is not None:
+                    torch.index_select(self.recv_img, 0, self.row_index, out=self.full_img)
+            elif self.row_index is not None and side is not None:
+                self._work.wait()   # (the side stream waits for the collective, not the host)
                 torch.index_select(self.recv_img, 0, self.row_index, out=self.full_img)
-            self._all_gather(self.recv_vis, self.visible, self.group, False)
-            return self.recv_vis.max(dim=0).values
-        if self.row_index is not None and self._side is not None:
-            self._side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(self._side):
-                self._work.wait()
-                torch.index_select(self.recv_img, 0, self.row_index, out=self.full_img)
-        self._all_gather(self.recv_vis, self.visible, self.group, False)
-        return self.recv_vis.max(dim=0).values
+
+    def _union_visibility(self) -> torch.Tensor:
+        """Union of the per-rank visibility flags, IN PLACE in `self.visible` (the buffer the forward kernel writes): ONE
+        all-reduce (MAX over 0/1 bytes).  Round 3 all-gathered the flags and reduced them with a `max(dim=0)` kernel plus a
+        copy into the graphs' static buffer: 47 us per step on the critical path at world size 1 (RCCL 2.26, measured through
+        BENCH_FORCE_DIST) against 14 us for the gradient all-reduce of 25x the bytes -- latency, not bandwidth."""
+        dist.all_reduce(self.visible, op=dist.ReduceOp.MAX, group=self.group)
+        return self.visible
 
     def finish(self) -> torch.Tensor:
         """Wait for the image bands; returns the full render (N, S, S, ch) (strided view, no copy for equal bands)."""
+        if self._side_img is not None:
+            torch.cuda.current_stream().wait_stream(self._side_img)   # issue point + (blocking / cyclic) everything behind it
         if self._work is not None:
-            if self.row_index is None:
+            if self.row_index is None or self._side_img is not None:
                 self._work.wait()
-            elif self._side is not None:
-                torch.cuda.current_stream().wait_stream(self._side)
             else:  # CPU (tests)
                 self._work.wait()
                 torch.index_select(self.recv_img, 0, self.row_index, out=self.full_img)
@@ -326,6 +349,14 @@ class OverlappedExchange:
         if self.row_index is not None:
             return self.full_img.permute(1, 0, 2, 3)
         return self.recv_img[:self.part.S].permute(1, 0, 2, 3)
+
+
+class _null_context:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
 
 
 class GatherRows(torch.autograd.Function):

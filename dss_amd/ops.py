@@ -106,6 +106,7 @@ def _rasterize_coarse(points, radii, cloud_to_packed_first_idx, num_points_per_c
     to be handed to :func:`_rasterize_fine`.  ``bin_size`` / ``max_points_per_bin`` are accepted and ignored (tile size
     and list capacity are chosen by the library; lists never truncate)."""
     lib = _lib.load()
+    src = _bin_source(points, radii)   # what the CALLER handed over (before any normalisation copy)
     points = _lib.require_gpu(points, "points", _f32)
     dev = points.device
     radii = _lib.require_gpu(radii, "radii", _f32)
@@ -124,8 +125,8 @@ def _rasterize_coarse(points, radii, cloud_to_packed_first_idx, num_points_per_c
     # what the fine pass needs besides the lists, and what the lists were built from.  Kept in a registry keyed by the
     # buffer's address (not as a Python attribute of the tensor, which views, autograd saves and `detach()` drop): any
     # tensor that still refers to this storage finds it; a copy (clone / to) does not and is refused with a clear message.
-    _bin_registry[bin_points.data_ptr()] = (weakref.ref(bin_points), first, num, N, P, S,
-                                            (points.data_ptr(), points._version, radii.data_ptr(), radii._version))
+    # keyed by the STORAGE address, so that a view with a storage offset still finds its entry
+    _bin_registry[bin_points.untyped_storage().data_ptr()] = (weakref.ref(bin_points), first, num, N, P, S, src)
     if len(_bin_registry) > 64:
         for k in [k for k, v in _bin_registry.items() if v[0]() is None]:
             del _bin_registry[k]
@@ -135,19 +136,28 @@ def _rasterize_coarse(points, radii, cloud_to_packed_first_idx, num_points_per_c
 _bin_registry = {}
 
 
+def _bin_source(points, radii):
+    """identity of the caller's tensors as handed over: address, layout and version counter (a non-contiguous input is
+    normalised into a temporary inside the call; comparing the temporary's address would reject the same tensor next time,
+    or accept another one that recycled the address)"""
+    return tuple((t.data_ptr(), tuple(t.shape), tuple(t.stride()), t._version) for t in (points, radii))
+
+
 def _rasterize_fine(points, ellipse_params, cutoff_thres, radii, bin_points, depth_merging_thres: float, image_size: int,
                     bin_size: int, points_per_pixel: int):
     """``DSS._C._rasterize_fine`` (ext.cpp:12, rasterize_points.h:257-285) on the ``bin_points`` of
     :func:`_rasterize_coarse` -> ``(idx, zbuf, qvalue, occupancy)`` like ``splat_points``."""
     lib = _lib.load()
-    meta = _bin_registry.get(bin_points.data_ptr()) if isinstance(bin_points, torch.Tensor) and bin_points.is_cuda else None
+    meta = _bin_registry.get(bin_points.untyped_storage().data_ptr()) \
+        if isinstance(bin_points, torch.Tensor) and bin_points.is_cuda else None
     if meta is None or meta[0]() is None:
         raise RuntimeError("bin_points must be the tensor dss_amd.ops._rasterize_coarse returned, or a view of it (opaque "
                            "tile lists, not the reference's dense (N,B,B,M) table; a clone / device copy is not accepted)")
-    _, first, num, N, P, S, src = meta
+    whole, first, num, N, P, S, src = meta
+    whole = whole()   # the tensor _rasterize_coarse returned (bin_points may be a view of it)
     if int(image_size) != S or points.shape[0] != P:
         raise RuntimeError("bin_points were built for image_size=%d and %d points" % (S, P))
-    if src != (points.data_ptr(), points._version, radii.data_ptr(), radii._version):
+    if src != _bin_source(points, radii):
         raise RuntimeError("bin_points were built from other points / radii tensors (or these were modified since)")
     _check_raster_inputs(points, ellipse_params, cutoff_thres, radii, first, num)
     points = _lib.require_gpu(points, "points", _f32)
@@ -163,8 +173,8 @@ def _rasterize_fine(points, ellipse_params, cutoff_thres, radii, bin_points, dep
         occ = torch.empty((N, S, S), dtype=_f32, device=dev)
         rc = lib.dss_splat_fine(_lib.ptr(points), _lib.ptr(ellipse_params), _lib.ptr(cutoff_thres), _lib.ptr(radii),
                                 _lib.ptr(first), _lib.ptr(num), N, P, float(depth_merging_thres), S, K, 0, S, _lib.ptr(idx),
-                                _lib.ptr(zbuf), _lib.ptr(qv), _lib.ptr(occ), None, _lib.ptr(bin_points) if P > 0 else None,
-                                bin_points.numel(), _lib.stream_ptr(dev))
+                                _lib.ptr(zbuf), _lib.ptr(qv), _lib.ptr(occ), None, _lib.ptr(whole) if P > 0 else None,
+                                whole.numel(), _lib.stream_ptr(dev))
     _lib.check(rc, "dss_splat_fine")
     return idx, zbuf, qv, occ
 

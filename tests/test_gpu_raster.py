@@ -469,6 +469,14 @@ def test_dss_c_same_name_mirrors(golden_dir):
             ops._rasterize_fine(d["points"], d["ellipse"], d["cutoff"], d["radii"], bins.clone(), thr, S, 16, K)
         with pytest.raises(RuntimeError, match="other points"):
             ops._rasterize_fine(d["points"].clone(), d["ellipse"], d["cutoff"], d["radii"], bins, thr, S, 16, K)
+        # non-contiguous inputs (normalised into a temporary inside each call) are recognised as the same
+        # tensors, and a view of the lists WITH a storage offset finds its metadata (keyed by the storage)
+        pts_nc = torch.cat([d["points"], d["points"]], dim=1)[:, :3]
+        rad_nc = torch.cat([d["radii"], d["radii"]], dim=1)[:, :2]
+        assert not pts_nc.is_contiguous() and not rad_nc.is_contiguous()
+        bins_nc = ops._rasterize_coarse(pts_nc, rad_nc, d["first"], d["num"], S, 16, 10000)
+        out_nc = ops._rasterize_fine(pts_nc, d["ellipse"], d["cutoff"], rad_nc, bins_nc[16:], thr, S, 16, K)
+        assert torch.equal(out_nc[0], out[0]) and torch.equal(out_nc[2], out[2])
         # _splat_points_occ_backward (CUDA form): every point, box support radii * radii_s
         got = ops._splat_points_occ_backward(d["points"], d["radii"], t(z["grad_occ"]), d["first"], d["num"],
                                              float(z["radii_s"]), thr)
