@@ -108,6 +108,7 @@ class Workload:
             # multi-GPU: the forward kernel writes its RGBA band and visibility flags straight into the
             # all-gather send buffers; the backward writes both gradients into one all-reduce bucket
             self.fx = OverlappedExchange(part, self.N, 4, self.P, device, force=self.multi)
+            self.fx.late_image = os.environ.get("BENCH_IMAGE_LATE", "0") == "1"
             self.bucket = torch.empty(self.P * 6, device=device)
 
     def step(self, ev=None):
@@ -153,7 +154,7 @@ class Workload:
             # collectives 1-2/3: the RGBA bands leave on their own communicator and arrive during the backward;
             # only the small visibility all-reduce is waited for here (the band collective is issued behind the backward)
             mark("forward_compute")
-            vis_all = self.fx.start_visibility()
+            vis_all = self.fx.start_visibility() if self.fx.late_image else self.fx.start()
             mark("wait_visibility_allgather")
             g_band = p.slice(self.grad_out).contiguous()
             g_feat = self.bucket[:self.P * 3].view(self.P, 3)
@@ -161,7 +162,8 @@ class Workload:
             # same fused kernel on the band; visibility = union over ranks, clip after the reduction
             ops.render_backward(g_band, idx, qv, wsum, info["scaler"], info["pts_screen"], info["radii"], vis_all,
                                 self.first, self.num, RADII_S, -1.0, image_size=S, rows=p.rows, out=(g_feat, g_pts))
-            self.fx.start_image()   # issued behind the backward's launches, from a side stream that only waits for the forward
+            if self.fx.late_image:
+                self.fx.start_image()   # issued behind the backward's launches, from a side stream that only waits for the forward
             mark("backward_compute")
             dist.all_reduce(self.bucket, op=dist.ReduceOp.SUM)  # collective 3/3: both gradient partials, one bucket
             mark("wait_gradient_allreduce")
@@ -228,10 +230,15 @@ class Workload:
         mark("start")
         self._graphs[0].replay()
         mark("forward_compute")
-        self.fx.start_visibility(out=self.vis_all)
+        late = self.fx.late_image   # BENCH_IMAGE_LATE=1: the image collective is issued behind the backward graph
+        if late:
+            self.fx.start_visibility(out=self.vis_all)
+        else:
+            self.fx.start(out=self.vis_all)
         mark("wait_visibility_allgather")
         self._graphs[1].replay()
-        self.fx.start_image()   # host issue hidden behind the backward graph; the collective itself only waits for the forward
+        if late:
+            self.fx.start_image()
         mark("backward_compute")
         dist.all_reduce(self.bucket, op=dist.ReduceOp.SUM)
         mark("wait_gradient_allreduce")
@@ -733,7 +740,7 @@ def main():
         dist_block = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "forced": force_dist,
                       "rccl_version": nccl_v,
                       "visible_devices": torch.cuda.device_count(), "partition": part.describe(),
-                      "overlap": bool(wl.fx.overlap), "degraded": wl.fx.degraded, "segment_capture": seg_note or "ok",
+                      "overlap": bool(wl.fx.overlap), "image_issue": "behind the backward (side stream)" if wl.fx.late_image else "before the backward, after the visibility union", "degraded": wl.fx.degraded, "segment_capture": seg_note or "ok",
                       "timing_us": {k: {"min": round(float(allt[:, i].min()), 1), "max": round(float(allt[:, i].max()), 1),
                                         "mean": round(float(allt[:, i].mean()), 1)} for i, k in enumerate(keys)},
                       "timing_how": "HIP events on the compute stream around each segment of 20 eager steps, per rank; "

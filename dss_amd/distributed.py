@@ -265,7 +265,8 @@ class OverlappedExchange:
         on_gpu = torch.device(device).type == "cuda"
         self._side_img = torch.cuda.Stream(device=device) if on_gpu else None   # issue stream of the image collective
         self._fwd_event = torch.cuda.Event() if on_gpu else None
-        self._fwd_done = None
+        self._fwd_done = self._issued_on = None
+        self.late_image = False
         # load-balanced (unequal) bands travel padded to the largest one; the rows are put in place by ONE gather
         # kernel on the side stream as soon as the collective completes, i.e. still during the backward
         self.full_img = self.row_index = None
@@ -282,18 +283,19 @@ class OverlappedExchange:
         return dist.all_gather_into_tensor(out2d, send, group=group, async_op=async_op)
 
     def start(self, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """Issue both exchanges (visibility first: it is the one the backward waits for); returns the union of the
-        visibility flags, uint8 (P,) (written into `out` if given: a static buffer that captured graphs read)."""
+        """Issue both exchanges; returns the union of the visibility flags, uint8 (P,) (written into `out` if given: a static
+        buffer that captured graphs read).  The visibility union goes FIRST: it is the one the backward waits for, and the
+        GPU executes it while the host is still issuing the image collective (an RCCL call costs the host 15-20 us; measured
+        at world size 1, profiles/r4_c_forced_dist_issue_order.txt)."""
         vis = self.start_visibility(out)
         self.start_image()
         return vis
 
     def start_visibility(self, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """The critical exchange alone (call `start_image` after the backward has been launched: an RCCL call costs the
-        host ~15-20 us, and the GPU would sit idle behind the visibility union while the image collective is being issued).
-        Records the point of the stream up to which the image bands are complete."""
+        """The critical exchange alone.  `late_image`: also records the point of the stream up to which the image bands are
+        complete, for a `start_image` that is called after more work has been enqueued."""
         self._fwd_done = None
-        if self._fwd_event is not None:
+        if self.late_image and self._fwd_event is not None:
             self._fwd_done = self._fwd_event
             self._fwd_done.record()
         vis = self._union_visibility()
@@ -303,15 +305,16 @@ class OverlappedExchange:
         return vis
 
     def start_image(self) -> None:
-        """The all-gather of the RGBA bands, asynchronous on its own communicator.  It is issued from a side stream that only
-        waits for the END OF THE FORWARD (the event of `start_visibility`), so that it overlaps with a backward that has
-        already been launched on the compute stream."""
+        """The all-gather of the RGBA bands, asynchronous on its own communicator.  `late_image` (the caller issues it AFTER
+        launching the backward, to hide the host's issue time behind it): the collective goes through a side stream that
+        only waits for the end of the forward, so that it still overlaps with the backward -- measured slower at world size
+        1 (the extra stream switch and event cost the host more than the reordering saves), hence off by default."""
         G = self.part.world_size
-        side = self._side_img
-        if side is not None and self._fwd_done is not None:
+        side = self._side_img if (self.late_image and self._fwd_done is not None) else None
+        if side is not None:
             side.wait_event(self._fwd_done)
-        ctx = torch.cuda.stream(side) if side is not None else _null_context()
-        with ctx:
+        self._issued_on = side
+        with (torch.cuda.stream(side) if side is not None else _null_context()):
             if self.overlap:
                 try:
                     self._work = self._all_gather(self.recv_img.view(G, -1), self.send_img.view(-1), self.image_group, True)
@@ -323,9 +326,14 @@ class OverlappedExchange:
                 self._work = None
                 if self.row_index is not None:
                     torch.index_select(self.recv_img, 0, self.row_index, out=self.full_img)
-            elif self.row_index is not None and side is not None:
+        if self._work is not None and self.row_index is not None and self._side_img is not None:
+            # unequal / cyclic bands: the rows are put in place on the side stream as soon as the collective completes
+            if side is None:
+                self._side_img.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._side_img):
                 self._work.wait()   # (the side stream waits for the collective, not the host)
                 torch.index_select(self.recv_img, 0, self.row_index, out=self.full_img)
+            self._issued_on = self._side_img
 
     def _union_visibility(self) -> torch.Tensor:
         """Union of the per-rank visibility flags, IN PLACE in `self.visible` (the buffer the forward kernel writes): ONE
@@ -337,13 +345,13 @@ class OverlappedExchange:
 
     def finish(self) -> torch.Tensor:
         """Wait for the image bands; returns the full render (N, S, S, ch) (strided view, no copy for equal bands)."""
-        if self._side_img is not None:
-            torch.cuda.current_stream().wait_stream(self._side_img)   # issue point + (blocking / cyclic) everything behind it
+        on_side = self._issued_on is not None
+        if on_side:
+            torch.cuda.current_stream().wait_stream(self._issued_on)   # the issue point and everything enqueued behind it
+            self._issued_on = None
         if self._work is not None:
-            if self.row_index is None or self._side_img is not None:
-                self._work.wait()
-            else:  # CPU (tests)
-                self._work.wait()
+            self._work.wait()
+            if self.row_index is not None and not on_side:  # CPU (tests)
                 torch.index_select(self.recv_img, 0, self.row_index, out=self.full_img)
             self._work = None
         if self.row_index is not None:
