@@ -76,6 +76,9 @@ class Workload:
         # multi: take the multi-GPU path (send buffers, three collectives, gradient bucket); forced at world size 1 by
         # BENCH_FORCE_DIST=1 so that a one-GPU box executes the RCCL code path
         self.multi = part.world_size > 1 if multi is None else bool(multi)
+        # renderer-owned cached point order (clouds above 2M points: cfg4 / cfg5): every k-th step sorts and saves the
+        # order, the others bin through it (`SurfaceSplattingRenderer(order_refresh=k)`); 0 = every step sorts
+        self.order_refresh = int(os.environ.get("BENCH_ORDER_REFRESH", "16")) if n_cams * pts.shape[0] > 2_000_000 else 0
         S = part.S  # image side (module constant S for the benchmark; tools/bench_large.py passes others)
         self.Pc = pts.shape[0]
         self.P = self.N * self.Pc
@@ -104,6 +107,7 @@ class Workload:
         if not self.multi and self.N == 1 and part.world_size == 1:
             self._plan = ops.FusedPlan(device, 1, self.Pc, self.P, S, K, 3, True, False, False, False, CUTOFF, SIGMA, THR,
                                        want_zbuf=True)
+            self._plan.order_refresh = self.order_refresh
         if self.multi:
             # multi-GPU: the forward kernel writes its RGBA band and visibility flags straight into the
             # all-gather send buffers; the backward writes both gradients into one all-reduce bucket
@@ -137,7 +141,7 @@ class Workload:
         f = ops.render_forward(self.world, self.normals, self.h, self.M, self.V, self.znear, self.zfar, self.first,
                                self.num, self.colors, S, K, CUTOFF, THR, SIGMA, False, True, rows=p.rows,
                                out_image=self.fx.image if multi else None,
-                               out_visible=self.fx.visible if multi else None)
+                               out_visible=self.fx.visible if multi else None, order_refresh=self.order_refresh)
         info = {"pts_screen": f["pts_screen"], "radii": f["radii"], "scaler": f["scaler"], "valid": f["valid"]}
         idx, qv, vis, band, wsum = f["idx"], f["qvalue"], f["visible"], f["image"], f["wsum"]
         if not multi:
@@ -517,7 +521,7 @@ def main():
     args = ap.parse_args()
     large = args.workload != "cfg2"
     if args.steps is None:
-        args.steps = 20 if large else 200
+        args.steps = 32 if large else 200   # (large: two periods of the cached point order, BENCH_ORDER_REFRESH = 16)
     if args.warmup is None:
         args.warmup = 5 if large else 20
 
@@ -616,6 +620,8 @@ def main():
     graph, graph_u, ms_modes = None, None, {}
     unrollable = args.steps % UNROLL == 0 and args.steps >= UNROLL
     mode = args.mode or ("eager" if multi else None)
+    if large and wl.order_refresh > 0 and mode is None:
+        mode = "eager"   # (a captured step would freeze ONE of the two kinds of call: the saving or the reusing one)
     seg_note = None
     if multi and args.mode != "eager":
         # multi-GPU: the RCCL calls stay outside any graph, the compute segments between them are graphs
@@ -831,8 +837,10 @@ def main():
     if rank == 0:
         if large:
             wtxt = ("BASELINE configs[%d]: synthetic %d-point cloud, %d camera(s), %dx%d, K=5, fwd+bwd, image rows sharded "
-                    "over %d rank(s), randomly ordered points, density-scaled h" % (3 if args.workload == "cfg4" else 4,
-                                                                                   wl.Pc, wl.N, S, S, world))
+                    "over %d rank(s), randomly ordered points, density-scaled h; point order of the binning %s"
+                    % (3 if args.workload == "cfg4" else 4, wl.Pc, wl.N, S, S, world,
+                       ("cached by the renderer: sorted and saved every %d-th step, reused by the others (all inside the "
+                        "timed region)" % wl.order_refresh) if wl.order_refresh > 0 else "sorted in every step"))
         else:
             wtxt = ("BASELINE configs[1]: bunny-8000 x4 jitter = %d pts/cloud, %d camera(s), "
                     "512x512, K=5, fwd+bwd (setup+raster+blend and their backward), "

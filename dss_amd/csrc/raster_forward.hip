@@ -21,6 +21,8 @@
 #include "setup_body.h"
 #include <stdlib.h>
 #include <atomic>
+#include <mutex>
+#include <vector>
 
 namespace dss {
 
@@ -394,7 +396,7 @@ __global__ __launch_bounds__(256) void spill_kernel(
 struct SortGrid {
     int shift;     // cell side = 1 << shift pixels
     int cx, cy;    // cells per image row / column
-    int total;     // N * cx * cy (<= SORT_CELL_MAX)
+    int total;     // N * cx * cy + 1 (<= SORT_CELL_MAX)
 };
 static SortGrid make_sort_grid(int N, int S)
 {
@@ -403,7 +405,7 @@ static SortGrid make_sort_grid(int N, int S)
     for (;;) {
         c.cx = ((S - 1) >> c.shift) + 1;
         c.cy = c.cx;
-        c.total = N * c.cx * c.cy;
+        c.total = N * c.cx * c.cy + 1;   // + the cell of the culled splats (last; only filled when the order is saved)
         if (c.total <= SORT_CELL_MAX || c.shift >= 14) break;
         ++c.shift;
     }
@@ -421,16 +423,46 @@ static inline size_t sort_blocks(int64_t P)
     const int64_t chunk = (int64_t)SORT_THREADS * sort_per_thread(P);
     return (size_t)((P + chunk - 1) / chunk);
 }
+// MODE 0: the order of this call only (culled splats are left out).  MODE 1 (DSS_WS_ORDER_SAVE): culled splats are sorted
+// too, into the last cell, so that the order is a permutation of ALL points and stays usable when the culling changes.
+// MODE 2 (DSS_WS_ORDER_REUSE): no histogram at all -- the setup alone, plus the 16-byte binning record (px, py, rx, ry) of
+// every point in NATURAL order (rx = -1: culled) that bin_sorted_kernel<true> gathers through the saved order.
+template <int MODE>
 __global__ __launch_bounds__(SORT_THREADS) void setup_cell_kernel(const SetupArgs A, SortGrid sg, int per_thread,
                                                                    uint32_t *__restrict__ cell_of,
                                                                    uint32_t *__restrict__ block_hist, Spill sp,
-                                                                   uint8_t *__restrict__ visible_to_clear)
+                                                                   uint8_t *__restrict__ visible_to_clear,
+                                                                   float4 *__restrict__ geo)
 {
     extern __shared__ uint32_t s_hist[];
     if (sp.ctrl && blockIdx.x == 0 && threadIdx.x == 0) spill_begin(sp);
-    for (int c = threadIdx.x; c < sg.total; c += SORT_THREADS) s_hist[c] = 0u;
-    __syncthreads();
+    if (MODE != 2) {
+        for (int c = threadIdx.x; c < sg.total; c += SORT_THREADS) s_hist[c] = 0u;
+        __syncthreads();
+    }
     const int64_t b0 = (int64_t)blockIdx.x * SORT_THREADS * per_thread;
+    if (MODE == 2) {
+        // this kernel is nothing but streaming stores (~140 bytes per point): full wavefronts write them as contiguous runs
+        // (setup_wave_store; the dynamic LDS of this instantiation is 4 KB per wavefront)
+        float4 *wave_lds = reinterpret_cast<float4 *>(s_hist) + (threadIdx.x >> 6) * 256;
+        const bool wide = setup_wide_ok(A);
+#pragma unroll 1
+        for (int u = 0; u < per_thread; ++u) {
+            const int64_t p0 = b0 + (int64_t)u * SORT_THREADS + (threadIdx.x & ~63);   // first point of the wavefront
+            if (p0 >= A.P) break;
+            const int64_t p = p0 + (threadIdx.x & 63);
+            const bool full = wide && p0 + 64 <= A.P;
+            if (!full && p >= A.P) continue;
+            if (visible_to_clear) visible_to_clear[p] = 0;
+            const int n = find_cloud(p, A.first_idx, A.num_pts, A.N);
+            const SetupVals v = setup_point_compute(A, p, n);
+            if (full) setup_wave_store(A, p0, v, wave_lds);
+            else setup_point_store(A, p, v);
+            const bool live = n >= 0 && !(v.sz < 0);   // culled splats (pz = -1) never reach a tile list
+            geo[p] = make_float4(v.sx, v.sy, live ? v.rx : -1.0f, v.ry);
+        }
+        return;
+    }
 #pragma unroll 1
     for (int u = 0; u < per_thread; ++u) {
         const int64_t p = b0 + (int64_t)u * SORT_THREADS + threadIdx.x;
@@ -439,14 +471,17 @@ __global__ __launch_bounds__(SORT_THREADS) void setup_cell_kernel(const SetupArg
         const int n = find_cloud(p, A.first_idx, A.num_pts, A.N);
         float px, py, pz, rx, ry;
         setup_point(A, p, n, px, py, pz, rx, ry);
+        const bool live = n >= 0 && !(pz < 0);   // culled splats (pz = -1) never reach a tile list
         uint32_t key = SORT_NO_CELL;
-        if (n >= 0 && !(pz < 0)) {   // culled splats (pz = -1) never reach a tile list: they are left out of the order
+        if (live) {
             // pixel column / row of the centre (any monotone map of NDC does: only neighbourhood matters); NaN -> cell 0
             const float fx = (1.0f - px) * 0.5f * (float)A.S, fy = (1.0f - py) * 0.5f * (float)A.S;
             const int ix = min(max((int)fx, 0), A.S - 1) >> sg.shift, iy = min(max((int)fy, 0), A.S - 1) >> sg.shift;
             key = (uint32_t)((n * sg.cy + iy) * sg.cx + ix);
-            atomicAdd(&s_hist[key], 1u);
+        } else if (MODE == 1) {
+            key = (uint32_t)(sg.total - 1);
         }
+        if (key != SORT_NO_CELL) atomicAdd(&s_hist[key], 1u);
         cell_of[p] = key;
     }
     __syncthreads();
@@ -543,7 +578,8 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(
         const uint32_t key = cell_of[p];
         if (key == SORT_NO_CELL) continue;
         const float2 rr = reinterpret_cast<const float2 *>(radii)[p];
-        const float4 ge = make_float4(points[3 * p], points[3 * p + 1], rr.x, rr.y);
+        // (the last cell only receives splats when the order is saved: the culled ones, rx = -1 for the binning)
+        const float4 ge = make_float4(points[3 * p], points[3 * p + 1], key == (uint32_t)(sg.total - 1) ? -1.0f : rr.x, rr.y);
         const uint32_t pos = atomicAdd(&s_hist[key], 1u);
         s_geo[pos] = ge;
         s_id[pos] = (int32_t)p;
@@ -562,14 +598,19 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(
 #define SORT_EMPTY 0xffffffffu
 // (256 threads x 4 splats: a 1024-thread workgroup with one splat per thread ran one workgroup per CU -- four barrier-
 // separated phases of dependent latencies with nothing else resident to hide them: 508 us at 8M splats)
+// GATHER (DSS_WS_ORDER_REUSE): s_id is the order an earlier call saved -- a permutation of all P points --, s_geo the
+// records of THIS call in natural order: entry i bins point s_id[i] with s_geo[s_id[i]] (one 16-byte sector per splat).
+// Any permutation gives the same tile lists up to the order of their entries, which the fine pass does not depend on; a
+// stale order only costs locality.  (Ids are clamped to [0, P): a workspace that lost its order cannot fault.)
+template <bool GATHER>
 __global__ __launch_bounds__(SORT_BIN_THREADS) void bin_sorted_kernel(
     const float4 *__restrict__ s_geo, const int32_t *__restrict__ s_id, const uint32_t *__restrict__ sorted_count,
     const int64_t *__restrict__ first_idx, const int64_t *__restrict__ num_pts, int N, TileGrid g,
-    uint32_t *__restrict__ counts, int32_t *__restrict__ lists, uint32_t cap, TileQueue tq, Spill sp)
+    uint32_t *__restrict__ counts, int32_t *__restrict__ lists, uint32_t cap, TileQueue tq, Spill sp, uint32_t P)
 {
     __shared__ uint32_t h_key[SORT_HASH];
     __shared__ uint32_t h_cnt[SORT_HASH];   // count of the key, then (after the reservation) the run's first list position
-    const uint32_t count = *sorted_count;
+    const uint32_t count = GATHER ? P : *sorted_count;
     const uint32_t b0 = blockIdx.x * SORT_BIN_CHUNK;
     if (b0 >= count) return;
     for (int k = threadIdx.x; k < SORT_HASH; k += SORT_BIN_THREADS) { h_key[k] = SORT_EMPTY; h_cnt[k] = 0u; }
@@ -582,7 +623,14 @@ __global__ __launch_bounds__(SORT_BIN_THREADS) void bin_sorted_kernel(
         const uint32_t i = b0 + (uint32_t)j * SORT_BIN_THREADS + threadIdx.x;
         const uint32_t ic = i < count ? i : count - 1u;
         pid[j] = i < count ? s_id[ic] : -1;
-        ge[j] = s_geo[ic];
+        if (!GATHER) ge[j] = s_geo[ic];
+    }
+    if (GATHER) {
+#pragma unroll
+        for (int j = 0; j < SORT_BIN_PER_THREAD; ++j) {
+            if (pid[j] >= 0) pid[j] = (int)min((uint32_t)pid[j], P - 1u);
+            ge[j] = s_geo[pid[j] >= 0 ? pid[j] : 0];
+        }
     }
     __syncthreads();
     int cl[SORT_BIN_PER_THREAD], rx0[SORT_BIN_PER_THREAD], rx1[SORT_BIN_PER_THREAD], ry0[SORT_BIN_PER_THREAD], ry1[SORT_BIN_PER_THREAD];
@@ -593,7 +641,8 @@ __global__ __launch_bounds__(SORT_BIN_THREADS) void bin_sorted_kernel(
         const uint32_t sub = ((uint32_t)j + 4u * (threadIdx.x & 1u)) & (DSS_SUB - 1);
         int tx0 = 0, tx1 = -1, ty0 = 0, ty1 = -1;
         cl[j] = pid[j] >= 0 ? find_cloud(pid[j], first_idx, num_pts, N) : -1;
-        bool any = cl[j] >= 0 && splat_tile_rect(ge[j].x, ge[j].y, 0.0f, ge[j].z, ge[j].w, g, tx0, tx1, ty0, ty1);
+        bool any = cl[j] >= 0 && !(ge[j].z < 0) /* culled splat of a saved order */ &&
+                   splat_tile_rect(ge[j].x, ge[j].y, 0.0f, ge[j].z, ge[j].w, g, tx0, tx1, ty0, ty1);
         const bool small = any && tx1 - tx0 <= 1 && ty1 - ty0 <= 1;
         rx0[j] = tx0; rx1[j] = tx1; ry0[j] = ty0; ry1[j] = ty1;
         onm[j] = (any && !small) ? 16u : 0u;
@@ -1997,6 +2046,43 @@ extern "C" __attribute__((visibility("default"))) int dss_debug_set_fine_timing(
 // Fused single-call forward: [setup + binning] -> [fine + blend]: two kernel launches plus the counter
 // memset, and neither the screen records nor the fragment lists are re-read by a separate pass.
 // ---------------------------------------------------------------------------------------------
+// Workspaces that hold a saved point order (DSS_WS_ORDER_SAVE), host-side bookkeeping at call time: the calls on a workspace
+// are stream-ordered, so an order saved by an earlier call is complete when a later call's kernels read it.
+// what: 1 = this call saves, 2 = this call reuses (error unless an order of the same N, P, S is registered), 0 = this call
+// sorts for itself and overwrites whatever order the workspace held.
+namespace dss {
+struct SavedOrder { void *ws; int N; int64_t P; int S; };
+static int saved_order_update(void *ws, int N, int64_t P, int S, int what)
+{
+    static std::mutex mu;
+    static std::vector<SavedOrder> table;
+    std::lock_guard<std::mutex> lock(mu);
+    size_t at = table.size();
+    for (size_t i = 0; i < table.size(); ++i)
+        if (table[i].ws == ws) { at = i; break; }
+    if (what == 2) {
+        if (at == table.size() || table[at].N != N || table[at].P != P || table[at].S != S) {
+            set_error("dss_render_forward: DSS_WS_ORDER_REUSE, but no call with DSS_WS_ORDER_SAVE and the same N, P, S has "
+                      "run on this workspace (or a call without either flag has overwritten its order since)");
+            return DSS_ERR_INVALID_ARGUMENT;
+        }
+        return DSS_OK;
+    }
+    if (what == 1) {
+        const SavedOrder e = {ws, N, P, S};
+        if (at == table.size()) {
+            if (table.size() >= 64) table.erase(table.begin());
+            table.push_back(e);
+        } else {
+            table[at] = e;
+        }
+    } else if (at != table.size()) {
+        table.erase(table.begin() + (long)at);
+    }
+    return DSS_OK;
+}
+}  // namespace dss
+
 extern "C" size_t dss_render_forward_workspace(int N, int64_t P, int S, int K)
 {
     (void)K;
@@ -2044,6 +2130,12 @@ extern "C" int dss_render_forward(const float *world, const float *normals, cons
     if ((long long)N * tiles > 0x7fffffffll) { set_error("dss_render_forward: too many tiles"); return DSS_ERR_UNSUPPORTED; }
     FwdWorkspace w = carve_fwd(workspace, N, P, S, true);
     const bool packed = C == 3 && !lean_workspace();  // the records carry three feature channels
+    const int ws_flags = workspace_state & ~0xf;   // DSS_WS_ORDER_*
+    workspace_state &= 0xf;
+    if ((unsigned)workspace_state > DSS_WS_BINNED || (ws_flags & ~(DSS_WS_ORDER_SAVE | DSS_WS_ORDER_REUSE))) {
+        set_error("dss_render_forward: unknown workspace_state %d", workspace_state | ws_flags);
+        return DSS_ERR_INVALID_ARGUMENT;
+    }
     const bool clean = workspace_state == DSS_WS_CLEAN;
     const bool rerun = workspace_state == DSS_WS_BINNED;  // lists + records of this very input are in place: fine pass only
     if (!clean && !rerun && hipMemsetAsync(w.counts, 0, w.count_bytes, st) != hipSuccess)
@@ -2060,25 +2152,44 @@ extern "C" int dss_render_forward(const float *world, const float *normals, cons
     const int tb = 64;   // (64 / 128 / 256 threads measure the same at 8 x 1M and 4M points: not dispatch-bound there either)
     const int pb = (int)((P + tb - 1) / tb);
     const bool sorted = w.sort_cell_of != nullptr;   // large inputs: cell-ordered binning (see setup_cell_kernel)
+    // DSS_WS_ORDER_SAVE / DSS_WS_ORDER_REUSE (cell-ordered path only; no effect on the direct binning of smaller inputs)
+    const bool save_order = sorted && !rerun && (ws_flags & DSS_WS_ORDER_SAVE);
+    const bool reuse_order = sorted && !rerun && !save_order && (ws_flags & DSS_WS_ORDER_REUSE);
+    if (sorted && !rerun) {
+        const int rc_o = saved_order_update(workspace, N, P, S, save_order ? 1 : (reuse_order ? 2 : 0));
+        if (rc_o) return rc_o;
+    }
     if (!rerun && sorted) {
         const SortGrid sg = make_sort_grid(N, S);
         const unsigned sb = (unsigned)sort_blocks(P);
         const int per = sort_per_thread(P);
         const size_t lds = (size_t)sg.total * 4;
-        hipLaunchKernelGGL(setup_cell_kernel, dim3(sb), dim3(SORT_THREADS), lds, st, SA, sg, per, w.sort_cell_of,
-                           w.sort_block_hist, w.spill, visible);
-        const unsigned nseg = (sb + SORT_SEG - 1) / SORT_SEG;
-        hipLaunchKernelGGL(sort_block_scan_kernel, dim3((unsigned)((sg.total + 255) / 256), nseg), dim3(256), 0, st, sb,
-                           sg.total, w.sort_block_hist, w.sort_seg_tot);
-        hipLaunchKernelGGL(sort_seg_scan_kernel, dim3((unsigned)((sg.total + 255) / 256)), dim3(256), 0, st, nseg, sg.total,
-                           w.sort_seg_tot, w.sort_cell_total);
-        hipLaunchKernelGGL(sort_cell_scan_kernel, dim3(1), dim3(1024), 0, st, w.sort_cell_total, w.sort_cell_start, sg.total,
-                           w.sort_count);
-        hipLaunchKernelGGL(sort_scatter_kernel, dim3(sb), dim3(SORT_THREADS), lds, st, pts_screen, radii, P, sg, per,
-                           w.sort_cell_of, w.sort_cell_start, w.sort_block_hist, w.sort_seg_tot, w.sort_geo, w.sort_id);
-        hipLaunchKernelGGL(bin_sorted_kernel, dim3((unsigned)((P + SORT_BIN_CHUNK - 1) / SORT_BIN_CHUNK)),
-                           dim3(SORT_BIN_THREADS), 0, st, w.sort_geo, w.sort_id, w.sort_count, first_idx, num_pts, N, g, w.counts,
-                           w.lists, w.cap, w.queue, w.spill);
+        const unsigned bin_wgs = (unsigned)((P + SORT_BIN_CHUNK - 1) / SORT_BIN_CHUNK);
+        if (reuse_order) {
+            // the point order an earlier call left in the workspace: setup in natural order + one gathered binning pass
+            hipLaunchKernelGGL(setup_cell_kernel<2>, dim3(sb), dim3(SORT_THREADS), (SORT_THREADS / 64) * 4096, st, SA, sg, per, w.sort_cell_of,
+                               w.sort_block_hist, w.spill, visible, w.sort_geo);
+            hipLaunchKernelGGL(bin_sorted_kernel<true>, dim3(bin_wgs), dim3(SORT_BIN_THREADS), 0, st, w.sort_geo, w.sort_id,
+                               w.sort_count, first_idx, num_pts, N, g, w.counts, w.lists, w.cap, w.queue, w.spill, (uint32_t)P);
+        } else {
+            if (save_order)
+                hipLaunchKernelGGL(setup_cell_kernel<1>, dim3(sb), dim3(SORT_THREADS), lds, st, SA, sg, per, w.sort_cell_of,
+                                   w.sort_block_hist, w.spill, visible, w.sort_geo);
+            else
+                hipLaunchKernelGGL(setup_cell_kernel<0>, dim3(sb), dim3(SORT_THREADS), lds, st, SA, sg, per, w.sort_cell_of,
+                                   w.sort_block_hist, w.spill, visible, w.sort_geo);
+            const unsigned nseg = (sb + SORT_SEG - 1) / SORT_SEG;
+            hipLaunchKernelGGL(sort_block_scan_kernel, dim3((unsigned)((sg.total + 255) / 256), nseg), dim3(256), 0, st, sb,
+                               sg.total, w.sort_block_hist, w.sort_seg_tot);
+            hipLaunchKernelGGL(sort_seg_scan_kernel, dim3((unsigned)((sg.total + 255) / 256)), dim3(256), 0, st, nseg, sg.total,
+                               w.sort_seg_tot, w.sort_cell_total);
+            hipLaunchKernelGGL(sort_cell_scan_kernel, dim3(1), dim3(1024), 0, st, w.sort_cell_total, w.sort_cell_start, sg.total,
+                               w.sort_count);
+            hipLaunchKernelGGL(sort_scatter_kernel, dim3(sb), dim3(SORT_THREADS), lds, st, pts_screen, radii, P, sg, per,
+                               w.sort_cell_of, w.sort_cell_start, w.sort_block_hist, w.sort_seg_tot, w.sort_geo, w.sort_id);
+            hipLaunchKernelGGL(bin_sorted_kernel<false>, dim3(bin_wgs), dim3(SORT_BIN_THREADS), 0, st, w.sort_geo, w.sort_id,
+                               w.sort_count, first_idx, num_pts, N, g, w.counts, w.lists, w.cap, w.queue, w.spill, (uint32_t)P);
+        }
         hipLaunchKernelGGL(queue_build_kernel, dim3((unsigned)((N * tiles + 1023) / 1024)), dim3(1024), 0, st, w.counts,
                            N * tiles, g, w.queue);
     } else if (!rerun) {

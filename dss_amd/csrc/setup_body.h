@@ -29,10 +29,14 @@ struct SetupArgs {
     const float *feat;
 };
 
-// Setup of packed point p of cloud n (n < 0: unowned point -> culled).  Writes every output array and
-// returns the screen-space record the binning pass needs (px, py, pz, rx, ry).
-__device__ __forceinline__ void setup_point(const SetupArgs &A, int64_t p, int n, float &o_px, float &o_py, float &o_pz,
-                                            float &o_rx, float &o_ry)
+// Everything the setup of one point produces (the values of the output arrays at index p).
+struct SetupVals {
+    float sx, sy, sz, ea, eb, ec, rx, ry, sc, fr0, fr1, fr2;
+    uint8_t ok;
+};
+
+// Setup of packed point p of cloud n (n < 0: unowned point -> culled): the arithmetic alone.
+__device__ __forceinline__ SetupVals setup_point_compute(const SetupArgs &A, int64_t p, int n)
 {
     float sx = 0.f, sy = 0.f, sz = -1.0f, ea = 1.f, eb = 0.f, ec = 1.f, rx = 0.f, ry = 0.f, sc = 0.f;
     uint8_t ok = 0;
@@ -128,20 +132,86 @@ __device__ __forceinline__ void setup_point(const SetupArgs &A, int64_t p, int n
             sc = absdetMk / eps_denom_py(s2);
         }
     }
-    A.screen[3 * p] = sx; A.screen[3 * p + 1] = sy; A.screen[3 * p + 2] = sz;
-    A.ellipse[3 * p] = ea; A.ellipse[3 * p + 1] = eb; A.ellipse[3 * p + 2] = ec;
-    A.radii[2 * p] = rx; A.radii[2 * p + 1] = ry;
-    A.scaler[p] = sc;
+    SetupVals v;
+    v.sx = sx; v.sy = sy; v.sz = sz; v.ea = ea; v.eb = eb; v.ec = ec; v.rx = rx; v.ry = ry; v.sc = sc;
+    v.fr0 = fr0; v.fr1 = fr1; v.fr2 = fr2; v.ok = ok;
+    return v;
+}
+
+// one thread writes the outputs of its point
+__device__ __forceinline__ void setup_point_store(const SetupArgs &A, int64_t p, const SetupVals &v)
+{
+    A.screen[3 * p] = v.sx; A.screen[3 * p + 1] = v.sy; A.screen[3 * p + 2] = v.sz;
+    A.ellipse[3 * p] = v.ea; A.ellipse[3 * p + 1] = v.eb; A.ellipse[3 * p + 2] = v.ec;
+    A.radii[2 * p] = v.rx; A.radii[2 * p + 1] = v.ry;
+    A.scaler[p] = v.sc;
     A.cutoff[p] = A.cutoffC;
-    A.valid[p] = ok;
+    A.valid[p] = v.ok;
     if (A.rec) {
         float4 *R = A.rec + 4 * (size_t)p;
-        R[0] = make_float4(sx, sy, rx, ry);
-        R[1] = make_float4(ea, eb, ec, A.cutoffC);
-        R[2] = make_float4(sc, fr0, fr1, fr2);
-        R[3] = make_float4(sz, 0.0f, 0.0f, 0.0f);
+        R[0] = make_float4(v.sx, v.sy, v.rx, v.ry);
+        R[1] = make_float4(v.ea, v.eb, v.ec, A.cutoffC);
+        R[2] = make_float4(v.sc, v.fr0, v.fr1, v.fr2);
+        R[3] = make_float4(v.sz, 0.0f, 0.0f, 0.0f);
     }
-    o_px = sx; o_py = sy; o_pz = sz; o_rx = rx; o_ry = ry;
+}
+
+// Writes every output array and returns the screen-space record the binning pass needs (px, py, pz, rx, ry).
+__device__ __forceinline__ void setup_point(const SetupArgs &A, int64_t p, int n, float &o_px, float &o_py, float &o_pz,
+                                            float &o_rx, float &o_ry)
+{
+    const SetupVals v = setup_point_compute(A, p, n);
+    setup_point_store(A, p, v);
+    o_px = v.sx; o_py = v.sy; o_pz = v.sz; o_rx = v.rx; o_ry = v.ry;
+}
+
+// The same stores for the 64 CONSECUTIVE points [p0, p0 + 64) of a wavefront (lane l holds point p0 + l), transposed through
+// 4 KB of LDS owned by the wavefront so that every store instruction writes one contiguous run: the (P,3) arrays as 48
+// float4 (instead of three dword stores at a 12-byte lane stride), the 64-byte records as four runs of 1 KB (instead of four
+// float4 stores at a 64-byte lane stride, every lane in a cache line of its own).  Needs 16-byte aligned screen / ellipse /
+// record arrays and an 8-byte aligned radii array (`wide`, wave-uniform; the caller falls back to setup_point_store).
+__device__ __forceinline__ bool setup_wide_ok(const SetupArgs &A)
+{
+    return ((((uintptr_t)A.screen | (uintptr_t)A.ellipse | (uintptr_t)A.rec) & 15u) | ((uintptr_t)A.radii & 7u)) == 0;
+}
+__device__ __forceinline__ void setup_wave_store(const SetupArgs &A, int64_t p0, const SetupVals &v, float4 *lds /* [256] */)
+{
+    const int lane = threadIdx.x & 63;
+    float *l1 = reinterpret_cast<float *>(lds);
+    l1[3 * lane] = v.sx; l1[3 * lane + 1] = v.sy; l1[3 * lane + 2] = v.sz;
+    l1[192 + 3 * lane] = v.ea; l1[192 + 3 * lane + 1] = v.eb; l1[192 + 3 * lane + 2] = v.ec;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 48) {
+        const float4 a = lds[lane], b = lds[48 + lane];
+        reinterpret_cast<float4 *>(A.screen + 3 * p0)[lane] = a;
+        reinterpret_cast<float4 *>(A.ellipse + 3 * p0)[lane] = b;
+    }
+    const int64_t p = p0 + lane;
+    reinterpret_cast<float2 *>(A.radii)[p] = make_float2(v.rx, v.ry);
+    A.scaler[p] = v.sc;
+    A.cutoff[p] = A.cutoffC;
+    A.valid[p] = v.ok;
+    if (A.rec) {
+        __builtin_amdgcn_wave_barrier();
+        // record quarter k of lane l at float4 slot 4 l + k, rotated by l / 4 within the record so that the 16 lanes of a
+        // quarter-wave spread over the banks
+        const int rot = (lane >> 2) & 3;
+        lds[4 * lane + ((0 + rot) & 3)] = make_float4(v.sx, v.sy, v.rx, v.ry);
+        lds[4 * lane + ((1 + rot) & 3)] = make_float4(v.ea, v.eb, v.ec, A.cutoffC);
+        lds[4 * lane + ((2 + rot) & 3)] = make_float4(v.sc, v.fr0, v.fr1, v.fr2);
+        lds[4 * lane + ((3 + rot) & 3)] = make_float4(v.sz, 0.0f, 0.0f, 0.0f);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        float4 *R = A.rec + 4 * (size_t)p0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            // float4 slot s = 64 k + lane of the wave's 4 KB belongs to point s / 4, quarter s % 4
+            const int s = 64 * k + lane, pt = s >> 2, q = s & 3;
+            R[s] = lds[4 * pt + ((q + ((pt >> 2) & 3)) & 3)];
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
 }
 
 

@@ -431,12 +431,26 @@ def band_rows(row0: int, row1: int, cycle: int = 1) -> int:
     return full * 8 + min(rem, 8)
 
 
+def _order_state(ws, state: int, shape, order_refresh: int) -> int:
+    """workspace_state of a dss_render_forward call on buffer `ws` under the cached point order (``order_refresh`` = k: the
+    order saved by one call serves the next k - 1 calls on the same buffer).  The age lives on the buffer OBJECT: a new
+    buffer -- or one whose last call failed and was dropped -- starts with a save."""
+    if order_refresh <= 0 or state not in (0, 1):
+        return state
+    age = getattr(ws, "_dss_order_age", None)
+    if age is None or age[0] != shape or age[1] + 1 >= int(order_refresh):
+        ws._dss_order_age = (shape, 0)
+        return state | _lib.WS_ORDER_SAVE
+    ws._dss_order_age = (shape, age[1] + 1)
+    return state | _lib.WS_ORDER_REUSE
+
+
 def render_forward(world, normals, h, M, V, znear, zfar, cloud_to_packed_first_idx, num_points_per_cloud, features,
                    image_size: int, points_per_pixel: int, cutoff_threshold: float, depth_merging_thres: float,
                    antialiasing_sigma: float = 1.0, backface_culling: bool = False, shared_cloud: bool = False,
                    rows: Optional[Tuple[int, int]] = None, out_image: Optional[torch.Tensor] = None,
                    out_visible: Optional[torch.Tensor] = None, vr6=None, frame_normals=None, want_zbuf: bool = True,
-                   workspace_state: int = 1):
+                   workspace_state: int = 1, order_refresh: int = 0):
     """Fused forward (setup + binning + fine + blend, ``dss_render_forward``).  ``out_image`` (float32
     (N,rows,S,C+1), 16-byte aligned) / ``out_visible`` (uint8 (P,)) let the caller place these two outputs
     in its own buffer (the multi-GPU step points them into one all-gather send buffer).  ``features`` are the
@@ -445,7 +459,10 @@ def render_forward(world, normals, h, M, V, znear, zfar, cloud_to_packed_first_i
     visible, image, wsum``.  ``want_zbuf=False`` skips the depth plane (``zbuf`` is None): the fused backward never reads it.
     ``workspace_state``: 1 = DSS_WS_CLEAN (default: cached zero-initialised workspace, no memset launch), 0 = DSS_WS_UNKNOWN
     (memset + both launches, lists stay in place), 2 = DSS_WS_BINNED (after a state-0 call with the same inputs: repeat only
-    the fine + blend launch; profiling / timing of the dominant kernel)."""
+    the fine + blend launch; profiling / timing of the dominant kernel).
+    ``order_refresh`` = k > 0: renderer-owned cached point order (DSS_WS_ORDER_SAVE / DSS_WS_ORDER_REUSE, above 2M points):
+    the screen-cell order that the binning sorts the points into is kept in the workspace of this problem size and reused by
+    the next k - 1 calls on it, which then skip the sort (same outputs bit for bit; a stale order only costs locality)."""
     lib = _lib.load()
     world = _lib.require_gpu(world, "world", _f32)
     dev = world.device
@@ -495,8 +512,9 @@ def render_forward(world, normals, h, M, V, znear, zfar, cloud_to_packed_first_i
                                "(any camera / row strides that are multiples of 4 floats); out_visible uint8 (P,)")
         _keep, vr_p, fn_p = _aniso_args(vr6, frame_normals, Pw)
         # dedicated zero-initialised buffer per problem size: the library keeps it clean (no memset launch)
-        tag = ("render_forward" if workspace_state == 1 else "render_forward_binned", N, P, S)
+        tag = ("render_forward" if (int(workspace_state) & 0xf) == 1 else "render_forward_binned", N, P, S)
         ws = _lib.clean_workspace(dev, tag, lib.dss_render_forward_workspace(N, P, S, K))
+        state = _order_state(ws, int(workspace_state), (N, P, S), order_refresh)
         rc = lib.dss_render_forward(
             _lib.ptr(world), _lib.ptr(normals), _lib.ptr(h) if per_point else None, None if per_point else _lib.ptr(h),
             vr_p, fn_p, _lib.ptr(M), _lib.ptr(V), _lib.ptr(znear), _lib.ptr(zfar), _lib.ptr(first), _lib.ptr(num), N, P,
@@ -505,7 +523,7 @@ def render_forward(world, normals, h, M, V, znear, zfar, cloud_to_packed_first_i
             _lib.ptr(o["ellipse_params"]), _lib.ptr(o["radii"]), _lib.ptr(o["scaler"]), _lib.ptr(o["cutoff_threshold"]),
             _lib.ptr(valid), _lib.ptr(o["idx"]), _lib.ptr(o["zbuf"]), _lib.ptr(o["qvalue"]), _lib.ptr(o["occupancy"]),
             _lib.ptr(vis), _lib.ptr(img), int(img.stride(0)), int(img.stride(1)), _lib.ptr(o["wsum"]), _lib.ptr(ws),
-            ws.numel(), int(workspace_state), _lib.stream_ptr(dev))
+            ws.numel(), state, _lib.stream_ptr(dev))
         if rc:
             _lib.drop_clean_workspace(dev, tag)
     _lib.check(rc, "dss_render_forward")
@@ -630,6 +648,7 @@ class FusedPlan:
             self.layout[name] = (take(nbytes), int(nbytes), dt, shape)
         self.total = off[0]
         self.want_zbuf = want_zbuf
+        self.order_refresh = 0   # k > 0: cached point order, see render_forward (set by the rasterizer that owns the plan)
         self.fwd_ws_bytes = self.lib.dss_render_forward_workspace(N, P, S, K)
         self.bwd_ws_bytes = self.lib.dss_render_backward_workspace(N, P, S)
         self.tag = ("render_forward", N, P, S)
@@ -666,7 +685,8 @@ class FusedPlan:
                 shared, backface, S, K, cutoff, sigma, thr, 0, S, 1, feats.data_ptr(), C,
                 b + o["pts_screen"], b + o["ellipse_params"], b + o["radii"], b + o["scaler"], b + o["cutoff_threshold"],
                 b + o["valid"], b + o["idx"], (b + o["zbuf"]) if self.want_zbuf else None, b + o["qvalue"], b + o["occupancy"],
-                b + o["visible"], b + o["image"], 0, 0, b + o["wsum"], ws.data_ptr(), ws.numel(), 1,
+                b + o["visible"], b + o["image"], 0, 0, b + o["wsum"], ws.data_ptr(), ws.numel(),
+                _order_state(ws, 1, (N, P, S), self.order_refresh) if self.order_refresh else 1,
                 torch.cuda.current_stream(dev).cuda_stream)
             if rc:
                 _lib.drop_clean_workspace(dev, self.tag)

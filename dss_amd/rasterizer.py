@@ -570,6 +570,10 @@ class SurfaceSplatting(torch.nn.Module):
             raise ValueError("render_fused blends at most 8 feature channels, got %d (use the unfused forward() + "
                              "renderer for wider features)" % feats.shape[1])
         lean = self._lean_plan(a, feats, st)
+        # renderer-owned cached point order (large clouds; include/dss_hip.h DSS_WS_ORDER_*): refreshed every k-th call
+        order_refresh = int(kwargs.get("order_refresh", getattr(self, "order_refresh", 0)) or 0)
+        if lean is not None:
+            lean.order_refresh = order_refresh
         if lean is not None and kwargs.get("graphed", False):
             inputs = (a["world"], a["normals"], a["h"], a["M"], a["V"], a["znear"], a["zfar"], a["first_idx"], a["num_points"],
                       feats, a["vr6"], a["frame_n"])
@@ -612,7 +616,7 @@ class SurfaceSplatting(torch.nn.Module):
                                   a["M"], a["V"], a["znear"], a["zfar"], a["first_idx"], a["num_points"],
                                   st.image_size, st.points_per_pixel, st.cutoff_threshold, st.depth_merging_threshold,
                                   st.antialiasing_sigma, bool(st.backface_culling), a["shared"],
-                                  st.radii_backward_scaler, st.clip_pts_grad, a["vr6"], a["frame_n"])
+                                  st.radii_backward_scaler, st.clip_pts_grad, a["vr6"], a["frame_n"], order_refresh)
         image, idx, zbuf, qv, occ, scaler, pts_screen, radii, visible = outs
         fragments = PointFragments(idx=idx, zbuf=zbuf, qvalue=qv, scaler=scaler, occupancy=occ,
                                    geometry=(pts_screen, radii, visible, a["first_idx"], a["num_points"]))
@@ -722,10 +726,10 @@ class _RenderFused(autograd.Function):
     @staticmethod
     def forward(ctx, world, features, normals, h, M, V, znear, zfar, first_idx, num_points, image_size,
                 points_per_pixel, cutoff, merge_thr, sigma, backface, shared, radii_s, clip, vr6=None,
-                frame_normals=None):
+                frame_normals=None, order_refresh=0):
         f = ops.render_forward(world, normals, h, M, V, znear, zfar, first_idx, num_points, features, image_size,
                                points_per_pixel, cutoff, merge_thr, sigma, backface, shared, vr6=vr6,
-                               frame_normals=frame_normals)
+                               frame_normals=frame_normals, order_refresh=int(order_refresh))
         ctx.save_for_backward(world, M, V, first_idx, num_points, f["idx"], f["qvalue"], f["wsum"], f["scaler"],
                               f["pts_screen"], f["radii"], f["visible"], f["valid"])
         ctx.shared, ctx.radii_s = shared, float(radii_s)
@@ -750,4 +754,4 @@ class _RenderFused(autograd.Function):
         # clouds that are not shared between cameras: the projection backward ran in the gather's epilogue (g_pts is
         # already the world-space gradient); a shared cloud sums its cameras in the separate kernel
         g_world = g_pts if fuse else ops.project_backward(world, M, V, first_idx, num_points, g_pts, valid, ctx.shared)
-        return (g_world, g_feat) + (None,) * 19
+        return (g_world, g_feat) + (None,) * 20

@@ -50,7 +50,7 @@ class NormWeightedCompositor(torch.nn.Module):
 
 class SurfaceSplattingRenderer(torch.nn.Module):
     def __init__(self, rasterizer, compositor=None, antialiasing_sigma: float = 1.0, density: float = 1e-4,
-                 frnn_radius=-1, fused=None, graphed: bool = False):
+                 frnn_radius=-1, fused=None, graphed: bool = False, order_refresh: int = 0):
         """``fused`` (not in the reference signature): True runs rasterizer + blend as ONE autograd node on the fused
         kernels (dss_render_forward / dss_render_backward): same images, ~2x fewer launches; the only loss of generality
         is that gradients w.r.t. ``fragments.zbuf`` are not propagated.  False keeps rasterizer and blend as separate
@@ -61,10 +61,15 @@ class SurfaceSplattingRenderer(torch.nn.Module):
         hipGraphs over static buffers (`dss_amd.rasterizer._GraphedRender`): the host cost of an iteration drops to two graph
         launches.  The graphs read the point / normal / colour tensors in place, so keep handing over the SAME tensors
         (parameters updated in place); one render in flight per renderer: the returned image is overwritten by the
-        next call."""
+        next call.
+        ``order_refresh`` = k > 0 (fused path, clouds above 2M points; not in the reference signature): the renderer keeps the
+        screen-cell order its binning sorts the points into and reuses it for the next k - 1 renders of the same shape
+        (`include/dss_hip.h` DSS_WS_ORDER_SAVE / DSS_WS_ORDER_REUSE): a training loop moves its points a little per iteration,
+        so those renders skip the sort.  Images, fragments and gradients are identical bit for bit."""
         super().__init__()
         self.fused = fused
         self.graphed = bool(graphed)
+        self.order_refresh = int(order_refresh)
         self.rasterizer = rasterizer
         self.compositor = compositor
         self.cameras = self.rasterizer.cameras
@@ -93,6 +98,8 @@ class SurfaceSplattingRenderer(torch.nn.Module):
             kw["want_fragments"] = bool(kwargs.get("verbose", False))   # (only then are the fragment tensors materialised)
             if self.graphed:
                 kw["graphed"] = True
+            if self.order_refresh > 0 and "order_refresh" not in kw:
+                kw["order_refresh"] = self.order_refresh
             images, fragments, point_clouds = self.rasterizer.render_fused(point_clouds, **kw)
             if images.shape[-1] != 4:  # RGBA contract of renderer.py:75-78: first three feature channels + occupancy
                 images = torch.cat([images[..., :3], images[..., -1:]], dim=-1)

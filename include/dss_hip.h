@@ -268,6 +268,21 @@ DSS_API int dss_blend_backward_scatter(const float *grad_out, const int32_t *idx
 #define DSS_WS_UNKNOWN 0
 #define DSS_WS_CLEAN 1
 #define DSS_WS_BINNED 2
+/* Renderer-owned cached point order (flags, OR-ed into workspace_state DSS_WS_UNKNOWN / DSS_WS_CLEAN).  Above 2,000,000
+ * points the binning runs in screen-cell order, which the call creates with a counting sort of its own (the reference bins
+ * in input order, rasterize_points.cu:293-432; on a randomly ordered cloud that costs returning atomics and partial-sector
+ * appends).  A training loop moves its points a little per iteration, so the order of one iteration
+ * serves the next ones:
+ *   DSS_WS_ORDER_SAVE   sort as usual, but keep the order in the workspace as a permutation of ALL points (the culled ones
+ *                       behind the others), valid until a call without either flag sorts on the same workspace again;
+ *   DSS_WS_ORDER_REUSE  no sort: setup in natural order, then ONE binning pass that walks the saved order (two launches
+ *                       instead of six).  Needs an earlier DSS_WS_ORDER_SAVE call with the same (N, P, S) on this workspace
+ *                       (DSS_ERR_INVALID_ARGUMENT otherwise -- tracked on the host per workspace pointer; the caller must
+ *                       not hand in a re-allocated buffer that happens to have the same address).
+ * The outputs do not depend on the order in any bit (a pixel's K-set is independent of the order of its tile's candidates);
+ * a stale order only costs locality.  Both flags are ignored where the direct binning runs (P <= 2,000,000). */
+#define DSS_WS_ORDER_SAVE 0x10
+#define DSS_WS_ORDER_REUSE 0x20
 DSS_API size_t dss_render_forward_workspace(int N, int64_t P, int S, int K);
 DSS_API int dss_render_forward(const float *world, const float *normals, const float *h_point,
                                const float *h_cloud, const float *vr6, const float *frame_normals,

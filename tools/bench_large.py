@@ -36,7 +36,7 @@ for _ in range(3):
     wl.step()
 torch.cuda.synchronize()
 t0 = time.perf_counter()
-steps = 10
+steps = 2 * wl.order_refresh if wl.order_refresh > 0 else 10   # (whole periods of the cached point order)
 for _ in range(steps):
     wl.step()
 torch.cuda.synchronize()
@@ -46,7 +46,7 @@ K = bench.K
 alg = wl.N * S * S * (12 * K + 4 + 16 + 4) + wl.P * 52
 out = wl.step()
 img = out[0]
-rec = {"config": which, "point_order": "morton" if os.environ.get("DSS_BENCH_MORTON") == "1" else "random", "points_per_cloud": P, "cameras": N, "image_size": S, "ms_per_step_eager": round(ms, 4),
+rec = {"config": which, "order_refresh": wl.order_refresh, "point_order": "morton" if os.environ.get("DSS_BENCH_MORTON") == "1" else "random", "points_per_cloud": P, "cameras": N, "image_size": S, "ms_per_step_eager": round(ms, 4),
        "Msplats_per_s": round(wl.P / ms / 1e3, 2), "fine_kernel_ms": round(fine_mean, 4),
        "fine_algorithmic_bytes": alg, "fine_GBps": round(alg / fine_mean / 1e6, 1),
        "fine_frac_of_8TBps": round(alg / fine_mean / 1e6 / 8000, 4), "occupancy_mean": round(float(img[..., 3].mean()), 4), "h": h}
