@@ -49,13 +49,14 @@ def quick(fn, n=60):
 
 out = {"G": G, "workload": which, "cameras": wl.N, "points_per_cloud": wl.Pc, "image_size": S}
 N_IT = 60 if which == "cfg2" else 8
-for layout in ("bands", "cyclic"):
+TRACE = os.environ.get("BAND_TRACE") == "1"   # under rocprofv3 --kernel-trace: the cyclic partition, rank 3, eager launches only
+for layout in (("cyclic",) if TRACE else ("bands", "cyclic")):
     parts = [RowPartition(S, G, r, cyclic=(layout == "cyclic")) for r in range(G)]
     vis_all = torch.zeros(wl.P, dtype=torch.bool, device=dev)
     for p in parts:
         vis_all |= fwd(p.rows)["visible"]
     eager, graph = [], []
-    for p in parts:
+    for p in (parts[3:4] if TRACE else parts):
         g_band = p.slice(wl.grad_out).contiguous()
         bucket = torch.empty(wl.P * 6, device=dev)
         gf, gp = bucket[:wl.P * 3].view(wl.P, 3), bucket[wl.P * 3:].view(wl.P, 3)
@@ -66,6 +67,9 @@ for layout in ("bands", "cyclic"):
                                 wl.first, wl.num, bench.RADII_S, -1.0, image_size=S, rows=p.rows, out=(gf, gp))
             return ops.project_backward(wl.world, wl.M, wl.V, wl.first, wl.num, gp, f["valid"], True, clip=bench.CLIP)
         eager.append(quick(step, N_IT))
+        if TRACE:
+            graph.append(eager[-1])
+            continue
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
