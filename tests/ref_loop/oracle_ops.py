@@ -146,8 +146,9 @@ def _backward_zbuf(idx, grad_zbuf, point_z_grad):
 def render_forward(world, normals, h, M, V, znear, zfar, first, num, features, image_size, points_per_pixel,
                    cutoff_threshold, depth_merging_thres, antialiasing_sigma=1.0, backface_culling=False, shared_cloud=False,
                    rows=None, out_image=None, out_visible=None, vr6=None, frame_normals=None, want_zbuf=True,
-                   workspace_state=1):
-    """the fused forward (dss_render_forward) = setup -> rasterizer -> blend, composed from the doubles above"""
+                   workspace_state=1, order_refresh=0):
+    """the fused forward (dss_render_forward) = setup -> rasterizer -> blend, composed from the doubles above
+    (`order_refresh`: the cached point order of the HIP binning has no counterpart here -- the outputs do not depend on it)"""
     assert rows is None and out_image is None and vr6 is None
     o = point_setup(world, normals, h, M, V, znear, zfar, first, num, image_size, cutoff_threshold, antialiasing_sigma,
                     backface_culling, shared_cloud)
