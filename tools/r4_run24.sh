@@ -1,7 +1,7 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
-O=gpurun_out/r4_run26; mkdir -p $O
+O=gpurun_out/r4_run30; mkdir -p $O
 timeout 1500 python -m pytest tests/test_gpu_raster.py -x -q -m gpu -k "backward or median or radius" > $O/pytest.txt 2>&1
 echo "pytest rc $?" >> $O/pytest.txt
 for i in 1 2; do
