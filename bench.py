@@ -393,12 +393,15 @@ class Workload:
         return t_gather, t_full, t_prep, pairs, int(vis.sum().item())
 
 
-def api_path_ms(wl, n=60, graphed=False):
+def api_path_ms(wl, n=200, graphed=False, warm=400):
     """The same workload through the drop-in API a train_mvr.py user calls (DSS/core/renderer.py:36-82):
     `SurfaceSplattingRenderer(SurfaceSplatting(...), NormWeightedCompositor(), fused=True)(cloud)` + `.backward()`,
     eager, autograd and Python object handling included; h precomputed like the headline. -> ms per fwd+bwd
     (`graphed`: the renderer's graphed mode -- forward and backward replayed as two hipGraphs over static buffers; None if
-    this build of the renderer has no such mode)"""
+    this build of the renderer has no such mode).
+    This path is HOST-bound, and on the GPU boxes the host's speed for it varies by 2x between runs and between phases of one
+    run (0.10 ... 0.20 ms per iteration for the same 58 us of GPU work; profiles/r4_c_api_path_variability.txt, tools/
+    api_threads.py) -- so `warm` untimed iterations come first and the median of three blocks of `n` is reported."""
     import inspect
     from dss_amd.cloud import PointClouds3D
     from dss_amd.rasterizer import PointsRasterizationSettings, SurfaceSplatting
@@ -426,14 +429,17 @@ def api_path_ms(wl, n=60, graphed=False):
         C.grad = None
         img = renderer(PointClouds3D([X], [wl.normals], [C]), Vrk_h=h)
         img.backward(wl.grad_out)
-    for _ in range(5):
+    for _ in range(max(5, warm)):
         step()
-    torch.cuda.synchronize()
-    t = time.perf_counter()
-    for _ in range(n):
-        step()
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t) / n * 1e3
+    blocks = []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(n):
+            step()
+        torch.cuda.synchronize()
+        blocks.append((time.perf_counter() - t) / n * 1e3)
+    return sorted(blocks)[1]
 
 
 def cpu_baseline():
@@ -869,7 +875,7 @@ def main():
         if ms_api is not None:
             rec["value_via_api"] = round(splats / (ms_api * 1e-3) / 1e6, 3)
             rec["ms_per_step_via_api"] = round(ms_api, 5)
-            rec["via_api"] = "SurfaceSplattingRenderer(fused=True)(cloud) + .backward(), eager, autograd included, h precomputed"
+            rec["via_api"] = "SurfaceSplattingRenderer(fused=True)(cloud) + .backward(), eager, autograd included, h precomputed; median of 3 x 200 iterations after 400 untimed ones (host-bound path)"
         if ms_api_graphed is not None:
             rec["value_via_api_graphed"] = round(splats / (ms_api_graphed * 1e-3) / 1e6, 3)
             rec["ms_per_step_via_api_graphed"] = round(ms_api_graphed, 5)
