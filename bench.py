@@ -79,6 +79,7 @@ class Workload:
         # renderer-owned cached point order (clouds above 2M points: cfg4 / cfg5): every k-th step sorts and saves the
         # order, the others bin through it (`SurfaceSplattingRenderer(order_refresh=k)`); 0 = every step sorts
         self.order_refresh = int(os.environ.get("BENCH_ORDER_REFRESH", "16")) if n_cams * pts.shape[0] > 2_000_000 else 0
+        self.force_order = None   # "save" / "reuse": this step's kind is fixed (the two graphs of the cached-order mode)
         S = part.S  # image side (module constant S for the benchmark; tools/bench_large.py passes others)
         self.Pc = pts.shape[0]
         self.P = self.N * self.Pc
@@ -132,6 +133,7 @@ class Workload:
             # C calls as ops.render_forward / ops.render_backward below with the host work of a call cut down (one arena for the
             # 13 outputs, prebuilt argument lists): what `SurfaceSplattingRenderer` itself uses
             plan = self._plan
+            plan.force_state = self._order_ws_state()
             arena = plan.forward(self.world, self.normals, self.h, self.M, self.V, self.znear, self.zfar, self.first, self.num,
                                  self.colors)
             g_feat, g_world = plan.backward(arena, self.grad_out, self.first, self.num, RADII_S, CLIP, self.world, self.M)
@@ -141,7 +143,9 @@ class Workload:
         f = ops.render_forward(self.world, self.normals, self.h, self.M, self.V, self.znear, self.zfar, self.first,
                                self.num, self.colors, S, K, CUTOFF, THR, SIGMA, False, True, rows=p.rows,
                                out_image=self.fx.image if multi else None,
-                               out_visible=self.fx.visible if multi else None, order_refresh=self.order_refresh)
+                               out_visible=self.fx.visible if multi else None,
+                               **({"order_refresh": self.order_refresh} if self.force_order is None else
+                                  {"workspace_state": self._order_ws_state()}))
         info = {"pts_screen": f["pts_screen"], "radii": f["radii"], "scaler": f["scaler"], "valid": f["valid"]}
         idx, qv, vis, band, wsum = f["idx"], f["qvalue"], f["visible"], f["image"], f["wsum"]
         if not multi:
@@ -179,6 +183,11 @@ class Workload:
         g_col = g_feat.view(self.N, self.Pc, 3).sum(0) if self.N > 1 else g_feat
         mark("projection_compute")
         return image, g_world, g_col
+
+    def _order_ws_state(self):
+        """workspace_state of the forward when the kind of the step is fixed (None: the renderer's own bookkeeping decides)"""
+        from dss_amd import _lib
+        return None if self.force_order is None else (1 | (_lib.WS_ORDER_SAVE if self.force_order == "save" else _lib.WS_ORDER_REUSE))
 
     # ---- multi-GPU: the compute between the collectives as hipGraphs (VERDICT r2 item 3c) ---------------------------------
     def capture_segments(self):
@@ -591,8 +600,8 @@ def main():
     part = RowPartition(S, world, rank, cyclic=cyclic)
     wl = Workload(dev, cams, part, cloud=cloud, multi=multi)
 
-    def capture(unroll=1):
-        side = torch.cuda.Stream()
+    def capture(unroll=1, side=None):
+        side = side or torch.cuda.Stream()   # (the forward workspace -- and a saved point order in it -- is cached per stream)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(3):
@@ -626,8 +635,29 @@ def main():
     graph, graph_u, ms_modes = None, None, {}
     unrollable = args.steps % UNROLL == 0 and args.steps >= UNROLL
     mode = args.mode or ("eager" if multi else None)
-    if large and wl.order_refresh > 0 and mode is None:
-        mode = "eager"   # (a captured step would freeze ONE of the two kinds of call: the saving or the reusing one)
+    order_graphs = None
+    if large and wl.order_refresh > 0 and mode is None and not multi:
+        # cached point order: a captured step freezes ONE of the two kinds of call, so both are captured -- the step that sorts
+        # and saves the order, and the step that reuses it -- and replayed in the renderer's own rhythm (every k-th step saves)
+        k_ord = wl.order_refresh
+        ms_eager = quick(wl.step, n=k_ord)
+        order_side = torch.cuda.Stream()
+        wl.force_order = "save"
+        g_save = capture(side=order_side)
+        wl.force_order = "reuse"
+        g_reuse = capture(side=order_side)
+        wl.force_order = None
+        tick = [0]
+
+        def run_order_graphs():
+            (g_save if tick[0] % k_ord == 0 else g_reuse).replay()
+            tick[0] += 1
+        ms_graphs = quick(run_order_graphs, n=k_ord)
+        ms_modes = {"eager": ms_eager, "graph_save_reuse": ms_graphs}
+        mode = min(ms_modes, key=ms_modes.get)
+        order_graphs = run_order_graphs if mode == "graph_save_reuse" else None
+    elif large and wl.order_refresh > 0 and mode is None:
+        mode = "eager"
     seg_note = None
     if multi and args.mode != "eager":
         # multi-GPU: the RCCL calls stay outside any graph, the compute segments between them are graphs
@@ -650,6 +680,8 @@ def main():
     steps_per_launch = UNROLL if mode.startswith("graph_x") else 1
     run = graph_u.replay if steps_per_launch > 1 else (graph.replay if mode == "graph" else
                                                          (wl.step_segments if mode == "graph_segments" else wl.step))
+    if order_graphs is not None:
+        run = order_graphs
 
     for _ in range(-(-args.warmup // steps_per_launch)):
         run()

@@ -649,6 +649,7 @@ class FusedPlan:
         self.total = off[0]
         self.want_zbuf = want_zbuf
         self.order_refresh = 0   # k > 0: cached point order, see render_forward (set by the rasterizer that owns the plan)
+        self.force_state = None  # workspace_state passed as is (a caller that captures the saving and the reusing call as graphs)
         self.fwd_ws_bytes = self.lib.dss_render_forward_workspace(N, P, S, K)
         self.bwd_ws_bytes = self.lib.dss_render_backward_workspace(N, P, S)
         self.tag = ("render_forward", N, P, S)
@@ -686,7 +687,8 @@ class FusedPlan:
                 b + o["pts_screen"], b + o["ellipse_params"], b + o["radii"], b + o["scaler"], b + o["cutoff_threshold"],
                 b + o["valid"], b + o["idx"], (b + o["zbuf"]) if self.want_zbuf else None, b + o["qvalue"], b + o["occupancy"],
                 b + o["visible"], b + o["image"], 0, 0, b + o["wsum"], ws.data_ptr(), ws.numel(),
-                _order_state(ws, 1, (N, P, S), self.order_refresh) if self.order_refresh else 1,
+                self.force_state if self.force_state is not None else
+                (_order_state(ws, 1, (N, P, S), self.order_refresh) if self.order_refresh else 1),
                 torch.cuda.current_stream(dev).cuda_stream)
             if rc:
                 _lib.drop_clean_workspace(dev, self.tag)
