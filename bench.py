@@ -402,7 +402,7 @@ class Workload:
         return t_gather, t_full, t_prep, pairs, int(vis.sum().item())
 
 
-def api_path_ms(wl, n=200, graphed=False, warm=400):
+def api_path_ms(wl, n=200, graphed=False, warm=400, engine_thread=None):
     """The same workload through the drop-in API a train_mvr.py user calls (DSS/core/renderer.py:36-82):
     `SurfaceSplattingRenderer(SurfaceSplatting(...), NormWeightedCompositor(), fused=True)(cloud)` + `.backward()`,
     eager, autograd and Python object handling included; h precomputed like the headline. -> ms per fwd+bwd
@@ -423,6 +423,11 @@ def api_path_ms(wl, n=200, graphed=False, warm=400):
                                      image_size=wl.S, points_per_pixel=K, bin_size=None, clip_pts_grad=CLIP,
                                      antialiasing_sigma=SIGMA)
     kw = {}
+    if engine_thread is not None:
+        # (True: backward on the autograd engine's device thread instead of the calling thread: SurfaceSplattingRenderer docstring)
+        if "engine_thread" not in inspect.signature(SurfaceSplattingRenderer.__init__).parameters:
+            return None
+        kw["engine_thread"] = engine_thread
     if graphed:
         if "graphed" not in inspect.signature(SurfaceSplattingRenderer.__init__).parameters:
             return None
@@ -438,6 +443,7 @@ def api_path_ms(wl, n=200, graphed=False, warm=400):
         C.grad = None
         img = renderer(PointClouds3D([X], [wl.normals], [C]), Vrk_h=h)
         img.backward(wl.grad_out)
+    was = torch.autograd.is_multithreading_enabled()
     for _ in range(max(5, warm)):
         step()
     blocks = []
@@ -448,6 +454,7 @@ def api_path_ms(wl, n=200, graphed=False, warm=400):
             step()
         torch.cuda.synchronize()
         blocks.append((time.perf_counter() - t) / n * 1e3)
+    torch.autograd.set_multithreading_enabled(was)
     return sorted(blocks)[1]
 
 
@@ -765,6 +772,7 @@ def main():
         value_knn = splats / (ms_knn * 1e-3) / 1e6
     ms_api = api_path_ms(wl) if (not multi and not large) else None
     ms_api_graphed = api_path_ms(wl, graphed=True) if (not multi and not large) else None
+    ms_api_et = api_path_ms(wl, engine_thread=True) if (not multi and not large) else None
 
     dist_block = {"world_size": 1, "backend": None}
     if multi:
@@ -907,10 +915,15 @@ def main():
         if ms_api is not None:
             rec["value_via_api"] = round(splats / (ms_api * 1e-3) / 1e6, 3)
             rec["ms_per_step_via_api"] = round(ms_api, 5)
-            rec["via_api"] = "SurfaceSplattingRenderer(fused=True)(cloud) + .backward(), eager, autograd included, h precomputed; median of 3 x 200 iterations after 400 untimed ones (host-bound path)"
+            rec["via_api"] = "SurfaceSplattingRenderer(fused=True)(cloud) + .backward(), eager, autograd included (backward on the calling thread: the renderer's default, see value_via_api_engine_thread), h precomputed; median of 3 x 200 iterations after 400 untimed ones (host-bound path)"
         if ms_api_graphed is not None:
             rec["value_via_api_graphed"] = round(splats / (ms_api_graphed * 1e-3) / 1e6, 3)
             rec["ms_per_step_via_api_graphed"] = round(ms_api_graphed, 5)
+        if ms_api_et is not None:
+            # the same eager API path with SurfaceSplattingRenderer(engine_thread=True) / DSS_AMD_ENGINE_THREAD=1: backward
+            # handed to the autograd engine's per-device thread (PyTorch's default; the renderer's default is the calling thread)
+            rec["value_via_api_engine_thread"] = round(splats / (ms_api_et * 1e-3) / 1e6, 3)
+            rec["ms_per_step_via_api_engine_thread"] = round(ms_api_et, 5)
         for k, v in ms_modes.items():
             rec["config"]["calibration_ms_per_step_" + k] = round(v, 5)
         if not args.no_cpu_baseline and not large and not force_dist:

@@ -5,6 +5,8 @@ frnn_radius=-1).forward(point_clouds, **kwargs)`` returns the (N,H,W,4) RGBA ima
 occupancy), or ``None`` for an empty cloud (:41-42), or ``(images, fragments)`` with ``verbose``.
 Weights, NormWeightedCompositor and the RGBA concat (:53-78) run as ONE fused HIP kernel each way.
 """
+import os
+
 import torch
 import torch.autograd as autograd
 
@@ -50,7 +52,7 @@ class NormWeightedCompositor(torch.nn.Module):
 
 class SurfaceSplattingRenderer(torch.nn.Module):
     def __init__(self, rasterizer, compositor=None, antialiasing_sigma: float = 1.0, density: float = 1e-4,
-                 frnn_radius=-1, fused=None, graphed: bool = False, order_refresh: int = 0):
+                 frnn_radius=-1, fused=None, graphed: bool = False, order_refresh: int = 0, engine_thread=None):
         """``fused`` (not in the reference signature): True runs rasterizer + blend as ONE autograd node on the fused
         kernels (dss_render_forward / dss_render_backward): same images, ~2x fewer launches; the only loss of generality
         is that gradients w.r.t. ``fragments.zbuf`` are not propagated.  False keeps rasterizer and blend as separate
@@ -65,8 +67,23 @@ class SurfaceSplattingRenderer(torch.nn.Module):
         ``order_refresh`` = k > 0 (fused path, clouds above 2M points; not in the reference signature): the renderer keeps the
         screen-cell order its binning sorts the points into and reuses it for the next k - 1 renders of the same shape
         (`include/dss_hip.h` DSS_WS_ORDER_SAVE / DSS_WS_ORDER_REUSE): a training loop moves its points a little per iteration,
-        so those renders skip the sort.  Images, fragments and gradients are identical bit for bit."""
+        so those renders skip the sort.  Images, fragments and gradients are identical bit for bit.
+        ``engine_thread`` (not in the reference signature): whether ``loss.backward()`` hands its nodes to the autograd
+        engine's per-device thread (PyTorch's default) or runs them on the CALLING thread
+        (``torch.autograd.set_multithreading_enabled(False)``, thread-local, applied here for the constructing thread).  At
+        DSS sizes an iteration is ~60 us of GPU work behind ~100 us of Python, and that hand-over -- a futex wake-up, a GIL
+        transfer and a cold core per backward -- doubles the host time of an iteration on the GPU boxes unless the OS happens
+        to place the two threads next to each other: 0.25 vs 0.125 ms per forward + backward, alternating blocks in one
+        process (profiles/r4_c_api_path_variability.txt).  One process per GPU -- the execution model of this package,
+        SURVEY 8e -- has no backward work on other devices to overlap, so the default (None) is the calling thread;
+        ``engine_thread=True`` or the environment variable ``DSS_AMD_ENGINE_THREAD=1`` keeps PyTorch's engine thread (a
+        process that differentiates through several devices at once wants that)."""
         super().__init__()
+        if engine_thread is None:
+            engine_thread = os.environ.get("DSS_AMD_ENGINE_THREAD", "0") == "1"
+        self.engine_thread = bool(engine_thread)
+        if not self.engine_thread and torch.autograd.is_multithreading_enabled():
+            torch.autograd.set_multithreading_enabled(False)
         self.fused = fused
         self.graphed = bool(graphed)
         self.order_refresh = int(order_refresh)

@@ -277,3 +277,30 @@ def test_point_fragments_is_a_tuple_like_the_reference_named_tuple():
     g = PointFragments(idx, z, q, d, occ)           # reference-style per-fragment scaler
     assert g.scaler is d and g.scaler_packed is None
     assert isinstance(pickle.loads(pickle.dumps(f)), PointFragments)
+
+
+def test_renderer_runs_the_backward_on_the_calling_thread_unless_told_otherwise():
+    """`SurfaceSplattingRenderer` switches the autograd engine's per-device thread off for the constructing thread (it doubles
+    the host time of an iteration at DSS sizes); `engine_thread=True` / DSS_AMD_ENGINE_THREAD=1 keep PyTorch's default"""
+    import os
+    import torch
+    from dss_amd.rasterizer import SurfaceSplatting
+    from dss_amd.renderer import NormWeightedCompositor, SurfaceSplattingRenderer
+    was = torch.autograd.is_multithreading_enabled()
+    try:
+        torch.autograd.set_multithreading_enabled(True)
+        r = SurfaceSplattingRenderer(SurfaceSplatting(), NormWeightedCompositor(), engine_thread=True)
+        assert r.engine_thread is True and torch.autograd.is_multithreading_enabled()
+        os.environ["DSS_AMD_ENGINE_THREAD"] = "1"
+        SurfaceSplattingRenderer(SurfaceSplatting(), NormWeightedCompositor())
+        assert torch.autograd.is_multithreading_enabled()
+        os.environ.pop("DSS_AMD_ENGINE_THREAD")
+        r = SurfaceSplattingRenderer(SurfaceSplatting(), NormWeightedCompositor())
+        assert r.engine_thread is False and not torch.autograd.is_multithreading_enabled()
+        # gradients still flow, on the calling thread
+        x = torch.ones(3, requires_grad=True)
+        (x * 2).sum().backward()
+        assert torch.equal(x.grad, torch.full((3,), 2.0))
+    finally:
+        os.environ.pop("DSS_AMD_ENGINE_THREAD", None)
+        torch.autograd.set_multithreading_enabled(was)

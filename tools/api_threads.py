@@ -28,12 +28,14 @@ def step():
 for _ in range(3): step()
 torch.cuda.synchronize()
 rows = []
-for blk in range(12):
+for blk in range(16):
+    mt = (blk // 2) % 2 == 0   # two blocks with the autograd engine's device thread, two with the backward on the calling thread, ...
+    torch.autograd.set_multithreading_enabled(mt)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(100)]
     torch.cuda.synchronize(); t = time.perf_counter()
     for a, b in ev:
         a.record(); step(); b.record()
     torch.cuda.synchronize(); host = (time.perf_counter() - t) / 100 * 1e3
     gpu = sorted(a.elapsed_time(b) for a, b in ev)[50]
-    rows.append({"block": blk, "host_ms_per_iteration": round(host, 4), "gpu_ms_first_to_last_kernel_median": round(gpu, 4)})
+    rows.append({"block": blk, "engine_thread": mt, "host_ms_per_iteration": round(host, 4), "gpu_ms_first_to_last_kernel_median": round(gpu, 4)})
 print(json.dumps(rows))
