@@ -82,8 +82,8 @@ class SurfaceSplattingRenderer(torch.nn.Module):
         if engine_thread is None:
             engine_thread = os.environ.get("DSS_AMD_ENGINE_THREAD", "0") == "1"
         self.engine_thread = bool(engine_thread)
-        if not self.engine_thread and torch.autograd.is_multithreading_enabled():
-            torch.autograd.set_multithreading_enabled(False)
+        if torch.autograd.is_multithreading_enabled() != self.engine_thread:
+            torch.autograd.set_multithreading_enabled(self.engine_thread)
         self.fused = fused
         self.graphed = bool(graphed)
         self.order_refresh = int(order_refresh)
