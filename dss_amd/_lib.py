@@ -110,7 +110,7 @@ def load():
 
 
 WS_ORDER_SAVE, WS_ORDER_REUSE = 0x10, 0x20   # include/dss_hip.h DSS_WS_ORDER_* (flags of workspace_state)
-OPT_LEAN_WORKSPACE, OPT_BACKWARD_TPW, OPT_BACKWARD_ADDR64, OPT_BACKWARD_FUSED = 0, 1, 2, 3   # include/dss_hip.h DSS_OPT_*
+OPT_LEAN_WORKSPACE, OPT_BACKWARD_TPW, OPT_BACKWARD_ADDR64, OPT_BACKWARD_FUSED, OPT_KNN_QUERY = 0, 1, 2, 3, 4   # include/dss_hip.h DSS_OPT_*
 
 
 def set_option(option: int, value: int) -> int:

@@ -825,6 +825,7 @@ extern "C" size_t dss_knn_workspace(int N, int64_t P)
 }
 
 #define KNN_FULL_MAX_K 40
+#define KNN_COOP_KTH_MAX_P 120000   // K-th distance: crossover of the two query kernels between 65k (cooperative +24 %) and 131k points (tie), profiles/r4_d_knn_sweep.json
 
 // Per-cloud bounding boxes as ordered ints (decode with ord2f), for callers outside this file (regularizers.hip).
 int dss::launch_cloud_bbox(const float *points, const int64_t *first_idx, const int64_t *num_pts, int N, int64_t P,
@@ -905,17 +906,20 @@ static int knn_run(const char *who, const float *points, const int64_t *first_id
 #define KNN_LAUNCH_COOP(KK, FF)                                                                                     \
     hipLaunchKernelGGL((knn_query_coop_kernel<KK, FF>), dim3(cb), dim3(256), 0, st, points, first_idx, num_pts, N, P, grids, \
                        stride, offsets, sorted, K, kth_sqdist, dists, idx)
+    const int qopt = option(DSS_OPT_KNN_QUERY);   // 0: by size, 1: cooperative, 2: one thread per query
     if (full) {
         // full lists: the cooperative kernel wins while the launch is latency-bound (32k points, K = 12: 58 us against
         // ~100); at 100k points the merges of (distance, id) lists cost more than the shorter chains save (182 vs 155 us)
-        const bool coop = P <= 65536;
+        const bool coop = qopt == 1 || (qopt == 0 && P <= 65536);
         if (K <= 8) { if (coop) KNN_LAUNCH_COOP(8, true); else KNN_LAUNCH(8, true); }
         else if (K <= 12) { if (coop) KNN_LAUNCH_COOP(12, true); else KNN_LAUNCH(12, true); }  // the regularisers' knn_k (trainer.py:134-137)
         else if (K <= 16) { if (coop) KNN_LAUNCH_COOP(16, true); else KNN_LAUNCH(16, true); }
         else KNN_LAUNCH(KNN_FULL_MAX_K, true);
     } else {
-        if (K <= 8) KNN_LAUNCH_COOP(8, false);
-        else KNN_LAUNCH_COOP(KNN_MAX_K, false);
+        // K-th distance only: cooperative up to KNN_COOP_KTH_MAX_P points (tools/knn_sweep.py, profiles/r4_d_knn_sweep.json)
+        const bool coop = qopt == 1 || (qopt == 0 && P <= KNN_COOP_KTH_MAX_P);
+        if (K <= 8) { if (coop) KNN_LAUNCH_COOP(8, false); else KNN_LAUNCH(8, false); }
+        else { if (coop) KNN_LAUNCH_COOP(KNN_MAX_K, false); else KNN_LAUNCH(KNN_MAX_K, false); }
     }
 #undef KNN_LAUNCH_COOP
 #undef KNN_LAUNCH

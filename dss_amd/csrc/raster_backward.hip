@@ -2435,8 +2435,32 @@ static int render_backward_impl(bool run_prep, const float *grad_out, const int3
 #undef DSS_LAUNCH_RB_F
         return check_launch("dss_render_backward");
     }
+    // The grid is persistent and was sized for the variant the device cache measured (<C, true, 4, true>: 79 VGPRs, six
+    // workgroups per CU); some variants hold more registers (two tasks per wavefront without the fused preparation: 83, the
+    // 64-bit addressing: 100) -- a workgroup that is not resident at launch would start its share when the others end theirs,
+    // so every launch is clamped to what ITS instantiation keeps resident (occupancy queried once per instantiation).
+    auto resident_grid = [&](const void *fn) -> unsigned {
+        static std::atomic<const void *> keys[64];
+        static std::atomic<int> vals[64];
+        int per_cu = 0;
+        for (int i = 0; i < 64; ++i) {
+            const void *k = keys[i].load(std::memory_order_acquire);
+            if (k == fn) { per_cu = vals[i].load(std::memory_order_relaxed); break; }
+            if (k == nullptr) {
+                (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, 0);
+                (void)hipGetLastError();
+                if (per_cu < 1) per_cu = 1;
+                const void *expect = nullptr;
+                if (keys[i].compare_exchange_strong(expect, fn, std::memory_order_acq_rel)) vals[i].store(per_cu, std::memory_order_relaxed);
+                break;   // (lost the race for the slot: this call uses its own query, a later one finds the entry or the next slot)
+            }
+        }
+        if (per_cu < 1) return pgrid;
+        const unsigned g = (unsigned)n_cus * (unsigned)per_cu;
+        return g < pgrid ? g : pgrid;
+    };
 #define DSS_LAUNCH_RB_A(CC, SS, TT, AA)                                                                                 \
-    hipLaunchKernelGGL((render_backward_kernel<CC, SS, TT, AA>), dim3(pgrid), dim3(256), 0, st, grad_out, alpha, idx, qvalue, wsum, \
+    hipLaunchKernelGGL((render_backward_kernel<CC, SS, TT, AA>), dim3(resident_grid((const void *)render_backward_kernel<CC, SS, TT, AA>)), dim3(256), 0, st, grad_out, alpha, idx, qvalue, wsum, \
                        scaler, points, radii, rs, first_idx, num_pts, vis_count, vis_list, n_seg, seg_pts, N, S, K, C, clip, \
                        row0, rows, large_waves, grad_feat, grad_pts, 3, world, Mproj)
 #define DSS_LAUNCH_RB(CC, SS, TT) DSS_LAUNCH_RB_A(CC, SS, TT, true)
@@ -2452,7 +2476,7 @@ static int render_backward_impl(bool run_prep, const float *grad_out, const int3
             return DSS_ERR_UNSUPPORTED;
         }
 #define DSS_LAUNCH_RB_C(SS, TT)                                                                                          \
-    hipLaunchKernelGGL((render_backward_kernel<3, SS, TT, true, true>), dim3(pgrid), dim3(256), 0, st, grad_out, alpha, idx, qvalue, \
+    hipLaunchKernelGGL((render_backward_kernel<3, SS, TT, true, true>), dim3(resident_grid((const void *)render_backward_kernel<3, SS, TT, true, true>)), dim3(256), 0, st, grad_out, alpha, idx, qvalue, \
                        wsum, scaler, points, radii, rs, first_idx, num_pts, vis_count, vis_list, n_seg, seg_pts, N, S, K, C, clip, \
                        row0, rows, large_waves, grad_feat, grad_pts, tshift)
         if (small) { if (tpw == 4) DSS_LAUNCH_RB_C(true, 4); else if (tpw == 2) DSS_LAUNCH_RB_C(true, 2); else DSS_LAUNCH_RB_C(true, 1); }

@@ -68,6 +68,9 @@ DSS_API const char *dss_last_error(void);
  *   DSS_OPT_BACKWARD_TPW   visible points per wavefront of the backward gather: 1, 2 or 4; 0 (default) = chosen from P.
  *   DSS_OPT_BACKWARD_ADDR64 1: force the 64-bit addressing variant of the backward gather (normally only taken when a
  *                             gathered tensor exceeds 4 GB); exists so that a test can reach that variant.
+ *   DSS_OPT_KNN_QUERY       query kernel of dss_knn_kth_sqdist / dss_knn_points: 0 (default) = chosen from P and K (the
+ *                           cooperative kernel -- 16 lanes per query -- while the launch is latency-bound, one thread per
+ *                           query above), 1 = cooperative, 2 = one thread per query (K <= 16 for 1; A/B measurements).
  *   DSS_OPT_BACKWARD_FUSED  launch form of dss_render_backward for short lists (P <= 262,144, whole image): 0 (default) =
  *                             automatic; 1 = the round-3 sequence (compaction | median | gather kernels); 4 = two launches
  *                             (segments + alpha plane | medians + gather: the gather's workgroups do the blend half of their
@@ -79,7 +82,8 @@ DSS_API const char *dss_last_error(void);
 #define DSS_OPT_BACKWARD_TPW 1
 #define DSS_OPT_BACKWARD_ADDR64 2
 #define DSS_OPT_BACKWARD_FUSED 3
-#define DSS_OPT_COUNT 4
+#define DSS_OPT_KNN_QUERY 4
+#define DSS_OPT_COUNT 5
 DSS_API int dss_band_rows(int row0, int row1, int row_cycle); /* rows of a band tensor (see `row_cycle` above) */
 DSS_API int dss_set_option(int option, int value);
 DSS_API int dss_get_option(int option);
