@@ -261,6 +261,32 @@ class Workload:
         mark("projection_compute")
         return image, self._seg["g_world"], self._seg["g_col"]
 
+    # ---- multi-GPU: the WHOLE step as one hipGraph -- launches AND the three RCCL collectives -------------------------------
+    def capture_whole_step(self):
+        """One graph for the step of `step` (multi branch): RCCL collectives are stream operations like any other and can be
+        captured with the kernels around them (measured at world size 1, tools/whole_step_graph.py: 80 us per step against
+        120 with the three graph segments and 152 eagerly -- the host then issues ONE graph launch instead of three launches +
+        three collective calls).  -> the outputs of the captured step (static tensors the replays overwrite)."""
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                self.step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        res = {}
+        with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
+            res["out"] = self.step()
+        torch.cuda.synchronize()
+        self._whole = (g, res["out"])
+        return res["out"]
+
+    def step_whole(self, ev=None):
+        """`step` for N > 1 as ONE graph replay (see capture_whole_step)"""
+        self._whole[0].replay()
+        return self._whole[1]
+
     def dist_timing(self, iters=20):
         """Where a multi-GPU step spends its time, per rank: event-timed segments of `iters` eager steps (microseconds,
         means).  compute = forward + backward + projection kernels of this rank's band; wait_* = time the stream spends in
@@ -666,8 +692,10 @@ def main():
     elif large and wl.order_refresh > 0 and mode is None:
         mode = "eager"
     seg_note = None
+    whole_note = None
     if multi and args.mode != "eager":
-        # multi-GPU: the RCCL calls stay outside any graph, the compute segments between them are graphs
+        # multi-GPU: (i) the compute segments between the RCCL calls as graphs; (ii) if RCCL lets itself be captured, the whole
+        # step -- launches and collectives -- as ONE graph, checked against the eager step on every rank before it is used
         try:
             barrier()   # (no collective in flight while capturing)
             wl.capture_segments()
@@ -675,6 +703,32 @@ def main():
         except Exception as e:  # noqa: BLE001  (capture refused: plain launches, and say so)
             seg_note = "segment capture failed: %s: %s" % (type(e).__name__, str(e)[:160])
             mode = "eager"
+        whole_wanted = os.environ.get("BENCH_NO_WHOLE_GRAPH") != "1" and dist.get_backend() == "nccl"
+        if not whole_wanted:
+            # (a host-side backend -- gloo in the CPU-collective tests -- cannot be captured, and a refused capture leaves the
+            # thread's capture state unusable: not attempted)
+            whole_note = "not attempted (backend %s%s)" % (dist.get_backend(), ", BENCH_NO_WHOLE_GRAPH" if os.environ.get("BENCH_NO_WHOLE_GRAPH") == "1" else "")
+        if whole_wanted:
+            ok = 1.0
+            try:
+                barrier()
+                ref = [t.clone() for t in wl.step()]
+                barrier()
+                got = wl.capture_whole_step()
+                got = wl.step_whole()
+                torch.cuda.synchronize()
+                same = torch.equal(got[0], ref[0]) and all(
+                    float((a - b).abs().max()) <= 1e-6 * max(float(b.abs().max()), 1e-30) for a, b in zip(got[1:], ref[1:]))
+                if not same:
+                    ok, whole_note = 0.0, "whole-step graph gave other results than the eager step: not used"
+            except Exception as e:  # noqa: BLE001  (capture of the collectives refused: the segments stay)
+                ok, whole_note = 0.0, "whole-step capture failed: %s: %s" % (type(e).__name__, str(e)[:160])
+            flag = torch.tensor([ok], device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)   # (every rank takes the same path)
+            if float(flag.item()) == 1.0:
+                mode = "graph_step"
+            elif whole_note is None:
+                whole_note = "another rank could not capture the whole step"
     if mode is None:
         graph = capture()
         ms_modes = {"eager": quick(wl.step, n=8 if large else 40), "graph": quick(graph.replay, n=8 if large else 40)}
@@ -686,7 +740,8 @@ def main():
         graph = capture()
     steps_per_launch = UNROLL if mode.startswith("graph_x") else 1
     run = graph_u.replay if steps_per_launch > 1 else (graph.replay if mode == "graph" else
-                                                         (wl.step_segments if mode == "graph_segments" else wl.step))
+                                                         (wl.step_segments if mode == "graph_segments" else
+                                                          (wl.step_whole if mode == "graph_step" else wl.step)))
     if order_graphs is not None:
         run = order_graphs
 
@@ -793,6 +848,7 @@ def main():
                       "rccl_version": nccl_v,
                       "visible_devices": torch.cuda.device_count(), "partition": part.describe(),
                       "overlap": bool(wl.fx.overlap), "image_issue": "behind the backward (side stream)" if wl.fx.late_image else "before the backward, after the visibility union", "degraded": wl.fx.degraded, "segment_capture": seg_note or "ok",
+                      "whole_step_graph": whole_note or "ok",
                       "timing_us": {k: {"min": round(float(allt[:, i].min()), 1), "max": round(float(allt[:, i].max()), 1),
                                         "mean": round(float(allt[:, i].mean()), 1)} for i, k in enumerate(keys)},
                       "timing_how": "HIP events on the compute stream around each segment of 20 eager steps, per rank; "
