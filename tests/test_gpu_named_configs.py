@@ -101,6 +101,16 @@ def test_named_config_forward_backward_vs_oracle(name):
     assert rel_f <= 1e-3 and rel_p <= 1e-3, (rel_f, rel_p)
     gp = g_pts.cpu().numpy()
     assert np.isfinite(gp).all() and np.all(gp[~o_vis] == 0)
+    if P > 2_000_000:
+        # renderer-owned cached point order (DSS_WS_ORDER_SAVE / _REUSE, above 2M points: configs 4 and 5): the call that
+        # saves the order and two calls that reuse it give the fragments the oracle was just compared with, bit for bit
+        for _ in range(3):
+            fo = ops.render_forward(t(pts), t(nrm), torch.full((N,), h, device=DEV), t(M), t(V),
+                                    torch.full((N,), 0.1, device=DEV), torch.full((N,), 100.0, device=DEV), first, num,
+                                    t(np.tile(col, (N, 1))), S, K, CUTOFF, THR, SIGMA, False, True, order_refresh=3)
+            for key in ("idx", "zbuf", "qvalue", "occupancy", "visible", "image", "wsum"):
+                assert torch.equal(fo[key], f[key]), ("cached point order", key)
+        del fo
     # the unfused entry points agree with the fused ones bit for bit on the fragments
     idx2 = ops.splat_points(f["pts_screen"], f["ellipse_params"], f["cutoff_threshold"], f["radii"], first, num, THR, S, K)[0]
     assert torch.equal(idx2, f["idx"])
