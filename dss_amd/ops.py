@@ -435,7 +435,13 @@ def _order_state(ws, state: int, shape, order_refresh: int) -> int:
     """workspace_state of a dss_render_forward call on buffer `ws` under the cached point order (``order_refresh`` = k: the
     order saved by one call serves the next k - 1 calls on the same buffer).  The age lives on the buffer OBJECT: a new
     buffer -- or one whose last call failed and was dropped -- starts with a save."""
-    if order_refresh <= 0 or state not in (0, 1):
+    if state not in (0, 1):
+        return state
+    if order_refresh <= 0:
+        # a call without either flag sorts for itself and the library forgets the order this buffer held: the next call
+        # with order_refresh > 0 must save again (e.g. two renderers of the same shape, one of them without the option)
+        if getattr(ws, "_dss_order_age", None) is not None:
+            ws._dss_order_age = None
         return state
     age = getattr(ws, "_dss_order_age", None)
     if age is None or age[0] != shape or age[1] + 1 >= int(order_refresh):
@@ -687,8 +693,7 @@ class FusedPlan:
                 b + o["pts_screen"], b + o["ellipse_params"], b + o["radii"], b + o["scaler"], b + o["cutoff_threshold"],
                 b + o["valid"], b + o["idx"], (b + o["zbuf"]) if self.want_zbuf else None, b + o["qvalue"], b + o["occupancy"],
                 b + o["visible"], b + o["image"], 0, 0, b + o["wsum"], ws.data_ptr(), ws.numel(),
-                self.force_state if self.force_state is not None else
-                (_order_state(ws, 1, (N, P, S), self.order_refresh) if self.order_refresh else 1),
+                self.force_state if self.force_state is not None else _order_state(ws, 1, (N, P, S), self.order_refresh),
                 torch.cuda.current_stream(dev).cuda_stream)
             if rc:
                 _lib.drop_clean_workspace(dev, self.tag)

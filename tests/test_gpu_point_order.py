@@ -52,6 +52,11 @@ def test_cached_point_order_is_invisible_in_the_outputs():
     # call 5 refreshes (saves the order of the moved cloud), call 6 reuses it for camera A
     _same(_render(moved, order_refresh=4), ref_m)
     _same(_render(a, order_refresh=4), ref_a)
+    # a call WITHOUT the option on the same workspace in between (another renderer of the same shape): it sorts for itself, the
+    # library forgets the saved order, and the next call with the option saves again instead of failing
+    _same(_render(b), ref_b)
+    _same(_render(a, order_refresh=4), ref_a)
+    _same(_render(b, order_refresh=4), ref_b)
     # and the gradients through the fragments of a reused order
     f = _render(b, order_refresh=4)
     g = torch.randn(1, S, S, 4, device=DEV, generator=torch.Generator(DEV).manual_seed(3))
