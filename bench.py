@@ -13,6 +13,17 @@ the 8-row tile rows g, g + N, ...); bands are reassembled with an RCCL all-gathe
 partials are all-reduced.
 
 Metric: Msplats/s = (cameras * points per cloud) / step time, whole job.
+
+How the timed step is launched (recorded in `config.launch`): one GPU -- hipGraph replays of the identical launch sequence
+(`graph_x10`: ten steps per graph launch) unless --mode says otherwise; --workload cfg4|cfg5 -- two graphs, the step that
+sorts and saves the point order and the step that reuses it, replayed in the renderer's rhythm (`graph_save_reuse`); N > 1
+(or BENCH_FORCE_DIST=1) over RCCL -- the WHOLE step, launches and the three collectives, as one graph (`graph_step`) after it
+has been checked against the eager step on every rank, else graphs of the compute segments between host-issued collectives.
+Environment switches (development A/B; none is needed for the contract): BENCH_FORCE_DIST=1 (multi-GPU path at world size
+1), BENCH_DIST_BACKEND=gloo (CPU collectives, tests), BENCH_NO_WHOLE_GRAPH=1 (segments instead of the whole-step graph),
+BENCH_IMAGE_LATE=1 (image collective issued behind the backward), BENCH_ORDER_REFRESH=k (period of the cached point order of
+the large workloads, 0 = sort in every step; default 16), BENCH_BACKWARD_FUSED / BENCH_BACKWARD_TPW (DSS_OPT_* of the
+library), DSS_AMD_ENGINE_THREAD=1 (PyTorch's autograd engine thread for the API figures).
 """
 import argparse
 import json
