@@ -44,5 +44,20 @@ try:
     out["whole_graph_us"] = round(quick(g.replay), 1)
 except Exception as e:  # noqa: BLE001
     out["whole_graph_error"] = "%s: %s" % (type(e).__name__, str(e)[:300])
+# The layout N > 1 uses by default (tile-row-cyclic bands) reassembles the gathered rows with an index_select on a side stream
+# that waits for the asynchronous collective: at world size 1 the bands are uniform and that code does not run -- force it with
+# the identity permutation, so that the capture sees the stream fork / join it will see on eight GPUs.
+try:
+    wl2 = bench.Workload(dev, 1, bench.RowPartition(bench.S, 1, 0), multi=True)
+    fx = wl2.fx
+    fx.row_index = torch.arange(bench.S, device=dev, dtype=torch.int64)
+    fx.full_img = torch.empty((bench.S, 1, bench.S, 4), dtype=torch.float32, device=dev)
+    img2 = wl2.step()[0]; torch.cuda.synchronize()
+    out["row_index_path_eager_image_equal"] = bool(torch.equal(img2, ref[0]))
+    o2 = wl2.capture_whole_step(); wl2.step_whole(); torch.cuda.synchronize()
+    out["row_index_path_whole_graph_image_equal"] = bool(torch.equal(o2[0], ref[0]))
+    out["row_index_path_whole_graph_us"] = round(quick(wl2.step_whole), 1)
+except Exception as e:  # noqa: BLE001
+    out["row_index_path_error"] = "%s: %s" % (type(e).__name__, str(e)[:300])
 print(json.dumps(out), flush=True)
 dist.destroy_process_group()
