@@ -831,6 +831,35 @@ def test_tile_row_cyclic_bands_reproduce_the_full_render_and_its_gradients(S, G,
         assert _rel_l2(sum_f.cpu().numpy(), gf_full.cpu().numpy()) <= 1e-5, tpw
 
 
+def test_tile_row_cyclic_backward_refuses_what_it_was_not_built_for():
+    """The tile-row-cyclic gather is built for the training configuration (RGB features, 32-bit offsets): another channel
+    count or forced 64-bit addressing is DSS_ERR_UNSUPPORTED with a message, not a wrong gradient."""
+    sc = scenes.random_splats(2000, 64, 1, seed=3)
+    d = _dev(sc)
+    S, K, G = 64, 5, 2
+    idx, zbuf, qv, occ, vis = _fwd(d, S, K, 0.3, return_visible=True)
+    scaler = torch.from_numpy(sc["scaler"]).to(DEV)
+    own = torch.tensor([r for r in range(S) if (r // 8) % G == 0], device=DEV)
+    band = lambda t: t[:, own].contiguous()
+    for C, addr64 in ((1, 0), (5, 0), (3, 1)):
+        feat = torch.rand((sc["points"].shape[0], C), device=DEV)
+        img, wsum = ops.blend_forward(idx, qv, occ, scaler, feat, return_wsum=True)
+        go = torch.randn_like(img)
+        _lib.set_option(_lib.OPT_BACKWARD_ADDR64, addr64)
+        try:
+            with pytest.raises(RuntimeError, match="tile-row-cyclic band needs C == 3"):
+                ops.render_backward(band(go), band(idx), band(qv), band(wsum), scaler, d["points"], d["radii"], vis,
+                                    d["first"], d["num"], 4.0, -1.0, image_size=S, rows=(0, S, G))
+        finally:
+            _lib.set_option(_lib.OPT_BACKWARD_ADDR64, 0)
+    # ... and the supported shape of the same call goes through
+    feat = torch.rand((sc["points"].shape[0], 3), device=DEV)
+    img, wsum = ops.blend_forward(idx, qv, occ, scaler, feat, return_wsum=True)
+    gf, gp = ops.render_backward(band(torch.randn_like(img)), band(idx), band(qv), band(wsum), scaler, d["points"],
+                                 d["radii"], vis, d["first"], d["num"], 4.0, -1.0, image_size=S, rows=(0, S, G))
+    assert torch.isfinite(gp).all() and torch.isfinite(gf).all()
+
+
 @pytest.mark.parametrize("P,S,N", [(4000, 128, 1), (3000, 96, 3), (300000, 256, 2)])
 def test_render_backward_with_fused_projection_equals_project_backward(P, S, N):
     """`project=(world, M)`: the backward of the projection (dss_project_backward) evaluated in the gather's epilogue --
