@@ -273,7 +273,7 @@ class Workload:
         return image, self._seg["g_world"], self._seg["g_col"]
 
     # ---- multi-GPU: the WHOLE step as one hipGraph -- launches AND the three RCCL collectives -------------------------------
-    def capture_whole_step(self):
+    def capture_whole_step(self, unroll=1):
         """One graph for the step of `step` (multi branch): RCCL collectives are stream operations like any other and can be
         captured with the kernels around them (measured at world size 1, tools/whole_step_graph.py: 80 us per step against
         120 with the three graph segments and 152 eagerly -- the host then issues ONE graph launch instead of three launches +
@@ -288,7 +288,8 @@ class Workload:
         g = torch.cuda.CUDAGraph()
         res = {}
         with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
-            res["out"] = self.step()
+            for _ in range(unroll):   # (`unroll` consecutive steps per graph launch, like graph_x10 on one GPU)
+                res["out"] = self.step()
         torch.cuda.synchronize()
         self._whole = (g, res["out"])
         return res["out"]
@@ -738,6 +739,25 @@ def main():
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)   # (every rank takes the same path)
             if float(flag.item()) == 1.0:
                 mode = "graph_step"
+                if unrollable and os.environ.get("BENCH_NO_WHOLE_GRAPH_UNROLL") != "1":
+                    # ten consecutive steps per graph launch, as on one GPU (the stream idles ~8 us between two graph
+                    # launches): same captured step, checked the same way
+                    try:
+                        one = wl._whole
+                        got = wl.capture_whole_step(UNROLL)
+                        got = wl.step_whole()
+                        torch.cuda.synchronize()
+                        same = torch.equal(got[0], ref[0]) and all(
+                            float((a - b).abs().max()) <= 1e-6 * max(float(b.abs().max()), 1e-30) for a, b in zip(got[1:], ref[1:]))
+                        oku = 1.0 if same else 0.0
+                    except Exception:  # noqa: BLE001
+                        oku = 0.0
+                    flag = torch.tensor([oku], device=dev)
+                    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                    if float(flag.item()) == 1.0:
+                        mode = "graph_step_x%d" % UNROLL
+                    else:
+                        wl._whole = one
             elif whole_note is None:
                 whole_note = "another rank could not capture the whole step"
     if mode is None:
@@ -749,10 +769,12 @@ def main():
         mode = min(ms_modes, key=ms_modes.get)
     elif mode == "graph":
         graph = capture()
-    steps_per_launch = UNROLL if mode.startswith("graph_x") else 1
-    run = graph_u.replay if steps_per_launch > 1 else (graph.replay if mode == "graph" else
-                                                         (wl.step_segments if mode == "graph_segments" else
-                                                          (wl.step_whole if mode == "graph_step" else wl.step)))
+    steps_per_launch = UNROLL if (mode.startswith("graph_x") or mode.startswith("graph_step_x")) else 1
+    if mode.startswith("graph_step"):
+        run = wl.step_whole
+    else:
+        run = graph_u.replay if steps_per_launch > 1 else (graph.replay if mode == "graph" else
+                                                             (wl.step_segments if mode == "graph_segments" else wl.step))
     if order_graphs is not None:
         run = order_graphs
 
