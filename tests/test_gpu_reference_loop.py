@@ -131,7 +131,10 @@ def test_reference_train_mvr_converges_from_the_sphere_at_the_size_of_dss_yml(tm
                 "model_points_farther_than_0.2": float((d_mt > 0.2).mean())}
 
     model_pt = os.path.join(tmp, "exp", "dropin", "model.pt")
-    r = cfg3.run(common + ["--config", cfg_cls, "--scalars", sc, "--exit-after", "3"], 600)   # a few iterations from the sphere
+    # a few iterations from the sphere.  ONE second, not more: the snapshot is taken by time (train_mvr.py's own --exit-after),
+    # and since the renderer's host path got faster (18 ms per iteration of the reference's loop, 42 before) three seconds
+    # were already 160 iterations -- most of the early drop of the target -> model distance (1.13e-3 -> 0.78e-3) behind it
+    r = cfg3.run(common + ["--config", cfg_cls, "--scalars", sc, "--exit-after", "1"], 600)
     assert cfg3.reached_time_limit(r), r.stdout[-4000:]
     cd_early = chamfer(model_pt)
     loss, legs = [], 0
@@ -157,12 +160,14 @@ def test_reference_train_mvr_converges_from_the_sphere_at_the_size_of_dss_yml(tm
     assert all(l == l and l < 1e3 for l in loss)
     assert deciles[-1] < 0.8 * deciles[0], deciles
     # The model moves onto the target: the typical model point ends up on the target's surface (median model -> target
-    # distance: 0.275 -> 0.035 measured) and the target is covered better (target -> model: 1.13e-3 -> 0.72e-3).  The MEAN
+    # distance: 0.30 -> 0.034 measured) and the target is covered better (target -> model: 7.5e-2 -> 0.69e-3).  The MEAN
     # model -> target distance -- and with it the symmetric chamfer distance -- RISES (0.13 -> 0.77): the reference neither
     # prunes nor bounds its points (point_modeling.py:131-132 is commented out), and its hard-coded Adam(lr 0.01)
     # (train_mvr.py:84-94) carries the ~30 % of the sphere's points whose silhouette gradient keeps its sign out of the
     # view volume, 0.01 per iteration.  That is the reference's optimisation (the C-level leg of the test above reproduces
     # the class-level trajectory); both halves are recorded.
     assert cd_late["model_to_target_median"] < 0.5 * cd_early["model_to_target_median"], (cd_early, cd_late)
-    assert cd_late["target_to_model"] < 0.8 * cd_early["target_to_model"], (cd_early, cd_late)
+    # (coverage of the target: 0.69 ... 0.72e-3 at the end in every run; the early value depends on how many iterations fit
+    # into the first second -- 7.5e-2, practically the initial sphere, when the first iteration's one-off work fills it)
+    assert cd_late["target_to_model"] < 0.9 * cd_early["target_to_model"] and cd_late["target_to_model"] < 0.9e-3, (cd_early, cd_late)
     assert cd_late["model_points_farther_than_0.2"] < cd_early["model_points_farther_than_0.2"], (cd_early, cd_late)

@@ -1,7 +1,7 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
-O=gpurun_out/r4_run50; mkdir -p $O
+O=gpurun_out/r4_run54; mkdir -p $O
 timeout 2400 python -m pytest tests -x -q -m gpu > $O/pytest_all.txt 2>&1
 echo "pytest rc $?" >> $O/pytest_all.txt
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.txt 2>&1
