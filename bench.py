@@ -155,6 +155,7 @@ class Workload:
                                self.num, self.colors, S, K, CUTOFF, THR, SIGMA, False, True, rows=p.rows,
                                out_image=self.fx.image if multi else None,
                                out_visible=self.fx.visible if multi else None,
+                               band_outputs_only=multi and p.world_size > 1,   # (DSS_WS_BAND_OUTPUTS: a rank bins its band's splats only)
                                **({"order_refresh": self.order_refresh} if self.force_order is None else
                                   {"workspace_state": self._order_ws_state()}))
         info = {"pts_screen": f["pts_screen"], "radii": f["radii"], "scaler": f["scaler"], "valid": f["valid"]}
@@ -189,9 +190,9 @@ class Workload:
             image = self.fx.finish()  # full render, (N,S,S,4) view of the receive buffer
             mark("wait_image_allgather")
         # multi-GPU: the per-point clip follows the reduction and is applied inside the projection kernel
-        g_world = ops.project_backward(self.world, self.M, self.V, self.first, self.num, g_pts, info["valid"], True,
-                                       clip=CLIP if multi else -1.0)
-        g_col = g_feat.view(self.N, self.Pc, 3).sum(0) if self.N > 1 else g_feat
+        # (the per-camera colour gradients of the shared cloud are summed over the cameras in the same launch)
+        g_world, g_col = ops.project_backward(self.world, self.M, self.V, self.first, self.num, g_pts, info["valid"], True,
+                                              clip=CLIP if multi else -1.0, grad_features=g_feat)
         mark("projection_compute")
         return image, g_world, g_col
 
@@ -215,7 +216,8 @@ class Workload:
         def fwd():
             seg["f"] = ops.render_forward(self.world, self.normals, self.h, self.M, self.V, self.znear, self.zfar, self.first,
                                           self.num, self.colors, S, K, CUTOFF, THR, SIGMA, False, True, rows=p.rows,
-                                          out_image=self.fx.image, out_visible=self.fx.visible)
+                                          out_image=self.fx.image, out_visible=self.fx.visible,
+                                          band_outputs_only=p.world_size > 1)
 
         def bwd():
             f = seg["f"]
@@ -224,9 +226,8 @@ class Workload:
                                 out=(g_feat, g_pts))
 
         def proj():
-            seg["g_world"] = ops.project_backward(self.world, self.M, self.V, self.first, self.num, g_pts, seg["f"]["valid"],
-                                                  True, clip=CLIP)
-            seg["g_col"] = g_feat.view(self.N, self.Pc, 3).sum(0)
+            seg["g_world"], seg["g_col"] = ops.project_backward(self.world, self.M, self.V, self.first, self.num, g_pts,
+                                                                seg["f"]["valid"], True, clip=CLIP, grad_features=g_feat)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):

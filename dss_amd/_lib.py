@@ -83,6 +83,8 @@ SIGNATURES = {
     "dss_point_setup": (_c_int, [_c_vp] * 12 + [_c_int, _c_i64, _c_int, _c_int, _c_int, _c_f32, _c_f32]
                         + [_c_vp] * 6 + [_c_vp]),
     "dss_project_backward": (_c_int, [_c_vp] * 5 + [_c_int, _c_i64, _c_int, _c_vp, _c_vp, _c_f32, _c_vp, _c_vp]),
+    "dss_project_backward_features": (_c_int, [_c_vp] * 5 + [_c_int, _c_i64, _c_int, _c_vp, _c_vp, _c_f32, _c_vp, _c_vp, _c_int,
+                                                              _c_vp, _c_vp]),
     "dss_blend_backward": (_c_int, [_c_vp] * 10 + [_c_int, _c_i64, _c_int, _c_int, _c_int, _c_int, _c_int, _c_vp, _c_vp]),
     "dss_blend_backward_scatter": (_c_int, [_c_vp] * 4 + [_c_int] * 5 + [_c_i64, _c_vp, _c_vp]),
 }
@@ -110,6 +112,7 @@ def load():
 
 
 WS_ORDER_SAVE, WS_ORDER_REUSE = 0x10, 0x20   # include/dss_hip.h DSS_WS_ORDER_* (flags of workspace_state)
+WS_BAND_OUTPUTS = 0x40   # DSS_WS_BAND_OUTPUTS: ellipse / scaler / cutoff only for the splats that meet the row band
 OPT_LEAN_WORKSPACE, OPT_BACKWARD_TPW, OPT_BACKWARD_ADDR64, OPT_BACKWARD_FUSED, OPT_KNN_QUERY = 0, 1, 2, 3, 4   # include/dss_hip.h DSS_OPT_*
 
 

@@ -129,7 +129,7 @@ static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; 
 int check_launch(const char *what);
 int option(int which);                         // api.hip: value set by dss_set_option (0 = default)
 #define DSS_MAX_DEVICES 64
-#define DSS_DEV_CACHE_SLOTS 16
+#define DSS_DEV_CACHE_SLOTS 24
 std::atomic<int> *device_cache(int dev);       // api.hip: DSS_DEV_CACHE_SLOTS zero-initialised slots per device ordinal (nullptr beyond 64)
 
 // knn.hip: bbox (N,6) ordered ints = min xyz, max xyz of every cloud (NaN coordinates skipped)

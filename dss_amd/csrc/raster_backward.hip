@@ -848,10 +848,18 @@ static inline size_t cell_blocks(int64_t P) { return (size_t)((P + CELL_CHUNK - 
 // thread per cell walks the active blocks (running sum = each block's first position within the cell) and one workgroup
 // scans the cell totals; pass 3, every workgroup ranks its entries again in LDS and writes them to
 // cell_start[cell] + block_base[block][cell] + rank.
+// Row band (multi-GPU, round 5): rs is known by now (median_final_kernel precedes this launch), so the entries that cannot
+// reach the rank's rows -- neither with their own box nor with the search window; the conservative test of
+// band_filter_kernel -- get no cell: they drop out of the sorted list the gather walks (at 8 ranks seven eighths of the
+// ~3.2M tasks of 8 x 1M points were rejected one by one inside the gather: 0.6 ms per rank and step for 0.16 ms of work) and
+// their zero partial sums are stored here.
+#define CELL_NONE 0xffffffffu
 __global__ __launch_bounds__(CELL_THREADS) void cell_hist_kernel(
     const float *__restrict__ points, const int64_t *__restrict__ first_idx, const int64_t *__restrict__ num_pts, int N, int S,
     CellGrid cg, const uint32_t *__restrict__ vis_count, const int32_t *__restrict__ vis_list,
-    uint32_t *__restrict__ cell_of, uint32_t *__restrict__ block_hist)
+    uint32_t *__restrict__ cell_of, uint32_t *__restrict__ block_hist,
+    const float *__restrict__ radii /* NULL: whole image, no filter */, const float *__restrict__ rs, int row0, int rows,
+    int tshift, float *__restrict__ grad_pts, float *__restrict__ grad_feat, int C)
 {
     extern __shared__ uint32_t s_hist[];
     const uint32_t count = *vis_count;
@@ -869,9 +877,27 @@ __global__ __launch_bounds__(CELL_THREADS) void cell_hist_kernel(
             // pixel column / row of the point (any monotone map of NDC does: only neighbourhood matters)
             const float fx = (1.0f - px) * 0.5f * (float)S, fy = (1.0f - py) * 0.5f * (float)S;
             const int ix = min(max((int)fx, 0), S - 1) >> cg.shift, iy = min(max((int)fy, 0), S - 1) >> cg.shift;
-            const uint32_t key = (uint32_t)((n * cg.cy + iy) * cg.cx + ix);
+            uint32_t key = (uint32_t)((n * cg.cy + iy) * cg.cx + ix);
+            if (radii) {
+                const int last_row = row0 + (((rows - 1) >> 3) << tshift) + ((rows - 1) & 7);
+                const float band_lo = -1 + (2 * (S - 1 - last_row)) / (float)S;     // lower edge of the lowest pixel row
+                const float band_hi = -1 + (2 * (S - 1 - row0) + 2.0f) / (float)S;  // upper edge of the highest one
+                const float reach = fmaxf(rs[n], radii[2 * (size_t)p + 1]);
+                bool in_band = !(py + reach < band_lo || py - reach > band_hi);
+                if (in_band && tshift > 3) {
+                    int ylo, yhi;
+                    in_band = ndc_index_range(py, reach, S, ylo, yhi) &&
+                              band_row_ceil(S - 1 - yhi, row0, tshift) <= min(band_row_floor(S - 1 - ylo, row0, tshift), rows - 1);
+                }
+                if (!in_band) {
+                    key = CELL_NONE;
+                    grad_pts[3 * (size_t)p] = 0.0f; grad_pts[3 * (size_t)p + 1] = 0.0f; grad_pts[3 * (size_t)p + 2] = 0.0f;
+                    if (grad_feat)
+                        for (int ch = 0; ch < C; ++ch) grad_feat[(size_t)p * C + ch] = 0.0f;
+                }
+            }
             cell_of[i] = key;
-            atomicAdd(&s_hist[key], 1u);
+            if (key != CELL_NONE) atomicAdd(&s_hist[key], 1u);
         }
     }
     __syncthreads();
@@ -908,7 +934,7 @@ __global__ __launch_bounds__(256) void cell_block_scan_kernel(const uint32_t *__
 }
 // one workgroup: exclusive scan of the cell totals -> cell_start
 __global__ __launch_bounds__(1024) void cell_scan_kernel(const uint32_t *__restrict__ cell_total, uint32_t *__restrict__ cell_start,
-                                                         int total)
+                                                         int total, uint32_t *__restrict__ sorted_count /* entries of the sorted list */)
 {
     __shared__ uint32_t s_part[1024];
     const int tid = threadIdx.x;
@@ -929,6 +955,7 @@ __global__ __launch_bounds__(1024) void cell_scan_kernel(const uint32_t *__restr
         cell_start[i] = run;
         run += cell_total[i];
     }
+    if (tid == 1023) *sorted_count = s_part[1023];
 }
 __global__ __launch_bounds__(CELL_THREADS) void cell_scatter_kernel(
     CellGrid cg, const uint32_t *__restrict__ vis_count, const int32_t *__restrict__ vis_list,
@@ -945,7 +972,10 @@ __global__ __launch_bounds__(CELL_THREADS) void cell_scatter_kernel(
 #pragma unroll 4
     for (int u = 0; u < CELL_PER_THREAD; ++u) {
         const uint32_t i = b0 + (uint32_t)u * CELL_THREADS + threadIdx.x;
-        if (i < count) sorted[atomicAdd(&s_hist[cell_of[i]], 1u)] = vis_list[i];
+        if (i < count) {
+            const uint32_t key = cell_of[i];
+            if (key != CELL_NONE) sorted[atomicAdd(&s_hist[key], 1u)] = vis_list[i];
+        }
     }
 }
 
@@ -1046,6 +1076,8 @@ extern "C" __device__ unsigned long long dss_dispatch_id(void) __asm("llvm.amdgc
 #define FB_TAGS (8 * 64)
 #define FB_SPIN_LIMIT (1 << 20)
 #define FB_ALPHA_PER_WG 2048    // pixels of the alpha plane per (256-thread) workgroup of fb_prep_kernel
+#define FB_MAX_SEG 256          // segments of the list (= FB_THREADS: fb_median scans them one per thread)
+#define FB_MEDIAN_LDS (FB_CAND_MAX + FB_HIST + 3 * FB_MAX_SEG + 32)   // words of LDS of fb_median
 // level-0 bucket of an order-preserving radius key: 16 octaves [2^-16, 1) of NDC radius in 256 buckets (1/16 octave each;
 // everything below / above lands in the end buckets: any monotone map keeps the selection exact)
 #define FB_KEY_LO 0xB7800000u   // float_key(2^-16)
@@ -1236,15 +1268,14 @@ __device__ __forceinline__ float fb_median(const FusedPrep &F, int n, const int6
                                            const int64_t *__restrict__ num_pts, uint32_t *s_mem)
 {
     uint32_t *s_cand = s_mem /* also: 4 x 256 partial sums */, *s_hist = s_mem + FB_CAND_MAX /* also: 257 prefix sums */,
-             *s_cnt = s_hist + FB_HIST, *s_dst = s_cnt + 64, *s_base = s_dst + 64, *s_spare = s_base + 64, *s_w = s_spare + 64;
-    (void)s_spare;
+             *s_cnt = s_hist + FB_HIST, *s_dst = s_cnt + FB_MAX_SEG, *s_base = s_dst + FB_MAX_SEG, *s_w = s_base + FB_MAX_SEG;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int64_t f = first_idx[n];
     const int64_t cnt = max((int64_t)0, min(num_pts[n], F.P - f));
     if (cnt <= 0) return 0.0f;   // uniform
     const int64_t seg = (int64_t)F.per * FB_THREADS;
     const int c_lo = (int)(f / seg), c_hi = (int)((f + cnt - 1) / seg);
-    const int n_c = c_hi - c_lo + 1;   // <= 64
+    const int n_c = c_hi - c_lo + 1;   // <= FB_MAX_SEG (= FB_THREADS: one thread per segment in the scans below)
     const uint32_t *H = F.chunk_hist + ((size_t)n * F.chunks + c_lo) * FB_BUCKETS;
     const uint2 *R = F.seg_range + (size_t)n * F.chunks + c_lo;
     PREP_MARK(4);
@@ -1252,24 +1283,25 @@ __device__ __forceinline__ float fb_median(const FusedPrep &F, int n, const int6
     // segments, four consecutive buckets): sixteen 16-byte loads in flight ----
     {
         const int g = wid, qd = lane;
-        uint4 v[16];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const int c = g * 16 + u;
-            v[u] = make_uint4(0u, 0u, 0u, 0u);
-            if (c < n_c) v[u] = reinterpret_cast<const uint4 *>(H + (size_t)c * FB_BUCKETS)[qd];
-        }
         const uint2 rg = tid < n_c ? R[tid] : make_uint2(0u, 0u);   // (first entry, entries) of segment tid
         uint4 acc = make_uint4(0u, 0u, 0u, 0u);
+        for (int blk = 0; blk < n_c; blk += 64) {   // (one trip for up to 64 segments)
+            uint4 v[16];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
-        reinterpret_cast<uint4 *>(s_cand + g * FB_BUCKETS)[qd] = acc;
-        if (wid == 0) {
-            const uint32_t x = wave_incl_scan(2u * rg.y);   // two keys per visible point
-            if (lane == 63) s_hist[FB_BUCKETS] = x;          // all keys of the cloud
-            s_cnt[lane] = 2u * rg.y;                         // (keys of the segment, for the last bucket's end)
-            s_base[lane] = 2u * (uint32_t)((int64_t)(c_lo + lane) * seg) + 2u * rg.x;   // first key of (cloud, segment) in F.keys
+            for (int u = 0; u < 16; ++u) {
+                const int c = blk + g * 16 + u;
+                v[u] = make_uint4(0u, 0u, 0u, 0u);
+                if (c < n_c) v[u] = reinterpret_cast<const uint4 *>(H + (size_t)c * FB_BUCKETS)[qd];
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
         }
+        reinterpret_cast<uint4 *>(s_cand + g * FB_BUCKETS)[qd] = acc;
+        uint32_t all_keys;
+        (void)fb_block_excl_scan(2u * rg.y, s_w + 16, all_keys);   // two keys per visible point
+        if (tid == 0) s_hist[FB_BUCKETS] = all_keys;               // all keys of the cloud
+        s_cnt[tid] = 2u * rg.y;                                    // (keys of the segment, for the last bucket's end)
+        s_base[tid] = 2u * (uint32_t)((int64_t)(c_lo + tid) * seg) + 2u * rg.x;   // first key of (cloud, segment) in F.keys
     }
     __syncthreads();
     s_hist[tid] = (s_cand[tid] + s_cand[FB_BUCKETS + tid]) + (s_cand[2 * FB_BUCKETS + tid] + s_cand[3 * FB_BUCKETS + tid]);
@@ -1286,36 +1318,43 @@ __device__ __forceinline__ float fb_median(const FusedPrep &F, int n, const int6
     k = s_w[5];
     PREP_MARK(5);
     // ---- the bucket's keys: a contiguous run of every segment's sorted keys ----
-    if (wid == 0) {
+    {
         uint32_t e0 = 0, e1 = 0;
-        if (lane < n_c) {
-            const uint32_t *hc = H + (size_t)lane * FB_BUCKETS;
+        if (tid < n_c) {
+            const uint32_t *hc = H + (size_t)tid * FB_BUCKETS;
             e0 = hc[b1];
-            e1 = b1 + 1 < FB_BUCKETS ? hc[b1 + 1] : s_cnt[lane];
+            e1 = b1 + 1 < FB_BUCKETS ? hc[b1 + 1] : s_cnt[tid];
         }
         const uint32_t v = e1 - e0;
-        const uint32_t x = wave_incl_scan(v);
-        s_dst[lane] = x - v;
-        s_cnt[lane] = v;
-        s_base[lane] += e0;
+        uint32_t tot_unused;
+        const uint32_t ex = fb_block_excl_scan(v, s_w + 16, tot_unused);
+        s_dst[tid] = ex;
+        s_cnt[tid] = v;
+        s_base[tid] += e0;
     }
     __syncthreads();
     const bool in_lds = m <= FB_CAND_MAX;
-    const int cc = tid >> 2, q = tid & 3;   // 4 threads per segment
-    const uint32_t my_cnt = s_cnt[cc];
-    const uint32_t *my_keys = F.keys + (size_t)s_base[cc];
+    // 4 threads per segment when the cloud has up to 64 of them; fewer, larger segments get more threads each (the run of a
+    // segment inside the bucket is then long: 8 segments of 4096 points = ~270 keys per run, six dependent trips of 4 x 12)
+    const int tsh = n_c <= 8 ? 5 : (n_c <= 16 ? 4 : (n_c <= 32 ? 3 : 2));
+    const int tps = 1 << tsh;   // threads per segment (uniform)
+    const int q = tid & (tps - 1);
     uint32_t kmin = 0xffffffffu, kmax = 0u;
     constexpr int KB = 12;   // loads in flight per thread: a segment's ~40 keys of the bucket in ONE round trip
-    for (uint32_t j0 = q; j0 < my_cnt; j0 += 4 * KB) {
-        uint32_t key[KB];
+    for (int cc = tid >> tsh; cc < n_c; cc += FB_THREADS >> tsh) {
+        const uint32_t my_cnt = s_cnt[cc];
+        const uint32_t *my_keys = F.keys + (size_t)s_base[cc];
+        for (uint32_t j0 = q; j0 < my_cnt; j0 += (uint32_t)tps * KB) {
+            uint32_t key[KB];
 #pragma unroll
-        for (int u = 0; u < KB; ++u) key[u] = my_keys[min(j0 + 4u * u, my_cnt - 1u)];
+            for (int u = 0; u < KB; ++u) key[u] = my_keys[min(j0 + (uint32_t)tps * u, my_cnt - 1u)];
 #pragma unroll
-        for (int u = 0; u < KB; ++u) {
-            if (j0 + 4u * u < my_cnt) {
-                if (in_lds) s_cand[s_dst[cc] + j0 + 4u * u] = key[u];
-                kmin = min(kmin, key[u]);
-                kmax = max(kmax, key[u]);
+            for (int u = 0; u < KB; ++u) {
+                if (j0 + (uint32_t)tps * u < my_cnt) {
+                    if (in_lds) s_cand[s_dst[cc] + j0 + (uint32_t)tps * u] = key[u];
+                    kmin = min(kmin, key[u]);
+                    kmax = max(kmax, key[u]);
+                }
             }
         }
     }
@@ -1344,9 +1383,13 @@ __device__ __forceinline__ float fb_median(const FusedPrep &F, int n, const int6
                 if (key >= lo && key <= hi) atomicAdd(&s_hist[(key - lo) >> shift], 1u);
             }
         } else {
-            for (uint32_t j = q; j < my_cnt; j += 4) {
-                const uint32_t key = my_keys[j];
-                if (key >= lo && key <= hi) atomicAdd(&s_hist[(key - lo) >> shift], 1u);
+            for (int cc = tid >> tsh; cc < n_c; cc += FB_THREADS >> tsh) {
+                const uint32_t my_cnt = s_cnt[cc];
+                const uint32_t *my_keys = F.keys + (size_t)s_base[cc];
+                for (uint32_t j = q; j < my_cnt; j += (uint32_t)tps) {
+                    const uint32_t key = my_keys[j];
+                    if (key >= lo && key <= hi) atomicAdd(&s_hist[(key - lo) >> shift], 1u);
+                }
             }
         }
         __syncthreads();
@@ -1447,14 +1490,28 @@ __global__ __launch_bounds__(FB_THREADS) void fb_prep_kernel(const FusedPrep F, 
 __global__ __launch_bounds__(FB_THREADS) void fb_median_kernel(const FusedPrep F, const int64_t *__restrict__ first_idx,
                                                                const int64_t *__restrict__ num_pts)
 {
-    __shared__ uint32_t s_fb[FB_CAND_MAX + FB_HIST + 4 * 64 + 16];
+    __shared__ uint32_t s_fb[FB_MEDIAN_LDS];
     const float v = fb_median(F, (int)blockIdx.x, first_idx, num_pts, s_fb);
     if (threadIdx.x == 0) F.rs[blockIdx.x] = v;
 }
 
 // CYC: tile-row-cyclic band (tshift > 3): the windows are walked in BAND rows (the owned rows of a window are a
 // contiguous range of band rows), the NDC y of each comes from band_image_row.  CYC = false is the contiguous band.
-template <int C, bool SEG, int TPW, bool A32, bool CYC = false, bool PREP = false>
+// BAND (round 5; multi-GPU row bands on the two-phase launch, PREP && SEG): the visible list holds the points visible on ANY
+// rank, of which a rank's rows are reached by a fraction (own box: ~1/G; search window: 1/G + 2 rs / S for contiguous bands,
+// about half for 8-row cyclic units at 8 ranks).  Round 3 filtered the list in a launch of its own behind the median
+// (band_filter_kernel, 9.6 us + the 11.8 us median launch + a 9.7 us compaction: 7 launches per step and rank); here every
+// worker workgroup filters ITS share of the list (entry e belongs to workgroup e mod n_wg: a strided deal, so that a cloud
+// whose ids are spatially ordered still spreads over all workgroups) inside the launch -- once by the splat's own box before
+// the blend half, once by the search radius behind the wait for the medians -- into a list in LDS, which its four wavefronts
+// then share through an LDS counter; rejected points get their zero partial sums from the filtering thread.  No extra
+// launch, nothing crosses workgroups but rs.
+#ifndef DSS_BAND_RB
+#define DSS_BAND_RB 8    // rows of window loads in flight per trip of a BAND task (14 = a 12.8-pixel window in one trip for two
+                         // row phases: measured no faster -- 103 VGPRs, four workgroups per CU instead of five)
+#endif
+#define BAND_SHARE 512   // list entries per worker workgroup (two per thread); the host keeps P <= BAND_SHARE * workers
+template <int C, bool SEG, int TPW, bool A32, bool CYC = false, bool PREP = false, bool BAND = false>
 __global__ __launch_bounds__(256) void render_backward_kernel(
     const float *__restrict__ grad_out, const float *__restrict__ grad_alpha /* dense (N,rows,S); PREP: or grad_out + C, see astride */,
     const int32_t *__restrict__ idx, const float *__restrict__ qv,
@@ -1476,9 +1533,15 @@ __global__ __launch_bounds__(256) void render_backward_kernel(
     const int lane = threadIdx.x & 63, grp = lane / GS, rp = (lane % GS) >> 4, l = lane & 15;
     // PREP: the first N workgroups select the medians (fb_median) and take no gather tasks
     const uint32_t first_block = PREP ? (uint32_t)N : 0u;
+    // BAND: one pool of LDS -- the median workgroups use it as fb_median's scratch, the workers for their share's records
+    // and task lists (both at once would cost 42 KB per workgroup and the fifth resident workgroup of a CU)
+    constexpr int BAND_WORDS = 9 * BAND_SHARE;   // 7 record arrays + 2 lists
+    __shared__ uint32_t s_pool[BAND ? (FB_MEDIAN_LDS > BAND_WORDS ? FB_MEDIAN_LDS : BAND_WORDS) : 1];
     if (PREP && blockIdx.x < first_block) {
-        __shared__ uint32_t s_fb[FB_CAND_MAX + FB_HIST + 4 * 64 + 16];
+        __shared__ uint32_t s_fb_own[(PREP && !BAND) ? FB_MEDIAN_LDS : 1];
+        uint32_t *s_fb = BAND ? s_pool : s_fb_own;
         PREP_MARK(0);
+        __builtin_amdgcn_s_setprio(3);   // everybody else's second half waits for these few wavefronts
         const float v = fb_median(F, (int)blockIdx.x, first_idx, num_pts, s_fb);
         fb_publish_rs(F, (int)blockIdx.x, v, fb_launch_tag());
         PREP_MARK(1);
@@ -1489,7 +1552,15 @@ __global__ __launch_bounds__(256) void render_backward_kernel(
     // SEG: vis_count[0..n_seg) are per-segment counts written by backward_compact_kernel (n_seg <= 64): every
     // wavefront scans them in registers once; a task index t maps to (segment, offset) with one ballot.
     uint32_t count, seg_excl = 0;  // first task index of segment `lane`
-    if (SEG) {
+    __shared__ uint32_t s_bseg[BAND ? FB_MAX_SEG + 1 : 1];   // BAND: first list entry of every segment (+ the total)
+    __shared__ uint32_t s_bscan[4];
+    if (BAND) {
+        // up to FB_MAX_SEG segments (one per thread): exclusive scan of their counts over the workgroup
+        const uint32_t c = (int)threadIdx.x < n_seg ? vis_count[threadIdx.x] : 0u;
+        const uint32_t ex = fb_block_excl_scan(c, s_bscan, count);
+        s_bseg[threadIdx.x] = ex;
+        if (threadIdx.x == 0) s_bseg[FB_MAX_SEG] = count;
+    } else if (SEG) {
         const uint32_t seg_cnt = lane < n_seg ? vis_count[lane] : 0u;
         uint32_t seg_incl = seg_cnt;
 #pragma unroll
@@ -1506,7 +1577,7 @@ __global__ __launch_bounds__(256) void render_backward_kernel(
     // long lists use 6 workgroups per CU: more resident gathers only evict each other's image rows from L2
     const bool long_list = n_groups > 8u * n_waves;
     if (long_list) n_waves = min(n_waves, large_waves);
-    if (!PREP && wave >= n_waves) return;
+    if (!PREP && !BAND && wave >= n_waves) return;
     // Dealing of the groups.  Short lists: group t -> wave t mod n_waves.  Long lists are in screen-cell order (see
     // cell_count_kernel): runs of CH consecutive groups -- about one cell -- go to ONE XCD (blocks are dispatched to the
     // XCDs round robin), so that the rows a cell's tasks share are fetched into one L2 instead of eight.
@@ -1523,7 +1594,7 @@ __global__ __launch_bounds__(256) void render_backward_kernel(
         return chunked ? ((t / max(CH, 1u)) * 8u + xcd) * CH + (t % max(CH, 1u)) : t;
     };
     const uint32_t wave_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)qof(t0));
-    if (!PREP && wave_u >= n_groups) return;
+    if (!PREP && !BAND && wave_u >= n_groups) return;
     const bool has_tasks = wave < n_waves && wave_u < n_groups;   // (PREP: wavefronts without tasks still take part in the wait)
     const uint32_t t_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)t0);
 
@@ -1560,18 +1631,119 @@ __global__ __launch_bounds__(256) void render_backward_kernel(
     __shared__ uint32_t s_deal[2];
     const uint32_t blk4 = (blockIdx.x - first_block) * 4u;
     auto dyn_group = [&](uint32_t i) -> uint32_t { return blk4 + (i & 3u) + (i >> 2) * n_waves; };
-    if (PREP) {
+    // ---- BAND: this workgroup's share of the visible list, filtered into LDS ---------------------------------------------
+    // share slot t (= thread + 256 j): record arrays [id | cloud << 24, px, py, pz, rx, ry, scaler][BAND_SHARE], loaded ONCE
+    // by the filter pass (the tasks of both halves then start from LDS: one dependent memory round trip less per round);
+    // s_band: [0, SHARE): slots of the blend half's tasks, [SHARE, 2 SHARE): occupancy half
+    float *s_rec = reinterpret_cast<float *>(s_pool);
+    int32_t *s_band = reinterpret_cast<int32_t *>(s_pool) + (BAND ? 7 * BAND_SHARE : 0);
+    __shared__ uint32_t s_bcnt[2];
+    __shared__ float s_brs[BAND ? 64 : 1];                  // rs of every cloud, read once behind the wait
+    constexpr int BAND_NSH = 24;                            // list entry = cloud << 24 | point id (P <= 262,144, N <= 64)
+    int32_t b_id[2] = {-1, -1};    // this thread's (at most two) list entries: point id, cloud, NDC y, own / search reach
+    int b_n[2] = {-1, -1};
+    float b_py[2] = {0.f, 0.f}, b_ry[2] = {0.f, 0.f};
+    if (BAND) {
+        if (threadIdx.x == 0) { s_bcnt[0] = 0; s_bcnt[1] = 0; }
+        __syncthreads();
+        const uint32_t n_wg = gridDim.x - first_block, wg = blockIdx.x - first_block;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const uint32_t e = wg + ((uint32_t)threadIdx.x + 256u * (uint32_t)j) * n_wg;
+            if (e < count) {
+                // last segment that starts at or before e (empty segments share their successor's start)
+                int sg = 0;
+#pragma unroll
+                for (int st = FB_MAX_SEG / 2; st >= 1; st >>= 1) sg += (sg + st < FB_MAX_SEG && s_bseg[sg + st] <= e) ? st : 0;
+                b_id[j] = vis_list[(size_t)sg * seg_pts + (e - s_bseg[sg])];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (b_id[j] >= 0) {
+                const size_t i = (size_t)b_id[j];
+                const int slot = (int)threadIdx.x + 256 * j;
+                const float px_ = points[3 * i], py_ = points[3 * i + 1], pz_ = points[3 * i + 2];
+                const float2 rr_ = reinterpret_cast<const float2 *>(radii)[i];
+                const float sc_ = scaler ? scaler[i] : 0.0f;
+                b_py[j] = py_;
+                b_ry[j] = rr_.y;
+                b_n[j] = find_cloud(b_id[j], first_idx, num_pts, N);
+                reinterpret_cast<int32_t *>(s_rec)[slot] = b_id[j] | (max(b_n[j], 0) << BAND_NSH);
+                s_rec[BAND_SHARE + slot] = px_;
+                s_rec[2 * BAND_SHARE + slot] = py_;
+                s_rec[3 * BAND_SHARE + slot] = pz_;
+                s_rec[4 * BAND_SHARE + slot] = rr_.x;
+                s_rec[5 * BAND_SHARE + slot] = rr_.y;
+                s_rec[6 * BAND_SHARE + slot] = sc_;
+            }
+        }
+    }
+    // which = 0: by the splat's own box (blend half), 1: by the search radius (occupancy half; rs published).  Conservative
+    // (the task evaluates the exact rows); a rejected point's partial sum over this band is zero and is stored here.
+    auto band_filter = [&](auto which_tag) {
+        constexpr int WHICH = decltype(which_tag)::value;
+        const int last_row = row0 + (((rows - 1) >> 3) << tshift) + ((rows - 1) & 7);
+        const float band_lo = -1 + (2 * (S - 1 - last_row)) / (float)S;     // lower edge of the lowest pixel row
+        const float band_hi = -1 + (2 * (S - 1 - row0) + 2.0f) / (float)S;  // upper edge of the highest one
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            bool keep = false;
+            if (b_id[j] >= 0 && b_n[j] >= 0) {
+                const float reach = WHICH == 0 ? b_ry[j] : s_brs[b_n[j]];
+                const float py = b_py[j];
+                keep = !(py + reach < band_lo || py - reach > band_hi);
+                if (keep && CYC) {
+                    int ylo, yhi;
+                    keep = ndc_index_range(py, reach, S, ylo, yhi) &&
+                           band_row_ceil(S - 1 - yhi, row0, tshift) <= min(band_row_floor(S - 1 - ylo, row0, tshift), rows - 1);
+                }
+            }
+            const unsigned long long m = __ballot(keep);
+            uint32_t base = 0;
+            if (lane == 0 && m) base = atomicAdd(&s_bcnt[WHICH], (uint32_t)__popcll(m));
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            if (keep) {
+                s_band[WHICH * BAND_SHARE + base + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] =
+                    (int)threadIdx.x + 256 * j;   // the share slot: its record is in s_rec
+            } else if (b_id[j] >= 0) {
+                const size_t i = (size_t)b_id[j];
+                if (WHICH == 0) {
+                    if (grad_feat)
+                        for (int ch = 0; ch < Cn; ++ch) grad_feat[i * Cn + ch] = 0.0f;
+                } else {
+                    grad_pts[3 * i] = 0.0f; grad_pts[3 * i + 1] = 0.0f; grad_pts[3 * i + 2] = 0.0f;
+                }
+            }
+        }
+        __syncthreads();
+    };
+    const uint32_t wave_in_wg = threadIdx.x >> 6;
+    auto band_ids = [&](uint32_t q, int which) -> int {
+        const uint32_t t = (uint32_t)TPW * q + (uint32_t)grp;
+        return t < s_bcnt[which] ? s_band[which * BAND_SHARE + t] : -1;
+    };
+    if (PREP || BAND) {
         if (threadIdx.x < 2) s_deal[threadIdx.x] = 4u;   // (indices 0..3 are the wavefronts' first groups)
         __syncthreads();
     }
     auto run_tasks = [&](auto phase_tag) {
     constexpr int PH = decltype(phase_tag)::value;
     uint32_t t_cur = t_first;
-    int p_nx = task_ids(wave_u);
+    const uint32_t b_groups = BAND ? (s_bcnt[PH == 2 ? 1 : 0] + TPW - 1u) / TPW : 0u;   // groups of this workgroup's own list
+    int p_nx = BAND ? band_ids(wave_in_wg, PH == 2 ? 1 : 0) : task_ids(wave_u);
     for (;;) {
-        const int p = p_nx;
+        // BAND: p_nx is a share slot; id and cloud come from its record
+        const int b_slot = BAND ? max(p_nx, 0) : 0;
+        const int b_word = (BAND && p_nx >= 0) ? reinterpret_cast<const int32_t *>(s_rec)[b_slot] : -1;
+        const int p = BAND ? (b_word >= 0 ? (b_word & ((1 << BAND_NSH) - 1)) : -1) : p_nx;
+        const int p_cloud = b_word >= 0 ? (b_word >> BAND_NSH) : -1;
         uint32_t t_next, q_next;
-        if (PREP) {
+        if (BAND) {
+            uint32_t i_next = 0;
+            if (lane == 0) i_next = atomicAdd(&s_deal[PH == 2 ? 1 : 0], 1u);
+            q_next = t_next = (uint32_t)__builtin_amdgcn_readfirstlane((int)i_next);
+        } else if (PREP) {
             uint32_t i_next = 0;
             if (lane == 0) i_next = atomicAdd(&s_deal[PH == 2 ? 1 : 0], 1u);
             q_next = t_next = dyn_group((uint32_t)__builtin_amdgcn_readfirstlane((int)i_next));
@@ -1579,13 +1751,20 @@ __global__ __launch_bounds__(256) void render_backward_kernel(
             t_next = t_cur + t_stride;
             q_next = qof(t_next);
         }
-        const bool more = q_next < n_groups;
-        if (more) p_nx = task_ids(q_next);  // in flight during this group
+        const bool more = q_next < (BAND ? b_groups : n_groups);
+        if (more) p_nx = BAND ? band_ids(q_next, PH == 2 ? 1 : 0) : task_ids(q_next);  // in flight during this group
         // ---- record + cloud of the task's point ------------------------------------------------------------
         float px = 0.f, py = 0.f, pz = -1.f, rx = 0.f, ry = 0.f, sc = 0.f, cur_r = 0.f;
         float wx = 0.f, wy = 0.f, wz = 0.f;   // world position (fused projection backward only)
         int n = -1;
-        if (p >= 0) {
+        if (BAND) {
+            if (p >= 0) {
+                px = s_rec[BAND_SHARE + b_slot]; py = s_rec[2 * BAND_SHARE + b_slot]; pz = s_rec[3 * BAND_SHARE + b_slot];
+                rx = s_rec[4 * BAND_SHARE + b_slot]; ry = s_rec[5 * BAND_SHARE + b_slot]; sc = s_rec[6 * BAND_SHARE + b_slot];
+                n = p_cloud;
+                if (PH != 1) cur_r = s_brs[n];
+            }
+        } else if (p >= 0) {
             px = points[3 * (size_t)p]; py = points[3 * (size_t)p + 1]; pz = points[3 * (size_t)p + 2];
             const float2 rr = reinterpret_cast<const float2 *>(radii)[p];
             rx = rr.x; ry = rr.y;
@@ -1642,7 +1821,7 @@ __global__ __launch_bounds__(256) void render_backward_kernel(
             const int i1 = top * S + (S - 1 - x1c);
             // RB rows per trip: all their loads are issued before the first is used (one memory round trip per trip; a
             // row-at-a-time loop spent ~1 us per ROW waiting)
-            constexpr int RB = 8;
+            constexpr int RB = BAND ? DSS_BAND_RB : 8;
             // NDC y of the lane's rows: for S = 2^k every pixel centre and every centre-to-centre distance is an exact
             // fp32 multiple of 1/S, so the rows advance by exact additions (one v_add per row instead of convert +
             // multiply + add behind a branch); other sizes evaluate the reference expression per row
@@ -1929,7 +2108,25 @@ __global__ __launch_bounds__(256) void render_backward_kernel(
         t_cur = t_next;
     }
     };
-    if (!PREP) {
+    if (BAND) {
+        // row band: own-box filter -> blend half -> (medians) -> search-radius filter -> occupancy half
+        PREP_MARK(0);
+        if (grad_feat) {
+            band_filter(std::integral_constant<int, 0>{});
+            PREP_MARK(8);
+            if (wave_in_wg * TPW < s_bcnt[0]) run_tasks(std::integral_constant<int, 1>{});
+        }
+        PREP_MARK(1);
+        if (PREP) fb_wait_rs(F, N, fb_launch_tag());
+        if ((int)threadIdx.x < N)
+            s_brs[threadIdx.x] = PREP ? __hip_atomic_load(&rs[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : rs[threadIdx.x];
+        __syncthreads();
+        PREP_MARK(2);
+        band_filter(std::integral_constant<int, 1>{});
+        PREP_MARK(9);
+        if (wave_in_wg * TPW < s_bcnt[1]) run_tasks(std::integral_constant<int, 2>{});
+        PREP_MARK(3);
+    } else if (!PREP) {
         run_tasks(std::integral_constant<int, 0>{});
     } else {
         // the half of every task that needs no search radius, while the first workgroups select the medians
@@ -1979,9 +2176,12 @@ using namespace dss;
 struct PrepLayout {
     size_t seg_count, vis_list, vis_keys, chunk_hist, seg_range, rs, alpha, tags, bytes;
     int chunks, per;  // segments, points per thread of the compaction kernel (segment = per * 1024 points)
-    int f_chunks, f_per;  // single-launch backward (fb_prep_segment): segments of f_per * 256 points, at most 64
+    int f_chunks, f_per;  // two-launch backward (fb_prep_segment): segments of f_per * 256 points, at most 64 (whole image:
+                          // the gather maps a task to its segment with one ballot over 64 lanes) or FB_MAX_SEG (row band: the
+                          // BAND variants search a table in LDS; at 8 x 32,684 points 64 segments of 4096 points kept a
+                          // quarter of the CUs busy for 22 us, 256 of 1024 take a quarter of that)
 };
-static PrepLayout prep_layout(int N, int64_t P, int S)
+static PrepLayout prep_layout(int N, int64_t P, int S, bool band = false)
 {
     PrepLayout L;
     const size_t n = N > 0 ? N : 1, p = P > 0 ? (size_t)P : 1;
@@ -1989,14 +2189,15 @@ static PrepLayout prep_layout(int N, int64_t P, int S)
     const size_t seg = (size_t)L.per * PREP_THREADS;
     L.chunks = (int)((p + seg - 1) / seg);
     L.f_per = 1;
-    while (L.f_per < 16 && (size_t)L.f_per * FB_THREADS * PREP_MAX_SEG < p) L.f_per *= 2;
+    const size_t f_max_seg = (band && p > (size_t)2 * FB_THREADS * PREP_MAX_SEG) ? FB_MAX_SEG : PREP_MAX_SEG;
+    while (L.f_per < 16 && (size_t)L.f_per * FB_THREADS * f_max_seg < p) L.f_per *= 2;
     L.f_chunks = (int)((p + (size_t)L.f_per * FB_THREADS - 1) / ((size_t)L.f_per * FB_THREADS));
     size_t off = 0;
-    L.seg_count = off;  off += 256;                                              // PREP_MAX_SEG counters
+    L.seg_count = off;  off += (size_t)FB_MAX_SEG * 4;                           // segment counters (any segmentation)
     L.vis_list = off;   off += align_up(p * 4, 256);
     L.vis_keys = off;   off += align_up(p * 8, 256);
-    L.chunk_hist = off; off += align_up(n * (size_t)PREP_MAX_SEG * 256 * 4, 256);   // (either segmentation: <= 64 segments)
-    L.seg_range = off;  off += align_up(n * (size_t)PREP_MAX_SEG * 8, 256);
+    L.chunk_hist = off; off += align_up(n * (size_t)FB_MAX_SEG * 256 * 4, 256);   // (any segmentation: <= FB_MAX_SEG segments)
+    L.seg_range = off;  off += align_up(n * (size_t)FB_MAX_SEG * 8, 256);
     L.tags = off;       off += align_up((size_t)FB_TAGS * 8, 256);   // rs tags of the fused gather launch
     L.rs = off;         off += align_up(n * 4, 256);
     L.alpha = off;      off += align_up(n * (size_t)(S > 0 ? S : 0) * (size_t)(S > 0 ? S : 0) * 4, 256);  // S = 0: none
@@ -2288,17 +2489,49 @@ static int render_backward_impl(bool run_prep, const float *grad_out, const int3
     // medians + gather), 5 = three (segments + alpha plane | medians | gather).
     int fused_opt = option(DSS_OPT_BACKWARD_FUSED);
     if (fused_opt == 0) fused_opt = DSS_BACKWARD_FUSED_DEFAULT;
+    // grid of a BAND variant (below): the resident capacity of the instantiation, cached per device in slots 10.. of the cache
+    auto band_grid = [&](int tpw_) -> unsigned {
+        const int slot = 10 + (C == 3 ? (cyc ? 3 : 0) : 6) + (tpw_ == 4 ? 2 : (tpw_ == 2 ? 1 : 0));
+        int fcap = (dc && slot < DSS_DEV_CACHE_SLOTS) ? dc[slot].load(std::memory_order_relaxed) : 0;
+        if (fcap == 0) {
+            int per_cu = 0;
+#define DSS_OCC_B(CC, TT, YY) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_backward_kernel<CC, true, TT, true, YY, true, true>, 256, 0)
+            if (C == 3 && cyc) { if (tpw_ == 4) DSS_OCC_B(3, 4, true); else if (tpw_ == 2) DSS_OCC_B(3, 2, true); else DSS_OCC_B(3, 1, true); }
+            else if (C == 3) { if (tpw_ == 4) DSS_OCC_B(3, 4, false); else if (tpw_ == 2) DSS_OCC_B(3, 2, false); else DSS_OCC_B(3, 1, false); }
+            else { if (tpw_ == 4) DSS_OCC_B(0, 4, false); else if (tpw_ == 2) DSS_OCC_B(0, 2, false); else DSS_OCC_B(0, 1, false); }
+#undef DSS_OCC_B
+            (void)hipGetLastError();
+            fcap = n_cus * (per_cu > 0 ? per_cu : 1);
+            if (dc && slot < DSS_DEV_CACHE_SLOTS) dc[slot].store(fcap, std::memory_order_relaxed);
+        }
+        unsigned g = pgrid;
+        if ((unsigned)fcap < g) g = (unsigned)fcap;
+        if (g < (unsigned)N + 8u) g = (unsigned)N + 8u;
+        return g;
+    };
     FusedPrep FP = FusedPrep();
     const int astride = 1;
-    bool fused = false;
+    bool fused = false, band = false;
     if (small) {
-        const PrepLayout L = prep_layout(N, P, S);
-        fused = (fused_opt == 4 || fused_opt == 5) && rows == S && !cyc && a32 && N <= 64 && (unsigned)N + 8u <= pgrid;
+        band = rows < S || cyc;
+        const PrepLayout L = prep_layout(N, P, S, band);
+        // row band (multi-GPU): the two-launch form with the band filter inside the gather launch (BAND variants: fused_opt 4,
+        // RGB or generic features on a contiguous band, RGB on a tile-row-cyclic one, every worker workgroup's share of the
+        // list within BAND_SHARE entries); anything else takes the round-3 sequence
+        fused = (fused_opt == 4 || fused_opt == 5) && a32 && N <= 64 && (unsigned)N + 8u <= pgrid &&
+                (!band || (fused_opt == 4 && (!cyc || C == 3) && world == nullptr));
         if (fused && fused_opt == 4 && !(tpw_opt == 1 || tpw_opt == 2 || tpw_opt == 4)) {
             // two-phase gather with its groups dealt per workgroup: two tasks per wavefront win as soon as there is about a
             // task per resident wavefront (32,684 points @512^2: 58.7 us per step against 60.5 with one, 59.3 with four)
-            tpw = est_tasks >= 16ll * cap * 4 ? 4 : (est_tasks >= 1ll * cap * 4 ? 2 : 1);
+            // (a band keeps about (rows + two search radii) / S of the visible points: estimated as 2 rows / S)
+            const long long est = band ? est_tasks * 2 * rows / S : est_tasks;
+            tpw = est >= 16ll * cap * 4 ? 4 : (est >= 1ll * cap * 4 ? 2 : 1);
+            // a tile-row-cyclic band owns at most eight consecutive rows of any window: many small tasks, one lane row each
+            // (8 ranks x 32,684 points: 101-105 us per rank and step with four tasks per wavefront, 110-114 with two)
+            if (cyc) tpw = 4;
         }
+        // (every worker workgroup of a BAND launch holds its share of the list in LDS)
+        if (fused && band && (long long)BAND_SHARE * ((long long)band_grid(tpw) - N) < (long long)P) fused = false;
         if (fused) {
             n_seg = L.f_chunks;
             seg_pts = L.f_per * FB_THREADS;
@@ -2375,6 +2608,7 @@ static int render_backward_impl(bool run_prep, const float *grad_out, const int3
         uint32_t *block_hist = reinterpret_cast<uint32_t *>(w + off);
         int32_t *unsorted = vis_list;
         vis_list = sorted;
+
         if (run_prep) {
         hipLaunchKernelGGL(alpha_plane_kernel, dim3((unsigned)((npix + ALPHA_PIX_PER_WG - 1) / ALPHA_PIX_PER_WG)), dim3(1024),
                            0, st, grad_out, plane, npix, C);
@@ -2389,14 +2623,17 @@ static int render_backward_impl(bool run_prep, const float *grad_out, const int3
         hipLaunchKernelGGL(median_final_kernel, dim3(N), dim3(MED_THREADS), 0, st, hist, N, radii_s, rs);
         const unsigned cb = (unsigned)cell_blocks(P);   // (the visible count is only known on the device: P bounds it)
         const size_t lds = (size_t)cg.total * 4;
+        const bool band_l = rows < S || cyc;   // row band: the entries that cannot reach it drop out of the sorted list
         hipLaunchKernelGGL(cell_hist_kernel, dim3(cb), dim3(CELL_THREADS), lds, st, points, first_idx, num_pts, N, S, cg,
-                           vis_count, unsorted, cell_of, block_hist);
+                           vis_count, unsorted, cell_of, block_hist, band_l ? radii : nullptr, rs, row0, rows, tshift, grad_pts,
+                           grad_feat, C);
         hipLaunchKernelGGL(cell_block_scan_kernel, dim3((unsigned)((cg.total + 255) / 256)), dim3(256), 0, st, vis_count,
                            cg.total, block_hist, cell_total);
-        hipLaunchKernelGGL(cell_scan_kernel, dim3(1), dim3(1024), 0, st, cell_total, cell_start, cg.total);
+        hipLaunchKernelGGL(cell_scan_kernel, dim3(1), dim3(1024), 0, st, cell_total, cell_start, cg.total, vis_count + 1);
         hipLaunchKernelGGL(cell_scatter_kernel, dim3(cb), dim3(CELL_THREADS), lds, st, cg, vis_count, unsorted, cell_of,
                            cell_start, block_hist, sorted);
         }
+        vis_count += 1;   // the gather walks the SORTED list: its length (written by cell_scan_kernel) is the second word
     }
     if (fused) {
         // the gather launch, with the preparation stages the mode puts inside it (run_prep false: the gather stage alone,
@@ -2405,6 +2642,20 @@ static int render_backward_impl(bool run_prep, const float *grad_out, const int3
         // (a late workgroup would start its two halves when the others end theirs): capacity per variant, cached in
         // slots 4.. of the device cache.
         unsigned fgrid = pgrid;
+        if (band) {
+            // BAND variants: medians always inside the launch (run_prep false only skips the segment launch: the keys of the
+            // preceding full call are still in the workspace), grid = resident capacity of the variant
+            fgrid = band_grid(tpw);
+#define DSS_LAUNCH_RB_B(CC, TT, YY)                                                                                         \
+    hipLaunchKernelGGL((render_backward_kernel<CC, true, TT, true, YY, true, true>), dim3(fgrid), dim3(256), 0, st, grad_out, alpha, idx, \
+                       qvalue, wsum, scaler, points, radii, rs, first_idx, num_pts, vis_count, vis_list, n_seg, seg_pts, N, S, K, C, \
+                       clip, row0, rows, large_waves, grad_feat, grad_pts, tshift, nullptr, nullptr, FP, astride)
+            if (C == 3 && cyc) { if (tpw == 4) DSS_LAUNCH_RB_B(3, 4, true); else if (tpw == 2) DSS_LAUNCH_RB_B(3, 2, true); else DSS_LAUNCH_RB_B(3, 1, true); }
+            else if (C == 3) { if (tpw == 4) DSS_LAUNCH_RB_B(3, 4, false); else if (tpw == 2) DSS_LAUNCH_RB_B(3, 2, false); else DSS_LAUNCH_RB_B(3, 1, false); }
+            else { if (tpw == 4) DSS_LAUNCH_RB_B(0, 4, false); else if (tpw == 2) DSS_LAUNCH_RB_B(0, 2, false); else DSS_LAUNCH_RB_B(0, 1, false); }
+#undef DSS_LAUNCH_RB_B
+            return check_launch("dss_render_backward");
+        }
         if (run_prep && fused_opt != 5) {
             const int slot = 4 + (C == 3 ? 0 : 3) + (tpw == 4 ? 2 : (tpw == 2 ? 1 : 0));
             int fcap = dc ? dc[slot].load(std::memory_order_relaxed) : 0;

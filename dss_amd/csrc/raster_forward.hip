@@ -287,6 +287,9 @@ __global__ __launch_bounds__(256) void bin_kernel(
 
 // dss_render_forward: per-point setup (culling + projection + EWA terms) fused with the binning --
 // the screen record goes from registers straight into the tile lists.
+// BAND_ONLY (DSS_WS_BAND_OUTPUTS, multi-GPU): a splat whose tile rectangle misses the rank's band writes its screen position,
+// radii and validity only (see setup_point_store); a kernel of its own so that the whole-image launch keeps its schedule.
+template <bool BAND_ONLY>
 __global__ __launch_bounds__(256) void setup_bin_kernel(const SetupArgs A, TileGrid g, uint32_t *__restrict__ counts,
                                                         int32_t *__restrict__ lists, uint32_t cap, TileQueue tq,
                                                         Spill sp, uint8_t *__restrict__ visible_to_clear)
@@ -299,7 +302,16 @@ __global__ __launch_bounds__(256) void setup_bin_kernel(const SetupArgs A, TileG
     const int n = find_cloud(p, A.first_idx, A.num_pts, A.N);
     FT_MARK_S(1);
     float px, py, pz, rx, ry;
-    setup_point(A, p, n, px, py, pz, rx, ry);
+    if (BAND_ONLY) {
+        const SetupVals v = setup_point_compute(A, p, n);
+        int tx0, tx1, ty0, ty1;
+        const bool reach = n >= 0 && splat_tile_rect(v.sx, v.sy, v.sz, v.rx, v.ry, g, tx0, tx1, ty0, ty1);
+        setup_point_store(A, p, v, reach);
+        if (!reach) return;
+        px = v.sx; py = v.sy; pz = v.sz; rx = v.rx; ry = v.ry;
+    } else {
+        setup_point(A, p, n, px, py, pz, rx, ry);
+    }
     FT_MARK_S(2);
     bin_point(p, n, px, py, pz, rx, ry, g, counts, lists, cap, tq, sp);
     FT_MARK_S(5);
@@ -316,9 +328,20 @@ __device__ __forceinline__ bool spill_pass(
     unsigned block, unsigned nblocks)
 {
     if (__builtin_amdgcn_readfirstlane((int)sp.ctrl[0]) == 0) return false;
-    for (int64_t p = (int64_t)block * blockDim.x + threadIdx.x; p < P; p += (int64_t)nblocks * blockDim.x) {
-    const unsigned full = sp.mask[p];
-    if (full == 0) continue;
+    // The mask bytes are scanned SIXTEEN per load (the array is 256-byte aligned and padded to 256 bytes with zeros).  One
+    // byte per thread and trip was a chain of P / (workgroups * 256) dependent loads -- 61 trips, ~120 us, at 8M splats on
+    // 512 workgroups: invisible inside the 0.75 ms fine launch of the whole image, but the tiles that wait for the pool
+    // (the sphere's limb) ended the launch, and on a row band of the multi-GPU step the pass was half of the fine launch.
+    const int64_t nvec = (P + 15) / 16;
+    for (int64_t v = (int64_t)block * blockDim.x + threadIdx.x; v < nvec; v += (int64_t)nblocks * blockDim.x) {
+    const uint4 m4 = reinterpret_cast<const uint4 *>(sp.mask)[v];
+    if ((m4.x | m4.y | m4.z | m4.w) == 0u) continue;
+#pragma unroll 1
+    for (int mb = 0; mb < 16; ++mb) {
+    const uint32_t mword = mb < 8 ? (mb < 4 ? m4.x : m4.y) : (mb < 12 ? m4.z : m4.w);   // (selects: no indexed register array)
+    const unsigned full = (mword >> (8 * (mb & 3))) & 0xffu;
+    const int64_t p = 16 * v + mb;
+    if (full == 0 || p >= P) continue;
     sp.mask[p] = 0;  // (this thread is the byte's only reader: the DSS_WS_CLEAN state is restored here)
     const int n = find_cloud(p, first_idx, num_pts, N);
     int tx0, tx1, ty0, ty1;
@@ -349,6 +372,7 @@ __device__ __forceinline__ bool spill_pass(
             if (off1 == 0) sp.fail[0] = sp.epoch;  // gave up: the fine pass falls back to whole-cloud scans
         }
         if (off1 != 0 && (unsigned long long)(off1 - 1u) + pos < sp.cap_entries) sp.pool[(size_t)(off1 - 1u) + pos] = (int32_t)p;
+    }
     }
     }
     return true;
@@ -432,15 +456,19 @@ __global__ __launch_bounds__(SORT_THREADS) void setup_cell_kernel(const SetupArg
                                                                    uint32_t *__restrict__ cell_of,
                                                                    uint32_t *__restrict__ block_hist, Spill sp,
                                                                    uint8_t *__restrict__ visible_to_clear,
-                                                                   float4 *__restrict__ geo)
+                                                                   float4 *__restrict__ geo, TileGrid g, int band_only)
 {
+    // band_only (DSS_WS_BAND_OUTPUTS, multi-GPU): splats whose tile rectangle misses the rank's band store their screen
+    // position, radii and validity only; MODE 0 leaves them out of the sort, MODE 2 marks them in the binning record (rx = -1,
+    // like a culled splat) -- every rank still evaluates every splat (the medians of the backward need all radii), but of the
+    // ~140 bytes a splat writes here seven eighths of the cloud keep 38
     extern __shared__ uint32_t s_hist[];
     if (sp.ctrl && blockIdx.x == 0 && threadIdx.x == 0) spill_begin(sp);
     if (MODE != 2) {
         for (int c = threadIdx.x; c < sg.total; c += SORT_THREADS) s_hist[c] = 0u;
         __syncthreads();
     }
-    const int64_t b0 = (int64_t)blockIdx.x * SORT_THREADS * per_thread;
+    const int64_t b0 = (int64_t)blockIdx.x * (MODE == 2 ? (int)blockDim.x : SORT_THREADS) * per_thread;
     if (MODE == 2) {
         // this kernel is nothing but streaming stores (~140 bytes per point): full wavefronts write them as contiguous runs
         // (setup_wave_store; the dynamic LDS of this instantiation is 4 KB per wavefront)
@@ -448,7 +476,7 @@ __global__ __launch_bounds__(SORT_THREADS) void setup_cell_kernel(const SetupArg
         const bool wide = setup_wide_ok(A);
 #pragma unroll 1
         for (int u = 0; u < per_thread; ++u) {
-            const int64_t p0 = b0 + (int64_t)u * SORT_THREADS + (threadIdx.x & ~63);   // first point of the wavefront
+            const int64_t p0 = b0 + (int64_t)u * blockDim.x + (threadIdx.x & ~63);   // first point of the wavefront
             if (p0 >= A.P) break;
             const int64_t p = p0 + (threadIdx.x & 63);
             const bool full = wide && p0 + 64 <= A.P;
@@ -456,6 +484,40 @@ __global__ __launch_bounds__(SORT_THREADS) void setup_cell_kernel(const SetupArg
             if (visible_to_clear) visible_to_clear[p] = 0;
             const int n = find_cloud(p, A.first_idx, A.num_pts, A.N);
             const SetupVals v = setup_point_compute(A, p, n);
+            if (band_only) {
+                int tx0, tx1, ty0, ty1;
+                const bool reach = n >= 0 && splat_tile_rect(v.sx, v.sy, v.sz, v.rx, v.ry, g, tx0, tx1, ty0, ty1);
+                if (full) {
+                    // what every point writes, as contiguous runs (the (P,3) positions transposed through LDS like
+                    // setup_wave_store); the rest per lane, for the lanes whose splat meets the band
+                    float *l1 = reinterpret_cast<float *>(wave_lds);
+                    const int lane = threadIdx.x & 63;
+                    __builtin_amdgcn_wave_barrier();
+                    l1[3 * lane] = v.sx; l1[3 * lane + 1] = v.sy; l1[3 * lane + 2] = v.sz;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane < 48) reinterpret_cast<float4 *>(A.screen + 3 * p0)[lane] = wave_lds[lane];
+                    __builtin_amdgcn_wave_barrier();
+                    reinterpret_cast<float2 *>(A.radii)[p] = make_float2(v.rx, v.ry);
+                    A.valid[p] = v.ok;
+                    if (reach) {
+                        A.ellipse[3 * p] = v.ea; A.ellipse[3 * p + 1] = v.eb; A.ellipse[3 * p + 2] = v.ec;
+                        A.scaler[p] = v.sc;
+                        A.cutoff[p] = A.cutoffC;
+                        if (A.rec) {
+                            float4 *R = A.rec + 4 * (size_t)p;
+                            R[0] = make_float4(v.sx, v.sy, v.rx, v.ry);
+                            R[1] = make_float4(v.ea, v.eb, v.ec, A.cutoffC);
+                            R[2] = make_float4(v.sc, v.fr0, v.fr1, v.fr2);
+                            R[3] = make_float4(v.sz, 0.0f, 0.0f, 0.0f);
+                        }
+                    }
+                } else {
+                    setup_point_store(A, p, v, reach);
+                }
+                geo[p] = make_float4(v.sx, v.sy, reach ? v.rx : -1.0f, v.ry);
+                continue;
+            }
             if (full) setup_wave_store(A, p0, v, wave_lds);
             else setup_point_store(A, p, v);
             const bool live = n >= 0 && !(v.sz < 0);   // culled splats (pz = -1) never reach a tile list
@@ -470,8 +532,18 @@ __global__ __launch_bounds__(SORT_THREADS) void setup_cell_kernel(const SetupArg
         if (visible_to_clear) visible_to_clear[p] = 0;
         const int n = find_cloud(p, A.first_idx, A.num_pts, A.N);
         float px, py, pz, rx, ry;
-        setup_point(A, p, n, px, py, pz, rx, ry);
-        const bool live = n >= 0 && !(pz < 0);   // culled splats (pz = -1) never reach a tile list
+        bool reach = true;
+        if (band_only) {
+            const SetupVals v = setup_point_compute(A, p, n);
+            int tx0, tx1, ty0, ty1;
+            reach = n >= 0 && splat_tile_rect(v.sx, v.sy, v.sz, v.rx, v.ry, g, tx0, tx1, ty0, ty1);
+            setup_point_store(A, p, v, reach);
+            px = v.sx; py = v.sy; pz = v.sz; rx = v.rx; ry = v.ry;
+        } else {
+            setup_point(A, p, n, px, py, pz, rx, ry);
+        }
+        // culled splats (pz = -1) never reach a tile list; band_only, MODE 0: neither do the splats that miss the band
+        const bool live = n >= 0 && !(pz < 0) && (MODE == 1 || reach);
         uint32_t key = SORT_NO_CELL;
         if (live) {
             // pixel column / row of the centre (any monotone map of NDC does: only neighbourhood matters); NaN -> cell 0
@@ -2132,10 +2204,12 @@ extern "C" int dss_render_forward(const float *world, const float *normals, cons
     const bool packed = C == 3 && !lean_workspace();  // the records carry three feature channels
     const int ws_flags = workspace_state & ~0xf;   // DSS_WS_ORDER_*
     workspace_state &= 0xf;
-    if ((unsigned)workspace_state > DSS_WS_BINNED || (ws_flags & ~(DSS_WS_ORDER_SAVE | DSS_WS_ORDER_REUSE))) {
+    if ((unsigned)workspace_state > DSS_WS_BINNED || (ws_flags & ~(DSS_WS_ORDER_SAVE | DSS_WS_ORDER_REUSE | DSS_WS_BAND_OUTPUTS))) {
         set_error("dss_render_forward: unknown workspace_state %d", workspace_state | ws_flags);
         return DSS_ERR_INVALID_ARGUMENT;
     }
+    // DSS_WS_BAND_OUTPUTS: only with a real row band (the whole image is reached by every splat that is rendered at all)
+    const int band_only = ((ws_flags & DSS_WS_BAND_OUTPUTS) && (g.rows < S || row_cycle > 1)) ? 1 : 0;
     const bool clean = workspace_state == DSS_WS_CLEAN;
     const bool rerun = workspace_state == DSS_WS_BINNED;  // lists + records of this very input are in place: fine pass only
     if (!clean && !rerun && hipMemsetAsync(w.counts, 0, w.count_bytes, st) != hipSuccess)
@@ -2167,17 +2241,21 @@ extern "C" int dss_render_forward(const float *world, const float *normals, cons
         const unsigned bin_wgs = (unsigned)((P + SORT_BIN_CHUNK - 1) / SORT_BIN_CHUNK);
         if (reuse_order) {
             // the point order an earlier call left in the workspace: setup in natural order + one gathered binning pass
-            hipLaunchKernelGGL(setup_cell_kernel<2>, dim3(sb), dim3(SORT_THREADS), (SORT_THREADS / 64) * 4096, st, SA, sg, per, w.sort_cell_of,
-                               w.sort_block_hist, w.spill, visible, w.sort_geo);
+            // (no histogram in this mode: 256-thread workgroups of four splats per thread -- a 1024-thread workgroup at ~100
+            // VGPRs is ONE resident workgroup per CU, 16 of its 20 wavefront slots, each walking 15 splats one after the other)
+            const int per2 = 4, tb2 = 256;
+            const unsigned sb2 = (unsigned)((P + (int64_t)per2 * tb2 - 1) / ((int64_t)per2 * tb2));
+            hipLaunchKernelGGL(setup_cell_kernel<2>, dim3(sb2), dim3(tb2), (tb2 / 64) * 4096, st, SA, sg, per2, w.sort_cell_of,
+                               w.sort_block_hist, w.spill, visible, w.sort_geo, g, band_only);
             hipLaunchKernelGGL(bin_sorted_kernel<true>, dim3(bin_wgs), dim3(SORT_BIN_THREADS), 0, st, w.sort_geo, w.sort_id,
                                w.sort_count, first_idx, num_pts, N, g, w.counts, w.lists, w.cap, w.queue, w.spill, (uint32_t)P);
         } else {
             if (save_order)
                 hipLaunchKernelGGL(setup_cell_kernel<1>, dim3(sb), dim3(SORT_THREADS), lds, st, SA, sg, per, w.sort_cell_of,
-                                   w.sort_block_hist, w.spill, visible, w.sort_geo);
+                                   w.sort_block_hist, w.spill, visible, w.sort_geo, g, band_only);
             else
                 hipLaunchKernelGGL(setup_cell_kernel<0>, dim3(sb), dim3(SORT_THREADS), lds, st, SA, sg, per, w.sort_cell_of,
-                                   w.sort_block_hist, w.spill, visible, w.sort_geo);
+                                   w.sort_block_hist, w.spill, visible, w.sort_geo, g, band_only);
             const unsigned nseg = (sb + SORT_SEG - 1) / SORT_SEG;
             hipLaunchKernelGGL(sort_block_scan_kernel, dim3((unsigned)((sg.total + 255) / 256), nseg), dim3(256), 0, st, sb,
                                sg.total, w.sort_block_hist, w.sort_seg_tot);
@@ -2193,8 +2271,12 @@ extern "C" int dss_render_forward(const float *world, const float *normals, cons
         hipLaunchKernelGGL(queue_build_kernel, dim3((unsigned)((N * tiles + 1023) / 1024)), dim3(1024), 0, st, w.counts,
                            N * tiles, g, w.queue);
     } else if (!rerun) {
-        hipLaunchKernelGGL(setup_bin_kernel, dim3(pb), dim3(tb), 0, st, SA, g, w.counts, w.lists, w.cap, w.queue, w.spill,
-                           visible);
+        if (band_only)
+            hipLaunchKernelGGL(setup_bin_kernel<true>, dim3(pb), dim3(tb), 0, st, SA, g, w.counts, w.lists, w.cap, w.queue, w.spill,
+                               visible);
+        else
+            hipLaunchKernelGGL(setup_bin_kernel<false>, dim3(pb), dim3(tb), 0, st, SA, g, w.counts, w.lists, w.cap, w.queue,
+                               w.spill, visible);
     }
     FineArgs A;
     A.points = pts_screen; A.ellipse = ellipse; A.cutoff = cutoff; A.radii = radii;

@@ -30,51 +30,86 @@ __global__ __launch_bounds__(256) void point_setup_kernel(const SetupArgs A)
 //   d ndc_x / d world = (M[:3,0] - ndc_x M[:3,3]) / w   (same for y),   d z / d world = V[:3,2]
 // One thread per WORLD point; for a shared cloud the N cameras are summed in a fixed order
 // (deterministic, no atomics).
+// One thread per WORLD point; a cloud shared by the N cameras sums their contributions in camera order.  The per-camera
+// inputs (valid flag, screen gradient, optionally the feature gradient) of up to eight cameras are requested together before
+// any of them is used: as a loop of dependent loads with `continue` branches the eight-camera step of the multi-GPU bench
+// spent 12.7 us here (one memory round trip per camera).  `grad_feat` != NULL also reduces the per-camera feature gradients
+// (N Pw, C) of a shared cloud to the cloud's (Pw, C) -- the `grad.view(N, Pw, C).sum(0)` every caller of a shared cloud
+// otherwise runs as a launch of its own.
 __global__ __launch_bounds__(256) void project_backward_kernel(
     const float *__restrict__ world, const float *__restrict__ M, const float *__restrict__ V,
     const int64_t *__restrict__ first_idx, const int64_t *__restrict__ num_pts, int N, int64_t Pw, int shared,
     const float *__restrict__ grad_screen, const uint8_t *__restrict__ valid, float clip,
-    float *__restrict__ grad_world)
+    float *__restrict__ grad_world, const float *__restrict__ grad_feat, int C, float *__restrict__ grad_feat_world)
 {
     const int64_t wi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (wi >= Pw) return;
     const float x = world[3 * wi], y = world[3 * wi + 1], z = world[3 * wi + 2];
     float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+    float fs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // feature-gradient sums (C <= 8)
     const int n_lo = shared ? 0 : find_cloud(wi, first_idx, num_pts, N);
     const int n_hi = shared ? N : n_lo + 1;
-    for (int n = max(n_lo, 0); n < n_hi && n_lo >= 0; ++n) {
-        int64_t p = wi;
-        if (shared) {
-            if (wi >= num_pts[n]) continue;
-            p = first_idx[n] + wi;
-        }
-        if (!valid[p]) continue;
-        const float *m = M + 16 * n;
-        const float *v = V + 16 * n;
-        const float cx = x * m[0] + y * m[4] + z * m[8] + m[12];
-        const float cy = x * m[1] + y * m[5] + z * m[9] + m[13];
-        const float w = x * m[3] + y * m[7] + z * m[11] + m[15];
-        const float iw = 1.0f / w;
-        const float nx = cx * iw, ny = cy * iw;
-        float gx = grad_screen[3 * p], gy = grad_screen[3 * p + 1], gz = grad_screen[3 * p + 2];
-        if (clip > 0.0f) {  // the per-point norm clip hook (rasterizer.py:667-673), same arithmetic as clip_grad_kernel
-            const float nrm = sqrtf(gx * gx + gy * gy + gz * gz);
-            const float sc = fminf(nrm, clip), den = fmaxf(nrm, 1e-12f);
-            gx = gx / den * sc;
-            gy = gy / den * sc;
-            gz = gz / den * sc;
+    constexpr int NB = 8;
+    for (int nb = max(n_lo, 0); nb < n_hi && n_lo >= 0; nb += NB) {
+        int64_t pp[NB];
+        bool on[NB];
+        uint8_t vl[NB];
+        float gs[NB][3];
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int n = nb + u;
+            on[u] = n < n_hi;
+            pp[u] = wi;
+            if (on[u] && shared) {
+                on[u] = wi < num_pts[n];
+                pp[u] = first_idx[n] + wi;
+            }
+            if (!on[u]) pp[u] = wi;   // (a valid address: masked below)
         }
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const float jx = (m[i * 4 + 0] - nx * m[i * 4 + 3]) * iw;
-            const float jy = (m[i * 4 + 1] - ny * m[i * 4 + 3]) * iw;
-            const float t = jx * gx + jy * gy + v[i * 4 + 2] * gz;
-            if (i == 0) g0 += t;
-            else if (i == 1) g1 += t;
-            else g2 += t;
+        for (int u = 0; u < NB; ++u) {
+            vl[u] = valid[pp[u]];
+            gs[u][0] = grad_screen[3 * pp[u]]; gs[u][1] = grad_screen[3 * pp[u] + 1]; gs[u][2] = grad_screen[3 * pp[u] + 2];
+        }
+        if (grad_feat) {
+#pragma unroll
+            for (int u = 0; u < NB; ++u)
+                if (on[u])
+                    for (int ch = 0; ch < C; ++ch) fs[ch] += grad_feat[(size_t)pp[u] * C + ch];
+        }
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            if (!on[u] || !vl[u]) continue;
+            const int n = nb + u;
+            const float *m = M + 16 * n;
+            const float *v = V + 16 * n;
+            const float cx = x * m[0] + y * m[4] + z * m[8] + m[12];
+            const float cy = x * m[1] + y * m[5] + z * m[9] + m[13];
+            const float w = x * m[3] + y * m[7] + z * m[11] + m[15];
+            const float iw = 1.0f / w;
+            const float nx = cx * iw, ny = cy * iw;
+            float gx = gs[u][0], gy = gs[u][1], gz = gs[u][2];
+            if (clip > 0.0f) {  // the per-point norm clip hook (rasterizer.py:667-673), same arithmetic as clip_grad_kernel
+                const float nrm = sqrtf(gx * gx + gy * gy + gz * gz);
+                const float sc = fminf(nrm, clip), den = fmaxf(nrm, 1e-12f);
+                gx = gx / den * sc;
+                gy = gy / den * sc;
+                gz = gz / den * sc;
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const float jx = (m[i * 4 + 0] - nx * m[i * 4 + 3]) * iw;
+                const float jy = (m[i * 4 + 1] - ny * m[i * 4 + 3]) * iw;
+                const float t = jx * gx + jy * gy + v[i * 4 + 2] * gz;
+                if (i == 0) g0 += t;
+                else if (i == 1) g1 += t;
+                else g2 += t;
+            }
         }
     }
     grad_world[3 * wi] = g0; grad_world[3 * wi + 1] = g1; grad_world[3 * wi + 2] = g2;
+    if (grad_feat)
+        for (int ch = 0; ch < C; ++ch) grad_feat_world[(size_t)wi * C + ch] = fs[ch];
 }
 
 // PCA frames of the K-neighbourhoods -> anisotropic source variance (rasterizer.py:256-291, mathHelper.py:34-92):
@@ -223,18 +258,41 @@ extern "C" int dss_point_setup(const float *world, const float *normals, const f
     return check_launch("dss_point_setup");
 }
 
+static int project_backward_impl(const char *fn, const float *world, const float *M, const float *V, const int64_t *first_idx,
+                                 const int64_t *num_pts, int N, int64_t Pw, int shared_cloud, const float *grad_screen,
+                                 const uint8_t *valid, float clip, float *grad_world, const float *grad_feat, int C,
+                                 float *grad_feat_world, void *stream)
+{
+    if (N <= 0 || Pw < 0) { set_error("%s: bad sizes", fn); return DSS_ERR_INVALID_ARGUMENT; }
+    if (Pw == 0) return DSS_OK;
+    if (!world || !M || !V || !first_idx || !num_pts || !grad_screen || !valid || !grad_world) {
+        set_error("%s: NULL tensor pointer", fn);
+        return DSS_ERR_INVALID_ARGUMENT;
+    }
+    if (grad_feat && (!grad_feat_world || C < 1 || C > 8)) {
+        set_error("%s: the feature-gradient reduction needs an output and 1 <= C <= 8 (C = %d)", fn, C);
+        return DSS_ERR_INVALID_ARGUMENT;
+    }
+    hipLaunchKernelGGL(project_backward_kernel, dim3((unsigned)((Pw + 255) / 256)), dim3(256), 0, as_stream(stream),
+                       world, M, V, first_idx, num_pts, N, Pw, shared_cloud, grad_screen, valid, clip, grad_world, grad_feat, C,
+                       grad_feat_world);
+    return check_launch(fn);
+}
+
 extern "C" int dss_project_backward(const float *world, const float *M, const float *V, const int64_t *first_idx,
                                     const int64_t *num_pts, int N, int64_t Pw, int shared_cloud,
                                     const float *grad_screen, const uint8_t *valid, float clip, float *grad_world,
                                     void *stream)
 {
-    if (N <= 0 || Pw < 0) { set_error("dss_project_backward: bad sizes"); return DSS_ERR_INVALID_ARGUMENT; }
-    if (Pw == 0) return DSS_OK;
-    if (!world || !M || !V || !first_idx || !num_pts || !grad_screen || !valid || !grad_world) {
-        set_error("dss_project_backward: NULL tensor pointer");
-        return DSS_ERR_INVALID_ARGUMENT;
-    }
-    hipLaunchKernelGGL(project_backward_kernel, dim3((unsigned)((Pw + 255) / 256)), dim3(256), 0, as_stream(stream),
-                       world, M, V, first_idx, num_pts, N, Pw, shared_cloud, grad_screen, valid, clip, grad_world);
-    return check_launch("dss_project_backward");
+    return project_backward_impl("dss_project_backward", world, M, V, first_idx, num_pts, N, Pw, shared_cloud, grad_screen, valid,
+                                 clip, grad_world, nullptr, 0, nullptr, stream);
+}
+
+extern "C" int dss_project_backward_features(const float *world, const float *M, const float *V, const int64_t *first_idx,
+                                             const int64_t *num_pts, int N, int64_t Pw, int shared_cloud,
+                                             const float *grad_screen, const uint8_t *valid, float clip, float *grad_world,
+                                             const float *grad_feat, int C, float *grad_feat_world, void *stream)
+{
+    return project_backward_impl("dss_project_backward_features", world, M, V, first_idx, num_pts, N, Pw, shared_cloud, grad_screen,
+                                 valid, clip, grad_world, grad_feat, C, grad_feat_world, stream);
 }

@@ -138,15 +138,18 @@ __device__ __forceinline__ SetupVals setup_point_compute(const SetupArgs &A, int
     return v;
 }
 
-// one thread writes the outputs of its point
-__device__ __forceinline__ void setup_point_store(const SetupArgs &A, int64_t p, const SetupVals &v)
+// one thread writes the outputs of its point.  full = false (DSS_WS_BAND_OUTPUTS, a splat that cannot reach the rank's row
+// band): only what the backward of OTHER bands' visible points needs -- screen position, radii, validity; the ellipse, the
+// scaler, the cutoff and the packed record (84 of the ~105 bytes a point writes) are read for binned splats only.
+__device__ __forceinline__ void setup_point_store(const SetupArgs &A, int64_t p, const SetupVals &v, bool full = true)
 {
     A.screen[3 * p] = v.sx; A.screen[3 * p + 1] = v.sy; A.screen[3 * p + 2] = v.sz;
-    A.ellipse[3 * p] = v.ea; A.ellipse[3 * p + 1] = v.eb; A.ellipse[3 * p + 2] = v.ec;
     A.radii[2 * p] = v.rx; A.radii[2 * p + 1] = v.ry;
+    A.valid[p] = v.ok;
+    if (!full) return;
+    A.ellipse[3 * p] = v.ea; A.ellipse[3 * p + 1] = v.eb; A.ellipse[3 * p + 2] = v.ec;
     A.scaler[p] = v.sc;
     A.cutoff[p] = A.cutoffC;
-    A.valid[p] = v.ok;
     if (A.rec) {
         float4 *R = A.rec + 4 * (size_t)p;
         R[0] = make_float4(v.sx, v.sy, v.rx, v.ry);

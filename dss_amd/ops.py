@@ -456,7 +456,7 @@ def render_forward(world, normals, h, M, V, znear, zfar, cloud_to_packed_first_i
                    antialiasing_sigma: float = 1.0, backface_culling: bool = False, shared_cloud: bool = False,
                    rows: Optional[Tuple[int, int]] = None, out_image: Optional[torch.Tensor] = None,
                    out_visible: Optional[torch.Tensor] = None, vr6=None, frame_normals=None, want_zbuf: bool = True,
-                   workspace_state: int = 1, order_refresh: int = 0):
+                   workspace_state: int = 1, order_refresh: int = 0, band_outputs_only: bool = False):
     """Fused forward (setup + binning + fine + blend, ``dss_render_forward``).  ``out_image`` (float32
     (N,rows,S,C+1), 16-byte aligned) / ``out_visible`` (uint8 (P,)) let the caller place these two outputs
     in its own buffer (the multi-GPU step points them into one all-gather send buffer).  ``features`` are the
@@ -468,7 +468,10 @@ def render_forward(world, normals, h, M, V, znear, zfar, cloud_to_packed_first_i
     the fine + blend launch; profiling / timing of the dominant kernel).
     ``order_refresh`` = k > 0: renderer-owned cached point order (DSS_WS_ORDER_SAVE / DSS_WS_ORDER_REUSE, above 2M points):
     the screen-cell order that the binning sorts the points into is kept in the workspace of this problem size and reused by
-    the next k - 1 calls on it, which then skip the sort (same outputs bit for bit; a stale order only costs locality)."""
+    the next k - 1 calls on it, which then skip the sort (same outputs bit for bit; a stale order only costs locality).
+    ``band_outputs_only`` (DSS_WS_BAND_OUTPUTS; with ``rows`` only): ``ellipse_params``, ``scaler`` and ``cutoff_threshold`` are
+    written for the splats that meet the band only (undefined elsewhere); everything else is unchanged -- what a multi-GPU
+    rank asks for: it needs every point's position and radii for the backward, but bins an eighth of the cloud."""
     lib = _lib.load()
     world = _lib.require_gpu(world, "world", _f32)
     dev = world.device
@@ -521,6 +524,8 @@ def render_forward(world, normals, h, M, V, znear, zfar, cloud_to_packed_first_i
         tag = ("render_forward" if (int(workspace_state) & 0xf) == 1 else "render_forward_binned", N, P, S)
         ws = _lib.clean_workspace(dev, tag, lib.dss_render_forward_workspace(N, P, S, K))
         state = _order_state(ws, int(workspace_state), (N, P, S), order_refresh)
+        if band_outputs_only and (int(workspace_state) & 0xf) != 2:
+            state |= _lib.WS_BAND_OUTPUTS
         rc = lib.dss_render_forward(
             _lib.ptr(world), _lib.ptr(normals), _lib.ptr(h) if per_point else None, None if per_point else _lib.ptr(h),
             vr_p, fn_p, _lib.ptr(M), _lib.ptr(V), _lib.ptr(znear), _lib.ptr(zfar), _lib.ptr(first), _lib.ptr(num), N, P,
@@ -675,14 +680,18 @@ class FusedPlan:
         n, shape = self.layout["image"][1], self.layout["image"][3]
         return arena[:n].view(_f32).view(shape)
 
-    def forward(self, world, normals, h, M, V, znear, zfar, first, num, feats, vr6=None, frame_n=None):
-        """-> arena (uint8): every output of dss_render_forward at its offset (see `view`)."""
+    def forward(self, world, normals, h, M, V, znear, zfar, first, num, feats, vr6=None, frame_n=None, ws=None):
+        """-> arena (uint8): every output of dss_render_forward at its offset (see `view`).  `ws`: a caller-owned forward
+        workspace under the DSS_WS_CLEAN contract (zero-filled once, `fwd_ws_bytes` long) instead of the cached per-stream
+        one -- a captured graph bakes the workspace address into its launches and must own the buffer."""
         lib, dev, o = self.lib, self.dev, self._o
         N, P, S, K, C = self.N, self.P, self.S, self.K, self.C
         shared, backface, _, _, cutoff, sigma, thr = self.consts
+        own_ws = ws is not None
         with _on_device(dev):
             arena = torch.empty(self.total, dtype=_u8, device=dev)
-            ws = _lib.clean_workspace(dev, self.tag, self.fwd_ws_bytes)
+            if not own_ws:
+                ws = _lib.clean_workspace(dev, self.tag, self.fwd_ws_bytes)
             b = arena.data_ptr()
             hp = h.data_ptr()
             rc = lib.dss_render_forward(
@@ -696,13 +705,16 @@ class FusedPlan:
                 self.force_state if self.force_state is not None else _order_state(ws, 1, (N, P, S), self.order_refresh),
                 torch.cuda.current_stream(dev).cuda_stream)
             if rc:
-                _lib.drop_clean_workspace(dev, self.tag)
+                if own_ws:
+                    ws.zero_()   # (a failed call may leave counters behind: restore the contract's state)
+                else:
+                    _lib.drop_clean_workspace(dev, self.tag)
         _lib.check(rc, "dss_render_forward")
         return arena
 
-    def backward(self, arena, g_image, first, num, radii_s, clip, world=None, M=None):
+    def backward(self, arena, g_image, first, num, radii_s, clip, world=None, M=None, ws=None):
         """-> (grad_features (P,C), grad_pts (P,3)) -- world-space position gradients when (world, M) are given (fused
-        projection, see render_backward)."""
+        projection, see render_backward).  `ws`: a caller-owned backward workspace (`bwd_ws_bytes`), see `forward`."""
         lib, dev, o = self.lib, self.dev, self._o
         N, P, S, K, C = self.N, self.P, self.S, self.K, self.C
         with _on_device(dev):
@@ -713,7 +725,8 @@ class FusedPlan:
                 gf = torch.empty((P, C), dtype=_f32, device=dev)
                 gp = torch.empty((P, 3), dtype=_f32, device=dev)
             rs = torch.empty((N,), dtype=_f32, device=dev)
-            ws = _lib.workspace(dev, self.bwd_ws_bytes)
+            if ws is None:
+                ws = _lib.workspace(dev, self.bwd_ws_bytes)
             b = arena.data_ptr()
             rc = lib.dss_render_backward(
                 g_image.data_ptr(), b + o["idx"], b + o["qvalue"], b + o["wsum"], b + o["scaler"], b + o["pts_screen"],
@@ -809,9 +822,11 @@ def point_setup(world, normals, h, M, V, znear, zfar, cloud_to_packed_first_idx,
 
 
 def project_backward(world, M, V, cloud_to_packed_first_idx, num_points_per_cloud, grad_screen, valid,
-                     shared_cloud: bool = False, clip: float = -1.0):
+                     shared_cloud: bool = False, clip: float = -1.0, grad_features=None):
     """grad of (NDC x, NDC y, view z) w.r.t. the world points -> (Pw,3).  ``clip > 0`` applies the per-point norm
-    clip of ``clip_grad_`` to ``grad_screen`` on the fly (multi-GPU: the clip comes after the all-reduce)."""
+    clip of ``clip_grad_`` to ``grad_screen`` on the fly (multi-GPU: the clip comes after the all-reduce).
+    ``grad_features`` (P,C): also sums the per-camera feature gradients of a shared cloud over its cameras in the same
+    launch (``dss_project_backward_features``) -> (grad_world (Pw,3), grad_features_world (Pw,C))."""
     lib = _lib.load()
     world = _lib.require_gpu(world, "world", _f32)
     dev = world.device
@@ -824,6 +839,18 @@ def project_backward(world, M, V, cloud_to_packed_first_idx, num_points_per_clou
     N, Pw = first.shape[0], world.shape[0]
     with torch.cuda.device(dev):
         gw = torch.empty((Pw, 3), dtype=_f32, device=dev)
+        if grad_features is not None:
+            gfeat = _lib.require_gpu(grad_features, "grad_features", _f32)
+            P = N * Pw if shared_cloud else Pw
+            if gfeat.dim() != 2 or gfeat.shape[0] != P:
+                raise RuntimeError("grad_features must be packed (P,C) with P=%d, got %s" % (P, tuple(gfeat.shape)))
+            C = gfeat.shape[1]
+            gfw = torch.empty((Pw, C), dtype=_f32, device=dev)
+            rc = lib.dss_project_backward_features(_lib.ptr(world), _lib.ptr(M), _lib.ptr(V), _lib.ptr(first), _lib.ptr(num), N,
+                                                   Pw, int(shared_cloud), _lib.ptr(grad_screen), _lib.ptr(vis), float(clip),
+                                                   _lib.ptr(gw), _lib.ptr(gfeat), C, _lib.ptr(gfw), _lib.stream_ptr(dev))
+            _lib.check(rc, "dss_project_backward_features")
+            return gw, gfw
         rc = lib.dss_project_backward(_lib.ptr(world), _lib.ptr(M), _lib.ptr(V), _lib.ptr(first), _lib.ptr(num), N,
                                       Pw, int(shared_cloud), _lib.ptr(grad_screen), _lib.ptr(vis), float(clip),
                                       _lib.ptr(gw), _lib.stream_ptr(dev))

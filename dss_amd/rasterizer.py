@@ -219,6 +219,28 @@ class _ProjectAndSetup(autograd.Function):
         return (gw,) + (None,) * 15
 
 
+_CAMERA_FIELDS = ("R", "T", "znear", "zfar", "fov", "aspect_ratio")
+
+
+def _camera_state(cameras):
+    """(name, object, version) of every camera field the projection depends on -- the key `_prepare` memoises on.  A field
+    re-assigned to a fresh tensor changes identity, one modified in place changes version (a fresh tensor's version is 0
+    again, so the version alone is no key; the tuple keeps the objects alive, so an id cannot be recycled either)."""
+    return tuple((n, getattr(cameras, n, None), getattr(getattr(cameras, n, None), "_version", 0)) for n in _CAMERA_FIELDS)
+
+
+def _kw_state(v):
+    """memo key of a znear / zfar keyword: identity + version of a tensor, the value of a number, None"""
+    if v is None:
+        return None
+    if torch.is_tensor(v):
+        return (id(v), v._version)
+    try:
+        return ("v", float(v))
+    except (TypeError, ValueError):
+        return ("id", id(v))
+
+
 def knn_variance_scale(point_clouds, K: int = 7) -> torch.Tensor:
     """Per-point 0.5 * (K-th smallest squared distance to the own cloud, self included), packed (P,)
     = ``0.5 * knn(...)[:, :, 1:].max(-1)`` of rasterizer.py:310-321 / 366-383, computed by the HIP grid
@@ -323,7 +345,7 @@ class SurfaceSplatting(torch.nn.Module):
             memo_key = (id(cameras), tuple(id(t) for t in cam_state), tuple(getattr(t, "_version", 0) for t in cam_state),
                         tuple(id(t) for t in pl), None if nl is None else tuple(id(t) for t in nl),
                         tuple(t.shape[0] for t in pl), id(h_given), h_given._version, id(raster_settings),
-                        kwargs.get("znear", None) is None, kwargs.get("zfar", None) is None)
+                        _kw_state(kwargs.get("znear", None)), _kw_state(kwargs.get("zfar", None)))
             hit = getattr(self, "_prepare_memo", None)
             if hit is not None and hit[0] == memo_key:
                 a = dict(hit[1])
@@ -376,9 +398,11 @@ class SurfaceSplatting(torch.nn.Module):
         a = dict(N=N, shared=shared, world=world, normals=normals, h=h.to(dev, torch.float32), M=M, V=V,
                  znear=as_n("znear", 1.0), zfar=as_n("zfar", 100.0), first_idx=first_idx, num_points=num_points,
                  out_clouds=out_clouds, raster_settings=raster_settings, vr6=vr6, frame_n=frame_n)
-        if memo_key is not None:
+        if memo_key is not None and world is pl[0] and normals is nl[0]:
+            # (only when the packed tensors ARE the caller's tensors: a duck-typed cloud whose points_packed() is a copy --
+            # pytorch3d's torch.cat -- would otherwise be served a stale copy after an in-place optimiser step)
             # (the memo keeps the keyed objects alive -- an id cannot be recycled while it is the current entry)
-            keep = (cameras, cam_state, pl, nl, h_given, raster_settings)
+            keep = (cameras, cam_state, pl, nl, h_given, raster_settings, kwargs.get("znear", None), kwargs.get("zfar", None))
             self._prepare_memo = (memo_key, {k: v for k, v in a.items() if k not in ("out_clouds", "raster_settings")}, keep)
         return a
 
@@ -552,7 +576,7 @@ class SurfaceSplatting(torch.nn.Module):
                         and kwargs.get("Vrk_h", None) is k[3] and kwargs.get("cameras", self.cameras) is k[4] \
                         and kwargs.get("raster_settings", self.raster_settings) is k[5] and k[3]._version == k[6] \
                         and pl[0].data_ptr() == G.ptrs[0][0] and fl[0].data_ptr() == G.ptrs[9][0] \
-                        and k[7] == tuple(getattr(k[4], n)._version for n in ("R", "T")) \
+                        and all(getattr(k[4], n, None) is t and getattr(t, "_version", 0) == v for n, t, v in k[7]) \
                         and k[8] == tuple(getattr(k[5], n, None) for n in PointsRasterizationSettings.__slots__):
                     return _RenderFusedGraphed.apply(pl[0], fl[0], G), None, point_clouds
         if not point_clouds.isempty():
@@ -590,7 +614,7 @@ class SurfaceSplatting(torch.nn.Module):
             if len(pl) == 1 and a["N"] == 1 and h_given is not None and nl is not None and fl is not None \
                     and pl[0] is a["world"] and fl[0] is feats and hasattr(cams, "R") and hasattr(cams, "T"):
                 G.call_key = (pl[0], nl[0], fl[0], h_given, cams, st, h_given._version,
-                              tuple(getattr(cams, n)._version for n in ("R", "T")),
+                              _camera_state(cams),
                               tuple(getattr(st, n, None) for n in PointsRasterizationSettings.__slots__))   # (settings mutate in place)
             image = _RenderFusedGraphed.apply(a["world"], feats, G)
             arena = G.arena
@@ -639,23 +663,29 @@ class _GraphedRender:
         self.ptrs = self.signature(inputs)
         world, normals, h, M, V, znear, zfar, first, num, feats, vr6, frame_n = inputs
         dev = world.device
-        side = torch.cuda.Stream(device=dev)
+        # The graphs bake the addresses of both workspaces into their launches: they are PRIVATE to this object (the cached
+        # per-stream buffers of _lib are evicted / regrown by eager calls, and the capture stream's handle -- their cache key --
+        # returns to PyTorch's stream pool), allocated outside the capture and alive as long as the graphs are.
+        self.side = side = torch.cuda.Stream(device=dev)
+        self.fwd_ws = torch.zeros(int(plan.fwd_ws_bytes), dtype=torch.uint8, device=dev)            # DSS_WS_CLEAN: zero-filled once
+        self.bwd_ws = torch.empty(max(int(plan.bwd_ws_bytes), 256), dtype=torch.uint8, device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.no_grad(), torch.cuda.stream(side):
-            for _ in range(2):   # warm-up on the capture stream (its clean workspace is created and zeroed here)
-                arena = plan.forward(world, normals, h, M, V, znear, zfar, first, num, feats, vr6, frame_n)
+            for _ in range(2):   # warm-up on the capture stream
+                arena = plan.forward(world, normals, h, M, V, znear, zfar, first, num, feats, vr6, frame_n, ws=self.fwd_ws)
             self.g_static = torch.zeros(plan.layout["image"][3], dtype=torch.float32, device=dev)
             fuse = self._fuse(world)
-            plan.backward(arena, self.g_static, first, num, radii_s, clip, world if fuse else None, M if fuse else None)
+            plan.backward(arena, self.g_static, first, num, radii_s, clip, world if fuse else None, M if fuse else None,
+                          ws=self.bwd_ws)
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         self.graph_f = torch.cuda.CUDAGraph()
         with torch.no_grad(), torch.cuda.graph(self.graph_f, stream=side):
-            self.arena = plan.forward(world, normals, h, M, V, znear, zfar, first, num, feats, vr6, frame_n)
+            self.arena = plan.forward(world, normals, h, M, V, znear, zfar, first, num, feats, vr6, frame_n, ws=self.fwd_ws)
         self.graph_b = torch.cuda.CUDAGraph()
         with torch.no_grad(), torch.cuda.graph(self.graph_b, stream=side):
             g_feat, g_pts = plan.backward(self.arena, self.g_static, first, num, radii_s, clip, world if fuse else None,
-                                          M if fuse else None)
+                                          M if fuse else None, ws=self.bwd_ws)
             if not fuse:
                 g_pts = ops.project_backward(world, M, V, first, num, g_pts, plan.view(self.arena, "valid").view(torch.bool), shared)
             self.g_feat, self.g_world = g_feat, g_pts

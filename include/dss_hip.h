@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define DSS_HIP_VERSION 101
+#define DSS_HIP_VERSION 102
 
 #if defined(__GNUC__)
 #define DSS_API __attribute__((visibility("default")))
@@ -287,6 +287,17 @@ DSS_API int dss_blend_backward_scatter(const float *grad_out, const int32_t *idx
  * a stale order only costs locality.  Both flags are ignored where the direct binning runs (P <= 2,000,000). */
 #define DSS_WS_ORDER_SAVE 0x10
 #define DSS_WS_ORDER_REUSE 0x20
+/* Multi-GPU row bands (flag, OR-ed into workspace_state; ignored for the whole image): every rank evaluates the setup of
+ * every splat -- the backward needs the screen position and the radii of the points that are visible in OTHER ranks' bands
+ * (median search radius, windows that reach across a band boundary) --, but only the splats whose pixel rectangle meets the
+ * rank's own rows are binned, so only those have their ellipse, scaler and cutoff read again.
+ *   DSS_WS_BAND_OUTPUTS  pts_screen, radii and valid are written for every point; ellipse, scaler and cutoff only for the
+ *                        splats that meet the band (the rest of those three arrays keeps whatever the buffers held), and the
+ *                        other splats are left out of the call's sort / marked in its binning records.  The fragments, the
+ *                        image and the visibility flags are the same bits; dss_render_backward on the same band reads the
+ *                        scaler of a point only where the point has a fragment.  (The reference has no counterpart: it
+ *                        materialises every per-point tensor in PyTorch, rasterizer.py:525-565.) */
+#define DSS_WS_BAND_OUTPUTS 0x40
 DSS_API size_t dss_render_forward_workspace(int N, int64_t P, int S, int K);
 DSS_API int dss_render_forward(const float *world, const float *normals, const float *h_point,
                                const float *h_cloud, const float *vr6, const float *frame_normals,
@@ -387,6 +398,17 @@ DSS_API int dss_project_backward(const float *world, const float *M, const float
                                  const uint8_t *valid /* (P,) */,
                                  float clip /* > 0: apply the per-point norm clip of dss_clip_grad first */,
                                  float *grad_world /* (Pw,3) */, void *stream);
+
+/* dss_project_backward that also reduces the per-camera feature gradients of a cloud shared by the N cameras
+ * (Pointclouds.extend(N), rasterizer.py:236-240: the renderer's grad_feat is (N Pw, C), the model's colours are (Pw, C)):
+ * grad_feat_world[i][ch] = sum over the cameras n of grad_feat[first_idx[n] + i][ch], in camera order -- what autograd does
+ * for the extended cloud's features, here in the launch that already visits every (camera, point).  1 <= C <= 8;
+ * grad_feat == NULL: exactly dss_project_backward. */
+DSS_API int dss_project_backward_features(const float *world, const float *M, const float *V,
+                                          const int64_t *first_idx, const int64_t *num_pts, int N, int64_t Pw,
+                                          int shared_cloud, const float *grad_screen, const uint8_t *valid, float clip,
+                                          float *grad_world, const float *grad_feat /* (P,C) */, int C,
+                                          float *grad_feat_world /* (Pw,C) */, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * kNN statistic behind the source-space variance scale h (rasterizer.py:310-326, 366-388):

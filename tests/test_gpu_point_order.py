@@ -94,4 +94,4 @@ def test_order_flags_are_ignored_by_the_direct_binning():
         got = ops.render_forward(*inp, 256, K, CUTOFF, THR, SIGMA, False, False, workspace_state=0 | flag)
         assert torch.equal(got["idx"], ref["idx"]) and torch.equal(got["image"], ref["image"])
     with pytest.raises(RuntimeError, match="workspace_state"):
-        ops.render_forward(*inp, 256, K, CUTOFF, THR, SIGMA, False, False, workspace_state=0x40)
+        ops.render_forward(*inp, 256, K, CUTOFF, THR, SIGMA, False, False, workspace_state=0x80)

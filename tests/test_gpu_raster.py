@@ -227,6 +227,51 @@ def test_cell_ordered_binning_of_large_inputs_is_exact(dist):
         assert torch.equal(fb["idx"], f["idx"][:, own]) and torch.equal(fb["qvalue"], f["qvalue"][:, own]), part.describe()
 
 
+@pytest.mark.parametrize("reps,S", [(1, 128), (4, 256), (106, 512)])
+def test_band_outputs_only_gives_the_same_band_and_the_same_gradients(reps, S):
+    """DSS_WS_BAND_OUTPUTS (multi-GPU ranks; `render_forward(band_outputs_only=True)`): the splats that miss the rank's rows
+    keep out of the sort / binning and write position, radii and validity only.  The band's fragments, image, weight sums and
+    visibility flags are the same bits as without the flag; position / radii / validity are complete; ellipse / scaler /
+    cutoff are those of the plain call wherever a splat is visible; and the backward through these outputs (global
+    visibility) gives the same partial gradients.  Direct binning (small clouds) and the cell-ordered path of more than 2M
+    splats in all three forms: sorting for itself, saving the point order, reusing it."""
+    from dss_amd.distributed import RowPartition
+    pts, nrm = scenes.load_cloud("yoga6")
+    pts = scenes.normalize_unit_sphere(pts)
+    if reps > 1:
+        pts, nrm = scenes.upsample_jitter(pts, nrm, reps, seed=0)
+    Pc = len(pts)
+    h = scenes.global_h(pts[:: max(1, Pc // 25000)]) * (25000.0 / Pc if Pc > 25000 else 1.0)
+    K, thr, N = 5, 0.05, 2
+    M = np.concatenate([scenes.camera_matrices(2.0, 20.0, a)[0] for a in (30.0, 170.0)])
+    V = np.concatenate([scenes.camera_matrices(2.0, 20.0, a)[1] for a in (30.0, 170.0)])
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    first = torch.tensor([0, Pc], dtype=torch.int64, device=DEV)
+    num = torch.tensor([Pc, Pc - 100], dtype=torch.int64, device=DEV)     # the last 100 packed points belong to no cloud
+    feat = torch.rand((N * Pc, 3), device=DEV)
+    args = (t(pts), t(nrm), torch.full((N,), float(h), device=DEV), t(M), t(V), torch.full((N,), 0.1, device=DEV),
+            torch.full((N,), 100.0, device=DEV), first, num, feat, S, K, 1.0, thr, 1.0, False, True)
+    full = ops.render_forward(*args)
+    assert float(full["occupancy"].mean()) > 0.01
+    go = torch.randn((N, S, S, 4), device=DEV)
+    large = N * Pc > 2_000_000
+    for part in (RowPartition(S, 4, 1), RowPartition(S, 4, 2, cyclic=True), RowPartition(S, 4, 3, bounds=[0, 8, 40, S - 24, S])):
+        own = torch.tensor(part.row_indices(), device=DEV, dtype=torch.int64)
+        plain = ops.render_forward(*args, rows=part.rows)
+        kinds = [dict(order_refresh=0)] + ([dict(order_refresh=3), dict(order_refresh=3)] if large else [])   # sort | save | reuse
+        for kw in kinds:
+            f = ops.render_forward(*args, rows=part.rows, band_outputs_only=True, **kw)
+            for k in ("idx", "zbuf", "qvalue", "occupancy", "image", "wsum", "visible", "pts_screen", "radii", "valid"):
+                assert torch.equal(f[k], plain[k]), (k, part.describe(), kw)
+            vis = plain["visible"]
+            for k in ("ellipse_params", "scaler", "cutoff_threshold"):
+                assert torch.equal(f[k][vis], plain[k][vis]), (k, part.describe(), kw)
+            bw = lambda o: ops.render_backward(go[:, own].contiguous(), o["idx"], o["qvalue"], o["wsum"], o["scaler"], o["pts_screen"],
+                                               o["radii"], full["visible"], first, num, 4.0, -1.0, image_size=S, rows=part.rows)
+            (gf, gp), (gf0, gp0) = bw(f), bw(plain)
+            assert torch.equal(gf, gf0) and torch.equal(gp, gp0), (part.describe(), kw)
+
+
 def test_row_bands_concatenate_to_full_image():
     sc = scenes.random_splats(2000, 96, 2, seed=6)
     d = _dev(sc)

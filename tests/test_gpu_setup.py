@@ -438,6 +438,34 @@ def test_project_backward_fused_clip_equals_clip_then_project():
     assert torch.equal(fused, want)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("N", [1, 3, 8, 11])
+def test_project_backward_reduces_the_feature_gradients_of_a_shared_cloud(N):
+    """`dss_project_backward_features`: the per-camera feature gradients of a cloud shared by N cameras summed over the
+    cameras in the launch that projects the position gradients (more than eight cameras take a second batch of loads);
+    the position gradients are those of dss_project_backward bit for bit, with and without the clip."""
+    pts = scenes.normalize_unit_sphere(scenes.load_cloud("bunny")[0])[:3001]
+    Pc = pts.shape[0]
+    mats = [scenes.camera_matrices(2.0, 20.0, 360.0 * k / N + 10.0) for k in range(N)]
+    M, V = np.concatenate([m[0] for m in mats]), np.concatenate([m[1] for m in mats])
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    first = torch.arange(N, device=DEV) * Pc
+    num = torch.full((N,), Pc, device=DEV, dtype=torch.int64)
+    g = torch.randn(N * Pc, 3, device=DEV) * 0.1
+    valid = torch.rand(N * Pc, device=DEV) > 0.2
+    for C in (3, 5):
+        gf = torch.randn(N * Pc, C, device=DEV)
+        for clip in (-1.0, 0.05):
+            want = ops.project_backward(t(pts), t(M), t(V), first, num, g, valid, True, clip=clip)
+            gw, gfw = ops.project_backward(t(pts), t(M), t(V), first, num, g, valid, True, clip=clip, grad_features=gf)
+            assert torch.equal(gw, want)
+            ref = gf.view(N, Pc, C).double().sum(0)
+            assert float((gfw.double() - ref).abs().max()) <= 1e-5 * max(float(ref.abs().max()), 1.0)
+    # clouds that are not shared: the "reduction" is the identity
+    gw, gfw = ops.project_backward(t(np.tile(pts, (N, 1))), t(M), t(V), first, num, g, valid, False, grad_features=gf)
+    assert torch.equal(gfw, gf) and torch.equal(gw, ops.project_backward(t(np.tile(pts, (N, 1))), t(M), t(V), first, num, g, valid, False))
+
+
 def test_filters_object_drops_inactive_points_and_receives_visibility():
     """`point_clouds_filter` (DSS/core/cloud.py:284-351) through the renderer: inactive points are not rendered
     (rasterizer.py:230-234) and the per-point visibility comes back as a padded (N, P_max) mask over the ORIGINAL

@@ -18,8 +18,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 from dss_amd import ops  # noqa: E402
-from dss_amd.distributed import RowPartition  # noqa: E402
+from dss_amd.distributed import RowPartition, balanced_bounds  # noqa: E402
 
+from dss_amd import _lib  # noqa: E402
+if os.environ.get("BAND_TPW"):       # development A/B: DSS_OPT_BACKWARD_TPW
+    _lib.set_option(_lib.OPT_BACKWARD_TPW, int(os.environ["BAND_TPW"]))
+if os.environ.get("BAND_FUSED"):     # development A/B: DSS_OPT_BACKWARD_FUSED (1 = the round-3 launch sequence on the band)
+    _lib.set_option(_lib.OPT_BACKWARD_FUSED, int(os.environ["BAND_FUSED"]))
 G = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 which = sys.argv[2] if len(sys.argv) > 2 else "cfg2"
 dev = torch.device("cuda:0")
@@ -31,9 +36,15 @@ else:
     wl = bench.Workload(dev, cams, RowPartition(S, 1, 0), cloud=cloud)
 
 
+# clouds above 2M splats: the renderer-owned cached point order, like `bench.py --workload cfg4|cfg5` (every k-th call sorts
+# and saves, the others bin through the saved order)
+ORDER_REFRESH = int(os.environ.get("BAND_ORDER_REFRESH", "16")) if wl.P > 2_000_000 else 0
+
+
 def fwd(rows):
     return ops.render_forward(wl.world, wl.normals, wl.h, wl.M, wl.V, wl.znear, wl.zfar, wl.first, wl.num, wl.colors, S, K,
-                              bench.CUTOFF, bench.THR, bench.SIGMA, False, True, rows=rows)
+                              bench.CUTOFF, bench.THR, bench.SIGMA, False, True, rows=rows, order_refresh=ORDER_REFRESH,
+                              band_outputs_only=rows is not None and os.environ.get("BAND_FULL_OUTPUTS") != "1")
 
 
 def quick(fn, n=60):
@@ -48,15 +59,23 @@ def quick(fn, n=60):
 
 
 out = {"G": G, "workload": which, "cameras": wl.N, "points_per_cloud": wl.Pc, "image_size": S}
-N_IT = 60 if which == "cfg2" else 8
+N_IT = 60 if which == "cfg2" else 16
 TRACE = os.environ.get("BAND_TRACE") == "1"   # under rocprofv3 --kernel-trace: the cyclic partition, rank 3, eager launches only
-for layout in (("cyclic",) if TRACE else ("bands", "cyclic")):
-    parts = [RowPartition(S, G, r, cyclic=(layout == "cyclic")) for r in range(G)]
-    vis_all = torch.zeros(wl.P, dtype=torch.bool, device=dev)
-    for p in parts:
-        vis_all |= fwd(p.rows)["visible"]
+LAYOUTS = os.environ.get("BAND_LAYOUTS", "bands,balanced,cyclic").split(",")
+TRACE_RANK = int(os.environ.get("BAND_TRACE_RANK", "3"))
+for layout in ((os.environ.get("BAND_TRACE_LAYOUT", "cyclic"),) if TRACE else LAYOUTS):
+    bounds = None
+    if layout == "balanced":
+        # contiguous bands with (about) equal load: row weight = occupied pixels per image row, summed over the cameras, of a
+        # full render (every rank holds the gathered image of the previous step: the same weights everywhere, no collective)
+        w = fwd(None)["occupancy"].sum(dim=(0, 2)).double().cpu() + float(os.environ.get("BAND_ROW_BIAS", "0"))
+        bounds = balanced_bounds(w, G, align=8, min_rows=8)
+        out["balanced_bounds"] = bounds
+    parts = [RowPartition(S, G, r, cyclic=(layout == "cyclic"), bounds=bounds) for r in range(G)]
+    # (union of the ranks' visibility flags = the flags of the full render: one call instead of G band renders)
+    vis_all = fwd(None)["visible"].clone()
     eager, graph = [], []
-    for p in (parts[3:4] if TRACE else parts):
+    for p in (parts[TRACE_RANK:TRACE_RANK + 1] if TRACE else parts):
         g_band = p.slice(wl.grad_out).contiguous()
         bucket = torch.empty(wl.P * 6, device=dev)
         gf, gp = bucket[:wl.P * 3].view(wl.P, 3), bucket[wl.P * 3:].view(wl.P, 3)
@@ -65,7 +84,8 @@ for layout in (("cyclic",) if TRACE else ("bands", "cyclic")):
             f = fwd(p.rows)
             ops.render_backward(g_band, f["idx"], f["qvalue"], f["wsum"], f["scaler"], f["pts_screen"], f["radii"], vis_all,
                                 wl.first, wl.num, bench.RADII_S, -1.0, image_size=S, rows=p.rows, out=(gf, gp))
-            return ops.project_backward(wl.world, wl.M, wl.V, wl.first, wl.num, gp, f["valid"], True, clip=bench.CLIP)
+            return ops.project_backward(wl.world, wl.M, wl.V, wl.first, wl.num, gp, f["valid"], True, clip=bench.CLIP,
+                                        grad_features=gf)
         eager.append(quick(step, N_IT))
         if TRACE:
             graph.append(eager[-1])
@@ -84,7 +104,8 @@ for layout in (("cyclic",) if TRACE else ("bands", "cyclic")):
     out[layout] = {"eager_us": [round(x, 1) for x in eager], "graph_us": [round(x, 1) for x in graph],
                    "graph_max_over_min": round(max(graph) / min(graph), 3), "graph_max_us": round(max(graph), 1),
                    "eager_max_us": round(max(eager), 1)}
-one = RowPartition(S, 1, 0)
-wl1 = bench.Workload(dev, 1, one) if which == "cfg2" else wl
-out["single_gpu_step_us"] = {"eager": round(quick(wl1.step, N_IT), 1)}
+if not TRACE:   # (a kernel trace holds one rank's band step only)
+    one = RowPartition(S, 1, 0)
+    wl1 = bench.Workload(dev, 1, one) if which == "cfg2" else wl
+    out["single_gpu_step_us"] = {"eager": round(quick(wl1.step, N_IT), 1)}
 print(json.dumps(out))

@@ -37,7 +37,11 @@ else:
     pts, nrm, col = scenes.synthetic_cloud(P, seed=0)
     h = scenes.global_h(pts[:: max(1, P // 200_000)]) * (200_000 / P if P > 200_000 else 1.0)
     h = float(np.clip(h, 5e-6, 1e-3))
-    wl = bench.Workload(dev, N, bench.RowPartition(S, 1, 0), cloud=(pts, nrm, col, h))
+    part = bench.RowPartition(S, 1, 0)
+    if len(sys.argv) > 2:   # "row0,row1": the fine pass of that row band (a rank of the multi-GPU step)
+        r0, r1 = (int(x) for x in sys.argv[2].split(","))
+        part = bench.RowPartition(S, 3, 1, bounds=[0, r0, r1, S])
+    wl = bench.Workload(dev, N, part, cloud=(pts, nrm, col, h))
     blocks = N * (S // 8) ** 2
 buf = torch.zeros((2 * blocks + 4096, 12), dtype=torch.int64, device=dev)  # grid = queue slots (~tiles) + tiles/16 fill workgroups
 for _ in range(3):
