@@ -71,8 +71,7 @@ def large_cloud(which, morton=False):
     import scenes
     P, S_, N = LARGE_WORKLOADS[which]
     pts, nrm, col = scenes.synthetic_cloud(P, seed=0)
-    h = scenes.global_h(pts[:: max(1, P // 200_000)]) * (200_000 / P if P > 200_000 else 1.0)
-    h = float(np.clip(h, 5e-6, 1e-3))
+    h = scenes.large_cloud_h(pts)   # (shared with tests/test_gpu_named_configs.py: the benched scene is the parity-tested one)
     if morton:
         from dss_amd.cloud import spatial_order
         order = spatial_order(torch.from_numpy(pts)).numpy()
@@ -81,7 +80,7 @@ def large_cloud(which, morton=False):
 
 
 class Workload:
-    def __init__(self, device, n_cams, part: RowPartition, cloud=None, multi=None):
+    def __init__(self, device, n_cams, part: RowPartition, cloud=None, multi=None, fold=False):
         pts, nrm, col, h = bunny_cloud() if cloud is None else cloud
         self.dev, self.N, self.part = device, n_cams, part
         # multi: take the multi-GPU path (send buffers, three collectives, gradient bucket); forced at world size 1 by
@@ -123,9 +122,22 @@ class Workload:
         if self.multi:
             # multi-GPU: the forward kernel writes its RGBA band and visibility flags straight into the
             # all-gather send buffers; the backward writes both gradients into one all-reduce bucket
-            self.fx = OverlappedExchange(part, self.N, 4, self.P, device, force=self.multi)
-            self.fx.late_image = os.environ.get("BENCH_IMAGE_LATE", "0") == "1"
+            # two forms of the end-of-forward exchange (dss_amd/distributed.py): "overlap" -- three collectives per step, the
+            # image bands asynchronous on their own communicator -- and "fold" -- two, the visibility flags riding in one
+            # blocking image all-gather; main() measures both on the ranks it runs on and keeps the faster
+            self._fx = {False: OverlappedExchange(part, self.N, 4, self.P, device, force=self.multi)}
+            self._fx[False].late_image = os.environ.get("BENCH_IMAGE_LATE", "0") == "1"
+            self.fx = self._fx[False]
             self.bucket = torch.empty(self.P * 6, device=device)
+            if fold:
+                self.set_exchange(True)
+
+    def set_exchange(self, fold: bool):
+        """select the exchange form of the multi-GPU step (captured graphs hold the buffers of the form they were captured with)"""
+        if fold not in self._fx:
+            self._fx[fold] = OverlappedExchange(self.part, self.N, 4, self.P, self.dev, force=self.multi, fold=True)
+        self.fx = self._fx[fold]
+        self._graphs = self._whole = None
 
     def step(self, ev=None):
         """one forward + backward.  `ev` (multi-GPU diagnostics): a list that receives (label, event) marks recorded on the
@@ -208,7 +220,9 @@ class Workload:
         host three graph launches + three collective calls instead of ~10 kernel launches through Python."""
         p, S = self.part, self.S
         self.g_band = p.slice(self.grad_out).contiguous()
-        self.vis_all = self.fx.visible   # the forward kernel writes it, the all-reduce (MAX) of fx.start() unions it in place
+        # the forward kernel writes fx.visible; overlap: the all-reduce (MAX) of fx.start() unions it in place; fold: the union
+        # of the gathered copies lands in fx.union
+        self.vis_all = self.fx.union if self.fx.fold else self.fx.visible
         g_feat = self.bucket[:self.P * 3].view(self.P, 3)
         g_pts = self.bucket[self.P * 3:].view(self.P, 3)
         seg = {}
@@ -441,7 +455,7 @@ class Workload:
         return t_gather, t_full, t_prep, pairs, int(vis.sum().item())
 
 
-def api_path_ms(wl, n=200, graphed=False, warm=400, engine_thread=None):
+def api_path_ms(wl, n=200, graphed=False, warm=400, calling_thread=False):
     """The same workload through the drop-in API a train_mvr.py user calls (DSS/core/renderer.py:36-82):
     `SurfaceSplattingRenderer(SurfaceSplatting(...), NormWeightedCompositor(), fused=True)(cloud)` + `.backward()`,
     eager, autograd and Python object handling included; h precomputed like the headline. -> ms per fwd+bwd
@@ -462,11 +476,6 @@ def api_path_ms(wl, n=200, graphed=False, warm=400, engine_thread=None):
                                      image_size=wl.S, points_per_pixel=K, bin_size=None, clip_pts_grad=CLIP,
                                      antialiasing_sigma=SIGMA)
     kw = {}
-    if engine_thread is not None:
-        # (True: backward on the autograd engine's device thread instead of the calling thread: SurfaceSplattingRenderer docstring)
-        if "engine_thread" not in inspect.signature(SurfaceSplattingRenderer.__init__).parameters:
-            return None
-        kw["engine_thread"] = engine_thread
     if graphed:
         if "graphed" not in inspect.signature(SurfaceSplattingRenderer.__init__).parameters:
             return None
@@ -482,18 +491,21 @@ def api_path_ms(wl, n=200, graphed=False, warm=400, engine_thread=None):
         C.grad = None
         img = renderer(PointClouds3D([X], [wl.normals], [C]), Vrk_h=h)
         img.backward(wl.grad_out)
-    was = torch.autograd.is_multithreading_enabled()
-    for _ in range(max(5, warm)):
-        step()
-    blocks = []
-    for _ in range(3):
-        torch.cuda.synchronize()
-        t = time.perf_counter()
-        for _ in range(n):
+    # calling_thread: the caller's explicit opt-in, scoped around the loop (dss_amd.calling_thread_backward); otherwise the
+    # process's autograd state is whatever PyTorch's default is -- the renderer does not touch it
+    import contextlib
+    import dss_amd
+    with (dss_amd.calling_thread_backward() if calling_thread else contextlib.nullcontext()):
+        for _ in range(max(5, warm)):
             step()
-        torch.cuda.synchronize()
-        blocks.append((time.perf_counter() - t) / n * 1e3)
-    torch.autograd.set_multithreading_enabled(was)
+        blocks = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(n):
+                step()
+            torch.cuda.synchronize()
+            blocks.append((time.perf_counter() - t) / n * 1e3)
     return sorted(blocks)[1]
 
 
@@ -641,10 +653,20 @@ def main():
         cloud, S, cams = large_cloud(args.workload)
     # multi-GPU: tile-row-cyclic bands (rank g renders the 8-row tile rows g, g + G, ...: balanced for any scene, equal-size
     # all-gather) whenever the sizes allow it; BENCH_ROW_PARTITION=bands selects the contiguous equal bands of rounds 1-2
-    cyclic = world > 1 and world & (world - 1) == 0 and S % (8 * world) == 0 and \
-        os.environ.get("BENCH_ROW_PARTITION", "cyclic") == "cyclic"
+    # (round 5, emulated per-rank steps at 8 ranks, tools/band_timing.py: at the metric's configuration the cyclic bands take
+    # 99-101 us on every rank against 91-112 for load-balanced contiguous ones; at configs[3] -- per-point work dominates, the
+    # rows are cheap -- contiguous equal bands take 1.06-1.27 ms against 1.46-1.51 for the cyclic ones: the large workloads
+    # default to contiguous bands)
+    layout = os.environ.get("BENCH_ROW_PARTITION", "bands" if large else "cyclic")
+    cyclic = world > 1 and world & (world - 1) == 0 and S % (8 * world) == 0 and layout == "cyclic"
     part = RowPartition(S, world, rank, cyclic=cyclic)
     wl = Workload(dev, cams, part, cloud=cloud, multi=multi)
+    # end-of-forward exchange: measured, not assumed.  BENCH_EXCHANGE=overlap|fold fixes the form; "auto" (default) times a few
+    # eager steps of both forms on THESE ranks (max over the ranks, so that every rank takes the same decision) and keeps the
+    # faster: three collectives with the image bands off the critical path, or two with the flags folded into the image
+    # all-gather -- which one wins depends on the link time of the bands against the latency of a collective.
+    exchange_note = None
+    want_exchange = os.environ.get("BENCH_EXCHANGE", "auto") if multi else None
 
     def capture(unroll=1, side=None):
         side = side or torch.cuda.Stream()   # (the forward workspace -- and a saved point order in it -- is cached per stream)
@@ -704,63 +726,107 @@ def main():
         order_graphs = run_order_graphs if mode == "graph_save_reuse" else None
     elif large and wl.order_refresh > 0 and mode is None:
         mode = "eager"
+    def multi_runner():
+        """the launch mechanism of the multi-GPU step for the CURRENT exchange form: graphs of the compute segments around
+        host-issued collectives, and -- if RCCL lets itself be captured and the replay reproduces the eager step on every rank --
+        the whole step as one graph.  -> (mode, run, steps per launch, segment note, whole-step note)"""
+        mode, seg_note, whole_note = "eager", None, None
+        if True:
+            # multi-GPU: (i) the compute segments between the RCCL calls as graphs; (ii) if RCCL lets itself be captured, the whole
+            # step -- launches and collectives -- as ONE graph, checked against the eager step on every rank before it is used
+            try:
+                barrier()   # (no collective in flight while capturing)
+                wl.capture_segments()
+                mode = "graph_segments"
+            except Exception as e:  # noqa: BLE001  (capture refused: plain launches, and say so)
+                seg_note = "segment capture failed: %s: %s" % (type(e).__name__, str(e)[:160])
+                mode = "eager"
+            whole_wanted = os.environ.get("BENCH_NO_WHOLE_GRAPH") != "1" and dist.get_backend() == "nccl"
+            if not whole_wanted:
+                # (a host-side backend -- gloo in the CPU-collective tests -- cannot be captured, and a refused capture leaves the
+                # thread's capture state unusable: not attempted)
+                whole_note = "not attempted (backend %s%s)" % (dist.get_backend(), ", BENCH_NO_WHOLE_GRAPH" if os.environ.get("BENCH_NO_WHOLE_GRAPH") == "1" else "")
+            if whole_wanted:
+                ok = 1.0
+                try:
+                    barrier()
+                    ref = [t.clone() for t in wl.step()]
+                    barrier()
+                    got = wl.capture_whole_step()
+                    got = wl.step_whole()
+                    torch.cuda.synchronize()
+                    same = torch.equal(got[0], ref[0]) and all(
+                        float((a - b).abs().max()) <= 1e-6 * max(float(b.abs().max()), 1e-30) for a, b in zip(got[1:], ref[1:]))
+                    if not same:
+                        ok, whole_note = 0.0, "whole-step graph gave other results than the eager step: not used"
+                except Exception as e:  # noqa: BLE001  (capture of the collectives refused: the segments stay)
+                    ok, whole_note = 0.0, "whole-step capture failed: %s: %s" % (type(e).__name__, str(e)[:160])
+                flag = torch.tensor([ok], device=dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)   # (every rank takes the same path)
+                if float(flag.item()) == 1.0:
+                    mode = "graph_step"
+                    if unrollable and os.environ.get("BENCH_NO_WHOLE_GRAPH_UNROLL") != "1":
+                        # ten consecutive steps per graph launch, as on one GPU (the stream idles ~8 us between two graph
+                        # launches): same captured step, checked the same way
+                        try:
+                            one = wl._whole
+                            got = wl.capture_whole_step(UNROLL)
+                            got = wl.step_whole()
+                            torch.cuda.synchronize()
+                            same = torch.equal(got[0], ref[0]) and all(
+                                float((a - b).abs().max()) <= 1e-6 * max(float(b.abs().max()), 1e-30) for a, b in zip(got[1:], ref[1:]))
+                            oku = 1.0 if same else 0.0
+                        except Exception:  # noqa: BLE001
+                            oku = 0.0
+                        flag = torch.tensor([oku], device=dev)
+                        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                        if float(flag.item()) == 1.0:
+                            mode = "graph_step_x%d" % UNROLL
+                        else:
+                            wl._whole = one
+                elif whole_note is None:
+                    whole_note = "another rank could not capture the whole step"
+        spl = UNROLL if mode.startswith("graph_step_x") else 1
+        run = wl.step_whole if mode.startswith("graph_step") else (wl.step_segments if mode == "graph_segments" else wl.step)
+        return mode, run, spl, seg_note, whole_note
+
     seg_note = None
     whole_note = None
     if multi and args.mode != "eager":
-        # multi-GPU: (i) the compute segments between the RCCL calls as graphs; (ii) if RCCL lets itself be captured, the whole
-        # step -- launches and collectives -- as ONE graph, checked against the eager step on every rank before it is used
-        try:
-            barrier()   # (no collective in flight while capturing)
-            wl.capture_segments()
-            mode = "graph_segments"
-        except Exception as e:  # noqa: BLE001  (capture refused: plain launches, and say so)
-            seg_note = "segment capture failed: %s: %s" % (type(e).__name__, str(e)[:160])
-            mode = "eager"
-        whole_wanted = os.environ.get("BENCH_NO_WHOLE_GRAPH") != "1" and dist.get_backend() == "nccl"
-        if not whole_wanted:
-            # (a host-side backend -- gloo in the CPU-collective tests -- cannot be captured, and a refused capture leaves the
-            # thread's capture state unusable: not attempted)
-            whole_note = "not attempted (backend %s%s)" % (dist.get_backend(), ", BENCH_NO_WHOLE_GRAPH" if os.environ.get("BENCH_NO_WHOLE_GRAPH") == "1" else "")
-        if whole_wanted:
-            ok = 1.0
+        # end-of-forward exchange: measured, not assumed (BENCH_EXCHANGE=overlap|fold fixes it).  Every form is prepared in the
+        # launch mechanism the timed region will use and timed there (20 launches, max over the ranks: every rank takes the
+        # same decision); the faster one is prepared again and kept.  (Eager steps would mislead: at world size 1 the folded
+        # form is faster eagerly -- fewer host calls -- and slower as a graph -- two more kernels and a stream fork.)
+        forms = [want_exchange] if want_exchange in ("overlap", "fold") else ["overlap", "fold"]
+        t_form = {}
+        for form in forms:
             try:
+                wl.set_exchange(form == "fold")
+                m_, run_, spl_, _, _ = multi_runner()
+                for _ in range(3):
+                    run_()
                 barrier()
-                ref = [t.clone() for t in wl.step()]
-                barrier()
-                got = wl.capture_whole_step()
-                got = wl.step_whole()
+                t0 = time.perf_counter()
+                for _ in range(20):
+                    run_()
                 torch.cuda.synchronize()
-                same = torch.equal(got[0], ref[0]) and all(
-                    float((a - b).abs().max()) <= 1e-6 * max(float(b.abs().max()), 1e-30) for a, b in zip(got[1:], ref[1:]))
-                if not same:
-                    ok, whole_note = 0.0, "whole-step graph gave other results than the eager step: not used"
-            except Exception as e:  # noqa: BLE001  (capture of the collectives refused: the segments stay)
-                ok, whole_note = 0.0, "whole-step capture failed: %s: %s" % (type(e).__name__, str(e)[:160])
-            flag = torch.tensor([ok], device=dev)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)   # (every rank takes the same path)
-            if float(flag.item()) == 1.0:
-                mode = "graph_step"
-                if unrollable and os.environ.get("BENCH_NO_WHOLE_GRAPH_UNROLL") != "1":
-                    # ten consecutive steps per graph launch, as on one GPU (the stream idles ~8 us between two graph
-                    # launches): same captured step, checked the same way
-                    try:
-                        one = wl._whole
-                        got = wl.capture_whole_step(UNROLL)
-                        got = wl.step_whole()
-                        torch.cuda.synchronize()
-                        same = torch.equal(got[0], ref[0]) and all(
-                            float((a - b).abs().max()) <= 1e-6 * max(float(b.abs().max()), 1e-30) for a, b in zip(got[1:], ref[1:]))
-                        oku = 1.0 if same else 0.0
-                    except Exception:  # noqa: BLE001
-                        oku = 0.0
-                    flag = torch.tensor([oku], device=dev)
-                    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-                    if float(flag.item()) == 1.0:
-                        mode = "graph_step_x%d" % UNROLL
-                    else:
-                        wl._whole = one
-            elif whole_note is None:
-                whole_note = "another rank could not capture the whole step"
+                tt = torch.tensor([(time.perf_counter() - t0) / (20 * spl_) * 1e3], device=dev, dtype=torch.float64)
+            except Exception as e:  # noqa: BLE001  (a form that cannot run here drops out of the comparison)
+                tt = torch.tensor([float("inf")], device=dev, dtype=torch.float64)
+                exchange_note = {"error_" + form: "%s: %s" % (type(e).__name__, str(e)[:160])}
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            t_form[form] = float(tt.item())
+        best = min(t_form, key=t_form.get)
+        note = dict(exchange_note or {})
+        note.update({"form": best, "chosen": "BENCH_EXCHANGE" if len(forms) == 1 else
+                     "measured: 20 launches of the prepared step per form, max over the ranks",
+                     "ms_per_step": {k: (round(v, 5) if v != float("inf") else None) for k, v in t_form.items()}})
+        exchange_note = note
+        wl.set_exchange(best == "fold")
+        mode, _run, _spl, seg_note, whole_note = multi_runner()
+    elif multi:
+        wl.set_exchange(want_exchange == "fold")
+        exchange_note = {"form": "fold" if want_exchange == "fold" else "overlap", "chosen": "eager launches: not compared"}
     if mode is None:
         graph = capture()
         ms_modes = {"eager": quick(wl.step, n=8 if large else 40), "graph": quick(graph.replay, n=8 if large else 40)}
@@ -859,9 +925,11 @@ def main():
             except Exception as e:  # noqa: BLE001  (capture refused: keep the eager figure)
                 knn_mode = "eager (graph capture failed: %s)" % type(e).__name__
         value_knn = splats / (ms_knn * 1e-3) / 1e6
-    ms_api = api_path_ms(wl) if (not multi and not large) else None
-    ms_api_graphed = api_path_ms(wl, graphed=True) if (not multi and not large) else None
-    ms_api_et = api_path_ms(wl, engine_thread=True) if (not multi and not large) else None
+    api = not multi and not large
+    ms_api = api_path_ms(wl) if api else None                                                # PyTorch's default autograd state
+    ms_api_ct = api_path_ms(wl, calling_thread=True) if api else None                        # the caller's scoped opt-in
+    ms_api_graphed = api_path_ms(wl, graphed=True) if api else None
+    ms_api_graphed_ct = api_path_ms(wl, graphed=True, calling_thread=True) if api else None
 
     dist_block = {"world_size": 1, "backend": None}
     if multi:
@@ -881,7 +949,8 @@ def main():
         dist_block = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "forced": force_dist,
                       "rccl_version": nccl_v,
                       "visible_devices": torch.cuda.device_count(), "partition": part.describe(),
-                      "overlap": bool(wl.fx.overlap), "image_issue": "behind the backward (side stream)" if wl.fx.late_image else "before the backward, after the visibility union", "degraded": wl.fx.degraded, "segment_capture": seg_note or "ok",
+                      "exchange": exchange_note, "collectives_per_step": 2 if wl.fx.fold else 3,
+                      "overlap": bool(wl.fx.overlap) and not wl.fx.fold, "image_issue": "behind the backward (side stream)" if wl.fx.late_image else "before the backward, after the visibility union", "degraded": wl.fx.degraded, "segment_capture": seg_note or "ok",
                       "whole_step_graph": whole_note or "ok",
                       "timing_us": {k: {"min": round(float(allt[:, i].min()), 1), "max": round(float(allt[:, i].max()), 1),
                                         "mean": round(float(allt[:, i].mean()), 1)} for i, k in enumerate(keys)},
@@ -900,7 +969,7 @@ def main():
     achieved = alg_bytes / (fine_mean * 1e-3) / 1e9
     traffic, traffic_src, gather_traffic, prof_ms = None, None, None, {}
     tfile = os.path.join(ROOT, "profiles", "traffic_fine_kernel.json")
-    if not multi and not large and rank == 0 and not args.no_traffic:
+    if not multi and rank == 0 and not args.no_traffic:
         # HBM bytes per launch are PMC counters: they cannot be read in-process.  tools/collect_traffic.py runs this very
         # command (eager, 20 steps, --no-traffic) twice under `rocprofv3 --kernel-trace --pmc` (FETCH_SIZE and WRITE_SIZE in
         # separate passes, no other trace domain) and averages them over the fine_kernel dispatches: measured in THIS run.
@@ -909,8 +978,9 @@ def main():
         import subprocess
         if shutil.which("rocprofv3"):
             try:
-                r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "collect_traffic.py")], capture_output=True,
-                                   text=True, timeout=240)
+                r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "collect_traffic.py")] +
+                                   (["--workload", args.workload] if large else []), capture_output=True, text=True,
+                                   timeout=900 if large else 240)
                 tj = json.loads(r.stdout.strip().splitlines()[-1])
                 traffic = int(tj["traffic_bytes_per_launch"])
                 gather_traffic = tj.get("render_backward_kernel_traffic_bytes_per_launch")
@@ -1003,17 +1073,22 @@ def main():
             rec["ms_per_step_with_knn"] = round(ms_knn, 5)
             rec["with_knn_launch"] = knn_mode
         if ms_api is not None:
-            rec["value_via_api"] = round(splats / (ms_api * 1e-3) / 1e6, 3)
+            to_v = lambda ms: round(splats / (ms * 1e-3) / 1e6, 3)
+            rec["value_via_api"] = to_v(ms_api)
             rec["ms_per_step_via_api"] = round(ms_api, 5)
-            rec["via_api"] = "SurfaceSplattingRenderer(fused=True)(cloud) + .backward(), eager, autograd included (backward on the calling thread: the renderer's default, see value_via_api_engine_thread), h precomputed; median of 3 x 200 iterations after 400 untimed ones (host-bound path)"
-        if ms_api_graphed is not None:
-            rec["value_via_api_graphed"] = round(splats / (ms_api_graphed * 1e-3) / 1e6, 3)
-            rec["ms_per_step_via_api_graphed"] = round(ms_api_graphed, 5)
-        if ms_api_et is not None:
-            # the same eager API path with SurfaceSplattingRenderer(engine_thread=True) / DSS_AMD_ENGINE_THREAD=1: backward
-            # handed to the autograd engine's per-device thread (PyTorch's default; the renderer's default is the calling thread)
-            rec["value_via_api_engine_thread"] = round(splats / (ms_api_et * 1e-3) / 1e6, 3)
-            rec["ms_per_step_via_api_engine_thread"] = round(ms_api_et, 5)
+            rec["via_api"] = ("SurfaceSplattingRenderer(fused=True)(cloud) + .backward(), eager, autograd included, h precomputed; "
+                              "median of 3 x 200 iterations after 400 untimed ones (host-bound path).  value_via_api: PyTorch's "
+                              "default autograd state (backward handed to the engine's device thread; constructing a renderer "
+                              "does not change it).  *_calling_thread: the loop inside `with dss_amd.calling_thread_backward():` "
+                              "(the caller's scoped opt-in).  *_graphed: SurfaceSplattingRenderer(graphed=True), forward and "
+                              "backward replayed as two hipGraphs over static buffers")
+            rec["value_via_api_calling_thread"] = to_v(ms_api_ct)
+            rec["ms_per_step_via_api_calling_thread"] = round(ms_api_ct, 5)
+            if ms_api_graphed is not None:
+                rec["value_via_api_graphed"] = to_v(ms_api_graphed)
+                rec["ms_per_step_via_api_graphed"] = round(ms_api_graphed, 5)
+                rec["value_via_api_graphed_calling_thread"] = to_v(ms_api_graphed_ct)
+                rec["ms_per_step_via_api_graphed_calling_thread"] = round(ms_api_graphed_ct, 5)
         for k, v in ms_modes.items():
             rec["config"]["calibration_ms_per_step_" + k] = round(v, 5)
         if not args.no_cpu_baseline and not large and not force_dist:

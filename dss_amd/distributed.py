@@ -231,7 +231,7 @@ class OverlappedExchange:
     (``ops.render_forward(out_image=...)`` takes camera / row strides)."""
 
     def __init__(self, part: RowPartition, n_images: int, channels: int, num_points: int, device, group=None,
-                 image_group=None, force: bool = False):
+                 image_group=None, force: bool = False, fold: bool = False):
         # force: build the second communicator and issue every collective even in a world of ONE rank (a one-GPU box
         # then executes the RCCL code path line for line: bench.py BENCH_FORCE_DIST=1)
         self.part, self.group = part, group
@@ -241,7 +241,7 @@ class OverlappedExchange:
         # blocking all-gather -- slower, same result -- and says so (`overlap` False, `degraded` holds the reason): the
         # first multi-GPU run of a deployment must produce a diagnosable number rather than a stack trace.
         self.overlap, self.degraded = True, None
-        if image_group is None and (part.world_size > 1 or force) and dist.is_initialized():
+        if image_group is None and not fold and (part.world_size > 1 or force) and dist.is_initialized():
             try:
                 self.image_group = dist.new_group()  # collective: every rank constructs its exchange
             except Exception as e:  # noqa: BLE001  (RCCL refused a second communicator)
@@ -256,11 +256,29 @@ class OverlappedExchange:
                 self.image_group, self.overlap = group, False
                 self.degraded = "another rank could not create the second communicator"
         G, band, S = part.world_size, part.band, part.S
-        self.send_img = torch.zeros((band, n_images, S, channels), dtype=torch.float32, device=device)
-        self.recv_img = torch.empty((G * band, n_images, S, channels), dtype=torch.float32, device=device)
+        # fold: TWO collectives per step instead of three -- the visibility flags ride in the image all-gather as `vrows`
+        # extra rows behind every rank's band (one blocking all-gather on `group`, the union = a MAX over the G gathered
+        # copies, the image rows put in place by one gather kernel).  The price: the backward waits for the whole image
+        # exchange instead of a P-byte all-reduce, i.e. the image bytes move on the critical path.  Which form is faster
+        # depends on the link time of the image bands against the latency of one more collective: bench.py measures both on
+        # the ranks it runs on and keeps the faster (`config.dist.exchange`).
+        self.fold = bool(fold)
+        row_floats = n_images * S * channels
+        self.vrows = -(-int(num_points) // (4 * row_floats)) if self.fold else 0
+        self.stride_rows = band + self.vrows     # rows of one rank's chunk of the gathered buffer
+        self.send_img = torch.zeros((band + self.vrows, n_images, S, channels), dtype=torch.float32, device=device)
+        self.recv_img = torch.empty((G * (band + self.vrows), n_images, S, channels), dtype=torch.float32, device=device)
         rows = part.n_rows
         self.image = self.send_img[:rows].permute(1, 0, 2, 3)  # (N, rows, S, ch), strided
-        self.visible = torch.zeros(num_points, dtype=torch.uint8, device=device)
+        if self.fold:
+            # the forward kernel writes its flags straight into the tail of the send buffer
+            self.visible = self.send_img[band:].reshape(-1).view(torch.uint8)[:num_points]
+            self.union = torch.zeros(num_points, dtype=torch.uint8, device=device)
+            self._gathered_flags = self.recv_img.view(G, band + self.vrows, row_floats)[:, band:]   # (G, vrows, row_floats)
+        else:
+            self.visible = torch.zeros(num_points, dtype=torch.uint8, device=device)
+            self.union = None
+        self.num_points = int(num_points)
         self._work = None
         on_gpu = torch.device(device).type == "cuda"
         self._side_img = torch.cuda.Stream(device=device) if on_gpu else None   # issue stream of the image collective
@@ -270,10 +288,13 @@ class OverlappedExchange:
         # load-balanced (unequal) bands travel padded to the largest one; the rows are put in place by ONE gather
         # kernel on the side stream as soon as the collective completes, i.e. still during the backward
         self.full_img = self.row_index = None
-        if not part.uniform:
+        if not part.uniform or self.fold:
             # image row r sits at gather_index()[r] of the gathered buffer (unequal bands travel padded to the largest
-            # one; a cyclic partition interleaves the ranks' tile rows)
-            self.row_index = torch.tensor(part.gather_index(), dtype=torch.int64, device=device)
+            # one; a cyclic partition interleaves the ranks' tile rows; folded flags sit between the ranks' bands)
+            pos = part.gather_index()
+            if self.vrows:
+                pos = [(q // band) * self.stride_rows + q % band for q in pos]
+            self.row_index = torch.tensor(pos, dtype=torch.int64, device=device)
             self.full_img = torch.empty((S, n_images, S, channels), dtype=torch.float32, device=device)
 
     @staticmethod
@@ -287,9 +308,31 @@ class OverlappedExchange:
         buffer that captured graphs read).  The visibility union goes FIRST: it is the one the backward waits for, and the
         GPU executes it while the host is still issuing the image collective (an RCCL call costs the host 15-20 us; measured
         at world size 1, profiles/r4_c_forced_dist_issue_order.txt)."""
+        if self.fold:
+            return self._start_folded(out)
         vis = self.start_visibility(out)
         self.start_image()
         return vis
+
+    def _start_folded(self, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """`fold`: ONE blocking all-gather of [band rows | visibility flags] on `group`; the union of the flags is a MAX over
+        the gathered copies; the image rows are put in place by one gather kernel (on the side stream when there is one: it
+        overlaps with the backward, which only needs the union)."""
+        G = self.part.world_size
+        self._all_gather(self.recv_img.view(G, -1), self.send_img.view(-1), self.group, False)
+        flags = self._gathered_flags.reshape(G, -1).view(torch.uint8)[:, :self.num_points]
+        union = self.union if out is None else out
+        torch.amax(flags, dim=0, out=union)
+        self._work = None
+        if self._side_img is not None:
+            self._side_img.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._side_img):
+                torch.index_select(self.recv_img, 0, self.row_index, out=self.full_img)
+            self._issued_on = self._side_img
+        else:
+            torch.index_select(self.recv_img, 0, self.row_index, out=self.full_img)
+            self._issued_on = None
+        return union
 
     def start_visibility(self, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """The critical exchange alone.  `late_image`: also records the point of the stream up to which the image bands are

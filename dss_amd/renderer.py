@@ -68,22 +68,19 @@ class SurfaceSplattingRenderer(torch.nn.Module):
         screen-cell order its binning sorts the points into and reuses it for the next k - 1 renders of the same shape
         (`include/dss_hip.h` DSS_WS_ORDER_SAVE / DSS_WS_ORDER_REUSE): a training loop moves its points a little per iteration,
         so those renders skip the sort.  Images, fragments and gradients are identical bit for bit.
-        ``engine_thread`` (not in the reference signature): whether ``loss.backward()`` hands its nodes to the autograd
-        engine's per-device thread (PyTorch's default) or runs them on the CALLING thread
-        (``torch.autograd.set_multithreading_enabled(False)``, thread-local, applied here for the constructing thread).  At
-        DSS sizes an iteration is ~60 us of GPU work behind ~100 us of Python, and that hand-over -- a futex wake-up, a GIL
-        transfer and a cold core per backward -- doubles the host time of an iteration on the GPU boxes unless the OS happens
-        to place the two threads next to each other: 0.25 vs 0.125 ms per forward + backward, alternating blocks in one
-        process (profiles/r4_c_api_path_variability.txt).  One process per GPU -- the execution model of this package,
-        SURVEY 8e -- has no backward work on other devices to overlap, so the default (None) is the calling thread;
-        ``engine_thread=True`` or the environment variable ``DSS_AMD_ENGINE_THREAD=1`` keeps PyTorch's engine thread (a
-        process that differentiates through several devices at once wants that)."""
+        ``engine_thread`` (not in the reference signature; default None = PyTorch's autograd state is left ALONE): an
+        explicit ``engine_thread=False`` -- or the environment variable ``DSS_AMD_CALLING_THREAD_BACKWARD=1`` -- switches the
+        CONSTRUCTING thread to backward-on-the-calling-thread (``torch.autograd.set_multithreading_enabled(False)``,
+        thread-local, for everything that thread differentiates afterwards: a knowing, process-level opt-in).  The scoped form
+        is ``with dss_amd.calling_thread_backward(): loss.backward()``, which restores the state on exit; see there for why
+        it matters at DSS sizes (0.25 vs 0.125 ms of host time per forward + backward).  Round 4 flipped the switch in every
+        constructor; a drop-in for the reference's renderer must not change global engine state as a side effect."""
         super().__init__()
-        if engine_thread is None:
-            engine_thread = os.environ.get("DSS_AMD_ENGINE_THREAD", "0") == "1"
-        self.engine_thread = bool(engine_thread)
-        if torch.autograd.is_multithreading_enabled() != self.engine_thread:
-            torch.autograd.set_multithreading_enabled(self.engine_thread)
+        if engine_thread is None and os.environ.get("DSS_AMD_CALLING_THREAD_BACKWARD", "0") == "1":
+            engine_thread = False
+        self.engine_thread = engine_thread
+        if engine_thread is False and torch.autograd.is_multithreading_enabled():
+            torch.autograd.set_multithreading_enabled(False)
         self.fused = fused
         self.graphed = bool(graphed)
         self.order_refresh = int(order_refresh)

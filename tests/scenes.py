@@ -75,6 +75,24 @@ def global_h(points) -> float:
     return float(np.clip((0.5 * sq.max(1)).mean(), 5e-5, 1e-3))
 
 
+def large_cloud_h(points) -> float:
+    """Variance scale h of the synthetic large clouds (BASELINE configs[3] / configs[4]): the kNN-7 statistic of a 200k-point
+    subsample scaled by the density ratio (the reference's clamp [5e-5, 1e-3] would turn a 4M-point cloud into 20-pixel
+    splats), clipped to [5e-6, 1e-3].  ONE definition for `bench.py::large_cloud` and `tests/test_gpu_named_configs.py`: the
+    benched configuration is the parity-tested one."""
+    P = points.shape[0]
+    h = global_h(points[:: max(1, P // 200_000)]) * (200_000 / P if P > 200_000 else 1.0)
+    return float(np.clip(h, 5e-6, 1e-3))
+
+
+# cameras of the bench workloads: ring at distance 2, elevation 30 degrees, azimuth 45 + 45 k (bench.py Workload)
+BENCH_CAMERA = (2.0, 30.0)
+
+
+def bench_azimuths(n):
+    return [45.0 + 45.0 * k for k in range(n)]
+
+
 def camera_matrices(dist, elev, azim, znear=0.1, zfar=100.0, fov=60.0):
     """-> M (N,4,4) full projection, V (N,4,4) world->view (row-vector convention), float32."""
     from dss_amd.cameras import FoVPerspectiveCameras, look_at_view_transform

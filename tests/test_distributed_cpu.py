@@ -96,6 +96,21 @@ def _worker(rank, world, port, S, tmp):
             oxc.visible.copy_(vis_c)
             assert torch.equal(oxc.start(), vis)
             assert torch.equal(oxc.finish(), full_t * (rep + 1))
+        # folded exchange (two collectives per step): the flags ride behind every rank's band in ONE all-gather; union = MAX
+        # over the gathered copies; equal, load-balanced and tile-row-cyclic bands; twice, to cover buffer reuse
+        for pf, idx_f in ((part, None), (pb, None), (pc, idx_c)):
+            rows_f = np.array(pf.row_indices(), np.int64)
+            if idx_f is None:
+                idx_f = np.full_like(idx, -1)
+                idx_f[:, rows_f] = idx[:, rows_f]
+            vis_f = torch.from_numpy(oracle.visibility(idx_f, P).astype(np.uint8))
+            oxf = OverlappedExchange(pf, 2, full.shape[-1], P, "cpu", fold=True)
+            assert oxf.vrows >= 1 and oxf.visible.shape == (P,) and oxf.visible.dtype == torch.uint8
+            for rep in range(2):
+                oxf.image.copy_(full_t[:, rows_f] * (rep + 1))
+                oxf.visible.copy_(vis_f)
+                assert torch.equal(oxf.start(), vis), pf.describe()
+                assert torch.equal(oxf.finish(), full_t * (rep + 1)), pf.describe()
         rs = oracle.backward_radius(sc["radii"], vis.numpy(), sc["first_idx"], sc["num_pts"], 3.0)
         gocc = g_full[..., 3].numpy()
         masked_c = np.zeros_like(gocc)

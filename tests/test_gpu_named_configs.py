@@ -46,16 +46,17 @@ def _cfg3():
     return pts, nrm, col, M, V, 512, scenes.global_h(pts)
 
 
-def _synthetic(P, S, azim, h):
+def _synthetic(P, S, n_cams):
+    """the scene `bench.py --workload cfg4|cfg5` times: same generator, same cameras, same variance scale (scenes.large_cloud_h)"""
     pts, nrm, col = scenes.synthetic_cloud(P, seed=0)
-    M, V, _ = scenes.camera_matrices(2.0, 20.0, azim)
-    return pts, nrm, col, M, V, S, h
+    M, V, _ = scenes.camera_matrices(*scenes.BENCH_CAMERA, scenes.bench_azimuths(n_cams))
+    return pts, nrm, col, M, V, S, scenes.large_cloud_h(pts)
 
 
 CONFIGS = {
     "cfg3": _cfg3,
-    "cfg4": lambda: _synthetic(1_000_000, 1024, [45.0 * k for k in range(8)], 8e-5),
-    "cfg5": lambda: _synthetic(4_000_000, 2048, [45.0], 2e-5),
+    "cfg4": lambda: _synthetic(1_000_000, 1024, 8),
+    "cfg5": lambda: _synthetic(4_000_000, 2048, 1),
 }
 
 

@@ -688,6 +688,19 @@ for cyclic in (False, True):       # contiguous equal bands, and the tile-row-cy
     torch.cuda.synchronize()
     assert torch.equal(img, img1), "graph-segment step: image differs (cyclic=%%s)" %% cyclic
     assert rel(gw, gw1) < 1e-5 and rel(gc, gc1) < 1e-5, ("segments", cyclic, rel(gw, gw1), rel(gc, gc1))
+    # round 5: the folded exchange (two collectives: the visibility flags ride in the image all-gather), eager + segments
+    wl.set_exchange(True)
+    assert wl.fx.fold and wl.fx.vrows >= 1
+    img, gw, gc = wl.step()
+    torch.cuda.synchronize()
+    assert torch.equal(img, img1), "folded exchange: image differs (cyclic=%%s)" %% cyclic
+    assert rel(gw, gw1) < 1e-5 and rel(gc, gc1) < 1e-5, ("fold", cyclic, rel(gw, gw1), rel(gc, gc1))
+    wl.capture_segments()
+    for _ in range(2):
+        img, gw, gc = wl.step_segments()
+    torch.cuda.synchronize()
+    assert torch.equal(img, img1), "folded exchange, graph segments: image differs (cyclic=%%s)" %% cyclic
+    assert rel(gw, gw1) < 1e-5 and rel(gc, gc1) < 1e-5, ("fold segments", cyclic, rel(gw, gw1), rel(gc, gc1))
 open(os.path.join(%r, "ok%%d" %% rank), "w").write("%%g %%g" %% (rel(gw, gw1), rel(gc, gc1)))
 dist.destroy_process_group()
 ''' % (root, str(tmp_path)))
@@ -709,6 +722,7 @@ def test_bench_launches_its_own_ranks():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env["BENCH_DIST_BACKEND"] = "gloo"
+    env["BENCH_EXCHANGE"] = "overlap"   # (the three-collective form: "auto" would time both forms and keep the faster)
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
                           "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
@@ -719,6 +733,7 @@ def test_bench_launches_its_own_ranks():
     assert rec["n_gpus"] == 2 and d["world_size"] == 2 and d["backend"] == "gloo"
     # diagnosable multi-GPU line: the communicator set-up that was used and where the step's time went, per rank
     assert d["overlap"] is True and d["degraded"] is None and d["visible_devices"] >= 1 and "cyclic" in d["partition"]
+    assert d["exchange"]["form"] == "overlap" and d["collectives_per_step"] == 3
     assert rec["config"]["launch"] == "graph_segments" and d["segment_capture"] == "ok"
     t = d["timing_us"]
     for k in ("forward_compute", "backward_compute", "projection_compute", "compute_us", "wait_visibility_allgather",

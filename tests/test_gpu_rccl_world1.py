@@ -56,6 +56,17 @@ for _ in range(3):
     img, gw, gc = wl.step_whole()
 torch.cuda.synchronize()
 out["graph_step"] = {"image_equal": bool(torch.equal(img, img1)), "rel_world": rel(gw, gw1), "rel_colour": rel(gc, gc1)}
+# round 5: the folded exchange (two collectives per step: the flags ride in ONE blocking image all-gather)
+wl.set_exchange(True)
+img, gw, gc = wl.step()
+torch.cuda.synchronize()
+out["fold_eager"] = {"image_equal": bool(torch.equal(img, img1)), "rel_world": rel(gw, gw1), "rel_colour": rel(gc, gc1)}
+wl.capture_whole_step()
+for _ in range(3):
+    img, gw, gc = wl.step_whole()
+torch.cuda.synchronize()
+out["fold_graph_step"] = {"image_equal": bool(torch.equal(img, img1)), "rel_world": rel(gw, gw1), "rel_colour": rel(gc, gc1)}
+out["fold_collectives"] = 2 if wl.fx.fold else 3
 dist.barrier()
 dist.destroy_process_group()
 print("RESULT " + json.dumps(out))
@@ -65,7 +76,9 @@ print("RESULT " + json.dumps(out))
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
     assert out["backend"] == "nccl" and out["world_size"] == 1
     assert out["overlap"] is True and out["degraded"] is None and out["second_communicator"] is True, out
-    for leg in ("eager", "graph_segments", "graph_step"):   # (graph_step: launches AND the three collectives in ONE hipGraph)
+    assert out["fold_collectives"] == 2
+    # (graph_step: launches AND the collectives in ONE hipGraph; fold_*: the two-collective form of the exchange)
+    for leg in ("eager", "graph_segments", "graph_step", "fold_eager", "fold_graph_step"):
         assert out[leg]["image_equal"], (leg, out)
         assert out[leg]["rel_world"] < 1e-5 and out[leg]["rel_colour"] < 1e-5, (leg, out)
     for k in ("wait_visibility_allgather", "wait_gradient_allreduce", "wait_image_allgather", "forward_compute",
@@ -73,12 +86,15 @@ print("RESULT " + json.dumps(out))
         assert out["timing_us"][k] > 0, (k, out["timing_us"])
 
 
-def test_bench_forced_dist_runs_the_rccl_path_on_one_gpu():
+@pytest.mark.parametrize("exchange", ["overlap", "auto"])
+def test_bench_forced_dist_runs_the_rccl_path_on_one_gpu(exchange):
     """`BENCH_FORCE_DIST=1 python bench.py --gpus 1`: the driver's command line with the multi branch forced -- ONE JSON line
     whose `config.dist` records backend nccl, the second communicator in use, graph segments and the time in each
-    collective."""
+    collective.  `overlap`: the three-collective exchange; `auto` (the default): both forms of the exchange are timed on the
+    ranks of the run and the faster one is kept (`config.dist.exchange`)."""
     env = _env()
     env["BENCH_FORCE_DIST"] = "1"
+    env["BENCH_EXCHANGE"] = exchange
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5",
                         "--no-cpu-baseline", "--no-traffic"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
@@ -87,13 +103,20 @@ def test_bench_forced_dist_runs_the_rccl_path_on_one_gpu():
     rec = json.loads(lines[0])
     d = rec["config"]["dist"]
     assert d["backend"] == "nccl" and d["world_size"] == 1 and d["forced"] is True
-    assert d["overlap"] is True and d["degraded"] is None and d["segment_capture"] == "ok", d
+    assert d["degraded"] is None and d["segment_capture"] == "ok", d
     assert d["whole_step_graph"] == "ok", d   # (RCCL 2.26 lets its collectives be captured: the timed step is ONE graph)
     assert rec["config"]["launch"].startswith("graph_step") and rec["n_gpus"] == 1 and rec["value"] > 0
-    for k in ("wait_visibility_allgather", "wait_gradient_allreduce", "wait_image_allgather", "compute_us"):
-        assert d["timing_us"][k]["max"] > 0, (k, d["timing_us"])
+    if exchange == "overlap":
+        assert d["overlap"] is True and d["collectives_per_step"] == 3 and d["exchange"]["form"] == "overlap", d
+        for k in ("wait_visibility_allgather", "wait_gradient_allreduce", "wait_image_allgather", "compute_us"):
+            assert d["timing_us"][k]["max"] > 0, (k, d["timing_us"])
+    else:
+        ex = d["exchange"]
+        assert ex["form"] in ("overlap", "fold") and set(ex["ms_per_step"]) == {"overlap", "fold"}, d
+        assert d["collectives_per_step"] == (2 if ex["form"] == "fold" else 3), d
+        assert ex["ms_per_step"][ex["form"]] == min(ex["ms_per_step"].values()), d
     try:   # keep the line for profiles/ (scratch directory of the GPU box; harmless elsewhere)
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-        open(os.path.join(ROOT, "gpurun_out", "bench_forced_dist_world1.json"), "w").write(lines[0] + "\n")
+        open(os.path.join(ROOT, "gpurun_out", "bench_forced_dist_world1_%s.json" % exchange), "w").write(lines[0] + "\n")
     except OSError:
         pass

@@ -1,12 +1,14 @@
 #!/bin/bash
 # Developer tool (GPU box): every measurement the round's profiles/ files come from, into gpurun_out/$1/ (default r3).
 # Counter passes (--pmc) run on their own with --kernel-trace only; nothing here combines them with other trace domains.
-tag=${1:-r3}
+tag=${1:-r5}
 out=gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 python bench.py > $out/bench.json 2> $out/bench.err
-cp profiles/traffic_fine_kernel.json $out/traffic_fine_kernel.json 2>/dev/null
+# (the counters measured by that very run; the committed fallback profiles/traffic_fine_kernel.json is NOT copied under the
+# round's prefix any more: rounds 3-4 carried five byte-identical copies of the r2_f file)
+cp gpurun_out/traffic_fine_kernel.json $out/traffic_fine_kernel.json 2>/dev/null
 rocprofv3 --kernel-trace --stats -d $out/ks -o b --output-format csv -- python bench.py --mode eager --no-cpu-baseline --no-traffic > /dev/null 2>&1
 cp $(find $out/ks -name '*kernel_stats.csv' | head -1) $out/kernel_stats.csv; rm -rf $out/ks
 python tools/step_timeline.py graph > $out/timeline.txt 2>&1
@@ -14,7 +16,11 @@ python tools/pmc_kernels.py > $out/pmc_sq.txt 2>&1
 for c in cfg3 cfg4 cfg5; do python tools/bench_large.py $c 2>/dev/null | grep '^{' >> $out/bench_large.jsonl; done
 for c in cfg4 cfg5; do DSS_BENCH_MORTON=1 python tools/bench_large.py $c 2>/dev/null | grep '^{' >> $out/bench_large_morton.jsonl; done
 for c in cfg4 cfg5; do
-  rocprofv3 --kernel-trace --stats -d $out/ks -o b --output-format csv -- python tools/bench_large.py $c > /dev/null 2>&1
+  # the driver's entry point, counters and rocprofv3 averages inside the line; the kernel statistics from the timed region
+  # only (--timed-only: bench.py's own pair-counting torch kernels stay out of the trace)
+  python bench.py --workload $c --no-cpu-baseline > $out/bench_$c.json 2> $out/bench_$c.err
+  cp gpurun_out/traffic_fine_kernel_$c.json $out/traffic_fine_kernel_$c.json 2>/dev/null
+  rocprofv3 --kernel-trace --stats -d $out/ks -o b --output-format csv -- python bench.py --workload $c --timed-only --mode eager --no-cpu-baseline --no-traffic > /dev/null 2>&1
   cp $(find $out/ks -name '*kernel_stats.csv' | head -1) $out/kernel_stats_$c.csv; rm -rf $out/ks
 done
 python tools/fetch_large.py cfg4 > $out/fetch_cfg4.txt 2>&1
@@ -22,10 +28,12 @@ python tools/pmc_large.py cfg4 > $out/pmc_sq_cfg4.txt 2>&1
 python tools/fine_timing.py cfg2 > $out/fine_timing_cfg2.txt 2>&1
 python tools/fine_timing.py cfg4 > $out/fine_timing_cfg4.txt 2>&1
 build_ab/valu_rate > $out/valu_rate.txt 2>&1
-python tools/band_timing.py 8 > $out/band_timing.json 2>/dev/null
+for g in 2 4 8; do python tools/band_timing.py $g cfg2 >> $out/band_timing_cfg2.jsonl 2>/dev/null; done
+python tools/band_timing.py 8 cfg4 > $out/band_timing_cfg4.json 2>/dev/null
+python tools/predict_scaling.py cfg2 > $out/predicted_scaling_cfg2.json 2>/dev/null
 python tools/knn_timing.py > $out/knn_timing.json 2>/dev/null
 for c in cfg2 cfg3 cfg4 cfg5; do python tools/gather_split.py $c >> $out/gather_split.jsonl 2>/dev/null; done
 BENCH_DIST_BACKEND=gloo python bench.py --gpus 2 --no-cpu-baseline 2>/dev/null | grep '^{' > $out/bench_2ranks_gloo_one_gpu.json
 [ -n "$COLLECT_REF_LOOP" ] && python tools/train_mvr_ref.py $out/ref 30 > $out/train_mvr_ref.log 2>&1
-rm -rf gpurun_out/libdss_hip_timing.so gpurun_out/fine_timing.npy $out/ref/train_mvr_ref_prof $out/ref/*.pt $out/ref/*.png gpurun_out/timeline gpurun_out/pmc_sq gpurun_out/pmc_large gpurun_out/fetch_large gpurun_out/traffic
+rm -rf gpurun_out/libdss_hip_timing.so gpurun_out/fine_timing.npy gpurun_out/traffic_cfg4 gpurun_out/traffic_cfg5 $out/ref/train_mvr_ref_prof $out/ref/*.pt $out/ref/*.png gpurun_out/timeline gpurun_out/pmc_sq gpurun_out/pmc_large gpurun_out/fetch_large gpurun_out/traffic
 ls -la $out

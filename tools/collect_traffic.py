@@ -16,7 +16,12 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-OUT = os.path.join(ROOT, "gpurun_out", "traffic")
+# `--workload cfg4|cfg5`: the same passes over `bench.py --workload ...` (eager launches, the renderer's cached point order
+# inside the timed region): the line of the large workloads then carries its own counters and rocprofv3 averages
+WORKLOAD = sys.argv[sys.argv.index("--workload") + 1] if "--workload" in sys.argv else "cfg2"
+LARGE = WORKLOAD != "cfg2"
+WL_ARGS = ["--workload", WORKLOAD] if LARGE else []
+OUT = os.path.join(ROOT, "gpurun_out", "traffic" + ("_" + WORKLOAD if LARGE else ""))
 KERNEL = "fine_kernel"
 OTHER = "render_backward_kernel"   # the backward gather: reported next to it (same passes)
 OTHER_MEAN = {}
@@ -27,7 +32,8 @@ def one_pass(counter):
     os.makedirs(d, exist_ok=True)
     env = dict(os.environ, TMPDIR="/tmp")
     cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "--",
-           sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "eager", "--timed-only", "--steps", "20", "--warmup", "5"]
+           sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "eager", "--timed-only", "--steps", "16" if LARGE else "20",
+           "--warmup", "2" if LARGE else "5"] + WL_ARGS
     subprocess.run(cmd, cwd="/tmp", env=env, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     vals, other = [], []
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
@@ -51,7 +57,8 @@ def trace_pass():
     os.makedirs(d, exist_ok=True)
     env = dict(os.environ, TMPDIR="/tmp")
     cmd = ["rocprofv3", "--kernel-trace", "--output-format", "csv", "-d", d, "--",
-           sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "graph", "--timed-only", "--steps", "100", "--warmup", "10"]
+           sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "eager" if LARGE else "graph", "--timed-only", "--steps",
+           "16" if LARGE else "100", "--warmup", "2" if LARGE else "10"] + WL_ARGS
     subprocess.run(cmd, cwd="/tmp", env=env, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     acc = {}
     for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
@@ -69,7 +76,8 @@ def main():
         prof_ms, prof_n = trace_pass()
     except Exception:  # noqa: BLE001  (the traffic numbers stand on their own)
         prof_ms, prof_n = {}, {}
-    rec = {"kernel": "fine_kernel<5>", "command": "bench.py --mode eager --steps 20 (BASELINE configs[1])",
+    rec = {"kernel": "fine_kernel<5>", "workload": WORKLOAD,
+           "command": "bench.py --mode eager --timed-only --steps %s%s" % ("16" if LARGE else "20", " --workload " + WORKLOAD if LARGE else " (BASELINE configs[1])"),
            "FETCH_SIZE_KiB_raw": fetch, "WRITE_SIZE_KiB_raw": write, "samples": [nf, nw],
            "correction": "FETCH_SIZE x2 (gfx950 counts 128-B requests at 64 B), WRITE_SIZE as reported",
            "traffic_bytes_per_launch": int((2.0 * fetch + write) * 1024)}
@@ -79,7 +87,7 @@ def main():
     rec["rocprof_kernel_dispatches"] = prof_n
     rec["rocprof_kernel_ms_how"] = "rocprofv3 --kernel-trace (no counters) over bench.py --mode graph --steps 100: mean End - Start"
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", "traffic_fine_kernel.json"), "w") as f:
+    with open(os.path.join(ROOT, "gpurun_out", "traffic_fine_kernel%s.json" % ("_" + WORKLOAD if LARGE else "")), "w") as f:
         json.dump(rec, f, indent=1)
     print(json.dumps(rec))
 

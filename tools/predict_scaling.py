@@ -1,0 +1,99 @@
+#!/usr/bin/env python3
+"""Developer tool (GPU box, ONE GPU): the 1/2/4/8-GPU scaling table of `bench.py` PREDICTED from what one GPU can measure --
+labelled as such in its output; no N > 1 run has been available to this build (SCALE_r01..r05 are `skipped` records).
+
+    per-rank compute (measured, emulated)   tools/band_timing.py G <workload>: every rank's rows of the G-rank step rendered on
+                                            this GPU, global visibility, no collectives, replayed as a hipGraph; the slowest
+                                            rank sets the step
+  + collective floor (measured, world 1)    `BENCH_FORCE_DIST=1 bench.py --gpus 1` (the RCCL path in a world of one rank, whole
+                                            step as one graph) minus the same step's compute: what the collectives of a step
+                                            cost when no byte crosses a link -- a LOWER bound for any world size
+  = predicted step                          value = G x points / step; efficiency against the single-GPU line
+  (+ link time, ESTIMATED, reported beside) bytes per rank of the image all-gather and the gradient all-reduce over 7 xGMI
+                                            links x 153 GB/s (MI355X_MICROARCH.md), direct schedule; the overlapped exchange hides
+                                            the image bands behind the backward, the folded one does not
+
+    python tools/predict_scaling.py [cfg2|cfg4]  -> one JSON object on stdout"""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+which = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
+XGMI_LINK_GBS, LINKS = 153.0, 7
+
+
+def run(cmd, env=None, timeout=900):
+    e = dict(os.environ)
+    e.update(env or {})
+    r = subprocess.run(cmd, env=e, capture_output=True, text=True, timeout=timeout)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    if r.returncode != 0 or not lines:
+        raise RuntimeError("%s failed: %s" % (" ".join(cmd), (r.stdout + r.stderr)[-600:]))
+    return json.loads(lines[-1])
+
+
+py = sys.executable
+out = {"what": "PREDICTED scaling of `bench.py --gpus G%s` -- per-rank compute emulated on ONE GPU + the collective floor "
+               "measured at world size 1; NOT a measurement at G > 1" % ("" if which == "cfg2" else " --workload " + which),
+       "workload": which}
+bands = {}
+for G in (1, 2, 4, 8):
+    lay = "bands" if G == 1 else ("balanced,cyclic" if which == "cfg2" else "bands,cyclic")
+    bands[G] = run([py, os.path.join(ROOT, "tools", "band_timing.py"), str(G), which], {"BAND_LAYOUTS": lay})
+Pc, S = bands[1]["points_per_cloud"], bands[1]["image_size"]
+cams = {G: bands[G]["cameras"] for G in bands}
+out["per_rank_compute_us"] = {str(G): {k: {"max": v["graph_max_us"], "per_rank": v["graph_us"]} for k, v in b.items()
+                                       if isinstance(v, dict) and "graph_us" in v} for G, b in bands.items()}
+# the multi-GPU step's own compute at world size 1 (clip after the reduction, projection in a launch of its own) and the
+# single-GPU headline step
+multi1 = bands[1]["bands"]["graph_max_us"]
+floors = {}
+if which == "cfg2":
+    single = run([py, os.path.join(ROOT, "bench.py"), "--timed-only", "--no-cpu-baseline", "--no-traffic"])
+    single_us = single["ms_per_step"] * 1e3
+    for form in ("overlap", "fold"):
+        f = run([py, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--timed-only", "--no-cpu-baseline", "--no-traffic"],
+                {"BENCH_FORCE_DIST": "1", "BENCH_EXCHANGE": form})
+        floors[form] = {"forced_world1_step_us": round(f["ms_per_step"] * 1e3, 2), "launch": f["launch"],
+                        "collective_floor_us": round(max(f["ms_per_step"] * 1e3 - multi1, 0.0), 2)}
+else:
+    single_us = bands[1]["single_gpu_step_us"]["eager"]
+    # (the large workloads run eagerly; the collective floor of the metric's configuration is latency, not bytes: reused)
+    try:
+        prev = json.load(open(os.path.join(ROOT, "profiles", "r5_a_predicted_scaling_cfg2.json")))
+        floors = {k: {"collective_floor_us": v["collective_floor_us"], "from": "profiles/r5_a_predicted_scaling_cfg2.json"}
+                  for k, v in prev["collective_floor"].items()}
+    except Exception:  # noqa: BLE001
+        floors = {"overlap": {"collective_floor_us": 20.0, "from": "round-4 measurement (78.3 - 58 us)"}}
+out["single_gpu_step_us"] = round(single_us, 2)
+out["multi_step_compute_world1_us"] = multi1
+out["collective_floor"] = floors
+weak = which == "cfg2"
+table = []
+for G in (1, 2, 4, 8):
+    for layout, v in out["per_rank_compute_us"][str(G)].items():
+        row = {"G": G, "layout": layout, "max_rank_compute_us": v["max"]}
+        for form, fl in floors.items():
+            step = v["max"] + (fl["collective_floor_us"] if G > 1 else 0.0)
+            if G == 1:
+                step = single_us
+            splats = cams[G] * Pc
+            row["predicted_step_us_" + form] = round(step, 1)
+            row["predicted_Msplats_per_s_" + form] = round(splats / step, 1)
+            row["predicted_speedup_" + form] = round((splats / step) / (cams[1] * Pc / single_us), 2)
+        # link time of the two big collectives, estimated (bytes a rank sends / receives over its 7 links)
+        n_img = cams[G]
+        img_bytes_rank = n_img * S * S * 16 / G
+        grad_bytes = n_img * Pc * 24
+        if G > 1:
+            row["estimated_link_us"] = {
+                "image_all_gather": round(img_bytes_rank * (G - 1) / (min(G - 1, LINKS) * XGMI_LINK_GBS * 1e3), 1),
+                "gradient_all_reduce": round(2 * grad_bytes * (G - 1) / G / (min(G - 1, LINKS) * XGMI_LINK_GBS * 1e3), 1),
+                "note": "direct (fully connected) schedule at the link peak; RCCL's measured bus bandwidth at these sizes is "
+                        "lower.  Overlapped exchange: the image bands travel during the backward; folded: before it"}
+        table.append(row)
+out["table"] = table
+out["scaling"] = "weak (G cameras, one per rank's worth of rows x cameras)" if weak else "strong (fixed job, rows shared by G ranks)"
+print(json.dumps(out))
