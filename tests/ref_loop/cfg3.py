@@ -40,7 +40,7 @@ def reference_root(tmp):
                        "on a machine that has the reference checkout; the archive then travels to the GPU box")
 
 
-def write_configs(tmp, size=SIZE, points=POINTS, batch=BATCH):
+def write_configs(tmp, size=SIZE, points=POINTS, batch=BATCH, backup_every=0):
     """-> (class-level yml, c-level yml): dss.yml's parameters; the first selects the drop-in classes (INTEGRATION.md
     section 2), the second keeps the reference's OWN classes (configs/default.yaml) for `launcher --c-level`."""
     cfg = {
@@ -57,7 +57,8 @@ def write_configs(tmp, size=SIZE, points=POINTS, batch=BATCH):
                               "cutoff_threshold": 1.0, "depth_merging_threshold": 0.05, "image_size": size,
                               "points_per_pixel": 5, "radii_backward_scaler": 5},
         },
-        "training": {"out_dir": os.path.join(tmp, "exp"), "backup_every": 0, "batch_size": batch, "checkpoint_every": 0,
+        # backup_every = k: train_mvr.py:192-196 saves model_<it>.pt at every k-th ITERATION (a snapshot by iteration count)
+        "training": {"out_dir": os.path.join(tmp, "exp"), "backup_every": int(backup_every), "batch_size": batch, "checkpoint_every": 0,
                      "debug_every": 0, "visualize_every": 0, "validate_every": 0, "print_every": 1,
                      "lambda_dr_proj": 0.01, "lambda_dr_repel": 0.0, "lambda_dr_rgb": 1.0, "lambda_dr_silhouette": 1.0,
                      "n_workers": 0, "steps_dss_backward_radii": 200, "gamma_dss_backward_radii": 0.9,

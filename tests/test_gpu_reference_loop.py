@@ -103,15 +103,20 @@ def test_reference_train_mvr_converges_from_the_sphere_at_the_size_of_dss_yml(tm
     trains (`n_points_per_cloud: 5000`), and from the sphere its loss rises.  Here the SAME unmodified script and dataset
     (99,790-point yoga6 target, 128 CameraSampler views at 512^2, batches of 8, dss.yml raster parameters and weights) with
     dss.yml's own model size: the loss the reference's Trainer logs must FALL (last decile < 0.8 x first decile) and the
-    model must move towards the target surface (symmetric chamfer distance to the target cloud, the quantity
-    `Trainer.evaluate_3d` (trainer.py:144) reports, lower at the end than after the first iterations)."""
+    model must move ONTO the target surface: the median model -> target distance and the target -> model distance (coverage)
+    fall between the snapshot after FIVE iterations (`backup_every: 5` -> model_5.pt, train_mvr.py:192-196: by iteration count,
+    not by wall clock) and the end.  The symmetric chamfer distance (`Trainer.evaluate_3d`, trainer.py:144) does NOT fall: its
+    model -> target MEAN is dominated by the ~30 % of the points that the reference's optimisation (Adam(lr 0.01), no pruning:
+    point_modeling.py:131-132 is commented out) carries out of the view volume.  That this belongs to the reference and not to
+    the HIP gradient is MEASURED on the CPU by `tools/convergence_crosscheck_cpu.py` (profiles/r5_a_convergence_crosscheck_cpu.json):
+    the reference's own rasterizer / renderer classes on the oracle double lose the same fraction of the sphere."""
     import json
     import numpy as np
     import torch
     from scipy.spatial import cKDTree
     tmp = str(tmp_path)
     ref = cfg3.reference_root(tmp)
-    cfg_cls, _ = cfg3.write_configs(tmp, points=5000)
+    cfg_cls, _ = cfg3.write_configs(tmp, points=5000, backup_every=5)
     sc = os.path.join(tmp, "scalars_5000.jsonl")
     common = ["--reference", ref]
     r = cfg3.run(common + ["--config", cfg_cls, "--make-dataset", os.path.join(tmp, "data"), "--views", str(cfg3.VIEWS),
@@ -131,12 +136,15 @@ def test_reference_train_mvr_converges_from_the_sphere_at_the_size_of_dss_yml(tm
                 "model_points_farther_than_0.2": float((d_mt > 0.2).mean())}
 
     model_pt = os.path.join(tmp, "exp", "dropin", "model.pt")
-    # a few iterations from the sphere.  ONE second, not more: the snapshot is taken by time (train_mvr.py's own --exit-after),
-    # and since the renderer's host path got faster (18 ms per iteration of the reference's loop, 42 before) three seconds
-    # were already 160 iterations -- most of the early drop of the target -> model distance (1.13e-3 -> 0.78e-3) behind it
-    r = cfg3.run(common + ["--config", cfg_cls, "--scalars", sc, "--exit-after", "1"], 600)
+    # the early snapshot is taken by ITERATION COUNT: the first leg runs with `backup_every: 5` (train_mvr.py saves
+    # model_5.pt, model_10.pt, ... at those iterations) for a few seconds; the later legs run without backups.  (Round 4 took
+    # the snapshot after one second of wall clock: 50-160 iterations depending on the box)
+    r = cfg3.run(common + ["--config", cfg_cls, "--scalars", sc, "--exit-after", "3"], 600)
     assert cfg3.reached_time_limit(r), r.stdout[-4000:]
-    cd_early = chamfer(model_pt)
+    early_pt = os.path.join(tmp, "exp", "dropin", "model_5.pt")
+    assert os.path.isfile(early_pt), os.listdir(os.path.join(tmp, "exp", "dropin"))
+    cd_early = chamfer(early_pt)
+    cfg_cls, _ = cfg3.write_configs(tmp, points=5000, backup_every=0)
     loss, legs = [], 0
     while len(loss) < 1200 and legs < 4:   # resumes from its own model.pt (train_mvr.py:98-103)
         legs += 1
@@ -148,7 +156,7 @@ def test_reference_train_mvr_converges_from_the_sphere_at_the_size_of_dss_yml(tm
     assert n >= 600, (n, legs)
     deciles = [sum(loss[i * n // 10:(i + 1) * n // 10]) / ((i + 1) * n // 10 - i * n // 10) for i in range(10)]
     rec = {"points_per_cloud": 5000, "iterations": n, "ms_per_iteration": cfg3.ms_per_iteration(times, steps),
-           "loss_deciles": deciles, "chamfer_after_first_iterations": cd_early, "chamfer_at_end": cd_late}
+           "loss_deciles": deciles, "chamfer_after_5_iterations": cd_early, "chamfer_at_end": cd_late}
     print("dss.yml-sized model from the sphere:", json.dumps(rec))
     print("distances after the first iterations:", cd_early)
     print("distances at the end               :", cd_late)
@@ -167,7 +175,7 @@ def test_reference_train_mvr_converges_from_the_sphere_at_the_size_of_dss_yml(tm
     # view volume, 0.01 per iteration.  That is the reference's optimisation (the C-level leg of the test above reproduces
     # the class-level trajectory); both halves are recorded.
     assert cd_late["model_to_target_median"] < 0.5 * cd_early["model_to_target_median"], (cd_early, cd_late)
-    # (coverage of the target: 0.69 ... 0.72e-3 at the end in every run; the early value depends on how many iterations fit
-    # into the first second -- 7.5e-2, practically the initial sphere, when the first iteration's one-off work fills it)
-    assert cd_late["target_to_model"] < 0.9 * cd_early["target_to_model"] and cd_late["target_to_model"] < 0.9e-3, (cd_early, cd_late)
+    # (coverage of the target: 0.69 ... 0.72e-3 at the end in every run; after five iterations the model is practically the
+    # initial sphere: 7.5e-2)
+    assert cd_late["target_to_model"] < 0.1 * cd_early["target_to_model"] and cd_late["target_to_model"] < 0.9e-3, (cd_early, cd_late)
     assert cd_late["model_points_farther_than_0.2"] < cd_early["model_points_farther_than_0.2"], (cd_early, cd_late)
