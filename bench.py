@@ -661,12 +661,15 @@ def main():
     cyclic = world > 1 and world & (world - 1) == 0 and S % (8 * world) == 0 and layout == "cyclic"
     part = RowPartition(S, world, rank, cyclic=cyclic)
     wl = Workload(dev, cams, part, cloud=cloud, multi=multi)
-    # end-of-forward exchange: measured, not assumed.  BENCH_EXCHANGE=overlap|fold fixes the form; "auto" (default) times a few
-    # eager steps of both forms on THESE ranks (max over the ranks, so that every rank takes the same decision) and keeps the
-    # faster: three collectives with the image bands off the critical path, or two with the flags folded into the image
-    # all-gather -- which one wins depends on the link time of the bands against the latency of a collective.
+    # end-of-forward exchange: BENCH_EXCHANGE=overlap (default) | fold | auto (both forms are prepared in the launch mode of the
+    # timed region and timed on THESE ranks, max over the ranks, and the faster is kept): three collectives with the image bands
+    # off the critical path, or two with the flags folded into the image all-gather
     exchange_note = None
-    want_exchange = os.environ.get("BENCH_EXCHANGE", "auto") if multi else None
+    # (default: the three-collective form.  Measured at world size 1 in the launch mode of the timed region the folded form is
+    # 11 us per step SLOWER -- its two extra kernels and the stream fork cost more than the collective they save,
+    # profiles/r5_a_bench_forced_dist_world1_auto.json -- and at N > 1 it puts the image bytes on the critical path; the
+    # comparison on the ranks of the run is BENCH_EXCHANGE=auto, and costs two more graph captures per rank)
+    want_exchange = os.environ.get("BENCH_EXCHANGE", "overlap") if multi else None
 
     def capture(unroll=1, side=None):
         side = side or torch.cuda.Stream()   # (the forward workspace -- and a saved point order in it -- is cached per stream)

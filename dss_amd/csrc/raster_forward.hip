@@ -18,6 +18,15 @@
 // The per-pair arithmetic (dx, dy, Q, comparisons) is written exactly like the reference
 // (rasterize_points.cu:64-124) and compiled with -ffp-contract=off, so fragments are bit-identical
 // to the reference CPU/CUDA naive path; the K-set is defined by the total order (z, idx).
+#ifdef DSS_FINE_TIMING
+#include <hip/hip_runtime.h>
+namespace dss { extern __device__ long long *g_fine_timing; }
+#define DSS_SETUP_MARK(slot)                                                                                                  \
+    do {                                                                                                                      \
+        if (dss::g_fine_timing && threadIdx.x == 0)                                                                           \
+            dss::g_fine_timing[((size_t)blockIdx.x + 8192) * 12 + (slot)] = (long long)__builtin_amdgcn_s_memrealtime();       \
+    } while (0)
+#endif
 #include "setup_body.h"
 #include <stdlib.h>
 #include <atomic>
@@ -224,6 +233,10 @@ __device__ __forceinline__ void bin_point(int64_t p, int n, float px, float py, 
     if (n < 0) return;
     int tx0, tx1, ty0, ty1;
     if (!splat_tile_rect(px, py, pz, rx, ry, g, tx0, tx1, ty0, ty1)) return;
+#ifdef DSS_FINE_TIMING
+    asm volatile("" ::"v"(tx0), "v"(tx1), "v"(ty0), "v"(ty1));   // (the tile rectangle is known)
+    FT_MARK_S(8);
+#endif
     const size_t sub0 = ((size_t)n * g.tiles_x * g.tiles_y) * DSS_SUB + ((unsigned)p & (DSS_SUB - 1));
     if (tx1 - tx0 <= 1 && ty1 - ty0 <= 1) {
         // common case (splat overlaps at most 2x2 tiles): the returning atomics are independent, issue
@@ -232,6 +245,10 @@ __device__ __forceinline__ void bin_point(int64_t p, int n, float px, float py, 
         const size_t t01 = t00 + DSS_SUB, t10 = t00 + (size_t)g.tiles_x * DSS_SUB, t11 = t10 + DSS_SUB;
         const bool hx = tx1 > tx0, hy = ty1 > ty0;
         uint32_t p0, p1 = 1, p2 = 1, p3 = 1;
+#ifdef DSS_FINE_TIMING
+        asm volatile("" ::"v"(t00), "s"(cap));   // (addresses and the list capacity -- a late kernel argument -- are there)
+        FT_MARK_S(9);
+#endif
         p0 = atomicAdd(&counts[t00], 1u);
         if (hx) p1 = atomicAdd(&counts[t01], 1u);
         if (hy) p2 = atomicAdd(&counts[t10], 1u);
@@ -310,7 +327,15 @@ __global__ __launch_bounds__(256) void setup_bin_kernel(const SetupArgs A, TileG
         if (!reach) return;
         px = v.sx; py = v.sy; pz = v.sz; rx = v.rx; ry = v.ry;
     } else {
+#ifdef DSS_FINE_TIMING
+        const SetupVals v = setup_point_compute(A, p, n);
+        asm volatile("" ::"v"(v.rx), "v"(v.ry), "v"(v.sc), "v"(v.ea));   // (the arithmetic has finished)
+        FT_MARK_S(6);
+        setup_point_store(A, p, v);
+        px = v.sx; py = v.sy; pz = v.sz; rx = v.rx; ry = v.ry;
+#else
         setup_point(A, p, n, px, py, pz, rx, ry);
+#endif
     }
     FT_MARK_S(2);
     bin_point(p, n, px, py, pz, rx, ry, g, counts, lists, cap, tq, sp);

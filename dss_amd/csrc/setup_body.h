@@ -3,6 +3,10 @@
 #pragma once
 #include "common.h"
 
+#ifndef DSS_SETUP_MARK
+#define DSS_SETUP_MARK(slot)   // (timing builds of raster_forward.hip stamp the setup's phases: tools/setup_timing.py)
+#endif
+
 namespace dss {
 
 __device__ __forceinline__ float eps_sqrt_py(float d) { return fmaxf(fabsf(d), 1e-17f); }  // mathHelper.py:16-21
@@ -54,6 +58,10 @@ __device__ __forceinline__ SetupVals setup_point_compute(const SetupArgs &A, int
         const float *v = A.V + 16 * n;
         const float ph0 = A.world[3 * wi], ph1 = A.world[3 * wi + 1], ph2 = A.world[3 * wi + 2], ph3 = 1.0f;
         const float n0 = A.normals[3 * wi], n1 = A.normals[3 * wi + 1], n2 = A.normals[3 * wi + 2];
+#ifdef DSS_FINE_TIMING
+        asm volatile("" ::"v"(ph0), "v"(ph2), "v"(n0), "v"(n2));   // (the inputs have arrived)
+        DSS_SETUP_MARK(7);
+#endif
         const float zview = ph0 * v[2] + ph1 * v[6] + ph2 * v[10] + ph3 * v[14];
         // _filter_points_with_invalid_depth, rasterizer.py:183-217
         ok = (zview >= A.znear[n]) && (zview <= A.zfar[n]);

@@ -90,8 +90,8 @@ print("RESULT " + json.dumps(out))
 def test_bench_forced_dist_runs_the_rccl_path_on_one_gpu(exchange):
     """`BENCH_FORCE_DIST=1 python bench.py --gpus 1`: the driver's command line with the multi branch forced -- ONE JSON line
     whose `config.dist` records backend nccl, the second communicator in use, graph segments and the time in each
-    collective.  `overlap`: the three-collective exchange; `auto` (the default): both forms of the exchange are timed on the
-    ranks of the run and the faster one is kept (`config.dist.exchange`)."""
+    collective.  `overlap` (the default): the three-collective exchange; `auto`: both forms of the exchange are prepared in
+    the launch mode of the timed region, timed on the ranks of the run and the faster one is kept (`config.dist.exchange`)."""
     env = _env()
     env["BENCH_FORCE_DIST"] = "1"
     env["BENCH_EXCHANGE"] = exchange

@@ -29,9 +29,11 @@ for rep in range(3):
     t = t[used]
     t0 = t[:, 0].min()
     us = lambda a: (a - t0) / 100.0
-    names = ["start", "cloud found", "setup done (stores issued)", "counter atomics issued", "atomics returned", "claims + list stores done"]
+    names = {0: "start", 1: "cloud found", 7: "inputs arrived", 6: "arithmetic done", 2: "setup done (stores issued)",
+             8: "tile rectangle known", 9: "addresses ready", 3: "counter atomics issued", 4: "atomics returned",
+             5: "claims + list stores done"}
     print("rep %d: %d wavefronts" % (rep, len(t)))
-    for i, nm in enumerate(names):
+    for i, nm in names.items():
         col = t[:, i][t[:, i] > 0]
         if len(col):
             print("  %-30s mean %6.2f  p90 %6.2f  max %6.2f us (%d)" % (nm, us(col).mean(), np.percentile(us(col), 90), us(col).max(), len(col)))
