@@ -20,8 +20,7 @@ import scenes  # noqa: E402
 which = sys.argv[1] if len(sys.argv) > 1 else "cfg4"
 P, S, N = {"cfg4": (1_000_000, 1024, 8), "cfg5": (4_000_000, 2048, 1), "cfg3": (99_790, 512, 8)}[which]
 pts, nrm, col = scenes.synthetic_cloud(P, seed=0)
-h = scenes.global_h(pts[:: max(1, P // 200_000)]) * (200_000 / P if P > 200_000 else 1.0)  # density-scaled estimate
-h = float(np.clip(h, 5e-6, 1e-3))
+h = scenes.large_cloud_h(pts)   # (the one definition shared with bench.py::large_cloud and tests/test_gpu_named_configs.py)
 if os.environ.get("DSS_BENCH_MORTON") == "1":
     # spatially coherent point order (what a scanned or mesh-sampled cloud usually has; dss_amd.cloud.spatial_order)
     from dss_amd.cloud import spatial_order

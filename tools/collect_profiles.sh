@@ -31,6 +31,15 @@ build_ab/valu_rate > $out/valu_rate.txt 2>&1
 for g in 2 4 8; do python tools/band_timing.py $g cfg2 >> $out/band_timing_cfg2.jsonl 2>/dev/null; done
 python tools/band_timing.py 8 cfg4 > $out/band_timing_cfg4.json 2>/dev/null
 python tools/predict_scaling.py cfg2 > $out/predicted_scaling_cfg2.json 2>/dev/null
+python tools/predict_scaling.py cfg4 > $out/predicted_scaling_cfg4.json 2>/dev/null
+# one emulated rank of the 8-rank step under the kernel trace (metric's configuration: cyclic bands; configs[3]: contiguous)
+BAND_TRACE=1 BAND_TRACE_LAYOUT=cyclic rocprofv3 --kernel-trace --stats -d $out/ks -o b --output-format csv -- python tools/band_timing.py 8 cfg2 > /dev/null 2>&1
+cp $(find $out/ks -name '*kernel_stats.csv' | head -1) $out/band_kernel_stats_cfg2_cyclic_rank3.csv; rm -rf $out/ks
+BAND_TRACE=1 BAND_TRACE_LAYOUT=bands rocprofv3 --kernel-trace --stats -d $out/ks -o b --output-format csv -- python tools/band_timing.py 8 cfg4 > /dev/null 2>&1
+cp $(find $out/ks -name '*kernel_stats.csv' | head -1) $out/band_kernel_stats_cfg4_bands_rank3.csv; rm -rf $out/ks
+{ python tools/band_fused_timing.py 8 cyclic 3; TIMING_REBUILD=0 python tools/band_fused_timing.py 8 balanced 3; } > $out/band_gather_stamps.txt 2>&1
+python tools/setup_timing.py > $out/setup_timing.txt 2>&1
+for e in overlap auto; do BENCH_FORCE_DIST=1 BENCH_EXCHANGE=$e python bench.py --gpus 1 --no-cpu-baseline --no-traffic 2>/dev/null | grep '^{' > $out/bench_forced_dist_world1_$e.json; done
 python tools/knn_timing.py > $out/knn_timing.json 2>/dev/null
 for c in cfg2 cfg3 cfg4 cfg5; do python tools/gather_split.py $c >> $out/gather_split.jsonl 2>/dev/null; done
 BENCH_DIST_BACKEND=gloo python bench.py --gpus 2 --no-cpu-baseline 2>/dev/null | grep '^{' > $out/bench_2ranks_gloo_one_gpu.json
