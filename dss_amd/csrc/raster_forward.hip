@@ -224,15 +224,12 @@ __device__ __forceinline__ void claim_tile(const TileQueue tq, int n, int tx, in
     if (pos < tq.capq) tq.list[(size_t)q * tq.capq + pos] = tile + 1;  // (always true: queue_capacity)
 }
 
-// append splat p to the sub-list (p mod SUB) of every tile of its rectangle
-__device__ __forceinline__ void bin_point(int64_t p, int n, float px, float py, float pz, float rx, float ry,
-                                          const TileGrid g, uint32_t *__restrict__ counts,
-                                          int32_t *__restrict__ lists, uint32_t cap, const TileQueue tq,
-                                          const Spill sp)
+// append splat p to the sub-list (p mod SUB) of every tile of its (non-empty) tile rectangle [tx0, tx1] x [ty0, ty1]
+__device__ __forceinline__ void bin_rect(int64_t p, int n, int tx0, int tx1, int ty0, int ty1,
+                                         const TileGrid g, uint32_t *__restrict__ counts,
+                                         int32_t *__restrict__ lists, uint32_t cap, const TileQueue tq,
+                                         const Spill sp)
 {
-    if (n < 0) return;
-    int tx0, tx1, ty0, ty1;
-    if (!splat_tile_rect(px, py, pz, rx, ry, g, tx0, tx1, ty0, ty1)) return;
 #ifdef DSS_FINE_TIMING
     asm volatile("" ::"v"(tx0), "v"(tx1), "v"(ty0), "v"(ty1));   // (the tile rectangle is known)
     FT_MARK_S(8);
@@ -287,6 +284,18 @@ __device__ __forceinline__ void bin_point(int64_t p, int n, float px, float py, 
         }
 }
 
+// append splat p to the sub-list (p mod SUB) of every tile of its rectangle
+__device__ __forceinline__ void bin_point(int64_t p, int n, float px, float py, float pz, float rx, float ry,
+                                          const TileGrid g, uint32_t *__restrict__ counts,
+                                          int32_t *__restrict__ lists, uint32_t cap, const TileQueue tq,
+                                          const Spill sp)
+{
+    if (n < 0) return;
+    int tx0, tx1, ty0, ty1;
+    if (!splat_tile_rect(px, py, pz, rx, ry, g, tx0, tx1, ty0, ty1)) return;
+    bin_rect(p, n, tx0, tx1, ty0, ty1, g, counts, lists, cap, tq, sp);
+}
+
 __global__ __launch_bounds__(256) void bin_kernel(
     const float *__restrict__ points, const float *__restrict__ radii,
     const int64_t *__restrict__ first_idx, const int64_t *__restrict__ num_pts, int N, int64_t P,
@@ -324,8 +333,10 @@ __global__ __launch_bounds__(256) void setup_bin_kernel(const SetupArgs A, TileG
         int tx0, tx1, ty0, ty1;
         const bool reach = n >= 0 && splat_tile_rect(v.sx, v.sy, v.sz, v.rx, v.ry, g, tx0, tx1, ty0, ty1);
         setup_point_store(A, p, v, reach);
-        if (!reach) return;
-        px = v.sx; py = v.sy; pz = v.sz; rx = v.rx; ry = v.ry;
+        FT_MARK_S(2);
+        if (reach) bin_rect(p, n, tx0, tx1, ty0, ty1, g, counts, lists, cap, tq, sp);   // (the rectangle is computed once)
+        FT_MARK_S(5);
+        return;
     } else {
 #ifdef DSS_FINE_TIMING
         const SetupVals v = setup_point_compute(A, p, n);
