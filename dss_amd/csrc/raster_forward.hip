@@ -361,7 +361,9 @@ __device__ __forceinline__ bool spill_pass(
     const float *__restrict__ points, const float *__restrict__ radii, const int64_t *__restrict__ first_idx,
     const int64_t *__restrict__ num_pts, int N, int64_t P, const TileGrid g, const uint32_t *__restrict__ counts, uint32_t cap,
     const Spill sp, int sorted /* 1: the lists were filled by bin_sorted_kernel (sub-list in bits 4..6 of the mask byte) */,
-    unsigned block, unsigned nblocks)
+    unsigned block, unsigned nblocks,
+    const float4 *__restrict__ crec = nullptr /* sorted path: mask bytes, list and pool entries are POSITIONS of the order; */,
+    const int32_t *__restrict__ s_id = nullptr /* the splat's geometry comes from its candidate record, its id from the order */)
 {
     if (__builtin_amdgcn_readfirstlane((int)sp.ctrl[0]) == 0) return false;
     // The mask bytes are scanned SIXTEEN per load (the array is 256-byte aligned and padded to 256 bytes with zeros).  One
@@ -379,11 +381,16 @@ __device__ __forceinline__ bool spill_pass(
     const int64_t p = 16 * v + mb;
     if (full == 0 || p >= P) continue;
     sp.mask[p] = 0;  // (this thread is the byte's only reader: the DSS_WS_CLEAN state is restored here)
-    const int n = find_cloud(p, first_idx, num_pts, N);
+    const int n = find_cloud(crec ? (int64_t)s_id[p] : p, first_idx, num_pts, N);
     int tx0, tx1, ty0, ty1;
-    if (n < 0 || !splat_tile_rect(points[3 * p], points[3 * p + 1], points[3 * p + 2], radii[2 * p], radii[2 * p + 1], g, tx0,
-                                  tx1, ty0, ty1))
-        continue;
+    float gx, gy, gz, grx, gry;
+    if (crec) {
+        const float4 c0 = crec[2 * (size_t)p], c1 = crec[2 * (size_t)p + 1];
+        gx = c0.x; gy = c0.y; gz = c1.w; grx = c0.z; gry = c0.w;
+    } else {
+        gx = points[3 * p]; gy = points[3 * p + 1]; gz = points[3 * p + 2]; grx = radii[2 * p]; gry = radii[2 * p + 1];
+    }
+    if (n < 0 || !splat_tile_rect(gx, gy, gz, grx, gry, g, tx0, tx1, ty0, ty1)) continue;
     const size_t sub0 = ((size_t)n * g.tiles_x * g.tiles_y) * DSS_SUB + (sorted ? ((full >> 4) & (DSS_SUB - 1)) : ((unsigned)p & (DSS_SUB - 1)));
 #pragma unroll 1
     for (int k = 0; k < 4; ++k) {
@@ -492,7 +499,9 @@ __global__ __launch_bounds__(SORT_THREADS) void setup_cell_kernel(const SetupArg
                                                                    uint32_t *__restrict__ cell_of,
                                                                    uint32_t *__restrict__ block_hist, Spill sp,
                                                                    uint8_t *__restrict__ visible_to_clear,
-                                                                   float4 *__restrict__ geo, TileGrid g, int band_only)
+                                                                   float4 *__restrict__ crec /* (P,2) candidate records by position */,
+                                                                   const int32_t *__restrict__ inv /* MODE 2: position of every splat */,
+                                                                   TileGrid g, int band_only)
 {
     // band_only (DSS_WS_BAND_OUTPUTS, multi-GPU): splats whose tile rectangle misses the rank's band store their screen
     // position, radii and validity only; MODE 0 leaves them out of the sort, MODE 2 marks them in the binning record (rx = -1,
@@ -551,13 +560,21 @@ __global__ __launch_bounds__(SORT_THREADS) void setup_cell_kernel(const SetupArg
                 } else {
                     setup_point_store(A, p, v, reach);
                 }
-                geo[p] = make_float4(v.sx, v.sy, reach ? v.rx : -1.0f, v.ry);
+                const size_t pos = (size_t)min((uint32_t)inv[p], (uint32_t)(A.P - 1));   // (clamped: a lost order cannot fault)
+                crec[2 * pos] = make_float4(v.sx, v.sy, reach ? v.rx : -1.0f, v.ry);
+                crec[2 * pos + 1] = make_float4(v.ea, v.eb, v.ec, v.sz);
                 continue;
             }
             if (full) setup_wave_store(A, p0, v, wave_lds);
             else setup_point_store(A, p, v);
             const bool live = n >= 0 && !(v.sz < 0);   // culled splats (pz = -1) never reach a tile list
-            geo[p] = make_float4(v.sx, v.sy, live ? v.rx : -1.0f, v.ry);
+            {
+                // the candidate record goes to the splat's POSITION in the saved order (two 16-byte stores into one 32-byte
+                // slot: neighbours on the screen are neighbours there)
+                const size_t pos = (size_t)min((uint32_t)inv[p], (uint32_t)(A.P - 1));
+                crec[2 * pos] = make_float4(v.sx, v.sy, live ? v.rx : -1.0f, v.ry);
+                crec[2 * pos + 1] = make_float4(v.ea, v.eb, v.ec, v.sz);
+            }
         }
         return;
     }
@@ -667,10 +684,10 @@ __global__ __launch_bounds__(1024) void sort_cell_scan_kernel(const uint32_t *__
     if (tid == 1023) *sorted_count = s_part[1023];
 }
 __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(
-    const float *__restrict__ points, const float *__restrict__ radii, int64_t P, SortGrid sg, int per_thread,
-    const uint32_t *__restrict__ cell_of,
+    const float *__restrict__ points, const float *__restrict__ radii, const float *__restrict__ ellipse, int64_t P, SortGrid sg,
+    int per_thread, const uint32_t *__restrict__ cell_of,
     const uint32_t *__restrict__ cell_start, const uint32_t *__restrict__ block_base, const uint32_t *__restrict__ seg_base,
-    float4 *__restrict__ s_geo, int32_t *__restrict__ s_id)
+    float4 *__restrict__ crec, int32_t *__restrict__ s_id, int32_t *__restrict__ inv /* saved order only, else nullptr */)
 {
     extern __shared__ uint32_t s_hist[];
     // (merging two or four histogram blocks per scatter workgroup -- longer runs per cell -- measured 2-4 % slower)
@@ -688,9 +705,13 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(
         const float2 rr = reinterpret_cast<const float2 *>(radii)[p];
         // (the last cell only receives splats when the order is saved: the culled ones, rx = -1 for the binning)
         const float4 ge = make_float4(points[3 * p], points[3 * p + 1], key == (uint32_t)(sg.total - 1) ? -1.0f : rr.x, rr.y);
+        // (a splat that wrote position / radii only -- DSS_WS_BAND_OUTPUTS, saved order -- has no ellipse: it is never binned)
+        const float4 el = make_float4(ellipse[3 * p], ellipse[3 * p + 1], ellipse[3 * p + 2], points[3 * p + 2]);
         const uint32_t pos = atomicAdd(&s_hist[key], 1u);
-        s_geo[pos] = ge;
+        crec[2 * (size_t)pos] = ge;
+        crec[2 * (size_t)pos + 1] = el;
         s_id[pos] = (int32_t)p;
+        if (inv) inv[p] = (int32_t)pos;
     }
 }
 
@@ -712,7 +733,7 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(
 // stale order only costs locality.  (Ids are clamped to [0, P): a workspace that lost its order cannot fault.)
 template <bool GATHER>
 __global__ __launch_bounds__(SORT_BIN_THREADS) void bin_sorted_kernel(
-    const float4 *__restrict__ s_geo, const int32_t *__restrict__ s_id, const uint32_t *__restrict__ sorted_count,
+    const float4 *__restrict__ crec, const int32_t *__restrict__ s_id, const uint32_t *__restrict__ sorted_count,
     const int64_t *__restrict__ first_idx, const int64_t *__restrict__ num_pts, int N, TileGrid g,
     uint32_t *__restrict__ counts, int32_t *__restrict__ lists, uint32_t cap, TileQueue tq, Spill sp, uint32_t P)
 {
@@ -724,21 +745,19 @@ __global__ __launch_bounds__(SORT_BIN_THREADS) void bin_sorted_kernel(
     for (int k = threadIdx.x; k < SORT_HASH; k += SORT_BIN_THREADS) { h_key[k] = SORT_EMPTY; h_cnt[k] = 0u; }
     const int tiles = g.tiles_x * g.tiles_y;
     // the four splats of this thread: entries b0 + j * 256 + tid; all loads first
-    int pid[SORT_BIN_PER_THREAD];
+    // (round 5: the candidate records are stored by POSITION in both forms -- the saved order's records were gathered through
+    // the order before, one 16-byte sector of a random 128-byte line per splat -- and the lists / mask bytes hold positions)
+    int pid[SORT_BIN_PER_THREAD];       // point id (cloud lookup only)
+    uint32_t posn[SORT_BIN_PER_THREAD]; // position in the order = list entry
     float4 ge[SORT_BIN_PER_THREAD];
 #pragma unroll
     for (int j = 0; j < SORT_BIN_PER_THREAD; ++j) {
         const uint32_t i = b0 + (uint32_t)j * SORT_BIN_THREADS + threadIdx.x;
         const uint32_t ic = i < count ? i : count - 1u;
+        posn[j] = ic;
         pid[j] = i < count ? s_id[ic] : -1;
-        if (!GATHER) ge[j] = s_geo[ic];
-    }
-    if (GATHER) {
-#pragma unroll
-        for (int j = 0; j < SORT_BIN_PER_THREAD; ++j) {
-            if (pid[j] >= 0) pid[j] = (int)min((uint32_t)pid[j], P - 1u);
-            ge[j] = s_geo[pid[j] >= 0 ? pid[j] : 0];
-        }
+        ge[j] = crec[2 * (size_t)ic];
+        if (GATHER && pid[j] >= 0) pid[j] = (int)min((uint32_t)pid[j], P - 1u);   // (a lost order cannot fault)
     }
     __syncthreads();
     int cl[SORT_BIN_PER_THREAD], rx0[SORT_BIN_PER_THREAD], rx1[SORT_BIN_PER_THREAD], ry0[SORT_BIN_PER_THREAD], ry1[SORT_BIN_PER_THREAD];
@@ -804,11 +823,11 @@ __global__ __launch_bounds__(SORT_BIN_THREADS) void bin_sorted_kernel(
             if (!(onm[j] & (1u << k))) continue;
             const uint32_t key = h_key[slot[j][k]];
             const uint32_t pos = h_cnt[slot[j][k]] + rank[j][k];
-            if (pos < cap) lists[(size_t)key * cap + pos] = (int32_t)pid[j];
+            if (pos < cap) lists[(size_t)key * cap + pos] = (int32_t)posn[j];
             else full |= 1u << k;
         }
         if (full && sp.ctrl) {
-            sp.mask[pid[j]] = (uint8_t)(full | (sub << 4));
+            sp.mask[posn[j]] = (uint8_t)(full | (sub << 4));
             sp.ctrl[0] = 1u;
         }
         if (onm[j] & 16u) {
@@ -817,7 +836,7 @@ __global__ __launch_bounds__(SORT_BIN_THREADS) void bin_sorted_kernel(
                 for (int tx = rx0[j]; tx <= rx1[j]; ++tx) {
                     const size_t t = (size_t)(cl[j] * tiles + ty * g.tiles_x + tx) * DSS_SUB + sub;
                     const uint32_t pos = atomicAdd(&counts[t], 1u);
-                    if (pos < cap) lists[t * cap + pos] = (int32_t)pid[j];
+                    if (pos < cap) lists[t * cap + pos] = (int32_t)posn[j];
                     else if (sp.ctrl) sp.fail[0] = sp.epoch;
                 }
         }
@@ -871,6 +890,12 @@ __global__ __launch_bounds__(1024) void queue_build_kernel(const uint32_t *__res
 struct FineArgs {
     const float *points, *ellipse, *cutoff, *radii;
     const float4 *rec;         // packed 64-byte splat records (fused forward, see SetupArgs::rec) or nullptr
+    // cell-ordered path (round 5): list / pool entries are POSITIONS of the point order; crec (P,2) = the 32-byte candidate
+    // record {px,py,rx,ry} {a,b,c,pz} of every position, sort_id (P) = the splat id there; cutoffC = the call's Q threshold
+    // (constant in the fused forward).  nullptr: list entries are splat ids (direct binning)
+    const float4 *crec;
+    const int32_t *sort_id;
+    float cutoffC;
     const int64_t *first_idx, *num_pts;
     const uint32_t *counts;    // (N*tiles*DSS_SUB) sub-list fill counts, or nullptr (naive mode)
     const int32_t *lists;      // (N*tiles*DSS_SUB*cap)
@@ -1317,8 +1342,20 @@ __device__ __forceinline__ void fine_tile(const FineArgs &A_entry, const int til
             m = (int)min((int64_t)CHUNK, count - base);
         }
         __syncthreads();  // previous chunk fully consumed
+        // (cell-ordered path without packed records -- more than 8 fragments per pixel, other channel counts --: the entry is a
+        // position, the per-point arrays are indexed by the splat id)
+        if (!PACKED && have && use_list && A.crec != nullptr) p = A.sort_id[p];
         if (have) {
-            if (PACKED) {
+            if (PACKED && use_list && A.crec != nullptr) {
+                // cell-ordered path: the list entry is a POSITION of the point order; its 32-byte candidate record and its id
+                // sit next to those of the tile's other candidates (4 records per 128-byte line, shared with the
+                // neighbouring tiles on the same XCD)
+                const float4 *C = A.crec + 2 * p;
+                const float4 c1 = C[1];
+                s_geo[dst] = C[0];
+                s_ell[dst] = make_float4(c1.x, c1.y, c1.z, A.cutoffC);
+                s_zid[dst] = make_float2(__int_as_float(A.sort_id[p]), c1.w + 0.0f);
+            } else if (PACKED) {
                 // one 64-byte record = one half cache line per candidate: three loads, one memory transaction (the four
                 // separate arrays cost four transactions, and every XCD ended up fetching every line of all of them:
                 // point ids are spatially random, so each 128-byte line held a point of every screen region)
@@ -1645,7 +1682,7 @@ __global__ __launch_bounds__(FINE_THREADS) __attribute__((amdgpu_num_sgpr(96))) 
         // to the other XCDs, then count it as finished; the last one to finish resets the two words only this pass and
         // the binning use (all of its workgroups have read ctrl[0] by then).
         const bool ran = spill_pass(A.points, A.radii, A.first_idx, A.num_pts, A.N, A.P, A.g, A.counts, A.cap, A.spill,
-                                    A.spill_sorted, blockIdx.x, spill_wgs);
+                                    A.spill_sorted, blockIdx.x, spill_wgs, A.crec, A.sort_id);
         if (!ran) return;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         __syncthreads();
@@ -1849,8 +1886,12 @@ struct FwdWorkspace {
     uint32_t *sort_cell_total, *sort_cell_start;   // (cells)
     uint32_t *sort_seg_tot;      // (segments of SORT_SEG blocks, cells)
     uint32_t *sort_count;        // number of sorted (= not culled) splats
-    float4 *sort_geo;            // (P) px, py, rx, ry in cell order
-    int32_t *sort_id;            // (P) splat id in cell order
+    // Round 5: the cell-ordered path keeps a 32-byte CANDIDATE RECORD per position of the order -- {px, py, rx, ry} {a, b, c, pz};
+    // rx = -1: culled / not binned -- and the tile lists hold POSITIONS: a tile's candidates are neighbours in memory (the 64-byte
+    // records at random point ids pulled a 128-byte line each: 1.37 GB fetched for 0.42 GB of records at 8 x 1M points)
+    float4 *sort_crec;           // (P, 2) candidate records in cell order
+    int32_t *sort_id;            // (P) splat id in cell order (the saved point order)
+    int32_t *sort_inv;           // (P) position of every splat in the saved order (DSS_WS_ORDER_SAVE writes it, _REUSE reads it)
     size_t count_bytes;  // bytes to zero before binning (the DSS_WS_CLEAN region): everything in front of the lists
     size_t bytes;
 };
@@ -1933,6 +1974,7 @@ static FwdWorkspace carve_fwd(void *ws, int N, int64_t P, int S, bool with_recor
         w.bytes += align_up((size_t)P * 64, 256);
     }
     w.sort_cell_of = nullptr;
+    w.sort_crec = nullptr; w.sort_id = nullptr; w.sort_inv = nullptr;
     if (with_records && !lean_workspace() && P > SORT_MIN_P) {
         const SortGrid sg = make_sort_grid(N, S);
         w.sort_cell_of = reinterpret_cast<uint32_t *>(p + w.bytes);      w.bytes += align_up((size_t)P * 4, 256);
@@ -1942,8 +1984,9 @@ static FwdWorkspace carve_fwd(void *ws, int N, int64_t P, int S, bool with_recor
         w.sort_cell_total = reinterpret_cast<uint32_t *>(p + w.bytes);   w.bytes += align_up((size_t)sg.total * 4, 256);
         w.sort_cell_start = reinterpret_cast<uint32_t *>(p + w.bytes);   w.bytes += align_up((size_t)sg.total * 4, 256);
         w.sort_count = reinterpret_cast<uint32_t *>(p + w.bytes);        w.bytes += 256;
-        w.sort_geo = reinterpret_cast<float4 *>(p + w.bytes);            w.bytes += align_up((size_t)P * 16, 256);
+        w.sort_crec = reinterpret_cast<float4 *>(p + w.bytes);           w.bytes += align_up((size_t)P * 32, 256);
         w.sort_id = reinterpret_cast<int32_t *>(p + w.bytes);            w.bytes += align_up((size_t)P * 4, 256);
+        w.sort_inv = reinterpret_cast<int32_t *>(p + w.bytes);           w.bytes += align_up((size_t)P * 4, 256);
     }
     return w;
 }
@@ -2069,6 +2112,7 @@ static int splat_fine_impl(const float *points, const float *ellipse, const floa
     if (blocks_ll > 0x7fffffffll) { set_error("dss_splat_fine: too many tiles"); return DSS_ERR_UNSUPPORTED; }
     FineArgs A;
     A.points = points; A.ellipse = ellipse; A.cutoff = cutoff; A.radii = radii; A.rec = nullptr;
+    A.crec = nullptr; A.sort_id = nullptr; A.cutoffC = 0.0f;
     A.first_idx = first_idx; A.num_pts = num_pts;
     A.counts = nullptr; A.lists = nullptr; A.cap = 0;
     A.queue.tail = nullptr; A.queue.list = nullptr; A.queue.flag = nullptr; A.queue.capq = 0; A.queue_wgs = 0; A.prio = 0;
@@ -2282,16 +2326,16 @@ extern "C" int dss_render_forward(const float *world, const float *normals, cons
             const int per2 = 4, tb2 = 256;
             const unsigned sb2 = (unsigned)((P + (int64_t)per2 * tb2 - 1) / ((int64_t)per2 * tb2));
             hipLaunchKernelGGL(setup_cell_kernel<2>, dim3(sb2), dim3(tb2), (tb2 / 64) * 4096, st, SA, sg, per2, w.sort_cell_of,
-                               w.sort_block_hist, w.spill, visible, w.sort_geo, g, band_only);
-            hipLaunchKernelGGL(bin_sorted_kernel<true>, dim3(bin_wgs), dim3(SORT_BIN_THREADS), 0, st, w.sort_geo, w.sort_id,
+                               w.sort_block_hist, w.spill, visible, w.sort_crec, w.sort_inv, g, band_only);
+            hipLaunchKernelGGL(bin_sorted_kernel<true>, dim3(bin_wgs), dim3(SORT_BIN_THREADS), 0, st, w.sort_crec, w.sort_id,
                                w.sort_count, first_idx, num_pts, N, g, w.counts, w.lists, w.cap, w.queue, w.spill, (uint32_t)P);
         } else {
             if (save_order)
                 hipLaunchKernelGGL(setup_cell_kernel<1>, dim3(sb), dim3(SORT_THREADS), lds, st, SA, sg, per, w.sort_cell_of,
-                                   w.sort_block_hist, w.spill, visible, w.sort_geo, g, band_only);
+                                   w.sort_block_hist, w.spill, visible, w.sort_crec, w.sort_inv, g, band_only);
             else
                 hipLaunchKernelGGL(setup_cell_kernel<0>, dim3(sb), dim3(SORT_THREADS), lds, st, SA, sg, per, w.sort_cell_of,
-                                   w.sort_block_hist, w.spill, visible, w.sort_geo, g, band_only);
+                                   w.sort_block_hist, w.spill, visible, w.sort_crec, w.sort_inv, g, band_only);
             const unsigned nseg = (sb + SORT_SEG - 1) / SORT_SEG;
             hipLaunchKernelGGL(sort_block_scan_kernel, dim3((unsigned)((sg.total + 255) / 256), nseg), dim3(256), 0, st, sb,
                                sg.total, w.sort_block_hist, w.sort_seg_tot);
@@ -2299,9 +2343,10 @@ extern "C" int dss_render_forward(const float *world, const float *normals, cons
                                w.sort_seg_tot, w.sort_cell_total);
             hipLaunchKernelGGL(sort_cell_scan_kernel, dim3(1), dim3(1024), 0, st, w.sort_cell_total, w.sort_cell_start, sg.total,
                                w.sort_count);
-            hipLaunchKernelGGL(sort_scatter_kernel, dim3(sb), dim3(SORT_THREADS), lds, st, pts_screen, radii, P, sg, per,
-                               w.sort_cell_of, w.sort_cell_start, w.sort_block_hist, w.sort_seg_tot, w.sort_geo, w.sort_id);
-            hipLaunchKernelGGL(bin_sorted_kernel<false>, dim3(bin_wgs), dim3(SORT_BIN_THREADS), 0, st, w.sort_geo, w.sort_id,
+            hipLaunchKernelGGL(sort_scatter_kernel, dim3(sb), dim3(SORT_THREADS), lds, st, pts_screen, radii, ellipse, P, sg, per,
+                               w.sort_cell_of, w.sort_cell_start, w.sort_block_hist, w.sort_seg_tot, w.sort_crec, w.sort_id,
+                               save_order ? w.sort_inv : (int32_t *)nullptr);
+            hipLaunchKernelGGL(bin_sorted_kernel<false>, dim3(bin_wgs), dim3(SORT_BIN_THREADS), 0, st, w.sort_crec, w.sort_id,
                                w.sort_count, first_idx, num_pts, N, g, w.counts, w.lists, w.cap, w.queue, w.spill, (uint32_t)P);
         }
         hipLaunchKernelGGL(queue_build_kernel, dim3((unsigned)((N * tiles + 1023) / 1024)), dim3(1024), 0, st, w.counts,
@@ -2317,6 +2362,9 @@ extern "C" int dss_render_forward(const float *world, const float *normals, cons
     FineArgs A;
     A.points = pts_screen; A.ellipse = ellipse; A.cutoff = cutoff; A.radii = radii;
     A.rec = packed ? w.rec : nullptr;
+    A.crec = sorted ? w.sort_crec : nullptr;   // cell-ordered path: list entries are positions of the point order
+    A.sort_id = sorted ? w.sort_id : nullptr;
+    A.cutoffC = cutoff_threshold;
     A.first_idx = first_idx; A.num_pts = num_pts;
     A.counts = w.counts; A.lists = w.lists; A.cap = w.cap; A.queue = w.queue; A.spill = w.spill;
     A.queue_wgs = queue_workgroups(N, g);

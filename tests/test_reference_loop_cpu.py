@@ -69,7 +69,7 @@ def test_reference_train_mvr_runs_unmodified_on_the_drop_in_and_its_loss_decreas
     # train_mvr.py stops on a wall-clock limit, not an iteration count: run legs of 60 s (it resumes from its own model.pt,
     # train_mvr.py:98-103) until 450 iterations are in, so that a slow or busy machine does not decide the outcome
     loss, legs = [], 0
-    while len(loss) < 450 and legs < 4:
+    while len(loss) < 450 and legs < 8:
         legs += 1
         r = _run(["--config", cfg, "--scalars", scalars, "--no-cuda", "--exit-after", "60"], 400)
         # train_mvr.py:219-228 leaves through exit(3) when its time limit is reached -- after saving model.pt it joins
