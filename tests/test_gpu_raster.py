@@ -708,7 +708,7 @@ dist.destroy_process_group()
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
                           "--master-addr", "127.0.0.1", "--master-port", "29711", script],
                          env=env, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-12000:]
     assert os.path.exists(os.path.join(str(tmp_path), "ok0")) and os.path.exists(os.path.join(str(tmp_path), "ok1"))
 
 
@@ -725,7 +725,7 @@ def test_bench_launches_its_own_ranks():
     env["BENCH_EXCHANGE"] = "overlap"   # (the three-collective form: "auto" would time both forms and keep the faster)
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
                           "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
-    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-12000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout
     rec = json.loads(lines[0])
