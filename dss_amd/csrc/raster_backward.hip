@@ -279,7 +279,10 @@ __global__ __launch_bounds__(MED_THREADS) void visible_scan_kernel(
     const float *__restrict__ radii, const uint8_t *__restrict__ visible,
     const int64_t *__restrict__ first_idx, const int64_t *__restrict__ num_pts, int N, int64_t P,
     uint32_t *__restrict__ hist, uint32_t *__restrict__ vis_count, int32_t *__restrict__ vis_list,
-    float *__restrict__ grad_pts, float *__restrict__ grad_feat, int C)
+    float *__restrict__ grad_pts, float *__restrict__ grad_feat, int C,
+    int zero_all = 0 /* row band: also the visible points start from zero (contiguous stores here; the band filter of
+                        cell_hist_kernel then drops a point without the scattered zero stores it issued before -- 60 us of its
+                        92 us on a rank of configs[4]) */)
 {
     __shared__ uint32_t lh[MED_BINS];
     __shared__ uint32_t s_wave[MED_THREADS / 64];
@@ -321,9 +324,8 @@ __global__ __launch_bounds__(MED_THREADS) void visible_scan_kernel(
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
         const int64_t i = c0 + tid + (int64_t)u * MED_THREADS;
-        if (vis[u]) {
-            vis_list[base + rank[u]] = (int32_t)i;
-        } else if (i < c1) {
+        if (vis[u]) vis_list[base + rank[u]] = (int32_t)i;
+        if ((!vis[u] || zero_all) && i < c1) {
             grad_pts[3 * i] = 0.0f; grad_pts[3 * i + 1] = 0.0f; grad_pts[3 * i + 2] = 0.0f;
             if (grad_feat)
                 for (int ch = 0; ch < C; ++ch) grad_feat[(size_t)i * C + ch] = 0.0f;
@@ -889,12 +891,7 @@ __global__ __launch_bounds__(CELL_THREADS) void cell_hist_kernel(
                     in_band = ndc_index_range(py, reach, S, ylo, yhi) &&
                               band_row_ceil(S - 1 - yhi, row0, tshift) <= min(band_row_floor(S - 1 - ylo, row0, tshift), rows - 1);
                 }
-                if (!in_band) {
-                    key = CELL_NONE;
-                    grad_pts[3 * (size_t)p] = 0.0f; grad_pts[3 * (size_t)p + 1] = 0.0f; grad_pts[3 * (size_t)p + 2] = 0.0f;
-                    if (grad_feat)
-                        for (int ch = 0; ch < C; ++ch) grad_feat[(size_t)p * C + ch] = 0.0f;
-                }
+                if (!in_band) key = CELL_NONE;   // (its partial sums over this band are zero: visible_scan_kernel stored them)
             }
             cell_of[i] = key;
             if (key != CELL_NONE) atomicAdd(&s_hist[key], 1u);
@@ -2615,7 +2612,7 @@ static int render_backward_impl(bool run_prep, const float *grad_out, const int3
         if (hipMemsetAsync(hist, 0, hist_bytes + 256, st) != hipSuccess) return check_launch("memset render_backward");
         const unsigned blocks = (unsigned)((P + MED_PTS_PER_WG - 1) / MED_PTS_PER_WG);
         hipLaunchKernelGGL(visible_scan_kernel, dim3(blocks), dim3(MED_THREADS), 0, st, radii, visible, first_idx,
-                           num_pts, N, P, hist, vis_count, unsorted, grad_pts, grad_feat, C);
+                           num_pts, N, P, hist, vis_count, unsorted, grad_pts, grad_feat, C, (rows < S || cyc) ? 1 : 0);
         hipLaunchKernelGGL(median_hist_kernel<1>, dim3(blocks), dim3(MED_THREADS), 0, st, radii, visible, first_idx,
                            num_pts, N, P, hist);
         hipLaunchKernelGGL(median_hist_kernel<2>, dim3(blocks), dim3(MED_THREADS), 0, st, radii, visible, first_idx,

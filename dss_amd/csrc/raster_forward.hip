@@ -501,7 +501,7 @@ __global__ __launch_bounds__(SORT_THREADS) void setup_cell_kernel(const SetupArg
                                                                    uint8_t *__restrict__ visible_to_clear,
                                                                    float4 *__restrict__ crec /* (P,2) candidate records by position */,
                                                                    const int32_t *__restrict__ inv /* MODE 2: position of every splat */,
-                                                                   TileGrid g, int band_only)
+                                                                   TileGrid g, int band_only, uint8_t *__restrict__ live = nullptr)
 {
     // band_only (DSS_WS_BAND_OUTPUTS, multi-GPU): splats whose tile rectangle misses the rank's band store their screen
     // position, radii and validity only; MODE 0 leaves them out of the sort, MODE 2 marks them in the binning record (rx = -1,
@@ -560,9 +560,16 @@ __global__ __launch_bounds__(SORT_THREADS) void setup_cell_kernel(const SetupArg
                 } else {
                     setup_point_store(A, p, v, reach);
                 }
-                const size_t pos = (size_t)min((uint32_t)inv[p], (uint32_t)(A.P - 1));   // (clamped: a lost order cannot fault)
-                crec[2 * pos] = make_float4(v.sx, v.sy, reach ? v.rx : -1.0f, v.ry);
-                crec[2 * pos + 1] = make_float4(v.ea, v.eb, v.ec, v.sz);
+                // only the splats that meet the band store a candidate record (one scattered 32-byte store each: for all 8M
+                // splats of configs[3] that was 100 us of a rank's 240 us setup) and raise the byte of their position; the
+                // binning reads the bytes in position order, takes the raised ones and lowers them again, so that the stale
+                // record of a splat that has left the band is never looked at
+                if (reach) {
+                    const size_t pos = (size_t)min((uint32_t)inv[p], (uint32_t)(A.P - 1));   // (clamped: a lost order cannot fault)
+                    crec[2 * pos] = make_float4(v.sx, v.sy, v.rx, v.ry);
+                    crec[2 * pos + 1] = make_float4(v.ea, v.eb, v.ec, v.sz);
+                    live[pos] = 1;
+                }
                 continue;
             }
             if (full) setup_wave_store(A, p0, v, wave_lds);
@@ -735,14 +742,14 @@ template <bool GATHER>
 __global__ __launch_bounds__(SORT_BIN_THREADS) void bin_sorted_kernel(
     const float4 *__restrict__ crec, const int32_t *__restrict__ s_id, const uint32_t *__restrict__ sorted_count,
     const int64_t *__restrict__ first_idx, const int64_t *__restrict__ num_pts, int N, TileGrid g,
-    uint32_t *__restrict__ counts, int32_t *__restrict__ lists, uint32_t cap, TileQueue tq, Spill sp, uint32_t P)
+    uint32_t *__restrict__ counts, int32_t *__restrict__ lists, uint32_t cap, TileQueue tq, Spill sp, uint32_t P,
+    uint8_t *__restrict__ live_pos = nullptr /* GATHER, DSS_WS_BAND_OUTPUTS: the positions whose record this call's setup stored */)
 {
     __shared__ uint32_t h_key[SORT_HASH];
     __shared__ uint32_t h_cnt[SORT_HASH];   // count of the key, then (after the reservation) the run's first list position
     const uint32_t count = GATHER ? P : *sorted_count;
     const uint32_t b0 = blockIdx.x * SORT_BIN_CHUNK;
     if (b0 >= count) return;
-    for (int k = threadIdx.x; k < SORT_HASH; k += SORT_BIN_THREADS) { h_key[k] = SORT_EMPTY; h_cnt[k] = 0u; }
     const int tiles = g.tiles_x * g.tiles_y;
     // the four splats of this thread: entries b0 + j * 256 + tid; all loads first
     // (round 5: the candidate records are stored by POSITION in both forms -- the saved order's records were gathered through
@@ -755,10 +762,25 @@ __global__ __launch_bounds__(SORT_BIN_THREADS) void bin_sorted_kernel(
         const uint32_t i = b0 + (uint32_t)j * SORT_BIN_THREADS + threadIdx.x;
         const uint32_t ic = i < count ? i : count - 1u;
         posn[j] = ic;
-        pid[j] = i < count ? s_id[ic] : -1;
-        ge[j] = crec[2 * (size_t)ic];
+        bool fresh = i < count;
+        if (GATHER && live_pos != nullptr) {
+            fresh = fresh && live_pos[ic] != 0;
+            if (fresh) live_pos[ic] = 0;   // (this thread is the byte's only reader)
+        }
+        pid[j] = fresh ? s_id[ic] : -1;
+        ge[j] = fresh ? crec[2 * (size_t)ic] : make_float4(0.0f, 0.0f, -1.0f, 0.0f);
         if (GATHER && pid[j] >= 0) pid[j] = (int)min((uint32_t)pid[j], P - 1u);   // (a lost order cannot fault)
     }
+    if (GATHER) {
+        // a chunk without a single live record leaves here: on a rank of the multi-GPU step (DSS_WS_BAND_OUTPUTS) seven of
+        // eight chunks hold only splats outside the rank's rows (rx = -1), and the hash table's reset, scan and three
+        // barriers were most of what such a chunk cost
+        bool live = false;
+#pragma unroll
+        for (int j = 0; j < SORT_BIN_PER_THREAD; ++j) live = live || (pid[j] >= 0 && !(ge[j].z < 0));
+        if (!__syncthreads_or(live)) return;
+    }
+    for (int k = threadIdx.x; k < SORT_HASH; k += SORT_BIN_THREADS) { h_key[k] = SORT_EMPTY; h_cnt[k] = 0u; }
     __syncthreads();
     int cl[SORT_BIN_PER_THREAD], rx0[SORT_BIN_PER_THREAD], rx1[SORT_BIN_PER_THREAD], ry0[SORT_BIN_PER_THREAD], ry1[SORT_BIN_PER_THREAD];
     uint32_t slot[SORT_BIN_PER_THREAD][4], rank[SORT_BIN_PER_THREAD][4];
@@ -1892,6 +1914,7 @@ struct FwdWorkspace {
     float4 *sort_crec;           // (P, 2) candidate records in cell order
     int32_t *sort_id;            // (P) splat id in cell order (the saved point order)
     int32_t *sort_inv;           // (P) position of every splat in the saved order (DSS_WS_ORDER_SAVE writes it, _REUSE reads it)
+    uint8_t *sort_live;          // (P) by position: 1 = this call's setup stored a record there (DSS_WS_BAND_OUTPUTS + _REUSE, see setup_cell_kernel)
     size_t count_bytes;  // bytes to zero before binning (the DSS_WS_CLEAN region): everything in front of the lists
     size_t bytes;
 };
@@ -1974,7 +1997,7 @@ static FwdWorkspace carve_fwd(void *ws, int N, int64_t P, int S, bool with_recor
         w.bytes += align_up((size_t)P * 64, 256);
     }
     w.sort_cell_of = nullptr;
-    w.sort_crec = nullptr; w.sort_id = nullptr; w.sort_inv = nullptr;
+    w.sort_crec = nullptr; w.sort_id = nullptr; w.sort_inv = nullptr; w.sort_live = nullptr;
     if (with_records && !lean_workspace() && P > SORT_MIN_P) {
         const SortGrid sg = make_sort_grid(N, S);
         w.sort_cell_of = reinterpret_cast<uint32_t *>(p + w.bytes);      w.bytes += align_up((size_t)P * 4, 256);
@@ -1987,6 +2010,7 @@ static FwdWorkspace carve_fwd(void *ws, int N, int64_t P, int S, bool with_recor
         w.sort_crec = reinterpret_cast<float4 *>(p + w.bytes);           w.bytes += align_up((size_t)P * 32, 256);
         w.sort_id = reinterpret_cast<int32_t *>(p + w.bytes);            w.bytes += align_up((size_t)P * 4, 256);
         w.sort_inv = reinterpret_cast<int32_t *>(p + w.bytes);           w.bytes += align_up((size_t)P * 4, 256);
+        w.sort_live = reinterpret_cast<uint8_t *>(p + w.bytes);          w.bytes += align_up((size_t)P, 256);
     }
     return w;
 }
@@ -2326,10 +2350,13 @@ extern "C" int dss_render_forward(const float *world, const float *normals, cons
             const int per2 = 4, tb2 = 256;
             const unsigned sb2 = (unsigned)((P + (int64_t)per2 * tb2 - 1) / ((int64_t)per2 * tb2));
             hipLaunchKernelGGL(setup_cell_kernel<2>, dim3(sb2), dim3(tb2), (tb2 / 64) * 4096, st, SA, sg, per2, w.sort_cell_of,
-                               w.sort_block_hist, w.spill, visible, w.sort_crec, w.sort_inv, g, band_only);
+                               w.sort_block_hist, w.spill, visible, w.sort_crec, w.sort_inv, g, band_only, w.sort_live);
             hipLaunchKernelGGL(bin_sorted_kernel<true>, dim3(bin_wgs), dim3(SORT_BIN_THREADS), 0, st, w.sort_crec, w.sort_id,
-                               w.sort_count, first_idx, num_pts, N, g, w.counts, w.lists, w.cap, w.queue, w.spill, (uint32_t)P);
+                               w.sort_count, first_idx, num_pts, N, g, w.counts, w.lists, w.cap, w.queue, w.spill, (uint32_t)P,
+                               band_only ? w.sort_live : (uint8_t *)nullptr);
         } else {
+            // (the position bytes of the band ranks' binning start lowered with every saved order)
+            if (save_order && hipMemsetAsync(w.sort_live, 0, (size_t)P, st) != hipSuccess) return check_launch("dss_render_forward (order bytes)");
             if (save_order)
                 hipLaunchKernelGGL(setup_cell_kernel<1>, dim3(sb), dim3(SORT_THREADS), lds, st, SA, sg, per, w.sort_cell_of,
                                    w.sort_block_hist, w.spill, visible, w.sort_crec, w.sort_inv, g, band_only);

@@ -270,6 +270,18 @@ def test_band_outputs_only_gives_the_same_band_and_the_same_gradients(reps, S):
                                                o["radii"], full["visible"], first, num, 4.0, -1.0, image_size=S, rows=part.rows)
             (gf, gp), (gf0, gp0) = bw(f), bw(plain)
             assert torch.equal(gf, gf0) and torch.equal(gp, gp0), (part.describe(), kw)
+    if large:
+        # ONE saved order reused by different bands in turn (the workspace is shared): under DSS_WS_BAND_OUTPUTS only the splats
+        # that meet the band store their candidate record, so the records of the previous band's splats are stale where
+        # the next band does not reach -- they must never be binned (position bytes, setup_cell_kernel / bin_sorted_kernel)
+        seq = [(RowPartition(S, 4, 1), True), (RowPartition(S, 4, 1), True), (RowPartition(S, 4, 3), True),
+               (RowPartition(S, 1, 0), False), (RowPartition(S, 4, 0), True), (RowPartition(S, 4, 2, cyclic=True), True)]
+        ops.render_forward(*args, rows=seq[0][0].rows, order_refresh=0)     # (forget the order of the loop above)
+        for i, (part, band_only) in enumerate(seq):                         # call 0 saves, calls 1.. reuse
+            f = ops.render_forward(*args, rows=part.rows, band_outputs_only=band_only, order_refresh=len(seq) + 1)
+            plain = ops.render_forward(*args, rows=part.rows, workspace_state=0)
+            for k in ("idx", "zbuf", "qvalue", "occupancy", "image", "wsum", "visible"):
+                assert torch.equal(f[k], plain[k]), (k, i, part.describe())
 
 
 def test_row_bands_concatenate_to_full_image():
