@@ -132,6 +132,53 @@ def balanced_bounds(row_weight, world_size: int, align: int = 8, min_rows: int =
     return bounds
 
 
+def fitted_bounds(row_weight, samples, world_size: int, align: int = 8, min_rows: int = 8):
+    """Band boundaries from MEASURED per-rank step times: ``samples`` = [(bounds, times), ...] of at least two different
+    contiguous partitions (e.g. equal rows, then `balanced_bounds` of the occupancy).  Fits  t_rank = F + a * (row_weight
+    summed over the rank's rows) + b * (rows of the rank)  with F, a, b >= 0 -- F is the work every rank repeats (setup of
+    every splat, the medians), a the cost of covered pixels, b what a row costs covered or not -- and returns
+    `balanced_bounds` of the per-row cost a * row_weight + b, together with (F, a, b).  Occupancy alone (b = 0) moved too
+    many empty rows to the outer ranks at configs[3]/[4]: their rows are not free (tile lists, alpha plane, image bytes)."""
+    import itertools
+    import numpy as np
+    w = np.asarray(torch.as_tensor(row_weight, dtype=torch.float64).flatten().cpu())
+    cum = np.concatenate([[0.0], np.cumsum(w)])
+    A, y = [], []
+    for bounds, times in samples:
+        for r in range(len(bounds) - 1):
+            A.append([1.0, cum[bounds[r + 1]] - cum[bounds[r]], float(bounds[r + 1] - bounds[r])])
+            y.append(float(times[r]))
+    A, y = np.asarray(A), np.asarray(y)
+    scale = np.maximum(np.abs(A).max(axis=0), 1e-30)
+    best = None
+    for k in (3, 2, 1):                       # non-negative least squares over the subsets of {F, a, b}
+        for cols in itertools.combinations(range(3), k):
+            x = np.zeros(3)
+            sol = np.linalg.lstsq(A[:, cols] / scale[list(cols)], y, rcond=None)[0] / scale[list(cols)]
+            if (sol < 0).any():
+                continue
+            x[list(cols)] = sol
+            err = float(((A @ x - y) ** 2).sum())
+            if best is None or err < best[0] - 1e-12:
+                best = (err, x)
+    F, a, b = (float(v) for v in best[1])
+    if a <= 0 and b <= 0:
+        return balanced_bounds(np.ones_like(w), world_size, align, min_rows), (F, a, b)
+    return balanced_bounds(a * w + b, world_size, align, min_rows), (F, a, b)
+
+
+def rebalanced_bounds(bounds, times, fixed: float, align: int = 8, min_rows: int = 8):
+    """One step of measured-time rebalancing of contiguous bands: every rank's time above the repeated work ``fixed`` (the F
+    of `fitted_bounds`) is spread evenly over its rows -- a piecewise-constant cost per row, measured, whatever it is made
+    of (tile lists, depth complexity, window sizes) -- and the boundaries are moved so that every rank gets the same share."""
+    S, G = int(bounds[-1]), len(bounds) - 1
+    w = torch.zeros(S, dtype=torch.float64)
+    for r in range(G):
+        rows = bounds[r + 1] - bounds[r]
+        w[bounds[r]:bounds[r + 1]] = max(float(times[r]) - float(fixed), 1e-6) / max(rows, 1)
+    return balanced_bounds(w, G, align, min_rows)
+
+
 def gather_rows(band: torch.Tensor, part: RowPartition, group=None) -> torch.Tensor:
     """All-gather row bands ``(N, rows, S, ch)`` into the full image ``(N, S, S, ch)`` on every rank."""
     if part.world_size == 1:

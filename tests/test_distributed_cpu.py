@@ -157,6 +157,35 @@ def test_row_partition_bounds():
             assert b == c
 
 
+def test_bounds_from_measured_times():
+    """dss_amd.distributed.fitted_bounds / rebalanced_bounds (contiguous bands of the large multi-GPU workloads):
+    per-rank times that follow  F + a * covered pixels + b * rows  give the model back from two different partitions, the
+    fitted bands are level under that model, and a rebalancing step levels a cost profile the model does not know."""
+    from dss_amd.distributed import RowPartition, balanced_bounds, fitted_bounds, rebalanced_bounds
+    S, G = 1024, 8
+    rows = np.arange(S)
+    w = 60000.0 * np.exp(-((rows - 500) / 180.0) ** 2)
+    cum = np.concatenate([[0.0], np.cumsum(w)])
+    model = lambda b: [700.0 + 2e-4 * (cum[b[i + 1]] - cum[b[i]]) + 1.2 * (b[i + 1] - b[i]) for i in range(G)]
+    equal = [RowPartition(S, G, r).rows[0] for r in range(G)] + [S]
+    by_occupancy = balanced_bounds(w, G)
+    bounds, (F, a, b) = fitted_bounds(w, [(equal, model(equal)), (by_occupancy, model(by_occupancy))], G)
+    assert abs(F - 700.0) < 1e-3 and abs(a - 2e-4) < 1e-9 and abs(b - 1.2) < 1e-6
+    assert bounds[0] == 0 and bounds[-1] == S and all(y - x >= 8 and x % 8 == 0 for x, y in zip(bounds[:-1], bounds[1:]))
+    t = model(bounds)
+    assert max(t) - min(t) < 0.05 * (max(model(equal)) - min(model(equal))) + 2 * 8 * (2e-4 * w.max() + 1.2)
+    # a cost per row that is neither occupancy nor constant: two rebalancing steps bring the spread down
+    hidden = 1.0 + 4.0 * (rows > 700)
+    hc = np.concatenate([[0.0], np.cumsum(hidden)])
+    true = lambda bb: [300.0 + (hc[bb[i + 1]] - hc[bb[i]]) for i in range(G)]
+    b1 = rebalanced_bounds(equal, true(equal), 300.0)
+    b2 = rebalanced_bounds(b1, true(b1), 300.0)
+    spread = lambda bb: max(true(bb)) - min(true(bb))
+    assert spread(b2) < 0.25 * spread(equal)
+    with pytest.raises(ValueError):
+        balanced_bounds(w, 200)
+
+
 def test_cyclic_row_partition_layout():
     """tile-row-cyclic partition: every image row has exactly one owner, band sizes agree with dss_band_rows' formula
     (ops.band_rows), the gather index inverts the rank-major concatenation of the bands"""

@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 from dss_amd import ops  # noqa: E402
-from dss_amd.distributed import RowPartition, balanced_bounds  # noqa: E402
+from dss_amd.distributed import RowPartition, balanced_bounds, fitted_bounds, rebalanced_bounds  # noqa: E402
 
 from dss_amd import _lib  # noqa: E402
 if os.environ.get("BAND_TPW"):       # development A/B: DSS_OPT_BACKWARD_TPW
@@ -71,6 +71,17 @@ for layout in ((os.environ.get("BAND_TRACE_LAYOUT", "cyclic"),) if TRACE else LA
         w = fwd(None)["occupancy"].sum(dim=(0, 2)).double().cpu() + float(os.environ.get("BAND_ROW_BIAS", "0"))
         bounds = balanced_bounds(w, G, align=8, min_rows=8)
         out["balanced_bounds"] = bounds
+    if layout == "fitted":
+        # contiguous bands from the MEASURED times of the two layouts above (dss_amd.distributed.fitted_bounds)
+        w = fwd(None)["occupancy"].sum(dim=(0, 2)).double().cpu()
+        equal = [RowPartition(S, G, r).rows[0] for r in range(G)] + [S]
+        bounds, fit = fitted_bounds(w, [(equal, out["bands"]["graph_us"]), (out["balanced_bounds"], out["balanced"]["graph_us"])], G)
+        out["fitted_bounds"], out["fitted_model_F_a_b"] = bounds, [float("%.4g" % v) for v in fit]
+    if layout.startswith("rebalanced"):
+        # measured-time rebalancing (dss_amd.distributed.rebalanced_bounds), starting from the fitted layout; rebalanced2 = a second step
+        prev = "fitted" if layout == "rebalanced" else "rebalanced"
+        bounds = rebalanced_bounds(out[prev + "_bounds"], out[prev]["graph_us"], out["fitted_model_F_a_b"][0])
+        out[layout + "_bounds"] = bounds
     parts = [RowPartition(S, G, r, cyclic=(layout == "cyclic"), bounds=bounds) for r in range(G)]
     # (union of the ranks' visibility flags = the flags of the full render: one call instead of G band renders)
     vis_all = fwd(None)["visible"].clone()
