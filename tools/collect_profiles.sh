@@ -27,16 +27,18 @@ python tools/fetch_large.py cfg4 > $out/fetch_cfg4.txt 2>&1
 python tools/pmc_large.py cfg4 > $out/pmc_sq_cfg4.txt 2>&1
 python tools/fine_timing.py cfg2 > $out/fine_timing_cfg2.txt 2>&1
 python tools/fine_timing.py cfg4 > $out/fine_timing_cfg4.txt 2>&1
-build_ab/valu_rate > $out/valu_rate.txt 2>&1
+mkdir -p build_ab && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/valu_rate.hip -o build_ab/valu_rate 2>/dev/null; build_ab/valu_rate > $out/valu_rate.txt 2>&1
 for g in 2 4 8; do python tools/band_timing.py $g cfg2 >> $out/band_timing_cfg2.jsonl 2>/dev/null; done
-python tools/band_timing.py 8 cfg4 > $out/band_timing_cfg4.json 2>/dev/null
 python tools/predict_scaling.py cfg2 > $out/predicted_scaling_cfg2.json 2>/dev/null
-python tools/predict_scaling.py cfg4 > $out/predicted_scaling_cfg4.json 2>/dev/null
+for c in cfg4 cfg5; do PREDICT_FLOOR_FROM=$out/predicted_scaling_cfg2.json python tools/predict_scaling.py $c > $out/predicted_scaling_$c.json 2>/dev/null; done
 # one emulated rank of the 8-rank step under the kernel trace (metric's configuration: cyclic bands; configs[3]: contiguous)
 BAND_TRACE=1 BAND_TRACE_LAYOUT=cyclic rocprofv3 --kernel-trace --stats -d $out/ks -o b --output-format csv -- python tools/band_timing.py 8 cfg2 > /dev/null 2>&1
 cp $(find $out/ks -name '*kernel_stats.csv' | head -1) $out/band_kernel_stats_cfg2_cyclic_rank3.csv; rm -rf $out/ks
 BAND_TRACE=1 BAND_TRACE_LAYOUT=bands rocprofv3 --kernel-trace --stats -d $out/ks -o b --output-format csv -- python tools/band_timing.py 8 cfg4 > /dev/null 2>&1
 cp $(find $out/ks -name '*kernel_stats.csv' | head -1) $out/band_kernel_stats_cfg4_bands_rank3.csv; rm -rf $out/ks
+BAND_TRACE=1 BAND_TRACE_LAYOUT=bands rocprofv3 --kernel-trace --stats -d $out/ks -o b --output-format csv -- python tools/band_timing.py 8 cfg5 > /dev/null 2>&1
+cp $(find $out/ks -name '*kernel_stats.csv' | head -1) $out/band_kernel_stats_cfg5_bands_rank3.csv; rm -rf $out/ks
+for w in headline cfg3 cfg4 cfg5; do python tools/window_stats.py $w 2>/dev/null >> $out/backward_window_stats.jsonl; done
 { python tools/band_fused_timing.py 8 cyclic 3; TIMING_REBUILD=0 python tools/band_fused_timing.py 8 balanced 3; } > $out/band_gather_stamps.txt 2>&1
 python tools/setup_timing.py > $out/setup_timing.txt 2>&1
 for e in overlap auto; do BENCH_FORCE_DIST=1 BENCH_EXCHANGE=$e python bench.py --gpus 1 --no-cpu-baseline --no-traffic 2>/dev/null | grep '^{' > $out/bench_forced_dist_world1_$e.json; done

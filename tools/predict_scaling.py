@@ -13,7 +13,7 @@ labelled as such in its output; no N > 1 run has been available to this build (S
                                             links x 153 GB/s (MI355X_MICROARCH.md), direct schedule; the overlapped exchange hides
                                             the image bands behind the backward, the folded one does not
 
-    python tools/predict_scaling.py [cfg2|cfg4]  -> one JSON object on stdout"""
+    python tools/predict_scaling.py [cfg2|cfg4|cfg5]  -> one JSON object on stdout"""
 import json
 import os
 import subprocess
@@ -40,7 +40,8 @@ out = {"what": "PREDICTED scaling of `bench.py --gpus G%s` -- per-rank compute e
        "workload": which}
 bands = {}
 for G in (1, 2, 4, 8):
-    lay = "bands" if G == 1 else ("balanced,cyclic" if which == "cfg2" else "bands,cyclic")
+    # (large workloads: contiguous bands -- equal rows, occupancy-balanced, fitted to the measured times, two rebalancing steps)
+    lay = "bands" if G == 1 else ("balanced,cyclic" if which == "cfg2" else "bands,balanced,fitted,rebalanced,rebalanced2")
     bands[G] = run([py, os.path.join(ROOT, "tools", "band_timing.py"), str(G), which], {"BAND_LAYOUTS": lay})
 Pc, S = bands[1]["points_per_cloud"], bands[1]["image_size"]
 cams = {G: bands[G]["cameras"] for G in bands}
@@ -61,12 +62,15 @@ if which == "cfg2":
 else:
     single_us = bands[1]["single_gpu_step_us"]["eager"]
     # (the large workloads run eagerly; the collective floor of the metric's configuration is latency, not bytes: reused)
-    try:
-        prev = json.load(open(os.path.join(ROOT, "profiles", "r5_a_predicted_scaling_cfg2.json")))
-        floors = {k: {"collective_floor_us": v["collective_floor_us"], "from": "profiles/r5_a_predicted_scaling_cfg2.json"}
-                  for k, v in prev["collective_floor"].items()}
-    except Exception:  # noqa: BLE001
-        floors = {"overlap": {"collective_floor_us": 20.0, "from": "round-4 measurement (78.3 - 58 us)"}}
+    floors = {"overlap": {"collective_floor_us": 20.0, "from": "round-4 measurement (78.3 - 58 us)"}}
+    for src in (os.environ.get("PREDICT_FLOOR_FROM", ""), "profiles/r5_b_predicted_scaling_cfg2.json",
+                "profiles/r5_c_predicted_scaling_cfg2.json"):
+        try:
+            prev = json.load(open(os.path.join(ROOT, src)))
+            floors = {k: {"collective_floor_us": v["collective_floor_us"], "from": src} for k, v in prev["collective_floor"].items()}
+            break
+        except Exception:  # noqa: BLE001
+            continue
 out["single_gpu_step_us"] = round(single_us, 2)
 out["multi_step_compute_world1_us"] = multi1
 out["collective_floor"] = floors
