@@ -861,7 +861,7 @@ __global__ __launch_bounds__(CELL_THREADS) void cell_hist_kernel(
     CellGrid cg, const uint32_t *__restrict__ vis_count, const int32_t *__restrict__ vis_list,
     uint32_t *__restrict__ cell_of, uint32_t *__restrict__ block_hist,
     const float *__restrict__ radii /* NULL: whole image, no filter */, const float *__restrict__ rs, int row0, int rows,
-    int tshift, float *__restrict__ grad_pts, float *__restrict__ grad_feat, int C)
+    int tshift)
 {
     extern __shared__ uint32_t s_hist[];
     const uint32_t count = *vis_count;
@@ -2622,8 +2622,7 @@ static int render_backward_impl(bool run_prep, const float *grad_out, const int3
         const size_t lds = (size_t)cg.total * 4;
         const bool band_l = rows < S || cyc;   // row band: the entries that cannot reach it drop out of the sorted list
         hipLaunchKernelGGL(cell_hist_kernel, dim3(cb), dim3(CELL_THREADS), lds, st, points, first_idx, num_pts, N, S, cg,
-                           vis_count, unsorted, cell_of, block_hist, band_l ? radii : nullptr, rs, row0, rows, tshift, grad_pts,
-                           grad_feat, C);
+                           vis_count, unsorted, cell_of, block_hist, band_l ? radii : nullptr, rs, row0, rows, tshift);
         hipLaunchKernelGGL(cell_block_scan_kernel, dim3((unsigned)((cg.total + 255) / 256)), dim3(256), 0, st, vis_count,
                            cg.total, block_hist, cell_total);
         hipLaunchKernelGGL(cell_scan_kernel, dim3(1), dim3(1024), 0, st, cell_total, cell_start, cg.total, vis_count + 1);
