@@ -129,6 +129,15 @@ class Workload:
             self._fx[False].late_image = os.environ.get("BENCH_IMAGE_LATE", "0") == "1"
             self.fx = self._fx[False]
             self.bucket = torch.empty(self.P * 6, device=device)
+            # gradient exchange (round 5): "owner" -- the rank whose band holds a point's centre row computes the pair's WHOLE
+            # position gradient (dss_render_backward_owned; every rank holds the full image gradient), so clip + projection run
+            # before ONE all-reduce of the world-space sums (Pc x 6 floats); "bucket" -- rounds 2-4: partial sums of every
+            # (camera, point) pair reduced first (N Pc x 6 floats), clip + projection behind the reduction
+            # (default: owner on the long-list path -- above 262,144 (camera, point) pairs, where it is no slower per rank and the
+            # reduction shrinks by the camera count --, bucket below: the short-list gather reads the alpha channel of the full
+            # image gradient in place there and is ~6 us per rank slower, for an exchange that is latency either way)
+            self.owner = os.environ.get("BENCH_GRADIENT", "owner" if self.P > 262144 else "bucket") == "owner"
+            self.wbucket = torch.empty(self.Pc * 6, device=device)
             if fold:
                 self.set_exchange(True)
 
@@ -193,10 +202,23 @@ class Workload:
             g_pts = self.bucket[self.P * 3:].view(self.P, 3)
             # same fused kernel on the band; visibility = union over ranks, clip after the reduction
             ops.render_backward(g_band, idx, qv, wsum, info["scaler"], info["pts_screen"], info["radii"], vis_all,
-                                self.first, self.num, RADII_S, -1.0, image_size=S, rows=p.rows, out=(g_feat, g_pts))
+                                self.first, self.num, RADII_S, -1.0, image_size=S, rows=p.rows, out=(g_feat, g_pts),
+                                grad_out_full=self.grad_out if self.owner else None)
             if self.fx.late_image:
                 self.fx.start_image()   # issued behind the backward's launches, from a side stream that only waits for the forward
             mark("backward_compute")
+            if self.owner:
+                # the pairs' position gradients are complete on their owners: clip + projection + sum over the cameras first,
+                # then collective 3/3 on the world-space sums
+                g_world, g_col = self.wbucket[:self.Pc * 3].view(self.Pc, 3), self.wbucket[self.Pc * 3:].view(self.Pc, 3)
+                ops.project_backward(self.world, self.M, self.V, self.first, self.num, g_pts, info["valid"], True, clip=CLIP,
+                                     grad_features=g_feat, out=(g_world, g_col))
+                mark("projection_compute")
+                dist.all_reduce(self.wbucket, op=dist.ReduceOp.SUM)
+                mark("wait_gradient_allreduce")
+                image = self.fx.finish()
+                mark("wait_image_allgather")
+                return image, g_world, g_col
             dist.all_reduce(self.bucket, op=dist.ReduceOp.SUM)  # collective 3/3: both gradient partials, one bucket
             mark("wait_gradient_allreduce")
             image = self.fx.finish()  # full render, (N,S,S,4) view of the receive buffer
@@ -233,15 +255,19 @@ class Workload:
                                           out_image=self.fx.image, out_visible=self.fx.visible,
                                           band_outputs_only=p.world_size > 1)
 
+        def proj():
+            out = None
+            if self.owner:
+                out = (self.wbucket[:self.Pc * 3].view(self.Pc, 3), self.wbucket[self.Pc * 3:].view(self.Pc, 3))
+            seg["g_world"], seg["g_col"] = ops.project_backward(self.world, self.M, self.V, self.first, self.num, g_pts,
+                                                                seg["f"]["valid"], True, clip=CLIP, grad_features=g_feat, out=out)
+
         def bwd():
             f = seg["f"]
             ops.render_backward(self.g_band, f["idx"], f["qvalue"], f["wsum"], f["scaler"], f["pts_screen"], f["radii"],
                                 self.vis_all, self.first, self.num, RADII_S, -1.0, image_size=S, rows=p.rows,
-                                out=(g_feat, g_pts))
+                                out=(g_feat, g_pts), grad_out_full=self.grad_out if self.owner else None)
 
-        def proj():
-            seg["g_world"], seg["g_col"] = ops.project_backward(self.world, self.M, self.V, self.first, self.num, g_pts,
-                                                                seg["f"]["valid"], True, clip=CLIP, grad_features=g_feat)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -279,12 +305,16 @@ class Workload:
         if late:
             self.fx.start_image()
         mark("backward_compute")
-        dist.all_reduce(self.bucket, op=dist.ReduceOp.SUM)
+        if self.owner:   # clip + projection in front of the reduction (of the world-space sums)
+            self._graphs[2].replay()
+            mark("projection_compute")
+        dist.all_reduce(self.wbucket if self.owner else self.bucket, op=dist.ReduceOp.SUM)
         mark("wait_gradient_allreduce")
         image = self.fx.finish()
         mark("wait_image_allgather")
-        self._graphs[2].replay()
-        mark("projection_compute")
+        if not self.owner:
+            self._graphs[2].replay()
+            mark("projection_compute")
         return image, self._seg["g_world"], self._seg["g_col"]
 
     # ---- multi-GPU: the WHOLE step as one hipGraph -- launches AND the three RCCL collectives -------------------------------
@@ -953,6 +983,11 @@ def main():
                       "rccl_version": nccl_v,
                       "visible_devices": torch.cuda.device_count(), "partition": part.describe(),
                       "exchange": exchange_note, "collectives_per_step": 2 if wl.fx.fold else 3,
+                      "gradient_exchange": ("owner: the rank of a point's centre row computes the pair's whole position gradient "
+                                            "(dss_render_backward_owned), clip + projection, then ONE all-reduce of %d bytes"
+                                            % (wl.Pc * 24)) if wl.owner else
+                                           ("bucket: partial sums of every (camera, point) pair, ONE all-reduce of %d bytes, clip + "
+                                            "projection behind it" % (wl.P * 24)),
                       "overlap": bool(wl.fx.overlap) and not wl.fx.fold, "image_issue": "behind the backward (side stream)" if wl.fx.late_image else "before the backward, after the visibility union", "degraded": wl.fx.degraded, "segment_capture": seg_note or "ok",
                       "whole_step_graph": whole_note or "ok",
                       "timing_us": {k: {"min": round(float(allt[:, i].min()), 1), "max": round(float(allt[:, i].max()), 1),

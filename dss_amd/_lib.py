@@ -53,6 +53,8 @@ SIGNATURES = {
     "dss_render_backward_workspace": (_c_sz, [_c_int, _c_i64, _c_int]),
     "dss_render_backward": (_c_int, [_c_vp] * 10 + [_c_int, _c_i64, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_f32, _c_f32]
                             + [_c_vp] * 5 + [_c_vp, _c_sz, _c_vp]),
+    "dss_render_backward_owned": (_c_int, [_c_vp] * 11 + [_c_int, _c_i64, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_f32, _c_f32]
+                                  + [_c_vp] * 3 + [_c_vp, _c_sz, _c_vp]),
     "dss_render_backward_gather": (_c_int, [_c_vp] * 10 + [_c_int, _c_i64, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
                                                           _c_f32, _c_f32] + [_c_vp] * 5 + [_c_vp, _c_sz, _c_vp]),
     "dss_phong_forward": (_c_int, [_c_vp] * 5 + [_c_int, _c_i64, _c_int] + [_c_vp] * 4 + [_c_int, _c_int, _c_vp, _c_f32,

@@ -734,6 +734,49 @@ __device__ __forceinline__ int band_row_floor(int r, int row0, int tshift)
     return 8 * q + min(m, 7);
 }
 
+// is image row r one of the band's rows?
+__device__ __forceinline__ bool band_owns_row(int r, int row0, int rows, int tshift)
+{
+    const int x = r - row0;
+    if (x < 0) return false;
+    const int m = x & ((1 << tshift) - 1);
+    return m < 8 && 8 * (x >> tshift) + m < rows;
+}
+// OWNER mode of a row band (dss_render_backward_owned): the occupancy surrogate of a point -- its whole window, over all image
+// rows, read from the FULL image gradient every rank holds -- is computed by the one rank whose band contains the image row
+// of the point's centre; the blend half stays with the rows that hold the fragments.  The position gradient of a (camera,
+// point) pair is then complete on its owner (the other ranks store zeros): the non-linear per-point clip can run before the
+// reduction over the ranks, which shrinks from a dense (N P, 6) bucket to the world-space (P_cloud, 6) sums.
+struct OwnArgs {
+    const float *alpha;   // alpha channel of the full image gradient, (N, S, S) pixels `astride` floats apart; NULL: off
+    int astride;
+};
+__device__ __forceinline__ int centre_image_row(float py, int S)
+{
+    const float fy = (1.0f - py) * 0.5f * (float)S;   // pixel row of the centre (any fixed partition of the axis does)
+    return min(max((int)fy, 0), S - 1);
+}
+
+// Owner mode, long lists: the dense alpha plane in FULL-image layout (N,S,S), filled only where an owned window can reach
+// -- the rows within the largest search radius (read from rs on the device: the medians run in front of this launch) of one
+// of the band's rows.  (Reading the alpha channel in place, 16 bytes apart, costs the gather four times the cache lines.)
+__global__ __launch_bounds__(256) void alpha_rows_kernel(const float *__restrict__ grad_full, float *__restrict__ plane,
+                                                         const float *__restrict__ rs, int N, int S, int C, int row0, int rows,
+                                                         int tshift)
+{
+    const int r = blockIdx.x, n = blockIdx.y;
+    float rmax = 0.0f;
+    for (int c = 0; c < N; ++c) rmax = fmaxf(rmax, rs[c]);
+    const int H = (int)ceilf(fminf(rmax, 4.0f) * 0.5f * (float)S) + 2;   // pixels (NDC spans 2 over S pixels)
+    const int lf = band_row_floor(r, row0, tshift), lc = band_row_ceil(r, row0, tshift);
+    bool need = false;
+    if (lf >= 0 && r - band_image_row(min(lf, rows - 1), row0, tshift) <= H) need = true;
+    if (lc < rows && band_image_row(lc, row0, tshift) - r <= H) need = true;
+    if (!need) return;
+    const size_t base = ((size_t)n * S + r) * S;
+    for (int c = threadIdx.x; c < S; c += 256) plane[base + c] = grad_full[(base + c) * (size_t)(C + 1) + C];
+}
+
 // Row band (multi-GPU), after the median: drop the visible points that cannot reach this rank's rows from the
 // segment lists, in place (one workgroup per segment: all entries are read into registers before any is
 // written), and zero their gradient rows (this band's partial sum for them is zero).  Same conservative test
@@ -744,7 +787,7 @@ __global__ __launch_bounds__(PREP_THREADS) void band_filter_kernel(
     const float *__restrict__ points, const float *__restrict__ radii, const float *__restrict__ rs,
     const int64_t *__restrict__ first_idx, const int64_t *__restrict__ num_pts, int N, int S, int row0, int rows,
     uint32_t *__restrict__ seg_count, int32_t *__restrict__ vis_list, float *__restrict__ grad_pts,
-    float *__restrict__ grad_feat, int C, int tshift)
+    float *__restrict__ grad_feat, int C, int tshift, int own = 0 /* owner mode: only the splat's own box must meet the band */)
 {
     __shared__ uint32_t s_w[PER * PREP_THREADS / 64];
     constexpr int SEG_PTS = PER * PREP_THREADS;
@@ -767,7 +810,7 @@ __global__ __launch_bounds__(PREP_THREADS) void band_filter_kernel(
         if (id[u] >= 0) {
             const int n = find_cloud(id[u], first_idx, num_pts, N);
             const float py = points[3 * (size_t)id[u] + 1], ry = radii[2 * (size_t)id[u] + 1];
-            const float reach = fmaxf(n >= 0 ? rs[n] : 0.0f, ry);
+            const float reach = own ? ry : fmaxf(n >= 0 ? rs[n] : 0.0f, ry);
             bool in_band = n >= 0 && !(py + reach < band_lo || py - reach > band_hi);
             if (in_band && tshift > 3) {
                 // cyclic band: some OWNED row must lie within reach (conservative pixel range, one pixel of slack each side)
@@ -861,7 +904,7 @@ __global__ __launch_bounds__(CELL_THREADS) void cell_hist_kernel(
     CellGrid cg, const uint32_t *__restrict__ vis_count, const int32_t *__restrict__ vis_list,
     uint32_t *__restrict__ cell_of, uint32_t *__restrict__ block_hist,
     const float *__restrict__ radii /* NULL: whole image, no filter */, const float *__restrict__ rs, int row0, int rows,
-    int tshift)
+    int tshift, int own = 0)
 {
     extern __shared__ uint32_t s_hist[];
     const uint32_t count = *vis_count;
@@ -884,7 +927,7 @@ __global__ __launch_bounds__(CELL_THREADS) void cell_hist_kernel(
                 const int last_row = row0 + (((rows - 1) >> 3) << tshift) + ((rows - 1) & 7);
                 const float band_lo = -1 + (2 * (S - 1 - last_row)) / (float)S;     // lower edge of the lowest pixel row
                 const float band_hi = -1 + (2 * (S - 1 - row0) + 2.0f) / (float)S;  // upper edge of the highest one
-                const float reach = fmaxf(rs[n], radii[2 * (size_t)p + 1]);
+                const float reach = own ? radii[2 * (size_t)p + 1] : fmaxf(rs[n], radii[2 * (size_t)p + 1]);
                 bool in_band = !(py + reach < band_lo || py - reach > band_hi);
                 if (in_band && tshift > 3) {
                     int ylo, yhi;
@@ -1520,7 +1563,8 @@ __global__ __launch_bounds__(256) void render_backward_kernel(
     const float *__restrict__ world = nullptr /* (P,3): fused projection backward, see the epilogue */,
     const float *__restrict__ Mproj = nullptr /* (N,4,4) */,
     const FusedPrep F = FusedPrep() /* PREP: preparation stages inside this launch, see fb_prep_segment */,
-    int astride = 1 /* elements between two pixels of grad_alpha: 1 = dense plane, C + 1 = the alpha channel of grad_out in place */)
+    int astride = 1 /* elements between two pixels of grad_alpha: 1 = dense plane, C + 1 = the alpha channel of grad_out in place */,
+    const OwnArgs OW = OwnArgs{nullptr, 1} /* owner mode of a row band, see OwnArgs */)
 {
     constexpr int CM = (C > 0) ? C : BLEND_MAX_C;
     constexpr int KF = 8;            // fragment slots held in registers; deeper lists take the loop
@@ -1690,6 +1734,9 @@ __global__ __launch_bounds__(256) void render_backward_kernel(
                 const float reach = WHICH == 0 ? b_ry[j] : s_brs[b_n[j]];
                 const float py = b_py[j];
                 keep = !(py + reach < band_lo || py - reach > band_hi);
+                if (WHICH == 1 && OW.alpha != nullptr) {
+                    keep = band_owns_row(centre_image_row(py, S), row0, rows, tshift);   // owner mode: whole windows of the own centres
+                } else
                 if (keep && CYC) {
                     int ylo, yhi;
                     keep = ndc_index_range(py, reach, S, ylo, yhi) &&
@@ -1783,9 +1830,17 @@ __global__ __launch_bounds__(256) void render_backward_kernel(
         int xlo = 0, xhi = -1, ylo = 0, yhi = -1;
         bool o_ok = n >= 0 && !(pz < 0 || fabsf(py) > 1.0f || fabsf(px) > 1.0f) &&
                     ndc_index_range_tight(px, cur_r, S, xlo, xhi) && ndc_index_range_tight(py, cur_r, S, ylo, yhi);
+        // owner mode: the whole window over the full image, for the points whose centre row is one of this band's rows
+        const bool own_m = OW.alpha != nullptr;
+        const bool o_cyc = CYC && !own_m;
+        const int o_row0 = own_m ? 0 : row0, o_rows = own_m ? S : rows;
+        const size_t o_plane = own_m ? (size_t)S * S : plane;
+        const int o_astride = own_m ? OW.astride : astride;
+        const float *__restrict__ o_alpha = own_m ? OW.alpha : grad_alpha;
+        if (own_m) o_ok = o_ok && band_owns_row(centre_image_row(py, S), row0, rows, tshift);
         int l_hi = -1;   // CYC: band row of window row 0 (the window's rows are band rows l_hi, l_hi - 1, ..., l_hi - oh + 1)
         if (o_ok) {
-            if (CYC) {
+            if (o_cyc) {
                 // image rows S-1-yhi .. S-1-ylo -> the band rows among them
                 const int l_lo = band_row_ceil(S - 1 - yhi, row0, tshift);
                 l_hi = min(band_row_floor(S - 1 - ylo, row0, tshift), rows - 1);
@@ -1793,8 +1848,8 @@ __global__ __launch_bounds__(256) void render_backward_kernel(
                 ylo = 0;
                 yhi = l_hi - l_lo;   // (only yhi - ylo + 1 = the number of window rows is used below)
             } else {
-                ylo = max(ylo, S - row0 - rows);
-                yhi = min(yhi, S - 1 - row0);
+                ylo = max(ylo, S - o_row0 - o_rows);
+                yhi = min(yhi, S - 1 - o_row0);
                 o_ok = ylo <= yhi;
             }
         }
@@ -1802,7 +1857,7 @@ __global__ __launch_bounds__(256) void render_backward_kernel(
         const int ow = xhi - xlo + 1, oh = yhi - ylo + 1;          // 0 for an empty window
         const int ncp = (tasks_max<TPW>(ow) + 31) >> 5;             // column-slot pairs: wave-uniform
         const int nrow = (tasks_max<TPW>(oh) + RP - 1) / RP;        // rows per lane row: wave-uniform
-        const float *__restrict__ gimg = grad_alpha + (size_t)nn * plane * astride;
+        const float *__restrict__ gimg = o_alpha + (size_t)nn * o_plane * o_astride;
         for (int cp = 0; cp < ncp; ++cp) {
             // this lane's two columns of the pass: x0 = xlo + 32 cp + l, x1 = x0 + 16 (clamped: masked, in bounds)
             const int x0 = xlo + 32 * cp + l, x1 = x0 + 16;
@@ -1815,7 +1870,7 @@ __global__ __launch_bounds__(256) void render_backward_kernel(
             // "g > 0 and outside the splat's box": with ry_eff = -1 for out-of-box columns the row test alone decides
             const f2 ry_eff = {(fabsf(dx.x) > rx) ? -1.0f : ry, (fabsf(dx.y) > rx) ? -1.0f : ry};
             // image (row, col) of NDC (y, x) is (S-1-y, S-1-x); band row = S-1-y-row0: one image row up per NDC row
-            const int top = CYC ? max(l_hi, 0) : (S - 1 - row0 - max(ylo, 0));   // band row of window row 0
+            const int top = o_cyc ? max(l_hi, 0) : (S - 1 - o_row0 - max(ylo, 0));   // band row of window row 0
             const int i0 = top * S + (S - 1 - x0c);  // element offsets in the camera's plane
             const int i1 = top * S + (S - 1 - x1c);
             // RB rows per trip: all their loads are issued before the first is used (one memory round trip per trip; a
@@ -1831,10 +1886,10 @@ __global__ __launch_bounds__(256) void render_backward_kernel(
                     // unconditional loads from clamped (always valid) addresses, masked afterwards: no exec-mask branch
                     // around every load, 32-bit byte offsets from the tensor base
                     // (without the dense plane: the alpha channel of grad_out in place, `astride` floats per pixel)
-                    const uint32_t e4 = 4u * (uint32_t)astride;
+                    const uint32_t e4 = 4u * (uint32_t)o_astride;
                     const uint32_t S4 = (uint32_t)S * e4;
-                    const uint32_t w0 = ((uint32_t)nn * (uint32_t)plane + (uint32_t)(o_ok ? i0 : 0)) * e4;
-                    const uint32_t w1 = ((uint32_t)nn * (uint32_t)plane + (uint32_t)(o_ok ? i1 : 0)) * e4;
+                    const uint32_t w0 = ((uint32_t)nn * (uint32_t)o_plane + (uint32_t)(o_ok ? i0 : 0)) * e4;
+                    const uint32_t w1 = ((uint32_t)nn * (uint32_t)o_plane + (uint32_t)(o_ok ? i1 : 0)) * e4;
                     // a trip whose RB rows lie inside the window of every task of the wavefront (two of three trips at the
                     // bench sizes) walks two running offsets: no row test, no clamp, no mask (5 VALU per row less of 26);
                     // a task without a window stays on pixel 0 of its plane (step 0) and is dropped by its infinite dx2
@@ -1845,8 +1900,8 @@ __global__ __launch_bounds__(256) void render_backward_kernel(
                         uint32_t q0 = w0 - first, q1 = w1 - first;
 #pragma unroll
                         for (int u = 0; u < RB; ++u) {
-                            g0[u] = ld_off(grad_alpha, q0);
-                            g1[u] = ld_off(grad_alpha, q1);
+                            g0[u] = ld_off(o_alpha, q0);
+                            g1[u] = ld_off(o_alpha, q1);
                             q0 -= step4;
                             q1 -= step4;
                         }
@@ -1856,7 +1911,7 @@ __global__ __launch_bounds__(256) void render_backward_kernel(
                         const int i = rp + RP * (ib + u);   // window row of this lane row
                         const bool r_ok = i < oh;
                         const uint32_t back = __umul24((uint32_t)(r_ok ? i : 0), S4);
-                        const float a0 = ld_off(grad_alpha, w0 - back), a1 = ld_off(grad_alpha, w1 - back);
+                        const float a0 = ld_off(o_alpha, w0 - back), a1 = ld_off(o_alpha, w1 - back);
                         g0[u] = r_ok ? a0 : 0.0f;
                         g1[u] = r_ok ? a1 : 0.0f;
                     }
@@ -1868,8 +1923,8 @@ __global__ __launch_bounds__(256) void render_backward_kernel(
                     const bool r_ok = i < oh;
                     g0[u] = 0.0f;
                     g1[u] = 0.0f;
-                    if (r_ok && c0) g0[u] = gimg[(size_t)(i0 - i * S) * astride];
-                    if (r_ok && c1) g1[u] = gimg[(size_t)(i1 - i * S) * astride];
+                    if (r_ok && c0) g0[u] = gimg[(size_t)(i0 - i * S) * o_astride];
+                    if (r_ok && c1) g1[u] = gimg[(size_t)(i1 - i * S) * o_astride];
                 }
                 }
                 const float y_ib = ndc(ylo + rp + RP * ib);
@@ -1879,8 +1934,8 @@ __global__ __launch_bounds__(256) void render_backward_kernel(
                 for (int u = 0; u < RB; ++u) {
                     if (ib + u >= nrow) break;  // uniform
                     // CYC: window row i is band row l_hi - i; its image row comes from the band map
-                    const float yv = CYC ? ndc(S - 1 - band_image_row(max(l_hi - (rp + RP * (ib + u)), 0), row0, tshift))
-                                         : (POW2 ? y_ib + (float)u * y_step : ndc(ylo + rp + RP * (ib + u)));
+                    const float yv = o_cyc ? ndc(S - 1 - band_image_row(max(l_hi - (rp + RP * (ib + u)), 0), row0, tshift))
+                                           : (POW2 ? y_ib + (float)u * y_step : ndc(ylo + rp + RP * (ib + u)));
                     const float dy = yv - py;
                     const float dy2 = dy * dy;
                     const f2 gg = {g0[u], g1[u]};
@@ -2414,7 +2469,8 @@ static int render_backward_impl(bool run_prep, const float *grad_out, const int3
                                 const uint8_t *visible, const int64_t *first_idx, const int64_t *num_pts, int N,
                                 int64_t P, int S, int K, int C, int row0, int row1, int row_cycle, float radii_s, float clip,
                                 float *grad_feat, float *grad_pts, float *rs_out, const float *world, const float *Mproj,
-                                void *workspace, size_t workspace_bytes, void *stream)
+                                void *workspace, size_t workspace_bytes, void *stream,
+                                const float *grad_full = nullptr /* (N,S,S,C+1): owner mode of a row band, see OwnArgs */)
 {
     if (N <= 0 || P < 0 || S <= 0 || K <= 0 || C < 1 || C > BLEND_MAX_C || row0 < 0 || row1 > S || row0 >= row1 ||
         row_cycle < 1 || (row_cycle & (row_cycle - 1)) || row_cycle > 4096) {
@@ -2435,6 +2491,9 @@ static int render_backward_impl(bool run_prep, const float *grad_out, const int3
     const bool cyc = row_cycle > 1;
     if (P == 0) return DSS_OK;
     if (P > 0x7ffffff0ll) { set_error("dss_render_backward: P too large"); return DSS_ERR_UNSUPPORTED; }
+    // owner mode only means something on a band (the whole image owns every centre: the plain form)
+    OwnArgs OW = {(grad_full != nullptr && (rows < S || cyc)) ? grad_full + C : nullptr, C + 1};
+    const int own = OW.alpha != nullptr ? 1 : 0;
     if (!grad_out || !points || !radii || !visible || !first_idx || !num_pts || !grad_pts ||
         (grad_feat && (!idx || !qvalue || !scaler))) {
         set_error("dss_render_backward: NULL tensor pointer");
@@ -2494,8 +2553,9 @@ static int render_backward_impl(bool run_prep, const float *grad_out, const int3
     if (tpw_opt == 1 || tpw_opt == 2 || tpw_opt == 4) tpw = tpw_opt;
     // 32-bit byte offsets from the tensor bases (one VALU per gather address instead of 64-bit index arithmetic) whenever
     // every gathered tensor is smaller than 4 GB; larger problems take the 64-bit addressing, four tasks per wavefront
-    const unsigned long long widest = (unsigned long long)N * (unsigned long long)rows * (unsigned long long)S *
-                                      (unsigned long long)(K > C + 1 ? K : C + 1) * 4ull;
+    unsigned long long widest = (unsigned long long)N * (unsigned long long)rows * (unsigned long long)S *
+                                (unsigned long long)(K > C + 1 ? K : C + 1) * 4ull;
+    if (own) widest = std::max(widest, (unsigned long long)N * (unsigned long long)S * (unsigned long long)S * (unsigned long long)(C + 1) * 4ull);
     // (DSS_OPT_BACKWARD_ADDR64 forces the 64-bit variant: it only exists for tensors nobody allocates in a test)
     const bool a32 = widest < (1ull << 32) && option(DSS_OPT_BACKWARD_ADDR64) != 1;
     if (!a32) tpw = 4;
@@ -2595,10 +2655,10 @@ static int render_backward_impl(bool run_prep, const float *grad_out, const int3
         if (run_prep && rows < S) {  // row band: keep only the points that can reach it
             if (L.per == 2)
                 hipLaunchKernelGGL(band_filter_kernel<2>, dim3(L.chunks), dim3(PREP_THREADS), 0, st, points, radii, rs,
-                                   first_idx, num_pts, N, S, row0, rows, vis_count, vis_list, grad_pts, grad_feat, C, tshift);
+                                   first_idx, num_pts, N, S, row0, rows, vis_count, vis_list, grad_pts, grad_feat, C, tshift, own);
             else
                 hipLaunchKernelGGL(band_filter_kernel<4>, dim3(L.chunks), dim3(PREP_THREADS), 0, st, points, radii, rs,
-                                   first_idx, num_pts, N, S, row0, rows, vis_count, vis_list, grad_pts, grad_feat, C, tshift);
+                                   first_idx, num_pts, N, S, row0, rows, vis_count, vis_list, grad_pts, grad_feat, C, tshift, own);
         }
     } else if (!small) {
         const size_t hist_bytes = (size_t)3 * N * MED_BINS * 4;
@@ -2626,8 +2686,9 @@ static int render_backward_impl(bool run_prep, const float *grad_out, const int3
         vis_list = sorted;
 
         if (run_prep) {
-        hipLaunchKernelGGL(alpha_plane_kernel, dim3((unsigned)((npix + ALPHA_PIX_PER_WG - 1) / ALPHA_PIX_PER_WG)), dim3(1024),
-                           0, st, grad_out, plane, npix, C);
+        if (!own)
+            hipLaunchKernelGGL(alpha_plane_kernel, dim3((unsigned)((npix + ALPHA_PIX_PER_WG - 1) / ALPHA_PIX_PER_WG)), dim3(1024),
+                               0, st, grad_out, plane, npix, C);
         if (hipMemsetAsync(hist, 0, hist_bytes + 256, st) != hipSuccess) return check_launch("memset render_backward");
         const unsigned blocks = (unsigned)((P + MED_PTS_PER_WG - 1) / MED_PTS_PER_WG);
         hipLaunchKernelGGL(visible_scan_kernel, dim3(blocks), dim3(MED_THREADS), 0, st, radii, visible, first_idx,
@@ -2637,17 +2698,21 @@ static int render_backward_impl(bool run_prep, const float *grad_out, const int3
         hipLaunchKernelGGL(median_hist_kernel<2>, dim3(blocks), dim3(MED_THREADS), 0, st, radii, visible, first_idx,
                            num_pts, N, P, hist);
         hipLaunchKernelGGL(median_final_kernel, dim3(N), dim3(MED_THREADS), 0, st, hist, N, radii_s, rs);
+        if (own)   // (the band's own plane above is not read in owner mode: its region holds the full-layout one)
+            hipLaunchKernelGGL(alpha_rows_kernel, dim3((unsigned)S, (unsigned)N), dim3(256), 0, st, grad_full, plane, rs, N, S, C,
+                               row0, rows, tshift);
         const unsigned cb = (unsigned)cell_blocks(P);   // (the visible count is only known on the device: P bounds it)
         const size_t lds = (size_t)cg.total * 4;
         const bool band_l = rows < S || cyc;   // row band: the entries that cannot reach it drop out of the sorted list
         hipLaunchKernelGGL(cell_hist_kernel, dim3(cb), dim3(CELL_THREADS), lds, st, points, first_idx, num_pts, N, S, cg,
-                           vis_count, unsorted, cell_of, block_hist, band_l ? radii : nullptr, rs, row0, rows, tshift);
+                           vis_count, unsorted, cell_of, block_hist, band_l ? radii : nullptr, rs, row0, rows, tshift, own);
         hipLaunchKernelGGL(cell_block_scan_kernel, dim3((unsigned)((cg.total + 255) / 256)), dim3(256), 0, st, vis_count,
                            cg.total, block_hist, cell_total);
         hipLaunchKernelGGL(cell_scan_kernel, dim3(1), dim3(1024), 0, st, cell_total, cell_start, cg.total, vis_count + 1);
         hipLaunchKernelGGL(cell_scatter_kernel, dim3(cb), dim3(CELL_THREADS), lds, st, cg, vis_count, unsorted, cell_of,
                            cell_start, block_hist, sorted);
         }
+        if (own) { OW.alpha = plane; OW.astride = 1; }
         vis_count += 1;   // the gather walks the SORTED list: its length (written by cell_scan_kernel) is the second word
     }
     if (fused) {
@@ -2664,7 +2729,7 @@ static int render_backward_impl(bool run_prep, const float *grad_out, const int3
 #define DSS_LAUNCH_RB_B(CC, TT, YY)                                                                                         \
     hipLaunchKernelGGL((render_backward_kernel<CC, true, TT, true, YY, true, true>), dim3(fgrid), dim3(256), 0, st, grad_out, alpha, idx, \
                        qvalue, wsum, scaler, points, radii, rs, first_idx, num_pts, vis_count, vis_list, n_seg, seg_pts, N, S, K, C, \
-                       clip, row0, rows, large_waves, grad_feat, grad_pts, tshift, nullptr, nullptr, FP, astride)
+                       clip, row0, rows, large_waves, grad_feat, grad_pts, tshift, nullptr, nullptr, FP, astride, OW)
             if (C == 3 && cyc) { if (tpw == 4) DSS_LAUNCH_RB_B(3, 4, true); else if (tpw == 2) DSS_LAUNCH_RB_B(3, 2, true); else DSS_LAUNCH_RB_B(3, 1, true); }
             else if (C == 3) { if (tpw == 4) DSS_LAUNCH_RB_B(3, 4, false); else if (tpw == 2) DSS_LAUNCH_RB_B(3, 2, false); else DSS_LAUNCH_RB_B(3, 1, false); }
             else { if (tpw == 4) DSS_LAUNCH_RB_B(0, 4, false); else if (tpw == 2) DSS_LAUNCH_RB_B(0, 2, false); else DSS_LAUNCH_RB_B(0, 1, false); }
@@ -2690,7 +2755,7 @@ static int render_backward_impl(bool run_prep, const float *grad_out, const int3
 #define DSS_LAUNCH_RB_F(CC, TT, PP)                                                                                         \
     hipLaunchKernelGGL((render_backward_kernel<CC, true, TT, true, false, PP>), dim3(fgrid), dim3(256), 0, st, grad_out, alpha, idx, \
                        qvalue, wsum, scaler, points, radii, rs, first_idx, num_pts, vis_count, vis_list, n_seg, seg_pts, N, S, K, C, \
-                       clip, row0, rows, large_waves, grad_feat, grad_pts, 3, world, Mproj, FP, astride)
+                       clip, row0, rows, large_waves, grad_feat, grad_pts, 3, world, Mproj, FP, astride, OW)
 #define DSS_LAUNCH_RB_FT(CC, PP)                                                                                            \
     do {                                                                                                                   \
         if (tpw == 4) DSS_LAUNCH_RB_F(CC, 4, PP); else if (tpw == 2) DSS_LAUNCH_RB_F(CC, 2, PP); else DSS_LAUNCH_RB_F(CC, 1, PP); \
@@ -2728,7 +2793,7 @@ static int render_backward_impl(bool run_prep, const float *grad_out, const int3
 #define DSS_LAUNCH_RB_A(CC, SS, TT, AA)                                                                                 \
     hipLaunchKernelGGL((render_backward_kernel<CC, SS, TT, AA>), dim3(resident_grid((const void *)render_backward_kernel<CC, SS, TT, AA>)), dim3(256), 0, st, grad_out, alpha, idx, qvalue, wsum, \
                        scaler, points, radii, rs, first_idx, num_pts, vis_count, vis_list, n_seg, seg_pts, N, S, K, C, clip, \
-                       row0, rows, large_waves, grad_feat, grad_pts, 3, world, Mproj)
+                       row0, rows, large_waves, grad_feat, grad_pts, 3, world, Mproj, FusedPrep(), 1, OW)
 #define DSS_LAUNCH_RB(CC, SS, TT) DSS_LAUNCH_RB_A(CC, SS, TT, true)
 #define DSS_LAUNCH_RB_T(CC, SS)                                                                                        \
     do {                                                                                                               \
@@ -2744,7 +2809,7 @@ static int render_backward_impl(bool run_prep, const float *grad_out, const int3
 #define DSS_LAUNCH_RB_C(SS, TT)                                                                                          \
     hipLaunchKernelGGL((render_backward_kernel<3, SS, TT, true, true>), dim3(resident_grid((const void *)render_backward_kernel<3, SS, TT, true, true>)), dim3(256), 0, st, grad_out, alpha, idx, qvalue, \
                        wsum, scaler, points, radii, rs, first_idx, num_pts, vis_count, vis_list, n_seg, seg_pts, N, S, K, C, clip, \
-                       row0, rows, large_waves, grad_feat, grad_pts, tshift)
+                       row0, rows, large_waves, grad_feat, grad_pts, tshift, nullptr, nullptr, FusedPrep(), 1, OW)
         if (small) { if (tpw == 4) DSS_LAUNCH_RB_C(true, 4); else if (tpw == 2) DSS_LAUNCH_RB_C(true, 2); else DSS_LAUNCH_RB_C(true, 1); }
         else { if (tpw == 4) DSS_LAUNCH_RB_C(false, 4); else if (tpw == 2) DSS_LAUNCH_RB_C(false, 2); else DSS_LAUNCH_RB_C(false, 1); }
 #undef DSS_LAUNCH_RB_C
@@ -2768,6 +2833,20 @@ extern "C" int dss_render_backward(const float *grad_out, const int32_t *idx, co
 {
     return render_backward_impl(true, grad_out, idx, qvalue, wsum, scaler, points, radii, visible, first_idx, num_pts, N, P, S,
                                 K, C, row0, row1, row_cycle, radii_s, clip, grad_feat, grad_pts, rs_out, world, M, workspace, workspace_bytes, stream);
+}
+
+// Owner mode of a row band (see OwnArgs; include/dss_hip.h): grad_out_full = the image gradient of ALL rows
+extern "C" int dss_render_backward_owned(const float *grad_out, const float *grad_out_full, const int32_t *idx, const float *qvalue,
+                                         const float *wsum, const float *scaler, const float *points, const float *radii,
+                                         const uint8_t *visible, const int64_t *first_idx, const int64_t *num_pts, int N,
+                                         int64_t P, int S, int K, int C, int row0, int row1, int row_cycle, float radii_s, float clip,
+                                         float *grad_feat, float *grad_pts, float *rs_out, void *workspace, size_t workspace_bytes,
+                                         void *stream)
+{
+    if (!grad_out_full) { set_error("dss_render_backward_owned: grad_out_full is NULL"); return DSS_ERR_INVALID_ARGUMENT; }
+    return render_backward_impl(true, grad_out, idx, qvalue, wsum, scaler, points, radii, visible, first_idx, num_pts, N, P, S,
+                                K, C, row0, row1, row_cycle, radii_s, clip, grad_feat, grad_pts, rs_out, nullptr, nullptr, workspace,
+                                workspace_bytes, stream, grad_out_full);
 }
 
 // Second stage alone (the persistent gather kernel), on the workspace (visible lists, alpha plane, rs) and the zero-filled

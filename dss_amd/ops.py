@@ -546,14 +546,19 @@ def render_backward(grad_out, idx, qvalue, wsum, scaler, points, radii, visible,
                     num_points_per_cloud, radii_s: float, clip: float = -1.0, with_features: bool = True,
                     return_rs: bool = False, image_size: Optional[int] = None,
                     rows: Optional[Tuple[int, int]] = None, out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
-                    gather_only_rs: Optional[torch.Tensor] = None, project=None):
+                    gather_only_rs: Optional[torch.Tensor] = None, project=None,
+                    grad_out_full: Optional[torch.Tensor] = None):
     """Fused backward of renderer + rasterizer (blend backward + median radius + occupancy backward +
     clip) -> (grad_features (P,C) or None, grad_pts_screen (P,3)).  With ``rows`` (multi-GPU band) pass the
     union of the visibility flags and ``clip <= 0``; the results are the band's partial sums.
     ``project=(world (P,3), M (N,4,4))`` also fuses `project_backward` into the launch: the second result is then the
     WORLD-space position gradient (clouds that are not shared between cameras, whole image, 3 feature channels).
     ``gather_only_rs`` = the ``rs`` a preceding identical call returned (and ``out`` = its outputs): re-runs only the
-    second stage, the gather kernel (``dss_render_backward_gather``; per-kernel timing)."""
+    second stage, the gather kernel (``dss_render_backward_gather``; per-kernel timing).
+    ``grad_out_full`` (N,S,S,C+1) with ``rows``: OWNER mode of the band (``dss_render_backward_owned``) -- the position
+    gradient of every (camera, point) pair is computed completely, over its whole search window in the full image gradient,
+    by the rank whose band holds the image row of the point's centre (zeros on the other ranks), so that clip and projection
+    can precede the reduction over the ranks; the feature gradients stay partial sums of the band."""
     lib = _lib.load()
     grad_out = _lib.require_gpu(grad_out, "grad_out", _f32)
     dev = grad_out.device
@@ -602,6 +607,19 @@ def render_backward(grad_out, idx, qvalue, wsum, scaler, points, radii, visible,
                                    % (P, N, tuple(w_t.shape), tuple(m_t.shape)))
             w_p, m_p = _lib.ptr(w_t), _lib.ptr(m_t)
         ws = _lib.workspace(dev, lib.dss_render_backward_workspace(N, P, S))
+        if grad_out_full is not None:
+            if project is not None or gather_only_rs is not None:
+                raise RuntimeError("grad_out_full (owner mode of a band) excludes project= and gather_only_rs=")
+            full = _lib.require_gpu(grad_out_full, "grad_out_full", _f32)
+            if tuple(full.shape) != (N, S, S, C + 1) or not full.is_contiguous():
+                raise RuntimeError("grad_out_full must be contiguous (N,S,S,C+1)")
+            rc = lib.dss_render_backward_owned(
+                _lib.ptr(grad_out), _lib.ptr(full), _lib.ptr(idx), _lib.ptr(qvalue), _lib.ptr(wsum), _lib.ptr(scaler),
+                _lib.ptr(points), _lib.ptr(radii), _lib.ptr(vis), _lib.ptr(first), _lib.ptr(num), N, P, S, K, C, row0, row1, cyc,
+                float(radii_s), float(clip), _lib.ptr(gf), _lib.ptr(gp), _lib.ptr(rs), _lib.ptr(ws), ws.numel(),
+                _lib.stream_ptr(dev))
+            _lib.check(rc, "dss_render_backward_owned")
+            return (gf, gp, rs) if return_rs else (gf, gp)
         entry = lib.dss_render_backward if gather_only_rs is None else lib.dss_render_backward_gather
         rc = entry(_lib.ptr(grad_out), _lib.ptr(idx), _lib.ptr(qvalue), _lib.ptr(wsum),
                    _lib.ptr(scaler), _lib.ptr(points), _lib.ptr(radii), _lib.ptr(vis),
@@ -822,11 +840,13 @@ def point_setup(world, normals, h, M, V, znear, zfar, cloud_to_packed_first_idx,
 
 
 def project_backward(world, M, V, cloud_to_packed_first_idx, num_points_per_cloud, grad_screen, valid,
-                     shared_cloud: bool = False, clip: float = -1.0, grad_features=None):
+                     shared_cloud: bool = False, clip: float = -1.0, grad_features=None, out=None):
     """grad of (NDC x, NDC y, view z) w.r.t. the world points -> (Pw,3).  ``clip > 0`` applies the per-point norm
     clip of ``clip_grad_`` to ``grad_screen`` on the fly (multi-GPU: the clip comes after the all-reduce).
     ``grad_features`` (P,C): also sums the per-camera feature gradients of a shared cloud over its cameras in the same
-    launch (``dss_project_backward_features``) -> (grad_world (Pw,3), grad_features_world (Pw,C))."""
+    launch (``dss_project_backward_features``) -> (grad_world (Pw,3), grad_features_world (Pw,C)).
+    ``out`` = (grad_world, grad_features_world) to write into (contiguous float32, e.g. two views of one all-reduce
+    buffer)."""
     lib = _lib.load()
     world = _lib.require_gpu(world, "world", _f32)
     dev = world.device
@@ -838,14 +858,18 @@ def project_backward(world, M, V, cloud_to_packed_first_idx, num_points_per_clou
     vis = _lib.require_gpu(_as_u8(valid), "valid", _u8)
     N, Pw = first.shape[0], world.shape[0]
     with torch.cuda.device(dev):
-        gw = torch.empty((Pw, 3), dtype=_f32, device=dev)
+        gw = torch.empty((Pw, 3), dtype=_f32, device=dev) if out is None else out[0]
+        if out is not None and (tuple(gw.shape) != (Pw, 3) or gw.dtype != _f32 or not gw.is_contiguous()):
+            raise RuntimeError("out[0] must be a contiguous float32 (Pw,3) tensor")
         if grad_features is not None:
             gfeat = _lib.require_gpu(grad_features, "grad_features", _f32)
             P = N * Pw if shared_cloud else Pw
             if gfeat.dim() != 2 or gfeat.shape[0] != P:
                 raise RuntimeError("grad_features must be packed (P,C) with P=%d, got %s" % (P, tuple(gfeat.shape)))
             C = gfeat.shape[1]
-            gfw = torch.empty((Pw, C), dtype=_f32, device=dev)
+            gfw = torch.empty((Pw, C), dtype=_f32, device=dev) if out is None else out[1]
+            if out is not None and (tuple(gfw.shape) != (Pw, C) or gfw.dtype != _f32 or not gfw.is_contiguous()):
+                raise RuntimeError("out[1] must be a contiguous float32 (Pw,C) tensor")
             rc = lib.dss_project_backward_features(_lib.ptr(world), _lib.ptr(M), _lib.ptr(V), _lib.ptr(first), _lib.ptr(num), N,
                                                    Pw, int(shared_cloud), _lib.ptr(grad_screen), _lib.ptr(vis), float(clip),
                                                    _lib.ptr(gw), _lib.ptr(gfeat), C, _lib.ptr(gfw), _lib.stream_ptr(dev))

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define DSS_HIP_VERSION 102
+#define DSS_HIP_VERSION 103
 
 #if defined(__GNUC__)
 #define DSS_API __attribute__((visibility("default")))
@@ -340,6 +340,24 @@ DSS_API int dss_render_backward(const float *grad_out, const int32_t *idx, const
                                 float *grad_pts /* (P,3) */, float *rs_out /* (N,) or NULL */,
                                 const float *world /* NULL, or (P,3): see below */, const float *M /* (N,4,4) with world */,
                                 void *workspace, size_t workspace_bytes, void *stream);
+/* OWNER mode of a row band (multi-GPU; no counterpart in the reference, which has no distributed layer).  Same arguments as
+ * dss_render_backward on the band [row0,row1) / row_cycle, plus grad_out_full (N,S,S,C+1): the image gradient of ALL rows,
+ * which every rank of a row-partitioned step holds anyway (the loss is evaluated on the gathered image).  The occupancy
+ * surrogate of a (camera, point) pair -- its whole search window, over all image rows -- is then computed by the ONE rank
+ * whose band contains the image row of the point's centre, instead of every rank adding the rows it owns; the blend half
+ * stays with the rows that hold the fragments.  grad_pts (P,3): the COMPLETE screen-space position gradient of the pairs
+ * this band owns, zeros elsewhere (summing the ranks' outputs gives dss_render_backward of the whole image up to the
+ * order of the additions); grad_feat (P,C): this band's partial sums, as before.  Because a pair's position gradient is
+ * complete on its owner, the non-linear per-point clip and the projection backward (dss_project_backward) can run BEFORE
+ * the reduction over the ranks, which then carries the world-space (P_cloud, 3 + C) sums instead of a dense (N P_cloud, 3 + C)
+ * bucket.  On the whole image (row0 = 0, row1 = S, row_cycle = 1) it is dss_render_backward. */
+DSS_API int dss_render_backward_owned(const float *grad_out, const float *grad_out_full, const int32_t *idx,
+                                      const float *qvalue, const float *wsum, const float *scaler,
+                                      const float *points, const float *radii, const uint8_t *visible,
+                                      const int64_t *first_idx, const int64_t *num_pts, int N, int64_t P, int S,
+                                      int K, int C, int row0, int row1, int row_cycle, float radii_s, float clip,
+                                      float *grad_feat, float *grad_pts, float *rs_out, void *workspace,
+                                      size_t workspace_bytes, void *stream);
 /* Second stage of dss_render_backward alone (the persistent gather kernel = blend backward + occupancy surrogate + clip of
  * every visible point, rasterize_points_backward.cu:30-212): runs on the workspace (visible lists, alpha plane, rs) and the
  * zero-filled gradients that a preceding dss_render_backward call with the SAME arguments left behind; same result.

@@ -28,7 +28,7 @@ def test_header_symbols_exported_and_bound():
 
 def test_version_and_error_channel():
     lib = _lib.load()
-    assert lib.dss_version() == 102
+    assert lib.dss_version() == 103
     rc = lib.dss_splat_forward(None, None, None, None, None, None, 0, 0, 0.05, 16, 5, 0, 0, 16,
                                None, None, None, None, None, None, 0, None)
     assert rc == -1

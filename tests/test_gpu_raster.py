@@ -227,6 +227,59 @@ def test_cell_ordered_binning_of_large_inputs_is_exact(dist):
         assert torch.equal(fb["idx"], f["idx"][:, own]) and torch.equal(fb["qvalue"], f["qvalue"][:, own]), part.describe()
 
 
+@pytest.mark.parametrize("reps,S,form", [(4, 256, 0), (4, 256, 1), (16, 512, 0)])
+def test_owner_mode_of_the_band_backward(reps, S, form):
+    """dss_render_backward_owned (`render_backward(grad_out_full=...)`): on a row band the occupancy surrogate of a (camera,
+    point) pair is computed -- whole window, full image gradient -- by the ONE rank whose band holds the image row of the
+    point's centre.  Over the ranks of a partition (contiguous, unequal, tile-row-cyclic): every pair has a non-zero position
+    gradient on at most one rank, the ranks' position gradients sum to the whole-image backward, and so do the partial
+    feature gradients.  Short lists in the two-launch form with the filter inside the gather (form 0) and in the round-3
+    launch sequence (form 1), and a list above 262,144 points (cell-sorted gather)."""
+    from dss_amd import _lib
+    from dss_amd.distributed import RowPartition
+    pts, nrm = scenes.load_cloud("yoga6")
+    pts = scenes.normalize_unit_sphere(pts)
+    pts, nrm = scenes.upsample_jitter(pts, nrm, reps, seed=0)
+    Pc = len(pts)
+    h = scenes.global_h(pts[:: max(1, Pc // 25000)]) * (25000.0 / Pc if Pc > 25000 else 1.0)
+    K, thr, N = 5, 0.05, 2
+    M = np.concatenate([scenes.camera_matrices(2.0, 20.0, a)[0] for a in (30.0, 170.0)])
+    V = np.concatenate([scenes.camera_matrices(2.0, 20.0, a)[1] for a in (30.0, 170.0)])
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    first = torch.tensor([0, Pc], dtype=torch.int64, device=DEV)
+    num = torch.tensor([Pc, Pc - 100], dtype=torch.int64, device=DEV)
+    feat = torch.rand((N * Pc, 3), device=DEV)
+    args = (t(pts), t(nrm), torch.full((N,), float(h), device=DEV), t(M), t(V), torch.full((N,), 0.1, device=DEV),
+            torch.full((N,), 100.0, device=DEV), first, num, feat, S, K, 1.0, thr, 1.0, False, True)
+    full = ops.render_forward(*args)
+    go = torch.randn((N, S, S, 4), device=DEV)
+    rel = lambda a, b: float((a - b).norm() / b.norm())
+    try:
+        if form:
+            _lib.set_option(_lib.OPT_BACKWARD_FUSED, form)
+        gf0, gp0 = ops.render_backward(go, full["idx"], full["qvalue"], full["wsum"], full["scaler"], full["pts_screen"],
+                                       full["radii"], full["visible"], first, num, 4.0, -1.0)
+        assert float(gp0.abs().sum()) > 0 and float(gf0.abs().sum()) > 0
+        for parts in ([RowPartition(S, 4, r) for r in range(4)], [RowPartition(S, 4, r, cyclic=True) for r in range(4)],
+                      [RowPartition(S, 3, r, bounds=[0, 8, S - 40, S]) for r in range(3)]):
+            gf_sum, gp_sum, owners = torch.zeros_like(gf0), torch.zeros_like(gp0), torch.zeros(N * Pc, device=DEV)
+            for part in parts:
+                own = torch.tensor(part.row_indices(), device=DEV, dtype=torch.int64)
+                o = ops.render_forward(*args, rows=part.rows)
+                gf, gp = ops.render_backward(go[:, own].contiguous(), o["idx"], o["qvalue"], o["wsum"], o["scaler"], o["pts_screen"],
+                                             o["radii"], full["visible"], first, num, 4.0, -1.0, image_size=S, rows=part.rows,
+                                             grad_out_full=go)
+                gf_sum += gf
+                gp_sum += gp
+                owners += (gp != 0).any(dim=1).float()
+            assert float(owners.max()) <= 1.0, parts[0].describe()
+            # every pair the whole-image backward moves has an owner (its centre lies on the image)
+            assert bool((~(gp0 != 0).any(dim=1) | (owners > 0)).all()), parts[0].describe()
+            assert rel(gp_sum, gp0) < 1e-5 and rel(gf_sum, gf0) < 1e-5, (parts[0].describe(), rel(gp_sum, gp0), rel(gf_sum, gf0))
+    finally:
+        _lib.set_option(_lib.OPT_BACKWARD_FUSED, 0)
+
+
 @pytest.mark.parametrize("reps,S", [(1, 128), (4, 256), (106, 512)])
 def test_band_outputs_only_gives_the_same_band_and_the_same_gradients(reps, S):
     """DSS_WS_BAND_OUTPUTS (multi-GPU ranks; `render_forward(band_outputs_only=True)`): the splats that miss the rank's rows
@@ -687,8 +740,12 @@ dist.init_process_group("gloo")
 ref = bench.Workload(dev, world, bench.RowPartition(bench.S, 1, 0))
 img1, gw1, gc1 = ref.step()
 rel = lambda a, b: float((a - b).norm() / b.norm())
-for cyclic in (False, True):       # contiguous equal bands, and the tile-row-cyclic partition bench.py --gpus N uses
+# gradient exchange: "owner" (round 5: whole position gradients on the owner of a point's centre row, clip + projection in
+# front of ONE all-reduce of the world-space sums) and "bucket" (partial sums of every pair reduced first)
+for cyclic, grad in ((False, "owner"), (True, "owner"), (False, "bucket"), (True, "bucket")):
+    os.environ["BENCH_GRADIENT"] = grad
     wl = bench.Workload(dev, world, bench.RowPartition(bench.S, world, rank, cyclic=cyclic))
+    assert wl.owner == (grad == "owner")
     img, gw, gc = wl.step()
     torch.cuda.synchronize()
     assert torch.equal(img, img1), "gathered image differs from the single-rank render (cyclic=%%s)" %% cyclic

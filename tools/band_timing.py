@@ -59,7 +59,10 @@ def quick(fn, n=60):
 
 
 out = {"G": G, "workload": which, "cameras": wl.N, "points_per_cloud": wl.Pc, "image_size": S}
+GRADIENT = os.environ.get("BAND_GRADIENT", "owner" if wl.P > 262144 else "bucket")   # bench.py's default rule
+out["gradient"] = GRADIENT
 N_IT = 60 if which == "cfg2" else 16
+OWNER = GRADIENT == "owner"   # gradient exchange of the step (bench.py BENCH_GRADIENT): owner | bucket
 TRACE = os.environ.get("BAND_TRACE") == "1"   # under rocprofv3 --kernel-trace: the cyclic partition, rank 3, eager launches only
 LAYOUTS = os.environ.get("BAND_LAYOUTS", "bands,balanced,cyclic").split(",")
 TRACE_RANK = int(os.environ.get("BAND_TRACE_RANK", "3"))
@@ -94,7 +97,8 @@ for layout in ((os.environ.get("BAND_TRACE_LAYOUT", "cyclic"),) if TRACE else LA
         def step():
             f = fwd(p.rows)
             ops.render_backward(g_band, f["idx"], f["qvalue"], f["wsum"], f["scaler"], f["pts_screen"], f["radii"], vis_all,
-                                wl.first, wl.num, bench.RADII_S, -1.0, image_size=S, rows=p.rows, out=(gf, gp))
+                                wl.first, wl.num, bench.RADII_S, -1.0, image_size=S, rows=p.rows, out=(gf, gp),
+                                grad_out_full=wl.grad_out if OWNER else None)
             return ops.project_backward(wl.world, wl.M, wl.V, wl.first, wl.num, gp, f["valid"], True, clip=bench.CLIP,
                                         grad_features=gf)
         eager.append(quick(step, N_IT))

@@ -90,13 +90,20 @@ for G in (1, 2, 4, 8):
         # link time of the two big collectives, estimated (bytes a rank sends / receives over its 7 links)
         n_img = cams[G]
         img_bytes_rank = n_img * S * S * 16 / G
-        grad_bytes = n_img * Pc * 24
+        # (owner mode -- bench.py's default above 262,144 pairs -- reduces the world-space sums, not every (camera, point) pair)
+        owner = bands[G].get("gradient") == "owner"
+        grad_bytes = Pc * 24 if owner else n_img * Pc * 24
+        row["gradient_exchange"] = "owner" if owner else "bucket"
         if G > 1:
             row["estimated_link_us"] = {
                 "image_all_gather": round(img_bytes_rank * (G - 1) / (min(G - 1, LINKS) * XGMI_LINK_GBS * 1e3), 1),
                 "gradient_all_reduce": round(2 * grad_bytes * (G - 1) / G / (min(G - 1, LINKS) * XGMI_LINK_GBS * 1e3), 1),
                 "note": "direct (fully connected) schedule at the link peak; RCCL's measured bus bandwidth at these sizes is "
                         "lower.  Overlapped exchange: the image bands travel during the backward; folded: before it"}
+            # the same prediction with the ESTIMATED link time of the collective that cannot overlap (the gradient all-reduce)
+            step_l = row["predicted_step_us_overlap"] + row["estimated_link_us"]["gradient_all_reduce"]
+            row["predicted_step_us_overlap_with_link_estimate"] = round(step_l, 1)
+            row["predicted_speedup_overlap_with_link_estimate"] = round((cams[G] * Pc / step_l) / (cams[1] * Pc / single_us), 2)
         table.append(row)
 out["table"] = table
 out["scaling"] = "weak (G cameras, one per rank's worth of rows x cameras)" if weak else "strong (fixed job, rows shared by G ranks)"
