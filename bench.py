@@ -697,7 +697,7 @@ def main():
     exchange_note = None
     # (default: the three-collective form.  Measured at world size 1 in the launch mode of the timed region the folded form is
     # 11 us per step SLOWER -- its two extra kernels and the stream fork cost more than the collective they save,
-    # profiles/r5_c_bench_forced_dist_world1_auto.json -- and at N > 1 it puts the image bytes on the critical path; the
+    # profiles/r5_d_bench_forced_dist_world1_auto.json -- and at N > 1 it puts the image bytes on the critical path; the
     # comparison on the ranks of the run is BENCH_EXCHANGE=auto, and costs two more graph captures per rank)
     want_exchange = os.environ.get("BENCH_EXCHANGE", "overlap") if multi else None
 

@@ -64,7 +64,7 @@ else:
     # (the large workloads run eagerly; the collective floor of the metric's configuration is latency, not bytes: reused)
     floors = {"overlap": {"collective_floor_us": 20.0, "from": "round-4 measurement (78.3 - 58 us)"}}
     for src in (os.environ.get("PREDICT_FLOOR_FROM", ""), "profiles/r5_b_predicted_scaling_cfg2.json",
-                "profiles/r5_c_predicted_scaling_cfg2.json"):
+                "profiles/r5_d_predicted_scaling_cfg2.json"):
         try:
             prev = json.load(open(os.path.join(ROOT, src)))
             floors = {k: {"collective_floor_us": v["collective_floor_us"], "from": src} for k, v in prev["collective_floor"].items()}
