@@ -6,9 +6,6 @@ sys.path.insert(0, ROOT)
 import bench
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dev = torch.device("cuda:0"); torch.cuda.set_device(dev)
-from dss_amd import _lib, ops
-if os.environ.get("DBG_KNN_BUILD"):
-    _lib.set_option(_lib.OPT_KNN_BUILD, int(os.environ["DBG_KNN_BUILD"]))
 dist.init_process_group("gloo")
 ref = bench.Workload(dev, world, bench.RowPartition(bench.S, 1, 0))
 img1, gw1, gc1 = ref.step()
