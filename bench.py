@@ -133,10 +133,9 @@ class Workload:
             # position gradient (dss_render_backward_owned; every rank holds the full image gradient), so clip + projection run
             # before ONE all-reduce of the world-space sums (Pc x 6 floats); "bucket" -- rounds 2-4: partial sums of every
             # (camera, point) pair reduced first (N Pc x 6 floats), clip + projection behind the reduction
-            # (default: owner on the long-list path -- above 262,144 (camera, point) pairs, where it is no slower per rank and the
-            # reduction shrinks by the camera count --, bucket below: the short-list gather reads the alpha channel of the full
-            # image gradient in place there and is ~6 us per rank slower, for an exchange that is latency either way)
-            self.owner = os.environ.get("BENCH_GRADIENT", "owner" if self.P > 262144 else "bucket") == "owner"
+            # (default: owner.  Per rank it costs what the bucket form costs -- emulated at 8 ranks: 96.5-99.8 against 96.0-99.2 us
+            # at 8 x configs[1], 0.95-1.13 against 0.95-1.15 ms at configs[3] -- and the reduction shrinks by the camera count)
+            self.owner = os.environ.get("BENCH_GRADIENT", "owner") == "owner"
             self.wbucket = torch.empty(self.Pc * 6, device=device)
             if fold:
                 self.set_exchange(True)

@@ -2623,12 +2623,17 @@ static int render_backward_impl(bool run_prep, const float *grad_out, const int3
             FP.chunks = L.f_chunks; FP.per = L.f_per; FP.radii_s = radii_s;
             float *plane = reinterpret_cast<float *>(w + L.alpha);
             alpha = plane;
+            // owner mode: the dense plane holds the alpha channel of the FULL image gradient (the medians run inside the next
+            // launch, so the rows an owned window can reach are not known yet; the blend half does not read the plane)
+            const float *plane_src = own ? grad_full : grad_out;
+            const size_t plane_px = own ? (size_t)N * S * S : npix;
+            if (own) { OW.alpha = plane; OW.astride = 1; }
             if (run_prep) {
                 // stage 1: one workgroup per segment + the dense alpha plane in extra workgroups
-                const unsigned alpha_wgs = (unsigned)((npix + FB_ALPHA_PER_WG - 1) / FB_ALPHA_PER_WG);
+                const unsigned alpha_wgs = (unsigned)((plane_px + FB_ALPHA_PER_WG - 1) / FB_ALPHA_PER_WG);
 #define DSS_LAUNCH_FB_PREP(PER_)                                                                                          \
     hipLaunchKernelGGL(fb_prep_kernel<PER_>, dim3((unsigned)L.f_chunks + alpha_wgs), dim3(FB_THREADS), 0, st, FP, radii,   \
-                       first_idx, num_pts, N, grad_pts, grad_feat, C, grad_out, plane, npix)
+                       first_idx, num_pts, N, grad_pts, grad_feat, C, plane_src, plane, plane_px)
                 switch (L.f_per) {
                     case 1: DSS_LAUNCH_FB_PREP(1); break;
                     case 2: DSS_LAUNCH_FB_PREP(2); break;

@@ -59,7 +59,7 @@ def quick(fn, n=60):
 
 
 out = {"G": G, "workload": which, "cameras": wl.N, "points_per_cloud": wl.Pc, "image_size": S}
-GRADIENT = os.environ.get("BAND_GRADIENT", "owner" if wl.P > 262144 else "bucket")   # bench.py's default rule
+GRADIENT = os.environ.get("BAND_GRADIENT", "owner")   # bench.py's default
 out["gradient"] = GRADIENT
 N_IT = 60 if which == "cfg2" else 16
 OWNER = GRADIENT == "owner"   # gradient exchange of the step (bench.py BENCH_GRADIENT): owner | bucket

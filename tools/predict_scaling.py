@@ -43,6 +43,10 @@ for G in (1, 2, 4, 8):
     # (large workloads: contiguous bands -- equal rows, occupancy-balanced, fitted to the measured times, two rebalancing steps)
     lay = "bands" if G == 1 else ("balanced,cyclic" if which == "cfg2" else "bands,balanced,fitted,rebalanced,rebalanced2")
     bands[G] = run([py, os.path.join(ROOT, "tools", "band_timing.py"), str(G), which], {"BAND_LAYOUTS": lay})
+# (a cold box has once timed the first process of this script at 2.5x the others: repeat an implausible world-1 measurement)
+for _ in range(2):
+    if bands[1]["bands"]["graph_max_us"] > 1.4 * min(v["graph_max_us"] for v in bands[2].values() if isinstance(v, dict) and "graph_max_us" in v):
+        bands[1] = run([py, os.path.join(ROOT, "tools", "band_timing.py"), "1", which], {"BAND_LAYOUTS": "bands"})
 Pc, S = bands[1]["points_per_cloud"], bands[1]["image_size"]
 cams = {G: bands[G]["cameras"] for G in bands}
 out["per_rank_compute_us"] = {str(G): {k: {"max": v["graph_max_us"], "per_rank": v["graph_us"]} for k, v in b.items()
