@@ -79,6 +79,18 @@ def large_cloud(which, morton=False):
     return (pts, nrm, col, h), S_, N
 
 
+def drain_collective_watchdog():
+    """Before a graph capture in a process that has issued RCCL collectives: wait until the process group's watchdog thread
+    has dropped the finished ones.  It polls the end events of the outstanding collectives every 100 ms; those events were
+    recorded on RCCL's internal stream, and if a poll falls into the capture of a step whose collectives put that stream into
+    capture mode, HIP refuses the query (hipErrorCapturedEvent, "an event last recorded in a capturing stream") and the
+    watchdog takes the process down -- seen once in ~40 runs of `BENCH_FORCE_DIST=1 BENCH_EXCHANGE=auto bench.py --gpus 1`.
+    After a device synchronisation every collective has finished; three poll intervals later none is on the list."""
+    torch.cuda.synchronize()
+    if dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl":
+        time.sleep(0.35)
+
+
 class Workload:
     def __init__(self, device, n_cams, part: RowPartition, cloud=None, multi=None, fold=False):
         pts, nrm, col, h = bunny_cloud() if cloud is None else cloud
@@ -273,7 +285,7 @@ class Workload:
             for _ in range(3):
                 fwd(); bwd(); proj()
         torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
+        drain_collective_watchdog()
         graphs = []
         # thread-local capture mode: the process group's watchdog thread may query events while this thread captures; in
         # the default (global) mode such a call from ANOTHER thread invalidates the capture
@@ -328,7 +340,7 @@ class Workload:
             for _ in range(3):
                 self.step()
         torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
+        drain_collective_watchdog()
         g = torch.cuda.CUDAGraph()
         res = {}
         with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
@@ -707,7 +719,7 @@ def main():
             for _ in range(3):
                 wl.step()
         torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
+        drain_collective_watchdog()
         g = torch.cuda.CUDAGraph()
         # capture on the stream the warm-up ran on: the zero-initialised forward workspace is cached per stream, and
         # a first use on a fresh capture stream would record its one-off torch.zeros fill (5.5 us) into every replay

@@ -32,7 +32,7 @@ try:
     side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
         for _ in range(3): wl.step()
-    torch.cuda.current_stream().wait_stream(side); torch.cuda.synchronize()
+    torch.cuda.current_stream().wait_stream(side); bench.drain_collective_watchdog()
     g = torch.cuda.CUDAGraph(); res = {}
     with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
         res["o"] = wl.step()
