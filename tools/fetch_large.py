@@ -13,7 +13,7 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
     acc = collections.defaultdict(list)
     for f in glob.glob(os.path.join(OUT, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            acc[r["Kernel_Name"].split("(")[0][-60:]].append(float(r["Counter_Value"]))
+            acc[r["Kernel_Name"].split("(")[0][:96]].append(float(r["Counter_Value"]))
     for k, v in acc.items():
         res[k][ctr] = sum(v) / len(v)
 print(cfg, "per launch: FETCH MB (raw KiB x2 x1024: gfx950 correction) | WRITE MB")

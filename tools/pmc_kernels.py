@@ -13,8 +13,8 @@ subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), check=True,
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(os.path.join(OUT, "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
-        acc[r["Kernel_Name"].split("(")[0][-60:]][r["Counter_Name"]].append(float(r["Counter_Value"]))
-print("kernel".ljust(42), " ".join(c[3:].rjust(14) for c in ctrs))
+        acc[r["Kernel_Name"].split("(")[0][:96]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+print("kernel".ljust(72), " ".join(c[3:].rjust(14) for c in ctrs))
 for k, d in acc.items():
     if "dss::" not in k: continue
-    print(k.ljust(42), " ".join(("%.0f" % (sum(d[c]) / max(len(d[c]), 1))).rjust(14) for c in ctrs))
+    print(k.ljust(72), " ".join(("%.0f" % (sum(d[c]) / max(len(d[c]), 1))).rjust(14) for c in ctrs))
