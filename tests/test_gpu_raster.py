@@ -227,14 +227,16 @@ def test_cell_ordered_binning_of_large_inputs_is_exact(dist):
         assert torch.equal(fb["idx"], f["idx"][:, own]) and torch.equal(fb["qvalue"], f["qvalue"][:, own]), part.describe()
 
 
-@pytest.mark.parametrize("reps,S,form", [(4, 256, 0), (4, 256, 1), (16, 512, 0)])
-def test_owner_mode_of_the_band_backward(reps, S, form):
+@pytest.mark.parametrize("reps,S,form,C", [(4, 256, 0, 3), (4, 256, 1, 3), (16, 512, 0, 3), (4, 192, 0, 3), (4, 192, 0, 5), (16, 320, 0, 5)])
+def test_owner_mode_of_the_band_backward(reps, S, form, C):
     """dss_render_backward_owned (`render_backward(grad_out_full=...)`): on a row band the occupancy surrogate of a (camera,
     point) pair is computed -- whole window, full image gradient -- by the ONE rank whose band holds the image row of the
     point's centre.  Over the ranks of a partition (contiguous, unequal, tile-row-cyclic): every pair has a non-zero position
     gradient on at most one rank, the ranks' position gradients sum to the whole-image backward, and so do the partial
     feature gradients.  Short lists in the two-launch form with the filter inside the gather (form 0) and in the round-3
-    launch sequence (form 1), and a list above 262,144 points (cell-sorted gather)."""
+    launch sequence (form 1), a list above 262,144 points (cell-sorted gather), image sizes that are not powers of two (the
+    rows' NDC then comes from the reference expression, not from exact additions) and five feature channels (generic-channel
+    kernels; a tile-row-cyclic band is built for RGB only and is left out there)."""
     from dss_amd import _lib
     from dss_amd.distributed import RowPartition
     pts, nrm = scenes.load_cloud("yoga6")
@@ -248,11 +250,11 @@ def test_owner_mode_of_the_band_backward(reps, S, form):
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
     first = torch.tensor([0, Pc], dtype=torch.int64, device=DEV)
     num = torch.tensor([Pc, Pc - 100], dtype=torch.int64, device=DEV)
-    feat = torch.rand((N * Pc, 3), device=DEV)
+    feat = torch.rand((N * Pc, C), device=DEV)
     args = (t(pts), t(nrm), torch.full((N,), float(h), device=DEV), t(M), t(V), torch.full((N,), 0.1, device=DEV),
             torch.full((N,), 100.0, device=DEV), first, num, feat, S, K, 1.0, thr, 1.0, False, True)
     full = ops.render_forward(*args)
-    go = torch.randn((N, S, S, 4), device=DEV)
+    go = torch.randn((N, S, S, C + 1), device=DEV)
     rel = lambda a, b: float((a - b).norm() / b.norm())
     try:
         if form:
@@ -260,8 +262,10 @@ def test_owner_mode_of_the_band_backward(reps, S, form):
         gf0, gp0 = ops.render_backward(go, full["idx"], full["qvalue"], full["wsum"], full["scaler"], full["pts_screen"],
                                        full["radii"], full["visible"], first, num, 4.0, -1.0)
         assert float(gp0.abs().sum()) > 0 and float(gf0.abs().sum()) > 0
-        for parts in ([RowPartition(S, 4, r) for r in range(4)], [RowPartition(S, 4, r, cyclic=True) for r in range(4)],
-                      [RowPartition(S, 3, r, bounds=[0, 8, S - 40, S]) for r in range(3)]):
+        layouts = [[RowPartition(S, 4, r) for r in range(4)], [RowPartition(S, 3, r, bounds=[0, 8, S - 40, S]) for r in range(3)]]
+        if C == 3:
+            layouts.append([RowPartition(S, 4, r, cyclic=True) for r in range(4)])
+        for parts in layouts:
             gf_sum, gp_sum, owners = torch.zeros_like(gf0), torch.zeros_like(gp0), torch.zeros(N * Pc, device=DEV)
             for part in parts:
                 own = torch.tensor(part.row_indices(), device=DEV, dtype=torch.int64)
