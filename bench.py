@@ -4,13 +4,14 @@
 One "step" = one forward + backward pass of the whole hot path over one batch of synthetic input
 already resident in HBM:
     point_setup -> splat_forward (bin + fine) -> blend_forward -> [row all-gather]
-    -> blend_backward -> backward_radius -> occ_backward -> [grad all-reduce] -> clip -> project_backward
+    -> blend_backward -> backward_radius -> occ_backward -> clip -> project_backward -> [grad all-reduce]
+    (BENCH_GRADIENT=bucket: [grad all-reduce of every (camera, point) pair] -> clip -> project_backward, rounds 2-4)
 Workload at N=1 = BASELINE.json configs[1]: "bunny ~30k" (bunny-8000 x4 tangent-plane jitter =
 32,684 points), 1 camera, 512x512, K=5, fwd+bwd with grad_out = randn(seed 1) on RGBA.
 For N GPUs the batch holds N cameras (ring, azim = 45 deg * k) and every image is row-partitioned
 across the N ranks (weak scaling: rows x cameras per rank is constant; tile-row-cyclic: rank g renders
-the 8-row tile rows g, g + N, ...); bands are reassembled with an RCCL all-gather and gradient
-partials are all-reduced.
+the 8-row tile rows g, g + N, ...); bands are reassembled with an RCCL all-gather and the world-space
+gradient sums are all-reduced.
 
 Metric: Msplats/s = (cameras * points per cloud) / step time, whole job.
 
@@ -21,7 +22,8 @@ sorts and saves the point order and the step that reuses it, replayed in the ren
 has been checked against the eager step on every rank, else graphs of the compute segments between host-issued collectives.
 Environment switches (development A/B; none is needed for the contract): BENCH_FORCE_DIST=1 (multi-GPU path at world size
 1), BENCH_DIST_BACKEND=gloo (CPU collectives, tests), BENCH_NO_WHOLE_GRAPH=1 (segments instead of the whole-step graph),
-BENCH_IMAGE_LATE=1 (image collective issued behind the backward), BENCH_ORDER_REFRESH=k (period of the cached point order of
+BENCH_IMAGE_LATE=1 (image collective issued behind the backward), BENCH_EXCHANGE=overlap|fold|auto (end-of-forward exchange),
+BENCH_GRADIENT=owner|bucket (gradient exchange), BENCH_ROW_PARTITION=cyclic|bands (row layout), BENCH_ORDER_REFRESH=k (period of the cached point order of
 the large workloads, 0 = sort in every step; default 16), BENCH_BACKWARD_FUSED / BENCH_BACKWARD_TPW (DSS_OPT_* of the
 library), DSS_AMD_ENGINE_THREAD=1 (PyTorch's autograd engine thread for the API figures).
 """
