@@ -3,29 +3,33 @@
 
 One "step" = one forward + backward pass of the whole hot path over one batch of synthetic input
 already resident in HBM:
-    point_setup -> splat_forward (bin + fine) -> blend_forward -> [row all-gather]
-    -> blend_backward -> backward_radius -> occ_backward -> clip -> project_backward -> [grad all-reduce]
-    (BENCH_GRADIENT=bucket: [grad all-reduce of every (camera, point) pair] -> clip -> project_backward, rounds 2-4)
+    point_setup -> splat_forward (bin + fine) -> blend_forward -> blend_backward -> backward_radius -> occ_backward -> clip
+    -> project_backward
 Workload at N=1 = BASELINE.json configs[1]: "bunny ~30k" (bunny-8000 x4 tangent-plane jitter =
 32,684 points), 1 camera, 512x512, K=5, fwd+bwd with grad_out = randn(seed 1) on RGBA.
 For N GPUs the batch holds N cameras (ring, azim = 45 deg * k) and every image is row-partitioned
 across the N ranks (weak scaling: rows x cameras per rank is constant; tile-row-cyclic: rank g renders
-the 8-row tile rows g, g + N, ...); bands are reassembled with an RCCL all-gather and the world-space
-gradient sums are all-reduced.
+the 8-row tile rows g, g + N, ...).  The N > 1 step is the object `SurfaceSplattingRenderer(row_partition=...)` drives
+(dss_amd.sharded.RowShardedRender) and it is CAUSAL -- the image gradient comes from data the rank holds at that moment:
+    forward of the rank's rows -> [visibility all-reduce | image all-gather, asynchronous] -> the reference's image loss
+    (Trainer.calc_dr_loss) of the rank's own rows, per-image sums all-reduced -> [owner form: all-gather of the alpha-gradient
+    plane] -> backward of the rank's rows -> clip + projection -> [all-reduce of the world-space gradient sums]
+    (BENCH_GRADIENT=bucket: backward -> [all-reduce of every (camera, point) pair's partial sums] -> clip + projection)
 
 Metric: Msplats/s = (cameras * points per cloud) / step time, whole job.
 
 How the timed step is launched (recorded in `config.launch`): one GPU -- hipGraph replays of the identical launch sequence
 (`graph_x10`: ten steps per graph launch) unless --mode says otherwise; --workload cfg4|cfg5 -- two graphs, the step that
 sorts and saves the point order and the step that reuses it, replayed in the renderer's rhythm (`graph_save_reuse`); N > 1
-(or BENCH_FORCE_DIST=1) over RCCL -- the WHOLE step, launches and the three collectives, as one graph (`graph_step`) after it
+(or BENCH_FORCE_DIST=1) over RCCL -- the WHOLE step, launches and collectives, as one graph (`graph_step`) after it
 has been checked against the eager step on every rank, else graphs of the compute segments between host-issued collectives.
 Environment switches (development A/B; none is needed for the contract): BENCH_FORCE_DIST=1 (multi-GPU path at world size
 1), BENCH_DIST_BACKEND=gloo (CPU collectives, tests), BENCH_NO_WHOLE_GRAPH=1 (segments instead of the whole-step graph),
 BENCH_IMAGE_LATE=1 (image collective issued behind the backward), BENCH_EXCHANGE=overlap|fold|auto (end-of-forward exchange),
 BENCH_GRADIENT=owner|bucket (gradient exchange), BENCH_ROW_PARTITION=cyclic|bands (row layout), BENCH_ORDER_REFRESH=k (period of the cached point order of
 the large workloads, 0 = sort in every step; default 16), BENCH_BACKWARD_FUSED / BENCH_BACKWARD_TPW (DSS_OPT_* of the
-library), DSS_AMD_ENGINE_THREAD=1 (PyTorch's autograd engine thread for the API figures).
+library), DSS_AMD_CALLING_THREAD_BACKWARD=1 (backward on the calling thread for the API figures; the scoped form is
+`with dss_amd.calling_thread_backward():`).
 """
 import argparse
 import json
@@ -42,7 +46,8 @@ sys.path.insert(0, ROOT)
 
 from dss_amd import _lib, ops  # noqa: E402
 from dss_amd.cameras import FoVPerspectiveCameras, look_at_view_transform  # noqa: E402
-from dss_amd.distributed import OverlappedExchange, RowPartition, gather_rows  # noqa: E402
+from dss_amd.distributed import RowPartition, gather_rows  # noqa: E402
+from dss_amd.sharded import RowShardedRender  # noqa: E402
 
 S, K, THR, RADII_S, CLIP, CUTOFF, SIGMA = 512, 5, 0.05, 5.0, 0.05, 1.0, 1.0
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
@@ -97,8 +102,13 @@ class Workload:
     def __init__(self, device, n_cams, part: RowPartition, cloud=None, multi=None, fold=False):
         pts, nrm, col, h = bunny_cloud() if cloud is None else cloud
         self.dev, self.N, self.part = device, n_cams, part
-        # multi: take the multi-GPU path (send buffers, three collectives, gradient bucket); forced at world size 1 by
-        # BENCH_FORCE_DIST=1 so that a one-GPU box executes the RCCL code path
+        # multi: take the multi-GPU path (dss_amd.sharded.RowShardedRender: send buffers, the exchanges, the band loss, the
+        # gradient reduction); forced at world size 1 by BENCH_FORCE_DIST=1 so that a one-GPU box executes the RCCL code path.
+        # multi="local": the same causal step (render -> image loss -> backward) on ONE rank without any collective -- the
+        # single-rank reference of the tests and the like-for-like single-GPU figure `value_with_image_loss`
+        self.local = multi == "local"
+        if self.local and part.world_size != 1:
+            raise ValueError("multi='local' is the one-rank form of the step")
         self.multi = part.world_size > 1 if multi is None else bool(multi)
         # renderer-owned cached point order (clouds above 2M points: cfg4 / cfg5): every k-th step sorts and saves the
         # order, the others bin through it (`SurfaceSplattingRenderer(order_refresh=k)`); 0 = every step sorts
@@ -126,44 +136,105 @@ class Workload:
         self.zfar = torch.full((self.N,), 100.0, device=device)
         self.first = torch.arange(self.N, device=device, dtype=torch.int64) * self.Pc
         self.num = torch.full((self.N,), self.Pc, device=device, dtype=torch.int64)
-        g = torch.Generator(device="cpu").manual_seed(1)
-        self.grad_out = torch.randn((self.N, S, S, 4), generator=g).to(device)  # d loss / d RGBA
         self.S = S
+        self.grad_out = None
+        if not self.multi:
+            # one GPU (the metric's configuration): d loss / d RGBA = randn(seed 1), an input of the step
+            g = torch.Generator(device="cpu").manual_seed(1)
+            self.grad_out = torch.randn((self.N, S, S, 4), generator=g).to(device)
         if not self.multi and self.N == 1 and part.world_size == 1:
             self._plan = ops.FusedPlan(device, 1, self.Pc, self.P, S, K, 3, True, False, False, False, CUTOFF, SIGMA, THR,
                                        want_zbuf=True)
             self._plan.order_refresh = self.order_refresh
         if self.multi:
-            # multi-GPU: the forward kernel writes its RGBA band and visibility flags straight into the
-            # all-gather send buffers; the backward writes both gradients into one all-reduce bucket
-            # two forms of the end-of-forward exchange (dss_amd/distributed.py): "overlap" -- three collectives per step, the
-            # image bands asynchronous on their own communicator -- and "fold" -- two, the visibility flags riding in one
-            # blocking image all-gather; main() measures both on the ranks it runs on and keeps the faster
-            self._fx = {False: OverlappedExchange(part, self.N, 4, self.P, device, force=self.multi)}
-            self._fx[False].late_image = os.environ.get("BENCH_IMAGE_LATE", "0") == "1"
-            self.fx = self._fx[False]
-            self.bucket = torch.empty(self.P * 6, device=device)
-            # gradient exchange (round 5): "owner" -- the rank whose band holds a point's centre row computes the pair's WHOLE
-            # position gradient (dss_render_backward_owned; every rank holds the full image gradient), so clip + projection run
-            # before ONE all-reduce of the world-space sums (Pc x 6 floats); "bucket" -- rounds 2-4: partial sums of every
-            # (camera, point) pair reduced first (N Pc x 6 floats), clip + projection behind the reduction
-            # (default: owner.  Per rank it costs what the bucket form costs -- emulated at 8 ranks: 96.5-99.8 against 96.0-99.2 us
-            # at 8 x configs[1], 0.95-1.13 against 0.95-1.15 ms at configs[3] -- and the reduction shrinks by the camera count)
-            self.owner = os.environ.get("BENCH_GRADIENT", "owner") == "owner"
-            self.wbucket = torch.empty(self.Pc * 6, device=device)
-            if fold:
-                self.set_exchange(True)
+            # multi-GPU: ONE object holds the rank's share of the step -- dss_amd.sharded.RowShardedRender, the same one
+            # `SurfaceSplattingRenderer(row_partition=...)` drives.  The forward kernel writes its RGBA band and visibility flags
+            # straight into the exchange's send buffers.  The step is CAUSAL: the image gradient is the reference's image loss
+            # (Trainer.calc_dr_loss, trainer.py:332-376: masked L1 on RGB + L1 + 0.01 IoU on the occupancy) of the rank's OWN
+            # band against fixed targets, its per-image sums all-reduced (dss_amd.distributed.band_image_loss's kernels).
+            # Gradient exchange (BENCH_GRADIENT): "owner" (default) -- the rank whose band holds a point's centre row computes
+            # the pair's WHOLE position gradient; it needs the occupancy gradient of all rows, so the ranks all-gather that one
+            # channel (N S^2 4 bytes) between the loss and the backward; clip + projection then run before ONE all-reduce of
+            # the world-space sums (Pc x 6 floats).  "bucket" -- partial sums of every (camera, point) pair from the band's own
+            # gradient, ONE all-reduce of N Pc x 6 floats, clip + projection behind it.
+            # End-of-forward exchange: "overlap" -- visibility all-reduce (critical) + asynchronous image all-gather on a second
+            # communicator (nobody in the step reads the full image: it is the step's output) -- or "fold", see main().
+            self.engine = RowShardedRender(part, self.N, self.Pc, self.P, S, K, 3, device, True, CUTOFF, SIGMA, THR,
+                                           gradient=os.environ.get("BENCH_GRADIENT", "owner"), features_shared=True,
+                                           fold=fold, force=not self.local,
+                                           late_image=os.environ.get("BENCH_IMAGE_LATE", "0") == "1")
+            self.owner = self.engine.owner
+            # targets of the loss: the scene's own render shifted by a few pixels (identical on every rank, outside the timed
+            # region): the silhouette term then pulls on every point near the outline, like an early training iteration
+            f0 = ops.render_forward(self.world, self.normals, self.h, self.M, self.V, self.znear, self.zfar, self.first,
+                                    self.num, self.colors, S, K, CUTOFF, THR, SIGMA, False, True, want_zbuf=False)
+            img0 = torch.roll(f0["image"], shifts=(5, 9), dims=(1, 2))
+            self.target_rgb = img0[..., :3].contiguous()
+            self.target_mask = (img0[..., 3] > 0).float().contiguous()
+            self.band_targets = tuple(x.contiguous() for x in ops.band_targets(self.target_rgb, self.target_mask, part.rows))
+            del f0, img0
+            self._st = {}
+
+    # the exchange object of the current form (tests and the diagnostics look at it)
+    fx = property(lambda self: self.engine.fx)
 
     def set_exchange(self, fold: bool):
         """select the exchange form of the multi-GPU step (captured graphs hold the buffers of the form they were captured with)"""
-        if fold not in self._fx:
-            self._fx[fold] = OverlappedExchange(self.part, self.N, 4, self.P, self.dev, force=self.multi, fold=True)
-        self.fx = self._fx[fold]
+        self.engine.set_exchange(fold)
         self._graphs = self._whole = None
+
+    # ---- the stages of the multi-GPU step: compute ("c") and collectives ("x") alternate ----------------------------------
+    def _st_forward(self):
+        kw = {"order_refresh": self.order_refresh} if self.force_order is None else {"workspace_state": self._order_ws_state()}
+        self._st["f"] = self.engine.forward(self.world, self.normals, self.h, self.M, self.V, self.znear, self.zfar, self.first,
+                                            self.num, self.colors, **kw)
+
+    def _st_exchange(self):
+        e = self.engine
+        self._st["vis"] = e.start_exchange()   # (a static buffer either way: the flags in place, or the folded form's union)
+
+    def _st_loss_sums(self):
+        band = self.engine.band_image
+        self._st["band"] = band = band if band.is_contiguous() else band.contiguous()
+        self._st["sums"] = ops.image_loss_band_partials(band, self.target_rgb, self.target_mask, self.part.rows,
+                                                        band_targets=self.band_targets)
+
+    def _st_loss_reduce(self):
+        if self.engine.active:
+            dist.all_reduce(self._st["sums"], op=dist.ReduceOp.SUM)      # block partials of the five sums: 2560 N bytes
+
+    def _st_loss_grad(self):
+        st = self._st
+        st["g_band"], st["losses"] = ops.image_loss_band_backward_partials(
+            st["band"], self.target_rgb, self.target_mask, self.part.rows, 1.0, 1.0, st["sums"], band_targets=self.band_targets)
+        self.engine.bwd_begin(st["g_band"])
+
+    def _st_backward(self):
+        self.engine.bwd_compute(RADII_S, CLIP, self.world, self.M, self.V, self.first, self.num, f=self._st["f"],
+                                vis_all=self._st["vis"])
+        if self.engine.late_image:
+            self.engine.start_image()
+
+    def _st_finish(self):
+        self._st["out"] = self.engine.bwd_finish(CLIP, self.world, self.M, self.V, self.first, self.num)
+
+    def _st_image(self):
+        self._st["image"] = self.engine.full_image()
+
+    def stages(self):
+        """[(kind, label, callable)] of one multi-GPU step, in order; kind "c" = kernels of this rank, "x" = a collective"""
+        e = self.engine
+        alpha = e.owner and self.part.world_size > 1
+        return ([("c", "forward", self._st_forward), ("x", "visibility_allreduce", self._st_exchange),
+                 ("c", "loss_sums", self._st_loss_sums), ("x", "loss_allreduce", self._st_loss_reduce),
+                 ("c", "loss_gradient", self._st_loss_grad)]
+                + ([("x", "alpha_allgather", e.bwd_exchange_alpha)] if alpha else [])
+                + [("c", "backward", self._st_backward), ("x", "gradient_allreduce", e.bwd_reduce),
+                   ("c", "projection", self._st_finish), ("x", "image_allgather", self._st_image)])
 
     def step(self, ev=None):
         """one forward + backward.  `ev` (multi-GPU diagnostics): a list that receives (label, event) marks recorded on the
-        current stream between the compute segments and the collectives."""
+        current stream between the compute stages and the collectives."""
         def mark(label):
             if ev is not None:
                 e = torch.cuda.Event(enable_timing=True)
@@ -171,9 +242,8 @@ class Workload:
                 ev.append((label, e))
         p = self.part
         S = self.S
-        multi = self.multi
         mark("start")
-        if not multi and self.N == 1 and p.world_size == 1:
+        if not self.multi and self.N == 1 and p.world_size == 1:
             # one GPU, one camera (the metric's configuration): the two fused entry points through ops.FusedPlan -- the same
             # C calls as ops.render_forward / ops.render_backward below with the host work of a call cut down (one arena for the
             # 13 outputs, prebuilt argument lists): what `SurfaceSplattingRenderer` itself uses
@@ -184,64 +254,23 @@ class Workload:
             g_feat, g_world = plan.backward(arena, self.grad_out, self.first, self.num, RADII_S, CLIP, self.world, self.M)
             mark("projection_compute")
             return plan.image(arena), g_world, g_feat
-        # fused forward: [setup + binning] -> [fine + blend]
-        f = ops.render_forward(self.world, self.normals, self.h, self.M, self.V, self.znear, self.zfar, self.first,
-                               self.num, self.colors, S, K, CUTOFF, THR, SIGMA, False, True, rows=p.rows,
-                               out_image=self.fx.image if multi else None,
-                               out_visible=self.fx.visible if multi else None,
-                               band_outputs_only=multi and p.world_size > 1,   # (DSS_WS_BAND_OUTPUTS: a rank bins its band's splats only)
-                               **({"order_refresh": self.order_refresh} if self.force_order is None else
-                                  {"workspace_state": self._order_ws_state()}))
-        info = {"pts_screen": f["pts_screen"], "radii": f["radii"], "scaler": f["scaler"], "valid": f["valid"]}
-        idx, qv, vis, band, wsum = f["idx"], f["qvalue"], f["visible"], f["image"], f["wsum"]
-        if not multi:
-            image = gather_rows(band, p)
-            # fused backward: persistent wavefronts over the compacted visible list (dss_render_backward)
-            # (one camera: packed index == world index, so the projection backward rides in the gather's epilogue)
-            g_feat, g_pts = ops.render_backward(self.grad_out, idx, qv, wsum, info["scaler"], info["pts_screen"],
-                                                info["radii"], vis, self.first, self.num, RADII_S, CLIP,
-                                                project=(self.world, self.M) if self.N == 1 else None)
-            if self.N == 1:
-                mark("projection_compute")
-                return image, g_pts, g_feat
-        else:
-            # collectives 1-2/3: the RGBA bands leave on their own communicator and arrive during the backward;
-            # only the small visibility all-reduce is waited for here (the band collective is issued behind the backward)
-            mark("forward_compute")
-            vis_all = self.fx.start_visibility() if self.fx.late_image else self.fx.start()
-            mark("wait_visibility_allgather")
-            g_band = p.slice(self.grad_out).contiguous()
-            g_feat = self.bucket[:self.P * 3].view(self.P, 3)
-            g_pts = self.bucket[self.P * 3:].view(self.P, 3)
-            # same fused kernel on the band; visibility = union over ranks, clip after the reduction
-            ops.render_backward(g_band, idx, qv, wsum, info["scaler"], info["pts_screen"], info["radii"], vis_all,
-                                self.first, self.num, RADII_S, -1.0, image_size=S, rows=p.rows, out=(g_feat, g_pts),
-                                grad_out_full=self.grad_out if self.owner else None)
-            if self.fx.late_image:
-                self.fx.start_image()   # issued behind the backward's launches, from a side stream that only waits for the forward
-            mark("backward_compute")
-            if self.owner:
-                # the pairs' position gradients are complete on their owners: clip + projection + sum over the cameras first,
-                # then collective 3/3 on the world-space sums
-                g_world, g_col = self.wbucket[:self.Pc * 3].view(self.Pc, 3), self.wbucket[self.Pc * 3:].view(self.Pc, 3)
-                ops.project_backward(self.world, self.M, self.V, self.first, self.num, g_pts, info["valid"], True, clip=CLIP,
-                                     grad_features=g_feat, out=(g_world, g_col))
-                mark("projection_compute")
-                dist.all_reduce(self.wbucket, op=dist.ReduceOp.SUM)
-                mark("wait_gradient_allreduce")
-                image = self.fx.finish()
-                mark("wait_image_allgather")
-                return image, g_world, g_col
-            dist.all_reduce(self.bucket, op=dist.ReduceOp.SUM)  # collective 3/3: both gradient partials, one bucket
-            mark("wait_gradient_allreduce")
-            image = self.fx.finish()  # full render, (N,S,S,4) view of the receive buffer
-            mark("wait_image_allgather")
-        # multi-GPU: the per-point clip follows the reduction and is applied inside the projection kernel
-        # (the per-camera colour gradients of the shared cloud are summed over the cameras in the same launch)
-        g_world, g_col = ops.project_backward(self.world, self.M, self.V, self.first, self.num, g_pts, info["valid"], True,
-                                              clip=CLIP if multi else -1.0, grad_features=g_feat)
-        mark("projection_compute")
-        return image, g_world, g_col
+        if not self.multi:
+            # one GPU, several cameras (emulation tools): fused forward, fused backward, projection + colour reduction
+            f = ops.render_forward(self.world, self.normals, self.h, self.M, self.V, self.znear, self.zfar, self.first,
+                                   self.num, self.colors, S, K, CUTOFF, THR, SIGMA, False, True, rows=p.rows,
+                                   **({"order_refresh": self.order_refresh} if self.force_order is None else
+                                      {"workspace_state": self._order_ws_state()}))
+            image = gather_rows(f["image"], p)
+            g_feat, g_pts = ops.render_backward(self.grad_out, f["idx"], f["qvalue"], f["wsum"], f["scaler"], f["pts_screen"],
+                                                f["radii"], f["visible"], self.first, self.num, RADII_S, CLIP)
+            g_world, g_col = ops.project_backward(self.world, self.M, self.V, self.first, self.num, g_pts, f["valid"], True,
+                                                  clip=-1.0, grad_features=g_feat)
+            mark("projection_compute")
+            return image, g_world, g_col
+        for kind, label, fn in self.stages():
+            fn()
+            mark(("wait_" + label) if kind == "x" else (label + "_compute"))
+        return self._st["image"], self._st["out"][0], self._st["out"][1]
 
     def _order_ws_state(self):
         """workspace_state of the forward when the kind of the step is fixed (None: the renderer's own bookkeeping decides)"""
@@ -250,53 +279,46 @@ class Workload:
 
     # ---- multi-GPU: the compute between the collectives as hipGraphs ---------------------------------
     def capture_segments(self):
-        """Three graphs -- [setup + binning + fine + blend], [compaction + median + band filter + gather],
-        [clip + projection backward] -- replayed around the three collectives of `step`: the multi-rank step then costs the
-        host three graph launches + three collective calls instead of ~10 kernel launches through Python."""
-        p, S = self.part, self.S
-        self.g_band = p.slice(self.grad_out).contiguous()
-        # the forward kernel writes fx.visible; overlap: the all-reduce (MAX) of fx.start() unions it in place; fold: the union
-        # of the gathered copies lands in fx.union
-        self.vis_all = self.fx.union if self.fx.fold else self.fx.visible
-        g_feat = self.bucket[:self.P * 3].view(self.P, 3)
-        g_pts = self.bucket[self.P * 3:].view(self.P, 3)
-        seg = {}
-
-        def fwd():
-            seg["f"] = ops.render_forward(self.world, self.normals, self.h, self.M, self.V, self.znear, self.zfar, self.first,
-                                          self.num, self.colors, S, K, CUTOFF, THR, SIGMA, False, True, rows=p.rows,
-                                          out_image=self.fx.image, out_visible=self.fx.visible,
-                                          band_outputs_only=p.world_size > 1)
-
-        def proj():
-            out = None
-            if self.owner:
-                out = (self.wbucket[:self.Pc * 3].view(self.Pc, 3), self.wbucket[self.Pc * 3:].view(self.Pc, 3))
-            seg["g_world"], seg["g_col"] = ops.project_backward(self.world, self.M, self.V, self.first, self.num, g_pts,
-                                                                seg["f"]["valid"], True, clip=CLIP, grad_features=g_feat, out=out)
-
-        def bwd():
-            f = seg["f"]
-            ops.render_backward(self.g_band, f["idx"], f["qvalue"], f["wsum"], f["scaler"], f["pts_screen"], f["radii"],
-                                self.vis_all, self.first, self.num, RADII_S, -1.0, image_size=S, rows=p.rows,
-                                out=(g_feat, g_pts), grad_out_full=self.grad_out if self.owner else None)
-
+        """One graph per run of consecutive compute stages of `stages()`, replayed around the host-issued collectives: the
+        multi-rank step then costs the host a handful of graph launches + the collective calls instead of ~15 kernel
+        launches through Python."""
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(3):
-                fwd(); bwd(); proj()
+                self.step()
         torch.cuda.current_stream().wait_stream(side)
         drain_collective_watchdog()
-        graphs = []
+        plan, run = [], []
+        for kind, label, fn in self.stages():
+            if kind == "c":
+                run.append(fn)
+                continue
+            if run:
+                plan.append(("c", run))
+                run = []
+            plan.append(("x", fn))
+        if run:
+            plan.append(("c", run))
         # thread-local capture mode: the process group's watchdog thread may query events while this thread captures; in
-        # the default (global) mode such a call from ANOTHER thread invalidates the capture
-        for fn in (fwd, bwd, proj):
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
-                fn()
-            graphs.append(g)
-        self._seg, self._graphs = seg, graphs
+        # the default (global) mode such a call from ANOTHER thread invalidates the capture.  The collectives between the
+        # segments are issued eagerly while capturing, so that every segment is captured on the state its predecessors left.
+        graphs = []
+        with torch.cuda.stream(side):
+            for kind, what in plan:
+                if kind == "x":
+                    what()
+                    graphs.append(("x", what))
+                    continue
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
+                    for fn in what:
+                        fn()
+                g.replay()
+                graphs.append(("c", g))
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self._graphs = graphs
 
     def step_segments(self, ev=None):
         """`step` for N > 1 with the compute segments replayed as graphs (same launches, same collectives)"""
@@ -306,31 +328,18 @@ class Workload:
                 e.record()
                 ev.append((label, e))
         mark("start")
-        self._graphs[0].replay()
-        mark("forward_compute")
-        late = self.fx.late_image   # BENCH_IMAGE_LATE=1: the image collective is issued behind the backward graph
-        if late:
-            self.fx.start_visibility(out=self.vis_all)
-        else:
-            self.fx.start(out=self.vis_all)
-        mark("wait_visibility_allgather")
-        self._graphs[1].replay()
-        if late:
-            self.fx.start_image()
-        mark("backward_compute")
-        if self.owner:   # clip + projection in front of the reduction (of the world-space sums)
-            self._graphs[2].replay()
-            mark("projection_compute")
-        dist.all_reduce(self.wbucket if self.owner else self.bucket, op=dist.ReduceOp.SUM)
-        mark("wait_gradient_allreduce")
-        image = self.fx.finish()
-        mark("wait_image_allgather")
-        if not self.owner:
-            self._graphs[2].replay()
-            mark("projection_compute")
-        return image, self._seg["g_world"], self._seg["g_col"]
+        i = 0
+        for kind, what in self._graphs:
+            if kind == "c":
+                what.replay()
+                mark("segment%d_compute" % i)
+            else:
+                what()
+                mark("wait_collective%d" % i)
+            i += 1
+        return self._st["image"], self._st["out"][0], self._st["out"][1]
 
-    # ---- multi-GPU: the WHOLE step as one hipGraph -- launches AND the three RCCL collectives -------------------------------
+    # ---- multi-GPU: the WHOLE step as one hipGraph -- launches AND the RCCL collectives -------------------------------------
     def capture_whole_step(self, unroll=1):
         """One graph for the step of `step` (multi branch): RCCL collectives are stream operations like any other and can be
         captured with the kernels around them (measured at world size 1, tools/whole_step_graph.py: 80 us per step against
@@ -358,16 +367,15 @@ class Workload:
         return self._whole[1]
 
     def dist_timing(self, iters=20):
-        """Where a multi-GPU step spends its time, per rank: event-timed segments of `iters` eager steps (microseconds,
-        means).  compute = forward + backward + projection kernels of this rank's band; wait_* = time the stream spends in
-        (waiting for) each of the three collectives.  -> dict of label -> us, plus 'compute_us'."""
-        step = self.step_segments if getattr(self, "_graphs", None) else self.step
+        """Where a multi-GPU step spends its time, per rank: event-timed stages of `iters` eager steps (microseconds,
+        means).  *_compute = kernels of this rank's band; wait_* = time the stream spends in (waiting for) each
+        collective.  -> dict of label -> us, plus 'compute_us'."""
         for _ in range(3):
-            step()
+            self.step()
         acc = {}
         for _ in range(iters):
             ev = []
-            step(ev)
+            self.step(ev)
             torch.cuda.synchronize()
             for (l0, e0), (l1, e1) in zip(ev[:-1], ev[1:]):
                 acc[l1] = acc.get(l1, 0.0) + e0.elapsed_time(e1) * 1e3 / iters
@@ -443,7 +451,8 @@ class Workload:
         p, S = self.part, self.S
         f = ops.render_forward(self.world, self.normals, self.h, self.M, self.V, self.znear, self.zfar, self.first,
                                self.num, self.colors, S, K, CUTOFF, THR, SIGMA, False, True, rows=p.rows)
-        g = p.slice(self.grad_out).contiguous()
+        # (multi-GPU path: the band gradient the last step's loss produced)
+        g = p.slice(self.grad_out).contiguous() if self.grad_out is not None else self._st["g_band"]
         args = (g, f["idx"], f["qvalue"], f["wsum"], f["scaler"], f["pts_screen"], f["radii"], f["visible"], self.first,
                 self.num, RADII_S, CLIP)
         gf, gp, rs0 = ops.render_backward(*args, image_size=S, rows=p.rows, return_rs=True)
@@ -992,20 +1001,35 @@ def main():
             nccl_v = ".".join(str(x) for x in torch.cuda.nccl.version())
         except Exception:  # noqa: BLE001
             pass
+        eng = wl.engine
+        stage_list = [("%s:%s" % (k, l)) for k, l, _ in wl.stages()]
+        n_coll = sum(1 for k, _, _ in wl.stages() if k == "x")
         dist_block = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "forced": force_dist,
                       "rccl_version": nccl_v,
                       "visible_devices": torch.cuda.device_count(), "partition": part.describe(),
-                      "exchange": exchange_note, "collectives_per_step": 2 if wl.fx.fold else 3,
+                      "engine": "dss_amd.sharded.RowShardedRender (the object SurfaceSplattingRenderer(row_partition=...) drives)",
+                      "causal": True,
+                      "loss": "Trainer.calc_dr_loss (trainer.py:332-376) of the rank's own band against fixed targets (the scene's "
+                              "render shifted by (5, 9) pixels), block partials of its five per-image sums all-reduced (%d bytes); two launches: "
+                              "dss_image_loss_band_partials | dss_image_loss_band_backward_partials" % (2560 * wl.N),
+                      "stages": stage_list,
+                      "exchange": exchange_note, "collectives_per_step": n_coll,
+                      "collectives_on_the_critical_path": n_coll - (0 if eng.fx.fold else 1),
                       "gradient_exchange": ("owner: the rank of a point's centre row computes the pair's whole position gradient "
-                                            "(dss_render_backward_owned), clip + projection, then ONE all-reduce of %d bytes"
-                                            % (wl.Pc * 24)) if wl.owner else
-                                           ("bucket: partial sums of every (camera, point) pair, ONE all-reduce of %d bytes, clip + "
-                                            "projection behind it" % (wl.P * 24)),
-                      "overlap": bool(wl.fx.overlap) and not wl.fx.fold, "image_issue": "behind the backward (side stream)" if wl.fx.late_image else "before the backward, after the visibility union", "degraded": wl.fx.degraded, "segment_capture": seg_note or "ok",
+                                            "(dss_render_backward_owned_plane) from the all-gathered alpha-gradient plane (%d bytes "
+                                            "per rank), clip + projection, then ONE all-reduce of %d bytes"
+                                            % (wl.N * part.band * S * 4, wl.Pc * 24)) if wl.owner else
+                                           ("bucket: partial sums of every (camera, point) pair from the band's own gradient, ONE "
+                                            "all-reduce of %d bytes, clip + projection behind it" % (wl.P * 24)),
+                      "defaults": "provisional: chosen from single-GPU emulation of the ranks and RCCL at world size 1; no N > 1 "
+                                  "RCCL run has confirmed them (BENCH_GRADIENT / BENCH_ROW_PARTITION / BENCH_EXCHANGE override)",
+                      "overlap": bool(eng.fx.overlap) and not eng.fx.fold,
+                      "image_issue": "behind the backward (side stream)" if eng.late_image else "at the end of the forward, asynchronous",
+                      "degraded": eng.fx.degraded, "segment_capture": seg_note or "ok",
                       "whole_step_graph": whole_note or "ok",
                       "timing_us": {k: {"min": round(float(allt[:, i].min()), 1), "max": round(float(allt[:, i].max()), 1),
                                         "mean": round(float(allt[:, i].mean()), 1)} for i, k in enumerate(keys)},
-                      "timing_how": "HIP events on the compute stream around each segment of 20 eager steps, per rank; "
+                      "timing_how": "HIP events on the compute stream around each stage of 20 eager steps, per rank; "
                                     "min / max / mean over the ranks"}
 
     # ---- roofline of the dominant kernel, picked from a per-kernel event-timing pass --------------------------------
@@ -1101,8 +1125,9 @@ def main():
         else:
             wtxt = ("BASELINE configs[1]: bunny-8000 x4 jitter = %d pts/cloud, %d camera(s), "
                     "512x512, K=5, fwd+bwd (setup+raster+blend and their backward), "
-                    "grad_out=randn(seed 1), variance scale h precomputed (kNN-7 outside the step; "
-                    "see value_with_knn)" % (wl.Pc, wl.N))
+                    "%s, variance scale h precomputed (kNN-7 outside the step; "
+                    "see value_with_knn)" % (wl.Pc, wl.N, "image gradient = the reference's image loss of the rank's own rows "
+                                             "(inside the step, sums all-reduced)" if multi else "grad_out=randn(seed 1)"))
         rec = {
             "metric": "Msplats/s fwd+bwd @%d^2" % S, "value": round(value, 3), "unit": "Msplats/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 5),

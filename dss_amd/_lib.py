@@ -55,6 +55,9 @@ SIGNATURES = {
                             + [_c_vp] * 5 + [_c_vp, _c_sz, _c_vp]),
     "dss_render_backward_owned": (_c_int, [_c_vp] * 11 + [_c_int, _c_i64, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_f32, _c_f32]
                                   + [_c_vp] * 3 + [_c_vp, _c_sz, _c_vp]),
+    "dss_render_backward_owned_plane": (_c_int, [_c_vp] * 11 + [_c_int, _c_i64, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_f32,
+                                                               _c_f32] + [_c_vp] * 3 + [_c_vp, _c_sz, _c_vp]),
+    "dss_gather_rows": (_c_int, [_c_vp, _c_vp, _c_int, _c_int, _c_int, _c_vp, _c_vp]),
     "dss_render_backward_gather": (_c_int, [_c_vp] * 10 + [_c_int, _c_i64, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
                                                           _c_f32, _c_f32] + [_c_vp] * 5 + [_c_vp, _c_sz, _c_vp]),
     "dss_phong_forward": (_c_int, [_c_vp] * 5 + [_c_int, _c_i64, _c_int] + [_c_vp] * 4 + [_c_int, _c_int, _c_vp, _c_f32,
@@ -76,6 +79,11 @@ SIGNATURES = {
     "dss_image_loss_from_sums": (_c_int, [_c_vp, _c_int, _c_int, _c_int, _c_f32, _c_f32, _c_vp, _c_vp]),
     "dss_image_loss_band_backward": (_c_int, [_c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_i64, _c_vp, _c_i64, _c_int, _c_int,
                                               _c_int, _c_int, _c_f32, _c_f32, _c_vp, _c_vp, _c_vp, _c_vp]),
+    "dss_image_loss_band_partials_count": (_c_sz, [_c_int]),
+    "dss_image_loss_band_partials": (_c_int, [_c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_i64, _c_vp, _c_i64, _c_int, _c_int, _c_int,
+                                              _c_vp, _c_vp]),
+    "dss_image_loss_band_backward_partials": (_c_int, [_c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_i64, _c_vp, _c_i64, _c_int, _c_int,
+                                                       _c_int, _c_int, _c_f32, _c_f32, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp]),
     "dss_knn_workspace": (_c_sz, [_c_int, _c_i64]),
     "dss_knn_kth_sqdist": (_c_int, [_c_vp] * 3 + [_c_int, _c_i64, _c_int, _c_vp, _c_vp, _c_sz, _c_vp]),
     "dss_knn_points": (_c_int, [_c_vp] * 3 + [_c_int, _c_i64, _c_int, _c_vp, _c_vp, _c_vp, _c_sz, _c_vp]),

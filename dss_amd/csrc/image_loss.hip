@@ -23,37 +23,61 @@ struct TargetView {  // target colours with arbitrary element strides: (N,H,W,3)
 
 __device__ __forceinline__ float sign_of(float v) { return (float)((v > 0.f) - (v < 0.f)); }
 
-__global__ __launch_bounds__(256) void image_loss_reduce_kernel(const float4 *__restrict__ rgba, const TargetView img,
-                                                                const float *__restrict__ mask, int64_t mask_sn, int H,
-                                                                int W, double *__restrict__ part /* (N, blocks, 5) */)
+#define IMG_LOSS_REDUCE_THREADS 1024
+__global__ __launch_bounds__(IMG_LOSS_REDUCE_THREADS) void image_loss_reduce_kernel(
+    const float4 *__restrict__ rgba, const TargetView img, const float *__restrict__ mask, int64_t mask_sn, int H, int W,
+    double *__restrict__ part /* (N, blocks, 5) */)
 {
-    __shared__ float wave_part[4][IMG_LOSS_TERMS];
+    constexpr int T = IMG_LOSS_REDUCE_THREADS, WAVES = T / 64;
+    __shared__ float wave_part[WAVES][IMG_LOSS_TERMS];
     const int n = blockIdx.y, b = blockIdx.x, nb = gridDim.x;
-    const int64_t HW = (int64_t)H * W;
+    const unsigned HW = (unsigned)H * (unsigned)W;   // (pixels of ONE image: below 2^31; 32-bit divides for row / column)
+    const int64_t base = (int64_t)n * HW;
     float cnt = 0.f, srgb = 0.f, smask = 0.f, inter = 0.f, uni = 0.f;  // <= a few hundred terms per thread: exact counts
-    for (int64_t i = (int64_t)b * 256 + threadIdx.x; i < HW; i += (int64_t)nb * 256) {
-        const int64_t q = (int64_t)n * HW + i;
-        const float4 px = rgba[q];
-        const float t = mask[(int64_t)n * mask_sn + i];  // mask_sn = H*W, or the full image's stride for a row band
-        const int y = (int)(i / W), x = (int)(i - (int64_t)y * W);
-        const float *tp = img.p + n * img.sn + y * img.sh + x * img.sw;
-        const float d = fabsf(tp[0] - px.x) + fabsf(tp[img.sc] - px.y) + fabsf(tp[2 * img.sc] - px.z);
-        const bool inside = t != 0.f && px.w != 0.f;
-        cnt += inside ? 1.f : 0.f;
-        srgb += inside ? d : 0.f;
-        smask += fabsf(t - px.w);
-        inter += px.w * t;
-        uni += px.w + t - px.w * t;
+    // 16 wavefronts per block (at most 64 blocks per image: a quarter of the CUs, so each of them gets a full CU's worth of
+    // loads in flight), four pixels per trip with all their loads issued before the first is used; the terms are added in
+    // pixel order
+    const unsigned stride = (unsigned)nb * T;
+    for (unsigned i0 = (unsigned)b * T + threadIdx.x; i0 < HW; i0 += 4u * stride) {
+        float4 px[4];
+        float t[4], c0[4], c1[4], c2[4];
+        bool ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const unsigned i = i0 + (unsigned)u * stride;
+            ok[u] = i < HW && i >= i0;
+            const unsigned ic = ok[u] ? i : i0;
+            px[u] = rgba[base + ic];
+            t[u] = mask[(int64_t)n * mask_sn + ic];  // mask_sn = H*W, or the full image's stride for a row band
+            const unsigned y = ic / (unsigned)W, x = ic - y * (unsigned)W;
+            const float *tp = img.p + n * img.sn + (int64_t)y * img.sh + (int64_t)x * img.sw;
+            c0[u] = tp[0];
+            c1[u] = tp[img.sc];
+            c2[u] = tp[2 * img.sc];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (!ok[u]) continue;
+            const float d = fabsf(c0[u] - px[u].x) + fabsf(c1[u] - px[u].y) + fabsf(c2[u] - px[u].z);
+            const bool inside = t[u] != 0.f && px[u].w != 0.f;
+            cnt += inside ? 1.f : 0.f;
+            srgb += inside ? d : 0.f;
+            smask += fabsf(t[u] - px[u].w);
+            inter += px[u].w * t[u];
+            uni += px[u].w + t[u] - px[u].w * t[u];
+        }
     }
     const float v[IMG_LOSS_TERMS] = {wave_sum(cnt), wave_sum(srgb), wave_sum(smask), wave_sum(inter), wave_sum(uni)};
     if ((threadIdx.x & 63) == 0)
 #pragma unroll
         for (int k = 0; k < IMG_LOSS_TERMS; ++k) wave_part[threadIdx.x >> 6][k] = v[k];
     __syncthreads();
-    if (threadIdx.x < IMG_LOSS_TERMS)
-        part[((size_t)n * nb + b) * IMG_LOSS_TERMS + threadIdx.x] =
-            ((double)wave_part[0][threadIdx.x] + (double)wave_part[1][threadIdx.x]) +
-            ((double)wave_part[2][threadIdx.x] + (double)wave_part[3][threadIdx.x]);
+    if (threadIdx.x < IMG_LOSS_TERMS) {
+        double a = 0.0;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) a += (double)wave_part[w][threadIdx.x];
+        part[((size_t)n * nb + b) * IMG_LOSS_TERMS + threadIdx.x] = a;
+    }
 }
 
 // sums (N+1, 5): rows 0..N-1 per image, row N the totals over the batch.  losses (4): total, weighted rgb term,
@@ -123,12 +147,13 @@ __global__ __launch_bounds__(256) void image_loss_grad_kernel(const float4 *__re
                                                               const float *__restrict__ grad_total,
                                                               float4 *__restrict__ grad_rgba)
 {
-    const int64_t HW = (int64_t)H * W;
-    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= (int64_t)N * HW) return;
-    const int n = (int)(q / HW);
-    const int64_t i = q - (int64_t)n * HW;
-    const int y = (int)(i / W), x = (int)(i - (int64_t)y * W);
+    // (N H W pixels below 2^32 -- checked on the host: 32-bit divides for image / row / column)
+    const unsigned HW = (unsigned)H * (unsigned)W;
+    const unsigned q = blockIdx.x * blockDim.x + threadIdx.x;
+    if ((uint64_t)q >= (uint64_t)N * HW) return;
+    const unsigned n = q / HW;
+    const unsigned i = q - n * HW;
+    const unsigned y = i / (unsigned)W, x = i - y * (unsigned)W;
     const float up = grad_total ? grad_total[0] : 1.0f;
     const double cnt = sums[(size_t)N * IMG_LOSS_TERMS];
     const double I = sums[(size_t)n * IMG_LOSS_TERMS + 3], U = sums[(size_t)n * IMG_LOSS_TERMS + 4];
@@ -136,7 +161,7 @@ __global__ __launch_bounds__(256) void image_loss_grad_kernel(const float4 *__re
     const float w_l1 = (float)((double)lambda_sil / ((double)N * pix_per_image));
     const float4 px = rgba[q];
     const float t = mask[(int64_t)n * mask_sn + i];
-    const float *tp = img.p + n * img.sn + y * img.sh + x * img.sw;
+    const float *tp = img.p + (int64_t)n * img.sn + (int64_t)y * img.sh + (int64_t)x * img.sw;
     const bool inside = t != 0.f && px.w != 0.f;
     float4 g;
     g.x = inside ? w_rgb * sign_of(px.x - tp[0]) * up : 0.f;
@@ -149,16 +174,93 @@ __global__ __launch_bounds__(256) void image_loss_grad_kernel(const float4 *__re
     grad_rgba[q] = g;
 }
 
+// Row bands, two launches per step: the block partials themselves are what the ranks all-reduce ((N, 64, 5) doubles: 20 KB
+// at 8 cameras, a latency-bound collective either way), and the gradient kernel adds them up in its prologue -- every block
+// in the same fixed order, so every rank derives the same bits.  Replaces reduce | finalize | [all-reduce] | finalize |
+// gradient (three of whose five launches were ~6 us single-workgroup kernels).
+#define IMG_LOSS_BAND_BLOCKS 64
+__global__ __launch_bounds__(256) void image_loss_band_grad_kernel(const float4 *__restrict__ rgba, const TargetView img,
+                                                                   const float *__restrict__ mask, int64_t mask_sn, int N, int H,
+                                                                   int W, double pix_per_image, float lambda_rgb,
+                                                                   float lambda_sil, const double *__restrict__ part,
+                                                                   const float *__restrict__ grad_total,
+                                                                   float4 *__restrict__ grad_rgba, float *__restrict__ losses,
+                                                                   double *__restrict__ sums_out)
+{
+    __shared__ double s_sum[64][IMG_LOSS_TERMS];   // per image (N <= 64)
+    // thread (n, k) adds the 64 block partials of term k of image n in block order
+    for (int e = threadIdx.x; e < N * IMG_LOSS_TERMS; e += 256) {
+        const int n = e / IMG_LOSS_TERMS, k = e - n * IMG_LOSS_TERMS;
+        const double *pp = part + (size_t)n * IMG_LOSS_BAND_BLOCKS * IMG_LOSS_TERMS + k;
+        double a = 0.0;
+#pragma unroll 16
+        for (int b = 0; b < IMG_LOSS_BAND_BLOCKS; ++b) a += pp[(size_t)b * IMG_LOSS_TERMS];
+        s_sum[n][k] = a;
+    }
+    __syncthreads();
+    double cnt = 0.0;
+    for (int n = 0; n < N; ++n) cnt += s_sum[n][0];
+    if (blockIdx.x == 0 && threadIdx.x == 0 && (losses || sums_out)) {
+        double tot[IMG_LOSS_TERMS] = {0.0, 0.0, 0.0, 0.0, 0.0}, iou = 0.0;
+        for (int n = 0; n < N; ++n) {
+#pragma unroll
+            for (int k = 0; k < IMG_LOSS_TERMS; ++k) {
+                tot[k] += s_sum[n][k];
+                if (sums_out) sums_out[(size_t)n * IMG_LOSS_TERMS + k] = s_sum[n][k];
+            }
+            const double u = s_sum[n][4];
+            const double den = (u < 0 ? -1.0 : 1.0) * fmax(fabs(u), 1e-17);  // eps_denom, mathHelper.py:10-14
+            iou += 1.0 - s_sum[n][3] / den;
+        }
+        if (sums_out)
+#pragma unroll
+            for (int k = 0; k < IMG_LOSS_TERMS; ++k) sums_out[(size_t)N * IMG_LOSS_TERMS + k] = tot[k];
+        if (losses) {
+            iou /= N;
+            const double rgb = tot[0] > 0 ? tot[1] / tot[0] : 0.0;  // `if mask_pred.sum() > 0`, trainer.py:352
+            const double sil = tot[2] / ((double)N * pix_per_image) + 0.01 * iou;
+            losses[0] = (float)(lambda_rgb * rgb + lambda_sil * sil);
+            losses[1] = (float)(lambda_rgb * rgb);
+            losses[2] = (float)(lambda_sil * sil);
+            losses[3] = (float)iou;
+        }
+    }
+    // (N H W pixels below 2^32 -- checked on the host: 32-bit divides for image / row / column)
+    const unsigned HW = (unsigned)H * (unsigned)W;
+    const unsigned q = blockIdx.x * blockDim.x + threadIdx.x;
+    if ((uint64_t)q >= (uint64_t)N * HW) return;
+    const unsigned n = q / HW;
+    const unsigned i = q - n * HW;
+    const unsigned y = i / (unsigned)W, x = i - y * (unsigned)W;
+    const float up = grad_total ? grad_total[0] : 1.0f;
+    const double I = s_sum[n][3], U = s_sum[n][4];
+    const float w_rgb = cnt > 0 ? (float)((double)lambda_rgb / cnt) : 0.f;
+    const float w_l1 = (float)((double)lambda_sil / ((double)N * pix_per_image));
+    const float4 px = rgba[q];
+    const float t = mask[(int64_t)n * mask_sn + i];
+    const float *tp = img.p + (int64_t)n * img.sn + (int64_t)y * img.sh + (int64_t)x * img.sw;
+    const bool inside = t != 0.f && px.w != 0.f;
+    float4 g;
+    g.x = inside ? w_rgb * sign_of(px.x - tp[0]) * up : 0.f;
+    g.y = inside ? w_rgb * sign_of(px.y - tp[img.sc]) * up : 0.f;
+    g.z = inside ? w_rgb * sign_of(px.z - tp[2 * img.sc]) * up : 0.f;
+    // (same expressions as image_loss_grad_kernel)
+    const double Ue = (U < 0 ? -1.0 : 1.0) * fmax(fabs(U), 1e-17);
+    const double diou = fabs(U) > 1e-17 ? -((double)t * Ue - I * (1.0 - (double)t)) / (Ue * Ue) : -(double)t / Ue;
+    g.w = (w_l1 * sign_of(px.w - t) + (float)((double)lambda_sil * 0.01 * diou / N)) * up;
+    grad_rgba[q] = g;
+}
+
 static int image_blocks(int H, int W)
 {
-    const int64_t b = ((int64_t)H * W + 4095) / 4096;
+    const int64_t b = ((int64_t)H * W + 4 * IMG_LOSS_REDUCE_THREADS - 1) / (4 * IMG_LOSS_REDUCE_THREADS);
     return (int)(b < 1 ? 1 : (b > IMG_LOSS_MAX_BLOCKS ? IMG_LOSS_MAX_BLOCKS : b));
 }
 
 static int check_image_args(const char *who, const void *rgba, const void *img, const void *mask, int N, int H, int W)
 {
-    if (N <= 0 || H <= 0 || W <= 0) {
-        set_error("%s: bad sizes N=%d H=%d W=%d", who, N, H, W);
+    if (N <= 0 || H <= 0 || W <= 0 || (int64_t)N * H * W >= (1ll << 32)) {
+        set_error("%s: bad sizes N=%d H=%d W=%d (at most 2^32 pixels)", who, N, H, W);
         return DSS_ERR_INVALID_ARGUMENT;
     }
     if (!rgba || !img || !mask) {
@@ -199,7 +301,7 @@ extern "C" int dss_image_loss_forward(const float *rgba, const float *target_rgb
     const int nb = image_blocks(H, W);
     const TargetView tv = {target_rgb, t_stride_n, t_stride_h, t_stride_w, t_stride_c};
     double *part = reinterpret_cast<double *>(workspace);
-    hipLaunchKernelGGL(image_loss_reduce_kernel, dim3(nb, N), dim3(256), 0, st, reinterpret_cast<const float4 *>(rgba), tv,
+    hipLaunchKernelGGL(image_loss_reduce_kernel, dim3(nb, N), dim3(IMG_LOSS_REDUCE_THREADS), 0, st, reinterpret_cast<const float4 *>(rgba), tv,
                        target_mask, (int64_t)H * W, H, W, part);
     hipLaunchKernelGGL(image_loss_finalize_kernel, dim3(1), dim3(256), 0, st, part, N, nb, (double)H * (double)W, lambda_rgb,
                        lambda_silhouette, sums, losses, 0);
@@ -239,7 +341,7 @@ extern "C" int dss_image_loss_band_sums(const float *rgba_band, const float *tar
     const int nb = image_blocks(rows, W);
     const TargetView tv = {target_rgb, t_stride_n, t_stride_h, t_stride_w, t_stride_c};
     double *part = reinterpret_cast<double *>(workspace);
-    hipLaunchKernelGGL(image_loss_reduce_kernel, dim3(nb, N), dim3(256), 0, st, reinterpret_cast<const float4 *>(rgba_band),
+    hipLaunchKernelGGL(image_loss_reduce_kernel, dim3(nb, N), dim3(IMG_LOSS_REDUCE_THREADS), 0, st, reinterpret_cast<const float4 *>(rgba_band),
                        tv, target_mask, mask_stride_n, rows, W, part);
     hipLaunchKernelGGL(image_loss_finalize_kernel, dim3(1), dim3(256), 0, st, part, N, nb, 0.0, 0.f, 0.f, sums, nullptr, 1);
     return check_launch("dss_image_loss_band_sums");
@@ -275,4 +377,46 @@ extern "C" int dss_image_loss_band_backward(const float *rgba_band, const float 
                        (double)H * (double)W, lambda_rgb, lambda_silhouette, sums, grad_total,
                        reinterpret_cast<float4 *>(grad_band));
     return check_launch("dss_image_loss_band_backward");
+}
+
+// ---- row bands, fused form: block partials -> [all-reduce of the partials by the caller] -> band gradient + losses -------
+extern "C" size_t dss_image_loss_band_partials_count(int N) { return (size_t)(N > 0 ? N : 1) * IMG_LOSS_BAND_BLOCKS * IMG_LOSS_TERMS; }
+
+extern "C" int dss_image_loss_band_partials(const float *rgba_band, const float *target_rgb, int64_t t_stride_n,
+                                            int64_t t_stride_h, int64_t t_stride_w, int64_t t_stride_c,
+                                            const float *target_mask, int64_t mask_stride_n, int N, int rows, int W,
+                                            double *partials, void *stream)
+{
+    if (N <= 0 || N > 64 || rows < 0 || W <= 0 || (int64_t)N * rows * W >= (1ll << 32) || !partials || (rows > 0 && (!rgba_band || !target_rgb || !target_mask)) ||
+        (reinterpret_cast<uintptr_t>(rgba_band) & 15) != 0) {
+        set_error("dss_image_loss_band_partials: bad arguments (1 <= N <= 64, 16-byte aligned band)");
+        return DSS_ERR_INVALID_ARGUMENT;
+    }
+    const TargetView tv = {target_rgb, t_stride_n, t_stride_h, t_stride_w, t_stride_c};
+    // (an empty band -- a rank without rows -- contributes zeros: the loop of the kernel does not run)
+    hipLaunchKernelGGL(image_loss_reduce_kernel, dim3(IMG_LOSS_BAND_BLOCKS, N), dim3(IMG_LOSS_REDUCE_THREADS), 0, as_stream(stream),
+                       reinterpret_cast<const float4 *>(rgba_band), tv, target_mask, mask_stride_n, rows, W, partials);
+    return check_launch("dss_image_loss_band_partials");
+}
+
+extern "C" int dss_image_loss_band_backward_partials(const float *rgba_band, const float *target_rgb, int64_t t_stride_n,
+                                                     int64_t t_stride_h, int64_t t_stride_w, int64_t t_stride_c,
+                                                     const float *target_mask, int64_t mask_stride_n, int N, int rows, int W,
+                                                     int H, float lambda_rgb, float lambda_silhouette, const double *partials,
+                                                     const float *grad_total, float *grad_band, float *losses, double *sums,
+                                                     void *stream)
+{
+    if (N <= 0 || N > 64 || rows < 0 || W <= 0 || H < rows || (int64_t)N * rows * W >= (1ll << 32) || !partials || (rows > 0 && (!rgba_band || !target_rgb || !target_mask || !grad_band)) ||
+        ((reinterpret_cast<uintptr_t>(grad_band) | reinterpret_cast<uintptr_t>(rgba_band)) & 15) != 0) {
+        set_error("dss_image_loss_band_backward_partials: bad arguments (1 <= N <= 64, H >= rows, 16-byte aligned band tensors)");
+        return DSS_ERR_INVALID_ARGUMENT;
+    }
+    const TargetView tv = {target_rgb, t_stride_n, t_stride_h, t_stride_w, t_stride_c};
+    const int64_t total = (int64_t)N * rows * W;
+    const unsigned blocks = (unsigned)((total + 255) / 256);
+    hipLaunchKernelGGL(image_loss_band_grad_kernel, dim3(blocks > 0 ? blocks : 1u), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const float4 *>(rgba_band), tv, target_mask, mask_stride_n, N, rows, W,
+                       (double)H * (double)W, lambda_rgb, lambda_silhouette, partials, grad_total,
+                       reinterpret_cast<float4 *>(grad_band), losses, sums);
+    return check_launch("dss_image_loss_band_backward_partials");
 }

@@ -2470,7 +2470,8 @@ static int render_backward_impl(bool run_prep, const float *grad_out, const int3
                                 int64_t P, int S, int K, int C, int row0, int row1, int row_cycle, float radii_s, float clip,
                                 float *grad_feat, float *grad_pts, float *rs_out, const float *world, const float *Mproj,
                                 void *workspace, size_t workspace_bytes, void *stream,
-                                const float *grad_full = nullptr /* (N,S,S,C+1): owner mode of a row band, see OwnArgs */)
+                                const float *grad_full = nullptr /* (N,S,S,C+1): owner mode of a row band, see OwnArgs */,
+                                const float *occ_full = nullptr /* (N,S,S) dense: owner mode fed by the all-gathered alpha-gradient plane */)
 {
     if (N <= 0 || P < 0 || S <= 0 || K <= 0 || C < 1 || C > BLEND_MAX_C || row0 < 0 || row1 > S || row0 >= row1 ||
         row_cycle < 1 || (row_cycle & (row_cycle - 1)) || row_cycle > 4096) {
@@ -2493,6 +2494,9 @@ static int render_backward_impl(bool run_prep, const float *grad_out, const int3
     if (P > 0x7ffffff0ll) { set_error("dss_render_backward: P too large"); return DSS_ERR_UNSUPPORTED; }
     // owner mode only means something on a band (the whole image owns every centre: the plain form)
     OwnArgs OW = {(grad_full != nullptr && (rows < S || cyc)) ? grad_full + C : nullptr, C + 1};
+    // (the dense plane of the occupancy gradient handed in: nothing to extract, the owned windows read it as it is)
+    const bool own_given = occ_full != nullptr && (rows < S || cyc);
+    if (own_given) { OW.alpha = occ_full; OW.astride = 1; }
     const int own = OW.alpha != nullptr ? 1 : 0;
     if (!grad_out || !points || !radii || !visible || !first_idx || !num_pts || !grad_pts ||
         (grad_feat && (!idx || !qvalue || !scaler))) {
@@ -2555,7 +2559,7 @@ static int render_backward_impl(bool run_prep, const float *grad_out, const int3
     // every gathered tensor is smaller than 4 GB; larger problems take the 64-bit addressing, four tasks per wavefront
     unsigned long long widest = (unsigned long long)N * (unsigned long long)rows * (unsigned long long)S *
                                 (unsigned long long)(K > C + 1 ? K : C + 1) * 4ull;
-    if (own) widest = std::max(widest, (unsigned long long)N * (unsigned long long)S * (unsigned long long)S * (unsigned long long)(C + 1) * 4ull);
+    if (own) widest = std::max(widest, (unsigned long long)N * (unsigned long long)S * (unsigned long long)S * (unsigned long long)(own_given ? 1 : C + 1) * 4ull);
     // (DSS_OPT_BACKWARD_ADDR64 forces the 64-bit variant: it only exists for tensors nobody allocates in a test)
     const bool a32 = widest < (1ull << 32) && option(DSS_OPT_BACKWARD_ADDR64) != 1;
     if (!a32) tpw = 4;
@@ -2626,8 +2630,8 @@ static int render_backward_impl(bool run_prep, const float *grad_out, const int3
             // owner mode: the dense plane holds the alpha channel of the FULL image gradient (the medians run inside the next
             // launch, so the rows an owned window can reach are not known yet; the blend half does not read the plane)
             const float *plane_src = own ? grad_full : grad_out;
-            const size_t plane_px = own ? (size_t)N * S * S : npix;
-            if (own) { OW.alpha = plane; OW.astride = 1; }
+            const size_t plane_px = own_given ? (size_t)0 : (own ? (size_t)N * S * S : npix);
+            if (own && !own_given) { OW.alpha = plane; OW.astride = 1; }
             if (run_prep) {
                 // stage 1: one workgroup per segment + the dense alpha plane in extra workgroups
                 const unsigned alpha_wgs = (unsigned)((plane_px + FB_ALPHA_PER_WG - 1) / FB_ALPHA_PER_WG);
@@ -2703,7 +2707,7 @@ static int render_backward_impl(bool run_prep, const float *grad_out, const int3
         hipLaunchKernelGGL(median_hist_kernel<2>, dim3(blocks), dim3(MED_THREADS), 0, st, radii, visible, first_idx,
                            num_pts, N, P, hist);
         hipLaunchKernelGGL(median_final_kernel, dim3(N), dim3(MED_THREADS), 0, st, hist, N, radii_s, rs);
-        if (own)   // (the band's own plane above is not read in owner mode: its region holds the full-layout one)
+        if (own && !own_given)   // (the band's own plane above is not read in owner mode: its region holds the full-layout one)
             hipLaunchKernelGGL(alpha_rows_kernel, dim3((unsigned)S, (unsigned)N), dim3(256), 0, st, grad_full, plane, rs, N, S, C,
                                row0, rows, tshift);
         const unsigned cb = (unsigned)cell_blocks(P);   // (the visible count is only known on the device: P bounds it)
@@ -2717,7 +2721,7 @@ static int render_backward_impl(bool run_prep, const float *grad_out, const int3
         hipLaunchKernelGGL(cell_scatter_kernel, dim3(cb), dim3(CELL_THREADS), lds, st, cg, vis_count, unsorted, cell_of,
                            cell_start, block_hist, sorted);
         }
-        if (own) { OW.alpha = plane; OW.astride = 1; }
+        if (own && !own_given) { OW.alpha = plane; OW.astride = 1; }
         vis_count += 1;   // the gather walks the SORTED list: its length (written by cell_scan_kernel) is the second word
     }
     if (fused) {
@@ -2852,6 +2856,21 @@ extern "C" int dss_render_backward_owned(const float *grad_out, const float *gra
     return render_backward_impl(true, grad_out, idx, qvalue, wsum, scaler, points, radii, visible, first_idx, num_pts, N, P, S,
                                 K, C, row0, row1, row_cycle, radii_s, clip, grad_feat, grad_pts, rs_out, nullptr, nullptr, workspace,
                                 workspace_bytes, stream, grad_out_full);
+}
+
+// Owner mode fed by the dense plane of the occupancy gradient (N,S,S) -- what a rank holds after an all-gather of the alpha
+// channel of the band-local loss gradients (dss_gather_rows puts the gathered rows in image order)
+extern "C" int dss_render_backward_owned_plane(const float *grad_out, const float *grad_occ_full, const int32_t *idx, const float *qvalue,
+                                               const float *wsum, const float *scaler, const float *points, const float *radii,
+                                               const uint8_t *visible, const int64_t *first_idx, const int64_t *num_pts, int N,
+                                               int64_t P, int S, int K, int C, int row0, int row1, int row_cycle, float radii_s, float clip,
+                                               float *grad_feat, float *grad_pts, float *rs_out, void *workspace, size_t workspace_bytes,
+                                               void *stream)
+{
+    if (!grad_occ_full) { set_error("dss_render_backward_owned_plane: grad_occ_full is NULL"); return DSS_ERR_INVALID_ARGUMENT; }
+    return render_backward_impl(true, grad_out, idx, qvalue, wsum, scaler, points, radii, visible, first_idx, num_pts, N, P, S,
+                                K, C, row0, row1, row_cycle, radii_s, clip, grad_feat, grad_pts, rs_out, nullptr, nullptr, workspace,
+                                workspace_bytes, stream, nullptr, grad_occ_full);
 }
 
 // Second stage alone (the persistent gather kernel), on the workspace (visible lists, alpha plane, rs) and the zero-filled

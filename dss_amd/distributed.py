@@ -138,7 +138,9 @@ def fitted_bounds(row_weight, samples, world_size: int, align: int = 8, min_rows
     summed over the rank's rows) + b * (rows of the rank)  with F, a, b >= 0 -- F is the work every rank repeats (setup of
     every splat, the medians), a the cost of covered pixels, b what a row costs covered or not -- and returns
     `balanced_bounds` of the per-row cost a * row_weight + b, together with (F, a, b).  Occupancy alone (b = 0) moved too
-    many empty rows to the outer ranks at configs[3]/[4]: their rows are not free (tile lists, alpha plane, image bytes)."""
+    many empty rows to the outer ranks at configs[3]/[4]: their rows are not free (tile lists, alpha plane, image bytes).
+    EVERY RANK MUST PASS THE SAME ``samples`` (all-gather the measured times first): ranks that derive different bounds
+    disagree about the band sizes of the exchange and hang in it.  `agree_on_bounds` broadcasts rank 0's result."""
     import itertools
     import numpy as np
     w = np.asarray(torch.as_tensor(row_weight, dtype=torch.float64).flatten().cpu())
@@ -161,6 +163,9 @@ def fitted_bounds(row_weight, samples, world_size: int, align: int = 8, min_rows
             err = float(((A @ x - y) ** 2).sum())
             if best is None or err < best[0] - 1e-12:
                 best = (err, x)
+    if best is None:
+        raise ValueError("fitted_bounds: no non-negative fit of t = F + a * weight + b * rows exists for these samples "
+                         "(are the times positive and finite?)")
     F, a, b = (float(v) for v in best[1])
     if a <= 0 and b <= 0:
         return balanced_bounds(np.ones_like(w), world_size, align, min_rows), (F, a, b)
@@ -170,13 +175,26 @@ def fitted_bounds(row_weight, samples, world_size: int, align: int = 8, min_rows
 def rebalanced_bounds(bounds, times, fixed: float, align: int = 8, min_rows: int = 8):
     """One step of measured-time rebalancing of contiguous bands: every rank's time above the repeated work ``fixed`` (the F
     of `fitted_bounds`) is spread evenly over its rows -- a piecewise-constant cost per row, measured, whatever it is made
-    of (tile lists, depth complexity, window sizes) -- and the boundaries are moved so that every rank gets the same share."""
+    of (tile lists, depth complexity, window sizes) -- and the boundaries are moved so that every rank gets the same share.
+    ``times`` must be the same list on every rank (see `fitted_bounds`; `agree_on_bounds`)."""
     S, G = int(bounds[-1]), len(bounds) - 1
     w = torch.zeros(S, dtype=torch.float64)
     for r in range(G):
         rows = bounds[r + 1] - bounds[r]
         w[bounds[r]:bounds[r + 1]] = max(float(times[r]) - float(fixed), 1e-6) / max(rows, 1)
     return balanced_bounds(w, G, align, min_rows)
+
+
+def agree_on_bounds(bounds, group=None, device=None):
+    """Rank 0's band boundaries on every rank (a broadcast of world_size + 1 integers): the guard for bounds derived from
+    locally measured quantities.  Without an initialised process group the input is returned as it is."""
+    b = [int(x) for x in bounds]
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return b
+    on_gpu = dist.get_backend(group) != "gloo"
+    t = torch.tensor(b, dtype=torch.int64, device=(device if device is not None else "cuda") if on_gpu else "cpu")
+    dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    return [int(x) for x in t.tolist()]
 
 
 def gather_rows(band: torch.Tensor, part: RowPartition, group=None) -> torch.Tensor:
@@ -449,6 +467,61 @@ class OverlappedExchange:
         return self.recv_img[:self.part.S].permute(1, 0, 2, 3)
 
 
+class AlphaPlaneExchange:
+    """All-gather of ONE channel of the bands' image gradients -- the occupancy (alpha) gradient -- into the dense
+    (N, S, S) plane the owner form of the backward reads (`ops.render_backward(grad_occ_full=...)`).
+
+    A rank that evaluates the loss on its own band (`band_image_loss`) only holds the gradient of its rows; the owned
+    search windows reach ``rs`` beyond them (and, for tile-row-cyclic bands, into every other rank's rows).  Only the alpha
+    channel is needed there (`rasterize_points_backward.cu:141-178` reads ``grad_occ``), so ``N S^2 4`` bytes cross the links
+    in total -- a quarter of the RGBA gradient, an eighth of it per rank and link at 8 ranks; the RGB gradient stays where it
+    was computed.  On the critical path (between the loss and the backward): issued on ``group``, blocking on the stream.
+    Send layout (band row, camera, col), like the image exchange: equal contiguous bands of one camera ARE the plane."""
+
+    def __init__(self, part: RowPartition, n_images: int, device, group=None):
+        self.part, self.group, self.N = part, group, int(n_images)
+        G, band, S = part.world_size, part.band, part.S
+        self.send = torch.zeros((band, self.N, S), dtype=torch.float32, device=device)
+        self.recv = torch.empty((G * band, self.N, S), dtype=torch.float32, device=device)
+        # rows already in image order and one camera: the receive buffer is the plane
+        self.direct = part.uniform and self.N == 1
+        self.row_pos = self.plane = None
+        if not self.direct:
+            self.row_pos = torch.tensor(part.gather_index(), dtype=torch.int32, device=device)
+            self.plane = torch.empty((self.N, S, S), dtype=torch.float32, device=device)
+
+    def pack(self, g_band: torch.Tensor) -> None:
+        """``g_band`` (N, rows, S, C+1), this rank's band of the image gradient: its last channel into the send buffer
+        (one strided copy, (row, camera, col) order)"""
+        self.send[:g_band.shape[1]].copy_(g_band[..., -1].permute(1, 0, 2))
+
+    def gather(self) -> None:
+        """the collective (blocking on the stream, on ``group``)"""
+        G = self.part.world_size
+        if dist.is_available() and dist.is_initialized():
+            OverlappedExchange._all_gather(self.recv.view(G, -1), self.send.view(-1), self.group, False)
+        else:
+            self.recv.copy_(self.send)
+
+    def plane_in_image_order(self) -> torch.Tensor:
+        """-> (N, S, S) alpha gradient of all rows, rows in image order"""
+        S = self.part.S
+        if self.direct:
+            return self.recv[:S].view(1, S, S)
+        if self.recv.is_cuda:
+            from . import ops
+            return ops.gather_rows(self.recv, self.row_pos, self.N, S, S, out=self.plane)
+        # (CPU tensors only occur in the gloo tests of the exchange logic)
+        self.plane.copy_(torch.index_select(self.recv, 0, self.row_pos.long()).permute(1, 0, 2))
+        return self.plane
+
+    def exchange(self, g_band: torch.Tensor) -> torch.Tensor:
+        """pack + gather + rows in image order"""
+        self.pack(g_band)
+        self.gather()
+        return self.plane_in_image_order()
+
+
 class _null_context:
     def __enter__(self):
         return self
@@ -500,29 +573,26 @@ def reduce_grads_(*grads: torch.Tensor, part: RowPartition, group=None):
 
 class _BandImageLoss(torch.autograd.Function):
     """Image loss of a row band with the per-image sums all-reduced over the ranks: every rank gets the GLOBAL loss
-    value and the gradient of it with respect to its own band."""
+    value and the gradient of it with respect to its own band.  Two launches + one collective: block partials of the band
+    (`ops.image_loss_band_partials`), all-reduce (SUM) of the partials (20 KB at 8 cameras), band gradient + the losses in
+    one launch (`ops.image_loss_band_backward_partials`, kept for the backward: the loss is linear in `grad_total`)."""
 
     @staticmethod
     def forward(ctx, rgba_band, img, mask_img, rows, lambda_rgb, lambda_silhouette, group):
         from . import ops
-        sums = ops.image_loss_band_sums(rgba_band, img, mask_img, rows)
+        part = ops.image_loss_band_partials(rgba_band, img, mask_img, rows)
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-            dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)   # 40 (N + 1) bytes
-        losses = ops.image_loss_from_sums(sums, (img.shape[1], img.shape[2]), lambda_rgb, lambda_silhouette)
-        ctx.save_for_backward(rgba_band, img, mask_img, sums)
-        ctx.args = (rows, lambda_rgb, lambda_silhouette)
+            dist.all_reduce(part, op=dist.ReduceOp.SUM, group=group)
+        grad, losses = ops.image_loss_band_backward_partials(rgba_band, img, mask_img, rows, lambda_rgb, lambda_silhouette, part)
+        ctx.save_for_backward(grad)
         total, rest = losses[0], losses[1:]
         ctx.mark_non_differentiable(rest)
         return total, rest
 
     @staticmethod
     def backward(ctx, grad_total, _grad_rest):
-        from . import ops
-        rgba_band, img, mask_img, sums = ctx.saved_tensors
-        rows, lambda_rgb, lambda_silhouette = ctx.args
-        grad = ops.image_loss_band_backward(rgba_band, img, mask_img, rows, lambda_rgb, lambda_silhouette, sums,
-                                            grad_total=grad_total.contiguous())
-        return grad, None, None, None, None, None, None
+        (grad,) = ctx.saved_tensors
+        return grad * grad_total, None, None, None, None, None, None
 
 
 def band_image_loss(rgba_band, img, mask_img, part: RowPartition, lambda_dr_rgb: float = 1.0,

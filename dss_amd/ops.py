@@ -456,7 +456,8 @@ def render_forward(world, normals, h, M, V, znear, zfar, cloud_to_packed_first_i
                    antialiasing_sigma: float = 1.0, backface_culling: bool = False, shared_cloud: bool = False,
                    rows: Optional[Tuple[int, int]] = None, out_image: Optional[torch.Tensor] = None,
                    out_visible: Optional[torch.Tensor] = None, vr6=None, frame_normals=None, want_zbuf: bool = True,
-                   workspace_state: int = 1, order_refresh: int = 0, band_outputs_only: bool = False):
+                   workspace_state: int = 1, order_refresh: int = 0, band_outputs_only: bool = False,
+                   point_outputs=None):
     """Fused forward (setup + binning + fine + blend, ``dss_render_forward``).  ``out_image`` (float32
     (N,rows,S,C+1), 16-byte aligned) / ``out_visible`` (uint8 (P,)) let the caller place these two outputs
     in its own buffer (the multi-GPU step points them into one all-gather send buffer).  ``features`` are the
@@ -470,8 +471,9 @@ def render_forward(world, normals, h, M, V, znear, zfar, cloud_to_packed_first_i
     the screen-cell order that the binning sorts the points into is kept in the workspace of this problem size and reused by
     the next k - 1 calls on it, which then skip the sort (same outputs bit for bit; a stale order only costs locality).
     ``band_outputs_only`` (DSS_WS_BAND_OUTPUTS; with ``rows`` only): ``ellipse_params``, ``scaler`` and ``cutoff_threshold`` are
-    written for the splats that meet the band only (undefined elsewhere); everything else is unchanged -- what a multi-GPU
-    rank asks for: it needs every point's position and radii for the backward, but bins an eighth of the cloud."""
+    written for the splats that meet the band only (zero elsewhere); everything else is unchanged -- what a multi-GPU
+    rank asks for: it needs every point's position and radii for the backward, but bins an eighth of the cloud.
+    ``point_outputs`` = (ellipse (P,3), scaler (P,), cutoff (P,)): caller-owned buffers for those three outputs."""
     lib = _lib.load()
     world = _lib.require_gpu(world, "world", _f32)
     dev = world.device
@@ -508,7 +510,21 @@ def render_forward(world, normals, h, M, V, znear, zfar, cloud_to_packed_first_i
                  image=e(N, 0, S, C + 1) if out_image is None else out_image, wsum=e(N, 0, S), visible=vis.view(torch.bool))
         return o
     with torch.cuda.device(dev):
-        o = dict(pts_screen=e(P, 3), ellipse_params=e(P, 3), radii=e(P, 2), scaler=e(P), cutoff_threshold=e(P),
+        # band_outputs_only: the library writes ellipse / scaler / cutoff only for the splats that meet the band; the rest of
+        # those three arrays is handed out ZERO-filled, never as uninitialised device memory (one fill of 20 P bytes)
+        if point_outputs is not None:
+            # caller-owned (ellipse (P,3), scaler (P,), cutoff (P,)): a multi-GPU step zero-fills them ONCE and hands them to
+            # every forward (entries of splats outside the band then hold zeros or the value of an earlier step: defined)
+            ell, sca, cut = point_outputs
+            if tuple(ell.shape) != (P, 3) or tuple(sca.shape) != (P,) or tuple(cut.shape) != (P,) or \
+                    any(t.dtype != _f32 or not t.is_contiguous() or t.device != dev for t in (ell, sca, cut)):
+                raise RuntimeError("point_outputs must be contiguous float32 (P,3), (P,), (P,) tensors on the device")
+        elif band_outputs_only and (int(workspace_state) & 0xf) != 2:
+            z3 = torch.zeros(P * 5, dtype=_f32, device=dev)
+            ell, sca, cut = z3[:P * 3].view(P, 3), z3[P * 3:P * 4], z3[P * 4:]
+        else:
+            ell, sca, cut = e(P, 3), e(P), e(P)
+        o = dict(pts_screen=e(P, 3), ellipse_params=ell, radii=e(P, 2), scaler=sca, cutoff_threshold=cut,
                  idx=e(N, nr, S, K, dtype=_i32), zbuf=e(N, nr, S, K) if want_zbuf else None, qvalue=e(N, nr, S, K),
                  occupancy=e(N, nr, S), image=e(N, nr, S, C + 1) if out_image is None else out_image, wsum=e(N, nr, S))
         valid = e(P, dtype=_u8)
@@ -547,7 +563,7 @@ def render_backward(grad_out, idx, qvalue, wsum, scaler, points, radii, visible,
                     return_rs: bool = False, image_size: Optional[int] = None,
                     rows: Optional[Tuple[int, int]] = None, out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
                     gather_only_rs: Optional[torch.Tensor] = None, project=None,
-                    grad_out_full: Optional[torch.Tensor] = None):
+                    grad_out_full: Optional[torch.Tensor] = None, grad_occ_full: Optional[torch.Tensor] = None):
     """Fused backward of renderer + rasterizer (blend backward + median radius + occupancy backward +
     clip) -> (grad_features (P,C) or None, grad_pts_screen (P,3)).  With ``rows`` (multi-GPU band) pass the
     union of the visibility flags and ``clip <= 0``; the results are the band's partial sums.
@@ -558,7 +574,9 @@ def render_backward(grad_out, idx, qvalue, wsum, scaler, points, radii, visible,
     ``grad_out_full`` (N,S,S,C+1) with ``rows``: OWNER mode of the band (``dss_render_backward_owned``) -- the position
     gradient of every (camera, point) pair is computed completely, over its whole search window in the full image gradient,
     by the rank whose band holds the image row of the point's centre (zeros on the other ranks), so that clip and projection
-    can precede the reduction over the ranks; the feature gradients stay partial sums of the band."""
+    can precede the reduction over the ranks; the feature gradients stay partial sums of the band.
+    ``grad_occ_full`` (N,S,S) with ``rows``: the same owner mode fed by the dense plane of the occupancy gradient alone
+    (``dss_render_backward_owned_plane``) -- what the ranks of a step with a band-local loss all-gather (`gather_rows`)."""
     lib = _lib.load()
     grad_out = _lib.require_gpu(grad_out, "grad_out", _f32)
     dev = grad_out.device
@@ -607,6 +625,19 @@ def render_backward(grad_out, idx, qvalue, wsum, scaler, points, radii, visible,
                                    % (P, N, tuple(w_t.shape), tuple(m_t.shape)))
             w_p, m_p = _lib.ptr(w_t), _lib.ptr(m_t)
         ws = _lib.workspace(dev, lib.dss_render_backward_workspace(N, P, S))
+        if grad_occ_full is not None:
+            if project is not None or gather_only_rs is not None or grad_out_full is not None:
+                raise RuntimeError("grad_occ_full (owner mode of a band) excludes project=, gather_only_rs= and grad_out_full=")
+            plane = _lib.require_gpu(grad_occ_full, "grad_occ_full", _f32)
+            if tuple(plane.shape) != (N, S, S):
+                raise RuntimeError("grad_occ_full must be (N,S,S) = %s, got %s" % ((N, S, S), tuple(plane.shape)))
+            rc = lib.dss_render_backward_owned_plane(
+                _lib.ptr(grad_out), _lib.ptr(plane), _lib.ptr(idx), _lib.ptr(qvalue), _lib.ptr(wsum), _lib.ptr(scaler),
+                _lib.ptr(points), _lib.ptr(radii), _lib.ptr(vis), _lib.ptr(first), _lib.ptr(num), N, P, S, K, C, row0, row1, cyc,
+                float(radii_s), float(clip), _lib.ptr(gf), _lib.ptr(gp), _lib.ptr(rs), _lib.ptr(ws), ws.numel(),
+                _lib.stream_ptr(dev))
+            _lib.check(rc, "dss_render_backward_owned_plane")
+            return (gf, gp, rs) if return_rs else (gf, gp)
         if grad_out_full is not None:
             if project is not None or gather_only_rs is not None:
                 raise RuntimeError("grad_out_full (owner mode of a band) excludes project= and gather_only_rs=")
@@ -628,6 +659,26 @@ def render_backward(grad_out, idx, qvalue, wsum, scaler, points, radii, visible,
                    _lib.stream_ptr(dev))
     _lib.check(rc, "dss_render_backward")
     return (gf, gp, rs) if return_rs else (gf, gp)
+
+
+def gather_rows(src, row_pos, n_images: int, rows: int, row_floats: int, out=None):
+    """``dss_gather_rows``: rows of an all-gathered (position, camera, row_floats) float32 buffer put in image order ->
+    dense (n_images, rows, row_floats); ``row_pos`` int32 (rows,) = position of image row r in ``src``."""
+    lib = _lib.load()
+    src = _lib.require_gpu(src, "src", _f32)
+    dev = src.device
+    row_pos = _lib.require_gpu(row_pos, "row_pos", _i32)
+    if row_pos.numel() != rows or src.numel() % (n_images * row_floats):
+        raise RuntimeError("gather_rows: row_pos must have %d entries and src whole (camera, row) slices" % rows)
+    with torch.cuda.device(dev):
+        if out is None:
+            out = torch.empty((n_images, rows, row_floats), dtype=_f32, device=dev)
+        elif out.numel() != n_images * rows * row_floats or out.dtype != _f32 or not out.is_contiguous():
+            raise RuntimeError("gather_rows: out must be a contiguous float32 tensor of %d elements" % (n_images * rows * row_floats))
+        rc = lib.dss_gather_rows(_lib.ptr(src), _lib.ptr(row_pos), int(n_images), int(rows), int(row_floats), _lib.ptr(out),
+                                 _lib.stream_ptr(dev))
+    _lib.check(rc, "dss_gather_rows")
+    return out
 
 
 class _NoSwitch:
@@ -1191,7 +1242,20 @@ def _band_row_index(row0, row1, cyc, device):
     return t
 
 
-def _band_args(rgba_band, target_rgb, target_mask, rows):
+def band_targets(target_rgb, target_mask, rows):
+    """The rows ``rows`` of the targets of a band loss, gathered ONCE (a tile-row-cyclic band costs two index_select launches
+    per call otherwise): pass the result as ``band_targets=`` to `image_loss_band_sums` / `image_loss_band_backward` while the
+    targets stay the same."""
+    row0, row1, cyc = _band(rows, None) if len(rows) > 2 else (int(rows[0]), int(rows[1]), 1)
+    N, H, W = target_rgb.shape[0], target_rgb.shape[1], target_rgb.shape[2]
+    target_mask = target_mask.to(_f32).reshape(N, H, W)
+    if cyc > 1:
+        ri = _band_row_index(row0, row1, cyc, target_rgb.device)
+        return target_rgb.index_select(1, ri).contiguous(), target_mask.index_select(1, ri).contiguous()
+    return target_rgb[:, row0:row1], target_mask[:, row0:row1]
+
+
+def _band_args(rgba_band, target_rgb, target_mask, rows, band_targets=None):
     """Row band of an image loss: the band render (N,rows,W,4) against the FULL targets (N,H,W,3) / (N,H,W); returns the
     tensors plus the targets' band and the image stride of its mask.  ``rows`` = (row0, row1) for a contiguous band (views of
     the targets, no copy) or (row0, row1, cycle) for a tile-row-cyclic one (`RowPartition(cyclic=True).rows`: the owned
@@ -1208,6 +1272,11 @@ def _band_args(rgba_band, target_rgb, target_mask, rows):
     if target_rgb.dim() != 4 or tuple(target_rgb.shape) != (N, H, W, 3) or not (0 <= row0 <= row1 <= H):
         raise RuntimeError("dss_amd: target_rgb must be the full (N,H,W,3) target with 0 <= row0 <= row1 <= H")
     target_mask = _lib.require_gpu(target_mask, "target_mask", _f32).reshape(N, H, W)
+    if band_targets is not None:
+        band_rgb, band_mask = band_targets
+        if tuple(band_rgb.shape) != (N, nr, W, 3) or tuple(band_mask.shape) != (N, nr, W):
+            raise RuntimeError("dss_amd: band_targets must be (N,%d,W,3) and (N,%d,W)" % (nr, nr))
+        return rgba_band, band_rgb, band_mask, target_mask, N, nr, W, H, int(band_mask.stride(0))
     if cyc > 1:
         ri = _band_row_index(row0, row1, cyc, rgba_band.device)
         band_rgb = target_rgb.index_select(1, ri)
@@ -1218,11 +1287,11 @@ def _band_args(rgba_band, target_rgb, target_mask, rows):
     return rgba_band, band_rgb, band_mask, target_mask, N, nr, W, H, H * W
 
 
-def image_loss_band_sums(rgba_band, target_rgb, target_mask, rows):
+def image_loss_band_sums(rgba_band, target_rgb, target_mask, rows, band_targets=None):
     """Per-image sums of ``Trainer.calc_dr_loss`` over the row band ``rows = (row0, row1)`` -> float64 (N+1,5) whose
     first N rows are filled; all-reduce (SUM) ``sums[:N]`` over the ranks, then :func:`image_loss_from_sums`."""
     lib = _lib.load()
-    rgba_band, band_rgb, band_mask, _keep, N, nr, W, H, mstride = _band_args(rgba_band, target_rgb, target_mask, rows)
+    rgba_band, band_rgb, band_mask, _keep, N, nr, W, H, mstride = _band_args(rgba_band, target_rgb, target_mask, rows, band_targets)
     dev = rgba_band.device
     with torch.cuda.device(dev):
         sums = torch.zeros((N + 1, 5), dtype=torch.float64, device=dev)
@@ -1251,10 +1320,10 @@ def image_loss_from_sums(sums, image_size, lambda_rgb: float, lambda_silhouette:
 
 
 def image_loss_band_backward(rgba_band, target_rgb, target_mask, rows, lambda_rgb: float, lambda_silhouette: float, sums,
-                             grad_total=None):
+                             grad_total=None, band_targets=None):
     """The band ``rows`` of d total / d rgba, (N,rows,W,4), from the reduced ``sums`` (after image_loss_from_sums)."""
     lib = _lib.load()
-    rgba_band, band_rgb, band_mask, _keep, N, nr, W, H, mstride = _band_args(rgba_band, target_rgb, target_mask, rows)
+    rgba_band, band_rgb, band_mask, _keep, N, nr, W, H, mstride = _band_args(rgba_band, target_rgb, target_mask, rows, band_targets)
     dev = rgba_band.device
     sums = _lib.require_gpu(sums, "sums", torch.float64)
     if grad_total is not None:
@@ -1269,3 +1338,47 @@ def image_loss_band_backward(rgba_band, target_rgb, target_mask, rows, lambda_rg
                                                   _lib.ptr(grad_total), _lib.ptr(grad), _lib.stream_ptr(dev))
             _lib.check(rc, "dss_image_loss_band_backward")
     return grad
+
+
+def image_loss_band_partials(rgba_band, target_rgb, target_mask, rows, band_targets=None, out=None):
+    """First launch of the two-launch band loss (``dss_image_loss_band_partials``): the block partials of the band's five
+    per-image sums -> float64 (N, 64, 5).  All-reduce THEM (SUM) over the ranks, then `image_loss_band_backward_partials`.
+    ``out``: a caller-owned buffer of that shape (a step that replays as a graph all-reduces a static one)."""
+    lib = _lib.load()
+    rgba_band, band_rgb, band_mask, _keep, N, nr, W, H, mstride = _band_args(rgba_band, target_rgb, target_mask, rows, band_targets)
+    dev = rgba_band.device
+    with torch.cuda.device(dev):
+        n = lib.dss_image_loss_band_partials_count(N)
+        part = torch.empty((N, n // (5 * N), 5), dtype=torch.float64, device=dev) if out is None else out
+        if part.numel() != n or part.dtype != torch.float64 or not part.is_contiguous():
+            raise RuntimeError("dss_amd: out must be a contiguous float64 tensor of %d elements" % n)
+        sn, sh, sw, sc = band_rgb.stride() if nr > 0 else (0, 0, 0, 0)
+        rc = lib.dss_image_loss_band_partials(_lib.ptr(rgba_band), _lib.ptr(band_rgb), sn, sh, sw, sc, _lib.ptr(band_mask), mstride,
+                                              N, nr, W, _lib.ptr(part), _lib.stream_ptr(dev))
+    _lib.check(rc, "dss_image_loss_band_partials")
+    return part
+
+
+def image_loss_band_backward_partials(rgba_band, target_rgb, target_mask, rows, lambda_rgb: float, lambda_silhouette: float,
+                                      partials, grad_total=None, band_targets=None, want_sums: bool = False):
+    """Second launch: from the ALL-REDUCED partials -> (band of d total / d rgba (N,rows,W,4), losses (4,) = total, weighted
+    rgb term, weighted silhouette term, IoU term[, sums (N+1,5) float64]) -- identical bits on every rank."""
+    lib = _lib.load()
+    rgba_band, band_rgb, band_mask, _keep, N, nr, W, H, mstride = _band_args(rgba_band, target_rgb, target_mask, rows, band_targets)
+    dev = rgba_band.device
+    partials = _lib.require_gpu(partials, "partials", torch.float64)
+    if partials.numel() != lib.dss_image_loss_band_partials_count(N):
+        raise RuntimeError("dss_amd: partials must come from image_loss_band_partials")
+    if grad_total is not None:
+        grad_total = _lib.require_gpu(grad_total, "grad_total", _f32).reshape(1)
+    with torch.cuda.device(dev):
+        grad = torch.empty_like(rgba_band)
+        losses = torch.empty((4,), dtype=_f32, device=dev)
+        sums = torch.empty((N + 1, 5), dtype=torch.float64, device=dev) if want_sums else None
+        sn, sh, sw, sc = band_rgb.stride() if nr > 0 else (0, 0, 0, 0)
+        rc = lib.dss_image_loss_band_backward_partials(_lib.ptr(rgba_band), _lib.ptr(band_rgb), sn, sh, sw, sc, _lib.ptr(band_mask),
+                                                       mstride, N, nr, W, H, float(lambda_rgb), float(lambda_silhouette),
+                                                       _lib.ptr(partials), _lib.ptr(grad_total), _lib.ptr(grad), _lib.ptr(losses),
+                                                       _lib.ptr(sums), _lib.stream_ptr(dev))
+    _lib.check(rc, "dss_image_loss_band_backward_partials")
+    return (grad, losses, sums) if want_sums else (grad, losses)

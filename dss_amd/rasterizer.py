@@ -559,6 +559,45 @@ class SurfaceSplatting(torch.nn.Module):
             plan = plans[key] = FusedPlan(*key)
         return plan
 
+    def _render_sharded(self, a, feats, st, part, point_clouds_filter, original_clouds, **kwargs):
+        """`render_fused` on a row partition (`dss_amd.sharded.RowShardedRender`, multi-GPU): -> (image, fragments, clouds)
+        with ``image`` the FULL (N,S,S,C+1) render (gathered from all ranks) or, with ``band_only=True``, this rank's rows
+        (N,rows,S,C+1) for `dss_amd.distributed.band_image_loss`.  The fragments are those of the rank's rows."""
+        from .sharded import RowShardedRender
+        if st.points_per_pixel > 32:
+            raise ValueError("a row-partitioned render needs points_per_pixel <= 32 (the fused kernels)")
+        dev, N, Pw = a["world"].device, a["N"], a["world"].shape[0]
+        P = N * Pw if a["shared"] else Pw
+        S, K, C = int(st.image_size), int(st.points_per_pixel), int(feats.shape[1])
+        gradient = kwargs.get("gradient_exchange", "owner")
+        group = kwargs.get("process_group", None)
+        key = (dev, N, Pw, P, S, K, C, bool(a["shared"]), bool(st.backface_culling), float(st.cutoff_threshold),
+               float(st.antialiasing_sigma), float(st.depth_merging_threshold), part.world_size, part.rank, part.cyclic,
+               None if part.cyclic else tuple(part._bounds), gradient, id(group))
+        engines = self.__dict__.setdefault("_sharded", {})
+        engine = engines.get(key)
+        if engine is None:
+            if len(engines) > 4:
+                engines.clear()
+            engine = engines[key] = RowShardedRender(part, N, Pw, P, S, K, C, dev, a["shared"], st.cutoff_threshold,
+                                                     st.antialiasing_sigma, st.depth_merging_threshold,
+                                                     bool(st.backface_culling), group=group, gradient=gradient,
+                                                     static_buffers=False)
+        band_only = bool(kwargs.get("band_only", False))
+        aux = (a["normals"], a["h"], a["M"], a["V"], a["znear"], a["zfar"], a["first_idx"], a["num_points"], a["vr6"],
+               a["frame_n"], float(st.radii_backward_scaler), -1.0 if st.clip_pts_grad is None else float(st.clip_pts_grad),
+               band_only, int(kwargs.get("order_refresh", getattr(self, "order_refresh", 0)) or 0))
+        image = _RenderRowSharded.apply(a["world"], feats.contiguous(), engine, aux)
+        f = engine.f
+        visible = engine.vis_all.view(torch.bool)
+        fragments = None
+        if kwargs.get("want_fragments", True):
+            fragments = PointFragments(idx=f["idx"], zbuf=f["zbuf"], qvalue=f["qvalue"], scaler=f["scaler"],
+                                       occupancy=f["occupancy"],
+                                       geometry=(f["pts_screen"], f["radii"], visible, a["first_idx"], a["num_points"]))
+        self._store_visibility(point_clouds_filter, visible.clone(), a["N"], a["shared"], original_clouds)
+        return image, fragments, a["out_clouds"]
+
     def render_fused(self, point_clouds, point_clouds_filter=None, **kwargs):
         """Rasterize AND blend in the fused kernels (``dss_render_forward`` / ``dss_render_backward``):
         -> ``(images (N,S,S,C+1), PointFragments, point_clouds)``.  Same values as ``forward`` + the
@@ -593,6 +632,9 @@ class SurfaceSplatting(torch.nn.Module):
         if feats.shape[1] > 8:
             raise ValueError("render_fused blends at most 8 feature channels, got %d (use the unfused forward() + "
                              "renderer for wider features)" % feats.shape[1])
+        part = kwargs.get("row_partition", None)
+        if part is not None:
+            return self._render_sharded(a, feats, st, part, point_clouds_filter, original_clouds, **kwargs)
         lean = self._lean_plan(a, feats, st)
         # renderer-owned cached point order (large clouds; include/dss_hip.h DSS_WS_ORDER_*): refreshed every k-th call
         order_refresh = int(kwargs.get("order_refresh", getattr(self, "order_refresh", 0)) or 0)
@@ -646,6 +688,33 @@ class SurfaceSplatting(torch.nn.Module):
                                    geometry=(pts_screen, radii, visible, a["first_idx"], a["num_points"]))
         self._store_visibility(point_clouds_filter, visible, a["N"], a["shared"], original_clouds)
         return image, fragments, a["out_clouds"]
+
+
+class _RenderRowSharded(autograd.Function):
+    """The fused renderer with its image rows partitioned over the ranks of a process group (`dss_amd.sharded`), as ONE
+    autograd node: forward = this rank's rows + the exchanges, backward = this rank's rows + the gradient exchange.  The
+    gradients it returns are the sums over all ranks, identical on every rank."""
+
+    @staticmethod
+    def forward(ctx, world, features, engine, aux):
+        normals, h, M, V, znear, zfar, first, num, vr6, frame_n, radii_s, clip, band_only, order_refresh = aux
+        f = engine.forward(world, normals, h, M, V, znear, zfar, first, num, features, vr6, frame_n, order_refresh)
+        # (private copies of what lives in the engine's exchange buffers: a second render before this one's backward --
+        # Model.prune_points, an evaluation pass -- must not change what this node differentiates)
+        vis = engine.start_exchange().clone()
+        ctx.save_for_backward(world)
+        ctx.engine, ctx.f, ctx.vis, ctx.aux = engine, f, vis, (M, V, first, num, radii_s, clip)
+        # band_only: the image all-gather stays in flight behind the loss and the backward (`engine.full_image()` waits for
+        # it; the next forward does before it overwrites the send buffer)
+        image = engine.band_image if band_only else engine.full_image()
+        return image.clone(memory_format=torch.contiguous_format)
+
+    @staticmethod
+    def backward(ctx, g_image):
+        (world,) = ctx.saved_tensors
+        M, V, first, num, radii_s, clip = ctx.aux
+        g_world, g_feat = ctx.engine.backward(g_image, radii_s, clip, world, M, V, first, num, f=ctx.f, vis_all=ctx.vis)
+        return g_world.clone(), g_feat.clone(), None, None
 
 
 class _GraphedRender:

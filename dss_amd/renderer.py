@@ -12,7 +12,7 @@ import torch.autograd as autograd
 
 from . import ops
 
-__all__ = ["SurfaceSplattingRenderer", "NormWeightedCompositor"]
+__all__ = ["SurfaceSplattingRenderer", "RowShardedSurfaceSplattingRenderer", "NormWeightedCompositor"]
 
 
 class _Blend(autograd.Function):
@@ -52,7 +52,8 @@ class NormWeightedCompositor(torch.nn.Module):
 
 class SurfaceSplattingRenderer(torch.nn.Module):
     def __init__(self, rasterizer, compositor=None, antialiasing_sigma: float = 1.0, density: float = 1e-4,
-                 frnn_radius=-1, fused=None, graphed: bool = False, order_refresh: int = 0, engine_thread=None):
+                 frnn_radius=-1, fused=None, graphed: bool = False, order_refresh: int = 0, engine_thread=None,
+                 row_partition=None, gradient_exchange: str = "owner", row_output: str = "full", process_group=None):
         """``fused`` (not in the reference signature): True runs rasterizer + blend as ONE autograd node on the fused
         kernels (dss_render_forward / dss_render_backward): same images, ~2x fewer launches; the only loss of generality
         is that gradients w.r.t. ``fragments.zbuf`` are not propagated.  False keeps rasterizer and blend as separate
@@ -74,7 +75,15 @@ class SurfaceSplattingRenderer(torch.nn.Module):
         thread-local, for everything that thread differentiates afterwards: a knowing, process-level opt-in).  The scoped form
         is ``with dss_amd.calling_thread_backward(): loss.backward()``, which restores the state on exit; see there for why
         it matters at DSS sizes (0.25 vs 0.125 ms of host time per forward + backward).  Round 4 flipped the switch in every
-        constructor; a drop-in for the reference's renderer must not change global engine state as a side effect."""
+        constructor; a drop-in for the reference's renderer must not change global engine state as a side effect.
+        ``row_partition`` (multi-GPU, not in the reference, which has no distributed layer): a
+        `dss_amd.distributed.RowPartition`, or "auto" / "cyclic" / "bands" = this rank's share of the initialised
+        ``torch.distributed`` process group (``process_group``, default the world; no group or a world of one: the plain
+        single-GPU path).  Every rank then renders its image rows only and the call returns, through ONE autograd node
+        (`dss_amd.rasterizer._RenderRowSharded`), with ``row_output="full"`` the whole (N,H,W,4) image gathered from all ranks
+        -- an unmodified training loop evaluates its loss on it on every rank -- or with ``row_output="band"`` the rank's own
+        rows (N,rows,W,4) for `dss_amd.distributed.band_image_loss`; ``loss.backward()`` leaves the SAME gradients (the sums
+        over all ranks) on every rank.  ``gradient_exchange``: "owner" (default) or "bucket", see `dss_amd.sharded`."""
         super().__init__()
         if engine_thread is None and os.environ.get("DSS_AMD_CALLING_THREAD_BACKWARD", "0") == "1":
             engine_thread = False
@@ -84,6 +93,11 @@ class SurfaceSplattingRenderer(torch.nn.Module):
         self.fused = fused
         self.graphed = bool(graphed)
         self.order_refresh = int(order_refresh)
+        if row_output not in ("full", "band"):
+            raise ValueError("row_output must be 'full' or 'band', got %r" % (row_output,))
+        self.row_partition, self.gradient_exchange, self.row_output = row_partition, gradient_exchange, row_output
+        self.process_group = process_group
+        self._auto_part = None
         self.rasterizer = rasterizer
         self.compositor = compositor
         self.cameras = self.rasterizer.cameras
@@ -98,11 +112,47 @@ class SurfaceSplattingRenderer(torch.nn.Module):
         return isinstance(self.compositor, NormWeightedCompositor) or \
             type(self.compositor).__name__ == "NormWeightedCompositor"
 
+    def _partition(self, raster_settings):
+        """the row partition of this call: the object given, or this rank's share of the process group (resolved per image
+        size, once), or None = single-GPU path"""
+        rp = self.row_partition
+        if rp is None:
+            return None
+        st = self.rasterizer.raster_settings if raster_settings is None else raster_settings
+        S = int(st.image_size)
+        if isinstance(rp, str):
+            hit = self._auto_part
+            if hit is None or hit[0] != S:
+                from .sharded import default_partition
+                hit = self._auto_part = (S, default_partition(S, self.process_group, layout=rp))
+            return hit[1]
+        if rp.S != S:
+            raise ValueError("row_partition is for %d image rows, the raster settings say %d" % (rp.S, S))
+        return rp if rp.world_size > 1 else None
+
     def forward(self, point_clouds, **kwargs):
         if point_clouds.isempty():
             return None
         fragments = kwargs.get("fragments", None)
         fused = (not kwargs.get("verbose", False)) if self.fused is None else bool(self.fused)
+        part = self._partition(kwargs.get("raster_settings")) if fragments is None else None
+        if part is not None:
+            # multi-GPU: the fused path on this rank's rows, or nothing -- silently rendering the whole image on every rank
+            # would hide a mis-configured job
+            if not (hasattr(self.rasterizer, "render_fused") and self._is_norm_weighted()
+                    and not self.rasterizer.compacts(kwargs.get("raster_settings"))):
+                raise RuntimeError("a row-partitioned render needs dss_amd's SurfaceSplatting, a NormWeightedCompositor and "
+                                   "the masked culling path (backface_culling off or compact_culled=False)")
+            kw = {k: v for k, v in kwargs.items() if k != "fragments"}
+            kw.update(row_partition=part, gradient_exchange=self.gradient_exchange, process_group=self.process_group,
+                      band_only=kwargs.get("band_only", self.row_output == "band"),
+                      want_fragments=bool(kwargs.get("verbose", False)))
+            if self.order_refresh > 0 and "order_refresh" not in kw:
+                kw["order_refresh"] = self.order_refresh
+            images, fragments, point_clouds = self.rasterizer.render_fused(point_clouds, **kw)
+            if images.shape[-1] != 4:
+                images = torch.cat([images[..., :3], images[..., -1:]], dim=-1)
+            return (images, fragments) if kwargs.get("verbose", False) else images
         if (fragments is None and fused and hasattr(self.rasterizer, "render_fused")
                 and not self.rasterizer.compacts(kwargs.get("raster_settings"))   # (that mode rebuilds the clouds first: unfused)
                 and self._is_norm_weighted()
@@ -152,3 +202,38 @@ class SurfaceSplattingRenderer(torch.nn.Module):
         if kwargs.get("verbose", False):
             return images, fragments
         return images
+
+
+class RowShardedSurfaceSplattingRenderer(SurfaceSplattingRenderer):
+    """`SurfaceSplattingRenderer` that shards its image rows over the GPUs of the node -- the class a YAML names to run the
+    reference's unmodified training script on several GPUs (``config.py:241-261`` can pass no constructor argument, only a
+    class path)::
+
+        renderer:
+          renderer_type: dss_amd.renderer.RowShardedSurfaceSplattingRenderer
+          raster_type: dss_amd.rasterizer.SurfaceSplatting
+          compositor_type: dss_amd.renderer.NormWeightedCompositor
+
+        torchrun --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 train_mvr.py --config cfg.yml
+
+    Every rank runs the same script on the same batches (the reference seeds its RNGs identically in every process,
+    ``DSS/__init__.py:12-16``): a replicated loop around a sharded render.  The constructor is where the process joins the job
+    -- an explicit opt-in by class choice: when ``WORLD_SIZE`` > 1 is in the environment and no process group exists yet it
+    selects the GPU ``LOCAL_RANK`` (``train_mvr.py:32-33`` then places the model on the current device) and initialises
+    ``torch.distributed`` (backend ``nccl`` = RCCL; ``DSS_AMD_DIST_BACKEND`` overrides, e.g. ``gloo`` in tests)."""
+
+    def __init__(self, rasterizer, compositor=None, **kwargs):
+        import torch.distributed as dist
+        kwargs.setdefault("row_partition", os.environ.get("DSS_AMD_ROW_PARTITION", "auto"))
+        kwargs.setdefault("gradient_exchange", os.environ.get("DSS_AMD_GRADIENT_EXCHANGE", "owner"))
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        if world > 1 and dist.is_available() and not dist.is_initialized():
+            if torch.cuda.is_available():
+                torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            backend = os.environ.get("DSS_AMD_DIST_BACKEND", "nccl")
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", torch.cuda.current_device()))
+            else:
+                dist.init_process_group(backend)
+        super().__init__(rasterizer, compositor, **kwargs)

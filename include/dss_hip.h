@@ -358,6 +358,24 @@ DSS_API int dss_render_backward_owned(const float *grad_out, const float *grad_o
                                       int K, int C, int row0, int row1, int row_cycle, float radii_s, float clip,
                                       float *grad_feat, float *grad_pts, float *rs_out, void *workspace,
                                       size_t workspace_bytes, void *stream);
+/* dss_render_backward_owned fed by the DENSE plane of the occupancy gradient, grad_occ_full (N,S,S) -- the alpha channel of
+ * the image gradient of all rows.  A rank that evaluates the loss on its own band (Trainer.calc_dr_loss, trainer.py:332-376,
+ * with the per-image sums all-reduced) only has the gradient of its band; the owned windows need the alpha channel of the
+ * other rows too (N S^2 4 bytes over all ranks): the ranks all-gather that channel alone and put the rows in image order
+ * (dss_gather_rows), the RGB gradient never leaves its rank.  grad_out (N,rows,S,C+1) is the band's gradient as before. */
+DSS_API int dss_render_backward_owned_plane(const float *grad_out, const float *grad_occ_full, const int32_t *idx,
+                                            const float *qvalue, const float *wsum, const float *scaler,
+                                            const float *points, const float *radii, const uint8_t *visible,
+                                            const int64_t *first_idx, const int64_t *num_pts, int N, int64_t P, int S,
+                                            int K, int C, int row0, int row1, int row_cycle, float radii_s, float clip,
+                                            float *grad_feat, float *grad_pts, float *rs_out, void *workspace,
+                                            size_t workspace_bytes, void *stream);
+/* Rows of an all-gathered exchange buffer put in image order (multi-GPU row bands; the reference assembles its image on one
+ * device, renderer.py:75-78):  dst[n][r][0..row_floats) = src[row_pos[r]][n][0..row_floats)  for r < rows, n < N.  src is
+ * what an all-gather of (band row, camera, col, channel) send buffers leaves behind, row_pos (rows,) int32 the position of
+ * image row r in it (contiguous, padded or tile-row-cyclic bands alike), dst the dense (N, rows, row_floats) image. */
+DSS_API int dss_gather_rows(const float *src, const int32_t *row_pos, int N, int rows, int row_floats, float *dst,
+                            void *stream);
 /* Second stage of dss_render_backward alone (the persistent gather kernel = blend backward + occupancy surrogate + clip of
  * every visible point, rasterize_points_backward.cu:30-212): runs on the workspace (visible lists, alpha plane, rs) and the
  * zero-filled gradients that a preceding dss_render_backward call with the SAME arguments left behind; same result.
@@ -565,6 +583,24 @@ DSS_API int dss_image_loss_band_backward(const float *rgba_band, const float *ta
                                          const float *target_mask, int64_t mask_stride_n, int N, int rows, int W,
                                          int H, float lambda_rgb, float lambda_silhouette, const double *sums,
                                          const float *grad_total, float *grad_band, void *stream);
+
+/* The same band loss in TWO launches per step: dss_image_loss_band_partials writes the block partials of the band,
+ * (N, 64, 5) doubles (dss_image_loss_band_partials_count(N) of them; a rank without rows writes zeros); the caller
+ * all-reduces THEM (SUM: 20 KB at 8 cameras -- latency-bound like the 40 N bytes of the sums); and
+ * dss_image_loss_band_backward_partials adds them up in its prologue (every block in the same fixed order: the same bits on
+ * every rank) and writes the band of the gradient image, the four losses (may be NULL) and the (N+1,5) sums (may be NULL). */
+DSS_API size_t dss_image_loss_band_partials_count(int N);
+DSS_API int dss_image_loss_band_partials(const float *rgba_band, const float *target_rgb, int64_t t_stride_n,
+                                         int64_t t_stride_h, int64_t t_stride_w, int64_t t_stride_c,
+                                         const float *target_mask, int64_t mask_stride_n, int N, int rows, int W,
+                                         double *partials, void *stream);
+DSS_API int dss_image_loss_band_backward_partials(const float *rgba_band, const float *target_rgb, int64_t t_stride_n,
+                                                  int64_t t_stride_h, int64_t t_stride_w, int64_t t_stride_c,
+                                                  const float *target_mask, int64_t mask_stride_n, int N, int rows,
+                                                  int W, int H, float lambda_rgb, float lambda_silhouette,
+                                                  const double *partials, const float *grad_total, float *grad_band,
+                                                  float *losses /* (4) or NULL */, double *sums /* (N+1,5) or NULL */,
+                                                  void *stream);
 
 #ifdef __cplusplus
 }

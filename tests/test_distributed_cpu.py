@@ -267,7 +267,22 @@ def _band_loss_worker(rank, world, port, tmp, cyclic=False):
             g[..., 3] = l_sil * (torch.sign(a - t) / (N * H * W) + 0.01 * (-(t * U - I * (1 - t)) / (U * U)) / N)
             return (g * (1.0 if grad_total is None else float(grad_total))).float()
 
-        ops.image_loss_band_sums, ops.image_loss_from_sums, ops.image_loss_band_backward = band_sums, from_sums, band_backward
+        # the two-launch form band_image_loss uses: block partials (N, 64, 5) -> [all-reduce] -> gradient + losses
+        def band_partials(rgba_band, target_rgb, target_mask, rows, band_targets=None, out=None):
+            part = torch.zeros(N, 64, 5, dtype=torch.float64)
+            s = band_sums(rgba_band, target_rgb, target_mask, rows)[:N]
+            part[:, 0] = 0.25 * s          # spread over a few blocks: the consumer has to add them up
+            part[:, 17] = 0.75 * s
+            return part
+
+        def band_backward_partials(rgba_band, target_rgb, target_mask, rows, l_rgb, l_sil, partials, grad_total=None,
+                                   band_targets=None, want_sums=False):
+            sums = torch.zeros(N + 1, 5, dtype=torch.float64)
+            sums[:N] = partials.sum(1)
+            losses = from_sums(sums, (H, W), l_rgb, l_sil)
+            return band_backward(rgba_band, target_rgb, target_mask, rows, l_rgb, l_sil, sums, grad_total), losses
+
+        ops.image_loss_band_partials, ops.image_loss_band_backward_partials = band_partials, band_backward_partials
         part = RowPartition(H, world, rank, cyclic=cyclic)
         ri = part.row_indices()
         band = torch.from_numpy(rgba[:, ri].copy()).requires_grad_(True)

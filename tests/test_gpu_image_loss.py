@@ -117,6 +117,22 @@ def test_row_bands_reproduce_the_full_image_loss(bounds):
         gb = ops.image_loss_band_backward(rgba[:, r0:r1].contiguous(), img, mask, (r0, r1), 0.7, 2.0, reduced, grad_total=up)
         assert tuple(gb.shape) == (N, r1 - r0, W, 4)
         assert torch.allclose(gb, grad[:, r0:r1], rtol=1e-6, atol=1e-12)
+    # the two-launch form (what band_image_loss and bench.py's multi-GPU step use): the block partials are what the ranks
+    # all-reduce; gradient, losses and sums come out of ONE launch; precomputed band targets give the same bits
+    parts_ = [ops.image_loss_band_partials(rgba[:, bounds[g]:bounds[g + 1]].contiguous(), img, mask, (bounds[g], bounds[g + 1]))
+              for g in range(G)]
+    red = torch.stack(parts_).sum(0)                                                      # the all-reduce
+    for g in range(G):
+        r0, r1 = bounds[g], bounds[g + 1]
+        band = rgba[:, r0:r1].contiguous()
+        gb, lb, sb = ops.image_loss_band_backward_partials(band, img, mask, (r0, r1), 0.7, 2.0, red, grad_total=up, want_sums=True)
+        assert torch.allclose(gb, grad[:, r0:r1], rtol=1e-6, atol=1e-12) and torch.allclose(lb, losses, rtol=1e-6)
+        # (the per-thread sums are fp32 over another partition of the pixels: counts exact, the real-valued terms to fp32)
+        assert torch.allclose(sb, sums, rtol=1e-6) and torch.equal(sb[:, 0], sums[:, 0])
+        if r1 > r0:
+            bt = ops.band_targets(img, mask, (r0, r1))
+            gb2, lb2 = ops.image_loss_band_backward_partials(band, img, mask, (r0, r1), 0.7, 2.0, red, grad_total=up, band_targets=bt)
+            assert torch.equal(gb2, gb) and torch.equal(lb2, lb)
     # the autograd wrapper on a single rank (no process group): the band IS the image
     part = RowPartition(H, 1, 0)
     leaf = rgba.clone().requires_grad_(True)
@@ -147,7 +163,12 @@ def test_tile_row_cyclic_bands_reproduce_the_full_image_loss(G, H):
     reduced = torch.stack([ops.image_loss_band_sums(b, img, mask, p.rows) for b, p in zip(bands, parts)]).sum(0)
     assert torch.allclose(reduced[:N], sums[:N], rtol=1e-6, atol=0) and torch.equal(reduced[:N, 0], sums[:N, 0])
     assert torch.allclose(ops.image_loss_from_sums(reduced, (H, W), 0.7, 2.0), losses, rtol=1e-6)
+    red = torch.stack([ops.image_loss_band_partials(b, img, mask, p.rows) for b, p in zip(bands, parts)]).sum(0)
     for b, p in zip(bands, parts):
         gb = ops.image_loss_band_backward(b, img, mask, p.rows, 0.7, 2.0, reduced, grad_total=up)
         assert tuple(gb.shape) == (N, p.n_rows, W, 4)
         assert torch.allclose(gb, p.slice(grad), rtol=1e-6, atol=1e-12)
+        # two-launch form, with the band's targets gathered once (tile-row-cyclic: contiguous copies of the owned rows)
+        bt = tuple(x.contiguous() for x in ops.band_targets(img, mask, p.rows))
+        gb2, lb2 = ops.image_loss_band_backward_partials(b, img, mask, p.rows, 0.7, 2.0, red, grad_total=up, band_targets=bt)
+        assert torch.allclose(gb2, p.slice(grad), rtol=1e-6, atol=1e-12) and torch.allclose(lb2, losses, rtol=1e-6)

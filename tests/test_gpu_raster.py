@@ -741,8 +741,9 @@ import bench
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dev = torch.device("cuda:0"); torch.cuda.set_device(dev)
 dist.init_process_group("gloo")
-ref = bench.Workload(dev, world, bench.RowPartition(bench.S, 1, 0))
-img1, gw1, gc1 = ref.step()
+# the reference: the same causal step (render -> image loss -> backward) on one rank, no collective
+ref = bench.Workload(dev, world, bench.RowPartition(bench.S, 1, 0), multi="local")
+img1, gw1, gc1 = [t.clone() for t in ref.step()]
 rel = lambda a, b: float((a - b).norm() / b.norm())
 # gradient exchange: "owner" (round 5: whole position gradients on the owner of a point's centre row, clip + projection in
 # front of ONE all-reduce of the world-space sums) and "bucket" (partial sums of every pair reduced first)
@@ -806,11 +807,13 @@ def test_bench_launches_its_own_ranks():
     assert rec["n_gpus"] == 2 and d["world_size"] == 2 and d["backend"] == "gloo"
     # diagnosable multi-GPU line: the communicator set-up that was used and where the step's time went, per rank
     assert d["overlap"] is True and d["degraded"] is None and d["visible_devices"] >= 1 and "cyclic" in d["partition"]
-    assert d["exchange"]["form"] == "overlap" and d["collectives_per_step"] == 3
+    # visibility, loss sums, alpha-gradient plane (owner form, two ranks), gradient sums, image
+    assert d["exchange"]["form"] == "overlap" and d["collectives_per_step"] == 5 and d["causal"] is True
     assert rec["config"]["launch"] == "graph_segments" and d["segment_capture"] == "ok"
     t = d["timing_us"]
-    for k in ("forward_compute", "backward_compute", "projection_compute", "compute_us", "wait_visibility_allgather",
-              "wait_gradient_allreduce", "wait_image_allgather"):
+    for k in ("forward_compute", "loss_sums_compute", "loss_gradient_compute", "backward_compute", "compute_us",
+              "wait_visibility_allreduce", "wait_loss_allreduce", "wait_alpha_allgather", "wait_gradient_allreduce",
+              "wait_image_allgather"):
         assert t[k]["min"] <= t[k]["mean"] <= t[k]["max"] and t[k]["max"] > 0, (k, t[k])
     assert rec["config"]["cameras"] == 2 and rec["value"] > 0
     # a launcher whose world size disagrees with --gpus is an error, not a silent mismatch

@@ -37,7 +37,8 @@ dev = torch.device("cuda:0"); torch.cuda.set_device(dev)
 os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29733", RANK="0", WORLD_SIZE="1")
 dist.init_process_group("nccl", device_id=dev)
 part = bench.RowPartition(bench.S, 1, 0)
-img1, gw1, gc1 = bench.Workload(dev, 1, part).step()
+# the reference: the same causal step (render -> image loss of the rendered rows -> backward) without any collective
+img1, gw1, gc1 = [t.clone() for t in bench.Workload(dev, 1, part, multi="local").step()]
 rel = lambda a, b: float((a - b).norm() / b.norm())
 wl = bench.Workload(dev, 1, part, multi=True)
 out = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "overlap": bool(wl.fx.overlap),
@@ -66,7 +67,7 @@ for _ in range(3):
     img, gw, gc = wl.step_whole()
 torch.cuda.synchronize()
 out["fold_graph_step"] = {"image_equal": bool(torch.equal(img, img1)), "rel_world": rel(gw, gw1), "rel_colour": rel(gc, gc1)}
-out["fold_collectives"] = 2 if wl.fx.fold else 3
+out["fold_collectives"] = sum(1 for k, _, _ in wl.stages() if k == "x")
 dist.barrier()
 dist.destroy_process_group()
 print("RESULT " + json.dumps(out))
@@ -76,13 +77,14 @@ print("RESULT " + json.dumps(out))
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
     assert out["backend"] == "nccl" and out["world_size"] == 1
     assert out["overlap"] is True and out["degraded"] is None and out["second_communicator"] is True, out
-    assert out["fold_collectives"] == 2
+    # (world of one: visibility / image [folded into one], loss sums, gradient -- no alpha-plane exchange without a band)
+    assert out["fold_collectives"] == 4
     # (graph_step: launches AND the collectives in ONE hipGraph; fold_*: the two-collective form of the exchange)
     for leg in ("eager", "graph_segments", "graph_step", "fold_eager", "fold_graph_step"):
         assert out[leg]["image_equal"], (leg, out)
         assert out[leg]["rel_world"] < 1e-5 and out[leg]["rel_colour"] < 1e-5, (leg, out)
-    for k in ("wait_visibility_allgather", "wait_gradient_allreduce", "wait_image_allgather", "forward_compute",
-              "backward_compute"):
+    for k in ("wait_visibility_allreduce", "wait_loss_allreduce", "wait_gradient_allreduce", "wait_image_allgather",
+              "forward_compute", "loss_sums_compute", "loss_gradient_compute", "backward_compute"):
         assert out["timing_us"][k] > 0, (k, out["timing_us"])
 
 
@@ -106,14 +108,16 @@ def test_bench_forced_dist_runs_the_rccl_path_on_one_gpu(exchange):
     assert d["degraded"] is None and d["segment_capture"] == "ok", d
     assert d["whole_step_graph"] == "ok", d   # (RCCL 2.26 lets its collectives be captured: the timed step is ONE graph)
     assert rec["config"]["launch"].startswith("graph_step") and rec["n_gpus"] == 1 and rec["value"] > 0
+    assert d["causal"] is True and d["engine"].startswith("dss_amd.sharded.RowShardedRender"), d
     if exchange == "overlap":
-        assert d["overlap"] is True and d["collectives_per_step"] == 3 and d["exchange"]["form"] == "overlap", d
-        for k in ("wait_visibility_allgather", "wait_gradient_allreduce", "wait_image_allgather", "compute_us"):
+        assert d["overlap"] is True and d["collectives_per_step"] == 4 and d["exchange"]["form"] == "overlap", d
+        for k in ("wait_visibility_allreduce", "wait_loss_allreduce", "wait_gradient_allreduce", "wait_image_allgather",
+                  "compute_us"):
             assert d["timing_us"][k]["max"] > 0, (k, d["timing_us"])
     else:
         ex = d["exchange"]
         assert ex["form"] in ("overlap", "fold") and set(ex["ms_per_step"]) == {"overlap", "fold"}, d
-        assert d["collectives_per_step"] == (2 if ex["form"] == "fold" else 3), d
+        assert d["collectives_per_step"] == 4, d
         assert ex["ms_per_step"][ex["form"]] == min(ex["ms_per_step"].values()), d
     try:   # keep the line for profiles/ (scratch directory of the GPU box; harmless elsewhere)
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)

@@ -1,0 +1,167 @@
+"""GPU: the row-partitioned (multi-GPU) render behind the drop-in classes -- `SurfaceSplattingRenderer(row_partition=...)`,
+`dss_amd.sharded.RowShardedRender` -- and the two entry points it adds to the C ABI.
+
+The reference has no distributed layer; what is pinned here is that the sharded render IS the single-GPU
+render: the gathered image bit for bit, the gradients a training loop sees (``points.grad`` / ``colors.grad`` after a loss
+computed FROM the rendered image) to fp32 reduction order.  One GPU on the test box, so two ranks share it over gloo; RCCL
+itself is exercised at world size 1 by tests/test_gpu_rccl_world1.py."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def test_gather_rows_puts_gathered_rows_in_image_order():
+    from dss_amd import ops
+    from dss_amd.distributed import RowPartition
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(0)
+    for S, G, N, W, cyclic in ((64, 4, 3, 64 * 4, True), (40, 4, 2, 40, False), (70, 4, 1, 70 * 3, True), (48, 2, 2, 48 * 4, False)):
+        part = RowPartition(S, G, 0, cyclic=cyclic)   # (S = 70 at 4 ranks: unequal tile rows, padded positions)
+        pos = part.gather_index()
+        src = torch.randn((G * part.band, N, W), generator=g).to(dev)
+        row_pos = torch.tensor(pos, dtype=torch.int32, device=dev)
+        got = ops.gather_rows(src, row_pos, N, S, W)
+        want = src.index_select(0, row_pos.long()).permute(1, 0, 2).contiguous()
+        assert torch.equal(got, want), (S, G, N, W, cyclic)
+
+
+@pytest.mark.parametrize("cyclic", [False, True])
+def test_owner_mode_from_the_dense_alpha_plane_equals_owner_mode_from_the_full_gradient(cyclic):
+    """dss_render_backward_owned_plane (the alpha channel of all rows as a dense (N,S,S) plane: what the ranks all-gather
+    behind a band-local loss) against dss_render_backward_owned (the full RGBA gradient): same bits."""
+    import scenes
+    from dss_amd import ops
+    from dss_amd.distributed import RowPartition
+    dev = torch.device("cuda:0")
+    S, K, N = 128, 5, 2
+    pts, nrm = scenes.load_cloud("bunny")
+    pts = scenes.normalize_unit_sphere(pts)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    world, normals = t(pts), t(nrm)
+    Pc = world.shape[0]
+    col = torch.rand((N * Pc, 3), generator=torch.Generator().manual_seed(2)).to(dev)
+    from dss_amd.cameras import FoVPerspectiveCameras, look_at_view_transform
+    R, T = look_at_view_transform(2.0, 30.0, [45.0, 130.0])
+    cam = FoVPerspectiveCameras(znear=0.1, zfar=100.0, fov=60.0, R=R, T=T)
+    M = cam.get_full_projection_transform().get_matrix().to(dev).contiguous()
+    V = cam.get_world_to_view_transform().get_matrix().to(dev).contiguous()
+    zn, zf = torch.full((N,), 0.1, device=dev), torch.full((N,), 100.0, device=dev)
+    first = torch.arange(N, device=dev, dtype=torch.int64) * Pc
+    num = torch.full((N,), Pc, device=dev, dtype=torch.int64)
+    h = torch.full((N,), 4e-4, device=dev)
+    gfull = torch.randn((N, S, S, 4), generator=torch.Generator().manual_seed(1)).to(dev)
+    whole = ops.render_forward(world, normals, h, M, V, zn, zf, first, num, col, S, K, 1.0, 0.05, 1.0, False, True)
+    vis_all = whole["visible"]
+    for rank in range(2):
+        part = RowPartition(S, 2, rank, cyclic=cyclic)
+        f = ops.render_forward(world, normals, h, M, V, zn, zf, first, num, col, S, K, 1.0, 0.05, 1.0, False, True, rows=part.rows)
+        gband = part.slice(gfull).contiguous()
+        a = ops.render_backward(gband, f["idx"], f["qvalue"], f["wsum"], f["scaler"], f["pts_screen"], f["radii"], vis_all, first,
+                                num, 5.0, -1.0, image_size=S, rows=part.rows, grad_out_full=gfull)
+        b = ops.render_backward(gband, f["idx"], f["qvalue"], f["wsum"], f["scaler"], f["pts_screen"], f["radii"], vis_all, first,
+                                num, 5.0, -1.0, image_size=S, rows=part.rows, grad_occ_full=gfull[..., 3].contiguous())
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), (cyclic, rank)
+        assert float(a[1].abs().max()) > 0
+
+
+_TWO_RANK = '''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import numpy as np
+import scenes
+from dss_amd.cameras import FoVPerspectiveCameras, look_at_view_transform
+from dss_amd.cloud import PointClouds3D
+from dss_amd.distributed import RowPartition, band_image_loss
+from dss_amd.losses import calc_dr_loss
+from dss_amd.rasterizer import PointsRasterizationSettings, SurfaceSplatting
+from dss_amd.renderer import NormWeightedCompositor, SurfaceSplattingRenderer
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dev = torch.device("cuda:0"); torch.cuda.set_device(dev)
+dist.init_process_group("gloo")
+S, N = 256, 2
+pts, nrm = scenes.load_cloud("bunny")
+pts = scenes.normalize_unit_sphere(pts)
+t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+R, T = look_at_view_transform(2.0, 30.0, [45.0, 130.0])
+cams = FoVPerspectiveCameras(znear=0.1, zfar=100.0, fov=60.0, R=R, T=T, device=dev)
+st = PointsRasterizationSettings(backface_culling=False, cutoff_threshold=1.0, depth_merging_threshold=0.05, Vrk_invariant=True,
+                                 Vrk_isotropic=False, radii_backward_scaler=5.0, image_size=S, points_per_pixel=5,
+                                 bin_size=None, clip_pts_grad=0.05, antialiasing_sigma=1.0)
+normals = t(nrm)
+col0 = torch.rand((pts.shape[0], 3), generator=torch.Generator().manual_seed(3)).to(dev)
+h = torch.full((1,), 4e-4, device=dev)
+
+
+def run(**kw):
+    """one training iteration through the classes: render -> loss FROM the rendered image -> backward"""
+    X = torch.nn.Parameter(t(pts).clone())
+    C = torch.nn.Parameter(col0.clone())
+    renderer = SurfaceSplattingRenderer(SurfaceSplatting(cameras=cams, raster_settings=st), NormWeightedCompositor(), **kw)
+    img = renderer(PointClouds3D([X], [normals], [C]), Vrk_h=h)
+    return renderer, X, C, img
+
+
+# single rank: the plain renderer; targets = its own render shifted (identical on both ranks)
+_, X1, C1, img1 = run()
+target = torch.roll(img1.detach(), shifts=(4, 7), dims=(1, 2))
+target_rgb, target_mask = target[..., :3].contiguous(), (target[..., 3] > 0).float().contiguous()
+loss1 = calc_dr_loss(img1, target_rgb, target_mask)["loss"]
+loss1.backward()
+rel = lambda a, b: float((a - b).norm() / b.norm())
+assert float(X1.grad.abs().max()) > 0 and float(C1.grad.abs().max()) > 0
+report = []
+for cyclic in (False, True):
+    part = RowPartition(S, world, rank, cyclic=cyclic)
+    for grad in ("owner", "bucket"):
+        # replicated loss: the FULL image on every rank, the loss evaluated on it like an unmodified training loop
+        _, X, C, img = run(row_partition=part, gradient_exchange=grad)
+        assert img.shape == img1.shape and torch.equal(img, img1.detach()), ("full image differs", cyclic, grad)
+        loss = calc_dr_loss(img, target_rgb, target_mask)["loss"]
+        assert abs(float(loss) - float(loss1)) <= 1e-6 * abs(float(loss1))
+        loss.backward()
+        r = (rel(X.grad, X1.grad), rel(C.grad, C1.grad))
+        assert r[0] < 1e-5 and r[1] < 1e-5, ("full", cyclic, grad, r)
+        report.append(("full", cyclic, grad) + r)
+        # band loss: the rank's own rows, the reference's image loss with its sums all-reduced
+        ren, X, C, band = run(row_partition=part, gradient_exchange=grad, row_output="band")
+        assert tuple(band.shape) == (N, part.n_rows, S, 4) and torch.equal(band, part.slice(img1.detach()))
+        loss = band_image_loss(band, target_rgb, target_mask, part)["loss"]
+        assert abs(float(loss) - float(loss1)) <= 1e-6 * abs(float(loss1)), (float(loss), float(loss1))
+        loss.backward()
+        r = (rel(X.grad, X1.grad), rel(C.grad, C1.grad))
+        assert r[0] < 1e-5 and r[1] < 1e-5, ("band", cyclic, grad, r)
+        report.append(("band", cyclic, grad) + r)
+        # the image exchange of the band render ran behind the loss and the backward: the full picture is there for whoever looks
+        eng = next(iter(ren.rasterizer._sharded.values()))
+        assert torch.equal(eng.full_image(), img1.detach())
+# "auto": this rank's share of the initialised process group; two renders in flight (the second must not disturb the first)
+_, X, C, img = run(row_partition="auto")
+_, X2, C2, img2 = run(row_partition="auto")
+calc_dr_loss(img, target_rgb, target_mask)["loss"].backward()
+assert rel(X.grad, X1.grad) < 1e-5 and rel(C.grad, C1.grad) < 1e-5
+open(os.path.join(%(tmp)r, "ok%%d" %% rank), "w").write(repr(report))
+dist.destroy_process_group()
+'''
+
+
+def test_row_partitioned_renderer_classes_match_the_single_gpu_renderer(tmp_path):
+    """Two ranks (gloo, one GPU): `SurfaceSplattingRenderer(row_partition=...)` -- full-image output with a replicated loss and
+    band output with `band_image_loss`, owner and bucket gradient exchange, contiguous and tile-row-cyclic bands -- against the
+    plain renderer: image bit for bit, `points.grad` / `colors.grad` <= 1e-5."""
+    script = os.path.join(str(tmp_path), "two_rank_classes.py")
+    open(script, "w").write(_TWO_RANK % {"root": ROOT, "tmp": str(tmp_path)})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29721", script],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-12000:]
+    assert os.path.exists(os.path.join(str(tmp_path), "ok0")) and os.path.exists(os.path.join(str(tmp_path), "ok1"))
