@@ -194,8 +194,8 @@ class Workload:
         self._st["vis"] = e.start_exchange()   # (a static buffer either way: the flags in place, or the folded form's union)
 
     def _st_loss_sums(self):
-        band = self.engine.band_image
-        self._st["band"] = band = band if band.is_contiguous() else band.contiguous()
+        # (the band as the forward wrote it: the strided (N, rows, S, 4) view of the exchange's send buffer, no copy)
+        self._st["band"] = band = self.engine.band_image
         self._st["sums"] = ops.image_loss_band_partials(band, self.target_rgb, self.target_mask, self.part.rows,
                                                         band_targets=self.band_targets)
 
@@ -205,9 +205,12 @@ class Workload:
 
     def _st_loss_grad(self):
         st = self._st
+        # owner form on a band: the loss kernel also writes the alpha channel of its gradient into the send buffer of the
+        # alpha-plane exchange
         st["g_band"], st["losses"] = ops.image_loss_band_backward_partials(
-            st["band"], self.target_rgb, self.target_mask, self.part.rows, 1.0, 1.0, st["sums"], band_targets=self.band_targets)
-        self.engine.bwd_begin(st["g_band"])
+            st["band"], self.target_rgb, self.target_mask, self.part.rows, 1.0, 1.0, st["sums"], band_targets=self.band_targets,
+            alpha_out=self.engine.alpha_send_view())
+        self.engine.bwd_begin(st["g_band"], alpha_packed=True)
 
     def _st_backward(self):
         self.engine.bwd_compute(RADII_S, CLIP, self.world, self.M, self.V, self.first, self.num, f=self._st["f"],
@@ -676,11 +679,13 @@ def main():
     multi = world > 1 or force_dist
     if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        own_port = False
         if "MASTER_PORT" not in os.environ:   # (no launcher: forced world of one)
             import socket
             with socket.socket() as sk:
                 sk.bind(("127.0.0.1", 0))
                 os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+            own_port = True
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
@@ -689,10 +694,23 @@ def main():
                   % (world, backend, torch.cuda.device_count(), torch.__version__,
                      os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"), " (BENCH_FORCE_DIST)" if force_dist else ""),
                   file=sys.stderr, flush=True)
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
+        for attempt in range(5):
+            try:
+                if backend == "nccl":
+                    dist.init_process_group("nccl", device_id=dev)
+                else:
+                    dist.init_process_group(backend)
+                break
+            except Exception as e:  # noqa: BLE001
+                # a forced world of one picks its own rendezvous port (bind to 0, close, listen): another process can take the
+                # port in between (EADDRINUSE, seen once between two back-to-back runs) -- pick another one; a launcher's port
+                # is the launcher's business
+                if not own_port or attempt == 4 or "EADDRINUSE" not in str(e) and "address already in use" not in str(e):
+                    raise
+                import socket
+                with socket.socket() as sk:
+                    sk.bind(("127.0.0.1", 0))
+                    os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
 
     def barrier():
         if multi:

@@ -26,13 +26,14 @@ __device__ __forceinline__ float sign_of(float v) { return (float)((v > 0.f) - (
 #define IMG_LOSS_REDUCE_THREADS 1024
 __global__ __launch_bounds__(IMG_LOSS_REDUCE_THREADS) void image_loss_reduce_kernel(
     const float4 *__restrict__ rgba, const TargetView img, const float *__restrict__ mask, int64_t mask_sn, int H, int W,
-    double *__restrict__ part /* (N, blocks, 5) */)
+    double *__restrict__ part /* (N, blocks, 5) */, int64_t rgba_sn4 = 0, int64_t rgba_sh4 = 0 /* float4 strides; 0: dense */)
 {
     constexpr int T = IMG_LOSS_REDUCE_THREADS, WAVES = T / 64;
     __shared__ float wave_part[WAVES][IMG_LOSS_TERMS];
     const int n = blockIdx.y, b = blockIdx.x, nb = gridDim.x;
     const unsigned HW = (unsigned)H * (unsigned)W;   // (pixels of ONE image: below 2^31; 32-bit divides for row / column)
-    const int64_t base = (int64_t)n * HW;
+    const bool dense = rgba_sh4 == 0;
+    const int64_t base = dense ? (int64_t)n * HW : (int64_t)n * rgba_sn4;
     float cnt = 0.f, srgb = 0.f, smask = 0.f, inter = 0.f, uni = 0.f;  // <= a few hundred terms per thread: exact counts
     // 16 wavefronts per block (at most 64 blocks per image: a quarter of the CUs, so each of them gets a full CU's worth of
     // loads in flight), four pixels per trip with all their loads issued before the first is used; the terms are added in
@@ -47,9 +48,9 @@ __global__ __launch_bounds__(IMG_LOSS_REDUCE_THREADS) void image_loss_reduce_ker
             const unsigned i = i0 + (unsigned)u * stride;
             ok[u] = i < HW && i >= i0;
             const unsigned ic = ok[u] ? i : i0;
-            px[u] = rgba[base + ic];
-            t[u] = mask[(int64_t)n * mask_sn + ic];  // mask_sn = H*W, or the full image's stride for a row band
             const unsigned y = ic / (unsigned)W, x = ic - y * (unsigned)W;
+            px[u] = rgba[dense ? base + ic : base + (int64_t)y * rgba_sh4 + x];
+            t[u] = mask[(int64_t)n * mask_sn + ic];  // mask_sn = H*W, or the full image's stride for a row band
             const float *tp = img.p + n * img.sn + (int64_t)y * img.sh + (int64_t)x * img.sw;
             c0[u] = tp[0];
             c1[u] = tp[img.sc];
@@ -185,7 +186,9 @@ __global__ __launch_bounds__(256) void image_loss_band_grad_kernel(const float4 
                                                                    float lambda_sil, const double *__restrict__ part,
                                                                    const float *__restrict__ grad_total,
                                                                    float4 *__restrict__ grad_rgba, float *__restrict__ losses,
-                                                                   double *__restrict__ sums_out)
+                                                                   double *__restrict__ sums_out, int64_t rgba_sn4,
+                                                                   int64_t rgba_sh4, float *__restrict__ alpha_out,
+                                                                   int64_t alpha_sn, int64_t alpha_sh)
 {
     __shared__ double s_sum[64][IMG_LOSS_TERMS];   // per image (N <= 64)
     // thread (n, k) adds the 64 block partials of term k of image n in block order
@@ -236,7 +239,7 @@ __global__ __launch_bounds__(256) void image_loss_band_grad_kernel(const float4 
     const double I = s_sum[n][3], U = s_sum[n][4];
     const float w_rgb = cnt > 0 ? (float)((double)lambda_rgb / cnt) : 0.f;
     const float w_l1 = (float)((double)lambda_sil / ((double)N * pix_per_image));
-    const float4 px = rgba[q];
+    const float4 px = rgba[rgba_sh4 == 0 ? (int64_t)q : (int64_t)n * rgba_sn4 + (int64_t)y * rgba_sh4 + x];
     const float t = mask[(int64_t)n * mask_sn + i];
     const float *tp = img.p + (int64_t)n * img.sn + (int64_t)y * img.sh + (int64_t)x * img.sw;
     const bool inside = t != 0.f && px.w != 0.f;
@@ -249,6 +252,9 @@ __global__ __launch_bounds__(256) void image_loss_band_grad_kernel(const float4 
     const double diou = fabs(U) > 1e-17 ? -((double)t * Ue - I * (1.0 - (double)t)) / (Ue * Ue) : -(double)t / Ue;
     g.w = (w_l1 * sign_of(px.w - t) + (float)((double)lambda_sil * 0.01 * diou / N)) * up;
     grad_rgba[q] = g;
+    // the occupancy gradient once more, where the owner form's exchange sends it from ((row, camera, col) send buffer of
+    // dss_amd.distributed.AlphaPlaneExchange): saves the strided copy that would extract it
+    if (alpha_out) alpha_out[(int64_t)n * alpha_sn + (int64_t)y * alpha_sh + x] = g.w;
 }
 
 static int image_blocks(int H, int W)
@@ -385,8 +391,12 @@ extern "C" size_t dss_image_loss_band_partials_count(int N) { return (size_t)(N 
 extern "C" int dss_image_loss_band_partials(const float *rgba_band, const float *target_rgb, int64_t t_stride_n,
                                             int64_t t_stride_h, int64_t t_stride_w, int64_t t_stride_c,
                                             const float *target_mask, int64_t mask_stride_n, int N, int rows, int W,
-                                            double *partials, void *stream)
+                                            int64_t rgba_stride_n, int64_t rgba_stride_h, double *partials, void *stream)
 {
+    if ((rgba_stride_h != 0 && (rgba_stride_h % 4 || rgba_stride_n % 4 || rgba_stride_h < (int64_t)W * 4))) {
+        set_error("dss_image_loss_band_partials: rgba strides must be multiples of 4 floats, rows of W pixels contiguous");
+        return DSS_ERR_INVALID_ARGUMENT;
+    }
     if (N <= 0 || N > 64 || rows < 0 || W <= 0 || (int64_t)N * rows * W >= (1ll << 32) || !partials || (rows > 0 && (!rgba_band || !target_rgb || !target_mask)) ||
         (reinterpret_cast<uintptr_t>(rgba_band) & 15) != 0) {
         set_error("dss_image_loss_band_partials: bad arguments (1 <= N <= 64, 16-byte aligned band)");
@@ -395,7 +405,8 @@ extern "C" int dss_image_loss_band_partials(const float *rgba_band, const float 
     const TargetView tv = {target_rgb, t_stride_n, t_stride_h, t_stride_w, t_stride_c};
     // (an empty band -- a rank without rows -- contributes zeros: the loop of the kernel does not run)
     hipLaunchKernelGGL(image_loss_reduce_kernel, dim3(IMG_LOSS_BAND_BLOCKS, N), dim3(IMG_LOSS_REDUCE_THREADS), 0, as_stream(stream),
-                       reinterpret_cast<const float4 *>(rgba_band), tv, target_mask, mask_stride_n, rows, W, partials);
+                       reinterpret_cast<const float4 *>(rgba_band), tv, target_mask, mask_stride_n, rows, W, partials,
+                       rgba_stride_n / 4, rgba_stride_h / 4);
     return check_launch("dss_image_loss_band_partials");
 }
 
@@ -404,8 +415,13 @@ extern "C" int dss_image_loss_band_backward_partials(const float *rgba_band, con
                                                      const float *target_mask, int64_t mask_stride_n, int N, int rows, int W,
                                                      int H, float lambda_rgb, float lambda_silhouette, const double *partials,
                                                      const float *grad_total, float *grad_band, float *losses, double *sums,
-                                                     void *stream)
+                                                     int64_t rgba_stride_n, int64_t rgba_stride_h, float *alpha_out,
+                                                     int64_t alpha_stride_n, int64_t alpha_stride_h, void *stream)
 {
+    if ((rgba_stride_h != 0 && (rgba_stride_h % 4 || rgba_stride_n % 4 || rgba_stride_h < (int64_t)W * 4))) {
+        set_error("dss_image_loss_band_backward_partials: rgba strides must be multiples of 4 floats, rows of W pixels contiguous");
+        return DSS_ERR_INVALID_ARGUMENT;
+    }
     if (N <= 0 || N > 64 || rows < 0 || W <= 0 || H < rows || (int64_t)N * rows * W >= (1ll << 32) || !partials || (rows > 0 && (!rgba_band || !target_rgb || !target_mask || !grad_band)) ||
         ((reinterpret_cast<uintptr_t>(grad_band) | reinterpret_cast<uintptr_t>(rgba_band)) & 15) != 0) {
         set_error("dss_image_loss_band_backward_partials: bad arguments (1 <= N <= 64, H >= rows, 16-byte aligned band tensors)");
@@ -417,6 +433,7 @@ extern "C" int dss_image_loss_band_backward_partials(const float *rgba_band, con
     hipLaunchKernelGGL(image_loss_band_grad_kernel, dim3(blocks > 0 ? blocks : 1u), dim3(256), 0, as_stream(stream),
                        reinterpret_cast<const float4 *>(rgba_band), tv, target_mask, mask_stride_n, N, rows, W,
                        (double)H * (double)W, lambda_rgb, lambda_silhouette, partials, grad_total,
-                       reinterpret_cast<float4 *>(grad_band), losses, sums);
+                       reinterpret_cast<float4 *>(grad_band), losses, sums, rgba_stride_n / 4, rgba_stride_h / 4, alpha_out,
+                       alpha_stride_n, alpha_stride_h);
     return check_launch("dss_image_loss_band_backward_partials");
 }

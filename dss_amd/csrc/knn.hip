@@ -798,6 +798,58 @@ __global__ __launch_bounds__(1024) void cloud_mean_kernel(const float *__restric
     }
 }
 
+// The reference's Vrk_invariant statistic under culling (rasterizer.py:236-240, 183-217, 320-326): the cloud is extended
+// to the N cameras, every camera DROPS the points outside its depth range, and h_n = clamp(mean over the PADDED cloud n of
+// 0.5 max kNN-7 d^2) -- `h_k.mean(dim=1)` runs over the padded length P_max = the largest kept count of the batch, the padding
+// contributing zeros.  Here the points are masked, not dropped: phase 1 sums values * scale over the points camera n keeps
+// (the depth test of setup_point_compute, same expression) and counts them; phase 2 divides by the largest count.
+// (values = K-th neighbour distances within the WHOLE cloud: a kept point whose 7 nearest include a dropped point sees a
+// slightly smaller distance than the reference's search among the kept points -- second order, documented.)
+__global__ __launch_bounds__(1024) void renderable_sum_kernel(const float *__restrict__ vals, const float *__restrict__ world,
+                                                              const float *__restrict__ V, const float *__restrict__ znear,
+                                                              const float *__restrict__ zfar, const int64_t *__restrict__ first_idx,
+                                                              const int64_t *__restrict__ num_pts, int shared, float scale,
+                                                              double *__restrict__ sums /* (N,2): sum, count */)
+{
+    __shared__ double part[16], partc[16];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const int64_t f0 = shared ? 0 : first_idx[n], cnt = num_pts[n];
+    const float *v = V + 16 * n;
+    const float v2 = v[2], v6 = v[6], v10 = v[10], v14 = v[14], zn = znear[n], zf = zfar[n];
+    double a = 0.0;
+    float c = 0.f;
+    for (int64_t i = tid; i < cnt; i += 1024) {
+        const int64_t wi = f0 + i;
+        const float zview = world[3 * wi] * v2 + world[3 * wi + 1] * v6 + world[3 * wi + 2] * v10 + 1.0f * v14;
+        const bool ok = (zview >= zn) && (zview <= zf);
+        a += ok ? (double)(vals[wi] * scale) : 0.0;
+        c += ok ? 1.f : 0.f;
+    }
+    double cc = (double)c;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); cc += __shfl_xor(cc, o); }
+    if ((tid & 63) == 0) { part[tid >> 6] = a; partc[tid >> 6] = cc; }
+    __syncthreads();
+    if (tid == 0) {
+        double t = 0.0, tc = 0.0;
+        for (int w = 0; w < 16; ++w) { t += part[w]; tc += partc[w]; }
+        sums[2 * n] = t;
+        sums[2 * n + 1] = tc;
+    }
+}
+__global__ __launch_bounds__(64) void renderable_mean_kernel(const double *__restrict__ sums, int N, float lo, float hi,
+                                                             float fallback, int min_points, float *__restrict__ out)
+{
+    double pmax = 0.0;
+    for (int m = 0; m < N; ++m) pmax = fmax(pmax, sums[2 * m + 1]);
+    for (int n = threadIdx.x; n < N; n += 64) {
+        const double cnt = sums[2 * n + 1];
+        // `sq_dist[num_points_per_cloud < 7] = 1e-3` fills the whole padded row of a small cloud (rasterizer.py:322)
+        const float m = (cnt >= (double)min_points && pmax > 0.0) ? (float)(sums[2 * n] / pmax) : fallback;
+        out[n] = fminf(fmaxf(m, lo), hi);
+    }
+}
+
 }  // namespace dss
 
 using namespace dss;
@@ -957,4 +1009,24 @@ extern "C" int dss_cloud_mean_clamp(const float *values, const int64_t *first_id
     hipLaunchKernelGGL(cloud_mean_kernel, dim3(N), dim3(1024), 0, as_stream(stream), values, first_idx, num_pts, scale,
                        lo, hi, fallback, min_points, out);
     return check_launch("dss_cloud_mean_clamp");
+}
+
+// dss_cloud_mean_clamp under the reference's depth culling, for clouds whose culled points are masked instead of dropped
+// (see renderable_sum_kernel).  values (Pw,) per WORLD point; shared_cloud = 1: one cloud of num_pts[0] points seen by N
+// cameras; workspace: 16 N bytes.
+extern "C" int dss_renderable_mean_clamp(const float *values, const float *world, const float *V, const float *znear,
+                                         const float *zfar, const int64_t *first_idx, const int64_t *num_pts, int N,
+                                         int shared_cloud, float scale, float lo, float hi, float fallback, int min_points,
+                                         float *out, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (N <= 0 || !values || !world || !V || !znear || !zfar || !first_idx || !num_pts || !out || !workspace ||
+        workspace_bytes < (size_t)N * 16) {
+        set_error("dss_renderable_mean_clamp: bad arguments (workspace of 16 N bytes)");
+        return DSS_ERR_INVALID_ARGUMENT;
+    }
+    double *sums = reinterpret_cast<double *>(workspace);
+    hipLaunchKernelGGL(renderable_sum_kernel, dim3(N), dim3(1024), 0, as_stream(stream), values, world, V, znear, zfar,
+                       first_idx, num_pts, shared_cloud, scale, sums);
+    hipLaunchKernelGGL(renderable_mean_kernel, dim3(1), dim3(64), 0, as_stream(stream), sums, N, lo, hi, fallback, min_points, out);
+    return check_launch("dss_renderable_mean_clamp");
 }

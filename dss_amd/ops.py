@@ -989,6 +989,34 @@ def cloud_mean_clamp(values, cloud_to_packed_first_idx, num_points_per_cloud, sc
     return out
 
 
+def renderable_mean_clamp(values, world, V, znear, zfar, cloud_to_packed_first_idx, num_points_per_cloud, shared_cloud: bool,
+                          scale: float, lo: float, hi: float, fallback: float, min_points: int):
+    """``cloud_mean_clamp`` under the reference's depth culling for MASKED clouds (``dss_renderable_mean_clamp``): per camera
+    the mean over the points it keeps (view z in [znear, zfar]), divided by the LARGEST kept count of the batch like the
+    reference's mean over the padded clouds (rasterizer.py:183-217, 320-326) -> (N,)."""
+    lib = _lib.load()
+    values = _lib.require_gpu(values, "values", _f32)
+    dev = values.device
+    world = _lib.require_gpu(world, "world", _f32)
+    V = _lib.require_gpu(V, "V", _f32)
+    znear = _lib.require_gpu(znear, "znear", _f32)
+    zfar = _lib.require_gpu(zfar, "zfar", _f32)
+    first = _lib.require_gpu(cloud_to_packed_first_idx, "cloud_to_packed_first_idx", _i64)
+    num = _lib.require_gpu(num_points_per_cloud, "num_points_per_cloud", _i64)
+    N = V.shape[0]
+    if values.shape[0] != world.shape[0] or first.shape[0] != N or znear.numel() != N or zfar.numel() != N:
+        raise RuntimeError("renderable_mean_clamp: values / world per world point, V, znear, zfar, first_idx, num_points per camera")
+    with torch.cuda.device(dev):
+        out = torch.empty((N,), dtype=_f32, device=dev)
+        ws = _lib.workspace(dev, 16 * N)
+        rc = lib.dss_renderable_mean_clamp(_lib.ptr(values), _lib.ptr(world), _lib.ptr(V), _lib.ptr(znear), _lib.ptr(zfar),
+                                           _lib.ptr(first), _lib.ptr(num), N, int(shared_cloud), float(scale), float(lo),
+                                           float(hi), float(fallback), int(min_points), _lib.ptr(out), _lib.ptr(ws), ws.numel(),
+                                           _lib.stream_ptr(dev))
+    _lib.check(rc, "dss_renderable_mean_clamp")
+    return out
+
+
 def _phong_common(world, normals, rgb, first, num, shared_cloud, ambient, diffuse_color, specular_color, light_vec,
                   cam_center):
     world = _lib.require_gpu(world, "world", _f32)
@@ -1255,12 +1283,14 @@ def band_targets(target_rgb, target_mask, rows):
     return target_rgb[:, row0:row1], target_mask[:, row0:row1]
 
 
-def _band_args(rgba_band, target_rgb, target_mask, rows, band_targets=None):
+def _band_args(rgba_band, target_rgb, target_mask, rows, band_targets=None, keep_strides=False):
     """Row band of an image loss: the band render (N,rows,W,4) against the FULL targets (N,H,W,3) / (N,H,W); returns the
     tensors plus the targets' band and the image stride of its mask.  ``rows`` = (row0, row1) for a contiguous band (views of
     the targets, no copy) or (row0, row1, cycle) for a tile-row-cyclic one (`RowPartition(cyclic=True).rows`: the owned
-    rows of the targets are gathered once per call)."""
-    rgba_band = _lib.require_gpu(rgba_band, "rgba_band", _f32)
+    rows of the targets are gathered once per call).  ``keep_strides``: the band has been vetted by `_strided_band` and is
+    taken as it is (not made contiguous)."""
+    if not keep_strides:
+        rgba_band = _lib.require_gpu(rgba_band, "rgba_band", _f32)
     row0, row1, cyc = _band(rows, None) if rows is not None and len(rows) > 2 else (int(rows[0]), int(rows[1]), 1)
     want = band_rows(row0, row1, cyc)
     if rgba_band.dim() != 4 or rgba_band.shape[-1] != 4 or rgba_band.shape[1] != want:
@@ -1340,45 +1370,73 @@ def image_loss_band_backward(rgba_band, target_rgb, target_mask, rows, lambda_rg
     return grad
 
 
+def _strided_band(rgba_band):
+    """-> (tensor, camera stride, row stride) of an (N, rows, W, 4) float32 band whose pixels and rows of pixels are contiguous
+    (the (row, camera, col, channel) send buffer of the multi-GPU renderer through its (N, rows, W, 4) view); (t, 0, 0) for a
+    dense band; anything else is copied"""
+    if not isinstance(rgba_band, torch.Tensor) or not rgba_band.is_cuda or rgba_band.dtype != _f32:
+        raise RuntimeError("dss_amd: rgba_band must be a float32 GPU tensor (no CPU fallback)")
+    if rgba_band.dim() != 4 or rgba_band.shape[-1] != 4:
+        raise RuntimeError("dss_amd: rgba_band must be (N,rows,W,4), got %s" % (tuple(rgba_band.shape),))
+    if rgba_band.is_contiguous():
+        return rgba_band, 0, 0
+    sn, sh, sw, sc = rgba_band.stride()
+    if sc == 1 and sw == 4 and sn % 4 == 0 and sh % 4 == 0 and sh >= 4 * rgba_band.shape[2] and rgba_band.data_ptr() % 16 == 0:
+        return rgba_band, int(sn), int(sh)
+    return rgba_band.contiguous(), 0, 0
+
+
 def image_loss_band_partials(rgba_band, target_rgb, target_mask, rows, band_targets=None, out=None):
     """First launch of the two-launch band loss (``dss_image_loss_band_partials``): the block partials of the band's five
     per-image sums -> float64 (N, 64, 5).  All-reduce THEM (SUM) over the ranks, then `image_loss_band_backward_partials`.
+    ``rgba_band`` may be the strided (N, rows, W, 4) view of a (row, camera, col, channel) buffer (no copy).
     ``out``: a caller-owned buffer of that shape (a step that replays as a graph all-reduces a static one)."""
     lib = _lib.load()
-    rgba_band, band_rgb, band_mask, _keep, N, nr, W, H, mstride = _band_args(rgba_band, target_rgb, target_mask, rows, band_targets)
-    dev = rgba_band.device
+    view, rsn, rsh = _strided_band(rgba_band)
+    _c, band_rgb, band_mask, _keep, N, nr, W, H, mstride = _band_args(view, target_rgb, target_mask, rows, band_targets,
+                                                                      keep_strides=True)
+    dev = view.device
     with torch.cuda.device(dev):
         n = lib.dss_image_loss_band_partials_count(N)
         part = torch.empty((N, n // (5 * N), 5), dtype=torch.float64, device=dev) if out is None else out
         if part.numel() != n or part.dtype != torch.float64 or not part.is_contiguous():
             raise RuntimeError("dss_amd: out must be a contiguous float64 tensor of %d elements" % n)
         sn, sh, sw, sc = band_rgb.stride() if nr > 0 else (0, 0, 0, 0)
-        rc = lib.dss_image_loss_band_partials(_lib.ptr(rgba_band), _lib.ptr(band_rgb), sn, sh, sw, sc, _lib.ptr(band_mask), mstride,
-                                              N, nr, W, _lib.ptr(part), _lib.stream_ptr(dev))
+        rc = lib.dss_image_loss_band_partials(_lib.ptr(view), _lib.ptr(band_rgb), sn, sh, sw, sc, _lib.ptr(band_mask), mstride,
+                                              N, nr, W, rsn, rsh, _lib.ptr(part), _lib.stream_ptr(dev))
     _lib.check(rc, "dss_image_loss_band_partials")
     return part
 
 
 def image_loss_band_backward_partials(rgba_band, target_rgb, target_mask, rows, lambda_rgb: float, lambda_silhouette: float,
-                                      partials, grad_total=None, band_targets=None, want_sums: bool = False):
-    """Second launch: from the ALL-REDUCED partials -> (band of d total / d rgba (N,rows,W,4), losses (4,) = total, weighted
-    rgb term, weighted silhouette term, IoU term[, sums (N+1,5) float64]) -- identical bits on every rank."""
+                                      partials, grad_total=None, band_targets=None, want_sums: bool = False, alpha_out=None):
+    """Second launch: from the ALL-REDUCED partials -> (band of d total / d rgba (N,rows,W,4) dense, losses (4,) = total,
+    weighted rgb term, weighted silhouette term, IoU term[, sums (N+1,5) float64]) -- identical bits on every rank.
+    ``alpha_out`` (N, rows, W) float32, last dimension contiguous (any camera / row strides): receives the alpha channel of
+    the gradient a second time -- the send buffer of the owner form's alpha-plane exchange, no extraction copy."""
     lib = _lib.load()
-    rgba_band, band_rgb, band_mask, _keep, N, nr, W, H, mstride = _band_args(rgba_band, target_rgb, target_mask, rows, band_targets)
-    dev = rgba_band.device
+    view, rsn, rsh = _strided_band(rgba_band)
+    _c, band_rgb, band_mask, _keep, N, nr, W, H, mstride = _band_args(view, target_rgb, target_mask, rows, band_targets,
+                                                                      keep_strides=True)
+    dev = view.device
     partials = _lib.require_gpu(partials, "partials", torch.float64)
     if partials.numel() != lib.dss_image_loss_band_partials_count(N):
         raise RuntimeError("dss_amd: partials must come from image_loss_band_partials")
     if grad_total is not None:
         grad_total = _lib.require_gpu(grad_total, "grad_total", _f32).reshape(1)
+    a_p, asn, ash = None, 0, 0
+    if alpha_out is not None:
+        if tuple(alpha_out.shape) != (N, nr, W) or alpha_out.dtype != _f32 or not alpha_out.is_cuda or (nr > 0 and alpha_out.stride(2) != 1):
+            raise RuntimeError("dss_amd: alpha_out must be a float32 GPU tensor (N,%d,%d) with contiguous rows" % (nr, W))
+        a_p, asn, ash = _lib.ptr(alpha_out), int(alpha_out.stride(0)), int(alpha_out.stride(1))
     with torch.cuda.device(dev):
-        grad = torch.empty_like(rgba_band)
+        grad = torch.empty((N, nr, W, 4), dtype=_f32, device=dev)
         losses = torch.empty((4,), dtype=_f32, device=dev)
         sums = torch.empty((N + 1, 5), dtype=torch.float64, device=dev) if want_sums else None
         sn, sh, sw, sc = band_rgb.stride() if nr > 0 else (0, 0, 0, 0)
-        rc = lib.dss_image_loss_band_backward_partials(_lib.ptr(rgba_band), _lib.ptr(band_rgb), sn, sh, sw, sc, _lib.ptr(band_mask),
+        rc = lib.dss_image_loss_band_backward_partials(_lib.ptr(view), _lib.ptr(band_rgb), sn, sh, sw, sc, _lib.ptr(band_mask),
                                                        mstride, N, nr, W, H, float(lambda_rgb), float(lambda_silhouette),
                                                        _lib.ptr(partials), _lib.ptr(grad_total), _lib.ptr(grad), _lib.ptr(losses),
-                                                       _lib.ptr(sums), _lib.stream_ptr(dev))
+                                                       _lib.ptr(sums), rsn, rsh, a_p, asn, ash, _lib.stream_ptr(dev))
     _lib.check(rc, "dss_image_loss_band_backward_partials")
     return (grad, losses, sums) if want_sums else (grad, losses)

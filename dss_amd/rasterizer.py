@@ -279,7 +279,12 @@ class SurfaceSplatting(torch.nn.Module):
         return bool(getattr(rs, "backface_culling", False))
 
     # -- source-space variance scale h (rasterizer.py:293-402) ------------------------------------
-    def _variance_scale(self, point_clouds, raster_settings, refresh=True):
+    def _variance_scale(self, point_clouds, raster_settings, refresh=True, view=None):
+        """``view`` = (V (N,4,4), znear (N,), zfar (N,), shared): the cameras of this render.  The reference computes the
+        Vrk_invariant statistic AFTER `filter_renderable` has extended the cloud to the cameras and dropped the points outside
+        each camera's depth range (rasterizer.py:599, 236-240, 183-217): one h per camera, the mean taken over the padded
+        length of the batch (:325).  With it the masked representation follows that order to first order
+        (`ops.renderable_mean_clamp`); without it (callers outside a render) the mean runs over the whole clouds."""
         n_total = sum(p.shape[0] for p in point_clouds.points_list())
         if not refresh and self._Vrk_h is not None and (raster_settings.Vrk_invariant or
                                                        self._Vrk_h.shape[0] == n_total):  # rasterizer.py:359-361
@@ -292,7 +297,19 @@ class SurfaceSplatting(torch.nn.Module):
         if raster_settings.Vrk_invariant:
             # one scalar per cloud: mean_i(0.5 max kNN-7 d^2) clamped to [5e-5, 1e-3]; clouds with fewer than
             # 7 points use sq_dist = 1e-3 (rasterizer.py:320-326)
-            h = ops.cloud_mean_clamp(d, first, num, 0.5, 5e-5, 1e-3, 0.5e-3, 7)
+            if view is not None:
+                V, znear, zfar, shared = view
+                N = V.shape[0]
+                if shared:
+                    f1 = first.new_zeros(N)
+                    n1 = num[:1].expand(N).contiguous()
+                else:
+                    f1, n1 = first, num
+                with torch.no_grad():
+                    h = ops.renderable_mean_clamp(d, point_clouds.points_packed().detach(), V, znear, zfar, f1, n1, shared,
+                                                  0.5, 5e-5, 1e-3, 0.5e-3, 7)
+            else:
+                h = ops.cloud_mean_clamp(d, first, num, 0.5, 5e-5, 1e-3, 0.5e-3, 7)
         elif raster_settings.Vrk_isotropic:
             h = (0.5 * d).clamp_(5e-5, 0.01)  # per point (rasterizer.py:383-388)
             sizes = [p.shape[0] for p in point_clouds.points_list()]
@@ -369,9 +386,19 @@ class SurfaceSplatting(torch.nn.Module):
                 geometry = type(point_clouds)([pl[0]], [nl[0]]) if isinstance(point_clouds, PointClouds3D) else None
                 if geometry is None:
                     shared, geometry = False, point_clouds
+        M = cameras.get_full_projection_transform().get_matrix().to(dev, torch.float32).contiguous()
+        V = cameras.get_world_to_view_transform().get_matrix().to(dev, torch.float32).contiguous()
+
+        def as_n(v, d):
+            t = getattr(cameras, v, kwargs.get(v, d))
+            if (torch.is_tensor(t) and t.dtype == torch.float32 and t.device == dev and t.dim() == 1
+                    and t.shape[0] == N and t.is_contiguous()):
+                return t  # the usual case: no copy, no launch
+            return torch.as_tensor(t, dtype=torch.float32, device=dev).reshape(-1).expand(N).contiguous()
+        znear, zfar = as_n("znear", 1.0), as_n("zfar", 100.0)
         h = kwargs.get("Vrk_h", None)
         if h is None:
-            h = self._variance_scale(geometry, raster_settings, kwargs.get("refresh", True))
+            h = self._variance_scale(geometry, raster_settings, kwargs.get("refresh", True), view=(V, znear, zfar, shared))
         vr6 = frame_n = None
         if not raster_settings.Vrk_invariant and not raster_settings.Vrk_isotropic:
             vr6, frame_n = self._local_frames(geometry)
@@ -385,18 +412,8 @@ class SurfaceSplatting(torch.nn.Module):
         else:
             first_idx, num_points = point_clouds.cloud_to_packed_first_idx(), point_clouds.num_points_per_cloud()
             out_clouds = point_clouds
-        M = cameras.get_full_projection_transform().get_matrix().to(dev, torch.float32).contiguous()
-        V = cameras.get_world_to_view_transform().get_matrix().to(dev, torch.float32).contiguous()
-
-        def as_n(v, d):
-            t = getattr(cameras, v, kwargs.get(v, d))
-            if (torch.is_tensor(t) and t.dtype == torch.float32 and t.device == dev and t.dim() == 1
-                    and t.shape[0] == N and t.is_contiguous()):
-                return t  # the usual case: no copy, no launch
-            return torch.as_tensor(t, dtype=torch.float32, device=dev).reshape(-1).expand(N).contiguous()
-
         a = dict(N=N, shared=shared, world=world, normals=normals, h=h.to(dev, torch.float32), M=M, V=V,
-                 znear=as_n("znear", 1.0), zfar=as_n("zfar", 100.0), first_idx=first_idx, num_points=num_points,
+                 znear=znear, zfar=zfar, first_idx=first_idx, num_points=num_points,
                  out_clouds=out_clouds, raster_settings=raster_settings, vr6=vr6, frame_n=frame_n)
         if memo_key is not None and world is pl[0] and normals is nl[0]:
             # (only when the packed tensors ARE the caller's tensors: a duck-typed cloud whose points_packed() is a copy --

@@ -183,9 +183,20 @@ class RowShardedRender:
         if self.mark is not None:
             self.mark(label)
 
-    def bwd_begin(self, grad):
+    def alpha_send_view(self):
+        """(N, rows, S) view of the alpha-plane exchange's send buffer, or None when this step has no such exchange (bucket form,
+        a world of one): a loss kernel that produces the band's gradient can write its alpha channel there directly
+        (`ops.image_loss_band_backward_partials(alpha_out=...)`; then `bwd_begin(..., alpha_packed=True)`)"""
+        if not (self.owner and self.part.world_size > 1):
+            return None
+        if self.alpha_x is None:
+            self.alpha_x = AlphaPlaneExchange(self.part, self.N, self.dev, group=self.group)
+        return self.alpha_x.send[:self.part.n_rows].permute(1, 0, 2)
+
+    def bwd_begin(self, grad, alpha_packed: bool = False):
         """stage 1 (compute): the band's gradient, contiguous; band loss + owner form: the alpha channel packed for its
-        exchange.  ``grad``: gradient of the FULL image (N,S,S,C+1) -- replicated loss -- or of this rank's band."""
+        exchange (unless the producer of ``grad`` already wrote it into `alpha_send_view()`).  ``grad``: gradient of the FULL
+        image (N,S,S,C+1) -- replicated loss -- or of this rank's band."""
         p, S = self.part, self.S
         rows = p.n_rows
         banded = p.world_size > 1          # (a forced world of one owns every row: the plain backward, then the collectives)
@@ -199,7 +210,8 @@ class RowShardedRender:
         if st["alpha"]:
             if self.alpha_x is None:
                 self.alpha_x = AlphaPlaneExchange(self.part, self.N, self.dev, group=self.group)
-            self.alpha_x.pack(st["g_band"])
+            if not alpha_packed:
+                self.alpha_x.pack(st["g_band"])
         self._bwd = st
         return st
 

@@ -471,6 +471,17 @@ DSS_API int dss_knn_points(const float *points /* (P,3) */, const int64_t *first
 DSS_API int dss_cloud_mean_clamp(const float *values /* (P,) */, const int64_t *first_idx,
                                  const int64_t *num_pts, int N, float scale, float lo, float hi,
                                  float fallback, int min_points, float *out /* (N,) */, void *stream);
+/* dss_cloud_mean_clamp under the reference's depth culling (rasterizer.py:236-240: the cloud is extended to the N cameras;
+ * :183-217: every camera drops the points outside [znear, zfar]; :320-326: h_n = clamp(mean over the PADDED cloud n) -- the
+ * mean of `h_k.mean(dim=1)` runs over P_max = the largest kept count of the batch, padding contributing zeros).  For the
+ * masked (not compacted) representation: out[n] = clamp(sum over the points camera n keeps of values[p] * scale / max_m
+ * kept_m, lo, hi); `fallback` for a camera that keeps fewer than min_points points.  values (Pw,) per WORLD point (the
+ * K-th-neighbour distances within the whole cloud), world (Pw,3), V (N,4,4); shared_cloud = 1: one cloud of num_pts[0]
+ * points for all cameras, else camera n sees world points [first_idx[n], first_idx[n] + num_pts[n]).  workspace: 16 N bytes. */
+DSS_API int dss_renderable_mean_clamp(const float *values, const float *world, const float *V, const float *znear,
+                                      const float *zfar, const int64_t *first_idx, const int64_t *num_pts, int N,
+                                      int shared_cloud, float scale, float lo, float hi, float fallback, int min_points,
+                                      float *out, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Phong shading of the points = LightingTexture.forward (DSS/core/texture.py:65-125):
@@ -588,19 +599,24 @@ DSS_API int dss_image_loss_band_backward(const float *rgba_band, const float *ta
  * (N, 64, 5) doubles (dss_image_loss_band_partials_count(N) of them; a rank without rows writes zeros); the caller
  * all-reduces THEM (SUM: 20 KB at 8 cameras -- latency-bound like the 40 N bytes of the sums); and
  * dss_image_loss_band_backward_partials adds them up in its prologue (every block in the same fixed order: the same bits on
- * every rank) and writes the band of the gradient image, the four losses (may be NULL) and the (N+1,5) sums (may be NULL). */
+ * every rank) and writes the band of the gradient image, the four losses (may be NULL) and the (N+1,5) sums (may be NULL).
+ * rgba_stride_n / rgba_stride_h: element strides of rgba_band over (camera, band row), multiples of 4; 0, 0 = dense -- the
+ * multi-GPU renderer's band lives in a (row, camera, col, channel) send buffer (dss_render_forward image_*_stride).
+ * alpha_out (may be NULL) + its element strides over (camera, band row): the alpha channel of the gradient written a second
+ * time, into the (row, camera, col) send buffer of the owner form's alpha-plane exchange. */
 DSS_API size_t dss_image_loss_band_partials_count(int N);
 DSS_API int dss_image_loss_band_partials(const float *rgba_band, const float *target_rgb, int64_t t_stride_n,
                                          int64_t t_stride_h, int64_t t_stride_w, int64_t t_stride_c,
                                          const float *target_mask, int64_t mask_stride_n, int N, int rows, int W,
-                                         double *partials, void *stream);
+                                         int64_t rgba_stride_n, int64_t rgba_stride_h, double *partials, void *stream);
 DSS_API int dss_image_loss_band_backward_partials(const float *rgba_band, const float *target_rgb, int64_t t_stride_n,
                                                   int64_t t_stride_h, int64_t t_stride_w, int64_t t_stride_c,
                                                   const float *target_mask, int64_t mask_stride_n, int N, int rows,
                                                   int W, int H, float lambda_rgb, float lambda_silhouette,
                                                   const double *partials, const float *grad_total, float *grad_band,
                                                   float *losses /* (4) or NULL */, double *sums /* (N+1,5) or NULL */,
-                                                  void *stream);
+                                                  int64_t rgba_stride_n, int64_t rgba_stride_h, float *alpha_out,
+                                                  int64_t alpha_stride_n, int64_t alpha_stride_h, void *stream);
 
 #ifdef __cplusplus
 }

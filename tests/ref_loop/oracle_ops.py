@@ -123,6 +123,23 @@ def cloud_mean_clamp(values, first, num, scale, lo, hi, fallback, min_points):
     return torch.tensor(out, dtype=torch.float32)
 
 
+def renderable_mean_clamp(values, world, V, znear, zfar, first, num, shared_cloud, scale, lo, hi, fallback, min_points):
+    """ops.renderable_mean_clamp: per camera the sum over the points it keeps (view z in [znear, zfar], the fp32 expression of
+    the setup) divided by the LARGEST kept count (the reference's mean over the padded batch, rasterizer.py:320-326)"""
+    N = V.shape[0]
+    sums, cnts = [], []
+    for n in range(N):
+        f, c = (0, int(num[0])) if shared_cloud else (int(first[n]), int(num[n]))
+        w, v = world[f:f + c].float(), V[n].float()
+        z = w[:, 0] * v[0, 2] + w[:, 1] * v[1, 2] + w[:, 2] * v[2, 2] + 1.0 * v[3, 2]
+        ok = (z >= znear[n]) & (z <= zfar[n])
+        sums.append(float((values[f:f + c][ok].float() * scale).double().sum()))
+        cnts.append(int(ok.sum()))
+    pmax = max(cnts)
+    return torch.tensor([float(min(max(s / pmax, lo), hi)) if (c >= min_points and pmax > 0) else float(min(max(fallback, lo), hi))
+                         for s, c in zip(sums, cnts)], dtype=torch.float32)
+
+
 def _splat_points_occ_fast_cuda_backward(points_sorted, radii_sorted, rs, grad_occ, num_points_per_cloud,
                                          cloud_to_packed_first_idx, points_grid_off=None, grid_params=None):
     """ext.cpp:14 -- the reference calls it with the VISIBLE points only; the FRNN grid arguments are not needed"""
@@ -175,6 +192,6 @@ def render_backward(grad_out, idx, qvalue, wsum, scaler, points, radii, visible,
 
 def install(ops_module) -> None:
     for name in ("point_setup", "project_backward", "splat_points", "splat_backward", "blend_forward", "blend_backward",
-                 "knn_kth_sqdist", "cloud_mean_clamp", "_splat_points_occ_fast_cuda_backward", "_backward_zbuf",
+                 "knn_kth_sqdist", "cloud_mean_clamp", "renderable_mean_clamp", "_splat_points_occ_fast_cuda_backward", "_backward_zbuf",
                  "render_forward", "render_backward"):
         setattr(ops_module, name, globals()[name])

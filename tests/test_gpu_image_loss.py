@@ -172,3 +172,18 @@ def test_tile_row_cyclic_bands_reproduce_the_full_image_loss(G, H):
         bt = tuple(x.contiguous() for x in ops.band_targets(img, mask, p.rows))
         gb2, lb2 = ops.image_loss_band_backward_partials(b, img, mask, p.rows, 0.7, 2.0, red, grad_total=up, band_targets=bt)
         assert torch.allclose(gb2, p.slice(grad), rtol=1e-6, atol=1e-12) and torch.allclose(lb2, losses, rtol=1e-6)
+        # the band where the multi-GPU forward leaves it: a (row, camera, col, channel) send buffer seen through its strided
+        # (N, rows, W, 4) view -- no copy --, and the alpha channel of the gradient written once more into the (row, camera, col)
+        # send buffer of the owner form's exchange: same bits as the dense call
+        send = torch.zeros((p.n_rows + 3, N, W, 4), device=DEV)
+        view = send[:p.n_rows].permute(1, 0, 2, 3)
+        view.copy_(b)
+        assert not view.is_contiguous()
+        assert torch.equal(ops.image_loss_band_partials(view, img, mask, p.rows, band_targets=bt),
+                           ops.image_loss_band_partials(b, img, mask, p.rows, band_targets=bt))
+        asend = torch.full((p.n_rows + 3, N, W), 7.0, device=DEV)
+        aview = asend[:p.n_rows].permute(1, 0, 2)
+        gb3, lb3 = ops.image_loss_band_backward_partials(view, img, mask, p.rows, 0.7, 2.0, red, grad_total=up, band_targets=bt,
+                                                         alpha_out=aview)
+        assert torch.equal(gb3, gb2) and torch.equal(lb3, lb2) and gb3.is_contiguous()
+        assert torch.equal(aview, gb2[..., 3]) and bool((asend[p.n_rows:] == 7.0).all())

@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Developer tool (GPU box): per-rank COMPUTE time of the multi-GPU bench step, emulated on one GPU: G cameras, each
-rank's rows (contiguous equal bands and the tile-row-cyclic partition), visibility = union over all ranks (computed by
-rendering every rank's rows once, untimed).  No collectives: this is the part of the G-GPU step that RCCL time is added
-to.  Per rank the step is timed twice: eager launches (host-bound at these sizes) and as a hipGraph replay (device time).
+rank's rows (contiguous equal bands and the tile-row-cyclic partition) through the SAME object `bench.py --gpus G` drives
+(dss_amd.sharded.RowShardedRender): forward of the rows, the image loss of the rows, backward, clip + projection.  What the
+collectives would deliver (visibility union, all-reduced loss partials, all-gathered alpha-gradient plane) is computed once,
+untimed, from the full image.  No collectives: this is the part of the G-GPU step that RCCL time is added to.  Per rank the step is timed twice: eager launches (host-bound at these sizes) and as a hipGraph replay (device time).
 
     python tools/band_timing.py [G] [cfg2|cfg4|cfg5] -> one JSON line: per-rank microseconds, max / min spread, for both layouts
 (cfg2: G cameras x 32,684 points @512^2, the weak-scaling workload of `bench.py --gpus G`; cfg4 / cfg5: BASELINE configs[3] /
@@ -19,6 +20,7 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 from dss_amd import ops  # noqa: E402
 from dss_amd.distributed import RowPartition, balanced_bounds, fitted_bounds, rebalanced_bounds  # noqa: E402
+from dss_amd.sharded import RowShardedRender  # noqa: E402
 
 from dss_amd import _lib  # noqa: E402
 if os.environ.get("BAND_TPW"):       # development A/B: DSS_OPT_BACKWARD_TPW
@@ -87,20 +89,40 @@ for layout in ((os.environ.get("BAND_TRACE_LAYOUT", "cyclic"),) if TRACE else LA
         out[layout + "_bounds"] = bounds
     parts = [RowPartition(S, G, r, cyclic=(layout == "cyclic"), bounds=bounds) for r in range(G)]
     # (union of the ranks' visibility flags = the flags of the full render: one call instead of G band renders)
-    vis_all = fwd(None)["visible"].clone()
+    full = fwd(None)
+    vis_all = full["visible"].clone()
+    # the CAUSAL step of bench.py --gpus G (dss_amd.sharded.RowShardedRender): the image gradient is the reference's image loss
+    # of the rank's own rows; what the collectives would deliver is computed once, untimed, from the full image -- the
+    # all-reduced loss partials and (owner form) the all-gathered alpha-gradient plane
+    img0 = torch.roll(full["image"], shifts=(5, 9), dims=(1, 2))
+    t_rgb, t_mask = img0[..., :3].contiguous(), (img0[..., 3] > 0).float().contiguous()
+    red = ops.image_loss_band_partials(full["image"].contiguous(), t_rgb, t_mask, (0, S))
+    g_full, _ = ops.image_loss_band_backward_partials(full["image"].contiguous(), t_rgb, t_mask, (0, S), 1.0, 1.0, red)
+    alpha_full = g_full[..., 3].contiguous()          # (N, S, S)
     eager, graph = [], []
     for p in (parts[TRACE_RANK:TRACE_RANK + 1] if TRACE else parts):
-        g_band = p.slice(wl.grad_out).contiguous()
-        bucket = torch.empty(wl.P * 6, device=dev)
-        gf, gp = bucket[:wl.P * 3].view(wl.P, 3), bucket[wl.P * 3:].view(wl.P, 3)
+        eng = RowShardedRender(p, wl.N, wl.Pc, wl.P, S, K, 3, dev, True, bench.CUTOFF, bench.SIGMA, bench.THR,
+                               gradient=GRADIENT, features_shared=True, force=False)
+        eng.active = False                            # no process group here: the collectives are emulated by their results
+        bt = tuple(x.contiguous() for x in ops.band_targets(t_rgb, t_mask, p.rows))
+        alpha_needed = OWNER and G > 1
+        if alpha_needed:
+            from dss_amd.distributed import AlphaPlaneExchange
+            eng.alpha_x = AlphaPlaneExchange(p, wl.N, dev)
+            pos = torch.tensor(p.gather_index(), dtype=torch.int64, device=dev)
+            eng.alpha_x.recv.zero_()
+            eng.alpha_x.recv[pos] = alpha_full.permute(1, 0, 2)     # what the all-gather would leave behind
 
         def step():
-            f = fwd(p.rows)
-            ops.render_backward(g_band, f["idx"], f["qvalue"], f["wsum"], f["scaler"], f["pts_screen"], f["radii"], vis_all,
-                                wl.first, wl.num, bench.RADII_S, -1.0, image_size=S, rows=p.rows, out=(gf, gp),
-                                grad_out_full=wl.grad_out if OWNER else None)
-            return ops.project_backward(wl.world, wl.M, wl.V, wl.first, wl.num, gp, f["valid"], True, clip=bench.CLIP,
-                                        grad_features=gf)
+            f = eng.forward(wl.world, wl.normals, wl.h, wl.M, wl.V, wl.znear, wl.zfar, wl.first, wl.num, wl.colors,
+                            order_refresh=ORDER_REFRESH)
+            band = eng.band_image                                                                # (strided view of the send buffer)
+            ops.image_loss_band_partials(band, t_rgb, t_mask, p.rows, band_targets=bt)           # (its all-reduced form: `red`)
+            g_band, _ = ops.image_loss_band_backward_partials(band, t_rgb, t_mask, p.rows, 1.0, 1.0, red, band_targets=bt,
+                                                              alpha_out=eng.alpha_send_view())   # (owner: + the alpha channel, packed)
+            eng.bwd_begin(g_band, alpha_packed=True)
+            eng.bwd_compute(bench.RADII_S, bench.CLIP, wl.world, wl.M, wl.V, wl.first, wl.num, f=f, vis_all=vis_all)
+            return eng.bwd_finish(bench.CLIP, wl.world, wl.M, wl.V, wl.first, wl.num)
         eager.append(quick(step, N_IT))
         if TRACE:
             graph.append(eager[-1])

@@ -140,6 +140,19 @@ while it + 1 < ITER:
             row["probe_grad_normals_rel_l2"] = rel(Pb.model.normals.grad, gA[1])
             row["probe_grad_points_max_abs_diff"] = float((Pb.model.points.grad - gA[0]).abs().max())
             row["grad_points_max_abs"] = float(gA[0].abs().max())
+            # what the reference's culling does at this state: points outside a camera's depth range, and the variance scale
+            # h each stack derived (rasterizer.py:183-217, 320-326)
+            with torch.no_grad():
+                cam = A.cameras
+                Vm = cam.get_world_to_view_transform().get_matrix()
+                z = torch.einsum("pc,nc->np", Pb.model.points[0].detach(), Vm[:, :3, 2]) + Vm[:, 3, 2][:, None]
+                zn = torch.as_tensor(cam.znear).reshape(-1, 1).float()
+                zf = torch.as_tensor(cam.zfar).reshape(-1, 1).float()
+                row["points_culled_per_view"] = [int(v) for v in ((z < zn) | (z > zf)).sum(1)]
+                hA = getattr(A.model.renderer.rasterizer, "_Vrk_h", None)
+                hB = getattr(Pb.model.renderer.rasterizer, "_Vrk_h", None)
+                row["h_A_min_max"] = None if hA is None else [float(hA.min()), float(hA.max())]
+                row["h_B_min_max"] = None if hB is None else [float(hB.min()), float(hB.max())]
         torch.set_rng_state(st)
         row["loss_B"] = B.step(batch, it)
         torch.set_rng_state(st)

@@ -35,9 +35,12 @@ def run(cmd, env=None, timeout=900):
 
 
 py = sys.executable
-out = {"what": "PREDICTED scaling of `bench.py --gpus G%s` -- per-rank compute emulated on ONE GPU + the collective floor "
-               "measured at world size 1; NOT a measurement at G > 1" % ("" if which == "cfg2" else " --workload " + which),
-       "workload": which}
+out = {"what": "PREDICTED scaling of `bench.py --gpus G%s` -- per-rank compute of the CAUSAL step (render -> image loss of the "
+               "rank's rows -> backward) emulated on ONE GPU + the collective floor measured at world size 1; NOT a measurement "
+               "at G > 1" % ("" if which == "cfg2" else " --workload " + which),
+       "workload": which, "causal": True,
+       "speedup_against": "the single-GPU line of bench.py (grad_out = randn, NO image loss in the step); "
+                          "`speedup_vs_causal_single_gpu_step` divides by the one-rank causal step instead"}
 bands = {}
 for G in (1, 2, 4, 8):
     # (large workloads: contiguous bands -- equal rows, occupancy-balanced, fitted to the measured times, two rebalancing steps)
@@ -76,6 +79,7 @@ else:
         except Exception:  # noqa: BLE001
             continue
 out["single_gpu_step_us"] = round(single_us, 2)
+out["causal_single_gpu_step_us"] = multi1
 out["multi_step_compute_world1_us"] = multi1
 out["collective_floor"] = floors
 weak = which == "cfg2"
@@ -91,23 +95,46 @@ for G in (1, 2, 4, 8):
             row["predicted_step_us_" + form] = round(step, 1)
             row["predicted_Msplats_per_s_" + form] = round(splats / step, 1)
             row["predicted_speedup_" + form] = round((splats / step) / (cams[1] * Pc / single_us), 2)
-        # link time of the two big collectives, estimated (bytes a rank sends / receives over its 7 links)
+        # link time of the collectives, ESTIMATED (bytes a rank sends / receives over its links at the link peak).  The step is
+        # causal (bench.py's N > 1 step: the image gradient is the loss of the rank's own rows): on the CRITICAL path sit the
+        # visibility all-reduce (P bytes), the all-reduce of the loss partials (2560 N bytes), in the owner form the all-gather
+        # of the alpha-gradient plane (N S^2 4 / G bytes per rank) and the gradient all-reduce; the image all-gather
+        # (N S^2 16 / G bytes per rank) is asynchronous on its own communicator -- nothing in the step reads the full image.
         n_img = cams[G]
         img_bytes_rank = n_img * S * S * 16 / G
-        # (owner mode -- bench.py's default above 262,144 pairs -- reduces the world-space sums, not every (camera, point) pair)
+        alpha_bytes_rank = n_img * S * S * 4 / G
         owner = bands[G].get("gradient") == "owner"
         grad_bytes = Pc * 24 if owner else n_img * Pc * 24
+        vis_bytes = n_img * Pc
         row["gradient_exchange"] = "owner" if owner else "bucket"
+        row["causal"] = True
         if G > 1:
+            bw = min(G - 1, LINKS) * XGMI_LINK_GBS * 1e3          # bytes per microsecond over the links a rank uses
+            ar = lambda b: 2 * b * (G - 1) / G / bw                # reduce-scatter + all-gather
+            ag = lambda b_rank: b_rank * (G - 1) / bw
+            crit = {"visibility_all_reduce": round(ar(vis_bytes), 1), "loss_partials_all_reduce": round(ar(2560 * n_img), 2),
+                    "gradient_all_reduce": round(ar(grad_bytes), 1)}
+            if owner:
+                crit["alpha_plane_all_gather"] = round(ag(alpha_bytes_rank), 1)
             row["estimated_link_us"] = {
-                "image_all_gather": round(img_bytes_rank * (G - 1) / (min(G - 1, LINKS) * XGMI_LINK_GBS * 1e3), 1),
-                "gradient_all_reduce": round(2 * grad_bytes * (G - 1) / G / (min(G - 1, LINKS) * XGMI_LINK_GBS * 1e3), 1),
-                "note": "direct (fully connected) schedule at the link peak; RCCL's measured bus bandwidth at these sizes is "
-                        "lower.  Overlapped exchange: the image bands travel during the backward; folded: before it"}
-            # the same prediction with the ESTIMATED link time of the collective that cannot overlap (the gradient all-reduce)
-            step_l = row["predicted_step_us_overlap"] + row["estimated_link_us"]["gradient_all_reduce"]
+                "critical_path": crit, "critical_path_sum": round(sum(crit.values()), 1),
+                "image_all_gather_off_the_critical_path": round(ag(img_bytes_rank), 1),
+                "note": "direct (fully connected) schedule at the link peak; RCCL's measured bus bandwidth at these sizes is lower, "
+                        "and every collective also pays a latency the world-1 floor only bounds from below"}
+            # the world-1 floor covers four collectives (visibility, loss partials, gradient, image); the owner form of G > 1 has
+            # a fifth on the critical path (alpha plane): one more share of the floor
+            n_floor = 4
+            for form, fl in floors.items():
+                extra = fl["collective_floor_us"] / n_floor if owner else 0.0
+                step = row["predicted_step_us_" + form] + extra
+                row["predicted_step_us_" + form] = round(step, 1)
+                row["predicted_Msplats_per_s_" + form] = round(cams[G] * Pc / step, 1)
+                row["predicted_speedup_" + form] = round((cams[G] * Pc / step) / (cams[1] * Pc / single_us), 2)
+            step_l = row["predicted_step_us_overlap"] + row["estimated_link_us"]["critical_path_sum"]
             row["predicted_step_us_overlap_with_link_estimate"] = round(step_l, 1)
             row["predicted_speedup_overlap_with_link_estimate"] = round((cams[G] * Pc / step_l) / (cams[1] * Pc / single_us), 2)
+        if G > 1:
+            row["speedup_vs_causal_single_gpu_step"] = round((cams[G] * Pc / row["predicted_step_us_overlap"]) / (cams[1] * Pc / multi1), 2)
         table.append(row)
 out["table"] = table
 out["scaling"] = "weak (G cameras, one per rank's worth of rows x cameras)" if weak else "strong (fixed job, rows shared by G ranks)"
