@@ -112,7 +112,10 @@ class Workload:
         self.multi = part.world_size > 1 if multi is None else bool(multi)
         # renderer-owned cached point order (clouds above 2M points: cfg4 / cfg5): every k-th step sorts and saves the
         # order, the others bin through it (`SurfaceSplattingRenderer(order_refresh=k)`); 0 = every step sorts
-        self.order_refresh = int(os.environ.get("BENCH_ORDER_REFRESH", "16")) if n_cams * pts.shape[0] > 2_000_000 else 0
+        # (below 2M splats the library bins directly and ignores the order flags; BENCH_ORDER_REFRESH set explicitly is passed on
+        # all the same: A/B builds with another threshold, tools/ab_bench.py)
+        self.order_refresh = int(os.environ.get("BENCH_ORDER_REFRESH", "16")) if (
+            n_cams * pts.shape[0] > 2_000_000 or "BENCH_ORDER_REFRESH" in os.environ) else 0
         self.force_order = None   # "save" / "reuse": this step's kind is fixed (the two graphs of the cached-order mode)
         S = part.S  # image side (module constant S for the benchmark; tools/bench_large.py passes others)
         self.Pc = pts.shape[0]
@@ -645,7 +648,7 @@ def main():
                     help="profiler passes: run warm-up + the timed region only (no per-kernel event timing, no API / kNN legs), "
                          "print a short JSON line")
     ap.add_argument("--no-traffic", action="store_true",
-                    help="do not spawn the two rocprofv3 counter passes (roofline.traffic then quotes the committed measurement)")
+                    help="do not spawn the rocprofv3 counter passes (roofline.traffic is then null, traffic_source 'not measured')")
     args = ap.parse_args()
     large = args.workload != "cfg2"
     if args.steps is None:
@@ -998,6 +1001,32 @@ def main():
             except Exception as e:  # noqa: BLE001  (capture refused: keep the eager figure)
                 knn_mode = "eager (graph capture failed: %s)" % type(e).__name__
         value_knn = splats / (ms_knn * 1e-3) / 1e6
+    # third reported figure (single GPU): the CAUSAL form of the step -- the one `bench.py --gpus N` times on N > 1 ranks: the
+    # image gradient is not an input but the reference's image loss (Trainer.calc_dr_loss) of the rendered image, computed
+    # inside the step.  The like-for-like single-GPU line for a scaling ratio against the N > 1 values.
+    value_loss = ms_loss = loss_mode = None
+    if not multi and not large:
+        try:
+            wl_c = Workload(dev, 1, part, multi="local")
+            ms_loss, loss_mode = quick(wl_c.step, n=max(20, args.steps // 4)), "eager"
+            if mode != "eager":
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    for _ in range(3):
+                        wl_c.step()
+                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize()
+                gl = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gl, stream=side):
+                    for _ in range(steps_per_launch):
+                        wl_c.step()
+                ms_g = quick(gl.replay, n=max(8, args.steps // (4 * steps_per_launch))) / steps_per_launch
+                if ms_g < ms_loss:
+                    ms_loss, loss_mode = ms_g, mode
+            value_loss = splats / (ms_loss * 1e-3) / 1e6
+        except Exception as e:  # noqa: BLE001  (an extra figure must not take the headline down)
+            loss_mode = "failed: %s: %s" % (type(e).__name__, str(e)[:120])
     api = not multi and not large
     ms_api = api_path_ms(wl) if api else None                                                # PyTorch's default autograd state
     ms_api_ct = api_path_ms(wl, calling_thread=True) if api else None                        # the caller's scoped opt-in
@@ -1061,7 +1090,6 @@ def main():
     alg_bytes = wl.N * (r1 - r0) * S * (12 * K + 4 + 16 + 4) + wl.P * 52
     achieved = alg_bytes / (fine_mean * 1e-3) / 1e9
     traffic, traffic_src, gather_traffic, prof_ms = None, None, None, {}
-    tfile = os.path.join(ROOT, "profiles", "traffic_fine_kernel.json")
     if not multi and rank == 0 and not args.no_traffic:
         # HBM bytes per launch are PMC counters: they cannot be read in-process.  tools/collect_traffic.py runs this very
         # command (eager, 20 steps, --no-traffic) twice under `rocprofv3 --kernel-trace --pmc` (FETCH_SIZE and WRITE_SIZE in
@@ -1082,10 +1110,9 @@ def main():
                                "same step, FETCH x2 (gfx950), %d + %d fine_kernel dispatches" % tuple(tj["samples"]))
             except Exception as e:  # noqa: BLE001  (no profiler on the box, counters unavailable, timeout)
                 traffic_src = "live measurement failed (%s); " % type(e).__name__
-    if traffic is None and not multi and not large and os.path.exists(tfile):
-        tj = json.load(open(tfile))
-        traffic = tj.get("traffic_bytes_per_launch")
-        traffic_src = (traffic_src or "") + "profiles/traffic_fine_kernel.json (%s)" % tj.get("round", "r1")
+    if traffic is None:
+        # no committed fallback any more (rounds 2-5 quoted a stale file here): what this run did not measure it does not report
+        traffic_src = (traffic_src or "") + "not measured"
     # the fractions are computed from the rocprofv3 average of the kernel whenever this run measured it
     # (`kernel_ms_rocprofv3`); the event timings stay in the line beside it
     fine_prof = prof_ms.get("fine_kernel")
@@ -1166,6 +1193,16 @@ def main():
             rec["value_with_knn"] = round(value_knn, 3)
             rec["ms_per_step_with_knn"] = round(ms_knn, 5)
             rec["with_knn_launch"] = knn_mode
+            rec["knn_chain_ms"] = round(ms_knn - ms_step, 5)
+            rec["with_knn"] = ("the same step with the kNN-7 statistic of rasterizer.py:310-326 recomputed inside it (the reference's "
+                               "refresh=True default): six launches (bounding box | cell counts + grid | scan | fill | query | mean)")
+        if loss_mode is not None:
+            rec["value_with_image_loss"] = None if value_loss is None else round(value_loss, 3)
+            rec["ms_per_step_with_image_loss"] = None if ms_loss is None else round(ms_loss, 5)
+            rec["with_image_loss_launch"] = loss_mode
+            rec["with_image_loss"] = ("the causal form of the step (what --gpus N times on N > 1 ranks): render -> "
+                                      "Trainer.calc_dr_loss of the rendered image against fixed targets -> backward, one rank, "
+                                      "no collective (Workload(multi='local'))")
         if ms_api is not None:
             to_v = lambda ms: round(splats / (ms * 1e-3) / 1e6, 3)
             rec["value_via_api"] = to_v(ms_api)

@@ -70,7 +70,9 @@ __device__ long long *g_fine_timing = nullptr;  // (blocks, 12) int64
 // the bunny scene cost ~30 us); splitting cuts the depth of every hot address by DSS_SUB.
 // Sub-lists have a fixed capacity `cap` >= 32 (workspace layout: counts (N*tiles*SUB) uint32, ..., lists
 // (N*tiles*SUB*cap) int32), see bin_capacity; a count above `cap` marks the tile as overflowed.
+#ifndef DSS_SUB     // (-DDSS_SUB=16 -DSPEC=16: development A/B build, profiles/r6_a_setup_bin_ab.txt)
 #define DSS_SUB 8
+#endif
 
 // Queue of OCCUPIED tiles.  The thread whose append is the first of a sub-list (returned position 0) claims the
 // tile with one atomicExch on its flag word; the winner appends the tile to one of DSS_QUEUES queues.  The fine
@@ -455,7 +457,9 @@ __global__ __launch_bounds__(256) void spill_kernel(
 // The tile lists, counters, flags, queues and the spill path are the ones of the direct binning: the fine pass does not
 // know which of the two filled them (the K-set of a pixel does not depend on the order of its candidates).
 // ---------------------------------------------------------------------------------------------
+#ifndef SORT_MIN_P               // (-DSORT_MIN_P=...: development A/B builds, tools/ab_bench.py)
 #define SORT_MIN_P 2000000      // below ~2M splats the direct binning wins (8 x 99,790 points: 0.69 vs 0.73 ms per step)
+#endif
 #define SORT_THREADS 1024
 #define SORT_PER_THREAD 16                            // at most: 16,384 splats per workgroup of the histogram pass
 #define SORT_CELL_MAX 16384                           // 64 KB of LDS counters
@@ -1060,7 +1064,9 @@ __device__ __forceinline__ void merge_round(unsigned long long (&key)[KMAX])
 #define FINE_WAVES (FOOT_PER_ROW * FOOT_PER_ROW)
 #define FINE_THREADS (FINE_WAVES * 64)
 #define CHUNK FINE_THREADS
+#ifndef SPEC
 #define SPEC 32   // list entries per sub-list and chunk: DSS_SUB * SPEC == CHUNK
+#endif
 static_assert(DSS_SUB * SPEC == CHUNK, "one list slot per thread and chunk");
 
 // fill values of the rows [row_begin, valid rows) step row_step of one EMPTY tile, written by one wavefront

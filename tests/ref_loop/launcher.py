@@ -353,6 +353,9 @@ def main():
     ap.add_argument("--no-cuda", action="store_true")
     ap.add_argument("--scalars", default=os.devnull, help="JSON-lines file the SummaryWriter stand-in appends to")
     args = ap.parse_args()
+    if "RANK" in os.environ and args.scalars != os.devnull:
+        # under torchrun (the row-sharded renderer: every rank runs the same script on the same batches): one scalars file per rank
+        args.scalars = "%s.rank%d" % (args.scalars, int(os.environ["RANK"]))
     for p in (os.path.join(ROOT, "compat"), ROOT, os.path.join(ROOT, "tests"), args.reference):
         if p not in sys.path:
             sys.path.insert(0, p)

@@ -179,3 +179,56 @@ def test_reference_train_mvr_converges_from_the_sphere_at_the_size_of_dss_yml(tm
     # initial sphere: 7.5e-2)
     assert cd_late["target_to_model"] < 0.1 * cd_early["target_to_model"] and cd_late["target_to_model"] < 0.9e-3, (cd_early, cd_late)
     assert cd_late["model_points_farther_than_0.2"] < cd_early["model_points_farther_than_0.2"], (cd_early, cd_late)
+
+
+@pytest.mark.timeout(900)
+def test_reference_train_mvr_unmodified_under_torchrun_with_the_row_sharded_renderer(tmp_path):
+    """VERDICT r5 item 1 ("a training loop cannot select it from YAML today"): the reference's unmodified `train_mvr.py`
+    started by `torch.distributed.run` with TWO ranks, its YAML naming `dss_amd.renderer.RowShardedSurfaceSplattingRenderer`
+    (config.py:241-261 can only pass a class path).  Every rank runs the same script on the same batches and renders its own
+    image rows; the class joins the process group in its constructor (gloo here: both ranks share the one GPU of the test box;
+    RCCL on a multi-GPU node).  The loss the Trainer logs must be THE SAME on both ranks in every iteration (same full image,
+    same all-reduced gradients -> same parameters) and must follow the single-GPU run of the same YAML with the plain
+    renderer (identical batches; fp32 reduction order differs)."""
+    import yaml
+    tmp = str(tmp_path)
+    ref = cfg3.reference_root(tmp)
+    cfg_cls, _ = cfg3.write_configs(tmp, size=256, points=5000, batch=4)
+    common = ["--reference", ref]
+    r = cfg3.run(common + ["--config", cfg_cls, "--make-dataset", os.path.join(tmp, "data"), "--views", "16", "--jitter", "2",
+                           "--camera-sampler"], 600)
+    assert r.returncode == 0, r.stdout[-3000:]
+    # single GPU, plain renderer
+    sc1 = os.path.join(tmp, "scalars_single.jsonl")
+    r = cfg3.run(common + ["--config", cfg_cls, "--scalars", sc1, "--exit-after", "12"], 600)
+    assert cfg3.reached_time_limit(r), r.stdout[-4000:]
+    single, _, _ = cfg3.losses(sc1)
+    assert len(single) >= 12, len(single)
+    # two ranks, the row-sharded renderer selected by the YAML
+    c = yaml.safe_load(open(cfg_cls))
+    c["name"] = "sharded"
+    c["renderer"]["renderer_type"] = "dss_amd.renderer.RowShardedSurfaceSplattingRenderer"
+    cfg_sh, sc2 = os.path.join(tmp, "sharded.yml"), os.path.join(tmp, "scalars_sharded.jsonl")
+    yaml.safe_dump(c, open(cfg_sh, "w"))
+    os.makedirs(os.path.join(tmp, "exp", "sharded"), exist_ok=True)   # (train_mvr.py:54-55 is not written for two processes)
+    env_keep = dict(os.environ)
+    os.environ["DSS_AMD_DIST_BACKEND"] = "gloo"
+    try:
+        r = cfg3.run(common + ["--config", cfg_sh, "--scalars", sc2, "--exit-after", "12"], 800,
+                     prefix=[sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+                             "127.0.0.1", "--master-port", "29741", "--no-python"])
+    finally:
+        os.environ.clear()
+        os.environ.update(env_keep)
+    out = r.stdout
+    assert "Time limit reached" in out or cfg3.reached_time_limit(r), out[-6000:]
+    l0, s0, _ = cfg3.losses(sc2 + ".rank0")
+    l1, s1, _ = cfg3.losses(sc2 + ".rank1")
+    n = min(len(l0), len(l1))
+    assert n >= 8, (len(l0), len(l1), out[-3000:])
+    # the ranks hold the same parameters after every step: the logged loss is bit-identical
+    assert l0[:n] == l1[:n], [(a, b) for a, b in zip(l0[:n], l1[:n]) if a != b][:4]
+    m = min(n, len(single), 8)
+    rel = [abs(a - b) / abs(b) for a, b in zip(l0[:m], single[:m])]
+    print("row-sharded (2 ranks) vs single GPU, first %d iterations, rel. loss differences: %s" % (m, ["%.1e" % v for v in rel]))
+    assert max(rel[:3]) <= 1e-4 and max(rel) <= 2e-2, rel

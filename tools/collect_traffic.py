@@ -6,8 +6,8 @@ Runs bench.py under rocprofv3 twice -- FETCH_SIZE and WRITE_SIZE in SEPARATE pas
 WRITE_SIZE 2; they do not fit one pass) -- and averages the counters over the fine_kernel
 dispatches.  Corrections per MI355X_MICROARCH.md "HBM": both counters are in KiB; on gfx950
 FETCH_SIZE reports half of the bytes of wide coalesced reads -> doubled; WRITE_SIZE is taken as is
-(uncalibrated).  Writes profiles/traffic_fine_kernel.json, which bench.py reports as
-roofline.traffic (bytes per launch)."""
+(uncalibrated).  Prints one JSON line (bench.py spawns this script and reports the result as roofline.traffic, bytes per
+launch) and leaves a copy under gpurun_out/ for tools/collect_profiles.sh."""
 import csv
 import glob
 import json
