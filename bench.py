@@ -26,7 +26,7 @@ has been checked against the eager step on every rank, else graphs of the comput
 Environment switches (development A/B; none is needed for the contract): BENCH_FORCE_DIST=1 (multi-GPU path at world size
 1), BENCH_DIST_BACKEND=gloo (CPU collectives, tests), BENCH_NO_WHOLE_GRAPH=1 (segments instead of the whole-step graph),
 BENCH_IMAGE_LATE=1 (image collective issued behind the backward), BENCH_EXCHANGE=overlap|fold|auto (end-of-forward exchange),
-BENCH_GRADIENT=owner|bucket (gradient exchange), BENCH_ROW_PARTITION=cyclic|bands (row layout), BENCH_ORDER_REFRESH=k (period of the cached point order of
+BENCH_GRADIENT=auto|owner|bucket (gradient exchange), BENCH_ROW_PARTITION=cyclic|bands (row layout), BENCH_ORDER_REFRESH=k (period of the cached point order of
 the large workloads, 0 = sort in every step; default 16), BENCH_BACKWARD_FUSED / BENCH_BACKWARD_TPW (DSS_OPT_* of the
 library), DSS_AMD_CALLING_THREAD_BACKWARD=1 (backward on the calling thread for the API figures; the scoped form is
 `with dss_amd.calling_thread_backward():`).
@@ -155,7 +155,8 @@ class Workload:
             # straight into the exchange's send buffers.  The step is CAUSAL: the image gradient is the reference's image loss
             # (Trainer.calc_dr_loss, trainer.py:332-376: masked L1 on RGB + L1 + 0.01 IoU on the occupancy) of the rank's OWN
             # band against fixed targets, its per-image sums all-reduced (dss_amd.distributed.band_image_loss's kernels).
-            # Gradient exchange (BENCH_GRADIENT): "owner" (default) -- the rank whose band holds a point's centre row computes
+            # Gradient exchange (BENCH_GRADIENT=auto|owner|bucket; auto = dss_amd.sharded.choose_gradient_exchange, from the
+            # bytes each form puts on the critical path: bucket at the metric's configuration, owner at configs[3] / [4]): "owner" -- the rank whose band holds a point's centre row computes
             # the pair's WHOLE position gradient; it needs the occupancy gradient of all rows, so the ranks all-gather that one
             # channel (N S^2 4 bytes) between the loss and the backward; clip + projection then run before ONE all-reduce of
             # the world-space sums (Pc x 6 floats).  "bucket" -- partial sums of every (camera, point) pair from the band's own
@@ -163,7 +164,7 @@ class Workload:
             # End-of-forward exchange: "overlap" -- visibility all-reduce (critical) + asynchronous image all-gather on a second
             # communicator (nobody in the step reads the full image: it is the step's output) -- or "fold", see main().
             self.engine = RowShardedRender(part, self.N, self.Pc, self.P, S, K, 3, device, True, CUTOFF, SIGMA, THR,
-                                           gradient=os.environ.get("BENCH_GRADIENT", "owner"), features_shared=True,
+                                           gradient=os.environ.get("BENCH_GRADIENT", "auto"), features_shared=True,
                                            fold=fold, force=not self.local,
                                            late_image=os.environ.get("BENCH_IMAGE_LATE", "0") == "1")
             self.owner = self.engine.owner

@@ -586,7 +586,11 @@ class SurfaceSplatting(torch.nn.Module):
         dev, N, Pw = a["world"].device, a["N"], a["world"].shape[0]
         P = N * Pw if a["shared"] else Pw
         S, K, C = int(st.image_size), int(st.points_per_pixel), int(feats.shape[1])
-        gradient = kwargs.get("gradient_exchange", "owner")
+        from .sharded import choose_gradient_exchange
+        band_only = bool(kwargs.get("band_only", False))
+        gradient = kwargs.get("gradient_exchange", "auto")
+        if gradient == "auto":   # (a replicated loss hands the owner form the full gradient: no alpha-plane exchange)
+            gradient = choose_gradient_exchange(N, Pw, P, S, C, part.world_size, band_loss=band_only)
         group = kwargs.get("process_group", None)
         key = (dev, N, Pw, P, S, K, C, bool(a["shared"]), bool(st.backface_culling), float(st.cutoff_threshold),
                float(st.antialiasing_sigma), float(st.depth_merging_threshold), part.world_size, part.rank, part.cyclic,
@@ -600,7 +604,6 @@ class SurfaceSplatting(torch.nn.Module):
                                                      st.antialiasing_sigma, st.depth_merging_threshold,
                                                      bool(st.backface_culling), group=group, gradient=gradient,
                                                      static_buffers=False)
-        band_only = bool(kwargs.get("band_only", False))
         aux = (a["normals"], a["h"], a["M"], a["V"], a["znear"], a["zfar"], a["first_idx"], a["num_points"], a["vr6"],
                a["frame_n"], float(st.radii_backward_scaler), -1.0 if st.clip_pts_grad is None else float(st.clip_pts_grad),
                band_only, int(kwargs.get("order_refresh", getattr(self, "order_refresh", 0)) or 0))

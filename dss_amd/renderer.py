@@ -53,7 +53,7 @@ class NormWeightedCompositor(torch.nn.Module):
 class SurfaceSplattingRenderer(torch.nn.Module):
     def __init__(self, rasterizer, compositor=None, antialiasing_sigma: float = 1.0, density: float = 1e-4,
                  frnn_radius=-1, fused=None, graphed: bool = False, order_refresh: int = 0, engine_thread=None,
-                 row_partition=None, gradient_exchange: str = "owner", row_output: str = "full", process_group=None):
+                 row_partition=None, gradient_exchange: str = "auto", row_output: str = "full", process_group=None):
         """``fused`` (not in the reference signature): True runs rasterizer + blend as ONE autograd node on the fused
         kernels (dss_render_forward / dss_render_backward): same images, ~2x fewer launches; the only loss of generality
         is that gradients w.r.t. ``fragments.zbuf`` are not propagated.  False keeps rasterizer and blend as separate
@@ -83,7 +83,8 @@ class SurfaceSplattingRenderer(torch.nn.Module):
         (`dss_amd.rasterizer._RenderRowSharded`), with ``row_output="full"`` the whole (N,H,W,4) image gathered from all ranks
         -- an unmodified training loop evaluates its loss on it on every rank -- or with ``row_output="band"`` the rank's own
         rows (N,rows,W,4) for `dss_amd.distributed.band_image_loss`; ``loss.backward()`` leaves the SAME gradients (the sums
-        over all ranks) on every rank.  ``gradient_exchange``: "owner" (default) or "bucket", see `dss_amd.sharded`."""
+        over all ranks) on every rank.  ``gradient_exchange``: "owner", "bucket" or "auto" (default: chosen from the bytes each form
+        puts on the critical path, `dss_amd.sharded.choose_gradient_exchange`)."""
         super().__init__()
         if engine_thread is None and os.environ.get("DSS_AMD_CALLING_THREAD_BACKWARD", "0") == "1":
             engine_thread = False
@@ -225,7 +226,7 @@ class RowShardedSurfaceSplattingRenderer(SurfaceSplattingRenderer):
     def __init__(self, rasterizer, compositor=None, **kwargs):
         import torch.distributed as dist
         kwargs.setdefault("row_partition", os.environ.get("DSS_AMD_ROW_PARTITION", "auto"))
-        kwargs.setdefault("gradient_exchange", os.environ.get("DSS_AMD_GRADIENT_EXCHANGE", "owner"))
+        kwargs.setdefault("gradient_exchange", os.environ.get("DSS_AMD_GRADIENT_EXCHANGE", "auto"))
         world = int(os.environ.get("WORLD_SIZE", "1"))
         if world > 1 and dist.is_available() and not dist.is_initialized():
             if torch.cuda.is_available():

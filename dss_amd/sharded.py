@@ -35,7 +35,7 @@ import torch.distributed as dist
 from . import ops
 from .distributed import AlphaPlaneExchange, OverlappedExchange, RowPartition
 
-__all__ = ["RowShardedRender", "default_partition"]
+__all__ = ["RowShardedRender", "default_partition", "choose_gradient_exchange"]
 
 
 def default_partition(image_size: int, group=None, layout: str = "auto") -> Optional[RowPartition]:
@@ -52,6 +52,22 @@ def default_partition(image_size: int, group=None, layout: str = "auto") -> Opti
     if layout == "cyclic" and not cyclic:
         raise ValueError("a tile-row-cyclic partition needs a power-of-two world size and S %% (8 G) == 0, got G=%d S=%d" % (G, S))
     return RowPartition(S, G, g, cyclic=cyclic)
+
+
+def choose_gradient_exchange(N: int, Pw: int, P: int, S: int, C: int, world_size: int, band_loss: bool = True,
+                             features_shared: bool = False) -> str:
+    """"owner" or "bucket" from the bytes each form puts on the critical path of a step (PROVISIONAL: xGMI link peak of
+    MI355X_MICROARCH.md at half efficiency, 10 us per extra collective; no multi-GPU run has calibrated it).  bucket: ONE
+    all-reduce of P (3 + C) floats; owner: an all-reduce of the world-space sums plus -- with a band-local loss -- the
+    all-gather of the alpha-gradient plane.  Small jobs (the metric's configuration: 6 MB of partial sums) take the bucket
+    form, large ones (configs[3]: 192 MB against 24 + 4 MB) the owner form."""
+    G = max(int(world_size), 2)
+    bw = min(G - 1, 7) * 153.0e3 * 0.5                 # bytes per microsecond
+    ar = lambda b: 2.0 * b * (G - 1) / G / bw
+    bucket = ar(4.0 * P * (3 + C))
+    nf = Pw if features_shared else P
+    owner = ar(4.0 * (3 * Pw + nf * C)) + ((4.0 * N * S * S / G) * (G - 1) / bw + 10.0 if band_loss else 0.0)
+    return "bucket" if bucket <= owner else "owner"
 
 
 class RowShardedRender:
@@ -71,8 +87,10 @@ class RowShardedRender:
                  cutoff: float, sigma: float, thr: float, backface: bool = False, group=None, gradient: str = "owner",
                  features_shared: bool = False, fold: bool = False, force: bool = False, late_image: bool = False,
                  gather_image: bool = True, static_buffers: bool = True):
+        if gradient == "auto":
+            gradient = choose_gradient_exchange(N, Pw, P, S, C, part.world_size, True, features_shared and shared)
         if gradient not in ("owner", "bucket"):
-            raise ValueError("gradient must be 'owner' or 'bucket', got %r" % (gradient,))
+            raise ValueError("gradient must be 'owner', 'bucket' or 'auto', got %r" % (gradient,))
         if part.S != S:
             raise ValueError("the partition is for %d rows, the image has %d" % (part.S, S))
         self.part, self.group, self.dev = part, group, torch.device(device)

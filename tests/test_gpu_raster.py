@@ -797,6 +797,7 @@ def test_bench_launches_its_own_ranks():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env["BENCH_DIST_BACKEND"] = "gloo"
     env["BENCH_EXCHANGE"] = "overlap"   # (the three-collective form: "auto" would time both forms and keep the faster)
+    env["BENCH_GRADIENT"] = "owner"     # (the form with the alpha-plane exchange; the default "auto" picks the bucket form at this size)
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
                           "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-12000:]

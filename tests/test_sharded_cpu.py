@@ -1,0 +1,94 @@
+"""CPU, gloo worlds of 2 and 4: `dss_amd.sharded.RowShardedRender` -- the object behind
+`SurfaceSplattingRenderer(row_partition=...)` and `bench.py --gpus N` -- with the per-band compute supplied by the oracle
+(tests/band_ops_double.py).  Under test: which rank renders what, what travels in which collective, and that every form of the
+step (replicated loss / band loss, owner / bucket gradient exchange, contiguous / tile-row-cyclic bands) reproduces the
+single-process image and gradients."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import scenes
+    from dss_amd import ops
+    import band_ops_double
+    band_ops_double.install(ops)
+    from dss_amd.distributed import RowPartition
+    from dss_amd.sharded import RowShardedRender, default_partition
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        S, K, N, C = 64, 4, 2, 3
+        pts, nrm = scenes.load_cloud("bunny")
+        pts = scenes.normalize_unit_sphere(pts)[::6].copy()
+        nrm = nrm[::6].copy()
+        Pw = pts.shape[0]
+        P = N * Pw
+        world_t, normals = torch.from_numpy(pts), torch.from_numpy(nrm)
+        Mn, Vn, _ = scenes.camera_matrices(2.0, 30.0, [45.0, 150.0])
+        M, V = torch.from_numpy(Mn).contiguous(), torch.from_numpy(Vn).contiguous()
+        zn, zf = torch.full((N,), 0.1), torch.full((N,), 100.0)
+        first = torch.arange(N, dtype=torch.int64) * Pw
+        num = torch.full((N,), Pw, dtype=torch.int64)
+        h = torch.full((N,), 1.5e-3)
+        feats = torch.rand((P, C), generator=torch.Generator().manual_seed(1))
+        g_full = torch.randn((N, S, S, C + 1), generator=torch.Generator().manual_seed(2))
+        args = (world_t, normals, h, M, V, zn, zf, first, num, feats)
+        # single process: the whole image through the same doubles
+        f1 = ops.render_forward(*args, S, K, 1.0, 0.05, 1.0, False, True)
+        gf1, gp1 = ops.render_backward(g_full, f1["idx"], f1["qvalue"], f1["wsum"], f1["scaler"], f1["pts_screen"], f1["radii"],
+                                       f1["visible"], first, num, 5.0, -1.0)
+        gw1 = ops.project_backward(world_t, M, V, first, num, gp1, f1["valid"], True, clip=0.05)
+        assert float(gw1.abs().max()) > 0 and float(f1["image"][..., 3].sum()) > 50
+        rel = lambda a, b: float((a - b).norm() / b.norm().clamp_min(1e-30))
+        assert default_partition(S).world_size == world and default_partition(S).rank == rank
+        for cyclic in (False, True):
+            if cyclic and S % (8 * world):
+                continue
+            part = RowPartition(S, world, rank, cyclic=cyclic)
+            for gradient in ("owner", "bucket"):
+                for shared_f in (False, True):
+                    eng = RowShardedRender(part, N, Pw, P, S, K, C, "cpu", True, 1.0, 1.0, 0.05, gradient=gradient,
+                                           features_shared=shared_f)
+                    for band_loss in (False, True):
+                        eng.forward(*args)
+                        vis = eng.start_exchange()
+                        assert torch.equal(vis.bool(), f1["visible"]), "visibility union differs"
+                        img = eng.full_image()
+                        assert torch.equal(img, f1["image"]), ("gathered image differs", cyclic, gradient)
+                        assert torch.equal(eng.band_image, part.slice(f1["image"]))
+                        grad = part.slice(g_full).contiguous() if band_loss else g_full
+                        gw, gf = eng.backward(grad, 5.0, 0.05, world_t, M, V, first, num)
+                        want_f = gf1.view(N, Pw, C).sum(0) if shared_f else gf1
+                        assert rel(gw, gw1) < 1e-5 and rel(gf, want_f) < 1e-5, (cyclic, gradient, shared_f, band_loss,
+                                                                              rel(gw, gw1), rel(gf, want_f))
+                        # the reduced sums are the same bits on every rank
+                        both = [torch.zeros_like(gw) for _ in range(world)]
+                        dist.all_gather(both, gw.contiguous())
+                        assert all(torch.equal(b, both[0]) for b in both)
+        open(os.path.join(tmp, "ok%d" % rank), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(world, tmp_path, port0):
+    port = port0 + (os.getpid() % 80)
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / ("ok%d" % r)).exists() for r in range(world))
+
+
+def test_row_sharded_engine_gloo_world2(tmp_path):
+    _run(2, tmp_path, 29450)
+
+
+def test_row_sharded_engine_gloo_world4(tmp_path):
+    _run(4, tmp_path, 29550)
