@@ -61,9 +61,14 @@ def quick(fn, n=60):
 
 
 out = {"G": G, "workload": which, "cameras": wl.N, "points_per_cloud": wl.Pc, "image_size": S}
-GRADIENT = os.environ.get("BAND_GRADIENT", "owner")   # bench.py's default
+GRADIENT = os.environ.get("BAND_GRADIENT", "auto")   # bench.py's default: chosen from the bytes on the critical path
+if GRADIENT == "auto":
+    from dss_amd.sharded import choose_gradient_exchange
+    GRADIENT = choose_gradient_exchange(wl.N, wl.Pc, wl.P, S, 3, max(G, 2), os.environ.get("BAND_LOSS", "band") != "replicated", True)
 out["gradient"] = GRADIENT
 N_IT = 60 if which == "cfg2" else 16
+REPLICATED = os.environ.get("BAND_LOSS", "band") == "replicated"   # loss on the gathered image on every rank (unmodified loops)
+out["loss"] = "replicated" if REPLICATED else "band"
 OWNER = GRADIENT == "owner"   # gradient exchange of the step (bench.py BENCH_GRADIENT): owner | bucket
 TRACE = os.environ.get("BAND_TRACE") == "1"   # under rocprofv3 --kernel-trace: the cyclic partition, rank 3, eager launches only
 LAYOUTS = os.environ.get("BAND_LAYOUTS", "bands,balanced,cyclic").split(",")
@@ -99,6 +104,7 @@ for layout in ((os.environ.get("BAND_TRACE_LAYOUT", "cyclic"),) if TRACE else LA
     red = ops.image_loss_band_partials(full["image"].contiguous(), t_rgb, t_mask, (0, S))
     g_full, _ = ops.image_loss_band_backward_partials(full["image"].contiguous(), t_rgb, t_mask, (0, S), 1.0, 1.0, red)
     alpha_full = g_full[..., 3].contiguous()          # (N, S, S)
+    full_image = full["image"].contiguous()
     eager, graph = [], []
     for p in (parts[TRACE_RANK:TRACE_RANK + 1] if TRACE else parts):
         eng = RowShardedRender(p, wl.N, wl.Pc, wl.P, S, K, 3, dev, True, bench.CUTOFF, bench.SIGMA, bench.THR,
@@ -113,7 +119,21 @@ for layout in ((os.environ.get("BAND_TRACE_LAYOUT", "cyclic"),) if TRACE else LA
             eng.alpha_x.recv.zero_()
             eng.alpha_x.recv[pos] = alpha_full.permute(1, 0, 2)     # what the all-gather would leave behind
 
+        def step_replicated():
+            # BAND_LOSS=replicated: what an UNMODIFIED training loop does with `row_output="full"` -- every rank evaluates the
+            # loss on the whole gathered image (here: the full render, as the all-gather would deliver it) and hands the full
+            # gradient to the backward (owner form: no further exchange; bucket form: its own rows of it)
+            f = eng.forward(wl.world, wl.normals, wl.h, wl.M, wl.V, wl.znear, wl.zfar, wl.first, wl.num, wl.colors,
+                            order_refresh=ORDER_REFRESH)
+            losses, sums = ops.image_loss_forward(full_image, t_rgb, t_mask, 1.0, 1.0)
+            g = ops.image_loss_backward(full_image, t_rgb, t_mask, 1.0, 1.0, sums)
+            eng.bwd_begin(g)
+            eng.bwd_compute(bench.RADII_S, bench.CLIP, wl.world, wl.M, wl.V, wl.first, wl.num, f=f, vis_all=vis_all)
+            return eng.bwd_finish(bench.CLIP, wl.world, wl.M, wl.V, wl.first, wl.num)
+
         def step():
+            if REPLICATED:
+                return step_replicated()
             f = eng.forward(wl.world, wl.normals, wl.h, wl.M, wl.V, wl.znear, wl.zfar, wl.first, wl.num, wl.colors,
                             order_refresh=ORDER_REFRESH)
             band = eng.band_image                                                                # (strided view of the send buffer)

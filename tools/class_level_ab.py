@@ -116,6 +116,55 @@ assert classes["A"].startswith("DSS.") and classes["B"].startswith("dss_amd."), 
 
 gen = torch.Generator().manual_seed(0)
 rel = lambda a, b: float((a - b).norm() / b.norm().clamp_min(1e-30))
+SAVE_AT = int(os.environ.get("AB_SAVE_AT", "-1"))      # save stack A's state before this iteration and stop (debugging aid)
+LOAD = os.environ.get("AB_LOAD", "")                   # ... and compare the two class stacks AT that state, term by term
+
+
+def scalars_of(stack, batch, it):
+    """loss terms the Trainer logs + the rendered image of one forward/backward at the stack's current state"""
+    seen, imgs = {}, []
+    tb = stack.trainer.tb_logger
+    keep = tb.add_scalar
+    tb.add_scalar = lambda tag, value, step=None, *a, **k: seen.__setitem__(tag, float(value))
+    ren = stack.model.renderer
+    fwd = ren.forward
+
+    def spy(*a, **k):
+        out = fwd(*a, **k)
+        imgs.append((out[0] if isinstance(out, tuple) else out).detach().clone())
+        return out
+    ren.forward = spy
+    try:
+        stack.grads_only(batch, it)
+    finally:
+        ren.forward = fwd
+        tb.add_scalar = keep
+    return seen, imgs
+
+
+if LOAD:
+    st = torch.load(LOAD)
+    for S_ in (A, Pb):
+        S_.model.load_state_dict(st["model"])
+        S_.model.points_filter = copy.deepcopy(st["points_filter"])
+    torch.set_rng_state(st["rng"])
+    sa, ia = scalars_of(A, st["batch"], st["it"])
+    torch.set_rng_state(st["rng"])
+    sb, ib = scalars_of(Pb, st["batch"], st["it"])
+    out = {"it": st["it"], "terms_A": sa, "terms_B": sb, "renders": len(ia)}
+    for k, (x, y) in enumerate(zip(ia, ib)):
+        d = (x - y).abs()
+        out["render%d" % k] = {"shape": list(x.shape), "max_abs_diff": float(d.max()), "pixels_differing_gt_1e-4": int((d.amax(-1) > 1e-4).sum()),
+                               "alpha_differs": int((x[..., -1] != y[..., -1]).sum()),
+                               "per_view_pixels_differing": [int(v) for v in (d.amax(-1) > 1e-4).flatten(1).sum(1)]}
+    out["grad_points_rel_l2"] = rel(Pb.model.points.grad, A.model.points.grad)
+    out["grad_normals_rel_l2"] = rel(Pb.model.normals.grad, A.model.normals.grad)
+    hA = getattr(A.model.renderer.rasterizer, "_Vrk_h", None)
+    hB = getattr(Pb.model.renderer.rasterizer, "_Vrk_h", None)
+    out["h_A"] = None if hA is None else sorted(set(round(float(v), 9) for v in hA.flatten()[:: max(1, hA.numel() // 64)]))
+    out["h_B"] = None if hB is None else [float(v) for v in hB.flatten()[:16]]
+    print(json.dumps(out), flush=True)
+    sys.exit(0)
 rows, it, t0 = [], -1, time.time()
 while it + 1 < ITER:
     loader = torch.utils.data.DataLoader(A.dataset, batch_size=BATCH, shuffle=True, generator=gen, drop_last=True,
@@ -125,7 +174,12 @@ while it + 1 < ITER:
         if it >= ITER:
             break
         row = {"it": it}
-        probe = it < DENSE or it % EVERY == 0
+        if it == SAVE_AT:
+            torch.save({"model": A.model.state_dict(), "points_filter": copy.deepcopy(A.model.points_filter), "batch": batch,
+                        "it": it, "rng": torch.get_rng_state()}, os.environ.get("AB_SAVE_TO", "/tmp/ab_state.pt"))
+            print(json.dumps({"saved_at": it}), flush=True)
+            sys.exit(0)
+        probe = (it < DENSE or it % EVERY == 0) and SAVE_AT < 0
         st = torch.get_rng_state()
         if probe:
             Pb.model.load_state_dict(A.model.state_dict())
