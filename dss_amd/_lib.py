@@ -87,10 +87,13 @@ SIGNATURES = {
                                                        _c_i64, _c_i64, _c_vp, _c_i64, _c_i64, _c_vp]),
     "dss_knn_workspace": (_c_sz, [_c_int, _c_i64]),
     "dss_knn_kth_sqdist": (_c_int, [_c_vp] * 3 + [_c_int, _c_i64, _c_int, _c_vp, _c_vp, _c_sz, _c_vp]),
+    "dss_knn_kth_sqdist_radius": (_c_int, [_c_vp] * 3 + [_c_int, _c_i64, _c_int, _c_f32, _c_vp, _c_vp, _c_sz, _c_vp]),
     "dss_knn_points": (_c_int, [_c_vp] * 3 + [_c_int, _c_i64, _c_int, _c_vp, _c_vp, _c_vp, _c_sz, _c_vp]),
     "dss_cloud_mean_clamp": (_c_int, [_c_vp] * 3 + [_c_int, _c_f32, _c_f32, _c_f32, _c_f32, _c_int, _c_vp, _c_vp]),
-    "dss_renderable_mean_clamp": (_c_int, [_c_vp] * 7 + [_c_int, _c_int, _c_f32, _c_f32, _c_f32, _c_f32, _c_int, _c_vp, _c_vp, _c_sz,
-                                           _c_vp]),
+    "dss_renderable_mean_clamp": (_c_int, [_c_vp] * 7 + [_c_int, _c_int, _c_f32, _c_f32, _c_f32, _c_f32, _c_int, _c_i64, _c_vp, _c_vp,
+                                           _c_sz, _c_vp]),
+    "dss_knn_kth_sqdist_view": (_c_int, [_c_vp] * 3 + [_c_int, _c_i64, _c_int, _c_f32, _c_vp, _c_vp, _c_vp, _c_int, _c_int, _c_vp, _c_vp,
+                                         _c_sz, _c_vp]),
     "dss_blend_forward": (_c_int, [_c_vp] * 5 + [_c_int] * 5 + [_c_vp, _c_vp, _c_vp]),
     "dss_local_frames": (_c_int, [_c_vp] * 4 + [_c_int, _c_i64, _c_int, _c_vp, _c_vp, _c_vp, _c_vp]),
     "dss_point_setup": (_c_int, [_c_vp] * 12 + [_c_int, _c_i64, _c_int, _c_int, _c_int, _c_f32, _c_f32]

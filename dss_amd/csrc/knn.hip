@@ -385,17 +385,33 @@ __global__ __launch_bounds__(1024) void knn_scan_single_kernel(const uint32_t *_
     if (tid == 0 && (b + 1) * KNN_SCAN_BLOCK >= cells) offsets[(size_t)n * stride + cells] = prefix + total;
 }
 
+// Per-camera depth culling inside the search (dss_knn_kth_sqdist_view): the reference runs its neighbour search AFTER
+// filter_renderable has dropped, per camera, the points outside [znear, zfar] (rasterizer.py:599, 183-217, 310-326) -- a point's
+// neighbours are then the ones the SAME camera keeps.  mode 1: one cloud shared by the cameras, blockIdx.y = camera, results at
+// kth_sqdist[camera * P + p]; mode 2: cloud n belongs to camera n.  A query point its camera drops gets 0 (never read).
+struct KnnView {
+    const float *V;        // (cameras, 4, 4) world -> view, row-vector convention
+    const float *znear, *zfar;
+    int mode;              // 0: off
+};
+__device__ __forceinline__ bool knn_kept(float x, float y, float z, float v2, float v6, float v10, float v14, float zn, float zf)
+{
+    const float zview = x * v2 + y * v6 + z * v10 + 1.0f * v14;   // the expression of setup_point_compute
+    return (zview >= zn) && (zview <= zf);
+}
+
 // FULL = false: K-th squared distance only (kth_sqdist (P,)).  FULL = true: the whole neighbour list, ascending in
 // (distance, id): dists (P,Krt) squared distances and idx (P,Krt) cloud-local ids, zero-padded when the cloud has
 // fewer than Krt points (the layout pytorch3d.ops.knn_points returns for a self query, losses.py:157-180).
-template <int K, bool FULL>
+template <int K, bool FULL, bool VIEW = false>
 __global__ __launch_bounds__(256) void knn_query_kernel(const float *__restrict__ pts, const int64_t *__restrict__ first_idx,
                                                         const int64_t *__restrict__ num_pts, int N, int64_t P,
                                                         const KnnGrid *__restrict__ grids, size_t stride,
                                                         const uint32_t *__restrict__ offsets,
                                                         const float4 *__restrict__ sorted, int Krt,
                                                         float *__restrict__ kth_sqdist, float *__restrict__ dists,
-                                                        int64_t *__restrict__ idx)
+                                                        int64_t *__restrict__ idx, float r2 /* > 0: FRNN semantics, see dss_knn_kth_sqdist_radius */,
+    const KnnView view = KnnView())
 {
     const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= P) return;
@@ -417,6 +433,14 @@ __global__ __launch_bounds__(256) void knn_query_kernel(const float *__restrict_
     const float4 self = sorted[slot];
     const int64_t p = (int64_t)__float_as_int(self.w);
     const float qx = self.x, qy = self.y, qz = self.z;
+    float v2 = 0.f, v6 = 0.f, v10 = 0.f, v14 = 0.f, zn = 0.f, zf = 0.f;
+    if (VIEW) {
+        const int cam = view.mode == 1 ? (int)blockIdx.y : n;
+        const float *vm = view.V + 16 * cam;
+        v2 = vm[2]; v6 = vm[6]; v10 = vm[10]; v14 = vm[14]; zn = view.znear[cam]; zf = view.zfar[cam];
+        if (view.mode == 1) kth_sqdist += (size_t)cam * (size_t)P;
+        if (!knn_kept(qx, qy, qz, v2, v6, v10, v14, zn, zf)) { kth_sqdist[p] = 0.0f; return; }
+    }
     const int cx = cell_coord(qx, g.minx, g.inv_cell, g.res);
     const int cy = cell_coord(qy, g.miny, g.inv_cell, g.res);
     const int cz = cell_coord(qz, g.minz, g.inv_cell, g.res);
@@ -434,15 +458,16 @@ __global__ __launch_bounds__(256) void knn_query_kernel(const float *__restrict_
     // One candidate: keep the K best in (distance, id) order (FULL) or by distance (kth only).
     auto consider = [&](const float4 q) {
         const float dx = q.x - qx, dy = q.y - qy, dz = q.z - qz;
-        const float d2 = dx * dx + dy * dy + dz * dz;
+        float d2 = dx * dx + dy * dy + dz * dz;
+        if (VIEW && !knn_kept(q.x, q.y, q.z, v2, v6, v10, v14, zn, zf)) d2 = __builtin_huge_valf();   // the camera drops it
         if (FULL) {
             // total order (distance, id): deterministic lists whatever the cell order
             const int id = __float_as_int(q.w);
             // bitwise | and &: the short-circuit forms compile to two nested exec-mask branches per comparison
-            if ((d2 < best[K - 1]) | ((d2 == best[K - 1]) & (id < bid[K - 1]))) {
+            if ((d2 < best[K - 1]) | ((d2 == best[K - 1]) & (id < bid[FULL ? K - 1 : 0]))) {
                 bool lt[K];
 #pragma unroll
-                for (int k = 0; k < K; ++k) lt[k] = (d2 < best[k]) | ((d2 == best[k]) & (id < bid[k]));
+                for (int k = 0; k < K; ++k) lt[k] = (d2 < best[k]) | ((d2 == best[k]) & (id < bid[FULL ? k : 0]));
 #pragma unroll
                 for (int k = K - 1; k >= 1; --k) {
                     // the empty asm keeps the operands values: left alone, the compiler rewrites select(c, bid[k-1],
@@ -548,6 +573,14 @@ __global__ __launch_bounds__(256) void knn_query_kernel(const float *__restrict_
     float kth = best[0];
 #pragma unroll
     for (int k = 1; k < K; ++k) kth = (k < kk) ? best[k] : kth;
+    if (r2 > 0.0f) {
+        // fixed-radius semantics of the reference's default neighbour search (frnn_grid_points(K, r), rasterizer.py:317-326):
+        // neighbours beyond r come back as -1 and the statistic is the MAX over the K - 1 returned distances -- the farthest
+        // neighbour found within r, or -1 for a point without any
+        kth = -1.0f;
+#pragma unroll
+        for (int k = 1; k < K; ++k) kth = (k < kk && best[k] <= r2) ? best[k] : kth;
+    }
     kth_sqdist[p] = kth;
 }
 
@@ -608,14 +641,15 @@ __device__ __forceinline__ void knn_merge_round(float (&best)[K], int (&bid)[FUL
     }
 }
 
-template <int K, bool FULL>
+template <int K, bool FULL, bool VIEW = false>
 __global__ __launch_bounds__(256) void knn_query_coop_kernel(const float *__restrict__ pts, const int64_t *__restrict__ first_idx,
                                                              const int64_t *__restrict__ num_pts, int N, int64_t P,
                                                              const KnnGrid *__restrict__ grids, size_t stride,
                                                              const uint32_t *__restrict__ offsets,
                                                              const float4 *__restrict__ sorted, int Krt,
                                                              float *__restrict__ kth_sqdist, float *__restrict__ dists,
-                                                             int64_t *__restrict__ idx)
+                                                             int64_t *__restrict__ idx, float r2 /* > 0: FRNN semantics, see dss_knn_kth_sqdist_radius */,
+    const KnnView view = KnnView())
 {
     constexpr int GPB = 256 / KNN_LPQ;   // query groups per workgroup
     const int grp = threadIdx.x / KNN_LPQ, sub = threadIdx.x % KNN_LPQ;
@@ -639,6 +673,17 @@ __global__ __launch_bounds__(256) void knn_query_coop_kernel(const float *__rest
     const float4 self = sorted[slot];   // the slot-th point of the cell-sorted order
     const int64_t p = (int64_t)__float_as_int(self.w);
     const float qx = self.x, qy = self.y, qz = self.z;
+    float v2 = 0.f, v6 = 0.f, v10 = 0.f, v14 = 0.f, zn = 0.f, zf = 0.f;
+    if (VIEW) {
+        const int cam = view.mode == 1 ? (int)blockIdx.y : n;
+        const float *vm = view.V + 16 * cam;
+        v2 = vm[2]; v6 = vm[6]; v10 = vm[10]; v14 = vm[14]; zn = view.znear[cam]; zf = view.zfar[cam];
+        if (view.mode == 1) kth_sqdist += (size_t)cam * (size_t)P;
+        if (!knn_kept(qx, qy, qz, v2, v6, v10, v14, zn, zf)) {   // (the whole 16-lane group shares the query: leaves together)
+            if (sub == 0) kth_sqdist[p] = 0.0f;
+            return;
+        }
+    }
     const int cx = cell_coord(qx, g.minx, g.inv_cell, g.res);
     const int cy = cell_coord(qy, g.miny, g.inv_cell, g.res);
     const int cz = cell_coord(qz, g.minz, g.inv_cell, g.res);
@@ -655,6 +700,7 @@ __global__ __launch_bounds__(256) void knn_query_coop_kernel(const float *__rest
     }
     auto consider = [&](const float4 q, bool on) {
         const float dx = q.x - qx, dy = q.y - qy, dz = q.z - qz;
+        if (VIEW) on = on && knn_kept(q.x, q.y, q.z, v2, v6, v10, v14, zn, zf);   // the camera drops it
         const float d2 = on ? dx * dx + dy * dy + dz * dz : __builtin_huge_valf();
         if (FULL) {
             const int id = on ? __float_as_int(q.w) : 0x7fffffff;
@@ -765,6 +811,14 @@ __global__ __launch_bounds__(256) void knn_query_coop_kernel(const float *__rest
     float kth = best[0];
 #pragma unroll
     for (int k = 1; k < K; ++k) kth = (k < kk) ? best[k] : kth;
+    if (r2 > 0.0f) {
+        // fixed-radius semantics of the reference's default neighbour search (frnn_grid_points(K, r), rasterizer.py:317-326):
+        // neighbours beyond r come back as -1 and the statistic is the MAX over the K - 1 returned distances -- the farthest
+        // neighbour found within r, or -1 for a point without any
+        kth = -1.0f;
+#pragma unroll
+        for (int k = 1; k < K; ++k) kth = (k < kk && best[k] <= r2) ? best[k] : kth;
+    }
     kth_sqdist[p] = kth;
 }
 
@@ -809,7 +863,8 @@ __global__ __launch_bounds__(1024) void renderable_sum_kernel(const float *__res
                                                               const float *__restrict__ V, const float *__restrict__ znear,
                                                               const float *__restrict__ zfar, const int64_t *__restrict__ first_idx,
                                                               const int64_t *__restrict__ num_pts, int shared, float scale,
-                                                              double *__restrict__ sums /* (N,2): sum, count */)
+                                                              double *__restrict__ sums /* (N,2): sum, count */,
+                                                              int64_t vals_cam_stride /* 0: one value per world point */)
 {
     __shared__ double part[16], partc[16];
     const int n = blockIdx.x, tid = threadIdx.x;
@@ -822,7 +877,7 @@ __global__ __launch_bounds__(1024) void renderable_sum_kernel(const float *__res
         const int64_t wi = f0 + i;
         const float zview = world[3 * wi] * v2 + world[3 * wi + 1] * v6 + world[3 * wi + 2] * v10 + 1.0f * v14;
         const bool ok = (zview >= zn) && (zview <= zf);
-        a += ok ? (double)(vals[wi] * scale) : 0.0;
+        a += ok ? (double)(vals[(size_t)n * (size_t)vals_cam_stride + wi] * scale) : 0.0;
         c += ok ? 1.f : 0.f;
     }
     double cc = (double)c;
@@ -892,7 +947,7 @@ int dss::launch_cloud_bbox(const float *points, const int64_t *first_idx, const 
 // grid build + query; exactly one of (kth_sqdist) / (dists, idx) is written
 static int knn_run(const char *who, const float *points, const int64_t *first_idx, const int64_t *num_pts, int N, int64_t P,
                    int K, float *kth_sqdist, float *dists, int64_t *idx, void *workspace, size_t workspace_bytes,
-                   void *stream)
+                   void *stream, float r2 = -1.0f, const KnnView view = KnnView(), int n_cams = 1)
 {
     const bool full = dists != nullptr;
     if (N <= 0 || P < 0 || K < 1 || K > (full ? KNN_FULL_MAX_K : KNN_MAX_K)) {
@@ -950,15 +1005,28 @@ static int knn_run(const char *who, const float *points, const int64_t *first_id
     // small inputs: one wavefront per workgroup, so that the few hundred wavefronts spread over all 256 CUs
     const unsigned qt = P <= 131072 ? 64u : 256u;
     const unsigned qb = (unsigned)((P + qt - 1) / qt);
+    const unsigned gy = view.mode == 1 ? (unsigned)n_cams : 1u;
 #define KNN_LAUNCH(KK, FF)                                                                                          \
     hipLaunchKernelGGL((knn_query_kernel<KK, FF>), dim3(qb), dim3(qt), 0, st, points, first_idx, num_pts, N, P, grids,  \
-                       stride, offsets, sorted, K, kth_sqdist, dists, idx)
+                       stride, offsets, sorted, K, kth_sqdist, dists, idx, r2, KnnView())
     // cooperative kernel: 16 lanes per query (K <= 16); the one-thread-per-query kernel keeps the deep lists
     const unsigned cb = (unsigned)((P + (256 / KNN_LPQ) - 1) / (256 / KNN_LPQ));
 #define KNN_LAUNCH_COOP(KK, FF)                                                                                     \
     hipLaunchKernelGGL((knn_query_coop_kernel<KK, FF>), dim3(cb), dim3(256), 0, st, points, first_idx, num_pts, N, P, grids, \
-                       stride, offsets, sorted, K, kth_sqdist, dists, idx)
+                       stride, offsets, sorted, K, kth_sqdist, dists, idx, r2, KnnView())
     const int qopt = option(DSS_OPT_KNN_QUERY);   // 0: by size, 1: cooperative, 2: one thread per query
+    if (view.mode != 0) {
+        // K-th distance under per-camera culling (K <= 8: the variance-scale statistic): one grid row per camera
+        if (full || K > 8) { set_error("%s: the per-camera search is built for the K-th distance with K <= 8", who); return DSS_ERR_UNSUPPORTED; }
+        const bool coop = qopt == 1 || (qopt == 0 && P <= KNN_COOP_KTH_MAX_P);
+        if (coop)
+            hipLaunchKernelGGL((knn_query_coop_kernel<8, false, true>), dim3(cb, gy), dim3(256), 0, st, points, first_idx, num_pts,
+                               N, P, grids, stride, offsets, sorted, K, kth_sqdist, dists, idx, r2, view);
+        else
+            hipLaunchKernelGGL((knn_query_kernel<8, false, true>), dim3(qb, gy), dim3(qt), 0, st, points, first_idx, num_pts, N, P,
+                               grids, stride, offsets, sorted, K, kth_sqdist, dists, idx, r2, view);
+        return check_launch(who);
+    }
     if (full) {
         // full lists: the cooperative kernel wins while the launch is latency-bound (32k points, K = 12: 58 us against
         // ~100); at 100k points the merges of (distance, id) lists cost more than the shorter chains save (182 vs 155 us)
@@ -1017,7 +1085,8 @@ extern "C" int dss_cloud_mean_clamp(const float *values, const int64_t *first_id
 extern "C" int dss_renderable_mean_clamp(const float *values, const float *world, const float *V, const float *znear,
                                          const float *zfar, const int64_t *first_idx, const int64_t *num_pts, int N,
                                          int shared_cloud, float scale, float lo, float hi, float fallback, int min_points,
-                                         float *out, void *workspace, size_t workspace_bytes, void *stream)
+                                         int64_t values_cam_stride, float *out, void *workspace, size_t workspace_bytes,
+                                         void *stream)
 {
     if (N <= 0 || !values || !world || !V || !znear || !zfar || !first_idx || !num_pts || !out || !workspace ||
         workspace_bytes < (size_t)N * 16) {
@@ -1026,7 +1095,41 @@ extern "C" int dss_renderable_mean_clamp(const float *values, const float *world
     }
     double *sums = reinterpret_cast<double *>(workspace);
     hipLaunchKernelGGL(renderable_sum_kernel, dim3(N), dim3(1024), 0, as_stream(stream), values, world, V, znear, zfar,
-                       first_idx, num_pts, shared_cloud, scale, sums);
+                       first_idx, num_pts, shared_cloud, scale, sums, values_cam_stride);
     hipLaunchKernelGGL(renderable_mean_kernel, dim3(1), dim3(64), 0, as_stream(stream), sums, N, lo, hi, fallback, min_points, out);
     return check_launch("dss_renderable_mean_clamp");
+}
+
+// dss_knn_kth_sqdist with the fixed-radius semantics of the reference's DEFAULT neighbour search: SurfaceSplatting is built
+// with frnn_radius = 0.2 (rasterizer.py:110) and then calls frnn.frnn_grid_points(K = 7, r = frnn_radius) (:317, :373), which
+// reports neighbours beyond r as -1 [third party, lxxue/FRNN, not vendored: behaviour as restated by tests/ref_loop/launcher.py];
+// the statistic 0.5 * max over the K - 1 returned distances is then the farthest neighbour FOUND within r -- or -0.5 for an
+// isolated point, which pulls the cloud's mean h down once points have drifted away from the surface.  radius <= 0: the plain
+// K-th distance (the reference's knn_points branch, frnn_radius <= 0).
+extern "C" int dss_knn_kth_sqdist_radius(const float *points, const int64_t *first_idx, const int64_t *num_pts, int N,
+                                         int64_t P, int K, float radius, float *kth_sqdist, void *workspace,
+                                         size_t workspace_bytes, void *stream)
+{
+    return knn_run("dss_knn_kth_sqdist_radius", points, first_idx, num_pts, N, P, K, kth_sqdist, nullptr, nullptr, workspace,
+                   workspace_bytes, stream, radius > 0.0f ? radius * radius : -1.0f);
+}
+
+// dss_knn_kth_sqdist[_radius] in the reference's ORDER under depth culling: filter_renderable extends the cloud to the
+// cameras and drops, per camera, the points outside [znear, zfar] BEFORE the neighbour search (rasterizer.py:599, 236-240,
+// 183-217, 310-326), so a point's neighbours are the ones the same camera keeps.  shared_cloud = 1: ONE cloud (N must be 1)
+// seen by n_cams cameras; kth_sqdist (n_cams, P): row c = the statistic among the points camera c keeps (0 for the points it
+// drops).  shared_cloud = 0: cloud n is seen by camera n (n_cams == N); kth_sqdist (P,).  K <= 8.  One grid build, one query
+// launch with a grid row per camera.
+extern "C" int dss_knn_kth_sqdist_view(const float *points, const int64_t *first_idx, const int64_t *num_pts, int N,
+                                       int64_t P, int K, float radius, const float *V, const float *znear, const float *zfar,
+                                       int n_cams, int shared_cloud, float *kth_sqdist, void *workspace, size_t workspace_bytes,
+                                       void *stream)
+{
+    if (!V || !znear || !zfar || n_cams <= 0 || (shared_cloud ? N != 1 : n_cams != N)) {
+        set_error("dss_knn_kth_sqdist_view: cameras missing, or the cloud / camera counts do not fit (shared: one cloud; else one camera per cloud)");
+        return DSS_ERR_INVALID_ARGUMENT;
+    }
+    KnnView view = {V, znear, zfar, shared_cloud ? 1 : 2};
+    return knn_run("dss_knn_kth_sqdist_view", points, first_idx, num_pts, N, P, K, kth_sqdist, nullptr, nullptr, workspace,
+                   workspace_bytes, stream, radius > 0.0f ? radius * radius : -1.0f, view, n_cams);
 }

@@ -57,12 +57,18 @@ def self_knn(points, first, num, sizes, K: int):
     return dists, idx
 
 
-def kth_sqdist(points, first, num, sizes, K: int):
+def kth_sqdist(points, first, num, sizes, K: int, radius: float = -1.0):
     """``ops.knn_kth_sqdist`` (K-th smallest squared distance, self included), through the shared lists when a
     consumer asked for them and every cloud has at least that many points (short clouds differ: farthest point vs
-    zero padding), else by the dedicated kernel."""
+    zero padding), else by the dedicated kernel.  ``radius`` > 0: the fixed-radius semantics of the reference's default
+    search (``frnn_grid_points(K, r)``, rasterizer.py:317: neighbours beyond r count as -1, the statistic is the max over the
+    K - 1 returned distances) -- the farthest neighbour found within r, -1 for a point without any."""
     want = max(int(K), _requested_k)
+    r2 = float(radius) * float(radius) if radius is not None and radius > 0 else -1.0
     if _requested_k > 0 and sizes and min(sizes) >= want:
         dists, _ = self_knn(points, first, num, sizes, want)
-        return dists[:, K - 1].contiguous()
-    return ops.knn_kth_sqdist(points.detach(), first, num, int(K))
+        if r2 <= 0:
+            return dists[:, K - 1].contiguous()
+        d = dists[:, 1:K]
+        return torch.where(d <= r2, d, torch.full_like(d, -1.0)).amax(dim=1)
+    return ops.knn_kth_sqdist(points.detach(), first, num, int(K), radius=radius if r2 > 0 else None)

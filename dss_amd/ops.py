@@ -933,10 +933,12 @@ def project_backward(world, M, V, cloud_to_packed_first_idx, num_points_per_clou
     return gw
 
 
-def knn_kth_sqdist(points, cloud_to_packed_first_idx, num_points_per_cloud, K: int = 7):
+def knn_kth_sqdist(points, cloud_to_packed_first_idx, num_points_per_cloud, K: int = 7, radius=None):
     """K-th smallest squared distance of every point to its own cloud (self included) -> (P,).
     Exact grid search in HIP; replaces frnn.frnn_grid_points / pytorch3d.ops.knn_points for the
-    variance-scale statistic (rasterizer.py:310-321, 366-383)."""
+    variance-scale statistic (rasterizer.py:310-321, 366-383).  ``radius`` > 0 (``dss_knn_kth_sqdist_radius``): the
+    fixed-radius semantics of the reference's DEFAULT search, ``frnn_grid_points(K, r = frnn_radius = 0.2)`` -- the largest of
+    the K - 1 neighbour distances that lie within ``radius``, -1 for a point that has no neighbour there."""
     lib = _lib.load()
     points = _lib.require_gpu(points, "points", _f32)
     dev = points.device
@@ -946,8 +948,12 @@ def knn_kth_sqdist(points, cloud_to_packed_first_idx, num_points_per_cloud, K: i
     with torch.cuda.device(dev):
         out = torch.empty((P,), dtype=_f32, device=dev)
         ws = _lib.workspace(dev, lib.dss_knn_workspace(N, P))
-        rc = lib.dss_knn_kth_sqdist(_lib.ptr(points), _lib.ptr(first), _lib.ptr(num), N, P, int(K), _lib.ptr(out),
-                                    _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
+        if radius is not None and radius > 0:
+            rc = lib.dss_knn_kth_sqdist_radius(_lib.ptr(points), _lib.ptr(first), _lib.ptr(num), N, P, int(K), float(radius),
+                                               _lib.ptr(out), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
+        else:
+            rc = lib.dss_knn_kth_sqdist(_lib.ptr(points), _lib.ptr(first), _lib.ptr(num), N, P, int(K), _lib.ptr(out),
+                                        _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
     _lib.check(rc, "dss_knn_kth_sqdist")
     return out
 
@@ -993,7 +999,8 @@ def renderable_mean_clamp(values, world, V, znear, zfar, cloud_to_packed_first_i
                           scale: float, lo: float, hi: float, fallback: float, min_points: int):
     """``cloud_mean_clamp`` under the reference's depth culling for MASKED clouds (``dss_renderable_mean_clamp``): per camera
     the mean over the points it keeps (view z in [znear, zfar]), divided by the LARGEST kept count of the batch like the
-    reference's mean over the padded clouds (rasterizer.py:183-217, 320-326) -> (N,)."""
+    reference's mean over the padded clouds (rasterizer.py:183-217, 320-326) -> (N,).  ``values``: (Pw,) one per world point,
+    or (N, Pw) per (camera, point) from `knn_kth_sqdist_view` (a shared cloud in the reference's exact order)."""
     lib = _lib.load()
     values = _lib.require_gpu(values, "values", _f32)
     dev = values.device
@@ -1003,17 +1010,44 @@ def renderable_mean_clamp(values, world, V, znear, zfar, cloud_to_packed_first_i
     zfar = _lib.require_gpu(zfar, "zfar", _f32)
     first = _lib.require_gpu(cloud_to_packed_first_idx, "cloud_to_packed_first_idx", _i64)
     num = _lib.require_gpu(num_points_per_cloud, "num_points_per_cloud", _i64)
-    N = V.shape[0]
-    if values.shape[0] != world.shape[0] or first.shape[0] != N or znear.numel() != N or zfar.numel() != N:
-        raise RuntimeError("renderable_mean_clamp: values / world per world point, V, znear, zfar, first_idx, num_points per camera")
+    N, Pw = V.shape[0], world.shape[0]
+    per_cam = values.dim() == 2
+    if (tuple(values.shape) != ((N, Pw) if per_cam else (Pw,))) or first.shape[0] != N or znear.numel() != N or zfar.numel() != N:
+        raise RuntimeError("renderable_mean_clamp: values (Pw,) or (N,Pw); V, znear, zfar, first_idx, num_points per camera")
     with torch.cuda.device(dev):
         out = torch.empty((N,), dtype=_f32, device=dev)
         ws = _lib.workspace(dev, 16 * N)
         rc = lib.dss_renderable_mean_clamp(_lib.ptr(values), _lib.ptr(world), _lib.ptr(V), _lib.ptr(znear), _lib.ptr(zfar),
                                            _lib.ptr(first), _lib.ptr(num), N, int(shared_cloud), float(scale), float(lo),
-                                           float(hi), float(fallback), int(min_points), _lib.ptr(out), _lib.ptr(ws), ws.numel(),
-                                           _lib.stream_ptr(dev))
+                                           float(hi), float(fallback), int(min_points), Pw if per_cam else 0, _lib.ptr(out),
+                                           _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
     _lib.check(rc, "dss_renderable_mean_clamp")
+    return out
+
+
+def knn_kth_sqdist_view(points, cloud_to_packed_first_idx, num_points_per_cloud, K: int, V, znear, zfar, shared_cloud: bool,
+                        radius=None):
+    """`knn_kth_sqdist` in the reference's order under depth culling (``dss_knn_kth_sqdist_view``): every camera drops the
+    points outside its [znear, zfar] BEFORE the neighbour search (rasterizer.py:599, 183-217, 310-326).  ``shared_cloud``:
+    one cloud, N cameras -> (N, P) (row c: among the points camera c keeps; 0 for the ones it drops); else cloud n belongs to
+    camera n -> (P,)."""
+    lib = _lib.load()
+    points = _lib.require_gpu(points, "points", _f32)
+    dev = points.device
+    first = _lib.require_gpu(cloud_to_packed_first_idx, "cloud_to_packed_first_idx", _i64)
+    num = _lib.require_gpu(num_points_per_cloud, "num_points_per_cloud", _i64)
+    V = _lib.require_gpu(V, "V", _f32)
+    znear = _lib.require_gpu(znear, "znear", _f32)
+    zfar = _lib.require_gpu(zfar, "zfar", _f32)
+    N, P, n_cams = first.shape[0], points.shape[0], V.shape[0]
+    with torch.cuda.device(dev):
+        out = torch.empty((n_cams, P) if shared_cloud else (P,), dtype=_f32, device=dev)
+        ws = _lib.workspace(dev, lib.dss_knn_workspace(N, P))
+        rc = lib.dss_knn_kth_sqdist_view(_lib.ptr(points), _lib.ptr(first), _lib.ptr(num), N, P, int(K),
+                                         float(radius) if radius is not None else -1.0, _lib.ptr(V), _lib.ptr(znear),
+                                         _lib.ptr(zfar), n_cams, int(shared_cloud), _lib.ptr(out), _lib.ptr(ws), ws.numel(),
+                                         _lib.stream_ptr(dev))
+    _lib.check(rc, "dss_knn_kth_sqdist_view")
     return out
 
 

@@ -290,26 +290,33 @@ class SurfaceSplatting(torch.nn.Module):
                                                        self._Vrk_h.shape[0] == n_total):  # rasterizer.py:359-361
             return self._Vrk_h
         first, num = point_clouds.cloud_to_packed_first_idx(), point_clouds.num_points_per_cloud()
+        # `frnn_radius` > 0 (the reference's default 0.2): its fixed-radius search reports neighbours beyond the radius as -1
+        # (rasterizer.py:316-319) -- honoured: it decides h once points have drifted away from the surface
+        radius = self.frnn_radius if (self.frnn_radius is not None and self.frnn_radius > 0) else -1.0
+        if raster_settings.Vrk_invariant and view is not None:
+            # the reference's order: per camera, drop the points outside its depth range, THEN search the neighbours among the
+            # kept ones, then the mean over the padded batch (rasterizer.py:599, 183-217, 310-326) -- one grid build, one query
+            # launch with a grid row per camera (`ops.knn_kth_sqdist_view`), one masked mean
+            V, znear, zfar, shared = view
+            N = V.shape[0]
+            pts = point_clouds.points_packed().detach()
+            with torch.no_grad():
+                d = ops.knn_kth_sqdist_view(pts, first, num, 7, V, znear, zfar, shared, radius=radius)
+                if shared:
+                    f1, n1 = first.new_zeros(N), num[:1].expand(N).contiguous()
+                else:
+                    f1, n1 = first, num
+                h = ops.renderable_mean_clamp(d, pts, V, znear, zfar, f1, n1, shared, 0.5, 5e-5, 1e-3, 0.5e-3, 7)
+            self._Vrk_h = h
+            return h
         with torch.no_grad():
             # through dss_amd.neighbours: one search serves this statistic and the regularisers of the same iteration
             d = neighbours.kth_sqdist(point_clouds.points_packed(), first, num,
-                                      [p.shape[0] for p in point_clouds.points_list()], 7)
+                                      [p.shape[0] for p in point_clouds.points_list()], 7, radius=radius)
         if raster_settings.Vrk_invariant:
             # one scalar per cloud: mean_i(0.5 max kNN-7 d^2) clamped to [5e-5, 1e-3]; clouds with fewer than
             # 7 points use sq_dist = 1e-3 (rasterizer.py:320-326)
-            if view is not None:
-                V, znear, zfar, shared = view
-                N = V.shape[0]
-                if shared:
-                    f1 = first.new_zeros(N)
-                    n1 = num[:1].expand(N).contiguous()
-                else:
-                    f1, n1 = first, num
-                with torch.no_grad():
-                    h = ops.renderable_mean_clamp(d, point_clouds.points_packed().detach(), V, znear, zfar, f1, n1, shared,
-                                                  0.5, 5e-5, 1e-3, 0.5e-3, 7)
-            else:
-                h = ops.cloud_mean_clamp(d, first, num, 0.5, 5e-5, 1e-3, 0.5e-3, 7)
+            h = ops.cloud_mean_clamp(d, first, num, 0.5, 5e-5, 1e-3, 0.5e-3, 7)
         elif raster_settings.Vrk_isotropic:
             h = (0.5 * d).clamp_(5e-5, 0.01)  # per point (rasterizer.py:383-388)
             sizes = [p.shape[0] for p in point_clouds.points_list()]

@@ -465,6 +465,15 @@ DSS_API int dss_knn_kth_sqdist(const float *points /* (P,3) */, const int64_t *f
  * lengths, K) of the regularisers, losses.py:157-180): dists (P,K) squared distances ascending in (distance, id),
  * idx (P,K) int64 cloud-local ids; the point itself is entry 0; clouds with fewer than K points are zero-padded
  * like pytorch3d's padded result.  1 <= K <= 40.  Same workspace as dss_knn_kth_sqdist. */
+/* dss_knn_kth_sqdist with the fixed-radius semantics of the reference's DEFAULT neighbour search: SurfaceSplatting is
+ * constructed with frnn_radius = 0.2 (rasterizer.py:110) and calls frnn.frnn_grid_points(K = 7, r = frnn_radius) (:317, :373),
+ * which reports a neighbour beyond r as -1 [third party lxxue/FRNN, not vendored]; `0.5 * sq_dist[:, :, 1:].max(-1)` (:320-324)
+ * is then the farthest neighbour FOUND within r, or -0.5 for a point that has none.  kth_sqdist[p] = the largest of the K - 1
+ * nearest non-self squared distances that is <= radius^2, -1 if there is none.  radius <= 0: exactly dss_knn_kth_sqdist (the
+ * reference's pytorch3d knn_points branch, frnn_radius <= 0). */
+DSS_API int dss_knn_kth_sqdist_radius(const float *points, const int64_t *first_idx, const int64_t *num_pts, int N,
+                                      int64_t P, int K, float radius, float *kth_sqdist, void *workspace,
+                                      size_t workspace_bytes, void *stream);
 DSS_API int dss_knn_points(const float *points /* (P,3) */, const int64_t *first_idx, const int64_t *num_pts,
                            int N, int64_t P, int K, float *dists /* (P,K) */, int64_t *idx /* (P,K) */,
                            void *workspace, size_t workspace_bytes, void *stream);
@@ -476,12 +485,25 @@ DSS_API int dss_cloud_mean_clamp(const float *values /* (P,) */, const int64_t *
  * mean of `h_k.mean(dim=1)` runs over P_max = the largest kept count of the batch, padding contributing zeros).  For the
  * masked (not compacted) representation: out[n] = clamp(sum over the points camera n keeps of values[p] * scale / max_m
  * kept_m, lo, hi); `fallback` for a camera that keeps fewer than min_points points.  values (Pw,) per WORLD point (the
- * K-th-neighbour distances within the whole cloud), world (Pw,3), V (N,4,4); shared_cloud = 1: one cloud of num_pts[0]
- * points for all cameras, else camera n sees world points [first_idx[n], first_idx[n] + num_pts[n]).  workspace: 16 N bytes. */
+ * K-th-neighbour distances), world (Pw,3), V (N,4,4); shared_cloud = 1: one cloud of num_pts[0] points for all cameras, else
+ * camera n sees world points [first_idx[n], first_idx[n] + num_pts[n]).  values_cam_stride: 0 = one value per world point
+ * (distances searched in the whole cloud: first order only); Pw = values (N, Pw) per (camera, point) from
+ * dss_knn_kth_sqdist_view (the reference's order, exact).  workspace: 16 N bytes. */
 DSS_API int dss_renderable_mean_clamp(const float *values, const float *world, const float *V, const float *znear,
                                       const float *zfar, const int64_t *first_idx, const int64_t *num_pts, int N,
                                       int shared_cloud, float scale, float lo, float hi, float fallback, int min_points,
-                                      float *out, void *workspace, size_t workspace_bytes, void *stream);
+                                      int64_t values_cam_stride, float *out, void *workspace, size_t workspace_bytes,
+                                      void *stream);
+/* dss_knn_kth_sqdist[_radius] in the reference's ORDER under depth culling: filter_renderable extends the cloud to the
+ * cameras and drops, per camera, the points outside [znear, zfar] BEFORE the neighbour search (rasterizer.py:599, 236-240,
+ * 183-217, 310-326), so a point's neighbours are the ones the same camera keeps.  shared_cloud = 1: ONE cloud (N == 1) seen
+ * by n_cams cameras, kth_sqdist (n_cams, P): row c = the statistic among the points camera c keeps (0 for the ones it drops);
+ * shared_cloud = 0: cloud n is seen by camera n (n_cams == N), kth_sqdist (P,).  K <= 8; radius as in
+ * dss_knn_kth_sqdist_radius.  Feed the result to dss_renderable_mean_clamp with values_cam_stride = P (shared) or 0. */
+DSS_API int dss_knn_kth_sqdist_view(const float *points, const int64_t *first_idx, const int64_t *num_pts, int N,
+                                    int64_t P, int K, float radius, const float *V, const float *znear, const float *zfar,
+                                    int n_cams, int shared_cloud, float *kth_sqdist, void *workspace,
+                                    size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Phong shading of the points = LightingTexture.forward (DSS/core/texture.py:65-125):

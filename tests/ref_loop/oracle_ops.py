@@ -105,14 +105,19 @@ def blend_backward(grad_out, idx, qvalue, scaler, num_points, geometry=None, wsu
     return torch.from_numpy(gf), torch.from_numpy(go)
 
 
-def knn_kth_sqdist(points, first, num, K=7):
+def knn_kth_sqdist(points, first, num, K=7, radius=None):
     out = torch.zeros(points.shape[0])
     for f, c in zip(first.tolist(), num.tolist()):
         if c == 0:
             continue
         p = points[f:f + c].double()
         d2 = torch.cdist(p, p) ** 2
-        out[f:f + c] = torch.kthvalue(d2, min(K, c), dim=1).values.float()  # self included (distance 0) as the first
+        if radius is not None and radius > 0:   # frnn_grid_points(K, r): the farthest of the K - 1 neighbours found within r, else -1
+            near = torch.topk(d2, min(K, c), dim=1, largest=False).values[:, 1:]
+            near = torch.where(near <= float(radius) ** 2, near, torch.full_like(near, -1.0))
+            out[f:f + c] = (near.amax(dim=1) if near.shape[1] else torch.full((c,), -1.0, dtype=torch.float64)).float()
+        else:
+            out[f:f + c] = torch.kthvalue(d2, min(K, c), dim=1).values.float()  # self included (distance 0) as the first
     return out
 
 
@@ -123,21 +128,42 @@ def cloud_mean_clamp(values, first, num, scale, lo, hi, fallback, min_points):
     return torch.tensor(out, dtype=torch.float32)
 
 
+def _kept(world, Vn, zn, zf):
+    """the depth test of the setup, same fp32 expression"""
+    w, v = world.float(), Vn.float()
+    z = w[:, 0] * v[0, 2] + w[:, 1] * v[1, 2] + w[:, 2] * v[2, 2] + 1.0 * v[3, 2]
+    return (z >= zn) & (z <= zf)
+
+
 def renderable_mean_clamp(values, world, V, znear, zfar, first, num, shared_cloud, scale, lo, hi, fallback, min_points):
-    """ops.renderable_mean_clamp: per camera the sum over the points it keeps (view z in [znear, zfar], the fp32 expression of
-    the setup) divided by the LARGEST kept count (the reference's mean over the padded batch, rasterizer.py:320-326)"""
+    """ops.renderable_mean_clamp: per camera the sum over the points it keeps divided by the LARGEST kept count (the
+    reference's mean over the padded batch, rasterizer.py:320-326); values (Pw,) or (N,Pw)"""
     N = V.shape[0]
     sums, cnts = [], []
     for n in range(N):
         f, c = (0, int(num[0])) if shared_cloud else (int(first[n]), int(num[n]))
-        w, v = world[f:f + c].float(), V[n].float()
-        z = w[:, 0] * v[0, 2] + w[:, 1] * v[1, 2] + w[:, 2] * v[2, 2] + 1.0 * v[3, 2]
-        ok = (z >= znear[n]) & (z <= zfar[n])
-        sums.append(float((values[f:f + c][ok].float() * scale).double().sum()))
+        ok = _kept(world[f:f + c], V[n], znear[n], zfar[n])
+        vals = values[n, f:f + c] if values.dim() == 2 else values[f:f + c]
+        sums.append(float((vals[ok].float() * scale).double().sum()))
         cnts.append(int(ok.sum()))
     pmax = max(cnts)
     return torch.tensor([float(min(max(s / pmax, lo), hi)) if (c >= min_points and pmax > 0) else float(min(max(fallback, lo), hi))
                          for s, c in zip(sums, cnts)], dtype=torch.float32)
+
+
+def knn_kth_sqdist_view(points, first, num, K, V, znear, zfar, shared_cloud, radius=None):
+    """ops.knn_kth_sqdist_view: the search among the points the camera keeps"""
+    n_cams, P = V.shape[0], points.shape[0]
+    out = torch.zeros((n_cams, P) if shared_cloud else (P,))
+    one = torch.zeros(1, dtype=torch.int64)
+    for n in range(n_cams):
+        f, c = (0, int(num[0])) if shared_cloud else (int(first[n]), int(num[n]))
+        ok = _kept(points[f:f + c], V[n], znear[n], zfar[n])
+        sub = points[f:f + c][ok]
+        vals = knn_kth_sqdist(sub, one, torch.tensor([sub.shape[0]]), K, radius) if sub.shape[0] else torch.zeros(0)
+        dst = out[n, f:f + c] if shared_cloud else out[f:f + c]
+        dst[ok] = vals
+    return out
 
 
 def _splat_points_occ_fast_cuda_backward(points_sorted, radii_sorted, rs, grad_occ, num_points_per_cloud,
@@ -192,6 +218,6 @@ def render_backward(grad_out, idx, qvalue, wsum, scaler, points, radii, visible,
 
 def install(ops_module) -> None:
     for name in ("point_setup", "project_backward", "splat_points", "splat_backward", "blend_forward", "blend_backward",
-                 "knn_kth_sqdist", "cloud_mean_clamp", "renderable_mean_clamp", "_splat_points_occ_fast_cuda_backward", "_backward_zbuf",
+                 "knn_kth_sqdist", "cloud_mean_clamp", "renderable_mean_clamp", "knn_kth_sqdist_view", "_splat_points_occ_fast_cuda_backward", "_backward_zbuf",
                  "render_forward", "render_backward"):
         setattr(ops_module, name, globals()[name])

@@ -144,3 +144,75 @@ def test_knn_points_lists_match_kdtree(K):
             sep[:, 1:] &= gap
             sep[:, :-1] &= gap
         assert (gi[:, :k][sep] == wi[sep]).all()
+
+
+def _ref_radius_stat(points, K, r):
+    """frnn_grid_points(K, r) followed by `sq_dist[:, :, 1:].max(-1)` (rasterizer.py:317-324): neighbours beyond r come back
+    as -1; the statistic is the farthest of the K - 1 nearest non-self neighbours that lies within r, -1 if there is none"""
+    P = points.shape[0]
+    if P == 0:
+        return np.zeros(0, np.float32)
+    k = min(K, P)
+    d, _ = cKDTree(points.astype(np.float64)).query(points.astype(np.float64), k=k)
+    d2 = d.reshape(P, -1)[:, 1:] ** 2
+    d2 = np.where(d2 <= float(r) ** 2, d2, -1.0)
+    return (d2.max(1) if d2.shape[1] else np.full(P, -1.0)).astype(np.float32)
+
+
+@pytest.mark.parametrize("r", [0.2, 0.05])
+def test_knn_fixed_radius_statistic_of_the_references_default_search(r):
+    """round 6: SurfaceSplatting's default frnn_radius = 0.2 selects frnn_grid_points(K = 7, r), whose
+    missing neighbours count as -1 -- an isolated point contributes -0.5 to the cloud's mean h."""
+    rng = np.random.default_rng(11)
+    bunny, _ = scenes.load_cloud("bunny")
+    surface = scenes.normalize_unit_sphere(bunny)[::3]
+    strays = rng.uniform(-3, 3, (60, 3)).astype(np.float32)          # far from everything: no neighbour within r
+    pairs = np.repeat(rng.uniform(4, 5, (10, 3)), 2, 0).astype(np.float32) + rng.normal(0, 0.01, (20, 3)).astype(np.float32)
+    clouds = [np.concatenate([surface, strays, pairs]), rng.uniform(-1, 1, (4000, 3)).astype(np.float32)]
+    pts = np.concatenate(clouds, 0)
+    num = np.array([c.shape[0] for c in clouds], np.int64)
+    first = np.cumsum(num) - num
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    got = ops.knn_kth_sqdist(t(pts), t(first), t(num), 7, radius=r).cpu().numpy()
+    want = np.concatenate([_ref_radius_stat(c, 7, r) for c in clouds])
+    assert ((got < 0) == (want < 0)).all() and (want < 0).sum() >= 40
+    assert np.allclose(got, want, rtol=2e-5, atol=1e-9), np.abs(got - want).max()
+    # radius None / <= 0: the plain K-th distance
+    assert torch.equal(ops.knn_kth_sqdist(t(pts), t(first), t(num), 7, radius=-1.0), ops.knn_kth_sqdist(t(pts), t(first), t(num), 7))
+
+
+@pytest.mark.parametrize("shared", [True, False])
+def test_knn_statistic_in_the_references_order_under_depth_culling(shared):
+    """The reference drops, per camera, the points outside [znear, zfar] BEFORE its neighbour search and takes the mean over
+    the padded batch (rasterizer.py:599, 183-217, 310-326): `knn_kth_sqdist_view` + `renderable_mean_clamp` against a KD-tree
+    over each camera's kept subset."""
+    rng = np.random.default_rng(5)
+    bunny, _ = scenes.load_cloud("bunny")
+    base = scenes.normalize_unit_sphere(bunny)[::2].astype(np.float32)
+    Mn, Vn, _ = scenes.camera_matrices([1.3, 1.6, 2.5], [10.0, 40.0, -20.0], [0.0, 120.0, 250.0])
+    N = Vn.shape[0]
+    znear, zfar = np.array([1.0, 1.2, 1.0], np.float32), np.array([100.0, 1.9, 2.6], np.float32)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    clouds = [base] if shared else [base, base[::2] * 1.1, base[1::3]]
+    pts = np.concatenate(clouds, 0)
+    num = np.array([c.shape[0] for c in clouds], np.int64)
+    first = np.cumsum(num) - num
+    r = 0.2
+    got = ops.knn_kth_sqdist_view(t(pts), t(first), t(num), 7, t(Vn), t(znear), t(zfar), shared, radius=r).cpu().numpy()
+    sums, cnts = [], []
+    for n in range(N):
+        c = clouds[0] if shared else clouds[n]
+        z = c[:, 0] * Vn[n, 0, 2] + c[:, 1] * Vn[n, 1, 2] + c[:, 2] * Vn[n, 2, 2] + Vn[n, 3, 2]
+        ok = (z >= znear[n]) & (z <= zfar[n])
+        assert 0 < ok.sum() < c.shape[0]                      # every camera drops something
+        want = _ref_radius_stat(c[ok], 7, r)
+        mine = got[n] if shared else got[first[n]:first[n] + num[n]]
+        assert np.allclose(mine[ok], want, rtol=2e-5, atol=1e-9), (n, np.abs(mine[ok] - want).max())
+        assert (mine[~ok] == 0).all()
+        sums.append(float((0.5 * want.astype(np.float64)).sum()))
+        cnts.append(int(ok.sum()))
+    f1 = t(np.zeros(N, np.int64)) if shared else t(first)
+    n1 = t(np.full(N, num[0], np.int64)) if shared else t(num)
+    h = ops.renderable_mean_clamp(t(got), t(pts), t(Vn), t(znear), t(zfar), f1, n1, shared, 0.5, 5e-5, 1e-3, 0.5e-3, 7).cpu().numpy()
+    want_h = np.clip(np.array(sums) / max(cnts), 5e-5, 1e-3)   # mean over the PADDED batch: the largest kept count
+    assert np.allclose(h, want_h, rtol=1e-5), (h, want_h)

@@ -73,6 +73,40 @@ def test_owner_mode_from_the_dense_alpha_plane_equals_owner_mode_from_the_full_g
         assert float(a[1].abs().max()) > 0
 
 
+def test_band_outputs_only_hands_out_zeros_not_uninitialised_memory():
+    """ADVICE r5: with DSS_WS_BAND_OUTPUTS the library writes ellipse / scaler / cutoff only for the splats that meet the band;
+    the rest of those three arrays must be DEFINED (zero), whatever the allocator's memory held before."""
+    import scenes
+    from dss_amd import ops
+    dev = torch.device("cuda:0")
+    S, K, N = 128, 5, 1
+    pts, nrm = scenes.load_cloud("bunny")
+    pts = scenes.normalize_unit_sphere(pts)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    world, normals = t(pts), t(nrm)
+    Pc = world.shape[0]
+    col = torch.rand((Pc, 3), generator=torch.Generator().manual_seed(2)).to(dev)
+    Mn, Vn, _ = scenes.camera_matrices(2.0, 30.0, 45.0)
+    M, V = t(Mn), t(Vn)
+    zn, zf = torch.full((N,), 0.1, device=dev), torch.full((N,), 100.0, device=dev)
+    first = torch.zeros(N, device=dev, dtype=torch.int64)
+    num = torch.full((N,), Pc, device=dev, dtype=torch.int64)
+    h = torch.full((N,), 4e-4, device=dev)
+    args = (world, normals, h, M, V, zn, zf, first, num, col, S, K, 1.0, 0.05, 1.0, False, True)
+    full = ops.render_forward(*args)
+    for _ in range(3):   # poison the allocator's free blocks, then render a band
+        junk = torch.full((Pc * 8,), float("nan"), device=dev)
+        del junk
+        f = ops.render_forward(*args, rows=(32, 48), band_outputs_only=True)
+        for k in ("ellipse_params", "scaler", "cutoff_threshold"):
+            a, b = f[k].reshape(Pc, -1), full[k].reshape(Pc, -1)
+            assert bool(torch.isfinite(a).all()), k
+            written = (a == b).all(dim=1)
+            assert bool(((a == 0).all(dim=1) | written).all()), k       # either the splat's values or zeros
+        assert bool((f["scaler"] != 0).any()) and bool((f["scaler"] == 0).any())
+        assert torch.equal(f["idx"], full["idx"][:, 32:48]) and torch.equal(f["image"], full["image"][:, 32:48])
+
+
 _TWO_RANK = '''
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))

@@ -143,7 +143,7 @@ def scalars_of(stack, batch, it):
 
 
 if LOAD:
-    st = torch.load(LOAD)
+    st = torch.load(LOAD, weights_only=False)   # (our own file: model state, filter object, batch)
     for S_ in (A, Pb):
         S_.model.load_state_dict(st["model"])
         S_.model.points_filter = copy.deepcopy(st["points_filter"])

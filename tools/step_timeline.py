@@ -12,6 +12,8 @@ import collections
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "gpurun_out", "timeline")
 mode = sys.argv[1] if len(sys.argv) > 1 else "graph"
+import shutil
+shutil.rmtree(OUT, ignore_errors=True)   # (the traces of an earlier run in the same directory would be averaged in)
 subprocess.run(["rocprofv3", "--kernel-trace", "--output-format", "csv", "-d", OUT, "--", sys.executable,
                 os.path.join(ROOT, "bench.py"), "--mode", mode, "--timed-only", "--steps", "100", "--warmup", "10"],
                cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
