@@ -13,7 +13,7 @@ __device__ __forceinline__ float eps_sqrt_py(float d) { return fmaxf(fabsf(d), 1
 
 struct SetupArgs {
     const float *world, *normals;     // (Pw,3)
-    const float *h_point;             // (Pw,) or nullptr
+    const float *h_point;             // (Pw,) or nullptr; with h_cloud also given: (P,) per packed point
     const float *h_cloud;             // (N,) or nullptr
     const float *vr6, *frame_n;       // anisotropic mode: (Pw,6) Vrk xx,xy,xz,yy,yz,zz + (Pw,3) PCA normal; or nullptr
     const float *M, *V;               // (N,4,4) row-vector convention
@@ -91,7 +91,9 @@ __device__ __forceinline__ SetupVals setup_point_compute(const SetupArgs &A, int
             const bool aniso = A.vr6 != nullptr;
             const float f0 = aniso ? A.frame_n[3 * wi] : n0, f1 = aniso ? A.frame_n[3 * wi + 1] : n1,
                         f2 = aniso ? A.frame_n[3 * wi + 2] : n2;
-            const float hh = aniso ? 0.0f : (A.h_point ? A.h_point[wi] : A.h_cloud[n]);
+            // h_point AND h_cloud given: h_point holds one value per PACKED point (a shared cloud whose cameras cull differently:
+            // the reference evaluates the isotropic scale on each camera's filtered cloud, rasterizer.py:344-402)
+            const float hh = aniso ? 0.0f : (A.h_point ? A.h_point[A.h_cloud ? p : wi] : A.h_cloud[n]);
             // Sk^T Sk = I - n^ n^^T with the NORMALISED normal (rasterizer.py:337-341); zero normal -> 0
             const float nlen = sqrtf(f0 * f0 + f1 * f1 + f2 * f2);
             const float nden = nlen > 1e-12f ? nlen : 1e-12f;

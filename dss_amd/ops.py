@@ -495,8 +495,9 @@ def render_forward(world, normals, h, M, V, znear, zfar, cloud_to_packed_first_i
     if features.shape[0] != P:
         raise RuntimeError("features must be packed (P,C) with P=%d, got %s" % (P, tuple(features.shape)))
     per_point = h.numel() == Pw and not (h.numel() == N and Pw == N)
-    if not per_point and h.numel() != N:
-        raise RuntimeError("h must have %d (per point) or %d (per cloud) entries" % (Pw, N))
+    packed_h = (not per_point) and shared_cloud and N > 1 and h.numel() == P    # one value per (camera, point) pair
+    if not per_point and not packed_h and h.numel() != N:
+        raise RuntimeError("h must have %d (per point), %d (per cloud) or, for a shared cloud, %d (per packed point) entries" % (Pw, N, P))
     S, K, C = int(image_size), int(points_per_pixel), features.shape[1]
     row0, row1, cyc = _band(rows, S)
     nr = band_rows(row0, row1, cyc)
@@ -543,7 +544,7 @@ def render_forward(world, normals, h, M, V, znear, zfar, cloud_to_packed_first_i
         if band_outputs_only and (int(workspace_state) & 0xf) != 2:
             state |= _lib.WS_BAND_OUTPUTS
         rc = lib.dss_render_forward(
-            _lib.ptr(world), _lib.ptr(normals), _lib.ptr(h) if per_point else None, None if per_point else _lib.ptr(h),
+            _lib.ptr(world), _lib.ptr(normals), _lib.ptr(h) if (per_point or packed_h) else None, None if per_point else _lib.ptr(h),
             vr_p, fn_p, _lib.ptr(M), _lib.ptr(V), _lib.ptr(znear), _lib.ptr(zfar), _lib.ptr(first), _lib.ptr(num), N, P,
             int(shared_cloud), int(backface_culling), S, K, float(cutoff_threshold), float(antialiasing_sigma),
             float(depth_merging_thres), row0, row1, cyc, _lib.ptr(features), C, _lib.ptr(o["pts_screen"]),
@@ -709,7 +710,8 @@ class FusedPlan:
     def __init__(self, device, N, Pw, P, S, K, C, shared, per_point_h, aniso, backface, cutoff, sigma, thr, want_zbuf=True):
         self.lib = _lib.load()
         self.dev, self.N, self.Pw, self.P, self.S, self.K, self.C = device, N, Pw, P, S, K, C
-        self.shared, self.per_point_h, self.aniso = bool(shared), bool(per_point_h), bool(aniso)
+        # per_point_h: 0 = one h per cloud, 1 = per world point, 2 = per PACKED point (shared cloud, cameras that cull differently)
+        self.shared, self.per_point_h, self.aniso = bool(shared), int(per_point_h), bool(aniso)
         off = [0]
 
         def take(nbytes):
@@ -764,7 +766,7 @@ class FusedPlan:
             b = arena.data_ptr()
             hp = h.data_ptr()
             rc = lib.dss_render_forward(
-                world.data_ptr(), normals.data_ptr(), hp if self.per_point_h else None, None if self.per_point_h else hp,
+                world.data_ptr(), normals.data_ptr(), hp if self.per_point_h else None, None if self.per_point_h == 1 else hp,
                 None if vr6 is None else vr6.data_ptr(), None if frame_n is None else frame_n.data_ptr(),
                 M.data_ptr(), V.data_ptr(), znear.data_ptr(), zfar.data_ptr(), first.data_ptr(), num.data_ptr(), N, P,
                 shared, backface, S, K, cutoff, sigma, thr, 0, S, 1, feats.data_ptr(), C,
@@ -868,8 +870,9 @@ def point_setup(world, normals, h, M, V, znear, zfar, cloud_to_packed_first_idx,
         raise RuntimeError("normals must match world points")
     P = N * Pw if shared_cloud else Pw
     per_point = h.numel() == Pw and not (h.numel() == N and Pw == N)
-    if not per_point and h.numel() != N:
-        raise RuntimeError("h must have %d (per point) or %d (per cloud) entries" % (Pw, N))
+    packed_h = (not per_point) and shared_cloud and N > 1 and h.numel() == P    # one value per (camera, point) pair
+    if not per_point and not packed_h and h.numel() != N:
+        raise RuntimeError("h must have %d (per point), %d (per cloud) or, for a shared cloud, %d (per packed point) entries" % (Pw, N, P))
     with torch.cuda.device(dev):
         out = dict(pts_screen=torch.empty((P, 3), dtype=_f32, device=dev),
                    ellipse_params=torch.empty((P, 3), dtype=_f32, device=dev),
@@ -878,7 +881,7 @@ def point_setup(world, normals, h, M, V, znear, zfar, cloud_to_packed_first_idx,
                    cutoff_threshold=torch.empty((P,), dtype=_f32, device=dev))
         valid = torch.empty((P,), dtype=_u8, device=dev)
         _keep, vr_p, fn_p = _aniso_args(vr6, frame_normals, Pw)
-        rc = lib.dss_point_setup(_lib.ptr(world), _lib.ptr(normals), _lib.ptr(h) if per_point else None,
+        rc = lib.dss_point_setup(_lib.ptr(world), _lib.ptr(normals), _lib.ptr(h) if (per_point or packed_h) else None,
                                  None if per_point else _lib.ptr(h), vr_p, fn_p, _lib.ptr(M), _lib.ptr(V), _lib.ptr(znear),
                                  _lib.ptr(zfar), _lib.ptr(first), _lib.ptr(num), N, P, int(shared_cloud),
                                  int(backface_culling), int(image_size), float(cutoff_threshold),

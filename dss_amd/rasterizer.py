@@ -281,50 +281,56 @@ class SurfaceSplatting(torch.nn.Module):
     # -- source-space variance scale h (rasterizer.py:293-402) ------------------------------------
     def _variance_scale(self, point_clouds, raster_settings, refresh=True, view=None):
         """``view`` = (V (N,4,4), znear (N,), zfar (N,), shared): the cameras of this render.  The reference computes the
-        Vrk_invariant statistic AFTER `filter_renderable` has extended the cloud to the cameras and dropped the points outside
-        each camera's depth range (rasterizer.py:599, 236-240, 183-217): one h per camera, the mean taken over the padded
-        length of the batch (:325).  With it the masked representation follows that order to first order
-        (`ops.renderable_mean_clamp`); without it (callers outside a render) the mean runs over the whole clouds."""
+        statistic AFTER `filter_renderable` has extended the cloud to the cameras and dropped, per camera, the points outside
+        its depth range (rasterizer.py:599, 236-240, 183-217): the neighbours of a point are the ones the SAME camera keeps,
+        Vrk_invariant takes one h per camera as a mean over the padded length of the batch (:325), Vrk_isotropic one h per
+        (camera, point).  With ``view`` the search runs in that order (`ops.knn_kth_sqdist_view`: one grid build, one query
+        launch with a grid row per camera); without it (callers outside a render) over the whole clouds.
+        ``frnn_radius`` > 0 (the reference's default 0.2) selects its fixed-radius search, which reports neighbours beyond the
+        radius as -1 (rasterizer.py:316-319): honoured -- it decides h once points have drifted away from the surface."""
         n_total = sum(p.shape[0] for p in point_clouds.points_list())
         if not refresh and self._Vrk_h is not None and (raster_settings.Vrk_invariant or
                                                        self._Vrk_h.shape[0] == n_total):  # rasterizer.py:359-361
             return self._Vrk_h
         first, num = point_clouds.cloud_to_packed_first_idx(), point_clouds.num_points_per_cloud()
-        # `frnn_radius` > 0 (the reference's default 0.2): its fixed-radius search reports neighbours beyond the radius as -1
-        # (rasterizer.py:316-319) -- honoured: it decides h once points have drifted away from the surface
+        sizes = [p.shape[0] for p in point_clouds.points_list()]
         radius = self.frnn_radius if (self.frnn_radius is not None and self.frnn_radius > 0) else -1.0
-        if raster_settings.Vrk_invariant and view is not None:
-            # the reference's order: per camera, drop the points outside its depth range, THEN search the neighbours among the
-            # kept ones, then the mean over the padded batch (rasterizer.py:599, 183-217, 310-326) -- one grid build, one query
-            # launch with a grid row per camera (`ops.knn_kth_sqdist_view`), one masked mean
+        invariant, isotropic = bool(raster_settings.Vrk_invariant), bool(raster_settings.Vrk_isotropic)
+        if not invariant and not isotropic:
+            h = torch.zeros(n_total, device=point_clouds.device)   # unused: the anisotropic variance comes from _local_frames
+            self._Vrk_h = h
+            return h
+        pts = point_clouds.points_packed().detach()
+        if view is not None:
             V, znear, zfar, shared = view
             N = V.shape[0]
-            pts = point_clouds.points_packed().detach()
             with torch.no_grad():
-                d = ops.knn_kth_sqdist_view(pts, first, num, 7, V, znear, zfar, shared, radius=radius)
-                if shared:
-                    f1, n1 = first.new_zeros(N), num[:1].expand(N).contiguous()
+                d = ops.knn_kth_sqdist_view(pts, first, num, 7, V, znear, zfar, shared, radius=radius)   # (N,Pw) shared, else (P,)
+                if invariant:
+                    f1, n1 = (first.new_zeros(N), num[:1].expand(N).contiguous()) if shared else (first, num)
+                    h = ops.renderable_mean_clamp(d, pts, V, znear, zfar, f1, n1, shared, 0.5, 5e-5, 1e-3, 0.5e-3, 7)
                 else:
-                    f1, n1 = first, num
-                h = ops.renderable_mean_clamp(d, pts, V, znear, zfar, f1, n1, shared, 0.5, 5e-5, 1e-3, 0.5e-3, 7)
+                    # per point (rasterizer.py:383-388); for a shared cloud one value per (camera, point) pair, packed like
+                    # the extended cloud
+                    h = (0.5 * d).clamp_(5e-5, 0.01).reshape(-1)
+                    if min(sizes) < 7:   # "knn search is unreliable, set sq_dist manually" (rasterizer.py:378-379)
+                        small = torch.cat([torch.full((n,), n < 7, dtype=torch.bool) for n in sizes]).to(h.device)
+                        small = small.repeat(N) if (shared and N > 1) else small
+                        h = torch.where(small, torch.full_like(h, 0.5e-3), h)
             self._Vrk_h = h
             return h
         with torch.no_grad():
             # through dss_amd.neighbours: one search serves this statistic and the regularisers of the same iteration
-            d = neighbours.kth_sqdist(point_clouds.points_packed(), first, num,
-                                      [p.shape[0] for p in point_clouds.points_list()], 7, radius=radius)
-        if raster_settings.Vrk_invariant:
+            d = neighbours.kth_sqdist(pts, first, num, sizes, 7, radius=radius)
+        if invariant:
             # one scalar per cloud: mean_i(0.5 max kNN-7 d^2) clamped to [5e-5, 1e-3]; clouds with fewer than
             # 7 points use sq_dist = 1e-3 (rasterizer.py:320-326)
             h = ops.cloud_mean_clamp(d, first, num, 0.5, 5e-5, 1e-3, 0.5e-3, 7)
-        elif raster_settings.Vrk_isotropic:
+        else:
             h = (0.5 * d).clamp_(5e-5, 0.01)  # per point (rasterizer.py:383-388)
-            sizes = [p.shape[0] for p in point_clouds.points_list()]
             if min(sizes) < 7:  # "knn search is unreliable, set sq_dist manually" (rasterizer.py:378-379): 0.5 * 1e-3
                 small = torch.cat([torch.full((n,), n < 7, dtype=torch.bool) for n in sizes]).to(h.device)
                 h = torch.where(small, torch.full_like(h, 0.5e-3), h)
-        else:
-            h = torch.zeros_like(d)  # unused: the anisotropic variance comes from _local_frames
         self._Vrk_h = h
         return h
 
@@ -569,7 +575,9 @@ class SurfaceSplatting(torch.nn.Module):
             return None
         P = N * Pw if a["shared"] else Pw
         h = a["h"]
-        per_point = h.numel() == Pw and not (h.numel() == N and Pw == N)
+        per_point = 1 if (h.numel() == Pw and not (h.numel() == N and Pw == N)) else 0
+        if not per_point and a["shared"] and N > 1 and h.numel() == P:
+            per_point = 2          # one value per (camera, point) pair
         if feats.shape[0] != P or (not per_point and h.numel() != N) or P == 0:
             return None
         key = (dev, N, Pw, P, int(st.image_size), int(st.points_per_pixel), feats.shape[1], bool(a["shared"]), per_point,

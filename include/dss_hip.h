@@ -394,7 +394,9 @@ DSS_API int dss_render_backward_gather(const float *grad_out, const int32_t *idx
  *   pytorch3d PointsRasterizer.transform (rasterizer.py:614: NDC x,y + view-space z),
  *   _compute_WJk (:443-496), Vrk = h (I - n n^T) (:293-402), _compute_variance_and_detMk (:404-441),
  *   _get_per_point_info / _get_ellipse_axis_aligned_radius (:525-565, :498-523).
- *   world, normals (Pw,3); h_point (Pw,) or h_cloud (N,) (exactly one may be NULL);
+ *   world, normals (Pw,3); h_point (Pw,) or h_cloud (N,) (one of them NULL); BOTH non-NULL: h_point is (P,), one value per
+ *   PACKED point, h_cloud is not read (a shared cloud whose cameras cull differently: the reference evaluates the isotropic
+ *   scale on each camera's filtered cloud, rasterizer.py:344-402);
  *   anisotropic mode (Vrk_invariant = Vrk_isotropic = False, rasterizer.py:256-291): vr6 (Pw,6) = Vrk per point
  *   (xx,xy,xz,yy,yz,zz) and frame_normals (Pw,3) = normal of the PCA frame, both from dss_local_frames; h is then
  *   unused and may be NULL;

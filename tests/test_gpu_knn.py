@@ -216,3 +216,44 @@ def test_knn_statistic_in_the_references_order_under_depth_culling(shared):
     h = ops.renderable_mean_clamp(t(got), t(pts), t(Vn), t(znear), t(zfar), f1, n1, shared, 0.5, 5e-5, 1e-3, 0.5e-3, 7).cpu().numpy()
     want_h = np.clip(np.array(sums) / max(cnts), 5e-5, 1e-3)   # mean over the PADDED batch: the largest kept count
     assert np.allclose(h, want_h, rtol=1e-5), (h, want_h)
+
+
+@pytest.mark.parametrize("mode", ["invariant", "isotropic"])
+def test_masked_culling_renders_what_the_references_drop_then_search_order_renders(mode):
+    """Round 6: with cameras that cull DIFFERENT points of one shared cloud, the sync-free masked path (culled points keep their
+    slot) must give the image of the reference's order -- extend, drop per camera, THEN search the neighbours and derive h
+    (`compact_culled=True` does literally that, with host syncs): the variance scale is per camera (invariant: mean over the
+    padded batch) or per (camera, point) pair (isotropic), from the fixed-radius search of the default frnn_radius = 0.2."""
+    from dss_amd.renderer import NormWeightedCompositor, SurfaceSplattingRenderer
+    bunny, nrm = scenes.load_cloud("bunny")
+    pts = scenes.normalize_unit_sphere(bunny)
+    rng = np.random.default_rng(2)
+    # a few strays (no neighbour within 0.2) and a cloud deep enough that tight depth ranges cut it differently per camera
+    strays = rng.uniform(-1.5, 1.5, (2, 3)).astype(np.float32)   # (each pulls the mean h down by 0.5 / P: two keep it unclamped)
+    pts = np.concatenate([pts, strays]).astype(np.float32)
+    nrm = np.concatenate([nrm, np.tile(np.array([[0, 0, 1]], np.float32), (2, 1))]).astype(np.float32)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    R, T = look_at_view_transform([2.0, 2.2], [20.0, -10.0], [30.0, 200.0])
+    cams = FoVPerspectiveCameras(fov=60.0, R=R, T=T, device=DEV)
+    cams.znear = torch.tensor([1.9, 1.0], device=DEV)
+    cams.zfar = torch.tensor([100.0, 2.3], device=DEV)
+    st = PointsRasterizationSettings(backface_culling=False, cutoff_threshold=1.0, depth_merging_threshold=0.05,
+                                     Vrk_invariant=mode == "invariant", Vrk_isotropic=mode == "isotropic",
+                                     radii_backward_scaler=5.0, image_size=128, points_per_pixel=5, bin_size=None,
+                                     clip_pts_grad=0.05, antialiasing_sigma=1.0)
+    col = torch.rand((pts.shape[0], 3), generator=torch.Generator().manual_seed(1)).to(DEV)
+    images, hs = {}, {}
+    for compact in (False, True):
+        ras = SurfaceSplatting(cameras=cams, raster_settings=st, compact_culled=compact)
+        ren = SurfaceSplattingRenderer(ras, NormWeightedCompositor())
+        with torch.no_grad():
+            images[compact] = ren(PointClouds3D([t(pts)], [t(nrm)], [col]))
+        hs[compact] = ras._Vrk_h
+        if not compact:
+            assert hs[compact].numel() == (2 if mode == "invariant" else 2 * pts.shape[0])
+    if mode == "invariant":   # one h per camera, the same in both orders, not clamped away, different per camera
+        assert torch.allclose(hs[False], hs[True], rtol=1e-6), (hs[False], hs[True])
+        assert 5e-5 < float(hs[False].min()) and float(hs[False].max()) < 1e-3 and float(hs[False][0]) != float(hs[False][1]), hs[False]
+    a, b = images[False], images[True]
+    assert a.shape == b.shape and float(a[..., 3].sum()) > 500
+    assert torch.equal(a[..., 3], b[..., 3]) and float((a - b).abs().max()) <= 1e-6, float((a - b).abs().max())

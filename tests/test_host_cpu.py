@@ -155,7 +155,7 @@ def test_neighbour_cache_logic_with_a_cpu_stand_in(monkeypatch):
         calls["lists"] += 1
         return brute(points, K)
 
-    def kth(points, first, num, K):
+    def kth(points, first, num, K, radius=None):
         calls["kth"] += 1
         return brute(points, K)[0][:, K - 1].contiguous()
 
