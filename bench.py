@@ -214,7 +214,7 @@ class Workload:
         st["g_band"], st["losses"] = ops.image_loss_band_backward_partials(
             st["band"], self.target_rgb, self.target_mask, self.part.rows, 1.0, 1.0, st["sums"], band_targets=self.band_targets,
             alpha_out=self.engine.alpha_send_view())
-        self.engine.bwd_begin(st["g_band"], alpha_packed=True)
+        self.engine.bwd_begin(st["g_band"], alpha_packed=True, full=False)
 
     def _st_backward(self):
         self.engine.bwd_compute(RADII_S, CLIP, self.world, self.M, self.V, self.first, self.num, f=self._st["f"],

@@ -601,6 +601,14 @@ class SurfaceSplatting(torch.nn.Module):
         dev, N, Pw = a["world"].device, a["N"], a["world"].shape[0]
         P = N * Pw if a["shared"] else Pw
         S, K, C = int(st.image_size), int(st.points_per_pixel), int(feats.shape[1])
+        if part.cyclic and C != 3:
+            # the tile-row-cyclic variants of the backward are built for RGB features (include/dss_hip.h)
+            if kwargs.get("row_partition_auto", False):
+                from .distributed import RowPartition
+                part = RowPartition(S, part.world_size, part.rank)          # contiguous equal bands instead
+            else:
+                raise ValueError("a tile-row-cyclic row partition needs 3 feature channels, got %d: use contiguous bands "
+                                 "(RowPartition(S, world, rank) or row_partition='bands')" % C)
         from .sharded import choose_gradient_exchange
         band_only = bool(kwargs.get("band_only", False))
         gradient = kwargs.get("gradient_exchange", "auto")
@@ -738,7 +746,7 @@ class _RenderRowSharded(autograd.Function):
         # Model.prune_points, an evaluation pass -- must not change what this node differentiates)
         vis = engine.start_exchange().clone()
         ctx.save_for_backward(world)
-        ctx.engine, ctx.f, ctx.vis, ctx.aux = engine, f, vis, (M, V, first, num, radii_s, clip)
+        ctx.engine, ctx.f, ctx.vis, ctx.aux = engine, f, vis, (M, V, first, num, radii_s, clip, not band_only)
         # band_only: the image all-gather stays in flight behind the loss and the backward (`engine.full_image()` waits for
         # it; the next forward does before it overwrites the send buffer)
         image = engine.band_image if band_only else engine.full_image()
@@ -747,8 +755,8 @@ class _RenderRowSharded(autograd.Function):
     @staticmethod
     def backward(ctx, g_image):
         (world,) = ctx.saved_tensors
-        M, V, first, num, radii_s, clip = ctx.aux
-        g_world, g_feat = ctx.engine.backward(g_image, radii_s, clip, world, M, V, first, num, f=ctx.f, vis_all=ctx.vis)
+        M, V, first, num, radii_s, clip, full = ctx.aux
+        g_world, g_feat = ctx.engine.backward(g_image, radii_s, clip, world, M, V, first, num, f=ctx.f, vis_all=ctx.vis, full=full)
         return g_world.clone(), g_feat.clone(), None, None
 
 

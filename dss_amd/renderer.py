@@ -145,7 +145,8 @@ class SurfaceSplattingRenderer(torch.nn.Module):
                 raise RuntimeError("a row-partitioned render needs dss_amd's SurfaceSplatting, a NormWeightedCompositor and "
                                    "the masked culling path (backface_culling off or compact_culled=False)")
             kw = {k: v for k, v in kwargs.items() if k != "fragments"}
-            kw.update(row_partition=part, gradient_exchange=self.gradient_exchange, process_group=self.process_group,
+            kw.update(row_partition=part, row_partition_auto=isinstance(self.row_partition, str) and self.row_partition == "auto",
+                      gradient_exchange=self.gradient_exchange, process_group=self.process_group,
                       band_only=kwargs.get("band_only", self.row_output == "band"),
                       want_fragments=bool(kwargs.get("verbose", False)))
             if self.order_refresh > 0 and "order_refresh" not in kw:

@@ -211,17 +211,22 @@ class RowShardedRender:
             self.alpha_x = AlphaPlaneExchange(self.part, self.N, self.dev, group=self.group)
         return self.alpha_x.send[:self.part.n_rows].permute(1, 0, 2)
 
-    def bwd_begin(self, grad, alpha_packed: bool = False):
+    def bwd_begin(self, grad, alpha_packed: bool = False, full=None):
         """stage 1 (compute): the band's gradient, contiguous; band loss + owner form: the alpha channel packed for its
         exchange (unless the producer of ``grad`` already wrote it into `alpha_send_view()`).  ``grad``: gradient of the FULL
         image (N,S,S,C+1) -- replicated loss -- or of this rank's band."""
         p, S = self.part, self.S
         rows = p.n_rows
         banded = p.world_size > 1          # (a forced world of one owns every row: the plain backward, then the collectives)
-        full = banded and grad.shape[1] == S and rows != S
-        if not full and grad.shape[1] != rows:
-            raise RuntimeError("grad must be the full image gradient (N,%d,S,C+1) or the band's (N,%d,S,C+1), got %s"
-                               % (S, rows, tuple(grad.shape)))
+        # whether `grad` is the full image's gradient decides which COLLECTIVES the step issues (band loss + owner form: the
+        # alpha-plane exchange): every rank must decide alike, so the caller says so (`full`); inferring it from the shape is
+        # only unambiguous when no rank owns all the rows or none
+        if full is None:
+            full = banded and grad.shape[1] == S and rows != S
+        full = bool(full) and banded
+        if grad.shape[1] != (S if full else rows):
+            raise RuntimeError("grad must be the full image gradient (N,%d,S,C+1) or the band's (N,%d,S,C+1), got %s (full=%s)"
+                               % (S, rows, tuple(grad.shape), full))
         st = {"full": full, "banded": banded, "grad": grad.contiguous() if full else None}
         st["g_band"] = p.slice(grad).contiguous() if full else grad.contiguous()
         st["alpha"] = self.owner and banded and not full
@@ -305,12 +310,13 @@ class RowShardedRender:
         self._mark("projection_compute")
         return g_world, g_feat
 
-    def backward(self, grad, radii_s: float, clip: float, world, M, V, first, num, f=None, vis_all=None):
+    def backward(self, grad, radii_s: float, clip: float, world, M, V, first, num, f=None, vis_all=None, full=None):
         """Backward of this rank's rows + the gradient exchange.  ``grad`` is either the gradient of the FULL image
         (N, S, S, C+1) -- replicated loss -- or of the rank's band (N, rows, S, C+1) -- band loss.
         -> (grad_world (Pw,3), grad_features ((Pw,C) if `features_shared` else (P,C))): the sums over all ranks, identical on
-        every rank, in buffers this object owns (overwritten by the next backward)."""
-        self.bwd_begin(grad)
+        every rank, in buffers this object owns (overwritten by the next backward).  ``full``: say which of the two it is
+        (every rank must take the same branch; None infers it from the shape, ambiguous when a rank owns all rows or none)."""
+        self.bwd_begin(grad, full=full)
         self.bwd_exchange_alpha()
         self._mark("wait_alpha_allgather")
         self.bwd_compute(radii_s, clip, world, M, V, first, num, f=f, vis_all=vis_all)

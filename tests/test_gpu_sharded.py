@@ -199,3 +199,132 @@ def test_row_partitioned_renderer_classes_match_the_single_gpu_renderer(tmp_path
                          env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-12000:]
     assert os.path.exists(os.path.join(str(tmp_path), "ok0")) and os.path.exists(os.path.join(str(tmp_path), "ok1"))
+
+
+_TWO_RANK_EDGE = '''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import numpy as np
+import scenes
+from dss_amd.cameras import FoVPerspectiveCameras, look_at_view_transform
+from dss_amd.cloud import PointClouds3D, PointCloudsFilters
+from dss_amd.distributed import RowPartition
+from dss_amd.rasterizer import PointsRasterizationSettings, SurfaceSplatting
+from dss_amd.renderer import NormWeightedCompositor, SurfaceSplattingRenderer
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dev = torch.device("cuda:0"); torch.cuda.set_device(dev)
+dist.init_process_group("gloo")
+pts, nrm = scenes.load_cloud("bunny")
+pts = scenes.normalize_unit_sphere(pts)
+t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+rel = lambda a, b: float((a - b).norm() / b.norm().clamp_min(1e-30))
+gen = torch.Generator().manual_seed(7)
+
+
+def settings(S, **kw):
+    d = dict(backface_culling=False, cutoff_threshold=1.0, depth_merging_threshold=0.05, Vrk_invariant=True, Vrk_isotropic=False,
+             radii_backward_scaler=5.0, image_size=S, points_per_pixel=5, bin_size=None, clip_pts_grad=0.05, antialiasing_sigma=1.0)
+    d.update(kw)
+    return PointsRasterizationSettings(**d)
+
+
+def case(name, S, cams, clouds_fn, st, parts, verbose=False, with_filter=False, **ren_kw):
+    """plain renderer vs the row-partitioned one: image bit for bit, gradients of a fixed linear functional of the image"""
+    out = {}
+    for key, part in (("single", None),) + tuple(("part%%d" %% i, p) for i, p in enumerate(parts)):
+        Xs, Cs, cloud = clouds_fn()
+        ras = SurfaceSplatting(cameras=cams, raster_settings=st)
+        kw = dict(ren_kw)
+        if part is not None:
+            kw["row_partition"] = part
+            if isinstance(part, str):
+                from dss_amd.sharded import default_partition
+                part = RowPartition(S, world, rank)      # what "auto" must fall back to here (five channels)
+        ren = SurfaceSplattingRenderer(ras, NormWeightedCompositor(), **kw)
+        flt = PointCloudsFilters(device=dev, activation=torch.ones((len(Xs), Xs[0].shape[0]), dtype=torch.bool, device=dev)) if with_filter else None
+        res = ren(cloud, verbose=verbose, point_clouds_filter=flt) if with_filter else ren(cloud, verbose=verbose)
+        img, frag = res if verbose else (res, None)
+        if key == "single":
+            w = torch.randn(img.shape, generator=gen).to(dev)
+            out["w"] = w
+        (img * out["w"]).sum().backward()
+        out[key] = (img.detach(), [x.grad.clone() for x in Xs], [c.grad.clone() for c in Cs], frag,
+                    None if flt is None else flt.visibility.clone())
+    ref = out["single"]
+    for i, part in enumerate(parts):
+        part = RowPartition(S, world, rank) if isinstance(part, str) else part
+        got = out["part%%d" %% i]
+        assert torch.equal(got[0], ref[0]), (name, "image differs", i)
+        for a, b in zip(got[1] + got[2], ref[1] + ref[2]):
+            assert rel(a, b) < 1e-5, (name, i, rel(a, b))
+        if verbose:   # the fragments of a partitioned render are those of the rank's rows
+            ri = torch.tensor(part.row_indices(), device=dev, dtype=torch.int64)
+            assert torch.equal(got[3].idx, ref[3].idx.index_select(1, ri)) and torch.equal(got[3].zbuf, ref[3].zbuf.index_select(1, ri))
+        if with_filter:   # the visibility handed to the filter object is the union over the ranks
+            assert torch.equal(got[4], ref[4]), (name, "visibility filter differs")
+    return out
+
+
+# (1) N clouds for N cameras (not shared), five feature channels, fragments requested, the filter object's visibility
+S = 128
+R, T = look_at_view_transform(2.0, 25.0, [40.0, 160.0, 280.0])
+cams3 = FoVPerspectiveCameras(znear=0.1, zfar=100.0, fov=60.0, R=R, T=T, device=dev)
+
+
+def three_clouds():
+    Xs = [torch.nn.Parameter(t(pts[i::3]).clone() * (1.0 + 0.05 * i)) for i in range(3)]
+    Cs = [torch.nn.Parameter(torch.rand((x.shape[0], 5), generator=torch.Generator().manual_seed(i)).to(dev)) for i, x in enumerate(Xs)]
+    return Xs, Cs, PointClouds3D(Xs, [t(nrm[i::3]) for i in range(3)], Cs)
+
+
+case("per-camera clouds, C=5", S, cams3, three_clouds, settings(S),
+     [RowPartition(S, world, rank), RowPartition(S, world, rank, bounds=[0, 48, S])], verbose=True, with_filter=True)
+# (the tile-row-cyclic variants of the backward are built for RGB features: an explicit cyclic partition with five channels is
+# refused with a clear message, "auto" falls back to contiguous bands)
+try:
+    Xs, Cs, cloud = three_clouds()
+    SurfaceSplattingRenderer(SurfaceSplatting(cameras=cams3, raster_settings=settings(S)), NormWeightedCompositor(),
+                             row_partition=RowPartition(S, world, rank, cyclic=True))(cloud)
+    raise AssertionError("a cyclic partition with five feature channels must be refused")
+except ValueError as e:
+    assert "3 feature channels" in str(e)
+case("per-camera clouds, C=5, auto", S, cams3, three_clouds, settings(S), ["auto"])
+
+# (2) one camera, unequal contiguous bands incl. a rank WITHOUT rows, isotropic per-point scale
+cam1 = FoVPerspectiveCameras(znear=0.1, zfar=100.0, fov=60.0, R=R[:1], T=T[:1], device=dev)
+
+
+def one_cloud():
+    X = torch.nn.Parameter(t(pts).clone())
+    C = torch.nn.Parameter(torch.rand((pts.shape[0], 3), generator=torch.Generator().manual_seed(9)).to(dev))
+    return [X], [C], PointClouds3D([X], [t(nrm)], [C])
+
+
+S2 = 96
+case("one camera, bands (0, 96, 96) / (0, 40, 96), isotropic", S2, cam1, one_cloud, settings(S2, Vrk_invariant=False, Vrk_isotropic=True),
+     [RowPartition(S2, world, rank, bounds=[0, 96, 96]), RowPartition(S2, world, rank, bounds=[0, 40, 96])], gradient_exchange="owner")
+case("one camera, bucket", S2, cam1, one_cloud, settings(S2), [RowPartition(S2, world, rank, bounds=[0, 56, 96])], gradient_exchange="bucket")
+
+# (3) cameras that cull different points of one shared cloud (per-camera variance scale), band output
+R2, T2 = look_at_view_transform([2.0, 2.2], [20.0, -10.0], [30.0, 200.0])
+cams2 = FoVPerspectiveCameras(fov=60.0, R=R2, T=T2, device=dev)
+cams2.znear = torch.tensor([1.9, 1.0], device=dev)
+cams2.zfar = torch.tensor([100.0, 2.3], device=dev)
+case("shared cloud, different culling per camera", S, cams2, one_cloud, settings(S), [RowPartition(S, world, rank, cyclic=True)])
+open(os.path.join(%(tmp)r, "edge_ok%%d" %% rank), "w").write("ok")
+dist.destroy_process_group()
+'''
+
+
+def test_row_partitioned_renderer_edge_cases(tmp_path):
+    """Two gloo ranks on one GPU through the classes: per-camera clouds with five feature channels, fragments (`verbose`) and
+    the filter object's visibility; one camera with unequal bands and a rank WITHOUT rows, isotropic scale; the bucket form;
+    cameras that cull different points of a shared cloud."""
+    script = os.path.join(str(tmp_path), "two_rank_edge.py")
+    open(script, "w").write(_TWO_RANK_EDGE % {"root": ROOT, "tmp": str(tmp_path)})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29723", script],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-12000:]
+    assert os.path.exists(os.path.join(str(tmp_path), "edge_ok0")) and os.path.exists(os.path.join(str(tmp_path), "edge_ok1"))

@@ -127,7 +127,7 @@ for layout in ((os.environ.get("BAND_TRACE_LAYOUT", "cyclic"),) if TRACE else LA
                             order_refresh=ORDER_REFRESH)
             losses, sums = ops.image_loss_forward(full_image, t_rgb, t_mask, 1.0, 1.0)
             g = ops.image_loss_backward(full_image, t_rgb, t_mask, 1.0, 1.0, sums)
-            eng.bwd_begin(g)
+            eng.bwd_begin(g, full=True)
             eng.bwd_compute(bench.RADII_S, bench.CLIP, wl.world, wl.M, wl.V, wl.first, wl.num, f=f, vis_all=vis_all)
             return eng.bwd_finish(bench.CLIP, wl.world, wl.M, wl.V, wl.first, wl.num)
 
@@ -140,7 +140,7 @@ for layout in ((os.environ.get("BAND_TRACE_LAYOUT", "cyclic"),) if TRACE else LA
             ops.image_loss_band_partials(band, t_rgb, t_mask, p.rows, band_targets=bt)           # (its all-reduced form: `red`)
             g_band, _ = ops.image_loss_band_backward_partials(band, t_rgb, t_mask, p.rows, 1.0, 1.0, red, band_targets=bt,
                                                               alpha_out=eng.alpha_send_view())   # (owner: + the alpha channel, packed)
-            eng.bwd_begin(g_band, alpha_packed=True)
+            eng.bwd_begin(g_band, alpha_packed=True, full=False)
             eng.bwd_compute(bench.RADII_S, bench.CLIP, wl.world, wl.M, wl.V, wl.first, wl.num, f=f, vis_all=vis_all)
             return eng.bwd_finish(bench.CLIP, wl.world, wl.M, wl.V, wl.first, wl.num)
         eager.append(quick(step, N_IT))
