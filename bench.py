@@ -1223,7 +1223,7 @@ def main():
                 rec["ms_per_step_via_api_graphed_calling_thread"] = round(ms_api_graphed_ct, 5)
         for k, v in ms_modes.items():
             rec["config"]["calibration_ms_per_step_" + k] = round(v, 5)
-        if not args.no_cpu_baseline and not large and not force_dist:
+        if not args.no_cpu_baseline and not large and not force_dist and world == 1:   # (rank 0 at N = 1 only: 30 s of one host core)
             rec["cpu_baseline"] = cpu_baseline()
         print(json.dumps(rec))
     if multi:
