@@ -151,6 +151,8 @@ def fitted_bounds(row_weight, samples, world_size: int, align: int = 8, min_rows
             A.append([1.0, cum[bounds[r + 1]] - cum[bounds[r]], float(bounds[r + 1] - bounds[r])])
             y.append(float(times[r]))
     A, y = np.asarray(A), np.asarray(y)
+    if not (np.isfinite(y).all() and (y >= 0).all()):
+        raise ValueError("fitted_bounds: the measured times must be finite and non-negative, got %r" % (y.tolist(),))
     scale = np.maximum(np.abs(A).max(axis=0), 1e-30)
     best = None
     for k in (3, 2, 1):                       # non-negative least squares over the subsets of {F, a, b}

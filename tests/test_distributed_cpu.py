@@ -324,3 +324,24 @@ def test_band_image_loss_gloo_world2_cyclic(tmp_path):
     port = 29650 + (os.getpid() % 90)
     mp.spawn(_band_loss_worker, args=(2, port, str(tmp_path), True), nprocs=2, join=True)
     assert (tmp_path / "band_ok0").exists() and (tmp_path / "band_ok1").exists()
+
+
+def test_gradient_exchange_choice_and_default_partition_without_a_process_group():
+    """host logic of dss_amd.sharded: the automatic choice of the gradient exchange from the bytes on the critical path, and
+    that no process group means no partition (the plain single-GPU path)"""
+    sys.path.insert(0, ROOT)
+    from dss_amd.sharded import choose_gradient_exchange, default_partition
+    assert default_partition(512) is None
+    # the metric's configuration (8 x 32,684 points, 512^2, band loss): 6.3 MB of partial sums beat an extra collective
+    assert choose_gradient_exchange(8, 32684, 8 * 32684, 512, 3, 8, True, True) == "bucket"
+    # BASELINE configs[3] (8 x 1M points, 1024^2): 192 MB of partial sums against 24 MB of world-space sums + a 4 MB plane
+    assert choose_gradient_exchange(8, 10 ** 6, 8 * 10 ** 6, 1024, 3, 8, True, True) == "owner"
+    # one camera (configs[4]): both forms reduce the same bytes, the owner form only adds the plane exchange
+    assert choose_gradient_exchange(1, 4 * 10 ** 6, 4 * 10 ** 6, 2048, 3, 8, True, True) == "bucket"
+    # a replicated loss hands the owner form the full gradient: no plane exchange, fewer bytes whenever cameras share a cloud
+    assert choose_gradient_exchange(8, 32684, 8 * 32684, 512, 3, 8, False, False) == "owner"
+    from dss_amd.distributed import agree_on_bounds
+    assert agree_on_bounds([0, 8, 16]) == [0, 8, 16]          # no process group: handed back
+    from dss_amd.distributed import fitted_bounds
+    with pytest.raises(ValueError):
+        fitted_bounds(torch.ones(16), [([0, 8, 16], [float("nan"), float("nan")])], 2)
