@@ -859,48 +859,78 @@ __global__ __launch_bounds__(1024) void cloud_mean_kernel(const float *__restric
 // (the depth test of setup_point_compute, same expression) and counts them; phase 2 divides by the largest count.
 // (values = K-th neighbour distances within the WHOLE cloud: a kept point whose 7 nearest include a dropped point sees a
 // slightly smaller distance than the reference's search among the kept points -- second order, documented.)
+#define RENDERABLE_BLOCKS 32   // workgroups per camera (one per camera left seven eighths of a 22 us launch to 8 CUs)
 __global__ __launch_bounds__(1024) void renderable_sum_kernel(const float *__restrict__ vals, const float *__restrict__ world,
                                                               const float *__restrict__ V, const float *__restrict__ znear,
                                                               const float *__restrict__ zfar, const int64_t *__restrict__ first_idx,
                                                               const int64_t *__restrict__ num_pts, int shared, float scale,
-                                                              double *__restrict__ sums /* (N,2): sum, count */,
+                                                              double *__restrict__ part /* (N, RENDERABLE_BLOCKS, 2): sum, count */,
                                                               int64_t vals_cam_stride /* 0: one value per world point */)
 {
-    __shared__ double part[16], partc[16];
-    const int n = blockIdx.x, tid = threadIdx.x;
+    __shared__ double psum[16], pcnt[16];
+    const int n = blockIdx.y, b = blockIdx.x, tid = threadIdx.x;
     const int64_t f0 = shared ? 0 : first_idx[n], cnt = num_pts[n];
     const float *v = V + 16 * n;
     const float v2 = v[2], v6 = v[6], v10 = v[10], v14 = v[14], zn = znear[n], zf = zfar[n];
     double a = 0.0;
     float c = 0.f;
-    for (int64_t i = tid; i < cnt; i += 1024) {
-        const int64_t wi = f0 + i;
-        const float zview = world[3 * wi] * v2 + world[3 * wi + 1] * v6 + world[3 * wi + 2] * v10 + 1.0f * v14;
-        const bool ok = (zview >= zn) && (zview <= zf);
-        a += ok ? (double)(vals[(size_t)n * (size_t)vals_cam_stride + wi] * scale) : 0.0;
-        c += ok ? 1.f : 0.f;
+    // block b of a camera takes the points b * 1024 + tid + k * (RENDERABLE_BLOCKS * 1024): a fixed assignment, so the sums
+    // are reproducible; four points per trip with their loads in flight together
+    const int64_t stride = (int64_t)RENDERABLE_BLOCKS * 1024;
+    for (int64_t i0 = (int64_t)b * 1024 + tid; i0 < cnt; i0 += 4 * stride) {
+        float x[4], y[4], z[4], q[4];
+        bool in[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t i = i0 + u * stride;
+            in[u] = i < cnt;
+            const int64_t wi = f0 + (in[u] ? i : i0);
+            x[u] = world[3 * wi]; y[u] = world[3 * wi + 1]; z[u] = world[3 * wi + 2];
+            q[u] = vals[(size_t)n * (size_t)vals_cam_stride + wi];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float zview = x[u] * v2 + y[u] * v6 + z[u] * v10 + 1.0f * v14;   // the expression of setup_point_compute
+            const bool ok = in[u] && (zview >= zn) && (zview <= zf);
+            a += ok ? (double)(q[u] * scale) : 0.0;
+            c += ok ? 1.f : 0.f;
+        }
     }
     double cc = (double)c;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); cc += __shfl_xor(cc, o); }
-    if ((tid & 63) == 0) { part[tid >> 6] = a; partc[tid >> 6] = cc; }
+    if ((tid & 63) == 0) { psum[tid >> 6] = a; pcnt[tid >> 6] = cc; }
     __syncthreads();
     if (tid == 0) {
         double t = 0.0, tc = 0.0;
-        for (int w = 0; w < 16; ++w) { t += part[w]; tc += partc[w]; }
-        sums[2 * n] = t;
-        sums[2 * n + 1] = tc;
+        for (int w = 0; w < 16; ++w) { t += psum[w]; tc += pcnt[w]; }
+        part[((size_t)n * RENDERABLE_BLOCKS + b) * 2] = t;
+        part[((size_t)n * RENDERABLE_BLOCKS + b) * 2 + 1] = tc;
     }
 }
-__global__ __launch_bounds__(64) void renderable_mean_kernel(const double *__restrict__ sums, int N, float lo, float hi,
+__global__ __launch_bounds__(64) void renderable_mean_kernel(double *__restrict__ part, int N, float lo, float hi,
                                                              float fallback, int min_points, float *__restrict__ out)
 {
-    double pmax = 0.0;
-    for (int m = 0; m < N; ++m) pmax = fmax(pmax, sums[2 * m + 1]);
+    // ONE wavefront.  Pass 1: lane l adds up the block partials of cameras l, l + 64, ... in block order (fixed) and parks
+    // the totals in the camera's first slot; the largest kept count of the batch is a wave maximum.  Pass 2: the means.
+    double cmax = 0.0;
     for (int n = threadIdx.x; n < N; n += 64) {
-        const double cnt = sums[2 * n + 1];
+        double s = 0.0, c = 0.0;
+#pragma unroll 8
+        for (int b = 0; b < RENDERABLE_BLOCKS; ++b) {
+            s += part[((size_t)n * RENDERABLE_BLOCKS + b) * 2];
+            c += part[((size_t)n * RENDERABLE_BLOCKS + b) * 2 + 1];
+        }
+        part[(size_t)n * RENDERABLE_BLOCKS * 2] = s;
+        part[(size_t)n * RENDERABLE_BLOCKS * 2 + 1] = c;
+        cmax = fmax(cmax, c);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cmax = fmax(cmax, __shfl_xor(cmax, o));
+    for (int n = threadIdx.x; n < N; n += 64) {
+        const double s = part[(size_t)n * RENDERABLE_BLOCKS * 2], cnt = part[(size_t)n * RENDERABLE_BLOCKS * 2 + 1];
         // `sq_dist[num_points_per_cloud < 7] = 1e-3` fills the whole padded row of a small cloud (rasterizer.py:322)
-        const float m = (cnt >= (double)min_points && pmax > 0.0) ? (float)(sums[2 * n] / pmax) : fallback;
+        const float m = (cnt >= (double)min_points && cmax > 0.0) ? (float)(s / cmax) : fallback;
         out[n] = fminf(fmaxf(m, lo), hi);
     }
 }
@@ -1089,12 +1119,12 @@ extern "C" int dss_renderable_mean_clamp(const float *values, const float *world
                                          void *stream)
 {
     if (N <= 0 || !values || !world || !V || !znear || !zfar || !first_idx || !num_pts || !out || !workspace ||
-        workspace_bytes < (size_t)N * 16) {
-        set_error("dss_renderable_mean_clamp: bad arguments (workspace of 16 N bytes)");
+        workspace_bytes < (size_t)N * 16 * RENDERABLE_BLOCKS) {
+        set_error("dss_renderable_mean_clamp: bad arguments (workspace of 512 N bytes)");
         return DSS_ERR_INVALID_ARGUMENT;
     }
     double *sums = reinterpret_cast<double *>(workspace);
-    hipLaunchKernelGGL(renderable_sum_kernel, dim3(N), dim3(1024), 0, as_stream(stream), values, world, V, znear, zfar,
+    hipLaunchKernelGGL(renderable_sum_kernel, dim3(RENDERABLE_BLOCKS, N), dim3(1024), 0, as_stream(stream), values, world, V, znear, zfar,
                        first_idx, num_pts, shared_cloud, scale, sums, values_cam_stride);
     hipLaunchKernelGGL(renderable_mean_kernel, dim3(1), dim3(64), 0, as_stream(stream), sums, N, lo, hi, fallback, min_points, out);
     return check_launch("dss_renderable_mean_clamp");

@@ -1019,7 +1019,7 @@ def renderable_mean_clamp(values, world, V, znear, zfar, cloud_to_packed_first_i
         raise RuntimeError("renderable_mean_clamp: values (Pw,) or (N,Pw); V, znear, zfar, first_idx, num_points per camera")
     with torch.cuda.device(dev):
         out = torch.empty((N,), dtype=_f32, device=dev)
-        ws = _lib.workspace(dev, 16 * N)
+        ws = _lib.workspace(dev, 512 * N)
         rc = lib.dss_renderable_mean_clamp(_lib.ptr(values), _lib.ptr(world), _lib.ptr(V), _lib.ptr(znear), _lib.ptr(zfar),
                                            _lib.ptr(first), _lib.ptr(num), N, int(shared_cloud), float(scale), float(lo),
                                            float(hi), float(fallback), int(min_points), Pw if per_cam else 0, _lib.ptr(out),

@@ -490,7 +490,7 @@ DSS_API int dss_cloud_mean_clamp(const float *values /* (P,) */, const int64_t *
  * K-th-neighbour distances), world (Pw,3), V (N,4,4); shared_cloud = 1: one cloud of num_pts[0] points for all cameras, else
  * camera n sees world points [first_idx[n], first_idx[n] + num_pts[n]).  values_cam_stride: 0 = one value per world point
  * (distances searched in the whole cloud: first order only); Pw = values (N, Pw) per (camera, point) from
- * dss_knn_kth_sqdist_view (the reference's order, exact).  workspace: 16 N bytes. */
+ * dss_knn_kth_sqdist_view (the reference's order, exact).  workspace: 512 N bytes. */
 DSS_API int dss_renderable_mean_clamp(const float *values, const float *world, const float *V, const float *znear,
                                       const float *zfar, const int64_t *first_idx, const int64_t *num_pts, int N,
                                       int shared_cloud, float scale, float lo, float hi, float fallback, int min_points,
