@@ -199,19 +199,72 @@ __global__ __launch_bounds__(256) void knn_scan_add_kernel(const KnnGrid *__rest
     if (tid == 0 && (b + 1) * KNN_SCAN_BLOCK >= cells) offsets[base + cells] = prefix + blk_tot[(size_t)n * nblk_max + b];
 }
 
+// Per-camera depth culling inside the search (dss_knn_kth_sqdist_view): the reference runs its neighbour search AFTER
+// filter_renderable has dropped, per camera, the points outside [znear, zfar] (rasterizer.py:599, 183-217, 310-326) -- a point's
+// neighbours are then the ones the SAME camera keeps.  mode 1: one cloud shared by the cameras, blockIdx.y = camera, results at
+// kth_sqdist[camera * P + p]; mode 2: cloud n belongs to camera n.  A query point its camera drops gets 0 (never read).
+struct KnnView {
+    const float *V;        // (cameras, 4, 4) world -> view, row-vector convention
+    const float *znear, *zfar;
+    int mode;              // 0: off
+    uint32_t *culls;       // (cameras) != 0: the camera drops at least one point of its cloud (written by knn_fill_kernel)
+    int n_cams;
+};
+// mode 1 (one cloud, several cameras): every camera that drops NOTHING sees the same statistic -- the plain search of the
+// whole cloud.  Only the first of them (`knn_plain_camera`) runs it; knn_view_rows_kernel copies its row to the others.  A
+// camera that drops points runs its own masked search.  (With the near plane where the reference's data sets put it, znear =
+// 0.1, no camera drops anything: one search instead of one per camera.)
+__device__ __forceinline__ int knn_plain_camera(const KnnView &view)
+{
+    for (int c = 0; c < view.n_cams; ++c)
+        if (view.culls[c] == 0u) return c;
+    return -1;
+}
+__device__ __forceinline__ bool knn_kept(float x, float y, float z, float v2, float v6, float v10, float v14, float zn, float zf)
+{
+    const float zview = x * v2 + y * v6 + z * v10 + 1.0f * v14;   // the expression of setup_point_compute
+    return (zview >= zn) && (zview <= zf);
+}
+
 __global__ __launch_bounds__(256) void knn_fill_kernel(const float *__restrict__ pts, const int64_t *__restrict__ first_idx,
                                                        const int64_t *__restrict__ num_pts, int N, int64_t P,
                                                        const int32_t *__restrict__ cell_of, size_t stride,
                                                        uint32_t *__restrict__ cursor,
-                                                       float4 *__restrict__ sorted /* (P) xyz + id, grouped by cell */)
+                                                       float4 *__restrict__ sorted /* (P) xyz + id, grouped by cell */,
+                                                       const KnnView view = KnnView())
 {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= P) return;
     const int c = cell_of[p];
     if (c < 0) return;
     const int n = find_cloud(p, first_idx, num_pts, N);
+    const float x = pts[3 * p], y = pts[3 * p + 1], z = pts[3 * p + 2];
     const uint32_t pos = atomicAdd(&cursor[(size_t)n * stride + c], 1u);
-    sorted[first_idx[n] + pos] = make_float4(pts[3 * p], pts[3 * p + 1], pts[3 * p + 2], __int_as_float((int)p));
+    sorted[first_idx[n] + pos] = make_float4(x, y, z, __int_as_float((int)p));
+    if (view.mode != 0) {
+        // which cameras drop a point of their cloud (dss_knn_kth_sqdist_view): one atomic per wavefront and camera that does
+        const int c0 = view.mode == 1 ? 0 : n, c1 = view.mode == 1 ? view.n_cams : n + 1;
+        for (int cam = c0; cam < c1; ++cam) {
+            const float *vm = view.V + 16 * cam;
+            const bool drop = !knn_kept(x, y, z, vm[2], vm[6], vm[10], vm[14], view.znear[cam], view.zfar[cam]);
+            const unsigned long long m = __ballot(drop);
+            if (drop && (threadIdx.x & 63) == (unsigned)__builtin_ctzll(m)) atomicOr(&view.culls[cam], 1u);
+        }
+    }
+}
+
+// mode 1 of dss_knn_kth_sqdist_view: the rows of the cameras that drop nothing = the row of the first of them
+__global__ __launch_bounds__(256) void knn_view_rows_kernel(float *__restrict__ kth, int64_t P, const KnnView view)
+{
+    const int cam = blockIdx.y;
+    const int src = knn_plain_camera(view);
+    if (view.culls[cam] != 0u || cam == src || src < 0) return;
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i + 3 < P && ((((uintptr_t)kth) & 15u) == 0) && (P & 3) == 0) {
+        reinterpret_cast<float4 *>(kth + (size_t)cam * P)[i >> 2] = reinterpret_cast<const float4 *>(kth + (size_t)src * P)[i >> 2];
+    } else {
+        for (int64_t j = i; j < min(i + 4, P); ++j) kth[(size_t)cam * P + j] = kth[(size_t)src * P + j];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -385,21 +438,6 @@ __global__ __launch_bounds__(1024) void knn_scan_single_kernel(const uint32_t *_
     if (tid == 0 && (b + 1) * KNN_SCAN_BLOCK >= cells) offsets[(size_t)n * stride + cells] = prefix + total;
 }
 
-// Per-camera depth culling inside the search (dss_knn_kth_sqdist_view): the reference runs its neighbour search AFTER
-// filter_renderable has dropped, per camera, the points outside [znear, zfar] (rasterizer.py:599, 183-217, 310-326) -- a point's
-// neighbours are then the ones the SAME camera keeps.  mode 1: one cloud shared by the cameras, blockIdx.y = camera, results at
-// kth_sqdist[camera * P + p]; mode 2: cloud n belongs to camera n.  A query point its camera drops gets 0 (never read).
-struct KnnView {
-    const float *V;        // (cameras, 4, 4) world -> view, row-vector convention
-    const float *znear, *zfar;
-    int mode;              // 0: off
-};
-__device__ __forceinline__ bool knn_kept(float x, float y, float z, float v2, float v6, float v10, float v14, float zn, float zf)
-{
-    const float zview = x * v2 + y * v6 + z * v10 + 1.0f * v14;   // the expression of setup_point_compute
-    return (zview >= zn) && (zview <= zf);
-}
-
 // FULL = false: K-th squared distance only (kth_sqdist (P,)).  FULL = true: the whole neighbour list, ascending in
 // (distance, id): dists (P,Krt) squared distances and idx (P,Krt) cloud-local ids, zero-padded when the cloud has
 // fewer than Krt points (the layout pytorch3d.ops.knn_points returns for a self query, losses.py:157-180).
@@ -436,6 +474,8 @@ __global__ __launch_bounds__(256) void knn_query_kernel(const float *__restrict_
     float v2 = 0.f, v6 = 0.f, v10 = 0.f, v14 = 0.f, zn = 0.f, zf = 0.f;
     if (VIEW) {
         const int cam = view.mode == 1 ? (int)blockIdx.y : n;
+        // (a camera that drops nothing sees the plain statistic: only the first such camera searches, see knn_plain_camera)
+        if (view.mode == 1 && view.culls[cam] == 0u && cam != knn_plain_camera(view)) return;
         const float *vm = view.V + 16 * cam;
         v2 = vm[2]; v6 = vm[6]; v10 = vm[10]; v14 = vm[14]; zn = view.znear[cam]; zf = view.zfar[cam];
         if (view.mode == 1) kth_sqdist += (size_t)cam * (size_t)P;
@@ -649,12 +689,25 @@ __global__ __launch_bounds__(256) void knn_query_coop_kernel(const float *__rest
                                                              const float4 *__restrict__ sorted, int Krt,
                                                              float *__restrict__ kth_sqdist, float *__restrict__ dists,
                                                              int64_t *__restrict__ idx, float r2 /* > 0: FRNN semantics, see dss_knn_kth_sqdist_radius */,
-    const KnnView view = KnnView())
+    const KnnView view = KnnView(), const uint32_t chunks = 0 /* VIEW: query chunks per camera (the grid is persistent) */)
 {
     constexpr int GPB = 256 / KNN_LPQ;   // query groups per workgroup
     const int grp = threadIdx.x / KNN_LPQ, sub = threadIdx.x % KNN_LPQ;
-    const int64_t slot = (int64_t)blockIdx.x * GPB + grp;
-    if (slot >= P) return;   // (whole DPP rows leave together)
+    __shared__ uint32_t row_lo[9][GPB], row_hi[9][GPB];
+    float *const kth_base = kth_sqdist;
+    // VIEW, one cloud seen by several cameras: a PERSISTENT grid walks the (camera, chunk) items and skips the cameras whose
+    // row is a copy of the plain camera's (knn_plain_camera) -- as grid rows those would still cost a workgroup dispatch each
+    // (~3 ns: 44,000 workgroups at 8 x 100k points).  Otherwise: one pass, item = this workgroup.
+    const bool walk = VIEW && view.mode == 1;
+    const int plain = walk ? knn_plain_camera(view) : -1;
+    const uint32_t n_items = walk ? chunks * (uint32_t)view.n_cams : 1u;
+    for (uint32_t item = walk ? blockIdx.x : 0u; item < n_items; item += walk ? gridDim.x : 1u) {
+    const int cam_y = walk ? (int)(item / chunks) : 0;
+    const uint32_t bx = walk ? item - (uint32_t)cam_y * chunks : blockIdx.x;
+    if (walk && view.culls[cam_y] == 0u && cam_y != plain) continue;
+    kth_sqdist = kth_base;
+    const int64_t slot = (int64_t)bx * GPB + grp;
+    if (slot >= P) continue;   // (whole DPP rows leave together)
     const int n = find_cloud(slot, first_idx, num_pts, N);
     if (n < 0) {  // packed slot outside every cloud
         if (sub == 0) {
@@ -664,7 +717,7 @@ __global__ __launch_bounds__(256) void knn_query_coop_kernel(const float *__rest
                 kth_sqdist[slot] = 0.0f;
             }
         }
-        return;
+        continue;
     }
     const KnnGrid g = grids[n];
     const int64_t f0 = first_idx[n];
@@ -675,13 +728,13 @@ __global__ __launch_bounds__(256) void knn_query_coop_kernel(const float *__rest
     const float qx = self.x, qy = self.y, qz = self.z;
     float v2 = 0.f, v6 = 0.f, v10 = 0.f, v14 = 0.f, zn = 0.f, zf = 0.f;
     if (VIEW) {
-        const int cam = view.mode == 1 ? (int)blockIdx.y : n;
+        const int cam = view.mode == 1 ? cam_y : n;
         const float *vm = view.V + 16 * cam;
         v2 = vm[2]; v6 = vm[6]; v10 = vm[10]; v14 = vm[14]; zn = view.znear[cam]; zf = view.zfar[cam];
-        if (view.mode == 1) kth_sqdist += (size_t)cam * (size_t)P;
+        if (view.mode == 1) kth_sqdist = kth_base + (size_t)cam * (size_t)P;
         if (!knn_kept(qx, qy, qz, v2, v6, v10, v14, zn, zf)) {   // (the whole 16-lane group shares the query: leaves together)
             if (sub == 0) kth_sqdist[p] = 0.0f;
-            return;
+            continue;
         }
     }
     const int cx = cell_coord(qx, g.minx, g.inv_cell, g.res);
@@ -696,7 +749,7 @@ __global__ __launch_bounds__(256) void knn_query_coop_kernel(const float *__rest
     const int kk = (int)min((int64_t)Krt, cnt_n);
     if (kk <= 0) {
         if (!FULL && sub == 0) kth_sqdist[p] = 0.0f;
-        return;
+        continue;
     }
     auto consider = [&](const float4 q, bool on) {
         const float dx = q.x - qx, dy = q.y - qy, dz = q.z - qz;
@@ -739,7 +792,6 @@ __global__ __launch_bounds__(256) void knn_query_coop_kernel(const float *__rest
             consider(q1, on1);
         }
     };
-    __shared__ uint32_t row_lo[9][GPB], row_hi[9][GPB];
     if (sub < 9) {   // lane r of the group fetches the offsets of row r of the 3 x 3 x 3 block
         const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.res - 1);
         const int z = cz + sub / 3 - 1, y = cy + sub % 3 - 1;
@@ -798,7 +850,7 @@ __global__ __launch_bounds__(256) void knn_query_coop_kernel(const float *__rest
             for (int k = 0; k < (FULL ? K : 1); ++k) bid[k] = 0x7fffffff;
         }
     }
-    if (sub != 0) return;
+    if (sub != 0) continue;
     if (FULL) {
 #pragma unroll
         for (int k = 0; k < K; ++k)
@@ -806,7 +858,7 @@ __global__ __launch_bounds__(256) void knn_query_coop_kernel(const float *__rest
                 dists[p * Krt + k] = k < kk ? best[k] : 0.0f;
                 idx[p * Krt + k] = k < kk ? (int64_t)bid[FULL ? k : 0] - f0 : 0;
             }
-        return;
+        continue;
     }
     float kth = best[0];
 #pragma unroll
@@ -820,6 +872,7 @@ __global__ __launch_bounds__(256) void knn_query_coop_kernel(const float *__rest
         for (int k = 1; k < K; ++k) kth = (k < kk && best[k] <= r2) ? best[k] : kth;
     }
     kth_sqdist[p] = kth;
+    }   // (items)
 }
 
 // deterministic per-cloud mean of values*scale clamped to [lo,hi]: one workgroup per cloud, fixed order (four independent
@@ -954,11 +1007,13 @@ static size_t knn_stride(int64_t P)
 static size_t knn_cells(int N, int64_t P) { return (size_t)(N > 0 ? N : 1) * knn_stride(P); }
 static int knn_blocks(int64_t P) { return (int)((knn_stride(P) - 1 + KNN_SCAN_BLOCK - 1) / KNN_SCAN_BLOCK); }
 
+#define KNN_MAX_VIEW_CAMS 1024
 extern "C" size_t dss_knn_workspace(int N, int64_t P)
 {
     const size_t n = N > 0 ? N : 1, p = P > 0 ? P : 1;
     return align_up(n * 6 * 4 * KNN_BB_WGS, 256) + align_up(n * sizeof(KnnGrid), 256) + align_up((knn_cells(N, P) + 1) * 4, 256) * 3 +
-           align_up(n * (size_t)knn_blocks(P) * 4, 256) + align_up(p * 4, 256) + align_up(p * 16, 256);
+           align_up(n * (size_t)knn_blocks(P) * 4, 256) + align_up(p * 4, 256) + align_up(p * 16, 256) +
+           KNN_MAX_VIEW_CAMS * 4;   // dss_knn_kth_sqdist_view: one "drops points" flag per camera
 }
 
 #define KNN_FULL_MAX_K 40
@@ -977,7 +1032,7 @@ int dss::launch_cloud_bbox(const float *points, const int64_t *first_idx, const 
 // grid build + query; exactly one of (kth_sqdist) / (dists, idx) is written
 static int knn_run(const char *who, const float *points, const int64_t *first_idx, const int64_t *num_pts, int N, int64_t P,
                    int K, float *kth_sqdist, float *dists, int64_t *idx, void *workspace, size_t workspace_bytes,
-                   void *stream, float r2 = -1.0f, const KnnView view = KnnView(), int n_cams = 1)
+                   void *stream, float r2 = -1.0f, KnnView view = KnnView(), int n_cams = 1)
 {
     const bool full = dists != nullptr;
     if (N <= 0 || P < 0 || K < 1 || K > (full ? KNN_FULL_MAX_K : KNN_MAX_K)) {
@@ -1006,7 +1061,13 @@ static int knn_run(const char *who, const float *points, const int64_t *first_id
     uint32_t *cursor = reinterpret_cast<uint32_t *>(w + off);     off += cbytes;
     uint32_t *blk_tot = reinterpret_cast<uint32_t *>(w + off);    off += align_up((size_t)N * nblk * 4, 256);
     int32_t *cell_of = reinterpret_cast<int32_t *>(w + off);      off += align_up((size_t)P * 4, 256);
-    float4 *sorted = reinterpret_cast<float4 *>(w + off);
+    float4 *sorted = reinterpret_cast<float4 *>(w + off);                    off += align_up((size_t)P * 16, 256);
+    if (view.mode != 0) {
+        if (n_cams > KNN_MAX_VIEW_CAMS) { set_error("%s: at most %d cameras", who, KNN_MAX_VIEW_CAMS); return DSS_ERR_UNSUPPORTED; }
+        view.culls = reinterpret_cast<uint32_t *>(w + off);
+        view.n_cams = n_cams;
+        if (hipMemsetAsync(view.culls, 0, (size_t)n_cams * 4, st) != hipSuccess) return check_launch("knn view memset");
+    }
     const unsigned pb_s = (unsigned)((P + 255) / 256);
     if (P <= KNN_SMALL_P && N <= KNN_GRID_LDS && nblk <= KNN_SCAN1_BLOCKS) {
         // small inputs: four launches instead of eight (see knn_bbox_partial_kernel)
@@ -1018,7 +1079,7 @@ static int knn_run(const char *who, const float *points, const int64_t *first_id
                            knn_res_cap(P), grids, stride, counts, cell_of);
         hipLaunchKernelGGL(knn_scan_single_kernel, dim3(nblk, N), dim3(1024), 0, st, counts, grids, stride, offsets, cursor);
         hipLaunchKernelGGL(knn_fill_kernel, dim3(pb_s), dim3(256), 0, st, points, first_idx, num_pts, N, P, cell_of, stride,
-                           cursor, sorted);
+                           cursor, sorted, view);
     } else {
         if (hipMemsetAsync(counts, 0, cbytes, st) != hipSuccess) return check_launch("knn memset");
         const unsigned pb = (unsigned)((P + 255) / 256);
@@ -1030,7 +1091,7 @@ static int knn_run(const char *who, const float *points, const int64_t *first_id
                            blk_tot);
         hipLaunchKernelGGL(knn_scan_add_kernel, dim3(nblk, N), dim3(256), 0, st, grids, stride, nblk, blk_tot, offsets, cursor);
         hipLaunchKernelGGL(knn_fill_kernel, dim3(pb), dim3(256), 0, st, points, first_idx, num_pts, N, P, cell_of, stride,
-                           cursor, sorted);
+                           cursor, sorted, view);
     }
     // small inputs: one wavefront per workgroup, so that the few hundred wavefronts spread over all 256 CUs
     const unsigned qt = P <= 131072 ? 64u : 256u;
@@ -1049,12 +1110,19 @@ static int knn_run(const char *who, const float *points, const int64_t *first_id
         // K-th distance under per-camera culling (K <= 8: the variance-scale statistic): one grid row per camera
         if (full || K > 8) { set_error("%s: the per-camera search is built for the K-th distance with K <= 8", who); return DSS_ERR_UNSUPPORTED; }
         const bool coop = qopt == 1 || (qopt == 0 && P <= KNN_COOP_KTH_MAX_P);
-        if (coop)
-            hipLaunchKernelGGL((knn_query_coop_kernel<8, false, true>), dim3(cb, gy), dim3(256), 0, st, points, first_idx, num_pts,
-                               N, P, grids, stride, offsets, sorted, K, kth_sqdist, dists, idx, r2, view);
-        else
+        if (coop) {
+            // one cloud, several cameras: a persistent grid over the (camera, chunk) items (at most 8 workgroups per CU's worth)
+            const unsigned long long items = (unsigned long long)cb * gy;
+            const unsigned grid = view.mode == 1 ? (unsigned)(items < 16384ull ? items : 16384ull) : cb;
+            hipLaunchKernelGGL((knn_query_coop_kernel<8, false, true>), dim3(grid), dim3(256), 0, st, points, first_idx, num_pts,
+                               N, P, grids, stride, offsets, sorted, K, kth_sqdist, dists, idx, r2, view, cb);
+        } else {
             hipLaunchKernelGGL((knn_query_kernel<8, false, true>), dim3(qb, gy), dim3(qt), 0, st, points, first_idx, num_pts, N, P,
                                grids, stride, offsets, sorted, K, kth_sqdist, dists, idx, r2, view);
+        }
+        if (view.mode == 1 && n_cams > 1)   // the rows of the cameras that drop nothing = the plain camera's row
+            hipLaunchKernelGGL(knn_view_rows_kernel, dim3((unsigned)((P + 1023) / 1024), (unsigned)n_cams), dim3(256), 0, st,
+                               kth_sqdist, P, view);
         return check_launch(who);
     }
     if (full) {
@@ -1159,7 +1227,7 @@ extern "C" int dss_knn_kth_sqdist_view(const float *points, const int64_t *first
         set_error("dss_knn_kth_sqdist_view: cameras missing, or the cloud / camera counts do not fit (shared: one cloud; else one camera per cloud)");
         return DSS_ERR_INVALID_ARGUMENT;
     }
-    KnnView view = {V, znear, zfar, shared_cloud ? 1 : 2};
+    KnnView view = {V, znear, zfar, shared_cloud ? 1 : 2, nullptr, n_cams};
     return knn_run("dss_knn_kth_sqdist_view", points, first_idx, num_pts, N, P, K, kth_sqdist, nullptr, nullptr, workspace,
                    workspace_bytes, stream, radius > 0.0f ? radius * radius : -1.0f, view, n_cams);
 }

@@ -181,8 +181,9 @@ def test_knn_fixed_radius_statistic_of_the_references_default_search(r):
     assert torch.equal(ops.knn_kth_sqdist(t(pts), t(first), t(num), 7, radius=-1.0), ops.knn_kth_sqdist(t(pts), t(first), t(num), 7))
 
 
+@pytest.mark.parametrize("culling", ["all", "none", "mixed"])
 @pytest.mark.parametrize("shared", [True, False])
-def test_knn_statistic_in_the_references_order_under_depth_culling(shared):
+def test_knn_statistic_in_the_references_order_under_depth_culling(shared, culling):
     """The reference drops, per camera, the points outside [znear, zfar] BEFORE its neighbour search and takes the mean over
     the padded batch (rasterizer.py:599, 183-217, 310-326): `knn_kth_sqdist_view` + `renderable_mean_clamp` against a KD-tree
     over each camera's kept subset."""
@@ -192,6 +193,12 @@ def test_knn_statistic_in_the_references_order_under_depth_culling(shared):
     Mn, Vn, _ = scenes.camera_matrices([1.3, 1.6, 2.5], [10.0, 40.0, -20.0], [0.0, 120.0, 250.0])
     N = Vn.shape[0]
     znear, zfar = np.array([1.0, 1.2, 1.0], np.float32), np.array([100.0, 1.9, 2.6], np.float32)
+    # "none": no camera drops a point (every row is the plain statistic: ONE search, the other rows are copies);
+    # "mixed": only the second camera does (its own masked search; the other two share the plain one)
+    if culling == "none":
+        znear, zfar = np.full(3, 0.01, np.float32), np.full(3, 100.0, np.float32)
+    elif culling == "mixed":
+        znear, zfar = np.array([0.01, 1.2, 0.01], np.float32), np.array([100.0, 1.9, 100.0], np.float32)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
     clouds = [base] if shared else [base, base[::2] * 1.1, base[1::3]]
     pts = np.concatenate(clouds, 0)
@@ -204,7 +211,8 @@ def test_knn_statistic_in_the_references_order_under_depth_culling(shared):
         c = clouds[0] if shared else clouds[n]
         z = c[:, 0] * Vn[n, 0, 2] + c[:, 1] * Vn[n, 1, 2] + c[:, 2] * Vn[n, 2, 2] + Vn[n, 3, 2]
         ok = (z >= znear[n]) & (z <= zfar[n])
-        assert 0 < ok.sum() < c.shape[0]                      # every camera drops something
+        drops = culling == "all" or (culling == "mixed" and n == 1)
+        assert (0 < ok.sum() < c.shape[0]) if drops else bool(ok.all())
         want = _ref_radius_stat(c[ok], 7, r)
         mine = got[n] if shared else got[first[n]:first[n] + num[n]]
         assert np.allclose(mine[ok], want, rtol=2e-5, atol=1e-9), (n, np.abs(mine[ok] - want).max())
