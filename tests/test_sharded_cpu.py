@@ -96,3 +96,8 @@ def test_row_sharded_engine_gloo_world2(tmp_path):
 
 def test_row_sharded_engine_gloo_world4(tmp_path):
     _run(4, tmp_path, 29550)
+
+
+def test_row_sharded_engine_gloo_world8(tmp_path):
+    """the world size of the target node: 8 rows per rank at S = 64 (one tile row each in the cyclic layout)"""
+    _run(8, tmp_path, 29350)
