@@ -158,7 +158,8 @@ class RowShardedRender:
         self.f = ops.render_forward(world, normals, h, M, V, znear, zfar, first, num, feats, self.S, self.K, cutoff, thr,
                                     sigma, backface, self.shared, rows=p.rows, out_image=self.fx.image,
                                     out_visible=self.fx.visible, vr6=vr6, frame_normals=frame_n, want_zbuf=want_zbuf,
-                                    band_outputs_only=band_only, point_outputs=self._point_outputs if (band_only and self.static_buffers) else None, **kw)
+                                    band_outputs_only=band_only,
+                                    point_outputs=self._point_outputs if (band_only and self.static_buffers) else None, **kw)
         return self.f
 
     def start_exchange(self, out: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -48,6 +48,7 @@ python tools/setup_timing.py > $out/setup_timing.txt 2>&1
 for e in overlap auto; do BENCH_FORCE_DIST=1 BENCH_EXCHANGE=$e python bench.py --gpus 1 --no-cpu-baseline --no-traffic 2>/dev/null | grep '^{' > $out/bench_forced_dist_world1_$e.json; done
 python tools/knn_timing.py > $out/knn_timing.json 2>/dev/null
 python tools/knn_graph_timing.py > $out/knn_graph_timing.txt 2>/dev/null
+{ python tools/knn_chain_timeline.py; python tools/knn_chain_timeline.py view; } > $out/knn_chain_timeline.txt 2>/dev/null
 for c in cfg2 cfg3 cfg4 cfg5; do python tools/gather_split.py $c >> $out/gather_split.jsonl 2>/dev/null; done
 BENCH_DIST_BACKEND=gloo python bench.py --gpus 2 --no-cpu-baseline 2>/dev/null | grep '^{' > $out/bench_2ranks_gloo_one_gpu.json
 [ -n "$COLLECT_REF_LOOP" ] && python tools/train_mvr_ref.py $out/ref 30 > $out/train_mvr_ref.log 2>&1
