@@ -1342,6 +1342,14 @@ __device__ __forceinline__ void fine_tile(const FineArgs &A_entry, const int til
         s_zid[CHUNK] = make_float2(0.f, 0.f);
     }
 
+    // Depth cut of this wavefront's footprint (wave-uniform, refreshed after every chunk that is not the last): a candidate
+    // deeper than EVERY pixel's current K-th entry, or farther than the depth-merge threshold behind EVERY pixel's nearest
+    // entry so far, fails `useful` below at each of the 16 pixels whatever slice it lands in -- it is dropped in the cull, before
+    // its 16 ellipse tests.  (A pixel's bound is the smallest over its four slices: a full slice holds K fragments in front
+    // of the candidate; the footprint's bound is the largest over its pixels.  Bit patterns of z >= 0 order like the
+    // values; an empty slot reads 0xffffffff = no bound.)  Clustered clouds -- the reference's training loop at
+    // configs[2] ends with hundreds of overlapping splats per pixel -- spent their time testing occluded candidates.
+    unsigned cut_k = 0xffffffffu, cut_0 = 0xffffffffu;
     for (int64_t base = 0; base < count; base += step) {
         // this thread's candidate of the chunk and its slot in the (dense) LDS staging area
         bool have;
@@ -1410,8 +1418,10 @@ __device__ __forceinline__ void fine_tile(const FineArgs &A_entry, const int til
                 const float4 ge = s_geo[j];
                 // conservative, rounding-monotone rejection against the footprint (see splat_tile_rect); bitwise on
                 // purpose: short-circuit forms compile to nested exec-mask branches
-                const bool out = (int)(s_zid[j].y < 0) | (int)((f_xmax - ge.x) < -ge.z) | (int)((f_xmin - ge.x) > ge.z) |
-                                 (int)((f_ymax - ge.y) < -ge.w) | (int)((f_ymin - ge.y) > ge.w);
+                const float ez = s_zid[j].y;
+                const bool out = (int)(ez < 0) | (int)((f_xmax - ge.x) < -ge.z) | (int)((f_xmin - ge.x) > ge.z) |
+                                 (int)((f_ymax - ge.y) < -ge.w) | (int)((f_ymin - ge.y) > ge.w) |
+                                 (int)(__float_as_uint(ez) > cut_k) | (int)(ez - __uint_as_float(cut_0) > A.thr);
                 keep = !out;
             }
             const unsigned long long mask = __ballot(keep);
@@ -1471,6 +1481,17 @@ __device__ __forceinline__ void fine_tile(const FineArgs &A_entry, const int til
                 const bool useful = (int)hit & (int)(ekey < key[KMAX - 1]) & (int)!(ez - znear_now > A.thr);
                 if (__ballot(useful) != 0ull) klist_insert<KMAX>(key, ekey, useful);
             }
+        }
+        if (base + step < count) {   // (wave-uniform) more chunks follow: refresh the footprint's depth cut
+            unsigned hk = (unsigned)(key[KMAX - 1] >> 32), h0 = (unsigned)(key[0] >> 32);
+            hk = min(hk, dpp_u32<0xB1>(hk)); h0 = min(h0, dpp_u32<0xB1>(h0));     // the pixel's four slices (quad_perm)
+            hk = min(hk, dpp_u32<0x4E>(hk)); h0 = min(h0, dpp_u32<0x4E>(h0));
+            hk = max(hk, dpp_u32<0x124>(hk)); h0 = max(h0, dpp_u32<0x124>(h0));   // the row's four pixels (row_ror:4, :8)
+            hk = max(hk, dpp_u32<0x128>(hk)); h0 = max(h0, dpp_u32<0x128>(h0));
+            cut_k = max(max((unsigned)__builtin_amdgcn_readlane((int)hk, 0), (unsigned)__builtin_amdgcn_readlane((int)hk, 16)),
+                        max((unsigned)__builtin_amdgcn_readlane((int)hk, 32), (unsigned)__builtin_amdgcn_readlane((int)hk, 48)));
+            cut_0 = max(max((unsigned)__builtin_amdgcn_readlane((int)h0, 0), (unsigned)__builtin_amdgcn_readlane((int)h0, 16)),
+                        max((unsigned)__builtin_amdgcn_readlane((int)h0, 32), (unsigned)__builtin_amdgcn_readlane((int)h0, 48)));
         }
     }
 

@@ -58,6 +58,22 @@ def test_forward_all_k_vs_oracle(K):
         assert np.array_equal(g.cpu().numpy(), w)
 
 
+@pytest.mark.parametrize("K,thr,ties", [(5, 0.05, False), (5, 0.4, True), (1, 0.05, False), (8, 10.0, False), (12, 0.05, True)])
+@pytest.mark.parametrize("bin_size", [None, 0])
+def test_forward_deep_overlap_with_the_footprint_depth_cut(K, thr, ties, bin_size):
+    """Hundreds of overlapping splats per pixel (the state the reference's training loop reaches at configs[2]): tiles take
+    many candidate chunks, and from the second chunk on the fine kernel drops candidates behind every pixel's K-th entry or
+    farther than the merge threshold behind every pixel's nearest entry before their ellipse tests (raster_forward.hip,
+    `cut_k` / `cut_0`).  Fragments stay bit-exact, with depth ties ((z, idx) order) and with a threshold that never cuts."""
+    S = 64
+    sc = scenes.random_splats(5000, S, 2, seed=K + int(thr * 100), rmin=3.0, rmax=8.0, ties=ties)
+    got = _fwd(_dev(sc), S, K, thr, bin_size)
+    want = oracle.splat_forward(sc["points"], sc["ellipse"], sc["cutoff"], sc["radii"], sc["first_idx"],
+                                sc["num_pts"], S, K, thr)
+    for g, w in zip(got, want):
+        assert np.array_equal(g.cpu().numpy(), w)
+
+
 def test_forward_k_too_large_raises():
     sc = scenes.random_splats(10, 16, 1)
     with pytest.raises(RuntimeError, match="kMaxPointsPerPixel"):
