@@ -109,7 +109,8 @@ __device__ __forceinline__ int cell_coord(float v, float mn, float inv_cell, int
 __global__ __launch_bounds__(256) void knn_count_kernel(const float *__restrict__ pts, const int64_t *__restrict__ first_idx,
                                                         const int64_t *__restrict__ num_pts, int N, int64_t P,
                                                         const KnnGrid *__restrict__ grids, size_t stride,
-                                                        uint32_t *__restrict__ counts, int32_t *__restrict__ cell_of)
+                                                        uint32_t *__restrict__ counts, int32_t *__restrict__ cell_of,
+                                                        uint32_t *__restrict__ rank_of /* the point's arrival number in its cell */)
 {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= P) return;
@@ -121,7 +122,9 @@ __global__ __launch_bounds__(256) void knn_count_kernel(const float *__restrict_
     const int cz = cell_coord(pts[3 * p + 2], g.minz, g.inv_cell, g.res);
     const int c = (cz * g.res + cy) * g.res + cx;
     cell_of[p] = c;
-    atomicAdd(&counts[(size_t)n * stride + c], 1u);
+    // the counting atomic's return value is the point's slot inside the cell: the fill pass needs no second atomic (on a
+    // clustered cloud both passes are bound by the fullest cell: 3,900 same-address atomics, 86 us each way)
+    rank_of[p] = atomicAdd(&counts[(size_t)n * stride + c], 1u);
 }
 
 // Two-level exclusive scan of the cell counts.  Grid (blocks, N); block b of cloud n owns cells [1024 b, 1024 b + 1024).
@@ -210,15 +213,27 @@ struct KnnView {
     uint32_t *culls;       // (cameras) != 0: the camera drops at least one point of its cloud (written by knn_fill_kernel)
     int n_cams;
 };
-// mode 1 (one cloud, several cameras): every camera that drops NOTHING sees the same statistic -- the plain search of the
-// whole cloud.  Only the first of them (`knn_plain_camera`) runs it; knn_view_rows_kernel copies its row to the others.  A
-// camera that drops points runs its own masked search.  (With the near plane where the reference's data sets put it, znear =
-// 0.1, no camera drops anything: one search instead of one per camera.)
-__device__ __forceinline__ int knn_plain_camera(const KnnView &view)
+// The unmasked search of the whole cloud runs FIRST (one launch: statistic and K-th distance of every point); a camera's
+// masked search is only needed for a query that has a dropped point among the neighbours that count, and a dropped point
+// lies on the far side of one of the camera's two depth planes: the distance from a KEPT query to it is at least the
+// query's distance to that plane.  So whenever both planes are farther from the query than rho -- the K-th distance of the
+// unmasked search, or the search radius r if that is smaller (neighbours beyond r do not count) -- the camera's result is
+// the unmasked one and is copied.  Likewise for a camera that drops nothing at all.  (With the near plane where the
+// reference's data sets put it, znear = 0.1, no camera drops anything: one search, N copies.  With znear = 1.0 cutting
+// through the cloud, only the queries within their neighbourhood's reach of the cut search again: 8 cameras x 99,790
+// points of the trained cloud of tools/clustered_timing.py took 1.26 ms as eight masked searches.)
+// Exactness: every dropped point is farther than rho; with rho = the K-th distance the K nearest are all kept, so the
+// masked list is the unmasked list; with rho = r < the K-th distance, the entries within r are the same in both lists and
+// the others do not count.  The margin allows for the rounding of the view depth (1e-5 (1 + |z|)) and for a view matrix
+// whose depth axis is not a unit vector.  plain_dk = inf (fewer than K points in the cloud) never takes the shortcut.
+__device__ __forceinline__ bool knn_view_shortcut(uint32_t camera_drops, float x, float y, float z, float v2, float v6, float v10,
+                                                  float v14, float zn, float zf, float plain_dk, float r2)
 {
-    for (int c = 0; c < view.n_cams; ++c)
-        if (view.culls[c] == 0u) return c;
-    return -1;
+    if (camera_drops == 0u) return true;
+    const float zview = x * v2 + y * v6 + z * v10 + 1.0f * v14;
+    const float margin = fminf(zview - zn, zf - zview) - 1e-5f * (1.0f + fabsf(zview));
+    const float rho2 = r2 > 0.0f ? fminf(plain_dk, r2) : plain_dk;
+    return margin > 0.0f && margin * margin > rho2 * (v2 * v2 + v6 * v6 + v10 * v10) * 1.0002f;
 }
 __device__ __forceinline__ bool knn_kept(float x, float y, float z, float v2, float v6, float v10, float v14, float zn, float zf)
 {
@@ -231,7 +246,8 @@ __global__ __launch_bounds__(256) void knn_fill_kernel(const float *__restrict__
                                                        const int32_t *__restrict__ cell_of, size_t stride,
                                                        uint32_t *__restrict__ cursor,
                                                        float4 *__restrict__ sorted /* (P) xyz + id, grouped by cell */,
-                                                       const KnnView view = KnnView())
+                                                       const KnnView view = KnnView(),
+                                                       const uint32_t *__restrict__ rank_of = nullptr /* given: `cursor` = the cell offsets, read only */)
 {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= P) return;
@@ -239,7 +255,7 @@ __global__ __launch_bounds__(256) void knn_fill_kernel(const float *__restrict__
     if (c < 0) return;
     const int n = find_cloud(p, first_idx, num_pts, N);
     const float x = pts[3 * p], y = pts[3 * p + 1], z = pts[3 * p + 2];
-    const uint32_t pos = atomicAdd(&cursor[(size_t)n * stride + c], 1u);
+    const uint32_t pos = rank_of ? cursor[(size_t)n * stride + c] + rank_of[p] : atomicAdd(&cursor[(size_t)n * stride + c], 1u);
     sorted[first_idx[n] + pos] = make_float4(x, y, z, __int_as_float((int)p));
     if (view.mode != 0) {
         // which cameras drop a point of their cloud (dss_knn_kth_sqdist_view): one atomic per wavefront and camera that does
@@ -248,23 +264,152 @@ __global__ __launch_bounds__(256) void knn_fill_kernel(const float *__restrict__
             const float *vm = view.V + 16 * cam;
             const bool drop = !knn_kept(x, y, z, vm[2], vm[6], vm[10], vm[14], view.znear[cam], view.zfar[cam]);
             const unsigned long long m = __ballot(drop);
-            if (drop && (threadIdx.x & 63) == (unsigned)__builtin_ctzll(m)) atomicOr(&view.culls[cam], 1u);
+            // (one atomic per wavefront, and none once the flag is seen up: 12,000 atomics on eight words took 100 us at 8 x 100k)
+            if (drop && (threadIdx.x & 63) == (unsigned)__builtin_ctzll(m) &&
+                __hip_atomic_load(&view.culls[cam], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u)
+                atomicOr(&view.culls[cam], 1u);
         }
     }
 }
 
-// mode 1 of dss_knn_kth_sqdist_view: the rows of the cameras that drop nothing = the row of the first of them
-__global__ __launch_bounds__(256) void knn_view_rows_kernel(float *__restrict__ kth, int64_t P, const KnnView view)
+// ---------------------------------------------------------------------------------------------------------------
+// Clustered clouds.  The grid is uniform, sized for ~8 points per occupied cell of an evenly sampled surface.  The model of
+// the reference's training loop does not stay that way: after ~900 iterations at BASELINE configs[2] a few outliers have
+// stretched the bounding box to +-2 while nine tenths of the points sit within 0.55 of the origin -- a typical point shares
+// its cell with 650 others (3,900 in the fullest cell), every query scans ~4,000 candidates instead of ~200, and the two
+// searches of an iteration go from 0.13 / 0.16 ms to 1.7 / 2.3 ms (profiles/r6_b_train_mvr_ref_kernel_stats.csv).  No
+// single cell size serves a cloud whose neighbour distances span two orders of magnitude.  So, from KNN_SKIP_MIN_P points
+// on, the cell-sorted array gets a skip structure:
+//   * knn_dense_list_kernel lists the DENSE cells (more than KNN_DENSE points) and raises `dense_flag`; knn_subsort_kernel
+//     orders the points of each along a Morton curve of their position inside the cell, so that consecutive slots are
+//     close in space;
+//   * knn_block_box_kernel records the bounding box of every KNN_BLOCK consecutive slots;
+//   * the one-thread-per-query kernel first looks at its own sorted neighbourhood (own cell dense: the KNN_SEED slots around
+//     the query's slot) -- which gives a K-th distance close to the final one at once -- and then walks long candidate runs
+//     block by block, skipping every block whose box lies farther than the current K-th distance.
+// Same candidates rule, same (distance, id) order: results are identical; only points that cannot enter the list are skipped.
+// On the trained cloud: 3,999 -> 200 candidates + 250 box tests per query.  A cloud without dense cells pays one scan of
+// the cell counts (the queries then run exactly as before: `dense_flag` stays 0 and the boxes are neither built nor read).
+// ---------------------------------------------------------------------------------------------------------------
+#define KNN_SKIP_MIN_P 65536     // per call: below, the grid build is a chain of launch latencies and clouds are small
+#define KNN_DENSE 64             // points in a cell (and slots in a candidate run) from which the skip structure is used
+#define KNN_BLOCK 16             // slots per box
+#define KNN_SEED 16              // slots on either side of the query's own slot looked at first
+#define KNN_SUBSORT_MAX 4096     // largest cell that is sub-sorted (larger ones stay in arrival order: correct, loose boxes)
+#define KNN_SUBSORT_WGS 1024     // workgroups of the (persistent) sub-sort launch
+#define KNN_SUBSORT_THREADS 1024  // (the launch lasts as long as its largest cell: ~80 bitonic stages of 4096 keys)
+
+__device__ __forceinline__ uint32_t knn_spread5(uint32_t v)   // bit i of v (i < 5) -> bit 3 i
 {
-    const int cam = blockIdx.y;
-    const int src = knn_plain_camera(view);
-    if (view.culls[cam] != 0u || cam == src || src < 0) return;
-    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
-    if (i + 3 < P && ((((uintptr_t)kth) & 15u) == 0) && (P & 3) == 0) {
-        reinterpret_cast<float4 *>(kth + (size_t)cam * P)[i >> 2] = reinterpret_cast<const float4 *>(kth + (size_t)src * P)[i >> 2];
-    } else {
-        for (int64_t j = i; j < min(i + 4, P); ++j) kth[(size_t)cam * P + j] = kth[(size_t)src * P + j];
+    return (v & 1u) | ((v & 2u) << 2) | ((v & 4u) << 4) | ((v & 8u) << 6) | ((v & 16u) << 8);
+}
+
+// Dense cells of all clouds -> list[] (cloud, cell), *n_list, dense_flag.
+// One thread per cell, one atomic per wavefront that found any.
+__global__ __launch_bounds__(256) void knn_dense_list_kernel(const KnnGrid *__restrict__ grids, size_t stride,
+                                                             const uint32_t *__restrict__ offsets, uint2 *__restrict__ list,
+                                                             uint32_t *__restrict__ n_list, uint32_t *__restrict__ dense_flag)
+{
+    const int n = blockIdx.y;
+    const int res = grids[n].res, cells = res * res * res;
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t *off = offsets + (size_t)n * stride;
+    const bool dense = c < cells && off[c + 1] - off[c] > (uint32_t)KNN_DENSE;
+    const unsigned long long m = __ballot(dense);
+    if (m == 0ull) return;
+    const int lane = threadIdx.x & 63, leader = __builtin_ctzll(m);
+    uint32_t base = 0;
+    if (lane == leader) {
+        base = atomicAdd(n_list, (uint32_t)__popcll(m));
+        atomicOr(dense_flag, 1u);
     }
+    base = (uint32_t)__shfl((int)base, leader);
+    if (dense) list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = make_uint2((uint32_t)n, (uint32_t)c);
+}
+
+// Persistent grid over the list: one workgroup sorts one dense cell at a time in LDS -- keys = (15-bit Morton code of the
+// position inside the cell) << 12 | local slot, bitonic network over the next power of two; the points travel through
+// registers (read in sorted order, barrier, written back in place).
+__global__ __launch_bounds__(KNN_SUBSORT_THREADS) void knn_subsort_kernel(const KnnGrid *__restrict__ grids, size_t stride,
+                                                          const uint32_t *__restrict__ offsets,
+                                                          const int64_t *__restrict__ first_idx, float4 *__restrict__ sorted,
+                                                          const uint2 *__restrict__ list, const uint32_t *__restrict__ n_list)
+{
+    __shared__ uint32_t s_key[KNN_SUBSORT_MAX];
+    const int tid = threadIdx.x;
+    const uint32_t total = *n_list;
+    for (uint32_t it = blockIdx.x; it < total; it += gridDim.x) {
+        const uint2 e = list[it];
+        const int n = (int)e.x, cell = (int)e.y;
+        const KnnGrid g = grids[n];
+        const uint32_t *off = offsets + (size_t)n * stride;
+        const int64_t f0 = first_idx[n];
+        const uint32_t s = off[cell], cnt = off[cell + 1] - s;
+        if (cnt > (uint32_t)KNN_SUBSORT_MAX) continue;   // (workgroup-uniform)
+        uint32_t m = 128;
+        while (m < cnt) m <<= 1;
+        const int cx = cell % g.res, cy = (cell / g.res) % g.res, cz = cell / (g.res * g.res);
+        const float bx = g.minx + (float)cx * g.cell, by = g.miny + (float)cy * g.cell, bz = g.minz + (float)cz * g.cell;
+        for (uint32_t i = tid; i < m; i += KNN_SUBSORT_THREADS) {
+            uint32_t key = 0xffffffffu;
+            if (i < cnt) {
+                const float4 q = sorted[f0 + s + i];
+                const uint32_t ux = (uint32_t)min(31, max(0, (int)((q.x - bx) * g.inv_cell * 32.0f)));
+                const uint32_t uy = (uint32_t)min(31, max(0, (int)((q.y - by) * g.inv_cell * 32.0f)));
+                const uint32_t uz = (uint32_t)min(31, max(0, (int)((q.z - bz) * g.inv_cell * 32.0f)));
+                key = ((knn_spread5(ux) | (knn_spread5(uy) << 1) | (knn_spread5(uz) << 2)) << 12) | i;
+            }
+            s_key[i] = key;
+        }
+        __syncthreads();
+        for (uint32_t k = 2; k <= m; k <<= 1)
+            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                for (uint32_t t = tid; t < (m >> 1); t += KNN_SUBSORT_THREADS) {
+                    const uint32_t lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo | j;   // the pair (lo, lo ^ j)
+                    const uint32_t a = s_key[lo], b = s_key[hi];
+                    const bool up = (lo & k) == 0;
+                    if ((a > b) == up) { s_key[lo] = b; s_key[hi] = a; }
+                }
+                __syncthreads();
+            }
+        float4 hold[KNN_SUBSORT_MAX / KNN_SUBSORT_THREADS];
+#pragma unroll
+        for (int u = 0; u < KNN_SUBSORT_MAX / KNN_SUBSORT_THREADS; ++u) {
+            const uint32_t i = (uint32_t)u * KNN_SUBSORT_THREADS + tid;
+            if (i < cnt) hold[u] = sorted[f0 + s + (s_key[i] & 0xfffu)];
+        }
+        __builtin_amdgcn_s_waitcnt(0);   // every read of the cell's slots has returned ...
+        __syncthreads();                 // ... in every wavefront, before the first slot is overwritten
+#pragma unroll
+        for (int u = 0; u < KNN_SUBSORT_MAX / KNN_SUBSORT_THREADS; ++u) {
+            const uint32_t i = (uint32_t)u * KNN_SUBSORT_THREADS + tid;
+            if (i < cnt) sorted[f0 + s + i] = hold[u];
+        }
+        __syncthreads();   // (s_key is rewritten by the next cell)
+    }
+}
+
+// boxes[2 b], boxes[2 b + 1] = min / max corner of the packed slots [16 b, 16 b + 16) of the cell-sorted array.  Slots that
+// belong to no cloud hold stale bytes: a box can only grow by them (NaN is ignored by fminf / fmaxf), never lose a point.
+__global__ __launch_bounds__(256) void knn_block_box_kernel(const float4 *__restrict__ sorted, int64_t P,
+                                                            const uint32_t *__restrict__ dense_flag, float4 *__restrict__ boxes)
+{
+    if (*dense_flag == 0u) return;
+    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (b * KNN_BLOCK >= P) return;
+    float lo[3] = {__builtin_huge_valf(), __builtin_huge_valf(), __builtin_huge_valf()};
+    float hi[3] = {-__builtin_huge_valf(), -__builtin_huge_valf(), -__builtin_huge_valf()};
+#pragma unroll
+    for (int i = 0; i < KNN_BLOCK; ++i) {
+        const int64_t j = b * KNN_BLOCK + i;
+        if (j < P) {
+            const float4 q = sorted[j];
+            lo[0] = fminf(lo[0], q.x); lo[1] = fminf(lo[1], q.y); lo[2] = fminf(lo[2], q.z);
+            hi[0] = fmaxf(hi[0], q.x); hi[1] = fmaxf(hi[1], q.y); hi[2] = fmaxf(hi[2], q.z);
+        }
+    }
+    boxes[2 * b] = make_float4(lo[0], lo[1], lo[2], 0.f);
+    boxes[2 * b + 1] = make_float4(hi[0], hi[1], hi[2], 0.f);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -449,10 +594,15 @@ __global__ __launch_bounds__(256) void knn_query_kernel(const float *__restrict_
                                                         const float4 *__restrict__ sorted, int Krt,
                                                         float *__restrict__ kth_sqdist, float *__restrict__ dists,
                                                         int64_t *__restrict__ idx, float r2 /* > 0: FRNN semantics, see dss_knn_kth_sqdist_radius */,
-    const KnnView view = KnnView())
+    const KnnView view = KnnView(), const float4 *__restrict__ boxes = nullptr /* skip structure, see knn_subsort_kernel */,
+    const uint32_t *__restrict__ dense_flag = nullptr, const int role = 0 /* 1: only clouds without dense cells, 2: only clouds with */,
+    float *__restrict__ dk_out = nullptr /* !VIEW: the K-th distance itself (inf: fewer than K points), see knn_view_shortcut */,
+    const float *__restrict__ plain_stat = nullptr, const float *__restrict__ plain_dk = nullptr /* VIEW: the unmasked search */)
 {
     const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= P) return;
+    const bool skip = boxes != nullptr && *dense_flag != 0u;
+    if ((role == 1 && skip) || (role == 2 && !skip)) return;   // (the launch next to this one takes the cloud)
     const int n = find_cloud(slot, first_idx, num_pts, N);
     if (n < 0) {  // packed slot outside every cloud
         if (FULL) {
@@ -474,12 +624,11 @@ __global__ __launch_bounds__(256) void knn_query_kernel(const float *__restrict_
     float v2 = 0.f, v6 = 0.f, v10 = 0.f, v14 = 0.f, zn = 0.f, zf = 0.f;
     if (VIEW) {
         const int cam = view.mode == 1 ? (int)blockIdx.y : n;
-        // (a camera that drops nothing sees the plain statistic: only the first such camera searches, see knn_plain_camera)
-        if (view.mode == 1 && view.culls[cam] == 0u && cam != knn_plain_camera(view)) return;
         const float *vm = view.V + 16 * cam;
         v2 = vm[2]; v6 = vm[6]; v10 = vm[10]; v14 = vm[14]; zn = view.znear[cam]; zf = view.zfar[cam];
         if (view.mode == 1) kth_sqdist += (size_t)cam * (size_t)P;
         if (!knn_kept(qx, qy, qz, v2, v6, v10, v14, zn, zf)) { kth_sqdist[p] = 0.0f; return; }
+        if (knn_view_shortcut(view.culls[cam], qx, qy, qz, v2, v6, v10, v14, zn, zf, plain_dk[p], r2)) { kth_sqdist[p] = plain_stat[p]; return; }
     }
     const int cx = cell_coord(qx, g.minx, g.inv_cell, g.res);
     const int cy = cell_coord(qy, g.miny, g.inv_cell, g.res);
@@ -496,7 +645,7 @@ __global__ __launch_bounds__(256) void knn_query_kernel(const float *__restrict_
         return;
     }
     // One candidate: keep the K best in (distance, id) order (FULL) or by distance (kth only).
-    auto consider = [&](const float4 q) {
+    auto consider = [&](const float4 q) __attribute__((always_inline)) {
         const float dx = q.x - qx, dy = q.y - qy, dz = q.z - qz;
         float d2 = dx * dx + dy * dy + dz * dz;
         if (VIEW && !knn_kept(q.x, q.y, q.z, v2, v6, v10, v14, zn, zf)) d2 = __builtin_huge_valf();   // the camera drops it
@@ -535,7 +684,34 @@ __global__ __launch_bounds__(256) void knn_query_kernel(const float *__restrict_
     // whole (z, y) row of the search block is ONE contiguous range.  Four candidates are requested per memory round
     // trip (clamped, unconditional loads): the walk is latency-bound -- ~100 dependent 16-byte loads per query at
     // 2 wavefronts per CU took 210 us for 32k points when issued one at a time.
-    auto visit = [&](uint32_t s, uint32_t e) {
+    // skip structure (clustered clouds, see knn_subsort_kernel): the slots [seed_lo, seed_hi) around the query's own slot
+    // have been looked at before the rings start and are passed over afterwards; runs longer than KNN_DENSE slots are
+    // walked block by block, a block whose box is farther than the current K-th distance is not read.  The box distance
+    // uses the expression of `consider` on the clamped offsets, which are never larger in magnitude than those of a point
+    // inside the box: rounding is monotone, so box distance <= point distance in fp32 as well -- and the comparison is
+    // strict, so a candidate that ties with the K-th entry (and may win on its id) is still read.
+    uint32_t seed_lo = 0, seed_hi = 0;
+    auto visit = [&](uint32_t s, uint32_t e) __attribute__((always_inline)) {
+        if (skip && e - s > (uint32_t)KNN_DENSE) {
+            const uint64_t a0 = (uint64_t)f0 + s, a1 = (uint64_t)f0 + e;   // packed slots
+            for (uint64_t b = a0 / KNN_BLOCK; b * KNN_BLOCK < a1; ++b) {
+                const float4 mn = boxes[2 * b], mx = boxes[2 * b + 1];
+                const float dx = fmaxf(fmaxf(mn.x - qx, qx - mx.x), 0.0f), dy = fmaxf(fmaxf(mn.y - qy, qy - mx.y), 0.0f),
+                            dz = fmaxf(fmaxf(mn.z - qz, qz - mx.z), 0.0f);
+                if (dx * dx + dy * dy + dz * dz > best[K - 1]) continue;
+                const uint32_t j0 = (uint32_t)(max(b * KNN_BLOCK, a0) - (uint64_t)f0);
+                const uint32_t j1 = (uint32_t)(min(b * KNN_BLOCK + KNN_BLOCK, a1) - (uint64_t)f0);
+                for (uint32_t j = j0; j < j1; j += 4) {
+                    const float4 q0 = sorted[f0 + j], q1 = sorted[f0 + min(j + 1, j1 - 1)], q2 = sorted[f0 + min(j + 2, j1 - 1)],
+                                 q3 = sorted[f0 + min(j + 3, j1 - 1)];
+                    const int cnt = (int)min(j1 - j, 4u);
+#pragma nounroll
+                    for (int i = 0; i < cnt; ++i)
+                        if (j + i < seed_lo || j + i >= seed_hi) consider(i == 0 ? q0 : (i == 1 ? q1 : (i == 2 ? q2 : q3)));
+                }
+            }
+            return;
+        }
         for (uint32_t j = s; j < e; j += 4) {
             const float4 q0 = sorted[f0 + j], q1 = sorted[f0 + min(j + 1, e - 1)], q2 = sorted[f0 + min(j + 2, e - 1)],
                          q3 = sorted[f0 + min(j + 3, e - 1)];
@@ -544,6 +720,17 @@ __global__ __launch_bounds__(256) void knn_query_kernel(const float *__restrict_
             for (int i = 0; i < cnt; ++i) consider(i == 0 ? q0 : (i == 1 ? q1 : (i == 2 ? q2 : q3)));  // ONE copy of the insert
         }
     };
+    if (skip) {
+        // own cell dense (its points lie along a Morton curve): the neighbours of the query's slot are neighbours in space
+        const int c_own = (cz * g.res + cy) * g.res + cx;
+        const uint32_t cs = off[c_own], ce = off[c_own + 1];
+        if (ce - cs > (uint32_t)KNN_DENSE) {
+            const uint32_t me = (uint32_t)(slot - f0);
+            seed_lo = me > cs + KNN_SEED ? me - KNN_SEED : cs;
+            seed_hi = min(ce, me + KNN_SEED);
+            for (uint32_t j = seed_lo; j < seed_hi; ++j) consider(sorted[f0 + j]);
+        }
+    }
     // The search starts with the 3x3x3 block (the own cell alone almost never proves K >= 7 neighbours final): the
     // offsets of its nine rows are requested together and parked in LDS (a register array indexed by a rolled loop
     // would go to scratch, nine unrolled copies of the walk cost 246 VGPRs).  Further rings, rarely needed, add their
@@ -600,6 +787,8 @@ __global__ __launch_bounds__(256) void knn_query_kernel(const float *__restrict_
 #pragma unroll
         for (int k = 1; k < K; ++k) kth = (k < kk) ? best[k] : kth;
         if (bound == __builtin_huge_valf() || (bound > 0.0f && kth <= bound * bound)) break;
+        // fixed-radius statistic: nothing beyond r counts, and everything not yet visited is farther than `bound`
+        if (!FULL && r2 > 0.0f && bound > 0.0f && bound * bound > r2) break;
     }
     if (FULL) {
 #pragma unroll
@@ -613,6 +802,7 @@ __global__ __launch_bounds__(256) void knn_query_kernel(const float *__restrict_
     float kth = best[0];
 #pragma unroll
     for (int k = 1; k < K; ++k) kth = (k < kk) ? best[k] : kth;
+    if (!VIEW && dk_out != nullptr) dk_out[p] = kk < Krt ? __builtin_huge_valf() : kth;
     if (r2 > 0.0f) {
         // fixed-radius semantics of the reference's default neighbour search (frnn_grid_points(K, r), rasterizer.py:317-326):
         // neighbours beyond r come back as -1 and the statistic is the MAX over the K - 1 returned distances -- the farthest
@@ -681,7 +871,7 @@ __device__ __forceinline__ void knn_merge_round(float (&best)[K], int (&bid)[FUL
     }
 }
 
-template <int K, bool FULL, bool VIEW = false>
+template <int K, bool FULL, bool VIEW = false, bool SKIP = false /* compiled with the skip structure (P >= KNN_SKIP_MIN_P): +20 VGPRs */>
 __global__ __launch_bounds__(256) void knn_query_coop_kernel(const float *__restrict__ pts, const int64_t *__restrict__ first_idx,
                                                              const int64_t *__restrict__ num_pts, int N, int64_t P,
                                                              const KnnGrid *__restrict__ grids, size_t stride,
@@ -689,22 +879,26 @@ __global__ __launch_bounds__(256) void knn_query_coop_kernel(const float *__rest
                                                              const float4 *__restrict__ sorted, int Krt,
                                                              float *__restrict__ kth_sqdist, float *__restrict__ dists,
                                                              int64_t *__restrict__ idx, float r2 /* > 0: FRNN semantics, see dss_knn_kth_sqdist_radius */,
-    const KnnView view = KnnView(), const uint32_t chunks = 0 /* VIEW: query chunks per camera (the grid is persistent) */)
+    const KnnView view = KnnView(), const uint32_t chunks = 0 /* VIEW: query chunks per camera (the grid is persistent) */,
+    const float4 *__restrict__ boxes = nullptr /* skip structure, see knn_subsort_kernel */,
+    const uint32_t *__restrict__ dense_flag = nullptr, const int role = 0 /* 1: only clouds without dense cells, 2: only clouds with */,
+    float *__restrict__ dk_out = nullptr /* !VIEW: the K-th distance itself (inf: fewer than K points), see knn_view_shortcut */,
+    const float *__restrict__ plain_stat = nullptr, const float *__restrict__ plain_dk = nullptr /* VIEW: the unmasked search */)
 {
+    const bool skip = SKIP && boxes != nullptr && *dense_flag != 0u;
+    if ((role == 1 && skip) || (role == 2 && !skip)) return;
     constexpr int GPB = 256 / KNN_LPQ;   // query groups per workgroup
     const int grp = threadIdx.x / KNN_LPQ, sub = threadIdx.x % KNN_LPQ;
-    __shared__ uint32_t row_lo[9][GPB], row_hi[9][GPB];
+    __shared__ uint32_t row_lo[KNN_LPQ][GPB], row_hi[KNN_LPQ][GPB];
     float *const kth_base = kth_sqdist;
-    // VIEW, one cloud seen by several cameras: a PERSISTENT grid walks the (camera, chunk) items and skips the cameras whose
-    // row is a copy of the plain camera's (knn_plain_camera) -- as grid rows those would still cost a workgroup dispatch each
-    // (~3 ns: 44,000 workgroups at 8 x 100k points).  Otherwise: one pass, item = this workgroup.
+    // VIEW, one cloud seen by several cameras: a PERSISTENT grid walks the (camera, chunk) items (as grid rows, 44,000
+    // workgroups at 8 x 100k points, most of which only copy, would cost ~3 ns of dispatch each).  Otherwise: one pass,
+    // item = this workgroup.
     const bool walk = VIEW && view.mode == 1;
-    const int plain = walk ? knn_plain_camera(view) : -1;
     const uint32_t n_items = walk ? chunks * (uint32_t)view.n_cams : 1u;
     for (uint32_t item = walk ? blockIdx.x : 0u; item < n_items; item += walk ? gridDim.x : 1u) {
     const int cam_y = walk ? (int)(item / chunks) : 0;
     const uint32_t bx = walk ? item - (uint32_t)cam_y * chunks : blockIdx.x;
-    if (walk && view.culls[cam_y] == 0u && cam_y != plain) continue;
     kth_sqdist = kth_base;
     const int64_t slot = (int64_t)bx * GPB + grp;
     if (slot >= P) continue;   // (whole DPP rows leave together)
@@ -736,6 +930,10 @@ __global__ __launch_bounds__(256) void knn_query_coop_kernel(const float *__rest
             if (sub == 0) kth_sqdist[p] = 0.0f;
             continue;
         }
+        if (knn_view_shortcut(view.culls[cam], qx, qy, qz, v2, v6, v10, v14, zn, zf, plain_dk[p], r2)) {
+            if (sub == 0) kth_sqdist[p] = plain_stat[p];
+            continue;
+        }
     }
     const int cx = cell_coord(qx, g.minx, g.inv_cell, g.res);
     const int cy = cell_coord(qy, g.miny, g.inv_cell, g.res);
@@ -751,7 +949,7 @@ __global__ __launch_bounds__(256) void knn_query_coop_kernel(const float *__rest
         if (!FULL && sub == 0) kth_sqdist[p] = 0.0f;
         continue;
     }
-    auto consider = [&](const float4 q, bool on) {
+    auto consider = [&](const float4 q, bool on) __attribute__((always_inline)) {
         const float dx = q.x - qx, dy = q.y - qy, dz = q.z - qz;
         if (VIEW) on = on && knn_kept(q.x, q.y, q.z, v2, v6, v10, v14, zn, zf);   // the camera drops it
         const float d2 = on ? dx * dx + dy * dy + dz * dz : __builtin_huge_valf();
@@ -783,7 +981,72 @@ __global__ __launch_bounds__(256) void knn_query_coop_kernel(const float *__rest
     };
     // candidates [s, e) of the cell-sorted array, every KNN_LPQ-th one for this lane: the group's 16 loads of a trip are
     // one contiguous 256-byte run; two trips are requested together
-    auto visit = [&](uint32_t s, uint32_t e) {
+    // skip structure (clustered clouds, see knn_subsort_kernel; the reasoning about exactness is in knn_query_kernel): `kb` is
+    // a K-th distance the GROUP has established (after the seed, after every ring, and after a long run walked without one);
+    // a lane prunes with the smaller of it and its own list's K-th entry.  Lane i tests the box of block i of sixteen; the
+    // group then reads the surviving blocks one after the other, a slot per lane.
+    float kb = __builtin_huge_valf();
+    uint32_t seed_lo = 0, seed_hi = 0;
+    const int gsh = (int)(threadIdx.x & 48u);   // bit position of the group's lanes in the wavefront's ballot
+    auto merge_all = [&]() __attribute__((always_inline)) {
+        knn_merge_round<K, FULL, 0xB1>(best, bid);
+        knn_merge_round<K, FULL, 0x4E>(best, bid);
+        knn_merge_round<K, FULL, 0x141>(best, bid);
+        knn_merge_round<K, FULL, 0x140>(best, bid);
+    };
+    auto keep_lane0 = [&]() __attribute__((always_inline)) {   // lane 0 carries the merged list, the others start empty (nothing is counted twice)
+        const bool drop = sub != 0;   // (selects on values: a branch around stores to bid[] sends the array to scratch memory)
+#pragma unroll
+        for (int k = 0; k < K; ++k) best[k] = drop ? __builtin_huge_valf() : best[k];
+#pragma unroll
+        for (int k = 0; k < (FULL ? K : 1); ++k) bid[k] = drop ? 0x7fffffff : bid[k];
+    };
+    auto visit = [&](uint32_t s, uint32_t e) __attribute__((always_inline)) {
+        if (skip && e - s > (uint32_t)KNN_DENSE) {
+            const uint64_t a0 = (uint64_t)f0 + s, a1 = (uint64_t)f0 + e;   // packed slots
+            const uint64_t b_last = (a1 - 1) / KNN_BLOCK;
+            for (uint64_t bb = a0 / KNN_BLOCK; bb <= b_last; bb += 2 * KNN_LPQ) {   // (group-uniform) 32 blocks per trip
+                // two boxes per lane, their four loads in flight together: the walk is a chain of dependent round trips (boxes,
+                // then the survivors' slots) at ~6 wavefronts per SIMD -- the fewer trips, the faster
+                const uint64_t bA = bb + (uint64_t)sub, bB = bA + KNN_LPQ;
+                const bool inA = bA <= b_last, inB = bB <= b_last;
+                const float4 mnA = boxes[2 * (inA ? bA : b_last)], mxA = boxes[2 * (inA ? bA : b_last) + 1];
+                const float4 mnB = boxes[2 * (inB ? bB : b_last)], mxB = boxes[2 * (inB ? bB : b_last) + 1];
+                const float lim = fminf(kb, best[K - 1]);
+                const float ax = fmaxf(fmaxf(mnA.x - qx, qx - mxA.x), 0.0f), ay = fmaxf(fmaxf(mnA.y - qy, qy - mxA.y), 0.0f),
+                            az = fmaxf(fmaxf(mnA.z - qz, qz - mxA.z), 0.0f);
+                const float cx2 = fmaxf(fmaxf(mnB.x - qx, qx - mxB.x), 0.0f), cy2 = fmaxf(fmaxf(mnB.y - qy, qy - mxB.y), 0.0f),
+                            cz2 = fmaxf(fmaxf(mnB.z - qz, qz - mxB.z), 0.0f);
+                const bool passA = inA && !(ax * ax + ay * ay + az * az > lim);
+                const bool passB = inB && !(cx2 * cx2 + cy2 * cy2 + cz2 * cz2 > lim);
+                unsigned gm = ((unsigned)(__ballot(passA) >> gsh) & 0xffffu) | (((unsigned)(__ballot(passB) >> gsh) & 0xffffu) << 16);
+                while (gm != 0u) {
+                    // up to four surviving blocks per trip, their loads in flight together
+                    uint64_t j[4];
+                    bool on[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const bool have = gm != 0u;
+                        j[u] = (bb + (uint64_t)(have ? __builtin_ctz(gm) : 0)) * KNN_BLOCK + (uint64_t)sub;
+                        gm &= gm - (have ? 1u : 0u);
+                        const uint32_t jl = (uint32_t)(j[u] - (uint64_t)f0);
+                        on[u] = have && j[u] >= a0 && j[u] < a1 && (jl < seed_lo || jl >= seed_hi);
+                    }
+                    const float4 q0 = sorted[on[0] ? j[0] : a0], q1 = sorted[on[1] ? j[1] : a0], q2 = sorted[on[2] ? j[2] : a0],
+                                 q3 = sorted[on[3] ? j[3] : a0];
+                    consider(q0, on[0]);
+                    consider(q1, on[1]);
+                    consider(q2, on[2]);
+                    consider(q3, on[3]);
+                }
+            }
+            if (kb == __builtin_huge_valf()) {   // a long run without a group bound: establish one now
+                merge_all();
+                kb = best[K - 1];
+                keep_lane0();
+            }
+            return;
+        }
         for (uint32_t base = s; base < e; base += 2 * KNN_LPQ) {   // (group-uniform trip count)
             const uint32_t j0 = base + (uint32_t)sub, j1 = j0 + KNN_LPQ;
             const bool on0 = j0 < e, on1 = j1 < e;
@@ -792,6 +1055,23 @@ __global__ __launch_bounds__(256) void knn_query_coop_kernel(const float *__rest
             consider(q1, on1);
         }
     };
+    if (skip) {
+        // own cell dense (its points lie along a Morton curve): the neighbours of the query's slot are neighbours in space
+        const int c_own = (cz * g.res + cy) * g.res + cx;
+        const uint32_t cs = off[c_own], ce = off[c_own + 1];
+        if (ce - cs > (uint32_t)KNN_DENSE) {
+            const uint32_t me = (uint32_t)(slot - f0);
+            seed_lo = me > cs + KNN_SEED ? me - KNN_SEED : cs;
+            seed_hi = min(ce, me + KNN_SEED);
+            for (uint32_t j = seed_lo + (uint32_t)sub; j < seed_lo + 2 * KNN_SEED; j += KNN_LPQ) {   // (two trips, group-uniform)
+                const bool on = j < seed_hi;
+                consider(sorted[f0 + (on ? j : seed_lo)], on);
+            }
+            merge_all();
+            kb = best[K - 1];
+            keep_lane0();
+        }
+    }
     if (sub < 9) {   // lane r of the group fetches the offsets of row r of the 3 x 3 x 3 block
         const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.res - 1);
         const int z = cz + sub / 3 - 1, y = cy + sub % 3 - 1;
@@ -808,29 +1088,47 @@ __global__ __launch_bounds__(256) void knn_query_coop_kernel(const float *__rest
         const int z0 = max(cz - ring, 0), z1 = min(cz + ring, g.res - 1);
         const int ny = y1 - y0 + 1;
         const int walks = ring == 1 ? 9 : 2 * ny * (z1 - z0 + 1);
+        if (ring == 1) {
 #pragma nounroll
-        for (int t = 0; t < walks; ++t) {
-            uint32_t s, e;
-            if (ring == 1) {
-                s = row_lo[t][grp];
-                e = row_hi[t][grp];
-            } else {
-                const int row = t >> 1, z = z0 + row / ny, y = y0 + row % ny;
-                const int c = (z * g.res + y) * g.res;
-                const bool full = z == cz - ring || z == cz + ring || y == cy - ring || y == cy + ring;
-                const int xa = full ? x0 : ((t & 1) ? cx + ring : cx - ring);
-                const int xb = full ? x1 : xa;
-                if ((full && (t & 1)) || xa < 0 || xb >= g.res) continue;
-                s = off[c + xa];
-                e = off[c + xb + 1];
+            for (int t = 0; t < 9; ++t) visit(row_lo[t][grp], row_hi[t][grp]);
+        } else {
+            // shells: the sixteen lanes fetch the ranges of sixteen walks together and the group visits the non-empty ones.
+            // (One walk after the other is a dependent round trip per walk, most of them for an EMPTY range: a stray point
+            // needs four or five rings -- ~600 walks --, and the launch lasts as long as its slowest query: 0.55 ms for the
+            // trained cloud of tools/clustered_timing.py whatever the rest of the kernel did.)
+#pragma nounroll
+            for (int t0 = 0; t0 < walks; t0 += KNN_LPQ) {
+                const int t = t0 + sub;
+                uint32_t s = 0, e = 0;
+                if (t < walks) {
+                    const int row = t >> 1, z = z0 + row / ny, y = y0 + row % ny;
+                    const int c = (z * g.res + y) * g.res;
+                    const bool full = z == cz - ring || z == cz + ring || y == cy - ring || y == cy + ring;
+                    const int xa = full ? x0 : ((t & 1) ? cx + ring : cx - ring);
+                    const int xb = full ? x1 : xa;
+                    if (!((full && (t & 1)) || xa < 0 || xb >= g.res)) {   // (a full row is one walk)
+                        s = off[c + xa];
+                        e = off[c + xb + 1];
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                row_lo[sub][grp] = s;
+                row_hi[sub][grp] = e;
+                __builtin_amdgcn_wave_barrier();   // (same wavefront writes and reads: LDS operations of a wave complete in order)
+                unsigned ne = (unsigned)(__ballot(e > s) >> gsh) & 0xffffu;
+                while (ne != 0u) {
+                    const int i = __builtin_ctz(ne);
+                    ne &= ne - 1u;
+                    visit(row_lo[i][grp], row_hi[i][grp]);
+                }
             }
-            visit(s, e);
         }
         // the group's K best: four merge rounds inside the DPP row, every lane ends with the same list
         knn_merge_round<K, FULL, 0xB1>(best, bid);    // quad_perm [1,0,3,2]
         knn_merge_round<K, FULL, 0x4E>(best, bid);    // quad_perm [2,3,0,1]
         knn_merge_round<K, FULL, 0x141>(best, bid);   // row_half_mirror
         knn_merge_round<K, FULL, 0x140>(best, bid);   // row_mirror
+        kb = best[K - 1];
         float bound = __builtin_huge_valf();
         if (cx - ring > 0) bound = fminf(bound, qx - (g.minx + (float)(cx - ring) * g.cell));
         if (cx + ring < g.res - 1) bound = fminf(bound, (g.minx + (float)(cx + ring + 1) * g.cell) - qx);
@@ -843,6 +1141,8 @@ __global__ __launch_bounds__(256) void knn_query_coop_kernel(const float *__rest
 #pragma unroll
         for (int k = 1; k < K; ++k) kth = (k < kk) ? best[k] : kth;
         if (bound == __builtin_huge_valf() || (bound > 0.0f && kth <= bound * bound)) break;
+        // fixed-radius statistic: nothing beyond r counts, and everything not yet visited is farther than `bound`
+        if (!FULL && r2 > 0.0f && bound > 0.0f && bound * bound > r2) break;
         if (sub != 0) {   // next ring: lane 0 carries the merged list, the others start empty (nothing is counted twice)
 #pragma unroll
             for (int k = 0; k < K; ++k) best[k] = __builtin_huge_valf();
@@ -851,6 +1151,12 @@ __global__ __launch_bounds__(256) void knn_query_coop_kernel(const float *__rest
         }
     }
     if (sub != 0) continue;
+    if (!FULL && !VIEW && dk_out != nullptr) {
+        float dk = best[0];
+#pragma unroll
+        for (int k = 1; k < K; ++k) dk = (k < kk) ? best[k] : dk;
+        dk_out[p] = kk < Krt ? __builtin_huge_valf() : dk;
+    }
     if (FULL) {
 #pragma unroll
         for (int k = 0; k < K; ++k)
@@ -1013,7 +1319,10 @@ extern "C" size_t dss_knn_workspace(int N, int64_t P)
     const size_t n = N > 0 ? N : 1, p = P > 0 ? P : 1;
     return align_up(n * 6 * 4 * KNN_BB_WGS, 256) + align_up(n * sizeof(KnnGrid), 256) + align_up((knn_cells(N, P) + 1) * 4, 256) * 3 +
            align_up(n * (size_t)knn_blocks(P) * 4, 256) + align_up(p * 4, 256) + align_up(p * 16, 256) +
-           KNN_MAX_VIEW_CAMS * 4;   // dss_knn_kth_sqdist_view: one "drops points" flag per camera
+           (KNN_MAX_VIEW_CAMS + 64) * 4 +   // dss_knn_kth_sqdist_view: one "drops points" flag per camera; the "dense cells" flag
+           align_up((p / KNN_BLOCK + 1) * 32, 256) +  // the block boxes of the skip structure (knn_subsort_kernel)
+           align_up((p / KNN_DENSE + 1) * 8, 256) +    // and its list of dense cells
+           align_up(p * 4, 256) * 3;                   // arrival numbers (knn_count_kernel); dss_knn_kth_sqdist_view: the unmasked search's two rows
 }
 
 #define KNN_FULL_MAX_K 40
@@ -1062,12 +1371,21 @@ static int knn_run(const char *who, const float *points, const int64_t *first_id
     uint32_t *blk_tot = reinterpret_cast<uint32_t *>(w + off);    off += align_up((size_t)N * nblk * 4, 256);
     int32_t *cell_of = reinterpret_cast<int32_t *>(w + off);      off += align_up((size_t)P * 4, 256);
     float4 *sorted = reinterpret_cast<float4 *>(w + off);                    off += align_up((size_t)P * 16, 256);
+    uint32_t *flags = reinterpret_cast<uint32_t *>(w + off);         off += (KNN_MAX_VIEW_CAMS + 64) * 4;   // [cameras | dense]
+    float4 *boxes = reinterpret_cast<float4 *>(w + off);            off += align_up(((size_t)P / KNN_BLOCK + 1) * 32, 256);
+    uint2 *dense_list = reinterpret_cast<uint2 *>(w + off);         off += align_up(((size_t)P / KNN_DENSE + 1) * 8, 256);
+    uint32_t *rank_of = reinterpret_cast<uint32_t *>(w + off);      off += align_up((size_t)P * 4, 256);
+    float *plain_stat = reinterpret_cast<float *>(w + off);         off += align_up((size_t)P * 4, 256);
+    float *plain_dk = reinterpret_cast<float *>(w + off);           off += align_up((size_t)P * 4, 256);
+    uint32_t *dense_flag = flags + KNN_MAX_VIEW_CAMS, *n_dense = dense_flag + 1;
+    const bool skip = P >= KNN_SKIP_MIN_P && option(DSS_OPT_KNN_QUERY) != 3;   // (3: the uniform-grid walk whatever the cloud, for A/B)
     if (view.mode != 0) {
         if (n_cams > KNN_MAX_VIEW_CAMS) { set_error("%s: at most %d cameras", who, KNN_MAX_VIEW_CAMS); return DSS_ERR_UNSUPPORTED; }
-        view.culls = reinterpret_cast<uint32_t *>(w + off);
+        view.culls = flags;
         view.n_cams = n_cams;
         if (hipMemsetAsync(view.culls, 0, (size_t)n_cams * 4, st) != hipSuccess) return check_launch("knn view memset");
     }
+    if (skip && hipMemsetAsync(dense_flag, 0, 8, st) != hipSuccess) return check_launch("knn flag memset");
     const unsigned pb_s = (unsigned)((P + 255) / 256);
     if (P <= KNN_SMALL_P && N <= KNN_GRID_LDS && nblk <= KNN_SCAN1_BLOCKS) {
         // small inputs: four launches instead of eight (see knn_bbox_partial_kernel)
@@ -1086,61 +1404,116 @@ static int knn_run(const char *who, const float *points, const int64_t *first_id
         if (int rc = launch_cloud_bbox(points, first_idx, num_pts, N, P, bbox, st)) return rc;
         hipLaunchKernelGGL(knn_grid_kernel, dim3((N + 63) / 64), dim3(64), 0, st, bbox, num_pts, N, knn_res_cap(P), grids);
         hipLaunchKernelGGL(knn_count_kernel, dim3(pb), dim3(256), 0, st, points, first_idx, num_pts, N, P, grids, stride,
-                           counts, cell_of);
+                           counts, cell_of, rank_of);
         hipLaunchKernelGGL(knn_scan_local_kernel, dim3(nblk, N), dim3(256), 0, st, counts, grids, stride, nblk, offsets,
                            blk_tot);
         hipLaunchKernelGGL(knn_scan_add_kernel, dim3(nblk, N), dim3(256), 0, st, grids, stride, nblk, blk_tot, offsets, cursor);
         hipLaunchKernelGGL(knn_fill_kernel, dim3(pb), dim3(256), 0, st, points, first_idx, num_pts, N, P, cell_of, stride,
-                           cursor, sorted, view);
+                           offsets, sorted, view, rank_of);
     }
+    if (skip) {
+        hipLaunchKernelGGL(knn_dense_list_kernel, dim3((unsigned)((stride + 254) / 256), N), dim3(256), 0, st, grids, stride, offsets,
+                           dense_list, n_dense, dense_flag);
+        hipLaunchKernelGGL(knn_subsort_kernel, dim3(KNN_SUBSORT_WGS), dim3(KNN_SUBSORT_THREADS), 0, st, grids, stride, offsets, first_idx, sorted,
+                           dense_list, n_dense);
+        hipLaunchKernelGGL(knn_block_box_kernel, dim3((unsigned)((P / KNN_BLOCK + 256) / 256)), dim3(256), 0, st, sorted, P,
+                           dense_flag, boxes);
+    }
+    const float4 *bx = skip ? boxes : nullptr;
+    const uint32_t *df = skip ? dense_flag : nullptr;
     // small inputs: one wavefront per workgroup, so that the few hundred wavefronts spread over all 256 CUs
     const unsigned qt = P <= 131072 ? 64u : 256u;
     const unsigned qb = (unsigned)((P + qt - 1) / qt);
     const unsigned gy = view.mode == 1 ? (unsigned)n_cams : 1u;
-#define KNN_LAUNCH(KK, FF)                                                                                          \
+    // ROLE 0: the launch takes every cloud (and uses the skip structure where `dense_flag` is up); 2: it runs only for clouds
+    // with dense cells, next to a cooperative launch that leaves those alone
+#define KNN_LAUNCH_R(KK, FF, ROLE)                                                                                  \
     hipLaunchKernelGGL((knn_query_kernel<KK, FF>), dim3(qb), dim3(qt), 0, st, points, first_idx, num_pts, N, P, grids,  \
-                       stride, offsets, sorted, K, kth_sqdist, dists, idx, r2, KnnView())
+                       stride, offsets, sorted, K, kth_sqdist, dists, idx, r2, KnnView(), bx, df, ROLE)
+#define KNN_LAUNCH(KK, FF) KNN_LAUNCH_R(KK, FF, 0)
     // cooperative kernel: 16 lanes per query (K <= 16); the one-thread-per-query kernel keeps the deep lists
     const unsigned cb = (unsigned)((P + (256 / KNN_LPQ) - 1) / (256 / KNN_LPQ));
-#define KNN_LAUNCH_COOP(KK, FF)                                                                                     \
-    hipLaunchKernelGGL((knn_query_coop_kernel<KK, FF>), dim3(cb), dim3(256), 0, st, points, first_idx, num_pts, N, P, grids, \
-                       stride, offsets, sorted, K, kth_sqdist, dists, idx, r2, KnnView())
-    const int qopt = option(DSS_OPT_KNN_QUERY);   // 0: by size, 1: cooperative, 2: one thread per query
+#define KNN_LAUNCH_COOP_R(KK, FF, ROLE)                                                                             \
+    do {                                                                                                            \
+        if (skip)                                                                                                   \
+            hipLaunchKernelGGL((knn_query_coop_kernel<KK, FF, false, true>), dim3(cb), dim3(256), 0, st, points, first_idx, num_pts, \
+                               N, P, grids, stride, offsets, sorted, K, kth_sqdist, dists, idx, r2, KnnView(), 0u, bx, df, ROLE); \
+        else                                                                                                        \
+            hipLaunchKernelGGL((knn_query_coop_kernel<KK, FF>), dim3(cb), dim3(256), 0, st, points, first_idx, num_pts, N, P, \
+                               grids, stride, offsets, sorted, K, kth_sqdist, dists, idx, r2, KnnView(), 0u, bx, df, ROLE); \
+    } while (0)
+#define KNN_LAUNCH_COOP(KK, FF) KNN_LAUNCH_COOP_R(KK, FF, 0)
+    // a size at which the one-thread kernel is the choice for an evenly sampled cloud, K <= 16: clouds with dense cells go to
+    // the cooperative kernel all the same (sixteen boxes tested per trip), as a second launch; each launch leaves at once
+    // when the cloud is not its kind
+#define KNN_LAUNCH_BOTH(KK, FF)                                                                                     \
+    do {                                                                                                            \
+        if (skip) { KNN_LAUNCH_R(KK, FF, 1); KNN_LAUNCH_COOP_R(KK, FF, 2); } else KNN_LAUNCH(KK, FF);                 \
+    } while (0)
+    const int qopt = option(DSS_OPT_KNN_QUERY) == 3 ? 0 : option(DSS_OPT_KNN_QUERY);   // 0: by size, 1: cooperative, 2: one thread per query (3: by size, no skip structure)
     if (view.mode != 0) {
         // K-th distance under per-camera culling (K <= 8: the variance-scale statistic): one grid row per camera
         if (full || K > 8) { set_error("%s: the per-camera search is built for the K-th distance with K <= 8", who); return DSS_ERR_UNSUPPORTED; }
         const bool coop = qopt == 1 || (qopt == 0 && P <= KNN_COOP_KTH_MAX_P);
+        // (1) the unmasked search of every point: statistic + K-th distance (see knn_view_shortcut)
+        if (coop) {
+            if (skip)
+                hipLaunchKernelGGL((knn_query_coop_kernel<8, false, false, true>), dim3(cb), dim3(256), 0, st, points, first_idx,
+                                   num_pts, N, P, grids, stride, offsets, sorted, K, plain_stat, dists, idx, r2, KnnView(), 0u, bx, df, 0,
+                                   plain_dk);
+            else
+                hipLaunchKernelGGL((knn_query_coop_kernel<8, false>), dim3(cb), dim3(256), 0, st, points, first_idx, num_pts, N, P,
+                                   grids, stride, offsets, sorted, K, plain_stat, dists, idx, r2, KnnView(), 0u, bx, df, 0, plain_dk);
+        } else if (skip) {
+            // (clouds with dense cells go to the cooperative kernel at every size, see KNN_LAUNCH_BOTH)
+            hipLaunchKernelGGL((knn_query_kernel<8, false>), dim3(qb), dim3(qt), 0, st, points, first_idx, num_pts, N, P, grids,
+                               stride, offsets, sorted, K, plain_stat, dists, idx, r2, KnnView(), bx, df, 1, plain_dk);
+            hipLaunchKernelGGL((knn_query_coop_kernel<8, false, false, true>), dim3(cb), dim3(256), 0, st, points, first_idx,
+                               num_pts, N, P, grids, stride, offsets, sorted, K, plain_stat, dists, idx, r2, KnnView(), 0u, bx, df, 2,
+                               plain_dk);
+        } else {
+            hipLaunchKernelGGL((knn_query_kernel<8, false>), dim3(qb), dim3(qt), 0, st, points, first_idx, num_pts, N, P, grids,
+                               stride, offsets, sorted, K, plain_stat, dists, idx, r2, KnnView(), bx, df, 0, plain_dk);
+        }
+        // (2) per camera: copy, or search again among the points the camera keeps
         if (coop) {
             // one cloud, several cameras: a persistent grid over the (camera, chunk) items (at most 8 workgroups per CU's worth)
             const unsigned long long items = (unsigned long long)cb * gy;
             const unsigned grid = view.mode == 1 ? (unsigned)(items < 16384ull ? items : 16384ull) : cb;
-            hipLaunchKernelGGL((knn_query_coop_kernel<8, false, true>), dim3(grid), dim3(256), 0, st, points, first_idx, num_pts,
-                               N, P, grids, stride, offsets, sorted, K, kth_sqdist, dists, idx, r2, view, cb);
+            if (skip)
+                hipLaunchKernelGGL((knn_query_coop_kernel<8, false, true, true>), dim3(grid), dim3(256), 0, st, points, first_idx,
+                                   num_pts, N, P, grids, stride, offsets, sorted, K, kth_sqdist, dists, idx, r2, view, cb, bx, df, 0,
+                                   nullptr, plain_stat, plain_dk);
+            else
+                hipLaunchKernelGGL((knn_query_coop_kernel<8, false, true>), dim3(grid), dim3(256), 0, st, points, first_idx, num_pts,
+                                   N, P, grids, stride, offsets, sorted, K, kth_sqdist, dists, idx, r2, view, cb, bx, df, 0, nullptr,
+                                   plain_stat, plain_dk);
         } else {
             hipLaunchKernelGGL((knn_query_kernel<8, false, true>), dim3(qb, gy), dim3(qt), 0, st, points, first_idx, num_pts, N, P,
-                               grids, stride, offsets, sorted, K, kth_sqdist, dists, idx, r2, view);
+                               grids, stride, offsets, sorted, K, kth_sqdist, dists, idx, r2, view, bx, df, 0, nullptr, plain_stat,
+                               plain_dk);
         }
-        if (view.mode == 1 && n_cams > 1)   // the rows of the cameras that drop nothing = the plain camera's row
-            hipLaunchKernelGGL(knn_view_rows_kernel, dim3((unsigned)((P + 1023) / 1024), (unsigned)n_cams), dim3(256), 0, st,
-                               kth_sqdist, P, view);
         return check_launch(who);
     }
     if (full) {
         // full lists: the cooperative kernel wins while the launch is latency-bound (32k points, K = 12: 58 us against
         // ~100); at 100k points the merges of (distance, id) lists cost more than the shorter chains save (182 vs 155 us)
         const bool coop = qopt == 1 || (qopt == 0 && P <= 65536);
-        if (K <= 8) { if (coop) KNN_LAUNCH_COOP(8, true); else KNN_LAUNCH(8, true); }
-        else if (K <= 12) { if (coop) KNN_LAUNCH_COOP(12, true); else KNN_LAUNCH(12, true); }  // the regularisers' knn_k (trainer.py:134-137)
-        else if (K <= 16) { if (coop) KNN_LAUNCH_COOP(16, true); else KNN_LAUNCH(16, true); }
+        if (K <= 8) { if (coop) KNN_LAUNCH_COOP(8, true); else KNN_LAUNCH_BOTH(8, true); }
+        else if (K <= 12) { if (coop) KNN_LAUNCH_COOP(12, true); else KNN_LAUNCH_BOTH(12, true); }  // the regularisers' knn_k (trainer.py:134-137)
+        else if (K <= 16) { if (coop) KNN_LAUNCH_COOP(16, true); else KNN_LAUNCH_BOTH(16, true); }
         else KNN_LAUNCH(KNN_FULL_MAX_K, true);
     } else {
         // K-th distance only: cooperative up to KNN_COOP_KTH_MAX_P points (tools/knn_sweep.py, profiles/r4_d_knn_sweep.json)
         const bool coop = qopt == 1 || (qopt == 0 && P <= KNN_COOP_KTH_MAX_P);
-        if (K <= 8) { if (coop) KNN_LAUNCH_COOP(8, false); else KNN_LAUNCH(8, false); }
-        else { if (coop) KNN_LAUNCH_COOP(KNN_MAX_K, false); else KNN_LAUNCH(KNN_MAX_K, false); }
+        if (K <= 8) { if (coop) KNN_LAUNCH_COOP(8, false); else KNN_LAUNCH_BOTH(8, false); }
+        else { if (coop) KNN_LAUNCH_COOP(KNN_MAX_K, false); else KNN_LAUNCH_BOTH(KNN_MAX_K, false); }
     }
+#undef KNN_LAUNCH_BOTH
 #undef KNN_LAUNCH_COOP
+#undef KNN_LAUNCH_COOP_R
 #undef KNN_LAUNCH
+#undef KNN_LAUNCH_R
     return check_launch(who);
 }
 

@@ -70,7 +70,11 @@ DSS_API const char *dss_last_error(void);
  *                             gathered tensor exceeds 4 GB); exists so that a test can reach that variant.
  *   DSS_OPT_KNN_QUERY       query kernel of dss_knn_kth_sqdist / dss_knn_points: 0 (default) = chosen from P and K (the
  *                           cooperative kernel -- 16 lanes per query -- while the launch is latency-bound, one thread per
- *                           query above), 1 = cooperative, 2 = one thread per query (K <= 16 for 1; A/B measurements).
+ *                           query above), 1 = cooperative, 2 = one thread per query (K <= 16 for 1; A/B measurements);
+ *                           3 = as 0 without the skip structure of clustered clouds (from 65,536 points on, cells with more
+ *                           than 64 points are ordered along a Morton curve and walked in 16-slot blocks whose boxes are
+ *                           tested against the current K-th distance: knn.hip, knn_subsort_kernel).  Results do not depend
+ *                           on it.
  *   DSS_OPT_BACKWARD_FUSED  launch form of dss_render_backward for short lists (P <= 262,144, whole image): 0 (default) =
  *                             automatic; 1 = the round-3 sequence (compaction | median | gather kernels); 4 = two launches
  *                             (segments + alpha plane | medians + gather: the gather's workgroups do the blend half of their

@@ -265,3 +265,81 @@ def test_masked_culling_renders_what_the_references_drop_then_search_order_rende
     a, b = images[False], images[True]
     assert a.shape == b.shape and float(a[..., 3].sum()) > 500
     assert torch.equal(a[..., 3], b[..., 3]) and float((a - b).abs().max()) <= 1e-6, float((a - b).abs().max())
+
+
+def _clustered_clouds():
+    """-> list of clouds: [0] the model of the reference's training loop after 893 iterations at configs[2] (dense bulk, thin
+    halo out to radius 2.1: tests/golden/trained_cloud_cfg3.npz), [1] a synthetic one with a cell of more than 4,096 points
+    (not sub-sorted), exact duplicates and far outliers, [2] an evenly sampled surface (no dense cell)."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "trained_cloud_cfg3.npz"))
+    rng = np.random.default_rng(7)
+    blob = rng.normal(0, 0.004, (12000, 3)).astype(np.float32)                      # > 4096 points in one cell
+    shell = rng.normal(0, 1, (30000, 3)); shell = (0.4 * shell / np.linalg.norm(shell, axis=1, keepdims=True)).astype(np.float32)
+    clump = (rng.normal(0, 0.02, (20000, 3)) + [0.3, 0.1, -0.2]).astype(np.float32)
+    dup = np.repeat(rng.uniform(-0.05, 0.05, (500, 3)), 4, 0).astype(np.float32)
+    far = rng.uniform(-3, 3, (300, 3)).astype(np.float32)
+    synth = np.concatenate([blob, shell, clump, dup, far])[rng.permutation(12000 + 30000 + 20000 + 2000 + 300)]
+    even, _, _ = scenes.synthetic_cloud(20000, seed=9)
+    return [z["points"].astype(np.float32), synth, even.astype(np.float32)]
+
+
+def _with_query_option(value, fn):
+    from dss_amd import _lib
+    _lib.set_option(_lib.OPT_KNN_QUERY, value)
+    try:
+        return fn()
+    finally:
+        _lib.set_option(_lib.OPT_KNN_QUERY, 0)
+
+
+@pytest.mark.parametrize("which", ["trained", "packed"])
+def test_knn_skip_structure_of_clustered_clouds_is_exact(which):
+    """From 65,536 points on, cells with more than 64 points are ordered along a Morton curve and long candidate runs are walked
+    in 16-slot blocks whose boxes are tested against the current K-th distance (knn.hip, knn_subsort_kernel).  Same results,
+    bit for bit, as the uniform walk (DSS_OPT_KNN_QUERY = 3), which the tests above pin against the KD-tree -- K-th distance,
+    full (distance, id) lists with ties, fixed-radius statistic, per-camera culling -- and against the KD-tree directly."""
+    clouds = _clustered_clouds()
+    clouds = clouds[:1] if which == "trained" else clouds
+    pts = np.concatenate(clouds, 0)
+    num = np.array([c.shape[0] for c in clouds], np.int64)
+    first = np.cumsum(num) - num
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    P, F, Nn = t(pts), t(first), t(num)
+    # K-th distance, plain and fixed-radius
+    for K, r in ((7, None), (7, 0.2), (16, None)):
+        a = ops.knn_kth_sqdist(P, F, Nn, K, radius=r)
+        b = _with_query_option(3, lambda: ops.knn_kth_sqdist(P, F, Nn, K, radius=r))
+        assert torch.equal(a, b), (K, r, (a != b).sum().item())
+        want = np.concatenate([_ref_kth(c, K) if r is None else _ref_radius_stat(c, K, r) for c in clouds])
+        assert np.allclose(a.cpu().numpy(), want, rtol=2e-5, atol=1e-9), np.abs(a.cpu().numpy() - want).max()
+    # full lists
+    for K in (12, 34):
+        da, ia = ops.knn_points(P, F, Nn, K)
+        db, ib = _with_query_option(3, lambda: ops.knn_points(P, F, Nn, K))
+        assert torch.equal(da, db) and torch.equal(ia, ib), K
+    rng = np.random.default_rng(0)
+    da, ia = ops.knn_points(P, F, Nn, 12)
+    da, ia = da.cpu().numpy(), ia.cpu().numpy()
+    for f, n, c in zip(first, num, clouds):
+        sel = rng.choice(n, 4000, replace=False)
+        d_ref, i_ref = cKDTree(c.astype(np.float64)).query(c[sel].astype(np.float64), k=12)
+        assert np.allclose(da[f + sel], d_ref ** 2, rtol=2e-5, atol=1e-12)
+        clear = (np.diff(d_ref, axis=1) > 1e-6 * d_ref[:, 1:]).all(1)   # rows without (near-)ties: the ids are determined
+        assert clear.sum() > 1000 and (ia[f + sel][clear] == i_ref[clear]).all()
+    # per-camera culling (one shared cloud seen by three cameras; one cloud per camera)
+    Mn, Vn, _ = scenes.camera_matrices([1.3, 1.6, 2.5], [10.0, 40.0, -20.0], [0.0, 120.0, 250.0])
+    znear, zfar = np.array([1.0, 0.01, 1.0], np.float32), np.array([100.0, 100.0, 2.6], np.float32)
+    if which == "trained":
+        args = (P, F, Nn, 7, t(Vn), t(znear), t(zfar), True)
+    else:
+        args = (P, F, Nn, 7, t(Vn), t(znear), t(zfar), False)
+    a = ops.knn_kth_sqdist_view(*args, radius=0.2)
+    b = _with_query_option(3, lambda: ops.knn_kth_sqdist_view(*args, radius=0.2))
+    assert torch.equal(a, b)
+    c0 = clouds[0]
+    zv = c0[:, 0] * Vn[0, 0, 2] + c0[:, 1] * Vn[0, 1, 2] + c0[:, 2] * Vn[0, 2, 2] + Vn[0, 3, 2]
+    ok = (zv >= znear[0]) & (zv <= zfar[0])
+    assert 0 < ok.sum() < len(c0)
+    mine = (a[0] if which == "trained" else a[:len(c0)]).cpu().numpy()
+    assert np.allclose(mine[ok], _ref_radius_stat(c0[ok], 7, 0.2), rtol=2e-5, atol=1e-9) and (mine[~ok] == 0).all()

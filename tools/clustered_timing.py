@@ -5,7 +5,8 @@ checkpoint of tools/train_mvr_ref.py): a dense bulk (median radius 0.33, 7th-nei
 halo out to radius 2.1 (7th-neighbour distance 0.1-0.3), hundreds of overlapping splats per pixel.  The uniform clouds
 of bench.py do not reach this state; the training loop lives in it (profiles/r6_b_train_mvr_ref_kernel_stats.csv: fine
 pass 0.2 ms at the start of the run, 2.6 ms at its end).
-    python tools/clustered_timing.py [lib.so ...]        # every library given (default: the shipped one), same process order
+    python tools/clustered_timing.py [lib.so|default[@knn=3] ...]   # every library given (default: the shipped one), in order;
+                                                                    # @knn=3: without the kNN skip structure (DSS_OPT_KNN_QUERY)
 Prints one JSON line per library: the render step (8 cameras, 512^2, forward + backward), the fine pass alone, the
 per-camera variance-scale search (kNN-7, fixed radius 0.2) and the kNN-12 search with indices of the regularisers."""
 import json
@@ -22,6 +23,7 @@ from dss_amd import _lib
 if %(so)r: _lib.LIB_PATH = %(so)r
 import bench
 from dss_amd import ops
+if %(knn)r: _lib.set_option(_lib.OPT_KNN_QUERY, int(%(knn)r))
 dev = torch.device("cuda:0")
 z = np.load(os.path.join(%(root)r, "tests", "golden", "trained_cloud_cfg3.npz"))
 pts, nrm = z["points"], z["normals"]
@@ -52,10 +54,11 @@ first = torch.zeros(1, dtype=torch.int64, device=dev)
 knn_view = timed(lambda: ops.knn_kth_sqdist_view(wl.world, first, cnt, 7, V, zn, zf, True, 0.2), 10)
 knn_plain = timed(lambda: ops.knn_kth_sqdist(wl.world, one, cnt, 7), 10)
 knn12 = timed(lambda: ops.knn_points(wl.world, one, cnt, 12), 10)
-print(json.dumps({"lib": %(so)r or "shipped", "h": float(wl.h[0]), "step_ms": round(step, 4), "fine_ms": round(fine, 4),
+print(json.dumps({"lib": (%(so)r or "shipped") + ("@knn=" + %(knn)r if %(knn)r else ""), "h": float(wl.h[0]), "step_ms": round(step, 4), "fine_ms": round(fine, 4),
                   "knn7_view_ms": round(knn_view, 4), "knn7_plain_ms": round(knn_plain, 4), "knn12_idx_ms": round(knn12, 4)}))
 '''
-for so in (sys.argv[1:] or [""]):
+for spec in (sys.argv[1:] or [""]):
+    so, _, knn = spec.partition("@knn=")   # "default@knn=3": DSS_OPT_KNN_QUERY = 3, the uniform-grid walk without the skip structure
     so = os.path.join(ROOT, so) if so and so != "default" else ""
-    r = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT, "so": so}], capture_output=True, text=True, timeout=900)
+    r = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT, "so": so, "knn": knn}], capture_output=True, text=True, timeout=900)
     print(r.stdout.strip() or ("FAILED " + r.stderr[-1500:]), flush=True)
