@@ -1072,34 +1072,59 @@ __global__ __launch_bounds__(256) void knn_query_coop_kernel(const float *__rest
             keep_lane0();
         }
     }
+    uint32_t s1 = 0, e1 = 0;
     if (sub < 9) {   // lane r of the group fetches the offsets of row r of the 3 x 3 x 3 block
         const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.res - 1);
         const int z = cz + sub / 3 - 1, y = cy + sub % 3 - 1;
         const bool in = z >= 0 && z < g.res && y >= 0 && y < g.res;
         const int c = in ? (z * g.res + y) * g.res : 0;
         const uint32_t s = off[c + x0], e = off[c + x1 + 1];
-        row_lo[sub][grp] = in ? s : 0u;
-        row_hi[sub][grp] = in ? e : 0u;
+        s1 = in ? s : 0u;
+        e1 = in ? e : 0u;
+        if (!SKIP) {
+            row_lo[sub][grp] = s1;
+            row_hi[sub][grp] = e1;
+        }
     }
-    __builtin_amdgcn_wave_barrier();   // same wavefront wrote and reads the row table (LDS operations of a wave complete in order)
+    if (!SKIP) __builtin_amdgcn_wave_barrier();   // same wavefront wrote and reads the row table (LDS operations of a wave complete in order)
     for (int ring = 1; ring <= g.res; ++ring) {
         const int x0 = max(cx - ring, 0), x1 = min(cx + ring, g.res - 1);
         const int y0 = max(cy - ring, 0), y1 = min(cy + ring, g.res - 1);
         const int z0 = max(cz - ring, 0), z1 = min(cz + ring, g.res - 1);
         const int ny = y1 - y0 + 1;
         const int walks = ring == 1 ? 9 : 2 * ny * (z1 - z0 + 1);
-        if (ring == 1) {
+        if constexpr (!SKIP) {
+            // (small clouds, P < KNN_SKIP_MIN_P: one walk after the other -- the batched form below costs this instantiation ten
+            // VGPRs, i.e. the eighth wavefront per SIMD that the latency-bound launch at 32k points lives on)
 #pragma nounroll
-            for (int t = 0; t < 9; ++t) visit(row_lo[t][grp], row_hi[t][grp]);
+            for (int t = 0; t < walks; ++t) {
+                uint32_t s, e;
+                if (ring == 1) {
+                    s = row_lo[t][grp];
+                    e = row_hi[t][grp];
+                } else {
+                    const int row = t >> 1, z = z0 + row / ny, y = y0 + row % ny;
+                    const int c = (z * g.res + y) * g.res;
+                    const bool full = z == cz - ring || z == cz + ring || y == cy - ring || y == cy + ring;
+                    const int xa = full ? x0 : ((t & 1) ? cx + ring : cx - ring);
+                    const int xb = full ? x1 : xa;
+                    if ((full && (t & 1)) || xa < 0 || xb >= g.res) continue;
+                    s = off[c + xa];
+                    e = off[c + xb + 1];
+                }
+                visit(s, e);
+            }
         } else {
-            // shells: the sixteen lanes fetch the ranges of sixteen walks together and the group visits the non-empty ones.
-            // (One walk after the other is a dependent round trip per walk, most of them for an EMPTY range: a stray point
-            // needs four or five rings -- ~600 walks --, and the launch lasts as long as its slowest query: 0.55 ms for the
-            // trained cloud of tools/clustered_timing.py whatever the rest of the kernel did.)
+        // The sixteen lanes fetch the candidate ranges of sixteen walks together and the group visits the non-empty ones (ring 1:
+        // the nine rows requested above).  One walk after the other is a dependent round trip per walk, most of them for an
+        // EMPTY range: a stray point needs four or five rings -- ~600 walks --, and the launch lasts as long as its slowest
+        // query (0.55 ms for the trained cloud of tools/clustered_timing.py whatever the rest of the kernel did).
 #pragma nounroll
-            for (int t0 = 0; t0 < walks; t0 += KNN_LPQ) {
+        for (int t0 = 0; t0 < walks; t0 += KNN_LPQ) {
+            uint32_t s = s1, e = e1;
+            if (ring > 1) {
                 const int t = t0 + sub;
-                uint32_t s = 0, e = 0;
+                s = e = 0u;
                 if (t < walks) {
                     const int row = t >> 1, z = z0 + row / ny, y = y0 + row % ny;
                     const int c = (z * g.res + y) * g.res;
@@ -1111,18 +1136,19 @@ __global__ __launch_bounds__(256) void knn_query_coop_kernel(const float *__rest
                         e = off[c + xb + 1];
                     }
                 }
-                __builtin_amdgcn_wave_barrier();
-                row_lo[sub][grp] = s;
-                row_hi[sub][grp] = e;
-                __builtin_amdgcn_wave_barrier();   // (same wavefront writes and reads: LDS operations of a wave complete in order)
-                unsigned ne = (unsigned)(__ballot(e > s) >> gsh) & 0xffffu;
-                while (ne != 0u) {
-                    const int i = __builtin_ctz(ne);
-                    ne &= ne - 1u;
-                    visit(row_lo[i][grp], row_hi[i][grp]);
-                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            row_lo[sub][grp] = s;
+            row_hi[sub][grp] = e;
+            __builtin_amdgcn_wave_barrier();   // (same wavefront writes and reads: LDS operations of a wave complete in order)
+            unsigned ne = (unsigned)(__ballot(e > s) >> gsh) & 0xffffu;
+            while (ne != 0u) {
+                const int i = __builtin_ctz(ne);
+                ne &= ne - 1u;
+                visit(row_lo[i][grp], row_hi[i][grp]);
             }
         }
+        }   // (SKIP)
         // the group's K best: four merge rounds inside the DPP row, every lane ends with the same list
         knn_merge_round<K, FULL, 0xB1>(best, bid);    // quad_perm [1,0,3,2]
         knn_merge_round<K, FULL, 0x4E>(best, bid);    // quad_perm [2,3,0,1]

@@ -255,8 +255,12 @@ class SurfaceSplatting(torch.nn.Module):
     """rasterizer.py:102-664.  ``forward(point_clouds, point_clouds_filter=None, **kwargs)`` returns the
     tuple ``(PointFragments, point_clouds[, per_point_info])`` (:655-664)."""
 
-    def __init__(self, cameras=None, raster_settings=None, frnn_radius=0.2, compact_culled: Optional[bool] = None):
+    def __init__(self, cameras=None, raster_settings=None, frnn_radius=0.2, compact_culled: Optional[bool] = None,
+                 detect_identical_clouds: bool = True):
         super().__init__()
+        # N equal-sized clouds arriving as separate tensors are compared once per forward (one launch, one host read): if
+        # they hold the same positions the neighbour statistic is searched in ONE of them (see _variance_scale)
+        self.detect_identical_clouds = bool(detect_identical_clouds)
         if raster_settings is None:
             raster_settings = PointsRasterizationSettings()
         self.cameras = cameras
@@ -304,6 +308,18 @@ class SurfaceSplatting(torch.nn.Module):
         if view is not None:
             V, znear, zfar, shared = view
             N = V.shape[0]
+            if not shared and N > 1 and len(sizes) == N and min(sizes) == max(sizes) and sizes[0] > 0 and self.detect_identical_clouds:
+                # N clouds of one size handed over as separate tensors: the reference's own texture does that to ONE model cloud
+                # (`pointclouds.extend(N)` CLONES it N times, texture.py:88, before the colours are made per camera), and
+                # its train_mvr.py reaches this rasterizer that way -- 8 x 99,790 points searched as 798k.  If the copies hold
+                # the same positions, the neighbour statistic of every camera is that of the one cloud under the camera's
+                # own culling: search the first copy as a cloud shared by the N cameras (same values, same (camera, point)
+                # layout).  Costs one comparison launch and one host read; the render itself still takes the N clouds as
+                # given, so the gradients keep their N separate ways back.
+                with torch.no_grad():
+                    copies = pts.view(N, sizes[0], 3)
+                    if bool((copies[1:] == copies[:1]).all()):
+                        shared, pts, first, num, sizes = True, copies[0], first[:1], num[:1], sizes[:1]
             with torch.no_grad():
                 d = ops.knn_kth_sqdist_view(pts, first, num, 7, V, znear, zfar, shared, radius=radius)   # (N,Pw) shared, else (P,)
                 if invariant:

@@ -343,3 +343,37 @@ def test_knn_skip_structure_of_clustered_clouds_is_exact(which):
     assert 0 < ok.sum() < len(c0)
     mine = (a[0] if which == "trained" else a[:len(c0)]).cpu().numpy()
     assert np.allclose(mine[ok], _ref_radius_stat(c0[ok], 7, 0.2), rtol=2e-5, atol=1e-9) and (mine[~ok] == 0).all()
+
+
+@pytest.mark.parametrize("mode", ["invariant", "isotropic"])
+def test_cloned_copies_of_one_cloud_are_searched_once(mode):
+    """The reference's texture hands ONE model cloud over as N clones (`pointclouds.extend(N)`, texture.py:88): separate tensors,
+    same positions.  `SurfaceSplatting` compares the copies (one launch, one host read) and searches the neighbour statistic
+    in the first one, as a cloud shared by the N cameras with each camera's own culling -- same h, bit for bit, as the N-cloud
+    search (`detect_identical_clouds=False`), and the same image; copies that differ in one coordinate take the N-cloud search."""
+    bunny, nrm = scenes.load_cloud("bunny")
+    pts = scenes.normalize_unit_sphere(bunny)[::2].astype(np.float32)
+    nrm = nrm[::2].astype(np.float32)
+    R, T = look_at_view_transform([1.3, 1.6, 2.5], [10.0, 40.0, -20.0], [0.0, 120.0, 250.0])
+    cams = FoVPerspectiveCameras(znear=torch.tensor([1.0, 0.01, 1.0]), zfar=torch.tensor([100.0, 100.0, 2.6]), R=R, T=T, device=DEV)
+    N = 3
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    st = PointsRasterizationSettings(backface_culling=False, Vrk_invariant=mode == "invariant", Vrk_isotropic=mode == "isotropic",
+                                     image_size=96, points_per_pixel=5, bin_size=None, radii_backward_scaler=5)
+
+    def run(points_list, detect):
+        cloud = PointClouds3D(points_list, [t(nrm) for _ in range(N)], [torch.ones(pts.shape[0], 3, device=DEV) for _ in range(N)])
+        rast = SurfaceSplatting(cameras=cams, raster_settings=st, detect_identical_clouds=detect)
+        frags, _ = rast(cloud)
+        return rast._Vrk_h.clone(), frags
+
+    h_once, f_once = run([t(pts).clone() for _ in range(N)], True)
+    h_each, f_each = run([t(pts).clone() for _ in range(N)], False)
+    assert h_once.shape == h_each.shape and torch.equal(h_once, h_each)
+    assert torch.equal(f_once.idx, f_each.idx) and torch.equal(f_once.zbuf, f_each.zbuf)
+    # a copy that differs: the general search, and a different h for that camera's cloud
+    moved = pts.copy()
+    moved[::2] *= 1.2      # (the third camera's h is not at its clamp: the statistic of ITS cloud must show)
+    h_diff, _ = run([t(pts).clone(), t(pts).clone(), t(moved)], True)
+    h_diff_each, _ = run([t(pts).clone(), t(pts).clone(), t(moved)], False)
+    assert torch.equal(h_diff, h_diff_each) and not torch.equal(h_diff, h_once)
