@@ -105,8 +105,13 @@ struct TileQueue {
 // camera put every occupied tile over capacity) and sized the capacity at 32x the mean load to make that rare (1 GB of
 // lists at 4M points); with the spill path the capacity is 4x the mean load.  (A log of (sub-list, id) pairs instead of
 // the mask was tried first: 8 more bytes per point, and its append counter(s) serialised -- 0.9 ms for 83k entries.)
-// Splats larger than 2 x 2 tiles that find a full sub-list only raise a flag: the spilled tiles are then rasterized from
-// their whole cloud as in round 1 (exact; rare: such a splat has a radius above 8 pixels).
+// A splat larger than 2 x 2 tiles (radius above 8 pixels) records its full tiles in a 64-bit mask of its own -- bit 8 dy + dx
+// of `big[p]`, valid when bit 7 of its mask byte is set -- for rectangles of up to 8 x 8 tiles; a wider one (radius above 28
+// pixels: a point close to the camera) appends one such mask per 8 x 8 block of its rectangle to the `giant` records.  Only
+// when those run out does a splat raise the flag that sends every spilled tile back to whole-cloud scans.  (Until round 6 every such splat raised it, "rare" being
+// the assumption: the reference's own training loop at configs[2] lives there -- h sits at its upper clamp 1e-3, splats are
+// ~10 pixels wide, hundreds overlap per pixel -- and ~1,900 tiles per call scanned all 99,790 points of their cloud: 1.9 of
+// the fine pass's 2.0 ms, tools/fine_timing.py trained.)
 struct Spill {
     uint32_t *cursor;   // (N*tiles*SUB) arrival counters of the pool pass                  (zero when binning starts)
     uint32_t *offset;   // (N*tiles*SUB) 1 + first pool entry of an overflowed sub-list      (zero when binning starts)
@@ -119,6 +124,11 @@ struct Spill {
                         // write-back order of their L2s), and a stale or uninitialised fail[0] can only equal the new
                         // epoch by a 2^-32 accident, which costs speed, not exactness.  Outside the zero region.
     int32_t *pool;
+    unsigned long long *big;  // (P) full tiles of a splat larger than 2 x 2 tiles (valid when bit 7 of its mask byte is set)
+    uint4 *giant;             // (8, giant_cap) records of splats wider than 8 x 8 tiles, one per 8 x 8 block of their rectangle that
+                              // met a full sub-list: {splat, block origin ty << 16 | tx, mask lo, mask hi}; segment = splat mod 8,
+                              // its record count in ctrl[2 + segment] (eight counters: one serialises at ~11 ns per append)
+    uint32_t giant_cap;       // records per segment
     uint32_t cap_entries;  // pool capacity in entries
     uint32_t epoch;        // unique per binning launch of this process (host counter)
 };
@@ -276,13 +286,34 @@ __device__ __forceinline__ void bin_rect(int64_t p, int n, int tx0, int tx1, int
         }
         return;
     }
-    for (int ty = ty0; ty <= ty1; ++ty)
-        for (int tx = tx0; tx <= tx1; ++tx) {
-            const size_t t = sub0 + (size_t)(ty * g.tiles_x + tx) * DSS_SUB;
-            const uint32_t pos = atomicAdd(&counts[t], 1u);
-            if (pos < cap) lists[t * cap + pos] = (int32_t)p;
-            else if (sp.ctrl) sp.fail[0] = sp.epoch;  // (a splat larger than 2 x 2 tiles: no mask for it)
-            if (tq.flag && pos == 0) claim_tile(tq, n, tx, ty, g);
+    const bool one_block = tx1 - tx0 < 8 && ty1 - ty0 < 8;
+    for (int by = ty0; by <= ty1; by += 8)
+        for (int bx = tx0; bx <= tx1; bx += 8) {   // (one trip unless the rectangle is wider than 8 x 8 tiles)
+            unsigned long long full = 0ull;
+            const int ye = min(by + 7, ty1), xe = min(bx + 7, tx1);
+            for (int ty = by; ty <= ye; ++ty)
+                for (int tx = bx; tx <= xe; ++tx) {
+                    const size_t t = sub0 + (size_t)(ty * g.tiles_x + tx) * DSS_SUB;
+                    const uint32_t pos = atomicAdd(&counts[t], 1u);
+                    if (pos < cap) lists[t * cap + pos] = (int32_t)p;
+                    else full |= 1ull << (8 * (ty - by) + (tx - bx));
+                    if (tq.flag && pos == 0) claim_tile(tq, n, tx, ty, g);
+                }
+            if (full == 0ull || !sp.ctrl) continue;
+            if (one_block && sp.big != nullptr) {
+                sp.big[p] = full;
+                sp.mask[p] = (uint8_t)0x80u;
+            } else if (sp.giant != nullptr) {
+                const unsigned seg = (unsigned)p & 7u;
+                const uint32_t r = atomicAdd(&sp.ctrl[2 + seg], 1u);
+                if (r < sp.giant_cap)
+                    sp.giant[(size_t)seg * sp.giant_cap + r] = make_uint4((uint32_t)p, ((uint32_t)by << 16) | (uint32_t)bx,
+                                                                          (uint32_t)full, (uint32_t)(full >> 32));
+                else sp.fail[0] = sp.epoch;   // (out of records)
+            } else {
+                sp.fail[0] = sp.epoch;        // (no mask for it)
+            }
+            sp.ctrl[0] = 1u;
         }
 }
 
@@ -372,6 +403,27 @@ __device__ __forceinline__ bool spill_pass(
     // byte per thread and trip was a chain of P / (workgroups * 256) dependent loads -- 61 trips, ~120 us, at 8M splats on
     // 512 workgroups: invisible inside the 0.75 ms fine launch of the whole image, but the tiles that wait for the pool
     // (the sphere's limb) ended the launch, and on a row band of the multi-GPU step the pass was half of the fine launch.
+    // one dropped (splat, sub-list) entry -> its place in the pool
+    auto pool_put = [&](const size_t t, const int64_t p) __attribute__((always_inline)) {
+        const uint32_t extra = counts[t] - cap;   // entries of this sub-list that live in the pool (final)
+        const uint32_t pos = atomicAdd(&sp.cursor[t], 1u);
+        uint32_t off1 = 0;
+        // the publisher's branch comes first in program order: a waiter of the same wavefront never spins ahead of it
+        if (pos == 0) {
+            off1 = atomicAdd(&sp.ctrl[1], extra) + 1u;
+            __hip_atomic_store(&sp.offset[t], off1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (pos != 0) {
+            // the thread that drew position 0 has executed its atomic before ours and publishes without waiting for
+            // anyone; the offset is its own tag (non-zero once written)
+            for (int spin = 0; spin < (1 << 22) && off1 == 0; ++spin) {
+                off1 = __hip_atomic_load(&sp.offset[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (off1 == 0) __builtin_amdgcn_s_sleep(2);
+            }
+            if (off1 == 0) sp.fail[0] = sp.epoch;  // gave up: the fine pass falls back to whole-cloud scans
+        }
+        if (off1 != 0 && (unsigned long long)(off1 - 1u) + pos < sp.cap_entries) sp.pool[(size_t)(off1 - 1u) + pos] = (int32_t)p;
+    };
     const int64_t nvec = (P + 15) / 16;
     for (int64_t v = (int64_t)block * blockDim.x + threadIdx.x; v < nvec; v += (int64_t)nblocks * blockDim.x) {
     const uint4 m4 = reinterpret_cast<const uint4 *>(sp.mask)[v];
@@ -394,31 +446,39 @@ __device__ __forceinline__ bool spill_pass(
     }
     if (n < 0 || !splat_tile_rect(gx, gy, gz, grx, gry, g, tx0, tx1, ty0, ty1)) continue;
     const size_t sub0 = ((size_t)n * g.tiles_x * g.tiles_y) * DSS_SUB + (sorted ? ((full >> 4) & (DSS_SUB - 1)) : ((unsigned)p & (DSS_SUB - 1)));
+    // the splat's full tiles: bits 0..3 of the mask byte (a rectangle of at most 2 x 2 tiles), or the 64-bit mask of a larger one
+    const bool is_big = !sorted && (full & 0x80u) != 0u;
+    unsigned long long todo = is_big ? sp.big[p] : (unsigned long long)(full & 0xfu);
 #pragma unroll 1
-    for (int k = 0; k < 4; ++k) {
-        if (!(full & (1u << k))) continue;
-        const int tx = (k & 1) ? tx1 : tx0, ty = (k & 2) ? ty1 : ty0;
-        const size_t t = sub0 + (size_t)(ty * g.tiles_x + tx) * DSS_SUB;
-        const uint32_t extra = counts[t] - cap;   // entries of this sub-list that live in the pool (final)
-        const uint32_t pos = atomicAdd(&sp.cursor[t], 1u);
-        uint32_t off1 = 0;
-        // the publisher's branch comes first in program order: a waiter of the same wavefront never spins ahead of it
-        if (pos == 0) {
-            off1 = atomicAdd(&sp.ctrl[1], extra) + 1u;
-            __hip_atomic_store(&sp.offset[t], off1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (pos != 0) {
-            // the thread that drew position 0 has executed its atomic before ours and publishes without waiting for
-            // anyone; the offset is its own tag (non-zero once written)
-            for (int spin = 0; spin < (1 << 22) && off1 == 0; ++spin) {
-                off1 = __hip_atomic_load(&sp.offset[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (off1 == 0) __builtin_amdgcn_s_sleep(2);
+    while (todo != 0ull) {
+        const int k = __builtin_ctzll(todo);
+        todo &= todo - 1ull;
+        const int tx = is_big ? tx0 + (k & 7) : ((k & 1) ? tx1 : tx0), ty = is_big ? ty0 + (k >> 3) : ((k & 2) ? ty1 : ty0);
+        pool_put(sub0 + (size_t)(ty * g.tiles_x + tx) * DSS_SUB, p);
+    }
+    }
+    }
+    // splats wider than 8 x 8 tiles: one record per 8 x 8 block of their rectangle that met a full sub-list (bin_rect)
+    if (!sorted && sp.giant != nullptr) {
+#pragma unroll 1
+        for (unsigned seg = 0; seg < 8u; ++seg) {
+            const uint32_t nrec = min((uint32_t)__builtin_amdgcn_readfirstlane((int)sp.ctrl[2 + seg]), sp.giant_cap);
+            for (uint32_t r = block * blockDim.x + threadIdx.x; r < nrec; r += nblocks * blockDim.x) {
+                const uint4 rec = sp.giant[(size_t)seg * sp.giant_cap + r];
+                const int64_t p = (int64_t)rec.x;
+                const int n = find_cloud(p, first_idx, num_pts, N);
+                if (n < 0) continue;
+                const int bx = (int)(rec.y & 0xffffu), by = (int)(rec.y >> 16);
+                const size_t sub0 = ((size_t)n * g.tiles_x * g.tiles_y) * DSS_SUB + ((unsigned)p & (DSS_SUB - 1));
+                unsigned long long todo = ((unsigned long long)rec.w << 32) | rec.z;
+#pragma unroll 1
+                while (todo != 0ull) {
+                    const int k = __builtin_ctzll(todo);
+                    todo &= todo - 1ull;
+                    pool_put(sub0 + (size_t)((by + (k >> 3)) * g.tiles_x + bx + (k & 7)) * DSS_SUB, p);
+                }
             }
-            if (off1 == 0) sp.fail[0] = sp.epoch;  // gave up: the fine pass falls back to whole-cloud scans
         }
-        if (off1 != 0 && (unsigned long long)(off1 - 1u) + pos < sp.cap_entries) sp.pool[(size_t)(off1 - 1u) + pos] = (int32_t)p;
-    }
-    }
     }
     return true;
 }
@@ -1738,8 +1798,8 @@ __global__ __launch_bounds__(FINE_THREADS) __attribute__((amdgpu_num_sgpr(96))) 
         if (threadIdx.x == 0) {
             const uint32_t before = __hip_atomic_fetch_add(&A.spill.fail[2], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
             if (before - A.spill.fail[3] == spill_wgs - 1u) {
-                __hip_atomic_store(&A.spill.ctrl[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&A.spill.ctrl[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int k = 0; k < 10; ++k)   // "some mask set", pool top, the eight record counters
+                    __hip_atomic_store(&A.spill.ctrl[k], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         return;
@@ -1775,9 +1835,9 @@ __global__ __launch_bounds__(FINE_THREADS) __attribute__((amdgpu_num_sgpr(96))) 
     }
     const uint32_t qb = blockIdx.x - fill_wgs - spill_wgs;  // queue workgroup index (identity mode: tile id)
     if (!qmode && (int)qb >= total) return;
-    if (qmode && clean && qb == 0 && threadIdx.x < DSS_QUEUES + (spill_wgs ? 0 : 2)) {
+    if (qmode && clean && qb == 0 && threadIdx.x < DSS_QUEUES + (spill_wgs ? 0 : 10)) {
         // state that only binning and the pool pass use: queue tails, and -- unless the pool pass runs in this launch and
-        // resets them itself -- "some mask set", pool top (contiguous words)
+        // resets them itself -- "some mask set", pool top, the eight record counters of the wide splats (contiguous words)
         A.queue.tail[threadIdx.x] = 0;
     }
     // one workgroup per queue slot (qb -> queue qb%32, slot qb/32): a loop over several slots per workgroup was tried and
@@ -1965,11 +2025,13 @@ static uint32_t bin_capacity(int N, int64_t P, int S)
     while (cap < 16384 && (double)cap < (lean ? 2.0 : 8.0) * mean_sub) cap <<= 1;
     return cap;
 }
-// spill pool entries: two per point (at least 64k): a scene with more over-capacity (splat, tile) pairs than that falls
-// back to whole-cloud scans for the tiles that did not fit (seen with 100k points on 25 tiles, 0.5 % of the screen)
+// spill pool entries: eight per point (at least 64k; two until round 6: the trained cloud of tools/clustered_timing.py puts
+// ~3.5 over-capacity (splat, tile) pairs per splat into it): a scene with more than that falls back to whole-cloud scans for
+// the tiles that did not fit (seen with 100k points on 25 tiles, 0.5 % of the screen).  Never zeroed, touched only when used.
 static uint32_t spill_capacity(int64_t P)
 {
-    const int64_t c = 2 * P > 65536 ? 2 * P : 65536;
+    const int64_t per = lean_workspace() ? 2 : 8;   // (DSS_OPT_LEAN_WORKSPACE keeps round 5's pool and has no masks for wide splats)
+    const int64_t c = per * P > 65536 ? per * P : 65536;
     return (uint32_t)(c < 0x7fffff00ll ? c : 0x7fffff00ll);
 }
 
@@ -2014,6 +2076,16 @@ static FwdWorkspace carve_fwd(void *ws, int N, int64_t P, int S, bool with_recor
     w.spill.cap_entries = spill_capacity(P);
     w.spill.pool = reinterpret_cast<int32_t *>(p + w.bytes);
     w.bytes += align_up((size_t)w.spill.cap_entries * 4, 256);
+    w.spill.big = nullptr;
+    w.spill.giant = nullptr;
+    w.spill.giant_cap = 0;
+    if (!lean_workspace()) {
+        w.spill.big = reinterpret_cast<unsigned long long *>(p + w.bytes);
+        w.bytes += align_up((size_t)P * 8, 256);
+        w.spill.giant_cap = (uint32_t)(P / 16 > 1024 ? P / 16 : 1024);   // eight segments: half a record per point (8 bytes)
+        w.spill.giant = reinterpret_cast<uint4 *>(p + w.bytes);
+        w.bytes += align_up((size_t)8 * w.spill.giant_cap * 16, 256);
+    }
     w.spill.fail = reinterpret_cast<uint32_t *>(p + w.bytes);
     static std::atomic<uint32_t> epoch{1};
     w.spill.epoch = ws ? epoch.fetch_add(1, std::memory_order_relaxed) : 0u;
@@ -2168,7 +2240,7 @@ static int splat_fine_impl(const float *points, const float *ellipse, const floa
     A.counts = nullptr; A.lists = nullptr; A.cap = 0;
     A.queue.tail = nullptr; A.queue.list = nullptr; A.queue.flag = nullptr; A.queue.capq = 0; A.queue_wgs = 0; A.prio = 0;
     A.spill.cursor = nullptr; A.spill.offset = nullptr; A.spill.mask = nullptr; A.spill.ctrl = nullptr; A.spill.fail = nullptr;
-    A.spill.pool = nullptr; A.spill.cap_entries = 0;
+    A.spill.pool = nullptr; A.spill.big = nullptr; A.spill.giant = nullptr; A.spill.giant_cap = 0; A.spill.cap_entries = 0;
     A.clean_counts = nullptr;
     A.spill_wgs = 0; A.spill_sorted = 0; A.P = P;   // (the pool pass ran behind the binning: dss_splat_bin)
     A.idx = idx; A.zbuf = zbuf; A.qv = qvalue; A.occ = occ; A.visible = visible;

@@ -121,6 +121,22 @@ def test_forward_list_overflow_goes_through_the_spill_pool():
         assert np.array_equal(g.cpu().numpy(), w)
 
 
+@pytest.mark.parametrize("rmin,rmax,P", [(9.0, 26.0, 6000), (2.0, 45.0, 8000), (30.0, 70.0, 3000)])
+def test_forward_overflowed_lists_of_wide_splats_stay_on_the_lists(rmin, rmax, P):
+    """Sub-lists far over capacity, filled by splats wider than 2 x 2 tiles: up to 8 x 8 tiles a splat records its full tiles in
+    a 64-bit mask of its own, wider ones append one record per 8 x 8 block (raster_forward.hip, `Spill::big` / `giant`), and
+    the pool pass moves all of them into the pool -- the state of the reference's training loop at configs[2] (10-pixel splats,
+    hundreds per pixel), where round 5 scanned the whole cloud for every spilled tile.  Exact, two clouds, both bin modes."""
+    S = 128
+    sc = scenes.random_splats(P, S, 2, seed=int(rmax), rmin=rmin, rmax=rmax)
+    want = oracle.splat_forward(sc["points"], sc["ellipse"], sc["cutoff"], sc["radii"], sc["first_idx"],
+                                sc["num_pts"], S, 5, 0.05)
+    for bs in (None, 0):
+        got = _fwd(_dev(sc), S, 5, 0.05, bs)
+        for g, w in zip(got, want):
+            assert np.array_equal(g.cpu().numpy(), w)
+
+
 def test_lean_workspace_mode_is_exact_and_smaller():
     """dss_set_option(DSS_OPT_LEAN_WORKSPACE, 1) halves the sub-list capacity and drops the packed records (raster_forward.hip
     `lean_workspace`): smaller workspace, same fragments bit for bit, same image."""

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Developer tool: per-workgroup phase timestamps of the fine kernel (s_memtime) on the bench scene (or cfg3 / cfg4 / cfg5 of
 tools/bench_large.py).  Builds a private -DDSS_FINE_TIMING copy of the library under gpurun_out/ and never touches the
-shipped libdss_hip.so.  Usage (GPU box): python tools/fine_timing.py [cfg3|cfg4|cfg5]"""
+shipped libdss_hip.so.  Usage (GPU box): python tools/fine_timing.py [cfg3|cfg4|cfg5|trained]"""
 import ctypes
 import os
 import subprocess
@@ -30,6 +30,12 @@ which = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
 if which == "cfg2":
     wl = bench.Workload(dev, 1, bench.RowPartition(bench.S, 1, 0))
     blocks = (bench.S // 8) ** 2  # DSS_TILE = 8
+elif which == "trained":   # the clustered cloud of tools/clustered_timing.py: 8 cameras, 512^2, h from the kNN statistic (clamped)
+    z = np.load(os.path.join(ROOT, "tests", "golden", "trained_cloud_cfg3.npz"))
+    col = np.random.default_rng(0).uniform(0, 1, z["points"].shape).astype(np.float32)
+    N, S = 8, 512
+    wl = bench.Workload(dev, N, bench.RowPartition(S, 1, 0), cloud=(z["points"], z["normals"], col, None))
+    blocks = N * (S // 8) ** 2
 else:
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import scenes  # noqa: E402
