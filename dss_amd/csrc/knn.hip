@@ -280,7 +280,7 @@ __global__ __launch_bounds__(256) void knn_fill_kernel(const float *__restrict__
 // searches of an iteration go from 0.13 / 0.16 ms to 1.7 / 2.3 ms (profiles/r6_b_train_mvr_ref_kernel_stats.csv).  No
 // single cell size serves a cloud whose neighbour distances span two orders of magnitude.  So, from KNN_SKIP_MIN_P points
 // on, the cell-sorted array gets a skip structure:
-//   * knn_dense_list_kernel lists the DENSE cells (more than KNN_DENSE points) and raises `dense_flag`; knn_subsort_kernel
+//   * knn_dense_list_kernel lists the DENSE cells (more than KNN_DENSE_CELL points) and raises `dense_flag`; knn_subsort_kernel
 //     orders the points of each along a Morton curve of their position inside the cell, so that consecutive slots are
 //     close in space;
 //   * knn_block_box_kernel records the bounding box of every KNN_BLOCK consecutive slots;
@@ -292,7 +292,11 @@ __global__ __launch_bounds__(256) void knn_fill_kernel(const float *__restrict__
 // the cell counts (the queries then run exactly as before: `dense_flag` stays 0 and the boxes are neither built nor read).
 // ---------------------------------------------------------------------------------------------------------------
 #define KNN_SKIP_MIN_P 65536     // per call: below, the grid build is a chain of launch latencies and clouds are small
-#define KNN_DENSE 64             // points in a cell (and slots in a candidate run) from which the skip structure is used
+#define KNN_DENSE 64             // slots in a candidate run (and points in the query's own cell, for the seed) from which the blocks are walked
+#define KNN_DENSE_CELL 64        // points in a cell from which it is listed and sub-sorted
+#define KNN_DENSE_SHARE 8        // `dense_flag` goes up when at least 1 / KNN_DENSE_SHARE of the points live in such cells (a 1M-point
+                                 // evenly sampled cloud at the resolution cap has a few of them: the cooperative walk it would
+                                 // select is 2.5x slower there than the one-thread kernel, 2.21 against 0.88 ms for K = 12 lists)
 #define KNN_BLOCK 16             // slots per box
 #define KNN_SEED 16              // slots on either side of the query's own slot looked at first
 #define KNN_SUBSORT_MAX 4096     // largest cell that is sub-sorted (larger ones stay in arrival order: correct, loose boxes)
@@ -304,24 +308,28 @@ __device__ __forceinline__ uint32_t knn_spread5(uint32_t v)   // bit i of v (i <
     return (v & 1u) | ((v & 2u) << 2) | ((v & 4u) << 4) | ((v & 8u) << 6) | ((v & 16u) << 8);
 }
 
-// Dense cells of all clouds -> list[] (cloud, cell), *n_list, dense_flag.
+// Dense cells of all clouds -> list[] (cloud, cell), *n_list, and the number of points they hold.
 // One thread per cell, one atomic per wavefront that found any.
 __global__ __launch_bounds__(256) void knn_dense_list_kernel(const KnnGrid *__restrict__ grids, size_t stride,
                                                              const uint32_t *__restrict__ offsets, uint2 *__restrict__ list,
-                                                             uint32_t *__restrict__ n_list, uint32_t *__restrict__ dense_flag)
+                                                             uint32_t *__restrict__ n_list, uint32_t *__restrict__ n_dense_pts)
 {
     const int n = blockIdx.y;
     const int res = grids[n].res, cells = res * res * res;
     const int c = blockIdx.x * 256 + threadIdx.x;
     const uint32_t *off = offsets + (size_t)n * stride;
-    const bool dense = c < cells && off[c + 1] - off[c] > (uint32_t)KNN_DENSE;
+    const uint32_t cnt = c < cells ? off[c + 1] - off[c] : 0u;
+    const bool dense = cnt > (uint32_t)KNN_DENSE_CELL;
     const unsigned long long m = __ballot(dense);
     if (m == 0ull) return;
     const int lane = threadIdx.x & 63, leader = __builtin_ctzll(m);
+    uint32_t pts_here = dense ? cnt : 0u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) pts_here += (uint32_t)__shfl_xor((int)pts_here, o);
     uint32_t base = 0;
     if (lane == leader) {
         base = atomicAdd(n_list, (uint32_t)__popcll(m));
-        atomicOr(dense_flag, 1u);
+        atomicAdd(n_dense_pts, pts_here);
     }
     base = (uint32_t)__shfl((int)base, leader);
     if (dense) list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = make_uint2((uint32_t)n, (uint32_t)c);
@@ -333,11 +341,15 @@ __global__ __launch_bounds__(256) void knn_dense_list_kernel(const KnnGrid *__re
 __global__ __launch_bounds__(KNN_SUBSORT_THREADS) void knn_subsort_kernel(const KnnGrid *__restrict__ grids, size_t stride,
                                                           const uint32_t *__restrict__ offsets,
                                                           const int64_t *__restrict__ first_idx, float4 *__restrict__ sorted,
-                                                          const uint2 *__restrict__ list, const uint32_t *__restrict__ n_list)
+                                                          const uint2 *__restrict__ list, const uint32_t *__restrict__ n_list,
+                                                          const uint32_t *__restrict__ n_dense_pts, int64_t P,
+                                                          uint32_t *__restrict__ dense_flag)
 {
     __shared__ uint32_t s_key[KNN_SUBSORT_MAX];
     const int tid = threadIdx.x;
     const uint32_t total = *n_list;
+    // the later launches walk the blocks only if the dense cells hold a real share of the points (KNN_DENSE_SHARE)
+    if (blockIdx.x == 0 && tid == 0) *dense_flag = (unsigned long long)*n_dense_pts * KNN_DENSE_SHARE >= (unsigned long long)P ? 1u : 0u;
     for (uint32_t it = blockIdx.x; it < total; it += gridDim.x) {
         const uint2 e = list[it];
         const int n = (int)e.x, cell = (int)e.y;
@@ -1347,7 +1359,7 @@ extern "C" size_t dss_knn_workspace(int N, int64_t P)
            align_up(n * (size_t)knn_blocks(P) * 4, 256) + align_up(p * 4, 256) + align_up(p * 16, 256) +
            (KNN_MAX_VIEW_CAMS + 64) * 4 +   // dss_knn_kth_sqdist_view: one "drops points" flag per camera; the "dense cells" flag
            align_up((p / KNN_BLOCK + 1) * 32, 256) +  // the block boxes of the skip structure (knn_subsort_kernel)
-           align_up((p / KNN_DENSE + 1) * 8, 256) +    // and its list of dense cells
+           align_up((p / KNN_DENSE_CELL + 1) * 8, 256) +  // and its list of dense cells
            align_up(p * 4, 256) * 3;                   // arrival numbers (knn_count_kernel); dss_knn_kth_sqdist_view: the unmasked search's two rows
 }
 
@@ -1399,11 +1411,11 @@ static int knn_run(const char *who, const float *points, const int64_t *first_id
     float4 *sorted = reinterpret_cast<float4 *>(w + off);                    off += align_up((size_t)P * 16, 256);
     uint32_t *flags = reinterpret_cast<uint32_t *>(w + off);         off += (KNN_MAX_VIEW_CAMS + 64) * 4;   // [cameras | dense]
     float4 *boxes = reinterpret_cast<float4 *>(w + off);            off += align_up(((size_t)P / KNN_BLOCK + 1) * 32, 256);
-    uint2 *dense_list = reinterpret_cast<uint2 *>(w + off);         off += align_up(((size_t)P / KNN_DENSE + 1) * 8, 256);
+    uint2 *dense_list = reinterpret_cast<uint2 *>(w + off);         off += align_up(((size_t)P / KNN_DENSE_CELL + 1) * 8, 256);
     uint32_t *rank_of = reinterpret_cast<uint32_t *>(w + off);      off += align_up((size_t)P * 4, 256);
     float *plain_stat = reinterpret_cast<float *>(w + off);         off += align_up((size_t)P * 4, 256);
     float *plain_dk = reinterpret_cast<float *>(w + off);           off += align_up((size_t)P * 4, 256);
-    uint32_t *dense_flag = flags + KNN_MAX_VIEW_CAMS, *n_dense = dense_flag + 1;
+    uint32_t *dense_flag = flags + KNN_MAX_VIEW_CAMS, *n_dense = dense_flag + 1, *n_dense_pts = dense_flag + 2;
     const bool skip = P >= KNN_SKIP_MIN_P && option(DSS_OPT_KNN_QUERY) != 3;   // (3: the uniform-grid walk whatever the cloud, for A/B)
     if (view.mode != 0) {
         if (n_cams > KNN_MAX_VIEW_CAMS) { set_error("%s: at most %d cameras", who, KNN_MAX_VIEW_CAMS); return DSS_ERR_UNSUPPORTED; }
@@ -1411,7 +1423,7 @@ static int knn_run(const char *who, const float *points, const int64_t *first_id
         view.n_cams = n_cams;
         if (hipMemsetAsync(view.culls, 0, (size_t)n_cams * 4, st) != hipSuccess) return check_launch("knn view memset");
     }
-    if (skip && hipMemsetAsync(dense_flag, 0, 8, st) != hipSuccess) return check_launch("knn flag memset");
+    if (skip && hipMemsetAsync(dense_flag, 0, 12, st) != hipSuccess) return check_launch("knn flag memset");
     const unsigned pb_s = (unsigned)((P + 255) / 256);
     if (P <= KNN_SMALL_P && N <= KNN_GRID_LDS && nblk <= KNN_SCAN1_BLOCKS) {
         // small inputs: four launches instead of eight (see knn_bbox_partial_kernel)
@@ -1439,9 +1451,9 @@ static int knn_run(const char *who, const float *points, const int64_t *first_id
     }
     if (skip) {
         hipLaunchKernelGGL(knn_dense_list_kernel, dim3((unsigned)((stride + 254) / 256), N), dim3(256), 0, st, grids, stride, offsets,
-                           dense_list, n_dense, dense_flag);
+                           dense_list, n_dense, n_dense_pts);
         hipLaunchKernelGGL(knn_subsort_kernel, dim3(KNN_SUBSORT_WGS), dim3(KNN_SUBSORT_THREADS), 0, st, grids, stride, offsets, first_idx, sorted,
-                           dense_list, n_dense);
+                           dense_list, n_dense, n_dense_pts, P, dense_flag);
         hipLaunchKernelGGL(knn_block_box_kernel, dim3((unsigned)((P / KNN_BLOCK + 256) / 256)), dim3(256), 0, st, sorted, P,
                            dense_flag, boxes);
     }
@@ -1523,8 +1535,10 @@ static int knn_run(const char *who, const float *points, const int64_t *first_id
     }
     if (full) {
         // full lists: the cooperative kernel wins while the launch is latency-bound (32k points, K = 12: 58 us against
-        // ~100); at 100k points the merges of (distance, id) lists cost more than the shorter chains save (182 vs 155 us)
-        const bool coop = qopt == 1 || (qopt == 0 && P <= 65536);
+        // ~100); at 100k points of an evenly sampled cloud the merges of (distance, id) lists cost more than the shorter
+        // chains save (182 vs 155 us) -- but the one-thread kernel falls off a cliff as soon as cells fill up (30-60 points
+        // per cell, the training loop on its way to the clustered state: 1.0 ms), the cooperative one does not
+        const bool coop = qopt == 1 || (qopt == 0 && P <= KNN_COOP_KTH_MAX_P);
         if (K <= 8) { if (coop) KNN_LAUNCH_COOP(8, true); else KNN_LAUNCH_BOTH(8, true); }
         else if (K <= 12) { if (coop) KNN_LAUNCH_COOP(12, true); else KNN_LAUNCH_BOTH(12, true); }  // the regularisers' knn_k (trainer.py:134-137)
         else if (K <= 16) { if (coop) KNN_LAUNCH_COOP(16, true); else KNN_LAUNCH_BOTH(16, true); }

@@ -51,6 +51,12 @@ python tools/knn_graph_timing.py > $out/knn_graph_timing.txt 2>/dev/null
 { python tools/knn_chain_timeline.py; python tools/knn_chain_timeline.py view; } > $out/knn_chain_timeline.txt 2>/dev/null
 for c in cfg2 cfg3 cfg4 cfg5; do python tools/gather_split.py $c >> $out/gather_split.jsonl 2>/dev/null; done
 BENCH_DIST_BACKEND=gloo python bench.py --gpus 2 --no-cpu-baseline 2>/dev/null | grep '^{' > $out/bench_2ranks_gloo_one_gpu.json
-[ -n "$COLLECT_REF_LOOP" ] && python tools/train_mvr_ref.py $out/ref 30 > $out/train_mvr_ref.log 2>&1
+# the clustered state of the reference's training loop (tests/golden/trained_cloud_cfg3.npz): kNN without / with the skip structure,
+# fine-pass phases, and the kernels of one step under the trace
+python tools/clustered_timing.py default@knn=3 default > $out/clustered_timing.txt 2>&1
+python tools/fine_timing.py trained > $out/fine_timing_trained.txt 2>&1
+rocprofv3 --kernel-trace --stats -d $out/ks -o b --output-format csv -- python tools/clustered_timing.py default > /dev/null 2>&1
+cp $(find $out/ks -name '*kernel_stats.csv' | head -1) $out/kernel_stats_trained_cloud.csv; rm -rf $out/ks
+[ -n "$COLLECT_REF_LOOP" ] && REF_LEGS=${REF_LEGS:-class} python tools/train_mvr_ref.py $out/ref 40 > $out/train_mvr_ref.log 2>&1
 rm -rf gpurun_out/libdss_hip_timing.so gpurun_out/fine_timing.npy gpurun_out/traffic_cfg4 gpurun_out/traffic_cfg5 $out/ref/train_mvr_ref_prof $out/ref/*.pt $out/ref/*.png gpurun_out/timeline gpurun_out/pmc_sq gpurun_out/pmc_large gpurun_out/fetch_large gpurun_out/traffic
 ls -la $out
