@@ -235,6 +235,21 @@ __device__ __forceinline__ bool knn_view_shortcut(uint32_t camera_drops, float x
     const float rho2 = r2 > 0.0f ? fminf(plain_dk, r2) : plain_dk;
     return margin > 0.0f && margin * margin > rho2 * (v2 * v2 + v6 * v6 + v10 * v10) * 1.0002f;
 }
+// mode 1 of dss_knn_kth_sqdist_view (one cloud, several cameras): the row of a camera that drops nothing is the unmasked search
+// itself -- a coalesced copy; the query launches skip such cameras
+__global__ __launch_bounds__(256) void knn_view_rows_kernel(float *__restrict__ kth, const float *__restrict__ plain, int64_t P,
+                                                            const uint32_t *__restrict__ culls)
+{
+    const int cam = blockIdx.y;
+    if (culls[cam] != 0u) return;
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    float *row = kth + (size_t)cam * (size_t)P;
+    if (i + 3 < P && ((((uintptr_t)row) | ((uintptr_t)plain)) & 15u) == 0) {
+        reinterpret_cast<float4 *>(row)[i >> 2] = reinterpret_cast<const float4 *>(plain)[i >> 2];
+    } else {
+        for (int64_t j = i; j < min(i + 4, P); ++j) row[j] = plain[j];
+    }
+}
 __device__ __forceinline__ bool knn_kept(float x, float y, float z, float v2, float v6, float v10, float v14, float zn, float zf)
 {
     const float zview = x * v2 + y * v6 + z * v10 + 1.0f * v14;   // the expression of setup_point_compute
@@ -636,6 +651,7 @@ __global__ __launch_bounds__(256) void knn_query_kernel(const float *__restrict_
     float v2 = 0.f, v6 = 0.f, v10 = 0.f, v14 = 0.f, zn = 0.f, zf = 0.f;
     if (VIEW) {
         const int cam = view.mode == 1 ? (int)blockIdx.y : n;
+        if (view.mode == 1 && view.culls[cam] == 0u) return;   // (the row is a copy: knn_view_rows_kernel)
         const float *vm = view.V + 16 * cam;
         v2 = vm[2]; v6 = vm[6]; v10 = vm[10]; v14 = vm[14]; zn = view.znear[cam]; zf = view.zfar[cam];
         if (view.mode == 1) kth_sqdist += (size_t)cam * (size_t)P;
@@ -903,14 +919,15 @@ __global__ __launch_bounds__(256) void knn_query_coop_kernel(const float *__rest
     const int grp = threadIdx.x / KNN_LPQ, sub = threadIdx.x % KNN_LPQ;
     __shared__ uint32_t row_lo[KNN_LPQ][GPB], row_hi[KNN_LPQ][GPB];
     float *const kth_base = kth_sqdist;
-    // VIEW, one cloud seen by several cameras: a PERSISTENT grid walks the (camera, chunk) items (as grid rows, 44,000
-    // workgroups at 8 x 100k points, most of which only copy, would cost ~3 ns of dispatch each).  Otherwise: one pass,
-    // item = this workgroup.
+    // VIEW, one cloud seen by several cameras: a grid row covers the query chunks of ONE camera (at most 16,384 workgroups, the
+    // rest by stride), there are two rows, and every workgroup takes its chunks for each camera of its row's share that drops
+    // points, one camera after the other (two rows: half the serial depth when every camera drops points) -- a
+    // camera that drops nothing costs a scalar load (its row is a copy, knn_view_rows_kernel), where a grid row per camera cost
+    // a workgroup dispatch per chunk.  Otherwise: one pass, chunk = this workgroup.
     const bool walk = VIEW && view.mode == 1;
-    const uint32_t n_items = walk ? chunks * (uint32_t)view.n_cams : 1u;
-    for (uint32_t item = walk ? blockIdx.x : 0u; item < n_items; item += walk ? gridDim.x : 1u) {
-    const int cam_y = walk ? (int)(item / chunks) : 0;
-    const uint32_t bx = walk ? item - (uint32_t)cam_y * chunks : blockIdx.x;
+    for (int cam_y = walk ? (int)blockIdx.y : 0; cam_y < (walk ? view.n_cams : 1); cam_y += walk ? (int)gridDim.y : 1) {
+    if (walk && view.culls[cam_y] == 0u) continue;
+    for (uint32_t bx = blockIdx.x; bx < (walk ? chunks : blockIdx.x + 1u); bx += gridDim.x) {
     kth_sqdist = kth_base;
     const int64_t slot = (int64_t)bx * GPB + grp;
     if (slot >= P) continue;   // (whole DPP rows leave together)
@@ -1216,7 +1233,8 @@ __global__ __launch_bounds__(256) void knn_query_coop_kernel(const float *__rest
         for (int k = 1; k < K; ++k) kth = (k < kk && best[k] <= r2) ? best[k] : kth;
     }
     kth_sqdist[p] = kth;
-    }   // (items)
+    }   // (chunks)
+    }   // (cameras)
 }
 
 // deterministic per-cloud mean of values*scale clamped to [lo,hi]: one workgroup per cloud, fixed order (four independent
@@ -1515,15 +1533,14 @@ static int knn_run(const char *who, const float *points, const int64_t *first_id
         }
         // (2) per camera: copy, or search again among the points the camera keeps
         if (coop) {
-            // one cloud, several cameras: a persistent grid over the (camera, chunk) items (at most 8 workgroups per CU's worth)
-            const unsigned long long items = (unsigned long long)cb * gy;
-            const unsigned grid = view.mode == 1 ? (unsigned)(items < 16384ull ? items : 16384ull) : cb;
+            // one cloud, several cameras: the grid covers one camera's chunks (see knn_query_coop_kernel)
+            const dim3 grid = view.mode == 1 ? dim3(cb < 16384u ? cb : 16384u, n_cams > 1 ? 2u : 1u) : dim3(cb);
             if (skip)
-                hipLaunchKernelGGL((knn_query_coop_kernel<8, false, true, true>), dim3(grid), dim3(256), 0, st, points, first_idx,
+                hipLaunchKernelGGL((knn_query_coop_kernel<8, false, true, true>), grid, dim3(256), 0, st, points, first_idx,
                                    num_pts, N, P, grids, stride, offsets, sorted, K, kth_sqdist, dists, idx, r2, view, cb, bx, df, 0,
                                    nullptr, plain_stat, plain_dk);
             else
-                hipLaunchKernelGGL((knn_query_coop_kernel<8, false, true>), dim3(grid), dim3(256), 0, st, points, first_idx, num_pts,
+                hipLaunchKernelGGL((knn_query_coop_kernel<8, false, true>), grid, dim3(256), 0, st, points, first_idx, num_pts,
                                    N, P, grids, stride, offsets, sorted, K, kth_sqdist, dists, idx, r2, view, cb, bx, df, 0, nullptr,
                                    plain_stat, plain_dk);
         } else {
@@ -1531,6 +1548,9 @@ static int knn_run(const char *who, const float *points, const int64_t *first_id
                                grids, stride, offsets, sorted, K, kth_sqdist, dists, idx, r2, view, bx, df, 0, nullptr, plain_stat,
                                plain_dk);
         }
+        if (view.mode == 1)   // the rows of the cameras that drop nothing = the unmasked search
+            hipLaunchKernelGGL(knn_view_rows_kernel, dim3((unsigned)((P + 1023) / 1024), (unsigned)n_cams), dim3(256), 0, st, kth_sqdist,
+                               plain_stat, P, view.culls);
         return check_launch(who);
     }
     if (full) {
