@@ -292,19 +292,23 @@ __global__ __launch_bounds__(256) void knn_fill_kernel(const float *__restrict__
 // the reference's training loop does not stay that way: after ~900 iterations at BASELINE configs[2] a few outliers have
 // stretched the bounding box to +-2 while nine tenths of the points sit within 0.55 of the origin -- a typical point shares
 // its cell with 650 others (3,900 in the fullest cell), every query scans ~4,000 candidates instead of ~200, and the two
-// searches of an iteration go from 0.13 / 0.16 ms to 1.7 / 2.3 ms (profiles/r6_b_train_mvr_ref_kernel_stats.csv).  No
+// searches of an iteration go from 0.13 / 0.16 ms to 1.7 / 2.3 ms (profiles/r6_b_train_mvr_ref_kernel_stats.csv, before this).  No
 // single cell size serves a cloud whose neighbour distances span two orders of magnitude.  So, from KNN_SKIP_MIN_P points
 // on, the cell-sorted array gets a skip structure:
-//   * knn_dense_list_kernel lists the DENSE cells (more than KNN_DENSE_CELL points) and raises `dense_flag`; knn_subsort_kernel
-//     orders the points of each along a Morton curve of their position inside the cell, so that consecutive slots are
-//     close in space;
+//   * knn_dense_list_kernel lists the DENSE cells (more than KNN_DENSE_CELL points) and counts the points they hold;
+//     knn_subsort_kernel orders the points of each along a Morton curve of their position inside the cell, so that
+//     consecutive slots are close in space, and raises `dense_flag` when those cells hold a real share of the cloud;
 //   * knn_block_box_kernel records the bounding box of every KNN_BLOCK consecutive slots;
-//   * the one-thread-per-query kernel first looks at its own sorted neighbourhood (own cell dense: the KNN_SEED slots around
-//     the query's slot) -- which gives a K-th distance close to the final one at once -- and then walks long candidate runs
-//     block by block, skipping every block whose box lies farther than the current K-th distance.
+//   * a query (both kernels) first looks at its own sorted neighbourhood (own cell dense: the KNN_SEED slots around the
+//     query's slot) -- which gives a K-th distance close to the final one at once -- and then walks long candidate runs
+//     block by block, skipping every block whose box lies farther than the current K-th distance.  The cooperative kernel
+//     tests 32 boxes per trip (two per lane) and reads up to four surviving blocks together; clouds with `dense_flag` up go
+//     to it at every size (a second launch next to the one-thread kernel's where that one is the choice for even clouds:
+//     each leaves at once when the cloud is not its kind).
 // Same candidates rule, same (distance, id) order: results are identical; only points that cannot enter the list are skipped.
-// On the trained cloud: 3,999 -> 200 candidates + 250 box tests per query.  A cloud without dense cells pays one scan of
-// the cell counts (the queries then run exactly as before: `dense_flag` stays 0 and the boxes are neither built nor read).
+// On the trained cloud: 3,999 -> 200 candidates + 250 box tests per query.  A cloud without dense cells pays four launches
+// that find nothing to do (~13 us at 100k-200k points; `dense_flag` stays 0, the boxes are neither built nor read and the
+// queries run as before).
 // ---------------------------------------------------------------------------------------------------------------
 #define KNN_SKIP_MIN_P 65536     // per call: below, the grid build is a chain of launch latencies and clouds are small
 #define KNN_DENSE 64             // slots in a candidate run (and points in the query's own cell, for the seed) from which the blocks are walked
