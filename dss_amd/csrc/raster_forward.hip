@@ -108,16 +108,17 @@ struct TileQueue {
 // A splat larger than 2 x 2 tiles (radius above 8 pixels) records its full tiles in a 64-bit mask of its own -- bit 8 dy + dx
 // of `big[p]`, valid when bit 7 of its mask byte is set -- for rectangles of up to 8 x 8 tiles; a wider one (radius above 28
 // pixels: a point close to the camera) appends one such mask per 8 x 8 block of its rectangle to the `giant` records.  Only
-// when those run out does a splat raise the flag that sends every spilled tile back to whole-cloud scans.  (Until round 6 every such splat raised it, "rare" being
-// the assumption: the reference's own training loop at configs[2] lives there -- h sits at its upper clamp 1e-3, splats are
-// ~10 pixels wide, hundreds overlap per pixel -- and ~1,900 tiles per call scanned all 99,790 points of their cloud: 1.9 of
-// the fine pass's 2.0 ms, tools/fine_timing.py trained.)
+// when those run out does a splat raise the flag that sends every spilled tile back to whole-cloud scans.  (Until round 6
+// every splat wider than 2 x 2 tiles raised it, "rare" being the assumption: the reference's own training loop at configs[2]
+// lives there -- h sits at its upper clamp 1e-3, splats are ~10 pixels wide, hundreds overlap per pixel -- and ~1,900 tiles
+// per call scanned all 99,790 points of their cloud: 1.3 of the fine pass's 1.56 ms, tools/fine_timing.py trained.)
+// The cell-ordered binning of more than 2M splats (bin_sorted_kernel) still does: its splats are 1-2 pixels wide.
 struct Spill {
     uint32_t *cursor;   // (N*tiles*SUB) arrival counters of the pool pass                  (zero when binning starts)
     uint32_t *offset;   // (N*tiles*SUB) 1 + first pool entry of an overflowed sub-list      (zero when binning starts)
     uint8_t *mask;      // (P) bit 0..3: tile (tx0,ty0), (tx1,ty0), (tx0,ty1), (tx1,ty1) was full (zero when binning starts)
     uint32_t *ctrl;     // [0] some mask is set, [1] pool entries handed out                 (zero when binning starts)
-    uint32_t *fail;     // fail[0] == fail[1]: a large splat overflowed / a waiter gave up -> spilled tiles fall back to
+    uint32_t *fail;     // fail[0] == fail[1]: a wide splat found no record for its full tiles / a waiter gave up -> spilled tiles fall back to
                         // whole-cloud scans.  fail[1] = the epoch of the binning launch (written by its first thread),
                         // fail[0] = that epoch, written by whoever fails.  Never reset: every racing writer of a word
                         // stores the same value (two different values from two XCDs would leave the outcome to the
