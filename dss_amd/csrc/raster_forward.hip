@@ -112,7 +112,7 @@ struct TileQueue {
 // every splat wider than 2 x 2 tiles raised it, "rare" being the assumption: the reference's own training loop at configs[2]
 // lives there -- h sits at its upper clamp 1e-3, splats are ~10 pixels wide, hundreds overlap per pixel -- and ~1,900 tiles
 // per call scanned all 99,790 points of their cloud: 1.3 of the fine pass's 1.56 ms, tools/fine_timing.py trained.)
-// The cell-ordered binning of more than 2M splats (bin_sorted_kernel) still does: its splats are 1-2 pixels wide.
+// The cell-ordered binning of more than 2M splats (bin_sorted_kernel) records them the same way.
 struct Spill {
     uint32_t *cursor;   // (N*tiles*SUB) arrival counters of the pool pass                  (zero when binning starts)
     uint32_t *offset;   // (N*tiles*SUB) 1 + first pool entry of an overflowed sub-list      (zero when binning starts)
@@ -127,7 +127,7 @@ struct Spill {
     int32_t *pool;
     unsigned long long *big;  // (P) full tiles of a splat larger than 2 x 2 tiles (valid when bit 7 of its mask byte is set)
     uint4 *giant;             // (8, giant_cap) records of splats wider than 8 x 8 tiles, one per 8 x 8 block of their rectangle that
-                              // met a full sub-list: {splat, block origin ty << 16 | tx, mask lo, mask hi}; segment = splat mod 8,
+                              // met a full sub-list: {splat (or its position), sub-list << 28 | block origin ty << 14 | tx, mask lo, mask hi}; segment = entry mod 8,
                               // its record count in ctrl[2 + segment] (eight counters: one serialises at ~11 ns per append)
     uint32_t giant_cap;       // records per segment
     uint32_t cap_entries;  // pool capacity in entries
@@ -308,7 +308,7 @@ __device__ __forceinline__ void bin_rect(int64_t p, int n, int tx0, int tx1, int
                 const unsigned seg = (unsigned)p & 7u;
                 const uint32_t r = atomicAdd(&sp.ctrl[2 + seg], 1u);
                 if (r < sp.giant_cap)
-                    sp.giant[(size_t)seg * sp.giant_cap + r] = make_uint4((uint32_t)p, ((uint32_t)by << 16) | (uint32_t)bx,
+                    sp.giant[(size_t)seg * sp.giant_cap + r] = make_uint4((uint32_t)p, (seg << 28) | ((uint32_t)by << 14) | (uint32_t)bx,
                                                                           (uint32_t)full, (uint32_t)(full >> 32));
                 else sp.fail[0] = sp.epoch;   // (out of records)
             } else {
@@ -448,7 +448,7 @@ __device__ __forceinline__ bool spill_pass(
     if (n < 0 || !splat_tile_rect(gx, gy, gz, grx, gry, g, tx0, tx1, ty0, ty1)) continue;
     const size_t sub0 = ((size_t)n * g.tiles_x * g.tiles_y) * DSS_SUB + (sorted ? ((full >> 4) & (DSS_SUB - 1)) : ((unsigned)p & (DSS_SUB - 1)));
     // the splat's full tiles: bits 0..3 of the mask byte (a rectangle of at most 2 x 2 tiles), or the 64-bit mask of a larger one
-    const bool is_big = !sorted && (full & 0x80u) != 0u;
+    const bool is_big = (full & 0x80u) != 0u;
     unsigned long long todo = is_big ? sp.big[p] : (unsigned long long)(full & 0xfu);
 #pragma unroll 1
     while (todo != 0ull) {
@@ -460,17 +460,17 @@ __device__ __forceinline__ bool spill_pass(
     }
     }
     // splats wider than 8 x 8 tiles: one record per 8 x 8 block of their rectangle that met a full sub-list (bin_rect)
-    if (!sorted && sp.giant != nullptr) {
+    if (sp.giant != nullptr) {
 #pragma unroll 1
         for (unsigned seg = 0; seg < 8u; ++seg) {
             const uint32_t nrec = min((uint32_t)__builtin_amdgcn_readfirstlane((int)sp.ctrl[2 + seg]), sp.giant_cap);
             for (uint32_t r = block * blockDim.x + threadIdx.x; r < nrec; r += nblocks * blockDim.x) {
                 const uint4 rec = sp.giant[(size_t)seg * sp.giant_cap + r];
-                const int64_t p = (int64_t)rec.x;
-                const int n = find_cloud(p, first_idx, num_pts, N);
+                const int64_t p = (int64_t)rec.x;   // (sorted path: a position of the order, like every list entry)
+                const int n = find_cloud(crec ? (int64_t)s_id[p] : p, first_idx, num_pts, N);
                 if (n < 0) continue;
-                const int bx = (int)(rec.y & 0xffffu), by = (int)(rec.y >> 16);
-                const size_t sub0 = ((size_t)n * g.tiles_x * g.tiles_y) * DSS_SUB + ((unsigned)p & (DSS_SUB - 1));
+                const int bx = (int)(rec.y & 0x3fffu), by = (int)((rec.y >> 14) & 0x3fffu);
+                const size_t sub0 = ((size_t)n * g.tiles_x * g.tiles_y) * DSS_SUB + (rec.y >> 28);
                 unsigned long long todo = ((unsigned long long)rec.w << 32) | rec.z;
 #pragma unroll 1
                 while (todo != 0ull) {
@@ -919,12 +919,34 @@ __global__ __launch_bounds__(SORT_BIN_THREADS) void bin_sorted_kernel(
         }
         if (onm[j] & 16u) {
             // a splat larger than 2 x 2 tiles (radius above 8 pixels): one returning atomic per tile, like the direct binning
-            for (int ty = ry0[j]; ty <= ry1[j]; ++ty)
-                for (int tx = rx0[j]; tx <= rx1[j]; ++tx) {
-                    const size_t t = (size_t)(cl[j] * tiles + ty * g.tiles_x + tx) * DSS_SUB + sub;
-                    const uint32_t pos = atomicAdd(&counts[t], 1u);
-                    if (pos < cap) lists[t * cap + pos] = (int32_t)posn[j];
-                    else if (sp.ctrl) sp.fail[0] = sp.epoch;
+            // (full tiles: a 64-bit mask per 8 x 8 block of the rectangle, as in bin_rect)
+            const bool one_block = rx1[j] - rx0[j] < 8 && ry1[j] - ry0[j] < 8;
+            for (int by = ry0[j]; by <= ry1[j]; by += 8)
+                for (int bx = rx0[j]; bx <= rx1[j]; bx += 8) {
+                    unsigned long long fullm = 0ull;
+                    const int ye = min(by + 7, (int)ry1[j]), xe = min(bx + 7, (int)rx1[j]);
+                    for (int ty = by; ty <= ye; ++ty)
+                        for (int tx = bx; tx <= xe; ++tx) {
+                            const size_t t = (size_t)(cl[j] * tiles + ty * g.tiles_x + tx) * DSS_SUB + sub;
+                            const uint32_t pos = atomicAdd(&counts[t], 1u);
+                            if (pos < cap) lists[t * cap + pos] = (int32_t)posn[j];
+                            else fullm |= 1ull << (8 * (ty - by) + (tx - bx));
+                        }
+                    if (fullm == 0ull || !sp.ctrl) continue;
+                    if (one_block && sp.big != nullptr) {
+                        sp.big[posn[j]] = fullm;
+                        sp.mask[posn[j]] = (uint8_t)(0x80u | (sub << 4));
+                    } else if (sp.giant != nullptr) {
+                        const unsigned seg = (unsigned)posn[j] & 7u;
+                        const uint32_t r = atomicAdd(&sp.ctrl[2 + seg], 1u);
+                        if (r < sp.giant_cap)
+                            sp.giant[(size_t)seg * sp.giant_cap + r] = make_uint4((uint32_t)posn[j], (sub << 28) | ((uint32_t)by << 14) | (uint32_t)bx,
+                                                                                  (uint32_t)fullm, (uint32_t)(fullm >> 32));
+                        else sp.fail[0] = sp.epoch;
+                    } else {
+                        sp.fail[0] = sp.epoch;
+                    }
+                    sp.ctrl[0] = 1u;
                 }
         }
     }

@@ -259,6 +259,43 @@ def test_cell_ordered_binning_of_large_inputs_is_exact(dist):
         assert torch.equal(fb["idx"], f["idx"][:, own]) and torch.equal(fb["qvalue"], f["qvalue"][:, own]), part.describe()
 
 
+def test_cell_ordered_binning_keeps_overflowing_wide_splats_on_the_lists():
+    """The cell-ordered path (> 2M splats) with WIDE splats among them: 1 % of the points get a variance scale 4000x the cloud's
+    (20-40 pixel splats, part of them wider than 8 x 8 tiles), sub-lists overflow under them, and `bin_sorted_kernel` records their full
+    tiles like the direct binning does (64-bit masks / block records: raster_forward.hip `Spill::big`, `giant`).  Same
+    fragments as the direct binning of `splat_points`, bit for bit, twice (the workspace is left clean)."""
+    pts, nrm = scenes.load_cloud("yoga6")
+    pts = scenes.normalize_unit_sphere(pts)
+    pts, nrm = scenes.upsample_jitter(pts, nrm, 106, seed=0)     # 1,057,774 points per cloud, two clouds
+    h0 = scenes.global_h(pts[::40]) / 40.0
+    S, K, thr = 512, 5, 0.05
+    # cloud 0 seen from nearby, cloud 1 from far away: there the whole cloud lands on a few tiles and every sub-list overflows
+    M = np.concatenate([scenes.camera_matrices(d, 20.0, a)[0] for d, a in ((2.0, 30.0), (5.0, 170.0))])
+    V = np.concatenate([scenes.camera_matrices(d, 20.0, a)[1] for d, a in ((2.0, 30.0), (5.0, 170.0))])
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    Pc = len(pts)
+    first = torch.tensor([0, Pc], dtype=torch.int64, device=DEV)
+    num = torch.tensor([Pc, Pc], dtype=torch.int64, device=DEV)
+    h = torch.full((2 * Pc,), float(h0), device=DEV)
+    pick = torch.from_numpy(np.random.default_rng(0).permutation(2 * Pc)).to(DEV)
+    h[pick[:(2 * Pc) // 100]] = float(h0) * 4000.0      # 20-40 pixels near, ~10 far
+    h[pick[:(2 * Pc) // 1000]] = float(h0) * 60000.0    # wider than 8 x 8 tiles in the far view as well
+    world, normals = t(np.concatenate([pts, pts])), t(np.concatenate([nrm, nrm]))
+    args = (world, normals, h, t(M), t(V), torch.full((2,), 0.1, device=DEV), torch.full((2,), 100.0, device=DEV), first, num,
+            torch.rand((2 * Pc, 3), device=DEV), S, K, 1.0, thr, 1.0, False, False)
+    f = ops.render_forward(*args)
+    rad_px = f["radii"].amax(1) * (S / 2)
+    far = rad_px[Pc:]
+    assert int((far > 8).sum()) > 3000 and int((far > 28).sum()) > 100, (int((far > 8).sum()), int((far > 28).sum()))
+    assert float(f["occupancy"][1].mean()) < 0.5
+    want = ops.splat_points(f["pts_screen"], f["ellipse_params"], f["cutoff_threshold"], f["radii"], first, num, thr, S, K,
+                            return_visible=True)
+    for k, w_ in zip(("idx", "zbuf", "qvalue", "occupancy", "visible"), want):
+        assert torch.equal(f[k], w_), k
+    f2 = ops.render_forward(*args)
+    assert torch.equal(f2["idx"], f["idx"]) and torch.equal(f2["occupancy"], f["occupancy"])
+
+
 @pytest.mark.parametrize("reps,S,form,C", [(4, 256, 0, 3), (4, 256, 1, 3), (16, 512, 0, 3), (4, 192, 0, 3), (4, 192, 0, 5), (16, 320, 0, 5)])
 def test_owner_mode_of_the_band_backward(reps, S, form, C):
     """dss_render_backward_owned (`render_backward(grad_out_full=...)`): on a row band the occupancy surrogate of a (camera,
