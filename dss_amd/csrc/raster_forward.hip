@@ -1799,7 +1799,12 @@ __host__ __device__ __forceinline__ uint32_t fill_workgroups(int total_tiles)
 }
 
 template <int KMAX, bool PACKED>
+#ifdef DSS_FINE_OCC8   // (A/B builds: eight wavefronts per SIMD, i.e. at most 64 VGPRs -- the kernel needs 69, seven wavefronts.  Measured at
+                       //  the end of round 6: 7 VGPR spills, the step +2 % at configs[1], +2 % at configs[3], +2 % at configs[4]: not taken)
+__global__ __launch_bounds__(FINE_THREADS) __attribute__((amdgpu_num_sgpr(96))) __attribute__((amdgpu_waves_per_eu(8, 8))) void fine_kernel(const FineArgs A)
+#else
 __global__ __launch_bounds__(FINE_THREADS) __attribute__((amdgpu_num_sgpr(96))) void fine_kernel(const FineArgs A)
+#endif
 {
     const int total = A.N * A.g.tiles_x * A.g.tiles_y;
     const bool qmode = A.queue.list != nullptr;
