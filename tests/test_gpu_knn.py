@@ -270,7 +270,7 @@ def test_masked_culling_renders_what_the_references_drop_then_search_order_rende
 def _clustered_clouds():
     """-> list of clouds: [0] the model of the reference's training loop after 893 iterations at configs[2] (dense bulk, thin
     halo out to radius 2.1: tests/golden/trained_cloud_cfg3.npz), [1] a synthetic one with a cell of more than 4,096 points
-    (not sub-sorted), exact duplicates and far outliers, [2] an evenly sampled surface (no dense cell)."""
+    (not sub-sorted), exact duplicates and far outliers, [2] an evenly sampled surface (no dense cell), [3] three points, [4] none."""
     import os
     z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "trained_cloud_cfg3.npz"))
     rng = np.random.default_rng(7)
@@ -281,7 +281,8 @@ def _clustered_clouds():
     far = rng.uniform(-3, 3, (300, 3)).astype(np.float32)
     synth = np.concatenate([blob, shell, clump, dup, far])[rng.permutation(12000 + 30000 + 20000 + 2000 + 300)]
     even, _, _ = scenes.synthetic_cloud(20000, seed=9)
-    return [z["points"].astype(np.float32), synth, even.astype(np.float32)]
+    tiny = rng.uniform(-0.3, 0.3, (3, 3)).astype(np.float32)      # fewer points than K: the shortcut of the per-camera search must not fire
+    return [z["points"].astype(np.float32), synth, even.astype(np.float32), tiny, np.zeros((0, 3), np.float32)]
 
 
 def _with_query_option(value, fn):
@@ -322,21 +323,31 @@ def test_knn_skip_structure_of_clustered_clouds_is_exact(which):
     da, ia = ops.knn_points(P, F, Nn, 12)
     da, ia = da.cpu().numpy(), ia.cpu().numpy()
     for f, n, c in zip(first, num, clouds):
+        if n < 4000:
+            continue
         sel = rng.choice(n, 4000, replace=False)
         d_ref, i_ref = cKDTree(c.astype(np.float64)).query(c[sel].astype(np.float64), k=12)
         assert np.allclose(da[f + sel], d_ref ** 2, rtol=2e-5, atol=1e-12)
         clear = (np.diff(d_ref, axis=1) > 1e-6 * d_ref[:, 1:]).all(1)   # rows without (near-)ties: the ids are determined
         assert clear.sum() > 1000 and (ia[f + sel][clear] == i_ref[clear]).all()
     # per-camera culling (one shared cloud seen by three cameras; one cloud per camera)
-    Mn, Vn, _ = scenes.camera_matrices([1.3, 1.6, 2.5], [10.0, 40.0, -20.0], [0.0, 120.0, 250.0])
-    znear, zfar = np.array([1.0, 0.01, 1.0], np.float32), np.array([100.0, 100.0, 2.6], np.float32)
-    if which == "trained":
-        args = (P, F, Nn, 7, t(Vn), t(znear), t(zfar), True)
-    else:
-        args = (P, F, Nn, 7, t(Vn), t(znear), t(zfar), False)
+    nc = 3 if which == "trained" else len(clouds)
+    Mn, Vn, _ = scenes.camera_matrices([1.3, 1.6, 2.5, 1.4, 1.4][:nc], [10.0, 40.0, -20.0, 5.0, 5.0][:nc], [0.0, 120.0, 250.0, 60.0, 60.0][:nc])
+    znear = np.array([1.0, 0.01, 1.0, 1.35, 1.0], np.float32)[:nc]
+    zfar = np.array([100.0, 100.0, 2.6, 100.0, 100.0], np.float32)[:nc]
+    args = (P, F, Nn, 7, t(Vn), t(znear), t(zfar), which == "trained")
+    for r in (0.2, None):
+        a = ops.knn_kth_sqdist_view(*args, radius=r)
+        b = _with_query_option(3, lambda: ops.knn_kth_sqdist_view(*args, radius=r))
+        assert torch.equal(a, b), r
     a = ops.knn_kth_sqdist_view(*args, radius=0.2)
-    b = _with_query_option(3, lambda: ops.knn_kth_sqdist_view(*args, radius=0.2))
-    assert torch.equal(a, b)
+    if which != "trained":
+        # the three-point cloud under a camera that drops part of it: the statistic among the points it keeps
+        c3, f3 = clouds[3], int(first[3])
+        zv3 = c3[:, 0] * Vn[3, 0, 2] + c3[:, 1] * Vn[3, 1, 2] + c3[:, 2] * Vn[3, 2, 2] + Vn[3, 3, 2]
+        ok3 = (zv3 >= znear[3]) & (zv3 <= zfar[3])
+        got3 = a[f3:f3 + 3].cpu().numpy()
+        assert (got3[~ok3] == 0).all() and np.allclose(got3[ok3], _ref_radius_stat(c3[ok3], 7, 0.2), rtol=2e-5, atol=1e-9), (ok3, got3)
     c0 = clouds[0]
     zv = c0[:, 0] * Vn[0, 0, 2] + c0[:, 1] * Vn[0, 1, 2] + c0[:, 2] * Vn[0, 2, 2] + Vn[0, 3, 2]
     ok = (zv >= znear[0]) & (zv <= zfar[0])
