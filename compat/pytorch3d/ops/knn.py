@@ -34,19 +34,16 @@ def _brute(p1, p2, lengths1, lengths2, K):
 
 
 def _self_query_on_gpu(p1, lengths1, K):
+    """the padded batch handed over as it lies: cloud n = rows [n P1, n P1 + lengths1[n]) of the packed array, the rows behind a
+    cloud's length belong to no cloud (the kernel zero-fills them).  No host value of `lengths1` is needed: slicing the clouds
+    out with int(lengths1[n]) waited for the GPU once per cloud and call"""
     from dss_amd import ops  # the HIP path; raises if the library is missing
     N, P1, _ = p1.shape
     num = lengths1.to(torch.int64)
-    first = torch.cumsum(num, 0) - num
-    packed = torch.cat([p1[n, : int(num[n])] for n in range(N)], 0).detach().contiguous().float()
+    first = torch.arange(N, device=p1.device, dtype=torch.int64) * P1
+    packed = p1.detach().reshape(N * P1, 3).contiguous().float()
     d, i = ops.knn_points(packed, first, num, K)
-    dists = p1.new_zeros((N, P1, K))
-    idx = torch.zeros((N, P1, K), dtype=torch.int64, device=p1.device)
-    for n in range(N):
-        f, c = int(first[n]), int(num[n])
-        dists[n, :c] = d[f:f + c]
-        idx[n, :c] = i[f:f + c]
-    return dists, idx
+    return d.view(N, P1, K).to(p1.dtype), i.view(N, P1, K)
 
 
 def knn_points(p1, p2, lengths1=None, lengths2=None, K: int = 1, version: int = -1, return_nn: bool = False,
@@ -60,12 +57,15 @@ def knn_points(p1, p2, lengths1=None, lengths2=None, K: int = 1, version: int = 
     p1 = p1.contiguous()
     p2 = p2.contiguous()
     N, P1, P2 = p1.shape[0], p1.shape[1], p2.shape[1]
+    both_full = lengths1 is None and lengths2 is None and P1 == P2
     if lengths1 is None:
         lengths1 = torch.full((N,), P1, dtype=torch.int64, device=p1.device)
     if lengths2 is None:
-        lengths2 = torch.full((N,), P2, dtype=torch.int64, device=p1.device)
-    same = p1.is_cuda and p1.shape == p2.shape and p1.shape[2] == 3 and (p1.data_ptr() == p2.data_ptr() or torch.equal(p1, p2)) \
-        and torch.equal(lengths1, lengths2) and K <= 64
+        lengths2 = lengths1 if both_full else torch.full((N,), P2, dtype=torch.int64, device=p1.device)
+    # (comparisons that ask the device only when the cheap identity tests do not settle the question)
+    same = p1.is_cuda and p1.shape == p2.shape and p1.shape[2] == 3 and K <= 64 \
+        and (p1.data_ptr() == p2.data_ptr() or torch.equal(p1, p2)) \
+        and (lengths1 is lengths2 or lengths1.data_ptr() == lengths2.data_ptr() or torch.equal(lengths1, lengths2))
     with torch.no_grad():
         if same:
             _, idx = _self_query_on_gpu(p1, lengths1, K)
@@ -91,7 +91,7 @@ def knn_gather(x, idx, lengths=None):
         lengths = torch.full((x.shape[0],), M, dtype=torch.int64, device=x.device)
     idx_expanded = idx[:, :, :, None].expand(-1, -1, -1, U)
     x_out = x[:, :, None].expand(-1, -1, K, -1).gather(1, idx_expanded)
-    needs_mask = lengths.min() < K
+    needs_mask = True if x.is_cuda else bool(lengths.min() < K)   # (on a GPU the question costs more than the mask: a host sync)
     if needs_mask:
         mask = lengths[:, None] <= torch.arange(K, device=x.device)[None]
         mask = mask[:, None].expand(-1, L, -1)

@@ -122,9 +122,36 @@ def inspect_is_plain(k, v) -> bool:
         or (k.startswith("_") and isinstance(v, dict))
 
 
+def _literal_key(x):
+    """a hashable form of a Python number or a (nested) tuple / list of numbers; None for anything else"""
+    if isinstance(x, (bool, int, float)):
+        return (type(x).__name__, x)
+    if isinstance(x, (tuple, list)):
+        parts = tuple(_literal_key(v) for v in x)
+        return None if any(p is None for p in parts) else ("seq",) + parts
+    return None
+
+
+_LITERALS = {}   # (literal, dtype, device) -> device tensor
+
+
 def format_tensor(input, dtype: torch.dtype = torch.float32, device="cpu") -> torch.Tensor:
     if not torch.is_tensor(input):
-        input = torch.tensor(input, dtype=dtype, device=device)
+        # A Python literal (shininess=64, a colour tuple, ...) becomes a device tensor through a host-to-device copy from
+        # pageable memory, which on a GPU waits for the stream: 28 such copies per iteration of the reference's train_mvr.py
+        # (lighting.py: convert_to_tensors_and_broadcast(..., shininess)) were 15 ms of a 41 ms iteration under the profiler.
+        # The copy is made once per distinct literal; every call gets its own clone (a device-side copy, asynchronous).
+        key = _literal_key(input)
+        if key is not None and torch.device(device).type != "cpu":
+            key = (key, dtype, str(torch.device(device)))
+            cached = _LITERALS.get(key)
+            if cached is None:
+                if len(_LITERALS) > 4096:
+                    _LITERALS.clear()
+                cached = _LITERALS[key] = torch.tensor(input, dtype=dtype, device=device)
+            input = cached.clone()
+        else:
+            input = torch.tensor(input, dtype=dtype, device=device)
     if input.dim() == 0:
         input = input.view(1)
     if input.device != torch.device(device):

@@ -8,6 +8,24 @@ import torch
 from . import utils as struct_utils
 
 
+_CONSTANTS = {}   # (values, dtype, device) -> device tensor made from host values once
+
+
+def _device_constant(values, dtype, device):
+    """a fresh device tensor holding `values` (a tuple of Python numbers): the host-to-device copy -- which waits for the stream
+    when it comes from pageable memory -- is made once per distinct tuple; callers get a clone (device-side, asynchronous)"""
+    device = torch.device(device)
+    if device.type == "cpu":
+        return torch.tensor(values, dtype=dtype)
+    key = (values, dtype, str(device))
+    t = _CONSTANTS.get(key)
+    if t is None:
+        if len(_CONSTANTS) > 4096:
+            _CONSTANTS.clear()
+        t = _CONSTANTS[key] = torch.tensor(values, dtype=dtype, device=device)
+    return t.clone()
+
+
 class Pointclouds:
     _INTERNAL_TENSORS = [
         "_points_packed", "_points_padded", "_normals_packed", "_normals_padded", "_features_packed",
@@ -19,6 +37,7 @@ class Pointclouds:
         self.device = torch.device("cpu")
         self.equisized = False
         self.valid = None
+        self._any_valid = False
         self._N = 0
         self._P = 0
         self._C = None
@@ -47,12 +66,15 @@ class Pointclouds:
                         raise ValueError("Clouds in list must be of shape Px3 or empty")
                     if p.device != self.device:
                         raise ValueError("All points must be on the same device")
-                num = torch.tensor([len(p) for p in self._points_list], device=self.device)
-                self._P = int(num.max())
-                self.valid = torch.tensor([len(p) > 0 for p in self._points_list], dtype=torch.bool, device=self.device)
-                if len(num.unique()) == 1:
+                # the sizes are host integers: nothing here has to ask the device (int(num.max()), num.unique() and the two
+                # host-to-device copies each waited for the GPU; train_mvr.py builds ~10 of these objects per iteration)
+                sizes = [len(p) for p in self._points_list]
+                self._P = max(sizes)
+                self._any_valid = any(n > 0 for n in sizes)
+                self.valid = _device_constant(tuple(n > 0 for n in sizes), torch.bool, self.device)
+                if len(set(sizes)) == 1:
                     self.equisized = True
-                self._num_points_per_cloud = num
+                self._num_points_per_cloud = _device_constant(tuple(sizes), torch.int64, self.device)
             else:
                 self._num_points_per_cloud = torch.tensor([], dtype=torch.int64)
         elif torch.is_tensor(points):
@@ -63,7 +85,8 @@ class Pointclouds:
             self._P = points.shape[1]
             self.device = points.device
             self.valid = torch.ones((self._N,), dtype=torch.bool, device=self.device)
-            self._num_points_per_cloud = torch.tensor([self._P] * self._N, device=self.device)
+            self._any_valid = self._N > 0
+            self._num_points_per_cloud = torch.full((self._N,), self._P, dtype=torch.int64, device=self.device)
             self.equisized = True
         else:
             raise ValueError("Points must be either a list or a tensor with shape (batch_size, P, 3) where P is the "
@@ -145,7 +168,8 @@ class Pointclouds:
         return self.__class__(points=points, normals=normals, features=features)
 
     def isempty(self) -> bool:
-        return self._N == 0 or bool(self.valid.eq(False).all())
+        # (pytorch3d asks the device: `self.valid.eq(False).all()`; `valid` is made from host integers in __init__)
+        return self._N == 0 or not self._any_valid
 
     # ---- list / packed / padded views ---------------------------------------------------------------------------
     def points_list(self) -> List[torch.Tensor]:

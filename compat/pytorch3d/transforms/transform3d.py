@@ -67,12 +67,14 @@ class Transform3d:
         return composed
 
     def _get_matrix_inverse(self) -> torch.Tensor:
-        return torch.inverse(self._matrix)
+        # same LU inverse as torch.inverse, without its host-side check of the singularity flag: that check waits for the GPU
+        # (2 ms per iteration of train_mvr.py at configs[2], where get_camera_center() comes here once per render)
+        return torch.linalg.inv_ex(self._matrix).inverse
 
     def inverse(self, invert_composed: bool = False):
         tinv = Transform3d(dtype=self.dtype, device=self.device)
         if invert_composed:
-            tinv._matrix = torch.inverse(self.get_matrix())
+            tinv._matrix = torch.linalg.inv_ex(self.get_matrix()).inverse
         else:
             i_matrix = self._get_matrix_inverse()
             if len(self._transforms) > 0:

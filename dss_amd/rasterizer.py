@@ -481,7 +481,7 @@ class SurfaceSplatting(torch.nn.Module):
         if dropped:
             keep = keep & act.to(vis.device).bool()[:, :p_max].expand(N, -1)
         full = torch.zeros((N, p_max), dtype=torch.bool, device=vis.device)
-        full[keep] = vis
+        full.masked_scatter_(keep, vis)   # (`full[keep] = vis` counts the kept positions on the host: a sync per render)
         point_clouds_filter.set_filter(visibility=full)
 
     def _forward_compacted(self, point_clouds, original_clouds, point_clouds_filter, **kwargs):

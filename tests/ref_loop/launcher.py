@@ -387,7 +387,21 @@ def main():
         return make_checkpoint(args)
     sys.argv = ["train_mvr.py", "--config", args.config, "--exit-after", str(args.exit_after)] + \
         (["--no-cuda"] if args.no_cuda else [])
-    runpy.run_path(os.path.join(args.reference, "train_mvr.py"), run_name="__main__")
+    prof_out = os.environ.get("DSS_REF_LOOP_CPROFILE")   # developer aid: host-side profile of the loop (cumulative, top 60) into this file
+    if not prof_out:
+        runpy.run_path(os.path.join(args.reference, "train_mvr.py"), run_name="__main__")
+        return
+    import cProfile
+    import io
+    import pstats
+    pr = cProfile.Profile()
+    try:
+        pr.runcall(runpy.run_path, os.path.join(args.reference, "train_mvr.py"), run_name="__main__")
+    finally:
+        buf = io.StringIO()
+        pstats.Stats(pr, stream=buf).sort_stats("cumulative").print_stats(60)
+        with open(prof_out, "w") as f:
+            f.write(buf.getvalue())
 
 
 if __name__ == "__main__":

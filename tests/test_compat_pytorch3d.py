@@ -266,3 +266,11 @@ def test_shim_objects_drive_the_drop_in_renderer_built_like_create_renderer():
     a = knn_points(pp, pp, K=8)
     b = knn_points(pp.cpu(), pp.cpu(), K=8)
     assert torch.equal(a.idx.cpu(), b.idx) and torch.allclose(a.dists.cpu(), b.dists, atol=1e-6)
+    # a padded batch of two clouds of different lengths (the padded rows go to the kernel as they lie: no host sync)
+    half = pp.shape[1] // 2
+    two = torch.stack([pp[0, :half], pp[0, half:2 * half]])
+    ln = torch.tensor([half, half - 300], device=dev)
+    a2 = knn_points(two, two, ln, ln, K=12)
+    b2 = knn_points(two.cpu(), two.cpu(), ln.cpu(), ln.cpu(), K=12)
+    assert torch.equal(a2.idx.cpu(), b2.idx) and torch.allclose(a2.dists.cpu(), b2.dists, atol=1e-6)
+    assert float(a2.dists[1, half - 300:].abs().sum()) == 0 and int(a2.idx[1, half - 300:].abs().sum()) == 0
