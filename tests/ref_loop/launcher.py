@@ -399,7 +399,9 @@ def main():
         pr.runcall(runpy.run_path, os.path.join(args.reference, "train_mvr.py"), run_name="__main__")
     finally:
         buf = io.StringIO()
-        pstats.Stats(pr, stream=buf).sort_stats("cumulative").print_stats(60)
+        st = pstats.Stats(pr, stream=buf).sort_stats("cumulative")
+        st.print_stats(60)
+        st.print_callers("'(cpu|item|tolist|nonzero)' of")   # who asks the device for a value (each such call drains the queue)
         with open(prof_out, "w") as f:
             f.write(buf.getvalue())
 
