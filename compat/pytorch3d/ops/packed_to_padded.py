@@ -24,6 +24,13 @@ def padded_to_packed(inputs, first_idxs, num_inputs: int):
     N, M = x.shape[:2]
     ends = torch.cat([first_idxs[1:], first_idxs.new_tensor([num_inputs])])
     counts = (ends - first_idxs).clamp(min=0, max=M)
+    if x.is_cuda and 0 <= int(num_inputs) <= N * M and hasattr(torch, "nonzero_static"):
+        # the rows to keep, found with a FIXED output size (num_inputs is a host integer): `repeat_interleave` with device-side
+        # counts and `int(counts.sum())` both wait for the GPU
+        keep = (torch.arange(M, device=x.device)[None, :] < counts[:, None]).reshape(-1)
+        pos = torch.nonzero_static(keep, size=int(num_inputs), fill_value=0)[:, 0]
+        out = x.reshape(N * M, *x.shape[2:])[pos]
+        return out[..., 0] if flat else out
     rows = torch.repeat_interleave(torch.arange(N, device=x.device), counts)
     cols = torch.arange(int(counts.sum()), device=x.device) - torch.repeat_interleave(torch.cumsum(counts, 0) - counts, counts)
     out = x[rows, cols]

@@ -21,9 +21,27 @@ class CamerasBase(TensorProperties):
         raise NotImplementedError()
 
     def get_camera_center(self, **kwargs) -> torch.Tensor:
-        w2v_trans = self.get_world_to_view_transform(**kwargs)
-        P = w2v_trans.inverse().get_matrix()
-        return P[:, 3, :3]
+        """the world point that maps to the view origin: x_view = x_world R + T  =>  C = -T R^-1.  pytorch3d inverts the composed
+        4 x 4 world-to-view transform and reads its last row; the reference's texture asks for it AFTER
+        `cameras.gather_props(packed_to_cloud_idx)`, i.e. for one camera per POINT (8 x 99,790 of them at configs[2]): a batch
+        of 798k 4 x 4 LU inverses and 4 x 4 products -- 16 ms of rocSOLVER / hipBLASLt kernels per iteration of train_mvr.py,
+        more than half of its GPU time.  Same value in closed form, elementwise: the columns of R^-1 are the cross products
+        of R's rows over the determinant."""
+        R = kwargs.get("R", self.R)
+        T = kwargs.get("T", self.T)
+        self.R = R
+        self.T = T
+        if R.dim() == 2:
+            R = R[None]
+        if T.dim() == 1:
+            T = T[None]
+        r0, r1, r2 = R[:, 0, :], R[:, 1, :], R[:, 2, :]
+        c0, c1, c2 = torch.cross(r1, r2, dim=1), torch.cross(r2, r0, dim=1), torch.cross(r0, r1, dim=1)
+        det = (r0 * c0).sum(1, keepdim=True)
+        if T.shape[0] != R.shape[0]:
+            T = T.expand(R.shape[0], -1) if T.shape[0] == 1 else T
+            c0, c1, c2, det = (v.expand(T.shape[0], -1) if v.shape[0] == 1 else v for v in (c0, c1, c2, det))
+        return -torch.stack([(T * c0).sum(1), (T * c1).sum(1), (T * c2).sum(1)], dim=1) / det
 
     def get_world_to_view_transform(self, **kwargs) -> Transform3d:
         R = kwargs.get("R", self.R)

@@ -8,22 +8,7 @@ import torch
 from . import utils as struct_utils
 
 
-_CONSTANTS = {}   # (values, dtype, device) -> device tensor made from host values once
-
-
-def _device_constant(values, dtype, device):
-    """a fresh device tensor holding `values` (a tuple of Python numbers): the host-to-device copy -- which waits for the stream
-    when it comes from pageable memory -- is made once per distinct tuple; callers get a clone (device-side, asynchronous)"""
-    device = torch.device(device)
-    if device.type == "cpu":
-        return torch.tensor(values, dtype=dtype)
-    key = (values, dtype, str(device))
-    t = _CONSTANTS.get(key)
-    if t is None:
-        if len(_CONSTANTS) > 4096:
-            _CONSTANTS.clear()
-        t = _CONSTANTS[key] = torch.tensor(values, dtype=dtype, device=device)
-    return t.clone()
+_device_constant = struct_utils.device_constant
 
 
 class Pointclouds:
@@ -38,6 +23,8 @@ class Pointclouds:
         self.equisized = False
         self.valid = None
         self._any_valid = False
+        self._sizes_host = []
+        self._sizes_src = None      # the size tensor `_sizes_host` was made with
         self._N = 0
         self._P = 0
         self._C = None
@@ -69,6 +56,7 @@ class Pointclouds:
                 # the sizes are host integers: nothing here has to ask the device (int(num.max()), num.unique() and the two
                 # host-to-device copies each waited for the GPU; train_mvr.py builds ~10 of these objects per iteration)
                 sizes = [len(p) for p in self._points_list]
+                self._sizes_host = sizes
                 self._P = max(sizes)
                 self._any_valid = any(n > 0 for n in sizes)
                 self.valid = _device_constant(tuple(n > 0 for n in sizes), torch.bool, self.device)
@@ -77,6 +65,7 @@ class Pointclouds:
                 self._num_points_per_cloud = _device_constant(tuple(sizes), torch.int64, self.device)
             else:
                 self._num_points_per_cloud = torch.tensor([], dtype=torch.int64)
+            self._sizes_src = self._num_points_per_cloud
         elif torch.is_tensor(points):
             if points.dim() != 3 or points.shape[2] != 3:
                 raise ValueError("Points tensor has incorrect dimensions.")
@@ -86,7 +75,9 @@ class Pointclouds:
             self.device = points.device
             self.valid = torch.ones((self._N,), dtype=torch.bool, device=self.device)
             self._any_valid = self._N > 0
+            self._sizes_host = [self._P] * self._N
             self._num_points_per_cloud = torch.full((self._N,), self._P, dtype=torch.int64, device=self.device)
+            self._sizes_src = self._num_points_per_cloud
             self.equisized = True
         else:
             raise ValueError("Points must be either a list or a tensor with shape (batch_size, P, 3) where P is the "
@@ -110,7 +101,7 @@ class Pointclouds:
             aux_input = list(aux_input)
             if len(aux_input) != self._N:
                 raise ValueError("Points and auxiliary input must be the same length.")
-            for p, d in zip(self._num_points_per_cloud, aux_input):
+            for p, d in zip(self._host_sizes(), aux_input):   # (host integers: iterating the device tensor asks the GPU per cloud)
                 if d is None:
                     continue
                 if int(p) != d.shape[0]:
@@ -167,15 +158,27 @@ class Pointclouds:
             features = [fl[i] for i in idx]
         return self.__class__(points=points, normals=normals, features=features)
 
+    def _host_sizes(self) -> List[int]:
+        """the clouds' sizes as host integers (kept from __init__; an object assembled without it asks the device once)"""
+        if len(self._sizes_host) != self._N or self._sizes_src is not self._num_points_per_cloud:
+            # (a size tensor put there from outside: ask the device once)
+            self._sizes_host = self._num_points_per_cloud.tolist() if torch.is_tensor(self._num_points_per_cloud) else []
+            self._sizes_src = self._num_points_per_cloud
+            self._any_valid = any(n > 0 for n in self._sizes_host)
+        return self._sizes_host
+
     def isempty(self) -> bool:
         # (pytorch3d asks the device: `self.valid.eq(False).all()`; `valid` is made from host integers in __init__)
-        return self._N == 0 or not self._any_valid
+        if self._N == 0:
+            return True
+        self._host_sizes()
+        return not self._any_valid
 
     # ---- list / packed / padded views ---------------------------------------------------------------------------
     def points_list(self) -> List[torch.Tensor]:
         if self._points_list is None:
             assert self._points_padded is not None, "points_padded is required to compute points_list."
-            self._points_list = [self._points_padded[i, : int(n)] for i, n in enumerate(self.num_points_per_cloud())]
+            self._points_list = [self._points_padded[i, : int(n)] for i, n in enumerate(self._host_sizes())]
         return self._points_list
 
     def _aux_list(self, name) -> Optional[List[torch.Tensor]]:
@@ -184,7 +187,7 @@ class Pointclouds:
             padded = getattr(self, "_%s_padded" % name)
             if padded is None:
                 return None
-            lst = [padded[i, : int(n)] for i, n in enumerate(self.num_points_per_cloud())]
+            lst = [padded[i, : int(n)] for i, n in enumerate(self._host_sizes())]
             setattr(self, "_%s_list" % name, lst)
         return lst
 
@@ -238,7 +241,7 @@ class Pointclouds:
         else:
             self._padded_to_packed_idx = torch.cat(
                 [torch.arange(int(v), dtype=torch.int64, device=self.device) + i * self._P
-                 for i, v in enumerate(self.num_points_per_cloud())], dim=0)
+                 for i, v in enumerate(self._host_sizes())], dim=0)
         return self._padded_to_packed_idx
 
     def _compute_padded(self, refresh: bool = False):
@@ -279,9 +282,9 @@ class Pointclouds:
         self._cloud_to_packed_first_idx = first
         self._normals_packed, self._features_packed = None, None
         if normals_list is not None:
-            self._normals_packed = struct_utils.list_to_packed(normals_list)[0]
+            self._normals_packed = torch.cat(normals_list, 0)     # (the index tensors are those of the points)
         if features_list is not None:
-            self._features_packed = struct_utils.list_to_packed(features_list)[0]
+            self._features_packed = torch.cat(features_list, 0)
 
     # ---- copies / devices ---------------------------------------------------------------------------------------
     def _copy_with(self, fn):
@@ -360,7 +363,7 @@ class Pointclouds:
         if offsets_packed.shape != points_packed.shape:
             raise ValueError("Offsets must have dimension (all_p, 3).")
         self._points_packed = points_packed + offsets_packed
-        new_points_list = list(self._points_packed.split(self.num_points_per_cloud().tolist(), 0))
+        new_points_list = list(self._points_packed.split(list(self._host_sizes()), 0))
         self._points_list = new_points_list
         if self._points_padded is not None:
             for i, points in enumerate(new_points_list):
@@ -459,6 +462,7 @@ class Pointclouds:
             v = getattr(self, k)
             if torch.is_tensor(v):
                 setattr(new, k, v)
+        new._sizes_host, new._sizes_src, new._any_valid = list(self._host_sizes()), new._num_points_per_cloud, self._any_valid
         if new._padded_to_packed_idx is None and self._N > 0:
             new.padded_to_packed_idx()
         if self._N > 0 and torch.is_tensor(new.padded_to_packed_idx()):
@@ -489,7 +493,7 @@ class Pointclouds:
             box = box.expand(sumP, 2, 3)
         elif box.shape[0] == self._N:
             box = box.unbind(0)
-            box = [b.expand(int(p), 2, 3) for (b, p) in zip(box, self.num_points_per_cloud())]
+            box = [b.expand(int(p), 2, 3) for (b, p) in zip(box, self._host_sizes())]
             box = torch.cat(box, 0)
         coord_inside = (points_packed >= box[:, 0]) * (points_packed <= box[:, 1])
         return coord_inside.all(dim=-1)

@@ -274,3 +274,8 @@ def test_shim_objects_drive_the_drop_in_renderer_built_like_create_renderer():
     b2 = knn_points(two.cpu(), two.cpu(), ln.cpu(), ln.cpu(), K=12)
     assert torch.equal(a2.idx.cpu(), b2.idx) and torch.allclose(a2.dists.cpu(), b2.dists, atol=1e-6)
     assert float(a2.dists[1, half - 300:].abs().sum()) == 0 and int(a2.idx[1, half - 300:].abs().sum()) == 0
+    # padded -> packed on the GPU (fixed-size nonzero, no host sync) == the CPU route
+    xp = torch.rand(3, 50, 3, device=dev)
+    fi = torch.tensor([0, 20, 70], device=dev)     # 20, 50 and 30 rows
+    assert torch.equal(padded_to_packed(xp, fi, 100).cpu(), padded_to_packed(xp.cpu(), fi.cpu(), 100))
+    assert torch.equal(padded_to_packed(xp[..., 0], fi, 100).cpu(), padded_to_packed(xp[..., 0].cpu(), fi.cpu(), 100))
