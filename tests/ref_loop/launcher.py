@@ -12,6 +12,9 @@ What this file adds around the untouched script (none of it is shipped; it is wh
   * two aliases removed from the libraries since the reference was written: `np.bool` (dataset.py:99), `torch._six`;
   * on a machine WITHOUT a GPU only: `dss_amd.ops` answered by the oracle (tests/ref_loop/oracle_ops.py), because the
     product refuses to run without the HIP library.  With a GPU the real kernels run.
+Developer aid: DSS_REF_LOOP_CPROFILE=<file> runs the script under cProfile and writes the top 60 entries (sorted by
+DSS_REF_LOOP_CPROFILE_SORT, default `cumulative`) plus the callers of .cpu() / .item() / .tolist() -- the requests that drain
+the GPU queue -- to that file.
 The script's working directory is the reference checkout (train_mvr.py:30 loads `configs/default.yaml` relatively); all
 outputs go to the out_dir named in the config."""
 import argparse
@@ -399,7 +402,7 @@ def main():
         pr.runcall(runpy.run_path, os.path.join(args.reference, "train_mvr.py"), run_name="__main__")
     finally:
         buf = io.StringIO()
-        st = pstats.Stats(pr, stream=buf).sort_stats("cumulative")
+        st = pstats.Stats(pr, stream=buf).sort_stats(os.environ.get("DSS_REF_LOOP_CPROFILE_SORT", "cumulative"))
         st.print_stats(60)
         st.print_callers("'(cpu|item|tolist|nonzero)' of")   # who asks the device for a value (each such call drains the queue)
         with open(prof_out, "w") as f:
