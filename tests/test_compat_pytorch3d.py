@@ -279,3 +279,24 @@ def test_shim_objects_drive_the_drop_in_renderer_built_like_create_renderer():
     fi = torch.tensor([0, 20, 70], device=dev)     # 20, 50 and 30 rows
     assert torch.equal(padded_to_packed(xp, fi, 100).cpu(), padded_to_packed(xp.cpu(), fi.cpu(), 100))
     assert torch.equal(padded_to_packed(xp[..., 0], fi, 100).cpu(), padded_to_packed(xp[..., 0].cpu(), fi.cpu(), 100))
+
+
+def test_camera_center_closed_form_equals_the_inverse_of_the_world_to_view_transform():
+    """`get_camera_center()` = last row of the inverse of the composed 4 x 4 world-to-view transform (pytorch3d's definition);
+    the stand-in evaluates C = -T R^-1 in closed form (the reference's texture asks for one centre per POINT: cameras.py).
+    Same value for rotations, for general invertible R, for per-call R / T overrides, and it carries gradients."""
+    torch.manual_seed(3)
+    R, T = look_at_view_transform([1.3, 2.0, 2.5], [10.0, 30.0, -20.0], [0.0, 45.0, 250.0])
+    cams = FoVPerspectiveCameras(R=R, T=T)
+    want = cams.get_world_to_view_transform().inverse().get_matrix()[:, 3, :3]
+    assert torch.allclose(cams.get_camera_center(), want, atol=1e-6)
+    R2 = (R + 0.2 * torch.rand_like(R)).requires_grad_(True)
+    T2 = (T + torch.rand_like(T)).requires_grad_(True)
+    got = cams.get_camera_center(R=R2, T=T2)
+    want2 = cams.get_world_to_view_transform(R=R2, T=T2).inverse().get_matrix()[:, 3, :3]
+    assert torch.allclose(got, want2, atol=1e-5)
+    g_closed = torch.autograd.grad(got.sum(), (R2, T2))
+    g_lu = torch.autograd.grad(want2.sum(), (R2, T2))
+    assert all(torch.allclose(a, b, atol=1e-4) for a, b in zip(g_closed, g_lu))
+    big = FoVPerspectiveCameras(R=R.repeat(1000, 1, 1), T=T.repeat(1000, 1))     # one camera per point, as the texture makes them
+    assert torch.allclose(big.get_camera_center(), want.repeat(1000, 1), atol=1e-6)
