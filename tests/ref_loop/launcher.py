@@ -404,6 +404,7 @@ def main():
         buf = io.StringIO()
         st = pstats.Stats(pr, stream=buf).sort_stats(os.environ.get("DSS_REF_LOOP_CPROFILE_SORT", "cumulative"))
         st.print_stats(60)
+        st.print_stats(ROOT.replace(os.sep, "/") + "/", 40)   # the same ordering, this repository's files only
         st.print_callers("'(cpu|item|tolist|nonzero)' of")   # who asks the device for a value (each such call drains the queue)
         with open(prof_out, "w") as f:
             f.write(buf.getvalue())
